@@ -1,0 +1,111 @@
+"""ctypes binding of libdnagpu.so (include/dnagpu.h, include/dnaadjust_c.h).
+
+The product path is the HIP library: importing this module fails loudly when the
+shared object has not been built (python __graft_entry__.py build).  There is no
+CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdnagpu.so")
+
+
+class DnaGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dnagpu error {code}: {msg}")
+        self.code = code
+
+
+DNAGPU_OK = 0
+DNAGPU_EINVAL = -1
+DNAGPU_ENOMEM = -2
+DNAGPU_EHIP = -3
+DNAGPU_ENOTPOSDEF = -4
+DNAGPU_ENODEVICE = -5
+
+_lib = None
+
+c_u32p = C.POINTER(C.c_uint32)
+c_f64p = C.POINTER(C.c_double)
+
+
+def _sig(lib, name, restype, argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = argtypes
+    return f
+
+
+def load():
+    """Load libdnagpu.so and declare every exported prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()')")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    i = C.c_int
+    u32 = C.c_uint32
+    sz = C.c_size_t
+    _sig(lib, "dnagpu_device_count", i, [])
+    _sig(lib, "dnagpu_create", i, [i, C.POINTER(vp)])
+    _sig(lib, "dnagpu_destroy", None, [vp])
+    _sig(lib, "dnagpu_last_error", C.c_char_p, [vp])
+    _sig(lib, "dnagpu_last_info", i, [vp])
+    _sig(lib, "dnagpu_sync", i, [vp])
+    _sig(lib, "dnagpu_cholesky_inverse_packed", i, [vp, c_f64p, u32, i])
+    _sig(lib, "dnagpu_multiply_sym_packed", i, [vp, c_f64p, c_f64p, c_f64p, u32])
+    _sig(lib, "dnagpu_profile_enable", i, [vp, i])
+    _sig(lib, "dnagpu_profile_reset", i, [vp])
+    _sig(lib, "dnagpu_profile_get", i, [vp, c_f64p, c_f64p, C.POINTER(C.c_uint64)])
+    _sig(lib, "dnagpu_matrix_create", i, [vp, u32, C.POINTER(vp)])
+    _sig(lib, "dnagpu_matrix_destroy", None, [vp, vp])
+    _sig(lib, "dnagpu_matrix_reset", i, [vp, i, vp, u32])
+    _sig(lib, "dnagpu_matrix_upload_packed", i, [vp, i, vp, c_f64p, u32])
+    _sig(lib, "dnagpu_matrix_download_packed", i, [vp, i, vp, c_f64p])
+    _sig(lib, "dnagpu_matrix_copy", i, [vp, i, vp, vp])
+    _sig(lib, "dnagpu_invert", i, [vp, i, vp, i])
+    _sig(lib, "dnagpu_block_create", i, [vp, u32, u32, u32])
+    _sig(lib, "dnagpu_block_destroy", i, [vp, u32])
+    _sig(lib, "dnagpu_block_set_stations", i, [vp, u32, c_f64p])
+    _sig(lib, "dnagpu_block_set_baselines", i, [vp, u32, c_u32p, c_u32p, c_f64p, c_f64p])
+    _sig(lib, "dnagpu_block_get_stations", i, [vp, i, u32, i, c_f64p])
+    _sig(lib, "dnagpu_block_put_stations", i, [vp, i, u32, i, c_f64p])
+    _sig(lib, "dnagpu_block_copy_stations", i, [vp, i, u32, i, i])
+    _sig(lib, "dnagpu_block_compute_b", i, [vp, i, u32])
+    _sig(lib, "dnagpu_block_get_b", i, [vp, i, u32, c_f64p])
+    _sig(lib, "dnagpu_block_get_weights", i, [vp, i, u32, c_f64p])
+    _sig(lib, "dnagpu_form_normals", i, [vp, i, u32, vp])
+    _sig(lib, "dnagpu_add_diag3x3", i, [vp, i, vp, c_u32p, c_f64p, sz, i])
+    _sig(lib, "dnagpu_form_rhs", i, [vp, i, u32])
+    _sig(lib, "dnagpu_solve_corrections", i, [vp, i, u32, vp])
+    _sig(lib, "dnagpu_update_estimates", i, [vp, i, u32, c_f64p, c_u32p])
+    _sig(lib, "dnagpu_block_get_corrections", i, [vp, i, u32, c_f64p])
+    _sig(lib, "dnagpu_block_get_rhs", i, [vp, i, u32, c_f64p])
+    _sig(lib, "dnagpu_junction_gather", i, [vp, i, u32, vp, c_u32p, sz, vp])
+    _sig(lib, "dnagpu_junction_scatter", i, [vp, i, vp, c_u32p, sz, vp])
+    _sig(lib, "dnagpu_junction_rhs", i, [vp, i, u32, c_u32p, sz, vp])
+    _sig(lib, "dnagpu_junction_get_estimates", i, [vp, i, vp, c_f64p])
+    _sig(lib, "dnagpu_junction_put_estimates", i, [vp, i, vp, c_f64p, sz])
+    _sig(lib, "dnagpu_chain_wait", i, [vp, i, i])
+    _sig(lib, "dnagpu_chain_sync", i, [vp, i])
+    _lib = lib
+    return lib
+
+
+EXPORTED_DNAGPU = [
+    "dnagpu_device_count", "dnagpu_create", "dnagpu_destroy", "dnagpu_last_error", "dnagpu_last_info", "dnagpu_sync",
+    "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset",
+    "dnagpu_profile_get", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
+    "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_copy", "dnagpu_invert",
+    "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines",
+    "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
+    "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
+    "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
+    "dnagpu_junction_gather", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
+    "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
+]

@@ -1,0 +1,19 @@
+// Internal launchers for the HBM-bound adjustment kernels (see adjust_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dnagpu {
+void launch_weights(const double* vcv6, double* w6, uint32_t n_bl, int* bad, hipStream_t s);
+void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s);
+void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pbl, const double* w6, double* F,
+                         uint32_t np, uint32_t n_pairs, hipStream_t s);
+void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s);
+void launch_form_rhs(const uint32_t* ioff, const uint32_t* inc, const double* w6, const double* b, double* rhs, uint32_t n_stn, hipStream_t s);
+void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s);
+void launch_junction_gather(const double* S, uint32_t nps, const uint32_t* idx, uint32_t k, double* J, uint32_t npj, hipStream_t s);
+void launch_gather_vec3(const double* x, const uint32_t* idx, uint32_t k, double* out, hipStream_t s);
+void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, hipStream_t s);
+void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, const double* jest,
+                         hipStream_t s);
+}  // namespace dnagpu

@@ -1,0 +1,239 @@
+// HBM-bound kernels of the adjustment path: measurement weights, meas-minus-computed,
+// deterministic normal-equation formation, sparse A^T W b, estimate update and the
+// junction gather / scatter of the phased chain.
+// Reference (under /root/reference/dynadjust/dynadjust/dnaadjust/dnaadjust.cpp):
+//   LoadVarianceMatrix_G :4214, UpdateDesignMeasMatrices_GX :5283, UpdateNormals_G :1664,
+//   Solve :6659 (AtVinv * b), UpdateEstimates* :3022, CarryStnEstimatesandVariances* :998/:1133/:3196.
+//
+// All sums are evaluated in a fixed order (CML order per matrix element), never with
+// floating-point atomics, so that a run is bit-reproducible and the formation matches
+// the CPU oracle bit for bit (contraction is off: the oracle is built with
+// -ffp-contract=off too).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "adjust_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace dnagpu {
+
+// index of symmetric 3x3 element (i,j) in the (xx, xy, yy, xz, yz, zz) storage
+__device__ __forceinline__ int sym6(int i, int j) {
+    int lo = i < j ? i : j, hi = i < j ? j : i;
+    return hi * (hi + 1) / 2 + lo;
+}
+
+// W = V^-1 through the Cholesky factor V = U^T U (the reference calls
+// dpotrf('U') + dpotri('U') on the 3x3, dnaadjust.cpp:4288 -> :8472).
+__global__ void weights_kernel(const double* __restrict__ vcv6, double* __restrict__ w6, uint32_t n_bl, int* __restrict__ bad) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bl) return;
+    const double* v = vcv6 + (size_t)i * 6;
+    double v11 = v[0], v12 = v[1], v22 = v[2], v13 = v[3], v23 = v[4], v33 = v[5];
+    double u11 = sqrt(v11);
+    double u12 = v12 / u11;
+    double u13 = v13 / u11;
+    double d22 = v22 - u12 * u12;
+    double u22 = sqrt(d22);
+    double u23 = (v23 - u12 * u13) / u22;
+    double d33 = (v33 - u13 * u13) - u23 * u23;
+    double u33 = sqrt(d33);
+    if (!(v11 > 0.0) || !(d22 > 0.0) || !(d33 > 0.0)) atomicMin(bad, (int)i);
+    double t11 = 1.0 / u11, t22 = 1.0 / u22, t33 = 1.0 / u33;
+    double t12 = -(t11 * u12) * t22;
+    double t23 = -(t22 * u23) * t33;
+    double t13 = -(t11 * (u12 * t23 + u13 * t33));
+    double* w = w6 + (size_t)i * 6;
+    w[0] = (t11 * t11 + t12 * t12) + t13 * t13;
+    w[1] = t12 * t22 + t13 * t23;
+    w[2] = t22 * t22 + t23 * t23;
+    w[3] = t13 * t33;
+    w[4] = t23 * t33;
+    w[5] = t33 * t33;
+}
+
+__global__ void compute_b_kernel(const uint32_t* __restrict__ s1, const uint32_t* __restrict__ s2, const double* __restrict__ obs,
+                                 const double* __restrict__ xe, double* __restrict__ b, uint32_t n_bl) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_bl * 3) return;
+    uint32_t i = t / 3, c = t - i * 3;
+    double comp = xe[3 * s2[i] + c] - xe[3 * s1[i] + c];
+    b[t] = obs[t] - comp;
+}
+
+// one thread per (station-pair block, element): N(3r+ei, 3c+ej) = sum over the
+// pair's baselines (CML order) of +W (diagonal block) or -W (off-diagonal block)
+__global__ void form_normals_kernel(const uint32_t* __restrict__ prow, const uint32_t* __restrict__ pcol,
+                                    const uint32_t* __restrict__ poff, const uint32_t* __restrict__ pbl,
+                                    const double* __restrict__ w6, double* __restrict__ F, uint32_t np, uint32_t n_pairs) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pairs * 9) return;
+    uint32_t p = t / 9, e = t - p * 9;
+    int ei = e % 3, ej = e / 3;
+    uint32_t r = prow[p], c = pcol[p];
+    bool diag = (r == c);
+    if (diag && ei < ej) return;
+    int k6 = sym6(ei, ej);
+    double s = 0.0;
+    uint32_t k0 = poff[p], k1 = poff[p + 1];
+    for (uint32_t k = k0; k < k1; ++k) {
+        double w = w6[(size_t)pbl[k] * 6 + k6];
+        s += diag ? w : -w;
+    }
+    F[(size_t)(3 * c + ej) * np + 3 * r + ei] = s;
+}
+
+__global__ void add_diag3x3_kernel(double* __restrict__ F, uint32_t np, const uint32_t* __restrict__ stn,
+                                   const double* __restrict__ w9, uint32_t k, double sign) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * 9) return;
+    uint32_t q = t / 9, e = t - q * 9;
+    int ei = e % 3, ej = e / 3;
+    if (ei < ej) return;
+    uint32_t s = stn[q];
+    F[(size_t)(3 * s + ej) * np + 3 * s + ei] += sign * w9[(size_t)q * 9 + ej * 3 + ei];
+}
+
+// rhs(3s+c) = sum over incident baselines (CML order) of +-(W b)_c
+__global__ void form_rhs_kernel(const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ inc, const double* __restrict__ w6,
+                                const double* __restrict__ b, double* __restrict__ rhs, uint32_t n_stn) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_stn * 3) return;
+    uint32_t s = t / 3;
+    int c = t - s * 3;
+    double acc = 0.0;
+    for (uint32_t k = ioff[s]; k < ioff[s + 1]; ++k) {
+        uint32_t e = inc[k];
+        uint32_t bl = e >> 1;
+        const double* w = w6 + (size_t)bl * 6;
+        const double* bb = b + (size_t)bl * 3;
+        double wb = (w[sym6(c, 0)] * bb[0] + w[sym6(c, 1)] * bb[1]) + w[sym6(c, 2)] * bb[2];
+        acc += (e & 1u) ? wb : -wb;
+    }
+    rhs[t] = acc;
+}
+
+// xe += corr ; (value, row) of the correction with the largest magnitude, first
+// occurrence wins (matrix_2d::compute_maximum_value, dnamatrix_contiguous.cpp:1532)
+__global__ __launch_bounds__(1024) void update_estimates_kernel(double* __restrict__ xe, const double* __restrict__ corr, uint32_t n,
+                                                                double* __restrict__ out_val, uint32_t* __restrict__ out_idx) {
+    __shared__ double sv[1024];
+    __shared__ uint32_t si[1024];
+    double best = -1.0;
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        double c = corr[i];
+        xe[i] += c;
+        double a = fabs(c);
+        if (a > best) { best = a; bi = i; }
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            double o = sv[threadIdx.x + s];
+            uint32_t oi = si[threadIdx.x + s];
+            if (o > sv[threadIdx.x] || (o == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = o;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        uint32_t idx = si[0];
+        *out_idx = idx;
+        *out_val = (idx < n) ? corr[idx] : 0.0;
+    }
+}
+
+// J(3a+ei, 3b+ej) = S(3 idx[a]+ei, 3 idx[b]+ej); S is full symmetric (N^-1)
+__global__ void junction_gather_kernel(const double* __restrict__ S, uint32_t nps, const uint32_t* __restrict__ idx, uint32_t k,
+                                       double* __restrict__ J, uint32_t npj) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // row of J
+    uint32_t j = blockIdx.y;                             // column of J
+    uint32_t nj = 3 * k;
+    if (i >= nj || j >= nj) return;
+    uint32_t si = 3 * idx[i / 3] + i % 3;
+    uint32_t sj = 3 * idx[j / 3] + j % 3;
+    J[(size_t)j * npj + i] = S[(size_t)sj * nps + si];
+}
+
+__global__ void gather_vec3_kernel(const double* __restrict__ x, const uint32_t* __restrict__ idx, uint32_t k, double* __restrict__ out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * k) return;
+    out[t] = x[3 * idx[t / 3] + t % 3];
+}
+
+// D(3 idx[a]+ei, 3 idx[b]+ej) += J(3a+ei, 3b+ej) on the lower triangle of D
+__global__ void junction_scatter_kernel(double* __restrict__ D, uint32_t npd, const uint32_t* __restrict__ idx, uint32_t k,
+                                        const double* __restrict__ J, uint32_t npj) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = blockIdx.y;
+    uint32_t nj = 3 * k;
+    if (i >= nj || j >= nj) return;
+    uint32_t di = 3 * idx[i / 3] + i % 3;
+    uint32_t dj = 3 * idx[j / 3] + j % 3;
+    if (di < dj) return;
+    D[(size_t)dj * npd + di] += J[(size_t)j * npj + i];
+}
+
+// rhs[3 idx[a]+ei] += sum_j J(i, j) * (jest[j] - xe[3 idx[j/3] + j%3])
+__global__ void junction_rhs_kernel(double* __restrict__ rhs, const double* __restrict__ xe, const uint32_t* __restrict__ idx, uint32_t k,
+                                    const double* __restrict__ J, uint32_t npj, const double* __restrict__ jest) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nj = 3 * k;
+    if (i >= nj) return;
+    double acc = 0.0;
+    for (uint32_t j = 0; j < nj; ++j) {
+        double bj = jest[j] - xe[3 * idx[j / 3] + j % 3];
+        acc += J[(size_t)j * npj + i] * bj;
+    }
+    rhs[3 * idx[i / 3] + i % 3] += acc;
+}
+
+// ---- launchers ---------------------------------------------------------------
+void launch_weights(const double* vcv6, double* w6, uint32_t n_bl, int* bad, hipStream_t s) {
+    if (!n_bl) return;
+    hipLaunchKernelGGL(weights_kernel, dim3((n_bl + 255) / 256), dim3(256), 0, s, vcv6, w6, n_bl, bad);
+}
+void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s) {
+    if (!n_bl) return;
+    hipLaunchKernelGGL(compute_b_kernel, dim3((n_bl * 3 + 255) / 256), dim3(256), 0, s, s1, s2, obs, xe, b, n_bl);
+}
+void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pbl, const double* w6, double* F,
+                         uint32_t np, uint32_t n_pairs, hipStream_t s) {
+    if (!n_pairs) return;
+    hipLaunchKernelGGL(form_normals_kernel, dim3((n_pairs * 9 + 255) / 256), dim3(256), 0, s, prow, pcol, poff, pbl, w6, F, np, n_pairs);
+}
+void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(add_diag3x3_kernel, dim3((k * 9 + 255) / 256), dim3(256), 0, s, F, np, stn, w9, k, sign);
+}
+void launch_form_rhs(const uint32_t* ioff, const uint32_t* inc, const double* w6, const double* b, double* rhs, uint32_t n_stn, hipStream_t s) {
+    if (!n_stn) return;
+    hipLaunchKernelGGL(form_rhs_kernel, dim3((n_stn * 3 + 255) / 256), dim3(256), 0, s, ioff, inc, w6, b, rhs, n_stn);
+}
+void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s) {
+    hipLaunchKernelGGL(update_estimates_kernel, dim3(1), dim3(1024), 0, s, xe, corr, n, out_val, out_idx);
+}
+void launch_junction_gather(const double* S, uint32_t nps, const uint32_t* idx, uint32_t k, double* J, uint32_t npj, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(junction_gather_kernel, dim3((3 * k + 255) / 256, 3 * k), dim3(256), 0, s, S, nps, idx, k, J, npj);
+}
+void launch_gather_vec3(const double* x, const uint32_t* idx, uint32_t k, double* out, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(gather_vec3_kernel, dim3((3 * k + 255) / 256), dim3(256), 0, s, x, idx, k, out);
+}
+void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(junction_scatter_kernel, dim3((3 * k + 255) / 256, 3 * k), dim3(256), 0, s, D, npd, idx, k, J, npj);
+}
+void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, const double* jest,
+                         hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(junction_rhs_kernel, dim3((3 * k + 255) / 256), dim3(256), 0, s, rhs, xe, idx, k, J, npj, jest);
+}
+
+}  // namespace dnagpu

@@ -1,0 +1,63 @@
+// Internal definition of the device context behind include/dnagpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/dnagpu.h"
+#include "sym_inverse.h"
+
+struct dnagpu_matrix {
+    double* F = nullptr;     // np_max x np_max storage, used with ld = np
+    double* jest = nullptr;  // junction estimates attached to the matrix (n_max doubles)
+    uint32_t n_max = 0, np_max = 0;
+    uint32_t n = 0, np = 0;  // current logical order / padded order
+};
+
+namespace dnagpu {
+
+struct Block {
+    uint32_t n_stn = 0, n_bl = 0;
+    // stations (3*n_stn)
+    double *x_orig = nullptr, *x_est = nullptr, *x_rig = nullptr;
+    double *rhs = nullptr, *corr = nullptr;
+    // baselines, SoA
+    uint32_t *s1 = nullptr, *s2 = nullptr;
+    double *obs = nullptr;  // 3*n_bl
+    double *W = nullptr;    // 6*n_bl  (xx, xy, yy, xz, yz, zz) of V^-1
+    double *b = nullptr;    // 3*n_bl
+    // deterministic formation structure: station-pair blocks (row >= col), each
+    // with the CML-ordered list of contributing baselines
+    uint32_t n_pairs = 0;
+    uint32_t *pair_row = nullptr, *pair_col = nullptr, *pair_off = nullptr;  // n_pairs(+1)
+    uint32_t *pair_bl = nullptr;  // baseline index per contribution
+    // per-station incidence (CML order) for the rhs: entry = baseline*2 + (1 if station is stn2)
+    uint32_t *inc_off = nullptr, *inc = nullptr;
+    // scratch for max-correction reduction
+    double* red = nullptr;
+};
+
+}  // namespace dnagpu
+
+struct dnagpu_ctx {
+    int device = 0;
+    std::string err;
+    int last_info = 0;
+    hipStream_t stream[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    hipEvent_t ev[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    dnagpu::InvWorkspace ws[DNAGPU_NUM_CHAINS];
+    double* symv_part[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    uint32_t symv_cap[DNAGPU_NUM_CHAINS] = {0, 0};
+    // small per-chain staging buffers for index lists / 3x3 weights / vectors
+    uint32_t* scr_u32[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    size_t scr_u32_cap[DNAGPU_NUM_CHAINS] = {0, 0};
+    double* scr_f64[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    size_t scr_f64_cap[DNAGPU_NUM_CHAINS] = {0, 0};
+    // pinned host landing zone for (max correction, row)
+    double* red_val_host[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    uint32_t* red_idx_host[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    int* bad_dev = nullptr;
+    std::map<uint32_t, dnagpu::Block> blocks;
+    bool profile = false;
+};

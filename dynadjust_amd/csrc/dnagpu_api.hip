@@ -1,0 +1,790 @@
+// Implementation of the C-ABI declared in include/dnagpu.h.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "adjust_kernels.h"
+#include "ctx.h"
+#include "la_kernels.h"
+#include "sym_inverse.h"
+
+using namespace dnagpu;
+
+namespace {
+
+constexpr uint32_t SYMV_CHUNKS = 32;
+constexpr int INFO_SENTINEL = 0x7f7f7f7f;
+
+int fail(dnagpu_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(buf, sizeof(buf), "%s", what);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(call)                                                      \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, #call, e_); \
+    } while (0)
+
+#define CHK_CTX()                                   \
+    do {                                            \
+        if (!ctx) return DNAGPU_EINVAL;             \
+        hipError_t e0_ = hipSetDevice(ctx->device); \
+        if (e0_ != hipSuccess) return fail(ctx, DNAGPU_EHIP, "hipSetDevice", e0_); \
+    } while (0)
+
+#define CHK_CHAIN()                                                               \
+    do {                                                                          \
+        if (chain < 0 || chain >= DNAGPU_NUM_CHAINS) return fail(ctx, DNAGPU_EINVAL, "bad chain"); \
+    } while (0)
+
+int ensure_ws(dnagpu_ctx* ctx, int chain, uint32_t np) {
+    InvWorkspace& ws = ctx->ws[chain];
+    if (ws.np_cap >= np) return DNAGPU_OK;
+    bool prof = ws.prof.enabled;
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    inv_workspace_free(ws);
+    hipError_t e = inv_workspace_alloc(ws, np, ctx->stream[chain]);
+    if (e != hipSuccess) {
+        inv_workspace_free(ws);
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "inverse workspace allocation", e);
+    }
+    ws.prof.enabled = prof;
+    return DNAGPU_OK;
+}
+
+int ensure_symv(dnagpu_ctx* ctx, int chain, uint32_t np) {
+    if (ctx->symv_cap[chain] >= np) return DNAGPU_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    if (ctx->symv_part[chain]) hipFree(ctx->symv_part[chain]);
+    ctx->symv_part[chain] = nullptr;
+    ctx->symv_cap[chain] = 0;
+    HIPCHK(hipMalloc(&ctx->symv_part[chain], (size_t)SYMV_CHUNKS * np * sizeof(double)));
+    ctx->symv_cap[chain] = np;
+    return DNAGPU_OK;
+}
+
+int ensure_scr_u32(dnagpu_ctx* ctx, int chain, size_t count) {
+    if (ctx->scr_u32_cap[chain] >= count) return DNAGPU_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    if (ctx->scr_u32[chain]) hipFree(ctx->scr_u32[chain]);
+    ctx->scr_u32[chain] = nullptr;
+    ctx->scr_u32_cap[chain] = 0;
+    size_t cap = std::max<size_t>(count, 4096);
+    HIPCHK(hipMalloc(&ctx->scr_u32[chain], cap * sizeof(uint32_t)));
+    ctx->scr_u32_cap[chain] = cap;
+    return DNAGPU_OK;
+}
+
+int ensure_scr_f64(dnagpu_ctx* ctx, int chain, size_t count) {
+    if (ctx->scr_f64_cap[chain] >= count) return DNAGPU_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    if (ctx->scr_f64[chain]) hipFree(ctx->scr_f64[chain]);
+    ctx->scr_f64[chain] = nullptr;
+    ctx->scr_f64_cap[chain] = 0;
+    size_t cap = std::max<size_t>(count, 4096);
+    HIPCHK(hipMalloc(&ctx->scr_f64[chain], cap * sizeof(double)));
+    ctx->scr_f64_cap[chain] = cap;
+    return DNAGPU_OK;
+}
+
+// upload a small host array to the chain's staging buffer (stream ordered)
+int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, uint32_t** dev) {
+    int rc = ensure_scr_u32(ctx, chain, count);
+    if (rc) return rc;
+    // the previous user of the staging buffer may still be running: the copy is
+    // stream ordered behind it, but the host source must stay valid -> sync copy
+    HIPCHK(hipMemcpyAsync(ctx->scr_u32[chain], host, count * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    *dev = ctx->scr_u32[chain];
+    return DNAGPU_OK;
+}
+
+int stage_f64(dnagpu_ctx* ctx, int chain, const double* host, size_t count, double** dev) {
+    int rc = ensure_scr_f64(ctx, chain, count);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->scr_f64[chain], host, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    *dev = ctx->scr_f64[chain];
+    return DNAGPU_OK;
+}
+
+Block* find_block(dnagpu_ctx* ctx, uint32_t blk) {
+    auto it = ctx->blocks.find(blk);
+    return it == ctx->blocks.end() ? nullptr : &it->second;
+}
+
+void free_block(Block& b) {
+    void* ptrs[] = {b.x_orig, b.x_est, b.x_rig, b.rhs, b.corr, b.s1, b.s2, b.obs, b.W, b.b, b.pair_row, b.pair_col,
+                    b.pair_off, b.pair_bl, b.inc_off, b.inc, b.red};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    b = Block();
+}
+
+double* station_vec(Block& b, int which) {
+    switch (which) {
+        case 0: return b.x_orig;
+        case 1: return b.x_est;
+        case 2: return b.x_rig;
+        default: return nullptr;
+    }
+}
+
+int check_info(dnagpu_ctx* ctx, int chain) {
+    int info = *ctx->ws[chain].info_host;
+    if (info != INFO_SENTINEL) {
+        ctx->last_info = info;
+        char buf[128];
+        snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (leading minor %d)", info);
+        ctx->err = buf;
+        return DNAGPU_ENOTPOSDEF;
+    }
+    ctx->last_info = 0;
+    return DNAGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dnagpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dnagpu_create(int device, dnagpu_ctx** out) {
+    if (!out) return DNAGPU_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DNAGPU_ENODEVICE;
+    dnagpu_ctx* ctx = new (std::nothrow) dnagpu_ctx();
+    if (!ctx) return DNAGPU_ENOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        return DNAGPU_EHIP;
+    }
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        if (hipStreamCreateWithFlags(&ctx->stream[c], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev[c], hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc(&ctx->red_val_host[c], sizeof(double)) != hipSuccess ||
+            hipHostMalloc(&ctx->red_idx_host[c], sizeof(uint32_t)) != hipSuccess) {
+            dnagpu_destroy(ctx);
+            return DNAGPU_EHIP;
+        }
+        ctx->ws[c].stream = ctx->stream[c];
+    }
+    if (hipMalloc(&ctx->bad_dev, sizeof(int)) != hipSuccess) {
+        dnagpu_destroy(ctx);
+        return DNAGPU_ENOMEM;
+    }
+    *out = ctx;
+    return DNAGPU_OK;
+}
+
+void dnagpu_destroy(dnagpu_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    for (auto& kv : ctx->blocks) free_block(kv.second);
+    ctx->blocks.clear();
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        inv_workspace_free(ctx->ws[c]);
+        if (ctx->symv_part[c]) hipFree(ctx->symv_part[c]);
+        if (ctx->scr_u32[c]) hipFree(ctx->scr_u32[c]);
+        if (ctx->scr_f64[c]) hipFree(ctx->scr_f64[c]);
+        if (ctx->red_val_host[c]) hipHostFree(ctx->red_val_host[c]);
+        if (ctx->red_idx_host[c]) hipHostFree(ctx->red_idx_host[c]);
+        if (ctx->ev[c]) hipEventDestroy(ctx->ev[c]);
+        if (ctx->stream[c]) hipStreamDestroy(ctx->stream[c]);
+    }
+    if (ctx->bad_dev) hipFree(ctx->bad_dev);
+    delete ctx;
+}
+
+const char* dnagpu_last_error(const dnagpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int dnagpu_last_info(const dnagpu_ctx* ctx) { return ctx ? ctx->last_info : 0; }
+
+int dnagpu_sync(dnagpu_ctx* ctx) {
+    CHK_CTX();
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) HIPCHK(hipStreamSynchronize(ctx->stream[c]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_chain_sync(dnagpu_ctx* ctx, int chain) {
+    CHK_CTX();
+    CHK_CHAIN();
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_chain_wait(dnagpu_ctx* ctx, int waiter, int signaller) {
+    CHK_CTX();
+    if (waiter < 0 || waiter >= DNAGPU_NUM_CHAINS || signaller < 0 || signaller >= DNAGPU_NUM_CHAINS)
+        return fail(ctx, DNAGPU_EINVAL, "bad chain");
+    if (waiter == signaller) return DNAGPU_OK;
+    HIPCHK(hipEventRecord(ctx->ev[signaller], ctx->stream[signaller]));
+    HIPCHK(hipStreamWaitEvent(ctx->stream[waiter], ctx->ev[signaller], 0));
+    return DNAGPU_OK;
+}
+
+/* ---- profiling ------------------------------------------------------------ */
+int dnagpu_profile_enable(dnagpu_ctx* ctx, int on) {
+    CHK_CTX();
+    ctx->profile = on != 0;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) ctx->ws[c].prof.enabled = ctx->profile;
+    return DNAGPU_OK;
+}
+int dnagpu_profile_reset(dnagpu_ctx* ctx) {
+    CHK_CTX();
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        HIPCHK(hipStreamSynchronize(ctx->stream[c]));
+        gemm_profile_reset(ctx->ws[c]);
+    }
+    return DNAGPU_OK;
+}
+int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uint64_t* launches) {
+    CHK_CTX();
+    double f = 0, ms = 0;
+    uint64_t l = 0;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        gemm_profile_collect(ctx->ws[c]);
+        f += ctx->ws[c].prof.flops;
+        ms += ctx->ws[c].prof.gemm_ms;
+        l += ctx->ws[c].prof.launches;
+    }
+    if (gemm_flops) *gemm_flops = f;
+    if (gemm_ms) *gemm_ms = ms;
+    if (launches) *launches = l;
+    return DNAGPU_OK;
+}
+
+/* ---- matrices -------------------------------------------------------------- */
+int dnagpu_matrix_create(dnagpu_ctx* ctx, uint32_t n_max, dnagpu_matrix** out) {
+    CHK_CTX();
+    if (!out) return fail(ctx, DNAGPU_EINVAL, "null out");
+    *out = nullptr;
+    dnagpu_matrix* m = new (std::nothrow) dnagpu_matrix();
+    if (!m) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    m->n_max = n_max;
+    m->np_max = pad128(n_max);
+    hipError_t e = hipMalloc(&m->F, (size_t)m->np_max * m->np_max * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&m->jest, (size_t)m->np_max * sizeof(double));
+    if (e != hipSuccess) {
+        if (m->F) hipFree(m->F);
+        delete m;
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "matrix allocation", e);
+    }
+    m->n = 0;
+    m->np = 128;
+    *out = m;
+    return DNAGPU_OK;
+}
+
+void dnagpu_matrix_destroy(dnagpu_ctx* ctx, dnagpu_matrix* m) {
+    if (!m) return;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+    }
+    if (m->F) hipFree(m->F);
+    if (m->jest) hipFree(m->jest);
+    delete m;
+}
+
+int dnagpu_matrix_reset(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, uint32_t n) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || n > m->n_max) return fail(ctx, DNAGPU_EINVAL, "matrix_reset: order exceeds capacity");
+    m->n = n;
+    m->np = pad128(n);
+    launch_init_padded(m->F, n, m->np, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_upload_packed(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* ap, uint32_t n) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || n > m->n_max || (!ap && n)) return fail(ctx, DNAGPU_EINVAL, "matrix_upload_packed: bad arguments");
+    m->n = n;
+    m->np = pad128(n);
+    size_t cnt = (size_t)n * (n + 1) / 2;
+    // stage the packed data in the inverse workspace's X buffer (np^2 >= n(n+1)/2)
+    int rc = ensure_ws(ctx, chain, m->np);
+    if (rc) return rc;
+    if (cnt) HIPCHK(hipMemcpyAsync(ctx->ws[chain].X, ap, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
+    launch_unpack_lower(ctx->ws[chain].X, m->F, n, m->np, ctx->stream[chain]);
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_download_packed(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || (!ap && m->n)) return fail(ctx, DNAGPU_EINVAL, "matrix_download_packed: bad arguments");
+    size_t cnt = (size_t)m->n * (m->n + 1) / 2;
+    int rc = ensure_ws(ctx, chain, m->np);
+    if (rc) return rc;
+    launch_pack_lower(m->F, ctx->ws[chain].X, m->n, m->np, ctx->stream[chain]);
+    if (cnt) HIPCHK(hipMemcpyAsync(ap, ctx->ws[chain].X, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dnagpu_matrix* src) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!dst || !src || src->n > dst->n_max) return fail(ctx, DNAGPU_EINVAL, "matrix_copy: bad arguments");
+    dst->n = src->n;
+    dst->np = src->np;
+    HIPCHK(hipMemcpyAsync(dst->F, src->F, (size_t)src->np * src->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
+    HIPCHK(hipMemcpyAsync(dst->jest, src->jest, (size_t)src->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_invert(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, int scale_to_unity) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m) return fail(ctx, DNAGPU_EINVAL, "invert: null matrix");
+    if (m->n == 0) return DNAGPU_OK;
+    int rc = ensure_ws(ctx, chain, m->np);
+    if (rc) return rc;
+    sym_inverse_async(ctx->ws[chain], m->F, m->n, m->np, scale_to_unity != 0);
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return check_info(ctx, chain);
+}
+
+/* ---- L2 seam ----------------------------------------------------------------- */
+int dnagpu_cholesky_inverse_packed(dnagpu_ctx* ctx, double* ap, uint32_t n, int scale_to_unity) {
+    CHK_CTX();
+    if (n == 0) return DNAGPU_OK;
+    if (!ap) return fail(ctx, DNAGPU_EINVAL, "cholesky_inverse_packed: null matrix");
+    if (n == 1) {
+        // FormInverseVarianceMatrix special case, dnaadjust.cpp:8474
+        ap[0] = 1.0 / ap[0];
+        return DNAGPU_OK;
+    }
+    dnagpu_matrix* m = nullptr;
+    int rc = dnagpu_matrix_create(ctx, n, &m);
+    if (rc) return rc;
+    rc = dnagpu_matrix_upload_packed(ctx, 0, m, ap, n);
+    if (!rc) rc = dnagpu_invert(ctx, 0, m, scale_to_unity);
+    if (!rc) rc = dnagpu_matrix_download_packed(ctx, 0, m, ap);
+    dnagpu_matrix_destroy(ctx, m);
+    return rc;
+}
+
+int dnagpu_multiply_sym_packed(dnagpu_ctx* ctx, const double* ap, const double* x, double* y, uint32_t n) {
+    CHK_CTX();
+    if (n == 0) return DNAGPU_OK;
+    if (!ap || !x || !y) return fail(ctx, DNAGPU_EINVAL, "multiply_sym_packed: null argument");
+    dnagpu_matrix* m = nullptr;
+    int rc = dnagpu_matrix_create(ctx, n, &m);
+    if (rc) return rc;
+    rc = dnagpu_matrix_upload_packed(ctx, 0, m, ap, n);
+    double* dx = nullptr;
+    if (!rc) rc = ensure_symv(ctx, 0, m->np);
+    if (!rc) rc = ensure_scr_f64(ctx, 0, 2 * (size_t)m->np);
+    if (!rc) {
+        hipStream_t s = ctx->stream[0];
+        dx = ctx->scr_f64[0];
+        double* dy = dx + m->np;
+        // mirror the lower triangle so that the symv kernel can stream full columns
+        hipError_t e = hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            launch_symmetrize(m->F, m->n, m->np, s);
+            launch_symv(m->F, dx, dy, ctx->symv_part[0], n, m->np, SYMV_CHUNKS, s);
+            e = hipMemcpyAsync(y, dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(ctx, DNAGPU_EHIP, "multiply_sym_packed", e);
+    }
+    dnagpu_matrix_destroy(ctx, m);
+    return rc;
+}
+
+/* ---- blocks ------------------------------------------------------------------ */
+int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint32_t n_baselines) {
+    CHK_CTX();
+    if (find_block(ctx, blk)) {
+        int rc = dnagpu_block_destroy(ctx, blk);
+        if (rc) return rc;
+    }
+    Block b;
+    b.n_stn = n_stations;
+    b.n_bl = n_baselines;
+    size_t nv = std::max<size_t>(3 * (size_t)n_stations, 1) * sizeof(double);
+    size_t nb = std::max<size_t>(n_baselines, 1);
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, bytes);
+    };
+    A((void**)&b.x_orig, nv);
+    A((void**)&b.x_est, nv);
+    A((void**)&b.x_rig, nv);
+    A((void**)&b.rhs, nv);
+    A((void**)&b.corr, nv);
+    A((void**)&b.s1, nb * sizeof(uint32_t));
+    A((void**)&b.s2, nb * sizeof(uint32_t));
+    A((void**)&b.obs, nb * 3 * sizeof(double));
+    A((void**)&b.W, nb * 6 * sizeof(double));
+    A((void**)&b.b, nb * 3 * sizeof(double));
+    A((void**)&b.red, 2 * sizeof(double));
+    if (e != hipSuccess) {
+        free_block(b);
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "block allocation", e);
+    }
+    hipMemset(b.rhs, 0, nv);
+    hipMemset(b.corr, 0, nv);
+    ctx->blocks[blk] = b;
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_destroy(dnagpu_ctx* ctx, uint32_t blk) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "block_destroy: unknown block");
+    HIPCHK(hipDeviceSynchronize());
+    free_block(*b);
+    ctx->blocks.erase(blk);
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_set_stations: bad arguments");
+    size_t bytes = 3 * (size_t)b->n_stn * sizeof(double);
+    if (!bytes) return DNAGPU_OK;
+    HIPCHK(hipMemcpy(b->x_orig, xyz, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->x_est, xyz, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->x_rig, xyz, bytes, hipMemcpyHostToDevice));
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_set_baselines(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
+                               const double* vcv6) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: unknown block");
+    const uint32_t m = b->n_bl, ns = b->n_stn;
+    if (m && (!stn1 || !stn2 || !obs || !vcv6)) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: null argument");
+    for (uint32_t i = 0; i < m; ++i)
+        if (stn1[i] >= ns || stn2[i] >= ns) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: station index out of range");
+
+    // station-pair structure: contributions sorted by (row, col), CML order inside a pair
+    struct Ent {
+        uint64_t key;
+        uint32_t bl;
+    };
+    std::vector<Ent> ents;
+    ents.reserve((size_t)m * 3);
+    for (uint32_t i = 0; i < m; ++i) {
+        uint32_t a = stn1[i], c = stn2[i];
+        // the reference adds stn2's diagonal block first, then stn1's (UpdateNormals_G, dnaadjust.cpp:1664-1684);
+        // they hit different elements unless a == c, where this order is kept
+        ents.push_back({(uint64_t)c * ns + c, i});
+        ents.push_back({(uint64_t)a * ns + a, i});
+        if (a != c) {
+            uint32_t r = std::max(a, c), q = std::min(a, c);
+            ents.push_back({(uint64_t)r * ns + q, i});
+        }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
+    std::vector<uint32_t> prow, pcol, poff, pbl(ents.size());
+    for (size_t k = 0; k < ents.size(); ++k) {
+        if (k == 0 || ents[k].key != ents[k - 1].key) {
+            prow.push_back((uint32_t)(ents[k].key / ns));
+            pcol.push_back((uint32_t)(ents[k].key % ns));
+            poff.push_back((uint32_t)k);
+        }
+        pbl[k] = ents[k].bl;
+    }
+    poff.push_back((uint32_t)ents.size());
+    // incidence per station (CML order)
+    std::vector<uint32_t> ioff(ns + 1, 0), inc((size_t)m * 2);
+    for (uint32_t i = 0; i < m; ++i) {
+        ioff[stn1[i] + 1]++;
+        ioff[stn2[i] + 1]++;
+    }
+    for (uint32_t s = 0; s < ns; ++s) ioff[s + 1] += ioff[s];
+    {
+        std::vector<uint32_t> cur(ioff.begin(), ioff.end() - 1);
+        for (uint32_t i = 0; i < m; ++i) {
+            inc[cur[stn1[i]]++] = i * 2u;
+            inc[cur[stn2[i]]++] = i * 2u + 1u;
+        }
+    }
+
+    for (void* p : {(void*)b->pair_row, (void*)b->pair_col, (void*)b->pair_off, (void*)b->pair_bl, (void*)b->inc_off, (void*)b->inc})
+        if (p) hipFree(p);
+    b->pair_row = b->pair_col = b->pair_off = b->pair_bl = b->inc_off = b->inc = nullptr;
+    b->n_pairs = (uint32_t)prow.size();
+    auto up = [&](uint32_t** dev, const std::vector<uint32_t>& v) -> hipError_t {
+        size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(uint32_t);
+        hipError_t e = hipMalloc((void**)dev, bytes);
+        if (e == hipSuccess && !v.empty()) e = hipMemcpy(*dev, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        return e;
+    };
+    HIPCHK(up(&b->pair_row, prow));
+    HIPCHK(up(&b->pair_col, pcol));
+    HIPCHK(up(&b->pair_off, poff));
+    HIPCHK(up(&b->pair_bl, pbl));
+    HIPCHK(up(&b->inc_off, ioff));
+    HIPCHK(up(&b->inc, inc));
+    if (m) {
+        HIPCHK(hipMemcpy(b->s1, stn1, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->s2, stn2, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->obs, obs, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice));
+        // stage the variances in b->b's neighbour: W buffer is the output, use a temp
+        double* vtmp = nullptr;
+        HIPCHK(hipMalloc(&vtmp, (size_t)m * 6 * sizeof(double)));
+        hipError_t e = hipMemcpy(vtmp, vcv6, (size_t)m * 6 * sizeof(double), hipMemcpyHostToDevice);
+        int bad = 0x7fffffff;
+        if (e == hipSuccess) e = hipMemcpy(ctx->bad_dev, &bad, sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_weights(vtmp, b->W, m, ctx->bad_dev, ctx->stream[0]);
+            e = hipStreamSynchronize(ctx->stream[0]);
+        }
+        if (e == hipSuccess) e = hipMemcpy(&bad, ctx->bad_dev, sizeof(int), hipMemcpyDeviceToHost);
+        hipFree(vtmp);
+        if (e != hipSuccess) return fail(ctx, DNAGPU_EHIP, "block_set_baselines: weights", e);
+        if (bad != 0x7fffffff) {
+            ctx->last_info = bad + 1;
+            char buf[160];
+            snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (variance matrix of baseline %d)", bad);
+            ctx->err = buf;
+            return DNAGPU_ENOTPOSDEF;
+        }
+    }
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_get_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int which, double* xyz) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !station_vec(*b, which) || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_stations: bad arguments");
+    if (!b->n_stn) return DNAGPU_OK;
+    HIPCHK(hipMemcpyAsync(xyz, station_vec(*b, which), 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_put_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int which, const double* xyz) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !station_vec(*b, which) || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_put_stations: bad arguments");
+    if (!b->n_stn) return DNAGPU_OK;
+    HIPCHK(hipMemcpyAsync(station_vec(*b, which), xyz, 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_copy_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int dst_which, int src_which) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !station_vec(*b, dst_which) || !station_vec(*b, src_which))
+        return fail(ctx, DNAGPU_EINVAL, "block_copy_stations: bad arguments");
+    if (!b->n_stn || dst_which == src_which) return DNAGPU_OK;
+    HIPCHK(hipMemcpyAsync(station_vec(*b, dst_which), station_vec(*b, src_which), 3 * (size_t)b->n_stn * sizeof(double),
+                          hipMemcpyDeviceToDevice, ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_compute_b(dnagpu_ctx* ctx, int chain, uint32_t blk) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "block_compute_b: unknown block");
+    launch_compute_b(b->s1, b->s2, b->obs, b->x_est, b->b, b->n_bl, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+static int d2h(dnagpu_ctx* ctx, int chain, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return DNAGPU_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_get_b(dnagpu_ctx* ctx, int chain, uint32_t blk, double* out) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || (!out && b->n_bl)) return fail(ctx, DNAGPU_EINVAL, "block_get_b: bad arguments");
+    return d2h(ctx, chain, out, b->b, (size_t)b->n_bl * 3 * sizeof(double));
+}
+
+int dnagpu_block_get_weights(dnagpu_ctx* ctx, int chain, uint32_t blk, double* w6) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || (!w6 && b->n_bl)) return fail(ctx, DNAGPU_EINVAL, "block_get_weights: bad arguments");
+    return d2h(ctx, chain, w6, b->W, (size_t)b->n_bl * 6 * sizeof(double));
+}
+
+int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, double* corr) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || (!corr && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_corrections: bad arguments");
+    return d2h(ctx, chain, corr, b->corr, (size_t)b->n_stn * 3 * sizeof(double));
+}
+
+int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || (!rhs && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_rhs: bad arguments");
+    return d2h(ctx, chain, rhs, b->rhs, (size_t)b->n_stn * 3 * sizeof(double));
+}
+
+int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !m || 3 * b->n_stn > m->n_max) return fail(ctx, DNAGPU_EINVAL, "form_normals: bad arguments");
+    m->n = 3 * b->n_stn;
+    m->np = pad128(m->n);
+    launch_init_padded(m->F, m->n, m->np, ctx->stream[chain]);
+    launch_form_normals(b->pair_row, b->pair_col, b->pair_off, b->pair_bl, b->W, m->F, m->np, b->n_pairs, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_add_diag3x3(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const uint32_t* stn, const double* w9, size_t k, int sign) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || (k && (!stn || !w9))) return fail(ctx, DNAGPU_EINVAL, "add_diag3x3: bad arguments");
+    if (!k) return DNAGPU_OK;
+    for (size_t i = 0; i < k; ++i)
+        if (3 * (uint64_t)stn[i] + 2 >= m->n) return fail(ctx, DNAGPU_EINVAL, "add_diag3x3: station out of range");
+    uint32_t* dstn = nullptr;
+    double* dw = nullptr;
+    int rc = stage_u32(ctx, chain, stn, k, &dstn);
+    if (!rc) rc = stage_f64(ctx, chain, w9, k * 9, &dw);
+    if (rc) return rc;
+    launch_add_diag3x3(m->F, m->np, dstn, dw, (uint32_t)k, sign < 0 ? -1.0 : 1.0, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_form_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "form_rhs: unknown block");
+    launch_form_rhs(b->inc_off, b->inc, b->W, b->b, b->rhs, b->n_stn, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_solve_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* m) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !m || m->n != 3 * b->n_stn) return fail(ctx, DNAGPU_EINVAL, "solve_corrections: bad arguments");
+    if (!m->n) return DNAGPU_OK;
+    int rc = ensure_symv(ctx, chain, m->np);
+    if (rc) return rc;
+    launch_symv(m->F, b->rhs, b->corr, ctx->symv_part[chain], m->n, m->np, SYMV_CHUNKS, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_update_estimates(dnagpu_ctx* ctx, int chain, uint32_t blk, double* max_corr, uint32_t* max_row) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "update_estimates: unknown block");
+    uint32_t n = 3 * b->n_stn;
+    double* dval = b->red;
+    uint32_t* didx = reinterpret_cast<uint32_t*>(b->red + 1);
+    launch_update_estimates(b->x_est, b->corr, n, dval, didx, ctx->stream[chain]);
+    HIPCHK(hipMemcpyAsync(ctx->red_val_host[chain], dval, sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
+    HIPCHK(hipMemcpyAsync(ctx->red_idx_host[chain], didx, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    if (max_corr) *max_corr = *ctx->red_val_host[chain];
+    if (max_row) *max_row = *ctx->red_idx_host[chain];
+    return DNAGPU_OK;
+}
+
+/* ---- junction carry ------------------------------------------------------------ */
+int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const dnagpu_matrix* src, const uint32_t* idx_from, size_t k,
+                           dnagpu_matrix* jm) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk_from);
+    if (!b || !src || !jm || (k && !idx_from) || 3 * k > jm->n_max || src->n != 3 * b->n_stn)
+        return fail(ctx, DNAGPU_EINVAL, "junction_gather: bad arguments");
+    for (size_t i = 0; i < k; ++i)
+        if (idx_from[i] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "junction_gather: station out of range");
+    jm->n = (uint32_t)(3 * k);
+    jm->np = pad128(jm->n);
+    launch_init_padded(jm->F, jm->n, jm->np, ctx->stream[chain]);
+    if (!k) return DNAGPU_OK;
+    uint32_t* didx = nullptr;
+    int rc = stage_u32(ctx, chain, idx_from, k, &didx);
+    if (rc) return rc;
+    launch_junction_gather(src->F, src->np, didx, (uint32_t)k, jm->F, jm->np, ctx->stream[chain]);
+    launch_gather_vec3(b->x_est, didx, (uint32_t)k, jm->jest, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_junction_scatter(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const uint32_t* idx_to, size_t k, const dnagpu_matrix* jm) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!dst || !jm || (k && !idx_to) || jm->n != 3 * k) return fail(ctx, DNAGPU_EINVAL, "junction_scatter: bad arguments");
+    for (size_t i = 0; i < k; ++i)
+        if (3 * (uint64_t)idx_to[i] + 2 >= dst->n) return fail(ctx, DNAGPU_EINVAL, "junction_scatter: station out of range");
+    if (!k) return DNAGPU_OK;
+    uint32_t* didx = nullptr;
+    int rc = stage_u32(ctx, chain, idx_to, k, &didx);
+    if (rc) return rc;
+    launch_junction_scatter(dst->F, dst->np, didx, (uint32_t)k, jm->F, jm->np, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_junction_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk_to, const uint32_t* idx_to, size_t k, const dnagpu_matrix* jm) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk_to);
+    if (!b || !jm || (k && !idx_to) || jm->n != 3 * k) return fail(ctx, DNAGPU_EINVAL, "junction_rhs: bad arguments");
+    for (size_t i = 0; i < k; ++i)
+        if (idx_to[i] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "junction_rhs: station out of range");
+    if (!k) return DNAGPU_OK;
+    uint32_t* didx = nullptr;
+    int rc = stage_u32(ctx, chain, idx_to, k, &didx);
+    if (rc) return rc;
+    launch_junction_rhs(b->rhs, b->x_est, didx, (uint32_t)k, jm->F, jm->np, jm->jest, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_junction_get_estimates(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* jm, double* est) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!jm || (!est && jm->n)) return fail(ctx, DNAGPU_EINVAL, "junction_get_estimates: bad arguments");
+    return d2h(ctx, chain, est, jm->jest, (size_t)jm->n * sizeof(double));
+}
+
+int dnagpu_junction_put_estimates(dnagpu_ctx* ctx, int chain, dnagpu_matrix* jm, const double* est, size_t k) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!jm || 3 * k > jm->n_max || (k && !est)) return fail(ctx, DNAGPU_EINVAL, "junction_put_estimates: bad arguments");
+    if (!k) return DNAGPU_OK;
+    HIPCHK(hipMemcpyAsync(jm->jest, est, 3 * k * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// Internal (C++) interface of the dense fp64 kernels.  Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dnagpu {
+
+enum KMode { KM_FULL = 0, KM_LE_J = 1, KM_GE_J = 2, KM_LE_I = 3, KM_GE_I = 4 };
+
+struct GemmArgs {
+    const double* A;
+    const double* B;
+    double* C;
+    int lda, ldb, ldc;
+    int mt, nt;  // tiles of 128 in M and N
+    int K;       // multiple of 16
+    double alpha, beta;
+    int kmode;   // KMode: restricts the k range per tile (triangular operands)
+    int lower;   // 1: only tiles it >= jt (square problems)
+    int mirror;  // 1: also store C(j,i) for off-diagonal tiles
+};
+
+void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);
+void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s);
+void launch_unpack_lower(const double* ap, double* F, uint32_t n, uint32_t np, hipStream_t s);
+void launch_pack_lower(const double* F, double* ap, uint32_t n, uint32_t np, hipStream_t s);
+void launch_init_padded(double* F, uint32_t n, uint32_t np, hipStream_t s);
+void launch_diag_rsqrt(const double* F, double* s, uint32_t n, uint32_t np, hipStream_t st);
+void launch_scale_sym(double* F, const double* s, uint32_t n, uint32_t np, int lower_only, hipStream_t st);
+void launch_symmetrize(double* F, uint32_t n, uint32_t np, hipStream_t s);
+void launch_symv(const double* F, const double* x, double* y, double* part, uint32_t n, uint32_t np, uint32_t nchunks,
+                 hipStream_t st);
+
+inline uint32_t pad128(uint32_t n) { return n == 0 ? 128u : ((n + 127u) / 128u) * 128u; }
+
+}  // namespace dnagpu

@@ -1,0 +1,420 @@
+// Dense fp64 linear-algebra kernels for gfx950 (MI355X): the arithmetic behind
+// dna_adjust::Solve -> FormInverseVarianceMatrix -> matrix_2d::cholesky_inverse
+// (reference: dynadjust/dynadjust/dnaadjust/dnaadjust.cpp:6586-6647, 8472-8517;
+//  dynadjust/include/math/dnamatrix_contiguous.cpp:952-1020 = dpotrf + dpotri).
+//
+// Layout in HBM: every symmetric matrix lives in a full square column-major
+// buffer of order np = ceil(n/128)*128 (ld = np).  The padding carries an
+// identity so that every kernel works on whole 128x128 tiles and never needs
+// edge predication.  The reference's packed-lower exchange format
+// (matrix_2d::packed_index, dnamatrix_contiguous.hpp:363) only exists at the
+// host boundary (pack/unpack kernels below).
+//
+// The inverse is a recursive blocked algorithm whose flops all go through ONE
+// tile kernel (gemm_f64) built on v_mfma_f64_16x16x4_f64:
+//   node(o,s):  node(left half)                      -> X11 = L11^-1
+//               W21  = A21 * X11^T        (NT, k <= j)   == L21
+//               A22 -= W21 * W21^T        (NT, lower)
+//               node(right half)                     -> X22
+//               T21  = W21 * X11          (NN, k >= j)
+//               X21  = -X22 * T21         (NN, k <= i)
+//   lauum:      Ninv = X^T X              (TN, k >= i, mirrored to both triangles)
+// Flop count n^3/3 + n^3/3 + n^3/3 = the reference's dpotrf + dpotri.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "la_kernels.h"
+
+namespace dnagpu {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ----------------------------------------------------------------------------
+// Tile GEMM:  C(it,jt) = alpha * sum_k opA(i,k) opB(k,j) + beta * C(it,jt)
+//   A_KC = false: A(i,k) at A[i + k*lda]   (row-contiguous, "N")
+//   A_KC = true : A(i,k) at A[k + i*lda]   (k-contiguous,  "T")
+//   B_KC = false: B(k,j) at B[j + k*ldb]   ("T": B given as its transpose)
+//   B_KC = true : B(k,j) at B[k + j*ldb]   ("N")
+// 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4 MFMA
+// 16x16 accumulators (128 VGPRs).  LDS is double buffered, one barrier per
+// BK=16 slab.  LDS layouts are chosen so that the MFMA fragment reads
+// (ds_read_b64, two 32-lane groups) are bank-conflict free:
+//   R layout  [k][row]      row stride 144 doubles (k+1 lands 32 banks away)
+//   P layout  [k/2][col][2] pair stride 258 doubles (32 lanes read 256 B contiguous)
+// ----------------------------------------------------------------------------
+constexpr int LDR = 144;
+constexpr int LDP = 258;
+constexpr int OPBUF = 16 * LDR;  // 2304 doubles >= 8*LDP = 2064
+
+template <bool KC>
+__device__ __forceinline__ void stage_load(const double* __restrict__ P, int ld, int r0, int k0, int tid, d2 (&g)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int idx = tid + 256 * q;
+        if (!KC) {
+            int k = idx >> 6, r2 = idx & 63;
+            g[q] = *reinterpret_cast<const d2*>(P + (size_t)(k0 + k) * ld + r0 + 2 * r2);
+        } else {
+            int k2 = idx & 7, c = idx >> 3;
+            g[q] = *reinterpret_cast<const d2*>(P + (size_t)(r0 + c) * ld + k0 + 2 * k2);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_store(double* buf, int tid, const d2 (&g)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int idx = tid + 256 * q;
+        if (!KC) {
+            int k = idx >> 6, r2 = idx & 63;
+            *reinterpret_cast<d2*>(buf + k * LDR + 2 * r2) = g[q];
+        } else {
+            int k2 = idx & 7, c = idx >> 3;
+            *reinterpret_cast<d2*>(buf + k2 * LDP + 2 * c) = g[q];
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ double frag_read(const double* buf, int kk, int rbase, int lane) {
+    int k = kk * 4 + (lane >> 4);
+    int r = rbase + (lane & 15);
+    if (!KC) return buf[k * LDR + r];
+    return buf[(k >> 1) * LDP + r * 2 + (k & 1)];
+}
+
+__device__ __forceinline__ void tile_from_linear(const GemmArgs& a, int& it, int& jt) {
+    // XCD-aware bijective remap: workgroup b runs on XCD b%8; give every XCD a
+    // contiguous chunk of the tile list so neighbouring tiles share an L2.
+    int total = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
+    int b = blockIdx.x;
+    int lin = b;
+    if (total >= 16) {
+        int xcd = b & 7, q = b >> 3;
+        int base = total >> 3, rem = total & 7;
+        int start = xcd * base + (xcd < rem ? xcd : rem);
+        lin = start + q;
+    }
+    if (a.lower) {
+        int r = (int)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > lin) --r;
+        while ((r + 1) * (r + 2) / 2 <= lin) ++r;
+        it = r;
+        jt = lin - r * (r + 1) / 2;
+    } else {
+        const int G = 8;
+        int tpg = G * a.nt;
+        int g = lin / tpg;
+        int first = g * G;
+        int gsz = a.mt - first < G ? a.mt - first : G;
+        int w = lin - g * tpg;
+        it = first + w % gsz;
+        jt = w / gsz;
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * OPBUF];
+    int it, jt;
+    tile_from_linear(a, it, jt);
+
+    int kbeg = 0, kend = a.K;
+    switch (a.kmode) {
+        case KM_LE_J: kend = (jt + 1) * 128; break;
+        case KM_GE_J: kbeg = jt * 128; break;
+        case KM_LE_I: kend = (it + 1) * 128; break;
+        case KM_GE_I: kbeg = it * 128; break;
+        default: break;
+    }
+    if (kend > a.K) kend = a.K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int i0 = it * 128, j0 = jt * 128;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    d2 ga[4], gb[4];
+    const int nk = (kend - kbeg) / 16;
+    if (nk > 0) {
+        stage_load<A_KC>(a.A, a.lda, i0, kbeg, tid, ga);
+        stage_load<B_KC>(a.B, a.ldb, j0, kbeg, tid, gb);
+        stage_store<A_KC>(lds, tid, ga);
+        stage_store<B_KC>(lds + OPBUF, tid, gb);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const double* As = lds + cur * 2 * OPBUF;
+        const double* Bs = As + OPBUF;
+        const bool more = (t + 1 < nk);
+        if (more) {
+            stage_load<A_KC>(a.A, a.lda, i0, kbeg + (t + 1) * 16, tid, ga);
+            stage_load<B_KC>(a.B, a.ldb, j0, kbeg + (t + 1) * 16, tid, gb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = frag_read<A_KC>(As, kk, wm * 64 + mi * 16, lane);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bf[ni] = frag_read<B_KC>(Bs, kk, wn * 64 + ni * 16, lane);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    // first operand indexes the result row (= j), second the result
+                    // column (= i = lane&15): stores become 128 B contiguous in i.
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) {
+            double* An = lds + (cur ^ 1) * 2 * OPBUF;
+            stage_store<A_KC>(An, tid, ga);
+            stage_store<B_KC>(An + OPBUF, tid, gb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[mi][ni][r] = C(i = i0+wm*64+mi*16+(lane&15), j = j0+wn*64+ni*16+(lane>>4)+4r)
+    const bool mirror = a.mirror && (it != jt);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int i = i0 + wm * 64 + mi * 16 + (lane & 15);
+                int j = j0 + wn * 64 + ni * 16 + (lane >> 4) + 4 * r;
+                double* c = a.C + (size_t)j * a.ldc + i;
+                double v = a.alpha * acc[mi][ni][r];
+                if (a.beta != 0.0) v += a.beta * (*c);
+                *c = v;
+                if (mirror) a.C[(size_t)i * a.ldc + j] = v;
+            }
+        }
+    }
+}
+
+void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
+    int total = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
+    if (total <= 0) return;
+    dim3 grid(total), block(256);
+    if (!a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, s, a);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, s, a);
+    else if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, s, a);
+}
+
+// ----------------------------------------------------------------------------
+// Leaf: one 128x128 diagonal tile.  Reads the lower triangle of A(o:o+128,o:o+128),
+// factors it (L L^T, unblocked right-looking, the tile lives in LDS) and writes
+// X = L^-1 (lower, zeros above the diagonal) to the X buffer.  A non-positive or
+// NaN pivot records info = (global column + 1) like dpotrf's info (the facade turns
+// it into the reference's "Matrix inversion failed, the matrix is singular.",
+// dnamatrix_contiguous.cpp:983).
+// ----------------------------------------------------------------------------
+constexpr int LS = 129;
+
+__global__ __launch_bounds__(256) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
+                                                               int ldx, int o, int* info) {
+    __shared__ double S[128 * LS];
+    __shared__ double dg[128];
+    const int tid = threadIdx.x;
+    const int row = tid & 127;
+    const int half = tid >> 7;
+
+    // load lower triangle (coalesced down columns)
+    for (int c = half; c < 128; c += 2) {
+        double v = A[(size_t)(o + c) * lda + o + row];
+        S[row * LS + c] = (row >= c) ? v : 0.0;
+    }
+    __syncthreads();
+
+    // Cholesky, right-looking
+    for (int k = 0; k < 128; ++k) {
+        double d = S[k * LS + k];
+        bool bad = !(d > 0.0);
+        if (bad) {
+            if (tid == 0) atomicMin(info, o + k + 1);
+            d = 1.0;
+        }
+        double r = sqrt(d);
+        double inv = 1.0 / r;
+        if (half == 0 && row > k) S[row * LS + k] *= inv;
+        if (tid == 0) dg[k] = r;
+        __syncthreads();
+        if (row > k) {
+            double lik = S[row * LS + k];
+            // columns k+1..row, split between the two halves
+            for (int j = k + 1 + half; j <= row; j += 2) S[row * LS + j] -= lik * S[j * LS + k];
+        }
+        __syncthreads();
+    }
+    // S strictly-lower = L, dg = diag(L).  In-place inverse of the lower triangle
+    // (Gauss-Jordan on [L | I]): after step k column k of L is dead and is reused
+    // for column k of M = L^-1.
+    for (int k = 0; k < 128; ++k) {
+        double mkk = 1.0 / dg[k];
+        // scale row k of M (columns < k); M[k][k] = mkk kept in dg
+        if (tid < k) S[k * LS + tid] *= mkk;
+        double lik = (row > k) ? S[row * LS + k] : 0.0;
+        __syncthreads();
+        if (row > k) {
+            for (int j = half; j < k; j += 2) S[row * LS + j] -= lik * S[k * LS + j];
+            if (half == 0) S[row * LS + k] = -lik * mkk;
+        }
+        if (tid == 0) dg[k] = mkk;
+        __syncthreads();
+    }
+    for (int c = half; c < 128; c += 2) {
+        double v = (row > c) ? S[row * LS + c] : (row == c ? dg[c] : 0.0);
+        X[(size_t)(o + c) * ldx + o + row] = v;
+    }
+}
+
+void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s) {
+    hipLaunchKernelGGL(leaf_potrf_trtri_kernel, dim3(1), dim3(256), 0, s, A, lda, X, ldx, o, info);
+}
+
+// ----------------------------------------------------------------------------
+// pack / unpack between the reference's packed-lower column-major layout
+// (index j*n - j(j-1)/2 + (i-j), dnamatrix_contiguous.hpp:363) and the padded
+// full-square device layout.  unpack also writes the identity padding.
+// ----------------------------------------------------------------------------
+__global__ void unpack_lower_kernel(const double* __restrict__ ap, double* __restrict__ F, uint32_t n, uint32_t np) {
+    uint32_t j = blockIdx.x;  // column
+    size_t colbase = (size_t)j * n - (size_t)j * (j > 0 ? j - 1 : 0) / 2;
+    for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+        double v;
+        if (j < n && i < n)
+            v = (i >= j) ? ap[colbase + (i - j)] : 0.0;
+        else
+            v = (i == j) ? 1.0 : 0.0;
+        F[(size_t)j * np + i] = v;
+    }
+}
+
+__global__ void pack_lower_kernel(const double* __restrict__ F, double* __restrict__ ap, uint32_t n, uint32_t np) {
+    uint32_t j = blockIdx.x;
+    size_t colbase = (size_t)j * n - (size_t)j * (j > 0 ? j - 1 : 0) / 2;
+    for (uint32_t i = j + threadIdx.x; i < n; i += blockDim.x) ap[colbase + (i - j)] = F[(size_t)j * np + i];
+}
+
+void launch_unpack_lower(const double* ap, double* F, uint32_t n, uint32_t np, hipStream_t s) {
+    hipLaunchKernelGGL(unpack_lower_kernel, dim3(np), dim3(256), 0, s, ap, F, n, np);
+}
+void launch_pack_lower(const double* F, double* ap, uint32_t n, uint32_t np, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pack_lower_kernel, dim3(n), dim3(256), 0, s, F, ap, n, np);
+}
+
+// zero the whole buffer and put 1.0 on the padded part of the diagonal
+__global__ void init_padded_kernel(double* __restrict__ F, uint32_t n, uint32_t np) {
+    uint32_t j = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) F[(size_t)j * np + i] = (i == j && j >= n) ? 1.0 : 0.0;
+}
+void launch_init_padded(double* F, uint32_t n, uint32_t np, hipStream_t s) {
+    hipLaunchKernelGGL(init_padded_kernel, dim3(np), dim3(256), 0, s, F, n, np);
+}
+
+// ----------------------------------------------------------------------------
+// scale_normals_to_unity (dnaadjust.cpp:6614-6645, scale_symmetric_diagonal
+// dnamatrix_contiguous.cpp:1145): s_i = 1/sqrt(N_ii);  N <- S N S (lower or full)
+// ----------------------------------------------------------------------------
+__global__ void diag_rsqrt_kernel(const double* __restrict__ F, double* __restrict__ s, uint32_t n, uint32_t np) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) s[i] = (i < n) ? 1.0 / sqrt(F[(size_t)i * np + i]) : 1.0;
+}
+__global__ void scale_sym_kernel(double* __restrict__ F, const double* __restrict__ s, uint32_t n, uint32_t np, int lower_only) {
+    uint32_t j = blockIdx.x;
+    double sj = s[j];
+    uint32_t ibeg = lower_only ? j : 0;
+    for (uint32_t i = ibeg + threadIdx.x; i < n; i += blockDim.x) F[(size_t)j * np + i] *= s[i] * sj;
+}
+void launch_diag_rsqrt(const double* F, double* s, uint32_t n, uint32_t np, hipStream_t st) {
+    hipLaunchKernelGGL(diag_rsqrt_kernel, dim3((np + 255) / 256), dim3(256), 0, st, F, s, n, np);
+}
+void launch_scale_sym(double* F, const double* s, uint32_t n, uint32_t np, int lower_only, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(scale_sym_kernel, dim3(n), dim3(256), 0, st, F, s, n, np, lower_only);
+}
+
+// copy the lower triangle into the upper one (tile transposes through LDS)
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ F, uint32_t np) {
+    __shared__ double t[32][33];
+    uint32_t bi = blockIdx.x, bj = blockIdx.y;
+    if (bi <= bj) return;  // strictly-lower 32x32 tiles only; diagonal tiles handled below
+    uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (uint32_t r = ty; r < 32; r += 8) t[r][tx] = F[(size_t)(bj * 32 + r) * np + bi * 32 + tx];  // t[col][row]
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8) F[(size_t)(bi * 32 + r) * np + bj * 32 + tx] = t[tx][r];
+}
+__global__ __launch_bounds__(256) void symmetrize_diag_kernel(double* __restrict__ F, uint32_t np) {
+    uint32_t b = blockIdx.x;
+    uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t r = ty; r < 32; r += 8) {
+        uint32_t i = b * 32 + tx, j = b * 32 + r;  // element (i, j)
+        if (i > j) F[(size_t)i * np + j] = F[(size_t)j * np + i];
+    }
+}
+void launch_symmetrize(double* F, uint32_t n, uint32_t np, hipStream_t s) {
+    (void)n;
+    uint32_t nb = np / 32;
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, s, F, np);
+    hipLaunchKernelGGL(symmetrize_diag_kernel, dim3(nb), dim3(256), 0, s, F, np);
+}
+
+// ----------------------------------------------------------------------------
+// y = F x for a full symmetric F (both triangles valid), deterministic:
+// phase 1: partial[c][i] = sum over column chunk c;  phase 2: y_i = sum_c partial.
+// HBM-bound: reads np*n*8 bytes once.  (reference: multiply_sym -> dspmv/dsymm,
+// dnamatrix_contiguous.cpp:1471-1510.)
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void symv_partial_kernel(const double* __restrict__ F, const double* __restrict__ x,
+                                                           double* __restrict__ part, uint32_t n, uint32_t np, uint32_t cols_per_chunk) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t c = blockIdx.y;
+    uint32_t j0 = c * cols_per_chunk;
+    uint32_t j1 = j0 + cols_per_chunk;
+    if (j1 > n) j1 = n;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    if (i < np) {
+        uint32_t j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            acc0 += F[(size_t)j * np + i] * x[j];
+            acc1 += F[(size_t)(j + 1) * np + i] * x[j + 1];
+            acc2 += F[(size_t)(j + 2) * np + i] * x[j + 2];
+            acc3 += F[(size_t)(j + 3) * np + i] * x[j + 3];
+        }
+        for (; j < j1; ++j) acc0 += F[(size_t)j * np + i] * x[j];
+        part[(size_t)c * np + i] = (acc0 + acc1) + (acc2 + acc3);
+    }
+}
+__global__ void symv_reduce_kernel(const double* __restrict__ part, double* __restrict__ y, uint32_t n, uint32_t np, uint32_t nchunks) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (uint32_t c = 0; c < nchunks; ++c) s += part[(size_t)c * np + i];
+    y[i] = s;
+}
+void launch_symv(const double* F, const double* x, double* y, double* part, uint32_t n, uint32_t np, uint32_t nchunks, hipStream_t st) {
+    if (n == 0) return;
+    uint32_t cpc = (n + nchunks - 1) / nchunks;
+    hipLaunchKernelGGL(symv_partial_kernel, dim3(np / 256 + (np % 256 ? 1 : 0), nchunks), dim3(256), 0, st, F, x, part, n, np, cpc);
+    hipLaunchKernelGGL(symv_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, y, n, np, nchunks);
+}
+
+}  // namespace dnagpu

@@ -1,0 +1,47 @@
+// Host driver for the in-place symmetric positive definite inverse on the device.
+// Restates matrix_2d::cholesky_inverse (dnamatrix_contiguous.cpp:952-1020:
+// dpotrf + dpotri) and the optional diagonal scaling of dna_adjust::Solve
+// (dnaadjust.cpp:6614-6645) as a recursive sequence of tile-GEMM launches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace dnagpu {
+
+struct GemmProfile {
+    bool enabled = false;
+    double flops = 0.0;      // actual flops issued by gemm launches since reset
+    double gemm_ms = 0.0;    // summed event time of gemm launches (after collect())
+    uint64_t launches = 0;
+    std::vector<hipEvent_t> pool;  // start/stop pairs
+    size_t used = 0;
+};
+
+// Workspace shared by every inverse run on one stream ("chain").
+struct InvWorkspace {
+    double* X = nullptr;     // np_cap^2 : L^-1
+    double* W = nullptr;     // np_cap^2 : L21 panels
+    double* svec = nullptr;  // np_cap   : diagonal scaling
+    int* info = nullptr;     // device int (dpotrf-style info, 0 = ok)
+    int* info_host = nullptr;  // pinned host copy
+    uint32_t np_cap = 0;
+    hipStream_t stream = nullptr;
+    GemmProfile prof;
+};
+
+// returns hipSuccess or an error; allocates for matrices up to np_cap (multiple of 128)
+hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t stream);
+void inv_workspace_free(InvWorkspace& ws);
+
+// F: np x np (ld = np) device buffer, lower triangle valid, identity padding beyond n.
+// On return F holds the inverse in BOTH triangles.  Asynchronous on ws.stream; the
+// dpotrf-style info is copied to ws.info_host (valid after stream sync).
+void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity);
+
+// sum the event timings recorded so far (synchronises the stream)
+void gemm_profile_collect(InvWorkspace& ws);
+void gemm_profile_reset(InvWorkspace& ws);
+
+}  // namespace dnagpu

@@ -1,0 +1,159 @@
+#include "sym_inverse.h"
+#include "la_kernels.h"
+
+namespace dnagpu {
+
+hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t stream) {
+    ws.np_cap = np_cap;
+    ws.stream = stream;
+    size_t bytes = (size_t)np_cap * np_cap * sizeof(double);
+    hipError_t e;
+    if ((e = hipMalloc(&ws.X, bytes)) != hipSuccess) return e;
+    if ((e = hipMalloc(&ws.W, bytes)) != hipSuccess) return e;
+    if ((e = hipMalloc(&ws.svec, (size_t)np_cap * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMalloc(&ws.info, sizeof(int))) != hipSuccess) return e;
+    if ((e = hipHostMalloc(&ws.info_host, sizeof(int))) != hipSuccess) return e;
+    *ws.info_host = 0;
+    return hipSuccess;
+}
+
+void inv_workspace_free(InvWorkspace& ws) {
+    if (ws.X) hipFree(ws.X);
+    if (ws.W) hipFree(ws.W);
+    if (ws.svec) hipFree(ws.svec);
+    if (ws.info) hipFree(ws.info);
+    if (ws.info_host) hipHostFree(ws.info_host);
+    for (hipEvent_t ev : ws.prof.pool) hipEventDestroy(ev);
+    ws = InvWorkspace();
+}
+
+static double gemm_flops(const GemmArgs& a) {
+    // sum over launched tiles of 2*128*128*klen(tile)
+    double f = 0.0;
+    for (int it = 0; it < a.mt; ++it) {
+        int jmax = a.lower ? it : a.nt - 1;
+        for (int jt = 0; jt <= jmax; ++jt) {
+            int kb = 0, ke = a.K;
+            switch (a.kmode) {
+                case KM_LE_J: ke = (jt + 1) * 128; break;
+                case KM_GE_J: kb = jt * 128; break;
+                case KM_LE_I: ke = (it + 1) * 128; break;
+                case KM_GE_I: kb = it * 128; break;
+                default: break;
+            }
+            if (ke > a.K) ke = a.K;
+            if (ke > kb) f += 2.0 * 128.0 * 128.0 * (double)(ke - kb);
+        }
+    }
+    return f;
+}
+
+static void gemm(InvWorkspace& ws, const GemmArgs& a, int akc, int bkc) {
+    GemmProfile& p = ws.prof;
+    if (p.enabled) {
+        if (p.used + 2 > p.pool.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t ev;
+                hipEventCreate(&ev);
+                p.pool.push_back(ev);
+            }
+        }
+        hipEventRecord(p.pool[p.used], ws.stream);
+        launch_gemm(a, akc, bkc, ws.stream);
+        hipEventRecord(p.pool[p.used + 1], ws.stream);
+        p.used += 2;
+        p.flops += gemm_flops(a);
+        p.launches++;
+    } else {
+        launch_gemm(a, akc, bkc, ws.stream);
+    }
+}
+
+void gemm_profile_collect(InvWorkspace& ws) {
+    GemmProfile& p = ws.prof;
+    hipStreamSynchronize(ws.stream);
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, p.pool[i], p.pool[i + 1]);
+        p.gemm_ms += ms;
+    }
+    p.used = 0;
+}
+
+void gemm_profile_reset(InvWorkspace& ws) {
+    ws.prof.flops = 0.0;
+    ws.prof.gemm_ms = 0.0;
+    ws.prof.launches = 0;
+    ws.prof.used = 0;
+}
+
+namespace {
+
+struct Rec {
+    InvWorkspace& ws;
+    double* F;
+    int ld;
+
+    double* f(int rt, int ct) { return F + (size_t)ct * 128 * ld + (size_t)rt * 128; }
+    double* x(int rt, int ct) { return ws.X + (size_t)ct * 128 * ld + (size_t)rt * 128; }
+    double* w(int rt, int ct) { return ws.W + (size_t)ct * 128 * ld + (size_t)rt * 128; }
+
+    void node(int o, int s) {
+        if (s == 1) {
+            launch_leaf(F, ld, ws.X, ld, o * 128, ws.info, ws.stream);
+            return;
+        }
+        int h = s / 2;
+        int r = s - h;
+        node(o, h);
+        GemmArgs a;
+        // W21 = A21 * X11^T   (L21 = A21 L11^-T)
+        a.A = f(o + h, o); a.lda = ld;
+        a.B = x(o, o); a.ldb = ld;
+        a.C = w(o + h, o); a.ldc = ld;
+        a.mt = r; a.nt = h; a.K = h * 128;
+        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_LE_J; a.lower = 0; a.mirror = 0;
+        gemm(ws, a, 0, 0);
+        // A22 -= W21 * W21^T  (lower tiles)
+        a.A = w(o + h, o); a.B = w(o + h, o); a.C = f(o + h, o + h);
+        a.mt = r; a.nt = r; a.K = h * 128;
+        a.alpha = -1.0; a.beta = 1.0; a.kmode = KM_FULL; a.lower = 1; a.mirror = 0;
+        gemm(ws, a, 0, 0);
+        node(o + h, r);
+        // T21 = W21 * X11  -> stored where A21 was
+        a.A = w(o + h, o); a.B = x(o, o); a.C = f(o + h, o);
+        a.mt = r; a.nt = h; a.K = h * 128;
+        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
+        gemm(ws, a, 0, 1);
+        // X21 = -X22 * T21
+        a.A = x(o + h, o + h); a.B = f(o + h, o); a.C = x(o + h, o);
+        a.mt = r; a.nt = h; a.K = r * 128;
+        a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
+        gemm(ws, a, 0, 1);
+    }
+};
+
+}  // namespace
+
+void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity) {
+    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
+    if (scale_to_unity) {
+        launch_diag_rsqrt(F, ws.svec, n, np, ws.stream);
+        launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
+    }
+    Rec rec{ws, F, (int)np};
+    int T = (int)(np / 128);
+    rec.node(0, T);
+    // Ninv = X^T X  (lauum), both triangles
+    GemmArgs a;
+    a.A = ws.X; a.lda = (int)np;
+    a.B = ws.X; a.ldb = (int)np;
+    a.C = F; a.ldc = (int)np;
+    a.mt = T; a.nt = T; a.K = (int)np;
+    a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
+    gemm(ws, a, 1, 1);
+    if (scale_to_unity) launch_scale_sym(F, ws.svec, n, np, 0, ws.stream);
+    hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, ws.stream);
+}
+
+}  // namespace dnagpu

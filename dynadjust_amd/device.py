@@ -1,0 +1,232 @@
+"""Thin numpy-facing wrapper over the dnagpu C-ABI (one context per GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DnaGpuError, c_f64p, c_u32p
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_f64p)
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(c_u32p)
+
+
+def packed_index(n, i, j):
+    """matrix_2d::packed_index (dnamatrix_contiguous.hpp:363), i >= j."""
+    return j * n - j * (j - 1) // 2 + (i - j)
+
+
+def pack_lower(full):
+    """column-major packed lower triangle of a square numpy matrix."""
+    n = full.shape[0]
+    out = np.empty(n * (n + 1) // 2, dtype=np.float64)
+    k = 0
+    for j in range(n):
+        out[k:k + n - j] = full[j:, j]
+        k += n - j
+    return out
+
+
+def unpack_lower(ap, n, symmetric=True):
+    full = np.zeros((n, n), dtype=np.float64)
+    k = 0
+    for j in range(n):
+        full[j:, j] = ap[k:k + n - j]
+        k += n - j
+    if symmetric:
+        full = full + np.tril(full, -1).T
+    return full
+
+
+class Matrix:
+    def __init__(self, ctx, n_max):
+        self.ctx = ctx
+        self.n_max = int(n_max)
+        self.n = 0
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.dnagpu_matrix_create(ctx.h, self.n_max, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.dnagpu_matrix_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def reset(self, n, chain=0):
+        self.ctx._chk(self.ctx.lib.dnagpu_matrix_reset(self.ctx.h, chain, self.h, int(n)))
+        self.n = int(n)
+
+    def upload_packed(self, ap, n, chain=0):
+        ap, p = _f64(ap)
+        assert ap.size == n * (n + 1) // 2
+        self.ctx._chk(self.ctx.lib.dnagpu_matrix_upload_packed(self.ctx.h, chain, self.h, p, int(n)))
+        self.n = int(n)
+
+    def download_packed(self, chain=0):
+        out = np.empty(self.n * (self.n + 1) // 2, dtype=np.float64)
+        self.ctx._chk(self.ctx.lib.dnagpu_matrix_download_packed(self.ctx.h, chain, self.h, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def invert(self, scale_to_unity=False, chain=0):
+        self.ctx._chk(self.ctx.lib.dnagpu_invert(self.ctx.h, chain, self.h, int(bool(scale_to_unity))))
+
+
+class DeviceContext:
+    """One dnagpu_ctx.  Raises DnaGpuError on every non-zero return code."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.dnagpu_create(int(device), C.byref(h))
+        if rc != 0:
+            raise DnaGpuError(rc, "dnagpu_create failed (no MI355X visible?)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.dnagpu_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DnaGpuError(rc, self.lib.dnagpu_last_error(self.h).decode())
+
+    def last_info(self):
+        return self.lib.dnagpu_last_info(self.h)
+
+    def sync(self):
+        self._chk(self.lib.dnagpu_sync(self.h))
+
+    # ---- L2 seam ---------------------------------------------------------
+    def cholesky_inverse_packed(self, ap, n, scale_to_unity=False):
+        ap = np.array(ap, dtype=np.float64, copy=True)
+        self._chk(self.lib.dnagpu_cholesky_inverse_packed(self.h, ap.ctypes.data_as(c_f64p), int(n), int(bool(scale_to_unity))))
+        return ap
+
+    def multiply_sym_packed(self, ap, x, n):
+        ap, pa = _f64(ap)
+        x, px = _f64(x)
+        y = np.empty(n, dtype=np.float64)
+        self._chk(self.lib.dnagpu_multiply_sym_packed(self.h, pa, px, y.ctypes.data_as(c_f64p), int(n)))
+        return y
+
+    # ---- profiling ---------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.lib.dnagpu_profile_enable(self.h, int(bool(on))))
+
+    def profile_reset(self):
+        self._chk(self.lib.dnagpu_profile_reset(self.h))
+
+    def profile_get(self):
+        f = C.c_double()
+        ms = C.c_double()
+        n = C.c_uint64()
+        self._chk(self.lib.dnagpu_profile_get(self.h, C.byref(f), C.byref(ms), C.byref(n)))
+        return {"gemm_flops": f.value, "gemm_ms": ms.value, "launches": n.value}
+
+    def matrix(self, n_max):
+        return Matrix(self, n_max)
+
+    # ---- blocks --------------------------------------------------------------
+    def block_create(self, blk, n_stations, n_baselines):
+        self._chk(self.lib.dnagpu_block_create(self.h, blk, int(n_stations), int(n_baselines)))
+
+    def block_destroy(self, blk):
+        self._chk(self.lib.dnagpu_block_destroy(self.h, blk))
+
+    def block_set_stations(self, blk, xyz):
+        xyz, p = _f64(xyz)
+        self._chk(self.lib.dnagpu_block_set_stations(self.h, blk, p))
+
+    def block_set_baselines(self, blk, stn1, stn2, obs, vcv6):
+        s1, p1 = _u32(stn1)
+        s2, p2 = _u32(stn2)
+        o, po = _f64(obs)
+        v, pv = _f64(vcv6)
+        self._chk(self.lib.dnagpu_block_set_baselines(self.h, blk, p1, p2, po, pv))
+
+    def block_get_stations(self, blk, which, n_stations, chain=0):
+        out = np.empty(3 * n_stations, dtype=np.float64)
+        self._chk(self.lib.dnagpu_block_get_stations(self.h, chain, blk, which, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def block_put_stations(self, blk, which, xyz, chain=0):
+        xyz, p = _f64(xyz)
+        self._chk(self.lib.dnagpu_block_put_stations(self.h, chain, blk, which, p))
+
+    def block_copy_stations(self, blk, dst, src, chain=0):
+        self._chk(self.lib.dnagpu_block_copy_stations(self.h, chain, blk, dst, src))
+
+    def block_compute_b(self, blk, chain=0):
+        self._chk(self.lib.dnagpu_block_compute_b(self.h, chain, blk))
+
+    def block_get_b(self, blk, n_baselines, chain=0):
+        out = np.empty(3 * n_baselines, dtype=np.float64)
+        self._chk(self.lib.dnagpu_block_get_b(self.h, chain, blk, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def block_get_weights(self, blk, n_baselines, chain=0):
+        out = np.empty(6 * n_baselines, dtype=np.float64)
+        self._chk(self.lib.dnagpu_block_get_weights(self.h, chain, blk, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def form_normals(self, blk, m, n_stations, chain=0):
+        self._chk(self.lib.dnagpu_form_normals(self.h, chain, blk, m.h))
+        m.n = 3 * int(n_stations)
+
+    def add_diag3x3(self, m, stn, w9, sign=1, chain=0):
+        s, ps = _u32(stn)
+        w, pw = _f64(w9)
+        self._chk(self.lib.dnagpu_add_diag3x3(self.h, chain, m.h, ps, pw, s.size, sign))
+
+    def form_rhs(self, blk, chain=0):
+        self._chk(self.lib.dnagpu_form_rhs(self.h, chain, blk))
+
+    def solve_corrections(self, blk, m, chain=0):
+        self._chk(self.lib.dnagpu_solve_corrections(self.h, chain, blk, m.h))
+
+    def update_estimates(self, blk, chain=0):
+        v = C.c_double()
+        r = C.c_uint32()
+        self._chk(self.lib.dnagpu_update_estimates(self.h, chain, blk, C.byref(v), C.byref(r)))
+        return v.value, r.value
+
+    def block_get_corrections(self, blk, n_stations, chain=0):
+        out = np.empty(3 * n_stations, dtype=np.float64)
+        self._chk(self.lib.dnagpu_block_get_corrections(self.h, chain, blk, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def block_get_rhs(self, blk, n_stations, chain=0):
+        out = np.empty(3 * n_stations, dtype=np.float64)
+        self._chk(self.lib.dnagpu_block_get_rhs(self.h, chain, blk, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def junction_gather(self, blk_from, src, idx_from, jm, chain=0):
+        ix, p = _u32(idx_from)
+        self._chk(self.lib.dnagpu_junction_gather(self.h, chain, blk_from, src.h, p, ix.size, jm.h))
+        jm.n = 3 * ix.size
+
+    def junction_scatter(self, dst, idx_to, jm, chain=0):
+        ix, p = _u32(idx_to)
+        self._chk(self.lib.dnagpu_junction_scatter(self.h, chain, dst.h, p, ix.size, jm.h))
+
+    def junction_rhs(self, blk_to, idx_to, jm, chain=0):
+        ix, p = _u32(idx_to)
+        self._chk(self.lib.dnagpu_junction_rhs(self.h, chain, blk_to, p, ix.size, jm.h))
+
+    def junction_get_estimates(self, jm, chain=0):
+        out = np.empty(jm.n, dtype=np.float64)
+        self._chk(self.lib.dnagpu_junction_get_estimates(self.h, chain, jm.h, out.ctypes.data_as(c_f64p)))
+        return out

@@ -1,0 +1,157 @@
+/*
+ * dnagpu.h -- C-ABI of the MI355X (gfx950) device layer behind DynAdjust's
+ * dna_adjust hot path.  Plain pointers and sizes only; no exceptions cross this
+ * boundary (every call returns 0 or a negative DNAGPU_E* code and leaves a
+ * message in dnagpu_last_error()).
+ *
+ * What each entry point replaces in the reference (paths under
+ * /root/reference/dynadjust/):
+ *
+ *   L2 seam (math::matrix_2d, include/math/dnamatrix_contiguous.{hpp,cpp})
+ *     dnagpu_cholesky_inverse_packed  matrix_2d::cholesky_inverse, packed path   dnamatrix_contiguous.cpp:952-991
+ *                                     (+ Solve()'s scale_normals_to_unity        dnaadjust/dnaadjust.cpp:6614-6645)
+ *     dnagpu_multiply_sym_packed      matrix_2d::multiply_sym (cblas_dspmv)      dnamatrix_contiguous.cpp:1471-1510
+ *
+ *   Block layer (dna_adjust, dynadjust/dnaadjust/dnaadjust.cpp)
+ *     dnagpu_block_create / _set_stations / _set_baselines
+ *                                     PrepareStationandVarianceMatrices :701, PrepareDesignAndMsrMnsCmpMatrices :798,
+ *                                     LoadVarianceMatrix_G :4214 (W = V^-1 per baseline)
+ *     dnagpu_block_compute_b          UpdateDesignMeasMatrices_GX :5283 / AddMsrtoMeasMinusComp :4719
+ *     dnagpu_form_normals             UpdateNormals :1364 / UpdateNormals_G :1664 (3x3 scatter into packed N)
+ *     dnagpu_add_diag3x3              AddConstraintStationstoNormals{Forward,Reverse,Combine,Simultaneous} :1884-2037
+ *     dnagpu_form_rhs                 Solve(): At_Vinv_m = AtVinv * measMinusComp (dense dgemm in the reference) :6659
+ *     dnagpu_invert                   Solve(): FormInverseVarianceMatrix :6628 / :8472
+ *     dnagpu_solve_corrections        Solve(): corrections = N^-1 * At_Vinv_m :6663-6667
+ *     dnagpu_update_estimates         UpdateEstimates{Forward,Reverse,Combine} :3022/:3678/:3718, compute_maximum_value
+ *     dnagpu_junction_gather/_invert/_scatter/_rhs
+ *                                     CarryStnEstimatesandVariances{Forward,Reverse,Combine} :998/:1133/:3196
+ *     dnagpu_download_* / dnagpu_save_rigorous
+ *                                     UpdateEstimatesFinal :3744 (v_rigorousStations_, v_rigorousVariances_)
+ *
+ * Symmetric matrices cross the boundary in the reference's packed-lower
+ * column-major layout: element (i >= j) at j*n - j*(j-1)/2 + (i-j)
+ * (matrix_2d::packed_index, dnamatrix_contiguous.hpp:363).
+ *
+ * Threading: a ctx is bound to one device; calls on one ctx must come from one
+ * host thread at a time.  Work is stream-ordered per "chain" (0 = forward,
+ * 1 = reverse/combine) so the facade can run both chains concurrently.
+ */
+#ifndef DNAGPU_H_
+#define DNAGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dnagpu_ctx dnagpu_ctx;
+
+#define DNAGPU_OK 0
+#define DNAGPU_EINVAL (-1)
+#define DNAGPU_ENOMEM (-2)
+#define DNAGPU_EHIP (-3)
+#define DNAGPU_ENOTPOSDEF (-4) /* dpotrf-style failure; column in dnagpu_last_info() */
+#define DNAGPU_ENODEVICE (-5)
+
+#define DNAGPU_NUM_CHAINS 2
+
+/* ---- context ------------------------------------------------------------ */
+int dnagpu_create(int device, dnagpu_ctx** out);
+void dnagpu_destroy(dnagpu_ctx* ctx);
+const char* dnagpu_last_error(const dnagpu_ctx* ctx);
+int dnagpu_last_info(const dnagpu_ctx* ctx);
+int dnagpu_device_count(void);
+/* wait for every stream of the ctx */
+int dnagpu_sync(dnagpu_ctx* ctx);
+
+/* ---- L2 seam: matrix_2d on host packed storage --------------------------- */
+/* ap (n(n+1)/2 doubles, packed lower) is replaced by its inverse. */
+int dnagpu_cholesky_inverse_packed(dnagpu_ctx* ctx, double* ap, uint32_t n, int scale_to_unity);
+/* y = A x for packed-lower symmetric A. */
+int dnagpu_multiply_sym_packed(dnagpu_ctx* ctx, const double* ap, const double* x, double* y, uint32_t n);
+
+/* ---- profiling ------------------------------------------------------------ */
+/* enable/disable per-launch HIP-event timing of the tile-GEMM kernel */
+int dnagpu_profile_enable(dnagpu_ctx* ctx, int on);
+int dnagpu_profile_reset(dnagpu_ctx* ctx);
+/* gemm_flops: flops actually issued; gemm_ms: summed kernel time; launches */
+int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uint64_t* launches);
+
+/* ---- device-resident work matrices ----------------------------------------
+ * A work matrix is an np x np (np = ceil(n/128)*128) column-major buffer that
+ * holds N, then N^-1.  Each chain owns one; junction matrices get their own. */
+typedef struct dnagpu_matrix dnagpu_matrix;
+int dnagpu_matrix_create(dnagpu_ctx* ctx, uint32_t n_max, dnagpu_matrix** out);
+void dnagpu_matrix_destroy(dnagpu_ctx* ctx, dnagpu_matrix* m);
+/* logical order n (<= n_max) + zero fill + identity padding */
+int dnagpu_matrix_reset(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, uint32_t n);
+int dnagpu_matrix_upload_packed(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* ap, uint32_t n);
+int dnagpu_matrix_download_packed(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap);
+int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dnagpu_matrix* src);
+/* in-place inverse (lower in, both triangles out); checks positive definiteness */
+int dnagpu_invert(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, int scale_to_unity);
+
+/* ---- blocks ---------------------------------------------------------------- */
+/* stations are block-local indices 0..n_stations-1 (ascending global station
+ * index, dnaadjust.cpp:10477-10499); unknowns = 3*n_stations. */
+int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint32_t n_baselines);
+int dnagpu_block_destroy(dnagpu_ctx* ctx, uint32_t blk);
+/* xyz: 3*n_stations; sets original == estimated == rigorous */
+int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz);
+/* stn1/stn2: block-local station of each baseline (CML order); obs: 3 per
+ * baseline (dX,dY,dZ); vcv6: upper triangle per baseline in bms order
+ * (XX, XY, YY, XZ, YZ, ZZ), already v-scaled.  Computes W = V^-1 on device. */
+int dnagpu_block_set_baselines(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
+                               const double* vcv6);
+/* which = 0 original, 1 estimated, 2 rigorous */
+int dnagpu_block_get_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int which, double* xyz);
+int dnagpu_block_put_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int which, const double* xyz);
+/* dst <- src within the block (which codes as above) */
+int dnagpu_block_copy_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int dst_which, int src_which);
+/* b = obs - (x2 - x1) from the estimated coordinates */
+int dnagpu_block_compute_b(dnagpu_ctx* ctx, int chain, uint32_t blk);
+int dnagpu_block_get_b(dnagpu_ctx* ctx, int chain, uint32_t blk, double* b);
+int dnagpu_block_get_weights(dnagpu_ctx* ctx, int chain, uint32_t blk, double* w6);
+
+/* m <- sum_i A_i^T W_i A_i (measurement contributions only, CML order) */
+int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m);
+/* m[3s..3s+2, 3s..3s+2] += sign * w9 (column-major 3x3) for k stations */
+int dnagpu_add_diag3x3(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const uint32_t* stn, const double* w9, size_t k, int sign);
+/* rhs = sum_i A_i^T W_i b_i (real measurements) */
+int dnagpu_form_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk);
+/* corrections = m * rhs  (m holds N^-1) */
+int dnagpu_solve_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* m);
+/* estimated += corrections; returns the correction of largest magnitude (signed) and its row */
+int dnagpu_update_estimates(dnagpu_ctx* ctx, int chain, uint32_t blk, double* max_corr, uint32_t* max_row);
+int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, double* corr);
+int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs);
+
+/* ---- junction carry -------------------------------------------------------- */
+/* A junction set = k stations; idx_from / idx_to are their block-local station
+ * indices in the source and destination block. */
+/* jm (order 3k) <- rows/cols of src (N^-1) at stations idx; jest (3k, device vector
+ * owned by the junction matrix) <- estimated coordinates of those stations */
+int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const dnagpu_matrix* src, const uint32_t* idx_from,
+                           size_t k, dnagpu_matrix* jm);
+/* dst[idx,idx] += jm (3x3 blocks), and rhs_extra of blk_to gets the pseudo
+ * measurement part:  rhs[idx] += jm * (jest - estimated_to[idx])  is applied
+ * by dnagpu_junction_rhs at solve time. */
+int dnagpu_junction_scatter(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const uint32_t* idx_to, size_t k,
+                            const dnagpu_matrix* jm);
+/* rhs(blk_to)[idx] += jm * (jest(jm) - estimated(blk_to)[idx]) */
+int dnagpu_junction_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk_to, const uint32_t* idx_to, size_t k, const dnagpu_matrix* jm);
+/* read / write the junction estimates attached to a junction matrix (3k doubles) */
+int dnagpu_junction_get_estimates(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* jm, double* est);
+int dnagpu_junction_put_estimates(dnagpu_ctx* ctx, int chain, dnagpu_matrix* jm, const double* est, size_t k);
+
+/* ---- stream ordering between chains ---------------------------------------- */
+/* make `waiter` chain wait for everything enqueued so far on `signaller` */
+int dnagpu_chain_wait(dnagpu_ctx* ctx, int waiter, int signaller);
+int dnagpu_chain_sync(dnagpu_ctx* ctx, int chain);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNAGPU_H_ */
