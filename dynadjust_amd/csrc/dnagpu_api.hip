@@ -788,3 +788,69 @@ int dnagpu_junction_put_estimates(dnagpu_ctx* ctx, int chain, dnagpu_matrix* jm,
 }
 
 }  // extern "C"
+
+/* ---- diagnostics ------------------------------------------------------------------
+ * Times `reps` launches of one tile-GEMM variant on scratch data (values irrelevant).
+ * variant: 0 = NT, 1 = NN, 2 = TN.  Returns average ms per launch and the flops of one launch. */
+extern "C" int dnagpu_bench_gemm(dnagpu_ctx* ctx, int variant, int mt, int nt, int K, int kmode, int lower, int reps, double* avg_ms,
+                                 double* flops) {
+    CHK_CTX();
+    if (mt <= 0 || nt <= 0 || K <= 0 || K % 16 || reps <= 0) return fail(ctx, DNAGPU_EINVAL, "bench_gemm: bad arguments");
+    size_t M = (size_t)mt * 128, N = (size_t)nt * 128;
+    size_t ld = std::max(std::max(M, N), (size_t)K);
+    double *A = nullptr, *B = nullptr, *Cc = nullptr;
+    HIPCHK(hipMalloc(&A, ld * ld * sizeof(double)));
+    HIPCHK(hipMalloc(&B, ld * ld * sizeof(double)));
+    HIPCHK(hipMalloc(&Cc, ld * ld * sizeof(double)));
+    // pseudo-random fill (full-range mantissas: zero fill would flatter the clocks)
+    std::vector<double> h(ld * 1024);
+    uint64_t s = 88172645463325252ull;
+    for (auto& v : h) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        v = (double)(int64_t)(s >> 11) / 9007199254740992.0 - 0.5;
+    }
+    for (size_t off = 0; off < ld * ld; off += h.size()) {
+        size_t cnt = std::min(h.size(), ld * ld - off);
+        hipMemcpy(A + off, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+        hipMemcpy(B + off, h.data() + 7, (cnt - 7) * sizeof(double), hipMemcpyHostToDevice);
+    }
+    hipMemset(Cc, 0, ld * ld * sizeof(double));
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = Cc; a.lda = a.ldb = a.ldc = (int)ld;
+    a.mt = mt; a.nt = nt; a.K = K; a.alpha = 1.0; a.beta = 0.0; a.kmode = kmode; a.lower = lower; a.mirror = 0;
+    int akc = variant == 2, bkc = variant >= 1;
+    hipStream_t st = ctx->stream[0];
+    HIPCHK(gemm_attach_order(ctx->ws[0], a));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    launch_gemm(a, akc, bkc, st);
+    hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r) launch_gemm(a, akc, bkc, st);
+    hipEventRecord(e1, st);
+    hipError_t e = hipStreamSynchronize(st);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(A); hipFree(B); hipFree(Cc);
+    if (e != hipSuccess) return fail(ctx, DNAGPU_EHIP, "bench_gemm", e);
+    if (avg_ms) *avg_ms = ms / reps;
+    if (flops) {
+        double f = 0.0;
+        for (int it = 0; it < mt; ++it) {
+            int jmax = lower ? it : nt - 1;
+            for (int jt = 0; jt <= jmax; ++jt) {
+                int kb = 0, ke = K;
+                if (kmode == KM_LE_J) ke = (jt + 1) * 128;
+                if (kmode == KM_GE_J) kb = jt * 128;
+                if (kmode == KM_LE_I) ke = (it + 1) * 128;
+                if (kmode == KM_GE_I) kb = it * 128;
+                if (ke > K) ke = K;
+                if (ke > kb) f += 2.0 * 128 * 128 * (ke - kb);
+            }
+        }
+        *flops = f;
+    }
+    return DNAGPU_OK;
+}

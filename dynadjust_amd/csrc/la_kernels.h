@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace dnagpu {
 
@@ -18,7 +19,13 @@ struct GemmArgs {
     int kmode;   // KMode: restricts the k range per tile (triangular operands)
     int lower;   // 1: only tiles it >= jt (square problems)
     int mirror;  // 1: also store C(j,i) for off-diagonal tiles
+    const uint32_t* order;  // device table: (it << 16 | jt) per workgroup, 0xffffffff = idle
+    int grid;               // number of workgroups (= table length)
 };
+
+// Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
+// Returns the table (length = grid, multiple of 8 when more than 8 tiles).
+std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower);
 
 void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s);

@@ -84,41 +84,14 @@ __device__ __forceinline__ double frag_read(const double* buf, int kk, int rbase
     return buf[(k >> 1) * LDP + r * 2 + (k & 1)];
 }
 
-__device__ __forceinline__ void tile_from_linear(const GemmArgs& a, int& it, int& jt) {
-    // XCD-aware bijective remap: workgroup b runs on XCD b%8; give every XCD a
-    // contiguous chunk of the tile list so neighbouring tiles share an L2.
-    int total = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
-    int b = blockIdx.x;
-    int lin = b;
-    if (total >= 16) {
-        int xcd = b & 7, q = b >> 3;
-        int base = total >> 3, rem = total & 7;
-        int start = xcd * base + (xcd < rem ? xcd : rem);
-        lin = start + q;
-    }
-    if (a.lower) {
-        int r = (int)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
-        while (r * (r + 1) / 2 > lin) --r;
-        while ((r + 1) * (r + 2) / 2 <= lin) ++r;
-        it = r;
-        jt = lin - r * (r + 1) / 2;
-    } else {
-        const int G = 8;
-        int tpg = G * a.nt;
-        int g = lin / tpg;
-        int first = g * G;
-        int gsz = a.mt - first < G ? a.mt - first : G;
-        int w = lin - g * tpg;
-        it = first + w % gsz;
-        jt = w / gsz;
-    }
-}
-
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) double lds[4 * OPBUF];
-    int it, jt;
-    tile_from_linear(a, it, jt);
+    // tile order table built on the host (tile_order.cpp): workgroup b runs on XCD b%8,
+    // every XCD walks its own work-balanced list of 2-D super-tiles (L2 locality).
+    const uint32_t packed = a.order[blockIdx.x];
+    if (packed == 0xffffffffu) return;
+    const int it = (int)(packed >> 16), jt = (int)(packed & 0xffffu);
 
     int kbeg = 0, kend = a.K;
     switch (a.kmode) {
@@ -205,9 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
 }
 
 void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
-    int total = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
-    if (total <= 0) return;
-    dim3 grid(total), block(256);
+    if (a.grid <= 0) return;
+    dim3 grid(a.grid), block(256);
     if (!a_kc && !b_kc)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, s, a);
     else if (!a_kc && b_kc)
@@ -228,16 +200,19 @@ void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
 // ----------------------------------------------------------------------------
 constexpr int LS = 129;
 
-__global__ __launch_bounds__(256) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
+__global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
                                                                int ldx, int o, int* info) {
     __shared__ double S[128 * LS];
+    // pivot column (phase 1) / pivot row (phase 2) lives in its own array so that the
+    // compiler can keep the rank-1 update loops free of LDS read-after-write waits
+    __shared__ double piv[2][128];
     __shared__ double dg[128];
     const int tid = threadIdx.x;
     const int row = tid & 127;
-    const int half = tid >> 7;
+    const int q = tid >> 7;  // 0..3: column residue class owned by this thread
 
     // load lower triangle (coalesced down columns)
-    for (int c = half; c < 128; c += 2) {
+    for (int c = q; c < 128; c += 4) {
         double v = A[(size_t)(o + c) * lda + o + row];
         S[row * LS + c] = (row >= c) ? v : 0.0;
     }
@@ -246,20 +221,25 @@ __global__ __launch_bounds__(256) void leaf_potrf_trtri_kernel(const double* __r
     // Cholesky, right-looking
     for (int k = 0; k < 128; ++k) {
         double d = S[k * LS + k];
-        bool bad = !(d > 0.0);
-        if (bad) {
+        if (!(d > 0.0)) {
             if (tid == 0) atomicMin(info, o + k + 1);
             d = 1.0;
         }
         double r = sqrt(d);
         double inv = 1.0 / r;
-        if (half == 0 && row > k) S[row * LS + k] *= inv;
+        double* pk = piv[k & 1];
+        if (q == 0 && row > k) {
+            double l = S[row * LS + k] * inv;
+            S[row * LS + k] = l;
+            pk[row] = l;
+        }
         if (tid == 0) dg[k] = r;
         __syncthreads();
         if (row > k) {
-            double lik = S[row * LS + k];
-            // columns k+1..row, split between the two halves
-            for (int j = k + 1 + half; j <= row; j += 2) S[row * LS + j] -= lik * S[j * LS + k];
+            const double lik = pk[row];
+            double* srow = S + row * LS;
+#pragma unroll 4
+            for (int j = k + 1 + q; j <= row; j += 4) srow[j] -= lik * pk[j];
         }
         __syncthreads();
     }
@@ -267,26 +247,32 @@ __global__ __launch_bounds__(256) void leaf_potrf_trtri_kernel(const double* __r
     // (Gauss-Jordan on [L | I]): after step k column k of L is dead and is reused
     // for column k of M = L^-1.
     for (int k = 0; k < 128; ++k) {
-        double mkk = 1.0 / dg[k];
-        // scale row k of M (columns < k); M[k][k] = mkk kept in dg
-        if (tid < k) S[k * LS + tid] *= mkk;
-        double lik = (row > k) ? S[row * LS + k] : 0.0;
+        const double mkk = 1.0 / dg[k];
+        double* pk = piv[k & 1];
+        if (tid < k) {  // scale row k of M (columns < k)
+            double v = S[k * LS + tid] * mkk;
+            S[k * LS + tid] = v;
+            pk[tid] = v;
+        }
+        const double lik = (row > k) ? S[row * LS + k] : 0.0;
         __syncthreads();
         if (row > k) {
-            for (int j = half; j < k; j += 2) S[row * LS + j] -= lik * S[k * LS + j];
-            if (half == 0) S[row * LS + k] = -lik * mkk;
+            double* srow = S + row * LS;
+#pragma unroll 4
+            for (int j = q; j < k; j += 4) srow[j] -= lik * pk[j];
+            if (q == 0) srow[k] = -lik * mkk;
         }
         if (tid == 0) dg[k] = mkk;
         __syncthreads();
     }
-    for (int c = half; c < 128; c += 2) {
+    for (int c = q; c < 128; c += 4) {
         double v = (row > c) ? S[row * LS + c] : (row == c ? dg[c] : 0.0);
         X[(size_t)(o + c) * ldx + o + row] = v;
     }
 }
 
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s) {
-    hipLaunchKernelGGL(leaf_potrf_trtri_kernel, dim3(1), dim3(256), 0, s, A, lda, X, ldx, o, info);
+    hipLaunchKernelGGL(leaf_potrf_trtri_kernel, dim3(1), dim3(512), 0, s, A, lda, X, ldx, o, info);
 }
 
 // ----------------------------------------------------------------------------

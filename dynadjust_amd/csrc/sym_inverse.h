@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <map>
+#include <set>
 #include <vector>
 
 namespace dnagpu {
@@ -29,7 +31,14 @@ struct InvWorkspace {
     uint32_t np_cap = 0;
     hipStream_t stream = nullptr;
     GemmProfile prof;
+    // workgroup->tile tables per launch shape (see tile_order.hip), device resident
+    std::map<uint64_t, std::pair<uint32_t*, int>> order_cache;
+    std::set<int> planned;  // matrix orders (in tiles) whose tables are all built
 };
+
+struct GemmArgs;
+// fills a.order / a.grid from the cache (building + uploading the table on first use)
+hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a);
 
 // returns hipSuccess or an error; allocates for matrices up to np_cap (multiple of 128)
 hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t stream);

@@ -24,6 +24,8 @@ void inv_workspace_free(InvWorkspace& ws) {
     if (ws.info) hipFree(ws.info);
     if (ws.info_host) hipHostFree(ws.info_host);
     for (hipEvent_t ev : ws.prof.pool) hipEventDestroy(ev);
+    for (auto& kv : ws.order_cache)
+        if (kv.second.first) hipFree(kv.second.first);
     ws = InvWorkspace();
 }
 
@@ -48,7 +50,29 @@ static double gemm_flops(const GemmArgs& a) {
     return f;
 }
 
-static void gemm(InvWorkspace& ws, const GemmArgs& a, int akc, int bkc) {
+hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a) {
+    uint64_t key = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
+                   ((uint64_t)(a.K / 16) << 40);
+    auto it = ws.order_cache.find(key);
+    if (it == ws.order_cache.end()) {
+        std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower);
+        uint32_t* dev = nullptr;
+        if (!tab.empty()) {
+            hipError_t e = hipMalloc(&dev, tab.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return e;
+            // synchronous copy: the table is immutable afterwards
+            e = hipMemcpy(dev, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return e;
+        }
+        it = ws.order_cache.emplace(key, std::make_pair(dev, (int)tab.size())).first;
+    }
+    a.order = it->second.first;
+    a.grid = it->second.second;
+    return hipSuccess;
+}
+
+void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
+    if (gemm_attach_order(ws, a) != hipSuccess) return;
     GemmProfile& p = ws.prof;
     if (p.enabled) {
         if (p.used + 2 > p.pool.size()) {
@@ -93,14 +117,22 @@ struct Rec {
     InvWorkspace& ws;
     double* F;
     int ld;
+    bool dry;  // planning pass: only build the tile-order tables, launch nothing
 
     double* f(int rt, int ct) { return F + (size_t)ct * 128 * ld + (size_t)rt * 128; }
     double* x(int rt, int ct) { return ws.X + (size_t)ct * 128 * ld + (size_t)rt * 128; }
     double* w(int rt, int ct) { return ws.W + (size_t)ct * 128 * ld + (size_t)rt * 128; }
 
+    void gemm(InvWorkspace& w_, GemmArgs a, int akc, int bkc) {
+        if (dry)
+            gemm_attach_order(w_, a);
+        else
+            dnagpu::gemm(w_, a, akc, bkc);
+    }
+
     void node(int o, int s) {
         if (s == 1) {
-            launch_leaf(F, ld, ws.X, ld, o * 128, ws.info, ws.stream);
+            if (!dry) launch_leaf(F, ld, ws.X, ld, o * 128, ws.info, ws.stream);
             return;
         }
         int h = s / 2;
@@ -141,8 +173,18 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
         launch_diag_rsqrt(F, ws.svec, n, np, ws.stream);
         launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
     }
-    Rec rec{ws, F, (int)np};
     int T = (int)(np / 128);
+    if (!ws.planned.count(T)) {
+        // first inverse of this order: build every tile-order table before the first launch
+        // so that the blocking table uploads never sit between kernels
+        Rec plan{ws, F, (int)np, true};
+        plan.node(0, T);
+        GemmArgs l;
+        l.mt = T; l.nt = T; l.K = (int)np; l.kmode = KM_GE_I; l.lower = 1;
+        gemm_attach_order(ws, l);
+        ws.planned.insert(T);
+    }
+    Rec rec{ws, F, (int)np, false};
     rec.node(0, T);
     // Ninv = X^T X  (lauum), both triangles
     GemmArgs a;
@@ -151,7 +193,7 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
     a.C = F; a.ldc = (int)np;
     a.mt = T; a.nt = T; a.K = (int)np;
     a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
-    gemm(ws, a, 1, 1);
+    dnagpu::gemm(ws, a, 1, 1);
     if (scale_to_unity) launch_scale_sym(F, ws.svec, n, np, 0, ws.stream);
     hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, ws.stream);
 }

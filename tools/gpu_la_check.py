@@ -48,7 +48,17 @@ for n in [4096, 8192, 16384, 30000]:
         M = spd(n, rng)
         m.upload_packed(pack_lower(M), n)
     else:
-        ctx.add_diag3x3(m, np.arange(n // 3, dtype=np.uint32), np.tile(np.array([4.0, 1, .5, 1, 5, .25, .5, .25, 6]), n // 3))
+        ns = n // 3
+        ctx.add_diag3x3(m, np.arange(ns, dtype=np.uint32), np.tile(np.array([4.0, 1, .5, 1, 5, .25, .5, .25, 6]), ns))
+        if n - 3 * ns:
+            m.reset(3 * ns)
+            ctx.add_diag3x3(m, np.arange(ns, dtype=np.uint32), np.tile(np.array([4.0, 1, .5, 1, 5, .25, .5, .25, 6]), ns))
+            n = 3 * ns
+    ctx.sync()
+    if n > 8192:
+        keep = ctx.matrix(n); ctx.lib.dnagpu_matrix_copy(ctx.h, 0, keep.h, m.h)
+        m.invert()   # warm-up (plans, clocks)
+        ctx.lib.dnagpu_matrix_copy(ctx.h, 0, m.h, keep.h); keep.close()
     ctx.sync()
     ctx.profile_reset()
     t0 = time.perf_counter()
