@@ -26,6 +26,24 @@ DNAGPU_ENODEVICE = -5
 
 _lib = None
 
+
+class DnaAdjSettings(C.Structure):
+    """dnaadj_settings (include/dnaadjust_c.h)"""
+    _fields_ = [("bst_file", C.c_char_p), ("bms_file", C.c_char_p), ("asl_file", C.c_char_p), ("seg_file", C.c_char_p),
+                ("adjust_mode", C.c_int), ("multi_thread", C.c_int), ("max_iterations", C.c_int),
+                ("iteration_threshold", C.c_float), ("free_std_dev", C.c_double), ("fixed_std_dev", C.c_double),
+                ("scale_normals_to_unity", C.c_int), ("device", C.c_int)]
+
+
+class DnaSynthSpec(C.Structure):
+    _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("n_baselines", C.c_uint64), ("n_blocks", C.c_uint32),
+                ("seed", C.c_uint64), ("initial_sigma", C.c_double)]
+
+
+class DnaSynthSummary(C.Structure):
+    _fields_ = [("stations", C.c_uint64), ("baselines", C.c_uint64), ("measurement_rows", C.c_uint64), ("blocks", C.c_uint64),
+                ("max_block_unknowns", C.c_uint64)]
+
 c_u32p = C.POINTER(C.c_uint32)
 c_f64p = C.POINTER(C.c_double)
 
@@ -93,6 +111,36 @@ def load():
     _sig(lib, "dnagpu_junction_put_estimates", i, [vp, i, vp, c_f64p, sz])
     _sig(lib, "dnagpu_chain_wait", i, [vp, i, i])
     _sig(lib, "dnagpu_chain_sync", i, [vp, i])
+    # ---- include/dnaadjust_c.h ------------------------------------------------
+    u64 = C.c_uint64
+    _sig(lib, "dnaadj_default_settings", None, [C.POINTER(DnaAdjSettings)])
+    _sig(lib, "dnaadj_create", i, [C.POINTER(vp)])
+    _sig(lib, "dnaadj_destroy", None, [vp])
+    _sig(lib, "dnaadj_last_error", C.c_char_p, [vp])
+    _sig(lib, "dnaadj_prepare", i, [vp, C.POINTER(DnaAdjSettings)])
+    _sig(lib, "dnaadj_adjust", i, [vp, C.POINTER(i)])
+    _sig(lib, "dnaadj_cancel", i, [vp])
+    _sig(lib, "dnaadj_block_count", u32, [vp])
+    _sig(lib, "dnaadj_iterations", u32, [vp])
+    _sig(lib, "dnaadj_max_correction", C.c_double, [vp])
+    _sig(lib, "dnaadj_iteration_correction", C.c_double, [vp, u32])
+    _sig(lib, "dnaadj_measurement_count", u32, [vp])
+    _sig(lib, "dnaadj_unknowns_count", u32, [vp])
+    _sig(lib, "dnaadj_degrees_of_freedom", i, [vp])
+    _sig(lib, "dnaadj_adjust_time_ms", C.c_double, [vp])
+    _sig(lib, "dnaadj_solve_flops", C.c_double, [vp])
+    _sig(lib, "dnaadj_solve_count", u32, [vp])
+    _sig(lib, "dnaadj_station_count", u32, [vp])
+    _sig(lib, "dnaadj_block_station_count", u32, [vp, u32])
+    _sig(lib, "dnaadj_block_stations", i, [vp, u32, c_u32p])
+    _sig(lib, "dnaadj_block_estimates", i, [vp, u32, c_f64p])
+    _sig(lib, "dnaadj_block_variances_packed", i, [vp, u32, c_f64p])
+    _sig(lib, "dnaadj_adjusted_coordinates", i, [vp, c_f64p])
+    _sig(lib, "dnaadj_device_context", vp, [vp])
+    _sig(lib, "dnasynth_write_network", i, [C.c_char_p, C.c_char_p, C.POINTER(DnaSynthSpec), C.POINTER(DnaSynthSummary), C.c_char_p, sz])
+    _sig(lib, "dnaio_file_summary", i, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_char_p, sz])
+    _sig(lib, "dnaio_sizeof_station", sz, [])
+    _sig(lib, "dnaio_sizeof_measurement", sz, [])
     _lib = lib
     return lib
 
@@ -108,4 +156,13 @@ EXPORTED_DNAGPU = [
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
     "dnagpu_junction_gather", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
+]
+
+EXPORTED_DNAADJ = [
+    "dnaadj_default_settings", "dnaadj_create", "dnaadj_destroy", "dnaadj_last_error", "dnaadj_prepare", "dnaadj_adjust",
+    "dnaadj_cancel", "dnaadj_block_count", "dnaadj_iterations", "dnaadj_max_correction", "dnaadj_iteration_correction",
+    "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
+    "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
+    "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
+    "dnasynth_write_network", "dnaio_file_summary", "dnaio_sizeof_station", "dnaio_sizeof_measurement",
 ]

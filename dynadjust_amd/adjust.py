@@ -1,0 +1,177 @@
+"""Python mirror of the reference's dna_adjust interface (dnaadjust.hpp:259-405) over the
+C-ABI of include/dnaadjust_c.h.  Method names, argument meaning and error behaviour follow
+the reference: PrepareAdjustment(project_settings) -> AdjustNetwork() -> getters; failures
+raise NetAdjustException with the reference's message text.  The work itself runs in the
+HIP library; this module contains no numerical code and no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import DnaAdjSettings, DnaSynthSpec, DnaSynthSummary, c_f64p, c_u32p
+
+SimultaneousMode = 0
+PhasedMode = 1
+
+ADJUST_SUCCESS = 0
+ADJUST_MAX_ITERATIONS_EXCEEDED = 1
+ADJUST_THRESHOLD_EXCEEDED = 2
+ADJUST_TEST_FAILED = 3
+ADJUST_BLOCK_ERROR = 4
+ADJUST_EXCEPTION_RAISED = 5
+ADJUST_CANCELLED = 6
+
+
+class NetAdjustException(RuntimeError):
+    """std::runtime_error thrown by dna_adjust::SignalExceptionAdjustment (dnaadjust.cpp:10049)."""
+
+
+class ProjectSettings:
+    """The members of project_settings (include/config/dnaoptions.hpp) the adjustment path reads."""
+
+    def __init__(self, network_name=None, folder=".", adjust_mode=SimultaneousMode, multi_thread=False,
+                 max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
+                 scale_normals_to_unity=False, device=0):
+        self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
+        if network_name is not None:
+            self.set_filenames(os.path.join(folder, network_name))
+        self.adjust_mode = adjust_mode
+        self.multi_thread = multi_thread
+        self.max_iterations = max_iterations
+        self.iteration_threshold = iteration_threshold
+        self.free_std_dev = free_std_dev
+        self.fixed_std_dev = fixed_std_dev
+        self.scale_normals_to_unity = scale_normals_to_unity
+        self.device = device
+
+    def set_filenames(self, base):
+        """adjust_settings::setFilenames (dnaoptions.hpp:455-460) + s.asl_file"""
+        self.bst_file = base + ".bst"
+        self.bms_file = base + ".bms"
+        self.seg_file = base + ".seg"
+        self.asl_file = base + ".asl"
+
+
+def _b(s):
+    return None if s is None else os.fsencode(s)
+
+
+class DnaAdjust:
+    def __init__(self):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        if self.lib.dnaadj_create(C.byref(h)) != 0:
+            raise NetAdjustException("dnaadj_create failed")
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.lib.dnaadj_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NetAdjustException(self.lib.dnaadj_last_error(self.h).decode(errors="replace"))
+
+    # ---- reference interface -------------------------------------------------
+    def PrepareAdjustment(self, p):
+        s = DnaAdjSettings()
+        self.lib.dnaadj_default_settings(C.byref(s))
+        self._keep = [_b(p.bst_file), _b(p.bms_file), _b(p.asl_file), _b(p.seg_file)]
+        s.bst_file, s.bms_file, s.asl_file, s.seg_file = self._keep
+        s.adjust_mode = int(p.adjust_mode)
+        s.multi_thread = int(bool(p.multi_thread))
+        s.max_iterations = int(p.max_iterations)
+        s.iteration_threshold = float(p.iteration_threshold)
+        s.free_std_dev = float(p.free_std_dev)
+        s.fixed_std_dev = float(p.fixed_std_dev)
+        s.scale_normals_to_unity = int(bool(p.scale_normals_to_unity))
+        s.device = int(p.device)
+        self._chk(self.lib.dnaadj_prepare(self.h, C.byref(s)))
+
+    def AdjustNetwork(self):
+        st = C.c_int()
+        self._chk(self.lib.dnaadj_adjust(self.h, C.byref(st)))
+        return st.value
+
+    def CancelAdjustment(self):
+        self._chk(self.lib.dnaadj_cancel(self.h))
+
+    def blockCount(self):
+        return self.lib.dnaadj_block_count(self.h)
+
+    def CurrentIteration(self):
+        return self.lib.dnaadj_iterations(self.h)
+
+    def GetMaxCorrection(self):
+        return self.lib.dnaadj_max_correction(self.h)
+
+    def GetIterationCorrection(self, it):
+        return self.lib.dnaadj_iteration_correction(self.h, it)
+
+    def GetMeasurementCount(self):
+        return self.lib.dnaadj_measurement_count(self.h)
+
+    def GetUnknownsCount(self):
+        return self.lib.dnaadj_unknowns_count(self.h)
+
+    def GetDegreesOfFreedom(self):
+        return self.lib.dnaadj_degrees_of_freedom(self.h)
+
+    def adjustTime(self):
+        """milliseconds spent inside AdjustNetwork()"""
+        return self.lib.dnaadj_adjust_time_ms(self.h)
+
+    # ---- results ---------------------------------------------------------------
+    def block_stations(self, block):
+        n = self.lib.dnaadj_block_station_count(self.h, block)
+        out = np.empty(n, dtype=np.uint32)
+        self._chk(self.lib.dnaadj_block_stations(self.h, block, out.ctypes.data_as(c_u32p)))
+        return out
+
+    def block_estimates(self, block):
+        n = self.lib.dnaadj_block_station_count(self.h, block)
+        out = np.empty(3 * n, dtype=np.float64)
+        self._chk(self.lib.dnaadj_block_estimates(self.h, block, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def block_variances_packed(self, block):
+        n = 3 * self.lib.dnaadj_block_station_count(self.h, block)
+        out = np.empty(n * (n + 1) // 2, dtype=np.float64)
+        self._chk(self.lib.dnaadj_block_variances_packed(self.h, block, out.ctypes.data_as(c_f64p)))
+        return out
+
+    def adjusted_coordinates(self, n_stations):
+        out = np.empty(3 * n_stations, dtype=np.float64)
+        self._chk(self.lib.dnaadj_adjusted_coordinates(self.h, out.ctypes.data_as(c_f64p)))
+        return out.reshape(-1, 3)
+
+    # ---- measurement -------------------------------------------------------------
+    def solve_flops(self):
+        return self.lib.dnaadj_solve_flops(self.h)
+
+    def solve_count(self):
+        return self.lib.dnaadj_solve_count(self.h)
+
+    def device_context(self):
+        return self.lib.dnaadj_device_context(self.h)
+
+
+def write_synthetic_network(folder, name, rows, cols, n_baselines=0, n_blocks=1, seed=20260928, initial_sigma=0.05):
+    """writes <folder>/<name>.{bst,bms,asl,seg,truth}; returns the summary dict."""
+    lib = _lib.load()
+    spec = DnaSynthSpec(rows, cols, n_baselines, n_blocks, seed, initial_sigma)
+    out = DnaSynthSummary()
+    err = C.create_string_buffer(512)
+    rc = lib.dnasynth_write_network(os.fsencode(folder), os.fsencode(name), C.byref(spec), C.byref(out), err, 512)
+    if rc != 0:
+        raise RuntimeError("dnasynth_write_network: " + err.value.decode(errors="replace"))
+    return {k: getattr(out, k) for k, _ in DnaSynthSummary._fields_}

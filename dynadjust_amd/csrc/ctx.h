@@ -20,13 +20,18 @@ namespace dnagpu {
 struct Block {
     uint32_t n_stn = 0, n_bl = 0;
     // stations (3*n_stn)
-    double *x_orig = nullptr, *x_est = nullptr, *x_rig = nullptr;
-    double *rhs = nullptr, *corr = nullptr;
+    // "estimated" state exists once per chain (the reference's v_*_ / v_*R_ twins,
+    // dnaadjust.hpp:1340-1348) so that the forward and the reverse/combine chain can
+    // work on the same block concurrently
+    double *x_orig = nullptr, *x_rig = nullptr;
+    double *x_est[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    double *rhs[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    double *corr[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
     // baselines, SoA
     uint32_t *s1 = nullptr, *s2 = nullptr;
     double *obs = nullptr;  // 3*n_bl
     double *W = nullptr;    // 6*n_bl  (xx, xy, yy, xz, yz, zz) of V^-1
-    double *b = nullptr;    // 3*n_bl
+    double *b[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};  // 3*n_bl, measured - computed
     // deterministic formation structure: station-pair blocks (row >= col), each
     // with the CML-ordered list of contributing baselines
     uint32_t n_pairs = 0;
@@ -34,8 +39,8 @@ struct Block {
     uint32_t *pair_bl = nullptr;  // baseline index per contribution
     // per-station incidence (CML order) for the rhs: entry = baseline*2 + (1 if station is stn2)
     uint32_t *inc_off = nullptr, *inc = nullptr;
-    // scratch for max-correction reduction
-    double* red = nullptr;
+    // scratch for max-correction reduction (value, index) per chain
+    double* red[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
 };
 
 }  // namespace dnagpu

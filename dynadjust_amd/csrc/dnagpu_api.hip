@@ -124,17 +124,17 @@ Block* find_block(dnagpu_ctx* ctx, uint32_t blk) {
 }
 
 void free_block(Block& b) {
-    void* ptrs[] = {b.x_orig, b.x_est, b.x_rig, b.rhs, b.corr, b.s1, b.s2, b.obs, b.W, b.b, b.pair_row, b.pair_col,
-                    b.pair_off, b.pair_bl, b.inc_off, b.inc, b.red};
+    void* ptrs[] = {b.x_orig, b.x_est[0], b.x_est[1], b.x_rig, b.rhs[0], b.rhs[1], b.corr[0], b.corr[1], b.s1, b.s2, b.obs, b.W,
+                    b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_bl, b.inc_off, b.inc, b.red[0], b.red[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     b = Block();
 }
 
-double* station_vec(Block& b, int which) {
+double* station_vec(Block& b, int which, int chain) {
     switch (which) {
         case 0: return b.x_orig;
-        case 1: return b.x_est;
+        case 1: return b.x_est[chain];
         case 2: return b.x_rig;
         default: return nullptr;
     }
@@ -431,22 +431,26 @@ int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint
         if (e == hipSuccess) e = hipMalloc(p, bytes);
     };
     A((void**)&b.x_orig, nv);
-    A((void**)&b.x_est, nv);
     A((void**)&b.x_rig, nv);
-    A((void**)&b.rhs, nv);
-    A((void**)&b.corr, nv);
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        A((void**)&b.x_est[c], nv);
+        A((void**)&b.rhs[c], nv);
+        A((void**)&b.corr[c], nv);
+        A((void**)&b.b[c], nb * 3 * sizeof(double));
+        A((void**)&b.red[c], 2 * sizeof(double));
+    }
     A((void**)&b.s1, nb * sizeof(uint32_t));
     A((void**)&b.s2, nb * sizeof(uint32_t));
     A((void**)&b.obs, nb * 3 * sizeof(double));
     A((void**)&b.W, nb * 6 * sizeof(double));
-    A((void**)&b.b, nb * 3 * sizeof(double));
-    A((void**)&b.red, 2 * sizeof(double));
     if (e != hipSuccess) {
         free_block(b);
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "block allocation", e);
     }
-    hipMemset(b.rhs, 0, nv);
-    hipMemset(b.corr, 0, nv);
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        hipMemset(b.rhs[c], 0, nv);
+        hipMemset(b.corr[c], 0, nv);
+    }
     ctx->blocks[blk] = b;
     return DNAGPU_OK;
 }
@@ -468,7 +472,7 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz) 
     size_t bytes = 3 * (size_t)b->n_stn * sizeof(double);
     if (!bytes) return DNAGPU_OK;
     HIPCHK(hipMemcpy(b->x_orig, xyz, bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->x_est, xyz, bytes, hipMemcpyHostToDevice));
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) HIPCHK(hipMemcpy(b->x_est[c], xyz, bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->x_rig, xyz, bytes, hipMemcpyHostToDevice));
     return DNAGPU_OK;
 }
@@ -575,9 +579,9 @@ int dnagpu_block_get_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int whic
     CHK_CTX();
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
-    if (!b || !station_vec(*b, which) || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_stations: bad arguments");
+    if (!b || !station_vec(*b, which, chain) || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_stations: bad arguments");
     if (!b->n_stn) return DNAGPU_OK;
-    HIPCHK(hipMemcpyAsync(xyz, station_vec(*b, which), 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
+    HIPCHK(hipMemcpyAsync(xyz, station_vec(*b, which, chain), 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
     HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
     return DNAGPU_OK;
 }
@@ -586,9 +590,9 @@ int dnagpu_block_put_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int whic
     CHK_CTX();
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
-    if (!b || !station_vec(*b, which) || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_put_stations: bad arguments");
+    if (!b || !station_vec(*b, which, chain) || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_put_stations: bad arguments");
     if (!b->n_stn) return DNAGPU_OK;
-    HIPCHK(hipMemcpyAsync(station_vec(*b, which), xyz, 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
+    HIPCHK(hipMemcpyAsync(station_vec(*b, which, chain), xyz, 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
     HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
     return DNAGPU_OK;
 }
@@ -597,10 +601,10 @@ int dnagpu_block_copy_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int dst
     CHK_CTX();
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
-    if (!b || !station_vec(*b, dst_which) || !station_vec(*b, src_which))
+    if (!b || !station_vec(*b, dst_which, chain) || !station_vec(*b, src_which, chain))
         return fail(ctx, DNAGPU_EINVAL, "block_copy_stations: bad arguments");
     if (!b->n_stn || dst_which == src_which) return DNAGPU_OK;
-    HIPCHK(hipMemcpyAsync(station_vec(*b, dst_which), station_vec(*b, src_which), 3 * (size_t)b->n_stn * sizeof(double),
+    HIPCHK(hipMemcpyAsync(station_vec(*b, dst_which, chain), station_vec(*b, src_which, chain), 3 * (size_t)b->n_stn * sizeof(double),
                           hipMemcpyDeviceToDevice, ctx->stream[chain]));
     return DNAGPU_OK;
 }
@@ -610,7 +614,7 @@ int dnagpu_block_compute_b(dnagpu_ctx* ctx, int chain, uint32_t blk) {
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b) return fail(ctx, DNAGPU_EINVAL, "block_compute_b: unknown block");
-    launch_compute_b(b->s1, b->s2, b->obs, b->x_est, b->b, b->n_bl, ctx->stream[chain]);
+    launch_compute_b(b->s1, b->s2, b->obs, b->x_est[chain], b->b[chain], b->n_bl, ctx->stream[chain]);
     return DNAGPU_OK;
 }
 
@@ -626,7 +630,7 @@ int dnagpu_block_get_b(dnagpu_ctx* ctx, int chain, uint32_t blk, double* out) {
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b || (!out && b->n_bl)) return fail(ctx, DNAGPU_EINVAL, "block_get_b: bad arguments");
-    return d2h(ctx, chain, out, b->b, (size_t)b->n_bl * 3 * sizeof(double));
+    return d2h(ctx, chain, out, b->b[chain], (size_t)b->n_bl * 3 * sizeof(double));
 }
 
 int dnagpu_block_get_weights(dnagpu_ctx* ctx, int chain, uint32_t blk, double* w6) {
@@ -642,7 +646,7 @@ int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, doubl
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b || (!corr && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_corrections: bad arguments");
-    return d2h(ctx, chain, corr, b->corr, (size_t)b->n_stn * 3 * sizeof(double));
+    return d2h(ctx, chain, corr, b->corr[chain], (size_t)b->n_stn * 3 * sizeof(double));
 }
 
 int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs) {
@@ -650,7 +654,7 @@ int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs) 
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b || (!rhs && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_rhs: bad arguments");
-    return d2h(ctx, chain, rhs, b->rhs, (size_t)b->n_stn * 3 * sizeof(double));
+    return d2h(ctx, chain, rhs, b->rhs[chain], (size_t)b->n_stn * 3 * sizeof(double));
 }
 
 int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m) {
@@ -686,7 +690,7 @@ int dnagpu_form_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk) {
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b) return fail(ctx, DNAGPU_EINVAL, "form_rhs: unknown block");
-    launch_form_rhs(b->inc_off, b->inc, b->W, b->b, b->rhs, b->n_stn, ctx->stream[chain]);
+    launch_form_rhs(b->inc_off, b->inc, b->W, b->b[chain], b->rhs[chain], b->n_stn, ctx->stream[chain]);
     return DNAGPU_OK;
 }
 
@@ -698,7 +702,7 @@ int dnagpu_solve_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, const dna
     if (!m->n) return DNAGPU_OK;
     int rc = ensure_symv(ctx, chain, m->np);
     if (rc) return rc;
-    launch_symv(m->F, b->rhs, b->corr, ctx->symv_part[chain], m->n, m->np, SYMV_CHUNKS, ctx->stream[chain]);
+    launch_symv(m->F, b->rhs[chain], b->corr[chain], ctx->symv_part[chain], m->n, m->np, SYMV_CHUNKS, ctx->stream[chain]);
     return DNAGPU_OK;
 }
 
@@ -708,9 +712,9 @@ int dnagpu_update_estimates(dnagpu_ctx* ctx, int chain, uint32_t blk, double* ma
     Block* b = find_block(ctx, blk);
     if (!b) return fail(ctx, DNAGPU_EINVAL, "update_estimates: unknown block");
     uint32_t n = 3 * b->n_stn;
-    double* dval = b->red;
-    uint32_t* didx = reinterpret_cast<uint32_t*>(b->red + 1);
-    launch_update_estimates(b->x_est, b->corr, n, dval, didx, ctx->stream[chain]);
+    double* dval = b->red[chain];
+    uint32_t* didx = reinterpret_cast<uint32_t*>(b->red[chain] + 1);
+    launch_update_estimates(b->x_est[chain], b->corr[chain], n, dval, didx, ctx->stream[chain]);
     HIPCHK(hipMemcpyAsync(ctx->red_val_host[chain], dval, sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
     HIPCHK(hipMemcpyAsync(ctx->red_idx_host[chain], didx, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream[chain]));
     HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
@@ -737,7 +741,7 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
     int rc = stage_u32(ctx, chain, idx_from, k, &didx);
     if (rc) return rc;
     launch_junction_gather(src->F, src->np, didx, (uint32_t)k, jm->F, jm->np, ctx->stream[chain]);
-    launch_gather_vec3(b->x_est, didx, (uint32_t)k, jm->jest, ctx->stream[chain]);
+    launch_gather_vec3(b->x_est[chain], didx, (uint32_t)k, jm->jest, ctx->stream[chain]);
     return DNAGPU_OK;
 }
 
@@ -766,7 +770,7 @@ int dnagpu_junction_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk_to, const uint3
     uint32_t* didx = nullptr;
     int rc = stage_u32(ctx, chain, idx_to, k, &didx);
     if (rc) return rc;
-    launch_junction_rhs(b->rhs, b->x_est, didx, (uint32_t)k, jm->F, jm->np, jm->jest, ctx->stream[chain]);
+    launch_junction_rhs(b->rhs[chain], b->x_est[chain], didx, (uint32_t)k, jm->F, jm->np, jm->jest, ctx->stream[chain]);
     return DNAGPU_OK;
 }
 

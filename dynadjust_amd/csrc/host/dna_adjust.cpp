@@ -1,0 +1,666 @@
+#include "dna_adjust.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <sstream>
+
+#include "geodesy.hpp"
+
+namespace dynadjust {
+namespace networkadjust {
+
+namespace {
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+constexpr double PRECISION_1E5 = 1.0e-5;
+}  // namespace
+
+dna_adjust::dna_adjust() {}
+
+dna_adjust::~dna_adjust() { FreeDevice(); }
+
+void dna_adjust::FreeDevice() {
+    if (!ctx_) return;
+    for (block_t& b : blocks_) {
+        if (b.jfwd) dnagpu_matrix_destroy(ctx_, b.jfwd);
+        if (b.jrev) dnagpu_matrix_destroy(ctx_, b.jrev);
+        if (b.rigvar) dnagpu_matrix_destroy(ctx_, b.rigvar);
+        b.jfwd = b.jrev = b.rigvar = nullptr;
+    }
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        if (work_[c]) dnagpu_matrix_destroy(ctx_, work_[c]);
+        work_[c] = nullptr;
+    }
+    dnagpu_destroy(ctx_);
+    ctx_ = nullptr;
+}
+
+// ADJ:10049-10069
+void dna_adjust::SignalExceptionAdjustment(const std::string& msg, UINT32 block_no) {
+    adjustStatus_ = ADJUST_EXCEPTION_RAISED;
+    exceptionRaised_ = true;
+    isPreparing_ = false;
+    isCombining_ = false;
+    isAdjusting_ = false;
+    std::string error_msg(msg);
+    switch (projectSettings_.a.adjust_mode) {
+        case Phased_Block_1Mode:
+        case PhasedMode: {
+            std::stringstream ss;
+            ss << msg << std::endl << "  Phased adjustment terminated whilst processing block " << block_no + 1 << std::endl;
+            error_msg = ss.str();
+        }
+    }
+    throw NetAdjustException(error_msg, block_no);
+}
+
+void dna_adjust::Check(int rc, UINT32 block, const char* where) {
+    if (rc == DNAGPU_OK) return;
+    std::string msg = ctx_ ? dnagpu_last_error(ctx_) : "device context unavailable";
+    if (rc == DNAGPU_ENOTPOSDEF)
+        // matrix_2d::cholesky_inverse -> MatrixInversionFailure (dnamatrix_contiguous.cpp:983) -> SolveTry (ADJ:6575-6582)
+        SignalExceptionAdjustment("Matrix inversion failed, the matrix is singular.", block);
+    std::stringstream ss;
+    ss << where << ": device error " << rc << " (" << msg << ")";
+    SignalExceptionAdjustment(ss.str(), block);
+}
+
+UINT32 dna_adjust::LocalIndex(UINT32 block, UINT32 stn) const {
+    const std::vector<UINT32>& l = v_parameterStationList_[block];
+    auto it = std::lower_bound(l.begin(), l.end(), stn);
+    if (it == l.end() || *it != stn) {
+        std::stringstream ss;
+        ss << "Station " << stn << " is not a parameter station of block " << block + 1 << ".";
+        throw std::runtime_error(ss.str());
+    }
+    return (UINT32)(it - l.begin());
+}
+
+// ADJ:10107 LoadNetworkFiles (+ NetworkDataLoader): bst, asl, bms
+void dna_adjust::LoadNetworkFiles() {
+    iostreams::read_bst(projectSettings_.a.bst_file, bstBinaryRecords_, bst_meta_);
+    iostreams::read_bms(projectSettings_.a.bms_file, bmsBinaryRecords_, bms_meta_);
+    if (!projectSettings_.s.asl_file.empty())
+        iostreams::read_asl(projectSettings_.s.asl_file, vAssocStnList_);
+    else
+        vAssocStnList_.assign(bstBinaryRecords_.size(), asl_entry_t());
+    if (vAssocStnList_.size() != bstBinaryRecords_.size())
+        throw std::runtime_error("LoadNetworkFiles(): the associated station list does not match the binary station file.");
+}
+
+// simultaneous mode: network_data_loader.cpp:103-134, measurement_processor.cpp:47-164
+void dna_adjust::BuildSimultaneousLists() {
+    blockCount_ = 1;
+    v_ISL_.assign(1, {});
+    v_JSL_.assign(1, {});
+    v_CML_.assign(1, {});
+    for (UINT32 s = 0; s < bstBinaryRecords_.size(); ++s)
+        if (vAssocStnList_[s].validity) v_ISL_[0].push_back(s);
+    UINT32 rows = 0;
+    for (UINT32 m = 0; m < bmsBinaryRecords_.size(); ++m) {
+        const measurement_t& r = bmsBinaryRecords_[m];
+        if (r.ignore) continue;
+        if (r.measStart != 0) continue;   // Y, Z and covariance rows are not measurement starts
+        v_CML_[0].push_back(m);
+        if (r.measType == 'G') rows += 3;
+    }
+    v_ContiguousNetList_.assign(1, 0);
+    v_measurementCount_.assign(1, rows);
+    v_unknownsCount_.assign(1, (UINT32)v_ISL_[0].size() * 3);
+    v_parameterStationCount_.assign(1, (UINT32)v_ISL_[0].size());
+}
+
+// ADJ:10426-10626
+void dna_adjust::LoadSegmentationMetrics() {
+    v_blockMeta_.assign(blockCount_, blockMeta_t());
+    v_parameterStationList_.assign(blockCount_, {});
+    UINT32 netID = 999999;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        v_blockMeta_[b]._blockFirst = (netID != v_ContiguousNetList_[b]);
+        netID = v_ContiguousNetList_[b];
+        if (b < blockCount_ - 1)
+            v_blockMeta_[b]._blockLast = (v_ContiguousNetList_[b] != v_ContiguousNetList_[b + 1]);
+        else
+            v_blockMeta_[b]._blockLast = true;
+        if (v_blockMeta_[b]._blockFirst && v_blockMeta_[b]._blockLast)
+            v_blockMeta_[b]._blockIsolated = true;
+        else if (!v_blockMeta_[b]._blockFirst && !v_blockMeta_[b]._blockLast)
+            v_blockMeta_[b]._blockIntermediate = true;
+        std::vector<UINT32>& p = v_parameterStationList_[b];
+        p = v_ISL_[b];
+        p.insert(p.end(), v_JSL_[b].begin(), v_JSL_[b].end());
+        std::sort(p.begin(), p.end());
+        if (std::adjacent_find(p.begin(), p.end()) != p.end())
+            throw std::runtime_error("LoadSegmentationMetrics(): a station is listed twice in one block.");
+        for (UINT32 s : p)
+            if (s >= bstBinaryRecords_.size()) throw std::runtime_error("LoadSegmentationMetrics(): station index out of range.");
+    }
+    // total unknown parameters over unique stations (ADJ:10559-10578)
+    std::vector<UINT32> all;
+    for (auto& p : v_parameterStationList_) all.insert(all.end(), p.begin(), p.end());
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    unknownsCount_ = (UINT32)all.size() * 3;
+    unknownParams_ = unknownsCount_;
+    for (UINT32 s : all)
+        for (int c = 0; c < 3; ++c)
+            if (bstBinaryRecords_[s].stationConst[c] == 'C') unknownParams_--;
+    allStationsFixed_ = (unknownParams_ == 0 && unknownsCount_ > 0);
+    measurementParams_ = 0;
+    for (UINT32 b = 0; b < blockCount_; ++b) measurementParams_ += v_measurementCount_[b];
+}
+
+// SegFile::CreateStnAppearanceList, seg_file.cpp:432-487 (simultaneous: BuildSimultaneousStnAppearance ADJ:1834)
+void dna_adjust::CreateStnAppearanceList() {
+    v_paramStnAppearance_.assign(blockCount_, {});
+    std::vector<char> free_fwd(bstBinaryRecords_.size(), 1), free_rev;
+    for (size_t s = 0; s < free_fwd.size(); ++s)
+        if (!vAssocStnList_[s].validity) free_fwd[s] = 0;
+    free_rev = free_fwd;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        v_paramStnAppearance_[b].resize(v_parameterStationList_[b].size());
+        for (size_t p = 0; p < v_parameterStationList_[b].size(); ++p) {
+            stn_appear& a = v_paramStnAppearance_[b][p];
+            a.station_id = v_parameterStationList_[b][p];
+            if (free_fwd[a.station_id]) {
+                a.first_appearance_fwd = true;
+                free_fwd[a.station_id] = 0;
+            }
+        }
+    }
+    for (UINT32 bb = blockCount_; bb-- > 0;)
+        for (stn_appear& a : v_paramStnAppearance_[bb])
+            if (free_rev[a.station_id]) {
+                a.first_appearance_rev = true;
+                free_rev[a.station_id] = 0;
+            }
+}
+
+// ADJ:2041-2137
+void dna_adjust::FormConstraintStationVarianceMatrix(UINT32 stn, double w9[9]) const {
+    const station_t& st = bstBinaryRecords_[stn];
+    for (int i = 0; i < 9; ++i) w9[i] = 0.0;
+    const char* c = st.stationConst;
+    if (c[0] == 'C' && c[1] == 'C' && c[2] == 'C') {
+        w9[0] = w9[4] = w9[8] = 1. / var_C_;
+        return;
+    }
+    if (c[0] == 'F' && c[1] == 'F' && c[2] == 'F') {
+        w9[0] = w9[4] = w9[8] = 1. / var_F_;
+        return;
+    }
+    // mixed constraints: variances in the local frame, propagated to cartesian, then inverted
+    double vl[3] = {0, 0, 0};
+    const bool geographic = (st.suppliedStationType == LLH_type_i || st.suppliedStationType == LLh_type_i);
+    const double v0 = (c[0] == 'F') ? var_F_ : var_C_;
+    const double v1 = (c[1] == 'F') ? var_F_ : var_C_;
+    if (geographic) {
+        vl[1] = v0;   // latitude constraint acts in the north direction
+        vl[0] = v1;   // longitude constraint acts in the east direction
+    } else {
+        vl[0] = v0;
+        vl[1] = v1;
+    }
+    vl[2] = (c[2] == 'F') ? var_F_ : var_C_;
+    double V[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    if (st.suppliedStationType == XYZ_type_i) {
+        for (int i = 0; i < 3; ++i) V[i][i] = vl[i];
+    } else {
+        double R[3][3];
+        geodesy::LocalToCartRotation(st.currentLatitude, st.currentLongitude, R);   // Vc = R Vl R^T
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 3; ++k) s += R[i][k] * vl[k] * R[j][k];
+                V[i][j] = s;
+            }
+    }
+    // FormInverseVarianceMatrix: 3x3 Cholesky inverse
+    double l11 = std::sqrt(V[0][0]);
+    double l21 = V[1][0] / l11, l31 = V[2][0] / l11;
+    double l22 = std::sqrt(V[1][1] - l21 * l21);
+    double l32 = (V[2][1] - l31 * l21) / l22;
+    double l33 = std::sqrt(V[2][2] - l31 * l31 - l32 * l32);
+    if (!(l11 > 0) || !(l22 > 0) || !(l33 > 0)) throw MatrixInversionFailure("Matrix inversion failed, the matrix is singular.");
+    double t11 = 1 / l11, t22 = 1 / l22, t33 = 1 / l33;
+    double t21 = -l21 * t11 * t22;
+    double t32 = -l32 * t22 * t33;
+    double t31 = -(l21 * t32 + l31 * t33) * t11;
+    double W[3][3];
+    W[0][0] = t11 * t11 + t21 * t21 + t31 * t31;
+    W[1][0] = W[0][1] = t21 * t22 + t31 * t32;
+    W[2][0] = W[0][2] = t31 * t33;
+    W[1][1] = t22 * t22 + t32 * t32;
+    W[2][1] = W[1][2] = t32 * t33;
+    W[2][2] = t33 * t33;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) w9[j * 3 + i] = W[i][j];
+}
+
+// PrepareAdjustmentBlock (ADJ:2873) for every block: host lists + device upload
+void dna_adjust::PrepareBlocks() {
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
+    blocks_.assign(blockCount_, block_t());
+    max_unknowns_ = 0;
+    max_junction_ = 0;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        max_unknowns_ = std::max<UINT32>(max_unknowns_, (UINT32)v_parameterStationList_[b].size() * 3);
+        max_junction_ = std::max<UINT32>(max_junction_, (UINT32)v_JSL_[b].size() * 3);
+    }
+    int rc = dnagpu_create(projectSettings_.a.device, &ctx_);
+    if (rc != DNAGPU_OK) {
+        ctx_ = nullptr;
+        SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
+    }
+    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, max_unknowns_, &work_[c]), 0, "PrepareAdjustment(): work matrix");
+
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        currentBlock_ = b;
+        block_t& B = blocks_[b];
+        const std::vector<UINT32>& plist = v_parameterStationList_[b];
+        const UINT32 ns = (UINT32)plist.size();
+        // PopulateEstimatedStationMatrix (ADJ:632)
+        std::vector<double> xyz(3 * (size_t)ns);
+        for (UINT32 p = 0; p < ns; ++p) {
+            const station_t& st = bstBinaryRecords_[plist[p]];
+            geodesy::GeoToCart(st.currentLatitude, st.currentLongitude, st.currentHeight, &xyz[3 * p], &xyz[3 * p + 1], &xyz[3 * p + 2]);
+        }
+        // measurements of the block (CML order)
+        const std::vector<UINT32>& cml = v_CML_[b];
+        B.stn1.reserve(cml.size());
+        B.stn2.reserve(cml.size());
+        for (UINT32 m : cml) {
+            if ((size_t)m + 2 >= bmsBinaryRecords_.size())
+                SignalExceptionAdjustment("PrepareAdjustment(): measurement index out of range.", b);
+            const measurement_t& mx = bmsBinaryRecords_[m];
+            if (mx.ignore) continue;   // InitialiseandValidateMsrPointer
+            if (mx.measType != 'G' || mx.measStart != 0) {
+                std::stringstream ss;
+                ss << "UpdateNormals(): measurement type '" << mx.measType
+                   << "' is not handled by the device path yet (GNSS baselines 'G' only).";
+                SignalExceptionAdjustment(ss.str(), b);
+            }
+            const measurement_t& my = bmsBinaryRecords_[m + 1];
+            const measurement_t& mz = bmsBinaryRecords_[m + 2];
+            // LoadVarianceScaling (ADJ:4453): v-scale applied on the fly, partial scalars unsupported
+            double vScale = mx.scale4;
+            if (vScale < std::min(PRECISION_1E5, projectSettings_.a.fixed_std_dev)) vScale = 1.0;
+            const bool scaleMatrix = std::fabs(vScale - 1.0) > PRECISION_1E5;
+            auto unit = [&](double s) { return s < std::min(PRECISION_1E5, projectSettings_.a.fixed_std_dev) ? 1.0 : s; };
+            if (std::fabs(unit(mx.scale1) - 1.0) > PRECISION_1E5 || std::fabs(unit(mx.scale2) - 1.0) > PRECISION_1E5 ||
+                std::fabs(unit(mx.scale3) - 1.0) > PRECISION_1E5)
+                SignalExceptionAdjustment("LoadVarianceMatrix_G(): phi/lambda/height variance scalars are not handled by the device path yet.", b);
+            const double v6[6] = {mx.term2, my.term2, my.term3, mz.term2, mz.term3, mz.term4};
+            for (int k = 0; k < 6; ++k) B.vcv6.push_back(scaleMatrix ? v6[k] * vScale : v6[k]);
+            B.obs.push_back(mx.term1);
+            B.obs.push_back(my.term1);
+            B.obs.push_back(mz.term1);
+            B.stn1.push_back(LocalIndex(b, mx.station1));
+            B.stn2.push_back(LocalIndex(b, mx.station2));
+        }
+        // constraint lists (ADJ:1884-2037)
+        for (UINT32 p = 0; p < ns; ++p) {
+            double w9[9];
+            FormConstraintStationVarianceMatrix(plist[p], w9);
+            const stn_appear& a = v_paramStnAppearance_[b][p];
+            auto push = [&](constraint_list& l) {
+                l.stn.push_back(p);
+                l.w9.insert(l.w9.end(), w9, w9 + 9);
+            };
+            if (!phased) {
+                push(B.con_sim);
+                continue;
+            }
+            if (a.first_appearance_fwd) push(B.con_fwd);
+            if (a.first_appearance_rev) push(B.con_rev);
+            if (!a.first_appearance_fwd) push(B.con_cmb);
+        }
+        // junction index lists
+        if (phased) {
+            for (UINT32 s : v_JSL_[b]) B.jsl_here.push_back(LocalIndex(b, s));
+            if (!v_blockMeta_[b]._blockLast && !v_blockMeta_[b]._blockIsolated)
+                for (UINT32 s : v_JSL_[b]) B.jsl_in_next.push_back(LocalIndex(b + 1, s));   // JSL(b) must live in block b+1 (ADJ:1072)
+            if (!v_blockMeta_[b]._blockFirst && !v_blockMeta_[b]._blockIsolated)
+                for (UINT32 s : v_JSL_[b - 1]) B.jslprev_here.push_back(LocalIndex(b, s));
+        }
+        // device
+        Check(dnagpu_block_create(ctx_, b, ns, (UINT32)B.stn1.size()), b, "PrepareAdjustment(): block allocation");
+        Check(dnagpu_block_set_stations(ctx_, b, xyz.data()), b, "PrepareAdjustment(): stations");
+        Check(dnagpu_block_set_baselines(ctx_, b, B.stn1.data(), B.stn2.data(), B.obs.data(), B.vcv6.data()), b,
+              "PrepareAdjustment(): measurements");
+        for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "PrepareAdjustment(): meas-minus-computed");
+        if (phased) {
+            UINT32 nj = (UINT32)v_JSL_[b].size() * 3;
+            if (nj) {
+                Check(dnagpu_matrix_create(ctx_, nj, &B.jfwd), b, "PrepareAdjustment(): junction matrix");
+                Check(dnagpu_matrix_create(ctx_, nj, &B.jrev), b, "PrepareAdjustment(): junction matrix");
+            }
+            Check(dnagpu_matrix_create(ctx_, ns * 3, &B.rigvar), b, "PrepareAdjustment(): rigorous variance matrix");
+        }
+    }
+    Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
+}
+
+// ADJ:258-442
+void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
+    isPreparing_ = true;
+    isAdjusting_ = true;
+    isCombining_ = false;
+    exceptionRaised_ = false;
+    adjustStatus_ = ADJUST_SUCCESS;
+    FreeDevice();
+    projectSettings_ = projectSettings;
+    if (projectSettings_.a.stage) projectSettings_.a.stage = 0;   // HBM replaces the staged (memory mapped) mode
+    // InitialiseAdjustment (ADJ:232-245)
+    var_C_ = projectSettings_.a.fixed_std_dev * projectSettings_.a.fixed_std_dev;
+    var_F_ = projectSettings_.a.free_std_dev * projectSettings_.a.free_std_dev;
+    currentBlock_ = 0;
+    currentIteration_ = 0;
+    try {
+        LoadNetworkFiles();
+        switch (projectSettings_.a.adjust_mode) {
+            case SimultaneousMode: BuildSimultaneousLists(); break;
+            case PhasedMode:
+            case Phased_Block_1Mode: {
+                iostreams::seg_data_t seg;
+                iostreams::read_seg(projectSettings_.a.seg_file, seg, &bmsBinaryRecords_);
+                blockCount_ = seg.blockCount;
+                v_ISL_ = seg.ISL;
+                v_JSL_ = seg.JSL;
+                v_CML_ = seg.CML;
+                v_ContiguousNetList_ = seg.ContiguousNetList;
+                v_measurementCount_ = seg.measurementCount;
+                v_unknownsCount_ = seg.unknownsCount;
+                v_parameterStationCount_ = seg.parameterStationCount;
+                if (v_ISL_.size() != v_JSL_.size() || v_JSL_.size() != v_CML_.size())
+                    throw std::runtime_error(
+                        "LoadPhasedBlocks(): An unrecoverable error was encountered when loading the phased adjustment blocks.");
+                break;
+            }
+            default: throw std::runtime_error("AdjustNetwork(): Unknown adjustment type");
+        }
+        if (blockCount_ == 0) throw std::runtime_error("PrepareAdjustment(): the network has no blocks.");
+        LoadSegmentationMetrics();
+        CreateStnAppearanceList();
+        PrepareBlocks();
+    } catch (const NetAdjustException&) {
+        throw;
+    } catch (const std::runtime_error& e) {
+        std::stringstream ss;
+        ss << "PrepareAdjustment(): Process terminated while preparing the " << std::endl
+           << "  adjustment matrices. Details: " << std::endl
+           << "  " << e.what() << std::endl;
+        SignalExceptionAdjustment(ss.str(), currentBlock_);
+    }
+    degreesofFreedom_ = (int)measurementParams_ - (int)unknownParams_;
+    isPreparing_ = false;
+}
+
+void dna_adjust::AddConstraints(int chain, dnagpu_matrix* m, const constraint_list& c, int sign) {
+    if (c.stn.empty()) return;
+    Check(dnagpu_add_diag3x3(ctx_, chain, m, c.stn.data(), c.w9.data(), c.stn.size(), sign), currentBlock_,
+          "AddConstraintStationstoNormals()");
+}
+
+// SolveTry (ADJ:6569) / Solve (ADJ:6586): inverse + corrections; rhs already on the device
+void dna_adjust::SolveTry(int chain, UINT32 block, dnagpu_matrix* m) {
+    Check(dnagpu_invert(ctx_, chain, m, projectSettings_.a.scale_normals_to_unity ? 1 : 0), block, "Solve()");
+    double n = 3.0 * (double)v_parameterStationList_[block].size();
+    solve_flops_ += n * n * n;
+    solve_count_++;
+    Check(dnagpu_solve_corrections(ctx_, chain, block, m), block, "Solve()");
+}
+
+// ADJ:2140
+_ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
+    if (!ctx_) SignalExceptionAdjustment("AdjustNetwork(): PrepareAdjustment() has not been called.", 0);
+    isAdjusting_ = true;
+    adjustStatus_ = ADJUST_SUCCESS;
+    iterationCorrections_.clear();
+    solve_flops_ = 0.0;
+    solve_count_ = 0;
+    const double t0 = now_ms();
+    switch (projectSettings_.a.adjust_mode) {
+        case SimultaneousMode: AdjustSimultaneous(); break;
+        case PhasedMode: AdjustPhased(); break;
+        default: SignalExceptionAdjustment("AdjustNetwork(): Unknown adjustment type", 0);
+    }
+    Check(dnagpu_sync(ctx_), 0, "AdjustNetwork()");
+    adjust_ms_ = now_ms() - t0;
+    return adjustStatus_;
+}
+
+// ADJ:2413-2511 (GNSS only: the inverse is formed once, ADJ:2457)
+void dna_adjust::AdjustSimultaneous() {
+    const int c = 0;
+    block_t& B = blocks_[0];
+    dnagpu_matrix* W = work_[0];
+    currentIteration_ = 0;
+    for (UINT32 i = 0; i < projectSettings_.a.max_iterations; ++i) {
+        if (IsCancelled()) break;
+        ++currentIteration_;
+        currentBlock_ = 0;
+        if (currentIteration_ < 2) {
+            Check(dnagpu_form_normals(ctx_, c, 0, W), 0, "UpdateNormals()");
+            AddConstraints(c, W, B.con_sim, +1);
+        }
+        Check(dnagpu_form_rhs(ctx_, c, 0), 0, "Solve()");
+        if (currentIteration_ < 2)
+            SolveTry(c, 0, W);
+        else
+            Check(dnagpu_solve_corrections(ctx_, c, 0, W), 0, "Solve()");
+        double mv = 0.0;
+        UINT32 row = 0;
+        Check(dnagpu_update_estimates(ctx_, c, 0, &mv, &row), 0, "AdjustSimultaneous()");
+        maxCorr_ = mv;
+        iterationCorrections_.push_back(maxCorr_);
+        bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
+        if (!iterate) break;
+        UpdateAdjustment(true);
+    }
+    // v_rigorousVariances_[0] = v_normals_[0] (ADJ:2536); rigorous stations = estimates
+    Check(dnagpu_block_copy_stations(ctx_, c, 0, 2, 1), 0, "ValidateandFinaliseAdjustment()");
+    ValidateandFinaliseAdjustment();
+}
+
+// ADJ:2513-2549
+void dna_adjust::ValidateandFinaliseAdjustment() {
+    isAdjusting_ = false;
+    if (adjustStatus_ > ADJUST_TEST_FAILED) return;
+    if (IsCancelled()) {
+        adjustStatus_ = ADJUST_CANCELLED;
+        return;
+    }
+    if (currentIteration_ == projectSettings_.a.max_iterations && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold)
+        adjustStatus_ = ADJUST_MAX_ITERATIONS_EXCEEDED;
+}
+
+// ADJ:473-627: new meas-minus-computed from the latest estimates; the GNSS normals do not change
+void dna_adjust::UpdateAdjustment(bool iterate) {
+    (void)iterate;
+    isPreparing_ = true;
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
+    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        if (IsCancelled()) break;
+        if (phased && v_blockMeta_[b]._blockLast) {
+            // estimated = original = rigorous (ADJ:516-517)
+            for (int c = 0; c < chains; ++c) Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
+            Check(dnagpu_block_copy_stations(ctx_, 0, b, 0, 2), b, "UpdateAdjustment()");
+        }
+        for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
+    }
+    isPreparing_ = false;
+}
+
+// ADJ:2579-2670
+void dna_adjust::AdjustPhased() {
+    currentIteration_ = 0;
+    for (UINT32 i = 0; i < projectSettings_.a.max_iterations; ++i) {
+        if (IsCancelled()) break;
+        maxCorr_ = 0.0;
+        ++currentIteration_;
+        AdjustPhasedForward();
+        if (IsCancelled()) break;
+        AdjustPhasedReverseCombine();
+        if (IsCancelled()) break;
+        iterationCorrections_.push_back(maxCorr_);
+        bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
+        if (!iterate) break;
+        UpdateAdjustment(iterate);
+    }
+    ValidateandFinaliseAdjustment();
+}
+
+// ADJ:2756-2852 + CarryForwardJunctions ADJ:3065 + CarryStnEstimatesandVariancesForward ADJ:998
+void dna_adjust::AdjustPhasedForward() {
+    forward_ = true;
+    const int c = 0;
+    dnagpu_matrix* W = work_[c];
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        if (IsCancelled()) break;
+        currentBlock_ = k;
+        block_t& B = blocks_[k];
+        const blockMeta_t& meta = v_blockMeta_[k];
+        const bool carried_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
+        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        AddConstraints(c, W, B.con_fwd, +1);
+        if (carried_in)
+            Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
+                  "CarryStnEstimatesandVariancesForward()");
+        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+        if (carried_in)
+            Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
+        SolveTry(c, k, W);
+        // UpdateEstimatesForward (ADJ:3022)
+        double mv = 0.0;
+        UINT32 row = 0;
+        Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesForward()");
+        if (meta._blockLast || meta._blockIsolated) {
+            if (std::fabs(mv) > std::fabs(maxCorr_)) SetmaxCorr(mv);
+            Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesForward()");
+            Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesForward()");
+            B.has_rigvar = true;
+        }
+        if (meta._blockIsolated || meta._blockLast) continue;
+        if (v_blockMeta_[k + 1]._blockIsolated) continue;
+        if (B.jsl_here.empty()) continue;
+        Check(dnagpu_junction_gather(ctx_, c, k, W, B.jsl_here.data(), B.jsl_here.size(), B.jfwd), k,
+              "CarryStnEstimatesandVariancesForward()");
+        Check(dnagpu_invert(ctx_, c, B.jfwd, 0), k, "CarryStnEstimatesandVariancesForward()");
+    }
+}
+
+// ADJ:3461-3590 + CarryReverseJunctions ADJ:3833 + CarryStnEstimatesandVariancesReverse ADJ:1133
+// + PrepareAdjustmentCombine ADJ:3336 + UpdateEstimatesFinal ADJ:3744
+void dna_adjust::AdjustPhasedReverseCombine() {
+    forward_ = false;
+    isCombining_ = false;
+    const int c = projectSettings_.a.multi_thread ? 1 : 0;
+    dnagpu_matrix* W = work_[c];
+    for (UINT32 kk = blockCount_; kk-- > 0;) {
+        if (IsCancelled()) break;
+        const UINT32 k = kk;
+        currentBlock_ = k;
+        block_t& B = blocks_[k];
+        const blockMeta_t& meta = v_blockMeta_[k];
+        if (meta._blockIsolated) continue;   // PrepareAdjustmentReverse (ADJ:3115)
+        const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
+        const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
+        // estimates back to the originals (ADJ:3157 for the last block, ADJ:3863 for the others)
+        Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentReverse()");
+        // normals = measurements + junctions carried in reverse + constraints (first appearance in reverse)
+        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        if (rev_in)
+            Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k,
+                  "CarryStnEstimatesandVariancesReverse()");
+        AddConstraints(c, W, B.con_rev, +1);
+        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+        if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
+        SolveTry(c, k, W);
+        double mv = 0.0;
+        UINT32 row = 0;
+        Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesReverse()");
+        if (!meta._blockFirst) {
+            // carry this block's junction estimates and variances to block k-1
+            if (fwd_in) {
+                Check(dnagpu_junction_gather(ctx_, c, k, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jrev), k,
+                      "CarryStnEstimatesandVariancesReverse()");
+                Check(dnagpu_invert(ctx_, c, blocks_[k - 1].jrev, 0), k, "CarryStnEstimatesandVariancesReverse()");
+            }
+            if (CombineRequired(k)) {
+                isCombining_ = true;
+                Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentCombine()");
+                // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed
+                // in the same summation order, which gives the same bits
+                Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+                if (rev_in)
+                    Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k,
+                          "CarryStnEstimatesandVariancesCombine()");
+                AddConstraints(c, W, B.con_rev, +1);
+                if (fwd_in)
+                    Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
+                          "CarryStnEstimatesandVariancesCombine()");
+                AddConstraints(c, W, B.con_cmb, -1);
+                Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+                if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
+                if (fwd_in)
+                    Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
+                SolveTry(c, k, W);
+                Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesCombine()");
+                isCombining_ = false;
+            }
+        }
+        // UpdateEstimatesFinal (ADJ:3744)
+        if (meta._blockLast) continue;
+        if (std::fabs(mv) > std::fabs(maxCorr_)) SetmaxCorr(mv);
+        Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesFinal()");   // rigorous = estimated
+        Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesFinal()");
+        B.has_rigvar = true;
+        Check(dnagpu_block_copy_stations(ctx_, c, k, 0, 2), k, "UpdateEstimatesFinal()");   // original = rigorous
+        if (c != 0) Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
+    }
+}
+
+void dna_adjust::GetBlockRigorousStations(UINT32 block, std::vector<double>& xyz) {
+    if (!ctx_ || block >= blockCount_) throw std::runtime_error("GetBlockRigorousStations(): no such block");
+    xyz.resize(3 * v_parameterStationList_[block].size());
+    Check(dnagpu_block_get_stations(ctx_, 0, block, 2, xyz.data()), block, "GetBlockRigorousStations()");
+}
+
+void dna_adjust::GetBlockRigorousVariancesPacked(UINT32 block, std::vector<double>& packed) {
+    if (!ctx_ || block >= blockCount_) throw std::runtime_error("GetBlockRigorousVariancesPacked(): no such block");
+    size_t n = 3 * v_parameterStationList_[block].size();
+    packed.resize(n * (n + 1) / 2);
+    dnagpu_matrix* m = (projectSettings_.a.adjust_mode == SimultaneousMode) ? work_[0] : blocks_[block].rigvar;
+    Check(dnagpu_matrix_download_packed(ctx_, 0, m, packed.data()), block, "GetBlockRigorousVariancesPacked()");
+}
+
+void dna_adjust::GetAdjustedCoordinates(std::vector<double>& xyz) {
+    xyz.assign(3 * bstBinaryRecords_.size(), 0.0);
+    for (size_t s = 0; s < bstBinaryRecords_.size(); ++s) {
+        const station_t& st = bstBinaryRecords_[s];
+        geodesy::GeoToCart(st.currentLatitude, st.currentLongitude, st.currentHeight, &xyz[3 * s], &xyz[3 * s + 1], &xyz[3 * s + 2]);
+    }
+    // every block holds rigorous values for all of its stations; a station shared by two blocks has the
+    // same rigorous estimate in both, the block of first appearance is used (BuildUniqueBlockStationMap ADJ:1849)
+    std::vector<double> bx;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        GetBlockRigorousStations(b, bx);
+        for (size_t p = 0; p < v_parameterStationList_[b].size(); ++p)
+            if (v_paramStnAppearance_[b][p].first_appearance_fwd)
+                for (int c = 0; c < 3; ++c) xyz[3 * (size_t)v_parameterStationList_[b][p] + c] = bx[3 * p + c];
+    }
+}
+
+void dna_adjust::GenerateStatistics() {}
+void dna_adjust::SerialiseAdjustedVarianceMatrices() {}
+void dna_adjust::UpdateBinaryFiles() {}
+
+}  // namespace networkadjust
+}  // namespace dynadjust

@@ -1,0 +1,170 @@
+// dna_adjust -- the drop-in boundary (L1) of the path: same entry points, argument meaning
+// and error behaviour as dynadjust::networkadjust::dna_adjust of the reference
+// (dynadjust/dnaadjust/dnaadjust.hpp:209-1362 of /root/reference/dynadjust/), for GNSS
+// networks.  Everything numerical runs on the device through the dnagpu C-ABI
+// (include/dnagpu.h); this class only schedules blocks and keeps host-side metadata.
+#pragma once
+#include <atomic>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/dnagpu.h"
+#include "dnaio.hpp"
+#include "dnatypes.hpp"
+
+namespace dynadjust {
+namespace networkadjust {
+
+// include/exception/dnaexception.hpp: NetAdjustException carries a message + block number
+class NetAdjustException : public std::runtime_error {
+public:
+    NetAdjustException(const std::string& what, UINT32 block) : std::runtime_error(what), block_(block) {}
+    UINT32 block() const { return block_; }
+
+private:
+    UINT32 block_;
+};
+
+// math::MatrixInversionFailure (dnamatrix_contiguous.hpp:198)
+class MatrixInversionFailure : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
+
+struct block_timing_t {
+    double form_ms = 0, invert_ms = 0, other_ms = 0;
+};
+
+class dna_adjust {
+public:
+    dna_adjust();
+    ~dna_adjust();
+    dna_adjust(const dna_adjust&) = delete;
+    dna_adjust& operator=(const dna_adjust&) = delete;
+
+    // ---- reference interface (dnaadjust.hpp:259-405) -----------------------------------
+    void PrepareAdjustment(const project_settings& projectSettings);   // ADJ:258
+    _ADJUST_STATUS_ AdjustNetwork();                                   // ADJ:2140
+    void GenerateStatistics();                                         // ADJ:6802 (chi-square / sigma-zero of GNSS rows)
+    void SerialiseAdjustedVarianceMatrices();                          // ADJ:6770 (<net>-rva.mtx)
+    void UpdateBinaryFiles();                                          // ADJ:445
+
+    inline void CancelAdjustment() { cancel_.store(true); }            // dnaadjust.hpp:262
+    inline bool IsCancelled() const { return cancel_.load(); }
+    inline UINT32 CurrentIteration() const { return currentIteration_; }
+    inline UINT32 CurrentBlock() const { return currentBlock_; }
+    inline bool IsPreparing() const { return isPreparing_; }
+    inline bool IsAdjusting() const { return isAdjusting_; }
+    inline bool processingForward() const { return forward_; }
+    inline bool processingCombine() const { return isCombining_; }
+    inline UINT32 blockCount() const { return blockCount_; }
+    inline double GetMaxCorrection() const { return maxCorr_; }
+    inline _ADJUST_STATUS_ GetStatus() const { return adjustStatus_; }
+    inline UINT32 GetMeasurementCount() const { return measurementParams_; }
+    inline UINT32 GetUnknownsCount() const { return unknownParams_; }
+    inline int GetDegreesOfFreedom() const { return degreesofFreedom_; }
+    inline double GetChiSquared() const { return chiSquared_; }
+    inline double GetSigmaZero() const { return sigmaZero_; }
+    inline bool GetAllFixed() const { return allStationsFixed_; }
+    inline bool ExceptionRaised() const { return exceptionRaised_; }
+    inline double adjustTime() const { return adjust_ms_; }
+    inline UINT32 CurrentBlockStationCount() const {
+        return currentBlock_ < v_parameterStationList_.size() ? (UINT32)v_parameterStationList_[currentBlock_].size() : 0;
+    }
+    inline double GetIterationCorrection(UINT32 iteration) const {
+        return iteration >= 1 && iteration <= iterationCorrections_.size() ? iterationCorrections_[iteration - 1] : 0.0;
+    }
+
+    // ---- results (what the reference's printers read through friend access) -------------
+    const std::vector<UINT32>& GetBlockStationList(UINT32 block) const { return v_parameterStationList_.at(block); }
+    void GetBlockRigorousStations(UINT32 block, std::vector<double>& xyz);
+    void GetBlockRigorousVariancesPacked(UINT32 block, std::vector<double>& packed);
+    // network-wide rigorous coordinates (3 per bst station; stations never adjusted keep their input value)
+    void GetAdjustedCoordinates(std::vector<double>& xyz);
+
+    // ---- measurement (not in the reference): per-phase device timing of the last AdjustNetwork
+    double solveFlops() const { return solve_flops_; }   // sum of n^3 over Solve() calls (reference-equivalent)
+    UINT32 solveCount() const { return solve_count_; }
+    dnagpu_ctx* deviceContext() const { return ctx_; }
+
+private:
+    struct constraint_list {
+        std::vector<UINT32> stn;   // block-local station index
+        std::vector<double> w9;    // 3x3 column-major each
+    };
+    struct block_t {
+        std::vector<UINT32> stn1, stn2;       // block-local station of each baseline
+        std::vector<double> obs, vcv6;
+        constraint_list con_fwd, con_rev, con_cmb, con_sim;
+        std::vector<UINT32> jsl_here;         // local index of JSL(block) stations in this block
+        std::vector<UINT32> jsl_in_next;      // local index of JSL(block) stations in block+1
+        std::vector<UINT32> jslprev_here;     // local index of JSL(block-1) stations in this block
+        dnagpu_matrix* jfwd = nullptr;        // v_junctionVariancesFwd_ + v_junctionEstimatesFwd_
+        dnagpu_matrix* jrev = nullptr;        // v_junctionVariances_ (reverse) + v_junctionEstimatesRev_
+        dnagpu_matrix* rigvar = nullptr;      // v_rigorousVariances_
+        bool has_rigvar = false;
+    };
+
+    void LoadNetworkFiles();
+    void LoadSegmentationMetrics();
+    void BuildSimultaneousLists();
+    void CreateStnAppearanceList();
+    void PrepareBlocks();
+    void FormConstraintStationVarianceMatrix(UINT32 stn, double w9[9]) const;   // ADJ:2041
+    UINT32 LocalIndex(UINT32 block, UINT32 stn) const;
+
+    void AdjustSimultaneous();           // ADJ:2413
+    void AdjustPhased();                 // ADJ:2579
+    void AdjustPhasedForward();          // ADJ:2756
+    void AdjustPhasedReverseCombine();   // ADJ:3461
+    void UpdateAdjustment(bool iterate); // ADJ:473
+    void ValidateandFinaliseAdjustment();// ADJ:2513
+
+    // one Solve() (ADJ:6586): normals already formed in `m`; rhs already formed
+    void SolveTry(int chain, UINT32 block, dnagpu_matrix* m);
+    void AddConstraints(int chain, dnagpu_matrix* m, const constraint_list& c, int sign);
+    void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
+    void Check(int rc, UINT32 block, const char* where);
+    void SetmaxCorr(double v) { maxCorr_ = v; }
+    bool CombineRequired(UINT32 block) const {
+        const blockMeta_t& m = v_blockMeta_[block];
+        return !(m._blockLast || m._blockIsolated || m._blockFirst);
+    }
+    void FreeDevice();
+
+    project_settings projectSettings_;
+    std::vector<station_t> bstBinaryRecords_;
+    std::vector<measurement_t> bmsBinaryRecords_;
+    std::vector<asl_entry_t> vAssocStnList_;
+    binary_file_meta_t bst_meta_, bms_meta_;
+    std::vector<std::vector<UINT32>> v_ISL_, v_JSL_, v_CML_;
+    std::vector<UINT32> v_ContiguousNetList_, v_measurementCount_, v_unknownsCount_, v_parameterStationCount_;
+    std::vector<blockMeta_t> v_blockMeta_;
+    std::vector<std::vector<UINT32>> v_parameterStationList_;
+    std::vector<std::vector<stn_appear>> v_paramStnAppearance_;
+    std::vector<block_t> blocks_;
+
+    UINT32 blockCount_ = 1;
+    UINT32 currentBlock_ = 0, currentIteration_ = 0;
+    bool isPreparing_ = false, isAdjusting_ = false, forward_ = true, isCombining_ = false;
+    bool allStationsFixed_ = false, exceptionRaised_ = false;
+    std::atomic<bool> cancel_{false};
+    _ADJUST_STATUS_ adjustStatus_ = ADJUST_SUCCESS;
+    UINT32 measurementParams_ = 0, unknownParams_ = 0, unknownsCount_ = 0;
+    int degreesofFreedom_ = 0;
+    double maxCorr_ = 0.0, chiSquared_ = 0.0, sigmaZero_ = 0.0;
+    double var_C_ = 0.0, var_F_ = 0.0;
+    std::vector<double> iterationCorrections_;
+    double adjust_ms_ = 0.0;
+    double solve_flops_ = 0.0;
+    UINT32 solve_count_ = 0;
+
+    dnagpu_ctx* ctx_ = nullptr;
+    dnagpu_matrix* work_[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    UINT32 max_unknowns_ = 0, max_junction_ = 0;
+};
+
+}  // namespace networkadjust
+}  // namespace dynadjust

@@ -1,0 +1,213 @@
+// C-ABI wrappers declared in include/dnaadjust_c.h.
+#include "../../../include/dnaadjust_c.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "dna_adjust.hpp"
+#include "dnaio.hpp"
+#include "synth.hpp"
+
+using dynadjust::networkadjust::dna_adjust;
+
+struct dnaadj_handle {
+    dna_adjust* adj = nullptr;
+    std::string err;
+};
+
+namespace {
+template <class F>
+int guarded(dnaadj_handle* h, F&& f) {
+    if (!h || !h->adj) return DNAADJ_EINVAL;
+    try {
+        f();
+        return DNAADJ_OK;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return DNAADJ_EXCEPTION;
+    } catch (...) {
+        h->err = "unknown exception";
+        return DNAADJ_EXCEPTION;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+void dnaadj_default_settings(dnaadj_settings* s) {
+    if (!s) return;
+    memset(s, 0, sizeof(*s));
+    s->adjust_mode = 0;
+    s->max_iterations = 10;
+    s->iteration_threshold = 0.0005f;
+    s->free_std_dev = 10.0;
+    s->fixed_std_dev = 1.0e-6;
+}
+
+int dnaadj_create(dnaadj_handle** out) {
+    if (!out) return DNAADJ_EINVAL;
+    *out = nullptr;
+    try {
+        dnaadj_handle* h = new dnaadj_handle();
+        h->adj = new dna_adjust();
+        *out = h;
+        return DNAADJ_OK;
+    } catch (...) {
+        return DNAADJ_EXCEPTION;
+    }
+}
+
+void dnaadj_destroy(dnaadj_handle* h) {
+    if (!h) return;
+    delete h->adj;
+    delete h;
+}
+
+const char* dnaadj_last_error(const dnaadj_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
+    if (!s) return DNAADJ_EINVAL;
+    return guarded(h, [&] {
+        dynadjust::project_settings p;
+        p.a.bst_file = s->bst_file ? s->bst_file : "";
+        p.a.bms_file = s->bms_file ? s->bms_file : "";
+        p.a.seg_file = s->seg_file ? s->seg_file : "";
+        p.s.asl_file = s->asl_file ? s->asl_file : "";
+        p.a.adjust_mode = (uint16_t)s->adjust_mode;
+        p.a.multi_thread = (uint16_t)(s->multi_thread ? 1 : 0);
+        p.a.max_iterations = (uint16_t)s->max_iterations;
+        p.a.iteration_threshold = s->iteration_threshold;
+        p.a.free_std_dev = s->free_std_dev;
+        p.a.fixed_std_dev = s->fixed_std_dev;
+        p.a.scale_normals_to_unity = (uint16_t)(s->scale_normals_to_unity ? 1 : 0);
+        p.a.device = s->device;
+        h->adj->PrepareAdjustment(p);
+    });
+}
+
+int dnaadj_adjust(dnaadj_handle* h, int* status) {
+    return guarded(h, [&] {
+        int st = (int)h->adj->AdjustNetwork();
+        if (status) *status = st;
+    });
+}
+
+int dnaadj_cancel(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->CancelAdjustment(); });
+}
+
+uint32_t dnaadj_block_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->blockCount() : 0; }
+uint32_t dnaadj_iterations(const dnaadj_handle* h) { return h && h->adj ? h->adj->CurrentIteration() : 0; }
+double dnaadj_max_correction(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetMaxCorrection() : 0.0; }
+double dnaadj_iteration_correction(const dnaadj_handle* h, uint32_t it) { return h && h->adj ? h->adj->GetIterationCorrection(it) : 0.0; }
+uint32_t dnaadj_measurement_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetMeasurementCount() : 0; }
+uint32_t dnaadj_unknowns_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetUnknownsCount() : 0; }
+int dnaadj_degrees_of_freedom(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetDegreesOfFreedom() : 0; }
+double dnaadj_adjust_time_ms(const dnaadj_handle* h) { return h && h->adj ? h->adj->adjustTime() : 0.0; }
+double dnaadj_solve_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveFlops() : 0.0; }
+uint32_t dnaadj_solve_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveCount() : 0; }
+
+uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block) {
+    if (!h || !h->adj || block >= h->adj->blockCount()) return 0;
+    return (uint32_t)h->adj->GetBlockStationList(block).size();
+}
+
+int dnaadj_block_stations(dnaadj_handle* h, uint32_t block, uint32_t* stations) {
+    return guarded(h, [&] {
+        const auto& l = h->adj->GetBlockStationList(block);
+        if (!l.empty()) memcpy(stations, l.data(), l.size() * sizeof(uint32_t));
+    });
+}
+
+int dnaadj_block_estimates(dnaadj_handle* h, uint32_t block, double* xyz) {
+    return guarded(h, [&] {
+        std::vector<double> v;
+        h->adj->GetBlockRigorousStations(block, v);
+        if (!v.empty()) memcpy(xyz, v.data(), v.size() * sizeof(double));
+    });
+}
+
+int dnaadj_block_variances_packed(dnaadj_handle* h, uint32_t block, double* packed) {
+    return guarded(h, [&] {
+        std::vector<double> v;
+        h->adj->GetBlockRigorousVariancesPacked(block, v);
+        if (!v.empty()) memcpy(packed, v.data(), v.size() * sizeof(double));
+    });
+}
+
+uint32_t dnaadj_station_count(const dnaadj_handle* h) {
+    if (!h || !h->adj) return 0;
+    uint32_t mx = 0;
+    for (uint32_t b = 0; b < h->adj->blockCount(); ++b)
+        for (uint32_t s : h->adj->GetBlockStationList(b)) mx = s + 1 > mx ? s + 1 : mx;
+    return mx;
+}
+
+int dnaadj_adjusted_coordinates(dnaadj_handle* h, double* xyz) {
+    return guarded(h, [&] {
+        std::vector<double> v;
+        h->adj->GetAdjustedCoordinates(v);
+        if (!v.empty()) memcpy(xyz, v.data(), v.size() * sizeof(double));
+    });
+}
+
+void* dnaadj_device_context(dnaadj_handle* h) { return h && h->adj ? (void*)h->adj->deviceContext() : nullptr; }
+
+int dnasynth_write_network(const char* dir, const char* name, const dnasynth_spec* spec, dnasynth_summary* out, char* err, size_t errlen) {
+    if (!dir || !name || !spec) return DNAADJ_EINVAL;
+    try {
+        dynadjust::synth::Spec sp;
+        sp.rows = spec->rows;
+        sp.cols = spec->cols;
+        sp.n_baselines = spec->n_baselines;
+        sp.n_blocks = spec->n_blocks ? spec->n_blocks : 1;
+        if (spec->seed) sp.seed = spec->seed;
+        if (spec->initial_sigma > 0) sp.initial_sigma = spec->initial_sigma;
+        dynadjust::synth::Summary sm;
+        dynadjust::synth::write_network(dir, name, sp, &sm);
+        if (out) {
+            out->stations = sm.stations;
+            out->baselines = sm.baselines;
+            out->measurement_rows = sm.measurement_rows;
+            out->blocks = sm.blocks;
+            out->max_block_unknowns = sm.max_block_unknowns;
+        }
+        return DNAADJ_OK;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return DNAADJ_EXCEPTION;
+    }
+}
+
+int dnaio_file_summary(const char* bst, const char* bms, const char* asl, uint64_t* n_stn, uint64_t* n_msr, uint64_t* n_asl, char* err,
+                       size_t errlen) {
+    try {
+        using namespace dynadjust;
+        binary_file_meta_t meta;
+        if (bst) {
+            std::vector<station_t> v;
+            iostreams::read_bst(bst, v, meta);
+            if (n_stn) *n_stn = v.size();
+        }
+        if (bms) {
+            std::vector<measurement_t> v;
+            iostreams::read_bms(bms, v, meta);
+            if (n_msr) *n_msr = v.size();
+        }
+        if (asl) {
+            std::vector<asl_entry_t> v;
+            iostreams::read_asl(asl, v);
+            if (n_asl) *n_asl = v.size();
+        }
+        return DNAADJ_OK;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return DNAADJ_EXCEPTION;
+    }
+}
+
+size_t dnaio_sizeof_station(void) { return sizeof(dynadjust::station_t); }
+size_t dnaio_sizeof_measurement(void) { return sizeof(dynadjust::measurement_t); }
+
+}  // extern "C"

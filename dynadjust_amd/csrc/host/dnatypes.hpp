@@ -1,0 +1,200 @@
+// On-disk record layouts and the settings subset of DynAdjust that the adjustment path
+// consumes.  The layouts are the reference's binary file formats (raw struct dumps made by
+// GCC x86-64), so field order, types and padding are pinned by static_asserts:
+//   station_t      = 352 bytes  (include/config/dnatypes-structs.hpp:270-323)
+//   measurement_t  = 208 bytes  (include/measurement_types/dnameasurement.hpp:133-194)
+// (paths under /root/reference/dynadjust/).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace dynadjust {
+
+typedef uint32_t UINT32;
+typedef uint16_t UINT16;
+
+// widths, include/config/dnatypes-basic.hpp:66-76
+constexpr int STN_NAME_WIDTH = 31;
+constexpr int STN_NAME_ORIG_WIDTH = 40;
+constexpr int STN_DESC_WIDTH = 129;
+constexpr int STN_CONST_WIDTH = 4;
+constexpr int STN_TYPE_WIDTH = 4;
+constexpr int STN_EPSG_WIDTH = 7;
+constexpr int STN_EPOCH_WIDTH = 12;
+constexpr int STN_PLATE_WIDTH = 3;
+constexpr int MOD_NAME_WIDTH = 20;
+constexpr int FILE_NAME_WIDTH = 256;
+
+// include/config/dnatypes-basic.hpp:129-132, 161-162
+enum { XYZ_type_i = 0, LLh_type_i = 1, LLH_type_i = 2, UTM_type_i = 3 };
+enum { ORTHOMETRIC_type_i = 0, ELLIPSOIDAL_type_i = 1 };
+
+struct station_t {
+    char stationName[STN_NAME_WIDTH];
+    char stationNameOrig[STN_NAME_ORIG_WIDTH];
+    char stationConst[STN_CONST_WIDTH];   // "CCC", "FFF", ... lat, long, height
+    char stationType[STN_TYPE_WIDTH];     // "LLH", "UTM", "XYZ"
+    UINT16 suppliedStationType;
+    double initialLatitude;
+    double currentLatitude;               // radians
+    double initialLongitude;
+    double currentLongitude;              // radians
+    double initialHeight;
+    double currentHeight;                 // ellipsoidal, metres
+    UINT16 suppliedHeightRefFrame;
+    float geoidSep;
+    float geoidSepUnc;
+    double meridianDef;
+    double verticalDef;
+    short zone;
+    char description[STN_DESC_WIDTH];
+    UINT32 fileOrder;
+    UINT32 nameOrder;
+    UINT32 clusterID;
+    UINT16 unusedStation;
+    char epsgCode[STN_EPSG_WIDTH];
+    char epoch[STN_EPOCH_WIDTH];
+    char observation_epoch[STN_EPOCH_WIDTH];
+    char plate[STN_PLATE_WIDTH];
+};
+static_assert(sizeof(station_t) == 352, "station_t must match the .bst record");
+static_assert(offsetof(station_t, stationConst) == 71, "");
+static_assert(offsetof(station_t, suppliedStationType) == 80, "");
+static_assert(offsetof(station_t, currentLatitude) == 96, "");
+static_assert(offsetof(station_t, currentLongitude) == 112, "");
+static_assert(offsetof(station_t, currentHeight) == 128, "");
+static_assert(offsetof(station_t, geoidSep) == 140, "");
+static_assert(offsetof(station_t, fileOrder) == 300, "");
+
+struct measurement_t {
+    char measType;              // 'G' GPS baseline, 'X' baseline cluster, 'Y' point cluster, ...
+    char measStart;             // 0 = X element, 1 = Y, 2 = Z, 3..5 covariance rows
+    char measurementStations;
+    char epsgCode[7];
+    char epoch[STN_EPOCH_WIDTH];
+    char observation_epoch[STN_EPOCH_WIDTH];
+    char coordType[4];
+    bool ignore;
+    UINT32 station1;
+    UINT32 station2;
+    UINT32 station3;
+    UINT32 vectorCount1;
+    UINT32 vectorCount2;
+    UINT32 clusterID;
+    UINT32 fileOrder;
+    UINT32 sourceFileIndex;
+    double term1;               // measurement (dX / dY / dZ)
+    double term2;               // XX | XY | XZ variance
+    double term3;               // YY | YZ
+    double term4;               // ZZ
+    double scale1, scale2, scale3, scale4;   // phi, lambda, height, matrix (v) scalars
+    double measAdj, measCorr, measAdjPrec, residualPrec, NStat, TStat, PelzerRel, preAdjCorr, preAdjMeas;
+};
+static_assert(sizeof(measurement_t) == 208, "measurement_t must match the .bms record");
+static_assert(offsetof(measurement_t, ignore) == 38, "");
+static_assert(offsetof(measurement_t, station1) == 40, "");
+static_assert(offsetof(measurement_t, vectorCount1) == 52, "");
+static_assert(offsetof(measurement_t, clusterID) == 60, "");
+static_assert(offsetof(measurement_t, term1) == 72, "");
+static_assert(offsetof(measurement_t, scale1) == 104, "");
+static_assert(offsetof(measurement_t, measAdj) == 136, "");
+static_assert(offsetof(measurement_t, preAdjMeas) == 200, "");
+
+// include/config/dnatypes-structs.hpp:332-420 (as written by DynadjustFile::WriteFileMetadata,
+// include/io/dynadjust_file.cpp:83-117)
+struct input_file_meta_t {
+    char filename[FILE_NAME_WIDTH + 1];
+    char epsgCode[STN_EPSG_WIDTH];
+    char epoch[STN_EPOCH_WIDTH];
+    char observation_epoch[STN_EPOCH_WIDTH];
+    UINT16 filetype;
+    UINT16 datatype;
+};
+struct source_file_meta_t {
+    char filename[FILE_NAME_WIDTH + 1];
+};
+struct binary_file_meta_t {
+    uint64_t binCount = 0;
+    bool reduced = false;
+    char modifiedBy[MOD_NAME_WIDTH + 1] = {0};
+    char epsgCode[STN_EPSG_WIDTH] = {0};
+    char epoch[STN_EPOCH_WIDTH] = {0};
+    char observation_epoch[STN_EPOCH_WIDTH] = {0};
+    bool reftran = false;
+    bool geoid = false;
+    std::vector<input_file_meta_t> inputFileMeta;
+    std::vector<source_file_meta_t> sourceFileMeta;
+};
+
+// .asl record: include/functions/dnatemplatestnmsrfuncs.hpp:884-918
+struct asl_entry_t {
+    UINT32 assocMsrCount = 0;
+    UINT32 amlStnIndex = 0;
+    UINT16 validity = 1;   // 1 = valid station
+};
+
+// block metadata, include/config/dnatypes-structs.hpp:258-268
+struct blockMeta_t {
+    bool _blockIsolated = false, _blockFirst = false, _blockLast = false, _blockIntermediate = false;
+};
+
+// station appearance, include/config/dnatypes-structs.hpp:36-61
+struct stn_appear {
+    UINT32 station_id = 0;
+    bool first_appearance_fwd = false;
+    bool first_appearance_rev = false;
+};
+
+// include/config/dnaoptions.hpp:50-52
+enum { SimultaneousMode = 0, PhasedMode = 1, Phased_Block_1Mode = 2 };
+
+// include/exception/dnaexception.hpp:51-59
+typedef enum _ADJUST_STATUS_ {
+    ADJUST_SUCCESS = 0,
+    ADJUST_MAX_ITERATIONS_EXCEEDED = 1,
+    ADJUST_THRESHOLD_EXCEEDED = 2,
+    ADJUST_TEST_FAILED = 3,
+    ADJUST_BLOCK_ERROR = 4,
+    ADJUST_EXCEPTION_RAISED = 5,
+    ADJUST_CANCELLED = 6
+} ADJUST_STATUS;
+
+// The members of project_settings (include/config/dnaoptions.hpp) that dna_adjust reads on this path.
+struct general_settings {
+    std::string network_name;
+    std::string output_folder = ".";
+    std::string input_folder = ".";
+    UINT16 verbose = 0;
+    UINT16 quiet = 0;
+};
+struct segment_settings {
+    std::string asl_file;
+    std::string aml_file;
+    std::string seg_file;
+};
+struct adjust_settings {
+    UINT16 adjust_mode = SimultaneousMode;
+    UINT16 max_iterations = 10;
+    float confidence_interval = 95.0f;
+    UINT16 report_mode = 0;
+    UINT16 multi_thread = 0;
+    UINT16 stage = 0;
+    UINT16 scale_normals_to_unity = 0;
+    float iteration_threshold = 0.0005f;
+    double free_std_dev = 10.0;
+    double fixed_std_dev = 1.0e-6;   // PRECISION_1E6
+    std::string bst_file, bms_file, seg_file;
+    int max_threads = 0;
+    // device selection (not in the reference): which GPU this process drives
+    int device = 0;
+};
+struct project_settings {
+    general_settings g;
+    segment_settings s;
+    adjust_settings a;
+};
+
+}  // namespace dynadjust

@@ -1,0 +1,238 @@
+// Synthetic GNSS networks written as real .bst/.bms/.asl/.seg files:
+// an R x C grid of stations, E / N / NE baselines thinned to an exact count, full 3x3
+// baseline VCVs, four constrained corner stations and a strip segmentation into B blocks
+// whose junction stations satisfy JSL(k) subset ISL(k+1) (the invariant the reference's
+// CarryStnEstimatesandVariancesForward relies on, dnaadjust.cpp:1072).
+#include "synth.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <stdexcept>
+
+#include "dnaio.hpp"
+#include "geodesy.hpp"
+
+namespace dynadjust {
+namespace synth {
+
+namespace {
+
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }  // [0,1)
+    double normal() {
+        double u1 = uniform(), u2 = uniform();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925 * u2);
+    }
+};
+
+void put_str(char* dst, size_t cap, const char* src) {
+    memset(dst, 0, cap);
+    snprintf(dst, cap, "%s", src);
+}
+
+}  // namespace
+
+void write_network(const std::string& dir, const std::string& name, const Spec& sp, Summary* summary) {
+    using namespace geodesy;
+    const uint32_t R = sp.rows, C = sp.cols, B = std::max<uint32_t>(1, sp.n_blocks);
+    if (R < 2 || C < 2) throw std::runtime_error("synth: the grid needs at least 2 x 2 stations");
+    const uint64_t n_stn = (uint64_t)R * C;
+    const uint64_t n_cand = (uint64_t)R * (C - 1) + (uint64_t)(R - 1) * C + (uint64_t)(R - 1) * (C - 1);
+    uint64_t target = sp.n_baselines ? sp.n_baselines : n_cand;
+    if (target > n_cand) throw std::runtime_error("synth: more baselines requested than the grid has E/N/NE neighbours");
+    if (B > R) throw std::runtime_error("synth: more blocks than grid rows");
+    const Ellipsoid ell;
+    const double deg = 3.14159265358979323846 / 180.0;
+    const double lat0 = -36.5 * deg, lon0 = 146.0 * deg, step = 0.01 * deg;
+    SplitMix64 rng(sp.seed);
+
+    // stations: truth, then perturbed initial coordinates
+    std::vector<double> truth(3 * n_stn);
+    std::vector<double> tlat(n_stn), tlon(n_stn);
+    std::vector<station_t> bst(n_stn);
+    for (uint32_t r = 0; r < R; ++r)
+        for (uint32_t c = 0; c < C; ++c) {
+            uint64_t s = (uint64_t)r * C + c;
+            double lat = lat0 + ((double)r - 0.5 * (R - 1)) * step;
+            double lon = lon0 + ((double)c - 0.5 * (C - 1)) * step;
+            double h = 200.0 + 100.0 * rng.uniform();
+            tlat[s] = lat;
+            tlon[s] = lon;
+            GeoToCart(lat, lon, h, &truth[3 * s], &truth[3 * s + 1], &truth[3 * s + 2], ell);
+            double x = truth[3 * s] + sp.initial_sigma * rng.normal();
+            double y = truth[3 * s + 1] + sp.initial_sigma * rng.normal();
+            double z = truth[3 * s + 2] + sp.initial_sigma * rng.normal();
+            double ilat, ilon, ih;
+            CartToGeo(x, y, z, &ilat, &ilon, &ih, ell);
+            station_t& st = bst[s];
+            memset(&st, 0, sizeof(st));
+            char nm[32];
+            snprintf(nm, sizeof(nm), "S%08llu", (unsigned long long)s);
+            put_str(st.stationName, sizeof(st.stationName), nm);
+            put_str(st.stationNameOrig, sizeof(st.stationNameOrig), nm);
+            bool corner = (r == 0 || r == R - 1) && (c == 0 || c == C - 1);
+            put_str(st.stationConst, sizeof(st.stationConst), corner ? "CCC" : "FFF");
+            put_str(st.stationType, sizeof(st.stationType), "LLh");
+            st.suppliedStationType = LLh_type_i;
+            st.initialLatitude = st.currentLatitude = ilat;
+            st.initialLongitude = st.currentLongitude = ilon;
+            st.initialHeight = st.currentHeight = ih;
+            st.suppliedHeightRefFrame = ELLIPSOIDAL_type_i;
+            st.fileOrder = (UINT32)s;
+            st.nameOrder = (UINT32)s;
+            put_str(st.epsgCode, sizeof(st.epsgCode), "7843");
+            put_str(st.epoch, sizeof(st.epoch), "01.01.2020");
+            put_str(st.observation_epoch, sizeof(st.observation_epoch), "01.01.2020");
+            put_str(st.description, sizeof(st.description), "synthetic grid station");
+        }
+
+    // baselines: selection sampling of exactly `target` of the candidate edges (Knuth 3.4.2 S)
+    std::vector<measurement_t> bms;
+    bms.reserve(3 * target);
+    std::vector<uint32_t> bl_s1, bl_s2;
+    bl_s1.reserve(target);
+    bl_s2.reserve(target);
+    uint64_t remaining = n_cand, need = target;
+    const double sd[3] = {sp.sigma_e, sp.sigma_n, sp.sigma_up};
+    auto consider = [&](uint64_t s1, uint64_t s2) {
+        bool take = (double)need > rng.uniform() * (double)remaining;
+        --remaining;
+        if (!take || need == 0) return;
+        --need;
+        double Rm[3][3];
+        LocalToCartRotation(tlat[s1], tlon[s1], Rm);
+        double V[3][3], eps[3] = {0, 0, 0};
+        double zr[3] = {rng.normal(), rng.normal(), rng.normal()};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < 3; ++k) v += Rm[i][k] * sd[k] * sd[k] * Rm[j][k];
+                V[i][j] = v;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 3; ++k) eps[i] += Rm[i][k] * sd[k] * zr[k];
+        uint32_t idx = (uint32_t)bl_s1.size();
+        bl_s1.push_back((uint32_t)s1);
+        bl_s2.push_back((uint32_t)s2);
+        for (int e = 0; e < 3; ++e) {
+            measurement_t m;
+            memset(&m, 0, sizeof(m));
+            m.measType = 'G';
+            m.measStart = (char)e;
+            m.measurementStations = 2;
+            put_str(m.epsgCode, sizeof(m.epsgCode), "7843");
+            put_str(m.epoch, sizeof(m.epoch), "01.01.2020");
+            put_str(m.observation_epoch, sizeof(m.observation_epoch), "01.01.2020");
+            put_str(m.coordType, sizeof(m.coordType), "XYZ");
+            m.ignore = false;
+            m.station1 = (UINT32)s1;
+            m.station2 = (UINT32)s2;
+            m.vectorCount1 = (e == 0) ? 1 : 0;
+            m.clusterID = idx;
+            m.fileOrder = idx;
+            m.term1 = (truth[3 * s2 + e] - truth[3 * s1 + e]) + eps[e];
+            if (e == 0) {
+                m.term2 = V[0][0];
+            } else if (e == 1) {
+                m.term2 = V[0][1];
+                m.term3 = V[1][1];
+            } else {
+                m.term2 = V[0][2];
+                m.term3 = V[1][2];
+                m.term4 = V[2][2];
+            }
+            m.scale1 = m.scale2 = m.scale3 = m.scale4 = 1.0;
+            m.preAdjMeas = m.term1;
+            bms.push_back(m);
+        }
+    };
+    for (uint32_t r = 0; r < R; ++r)
+        for (uint32_t c = 0; c < C; ++c) {
+            uint64_t s = (uint64_t)r * C + c;
+            if (c + 1 < C) consider(s, s + 1);
+            if (r + 1 < R) consider(s, s + C);
+            if (r + 1 < R && c + 1 < C) consider(s, s + C + 1);
+        }
+    const uint64_t n_bl = bl_s1.size();
+
+    // associated station list
+    std::vector<asl_entry_t> asl(n_stn);
+    for (uint64_t i = 0; i < n_bl; ++i) {
+        asl[bl_s1[i]].assocMsrCount++;
+        asl[bl_s2[i]].assocMsrCount++;
+    }
+    uint32_t off = 0;
+    for (uint64_t s = 0; s < n_stn; ++s) {
+        asl[s].amlStnIndex = off;
+        off += asl[s].assocMsrCount;
+        asl[s].validity = 1;
+    }
+
+    // strip segmentation
+    iostreams::seg_data_t seg;
+    seg.blockCount = B;
+    seg.blockThreshold = 0;
+    seg.minInnerStns = 0;
+    seg.ISL.assign(B, {});
+    seg.JSL.assign(B, {});
+    seg.CML.assign(B, {});
+    seg.ContiguousNetList.assign(B, 0);
+    const uint32_t rows_per = (R + B - 1) / B;
+    auto strip_of = [&](uint64_t s) {
+        uint32_t k = (uint32_t)((s / C) / rows_per);
+        return k >= B ? B - 1 : k;
+    };
+    for (uint64_t s = 0; s < n_stn; ++s) seg.ISL[strip_of(s)].push_back((UINT32)s);
+    for (uint64_t i = 0; i < n_bl; ++i) {
+        uint32_t k1 = strip_of(bl_s1[i]), k2 = strip_of(bl_s2[i]);
+        uint32_t k = std::min(k1, k2);
+        seg.CML[k].push_back((UINT32)(3 * i));
+        if (k1 != k) seg.JSL[k].push_back(bl_s1[i]);
+        if (k2 != k) seg.JSL[k].push_back(bl_s2[i]);
+    }
+    for (uint32_t k = 0; k < B; ++k) {
+        std::sort(seg.JSL[k].begin(), seg.JSL[k].end());
+        seg.JSL[k].erase(std::unique(seg.JSL[k].begin(), seg.JSL[k].end()), seg.JSL[k].end());
+        if (seg.ISL[k].empty()) throw std::runtime_error("synth: empty strip (reduce the block count)");
+    }
+
+    binary_file_meta_t meta;
+    put_str(meta.modifiedBy, sizeof(meta.modifiedBy), "dnagpu-synth");
+    put_str(meta.epsgCode, sizeof(meta.epsgCode), "7843");
+    put_str(meta.epoch, sizeof(meta.epoch), "01.01.2020");
+    put_str(meta.observation_epoch, sizeof(meta.observation_epoch), "01.01.2020");
+    meta.reduced = false;
+    const std::string base = dir + "/" + name;
+    iostreams::write_bst(base + ".bst", bst, meta);
+    iostreams::write_bms(base + ".bms", bms, meta);
+    iostreams::write_asl(base + ".asl", asl);
+    iostreams::write_seg(base + ".seg", seg, base + ".bst", base + ".bms", bms);
+    {
+        std::ofstream t(base + ".truth", std::ios::binary | std::ios::trunc);
+        t.write(reinterpret_cast<const char*>(truth.data()), (std::streamsize)(truth.size() * sizeof(double)));
+        if (!t) throw std::runtime_error("synth: cannot write " + base + ".truth");
+    }
+    if (summary) {
+        summary->stations = n_stn;
+        summary->baselines = n_bl;
+        summary->measurement_rows = 3 * n_bl;
+        summary->blocks = B;
+        summary->max_block_unknowns = 0;
+        for (uint32_t k = 0; k < B; ++k)
+            summary->max_block_unknowns = std::max<uint64_t>(summary->max_block_unknowns, 3 * (seg.ISL[k].size() + seg.JSL[k].size()));
+    }
+}
+
+}  // namespace synth
+}  // namespace dynadjust

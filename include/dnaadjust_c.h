@@ -1,0 +1,98 @@
+/*
+ * dnaadjust_c.h -- C-ABI over the C++ drop-in class dynadjust::networkadjust::dna_adjust
+ * (dynadjust_amd/csrc/host/dna_adjust.hpp), which mirrors the reference's
+ * dna_adjust entry points (dynadjust/dynadjust/dnaadjust/dnaadjust.hpp:259-405 of
+ * /root/reference): PrepareAdjustment / AdjustNetwork / getters.  This is what a non-C++
+ * host (the Python tests and bench, or a cgo/JNI caller) binds; the reference's own
+ * dnaadjustwrapper would link the C++ class directly.
+ *
+ * All functions return 0 on success or a negative code; the text of the C++ exception
+ * that the reference would have thrown is available through dnaadj_last_error().
+ */
+#ifndef DNAADJUST_C_H_
+#define DNAADJUST_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dnaadj_handle dnaadj_handle;
+
+/* subset of project_settings (include/config/dnaoptions.hpp:425-493) read by the path */
+typedef struct {
+    const char* bst_file;      /* a.bst_file */
+    const char* bms_file;      /* a.bms_file */
+    const char* asl_file;      /* s.asl_file (may be NULL: every station valid) */
+    const char* seg_file;      /* a.seg_file (phased mode) */
+    int adjust_mode;           /* 0 SimultaneousMode, 1 PhasedMode */
+    int multi_thread;          /* --multi-thread: forward and reverse chains on separate streams */
+    int max_iterations;        /* default 10 */
+    float iteration_threshold; /* default 0.0005 */
+    double free_std_dev;       /* default 10 */
+    double fixed_std_dev;      /* default 1e-6 */
+    int scale_normals_to_unity;
+    int device;                /* HIP device ordinal of this process */
+} dnaadj_settings;
+
+#define DNAADJ_OK 0
+#define DNAADJ_EXCEPTION (-1)   /* the reference would have thrown; see dnaadj_last_error() */
+#define DNAADJ_EINVAL (-2)
+
+void dnaadj_default_settings(dnaadj_settings* s);
+int dnaadj_create(dnaadj_handle** out);
+void dnaadj_destroy(dnaadj_handle* h);
+const char* dnaadj_last_error(const dnaadj_handle* h);
+
+int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s);        /* dna_adjust::PrepareAdjustment */
+int dnaadj_adjust(dnaadj_handle* h, int* status);                      /* dna_adjust::AdjustNetwork -> _ADJUST_STATUS_ */
+int dnaadj_cancel(dnaadj_handle* h);                                   /* dna_adjust::CancelAdjustment */
+
+uint32_t dnaadj_block_count(const dnaadj_handle* h);                   /* blockCount() */
+uint32_t dnaadj_iterations(const dnaadj_handle* h);                    /* CurrentIteration() */
+double dnaadj_max_correction(const dnaadj_handle* h);                  /* GetMaxCorrection() */
+double dnaadj_iteration_correction(const dnaadj_handle* h, uint32_t iteration);
+uint32_t dnaadj_measurement_count(const dnaadj_handle* h);             /* GetMeasurementCount() */
+uint32_t dnaadj_unknowns_count(const dnaadj_handle* h);                /* GetUnknownsCount() */
+int dnaadj_degrees_of_freedom(const dnaadj_handle* h);                 /* GetDegreesOfFreedom() */
+double dnaadj_adjust_time_ms(const dnaadj_handle* h);                  /* adjustTime() */
+double dnaadj_solve_flops(const dnaadj_handle* h);                     /* sum n^3 over Solve() calls */
+uint32_t dnaadj_solve_count(const dnaadj_handle* h);
+uint32_t dnaadj_station_count(const dnaadj_handle* h);
+
+uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block);
+int dnaadj_block_stations(dnaadj_handle* h, uint32_t block, uint32_t* stations);           /* global ids, ascending */
+int dnaadj_block_estimates(dnaadj_handle* h, uint32_t block, double* xyz);                 /* v_rigorousStations_ */
+int dnaadj_block_variances_packed(dnaadj_handle* h, uint32_t block, double* packed);       /* v_rigorousVariances_ */
+int dnaadj_adjusted_coordinates(dnaadj_handle* h, double* xyz);                            /* 3 per bst station */
+
+/* device context of the adjustment (for dnagpu_profile_*), NULL before prepare */
+void* dnaadj_device_context(dnaadj_handle* h);
+
+/* ---- synthetic networks: writes <dir>/<name>.{bst,bms,asl,seg,truth} ---- */
+typedef struct {
+    uint32_t rows, cols;
+    uint64_t n_baselines;   /* 0 = all E/N/NE neighbours */
+    uint32_t n_blocks;
+    uint64_t seed;
+    double initial_sigma;
+} dnasynth_spec;
+typedef struct {
+    uint64_t stations, baselines, measurement_rows, blocks, max_block_unknowns;
+} dnasynth_summary;
+int dnasynth_write_network(const char* dir, const char* name, const dnasynth_spec* spec, dnasynth_summary* out, char* err,
+                           size_t errlen);
+
+/* ---- file format helpers for tests (byte-exact readers of the reference's formats) ---- */
+/* returns record counts; any pointer may be NULL */
+int dnaio_file_summary(const char* bst, const char* bms, const char* asl, uint64_t* n_stn, uint64_t* n_msr, uint64_t* n_asl, char* err,
+                       size_t errlen);
+size_t dnaio_sizeof_station(void);
+size_t dnaio_sizeof_measurement(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

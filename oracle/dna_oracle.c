@@ -1,0 +1,867 @@
+/*
+ * dna_oracle.c -- CPU restatement of DynAdjust's phased / simultaneous adjustment path.
+ * TEST INFRASTRUCTURE ONLY (see dna_oracle.h).  Build with -ffp-contract=off.
+ *
+ * Reference files (under /root/reference/dynadjust/):
+ *   ADJ  = dynadjust/dnaadjust/dnaadjust.cpp
+ *   MAT  = include/math/dnamatrix_contiguous.cpp      MATH = ...contiguous.hpp
+ *   SEG  = include/io/seg_file.cpp
+ */
+#define _GNU_SOURCE
+#include "dna_oracle.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ========================================================================== */
+/* L2: matrix_2d                                                               */
+/* ========================================================================== */
+
+/* MATH:363-365 */
+size_t orc_packed_index(uint32_t n, uint32_t i, uint32_t j) {
+    return (size_t)j * n - (j ? (size_t)j * (j - 1) / 2 : 0) + (i - j);
+}
+
+typedef void (*lapack_potrf_t)(const char*, const int*, double*, const int*, int*);
+static lapack_potrf_t ext_potrf = NULL, ext_potri = NULL;
+static void* ext_handle = NULL;
+static char lapack_name[512] = "builtin";
+
+int orc_set_lapack(const char* lib) {
+    if (ext_handle) {
+        dlclose(ext_handle);
+        ext_handle = NULL;
+    }
+    ext_potrf = ext_potri = NULL;
+    snprintf(lapack_name, sizeof(lapack_name), "builtin");
+    if (!lib || !*lib) return 0;
+    void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return -1;
+    lapack_potrf_t f = (lapack_potrf_t)dlsym(h, "dpotrf_");
+    lapack_potrf_t g = (lapack_potrf_t)dlsym(h, "dpotri_");
+    if (!f || !g) {
+        dlclose(h);
+        return -2;
+    }
+    ext_handle = h;
+    ext_potrf = f;
+    ext_potri = g;
+    snprintf(lapack_name, sizeof(lapack_name), "%s", lib);
+    return 0;
+}
+
+const char* orc_lapack_name(void) { return lapack_name; }
+
+#define A_(i, j) a[(size_t)(j) * lda + (i)]
+
+/* dpotrf('L'), unblocked left-looking column Cholesky (LAPACK dpotf2 lower) */
+static int builtin_potrf_lower(uint32_t n, double* a, uint32_t lda) {
+    for (uint32_t j = 0; j < n; ++j) {
+        double ajj = A_(j, j);
+        for (uint32_t k = 0; k < j; ++k) ajj -= A_(j, k) * A_(j, k);
+        if (!(ajj > 0.0)) {
+            A_(j, j) = ajj;
+            return (int)j + 1;
+        }
+        ajj = sqrt(ajj);
+        A_(j, j) = ajj;
+        /* a[j+1:, j] -= A[j+1:, 0:j] * a[j, 0:j]^T  (column sweeps: contiguous) */
+        for (uint32_t k = 0; k < j; ++k) {
+            double ajk = A_(j, k);
+            if (ajk == 0.0) continue;
+            double* col = &A_(0, k);
+            double* dst = &A_(0, j);
+            for (uint32_t i = j + 1; i < n; ++i) dst[i] -= col[i] * ajk;
+        }
+        double r = 1.0 / ajj;
+        for (uint32_t i = j + 1; i < n; ++i) A_(i, j) *= r;
+    }
+    return 0;
+}
+
+/* dpotri('L') = dtrti2('L','N') followed by dlauu2('L') */
+static int builtin_potri_lower(uint32_t n, double* a, uint32_t lda) {
+    /* dtrti2 lower, non-unit: columns from last to first */
+    for (uint32_t jj = n; jj-- > 0;) {
+        if (A_(jj, jj) == 0.0) return (int)jj + 1;
+        A_(jj, jj) = 1.0 / A_(jj, jj);
+        double ajj = -A_(jj, jj);
+        if (jj + 1 < n) {
+            /* x = L22^-1 (already inverted, lower) * a[jj+1:, jj]   (dtrmv lower, no-trans) */
+            for (uint32_t i = n; i-- > jj + 1;) {
+                double s = 0.0;
+                for (uint32_t k = jj + 1; k <= i; ++k) s += A_(i, k) * A_(k, jj);
+                A_(i, jj) = s;  /* rows below i are already final; row i only needs k <= i of the old vector */
+            }
+            for (uint32_t i = jj + 1; i < n; ++i) A_(i, jj) *= ajj;
+        }
+    }
+    /* dlauu2 lower: A = L^T L */
+    for (uint32_t i = 0; i < n; ++i) {
+        double aii = A_(i, i);
+        if (i + 1 < n) {
+            double d = 0.0;
+            for (uint32_t k = i; k < n; ++k) d += A_(k, i) * A_(k, i);
+            /* row i, columns 0..i-1:  a(i,j) = aii*a(i,j) + sum_{k>i} a(k,i) a(k,j) */
+            for (uint32_t j = 0; j < i; ++j) {
+                double s = aii * A_(i, j);
+                for (uint32_t k = i + 1; k < n; ++k) s += A_(k, i) * A_(k, j);
+                A_(i, j) = s;
+            }
+            A_(i, i) = d;
+        } else {
+            for (uint32_t j = 0; j <= i; ++j) A_(i, j) *= aii;
+        }
+    }
+    return 0;
+}
+
+int orc_potrf_lower(uint32_t n, double* a, uint32_t lda) {
+    if (ext_potrf) {
+        int nn = (int)n, ld = (int)lda, info = 0;
+        ext_potrf("L", &nn, a, &ld, &info);
+        return info;
+    }
+    return builtin_potrf_lower(n, a, lda);
+}
+
+int orc_potri_lower(uint32_t n, double* a, uint32_t lda) {
+    if (ext_potri) {
+        int nn = (int)n, ld = (int)lda, info = 0;
+        ext_potri("L", &nn, a, &ld, &info);
+        return info;
+    }
+    return builtin_potri_lower(n, a, lda);
+}
+#undef A_
+
+/* MAT:993-1019 (non-packed path, LOWER_IS_CLEARED = false, fillupper) */
+int orc_cholesky_inverse_full(double* a, uint32_t n, uint32_t lda) {
+    if (n < 1) return 0;
+    int info = orc_potrf_lower(n, a, lda);
+    if (info) return info;
+    info = orc_potri_lower(n, a, lda);
+    if (info) return info;
+    for (uint32_t j = 0; j < n; ++j)
+        for (uint32_t i = j + 1; i < n; ++i) a[(size_t)i * lda + j] = a[(size_t)j * lda + i];
+    return 0;
+}
+
+/* MAT:962-991 */
+int orc_cholesky_inverse_packed(double* ap, uint32_t n) {
+    if (n < 1) return 0;
+    double* full = (double*)malloc((size_t)n * n * sizeof(double));
+    if (!full) return -1;
+    for (uint32_t j = 0; j < n; ++j)
+        for (uint32_t i = j; i < n; ++i) full[(size_t)j * n + i] = ap[orc_packed_index(n, i, j)];
+    int info = orc_potrf_lower(n, full, n);
+    if (!info) info = orc_potri_lower(n, full, n);
+    if (!info)
+        for (uint32_t j = 0; j < n; ++j)
+            for (uint32_t i = j; i < n; ++i) ap[orc_packed_index(n, i, j)] = full[(size_t)j * n + i];
+    free(full);
+    return info;
+}
+
+/* MAT:1145-1152 */
+void orc_scale_symmetric_diagonal_packed(double* ap, uint32_t n, const double* diag) {
+    for (uint32_t j = 0; j < n; ++j)
+        for (uint32_t i = j; i < n; ++i) ap[orc_packed_index(n, i, j)] *= diag[i] * diag[j];
+}
+
+/* MAT:1471-1497: cblas_dspmv(ColMajor, Lower) restated: y = A x */
+void orc_multiply_sym_packed(const double* ap, const double* x, double* y, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) y[i] = 0.0;
+    size_t kk = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        double t1 = x[j], t2 = 0.0;
+        y[j] += t1 * ap[kk];
+        size_t k = kk + 1;
+        for (uint32_t i = j + 1; i < n; ++i, ++k) {
+            y[i] += t1 * ap[k];
+            t2 += ap[k] * x[i];
+        }
+        y[j] += t2;
+        kk += n - j;
+    }
+}
+
+/* ADJ:6614-6645 around ADJ:8472 (FormInverseVarianceMatrix: 1x1 special case ADJ:8474) */
+int orc_inverse_normals_packed(double* ap, uint32_t n, int scale_to_unity) {
+    if (n == 1) {
+        ap[0] = 1.0 / ap[0];
+        return 0;
+    }
+    double* s = NULL;
+    if (scale_to_unity) {
+        s = (double*)malloc((size_t)n * sizeof(double));
+        for (uint32_t i = 0; i < n; ++i) s[i] = 1.0 / sqrt(ap[orc_packed_index(n, i, i)]);
+        orc_scale_symmetric_diagonal_packed(ap, n, s);
+    }
+    int info = orc_cholesky_inverse_packed(ap, n);
+    if (!info && scale_to_unity) orc_scale_symmetric_diagonal_packed(ap, n, s);
+    free(s);
+    return info;
+}
+
+/* ========================================================================== */
+/* geodesy: GeoToCart (dnatemplategeodesyfuncs.hpp:78-90), GRS80 ellipsoid      */
+/* ========================================================================== */
+void orc_geo_to_cart(double lat, double lon, double h, double* x, double* y, double* z) {
+    const double a = 6378137.0, inv_f = 298.257222101;
+    const double f = 1.0 / inv_f;
+    const double e2 = 2.0 * f - f * f;
+    double s = sin(lat);
+    double nu = a / sqrt(1.0 - e2 * s * s);
+    *x = (nu + h) * cos(lat) * cos(lon);
+    *y = (nu + h) * cos(lat) * sin(lon);
+    *z = ((nu * (1.0 - e2)) + h) * sin(lat);
+}
+
+/* ========================================================================== */
+/* measurement weights: ADJ:4214-4309 -> ADJ:8472 (dpotrf 'U' + dpotri 'U', 3x3) */
+/* The formulas below are the 3x3 instance of U^T U factorisation, inversion of */
+/* U and U^-1 U^-T, written in the same operation order as the device kernel.    */
+/* ========================================================================== */
+int orc_weight_3x3(const double* v, double* w) {
+    double v11 = v[0], v12 = v[1], v22 = v[2], v13 = v[3], v23 = v[4], v33 = v[5];
+    double u11 = sqrt(v11);
+    double u12 = v12 / u11;
+    double u13 = v13 / u11;
+    double d22 = v22 - u12 * u12;
+    double u22 = sqrt(d22);
+    double u23 = (v23 - u12 * u13) / u22;
+    double d33 = (v33 - u13 * u13) - u23 * u23;
+    double u33 = sqrt(d33);
+    if (!(v11 > 0.0) || !(d22 > 0.0) || !(d33 > 0.0)) return 1;
+    double t11 = 1.0 / u11, t22 = 1.0 / u22, t33 = 1.0 / u33;
+    double t12 = -(t11 * u12) * t22;
+    double t23 = -(t22 * u23) * t33;
+    double t13 = -(t11 * (u12 * t23 + u13 * t33));
+    w[0] = (t11 * t11 + t12 * t12) + t13 * t13;
+    w[1] = t12 * t22 + t13 * t23;
+    w[2] = t22 * t22 + t23 * t23;
+    w[3] = t13 * t33;
+    w[4] = t23 * t33;
+    w[5] = t33 * t33;
+    return 0;
+}
+
+static inline int sym6(int i, int j) {
+    int lo = i < j ? i : j, hi = i < j ? j : i;
+    return hi * (hi + 1) / 2 + lo;
+}
+
+/* ========================================================================== */
+/* adjustment                                                                  */
+/* ========================================================================== */
+typedef struct {
+    uint32_t k;          /* stations in the set */
+    uint32_t* stn;       /* global ids (junction order) */
+    double* W;           /* packed 3k x 3k: copy of the inverted junction variances (what the
+                            reference copies into the grown AtVinv columns) */
+    uint32_t row0;       /* first row in b */
+} pseudo_set;
+
+typedef struct {
+    uint32_t n_stn, n;
+    uint32_t* stations;          /* v_parameterStationList_ (ascending), ADJ:10477-10480 */
+    uint8_t *first_fwd, *first_rev;
+    int first, last, isolated;   /* blockMeta_t, ADJ:10449-10474 */
+    uint32_t n_jsl;
+    const uint32_t* jsl;         /* v_JSL_[block], file order */
+    uint32_t n_cml;
+    const uint32_t* cml;
+    uint32_t m;                  /* design rows of real measurements */
+    double *N, *NR;              /* v_normals_, v_normalsR_ (packed) */
+    double *est, *orig, *rig;    /* v_estimatedStations_, v_originalStations_, v_rigorousStations_ */
+    double* rigvar;              /* v_rigorousVariances_ (packed) */
+    double *corr, *corrR;        /* v_corrections_, v_correctionsR_ */
+    double* b;                   /* v_measMinusComp_ (grown capacity) */
+    uint32_t b_rows;
+    pseudo_set ps[2];
+    uint32_t n_ps;
+    double *jvar, *jvarFwd;      /* v_junctionVariances_, v_junctionVariancesFwd_ (packed 3*n_jsl) */
+    double *jestFwd;             /* v_junctionEstimatesFwd_[block]     (3*n_jsl) */
+    double *jestRev;             /* v_junctionEstimatesRev_[block]     (3*|JSL(block-1)|) */
+} blk_t;
+
+struct orc_adjustment {
+    orc_network net;
+    orc_settings set;
+    int phased;
+    uint32_t n_blocks;
+    blk_t* blk;
+    double* W;                   /* 6 per baseline */
+    uint32_t* simul_stations;    /* 0..n-1 for simultaneous mode */
+    uint32_t* simul_cml;
+    double var_C, var_F;
+    uint32_t iterations;
+    double max_corr_hist[64];
+    double maxCorr;
+    uint64_t solves;
+    double sum_n3;
+    char err[512];
+};
+
+static size_t psize(uint32_t n) { return (size_t)n * (n + 1) / 2; }
+
+/* v_blockStationsMap_.at(block)[stn] (std::map in the reference, ADJ:10498) */
+static uint32_t local_index(const blk_t* B, uint32_t stn) {
+    uint32_t lo = 0, hi = B->n_stn;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) / 2;
+        if (B->stations[mid] < stn)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo; /* caller guarantees membership (the reference does not check either, ADJ:1072) */
+}
+
+/* matrix_2d::lower_add on a packed matrix, MATH:405-411 */
+static inline void lower_add(double* N, uint32_t n, uint32_t r, uint32_t c, double v) {
+    if (r < c) return;
+    N[orc_packed_index(n, r, c)] += v;
+}
+
+static inline double packed_get(const double* P, uint32_t n, uint32_t i, uint32_t j) {
+    if (i < j) {
+        uint32_t t = i;
+        i = j;
+        j = t;
+    }
+    return P[orc_packed_index(n, i, j)];
+}
+
+static int cmp_u32(const void* a, const void* b) {
+    uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return x < y ? -1 : x > y;
+}
+
+/* UpdateNormals_G (ADJ:1664-1684) via add_normal_3x3_from_atvinv_columns (ADJ:1478-1491):
+ * AtVinv(stn1 rows) = -W, AtVinv(stn2 rows) = +W (ADJ:5388-5389). */
+static void update_normals_G(double* N, uint32_t n, uint32_t s1, uint32_t s2, const double* w6) {
+    /* station 2, scale 1:  N[s2+r][s2+c] += 1 * (+W[r][c]) */
+    for (int col = 0; col < 3; ++col)
+        for (int r = 0; r < 3; ++r) lower_add(N, n, s2 + r, s2 + col, 1. * w6[sym6(r, col)]);
+    /* station 1, scale -1: N[s1+r][s1+c] += -1 * (-W[r][c]) */
+    for (int col = 0; col < 3; ++col)
+        for (int r = 0; r < 3; ++r) lower_add(N, n, s1 + r, s1 + col, -1. * (-w6[sym6(r, col)]));
+    /* (stn1, stn2), scale 1:  += 1 * (-W) */
+    for (int col = 0; col < 3; ++col)
+        for (int r = 0; r < 3; ++r) lower_add(N, n, s1 + r, s2 + col, 1. * (-w6[sym6(r, col)]));
+    /* (stn2, stn1), scale -1: += -1 * (+W) */
+    for (int col = 0; col < 3; ++col)
+        for (int r = 0; r < 3; ++r) lower_add(N, n, s2 + r, s1 + col, -1. * w6[sym6(r, col)]);
+}
+
+/* UpdateNormals (ADJ:1364) for a GNSS-only block */
+static void update_normals(orc_adjustment* a, blk_t* B) {
+    for (uint32_t c = 0; c < B->n_cml; ++c) {
+        uint32_t i = B->cml[c];
+        uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
+        uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
+        update_normals_G(B->N, B->n, s1, s2, a->W + (size_t)i * 6);
+    }
+}
+
+/* FillDesignNormalMeasurementsMatrices(false) (ADJ:3888) -> UpdateDesignMeasMatrices_GX (ADJ:5283):
+ * b = term1 - (x2 - x1), AddMsrtoMeasMinusComp (ADJ:4719) */
+static void compute_b(orc_adjustment* a, blk_t* B, const double* est) {
+    for (uint32_t c = 0; c < B->n_cml; ++c) {
+        uint32_t i = B->cml[c];
+        uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
+        uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
+        for (int k = 0; k < 3; ++k) B->b[3 * c + k] = a->net.obs[3 * (size_t)i + k] - (est[s2 + k] - est[s1 + k]);
+    }
+}
+
+/* FormConstraintStationVarianceMatrix (ADJ:2041): CCC / FFF only */
+static int constraint_weight(const orc_adjustment* a, uint32_t stn, double* w) {
+    const char* c = a->net.constraints + 3 * (size_t)stn;
+    if (c[0] == 'C' && c[1] == 'C' && c[2] == 'C') {
+        *w = 1. / a->var_C;
+        return 0;
+    }
+    if (c[0] == 'F' && c[1] == 'F' && c[2] == 'F') {
+        *w = 1. / a->var_F;
+        return 0;
+    }
+    return -1;
+}
+
+/* blockadd / blocksubtract of the (diagonal) 3x3 constraint weight, packed dest */
+static void add_constraint(double* N, uint32_t n, uint32_t s, double w, double sign) {
+    for (int col = 0; col < 3; ++col)
+        for (int r = 0; r < 3; ++r) {
+            if (s + r < s + col) continue;
+            N[orc_packed_index(n, s + r, s + col)] += sign * (r == col ? w : 0.0);
+        }
+}
+
+/* AddConstraintStationstoNormals{Forward ADJ:1884, Reverse :1923, Combine :1960, Simultaneous :2010} */
+enum { CON_FWD, CON_REV, CON_CMB, CON_SIM };
+static int add_constraints(orc_adjustment* a, blk_t* B, int which) {
+    for (uint32_t p = 0; p < B->n_stn; ++p) {
+        double w, sign = 1.0;
+        if (which == CON_FWD && !B->first_fwd[p]) continue;
+        if (which == CON_REV && !B->first_rev[p]) continue;
+        if (which == CON_CMB) {
+            if (B->first_fwd[p]) continue;
+            sign = -1.0;
+        }
+        if (constraint_weight(a, B->stations[p], &w)) {
+            snprintf(a->err, sizeof(a->err), "oracle: mixed station constraints are not restated (station %u)", B->stations[p]);
+            return -1;
+        }
+        add_constraint(B->N, B->n, 3 * p, w, sign);
+    }
+    return 0;
+}
+
+/* Solve (ADJ:6586-6667) */
+static int solve(orc_adjustment* a, blk_t* B, int compute_inverse, uint32_t block) {
+    uint32_t n = B->n;
+    if (compute_inverse) {
+        int info = orc_inverse_normals_packed(B->N, n, a->set.scale_normals_to_unity);
+        a->solves++;
+        a->sum_n3 += (double)n * n * n;
+        if (info || isnan(B->N[0]) || isinf(B->N[0])) {
+            snprintf(a->err, sizeof(a->err), "Matrix inversion failed, the matrix is singular. (block %u, info %d)", block + 1, info);
+            return -1;
+        }
+    }
+    /* At_Vinv_m = AtVinv * measMinusComp (ADJ:6659-6660); AtVinv is never materialised */
+    double* rhs = (double*)calloc(n ? n : 1, sizeof(double));
+    for (uint32_t c = 0; c < B->n_cml; ++c) {
+        uint32_t i = B->cml[c];
+        const double* w = a->W + (size_t)i * 6;
+        const double* bb = B->b + 3 * (size_t)c;
+        uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
+        uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
+        for (int r = 0; r < 3; ++r) {
+            double wb = (w[sym6(r, 0)] * bb[0] + w[sym6(r, 1)] * bb[1]) + w[sym6(r, 2)] * bb[2];
+            rhs[s1 + r] += -wb;
+            rhs[s2 + r] += wb;
+        }
+    }
+    for (uint32_t q = 0; q < B->n_ps; ++q) {
+        const pseudo_set* P = &B->ps[q];
+        uint32_t nj = 3 * P->k;
+        for (uint32_t i = 0; i < nj; ++i) {
+            double acc = 0.0;
+            for (uint32_t j = 0; j < nj; ++j) acc += packed_get(P->W, nj, i, j) * B->b[P->row0 + j];
+            rhs[3 * local_index(B, P->stn[i / 3]) + i % 3] += acc;
+        }
+    }
+    /* corrections = N^-1 * At_Vinv_m (multiply_sym, ADJ:6665) */
+    orc_multiply_sym_packed(B->N, rhs, B->corr, n);
+    free(rhs);
+    return 0;
+}
+
+/* matrix_2d::compute_maximum_value (MAT:1532) on a column vector */
+static double max_value(const double* v, uint32_t n) {
+    uint32_t best = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (fabs(v[i]) > fabs(v[best])) best = i;
+    return n ? v[best] : 0.0;
+}
+
+static void free_pseudo(blk_t* B) {
+    for (uint32_t q = 0; q < 2; ++q) {
+        free(B->ps[q].W);
+        B->ps[q].W = NULL;
+        free(B->ps[q].stn);
+        B->ps[q].stn = NULL;
+    }
+    B->n_ps = 0;
+}
+
+/* shrink(): drop the last `sets` pseudo-measurement sets (rows of b / columns of AtVinv) */
+static void shrink_pseudo(blk_t* B, uint32_t sets) {
+    while (sets-- && B->n_ps) {
+        pseudo_set* P = &B->ps[B->n_ps - 1];
+        B->b_rows -= 3 * P->k;
+        free(P->W);
+        P->W = NULL;
+        free(P->stn);
+        P->stn = NULL;
+        B->n_ps--;
+    }
+}
+
+/* Steps 1-2 of CarryStnEstimatesandVariances{Forward ADJ:1006-1048, Reverse ADJ:1160-1202}:
+ * gather the junction block of the a-posteriori variances and the junction estimates, invert. */
+static int gather_junctions(orc_adjustment* a, const blk_t* From, const double* apost, const double* est, const uint32_t* jsl,
+                            uint32_t k, double* jvar, double* jest) {
+    uint32_t nj = 3 * k;
+    for (uint32_t p = 0; p < k; ++p) {
+        uint32_t sp = 3 * local_index(From, jsl[p]);
+        for (int c = 0; c < 3; ++c) jest[3 * p + c] = est[sp + c];
+        for (uint32_t q = p; q < k; ++q) {
+            uint32_t sq = 3 * local_index(From, jsl[q]);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    uint32_t i = 3 * q + r, j = 3 * p + c; /* lower part of the junction matrix */
+                    if (i < j) continue;
+                    jvar[orc_packed_index(nj, i, j)] = packed_get(apost, From->n, sq + r, sp + c);
+                }
+        }
+    }
+    if (nj == 0) return 0;
+    int info = orc_inverse_normals_packed(jvar, nj, 0); /* FormInverseVarianceMatrix(junctionVariances) */
+    a->solves += 0;
+    if (info) {
+        snprintf(a->err, sizeof(a->err), "Matrix inversion failed, the matrix is singular. (junction variances, info %d)", info);
+        return -1;
+    }
+    return 0;
+}
+
+/* Steps 4-5 of the carry functions (ADJ:1053-1127, 1204-1280, 3249-3319): grow b / AtVinv of
+ * the destination block by the junction pseudo measurements, add W_J into its normals. */
+static void attach_junctions(blk_t* To, const uint32_t* jsl, uint32_t k, const double* jvar, const double* jest) {
+    uint32_t nj = 3 * k;
+    pseudo_set* P = &To->ps[To->n_ps++];
+    P->k = k;
+    P->row0 = To->b_rows;
+    P->stn = (uint32_t*)malloc((k ? k : 1) * sizeof(uint32_t));
+    memcpy(P->stn, jsl, k * sizeof(uint32_t));
+    P->W = (double*)malloc((psize(nj) ? psize(nj) : 1) * sizeof(double));
+    memcpy(P->W, jvar, psize(nj) * sizeof(double));
+    To->b_rows += nj;
+    for (uint32_t p = 0; p < k; ++p) {
+        uint32_t sp = 3 * local_index(To, jsl[p]);
+        for (int c = 0; c < 3; ++c) To->b[P->row0 + 3 * p + c] = jest[3 * p + c] - To->est[sp + c];
+        for (uint32_t q = 0; q < k; ++q) {
+            uint32_t sq = 3 * local_index(To, jsl[q]);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) lower_add(To->N, To->n, sq + r, sp + c, packed_get(jvar, nj, 3 * q + r, 3 * p + c));
+        }
+    }
+}
+
+static void update_max_corr(orc_adjustment* a, const double* corr, uint32_t n) {
+    double mv = max_value(corr, n);
+    if (fabs(mv) > fabs(a->maxCorr)) a->maxCorr = mv;
+}
+
+orc_adjustment* orc_adjust_create(const orc_network* net, const orc_settings* set, int phased) {
+    orc_adjustment* a = (orc_adjustment*)calloc(1, sizeof(*a));
+    a->net = *net;
+    a->set = *set;
+    a->phased = phased;
+    a->var_C = set->fixed_std_dev * set->fixed_std_dev; /* ADJ:232-245 */
+    a->var_F = set->free_std_dev * set->free_std_dev;
+    a->n_blocks = phased ? net->n_blocks : 1;
+    a->blk = (blk_t*)calloc(a->n_blocks, sizeof(blk_t));
+    if (set->threads > 0) {
+        char buf[32];
+        snprintf(buf, sizeof(buf), "%d", set->threads);
+        setenv("MKL_NUM_THREADS", buf, 1);
+        setenv("OMP_NUM_THREADS", buf, 1);
+        if (ext_handle) {
+            void (*setn)(int) = (void (*)(int))dlsym(ext_handle, "MKL_Set_Num_Threads");
+            if (setn) setn(set->threads);
+        }
+    }
+    return a;
+}
+
+void orc_adjust_destroy(orc_adjustment* a) {
+    if (!a) return;
+    for (uint32_t b = 0; b < a->n_blocks; ++b) {
+        blk_t* B = &a->blk[b];
+        free_pseudo(B);
+        free(B->stations); free(B->first_fwd); free(B->first_rev);
+        free(B->N); free(B->NR); free(B->est); free(B->orig); free(B->rig); free(B->rigvar);
+        free(B->corr); free(B->corrR); free(B->b); free(B->jvar); free(B->jvarFwd); free(B->jestFwd); free(B->jestRev);
+    }
+    free(a->blk);
+    free(a->W);
+    free(a->simul_stations);
+    free(a->simul_cml);
+    free(a);
+}
+
+/* PrepareAdjustment (ADJ:258) -> LoadSegmentationMetrics (ADJ:10426), CreateStnAppearanceList (SEG:432),
+ * PrepareAdjustmentBlock (ADJ:2873) */
+int orc_adjust_prepare(orc_adjustment* a) {
+    const orc_network* net = &a->net;
+    /* measurement weights, LoadVarianceMatrix_G (ADJ:4214) */
+    a->W = (double*)malloc(((size_t)net->n_baselines * 6 + 1) * sizeof(double));
+    for (uint32_t i = 0; i < net->n_baselines; ++i)
+        if (orc_weight_3x3(net->vcv6 + (size_t)i * 6, a->W + (size_t)i * 6)) {
+            snprintf(a->err, sizeof(a->err), "Matrix inversion failed, the matrix is singular. (variance matrix of baseline %u)", i);
+            return -1;
+        }
+    if (!a->phased) {
+        a->simul_stations = (uint32_t*)malloc((net->n_stations + 1) * sizeof(uint32_t));
+        for (uint32_t s = 0; s < net->n_stations; ++s) a->simul_stations[s] = s;
+        a->simul_cml = (uint32_t*)malloc((net->n_baselines + 1) * sizeof(uint32_t));
+        for (uint32_t i = 0; i < net->n_baselines; ++i) a->simul_cml[i] = i;
+    }
+    uint32_t prev_net = 999999;
+    for (uint32_t b = 0; b < a->n_blocks; ++b) {
+        blk_t* B = &a->blk[b];
+        if (a->phased) {
+            uint32_t ni = net->isl_off[b + 1] - net->isl_off[b], nj = net->jsl_off[b + 1] - net->jsl_off[b];
+            B->n_stn = ni + nj;
+            B->stations = (uint32_t*)malloc((B->n_stn + 1) * sizeof(uint32_t));
+            memcpy(B->stations, net->isl + net->isl_off[b], ni * sizeof(uint32_t));
+            memcpy(B->stations + ni, net->jsl + net->jsl_off[b], nj * sizeof(uint32_t));
+            qsort(B->stations, B->n_stn, sizeof(uint32_t), cmp_u32);
+            B->n_jsl = nj;
+            B->jsl = net->jsl + net->jsl_off[b];
+            B->n_cml = net->cml_off[b + 1] - net->cml_off[b];
+            B->cml = net->cml + net->cml_off[b];
+            B->first = (net->net_id[b] != prev_net);
+            prev_net = net->net_id[b];
+            B->last = (b + 1 == a->n_blocks) || (net->net_id[b] != net->net_id[b + 1]);
+            B->isolated = B->first && B->last;
+        } else {
+            B->n_stn = net->n_stations;
+            B->stations = (uint32_t*)malloc((B->n_stn + 1) * sizeof(uint32_t));
+            memcpy(B->stations, a->simul_stations, B->n_stn * sizeof(uint32_t));
+            B->n_jsl = 0;
+            B->n_cml = net->n_baselines;
+            B->cml = a->simul_cml;
+            B->first = B->last = B->isolated = 1;
+        }
+        B->n = 3 * B->n_stn;
+        B->m = 3 * B->n_cml;
+        B->first_fwd = (uint8_t*)calloc(B->n_stn + 1, 1);
+        B->first_rev = (uint8_t*)calloc(B->n_stn + 1, 1);
+    }
+    /* CreateStnAppearanceList (SEG:432-487) */
+    {
+        uint8_t* seen = (uint8_t*)calloc(net->n_stations + 1, 1);
+        for (uint32_t b = 0; b < a->n_blocks; ++b)
+            for (uint32_t p = 0; p < a->blk[b].n_stn; ++p)
+                if (!seen[a->blk[b].stations[p]]) {
+                    seen[a->blk[b].stations[p]] = 1;
+                    a->blk[b].first_fwd[p] = 1;
+                }
+        memset(seen, 0, net->n_stations + 1);
+        for (uint32_t bb = a->n_blocks; bb-- > 0;)
+            for (uint32_t p = 0; p < a->blk[bb].n_stn; ++p)
+                if (!seen[a->blk[bb].stations[p]]) {
+                    seen[a->blk[bb].stations[p]] = 1;
+                    a->blk[bb].first_rev[p] = 1;
+                }
+        free(seen);
+    }
+    for (uint32_t b = 0; b < a->n_blocks; ++b) {
+        blk_t* B = &a->blk[b];
+        uint32_t n = B->n;
+        /* pseudo measurement capacity (ADJ:822-834): JSL(b) + JSL(b-1) */
+        uint32_t pseudo = 0;
+        if (a->phased && !B->isolated) {
+            pseudo = B->n_jsl;
+            if (!B->first) pseudo += a->blk[b - 1].n_jsl;
+        }
+        B->N = (double*)calloc(psize(n) + 1, sizeof(double));
+        B->NR = (double*)calloc(psize(n) + 1, sizeof(double));
+        B->rigvar = (double*)calloc(psize(n) + 1, sizeof(double));
+        B->est = (double*)calloc(n + 1, sizeof(double));
+        B->orig = (double*)calloc(n + 1, sizeof(double));
+        B->rig = (double*)calloc(n + 1, sizeof(double));
+        B->corr = (double*)calloc(n + 1, sizeof(double));
+        B->corrR = (double*)calloc(n + 1, sizeof(double));
+        B->b = (double*)calloc(B->m + 3 * pseudo + 1, sizeof(double));
+        B->b_rows = B->m;
+        uint32_t nj = 3 * B->n_jsl;
+        B->jvar = (double*)calloc(psize(nj) + 1, sizeof(double));
+        B->jvarFwd = (double*)calloc(psize(nj) + 1, sizeof(double));
+        B->jestFwd = (double*)calloc(nj + 1, sizeof(double));
+        B->jestRev = (double*)calloc((b > 0 && a->phased ? 3 * a->blk[b - 1].n_jsl : 0) + 1, sizeof(double));
+        /* PopulateEstimatedStationMatrix (ADJ:632) */
+        for (uint32_t p = 0; p < B->n_stn; ++p)
+            for (int c = 0; c < 3; ++c) B->est[3 * p + c] = B->orig[3 * p + c] = B->rig[3 * p + c] = net->xyz0[3 * (size_t)B->stations[p] + c];
+        /* FillDesignNormalMeasurementsMatrices(true) (ADJ:913): b, AtVinv, N */
+        compute_b(a, B, B->est);
+        update_normals(a, B);
+        /* back up (ADJ:2955), then constraints (ADJ:2961-2970) */
+        memcpy(B->NR, B->N, psize(n) * sizeof(double));
+        if (add_constraints(a, B, a->phased ? CON_FWD : CON_SIM)) return -1;
+    }
+    return 0;
+}
+
+/* AdjustSimultaneous (ADJ:2413-2511) for a GNSS-only network */
+static int adjust_simultaneous(orc_adjustment* a) {
+    blk_t* B = &a->blk[0];
+    a->iterations = 0;
+    for (uint32_t i = 0; i < a->set.max_iterations; ++i) {
+        a->iterations++;
+        if (solve(a, B, a->iterations < 2, 0)) return ORC_ADJUST_EXCEPTION_RAISED;       /* ADJ:2457 */
+        for (uint32_t k = 0; k < B->n; ++k) B->est[k] += B->corr[k];                      /* ADJ:2463 */
+        a->maxCorr = max_value(B->corr, B->n);                                            /* ADJ:2466 */
+        if (a->iterations <= 64) a->max_corr_hist[a->iterations - 1] = a->maxCorr;
+        if (!(fabs(a->maxCorr) > a->set.iteration_threshold)) break;                      /* ADJ:2477 */
+        int last = (i + 1 >= a->set.max_iterations);
+        /* UpdateAdjustment(!last) (ADJ:473): new meas-minus-computed; normals untouched (GNSS only) */
+        (void)last;
+        compute_b(a, B, B->est);
+    }
+    memcpy(B->rig, B->est, B->n * sizeof(double));
+    memcpy(B->rigvar, B->N, psize(B->n) * sizeof(double));                                 /* ADJ:2536 */
+    if (a->iterations == a->set.max_iterations && fabs(a->maxCorr) > a->set.iteration_threshold)
+        return ORC_ADJUST_MAX_ITERATIONS_EXCEEDED;
+    return ORC_ADJUST_SUCCESS;
+}
+
+/* AdjustPhasedForward (ADJ:2756-2852) */
+static int phased_forward(orc_adjustment* a) {
+    for (uint32_t k = 0; k < a->n_blocks; ++k) {
+        blk_t* B = &a->blk[k];
+        if (solve(a, B, 1, k)) return -1;                                                 /* ADJ:2812 */
+        /* UpdateEstimatesForward (ADJ:3022) */
+        for (uint32_t i = 0; i < B->n; ++i) B->est[i] += B->corr[i];
+        if (B->last || B->isolated) {
+            update_max_corr(a, B->corr, B->n);
+            memcpy(B->rig, B->est, B->n * sizeof(double));
+            memcpy(B->rigvar, B->N, psize(B->n) * sizeof(double));
+            if (B->last) memcpy(B->corrR, B->corr, B->n * sizeof(double));
+        }
+        /* ShrinkForwardMatrices (ADJ:3005) */
+        if (!B->isolated && !B->first) shrink_pseudo(B, 1);
+        /* CarryForwardJunctions (ADJ:3065) -> CarryStnEstimatesandVariancesForward (ADJ:998) */
+        if (B->isolated || B->last) continue;
+        blk_t* Nx = &a->blk[k + 1];
+        if (Nx->isolated) continue;
+        if (gather_junctions(a, B, B->N, B->est, B->jsl, B->n_jsl, B->jvar, B->jestFwd)) return -1;
+        memcpy(B->jvarFwd, B->jvar, psize(3 * B->n_jsl) * sizeof(double));                 /* ADJ:1051 */
+        attach_junctions(Nx, B->jsl, B->n_jsl, B->jvar, B->jestFwd);
+    }
+    return 0;
+}
+
+/* AdjustPhasedReverseCombine (ADJ:3461-3590) */
+static int phased_reverse_combine(orc_adjustment* a) {
+    for (uint32_t kk = a->n_blocks; kk-- > 0;) {
+        blk_t* B = &a->blk[kk];
+        /* PrepareAdjustmentReverse (ADJ:3112) */
+        if (B->isolated) continue;
+        if (B->last) {
+            memcpy(B->N, B->NR, psize(B->n) * sizeof(double));
+            memcpy(B->est, B->orig, B->n * sizeof(double));
+            if (add_constraints(a, B, CON_REV)) return -1;
+        }
+        int combine_required = !B->last && !B->isolated && !B->first;
+        /* BackupNormals (ADJ:3170) */
+        if (combine_required) memcpy(B->NR, B->N, psize(B->n) * sizeof(double));
+        if (solve(a, B, 1, kk)) return -1;                                                /* ADJ:3512 */
+        /* UpdateEstimatesReverse (ADJ:3678) */
+        for (uint32_t i = 0; i < B->n; ++i) B->est[i] += B->corr[i];
+        /* CarryReverseJunctions (ADJ:3833) */
+        if (!B->isolated && !B->first) {
+            blk_t* Nx = &a->blk[kk - 1];
+            memcpy(Nx->N, Nx->NR, psize(Nx->n) * sizeof(double));                          /* ADJ:3852 */
+            memcpy(Nx->est, Nx->orig, Nx->n * sizeof(double));                             /* ADJ:3863 */
+            /* CarryStnEstimatesandVariancesReverse(next = kk-1, this = kk) (ADJ:1133) */
+            if (gather_junctions(a, B, B->N, B->est, Nx->jsl, Nx->n_jsl, Nx->jvar, B->jestRev)) return -1;
+            attach_junctions(Nx, Nx->jsl, Nx->n_jsl, Nx->jvar, B->jestRev);
+            if (add_constraints(a, Nx, CON_REV)) return -1;                                /* ADJ:3880 */
+            /* PrepareAdjustmentCombine (ADJ:3336) */
+            if (combine_required) {
+                memcpy(B->est, B->orig, B->n * sizeof(double));                            /* ADJ:3385 */
+                /* CarryStnEstimatesandVariancesCombine(kk-1, kk) (ADJ:3196) */
+                memcpy(B->N, B->NR, psize(B->n) * sizeof(double));                         /* ADJ:3245 */
+                attach_junctions(B, Nx->jsl, Nx->n_jsl, Nx->jvarFwd, Nx->jestFwd);
+                if (add_constraints(a, B, CON_CMB)) return -1;                             /* ADJ:3392 */
+                if (solve(a, B, 1, kk)) return -1;                                        /* ADJ:3556 */
+                /* UpdateEstimatesCombine (ADJ:3718) */
+                for (uint32_t i = 0; i < B->n; ++i) B->est[i] += B->corr[i];
+                shrink_pseudo(B, 2);
+            }
+        }
+        /* UpdateEstimatesFinal (ADJ:3744) */
+        if (B->last) {
+            memcpy(B->corr, B->corrR, B->n * sizeof(double));
+            continue;
+        }
+        if (B->first) shrink_pseudo(B, 1);
+        update_max_corr(a, B->corr, B->n);
+        memcpy(B->rig, B->est, B->n * sizeof(double));
+        memcpy(B->rigvar, B->N, psize(B->n) * sizeof(double));
+        memcpy(B->orig, B->rig, B->n * sizeof(double));
+    }
+    return 0;
+}
+
+/* UpdateAdjustment(iterate = true) for phased mode (ADJ:473-592) */
+static int phased_update_adjustment(orc_adjustment* a) {
+    for (uint32_t k = 0; k < a->n_blocks; ++k) {
+        blk_t* B = &a->blk[k];
+        if (B->last) {
+            memcpy(B->est, B->rig, B->n * sizeof(double));
+            memcpy(B->orig, B->rig, B->n * sizeof(double));
+        }
+        compute_b(a, B, B->est);
+        memset(B->N, 0, psize(B->n) * sizeof(double));
+        update_normals(a, B);
+        memcpy(B->NR, B->N, psize(B->n) * sizeof(double));
+        if (add_constraints(a, B, CON_FWD)) return -1;
+    }
+    return 0;
+}
+
+int orc_adjust_iteration(orc_adjustment* a) {
+    a->maxCorr = 0.0;
+    if (!a->phased) {
+        blk_t* B = &a->blk[0];
+        if (solve(a, B, 1, 0)) return -1;
+        return 0;
+    }
+    if (phased_forward(a)) return -1;
+    if (phased_reverse_combine(a)) return -1;
+    return 0;
+}
+
+/* AdjustPhased (ADJ:2579-2670) */
+static int adjust_phased(orc_adjustment* a) {
+    a->iterations = 0;
+    for (uint32_t i = 0; i < a->set.max_iterations; ++i) {
+        a->maxCorr = 0.0;
+        a->iterations++;
+        if (phased_forward(a)) return ORC_ADJUST_EXCEPTION_RAISED;
+        if (phased_reverse_combine(a)) return ORC_ADJUST_EXCEPTION_RAISED;
+        if (a->iterations <= 64) a->max_corr_hist[a->iterations - 1] = a->maxCorr;
+        if (!(fabs(a->maxCorr) > a->set.iteration_threshold)) break;                      /* ADJ:2639 */
+        if (phased_update_adjustment(a)) return ORC_ADJUST_EXCEPTION_RAISED;
+    }
+    if (a->iterations == a->set.max_iterations && fabs(a->maxCorr) > a->set.iteration_threshold)
+        return ORC_ADJUST_MAX_ITERATIONS_EXCEEDED;                                        /* ADJ:2526-2528 */
+    return ORC_ADJUST_SUCCESS;
+}
+
+int orc_adjust_run(orc_adjustment* a) { return a->phased ? adjust_phased(a) : adjust_simultaneous(a); }
+
+uint32_t orc_adjust_iterations(const orc_adjustment* a) { return a->iterations; }
+double orc_adjust_max_correction(const orc_adjustment* a, uint32_t it) {
+    return (it >= 1 && it <= a->iterations && it <= 64) ? a->max_corr_hist[it - 1] : 0.0;
+}
+uint32_t orc_adjust_block_unknowns(const orc_adjustment* a, uint32_t b) { return a->blk[b].n; }
+const uint32_t* orc_adjust_block_stations(const orc_adjustment* a, uint32_t b, uint32_t* count) {
+    if (count) *count = a->blk[b].n_stn;
+    return a->blk[b].stations;
+}
+const double* orc_adjust_block_estimates(const orc_adjustment* a, uint32_t b) { return a->blk[b].rig; }
+const double* orc_adjust_block_variances(const orc_adjustment* a, uint32_t b) { return a->blk[b].rigvar; }
+const double* orc_adjust_block_normals(const orc_adjustment* a, uint32_t b) { return a->blk[b].N; }
+const double* orc_adjust_block_b(const orc_adjustment* a, uint32_t b, uint32_t* rows) {
+    if (rows) *rows = a->blk[b].b_rows;
+    return a->blk[b].b;
+}
+const double* orc_adjust_weights(const orc_adjustment* a) { return a->W; }
+const char* orc_adjust_error(const orc_adjustment* a) { return a->err; }
+void orc_adjust_solve_stats(const orc_adjustment* a, uint64_t* solves, double* sum_n3) {
+    if (solves) *solves = a->solves;
+    if (sum_n3) *sum_n3 = a->sum_n3;
+}

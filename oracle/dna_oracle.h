@@ -1,0 +1,126 @@
+/*
+ * dna_oracle.h -- CPU restatement of DynAdjust's adjustment hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in dynadjust_amd/ (the product) may include,
+ * link or call this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * Every function cites the reference lines it follows (paths under
+ * /root/reference/dynadjust/): ADJ = dynadjust/dnaadjust/dnaadjust.cpp,
+ * MAT/MATH = include/math/dnamatrix_contiguous.{cpp,hpp}, SEG = include/io/seg_file.cpp.
+ *
+ * Pinning: the reference's L1 (dna_adjust) and L2 (matrix_2d) cannot be built in
+ * this image without hand-written stand-ins for Boost and CBLAS headers, so no
+ * oracle/_ref exists.  The restatement is pinned against (a) the known-answer
+ * vectors of the reference's tests/test_matrix.cpp (tests/golden/matrix_golden.json),
+ * (b) LAPACK dpotrf/dpotri from the MKL runtime in the image -- the very routines
+ * matrix_2d::cholesky_inverse calls -- and (c) phased == simultaneous consistency.
+ */
+#ifndef DNA_ORACLE_H_
+#define DNA_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- L2: matrix_2d restatement -------------------------------------------------- */
+/* MATH:363 */
+size_t orc_packed_index(uint32_t n, uint32_t i, uint32_t j);
+/* LAPACK backend: 0 = built-in C (default); 1 = dpotrf_/dpotri_ resolved from `lib`
+ * (e.g. /opt/conda/lib/libmkl_rt.so).  Returns 0 on success. */
+int orc_set_lapack(const char* lib);
+const char* orc_lapack_name(void);
+/* dpotrf('L') / dpotri('L') on a full column-major matrix, lda >= n; return LAPACK info */
+int orc_potrf_lower(uint32_t n, double* a, uint32_t lda);
+int orc_potri_lower(uint32_t n, double* a, uint32_t lda);
+/* matrix_2d::cholesky_inverse, packed path (MAT:952-991): unpack, dpotrf, dpotri, repack.
+ * Returns 0, or the LAPACK info (> 0) where the reference throws MatrixInversionFailure. */
+int orc_cholesky_inverse_packed(double* ap, uint32_t n);
+/* full-storage path (MAT:993-1019), lower triangle in, both triangles out */
+int orc_cholesky_inverse_full(double* a, uint32_t n, uint32_t lda);
+/* matrix_2d::scale_symmetric_diagonal, packed (MAT:1145-1152) */
+void orc_scale_symmetric_diagonal_packed(double* ap, uint32_t n, const double* diag);
+/* matrix_2d::multiply_sym packed = dspmv (MAT:1471-1497): y = A x */
+void orc_multiply_sym_packed(const double* ap, const double* x, double* y, uint32_t n);
+/* Solve()'s inverse with the optional scale_normals_to_unity wrapper (ADJ:6614-6645) */
+int orc_inverse_normals_packed(double* ap, uint32_t n, int scale_to_unity);
+
+/* ---- geodesy --------------------------------------------------------------------- */
+/* GeoToCart (include/functions/dnatemplategeodesyfuncs.hpp:78-90), GRS80 */
+void orc_geo_to_cart(double lat, double lon, double h, double* x, double* y, double* z);
+
+/* ---- measurement weights ------------------------------------------------------- */
+/* W = V^-1 for a GNSS baseline: LoadVarianceMatrix_G (ADJ:4214) + FormInverseVarianceMatrix
+ * (ADJ:8472) = dpotrf('U') + dpotri('U') on the 3x3.  v6 = (XX, XY, YY, XZ, YZ, ZZ). */
+int orc_weight_3x3(const double* v6, double* w6);
+
+/* ---- network ----------------------------------------------------------------------- */
+typedef struct {
+    uint32_t n_stations;
+    const double* xyz0;        /* 3 per station: initial cartesian coordinates */
+    const char* constraints;   /* 3 chars per station, 'C' or 'F' (CCC / FFF supported) */
+    uint32_t n_baselines;
+    const uint32_t* stn1;      /* global station index */
+    const uint32_t* stn2;
+    const double* obs;         /* 3 per baseline */
+    const double* vcv6;        /* 6 per baseline, v-scaled */
+    uint32_t n_blocks;
+    const uint32_t* isl_off;   /* n_blocks+1 */
+    const uint32_t* isl;       /* inner stations per block (global ids) */
+    const uint32_t* jsl_off;
+    const uint32_t* jsl;       /* junction stations per block */
+    const uint32_t* cml_off;
+    const uint32_t* cml;       /* baseline indices per block, CML order */
+    const uint32_t* net_id;    /* contiguous network id per block */
+} orc_network;
+
+typedef struct {
+    double fixed_std_dev;       /* dnaoptions.hpp: 1e-6 */
+    double free_std_dev;        /* 10.0 */
+    double iteration_threshold; /* 0.0005 */
+    uint32_t max_iterations;    /* 10 */
+    int scale_normals_to_unity;
+    int threads;                /* LAPACK threads hint (MKL); 0 = leave default */
+} orc_settings;
+
+typedef struct orc_adjustment orc_adjustment;
+
+/* status codes = _ADJUST_STATUS_ (include/exception/dnaexception.hpp:51-59) */
+#define ORC_ADJUST_SUCCESS 0
+#define ORC_ADJUST_MAX_ITERATIONS_EXCEEDED 1
+#define ORC_ADJUST_EXCEPTION_RAISED 5
+
+/* mode 0 = simultaneous (one block: all stations, all baselines), 1 = phased */
+orc_adjustment* orc_adjust_create(const orc_network* net, const orc_settings* set, int phased);
+void orc_adjust_destroy(orc_adjustment* a);
+/* PrepareAdjustment (ADJ:258): returns 0 or a negative error (singular VCV ...) */
+int orc_adjust_prepare(orc_adjustment* a);
+/* AdjustNetwork (ADJ:2140) -> AdjustSimultaneous (ADJ:2413) | AdjustPhased (ADJ:2579) */
+int orc_adjust_run(orc_adjustment* a);
+/* one forward + reverse/combine sweep only (used by the CPU-baseline timer) */
+int orc_adjust_iteration(orc_adjustment* a);
+
+uint32_t orc_adjust_iterations(const orc_adjustment* a);
+double orc_adjust_max_correction(const orc_adjustment* a, uint32_t iteration /* 1-based */);
+uint32_t orc_adjust_block_unknowns(const orc_adjustment* a, uint32_t block);
+/* parameter station list (ascending global ids) of a block */
+const uint32_t* orc_adjust_block_stations(const orc_adjustment* a, uint32_t block, uint32_t* count);
+/* rigorous station estimates of a block (3 per station, block order) */
+const double* orc_adjust_block_estimates(const orc_adjustment* a, uint32_t block);
+/* rigorous variance matrix of a block, packed lower */
+const double* orc_adjust_block_variances(const orc_adjustment* a, uint32_t block);
+/* intermediate products for kernel-level parity tests (block state after prepare) */
+const double* orc_adjust_block_normals(const orc_adjustment* a, uint32_t block);   /* packed, with forward constraints */
+const double* orc_adjust_block_b(const orc_adjustment* a, uint32_t block, uint32_t* rows);
+const double* orc_adjust_weights(const orc_adjustment* a);                         /* 6 per baseline */
+const char* orc_adjust_error(const orc_adjustment* a);
+/* number of Solve() calls and sum of n^3 over them since create */
+void orc_adjust_solve_stats(const orc_adjustment* a, uint64_t* solves, double* sum_n3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,259 @@
+"""ctypes wrapper of oracle/liboracle.so (the CPU restatement; test infrastructure only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+MKL = "/opt/conda/lib/libmkl_rt.so"
+
+f64p = C.POINTER(C.c_double)
+u32p = C.POINTER(C.c_uint32)
+
+
+class OrcNetwork(C.Structure):
+    _fields_ = [("n_stations", C.c_uint32), ("xyz0", f64p), ("constraints", C.c_char_p), ("n_baselines", C.c_uint32),
+                ("stn1", u32p), ("stn2", u32p), ("obs", f64p), ("vcv6", f64p), ("n_blocks", C.c_uint32),
+                ("isl_off", u32p), ("isl", u32p), ("jsl_off", u32p), ("jsl", u32p), ("cml_off", u32p), ("cml", u32p),
+                ("net_id", u32p)]
+
+
+class OrcSettings(C.Structure):
+    _fields_ = [("fixed_std_dev", C.c_double), ("free_std_dev", C.c_double), ("iteration_threshold", C.c_double),
+                ("max_iterations", C.c_uint32), ("scale_normals_to_unity", C.c_int), ("threads", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        lib = C.CDLL(LIB)
+        lib.orc_packed_index.restype = C.c_size_t
+        lib.orc_packed_index.argtypes = [C.c_uint32] * 3
+        lib.orc_set_lapack.argtypes = [C.c_char_p]
+        lib.orc_lapack_name.restype = C.c_char_p
+        lib.orc_cholesky_inverse_packed.argtypes = [f64p, C.c_uint32]
+        lib.orc_inverse_normals_packed.argtypes = [f64p, C.c_uint32, C.c_int]
+        lib.orc_cholesky_inverse_full.argtypes = [f64p, C.c_uint32, C.c_uint32]
+        lib.orc_scale_symmetric_diagonal_packed.argtypes = [f64p, C.c_uint32, f64p]
+        lib.orc_multiply_sym_packed.argtypes = [f64p, f64p, f64p, C.c_uint32]
+        lib.orc_geo_to_cart.argtypes = [C.c_double] * 3 + [f64p] * 3
+        lib.orc_weight_3x3.argtypes = [f64p, f64p]
+        lib.orc_adjust_create.restype = C.c_void_p
+        lib.orc_adjust_create.argtypes = [C.POINTER(OrcNetwork), C.POINTER(OrcSettings), C.c_int]
+        lib.orc_adjust_destroy.argtypes = [C.c_void_p]
+        lib.orc_adjust_prepare.argtypes = [C.c_void_p]
+        lib.orc_adjust_run.argtypes = [C.c_void_p]
+        lib.orc_adjust_iteration.argtypes = [C.c_void_p]
+        lib.orc_adjust_iterations.restype = C.c_uint32
+        lib.orc_adjust_iterations.argtypes = [C.c_void_p]
+        lib.orc_adjust_max_correction.restype = C.c_double
+        lib.orc_adjust_max_correction.argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_adjust_block_unknowns.restype = C.c_uint32
+        lib.orc_adjust_block_unknowns.argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_adjust_block_stations.restype = u32p
+        lib.orc_adjust_block_stations.argtypes = [C.c_void_p, C.c_uint32, u32p]
+        for nm in ("orc_adjust_block_estimates", "orc_adjust_block_variances", "orc_adjust_block_normals"):
+            getattr(lib, nm).restype = f64p
+            getattr(lib, nm).argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_adjust_block_b.restype = f64p
+        lib.orc_adjust_block_b.argtypes = [C.c_void_p, C.c_uint32, u32p]
+        lib.orc_adjust_weights.restype = f64p
+        lib.orc_adjust_weights.argtypes = [C.c_void_p]
+        lib.orc_adjust_error.restype = C.c_char_p
+        lib.orc_adjust_error.argtypes = [C.c_void_p]
+        lib.orc_adjust_solve_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), f64p]
+        _lib = lib
+    return _lib
+
+
+def use_mkl(enable=True):
+    """switch the oracle's dpotrf/dpotri to the MKL runtime (the LAPACK the reference links)"""
+    lib = load()
+    if enable and os.path.exists(MKL):
+        return lib.orc_set_lapack(MKL.encode()) == 0
+    lib.orc_set_lapack(None)
+    return False
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def cholesky_inverse_packed(ap, n, scale=False):
+    lib = load()
+    ap = np.array(ap, dtype=np.float64, copy=True)
+    info = lib.orc_inverse_normals_packed(_p(ap, f64p), n, int(scale))
+    return ap, info
+
+
+def multiply_sym_packed(ap, x, n):
+    lib = load()
+    ap = np.ascontiguousarray(ap, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty(n)
+    lib.orc_multiply_sym_packed(_p(ap, f64p), _p(x, f64p), _p(y, f64p), n)
+    return y
+
+
+def geo_to_cart(lat, lon, h):
+    lib = load()
+    x, y, z = C.c_double(), C.c_double(), C.c_double()
+    lib.orc_geo_to_cart(lat, lon, h, C.byref(x), C.byref(y), C.byref(z))
+    return x.value, y.value, z.value
+
+
+def weight_3x3(v6):
+    lib = load()
+    v = np.ascontiguousarray(v6, dtype=np.float64)
+    w = np.empty(6)
+    rc = lib.orc_weight_3x3(_p(v, f64p), _p(w, f64p))
+    return w, rc
+
+
+class Network:
+    """Arrays of a GNSS network read with tests/dnaformats.py, in the form the oracle takes."""
+
+    def __init__(self, base, phased):
+        from . import dnaformats as F
+        bst = F.read_bst(base + ".bst")
+        bms = F.read_bms(base + ".bms")
+        self.n_stations = len(bst)
+        self.xyz0 = np.empty(3 * self.n_stations)
+        for s in range(self.n_stations):
+            self.xyz0[3 * s:3 * s + 3] = geo_to_cart(float(bst["currentLatitude"][s]), float(bst["currentLongitude"][s]),
+                                                     float(bst["currentHeight"][s]))
+        self.constraints = b"".join(bytes(c[:3]).ljust(3, b"F") for c in bst["stationConst"])
+        starts = np.nonzero((bms["measStart"] == 0) & (~bms["ignore"]))[0]
+        assert np.all(bms["measType"][starts] == b"G")
+        self.bl_of_record = {int(m): i for i, m in enumerate(starts)}
+        self.n_baselines = len(starts)
+        self.stn1 = np.ascontiguousarray(bms["station1"][starts], dtype=np.uint32)
+        self.stn2 = np.ascontiguousarray(bms["station2"][starts], dtype=np.uint32)
+        self.obs = np.ascontiguousarray(np.stack([bms["term1"][starts], bms["term1"][starts + 1], bms["term1"][starts + 2]], axis=1)).ravel()
+        vs = bms["scale4"][starts]
+        v6 = np.stack([bms["term2"][starts], bms["term2"][starts + 1], bms["term3"][starts + 1],
+                       bms["term2"][starts + 2], bms["term3"][starts + 2], bms["term4"][starts + 2]], axis=1)
+        scale = np.where(np.abs(vs - 1.0) > 1e-5, vs, 1.0)
+        self.vcv6 = np.ascontiguousarray(v6 * scale[:, None]).ravel()
+        if phased:
+            ISL, JSL, CML, nets = F.read_seg(base + ".seg")
+            self.n_blocks = len(ISL)
+            self.isl_off, self.isl = self._csr(ISL)
+            self.jsl_off, self.jsl = self._csr(JSL)
+            cml_bl = [np.array([self.bl_of_record[int(m)] for m in c], dtype=np.uint32) for c in CML]
+            self.cml_off, self.cml = self._csr(cml_bl)
+            self.net_id = np.ascontiguousarray(nets, dtype=np.uint32)
+        else:
+            self.n_blocks = 1
+            z = np.zeros(2, dtype=np.uint32)
+            self.isl_off = self.jsl_off = self.cml_off = z
+            self.isl = self.jsl = self.cml = np.zeros(1, dtype=np.uint32)
+            self.net_id = np.zeros(1, dtype=np.uint32)
+
+    @staticmethod
+    def _csr(lists):
+        off = np.zeros(len(lists) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(l) for l in lists])
+        flat = np.concatenate([np.asarray(l, dtype=np.uint32) for l in lists] + [np.zeros(0, dtype=np.uint32)]) if lists else np.zeros(0, np.uint32)
+        if flat.size == 0:
+            flat = np.zeros(1, dtype=np.uint32)
+        return off, np.ascontiguousarray(flat, dtype=np.uint32)
+
+    def c_struct(self):
+        n = OrcNetwork()
+        n.n_stations = self.n_stations
+        n.xyz0 = _p(self.xyz0, f64p)
+        n.constraints = self.constraints
+        n.n_baselines = self.n_baselines
+        n.stn1 = _p(self.stn1, u32p)
+        n.stn2 = _p(self.stn2, u32p)
+        n.obs = _p(self.obs, f64p)
+        n.vcv6 = _p(self.vcv6, f64p)
+        n.n_blocks = self.n_blocks
+        n.isl_off, n.isl = _p(self.isl_off, u32p), _p(self.isl, u32p)
+        n.jsl_off, n.jsl = _p(self.jsl_off, u32p), _p(self.jsl, u32p)
+        n.cml_off, n.cml = _p(self.cml_off, u32p), _p(self.cml, u32p)
+        n.net_id = _p(self.net_id, u32p)
+        return n
+
+
+class Adjustment:
+    """orc_adjustment: prepare() + run(), then per-block rigorous estimates / variances."""
+
+    def __init__(self, net, phased, fixed_std_dev=1e-6, free_std_dev=10.0, iteration_threshold=float(np.float32(0.0005)),
+                 max_iterations=10, scale_normals_to_unity=False, threads=0):
+        self.lib = load()
+        self.net = net
+        self.cnet = net.c_struct()
+        self.set = OrcSettings(fixed_std_dev, free_std_dev, iteration_threshold, max_iterations, int(scale_normals_to_unity), threads)
+        self.h = self.lib.orc_adjust_create(C.byref(self.cnet), C.byref(self.set), int(phased))
+        self.n_blocks = net.n_blocks if phased else 1
+
+    def close(self):
+        if self.h:
+            self.lib.orc_adjust_destroy(self.h)
+            self.h = None
+
+    def prepare(self):
+        rc = self.lib.orc_adjust_prepare(self.h)
+        if rc:
+            raise RuntimeError(self.lib.orc_adjust_error(self.h).decode())
+
+    def run(self):
+        st = self.lib.orc_adjust_run(self.h)
+        if st == 5:
+            raise RuntimeError(self.lib.orc_adjust_error(self.h).decode())
+        return st
+
+    def iteration(self):
+        if self.lib.orc_adjust_iteration(self.h):
+            raise RuntimeError(self.lib.orc_adjust_error(self.h).decode())
+
+    def iterations(self):
+        return self.lib.orc_adjust_iterations(self.h)
+
+    def max_correction(self, it):
+        return self.lib.orc_adjust_max_correction(self.h, it)
+
+    def block_stations(self, b):
+        cnt = C.c_uint32()
+        p = self.lib.orc_adjust_block_stations(self.h, b, C.byref(cnt))
+        return np.ctypeslib.as_array(p, shape=(cnt.value,)).copy()
+
+    def _vec(self, fn, b, count):
+        p = fn(self.h, b)
+        return np.ctypeslib.as_array(p, shape=(count,)).copy()
+
+    def block_estimates(self, b):
+        n = self.lib.orc_adjust_block_unknowns(self.h, b)
+        return self._vec(self.lib.orc_adjust_block_estimates, b, n)
+
+    def block_variances(self, b):
+        n = self.lib.orc_adjust_block_unknowns(self.h, b)
+        return self._vec(self.lib.orc_adjust_block_variances, b, n * (n + 1) // 2)
+
+    def block_normals(self, b):
+        n = self.lib.orc_adjust_block_unknowns(self.h, b)
+        return self._vec(self.lib.orc_adjust_block_normals, b, n * (n + 1) // 2)
+
+    def block_b(self, b):
+        rows = C.c_uint32()
+        p = self.lib.orc_adjust_block_b(self.h, b, C.byref(rows))
+        return np.ctypeslib.as_array(p, shape=(rows.value,)).copy()
+
+    def weights(self):
+        p = self.lib.orc_adjust_weights(self.h)
+        return np.ctypeslib.as_array(p, shape=(6 * self.net.n_baselines,)).copy()
+
+    def solve_stats(self):
+        s = C.c_uint64()
+        f = C.c_double()
+        self.lib.orc_adjust_solve_stats(self.h, C.byref(s), C.byref(f))
+        return s.value, f.value
