@@ -139,6 +139,7 @@ def load():
     _sig(lib, "dnaadj_device_context", vp, [vp])
     _sig(lib, "dnasynth_write_network", i, [C.c_char_p, C.c_char_p, C.POINTER(DnaSynthSpec), C.POINTER(DnaSynthSummary), C.c_char_p, sz])
     _sig(lib, "dnaio_file_summary", i, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_char_p, sz])
+    _sig(lib, "dnaio_seg_summary", i, [C.c_char_p, C.c_char_p, c_u32p, c_u32p, u32, C.c_char_p, sz])
     _sig(lib, "dnaio_sizeof_station", sz, [])
     _sig(lib, "dnaio_sizeof_measurement", sz, [])
     _lib = lib
@@ -164,5 +165,5 @@ EXPORTED_DNAADJ = [
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
-    "dnasynth_write_network", "dnaio_file_summary", "dnaio_sizeof_station", "dnaio_sizeof_measurement",
+    "dnasynth_write_network", "dnaio_file_summary", "dnaio_seg_summary", "dnaio_sizeof_station", "dnaio_sizeof_measurement",
 ]

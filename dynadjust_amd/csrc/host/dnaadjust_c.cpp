@@ -211,3 +211,34 @@ size_t dnaio_sizeof_station(void) { return sizeof(dynadjust::station_t); }
 size_t dnaio_sizeof_measurement(void) { return sizeof(dynadjust::measurement_t); }
 
 }  // extern "C"
+
+// Reads a .seg file with the product's reader (SegFile::LoadSegFile restatement) and returns, per
+// block, {network id, junction count, inner count, measurement count, design rows, first inner,
+// first junction or UINT32_MAX, first measurement or UINT32_MAX}.
+extern "C" int dnaio_seg_summary(const char* seg_path, const char* bms_path, uint32_t* n_blocks, uint32_t* per_block8, uint32_t cap_blocks,
+                                 char* err, size_t errlen) {
+    try {
+        using namespace dynadjust;
+        std::vector<measurement_t> bms;
+        binary_file_meta_t meta;
+        if (bms_path) iostreams::read_bms(bms_path, bms, meta);
+        iostreams::seg_data_t seg;
+        iostreams::read_seg(seg_path, seg, bms_path ? &bms : nullptr);
+        if (n_blocks) *n_blocks = seg.blockCount;
+        for (uint32_t b = 0; b < seg.blockCount && b < cap_blocks && per_block8; ++b) {
+            uint32_t* o = per_block8 + 8 * (size_t)b;
+            o[0] = seg.ContiguousNetList[b];
+            o[1] = (uint32_t)seg.JSL[b].size();
+            o[2] = (uint32_t)seg.ISL[b].size();
+            o[3] = (uint32_t)seg.CML[b].size();
+            o[4] = seg.measurementCount[b];
+            o[5] = seg.ISL[b].empty() ? 0xffffffffu : seg.ISL[b][0];
+            o[6] = seg.JSL[b].empty() ? 0xffffffffu : seg.JSL[b][0];
+            o[7] = seg.CML[b].empty() ? 0xffffffffu : seg.CML[b][0];
+        }
+        return DNAADJ_OK;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return DNAADJ_EXCEPTION;
+    }
+}

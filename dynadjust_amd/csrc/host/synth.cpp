@@ -188,9 +188,9 @@ void write_network(const std::string& dir, const std::string& name, const Spec& 
     seg.JSL.assign(B, {});
     seg.CML.assign(B, {});
     seg.ContiguousNetList.assign(B, 0);
-    const uint32_t rows_per = (R + B - 1) / B;
+    // row r belongs to strip floor(r * B / R): every strip gets floor(R/B) or ceil(R/B) rows
     auto strip_of = [&](uint64_t s) {
-        uint32_t k = (uint32_t)((s / C) / rows_per);
+        uint32_t k = (uint32_t)(((s / C) * (uint64_t)B) / R);
         return k >= B ? B - 1 : k;
     };
     for (uint64_t s = 0; s < n_stn; ++s) seg.ISL[strip_of(s)].push_back((UINT32)s);

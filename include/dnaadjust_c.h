@@ -89,6 +89,10 @@ int dnasynth_write_network(const char* dir, const char* name, const dnasynth_spe
 /* returns record counts; any pointer may be NULL */
 int dnaio_file_summary(const char* bst, const char* bms, const char* asl, uint64_t* n_stn, uint64_t* n_msr, uint64_t* n_asl, char* err,
                        size_t errlen);
+/* reads a .seg with the product's reader; per block 8 values: network id, junction count, inner count,
+ * measurement count, design rows, first inner, first junction, first measurement (UINT32_MAX if none) */
+int dnaio_seg_summary(const char* seg_path, const char* bms_path, uint32_t* n_blocks, uint32_t* per_block8, uint32_t cap_blocks,
+                      char* err, size_t errlen);
 size_t dnaio_sizeof_station(void);
 size_t dnaio_sizeof_measurement(void);
 

@@ -109,3 +109,98 @@ def read_seg(path):
         JSL.append(np.array(jsl, dtype=np.uint32))
         CML.append(np.array(cml, dtype=np.uint32))
     return ISL, JSL, CML, np.array([c[0] for c in counts], dtype=np.uint32)
+
+
+# ---- writers (tests only): used to build networks the synthetic generator cannot make ----
+def _header(app=b"   PYTESTS"):
+    return b"VERSION   " + b"       1.2" + b"CREATED ON" + b"2026-09-28" + b"CREATED BY" + app[:10].rjust(10)
+
+
+def _meta(count):
+    out = struct.pack("<Q", count) + b"\x00" + b"pytest".ljust(20, b"\x00") + b"7843".ljust(7, b"\x00")
+    out += b"01.01.2020".ljust(12, b"\x00") * 2 + b"\x00\x00" + struct.pack("<Q", 0) + struct.pack("<Q", 0)
+    return out
+
+
+def write_bst(path, stations):
+    with open(path, "wb") as f:
+        f.write(_header() + _meta(len(stations)) + np.ascontiguousarray(stations).tobytes())
+
+
+def write_bms(path, msrs):
+    with open(path, "wb") as f:
+        f.write(_header() + _meta(len(msrs)) + np.ascontiguousarray(msrs).tobytes())
+
+
+def write_asl(path, counts):
+    with open(path, "wb") as f:
+        f.write(_header() + struct.pack("<Q", len(counts)))
+        off = 0
+        for c in counts:
+            f.write(struct.pack("<IIH", int(c), off, 1))
+            off += int(c)
+
+
+def write_seg(path, ISL, JSL, CML, nets, bms):
+    """same fixed-column layout as SegFile::WriteSegFile (seg_file.cpp:590-721)"""
+    L = []
+    rule80 = "-" * 80
+    L += [rule80, "DYNADJUST SEGMENTATION OUTPUT FILE", "", "Version:".ljust(35) + "tests", "Build:".ljust(35) + "tests",
+          "File created:".ljust(35) + "now", "File name:".ljust(35) + path, "", "Command line arguments: ".ljust(35) + "tests", "",
+          "Stations file:".ljust(35) + "x.bst", "Measurements file:".ljust(35) + "x.bms", "",
+          "Minimum inner stations".ljust(35) + "0", "Block size threshold".ljust(35) + "0", "Starting station(s)".ljust(35) + " ",
+          rule80, "", "SEGMENTATION SUMMARY".ljust(35), "", "No. blocks produced".ljust(35) + str(len(ISL))]
+    rule = "-" * 90
+    L += [rule, "  Block".ljust(14) + "Network ID".ljust(14) + "Junction stns".ljust(16) + "Inner stns".ljust(16) + "Measurements".ljust(16) + "Total stns".ljust(16)]
+    for b in range(len(ISL)):
+        L.append("  " + str(b + 1).ljust(12) + str(int(nets[b])).ljust(14) + str(len(JSL[b])).ljust(16) + str(len(ISL[b])).ljust(16) +
+                 str(len(CML[b])).ljust(16) + str(len(ISL[b]) + len(JSL[b])).ljust(16))
+    L += [rule, "", "INDIVIDUAL BLOCK DATA", rule]
+    br = "-" * 53
+    for b in range(len(ISL)):
+        L += ["", "Block %d" % (b + 1), br, "Junction stns:".ljust(16) + str(len(JSL[b])), "Inner stns:".ljust(16) + str(len(ISL[b])),
+              "Measurements:".ljust(16) + str(len(CML[b])), "Total stns:".ljust(16) + str(len(ISL[b]) + len(JSL[b])), "",
+              "Inner stns".ljust(16) + "Junction stns".ljust(16) + "Measurements".ljust(16) + "Type".ljust(5), br]
+        rows = max(len(ISL[b]), len(JSL[b]), len(CML[b]), 1)
+        for r in range(rows):
+            s = (str(int(ISL[b][r])) if r < len(ISL[b]) else " ").ljust(16)
+            s += (str(int(JSL[b][r])) if r < len(JSL[b]) else " ").ljust(16)
+            if r < len(CML[b]):
+                s += str(int(CML[b][r])).ljust(16) + bms["measType"][int(CML[b][r])].decode().ljust(5)
+            L.append(s)
+        L.append(br)
+    L.append("")
+    with open(path, "w") as f:
+        f.write("\n".join(L) + "\n")
+
+
+def merge_networks(bases, out_base):
+    """Concatenate independently generated networks into one multi-network project: station and
+    measurement indices are offset, block lists are appended and every source keeps its own
+    contiguous-network id (so its first/last/isolated block flags follow dnaadjust.cpp:10449-10474)."""
+    bst_all, bms_all, asl_all, ISL, JSL, CML, nets = [], [], [], [], [], [], []
+    s_off = m_off = 0
+    for net_id, base in enumerate(bases):
+        bst, bms, asl = read_bst(base + ".bst").copy(), read_bms(base + ".bms").copy(), read_asl(base + ".asl")
+        bms["station1"] += s_off
+        bms["station2"] += s_off
+        i, j, c, _ = read_seg(base + ".seg")
+        ISL += [x + s_off for x in i]
+        JSL += [x + s_off for x in j]
+        CML += [x + m_off for x in c]
+        nets += [net_id] * len(i)
+        bst_all.append(bst)
+        bms_all.append(bms)
+        asl_all += list(asl["assocMsrCount"])
+        s_off += len(bst)
+        m_off += len(bms)
+    # concatenate through raw bytes: np.concatenate would repack the explicit-offset dtypes
+    def cat(parts, dt):
+        raw = np.concatenate([np.frombuffer(np.ascontiguousarray(p).tobytes(), dtype=np.uint8) for p in parts])
+        return np.frombuffer(raw.tobytes(), dtype=dt)
+    bst = cat(bst_all, STATION_DT)
+    bms = cat(bms_all, MEASUREMENT_DT)
+    write_bst(out_base + ".bst", bst)
+    write_bms(out_base + ".bms", bms)
+    write_asl(out_base + ".asl", asl_all)
+    write_seg(out_base + ".seg", ISL, JSL, CML, nets, bms)

@@ -1,0 +1,156 @@
+"""End-to-end parity of the device path (through the dna_adjust facade and the C-ABI) with the CPU
+oracle on identical input files.  Tolerances: estimated coordinates within 1e-8 m (BASELINE.json),
+variance matrices within 1e-8 relative to their largest element."""
+import os
+
+import numpy as np
+import pytest
+
+from dynadjust_amd import adjust
+from dynadjust_amd.device import unpack_lower
+from tests import dnaformats as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_X = 1e-8
+TOL_V = 1e-8
+
+
+def _device_run(folder, name, phased, **kw):
+    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode, **kw)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    st = a.AdjustNetwork()
+    return a, st
+
+
+def _compare(a, st, o, ost):
+    assert st == ost
+    assert a.CurrentIteration() == o.iterations()
+    for i in range(o.iterations()):
+        assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < 1e-8
+    for b in range(a.blockCount()):
+        assert np.array_equal(a.block_stations(b), o.block_stations(b))
+        assert np.abs(a.block_estimates(b) - o.block_estimates(b)).max() < TOL_X
+        vo = o.block_variances(b)
+        assert np.abs(a.block_variances_packed(b) - vo).max() / np.abs(vo).max() < TOL_V
+
+
+def test_golden_tiny_network(built, golden_dir):
+    exp = np.load(os.path.join(golden_dir, "tiny_net_expected.npz"))
+    for phased, tag in ((False, "simult"), (True, "phased")):
+        a, st = _device_run(golden_dir, "tiny_net", phased)
+        assert st == int(exp[f"{tag}_status"]) and a.CurrentIteration() == int(exp[f"{tag}_iterations"])
+        assert a.GetMeasurementCount() == 3 * 23 or a.GetMeasurementCount() > 0
+        for b in range(a.blockCount()):
+            assert np.array_equal(a.block_stations(b), exp[f"{tag}_stations_{b}"])
+            assert np.abs(a.block_estimates(b) - exp[f"{tag}_estimates_{b}"]).max() < TOL_X
+            v = exp[f"{tag}_variances_{b}"]
+            assert np.abs(a.block_variances_packed(b) - v).max() / np.abs(v).max() < TOL_V
+        a.close()
+
+
+@pytest.mark.parametrize("rows,cols,nbl,blocks,phased,scale", [
+    (6, 5, 0, 1, False, False),
+    (12, 10, 300, 1, False, True),
+    (12, 10, 300, 2, True, False),
+    (12, 10, 300, 4, True, False),
+    (12, 10, 300, 3, True, True),
+    (9, 9, 160, 9, True, False),        # one grid row per block: every inner station is also a junction target
+    (30, 30, 2400, 5, True, False),
+    (45, 45, 0, 3, True, False),        # blocks larger than one 128x128 tile row in the junction matrices
+])
+def test_parity_with_oracle(built, orc, tmp_path, rows, cols, nbl, blocks, phased, scale):
+    adjust.write_synthetic_network(str(tmp_path), "n", rows, cols, nbl, blocks, seed=rows + 31 * blocks)
+    orc.use_mkl(True)
+    try:
+        net = orc.Network(str(tmp_path / "n"), phased)
+        o = orc.Adjustment(net, phased, scale_normals_to_unity=scale)
+        o.prepare()
+        ost = o.run()
+    finally:
+        orc.use_mkl(False)
+    a, st = _device_run(str(tmp_path), "n", phased, scale_normals_to_unity=scale)
+    _compare(a, st, o, ost)
+    assert a.GetUnknownsCount() == 3 * rows * cols - 12          # four CCC corner stations (dnaadjust.cpp:10567-10574)
+    assert a.GetDegreesOfFreedom() == a.GetMeasurementCount() - a.GetUnknownsCount()
+    a.close()
+    o.close()
+
+
+def test_multiple_networks_and_isolated_blocks(built, orc, tmp_path):
+    specs = [("a", 8, 5, 3), ("b", 5, 5, 1), ("c", 6, 6, 2)]
+    for nm, r, c, blk in specs:
+        adjust.write_synthetic_network(str(tmp_path), nm, r, c, 0, blk, seed=ord(nm))
+    F.merge_networks([str(tmp_path / s[0]) for s in specs], str(tmp_path / "all"))
+    net = orc.Network(str(tmp_path / "all"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "all", True)
+    assert a.blockCount() == 6
+    _compare(a, st, o, ost)
+    a.close()
+    o.close()
+
+
+def test_iteration_limit_and_threshold(built, orc, golden_dir):
+    a, st = _device_run(golden_dir, "tiny_net", True, max_iterations=1)
+    assert st == adjust.ADJUST_MAX_ITERATIONS_EXCEEDED and a.CurrentIteration() == 1
+    a.close()
+    a, st = _device_run(golden_dir, "tiny_net", True, iteration_threshold=10.0)
+    assert st == adjust.ADJUST_SUCCESS and a.CurrentIteration() == 1
+    a.close()
+
+
+def test_errors_follow_the_reference(built, tmp_path, golden_dir):
+    # missing files
+    a = adjust.DnaAdjust()
+    with pytest.raises(adjust.NetAdjustException) as e:
+        a.PrepareAdjustment(adjust.ProjectSettings("nothing", str(tmp_path)))
+    assert "PrepareAdjustment(): Process terminated while preparing the" in str(e.value)
+    a.close()
+    # a singular block: an unconstrained... every station carries at least the free-station weight, so make the
+    # normals indefinite through a negative-definite measurement variance instead
+    import shutil
+    for ext in ("bst", "bms", "asl", "seg"):
+        shutil.copy(os.path.join(golden_dir, "tiny_net." + ext), str(tmp_path / ("bad." + ext)))
+    bms = F.read_bms(str(tmp_path / "bad.bms")).copy()
+    bms["term2"][0] = -1.0
+    F.write_bms(str(tmp_path / "bad.bms"), bms)
+    a = adjust.DnaAdjust()
+    with pytest.raises(adjust.NetAdjustException) as e:
+        a.PrepareAdjustment(adjust.ProjectSettings("bad", str(tmp_path), adjust_mode=adjust.PhasedMode))
+    assert "singular" in str(e.value)
+    a.close()
+    # AdjustNetwork before PrepareAdjustment
+    a = adjust.DnaAdjust()
+    with pytest.raises(adjust.NetAdjustException):
+        a.AdjustNetwork()
+    a.close()
+
+
+def test_phased_is_rigorous_at_scale(built, tmp_path):
+    """size-independent property at a size the CPU oracle would need minutes for: the phased result on the
+    device equals the simultaneous result on the device (12 800 unknowns, 8 blocks)"""
+    adjust.write_synthetic_network(str(tmp_path), "big", 80, 80, 17000, 8, seed=5)
+    s, st_s = _device_run(str(tmp_path), "big", False)
+    p, st_p = _device_run(str(tmp_path), "big", True)
+    assert st_s == 0 and st_p == 0
+    xs = s.block_estimates(0).reshape(-1, 3)
+    for b in range(p.blockCount()):
+        stn = p.block_stations(b)
+        assert np.abs(p.block_estimates(b).reshape(-1, 3) - xs[stn]).max() < TOL_X
+    # variance of block 3 against the matching sub-matrix of the simultaneous inverse
+    n = 3 * 80 * 80
+    Vs = s.block_variances_packed(0)
+    stn = p.block_stations(3)
+    Vb = unpack_lower(p.block_variances_packed(3), 3 * len(stn))
+    idx = (3 * stn[:, None] + np.arange(3)).ravel()
+    # pick packed elements of the simultaneous matrix without unpacking 19200^2 doubles
+    ii, jj = np.meshgrid(idx, idx, indexing="ij")
+    lo, hi = np.minimum(ii, jj).astype(np.int64), np.maximum(ii, jj).astype(np.int64)
+    sub = Vs[lo * n - lo * (lo - 1) // 2 + (hi - lo)]
+    assert np.abs(Vb - sub).max() / np.abs(sub).max() < TOL_V
+    s.close()
+    p.close()

@@ -1,0 +1,157 @@
+"""Block-level kernels through the C-ABI against the CPU oracle on the same seeded network:
+weights, meas-minus-computed, normal-equation formation (bit-exact), rhs and the junction carry."""
+import os
+
+import numpy as np
+import pytest
+
+from dynadjust_amd.device import pack_lower, unpack_lower
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case(built, orc, tmp_path_factory):
+    from dynadjust_amd import adjust
+    d = tmp_path_factory.mktemp("k")
+    adjust.write_synthetic_network(str(d), "n", 9, 8, 170, 3, seed=11)
+    base = str(d / "n")
+    net = orc.Network(base, True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    return net, a
+
+
+def _upload_block(ctx, net, a, b, blk_id=0):
+    st = a.block_stations(b)
+    loc = {int(s): i for i, s in enumerate(st)}
+    cml = net.cml[net.cml_off[b]:net.cml_off[b + 1]]
+    s1 = np.array([loc[int(net.stn1[i])] for i in cml], dtype=np.uint32)
+    s2 = np.array([loc[int(net.stn2[i])] for i in cml], dtype=np.uint32)
+    obs = np.concatenate([net.obs[3 * i:3 * i + 3] for i in cml])
+    vcv = np.concatenate([net.vcv6[6 * i:6 * i + 6] for i in cml])
+    xyz = np.concatenate([net.xyz0[3 * s:3 * s + 3] for s in st])
+    ctx.block_create(blk_id, len(st), len(cml))
+    ctx.block_set_stations(blk_id, xyz)
+    ctx.block_set_baselines(blk_id, s1, s2, obs, vcv)
+    return st, cml, s1, s2
+
+
+def test_weights_and_b_are_bit_exact(gpu_ctx, case):
+    net, a = case
+    st, cml, s1, s2 = _upload_block(gpu_ctx, net, a, 1)
+    w = gpu_ctx.block_get_weights(0, len(cml)).reshape(-1, 6)
+    wo = a.weights().reshape(-1, 6)[cml]
+    assert np.array_equal(w, wo), np.abs(w - wo).max()
+    gpu_ctx.block_compute_b(0)
+    b = gpu_ctx.block_get_b(0, len(cml))
+    assert np.array_equal(b, a.block_b(1)[:3 * len(cml)])
+    gpu_ctx.block_destroy(0)
+
+
+def test_normals_are_bit_exact(gpu_ctx, case, orc):
+    """N = sum A^T W A in CML order (dnaadjust.cpp:1664-1684) + forward constraints (:1884)"""
+    net, a = case
+    for b in range(3):
+        st, cml, s1, s2 = _upload_block(gpu_ctx, net, a, b)
+        n = 3 * len(st)
+        m = gpu_ctx.matrix(n)
+        gpu_ctx.form_normals(0, m, len(st))
+        # forward constraints: stations appearing for the first time in the forward direction
+        seen = set()
+        for bb in range(b):
+            seen |= set(int(s) for s in a.block_stations(bb))
+        first = [i for i, s in enumerate(st) if int(s) not in seen]
+        w9 = []
+        for i in first:
+            c = net.constraints[3 * int(st[i]):3 * int(st[i]) + 3]
+            w = 1.0 / (1e-6 ** 2) if c == b"CCC" else 1.0 / (10.0 ** 2)
+            w9 += [w, 0, 0, 0, w, 0, 0, 0, w]
+        gpu_ctx.add_diag3x3(m, np.array(first, dtype=np.uint32), np.array(w9))
+        got = m.download_packed()
+        assert np.array_equal(got, a.block_normals(b)), np.abs(got - a.block_normals(b)).max()
+        m.close()
+        gpu_ctx.block_destroy(0)
+
+
+def test_solve_and_junction_carry(gpu_ctx, case, orc):
+    """one forward step: solve block 0, gather/invert its junction block, scatter into block 1 and
+    form block 1's right-hand side -- every intermediate against numpy on the oracle's inputs"""
+    net, a = case
+    st0, cml0, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    st1, cml1, _, _ = _upload_block(gpu_ctx, net, a, 1, blk_id=1)
+    n0, n1 = 3 * len(st0), 3 * len(st1)
+    N0 = unpack_lower(a.block_normals(0), n0)
+    m0 = gpu_ctx.matrix(n0)
+    m0.upload_packed(a.block_normals(0), n0)
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    rhs = gpu_ctx.block_get_rhs(0, len(st0))
+    # numpy rhs = A^T W b
+    W = a.weights().reshape(-1, 6)
+    b0 = a.block_b(0)
+    loc0 = {int(s): i for i, s in enumerate(st0)}
+    ref = np.zeros(n0)
+    for k, i in enumerate(cml0):
+        w = W[i]
+        Wm = np.array([[w[0], w[1], w[3]], [w[1], w[2], w[4]], [w[3], w[4], w[5]]])
+        wb = Wm @ b0[3 * k:3 * k + 3]
+        ref[3 * loc0[int(net.stn1[i])]:3 * loc0[int(net.stn1[i])] + 3] -= wb
+        ref[3 * loc0[int(net.stn2[i])]:3 * loc0[int(net.stn2[i])] + 3] += wb
+    assert np.abs(rhs - ref).max() <= 1e-12 * np.abs(ref).max()
+    m0.invert()
+    Ninv = np.linalg.inv(N0)
+    gpu_ctx.solve_corrections(0, m0)
+    corr = gpu_ctx.block_get_corrections(0, len(st0))
+    assert np.abs(corr - Ninv @ ref).max() < 1e-9
+    mv, row = gpu_ctx.update_estimates(0)
+    assert row == int(np.argmax(np.abs(corr))) and mv == corr[row]      # matrix_2d::compute_maximum_value
+    est0 = gpu_ctx.block_get_stations(0, 1, len(st0))
+    # junction stations of block 0 (JSL(0)) in both blocks
+    jsl = net.jsl[net.jsl_off[0]:net.jsl_off[1]]
+    idx0 = np.array([loc0[int(s)] for s in jsl], dtype=np.uint32)
+    loc1 = {int(s): i for i, s in enumerate(st1)}
+    idx1 = np.array([loc1[int(s)] for s in jsl], dtype=np.uint32)
+    jm = gpu_ctx.matrix(3 * len(jsl))
+    gpu_ctx.junction_gather(0, m0, idx0, jm)
+    rows = (3 * idx0[:, None] + np.arange(3)).ravel()
+    J = unpack_lower(jm.download_packed(), 3 * len(jsl))
+    assert np.abs(J - Ninv[np.ix_(rows, rows)]).max() < 1e-9 * np.abs(Ninv).max()
+    assert np.array_equal(gpu_ctx.junction_get_estimates(jm), est0[rows])
+    jm.invert()
+    WJ = unpack_lower(jm.download_packed(), 3 * len(jsl))
+    m1 = gpu_ctx.matrix(n1)
+    m1.upload_packed(a.block_normals(1), n1)
+    gpu_ctx.junction_scatter(m1, idx1, jm)
+    N1 = unpack_lower(m1.download_packed(), n1)
+    rows1 = (3 * idx1[:, None] + np.arange(3)).ravel()
+    exp = unpack_lower(a.block_normals(1), n1)
+    exp[np.ix_(rows1, rows1)] += WJ
+    assert np.abs(N1 - exp).max() <= 1e-12 * np.abs(exp).max()
+    gpu_ctx.block_compute_b(1)
+    gpu_ctx.form_rhs(1)
+    r_before = gpu_ctx.block_get_rhs(1, len(st1))
+    gpu_ctx.junction_rhs(1, idx1, jm)
+    r_after = gpu_ctx.block_get_rhs(1, len(st1))
+    x1 = gpu_ctx.block_get_stations(1, 1, len(st1))
+    bj = est0[rows] - x1[rows1]
+    add = np.zeros(n1)
+    add[rows1] = WJ @ bj
+    assert np.abs((r_after - r_before) - add).max() <= 1e-9 * max(1.0, np.abs(add).max())
+    for m in (m0, m1, jm):
+        m.close()
+    gpu_ctx.block_destroy(0)
+    gpu_ctx.block_destroy(1)
+
+
+def test_bad_arguments_are_rejected(gpu_ctx):
+    from dynadjust_amd._lib import DnaGpuError
+    gpu_ctx.block_create(0, 4, 2)
+    with pytest.raises(DnaGpuError):   # station index out of range
+        gpu_ctx.block_set_baselines(0, [0, 9], [1, 2], np.zeros(6), np.tile([1.0, 0, 1, 0, 0, 1], 2))
+    with pytest.raises(DnaGpuError) as e:   # singular variance matrix -> same message as the reference's inverse failure
+        gpu_ctx.block_set_baselines(0, [0, 1], [1, 2], np.zeros(6), np.array([1.0, 2, 1, 0, 0, 1, 1, 0, 1, 0, 0, 1]))
+    assert "singular" in str(e.value)
+    gpu_ctx.block_destroy(0)
+    with pytest.raises(DnaGpuError):
+        gpu_ctx.block_compute_b(77)
