@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- stations adjusted / s of the phased least-squares adjustment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|small]
+
+A "step" is one complete dna_adjust::AdjustNetwork() (phased: forward + reverse + combine sweeps,
+iterated to the reference's convergence threshold) on one synthetic network whose matrices and
+measurements are already resident in HBM when the timed region starts (dnaadj_reset puts the
+coordinates back between steps; file loading and PrepareAdjustment are outside the timed region).
+
+Default workload (N = 1): BASELINE.json configs[2] "synthetic 100k-station / 800k-measurement
+network, phased adjustment, 16 blocks, 1 x MI355X" -- the largest named phased configuration that
+fits one GPU (the metric is quoted on the phased adjustment).
+
+One JSON line is printed by rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (rows, cols, baselines, blocks, phased, description)
+    "cfg3": (316, 317, 266666, 16, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, 16 blocks"),
+    "cfg2": (100, 100, 26666, 1, False, "synthetic 10k-station / 80k-measurement network, simultaneous adjustment"),
+    "small": (60, 60, 9600, 4, True, "synthetic 3.6k-station / 28.8k-measurement network, phased adjustment, 4 blocks (smoke size)"),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk)
+
+
+def cpu_baseline(workload, iterations, solves_per_step, sum_n3_per_step, stations):
+    """The CPU restatement (oracle/, LAPACK = MKL runtime when present) timed on this host's cores on a
+    bounded sample: one forward + reverse sweep over a 2-block strip with the workload's block shape;
+    extrapolated to the workload linearly in sum(n^3) of its Solve() calls."""
+    from dynadjust_amd import adjust
+    from tests import oracle
+    rows, cols, nbl, blocks, phased, _ = WORKLOADS[workload]
+    have_mkl = oracle.use_mkl(True)
+    cores = os.cpu_count() or 1
+    d = tempfile.mkdtemp(prefix="dnagpu_cpu_")
+    if phased:
+        rows_s = max(4, 2 * rows // blocks)
+        nb_s = 2
+    else:
+        rows_s, nb_s = rows, 1
+    # without a threaded LAPACK the sample must shrink (the built-in Cholesky is a scalar port)
+    if not have_mkl:
+        rows_s = max(4, min(rows_s, 12))
+        cols = min(cols, 60)
+    frac = (rows_s * cols) / float(rows * WORKLOADS[workload][1])
+    info = adjust.write_synthetic_network(d, "cpu", rows_s, cols, int(nbl * frac) if have_mkl else 0, nb_s)
+    net = oracle.Network(os.path.join(d, "cpu"), phased)
+    o = oracle.Adjustment(net, phased, threads=cores if have_mkl else 1)
+    o.prepare()
+    t0 = time.perf_counter()
+    o.iteration()
+    dt = time.perf_counter() - t0
+    solves, n3 = o.solve_stats()
+    o.close()
+    oracle.use_mkl(False)
+    cpu_flops = n3 / dt
+    projected = sum_n3_per_step / cpu_flops
+    return {
+        "value": stations / projected,
+        "unit": "stations/s",
+        "cores": cores if have_mkl else 1,
+        "kind": "port",
+        "lapack": "MKL runtime (libmkl_rt, all cores)" if have_mkl else "built-in scalar Cholesky",
+        "sample": (f"one forward+reverse sweep of the CPU restatement over a {nb_s}-block, {info['stations']}-station strip of the same "
+                   f"block shape ({solves} Solve() calls, sum n^3 = {n3:.3e}) in {dt:.2f} s = {cpu_flops / 1e12:.3f} TFLOP/s reference-equivalent; "
+                   f"extrapolated linearly in sum n^3 to the workload's {solves_per_step} Solve() calls per step"),
+        "seconds_sample": dt,
+        "tflops_reference_equivalent": cpu_flops / 1e12,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("DNAGPU_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the adjustment path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from dynadjust_amd import adjust
+    from dynadjust_amd.device import DeviceContext  # noqa: F401  (fails loudly if the HIP library is missing)
+
+    rows, cols, nbl, blocks, phased, desc = WORKLOADS[args.workload]
+    d = tempfile.mkdtemp(prefix=f"dnagpu_bench_r{rank}_")
+    info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, blocks)
+    stations = info["stations"]
+
+    if world > 1:
+        from dynadjust_amd import parallel
+        result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank)
+        if rank == 0:
+            result["config"]["workload"] = desc
+            print(json.dumps(result), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    a = adjust.DnaAdjust()
+    p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode,
+                               multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "0"))), device=local_rank)
+    a.PrepareAdjustment(p)
+    lib = a.lib
+    ctx = a.device_context()
+
+    def one_step():
+        a.ResetAdjustment()
+        st = a.AdjustNetwork()
+        if st != adjust.ADJUST_SUCCESS:
+            raise SystemExit(f"adjustment did not converge (status {st})")
+
+    for _ in range(args.warmup):
+        one_step()
+    lib.dnagpu_profile_enable(ctx, 1)
+    lib.dnagpu_profile_reset(ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    lib.dnagpu_sync(ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof_f, prof_ms, prof_n = C.c_double(), C.c_double(), C.c_uint64()
+    lib.dnagpu_profile_get(ctx, C.byref(prof_f), C.byref(prof_ms), C.byref(prof_n))
+    lib.dnagpu_profile_enable(ctx, 0)
+
+    iters = a.CurrentIteration()
+    solves = a.solve_count()
+    sum_n3 = a.solve_flops()
+    ms_per_step = dt * 1e3 / args.steps
+    value = stations * args.steps / dt
+    # roofline of the dominant kernel, gemm_f64_kernel (fp64 MFMA): algorithmic flops = the reference-equivalent
+    # n^3 per Solve() (n^3/3 dpotrf + 2n^3/3 dpotri) summed over the step's Solve() calls, divided by the summed
+    # HIP-event duration of the gemm launches of the step
+    gemm_ms_per_step = prof_ms.value / args.steps
+    achieved = (sum_n3 / 1e12) / (gemm_ms_per_step / 1e3) if gemm_ms_per_step > 0 else 0.0
+    out = {
+        "metric": "stations adjusted/sec + Cholesky TFLOP/s, phased adjustment, 1/2/4/8 MI355X",
+        "value": value,
+        "unit": "stations/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": desc,
+            "stations": stations, "baselines": info["baselines"], "measurement_rows": info["measurement_rows"], "blocks": blocks,
+            "max_block_unknowns": info["max_block_unknowns"], "iterations_to_converge": iters, "solves_per_step": solves,
+            "mode": "phased" if phased else "simultaneous", "parallelism": "1 GPU, one chain" if not p.multi_thread else "1 GPU, two chains",
+        },
+        "cholesky_tflops": (sum_n3 / 1e12) / (ms_per_step / 1e3),
+        "roofline": {
+            "kernel": "gemm_f64_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches_per_step": prof_n.value / args.steps,
+            "gemm_ms_per_step": gemm_ms_per_step,
+            "issued_tflops": (prof_f.value / 1e12) / (prof_ms.value / 1e3) if prof_ms.value > 0 else 0.0,
+        },
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, iters, solves, sum_n3, stations)
+    print(json.dumps(out), flush=True)
+    a.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,7 @@ def load():
     _sig(lib, "dnaadj_prepare", i, [vp, C.POINTER(DnaAdjSettings)])
     _sig(lib, "dnaadj_adjust", i, [vp, C.POINTER(i)])
     _sig(lib, "dnaadj_cancel", i, [vp])
+    _sig(lib, "dnaadj_reset", i, [vp])
     _sig(lib, "dnaadj_block_count", u32, [vp])
     _sig(lib, "dnaadj_iterations", u32, [vp])
     _sig(lib, "dnaadj_max_correction", C.c_double, [vp])
@@ -161,7 +162,7 @@ EXPORTED_DNAGPU = [
 
 EXPORTED_DNAADJ = [
     "dnaadj_default_settings", "dnaadj_create", "dnaadj_destroy", "dnaadj_last_error", "dnaadj_prepare", "dnaadj_adjust",
-    "dnaadj_cancel", "dnaadj_block_count", "dnaadj_iterations", "dnaadj_max_correction", "dnaadj_iteration_correction",
+    "dnaadj_cancel", "dnaadj_reset", "dnaadj_block_count", "dnaadj_iterations", "dnaadj_max_correction", "dnaadj_iteration_correction",
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",

@@ -102,6 +102,10 @@ class DnaAdjust:
         self._chk(self.lib.dnaadj_adjust(self.h, C.byref(st)))
         return st.value
 
+    def ResetAdjustment(self):
+        """measurement helper: state right after PrepareAdjustment, data stays resident in HBM"""
+        self._chk(self.lib.dnaadj_reset(self.h))
+
     def CancelAdjustment(self):
         self._chk(self.lib.dnaadj_cancel(self.h))
 

@@ -245,6 +245,7 @@ void dna_adjust::FormConstraintStationVarianceMatrix(UINT32 stn, double w9[9]) c
 void dna_adjust::PrepareBlocks() {
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
     blocks_.assign(blockCount_, block_t());
+    initial_xyz_.assign(blockCount_, {});
     max_unknowns_ = 0;
     max_junction_ = 0;
     for (UINT32 b = 0; b < blockCount_; ++b) {
@@ -270,6 +271,7 @@ void dna_adjust::PrepareBlocks() {
             const station_t& st = bstBinaryRecords_[plist[p]];
             geodesy::GeoToCart(st.currentLatitude, st.currentLongitude, st.currentHeight, &xyz[3 * p], &xyz[3 * p + 1], &xyz[3 * p + 2]);
         }
+        initial_xyz_[b] = xyz;
         // measurements of the block (CML order)
         const std::vector<UINT32>& cml = v_CML_[b];
         B.stn1.reserve(cml.size());
@@ -656,6 +658,22 @@ void dna_adjust::GetAdjustedCoordinates(std::vector<double>& xyz) {
             if (v_paramStnAppearance_[b][p].first_appearance_fwd)
                 for (int c = 0; c < 3; ++c) xyz[3 * (size_t)v_parameterStationList_[b][p] + c] = bx[3 * p + c];
     }
+}
+
+void dna_adjust::ResetAdjustment() {
+    if (!ctx_) SignalExceptionAdjustment("ResetAdjustment(): PrepareAdjustment() has not been called.", 0);
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
+    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        Check(dnagpu_block_set_stations(ctx_, b, initial_xyz_[b].data()), b, "ResetAdjustment()");
+        for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "ResetAdjustment()");
+        blocks_[b].has_rigvar = false;
+    }
+    Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
+    currentIteration_ = 0;
+    maxCorr_ = 0.0;
+    cancel_.store(false);
+    adjustStatus_ = ADJUST_SUCCESS;
 }
 
 void dna_adjust::GenerateStatistics() {}

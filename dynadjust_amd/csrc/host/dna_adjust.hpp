@@ -84,7 +84,10 @@ public:
     // network-wide rigorous coordinates (3 per bst station; stations never adjusted keep their input value)
     void GetAdjustedCoordinates(std::vector<double>& xyz);
 
-    // ---- measurement (not in the reference): per-phase device timing of the last AdjustNetwork
+    // ---- measurement helpers (not in the reference) ---------------------------------------
+    // put every block back to its state right after PrepareAdjustment (initial coordinates, fresh
+    // meas-minus-computed) so that AdjustNetwork can be timed repeatedly on resident data
+    void ResetAdjustment();
     double solveFlops() const { return solve_flops_; }   // sum of n^3 over Solve() calls (reference-equivalent)
     UINT32 solveCount() const { return solve_count_; }
     dnagpu_ctx* deviceContext() const { return ctx_; }
@@ -145,6 +148,7 @@ private:
     std::vector<std::vector<UINT32>> v_parameterStationList_;
     std::vector<std::vector<stn_appear>> v_paramStnAppearance_;
     std::vector<block_t> blocks_;
+    std::vector<std::vector<double>> initial_xyz_;   // per block, for ResetAdjustment
 
     UINT32 blockCount_ = 1;
     UINT32 currentBlock_ = 0, currentIteration_ = 0;

@@ -93,6 +93,10 @@ int dnaadj_adjust(dnaadj_handle* h, int* status) {
     });
 }
 
+int dnaadj_reset(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->ResetAdjustment(); });
+}
+
 int dnaadj_cancel(dnaadj_handle* h) {
     return guarded(h, [&] { h->adj->CancelAdjustment(); });
 }

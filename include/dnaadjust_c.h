@@ -49,6 +49,8 @@ const char* dnaadj_last_error(const dnaadj_handle* h);
 int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s);        /* dna_adjust::PrepareAdjustment */
 int dnaadj_adjust(dnaadj_handle* h, int* status);                      /* dna_adjust::AdjustNetwork -> _ADJUST_STATUS_ */
 int dnaadj_cancel(dnaadj_handle* h);                                   /* dna_adjust::CancelAdjustment */
+/* measurement helper (not in the reference): back to the state right after dnaadj_prepare, data stays in HBM */
+int dnaadj_reset(dnaadj_handle* h);
 
 uint32_t dnaadj_block_count(const dnaadj_handle* h);                   /* blockCount() */
 uint32_t dnaadj_iterations(const dnaadj_handle* h);                    /* CurrentIteration() */
