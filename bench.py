@@ -35,6 +35,26 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma
 
 
 def cpu_baseline(workload, iterations, solves_per_step, sum_n3_per_step, stations):
+    """Runs _cpu_baseline_sample in a clean subprocess: the MKL runtime must not share a process with torch's
+    OpenMP runtime (mixing libiomp5 and libgomp silently corrupts dpotrf results), and MKL_THREADING_LAYER=GNU
+    has to be in the environment before libmkl_rt is loaded."""
+    import subprocess
+    env = dict(os.environ, MKL_THREADING_LAYER="GNU")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload,
+           "--cpu-args", json.dumps([iterations, solves_per_step, sum_n3_per_step, stations])]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"value": None, "unit": "stations/s", "cores": 0, "kind": "port", "sample": "failed: " + (out.stderr or out.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "stations/s", "cores": 0, "kind": "port", "sample": "timed out after 600 s"}
+
+
+def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step, stations):
     """The CPU restatement (oracle/, LAPACK = MKL runtime when present) timed on this host's cores on a
     bounded sample: one forward + reverse sweep over a 2-block strip with the workload's block shape;
     extrapolated to the workload linearly in sum(n^3) of its Solve() calls."""
@@ -87,7 +107,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("DNAGPU_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(_cpu_baseline_sample(args.workload, *json.loads(args.cpu_args))), flush=True)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

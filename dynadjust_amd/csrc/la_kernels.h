@@ -13,7 +13,7 @@ struct GemmArgs {
     const double* B;
     double* C;
     int lda, ldb, ldc;
-    int mt, nt;  // tiles of 128 in M and N
+    int mt, nt;  // 128-wide tiles in M and N (the kernel re-tiles them when tile == 64)
     int K;       // multiple of 16
     double alpha, beta;
     int kmode;   // KMode: restricts the k range per tile (triangular operands)
@@ -21,11 +21,15 @@ struct GemmArgs {
     int mirror;  // 1: also store C(j,i) for off-diagonal tiles
     const uint32_t* order;  // device table: (it << 16 | jt) per workgroup, 0xffffffff = idle
     int grid;               // number of workgroups (= table length)
+    int tile;               // block tile of the launch: 128 (throughput) or 64 (small launches)
 };
+
+// launches with fewer 128-tiles than this run on 64x64 block tiles
+constexpr int SMALL_LAUNCH_TILES = 160;
 
 // Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).
-std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower);
+std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile);
 
 void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s);

@@ -42,17 +42,26 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 //   R layout  [k][row]      row stride 144 doubles (k+1 lands 32 banks away)
 //   P layout  [k/2][col][2] pair stride 258 doubles (32 lanes read 256 B contiguous)
 // ----------------------------------------------------------------------------
-constexpr int LDR = 144;
-constexpr int LDP = 258;
-constexpr int OPBUF = 16 * LDR;  // 2304 doubles >= 8*LDP = 2064
+// Two block-tile sizes share the code: TILE = 128 (4 waves x 64x64, the throughput shape, ~70 TFLOP/s)
+// and TILE = 64 (4 waves x 32x32) for the small nodes of the recursion, where a launch has only a
+// handful of 128-tiles and latency, not throughput, is what matters (4x the workgroups, 1/4 the k-loop time).
+template <int TILE>
+struct Geo {
+    static constexpr int LDR = TILE + 16;       // R layout row stride: k+1 lands 32 banks away
+    static constexpr int LDP = 2 * TILE + 2;    // P layout pair stride
+    static constexpr int OPBUF = 16 * LDR;      // doubles per operand buffer (>= 8 * LDP)
+    static constexpr int NQ = TILE / 32;        // 16-byte loads per thread per operand slab
+    static constexpr int WT = TILE / 2;         // wave tile
+    static constexpr int MI = WT / 16;          // MFMA tiles per wave per dimension
+};
 
-template <bool KC>
-__device__ __forceinline__ void stage_load(const double* __restrict__ P, int ld, int r0, int k0, int tid, d2 (&g)[4]) {
+template <bool KC, int TILE>
+__device__ __forceinline__ void stage_load(const double* __restrict__ P, int ld, int r0, int k0, int tid, d2 (&g)[Geo<TILE>::NQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Geo<TILE>::NQ; ++q) {
         int idx = tid + 256 * q;
         if (!KC) {
-            int k = idx >> 6, r2 = idx & 63;
+            int k = idx / (TILE / 2), r2 = idx % (TILE / 2);
             g[q] = *reinterpret_cast<const d2*>(P + (size_t)(k0 + k) * ld + r0 + 2 * r2);
         } else {
             int k2 = idx & 7, c = idx >> 3;
@@ -61,44 +70,47 @@ __device__ __forceinline__ void stage_load(const double* __restrict__ P, int ld,
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void stage_store(double* buf, int tid, const d2 (&g)[4]) {
+template <bool KC, int TILE>
+__device__ __forceinline__ void stage_store(double* buf, int tid, const d2 (&g)[Geo<TILE>::NQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Geo<TILE>::NQ; ++q) {
         int idx = tid + 256 * q;
         if (!KC) {
-            int k = idx >> 6, r2 = idx & 63;
-            *reinterpret_cast<d2*>(buf + k * LDR + 2 * r2) = g[q];
+            int k = idx / (TILE / 2), r2 = idx % (TILE / 2);
+            *reinterpret_cast<d2*>(buf + k * Geo<TILE>::LDR + 2 * r2) = g[q];
         } else {
             int k2 = idx & 7, c = idx >> 3;
-            *reinterpret_cast<d2*>(buf + k2 * LDP + 2 * c) = g[q];
+            *reinterpret_cast<d2*>(buf + k2 * Geo<TILE>::LDP + 2 * c) = g[q];
         }
     }
 }
 
-template <bool KC>
+template <bool KC, int TILE>
 __device__ __forceinline__ double frag_read(const double* buf, int kk, int rbase, int lane) {
     int k = kk * 4 + (lane >> 4);
     int r = rbase + (lane & 15);
-    if (!KC) return buf[k * LDR + r];
-    return buf[(k >> 1) * LDP + r * 2 + (k & 1)];
+    if (!KC) return buf[k * Geo<TILE>::LDR + r];
+    return buf[(k >> 1) * Geo<TILE>::LDP + r * 2 + (k & 1)];
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int TILE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[4 * OPBUF];
-    // tile order table built on the host (tile_order.cpp): workgroup b runs on XCD b%8,
+    using G = Geo<TILE>;
+    __shared__ __attribute__((aligned(16))) double lds[4 * G::OPBUF];
+    // tile order table built on the host (tile_order.hip): workgroup b runs on XCD b%8,
     // every XCD walks its own work-balanced list of 2-D super-tiles (L2 locality).
     const uint32_t packed = a.order[blockIdx.x];
     if (packed == 0xffffffffu) return;
     const int it = (int)(packed >> 16), jt = (int)(packed & 0xffffu);
 
+    // triangular operands restrict the k range in units of the 128-wide blocks of the recursion
+    const int bi = (it * TILE) / 128, bj = (jt * TILE) / 128;
     int kbeg = 0, kend = a.K;
     switch (a.kmode) {
-        case KM_LE_J: kend = (jt + 1) * 128; break;
-        case KM_GE_J: kbeg = jt * 128; break;
-        case KM_LE_I: kend = (it + 1) * 128; break;
-        case KM_GE_I: kbeg = it * 128; break;
+        case KM_LE_J: kend = (bj + 1) * 128; break;
+        case KM_GE_J: kbeg = bj * 128; break;
+        case KM_LE_I: kend = (bi + 1) * 128; break;
+        case KM_GE_I: kbeg = bi * 128; break;
         default: break;
     }
     if (kend > a.K) kend = a.K;
@@ -107,66 +119,66 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int i0 = it * 128, j0 = jt * 128;
+    const int i0 = it * TILE, j0 = jt * TILE;
 
-    d4 acc[4][4];
+    d4 acc[G::MI][G::MI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int ni = 0; ni < G::MI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    d2 ga[4], gb[4];
+    d2 ga[G::NQ], gb[G::NQ];
     const int nk = (kend - kbeg) / 16;
     if (nk > 0) {
-        stage_load<A_KC>(a.A, a.lda, i0, kbeg, tid, ga);
-        stage_load<B_KC>(a.B, a.ldb, j0, kbeg, tid, gb);
-        stage_store<A_KC>(lds, tid, ga);
-        stage_store<B_KC>(lds + OPBUF, tid, gb);
+        stage_load<A_KC, TILE>(a.A, a.lda, i0, kbeg, tid, ga);
+        stage_load<B_KC, TILE>(a.B, a.ldb, j0, kbeg, tid, gb);
+        stage_store<A_KC, TILE>(lds, tid, ga);
+        stage_store<B_KC, TILE>(lds + G::OPBUF, tid, gb);
     }
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        const double* As = lds + cur * 2 * OPBUF;
-        const double* Bs = As + OPBUF;
+        const double* As = lds + cur * 2 * G::OPBUF;
+        const double* Bs = As + G::OPBUF;
         const bool more = (t + 1 < nk);
         if (more) {
-            stage_load<A_KC>(a.A, a.lda, i0, kbeg + (t + 1) * 16, tid, ga);
-            stage_load<B_KC>(a.B, a.ldb, j0, kbeg + (t + 1) * 16, tid, gb);
+            stage_load<A_KC, TILE>(a.A, a.lda, i0, kbeg + (t + 1) * 16, tid, ga);
+            stage_load<B_KC, TILE>(a.B, a.ldb, j0, kbeg + (t + 1) * 16, tid, gb);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            double af[4], bf[4];
+            double af[G::MI], bf[G::MI];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi] = frag_read<A_KC>(As, kk, wm * 64 + mi * 16, lane);
+            for (int mi = 0; mi < G::MI; ++mi) af[mi] = frag_read<A_KC, TILE>(As, kk, wm * G::WT + mi * 16, lane);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bf[ni] = frag_read<B_KC>(Bs, kk, wn * 64 + ni * 16, lane);
+            for (int ni = 0; ni < G::MI; ++ni) bf[ni] = frag_read<B_KC, TILE>(Bs, kk, wn * G::WT + ni * 16, lane);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < G::MI; ++ni)
                     // first operand indexes the result row (= j), second the result
                     // column (= i = lane&15): stores become 128 B contiguous in i.
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
         }
         if (more) {
-            double* An = lds + (cur ^ 1) * 2 * OPBUF;
-            stage_store<A_KC>(An, tid, ga);
-            stage_store<B_KC>(An + OPBUF, tid, gb);
+            double* An = lds + (cur ^ 1) * 2 * G::OPBUF;
+            stage_store<A_KC, TILE>(An, tid, ga);
+            stage_store<B_KC, TILE>(An + G::OPBUF, tid, gb);
         }
         __syncthreads();
     }
 
-    // epilogue: acc[mi][ni][r] = C(i = i0+wm*64+mi*16+(lane&15), j = j0+wn*64+ni*16+(lane>>4)+4r)
+    // epilogue: acc[mi][ni][r] = C(i = i0+wm*WT+mi*16+(lane&15), j = j0+wn*WT+ni*16+(lane>>4)+4r)
     const bool mirror = a.mirror && (it != jt);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < G::MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < G::MI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int i = i0 + wm * 64 + mi * 16 + (lane & 15);
-                int j = j0 + wn * 64 + ni * 16 + (lane >> 4) + 4 * r;
+                int i = i0 + wm * G::WT + mi * 16 + (lane & 15);
+                int j = j0 + wn * G::WT + ni * 16 + (lane >> 4) + 4 * r;
                 double* c = a.C + (size_t)j * a.ldc + i;
                 double v = a.alpha * acc[mi][ni][r];
                 if (a.beta != 0.0) v += a.beta * (*c);
@@ -177,102 +189,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
     }
 }
 
-void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
-    if (a.grid <= 0) return;
+template <int TILE>
+static void launch_gemm_t(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
     dim3 grid(a.grid), block(256);
     if (!a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_kernel<false, false, TILE>), grid, block, 0, s, a);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true, TILE>), grid, block, 0, s, a);
     else if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_kernel<true, true, TILE>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_kernel<true, false, TILE>), grid, block, 0, s, a);
 }
 
-// ----------------------------------------------------------------------------
-// Leaf: one 128x128 diagonal tile.  Reads the lower triangle of A(o:o+128,o:o+128),
-// factors it (L L^T, unblocked right-looking, the tile lives in LDS) and writes
-// X = L^-1 (lower, zeros above the diagonal) to the X buffer.  A non-positive or
-// NaN pivot records info = (global column + 1) like dpotrf's info (the facade turns
-// it into the reference's "Matrix inversion failed, the matrix is singular.",
-// dnamatrix_contiguous.cpp:983).
-// ----------------------------------------------------------------------------
-constexpr int LS = 129;
-
-__global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
-                                                               int ldx, int o, int* info) {
-    __shared__ double S[128 * LS];
-    // pivot column (phase 1) / pivot row (phase 2) lives in its own array so that the
-    // compiler can keep the rank-1 update loops free of LDS read-after-write waits
-    __shared__ double piv[2][128];
-    __shared__ double dg[128];
-    const int tid = threadIdx.x;
-    const int row = tid & 127;
-    const int q = tid >> 7;  // 0..3: column residue class owned by this thread
-
-    // load lower triangle (coalesced down columns)
-    for (int c = q; c < 128; c += 4) {
-        double v = A[(size_t)(o + c) * lda + o + row];
-        S[row * LS + c] = (row >= c) ? v : 0.0;
-    }
-    __syncthreads();
-
-    // Cholesky, right-looking
-    for (int k = 0; k < 128; ++k) {
-        double d = S[k * LS + k];
-        if (!(d > 0.0)) {
-            if (tid == 0) atomicMin(info, o + k + 1);
-            d = 1.0;
-        }
-        double r = sqrt(d);
-        double inv = 1.0 / r;
-        double* pk = piv[k & 1];
-        if (q == 0 && row > k) {
-            double l = S[row * LS + k] * inv;
-            S[row * LS + k] = l;
-            pk[row] = l;
-        }
-        if (tid == 0) dg[k] = r;
-        __syncthreads();
-        if (row > k) {
-            const double lik = pk[row];
-            double* srow = S + row * LS;
-#pragma unroll 4
-            for (int j = k + 1 + q; j <= row; j += 4) srow[j] -= lik * pk[j];
-        }
-        __syncthreads();
-    }
-    // S strictly-lower = L, dg = diag(L).  In-place inverse of the lower triangle
-    // (Gauss-Jordan on [L | I]): after step k column k of L is dead and is reused
-    // for column k of M = L^-1.
-    for (int k = 0; k < 128; ++k) {
-        const double mkk = 1.0 / dg[k];
-        double* pk = piv[k & 1];
-        if (tid < k) {  // scale row k of M (columns < k)
-            double v = S[k * LS + tid] * mkk;
-            S[k * LS + tid] = v;
-            pk[tid] = v;
-        }
-        const double lik = (row > k) ? S[row * LS + k] : 0.0;
-        __syncthreads();
-        if (row > k) {
-            double* srow = S + row * LS;
-#pragma unroll 4
-            for (int j = q; j < k; j += 4) srow[j] -= lik * pk[j];
-            if (q == 0) srow[k] = -lik * mkk;
-        }
-        if (tid == 0) dg[k] = mkk;
-        __syncthreads();
-    }
-    for (int c = q; c < 128; c += 4) {
-        double v = (row > c) ? S[row * LS + c] : (row == c ? dg[c] : 0.0);
-        X[(size_t)(o + c) * ldx + o + row] = v;
-    }
-}
-
-void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s) {
-    hipLaunchKernelGGL(leaf_potrf_trtri_kernel, dim3(1), dim3(512), 0, s, A, lda, X, ldx, o, info);
+void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
+    if (a.grid <= 0) return;
+    if (a.tile == 64)
+        launch_gemm_t<64>(a, a_kc, b_kc, s);
+    else
+        launch_gemm_t<128>(a, a_kc, b_kc, s);
 }
 
 // ----------------------------------------------------------------------------

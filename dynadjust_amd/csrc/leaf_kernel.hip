@@ -1,0 +1,210 @@
+// Leaf of the recursive inverse: one 128x128 diagonal tile, one workgroup (8 waves).
+// Reads the lower triangle of A(o:o+128, o:o+128), factors it (L L^T) and writes X = L^-1
+// (lower, zeros above the diagonal) to the X buffer.  The tile lives in LDS (129 KiB of the
+// CU's 160 KiB).  Both phases are blocked by 16-column panels:
+//   phase A (Cholesky), per panel kb
+//     [wave 0]   factor the 16x16 diagonal block D and invert it, entirely in registers
+//                (one row / column per lane, v_readlane broadcasts, v_rsq_f64 + Newton)
+//     [waves]    P = A_panel * D^-T            one 16-row slab per wave, 4 MFMA f64 16x16x4
+//     [waves]    A_trail -= P P^T              16x16 tiles round-robin over the waves
+//   phase B (X = L^-1, in place), per panel kb -- the D^-1 of phase A are reused
+//     [waves]    M(kb, :kb) = D^-1 * M(kb, :kb)
+//     [waves]    M(i, :kb) -= L(i,kb) * M(kb, :kb);  M(i,kb) = -L(i,kb) * D^-1     (slab i per wave)
+// 5 barriers per panel instead of 4 per column.  A non-positive or NaN pivot records
+// info = global column + 1 (dpotrf's info; the facade turns it into the reference's
+// "Matrix inversion failed, the matrix is singular.", dnamatrix_contiguous.cpp:983).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "la_kernels.h"
+
+namespace dnagpu {
+
+namespace {
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int LS = 129;  // row stride of the tile in LDS
+constexpr int PS = 17;   // row stride of the 16x16 diagonal-block inverses
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// acc += sign * A * B for 16x16 operands in LDS: A(i,k) = a[i*ars + k*acs], B(k,j) = b[k*brs + j*bcs].
+// v_mfma_f64_16x16x4_f64: lane l feeds A(l&15, l>>4) and B(l>>4, l&15); acc[r] = D((l>>4) + 4r, l&15).
+__device__ __forceinline__ d4 mma16(const double* a, int ars, int acs, const double* b, int brs, int bcs, d4 acc, double sign, int lane) {
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kk + hi;
+        double av = sign * a[lo * ars + k * acs];
+        double bv = b[k * brs + lo * bcs];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ d4 tile_load(const double* S, int r0, int c0, int lane) {
+    const int lo = lane & 15, hi = lane >> 4;
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = S[(r0 + hi + 4 * r) * LS + c0 + lo];
+    return v;
+}
+
+__device__ __forceinline__ void tile_store(double* S, int r0, int c0, int lane, d4 v) {
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(r0 + hi + 4 * r) * LS + c0 + lo] = v[r];
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
+                                                               int ldx, int o, int* info) {
+    __shared__ double S[128 * LS];
+    __shared__ double Xd[8 * 16 * PS];  // D^-1 of every diagonal block
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int row = tid & 127;
+    const int q = tid >> 7;  // 0..3
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+
+    for (int c = q; c < 128; c += 4) {
+        double v = A[(size_t)(o + c) * lda + o + row];
+        S[row * LS + c] = (row >= c) ? v : 0.0;
+    }
+    __syncthreads();
+
+    // ------------------------------- phase A: Cholesky -------------------------------
+#pragma unroll 1
+    for (int kb = 0; kb < 8; ++kb) {
+        const int p0 = 16 * kb;
+        double* xd = Xd + kb * 16 * PS;
+        if (wave == 0) {
+            const int i = lane & 15;
+            double d[16], invs[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d[j] = S[(p0 + i) * LS + p0 + j];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                double pk = readlane_f64(d[k], k);
+                if (!(pk > 0.0)) {
+                    if (lane == 0) atomicMin(info, o + p0 + k + 1);
+                    pk = 1.0;
+                }
+                // y = pk^-1/2 (v_rsq_f64 + 2 Newton steps), r = pk^1/2 with one correction
+                double y = __builtin_amdgcn_rsq(pk);
+                const double h = 0.5 * pk;
+                y = y * fma(-h * y, y, 1.5);
+                y = y * fma(-h * y, y, 1.5);
+                double r = pk * y;
+                r = fma(fma(-r, r, pk), 0.5 * y, r);
+                invs[k] = y;
+                d[k] = (i == k) ? r : d[k] * y;
+#pragma unroll
+                for (int j = k + 1; j < 16; ++j) {
+                    double ljk = readlane_f64(d[k], j);
+                    d[j] = fma(-d[k], ljk, d[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j <= i) S[(p0 + i) * LS + p0 + j] = d[j];
+            }
+            // lane j solves column j of D X = I:  x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii
+            double x[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) {
+                double s = (ii == i) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < ii; ++k) {
+                    double lik = readlane_f64(d[k], ii);
+                    s = fma(-lik, x[k], s);
+                }
+                x[ii] = s * invs[ii];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) xd[ii * PS + i] = x[ii];  // X(ii, i); zero above the diagonal
+            }
+        }
+        __syncthreads();
+        // panel slabs below the diagonal block: P = A_panel * D^-T, one slab per wave
+        if (wave < 7 - kb) {
+            const int r0 = p0 + 16 + 16 * wave;
+            d4 acc = mma16(S + r0 * LS + p0, LS, 1, xd, 1, PS, zero, 1.0, lane);
+            tile_store(S, r0, p0, lane, acc);
+        }
+        __syncthreads();
+        // trailing update: tiles (ti, tj), kb < tj <= ti, round-robin over the waves
+        {
+            const int nt = 7 - kb;  // tile rows below the panel
+            int t = 0;
+            for (int ti = 0; ti < nt; ++ti)
+                for (int tj = 0; tj <= ti; ++tj, ++t) {
+                    if ((t & 7) != wave) continue;
+                    const int r0 = p0 + 16 + 16 * ti, c0 = p0 + 16 + 16 * tj;
+                    d4 acc = tile_load(S, r0, c0, lane);
+                    acc = mma16(S + r0 * LS + p0, LS, 1, S + c0 * LS + p0, 1, LS, acc, -1.0, lane);
+                    tile_store(S, r0, c0, lane, acc);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------- phase B: X = L^-1 -------------------------------
+#pragma unroll 1
+    for (int kb = 0; kb < 8; ++kb) {
+        const int p0 = 16 * kb;
+        const double* xd = Xd + kb * 16 * PS;
+        // row block kb, columns left of the panel: M_k <- D^-1 * M_k ; the diagonal block becomes D^-1
+        for (int tj = wave; tj <= kb; tj += 8) {
+            if (tj < kb) {
+                d4 acc = mma16(xd, PS, 1, S + p0 * LS + 16 * tj, LS, 1, zero, 1.0, lane);
+                tile_store(S, p0, 16 * tj, lane, acc);
+            } else {
+                const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(p0 + hi + 4 * r) * LS + p0 + lo] = xd[(hi + 4 * r) * PS + lo];
+            }
+        }
+        __syncthreads();
+        // slabs below: M(i, :kb) -= L(i,kb) M_k ;  M(i,kb) = -L(i,kb) D^-1   (one slab per wave: L(i,kb) is read
+        // by the wave that finally overwrites it)
+        if (wave < 7 - kb) {
+            const int r0 = p0 + 16 + 16 * wave;
+            const int lo = lane & 15, hi = lane >> 4;
+            double lf[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) lf[kk] = S[(r0 + lo) * LS + p0 + 4 * kk + hi];
+            for (int tj = 0; tj < kb; ++tj) {
+                d4 acc = tile_load(S, r0, 16 * tj, lane);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], S[(p0 + 4 * kk + hi) * LS + 16 * tj + lo], acc, 0, 0, 0);
+                tile_store(S, r0, 16 * tj, lane, acc);
+            }
+            d4 acc = zero;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], xd[(4 * kk + hi) * PS + lo], acc, 0, 0, 0);
+            tile_store(S, r0, p0, lane, acc);
+        }
+        __syncthreads();
+    }
+
+    for (int c = q; c < 128; c += 4) {
+        double v = (row >= c) ? S[row * LS + c] : 0.0;
+        X[(size_t)(o + c) * ldx + o + row] = v;
+    }
+}
+
+void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s) {
+    hipLaunchKernelGGL(leaf_potrf_trtri_kernel, dim3(1), dim3(512), 0, s, A, lda, X, ldx, o, info);
+}
+
+}  // namespace dnagpu

@@ -51,11 +51,13 @@ static double gemm_flops(const GemmArgs& a) {
 }
 
 hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a) {
+    long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
+    a.tile = total < SMALL_LAUNCH_TILES ? 64 : 128;
     uint64_t key = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
                    ((uint64_t)(a.K / 16) << 40);
     auto it = ws.order_cache.find(key);
     if (it == ws.order_cache.end()) {
-        std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower);
+        std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower, a.tile);
         uint32_t* dev = nullptr;
         if (!tab.empty()) {
             hipError_t e = hipMalloc(&dev, tab.size() * sizeof(uint32_t));

@@ -15,21 +15,24 @@
 
 namespace dnagpu {
 
-static inline int klen(int it, int jt, int K, int kmode) {
+// it / jt count tiles of `tile` columns; the k restrictions are in units of the recursion's 128-blocks
+static inline int klen(int it, int jt, int K, int kmode, int tile) {
     int kb = 0, ke = K;
+    const int bi = it * tile / 128, bj = jt * tile / 128;
     switch (kmode) {
-        case KM_LE_J: ke = (jt + 1) * 128; break;
-        case KM_GE_J: kb = jt * 128; break;
-        case KM_LE_I: ke = (it + 1) * 128; break;
-        case KM_GE_I: kb = it * 128; break;
+        case KM_LE_J: ke = (bj + 1) * 128; break;
+        case KM_GE_J: kb = bj * 128; break;
+        case KM_LE_I: ke = (bi + 1) * 128; break;
+        case KM_GE_I: kb = bi * 128; break;
         default: break;
     }
     if (ke > K) ke = K;
     return ke > kb ? ke - kb : 0;
 }
 
-std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower) {
+std::vector<uint32_t> build_tile_order(int mt128, int nt128, int K, int kmode, int lower, int tile) {
     std::vector<uint32_t> out;
+    const int mt = mt128 * (128 / tile), nt = nt128 * (128 / tile);
     long total = lower ? (long)mt * (mt + 1) / 2 : (long)mt * nt;
     if (total <= 0) return out;
     if (total <= 8) {
@@ -52,7 +55,7 @@ std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int low
             for (int it = si * G; it < std::min(mt, (si + 1) * G); ++it)
                 for (int jt = sj * G; jt < std::min(nt, (sj + 1) * G); ++jt) {
                     if (lower && jt > it) continue;
-                    w += klen(it, jt, K, kmode) + 16;  // + fixed per-tile cost
+                    w += klen(it, jt, K, kmode, tile) + 16;  // + fixed per-tile cost
                     ++cnt;
                 }
             if (cnt) supers.push_back({w, si, sj});
