@@ -55,6 +55,15 @@ int orc_set_lapack(const char* lib) {
 
 const char* orc_lapack_name(void) { return lapack_name; }
 
+/* thread count of the external LAPACK (MKL_Set_Num_Threads when the MKL runtime is loaded) */
+int orc_set_threads(int n) {
+    if (!ext_handle || n <= 0) return -1;
+    void (*setn)(int) = (void (*)(int))dlsym(ext_handle, "MKL_Set_Num_Threads");
+    if (!setn) return -2;
+    setn(n);
+    return 0;
+}
+
 #define A_(i, j) a[(size_t)(j) * lda + (i)]
 
 /* dpotrf('L'), unblocked left-looking column Cholesky (LAPACK dpotf2 lower) */

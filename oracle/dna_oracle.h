@@ -33,6 +33,7 @@ size_t orc_packed_index(uint32_t n, uint32_t i, uint32_t j);
  * (e.g. /opt/conda/lib/libmkl_rt.so).  Returns 0 on success. */
 int orc_set_lapack(const char* lib);
 const char* orc_lapack_name(void);
+int orc_set_threads(int n);
 /* dpotrf('L') / dpotri('L') on a full column-major matrix, lda >= n; return LAPACK info */
 int orc_potrf_lower(uint32_t n, double* a, uint32_t lda);
 int orc_potri_lower(uint32_t n, double* a, uint32_t lda);

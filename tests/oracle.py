@@ -38,6 +38,9 @@ def load():
         lib.orc_packed_index.argtypes = [C.c_uint32] * 3
         lib.orc_set_lapack.argtypes = [C.c_char_p]
         lib.orc_lapack_name.restype = C.c_char_p
+        lib.orc_set_threads.argtypes = [C.c_int]
+        lib.orc_potrf_lower.argtypes = [C.c_uint32, f64p, C.c_uint32]
+        lib.orc_potri_lower.argtypes = [C.c_uint32, f64p, C.c_uint32]
         lib.orc_cholesky_inverse_packed.argtypes = [f64p, C.c_uint32]
         lib.orc_inverse_normals_packed.argtypes = [f64p, C.c_uint32, C.c_int]
         lib.orc_cholesky_inverse_full.argtypes = [f64p, C.c_uint32, C.c_uint32]
