@@ -86,6 +86,8 @@ def load():
     _sig(lib, "dnagpu_matrix_upload_packed", i, [vp, i, vp, c_f64p, u32])
     _sig(lib, "dnagpu_matrix_download_packed", i, [vp, i, vp, c_f64p])
     _sig(lib, "dnagpu_matrix_copy", i, [vp, i, vp, vp])
+    _sig(lib, "dnagpu_matrix_export", i, [vp, i, vp, vp, sz])
+    _sig(lib, "dnagpu_matrix_import", i, [vp, i, vp, vp, u32])
     _sig(lib, "dnagpu_invert", i, [vp, i, vp, i])
     _sig(lib, "dnagpu_block_create", i, [vp, u32, u32, u32])
     _sig(lib, "dnagpu_block_destroy", i, [vp, u32])
@@ -138,6 +140,24 @@ def load():
     _sig(lib, "dnaadj_block_variances_packed", i, [vp, u32, c_f64p])
     _sig(lib, "dnaadj_adjusted_coordinates", i, [vp, c_f64p])
     _sig(lib, "dnaadj_device_context", vp, [vp])
+    ip = C.POINTER(C.c_int)
+    dp = C.POINTER(C.c_double)
+    _sig(lib, "dnaadj_block_flags", i, [vp, u32, ip, ip, ip])
+    _sig(lib, "dnaadj_junction_unknowns", u32, [vp, u32])
+    _sig(lib, "dnaadj_junction_payload_doubles", sz, [vp, u32])
+    _sig(lib, "dnaadj_phased_begin_iteration", i, [vp])
+    _sig(lib, "dnaadj_phased_forward_block", i, [vp, u32, dp])
+    _sig(lib, "dnaadj_phased_reverse_block", i, [vp, u32, dp])
+    _sig(lib, "dnaadj_phased_combine_block", i, [vp, u32, dp])
+    _sig(lib, "dnaadj_phased_finalise_block", i, [vp, u32])
+    _sig(lib, "dnaadj_phased_note_correction", i, [vp, C.c_double])
+    _sig(lib, "dnaadj_phased_end_iteration", i, [vp, ip])
+    _sig(lib, "dnaadj_phased_finish", i, [vp, ip])
+    _sig(lib, "dnaadj_junction_export", i, [vp, i, u32, vp])
+    _sig(lib, "dnaadj_junction_import", i, [vp, i, u32, vp])
+    _sig(lib, "dnaadj_block_get_coords", i, [vp, u32, i, c_f64p])
+    _sig(lib, "dnaadj_block_set_coords", i, [vp, u32, c_f64p])
+    _sig(lib, "dnaadj_block_recompute_b", i, [vp, u32])
     _sig(lib, "dnasynth_write_network", i, [C.c_char_p, C.c_char_p, C.POINTER(DnaSynthSpec), C.POINTER(DnaSynthSummary), C.c_char_p, sz])
     _sig(lib, "dnaio_file_summary", i, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_char_p, sz])
     _sig(lib, "dnaio_seg_summary", i, [C.c_char_p, C.c_char_p, c_u32p, c_u32p, u32, C.c_char_p, sz])
@@ -151,7 +171,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_device_count", "dnagpu_create", "dnagpu_destroy", "dnagpu_last_error", "dnagpu_last_info", "dnagpu_sync",
     "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset",
     "dnagpu_profile_get", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
-    "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_copy", "dnagpu_invert",
+    "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
@@ -166,5 +186,9 @@ EXPORTED_DNAADJ = [
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
+    "dnaadj_block_flags", "dnaadj_junction_unknowns", "dnaadj_junction_payload_doubles", "dnaadj_phased_begin_iteration",
+    "dnaadj_phased_forward_block", "dnaadj_phased_reverse_block", "dnaadj_phased_combine_block", "dnaadj_phased_finalise_block",
+    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_junction_export",
+    "dnaadj_junction_import", "dnaadj_block_get_coords", "dnaadj_block_set_coords", "dnaadj_block_recompute_b",
     "dnasynth_write_network", "dnaio_file_summary", "dnaio_seg_summary", "dnaio_sizeof_station", "dnaio_sizeof_measurement",
 ]

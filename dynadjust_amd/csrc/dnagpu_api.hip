@@ -353,6 +353,30 @@ int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dna
     return DNAGPU_OK;
 }
 
+int dnagpu_matrix_export(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* dst, size_t cap_doubles) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || !dst) return fail(ctx, DNAGPU_EINVAL, "matrix_export: null argument");
+    size_t need = (size_t)m->np * m->np + m->np;
+    if (cap_doubles < need) return fail(ctx, DNAGPU_EINVAL, "matrix_export: destination too small");
+    HIPCHK(hipMemcpyAsync(dst, m->F, (size_t)m->np * m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
+    HIPCHK(hipMemcpyAsync(dst + (size_t)m->np * m->np, m->jest, (size_t)m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* src, uint32_t n) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || !src || n > m->n_max) return fail(ctx, DNAGPU_EINVAL, "matrix_import: bad arguments");
+    m->n = n;
+    m->np = pad128(n);
+    HIPCHK(hipMemcpyAsync(m->F, src, (size_t)m->np * m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
+    HIPCHK(hipMemcpyAsync(m->jest, src + (size_t)m->np * m->np, (size_t)m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
 int dnagpu_invert(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, int scale_to_unity) {
     CHK_CTX();
     CHK_CHAIN();

@@ -342,7 +342,7 @@ void dna_adjust::PrepareBlocks() {
                 Check(dnagpu_matrix_create(ctx_, nj, &B.jfwd), b, "PrepareAdjustment(): junction matrix");
                 Check(dnagpu_matrix_create(ctx_, nj, &B.jrev), b, "PrepareAdjustment(): junction matrix");
             }
-            Check(dnagpu_matrix_create(ctx_, ns * 3, &B.rigvar), b, "PrepareAdjustment(): rigorous variance matrix");
+            // v_rigorousVariances_ is allocated when the block is finalised (only on the rank / chain that owns it)
         }
     }
     Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
@@ -403,9 +403,9 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     isPreparing_ = false;
 }
 
-void dna_adjust::AddConstraints(int chain, dnagpu_matrix* m, const constraint_list& c, int sign) {
+void dna_adjust::AddConstraints(int chain, dnagpu_matrix* m, const constraint_list& c, int sign, UINT32 block) {
     if (c.stn.empty()) return;
-    Check(dnagpu_add_diag3x3(ctx_, chain, m, c.stn.data(), c.w9.data(), c.stn.size(), sign), currentBlock_,
+    Check(dnagpu_add_diag3x3(ctx_, chain, m, c.stn.data(), c.w9.data(), c.stn.size(), sign), block,
           "AddConstraintStationstoNormals()");
 }
 
@@ -413,8 +413,11 @@ void dna_adjust::AddConstraints(int chain, dnagpu_matrix* m, const constraint_li
 void dna_adjust::SolveTry(int chain, UINT32 block, dnagpu_matrix* m) {
     Check(dnagpu_invert(ctx_, chain, m, projectSettings_.a.scale_normals_to_unity ? 1 : 0), block, "Solve()");
     double n = 3.0 * (double)v_parameterStationList_[block].size();
-    solve_flops_ += n * n * n;
-    solve_count_++;
+    {
+        std::lock_guard<std::mutex> lk(corr_mutex_);
+        solve_flops_ += n * n * n;
+        solve_count_++;
+    }
     Check(dnagpu_solve_corrections(ctx_, chain, block, m), block, "Solve()");
 }
 
@@ -449,7 +452,7 @@ void dna_adjust::AdjustSimultaneous() {
         currentBlock_ = 0;
         if (currentIteration_ < 2) {
             Check(dnagpu_form_normals(ctx_, c, 0, W), 0, "UpdateNormals()");
-            AddConstraints(c, W, B.con_sim, +1);
+            AddConstraints(c, W, B.con_sim, +1, 0);
         }
         Check(dnagpu_form_rhs(ctx_, c, 0), 0, "Solve()");
         if (currentIteration_ < 2)
@@ -495,7 +498,12 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
             for (int c = 0; c < chains; ++c) Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
             Check(dnagpu_block_copy_stations(ctx_, 0, b, 0, 2), b, "UpdateAdjustment()");
         }
-        for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
+        // every chain restarts from the rigorous estimates of the iteration just finished (multi-thread mode:
+        // v_estimatedStationsR_ = v_rigorousStations_ ADJ:569; v_estimatedStations_ = v_estimatedStationsR_ ADJ:3799)
+        for (int c = 0; c < chains; ++c) {
+            Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
+            Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
+        }
     }
     isPreparing_ = false;
 }
@@ -507,9 +515,13 @@ void dna_adjust::AdjustPhased() {
         if (IsCancelled()) break;
         maxCorr_ = 0.0;
         ++currentIteration_;
-        AdjustPhasedForward();
-        if (IsCancelled()) break;
-        AdjustPhasedReverseCombine();
+        if (projectSettings_.a.multi_thread) {
+            AdjustPhasedMultiThreadIteration();
+        } else {
+            AdjustPhasedForward();
+            if (IsCancelled()) break;
+            AdjustPhasedReverseCombine();
+        }
         if (IsCancelled()) break;
         iterationCorrections_.push_back(maxCorr_);
         bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
@@ -517,116 +529,6 @@ void dna_adjust::AdjustPhased() {
         UpdateAdjustment(iterate);
     }
     ValidateandFinaliseAdjustment();
-}
-
-// ADJ:2756-2852 + CarryForwardJunctions ADJ:3065 + CarryStnEstimatesandVariancesForward ADJ:998
-void dna_adjust::AdjustPhasedForward() {
-    forward_ = true;
-    const int c = 0;
-    dnagpu_matrix* W = work_[c];
-    for (UINT32 k = 0; k < blockCount_; ++k) {
-        if (IsCancelled()) break;
-        currentBlock_ = k;
-        block_t& B = blocks_[k];
-        const blockMeta_t& meta = v_blockMeta_[k];
-        const bool carried_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
-        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
-        AddConstraints(c, W, B.con_fwd, +1);
-        if (carried_in)
-            Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
-                  "CarryStnEstimatesandVariancesForward()");
-        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
-        if (carried_in)
-            Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
-        SolveTry(c, k, W);
-        // UpdateEstimatesForward (ADJ:3022)
-        double mv = 0.0;
-        UINT32 row = 0;
-        Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesForward()");
-        if (meta._blockLast || meta._blockIsolated) {
-            if (std::fabs(mv) > std::fabs(maxCorr_)) SetmaxCorr(mv);
-            Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesForward()");
-            Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesForward()");
-            B.has_rigvar = true;
-        }
-        if (meta._blockIsolated || meta._blockLast) continue;
-        if (v_blockMeta_[k + 1]._blockIsolated) continue;
-        if (B.jsl_here.empty()) continue;
-        Check(dnagpu_junction_gather(ctx_, c, k, W, B.jsl_here.data(), B.jsl_here.size(), B.jfwd), k,
-              "CarryStnEstimatesandVariancesForward()");
-        Check(dnagpu_invert(ctx_, c, B.jfwd, 0), k, "CarryStnEstimatesandVariancesForward()");
-    }
-}
-
-// ADJ:3461-3590 + CarryReverseJunctions ADJ:3833 + CarryStnEstimatesandVariancesReverse ADJ:1133
-// + PrepareAdjustmentCombine ADJ:3336 + UpdateEstimatesFinal ADJ:3744
-void dna_adjust::AdjustPhasedReverseCombine() {
-    forward_ = false;
-    isCombining_ = false;
-    const int c = projectSettings_.a.multi_thread ? 1 : 0;
-    dnagpu_matrix* W = work_[c];
-    for (UINT32 kk = blockCount_; kk-- > 0;) {
-        if (IsCancelled()) break;
-        const UINT32 k = kk;
-        currentBlock_ = k;
-        block_t& B = blocks_[k];
-        const blockMeta_t& meta = v_blockMeta_[k];
-        if (meta._blockIsolated) continue;   // PrepareAdjustmentReverse (ADJ:3115)
-        const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
-        const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
-        // estimates back to the originals (ADJ:3157 for the last block, ADJ:3863 for the others)
-        Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentReverse()");
-        // normals = measurements + junctions carried in reverse + constraints (first appearance in reverse)
-        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
-        if (rev_in)
-            Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k,
-                  "CarryStnEstimatesandVariancesReverse()");
-        AddConstraints(c, W, B.con_rev, +1);
-        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
-        if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
-        SolveTry(c, k, W);
-        double mv = 0.0;
-        UINT32 row = 0;
-        Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesReverse()");
-        if (!meta._blockFirst) {
-            // carry this block's junction estimates and variances to block k-1
-            if (fwd_in) {
-                Check(dnagpu_junction_gather(ctx_, c, k, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jrev), k,
-                      "CarryStnEstimatesandVariancesReverse()");
-                Check(dnagpu_invert(ctx_, c, blocks_[k - 1].jrev, 0), k, "CarryStnEstimatesandVariancesReverse()");
-            }
-            if (CombineRequired(k)) {
-                isCombining_ = true;
-                Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentCombine()");
-                // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed
-                // in the same summation order, which gives the same bits
-                Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
-                if (rev_in)
-                    Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k,
-                          "CarryStnEstimatesandVariancesCombine()");
-                AddConstraints(c, W, B.con_rev, +1);
-                if (fwd_in)
-                    Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
-                          "CarryStnEstimatesandVariancesCombine()");
-                AddConstraints(c, W, B.con_cmb, -1);
-                Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
-                if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
-                if (fwd_in)
-                    Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
-                SolveTry(c, k, W);
-                Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesCombine()");
-                isCombining_ = false;
-            }
-        }
-        // UpdateEstimatesFinal (ADJ:3744)
-        if (meta._blockLast) continue;
-        if (std::fabs(mv) > std::fabs(maxCorr_)) SetmaxCorr(mv);
-        Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesFinal()");   // rigorous = estimated
-        Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesFinal()");
-        B.has_rigvar = true;
-        Check(dnagpu_block_copy_stations(ctx_, c, k, 0, 2), k, "UpdateEstimatesFinal()");   // original = rigorous
-        if (c != 0) Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
-    }
 }
 
 void dna_adjust::GetBlockRigorousStations(UINT32 block, std::vector<double>& xyz) {
@@ -640,6 +542,7 @@ void dna_adjust::GetBlockRigorousVariancesPacked(UINT32 block, std::vector<doubl
     size_t n = 3 * v_parameterStationList_[block].size();
     packed.resize(n * (n + 1) / 2);
     dnagpu_matrix* m = (projectSettings_.a.adjust_mode == SimultaneousMode) ? work_[0] : blocks_[block].rigvar;
+    if (!m) throw std::runtime_error("GetBlockRigorousVariancesPacked(): this process holds no rigorous variances for the block");
     Check(dnagpu_matrix_download_packed(ctx_, 0, m, packed.data()), block, "GetBlockRigorousVariancesPacked()");
 }
 
@@ -672,6 +575,9 @@ void dna_adjust::ResetAdjustment() {
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
     currentIteration_ = 0;
     maxCorr_ = 0.0;
+    iterationCorrections_.clear();
+    solve_flops_ = 0.0;
+    solve_count_ = 0;
     cancel_.store(false);
     adjustStatus_ = ADJUST_SUCCESS;
 }

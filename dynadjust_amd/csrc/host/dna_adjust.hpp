@@ -6,6 +6,7 @@
 #pragma once
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -122,12 +123,41 @@ private:
     void AdjustPhased();                 // ADJ:2579
     void AdjustPhasedForward();          // ADJ:2756
     void AdjustPhasedReverseCombine();   // ADJ:3461
+    void AdjustPhasedMultiThreadIteration();   // dnaadjust-multi.cpp:92-244 (forward || reverse chains)
+public:
+    // ---- per-block steps of the phased chain; the drivers above and the multi-GPU orchestrator
+    //      (dynadjust_amd/parallel.py through dnaadjust_c.h) are built from these ----------------
+    // forward solve of block k (+ carry of its junctions to k+1); returns the signed largest correction
+    double PhasedForwardBlock(int chain, UINT32 k);
+    // reverse solve of block k (+ carry of JSL(k-1) to k-1); for the first block the result is rigorous
+    double PhasedReverseBlock(int chain, UINT32 k);
+    // combination solve of an intermediate block (needs jrev[k] and jfwd[k-1] on this device)
+    double PhasedCombineBlock(int chain, UINT32 k);
+    // UpdateEstimatesFinal (ADJ:3744): rigorous = estimated, rigorous variances = current inverse, original = rigorous
+    void PhasedFinaliseBlock(int chain, UINT32 k);
+    // start of an iteration on this process: maxCorr = 0 (+ iteration counter)
+    void PhasedBeginIteration();
+    void PhasedNoteCorrection(double mv);   // maxCorr_ update rule of ADJ:3036 / ADJ:3786
+    // end of an iteration: convergence test + UpdateAdjustment; returns true when another iteration is needed
+    bool PhasedEndIteration();
+    void PhasedFinish();                    // ValidateandFinaliseAdjustment
+    const blockMeta_t& BlockMeta(UINT32 k) const { return v_blockMeta_.at(k); }
+    UINT32 JunctionUnknowns(UINT32 k) const { return (UINT32)v_JSL_.at(k).size() * 3; }
+    // junction payload = np*np matrix (ld np) followed by np estimates, np = pad128(3|JSL(k)|); kind 0 = forward, 1 = reverse
+    size_t JunctionPayloadDoubles(UINT32 k) const;
+    void ExportJunction(int kind, UINT32 k, double* dst);         // dst: host or device memory
+    void ImportJunction(int kind, UINT32 k, const double* src);
+    void GetBlockStations(UINT32 k, int which, std::vector<double>& xyz);
+    void SetBlockStationsAll(UINT32 k, const double* xyz);        // original = estimated (all chains) = rigorous
+    void RecomputeMeasMinusComp(UINT32 k);
+private:
     void UpdateAdjustment(bool iterate); // ADJ:473
     void ValidateandFinaliseAdjustment();// ADJ:2513
 
     // one Solve() (ADJ:6586): normals already formed in `m`; rhs already formed
     void SolveTry(int chain, UINT32 block, dnagpu_matrix* m);
-    void AddConstraints(int chain, dnagpu_matrix* m, const constraint_list& c, int sign);
+    void AddConstraints(int chain, dnagpu_matrix* m, const constraint_list& c, int sign, UINT32 block);
+    void StoreRigorousVariances(int chain, UINT32 block, dnagpu_matrix* W);
     void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
     void Check(int rc, UINT32 block, const char* where);
     void SetmaxCorr(double v) { maxCorr_ = v; }
@@ -165,6 +195,7 @@ private:
     double solve_flops_ = 0.0;
     UINT32 solve_count_ = 0;
 
+    std::mutex corr_mutex_, alloc_mutex_;   // multi-thread mode: maxCorr_/solve counters, lazy allocations
     dnagpu_ctx* ctx_ = nullptr;
     dnagpu_matrix* work_[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
     UINT32 max_unknowns_ = 0, max_junction_ = 0;

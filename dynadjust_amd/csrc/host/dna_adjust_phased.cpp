@@ -1,0 +1,278 @@
+// The phased chain of dna_adjust, one block step at a time, and the three drivers built from the steps:
+//   AdjustPhasedForward + AdjustPhasedReverseCombine   sequential (reference ADJ:2756, ADJ:3461)
+//   AdjustPhasedMultiThreadIteration                     forward || reverse/combine on two chains of one GPU
+//                                                        (reference dnaadjust-multi.cpp:92-244, 365-641)
+//   the multi-GPU orchestrator (dynadjust_amd/parallel.py) calls the same steps through include/dnaadjust_c.h
+// Reference functions restated per step are cited at each function (ADJ = dynadjust/dnaadjust/dnaadjust.cpp).
+#include <cmath>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
+
+#include "dna_adjust.hpp"
+
+namespace dynadjust {
+namespace networkadjust {
+
+void dna_adjust::PhasedNoteCorrection(double mv) {
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    if (std::fabs(mv) > std::fabs(maxCorr_)) SetmaxCorr(mv);
+}
+
+// AdjustPhasedForward body for one block: Solve (ADJ:2812), UpdateEstimatesForward (ADJ:3022),
+// CarryForwardJunctions (ADJ:3065) -> CarryStnEstimatesandVariancesForward (ADJ:998)
+double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
+    dnagpu_matrix* W = work_[c];
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    const bool carried_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
+    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+    AddConstraints(c, W, B.con_fwd, +1, k);
+    if (carried_in)
+        Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
+              "CarryStnEstimatesandVariancesForward()");
+    Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+    if (carried_in)
+        Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
+    SolveTry(c, k, W);
+    double mv = 0.0;
+    UINT32 row = 0;
+    Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesForward()");
+    if (meta._blockLast || meta._blockIsolated) {
+        // the forward result of the last block is rigorous (ADJ:3033-3057)
+        PhasedNoteCorrection(mv);
+        Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesForward()");
+        StoreRigorousVariances(c, k, W);
+    }
+    if (meta._blockIsolated || meta._blockLast) return mv;
+    if (v_blockMeta_[k + 1]._blockIsolated) return mv;
+    if (B.jsl_here.empty()) return mv;
+    Check(dnagpu_junction_gather(ctx_, c, k, W, B.jsl_here.data(), B.jsl_here.size(), B.jfwd), k, "CarryStnEstimatesandVariancesForward()");
+    Check(dnagpu_invert(ctx_, c, B.jfwd, 0), k, "CarryStnEstimatesandVariancesForward()");
+    return mv;
+}
+
+// AdjustPhasedReverseCombine, reverse part for one block: PrepareAdjustmentReverse (ADJ:3112), Solve (ADJ:3512),
+// UpdateEstimatesReverse (ADJ:3678), CarryReverseJunctions (ADJ:3833) -> CarryStnEstimatesandVariancesReverse (ADJ:1133)
+double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
+    dnagpu_matrix* W = work_[c];
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    if (meta._blockIsolated) return 0.0;
+    const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
+    const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
+    // estimates back to the originals (ADJ:3157 for the last block, ADJ:3863 for the others)
+    Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentReverse()");
+    // normals = measurements + junctions carried in reverse + constraints (first appearance in reverse)
+    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+    if (rev_in)
+        Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
+    AddConstraints(c, W, B.con_rev, +1, k);
+    Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+    if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
+    SolveTry(c, k, W);
+    double mv = 0.0;
+    UINT32 row = 0;
+    Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesReverse()");
+    if (!meta._blockFirst && fwd_in) {
+        Check(dnagpu_junction_gather(ctx_, c, k, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jrev), k,
+              "CarryStnEstimatesandVariancesReverse()");
+        Check(dnagpu_invert(ctx_, c, blocks_[k - 1].jrev, 0), k, "CarryStnEstimatesandVariancesReverse()");
+    }
+    return mv;
+}
+
+// PrepareAdjustmentCombine (ADJ:3336) -> CarryStnEstimatesandVariancesCombine (ADJ:3196), Solve (ADJ:3556),
+// UpdateEstimatesCombine (ADJ:3718)
+double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
+    dnagpu_matrix* W = work_[c];
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
+    const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
+    Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentCombine()");
+    // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed in the
+    // same summation order, which gives the same bits
+    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+    if (rev_in)
+        Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesCombine()");
+    AddConstraints(c, W, B.con_rev, +1, k);
+    if (fwd_in)
+        Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
+              "CarryStnEstimatesandVariancesCombine()");
+    AddConstraints(c, W, B.con_cmb, -1, k);
+    Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+    if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
+    if (fwd_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
+    SolveTry(c, k, W);
+    double mv = 0.0;
+    UINT32 row = 0;
+    Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesCombine()");
+    return mv;
+}
+
+// v_rigorousVariances_[k] = the inverse currently held by the chain's work matrix
+void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
+    block_t& B = blocks_[k];
+    if (!B.rigvar) {
+        std::lock_guard<std::mutex> lk(alloc_mutex_);
+        Check(dnagpu_matrix_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, &B.rigvar), k, "rigorous variance matrix");
+    }
+    Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesFinal()");
+    B.has_rigvar = true;
+}
+
+// UpdateEstimatesFinal (ADJ:3744) for a block that is not the last of its network
+void dna_adjust::PhasedFinaliseBlock(int c, UINT32 k) {
+    Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesFinal()");   // rigorous = estimated
+    StoreRigorousVariances(c, k, work_[c]);
+    Check(dnagpu_block_copy_stations(ctx_, c, k, 0, 2), k, "UpdateEstimatesFinal()");   // original = rigorous
+    Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
+}
+
+// ADJ:2756-2852
+void dna_adjust::AdjustPhasedForward() {
+    forward_ = true;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        if (IsCancelled()) break;
+        currentBlock_ = k;
+        PhasedForwardBlock(0, k);
+    }
+}
+
+// ADJ:3461-3590
+void dna_adjust::AdjustPhasedReverseCombine() {
+    forward_ = false;
+    isCombining_ = false;
+    const int c = 0;
+    for (UINT32 kk = blockCount_; kk-- > 0;) {
+        if (IsCancelled()) break;
+        const UINT32 k = kk;
+        currentBlock_ = k;
+        const blockMeta_t& meta = v_blockMeta_[k];
+        if (meta._blockIsolated) continue;
+        double mv = PhasedReverseBlock(c, k);
+        if (CombineRequired(k)) {
+            isCombining_ = true;
+            mv = PhasedCombineBlock(c, k);
+            isCombining_ = false;
+        }
+        if (meta._blockLast) continue;   // rigorous from the forward pass (ADJ:3748-3756)
+        PhasedNoteCorrection(mv);
+        PhasedFinaliseBlock(c, k);
+    }
+}
+
+// One iteration with the forward chain on chain 0 and the reverse + combine chain on chain 1, each driven by
+// its own host thread (dnaadjust-multi.cpp:365 adjust_forward_thread, :475 adjust_reverse_thread, :593 combine).
+// combine(k) waits until the forward thread has published jfwd[k-1] (concurrent_block_adjustment, dnathreading.hpp:44).
+void dna_adjust::AdjustPhasedMultiThreadIteration() {
+    std::mutex m;
+    std::condition_variable cv;
+    int fwd_done = -1;           // highest block whose forward junctions are complete
+    bool fwd_failed = false;
+    std::exception_ptr fwd_error, rev_error;
+
+    std::thread fwd([&] {
+        try {
+            for (UINT32 k = 0; k < blockCount_; ++k) {
+                if (IsCancelled()) break;
+                PhasedForwardBlock(0, k);
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    fwd_done = (int)k;
+                }
+                cv.notify_all();
+            }
+        } catch (...) {
+            fwd_error = std::current_exception();
+            std::lock_guard<std::mutex> lk(m);
+            fwd_failed = true;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fwd_done = (int)blockCount_;
+        }
+        cv.notify_all();
+    });
+    try {
+        const int c = 1;
+        for (UINT32 kk = blockCount_; kk-- > 0;) {
+            if (IsCancelled()) break;
+            const UINT32 k = kk;
+            const blockMeta_t& meta = v_blockMeta_[k];
+            if (meta._blockIsolated) continue;
+            double mv = PhasedReverseBlock(c, k);
+            if (CombineRequired(k)) {
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return fwd_done >= (int)k - 1 || fwd_failed; });
+                    if (fwd_failed) break;
+                }
+                mv = PhasedCombineBlock(c, k);
+            }
+            if (meta._blockLast) continue;
+            PhasedNoteCorrection(mv);
+            PhasedFinaliseBlock(c, k);
+        }
+    } catch (...) {
+        rev_error = std::current_exception();
+    }
+    fwd.join();
+    if (fwd_error) std::rethrow_exception(fwd_error);   // dnaadjust-multi.cpp:182-190
+    if (rev_error) std::rethrow_exception(rev_error);
+}
+
+void dna_adjust::PhasedBeginIteration() {
+    maxCorr_ = 0.0;
+    ++currentIteration_;
+}
+
+bool dna_adjust::PhasedEndIteration() {
+    iterationCorrections_.push_back(maxCorr_);
+    bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
+    if (iterate && currentIteration_ >= projectSettings_.a.max_iterations) iterate = false;
+    if (iterate) UpdateAdjustment(true);
+    return iterate;
+}
+
+void dna_adjust::PhasedFinish() { ValidateandFinaliseAdjustment(); }
+
+size_t dna_adjust::JunctionPayloadDoubles(UINT32 k) const {
+    size_t n = (size_t)v_JSL_.at(k).size() * 3;
+    size_t np = n == 0 ? 128 : ((n + 127) / 128) * 128;
+    return np * np + np;
+}
+
+void dna_adjust::ExportJunction(int kind, UINT32 k, double* dst) {
+    block_t& B = blocks_.at(k);
+    dnagpu_matrix* jm = kind == 0 ? B.jfwd : B.jrev;
+    if (!jm) return;
+    Check(dnagpu_matrix_export(ctx_, 0, jm, dst, JunctionPayloadDoubles(k)), k, "ExportJunction()");
+}
+
+void dna_adjust::ImportJunction(int kind, UINT32 k, const double* src) {
+    block_t& B = blocks_.at(k);
+    dnagpu_matrix* jm = kind == 0 ? B.jfwd : B.jrev;
+    if (!jm) return;
+    Check(dnagpu_matrix_import(ctx_, 0, jm, src, JunctionUnknowns(k)), k, "ImportJunction()");
+}
+
+void dna_adjust::GetBlockStations(UINT32 k, int which, std::vector<double>& xyz) {
+    xyz.resize(3 * v_parameterStationList_.at(k).size());
+    Check(dnagpu_block_get_stations(ctx_, 0, k, which, xyz.data()), k, "GetBlockStations()");
+}
+
+void dna_adjust::SetBlockStationsAll(UINT32 k, const double* xyz) {
+    Check(dnagpu_block_set_stations(ctx_, k, xyz), k, "SetBlockStationsAll()");
+}
+
+void dna_adjust::RecomputeMeasMinusComp(UINT32 k) {
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
+    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, k), k, "FillDesignNormalMeasurementsMatrices()");
+}
+
+}  // namespace networkadjust
+}  // namespace dynadjust

@@ -246,3 +246,66 @@ extern "C" int dnaio_seg_summary(const char* seg_path, const char* bms_path, uin
         return DNAADJ_EXCEPTION;
     }
 }
+
+// ---- per-block steps of the phased chain -------------------------------------------------
+extern "C" {
+
+int dnaadj_block_flags(const dnaadj_handle* h, uint32_t block, int* first, int* last, int* isolated) {
+    if (!h || !h->adj || block >= h->adj->blockCount()) return DNAADJ_EINVAL;
+    const dynadjust::blockMeta_t& m = h->adj->BlockMeta(block);
+    if (first) *first = m._blockFirst;
+    if (last) *last = m._blockLast;
+    if (isolated) *isolated = m._blockIsolated;
+    return DNAADJ_OK;
+}
+uint32_t dnaadj_junction_unknowns(const dnaadj_handle* h, uint32_t block) {
+    return (h && h->adj && block < h->adj->blockCount()) ? h->adj->JunctionUnknowns(block) : 0;
+}
+size_t dnaadj_junction_payload_doubles(const dnaadj_handle* h, uint32_t block) {
+    return (h && h->adj && block < h->adj->blockCount()) ? h->adj->JunctionPayloadDoubles(block) : 0;
+}
+int dnaadj_phased_begin_iteration(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->PhasedBeginIteration(); });
+}
+int dnaadj_phased_forward_block(dnaadj_handle* h, uint32_t block, double* mv) {
+    return guarded(h, [&] { double v = h->adj->PhasedForwardBlock(0, block); if (mv) *mv = v; });
+}
+int dnaadj_phased_reverse_block(dnaadj_handle* h, uint32_t block, double* mv) {
+    return guarded(h, [&] { double v = h->adj->PhasedReverseBlock(0, block); if (mv) *mv = v; });
+}
+int dnaadj_phased_combine_block(dnaadj_handle* h, uint32_t block, double* mv) {
+    return guarded(h, [&] { double v = h->adj->PhasedCombineBlock(0, block); if (mv) *mv = v; });
+}
+int dnaadj_phased_finalise_block(dnaadj_handle* h, uint32_t block) {
+    return guarded(h, [&] { h->adj->PhasedFinaliseBlock(0, block); });
+}
+int dnaadj_phased_note_correction(dnaadj_handle* h, double mv) {
+    return guarded(h, [&] { h->adj->PhasedNoteCorrection(mv); });
+}
+int dnaadj_phased_end_iteration(dnaadj_handle* h, int* iterate) {
+    return guarded(h, [&] { bool it = h->adj->PhasedEndIteration(); if (iterate) *iterate = it ? 1 : 0; });
+}
+int dnaadj_phased_finish(dnaadj_handle* h, int* status) {
+    return guarded(h, [&] { h->adj->PhasedFinish(); if (status) *status = (int)h->adj->GetStatus(); });
+}
+int dnaadj_junction_export(dnaadj_handle* h, int kind, uint32_t block, double* buf) {
+    return guarded(h, [&] { h->adj->ExportJunction(kind, block, buf); });
+}
+int dnaadj_junction_import(dnaadj_handle* h, int kind, uint32_t block, const double* buf) {
+    return guarded(h, [&] { h->adj->ImportJunction(kind, block, buf); });
+}
+int dnaadj_block_get_coords(dnaadj_handle* h, uint32_t block, int which, double* xyz) {
+    return guarded(h, [&] {
+        std::vector<double> v;
+        h->adj->GetBlockStations(block, which, v);
+        if (!v.empty()) memcpy(xyz, v.data(), v.size() * sizeof(double));
+    });
+}
+int dnaadj_block_set_coords(dnaadj_handle* h, uint32_t block, const double* xyz) {
+    return guarded(h, [&] { h->adj->SetBlockStationsAll(block, xyz); });
+}
+int dnaadj_block_recompute_b(dnaadj_handle* h, uint32_t block) {
+    return guarded(h, [&] { h->adj->RecomputeMeasMinusComp(block); });
+}
+
+}  // extern "C"

@@ -1,0 +1,274 @@
+"""Multi-GPU schedule of the phased adjustment: one process per GPU, torch.distributed.
+
+The phased blocks form a chain (forward k -> k+1, reverse k -> k-1, combine(k) needs both), so the path shards the
+way the reference's multi-thread mode does (dnaadjust-multi.cpp:92-244): a forward chain, a reverse chain and the
+combination solves.  Per iteration:
+
+  phase 1   rank FWD runs the forward chain, rank REV the reverse chain (concurrently, no communication)
+  exchange  the junction matrices + junction estimates that the combination solves need travel point-to-point
+            (one grouped batch_isend_irecv; each payload is (3|JSL|)^2 + 3|JSL| doubles, padded to 128):
+            v_junctionVariancesFwd_/v_junctionEstimatesFwd_[k-1] from FWD, v_junctionVariances_/v_junctionEstimatesRev_[k] from REV
+  phase 2   the combination solves of the intermediate blocks, round-robin over ALL ranks
+  sync      rigorous coordinates of every block: one all_reduce(sum) of a 3*stations vector; largest correction:
+            one all_gather of a scalar per rank (the convergence test of dnaadjust.cpp:2639 on identical data everywhere)
+
+Rigorous variance matrices stay on the rank that produced them.  Critical path per iteration: B + ceil((B-2)/N) solves
+instead of 3B-2, i.e. strong scaling saturates near 2.5-2.9x; more GPUs need an intra-block distributed inverse.
+
+The compute is behind a small backend interface so that the schedule and the messaging can be exercised on CPU
+(gloo) with a numpy backend (tests/test_parallel_gloo.py); the product backend is DeviceBlockBackend (HIP, through the
+dna_adjust facade).  With NCCL (= RCCL on ROCm) the payloads are device tensors and travel over xGMI.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+
+class DeviceBlockBackend:
+    """Block steps on this rank's GPU: dna_adjust::Phased* through include/dnaadjust_c.h."""
+
+    def __init__(self, settings, comm_device):
+        import torch
+        from . import adjust
+        self.torch = torch
+        self.adj = adjust.DnaAdjust()
+        self.adj.PrepareAdjustment(settings)
+        self.lib = self.adj.lib
+        self.h = self.adj.h
+        self.comm_device = comm_device
+        self.n_blocks = self.adj.blockCount()
+        self._buf = {}
+
+    def close(self):
+        self.adj.close()
+
+    def _chk(self, rc):
+        self.adj._chk(rc)
+
+    def flags(self, k):
+        f, l, i = C.c_int(), C.c_int(), C.c_int()
+        self.lib.dnaadj_block_flags(self.h, k, C.byref(f), C.byref(l), C.byref(i))
+        return bool(f.value), bool(l.value), bool(i.value)
+
+    def n_stations(self, k):
+        return self.lib.dnaadj_block_station_count(self.h, k)
+
+    def stations(self, k):
+        return self.adj.block_stations(k)
+
+    def begin_iteration(self):
+        self._chk(self.lib.dnaadj_phased_begin_iteration(self.h))
+
+    def _step(self, fn, k):
+        mv = C.c_double()
+        self._chk(fn(self.h, k, C.byref(mv)))
+        return mv.value
+
+    def forward_block(self, k):
+        return self._step(self.lib.dnaadj_phased_forward_block, k)
+
+    def reverse_block(self, k):
+        return self._step(self.lib.dnaadj_phased_reverse_block, k)
+
+    def combine_block(self, k):
+        return self._step(self.lib.dnaadj_phased_combine_block, k)
+
+    def finalise_block(self, k):
+        self._chk(self.lib.dnaadj_phased_finalise_block(self.h, k))
+
+    def note_correction(self, mv):
+        self._chk(self.lib.dnaadj_phased_note_correction(self.h, float(mv)))
+
+    def max_correction(self):
+        return self.adj.GetMaxCorrection()
+
+    def end_iteration(self):
+        it = C.c_int()
+        self._chk(self.lib.dnaadj_phased_end_iteration(self.h, C.byref(it)))
+        return bool(it.value)
+
+    def finish(self):
+        st = C.c_int()
+        self._chk(self.lib.dnaadj_phased_finish(self.h, C.byref(st)))
+        return st.value
+
+    def junction_tensor(self, kind, k):
+        """communication buffer for the junction payload of block k (device tensor with NCCL, host tensor with gloo)"""
+        key = (kind, k)
+        if key not in self._buf:
+            n = self.lib.dnaadj_junction_payload_doubles(self.h, k)
+            self._buf[key] = self.torch.empty(n, dtype=self.torch.float64, device=self.comm_device)
+        return self._buf[key]
+
+    def export_junction(self, kind, k):
+        t = self.junction_tensor(kind, k)
+        self._chk(self.lib.dnaadj_junction_export(self.h, kind, k, C.c_void_p(t.data_ptr())))
+        return t
+
+    def import_junction(self, kind, k, t):
+        self._chk(self.lib.dnaadj_junction_import(self.h, kind, k, C.c_void_p(t.data_ptr())))
+
+    def get_coords(self, k):
+        out = np.empty(3 * self.n_stations(k), dtype=np.float64)
+        self._chk(self.lib.dnaadj_block_get_coords(self.h, k, 2, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def set_coords(self, k, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        self._chk(self.lib.dnaadj_block_set_coords(self.h, k, xyz.ctypes.data_as(C.POINTER(C.c_double))))
+
+
+class PhasedSchedule:
+    """who does what: static, identical on every rank"""
+
+    def __init__(self, flags, world):
+        self.B = len(flags)
+        self.flags = flags
+        self.world = world
+        self.fwd_rank = 0
+        self.rev_rank = 1 if world > 1 else 0
+        self.intermediate = [k for k, (f, l, i) in enumerate(flags) if not (f or l or i)]
+        self.combine_owner = {k: idx % world for idx, k in enumerate(self.intermediate)}
+
+    def final_owner(self, k):
+        f, l, i = self.flags[k]
+        if l or i:
+            return self.fwd_rank      # rigorous from the forward pass (dnaadjust.cpp:3033)
+        if f:
+            return self.rev_rank      # rigorous from the reverse pass
+        return self.combine_owner[k]
+
+
+def run_phased(backend, dist, rank, world, max_iterations=10):
+    """AdjustPhased (dnaadjust.cpp:2579) across `world` ranks; returns (status, iterations, per-iteration corrections)."""
+    import torch
+    flags = [backend.flags(k) for k in range(backend.n_blocks)]
+    sch = PhasedSchedule(flags, world)
+    B = sch.B
+    offs = np.zeros(B + 1, dtype=np.int64)
+    for k in range(B):
+        offs[k + 1] = offs[k] + 3 * backend.n_stations(k)
+    corrections = []
+    dev = backend.comm_device
+    for _ in range(max_iterations):
+        backend.begin_iteration()
+        # ---- phase 1: the two chains ------------------------------------------------------------------
+        if rank == sch.fwd_rank:
+            for k in range(B):
+                backend.forward_block(k)          # notes the correction of the last / isolated block itself
+        if rank == sch.rev_rank:
+            for k in range(B - 1, -1, -1):
+                f, l, i = flags[k]
+                if i:
+                    continue
+                mv = backend.reverse_block(k)
+                if f and not l:                   # first block of a network: rigorous now
+                    backend.note_correction(mv)
+                    backend.finalise_block(k)
+        # ---- exchange the junction payloads of the combination solves ----------------------------------
+        if world > 1:
+            ops, recvs = [], []
+            for k in sch.intermediate:
+                o = sch.combine_owner[k]
+                for kind, src, blk in ((0, sch.fwd_rank, k - 1), (1, sch.rev_rank, k)):
+                    if src == o:
+                        continue
+                    if rank == src:
+                        ops.append(dist.P2POp(dist.isend, backend.export_junction(kind, blk), o))
+                    elif rank == o:
+                        t = backend.junction_tensor(kind, blk)
+                        ops.append(dist.P2POp(dist.irecv, t, src))
+                        recvs.append((kind, blk, t))
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+            for kind, blk, t in recvs:
+                backend.import_junction(kind, blk, t)
+        # ---- phase 2: combination solves -----------------------------------------------------------------
+        for k in sch.intermediate:
+            if sch.combine_owner[k] == rank:
+                mv = backend.combine_block(k)
+                backend.note_correction(mv)
+                backend.finalise_block(k)
+        # ---- rigorous coordinates and the largest correction, on every rank -------------------------------
+        if world > 1:
+            flat = np.zeros(int(offs[B]), dtype=np.float64)
+            for k in range(B):
+                if sch.final_owner(k) == rank:
+                    flat[offs[k]:offs[k + 1]] = backend.get_coords(k)
+            t = torch.from_numpy(flat).to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            flat = t.cpu().numpy()
+            for k in range(B):
+                if sch.final_owner(k) != rank:
+                    backend.set_coords(k, flat[offs[k]:offs[k + 1]])
+            mine = torch.tensor([backend.max_correction()], dtype=torch.float64, device=dev)
+            allc = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(allc, mine)
+            for c in allc:
+                backend.note_correction(float(c.item()))
+        corrections.append(backend.max_correction())
+        if not backend.end_iteration():
+            break
+    status = backend.finish()
+    return status, len(corrections), corrections
+
+
+def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank):
+    """bench.py --gpus N (N > 1): the same network on N ranks, strong scaling; rank 0 returns the JSON dict."""
+    import torch
+    from . import adjust
+    if not phased:
+        raise SystemExit("the simultaneous adjustment does not shard: run it with --gpus 1")
+    dev = torch.device("cuda", local_rank)
+    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank)
+    be = DeviceBlockBackend(p, dev)
+    a = be.adj
+
+    def one_step():
+        a.ResetAdjustment()
+        st, its, corr = run_phased(be, dist, rank, world, max_iterations=p.max_iterations)
+        if st != adjust.ADJUST_SUCCESS:
+            raise SystemExit(f"adjustment did not converge (status {st})")
+        return its
+
+    for _ in range(args.warmup):
+        one_step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(args.steps):
+        its = one_step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    sol = torch.tensor([a.solve_flops(), float(a.solve_count())], dtype=torch.float64, device=dev)
+    dist.all_reduce(sol, op=dist.ReduceOp.SUM)
+    dt = float(dt.item())
+    stations = a.lib.dnaadj_station_count(a.h)
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "stations adjusted/sec + Cholesky TFLOP/s, phased adjustment, 1/2/4/8 MI355X",
+            "value": stations * args.steps / dt,
+            "unit": "stations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"stations": stations, "blocks": be.n_blocks, "iterations_to_converge": its, "mode": "phased",
+                       "solves_per_step": int(sol[1].item()),
+                       "parallelism": f"forward chain on rank 0, reverse chain on rank 1, combination solves round-robin over {world} ranks; "
+                                      "junction matrices point-to-point over RCCL"},
+            "cholesky_tflops": (float(sol[0].item()) / 1e12) / (dt / args.steps),
+        }
+    be.close()
+    return out

@@ -70,6 +70,27 @@ int dnaadj_block_estimates(dnaadj_handle* h, uint32_t block, double* xyz);      
 int dnaadj_block_variances_packed(dnaadj_handle* h, uint32_t block, double* packed);       /* v_rigorousVariances_ */
 int dnaadj_adjusted_coordinates(dnaadj_handle* h, double* xyz);                            /* 3 per bst station */
 
+/* ---- per-block steps of the phased chain (dna_adjust::Phased*): what the multi-GPU orchestrator schedules.
+ * AdjustPhasedForward / AdjustPhasedReverseCombine (dnaadjust.cpp:2756, 3461) are loops over exactly these. ---- */
+int dnaadj_block_flags(const dnaadj_handle* h, uint32_t block, int* first, int* last, int* isolated);   /* blockMeta_t */
+uint32_t dnaadj_junction_unknowns(const dnaadj_handle* h, uint32_t block);                              /* 3*|JSL(block)| */
+size_t dnaadj_junction_payload_doubles(const dnaadj_handle* h, uint32_t block);
+int dnaadj_phased_begin_iteration(dnaadj_handle* h);
+int dnaadj_phased_forward_block(dnaadj_handle* h, uint32_t block, double* max_corr);
+int dnaadj_phased_reverse_block(dnaadj_handle* h, uint32_t block, double* max_corr);
+int dnaadj_phased_combine_block(dnaadj_handle* h, uint32_t block, double* max_corr);
+int dnaadj_phased_finalise_block(dnaadj_handle* h, uint32_t block);
+int dnaadj_phased_note_correction(dnaadj_handle* h, double max_corr);
+int dnaadj_phased_end_iteration(dnaadj_handle* h, int* iterate);       /* convergence test + UpdateAdjustment */
+int dnaadj_phased_finish(dnaadj_handle* h, int* status);               /* ValidateandFinaliseAdjustment */
+/* kind 0 = forward (v_junctionVariancesFwd_/v_junctionEstimatesFwd_ of `block`), 1 = reverse; buf may be device memory */
+int dnaadj_junction_export(dnaadj_handle* h, int kind, uint32_t block, double* buf);
+int dnaadj_junction_import(dnaadj_handle* h, int kind, uint32_t block, const double* buf);
+/* which: 0 original, 1 estimated, 2 rigorous */
+int dnaadj_block_get_coords(dnaadj_handle* h, uint32_t block, int which, double* xyz);
+int dnaadj_block_set_coords(dnaadj_handle* h, uint32_t block, const double* xyz);   /* original = estimated = rigorous */
+int dnaadj_block_recompute_b(dnaadj_handle* h, uint32_t block);
+
 /* device context of the adjustment (for dnagpu_profile_*), NULL before prepare */
 void* dnaadj_device_context(dnaadj_handle* h);
 

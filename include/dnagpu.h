@@ -90,6 +90,11 @@ int dnagpu_matrix_reset(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, uint32_t n
 int dnagpu_matrix_upload_packed(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* ap, uint32_t n);
 int dnagpu_matrix_download_packed(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap);
 int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dnagpu_matrix* src);
+/* raw copies of a matrix together with its attached junction estimates: np*np doubles (ld = np) followed by np
+ * doubles, np = ceil(n/128)*128; dst / src may be host or device memory (this is the payload of the inter-GPU
+ * junction exchange, CarryStnEstimatesandVariances* ADJ:998/1133/3196) */
+int dnagpu_matrix_export(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* dst, size_t cap_doubles);
+int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* src, uint32_t n);
 /* in-place inverse (lower in, both triangles out); checks positive definiteness */
 int dnagpu_invert(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, int scale_to_unity);
 

@@ -1,0 +1,217 @@
+"""A dense numpy implementation of the block-step interface of dynadjust_amd/parallel.py, used to exercise the
+multi-rank schedule and its messaging on CPU (gloo).  Test infrastructure only: it restates the same steps as
+dna_adjust::Phased{Forward,Reverse,Combine,Finalise}Block with numpy.linalg on small networks."""
+import numpy as np
+import torch
+
+
+class NumpyBlockBackend:
+    def __init__(self, net, fixed_std_dev=1e-6, free_std_dev=10.0, threshold=float(np.float32(0.0005)), max_iterations=10):
+        self.comm_device = torch.device("cpu")
+        self.net = net
+        self.n_blocks = B = net.n_blocks
+        self.threshold = threshold
+        self.max_iterations = max_iterations
+        self.blk = []
+        seen_f, order = set(), []
+        for k in range(B):
+            isl = net.isl[net.isl_off[k]:net.isl_off[k + 1]]
+            jsl = net.jsl[net.jsl_off[k]:net.jsl_off[k + 1]]
+            st = np.array(sorted(set(int(s) for s in isl) | set(int(s) for s in jsl)), dtype=np.int64)
+            loc = {int(s): i for i, s in enumerate(st)}
+            cml = net.cml[net.cml_off[k]:net.cml_off[k + 1]]
+            d = dict(st=st, loc=loc, jsl=[int(s) for s in jsl], cml=cml,
+                     s1=np.array([loc[int(net.stn1[i])] for i in cml], dtype=np.int64),
+                     s2=np.array([loc[int(net.stn2[i])] for i in cml], dtype=np.int64))
+            d["first_fwd"] = [int(s) not in seen_f for s in st]
+            seen_f |= set(int(s) for s in st)
+            x = np.concatenate([net.xyz0[3 * s:3 * s + 3] for s in st])
+            d["orig"], d["est"], d["rig"] = x.copy(), x.copy(), x.copy()
+            d["rigvar"] = None
+            self.blk.append(d)
+        seen_r = set()
+        for k in range(B - 1, -1, -1):
+            d = self.blk[k]
+            d["first_rev"] = [int(s) not in seen_r for s in d["st"]]
+            seen_r |= set(int(s) for s in d["st"])
+        self.flags_ = []
+        for k in range(B):
+            first = k == 0 or net.net_id[k] != net.net_id[k - 1]
+            last = k == B - 1 or net.net_id[k] != net.net_id[k + 1]
+            self.flags_.append((first, last, first and last))
+        self.wc, self.wf = 1.0 / fixed_std_dev ** 2, 1.0 / free_std_dev ** 2
+        self.W = []
+        for i in range(net.n_baselines):
+            v = net.vcv6[6 * i:6 * i + 6]
+            V = np.array([[v[0], v[1], v[3]], [v[1], v[2], v[4]], [v[3], v[4], v[5]]])
+            self.W.append(np.linalg.inv(V))
+        for k in range(B):
+            self._compute_b(k)
+        self.jfwd, self.jrev = {}, {}
+        self.maxcorr = 0.0
+        self.iteration = 0
+        self.history = []
+
+    # ---- helpers ----
+    def _weight(self, s):
+        c = self.net.constraints[3 * s:3 * s + 3]
+        return self.wc if c == b"CCC" else self.wf
+
+    def _compute_b(self, k):
+        d = self.blk[k]
+        x = d["est"].reshape(-1, 3)
+        obs = np.stack([self.net.obs[3 * i:3 * i + 3] for i in d["cml"]]) if len(d["cml"]) else np.zeros((0, 3))
+        d["b"] = obs - (x[d["s2"]] - x[d["s1"]])
+
+    def _normals(self, k):
+        d = self.blk[k]
+        n = 3 * len(d["st"])
+        N = np.zeros((n, n))
+        rhs = np.zeros(n)
+        for j, i in enumerate(d["cml"]):
+            a, b = 3 * d["s1"][j], 3 * d["s2"][j]
+            W = self.W[i]
+            N[a:a + 3, a:a + 3] += W
+            N[b:b + 3, b:b + 3] += W
+            N[a:a + 3, b:b + 3] -= W
+            N[b:b + 3, a:a + 3] -= W
+            wb = W @ d["b"][j]
+            rhs[a:a + 3] -= wb
+            rhs[b:b + 3] += wb
+        return N, rhs
+
+    def _constraints(self, k, N, which, sign=1.0):
+        d = self.blk[k]
+        for p, s in enumerate(d["st"]):
+            if which == "fwd" and not d["first_fwd"][p]:
+                continue
+            if which == "rev" and not d["first_rev"][p]:
+                continue
+            if which == "cmb" and d["first_fwd"][p]:
+                continue
+            N[3 * p:3 * p + 3, 3 * p:3 * p + 3] += sign * self._weight(int(s)) * np.eye(3)
+
+    def _rows(self, k, stations):
+        loc = self.blk[k]["loc"]
+        return np.array([3 * loc[s] + c for s in stations for c in range(3)], dtype=np.int64)
+
+    def _junction_in(self, k, N, rhs, stations, payload):
+        if not stations:
+            return
+        WJ, est = payload
+        r = self._rows(k, stations)
+        N[np.ix_(r, r)] += WJ
+        rhs[r] += WJ @ (est - self.blk[k]["est"][r])
+
+    def _solve(self, k, N, rhs):
+        Ninv = np.linalg.inv(N)
+        corr = Ninv @ rhs
+        d = self.blk[k]
+        d["est"] = d["est"] + corr
+        i = int(np.argmax(np.abs(corr)))
+        self._Ninv = Ninv
+        return float(corr[i])
+
+    # ---- interface of parallel.run_phased ----
+    def flags(self, k):
+        return self.flags_[k]
+
+    def n_stations(self, k):
+        return len(self.blk[k]["st"])
+
+    def begin_iteration(self):
+        self.maxcorr = 0.0
+        self.iteration += 1
+
+    def note_correction(self, mv):
+        if abs(mv) > abs(self.maxcorr):
+            self.maxcorr = mv
+
+    def max_correction(self):
+        return self.maxcorr
+
+    def forward_block(self, k):
+        f, l, i = self.flags_[k]
+        d = self.blk[k]
+        N, rhs = self._normals(k)
+        self._constraints(k, N, "fwd")
+        if not f and not i:
+            self._junction_in(k, N, rhs, self.blk[k - 1]["jsl"], self.jfwd[k - 1])
+        mv = self._solve(k, N, rhs)
+        if l or i:
+            self.note_correction(mv)
+            d["rig"] = d["est"].copy()
+            d["rigvar"] = self._Ninv
+            return mv
+        if d["jsl"]:
+            r = self._rows(k, d["jsl"])
+            self.jfwd[k] = (np.linalg.inv(self._Ninv[np.ix_(r, r)]), d["est"][r].copy())
+        return mv
+
+    def reverse_block(self, k):
+        f, l, i = self.flags_[k]
+        d = self.blk[k]
+        d["est"] = d["orig"].copy()
+        N, rhs = self._normals(k)
+        if not l:
+            self._junction_in(k, N, rhs, d["jsl"], self.jrev[k])
+        self._constraints(k, N, "rev")
+        mv = self._solve(k, N, rhs)
+        if not f and self.blk[k - 1]["jsl"]:
+            r = self._rows(k, self.blk[k - 1]["jsl"])
+            self.jrev[k - 1] = (np.linalg.inv(self._Ninv[np.ix_(r, r)]), d["est"][r].copy())
+        return mv
+
+    def combine_block(self, k):
+        d = self.blk[k]
+        d["est"] = d["orig"].copy()
+        N, rhs = self._normals(k)
+        self._junction_in(k, N, rhs, d["jsl"], self.jrev[k])
+        self._constraints(k, N, "rev")
+        self._junction_in(k, N, rhs, self.blk[k - 1]["jsl"], self.jfwd[k - 1])
+        self._constraints(k, N, "cmb", -1.0)
+        return self._solve(k, N, rhs)
+
+    def finalise_block(self, k):
+        d = self.blk[k]
+        d["rig"] = d["est"].copy()
+        d["rigvar"] = self._Ninv
+        d["orig"] = d["rig"].copy()
+
+    def end_iteration(self):
+        self.history.append(self.maxcorr)
+        iterate = abs(self.maxcorr) > self.threshold and self.iteration < self.max_iterations
+        if iterate:
+            for k in range(self.n_blocks):
+                d = self.blk[k]
+                if self.flags_[k][1]:
+                    d["orig"] = d["rig"].copy()
+                d["est"] = d["rig"].copy()
+                self._compute_b(k)
+        return iterate
+
+    def finish(self):
+        return 1 if (self.iteration == self.max_iterations and abs(self.maxcorr) > self.threshold) else 0
+
+    def _njs(self, k):
+        return 3 * len(self.blk[k]["jsl"])
+
+    def junction_tensor(self, kind, k):
+        n = self._njs(k)
+        return torch.empty(n * n + n, dtype=torch.float64)
+
+    def export_junction(self, kind, k):
+        WJ, est = (self.jfwd if kind == 0 else self.jrev)[k]
+        return torch.from_numpy(np.concatenate([WJ.ravel(), est]))
+
+    def import_junction(self, kind, k, t):
+        n = self._njs(k)
+        a = t.numpy().copy()
+        (self.jfwd if kind == 0 else self.jrev)[k] = (a[:n * n].reshape(n, n), a[n * n:])
+
+    def get_coords(self, k):
+        return self.blk[k]["rig"].copy()
+
+    def set_coords(self, k, xyz):
+        d = self.blk[k]
+        d["orig"], d["est"], d["rig"] = xyz.copy(), xyz.copy(), xyz.copy()

@@ -154,3 +154,92 @@ def test_phased_is_rigorous_at_scale(built, tmp_path):
     assert np.abs(Vb - sub).max() / np.abs(sub).max() < TOL_V
     s.close()
     p.close()
+
+
+def test_multi_thread_mode_matches_oracle(built, orc, tmp_path):
+    """--multi-thread: forward chain and reverse/combine chain on two streams of one GPU, two host threads
+    (dnaadjust-multi.cpp:92-244); same results as the sequential schedule"""
+    adjust.write_synthetic_network(str(tmp_path), "n", 36, 20, 0, 6, seed=77)
+    net = orc.Network(str(tmp_path / "n"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "n", True, multi_thread=True)
+    _compare(a, st, o, ost)
+    # and bit-identical to the single-chain device run
+    s, st_s = _device_run(str(tmp_path), "n", True)
+    for b in range(a.blockCount()):
+        assert np.array_equal(a.block_estimates(b), s.block_estimates(b))
+    a.close()
+    s.close()
+    o.close()
+
+
+def test_orchestrator_single_rank_equals_facade(built, tmp_path):
+    """dynadjust_amd/parallel.run_phased on one rank drives the same per-block steps as AdjustPhased"""
+    from dynadjust_amd import parallel
+    import torch
+    adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 5, seed=9)
+    f, st_f = _device_run(str(tmp_path), "n", True)
+    p = adjust.ProjectSettings("n", str(tmp_path), adjust_mode=adjust.PhasedMode)
+    be = parallel.DeviceBlockBackend(p, torch.device("cpu"))
+    st, its, corr = parallel.run_phased(be, None, 0, 1)
+    assert st == st_f and its == f.CurrentIteration()
+    for b in range(f.blockCount()):
+        assert np.array_equal(be.adj.block_estimates(b), f.block_estimates(b))
+        assert np.array_equal(be.adj.block_variances_packed(b), f.block_variances_packed(b))
+    be.close()
+    f.close()
+
+
+def _two_rank_worker(rank, world, port, folder, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynadjust_amd import adjust as adj, parallel
+    p = adj.ProjectSettings("n", folder, adjust_mode=adj.PhasedMode)
+    be = parallel.DeviceBlockBackend(p, torch.device("cpu"))     # both ranks share the box's single GPU; payloads via host
+    st, its, corr = parallel.run_phased(be, dist, rank, world)
+    sch = parallel.PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world)
+    res = {"status": st, "iterations": its}
+    for k in range(be.n_blocks):
+        res[f"coords_{k}"] = be.get_coords(k)
+        if sch.final_owner(k) == rank:
+            res[f"var_{k}"] = be.adj.block_variances_packed(k)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    be.close()
+    dist.destroy_process_group()
+
+
+def test_orchestrator_two_ranks_device_backend(built, orc, tmp_path):
+    """the real device backend under a 2-rank schedule (gloo transport, both processes on this box's GPU):
+    junction export/import, combination solves on the 'other' rank, coordinate all_reduce"""
+    import socket
+    import torch.multiprocessing as mp
+    adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 6, seed=10)
+    net = orc.Network(str(tmp_path / "n"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), str(tmp_path)), nprocs=2, join=True)
+    seen = set()
+    for r in range(2):
+        res = np.load(str(tmp_path / f"rank{r}.npz"))
+        assert int(res["status"]) == ost and int(res["iterations"]) == o.iterations()
+        for k in range(6):
+            assert np.abs(res[f"coords_{k}"] - o.block_estimates(k)).max() < TOL_X
+            if f"var_{k}" in res:
+                seen.add(k)
+                vo = o.block_variances(k)
+                assert np.abs(res[f"var_{k}"] - vo).max() / np.abs(vo).max() < TOL_V
+    assert seen == set(range(6))
+    o.close()

@@ -1,0 +1,84 @@
+"""The N > 1 path on CPU: dynadjust_amd/parallel.py (schedule + junction exchange + coordinate all_reduce) under gloo
+with world sizes 2 and 3 and a numpy block backend, against the CPU oracle's single-process phased adjustment."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, base, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynadjust_amd import parallel
+    from tests import oracle
+    from tests.numpy_backend import NumpyBlockBackend
+    net = oracle.Network(base, True)
+    be = NumpyBlockBackend(net)
+    status, its, corr = parallel.run_phased(be, dist, rank, world)
+    sch = parallel.PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world)
+    res = {"status": status, "iterations": its, "corrections": np.array(corr)}
+    for k in range(be.n_blocks):
+        res[f"coords_{k}"] = be.blk[k]["rig"]          # every rank must hold the rigorous coordinates of every block
+        if sch.final_owner(k) == rank:
+            res[f"owned_var_{k}"] = be.blk[k]["rigvar"]
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,blocks", [(2, 5), (3, 6), (2, 2)])
+def test_distributed_schedule_matches_single_process(built, orc, tmp_path, world, blocks):
+    from dynadjust_amd import adjust
+    from dynadjust_amd.device import unpack_lower
+    adjust.write_synthetic_network(str(tmp_path), "n", 12, 6, 0, blocks, seed=3 + blocks)
+    base = str(tmp_path / "n")
+    net = orc.Network(base, True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    mp.spawn(_worker, args=(world, _free_port(), base, str(tmp_path)), nprocs=world, join=True)
+    owned = set()
+    for r in range(world):
+        res = np.load(str(tmp_path / f"rank{r}.npz"))
+        assert int(res["status"]) == ost and int(res["iterations"]) == o.iterations()
+        for i in range(o.iterations()):
+            assert abs(res["corrections"][i] - o.max_correction(i + 1)) < 1e-8
+        for k in range(blocks):
+            assert np.abs(res[f"coords_{k}"] - o.block_estimates(k)).max() < 1e-8
+            if f"owned_var_{k}" in res:
+                owned.add(k)
+                n = 3 * len(o.block_stations(k))
+                V = unpack_lower(o.block_variances(k), n)
+                assert np.abs(res[f"owned_var_{k}"] - V).max() / np.abs(V).max() < 1e-8
+    assert owned == set(range(blocks))      # every block's rigorous variances live on exactly one rank... or more
+    o.close()
+
+
+def test_schedule_roles():
+    from dynadjust_amd.parallel import PhasedSchedule
+    flags = [(True, False, False)] + [(False, False, False)] * 6 + [(False, True, False)]
+    s = PhasedSchedule(flags, 4)
+    assert s.intermediate == [1, 2, 3, 4, 5, 6]
+    assert [s.combine_owner[k] for k in s.intermediate] == [0, 1, 2, 3, 0, 1]      # every rank takes combination solves
+    assert s.final_owner(0) == s.rev_rank == 1 and s.final_owner(7) == s.fwd_rank == 0
+    s1 = PhasedSchedule(flags, 1)
+    assert s1.rev_rank == 0 and set(s1.combine_owner.values()) == {0}
+    iso = PhasedSchedule([(True, True, True), (True, False, False), (False, True, False)], 2)
+    assert iso.intermediate == [] and iso.final_owner(0) == 0 and iso.final_owner(1) == 1 and iso.final_owner(2) == 0
