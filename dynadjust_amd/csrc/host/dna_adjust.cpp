@@ -501,7 +501,7 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
         // every chain restarts from the rigorous estimates of the iteration just finished (multi-thread mode:
         // v_estimatedStationsR_ = v_rigorousStations_ ADJ:569; v_estimatedStations_ = v_estimatedStationsR_ ADJ:3799)
         for (int c = 0; c < chains; ++c) {
-            Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
+            if (phased) Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
             Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
         }
     }

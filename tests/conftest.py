@@ -1,6 +1,10 @@
 import os
 import sys
 
+# The oracle can dlopen the MKL runtime; MKL's default Intel OpenMP layer must never share a process with
+# torch's GNU OpenMP (dpotrf then returns silently wrong results), so pin the layer before anything loads MKL.
+os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

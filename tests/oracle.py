@@ -79,6 +79,7 @@ def load():
 def use_mkl(enable=True):
     """switch the oracle's dpotrf/dpotri to the MKL runtime (the LAPACK the reference links)"""
     lib = load()
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")   # see tests/conftest.py
     if enable and os.path.exists(MKL):
         return lib.orc_set_lapack(MKL.encode()) == 0
     lib.orc_set_lapack(None)
