@@ -37,7 +37,7 @@ class DnaAdjSettings(C.Structure):
 
 class DnaSynthSpec(C.Structure):
     _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("n_baselines", C.c_uint64), ("n_blocks", C.c_uint32),
-                ("seed", C.c_uint64), ("initial_sigma", C.c_double)]
+                ("seed", C.c_uint64), ("initial_sigma", C.c_double), ("x_clusters", C.c_uint32), ("y_cluster", C.c_uint32)]
 
 
 class DnaSynthSummary(C.Structure):
@@ -93,6 +93,7 @@ def load():
     _sig(lib, "dnagpu_block_destroy", i, [vp, u32])
     _sig(lib, "dnagpu_block_set_stations", i, [vp, u32, c_f64p])
     _sig(lib, "dnagpu_block_set_baselines", i, [vp, u32, c_u32p, c_u32p, c_f64p, c_f64p])
+    _sig(lib, "dnagpu_block_set_clusters", i, [vp, u32, c_u32p, c_u32p, c_f64p, u32, c_u32p, c_f64p])
     _sig(lib, "dnagpu_block_get_stations", i, [vp, i, u32, i, c_f64p])
     _sig(lib, "dnagpu_block_put_stations", i, [vp, i, u32, i, c_f64p])
     _sig(lib, "dnagpu_block_copy_stations", i, [vp, i, u32, i, i])
@@ -172,7 +173,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset",
     "dnagpu_profile_get", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
     "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
-    "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines",
+    "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",

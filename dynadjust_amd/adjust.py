@@ -169,10 +169,11 @@ class DnaAdjust:
         return self.lib.dnaadj_device_context(self.h)
 
 
-def write_synthetic_network(folder, name, rows, cols, n_baselines=0, n_blocks=1, seed=20260928, initial_sigma=0.05):
+def write_synthetic_network(folder, name, rows, cols, n_baselines=0, n_blocks=1, seed=20260928, initial_sigma=0.05,
+                            x_clusters=0, y_cluster=False):
     """writes <folder>/<name>.{bst,bms,asl,seg,truth}; returns the summary dict."""
     lib = _lib.load()
-    spec = DnaSynthSpec(rows, cols, n_baselines, n_blocks, seed, initial_sigma)
+    spec = DnaSynthSpec(rows, cols, n_baselines, n_blocks, seed, initial_sigma, int(x_clusters), int(bool(y_cluster)))
     out = DnaSynthSummary()
     err = C.create_string_buffer(512)
     rc = lib.dnasynth_write_network(os.fsencode(folder), os.fsencode(name), C.byref(spec), C.byref(out), err, 512)

@@ -4,12 +4,15 @@
 #include <stdint.h>
 
 namespace dnagpu {
-void launch_weights(const double* vcv6, double* w6, uint32_t n_bl, int* bad, hipStream_t s);
+void launch_weights(const double* vcv6, const uint32_t* dst, double* wblk, uint32_t n, int* bad, hipStream_t s);
+void launch_cluster_blocks(const double* F, uint32_t np, uint32_t k, double* wblk, hipStream_t s);
+void launch_diag_weights(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, double* w6, uint32_t n_vec, hipStream_t s);
 void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s);
-void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pbl, const double* w6, double* F,
+void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pent, const double* wblk, double* F,
                          uint32_t np, uint32_t n_pairs, hipStream_t s);
 void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s);
-void launch_form_rhs(const uint32_t* ioff, const uint32_t* inc, const double* w6, const double* b, double* rhs, uint32_t n_stn, hipStream_t s);
+void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const double* b, double* wb,
+                     uint32_t n_vec, const uint32_t* ioff, const uint32_t* inc, double* rhs, uint32_t n_stn, hipStream_t s);
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s);
 void launch_junction_gather(const double* S, uint32_t nps, const uint32_t* idx, uint32_t k, double* J, uint32_t npj, hipStream_t s);
 void launch_gather_vec3(const double* x, const uint32_t* idx, uint32_t k, double* out, hipStream_t s);

@@ -25,9 +25,10 @@ __device__ __forceinline__ int sym6(int i, int j) {
 
 // W = V^-1 through the Cholesky factor V = U^T U (the reference calls
 // dpotrf('U') + dpotri('U') on the 3x3, dnaadjust.cpp:4288 -> :8472).
-__global__ void weights_kernel(const double* __restrict__ vcv6, double* __restrict__ w6, uint32_t n_bl, int* __restrict__ bad) {
+__global__ void weights_kernel(const double* __restrict__ vcv6, const uint32_t* __restrict__ dst, double* __restrict__ wblk, uint32_t n,
+                               int* __restrict__ bad) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_bl) return;
+    if (i >= n) return;
     const double* v = vcv6 + (size_t)i * 6;
     double v11 = v[0], v12 = v[1], v22 = v[2], v13 = v[3], v23 = v[4], v33 = v[5];
     double u11 = sqrt(v11);
@@ -43,13 +44,37 @@ __global__ void weights_kernel(const double* __restrict__ vcv6, double* __restri
     double t12 = -(t11 * u12) * t22;
     double t23 = -(t22 * u23) * t33;
     double t13 = -(t11 * (u12 * t23 + u13 * t33));
-    double* w = w6 + (size_t)i * 6;
-    w[0] = (t11 * t11 + t12 * t12) + t13 * t13;
-    w[1] = t12 * t22 + t13 * t23;
-    w[2] = t22 * t22 + t23 * t23;
-    w[3] = t13 * t33;
-    w[4] = t23 * t33;
-    w[5] = t33 * t33;
+    double w0 = (t11 * t11 + t12 * t12) + t13 * t13;
+    double w1 = t12 * t22 + t13 * t23;
+    double w2 = t22 * t22 + t23 * t23;
+    double w3 = t13 * t33;
+    double w4 = t23 * t33;
+    double w5 = t33 * t33;
+    double* w = wblk + (size_t)dst[i] * 9;   // symmetric 3x3, column-major
+    w[0] = w0; w[1] = w1; w[2] = w3;
+    w[3] = w1; w[4] = w2; w[5] = w4;
+    w[6] = w3; w[7] = w4; w[8] = w5;
+}
+
+// scatter the inverse of a k-vector cluster's 3k x 3k variance matrix into its k*k 3x3 blocks:
+// block (j, j') element (ei, ej) = F(3j + ei, 3j' + ej)
+__global__ void cluster_blocks_kernel(const double* __restrict__ F, uint32_t np, uint32_t k, double* __restrict__ wblk) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * k * 9) return;
+    uint32_t blk = t / 9, e = t - blk * 9;
+    uint32_t j = blk / k, jp = blk - j * k;
+    uint32_t ei = e % 3, ej = e / 3;
+    wblk[(size_t)blk * 9 + e] = F[(size_t)(3 * jp + ej) * np + 3 * j + ei];
+}
+
+// (xx, xy, yy, xz, yz, zz) of every vector's own weight block (diagnostics / tests)
+__global__ void diag_weights_kernel(const double* __restrict__ wblk, const uint32_t* __restrict__ vec_wrow, const uint32_t* __restrict__ vec_c0,
+                                    double* __restrict__ w6, uint32_t n_vec) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vec) return;
+    const double* w = wblk + (size_t)(vec_wrow[v] + (v - vec_c0[v])) * 9;
+    double* o = w6 + (size_t)v * 6;
+    o[0] = w[0]; o[1] = w[3]; o[2] = w[4]; o[3] = w[6]; o[4] = w[7]; o[5] = w[8];
 }
 
 __global__ void compute_b_kernel(const uint32_t* __restrict__ s1, const uint32_t* __restrict__ s2, const double* __restrict__ obs,
@@ -57,28 +82,29 @@ __global__ void compute_b_kernel(const uint32_t* __restrict__ s1, const uint32_t
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_bl * 3) return;
     uint32_t i = t / 3, c = t - i * 3;
-    double comp = xe[3 * s2[i] + c] - xe[3 * s1[i] + c];
+    // baseline: computed = x2 - x1 (ADJ:5304); point cluster (no first station): computed = x (ADJ:6343)
+    double comp = xe[3 * s2[i] + c];
+    if (s1[i] != 0xffffffffu) comp = comp - xe[3 * s1[i] + c];
     b[t] = obs[t] - comp;
 }
 
-// one thread per (station-pair block, element): N(3r+ei, 3c+ej) = sum over the
-// pair's baselines (CML order) of +W (diagonal block) or -W (off-diagonal block)
+// one thread per (station-pair block, element): N(3r+ei, 3c+ej) = sum over the pair's contributions
+// (CML order) of +-W_block(ei, ej); a contribution = (index of a 3x3 weight block) << 1 | negative
 __global__ void form_normals_kernel(const uint32_t* __restrict__ prow, const uint32_t* __restrict__ pcol,
-                                    const uint32_t* __restrict__ poff, const uint32_t* __restrict__ pbl,
-                                    const double* __restrict__ w6, double* __restrict__ F, uint32_t np, uint32_t n_pairs) {
+                                    const uint32_t* __restrict__ poff, const uint32_t* __restrict__ pent,
+                                    const double* __restrict__ wblk, double* __restrict__ F, uint32_t np, uint32_t n_pairs) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_pairs * 9) return;
     uint32_t p = t / 9, e = t - p * 9;
     int ei = e % 3, ej = e / 3;
     uint32_t r = prow[p], c = pcol[p];
-    bool diag = (r == c);
-    if (diag && ei < ej) return;
-    int k6 = sym6(ei, ej);
+    if (r == c && ei < ej) return;
     double s = 0.0;
     uint32_t k0 = poff[p], k1 = poff[p + 1];
     for (uint32_t k = k0; k < k1; ++k) {
-        double w = w6[(size_t)pbl[k] * 6 + k6];
-        s += diag ? w : -w;
+        uint32_t ent = pent[k];
+        double w = wblk[(size_t)(ent >> 1) * 9 + e];
+        s += (ent & 1u) ? -w : w;
     }
     F[(size_t)(3 * c + ej) * np + 3 * r + ei] = s;
 }
@@ -94,9 +120,28 @@ __global__ void add_diag3x3_kernel(double* __restrict__ F, uint32_t np, const ui
     F[(size_t)(3 * s + ej) * np + 3 * s + ei] += sign * w9[(size_t)q * 9 + ej * 3 + ei];
 }
 
-// rhs(3s+c) = sum over incident baselines (CML order) of +-(W b)_c
-__global__ void form_rhs_kernel(const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ inc, const double* __restrict__ w6,
-                                const double* __restrict__ b, double* __restrict__ rhs, uint32_t n_stn) {
+// wb(v) = sum_j' W(v, j') b(j') over the vectors j' of v's cluster (the AtVinv columns of the cluster times b)
+__global__ void cluster_wb_kernel(const double* __restrict__ wblk, const uint32_t* __restrict__ vec_wrow, const uint32_t* __restrict__ vec_c0,
+                                  const uint32_t* __restrict__ vec_k, const double* __restrict__ b, double* __restrict__ wb, uint32_t n_vec) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_vec * 3) return;
+    uint32_t v = t / 3;
+    int c = t - v * 3;
+    const uint32_t k = vec_k[v], c0 = vec_c0[v];
+    const double* row = wblk + (size_t)vec_wrow[v] * 9;
+    double acc = 0.0;
+    for (uint32_t jp = 0; jp < k; ++jp) {
+        const double* w = row + (size_t)jp * 9;
+        const double* bb = b + (size_t)(c0 + jp) * 3;
+        double term = (w[c] * bb[0] + w[c + 3] * bb[1]) + w[c + 6] * bb[2];
+        acc = (jp == 0) ? term : acc + term;
+    }
+    wb[t] = acc;
+}
+
+// rhs(3s+c) = sum over incident vectors (CML order) of +-(W b)_c
+__global__ void form_rhs_kernel(const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ inc, const double* __restrict__ wb,
+                                double* __restrict__ rhs, uint32_t n_stn) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_stn * 3) return;
     uint32_t s = t / 3;
@@ -104,11 +149,8 @@ __global__ void form_rhs_kernel(const uint32_t* __restrict__ ioff, const uint32_
     double acc = 0.0;
     for (uint32_t k = ioff[s]; k < ioff[s + 1]; ++k) {
         uint32_t e = inc[k];
-        uint32_t bl = e >> 1;
-        const double* w = w6 + (size_t)bl * 6;
-        const double* bb = b + (size_t)bl * 3;
-        double wb = (w[sym6(c, 0)] * bb[0] + w[sym6(c, 1)] * bb[1]) + w[sym6(c, 2)] * bb[2];
-        acc += (e & 1u) ? wb : -wb;
+        double v = wb[(size_t)(e >> 1) * 3 + c];
+        acc += (e & 1u) ? v : -v;
     }
     rhs[t] = acc;
 }
@@ -194,26 +236,36 @@ __global__ void junction_rhs_kernel(double* __restrict__ rhs, const double* __re
 }
 
 // ---- launchers ---------------------------------------------------------------
-void launch_weights(const double* vcv6, double* w6, uint32_t n_bl, int* bad, hipStream_t s) {
-    if (!n_bl) return;
-    hipLaunchKernelGGL(weights_kernel, dim3((n_bl + 255) / 256), dim3(256), 0, s, vcv6, w6, n_bl, bad);
+void launch_weights(const double* vcv6, const uint32_t* dst, double* wblk, uint32_t n, int* bad, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, vcv6, dst, wblk, n, bad);
+}
+void launch_cluster_blocks(const double* F, uint32_t np, uint32_t k, double* wblk, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(cluster_blocks_kernel, dim3((k * k * 9 + 255) / 256), dim3(256), 0, s, F, np, k, wblk);
+}
+void launch_diag_weights(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, double* w6, uint32_t n_vec, hipStream_t s) {
+    if (!n_vec) return;
+    hipLaunchKernelGGL(diag_weights_kernel, dim3((n_vec + 255) / 256), dim3(256), 0, s, wblk, vec_wrow, vec_c0, w6, n_vec);
 }
 void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s) {
     if (!n_bl) return;
     hipLaunchKernelGGL(compute_b_kernel, dim3((n_bl * 3 + 255) / 256), dim3(256), 0, s, s1, s2, obs, xe, b, n_bl);
 }
-void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pbl, const double* w6, double* F,
+void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pent, const double* wblk, double* F,
                          uint32_t np, uint32_t n_pairs, hipStream_t s) {
     if (!n_pairs) return;
-    hipLaunchKernelGGL(form_normals_kernel, dim3((n_pairs * 9 + 255) / 256), dim3(256), 0, s, prow, pcol, poff, pbl, w6, F, np, n_pairs);
+    hipLaunchKernelGGL(form_normals_kernel, dim3((n_pairs * 9 + 255) / 256), dim3(256), 0, s, prow, pcol, poff, pent, wblk, F, np, n_pairs);
 }
 void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s) {
     if (!k) return;
     hipLaunchKernelGGL(add_diag3x3_kernel, dim3((k * 9 + 255) / 256), dim3(256), 0, s, F, np, stn, w9, k, sign);
 }
-void launch_form_rhs(const uint32_t* ioff, const uint32_t* inc, const double* w6, const double* b, double* rhs, uint32_t n_stn, hipStream_t s) {
+void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const double* b, double* wb,
+                     uint32_t n_vec, const uint32_t* ioff, const uint32_t* inc, double* rhs, uint32_t n_stn, hipStream_t s) {
+    if (n_vec) hipLaunchKernelGGL(cluster_wb_kernel, dim3((n_vec * 3 + 255) / 256), dim3(256), 0, s, wblk, vec_wrow, vec_c0, vec_k, b, wb, n_vec);
     if (!n_stn) return;
-    hipLaunchKernelGGL(form_rhs_kernel, dim3((n_stn * 3 + 255) / 256), dim3(256), 0, s, ioff, inc, w6, b, rhs, n_stn);
+    hipLaunchKernelGGL(form_rhs_kernel, dim3((n_stn * 3 + 255) / 256), dim3(256), 0, s, ioff, inc, wb, rhs, n_stn);
 }
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s) {
     hipLaunchKernelGGL(update_estimates_kernel, dim3(1), dim3(1024), 0, s, xe, corr, n, out_val, out_idx);

@@ -30,13 +30,18 @@ struct Block {
     // baselines, SoA
     uint32_t *s1 = nullptr, *s2 = nullptr;
     double *obs = nullptr;  // 3*n_bl
-    double *W = nullptr;    // 6*n_bl  (xx, xy, yy, xz, yz, zz) of V^-1
+    // measurement weights: 3x3 blocks (9 doubles, column-major) of every cluster's inverse variance
+    // matrix; a k-vector cluster owns k*k consecutive blocks, block (j, j') at wrow(j) + j'
+    double *Wblk = nullptr;
+    uint32_t n_wblk = 0;
+    uint32_t *vec_wrow = nullptr, *vec_c0 = nullptr, *vec_k = nullptr;   // per vector: first block of its row, first vector and size of its cluster
+    double *wb[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};                  // 3*n_bl: W b per vector
     double *b[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};  // 3*n_bl, measured - computed
     // deterministic formation structure: station-pair blocks (row >= col), each
     // with the CML-ordered list of contributing baselines
     uint32_t n_pairs = 0;
     uint32_t *pair_row = nullptr, *pair_col = nullptr, *pair_off = nullptr;  // n_pairs(+1)
-    uint32_t *pair_bl = nullptr;  // baseline index per contribution
+    uint32_t *pair_ent = nullptr;  // per contribution: weight-block index << 1 | negative
     // per-station incidence (CML order) for the rhs: entry = baseline*2 + (1 if station is stn2)
     uint32_t *inc_off = nullptr, *inc = nullptr;
     // scratch for max-correction reduction (value, index) per chain

@@ -124,8 +124,9 @@ Block* find_block(dnagpu_ctx* ctx, uint32_t blk) {
 }
 
 void free_block(Block& b) {
-    void* ptrs[] = {b.x_orig, b.x_est[0], b.x_est[1], b.x_rig, b.rhs[0], b.rhs[1], b.corr[0], b.corr[1], b.s1, b.s2, b.obs, b.W,
-                    b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_bl, b.inc_off, b.inc, b.red[0], b.red[1]};
+    void* ptrs[] = {b.x_orig, b.x_est[0], b.x_est[1], b.x_rig, b.rhs[0], b.rhs[1], b.corr[0], b.corr[1], b.s1, b.s2, b.obs, b.Wblk,
+                    b.vec_wrow, b.vec_c0, b.vec_k, b.wb[0], b.wb[1],
+                    b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc, b.red[0], b.red[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     b = Block();
@@ -461,12 +462,15 @@ int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint
         A((void**)&b.rhs[c], nv);
         A((void**)&b.corr[c], nv);
         A((void**)&b.b[c], nb * 3 * sizeof(double));
+        A((void**)&b.wb[c], nb * 3 * sizeof(double));
         A((void**)&b.red[c], 2 * sizeof(double));
     }
     A((void**)&b.s1, nb * sizeof(uint32_t));
     A((void**)&b.s2, nb * sizeof(uint32_t));
     A((void**)&b.obs, nb * 3 * sizeof(double));
-    A((void**)&b.W, nb * 6 * sizeof(double));
+    A((void**)&b.vec_wrow, nb * sizeof(uint32_t));
+    A((void**)&b.vec_c0, nb * sizeof(uint32_t));
+    A((void**)&b.vec_k, nb * sizeof(uint32_t));
     if (e != hipSuccess) {
         free_block(b);
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "block allocation", e);
@@ -501,64 +505,100 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz) 
     return DNAGPU_OK;
 }
 
-int dnagpu_block_set_baselines(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
-                               const double* vcv6) {
+int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
+                              uint32_t n_clusters, const uint32_t* cluster_off, const double* vcv) {
     CHK_CTX();
     Block* b = find_block(ctx, blk);
-    if (!b) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: unknown block");
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "block_set_clusters: unknown block");
     const uint32_t m = b->n_bl, ns = b->n_stn;
-    if (m && (!stn1 || !stn2 || !obs || !vcv6)) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: null argument");
+    if (m && (!stn1 || !stn2 || !obs || !vcv || !cluster_off)) return fail(ctx, DNAGPU_EINVAL, "block_set_clusters: null argument");
+    if (n_clusters && (cluster_off[0] != 0 || cluster_off[n_clusters] != m))
+        return fail(ctx, DNAGPU_EINVAL, "block_set_clusters: cluster offsets do not cover the vectors");
     for (uint32_t i = 0; i < m; ++i)
-        if (stn1[i] >= ns || stn2[i] >= ns) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: station index out of range");
+        if ((stn1[i] != DNAGPU_NO_STATION && stn1[i] >= ns) || stn2[i] >= ns)
+            return fail(ctx, DNAGPU_EINVAL, "block_set_clusters: station index out of range");
 
-    // station-pair structure: contributions sorted by (row, col), CML order inside a pair
+    // weight-block bookkeeping: cluster c (k vectors) owns k*k consecutive 3x3 blocks
+    std::vector<uint32_t> wrow(m), c0v(m), kv(m), woff(n_clusters + 1, 0);
+    std::vector<size_t> voff(n_clusters + 1, 0);   // offsets of the clusters' variance matrices in `vcv`
+    uint32_t kmax = 0;
+    for (uint32_t c = 0; c < n_clusters; ++c) {
+        if (cluster_off[c + 1] <= cluster_off[c]) return fail(ctx, DNAGPU_EINVAL, "block_set_clusters: empty cluster");
+        uint32_t k = cluster_off[c + 1] - cluster_off[c];
+        woff[c + 1] = woff[c] + k * k;
+        voff[c + 1] = voff[c] + (size_t)9 * k * k;
+        kmax = std::max(kmax, k);
+        for (uint32_t j = 0; j < k; ++j) {
+            uint32_t v = cluster_off[c] + j;
+            wrow[v] = woff[c] + j * k;
+            c0v[v] = cluster_off[c];
+            kv[v] = k;
+        }
+    }
+    const uint32_t n_wblk = woff[n_clusters];
+
+    // station-pair structure: contributions sorted by (row, col), CML order inside a pair.  A cluster contributes,
+    // for every ordered pair of its vectors (j, j') and every pair of their end stations (a, a') with a >= a',
+    // sign(a) sign(a') W(j, j'); the mirrored (a < a') case is produced by the pair (j', j).
     struct Ent {
         uint64_t key;
-        uint32_t bl;
+        uint32_t ent;
     };
     std::vector<Ent> ents;
     ents.reserve((size_t)m * 3);
-    for (uint32_t i = 0; i < m; ++i) {
-        uint32_t a = stn1[i], c = stn2[i];
-        // the reference adds stn2's diagonal block first, then stn1's (UpdateNormals_G, dnaadjust.cpp:1664-1684);
-        // they hit different elements unless a == c, where this order is kept
-        ents.push_back({(uint64_t)c * ns + c, i});
-        ents.push_back({(uint64_t)a * ns + a, i});
-        if (a != c) {
-            uint32_t r = std::max(a, c), q = std::min(a, c);
-            ents.push_back({(uint64_t)r * ns + q, i});
-        }
+    for (uint32_t c = 0; c < n_clusters; ++c) {
+        const uint32_t v0 = cluster_off[c], k = cluster_off[c + 1] - v0;
+        for (uint32_t j = 0; j < k; ++j)
+            for (uint32_t jp = 0; jp < k; ++jp) {
+                const uint32_t blkidx = woff[c] + j * k + jp;
+                // end stations: second station (+1) first, then the first station (-1): for a single baseline this is
+                // the order of UpdateNormals_G (dnaadjust.cpp:1664-1684)
+                const uint32_t ea[2] = {stn2[v0 + j], stn1[v0 + j]};
+                const uint32_t eb[2] = {stn2[v0 + jp], stn1[v0 + jp]};
+                for (int x = 0; x < 2; ++x) {
+                    if (ea[x] == DNAGPU_NO_STATION) continue;
+                    for (int y = 0; y < 2; ++y) {
+                        if (eb[y] == DNAGPU_NO_STATION) continue;
+                        if (ea[x] < eb[y]) continue;
+                        ents.push_back({(uint64_t)ea[x] * ns + eb[y], (blkidx << 1) | (uint32_t)(x != y)});
+                    }
+                }
+            }
     }
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
-    std::vector<uint32_t> prow, pcol, poff, pbl(ents.size());
+    std::vector<uint32_t> prow, pcol, poff, pent(ents.size());
     for (size_t k = 0; k < ents.size(); ++k) {
         if (k == 0 || ents[k].key != ents[k - 1].key) {
             prow.push_back((uint32_t)(ents[k].key / ns));
             pcol.push_back((uint32_t)(ents[k].key % ns));
             poff.push_back((uint32_t)k);
         }
-        pbl[k] = ents[k].bl;
+        pent[k] = ents[k].ent;
     }
     poff.push_back((uint32_t)ents.size());
-    // incidence per station (CML order)
-    std::vector<uint32_t> ioff(ns + 1, 0), inc((size_t)m * 2);
+    // incidence per station (CML order): vector * 2 + (1 if the station is the vector's second / only station)
+    std::vector<uint32_t> ioff(ns + 1, 0), inc;
     for (uint32_t i = 0; i < m; ++i) {
-        ioff[stn1[i] + 1]++;
+        if (stn1[i] != DNAGPU_NO_STATION) ioff[stn1[i] + 1]++;
         ioff[stn2[i] + 1]++;
     }
     for (uint32_t s = 0; s < ns; ++s) ioff[s + 1] += ioff[s];
+    inc.assign(ioff[ns], 0);
     {
         std::vector<uint32_t> cur(ioff.begin(), ioff.end() - 1);
         for (uint32_t i = 0; i < m; ++i) {
-            inc[cur[stn1[i]]++] = i * 2u;
+            if (stn1[i] != DNAGPU_NO_STATION) inc[cur[stn1[i]]++] = i * 2u;
             inc[cur[stn2[i]]++] = i * 2u + 1u;
         }
     }
 
-    for (void* p : {(void*)b->pair_row, (void*)b->pair_col, (void*)b->pair_off, (void*)b->pair_bl, (void*)b->inc_off, (void*)b->inc})
+    for (void* p : {(void*)b->pair_row, (void*)b->pair_col, (void*)b->pair_off, (void*)b->pair_ent, (void*)b->inc_off, (void*)b->inc,
+                    (void*)b->Wblk})
         if (p) hipFree(p);
-    b->pair_row = b->pair_col = b->pair_off = b->pair_bl = b->inc_off = b->inc = nullptr;
+    b->pair_row = b->pair_col = b->pair_off = b->pair_ent = b->inc_off = b->inc = nullptr;
+    b->Wblk = nullptr;
     b->n_pairs = (uint32_t)prow.size();
+    b->n_wblk = n_wblk;
     auto up = [&](uint32_t** dev, const std::vector<uint32_t>& v) -> hipError_t {
         size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(uint32_t);
         hipError_t e = hipMalloc((void**)dev, bytes);
@@ -568,35 +608,101 @@ int dnagpu_block_set_baselines(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* st
     HIPCHK(up(&b->pair_row, prow));
     HIPCHK(up(&b->pair_col, pcol));
     HIPCHK(up(&b->pair_off, poff));
-    HIPCHK(up(&b->pair_bl, pbl));
+    HIPCHK(up(&b->pair_ent, pent));
     HIPCHK(up(&b->inc_off, ioff));
     HIPCHK(up(&b->inc, inc));
-    if (m) {
-        HIPCHK(hipMemcpy(b->s1, stn1, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(b->s2, stn2, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(b->obs, obs, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice));
-        // stage the variances in b->b's neighbour: W buffer is the output, use a temp
+    HIPCHK(hipMalloc(&b->Wblk, std::max<size_t>(n_wblk, 1) * 9 * sizeof(double)));
+    if (!m) return DNAGPU_OK;
+    HIPCHK(hipMemcpy(b->s1, stn1, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->s2, stn2, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->obs, obs, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->vec_wrow, wrow.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->vec_c0, c0v.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->vec_k, kv.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+    // W = V^-1 per cluster (LoadVarianceMatrix_G/X/Y -> FormInverseVarianceMatrix, dnaadjust.cpp:4214/4312/4494, 8472).
+    // single vectors: one thread each, registers only; larger clusters: the dense inverse of the device layer
+    std::vector<double> v6;
+    std::vector<uint32_t> dst;
+    for (uint32_t c = 0; c < n_clusters; ++c)
+        if (cluster_off[c + 1] - cluster_off[c] == 1) {
+            const double* V = vcv + voff[c];   // 3x3 column-major
+            const double six[6] = {V[0], V[3], V[4], V[6], V[7], V[8]};   // xx, xy, yy, xz, yz, zz (upper triangle)
+            v6.insert(v6.end(), six, six + 6);
+            dst.push_back(woff[c]);
+        }
+    int bad = 0x7fffffff;
+    if (!dst.empty()) {
         double* vtmp = nullptr;
-        HIPCHK(hipMalloc(&vtmp, (size_t)m * 6 * sizeof(double)));
-        hipError_t e = hipMemcpy(vtmp, vcv6, (size_t)m * 6 * sizeof(double), hipMemcpyHostToDevice);
-        int bad = 0x7fffffff;
+        uint32_t* dtmp = nullptr;
+        HIPCHK(hipMalloc(&vtmp, v6.size() * sizeof(double)));
+        hipError_t e = hipMalloc(&dtmp, dst.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(vtmp, v6.data(), v6.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dtmp, dst.data(), dst.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(ctx->bad_dev, &bad, sizeof(int), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            launch_weights(vtmp, b->W, m, ctx->bad_dev, ctx->stream[0]);
+            launch_weights(vtmp, dtmp, b->Wblk, (uint32_t)dst.size(), ctx->bad_dev, ctx->stream[0]);
             e = hipStreamSynchronize(ctx->stream[0]);
         }
         if (e == hipSuccess) e = hipMemcpy(&bad, ctx->bad_dev, sizeof(int), hipMemcpyDeviceToHost);
         hipFree(vtmp);
-        if (e != hipSuccess) return fail(ctx, DNAGPU_EHIP, "block_set_baselines: weights", e);
+        if (dtmp) hipFree(dtmp);
+        if (e != hipSuccess) return fail(ctx, DNAGPU_EHIP, "block_set_clusters: weights", e);
         if (bad != 0x7fffffff) {
             ctx->last_info = bad + 1;
             char buf[160];
-            snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (variance matrix of baseline %d)", bad);
+            snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (variance matrix of measurement %d)", bad);
             ctx->err = buf;
             return DNAGPU_ENOTPOSDEF;
         }
     }
+    if (kmax > 1) {
+        dnagpu_matrix* vm = nullptr;
+        int rc = dnagpu_matrix_create(ctx, 3 * kmax, &vm);
+        if (rc) return rc;
+        for (uint32_t c = 0; c < n_clusters && !rc; ++c) {
+            const uint32_t k = cluster_off[c + 1] - cluster_off[c];
+            if (k == 1) continue;
+            const uint32_t n = 3 * k;
+            rc = dnagpu_matrix_reset(ctx, 0, vm, n);
+            if (!rc) {
+                hipError_t e = hipMemcpy2DAsync(vm->F, (size_t)vm->np * sizeof(double), vcv + voff[c], (size_t)n * sizeof(double),
+                                                (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, ctx->stream[0]);
+                if (e != hipSuccess) rc = fail(ctx, DNAGPU_EHIP, "block_set_clusters: variance upload", e);
+            }
+            if (!rc) rc = dnagpu_invert(ctx, 0, vm, 0);
+            if (!rc) {
+                launch_cluster_blocks(vm->F, vm->np, k, b->Wblk + (size_t)woff[c] * 9, ctx->stream[0]);
+                if (hipStreamSynchronize(ctx->stream[0]) != hipSuccess) rc = fail(ctx, DNAGPU_EHIP, "block_set_clusters: weight blocks");
+            }
+        }
+        dnagpu_matrix_destroy(ctx, vm);
+        if (rc) return rc;
+    }
     return DNAGPU_OK;
+}
+
+int dnagpu_block_set_baselines(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
+                               const double* vcv6) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: unknown block");
+    const uint32_t m = b->n_bl;
+    if (m && (!stn1 || !stn2 || !obs || !vcv6)) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: null argument");
+    for (uint32_t i = 0; i < m; ++i)
+        if (stn1[i] == DNAGPU_NO_STATION) return fail(ctx, DNAGPU_EINVAL, "block_set_baselines: station index out of range");
+    // every baseline is a cluster of one vector
+    std::vector<uint32_t> off(m + 1);
+    std::vector<double> vcv((size_t)m * 9);
+    for (uint32_t i = 0; i <= m; ++i) off[i] = i;
+    for (uint32_t i = 0; i < m; ++i) {
+        const double* v = vcv6 + (size_t)i * 6;
+        double* V = vcv.data() + (size_t)i * 9;
+        V[0] = v[0]; V[1] = v[1]; V[2] = v[3];
+        V[3] = v[1]; V[4] = v[2]; V[5] = v[4];
+        V[6] = v[3]; V[7] = v[4]; V[8] = v[5];
+    }
+    return dnagpu_block_set_clusters(ctx, blk, stn1, stn2, obs, m, off.data(), vcv.data());
 }
 
 int dnagpu_block_get_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int which, double* xyz) {
@@ -662,7 +768,11 @@ int dnagpu_block_get_weights(dnagpu_ctx* ctx, int chain, uint32_t blk, double* w
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b || (!w6 && b->n_bl)) return fail(ctx, DNAGPU_EINVAL, "block_get_weights: bad arguments");
-    return d2h(ctx, chain, w6, b->W, (size_t)b->n_bl * 6 * sizeof(double));
+    if (!b->n_bl) return DNAGPU_OK;
+    int rc = ensure_scr_f64(ctx, chain, (size_t)b->n_bl * 6);
+    if (rc) return rc;
+    launch_diag_weights(b->Wblk, b->vec_wrow, b->vec_c0, ctx->scr_f64[chain], b->n_bl, ctx->stream[chain]);
+    return d2h(ctx, chain, w6, ctx->scr_f64[chain], (size_t)b->n_bl * 6 * sizeof(double));
 }
 
 int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, double* corr) {
@@ -689,7 +799,7 @@ int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
     m->n = 3 * b->n_stn;
     m->np = pad128(m->n);
     launch_init_padded(m->F, m->n, m->np, ctx->stream[chain]);
-    launch_form_normals(b->pair_row, b->pair_col, b->pair_off, b->pair_bl, b->W, m->F, m->np, b->n_pairs, ctx->stream[chain]);
+    launch_form_normals(b->pair_row, b->pair_col, b->pair_off, b->pair_ent, b->Wblk, m->F, m->np, b->n_pairs, ctx->stream[chain]);
     return DNAGPU_OK;
 }
 
@@ -714,7 +824,8 @@ int dnagpu_form_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk) {
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b) return fail(ctx, DNAGPU_EINVAL, "form_rhs: unknown block");
-    launch_form_rhs(b->inc_off, b->inc, b->W, b->b[chain], b->rhs[chain], b->n_stn, ctx->stream[chain]);
+    launch_form_rhs(b->Wblk, b->vec_wrow, b->vec_c0, b->vec_k, b->b[chain], b->wb[chain], b->n_bl, b->inc_off, b->inc, b->rhs[chain], b->n_stn,
+                    ctx->stream[chain]);
     return DNAGPU_OK;
 }
 

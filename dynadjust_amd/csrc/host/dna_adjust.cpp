@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <sstream>
 
 #include "geodesy.hpp"
@@ -100,13 +101,21 @@ void dna_adjust::BuildSimultaneousLists() {
     v_CML_.assign(1, {});
     for (UINT32 s = 0; s < bstBinaryRecords_.size(); ++s)
         if (vAssocStnList_[s].validity) v_ISL_[0].push_back(s);
-    UINT32 rows = 0;
+    UINT32 rows = 0, clusterID = 0;
+    bool in_cluster = false;
     for (UINT32 m = 0; m < bmsBinaryRecords_.size(); ++m) {
         const measurement_t& r = bmsBinaryRecords_[m];
         if (r.ignore) continue;
-        if (r.measStart != 0) continue;   // Y, Z and covariance rows are not measurement starts
+        if (r.measStart > 2) continue;    // covariance rows (measurement_processor.cpp:79-83)
+        rows++;                           // every X / Y / Z element is one design row
+        if (r.measStart != 0) continue;   // only the first element starts a measurement
+        if (r.measType == 'X' || r.measType == 'Y') {
+            // only the first vector of a cluster enters the CML (measurement_processor.cpp:86-122)
+            if (in_cluster && clusterID == r.clusterID) continue;
+            in_cluster = true;
+            clusterID = r.clusterID;
+        }
         v_CML_[0].push_back(m);
-        if (r.measType == 'G') rows += 3;
     }
     v_ContiguousNetList_.assign(1, 0);
     v_measurementCount_.assign(1, rows);
@@ -241,6 +250,83 @@ void dna_adjust::FormConstraintStationVarianceMatrix(UINT32 stn, double w9[9]) c
         for (int i = 0; i < 3; ++i) w9[j * 3 + i] = W[i][j];
 }
 
+// One CML entry -> vectors + the cluster's full variance matrix.
+//   'G' UpdateDesignNormalMeasMatrices_G ADJ:5353 / LoadVarianceMatrix_G ADJ:4214
+//   'X' UpdateDesignNormalMeasMatrices_X ADJ:6056 / LoadVarianceMatrix_X ADJ:4312
+//   'Y' UpdateDesignNormalMeasMatrices_Y ADJ:6249 / LoadVarianceMatrix_Y ADJ:4494 (cartesian clusters)
+// Record layout of a cluster in the .bms: per vector 3 records (X, Y, Z: term1 = value, term2..4 = upper triangle of its
+// 3x3 variance block), followed by vectorCount2 covariance blocks of 3 records each (rows of the 3x3 block against the
+// following vectors, term1..3).
+void dna_adjust::ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B) {
+    const measurement_t& first = bmsBinaryRecords_[m];
+    const char type = first.measType;
+    if ((type != 'G' && type != 'X' && type != 'Y') || first.measStart != 0) {
+        std::stringstream ss;
+        ss << "UpdateNormals(): measurement type '" << type << "' is not handled by the device path yet (GNSS types G, X, Y only).";
+        SignalExceptionAdjustment(ss.str(), block);
+    }
+    if (type == 'Y' && strncmp(first.coordType, "XYZ", 3) != 0)
+        SignalExceptionAdjustment("UpdateDesignNormalMeasMatrices_Y(): GPS point clusters must be cartesian (XYZ) for the device path.", block);
+    // LoadVarianceScaling (ADJ:4453): the matrix scalar is applied on the fly, partial scalars are not handled yet
+    const double tiny = std::min(PRECISION_1E5, projectSettings_.a.fixed_std_dev);
+    double vScale = first.scale4;
+    if (vScale < tiny) vScale = 1.0;
+    const bool scaleMatrix = std::fabs(vScale - 1.0) > PRECISION_1E5;
+    auto unit = [&](double s) { return s < tiny ? 1.0 : s; };
+    if (std::fabs(unit(first.scale1) - 1.0) > PRECISION_1E5 || std::fabs(unit(first.scale2) - 1.0) > PRECISION_1E5 ||
+        std::fabs(unit(first.scale3) - 1.0) > PRECISION_1E5)
+        SignalExceptionAdjustment("LoadVarianceScaling(): phi/lambda/height variance scalars are not handled by the device path yet.", block);
+    const UINT32 k = (type == 'G') ? 1 : first.vectorCount1;
+    if (k == 0) SignalExceptionAdjustment("PrepareAdjustment(): a GNSS cluster without vectors.", block);
+    const UINT32 nc = 3 * k;
+    std::vector<double> V((size_t)nc * nc, 0.0);   // column-major, both triangles
+    auto put = [&](UINT32 r, UINT32 c, double v) {
+        if (scaleMatrix) v *= vScale;
+        V[(size_t)c * nc + r] = v;
+        V[(size_t)r * nc + c] = v;
+    };
+    size_t idx = m;
+    for (UINT32 j = 0; j < k; ++j) {
+        if (idx + 2 >= bmsBinaryRecords_.size()) SignalExceptionAdjustment("PrepareAdjustment(): truncated GNSS cluster.", block);
+        const measurement_t& mx = bmsBinaryRecords_[idx];
+        const measurement_t& my = bmsBinaryRecords_[idx + 1];
+        const measurement_t& mz = bmsBinaryRecords_[idx + 2];
+        B.obs.push_back(mx.term1);
+        B.obs.push_back(my.term1);
+        B.obs.push_back(mz.term1);
+        if (type == 'Y') {
+            B.stn1.push_back(DNAGPU_NO_STATION);
+            B.stn2.push_back(LocalIndex(block, mx.station1));
+        } else {
+            B.stn1.push_back(LocalIndex(block, mx.station1));
+            B.stn2.push_back(LocalIndex(block, mx.station2));
+        }
+        const UINT32 r0 = 3 * j;
+        put(r0, r0, mx.term2);
+        put(r0, r0 + 1, my.term2);
+        put(r0 + 1, r0 + 1, my.term3);
+        put(r0, r0 + 2, mz.term2);
+        put(r0 + 1, r0 + 2, mz.term3);
+        put(r0 + 2, r0 + 2, mz.term4);
+        const UINT32 ncov = (type == 'G') ? 0 : mx.vectorCount2;
+        idx += 3;
+        for (UINT32 c = 0; c < ncov; ++c) {
+            if (idx + 2 >= bmsBinaryRecords_.size() || j + 1 + c >= k)
+                SignalExceptionAdjustment("PrepareAdjustment(): malformed GNSS cluster covariances.", block);
+            const UINT32 c0 = 3 * (j + 1 + c);
+            for (UINT32 r = 0; r < 3; ++r) {
+                const measurement_t& cv = bmsBinaryRecords_[idx + r];
+                put(r0 + r, c0, cv.term1);
+                put(r0 + r, c0 + 1, cv.term2);
+                put(r0 + r, c0 + 2, cv.term3);
+            }
+            idx += 3;
+        }
+    }
+    B.vcv.insert(B.vcv.end(), V.begin(), V.end());
+    B.cluster_off.push_back((UINT32)B.stn1.size());
+}
+
 // PrepareAdjustmentBlock (ADJ:2873) for every block: host lists + device upload
 void dna_adjust::PrepareBlocks() {
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
@@ -272,38 +358,14 @@ void dna_adjust::PrepareBlocks() {
             geodesy::GeoToCart(st.currentLatitude, st.currentLongitude, st.currentHeight, &xyz[3 * p], &xyz[3 * p + 1], &xyz[3 * p + 2]);
         }
         initial_xyz_[b] = xyz;
-        // measurements of the block (CML order)
+        // measurements of the block (CML order): 'G' baselines, 'X' baseline clusters, 'Y' point clusters
         const std::vector<UINT32>& cml = v_CML_[b];
-        B.stn1.reserve(cml.size());
-        B.stn2.reserve(cml.size());
+        B.cluster_off.assign(1, 0);
         for (UINT32 m : cml) {
             if ((size_t)m + 2 >= bmsBinaryRecords_.size())
                 SignalExceptionAdjustment("PrepareAdjustment(): measurement index out of range.", b);
-            const measurement_t& mx = bmsBinaryRecords_[m];
-            if (mx.ignore) continue;   // InitialiseandValidateMsrPointer
-            if (mx.measType != 'G' || mx.measStart != 0) {
-                std::stringstream ss;
-                ss << "UpdateNormals(): measurement type '" << mx.measType
-                   << "' is not handled by the device path yet (GNSS baselines 'G' only).";
-                SignalExceptionAdjustment(ss.str(), b);
-            }
-            const measurement_t& my = bmsBinaryRecords_[m + 1];
-            const measurement_t& mz = bmsBinaryRecords_[m + 2];
-            // LoadVarianceScaling (ADJ:4453): v-scale applied on the fly, partial scalars unsupported
-            double vScale = mx.scale4;
-            if (vScale < std::min(PRECISION_1E5, projectSettings_.a.fixed_std_dev)) vScale = 1.0;
-            const bool scaleMatrix = std::fabs(vScale - 1.0) > PRECISION_1E5;
-            auto unit = [&](double s) { return s < std::min(PRECISION_1E5, projectSettings_.a.fixed_std_dev) ? 1.0 : s; };
-            if (std::fabs(unit(mx.scale1) - 1.0) > PRECISION_1E5 || std::fabs(unit(mx.scale2) - 1.0) > PRECISION_1E5 ||
-                std::fabs(unit(mx.scale3) - 1.0) > PRECISION_1E5)
-                SignalExceptionAdjustment("LoadVarianceMatrix_G(): phi/lambda/height variance scalars are not handled by the device path yet.", b);
-            const double v6[6] = {mx.term2, my.term2, my.term3, mz.term2, mz.term3, mz.term4};
-            for (int k = 0; k < 6; ++k) B.vcv6.push_back(scaleMatrix ? v6[k] * vScale : v6[k]);
-            B.obs.push_back(mx.term1);
-            B.obs.push_back(my.term1);
-            B.obs.push_back(mz.term1);
-            B.stn1.push_back(LocalIndex(b, mx.station1));
-            B.stn2.push_back(LocalIndex(b, mx.station2));
+            if (bmsBinaryRecords_[m].ignore) continue;   // InitialiseandValidateMsrPointer
+            ParseGnssMeasurement(b, m, B);
         }
         // constraint lists (ADJ:1884-2037)
         for (UINT32 p = 0; p < ns; ++p) {
@@ -333,8 +395,9 @@ void dna_adjust::PrepareBlocks() {
         // device
         Check(dnagpu_block_create(ctx_, b, ns, (UINT32)B.stn1.size()), b, "PrepareAdjustment(): block allocation");
         Check(dnagpu_block_set_stations(ctx_, b, xyz.data()), b, "PrepareAdjustment(): stations");
-        Check(dnagpu_block_set_baselines(ctx_, b, B.stn1.data(), B.stn2.data(), B.obs.data(), B.vcv6.data()), b,
-              "PrepareAdjustment(): measurements");
+        Check(dnagpu_block_set_clusters(ctx_, b, B.stn1.data(), B.stn2.data(), B.obs.data(), (UINT32)B.cluster_off.size() - 1,
+                                        B.cluster_off.data(), B.vcv.data()),
+              b, "PrepareAdjustment(): measurements");
         for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "PrepareAdjustment(): meas-minus-computed");
         if (phased) {
             UINT32 nj = (UINT32)v_JSL_[b].size() * 3;

@@ -100,7 +100,9 @@ private:
     };
     struct block_t {
         std::vector<UINT32> stn1, stn2;       // block-local station of each baseline
-        std::vector<double> obs, vcv6;
+        std::vector<double> obs;
+        std::vector<UINT32> cluster_off;      // vectors of measurement c: cluster_off[c] .. cluster_off[c+1]-1
+        std::vector<double> vcv;              // full 3k x 3k variance matrix per measurement, concatenated
         constraint_list con_fwd, con_rev, con_cmb, con_sim;
         std::vector<UINT32> jsl_here;         // local index of JSL(block) stations in this block
         std::vector<UINT32> jsl_in_next;      // local index of JSL(block) stations in block+1
@@ -116,6 +118,7 @@ private:
     void BuildSimultaneousLists();
     void CreateStnAppearanceList();
     void PrepareBlocks();
+    void ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B);
     void FormConstraintStationVarianceMatrix(UINT32 stn, double w9[9]) const;   // ADJ:2041
     UINT32 LocalIndex(UINT32 block, UINT32 stn) const;
 

@@ -168,6 +168,8 @@ int dnasynth_write_network(const char* dir, const char* name, const dnasynth_spe
         sp.n_blocks = spec->n_blocks ? spec->n_blocks : 1;
         if (spec->seed) sp.seed = spec->seed;
         if (spec->initial_sigma > 0) sp.initial_sigma = spec->initial_sigma;
+        sp.x_clusters = spec->x_clusters;
+        sp.y_cluster = spec->y_cluster != 0;
         dynadjust::synth::Summary sm;
         dynadjust::synth::write_network(dir, name, sp, &sm);
         if (out) {

@@ -98,79 +98,164 @@ void write_network(const std::string& dir, const std::string& name, const Spec& 
         }
 
     // baselines: selection sampling of exactly `target` of the candidate edges (Knuth 3.4.2 S)
-    std::vector<measurement_t> bms;
-    bms.reserve(3 * target);
     std::vector<uint32_t> bl_s1, bl_s2;
     bl_s1.reserve(target);
     bl_s2.reserve(target);
-    uint64_t remaining = n_cand, need = target;
+    {
+        uint64_t remaining = n_cand, need = target;
+        auto consider = [&](uint64_t s1, uint64_t s2) {
+            bool take = (double)need > rng.uniform() * (double)remaining;
+            --remaining;
+            if (!take || need == 0) return;
+            --need;
+            bl_s1.push_back((uint32_t)s1);
+            bl_s2.push_back((uint32_t)s2);
+        };
+        for (uint32_t r = 0; r < R; ++r)
+            for (uint32_t c = 0; c < C; ++c) {
+                uint64_t s = (uint64_t)r * C + c;
+                if (c + 1 < C) consider(s, s + 1);
+                if (r + 1 < R) consider(s, s + C);
+                if (r + 1 < R && c + 1 < C) consider(s, s + C + 1);
+            }
+    }
+    const uint64_t n_bl = bl_s1.size();
+
+    // measurement records.  A run of baselines leaving one station becomes one 'X' cluster for the first
+    // sp.x_clusters stations that have at least two; every other baseline is a 'G'.
+    std::vector<measurement_t> bms;
+    bms.reserve(3 * n_bl + 64);
+    std::vector<uint32_t> msr_first;      // first record of every measurement (CML entry)
+    std::vector<uint32_t> msr_station;    // the station whose strip owns the measurement
     const double sd[3] = {sp.sigma_e, sp.sigma_n, sp.sigma_up};
-    auto consider = [&](uint64_t s1, uint64_t s2) {
-        bool take = (double)need > rng.uniform() * (double)remaining;
-        --remaining;
-        if (!take || need == 0) return;
-        --need;
-        double Rm[3][3];
-        LocalToCartRotation(tlat[s1], tlon[s1], Rm);
-        double V[3][3], eps[3] = {0, 0, 0};
-        double zr[3] = {rng.normal(), rng.normal(), rng.normal()};
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double v = 0.0;
-                for (int k = 0; k < 3; ++k) v += Rm[i][k] * sd[k] * sd[k] * Rm[j][k];
-                V[i][j] = v;
+    uint32_t cluster_id = 1;
+    auto base_record = [&](char type, int start, uint32_t s1, uint32_t s2, uint32_t id) {
+        measurement_t m;
+        memset(&m, 0, sizeof(m));
+        m.measType = type;
+        m.measStart = (char)start;
+        m.measurementStations = (type == 'Y') ? 1 : 2;
+        put_str(m.epsgCode, sizeof(m.epsgCode), "7843");
+        put_str(m.epoch, sizeof(m.epoch), "01.01.2020");
+        put_str(m.observation_epoch, sizeof(m.observation_epoch), "01.01.2020");
+        put_str(m.coordType, sizeof(m.coordType), "XYZ");
+        m.ignore = false;
+        m.station1 = s1;
+        m.station2 = s2;
+        m.clusterID = id;
+        m.fileOrder = id;
+        m.scale1 = m.scale2 = m.scale3 = m.scale4 = 1.0;
+        return m;
+    };
+    // emits a cluster of k vectors with the full symmetric variance matrix V (3k x 3k, row-major here)
+    auto emit_cluster = [&](char type, const std::vector<uint32_t>& s1, const std::vector<uint32_t>& s2,
+                            const std::vector<double>& obs, const std::vector<double>& V) {
+        const uint32_t k = (uint32_t)s2.size(), nc = 3 * k;
+        msr_first.push_back((uint32_t)bms.size());
+        msr_station.push_back(type == 'Y' ? s2[0] : s1[0]);
+        const uint32_t id = cluster_id++;
+        for (uint32_t j = 0; j < k; ++j) {
+            for (int e = 0; e < 3; ++e) {
+                measurement_t m = base_record(type, e, type == 'Y' ? s2[j] : s1[j], type == 'Y' ? 0 : s2[j], id);
+                m.vectorCount1 = (type == 'G') ? (e == 0 ? 1 : 0) : k;
+                m.vectorCount2 = (type == 'G') ? 0 : k - 1 - j;
+                m.term1 = obs[3 * j + e];
+                const uint32_t r0 = 3 * j;
+                if (e == 0) {
+                    m.term2 = V[(size_t)r0 * nc + r0];
+                } else if (e == 1) {
+                    m.term2 = V[(size_t)r0 * nc + r0 + 1];
+                    m.term3 = V[(size_t)(r0 + 1) * nc + r0 + 1];
+                } else {
+                    m.term2 = V[(size_t)r0 * nc + r0 + 2];
+                    m.term3 = V[(size_t)(r0 + 1) * nc + r0 + 2];
+                    m.term4 = V[(size_t)(r0 + 2) * nc + r0 + 2];
+                }
+                m.preAdjMeas = m.term1;
+                bms.push_back(m);
             }
-        for (int i = 0; i < 3; ++i)
-            for (int k = 0; k < 3; ++k) eps[i] += Rm[i][k] * sd[k] * zr[k];
-        uint32_t idx = (uint32_t)bl_s1.size();
-        bl_s1.push_back((uint32_t)s1);
-        bl_s2.push_back((uint32_t)s2);
-        for (int e = 0; e < 3; ++e) {
-            measurement_t m;
-            memset(&m, 0, sizeof(m));
-            m.measType = 'G';
-            m.measStart = (char)e;
-            m.measurementStations = 2;
-            put_str(m.epsgCode, sizeof(m.epsgCode), "7843");
-            put_str(m.epoch, sizeof(m.epoch), "01.01.2020");
-            put_str(m.observation_epoch, sizeof(m.observation_epoch), "01.01.2020");
-            put_str(m.coordType, sizeof(m.coordType), "XYZ");
-            m.ignore = false;
-            m.station1 = (UINT32)s1;
-            m.station2 = (UINT32)s2;
-            m.vectorCount1 = (e == 0) ? 1 : 0;
-            m.clusterID = idx;
-            m.fileOrder = idx;
-            m.term1 = (truth[3 * s2 + e] - truth[3 * s1 + e]) + eps[e];
-            if (e == 0) {
-                m.term2 = V[0][0];
-            } else if (e == 1) {
-                m.term2 = V[0][1];
-                m.term3 = V[1][1];
-            } else {
-                m.term2 = V[0][2];
-                m.term3 = V[1][2];
-                m.term4 = V[2][2];
-            }
-            m.scale1 = m.scale2 = m.scale3 = m.scale4 = 1.0;
-            m.preAdjMeas = m.term1;
-            bms.push_back(m);
+            for (uint32_t c = j + 1; c < k; ++c)
+                for (int r = 0; r < 3; ++r) {
+                    measurement_t m = base_record(type, 3 + r, type == 'Y' ? s2[j] : s1[j], type == 'Y' ? 0 : s2[j], id);
+                    m.vectorCount1 = k;
+                    m.vectorCount2 = k - 1 - j;
+                    m.term1 = V[(size_t)(3 * j + r) * nc + 3 * c];
+                    m.term2 = V[(size_t)(3 * j + r) * nc + 3 * c + 1];
+                    m.term3 = V[(size_t)(3 * j + r) * nc + 3 * c + 2];
+                    bms.push_back(m);
+                }
         }
     };
-    for (uint32_t r = 0; r < R; ++r)
-        for (uint32_t c = 0; c < C; ++c) {
-            uint64_t s = (uint64_t)r * C + c;
-            if (c + 1 < C) consider(s, s + 1);
-            if (r + 1 < R) consider(s, s + C);
-            if (r + 1 < R && c + 1 < C) consider(s, s + C + 1);
+    // variance matrix of k vectors: block-diagonal local-frame variances + a common low-rank part (correlations)
+    auto make_vcv = [&](const std::vector<uint32_t>& at, bool correlated, std::vector<double>& V, std::vector<double>& noise) {
+        const uint32_t k = (uint32_t)at.size(), nc = 3 * k;
+        V.assign((size_t)nc * nc, 0.0);
+        noise.assign(nc, 0.0);
+        for (uint32_t j = 0; j < k; ++j) {
+            double Rm[3][3];
+            LocalToCartRotation(tlat[at[j]], tlon[at[j]], Rm);
+            double zr[3] = {rng.normal(), rng.normal(), rng.normal()};
+            for (int i = 0; i < 3; ++i) {
+                for (int q = 0; q < 3; ++q) {
+                    double v = 0.0;
+                    for (int t = 0; t < 3; ++t) v += Rm[i][t] * sd[t] * sd[t] * Rm[q][t];
+                    V[(size_t)(3 * j + i) * nc + 3 * j + q] = v;
+                }
+                for (int t = 0; t < 3; ++t) noise[3 * j + i] += Rm[i][t] * sd[t] * zr[t];
+            }
         }
-    const uint64_t n_bl = bl_s1.size();
+        if (correlated && k > 1) {
+            std::vector<double> g((size_t)nc * 2);
+            for (double& x : g) x = 0.002 * rng.normal();
+            for (uint32_t i = 0; i < nc; ++i)
+                for (uint32_t q = 0; q < nc; ++q) V[(size_t)i * nc + q] += g[2 * i] * g[2 * q] + g[2 * i + 1] * g[2 * q + 1];
+        }
+    };
+    uint32_t x_left = sp.x_clusters;
+    for (uint64_t i = 0; i < n_bl;) {
+        uint64_t e = i;
+        while (e < n_bl && bl_s1[e] == bl_s1[i]) ++e;
+        const bool cluster = x_left > 0 && e - i >= 2;
+        const uint64_t step = cluster ? e - i : 1;
+        std::vector<uint32_t> s1(bl_s1.begin() + i, bl_s1.begin() + i + step), s2(bl_s2.begin() + i, bl_s2.begin() + i + step);
+        std::vector<double> V, noise, obs(3 * step);
+        make_vcv(s1, cluster, V, noise);
+        for (uint64_t j = 0; j < step; ++j)
+            for (int c = 0; c < 3; ++c) obs[3 * j + c] = (truth[3 * (size_t)s2[j] + c] - truth[3 * (size_t)s1[j] + c]) + noise[3 * j + c];
+        emit_cluster(cluster ? 'X' : 'G', s1, s2, obs, V);
+        if (cluster) --x_left;
+        i += step;
+    }
+    if (sp.y_cluster) {
+        // the datum as a GNSS point cluster over the four corner stations (which are then free, FFF)
+        std::vector<uint32_t> none, corners = {0u, (uint32_t)(C - 1), (uint32_t)((uint64_t)(R - 1) * C), (uint32_t)((uint64_t)R * C - 1)};
+        std::vector<double> V, noise, obs(12);
+        make_vcv(corners, true, V, noise);
+        for (int j = 0; j < 4; ++j)
+            for (int c = 0; c < 3; ++c) obs[3 * j + c] = truth[3 * (size_t)corners[j] + c] + noise[3 * j + c];
+        // one cluster lives in one block: the corners of the first and the last strip are tied by one Y cluster each
+        std::vector<uint32_t> lo(corners.begin(), corners.begin() + 2), hi(corners.begin() + 2, corners.end());
+        auto sub = [&](int off, std::vector<double>& Vs, std::vector<double>& os) {
+            Vs.assign(36, 0.0);
+            os.assign(obs.begin() + 6 * off, obs.begin() + 6 * off + 6);
+            for (int i = 0; i < 6; ++i)
+                for (int q = 0; q < 6; ++q) Vs[i * 6 + q] = V[(size_t)(6 * off + i) * 12 + 6 * off + q];
+        };
+        std::vector<double> Vs, os;
+        sub(0, Vs, os);
+        emit_cluster('Y', none, lo, os, Vs);
+        sub(1, Vs, os);
+        emit_cluster('Y', none, hi, os, Vs);
+        for (uint32_t s : corners) put_str(bst[s].stationConst, sizeof(bst[s].stationConst), "FFF");
+    }
+    const uint64_t n_msr = msr_first.size();
 
     // associated station list
     std::vector<asl_entry_t> asl(n_stn);
-    for (uint64_t i = 0; i < n_bl; ++i) {
-        asl[bl_s1[i]].assocMsrCount++;
-        asl[bl_s2[i]].assocMsrCount++;
+    for (const measurement_t& m : bms) {
+        if (m.measStart != 0) continue;
+        asl[m.station1].assocMsrCount++;
+        if (m.measType != 'Y') asl[m.station2].assocMsrCount++;
     }
     uint32_t off = 0;
     for (uint64_t s = 0; s < n_stn; ++s) {
@@ -194,12 +279,17 @@ void write_network(const std::string& dir, const std::string& name, const Spec& 
         return k >= B ? B - 1 : k;
     };
     for (uint64_t s = 0; s < n_stn; ++s) seg.ISL[strip_of(s)].push_back((UINT32)s);
-    for (uint64_t i = 0; i < n_bl; ++i) {
-        uint32_t k1 = strip_of(bl_s1[i]), k2 = strip_of(bl_s2[i]);
-        uint32_t k = std::min(k1, k2);
-        seg.CML[k].push_back((UINT32)(3 * i));
-        if (k1 != k) seg.JSL[k].push_back(bl_s1[i]);
-        if (k2 != k) seg.JSL[k].push_back(bl_s2[i]);
+    for (uint64_t q = 0; q < n_msr; ++q) {
+        // a measurement belongs to the strip of the station it leaves; end stations in the next strip are junctions
+        const uint32_t k = strip_of(msr_station[q]);
+        seg.CML[k].push_back((UINT32)msr_first[q]);
+        const uint32_t end = (q + 1 < n_msr) ? msr_first[q + 1] : (uint32_t)bms.size();
+        for (uint32_t r = msr_first[q]; r < end; ++r) {
+            const measurement_t& m = bms[r];
+            if (m.measStart != 0) continue;
+            if (strip_of(m.station1) != k) seg.JSL[k].push_back(m.station1);
+            if (m.measType != 'Y' && strip_of(m.station2) != k) seg.JSL[k].push_back(m.station2);
+        }
     }
     for (uint32_t k = 0; k < B; ++k) {
         std::sort(seg.JSL[k].begin(), seg.JSL[k].end());
@@ -226,7 +316,7 @@ void write_network(const std::string& dir, const std::string& name, const Spec& 
     if (summary) {
         summary->stations = n_stn;
         summary->baselines = n_bl;
-        summary->measurement_rows = 3 * n_bl;
+        summary->measurement_rows = 3 * n_bl + (sp.y_cluster ? 12 : 0);
         summary->blocks = B;
         summary->max_block_unknowns = 0;
         for (uint32_t k = 0; k < B; ++k)

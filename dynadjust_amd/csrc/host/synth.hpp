@@ -13,6 +13,8 @@ struct Spec {
     uint64_t seed = 20260928;
     double initial_sigma = 0.05;             // metres, perturbation of the initial coordinates per axis
     double sigma_e = 0.003, sigma_n = 0.003, sigma_up = 0.006;   // baseline noise in the local frame
+    uint32_t x_clusters = 0;   // the baselines leaving each of the first x_clusters stations form one 'X' cluster (correlated VCV)
+    bool y_cluster = false;    // datum from two 'Y' point clusters over the corner stations instead of CCC constraints
 };
 
 struct Summary {

@@ -101,6 +101,8 @@ typedef struct {
     uint32_t n_blocks;
     uint64_t seed;
     double initial_sigma;
+    uint32_t x_clusters;    /* baselines leaving each of the first x_clusters stations become one 'X' cluster */
+    uint32_t y_cluster;     /* 1: datum from 'Y' point clusters over the corner stations (which become FFF) */
 } dnasynth_spec;
 typedef struct {
     uint64_t stations, baselines, measurement_rows, blocks, max_block_unknowns;

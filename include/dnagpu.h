@@ -110,6 +110,15 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz);
  * (XX, XY, YY, XZ, YZ, ZZ), already v-scaled.  Computes W = V^-1 on device. */
 int dnagpu_block_set_baselines(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
                                const double* vcv6);
+/* General GNSS measurements: `n_baselines` vectors of 3 design rows each, grouped into clusters that share a dense
+ * variance matrix ('G' = cluster of one baseline, 'X' = baseline cluster, 'Y' = point cluster; UpdateDesignNormalMeasMatrices_G
+ * / _X / _Y, dnaadjust.cpp:5353 / 6056 / 6249).  stn1[v] = first (negative) station or DNAGPU_NO_STATION for a point,
+ * stn2[v] = second (positive) station; cluster c owns vectors cluster_off[c] .. cluster_off[c+1]-1 (CML order);
+ * vcv = the clusters' full symmetric 3k x 3k variance matrices (column-major), one after the other, already scaled.
+ * W = V^-1 is computed on the device (LoadVarianceMatrix_G/X/Y + FormInverseVarianceMatrix). */
+#define DNAGPU_NO_STATION 0xffffffffu
+int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
+                              uint32_t n_clusters, const uint32_t* cluster_off, const double* vcv);
 /* which = 0 original, 1 estimated, 2 rigorous */
 int dnagpu_block_get_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int which, double* xyz);
 int dnagpu_block_put_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int which, const double* xyz);

@@ -304,7 +304,10 @@ struct orc_adjustment {
     int phased;
     uint32_t n_blocks;
     blk_t* blk;
-    double* W;                   /* 6 per baseline */
+    double* W;                   /* 6 per vector: its own weight block (exact path for single baselines) */
+    uint32_t n_clusters;
+    uint32_t* cl_off;            /* vectors of cluster c: cl_off[c] .. cl_off[c+1]-1 */
+    double** cl_W;               /* dense 3k x 3k inverse variance matrix per cluster (NULL for single baselines) */
     uint32_t* simul_stations;    /* 0..n-1 for simultaneous mode */
     uint32_t* simul_cml;
     double var_C, var_F;
@@ -368,24 +371,91 @@ static void update_normals_G(double* N, uint32_t n, uint32_t s1, uint32_t s2, co
         for (int r = 0; r < 3; ++r) lower_add(N, n, s2 + r, s1 + col, -1. * w6[sym6(r, col)]);
 }
 
-/* UpdateNormals (ADJ:1364) for a GNSS-only block */
+/* A cluster of k vectors ('X' baseline cluster ADJ:6056-6246 / 1687-1787, 'Y' point cluster ADJ:6249-6566 / 1790-1832):
+ * AtVinv rows of every station of the cluster are accumulated first (blockadd of the weight rows with the sign of the
+ * design element), then N(s, s') += AtVinv(s, cluster columns) * A(cluster rows, s').  rhs != NULL: rhs(s) += AtVinv(s,:) b. */
+static void cluster_contribution(orc_adjustment* a, blk_t* B, uint32_t c, double* N, double* rhs, const double* bvec) {
+    const uint32_t v0 = a->cl_off[c], k = a->cl_off[c + 1] - v0, nc = 3 * k;
+    const double* W = a->cl_W[c];
+    /* unique stations of the cluster (block-local indices) */
+    uint32_t* st = (uint32_t*)malloc(2 * k * sizeof(uint32_t));
+    uint32_t ns = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        uint32_t ends[2] = {a->net.stn1[v0 + j], a->net.stn2[v0 + j]};
+        for (int e = 0; e < 2; ++e) {
+            if (ends[e] == 0xffffffffu) continue;
+            uint32_t l = local_index(B, ends[e]);
+            uint32_t q = 0;
+            while (q < ns && st[q] != l) ++q;
+            if (q == ns) st[ns++] = l;
+        }
+    }
+    double* AtV = (double*)calloc((size_t)ns * 3 * nc, sizeof(double)); /* row-major [station row][cluster column] */
+    int* sgn = (int*)calloc((size_t)ns * k, sizeof(int));               /* design element of vector j at station q */
+    for (uint32_t j = 0; j < k; ++j) {
+        uint32_t ends[2] = {a->net.stn1[v0 + j], a->net.stn2[v0 + j]};
+        for (int e = 0; e < 2; ++e) {
+            if (ends[e] == 0xffffffffu) continue;
+            uint32_t l = local_index(B, ends[e]), q = 0;
+            while (st[q] != l) ++q;
+            double sg = e == 0 ? -1.0 : 1.0;
+            sgn[q * k + j] += (int)sg;
+            for (int r = 0; r < 3; ++r)
+                for (uint32_t col = 0; col < nc; ++col) AtV[((size_t)q * 3 + r) * nc + col] += sg * W[(size_t)col * nc + 3 * j + r];
+        }
+    }
+    for (uint32_t q = 0; q < ns; ++q) {
+        if (N)
+            for (uint32_t p = 0; p < ns; ++p)
+                for (int r = 0; r < 3; ++r)
+                    for (int cc = 0; cc < 3; ++cc) {
+                        double sum = 0.0;
+                        for (uint32_t j = 0; j < k; ++j)
+                            if (sgn[p * k + j]) sum += AtV[((size_t)q * 3 + r) * nc + 3 * j + cc] * (double)sgn[p * k + j];
+                        lower_add(N, B->n, 3 * st[q] + r, 3 * st[p] + cc, sum);
+                    }
+        if (rhs)
+            for (int r = 0; r < 3; ++r) {
+                double sum = 0.0;
+                for (uint32_t col = 0; col < nc; ++col) sum += AtV[((size_t)q * 3 + r) * nc + col] * bvec[col];
+                rhs[3 * st[q] + r] += sum;
+            }
+    }
+    free(AtV);
+    free(sgn);
+    free(st);
+}
+
+/* UpdateNormals (ADJ:1364) for a GNSS block */
 static void update_normals(orc_adjustment* a, blk_t* B) {
     for (uint32_t c = 0; c < B->n_cml; ++c) {
-        uint32_t i = B->cml[c];
-        uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
-        uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
-        update_normals_G(B->N, B->n, s1, s2, a->W + (size_t)i * 6);
+        uint32_t cl = B->cml[c];
+        uint32_t i = a->cl_off[cl];
+        if (!a->cl_W[cl]) {
+            uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
+            uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
+            update_normals_G(B->N, B->n, s1, s2, a->W + (size_t)i * 6);
+        } else
+            cluster_contribution(a, B, cl, B->N, NULL, NULL);
     }
 }
 
 /* FillDesignNormalMeasurementsMatrices(false) (ADJ:3888) -> UpdateDesignMeasMatrices_GX (ADJ:5283):
  * b = term1 - (x2 - x1), AddMsrtoMeasMinusComp (ADJ:4719) */
 static void compute_b(orc_adjustment* a, blk_t* B, const double* est) {
+    uint32_t row = 0;
     for (uint32_t c = 0; c < B->n_cml; ++c) {
-        uint32_t i = B->cml[c];
-        uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
-        uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
-        for (int k = 0; k < 3; ++k) B->b[3 * c + k] = a->net.obs[3 * (size_t)i + k] - (est[s2 + k] - est[s1 + k]);
+        uint32_t cl = B->cml[c];
+        for (uint32_t i = a->cl_off[cl]; i < a->cl_off[cl + 1]; ++i, row += 3) {
+            uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
+            if (a->net.stn1[i] == 0xffffffffu) {
+                /* point cluster: computed = station coordinate (ADJ:6343) */
+                for (int k = 0; k < 3; ++k) B->b[row + k] = a->net.obs[3 * (size_t)i + k] - est[s2 + k];
+            } else {
+                uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
+                for (int k = 0; k < 3; ++k) B->b[row + k] = a->net.obs[3 * (size_t)i + k] - (est[s2 + k] - est[s1 + k]);
+            }
+        }
     }
 }
 
@@ -446,10 +516,17 @@ static int solve(orc_adjustment* a, blk_t* B, int compute_inverse, uint32_t bloc
     }
     /* At_Vinv_m = AtVinv * measMinusComp (ADJ:6659-6660); AtVinv is never materialised */
     double* rhs = (double*)calloc(n ? n : 1, sizeof(double));
+    uint32_t brow = 0;
     for (uint32_t c = 0; c < B->n_cml; ++c) {
-        uint32_t i = B->cml[c];
+        uint32_t cl = B->cml[c];
+        uint32_t i = a->cl_off[cl];
+        const double* bb = B->b + brow;
+        brow += 3 * (a->cl_off[cl + 1] - i);
+        if (a->cl_W[cl]) {
+            cluster_contribution(a, B, cl, NULL, rhs, bb);
+            continue;
+        }
         const double* w = a->W + (size_t)i * 6;
-        const double* bb = B->b + 3 * (size_t)c;
         uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
         uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
         for (int r = 0; r < 3; ++r) {
@@ -593,6 +670,10 @@ void orc_adjust_destroy(orc_adjustment* a) {
     }
     free(a->blk);
     free(a->W);
+    if (a->cl_W)
+        for (uint32_t c = 0; c < a->n_clusters; ++c) free(a->cl_W[c]);
+    free(a->cl_W);
+    free(a->cl_off);
     free(a->simul_stations);
     free(a->simul_cml);
     free(a);
@@ -602,18 +683,49 @@ void orc_adjust_destroy(orc_adjustment* a) {
  * PrepareAdjustmentBlock (ADJ:2873) */
 int orc_adjust_prepare(orc_adjustment* a) {
     const orc_network* net = &a->net;
-    /* measurement weights, LoadVarianceMatrix_G (ADJ:4214) */
-    a->W = (double*)malloc(((size_t)net->n_baselines * 6 + 1) * sizeof(double));
-    for (uint32_t i = 0; i < net->n_baselines; ++i)
-        if (orc_weight_3x3(net->vcv6 + (size_t)i * 6, a->W + (size_t)i * 6)) {
-            snprintf(a->err, sizeof(a->err), "Matrix inversion failed, the matrix is singular. (variance matrix of baseline %u)", i);
+    /* clusters: without cluster arrays every vector is a single 'G' baseline */
+    a->n_clusters = net->n_clusters ? net->n_clusters : net->n_baselines;
+    a->cl_off = (uint32_t*)malloc(((size_t)a->n_clusters + 1) * sizeof(uint32_t));
+    a->cl_W = (double**)calloc((size_t)a->n_clusters + 1, sizeof(double*));
+    for (uint32_t c = 0; c <= a->n_clusters; ++c) a->cl_off[c] = net->n_clusters ? net->cluster_off[c] : c;
+    /* measurement weights: LoadVarianceMatrix_G / _X / _Y (ADJ:4214 / 4312 / 4494) + FormInverseVarianceMatrix (ADJ:8472) */
+    a->W = (double*)calloc((size_t)net->n_baselines * 6 + 1, sizeof(double));
+    size_t voff = 0;
+    for (uint32_t c = 0; c < a->n_clusters; ++c) {
+        uint32_t i = a->cl_off[c], k = a->cl_off[c + 1] - i, nc = 3 * k;
+        const double* V = net->n_clusters ? net->cluster_vcv + voff : NULL;
+        voff += (size_t)nc * nc;
+        if (k == 1 && net->stn1[i] != 0xffffffffu) {
+            double six[6];
+            const double* v6 = net->n_clusters ? six : net->vcv6 + (size_t)i * 6;
+            if (net->n_clusters) {
+                six[0] = V[0]; six[1] = V[3]; six[2] = V[4]; six[3] = V[6]; six[4] = V[7]; six[5] = V[8];
+            }
+            if (orc_weight_3x3(v6, a->W + (size_t)i * 6)) {
+                snprintf(a->err, sizeof(a->err), "Matrix inversion failed, the matrix is singular. (variance matrix of measurement %u)", c);
+                return -1;
+            }
+            continue;
+        }
+        double* Wc = (double*)malloc((size_t)nc * nc * sizeof(double));
+        memcpy(Wc, V, (size_t)nc * nc * sizeof(double));
+        if (orc_cholesky_inverse_full(Wc, nc, nc)) {
+            free(Wc);
+            snprintf(a->err, sizeof(a->err), "Matrix inversion failed, the matrix is singular. (variance matrix of measurement %u)", c);
             return -1;
         }
+        a->cl_W[c] = Wc;
+        for (uint32_t j = 0; j < k; ++j) {
+            double* w = a->W + (size_t)(i + j) * 6;
+            const double* D = Wc + (size_t)(3 * j) * nc + 3 * j;
+            w[0] = D[0]; w[1] = D[nc]; w[2] = D[nc + 1]; w[3] = D[2 * nc]; w[4] = D[2 * nc + 1]; w[5] = D[2 * nc + 2];
+        }
+    }
     if (!a->phased) {
         a->simul_stations = (uint32_t*)malloc((net->n_stations + 1) * sizeof(uint32_t));
         for (uint32_t s = 0; s < net->n_stations; ++s) a->simul_stations[s] = s;
-        a->simul_cml = (uint32_t*)malloc((net->n_baselines + 1) * sizeof(uint32_t));
-        for (uint32_t i = 0; i < net->n_baselines; ++i) a->simul_cml[i] = i;
+        a->simul_cml = (uint32_t*)malloc(((size_t)a->n_clusters + 1) * sizeof(uint32_t));
+        for (uint32_t i = 0; i < a->n_clusters; ++i) a->simul_cml[i] = i;
     }
     uint32_t prev_net = 999999;
     for (uint32_t b = 0; b < a->n_blocks; ++b) {
@@ -638,12 +750,13 @@ int orc_adjust_prepare(orc_adjustment* a) {
             B->stations = (uint32_t*)malloc((B->n_stn + 1) * sizeof(uint32_t));
             memcpy(B->stations, a->simul_stations, B->n_stn * sizeof(uint32_t));
             B->n_jsl = 0;
-            B->n_cml = net->n_baselines;
+            B->n_cml = a->n_clusters;
             B->cml = a->simul_cml;
             B->first = B->last = B->isolated = 1;
         }
         B->n = 3 * B->n_stn;
-        B->m = 3 * B->n_cml;
+        B->m = 0;
+        for (uint32_t q = 0; q < B->n_cml; ++q) B->m += 3 * (a->cl_off[B->cml[q] + 1] - a->cl_off[B->cml[q]]);
         B->first_fwd = (uint8_t*)calloc(B->n_stn + 1, 1);
         B->first_rev = (uint8_t*)calloc(B->n_stn + 1, 1);
     }

@@ -76,6 +76,13 @@ typedef struct {
     const uint32_t* cml_off;
     const uint32_t* cml;       /* baseline indices per block, CML order */
     const uint32_t* net_id;    /* contiguous network id per block */
+    /* optional measurement clusters ('X' baseline clusters, 'Y' point clusters).  n_clusters == 0: every vector is
+     * a single 'G' baseline with vcv6 and cml lists vector indices.  Otherwise cml lists cluster indices, cluster c
+     * owns vectors cluster_off[c]..cluster_off[c+1]-1, stn1 == 0xffffffff marks a point (no first station) and
+     * cluster_vcv holds the full symmetric 3k x 3k variance matrices (column-major), concatenated; vcv6 is unused. */
+    uint32_t n_clusters;
+    const uint32_t* cluster_off;
+    const double* cluster_vcv;
 } orc_network;
 
 typedef struct {

@@ -16,7 +16,7 @@ class OrcNetwork(C.Structure):
     _fields_ = [("n_stations", C.c_uint32), ("xyz0", f64p), ("constraints", C.c_char_p), ("n_baselines", C.c_uint32),
                 ("stn1", u32p), ("stn2", u32p), ("obs", f64p), ("vcv6", f64p), ("n_blocks", C.c_uint32),
                 ("isl_off", u32p), ("isl", u32p), ("jsl_off", u32p), ("jsl", u32p), ("cml_off", u32p), ("cml", u32p),
-                ("net_id", u32p)]
+                ("net_id", u32p), ("n_clusters", C.c_uint32), ("cluster_off", u32p), ("cluster_vcv", f64p)]
 
 
 class OrcSettings(C.Structure):
@@ -134,18 +134,23 @@ class Network:
             self.xyz0[3 * s:3 * s + 3] = geo_to_cart(float(bst["currentLatitude"][s]), float(bst["currentLongitude"][s]),
                                                      float(bst["currentHeight"][s]))
         self.constraints = b"".join(bytes(c[:3]).ljust(3, b"F") for c in bst["stationConst"])
-        starts = np.nonzero((bms["measStart"] == 0) & (~bms["ignore"]))[0]
-        assert np.all(bms["measType"][starts] == b"G")
-        self.bl_of_record = {int(m): i for i, m in enumerate(starts)}
-        self.n_baselines = len(starts)
-        self.stn1 = np.ascontiguousarray(bms["station1"][starts], dtype=np.uint32)
-        self.stn2 = np.ascontiguousarray(bms["station2"][starts], dtype=np.uint32)
-        self.obs = np.ascontiguousarray(np.stack([bms["term1"][starts], bms["term1"][starts + 1], bms["term1"][starts + 2]], axis=1)).ravel()
-        vs = bms["scale4"][starts]
-        v6 = np.stack([bms["term2"][starts], bms["term2"][starts + 1], bms["term3"][starts + 1],
-                       bms["term2"][starts + 2], bms["term3"][starts + 2], bms["term4"][starts + 2]], axis=1)
-        scale = np.where(np.abs(vs - 1.0) > 1e-5, vs, 1.0)
-        self.vcv6 = np.ascontiguousarray(v6 * scale[:, None]).ravel()
+        self.n_clusters = 0
+        self.cluster_off = np.zeros(1, dtype=np.uint32)
+        self.cluster_vcv = np.zeros(1)
+        if np.all(bms["measType"] == b"G"):
+            starts = np.nonzero((bms["measStart"] == 0) & (~bms["ignore"]))[0]
+            self.bl_of_record = {int(m): i for i, m in enumerate(starts)}
+            self.n_baselines = len(starts)
+            self.stn1 = np.ascontiguousarray(bms["station1"][starts], dtype=np.uint32)
+            self.stn2 = np.ascontiguousarray(bms["station2"][starts], dtype=np.uint32)
+            self.obs = np.ascontiguousarray(np.stack([bms["term1"][starts], bms["term1"][starts + 1], bms["term1"][starts + 2]], axis=1)).ravel()
+            vs = bms["scale4"][starts]
+            v6 = np.stack([bms["term2"][starts], bms["term2"][starts + 1], bms["term3"][starts + 1],
+                           bms["term2"][starts + 2], bms["term3"][starts + 2], bms["term4"][starts + 2]], axis=1)
+            scale = np.where(np.abs(vs - 1.0) > 1e-5, vs, 1.0)
+            self.vcv6 = np.ascontiguousarray(v6 * scale[:, None]).ravel()
+        else:
+            self._parse_clusters(bms)
         if phased:
             ISL, JSL, CML, nets = F.read_seg(base + ".seg")
             self.n_blocks = len(ISL)
@@ -160,6 +165,53 @@ class Network:
             self.isl_off = self.jsl_off = self.cml_off = z
             self.isl = self.jsl = self.cml = np.zeros(1, dtype=np.uint32)
             self.net_id = np.zeros(1, dtype=np.uint32)
+
+    def _parse_clusters(self, bms):
+        """G / X / Y records -> vectors + clusters (the .bms layout of LoadVarianceMatrix_G/_X/_Y, dnaadjust.cpp:4214-4560)"""
+        stn1, stn2, obs, vcv, off = [], [], [], [], [0]
+        self.bl_of_record = {}
+        i, n = 0, len(bms)
+        while i < n:
+            t = bytes(bms["measType"][i])
+            assert t in (b"G", b"X", b"Y") and bms["measStart"][i] == 0 and not bms["ignore"][i]
+            self.bl_of_record[i] = len(off) - 1      # cml entries become cluster indices
+            k = 1 if t == b"G" else int(bms["vectorCount1"][i])
+            vs = float(bms["scale4"][i])
+            scale = vs if abs(vs - 1.0) > 1e-5 and vs >= 1e-6 else 1.0
+            V = np.zeros((3 * k, 3 * k))
+            for j in range(k):
+                r0 = 3 * j
+                obs += [float(bms["term1"][i]), float(bms["term1"][i + 1]), float(bms["term1"][i + 2])]
+                if t == b"Y":
+                    stn1.append(0xffffffff)
+                    stn2.append(int(bms["station1"][i]))
+                else:
+                    stn1.append(int(bms["station1"][i]))
+                    stn2.append(int(bms["station2"][i]))
+                V[r0, r0] = bms["term2"][i]
+                V[r0, r0 + 1] = bms["term2"][i + 1]
+                V[r0 + 1, r0 + 1] = bms["term3"][i + 1]
+                V[r0, r0 + 2] = bms["term2"][i + 2]
+                V[r0 + 1, r0 + 2] = bms["term3"][i + 2]
+                V[r0 + 2, r0 + 2] = bms["term4"][i + 2]
+                ncov = 0 if t == b"G" else int(bms["vectorCount2"][i])
+                i += 3
+                for c in range(ncov):
+                    c0 = 3 * (j + 1 + c)
+                    for r in range(3):
+                        V[r0 + r, c0:c0 + 3] = [bms["term1"][i + r], bms["term2"][i + r], bms["term3"][i + r]]
+                    i += 3
+            V = np.triu(V) + np.triu(V, 1).T
+            vcv.append((V * scale if scale != 1.0 else V).ravel(order="F"))
+            off.append(len(stn1))
+        self.n_baselines = len(stn1)
+        self.stn1 = np.asarray(stn1, dtype=np.uint32)
+        self.stn2 = np.asarray(stn2, dtype=np.uint32)
+        self.obs = np.asarray(obs, dtype=np.float64)
+        self.vcv6 = np.zeros(6 * self.n_baselines)
+        self.n_clusters = len(off) - 1
+        self.cluster_off = np.asarray(off, dtype=np.uint32)
+        self.cluster_vcv = np.ascontiguousarray(np.concatenate(vcv))
 
     @staticmethod
     def _csr(lists):
@@ -185,6 +237,9 @@ class Network:
         n.jsl_off, n.jsl = _p(self.jsl_off, u32p), _p(self.jsl, u32p)
         n.cml_off, n.cml = _p(self.cml_off, u32p), _p(self.cml, u32p)
         n.net_id = _p(self.net_id, u32p)
+        n.n_clusters = self.n_clusters
+        n.cluster_off = _p(self.cluster_off, u32p)
+        n.cluster_vcv = _p(self.cluster_vcv, f64p)
         return n
 
 

@@ -78,6 +78,33 @@ def test_parity_with_oracle(built, orc, tmp_path, rows, cols, nbl, blocks, phase
     o.close()
 
 
+@pytest.mark.parametrize("rows,cols,nbl,blocks,phased,xcl,ycl", [
+    (6, 6, 0, 1, False, 8, False),
+    (7, 6, 0, 1, False, 1000, True),     # every station's baselines one 'X' cluster + 'Y' datum
+    (12, 10, 0, 3, True, 40, True),
+    (12, 10, 250, 4, True, 1000, False),
+    (30, 30, 0, 5, True, 1000, True),
+])
+def test_gnss_cluster_parity_with_oracle(built, orc, tmp_path, rows, cols, nbl, blocks, phased, xcl, ycl):
+    """'X' baseline clusters / 'Y' point clusters with full variance matrices (LoadVarianceMatrix_X/_Y, dnaadjust.cpp:4312/4494)"""
+    adjust.write_synthetic_network(str(tmp_path), "c", rows, cols, nbl, blocks, seed=5 * rows + blocks, x_clusters=xcl, y_cluster=ycl)
+    orc.use_mkl(True)
+    try:
+        net = orc.Network(str(tmp_path / "c"), phased)
+        assert net.n_clusters > 0 and int(np.diff(net.cluster_off).max()) >= 2
+        o = orc.Adjustment(net, phased)
+        o.prepare()
+        ost = o.run()
+    finally:
+        orc.use_mkl(False)
+    a, st = _device_run(str(tmp_path), "c", phased)
+    _compare(a, st, o, ost)
+    assert a.GetMeasurementCount() == 3 * net.n_baselines
+    assert a.GetUnknownsCount() == 3 * rows * cols - (0 if ycl else 12)
+    a.close()
+    o.close()
+
+
 def test_multiple_networks_and_isolated_blocks(built, orc, tmp_path):
     specs = [("a", 8, 5, 3), ("b", 5, 5, 1), ("c", 6, 6, 2)]
     for nm, r, c, blk in specs:

@@ -121,3 +121,62 @@ def test_scale_normals_to_unity_gives_same_solution(orc, golden_dir):
         assert np.abs(a.block_estimates(k) - b.block_estimates(k)).max() < 1e-8
     a.close()
     b.close()
+
+
+def _dense_solution(net, fixed_std_dev=1e-6, free_std_dev=10.0):
+    """independent dense numpy solution of the (linear) GNSS network, iterated the way AdjustSimultaneous does
+    (the station constraints weight the normals only, so every iteration pulls towards the previous estimates):
+    x <- x + (A'WA + Wc)^-1 A'W (obs - A x) until the largest correction is below the threshold"""
+    n = 3 * net.n_stations
+    m = 3 * net.n_baselines
+    A = np.zeros((m, n))
+    for i in range(net.n_baselines):
+        for c in range(3):
+            if net.stn1[i] != 0xffffffff:
+                A[3 * i + c, 3 * int(net.stn1[i]) + c] = -1.0
+            A[3 * i + c, 3 * int(net.stn2[i]) + c] = 1.0
+    W = np.zeros((m, m))
+    voff = 0
+    for c in range(net.n_clusters):
+        i0, i1 = int(net.cluster_off[c]), int(net.cluster_off[c + 1])
+        nc = 3 * (i1 - i0)
+        V = net.cluster_vcv[voff:voff + nc * nc].reshape(nc, nc, order="F")
+        voff += nc * nc
+        W[3 * i0:3 * i1, 3 * i0:3 * i1] = np.linalg.inv(V)
+    Wc = np.zeros(n)
+    for s in range(net.n_stations):
+        cst = net.constraints[3 * s:3 * s + 3]
+        assert cst in (b"CCC", b"FFF")
+        Wc[3 * s:3 * s + 3] = 1.0 / (fixed_std_dev if cst == b"CCC" else free_std_dev) ** 2
+    N = A.T @ W @ A + np.diag(Wc)
+    x = net.xyz0.copy()
+    for _ in range(10):
+        dx = np.linalg.solve(N, A.T @ W @ (net.obs - A @ x))
+        x += dx
+        if np.abs(dx).max() < float(np.float32(0.0005)):
+            break
+    return x, np.linalg.inv(N)
+
+
+@pytest.mark.parametrize("rows,cols,blocks,xcl,ycl", [(6, 6, 1, 8, False), (7, 6, 3, 12, True), (8, 5, 4, 1000, True)])
+def test_gnss_clusters(orc, built, tmp_path, rows, cols, blocks, xcl, ycl):
+    """'X' baseline clusters and 'Y' point clusters (full 3k x 3k variance matrices, dnaadjust.cpp:4312/4494):
+    the oracle against a dense numpy solution, and phased against simultaneous."""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "c", rows, cols, 0, blocks, seed=77 + rows, x_clusters=xcl, y_cluster=ycl)
+    base = str(tmp_path / "c")
+    bms = F.read_bms(base + ".bms")
+    types = set(bytes(t) for t in bms["measType"])
+    assert b"X" in types and (b"Y" in types) == ycl
+    net, a, st = _run(orc, base, False)
+    assert st == 0 and net.n_clusters > 0 and int(np.diff(net.cluster_off).max()) >= 2
+    x, V = _dense_solution(net)
+    assert np.abs(a.block_estimates(0) - x).max() < 2e-8
+    Vo = unpack_lower(a.block_variances(0), 3 * net.n_stations)
+    assert np.abs(Vo - V).max() / np.abs(V).max() < 1e-7
+    if ycl:      # the datum comes from the point clusters (millimetre noise), not from the perturbed initial coordinates
+        truth = np.fromfile(base + ".truth", dtype=np.float64)
+        assert np.abs(a.block_estimates(0) - truth).max() < 0.05
+    a.close()
+    if blocks > 1:
+        _phased_vs_simultaneous(orc, base)
