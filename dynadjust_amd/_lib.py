@@ -32,7 +32,16 @@ class DnaAdjSettings(C.Structure):
     _fields_ = [("bst_file", C.c_char_p), ("bms_file", C.c_char_p), ("asl_file", C.c_char_p), ("seg_file", C.c_char_p),
                 ("adjust_mode", C.c_int), ("multi_thread", C.c_int), ("max_iterations", C.c_int),
                 ("iteration_threshold", C.c_float), ("free_std_dev", C.c_double), ("fixed_std_dev", C.c_double),
-                ("scale_normals_to_unity", C.c_int), ("device", C.c_int)]
+                ("scale_normals_to_unity", C.c_int), ("device", C.c_int), ("confidence_interval", C.c_float),
+                ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p)]
+
+
+class DnaAdjStatistics(C.Structure):
+    """dnaadj_statistics (include/dnaadjust_c.h)"""
+    _fields_ = [("chi_squared", C.c_double), ("sigma_zero", C.c_double), ("global_pelzer", C.c_double),
+                ("chi_upper_limit", C.c_double), ("chi_lower_limit", C.c_double), ("measurement_params", C.c_uint32),
+                ("unknown_params", C.c_uint32), ("potential_outliers", C.c_uint32), ("test_result", C.c_uint32),
+                ("degrees_of_freedom", C.c_int)]
 
 
 class DnaSynthSpec(C.Structure):
@@ -100,6 +109,7 @@ def load():
     _sig(lib, "dnagpu_block_compute_b", i, [vp, i, u32])
     _sig(lib, "dnagpu_block_get_b", i, [vp, i, u32, c_f64p])
     _sig(lib, "dnagpu_block_get_weights", i, [vp, i, u32, c_f64p])
+    _sig(lib, "dnagpu_block_msr_statistics", i, [vp, i, u32, vp, c_f64p, c_f64p])
     _sig(lib, "dnagpu_form_normals", i, [vp, i, u32, vp])
     _sig(lib, "dnagpu_add_diag3x3", i, [vp, i, vp, c_u32p, c_f64p, sz, i])
     _sig(lib, "dnagpu_form_rhs", i, [vp, i, u32])
@@ -141,6 +151,16 @@ def load():
     _sig(lib, "dnaadj_block_variances_packed", i, [vp, u32, c_f64p])
     _sig(lib, "dnaadj_adjusted_coordinates", i, [vp, c_f64p])
     _sig(lib, "dnaadj_device_context", vp, [vp])
+    _sig(lib, "dnaadj_generate_statistics", i, [vp])
+    _sig(lib, "dnaadj_get_statistics", i, [vp, C.POINTER(DnaAdjStatistics)])
+    _sig(lib, "dnaadj_measurement_record_count", u64, [vp])
+    _sig(lib, "dnaadj_measurement_records", i, [vp, vp, u64])
+    _sig(lib, "dnaadj_block_prec_adj_msrs_count", u64, [vp, u32])
+    _sig(lib, "dnaadj_block_prec_adj_msrs", i, [vp, u32, c_f64p, u64])
+    _sig(lib, "dnaadj_serialise_adjusted_variance_matrices", i, [vp])
+    _sig(lib, "dnaadj_update_binary_files", i, [vp])
+    _sig(lib, "dnastat_normal_quantile", C.c_double, [C.c_double])
+    _sig(lib, "dnastat_chi_squared_quantile", C.c_double, [C.c_double, C.c_double])
     ip = C.POINTER(C.c_int)
     dp = C.POINTER(C.c_double)
     _sig(lib, "dnaadj_block_flags", i, [vp, u32, ip, ip, ip])
@@ -175,7 +195,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
-    "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
+    "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
     "dnagpu_junction_gather", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
@@ -187,6 +207,9 @@ EXPORTED_DNAADJ = [
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
+    "dnaadj_generate_statistics", "dnaadj_get_statistics", "dnaadj_measurement_record_count", "dnaadj_measurement_records",
+    "dnaadj_block_prec_adj_msrs_count", "dnaadj_block_prec_adj_msrs", "dnaadj_serialise_adjusted_variance_matrices",
+    "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",
     "dnaadj_block_flags", "dnaadj_junction_unknowns", "dnaadj_junction_payload_doubles", "dnaadj_phased_begin_iteration",
     "dnaadj_phased_forward_block", "dnaadj_phased_reverse_block", "dnaadj_phased_combine_block", "dnaadj_phased_finalise_block",
     "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_junction_export",

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import DnaAdjSettings, DnaSynthSpec, DnaSynthSummary, c_f64p, c_u32p
+from ._lib import DnaAdjSettings, DnaAdjStatistics, DnaSynthSpec, DnaSynthSummary, c_f64p, c_u32p
 
 SimultaneousMode = 0
 PhasedMode = 1
@@ -32,8 +32,12 @@ class ProjectSettings:
 
     def __init__(self, network_name=None, folder=".", adjust_mode=SimultaneousMode, multi_thread=False,
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
-                 scale_normals_to_unity=False, device=0):
+                 scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
+        self.network_name = network_name          # g.network_name
+        self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
+        self.confidence_interval = confidence_interval
+        self.output_tstat = output_tstat          # o._adj_msr_tstat
         if network_name is not None:
             self.set_filenames(os.path.join(folder, network_name))
         self.adjust_mode = adjust_mode
@@ -85,8 +89,11 @@ class DnaAdjust:
     def PrepareAdjustment(self, p):
         s = DnaAdjSettings()
         self.lib.dnaadj_default_settings(C.byref(s))
-        self._keep = [_b(p.bst_file), _b(p.bms_file), _b(p.asl_file), _b(p.seg_file)]
-        s.bst_file, s.bms_file, s.asl_file, s.seg_file = self._keep
+        self._keep = [_b(p.bst_file), _b(p.bms_file), _b(p.asl_file), _b(p.seg_file), _b(getattr(p, "network_name", None)),
+                      _b(getattr(p, "output_folder", None))]
+        s.bst_file, s.bms_file, s.asl_file, s.seg_file, s.network_name, s.output_folder = self._keep
+        s.confidence_interval = float(getattr(p, "confidence_interval", 95.0))
+        s.output_tstat = int(bool(getattr(p, "output_tstat", False)))
         s.adjust_mode = int(p.adjust_mode)
         s.multi_thread = int(bool(p.multi_thread))
         s.max_iterations = int(p.max_iterations)
@@ -134,7 +141,59 @@ class DnaAdjust:
         """milliseconds spent inside AdjustNetwork()"""
         return self.lib.dnaadj_adjust_time_ms(self.h)
 
+    def GenerateStatistics(self):
+        """dna_adjust::GenerateStatistics (dnaadjust.cpp:6802)"""
+        self._chk(self.lib.dnaadj_generate_statistics(self.h))
+
+    def _stats(self):
+        st = DnaAdjStatistics()
+        self._chk(self.lib.dnaadj_get_statistics(self.h, C.byref(st)))
+        return st
+
+    def GetChiSquared(self):
+        return self._stats().chi_squared
+
+    def GetSigmaZero(self):
+        return self._stats().sigma_zero
+
+    def GetGlobalPelzerRel(self):
+        return self._stats().global_pelzer
+
+    def GetChiSquaredUpperLimit(self):
+        return self._stats().chi_upper_limit
+
+    def GetChiSquaredLowerLimit(self):
+        return self._stats().chi_lower_limit
+
+    def GetPotentialOutlierCount(self):
+        return self._stats().potential_outliers
+
+    def GetTestResult(self):
+        return self._stats().test_result
+
+    def SerialiseAdjustedVarianceMatrices(self):
+        """<output_folder>/<network_name>-rva.mtx and -pam.mtx (dnaadjust.cpp:6770)"""
+        self._chk(self.lib.dnaadj_serialise_adjusted_variance_matrices(self.h))
+
+    def UpdateBinaryFiles(self):
+        """rewrites the .bst / .bms with the adjusted values (dnaadjust.cpp:445)"""
+        self._chk(self.lib.dnaadj_update_binary_files(self.h))
+
     # ---- results ---------------------------------------------------------------
+    def measurement_records(self):
+        """the measurement_t records held by the adjustment, as raw 208-byte records (numpy uint8 [n, 208])"""
+        n = self.lib.dnaadj_measurement_record_count(self.h)
+        out = np.zeros((n, 208), dtype=np.uint8)
+        self._chk(self.lib.dnaadj_measurement_records(self.h, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
+    def block_prec_adj_msrs(self, block):
+        n = self.lib.dnaadj_block_prec_adj_msrs_count(self.h, block)
+        out = np.zeros(n, dtype=np.float64)
+        if n:
+            self._chk(self.lib.dnaadj_block_prec_adj_msrs(self.h, block, out.ctypes.data_as(c_f64p), n))
+        return out
+
     def block_stations(self, block):
         n = self.lib.dnaadj_block_station_count(self.h, block)
         out = np.empty(n, dtype=np.uint32)

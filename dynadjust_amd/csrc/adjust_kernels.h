@@ -13,6 +13,9 @@ void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint3
 void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s);
 void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const double* b, double* wb,
                      uint32_t n_vec, const uint32_t* ioff, const uint32_t* inc, double* rhs, uint32_t n_stn, hipStream_t s);
+void launch_msr_stats(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const uint32_t* s1,
+                      const uint32_t* s2, const double* b, double* wb, const double* S, uint32_t nps, double* prec6, double* chi, uint32_t n_vec,
+                      hipStream_t s);
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s);
 void launch_junction_gather(const double* S, uint32_t nps, const uint32_t* idx, uint32_t k, double* J, uint32_t npj, hipStream_t s);
 void launch_gather_vec3(const double* x, const uint32_t* idx, uint32_t k, double* out, hipStream_t s);

@@ -139,6 +139,35 @@ __global__ void cluster_wb_kernel(const double* __restrict__ wblk, const uint32_
     wb[t] = acc;
 }
 
+// Post-adjustment statistics per GNSS vector (ComputePrecisionAdjMsrs_GX/_Y ADJ:8009/8037 + the chi-square terms of
+// ComputeChiSquare_G/_XY ADJ:8530/8551).  One thread per vector:
+//   prec6 = upper triangle (xx xy xz yy yz zz) of A S A^T with S = rigorous variances: (S22 - S12) - (S21 - S11) for a
+//           baseline (Precision_Adjusted_GNSS_bsl, dnatemplatematrixfuncs.hpp:255), S22 for a point;
+//   chi   = b . (W b) restricted to the vector's three rows (W b from cluster_wb_kernel).
+// S is read from its lower triangle only, so the result does not depend on how the upper triangle was filled.
+__global__ void msr_stats_kernel(const uint32_t* __restrict__ s1, const uint32_t* __restrict__ s2, const double* __restrict__ b,
+                                 const double* __restrict__ wb, const double* __restrict__ S, uint32_t nps, double* __restrict__ prec6,
+                                 double* __restrict__ chi, uint32_t n_vec) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vec) return;
+    const double* bb = b + (size_t)v * 3;
+    const double* ww = wb + (size_t)v * 3;
+    chi[v] = (bb[0] * ww[0] + bb[1] * ww[1]) + bb[2] * ww[2];
+    if (!S) return;
+    auto sym = [&](uint32_t r, uint32_t c) { return r >= c ? S[(size_t)c * nps + r] : S[(size_t)r * nps + c]; };
+    const uint32_t a = s1[v], e = 3 * s2[v];
+    int q = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j, ++q) {
+            double p = sym(e + i, e + j);
+            if (a != 0xffffffffu) {
+                const uint32_t f = 3 * a;
+                p = (p - sym(f + i, e + j)) - (sym(e + i, f + j) - sym(f + i, f + j));
+            }
+            prec6[(size_t)v * 6 + q] = p;
+        }
+}
+
 // rhs(3s+c) = sum over incident vectors (CML order) of +-(W b)_c
 __global__ void form_rhs_kernel(const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ inc, const double* __restrict__ wb,
                                 double* __restrict__ rhs, uint32_t n_stn) {
@@ -266,6 +295,13 @@ void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_
     if (n_vec) hipLaunchKernelGGL(cluster_wb_kernel, dim3((n_vec * 3 + 255) / 256), dim3(256), 0, s, wblk, vec_wrow, vec_c0, vec_k, b, wb, n_vec);
     if (!n_stn) return;
     hipLaunchKernelGGL(form_rhs_kernel, dim3((n_stn * 3 + 255) / 256), dim3(256), 0, s, ioff, inc, wb, rhs, n_stn);
+}
+void launch_msr_stats(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const uint32_t* s1,
+                      const uint32_t* s2, const double* b, double* wb, const double* S, uint32_t nps, double* prec6, double* chi, uint32_t n_vec,
+                      hipStream_t s) {
+    if (!n_vec) return;
+    hipLaunchKernelGGL(cluster_wb_kernel, dim3((n_vec * 3 + 255) / 256), dim3(256), 0, s, wblk, vec_wrow, vec_c0, vec_k, b, wb, n_vec);
+    hipLaunchKernelGGL(msr_stats_kernel, dim3((n_vec + 255) / 256), dim3(256), 0, s, s1, s2, b, wb, S, nps, prec6, chi, n_vec);
 }
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s) {
     hipLaunchKernelGGL(update_estimates_kernel, dim3(1), dim3(1024), 0, s, xe, corr, n, out_val, out_idx);

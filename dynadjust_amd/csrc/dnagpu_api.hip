@@ -775,6 +775,25 @@ int dnagpu_block_get_weights(dnagpu_ctx* ctx, int chain, uint32_t blk, double* w
     return d2h(ctx, chain, w6, ctx->scr_f64[chain], (size_t)b->n_bl * 6 * sizeof(double));
 }
 
+int dnagpu_block_msr_statistics(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* variances, double* prec6, double* chi) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || (b->n_bl && !chi) || (variances && (variances->n != 3 * b->n_stn || !prec6)))
+        return fail(ctx, DNAGPU_EINVAL, "block_msr_statistics: bad arguments");
+    if (!b->n_bl) return DNAGPU_OK;
+    int rc = ensure_scr_f64(ctx, chain, (size_t)b->n_bl * 7);
+    if (rc) return rc;
+    double* dprec = ctx->scr_f64[chain];
+    double* dchi = dprec + (size_t)b->n_bl * 6;
+    launch_msr_stats(b->Wblk, b->vec_wrow, b->vec_c0, b->vec_k, b->s1, b->s2, b->b[chain], b->wb[chain], variances ? variances->F : nullptr,
+                     variances ? variances->np : 0, dprec, dchi, b->n_bl, ctx->stream[chain]);
+    if (variances) {
+        HIPCHK(hipMemcpyAsync(prec6, dprec, (size_t)b->n_bl * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
+    }
+    return d2h(ctx, chain, chi, dchi, (size_t)b->n_bl * sizeof(double));
+}
+
 int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, double* corr) {
     CHK_CTX();
     CHK_CHAIN();

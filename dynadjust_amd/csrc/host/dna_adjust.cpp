@@ -1,10 +1,12 @@
 #include "dna_adjust.hpp"
+#include "statfuncs.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <sstream>
 
 #include "geodesy.hpp"
@@ -271,10 +273,11 @@ void dna_adjust::ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B) {
     const double tiny = std::min(PRECISION_1E5, projectSettings_.a.fixed_std_dev);
     double vScale = first.scale4;
     if (vScale < tiny) vScale = 1.0;
-    const bool scaleMatrix = std::fabs(vScale - 1.0) > PRECISION_1E5;
+    // a "reduced" .bms was written by an earlier adjustment: its variances are already scaled (ADJ:4190-4211)
+    const bool scaleMatrix = !bms_meta_.reduced && std::fabs(vScale - 1.0) > PRECISION_1E5;
     auto unit = [&](double s) { return s < tiny ? 1.0 : s; };
-    if (std::fabs(unit(first.scale1) - 1.0) > PRECISION_1E5 || std::fabs(unit(first.scale2) - 1.0) > PRECISION_1E5 ||
-        std::fabs(unit(first.scale3) - 1.0) > PRECISION_1E5)
+    if (!bms_meta_.reduced && (std::fabs(unit(first.scale1) - 1.0) > PRECISION_1E5 || std::fabs(unit(first.scale2) - 1.0) > PRECISION_1E5 ||
+        std::fabs(unit(first.scale3) - 1.0) > PRECISION_1E5))
         SignalExceptionAdjustment("LoadVarianceScaling(): phi/lambda/height variance scalars are not handled by the device path yet.", block);
     const UINT32 k = (type == 'G') ? 1 : first.vectorCount1;
     if (k == 0) SignalExceptionAdjustment("PrepareAdjustment(): a GNSS cluster without vectors.", block);
@@ -321,6 +324,35 @@ void dna_adjust::ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B) {
                 put(r0 + r, c0 + 2, cv.term3);
             }
             idx += 3;
+        }
+    }
+    if (scaleMatrix) {
+        // SetGPSVarianceMatrix (ADJ:4282): the scaled variances replace the ones held in memory, so that the
+        // statistics (sigma zero, Pelzer reliability, ...) see what the adjustment used
+        size_t r = m;
+        for (UINT32 j = 0; j < k; ++j) {
+            const UINT32 r0 = 3 * j;
+            measurement_t& mx = bmsBinaryRecords_[r];
+            measurement_t& my = bmsBinaryRecords_[r + 1];
+            measurement_t& mz = bmsBinaryRecords_[r + 2];
+            const UINT32 ncov = (type == 'G') ? 0 : mx.vectorCount2;
+            mx.term2 = V[(size_t)r0 * nc + r0];
+            my.term2 = V[(size_t)(r0 + 1) * nc + r0];
+            my.term3 = V[(size_t)(r0 + 1) * nc + r0 + 1];
+            mz.term2 = V[(size_t)(r0 + 2) * nc + r0];
+            mz.term3 = V[(size_t)(r0 + 2) * nc + r0 + 1];
+            mz.term4 = V[(size_t)(r0 + 2) * nc + r0 + 2];
+            r += 3;
+            for (UINT32 c = 0; c < ncov; ++c) {
+                const UINT32 c0 = 3 * (j + 1 + c);
+                for (UINT32 e = 0; e < 3; ++e) {
+                    measurement_t& cv = bmsBinaryRecords_[r + e];
+                    cv.term1 = V[(size_t)c0 * nc + r0 + e];
+                    cv.term2 = V[(size_t)(c0 + 1) * nc + r0 + e];
+                    cv.term3 = V[(size_t)(c0 + 2) * nc + r0 + e];
+                }
+                r += 3;
+            }
         }
     }
     B.vcv.insert(B.vcv.end(), V.begin(), V.end());
@@ -550,7 +582,6 @@ void dna_adjust::ValidateandFinaliseAdjustment() {
 
 // ADJ:473-627: new meas-minus-computed from the latest estimates; the GNSS normals do not change
 void dna_adjust::UpdateAdjustment(bool iterate) {
-    (void)iterate;
     isPreparing_ = true;
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
     const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
@@ -568,6 +599,8 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
             Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
         }
     }
+    // no further iterations: the station records take the adjusted coordinates (ADJ:496-531, ADJ:541-545)
+    if (!iterate && !IsCancelled()) UpdateGeographicCoords();
     isPreparing_ = false;
 }
 
@@ -645,9 +678,204 @@ void dna_adjust::ResetAdjustment() {
     adjustStatus_ = ADJUST_SUCCESS;
 }
 
-void dna_adjust::GenerateStatistics() {}
-void dna_adjust::SerialiseAdjustedVarianceMatrices() {}
-void dna_adjust::UpdateBinaryFiles() {}
+// ADJ:6802-6841: UpdateAdjustment(false) + ComputeStatistics()
+void dna_adjust::GenerateStatistics() {
+    if (!ctx_) SignalExceptionAdjustment("GenerateStatistics(): PrepareAdjustment() has not been called.", 0);
+    // meas-minus-computed from the final estimates; the inverses are kept (ADJ:549-557)
+    UpdateAdjustment(false);
+    ComputeStatistics();
+    isAdjustmentQuestionable_ = adjustStatus_ != ADJUST_SUCCESS || sigmaZero_ > 10.0 * chiSquaredUpperLimit_ ||
+                                std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
+}
+
+// ADJ:7116-7147 for GNSS measurements.  The per-vector gathers from the rigorous variances (still resident in HBM)
+// and the W.b products run on the device (dnagpu_block_msr_statistics); the O(measurements) scalar bookkeeping of
+// UpdateMsrRecord (ADJ:8187) happens here on the records held in memory.
+void dna_adjust::ComputeStatistics() {
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
+    // critical value of the normal distribution for the outlier flag (InitialiseAdjustment, ADJ:203-206)
+    double conf = projectSettings_.a.confidence_interval * 0.01;
+    conf += (1.0 - conf) / 2.0;
+    criticalValue_ = stat::normal_quantile(conf);
+    potentialOutlierCount_ = 0;
+    double chiSquared = 0.0;
+    std::vector<double> prec6, chi, bvec;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        block_t& B = blocks_[b];
+        const size_t nv = B.stn1.size();
+        dnagpu_matrix* var = phased ? (B.has_rigvar ? B.rigvar : nullptr) : work_[0];
+        if (!var) SignalExceptionAdjustment("ComputePrecisionAdjMsrs(): this process holds no rigorous variances for the block.", b);
+        prec6.assign(6 * nv + 1, 0.0);
+        chi.assign(nv + 1, 0.0);
+        bvec.assign(3 * nv + 1, 0.0);
+        Check(dnagpu_block_msr_statistics(ctx_, 0, b, var, prec6.data(), chi.data()), b, "ComputePrecisionAdjMsrs()");
+        Check(dnagpu_block_get_b(ctx_, 0, b, bvec.data()), b, "UpdateMsrRecords()");
+        B.prec_adj_msrs.assign(prec6.begin(), prec6.begin() + 6 * nv);            // v_precAdjMsrsFull_ (ADJ:7792)
+        // UpdateMsrRecords (ADJ:8083) -> UpdateMsrRecords_GXY (ADJ:8152)
+        size_t v = 0;
+        for (UINT32 m : v_CML_[b]) {
+            if (bmsBinaryRecords_[m].ignore || bmsBinaryRecords_[m].measStart != 0) continue;
+            const char type = bmsBinaryRecords_[m].measType;
+            const UINT32 k = (type == 'G') ? 1 : bmsBinaryRecords_[m].vectorCount1;
+            size_t r = m;
+            for (UINT32 j = 0; j < k; ++j, ++v) {
+                const UINT32 ncov = (type == 'G') ? 0 : bmsBinaryRecords_[r].vectorCount2;
+                static const int diag6[3] = {0, 3, 5};
+                for (int e = 0; e < 3; ++e) {
+                    measurement_t& rec = bmsBinaryRecords_[r + e];
+                    const double measPrec = e == 0 ? rec.term2 : (e == 1 ? rec.term3 : rec.term4);
+                    UpdateMsrRecord(rec, -bvec[3 * v + e], prec6[6 * v + diag6[e]], measPrec);
+                }
+                r += 3 + 3 * (size_t)ncov;
+            }
+        }
+        // ComputeChiSquare (ADJ:7257): the per-vector terms b.(W b) summed in CML order
+        double cs = 0.0;
+        for (size_t i = 0; i < nv; ++i) cs += chi[i];
+        chiSquared += cs;
+    }
+    chiSquared_ = chiSquared;                                                        // ComputeChiSquareNetwork (ADJ:7315)
+    // ComputeGlobalNetStat (ADJ:6854)
+    degreesofFreedom_ = (int)measurementParams_ - (int)unknownParams_;
+    sigmaZero_ = sigmaZeroSqRt_ = 0.0;
+    if (degreesofFreedom_ != 0) {
+        sigmaZero_ = chiSquared_ / degreesofFreedom_;
+        sigmaZeroSqRt_ = std::sqrt(sigmaZero_);
+    }
+    // ComputeTstatistics (ADJ:7094) -> UpdateMsrTstatistic_GXY (ADJ:7019)
+    if (projectSettings_.o._adj_msr_tstat)
+        ForEachMeasurementComponent([&](measurement_t& rec) {
+            rec.TStat = std::fabs(sigmaZeroSqRt_ - 0.0) < PRECISION_1E10 ? 0.0 : rec.NStat / sigmaZeroSqRt_;
+        });
+    // ComputeGlobalPelzer (ADJ:8302) -> _GXY (ADJ:8396)
+    double sum = 0.0;
+    UINT32 numMsr = 0;
+    ForEachMeasurementComponent([&](measurement_t& rec) {
+        if (rec.PelzerRel > 0.0 && rec.PelzerRel < UNRELIABLE) {
+            sum += (rec.PelzerRel * rec.PelzerRel - 1.0);
+            numMsr++;
+        } else
+            rec.PelzerRel = UNRELIABLE;
+    });
+    globalPelzerReliability_ = numMsr > 0 ? std::sqrt(sum / numMsr) : UNRELIABLE;
+    // ComputeGlobalTestStat (ADJ:6914) -> ComputeTestStat (ADJ:6866)
+    const double half = (100.0 - projectSettings_.a.confidence_interval) * 0.01 * 0.5;
+    if (degreesofFreedom_ > 0) {
+        chiSquaredUpperLimit_ = stat::chi_squared_quantile(degreesofFreedom_, 1.0 - half) / degreesofFreedom_;
+        chiSquaredLowerLimit_ = stat::chi_squared_quantile(degreesofFreedom_, half) / degreesofFreedom_;
+        if (phased) sigmaZero_ = chiSquared_ / degreesofFreedom_;
+        if (sigmaZero_ < chiSquaredLowerLimit_)
+            passFail_ = test_stat_warning;
+        else if (sigmaZero_ > chiSquaredUpperLimit_)
+            passFail_ = test_stat_fail;
+        else
+            passFail_ = test_stat_pass;
+    } else {
+        // boost::math::chi_squared throws for zero degrees of freedom; the reference reports a failed test (ADJ:6894-6908)
+        passFail_ = test_stat_fail;
+    }
+}
+
+// UpdateMsrRecord (ADJ:8187) + UpdateMsrRecordStats (ADJ:8291) for one X / Y / Z element of a GNSS measurement
+void dna_adjust::UpdateMsrRecord(measurement_t& rec, double measCorr, double measAdjPrec, double measPrec) {
+    rec.measCorr = measCorr;
+    rec.measAdj = rec.term1 + rec.measCorr;
+    rec.measAdjPrec = measAdjPrec;
+    rec.residualPrec = measPrec - rec.measAdjPrec;
+    if (rec.residualPrec < 0.0) rec.residualPrec = std::fabs(rec.residualPrec);
+    rec.PelzerRel = std::sqrt(measPrec) / std::sqrt(rec.residualPrec);
+    if (rec.PelzerRel < 0.0 || rec.PelzerRel > STABLE_LIMIT) rec.PelzerRel = UNRELIABLE;
+    rec.NStat = rec.measCorr / std::sqrt(rec.residualPrec);
+    if (std::fabs(rec.NStat) > criticalValue_) potentialOutlierCount_++;
+}
+
+// visits the X, Y, Z records of every GNSS vector, block by block in CML order
+void dna_adjust::ForEachMeasurementComponent(const std::function<void(measurement_t&)>& fn) {
+    for (UINT32 b = 0; b < blockCount_; ++b)
+        for (UINT32 m : v_CML_[b]) {
+            if (bmsBinaryRecords_[m].ignore || bmsBinaryRecords_[m].measStart != 0) continue;
+            const char type = bmsBinaryRecords_[m].measType;
+            const UINT32 k = (type == 'G') ? 1 : bmsBinaryRecords_[m].vectorCount1;
+            size_t r = m;
+            for (UINT32 j = 0; j < k; ++j) {
+                const UINT32 ncov = (type == 'G') ? 0 : bmsBinaryRecords_[r].vectorCount2;
+                for (int e = 0; e < 3; ++e) fn(bmsBinaryRecords_[r + e]);
+                r += 3 + 3 * (size_t)ncov;
+            }
+        }
+}
+// UpdateGeographicCoords (ADJ:8734) / UpdateGeographicCoordsPhased (ADJ:8711): the station records take the
+// adjusted coordinates (each station once, from the block of its first appearance)
+void dna_adjust::UpdateGeographicCoords() {
+    std::vector<double> bx;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        GetBlockStations(b, 1, bx);
+        for (size_t p = 0; p < v_parameterStationList_[b].size(); ++p) {
+            if (!v_paramStnAppearance_[b][p].first_appearance_fwd) continue;
+            station_t& st = bstBinaryRecords_[v_parameterStationList_[b][p]];
+            geodesy::CartToGeo(bx[3 * p], bx[3 * p + 1], bx[3 * p + 2], &st.currentLatitude, &st.currentLongitude, &st.currentHeight);
+        }
+    }
+}
+
+namespace {
+// matrix_2d binary stream layout (include/math/dnamatrix_contiguous.cpp:39-91): type, rows, cols, mem_rows, mem_cols,
+// pad, data, maxvalRow, maxvalCol
+void write_mtx_header(std::ofstream& f, UINT32 type, UINT32 rows, UINT32 cols) {
+    const UINT32 hdr[6] = {type, rows, cols, rows, cols, 0};
+    f.write(reinterpret_cast<const char*>(hdr), sizeof(hdr));
+}
+void write_mtx_trailer(std::ofstream& f) {
+    const UINT32 maxval[2] = {0, 0};
+    f.write(reinterpret_cast<const char*>(maxval), sizeof(maxval));
+}
+}  // namespace
+
+// ADJ:6770-6799: <network>-rva.mtx (rigorous variances, one lower-triangular matrix per block, columns left to right)
+// and <network>-pam.mtx (precisions of adjusted measurements, one column vector per block), the files that
+// `dnaadjust --report-results` and the printers of the reference read back (ADJ:6720-6767)
+void dna_adjust::SerialiseAdjustedVarianceMatrices() {
+    if (!ctx_) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): PrepareAdjustment() has not been called.", 0);
+    const std::string folder = projectSettings_.a.stage_path.empty() ? projectSettings_.g.output_folder : projectSettings_.a.stage_path;
+    const std::string base = folder + "/" + projectSettings_.g.network_name + "-";
+    std::ofstream rva(base + "rva.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
+    std::ofstream pam(base + "pam.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
+    if (!rva || !pam) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): cannot create " + base + "rva.mtx / pam.mtx", 0);
+    std::vector<double> packed;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        GetBlockRigorousVariancesPacked(b, packed);
+        const UINT32 n = (UINT32)v_parameterStationList_[b].size() * 3;
+        write_mtx_header(rva, 1 /* mtx_lower */, n, n);
+        rva.write(reinterpret_cast<const char*>(packed.data()), (std::streamsize)(packed.size() * sizeof(double)));
+        write_mtx_trailer(rva);
+        const std::vector<double>& prec = blocks_[b].prec_adj_msrs;
+        const UINT32 rows = (UINT32)(6 * blocks_[b].stn1.size());   // v_measurementVarianceCount_ (ADJ:10513-10560)
+        write_mtx_header(pam, 0 /* mtx_full */, rows, 1);
+        if (prec.size() == rows)
+            pam.write(reinterpret_cast<const char*>(prec.data()), (std::streamsize)(prec.size() * sizeof(double)));
+        else {
+            std::vector<double> zeros(rows, 0.0);   // GenerateStatistics() has not run: redim'd and zeroed (ADJ:938)
+            pam.write(reinterpret_cast<const char*>(zeros.data()), (std::streamsize)(zeros.size() * sizeof(double)));
+        }
+        write_mtx_trailer(pam);
+    }
+    if (!rva || !pam) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): write failed", 0);
+}
+
+// ADJ:445-470: the station and measurement records (adjusted coordinates, adjusted measurements and their
+// statistics, scaled variances) go back to the .bst / .bms files, flagged as reduced
+void dna_adjust::UpdateBinaryFiles() {
+    try {
+        snprintf(bst_meta_.modifiedBy, sizeof(bst_meta_.modifiedBy), "%s", "dnaadjust");
+        bst_meta_.reduced = true;
+        iostreams::write_bst(projectSettings_.a.bst_file, bstBinaryRecords_, bst_meta_, "dnaadjust");
+        snprintf(bms_meta_.modifiedBy, sizeof(bms_meta_.modifiedBy), "%s", "dnaadjust");
+        bms_meta_.reduced = true;
+        iostreams::write_bms(projectSettings_.a.bms_file, bmsBinaryRecords_, bms_meta_, "dnaadjust");
+    } catch (const std::runtime_error& e) {
+        SignalExceptionAdjustment(e.what(), 0);
+    }
+}
 
 }  // namespace networkadjust
 }  // namespace dynadjust

@@ -5,6 +5,7 @@
 // (include/dnagpu.h); this class only schedules blocks and keeps host-side metadata.
 #pragma once
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -68,6 +69,12 @@ public:
     inline int GetDegreesOfFreedom() const { return degreesofFreedom_; }
     inline double GetChiSquared() const { return chiSquared_; }
     inline double GetSigmaZero() const { return sigmaZero_; }
+    inline UINT32 GetPotentialOutlierCount() const { return potentialOutlierCount_; }     // dnaadjust.hpp:341
+    inline double GetChiSquaredUpperLimit() const { return chiSquaredUpperLimit_; }       // dnaadjust.hpp:344
+    inline double GetChiSquaredLowerLimit() const { return chiSquaredLowerLimit_; }       // dnaadjust.hpp:347
+    inline double GetGlobalPelzerRel() const { return globalPelzerReliability_; }         // dnaadjust.hpp:350
+    inline UINT32 GetTestResult() const { return passFail_; }                             // dnaadjust.hpp:353
+    inline bool IsAdjustmentQuestionable() const { return isAdjustmentQuestionable_; }
     inline bool GetAllFixed() const { return allStationsFixed_; }
     inline bool ExceptionRaised() const { return exceptionRaised_; }
     inline double adjustTime() const { return adjust_ms_; }
@@ -84,6 +91,10 @@ public:
     void GetBlockRigorousVariancesPacked(UINT32 block, std::vector<double>& packed);
     // network-wide rigorous coordinates (3 per bst station; stations never adjusted keep their input value)
     void GetAdjustedCoordinates(std::vector<double>& xyz);
+    // measurement records as GenerateStatistics() left them (measAdj, measCorr, measAdjPrec, residualPrec, NStat, TStat, PelzerRel)
+    const std::vector<measurement_t>& GetMeasurementRecords() const { return bmsBinaryRecords_; }
+    // v_precAdjMsrsFull_ of a block: 6 values (xx xy xz yy yz zz) per GNSS vector in CML order
+    const std::vector<double>& GetBlockPrecAdjMsrs(UINT32 block) const { return blocks_.at(block).prec_adj_msrs; }
 
     // ---- measurement helpers (not in the reference) ---------------------------------------
     // put every block back to its state right after PrepareAdjustment (initial coordinates, fresh
@@ -111,6 +122,7 @@ private:
         dnagpu_matrix* jrev = nullptr;        // v_junctionVariances_ (reverse) + v_junctionEstimatesRev_
         dnagpu_matrix* rigvar = nullptr;      // v_rigorousVariances_
         bool has_rigvar = false;
+        std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_
     };
 
     void LoadNetworkFiles();
@@ -154,6 +166,10 @@ public:
     void SetBlockStationsAll(UINT32 k, const double* xyz);        // original = estimated (all chains) = rigorous
     void RecomputeMeasMinusComp(UINT32 k);
 private:
+    void ComputeStatistics();            // ADJ:7116
+    void UpdateGeographicCoords();       // ADJ:8711 / ADJ:8734
+    void UpdateMsrRecord(measurement_t& rec, double measCorr, double measAdjPrec, double measPrec);   // ADJ:8187
+    void ForEachMeasurementComponent(const std::function<void(measurement_t&)>& fn);
     void UpdateAdjustment(bool iterate); // ADJ:473
     void ValidateandFinaliseAdjustment();// ADJ:2513
 
@@ -191,7 +207,10 @@ private:
     _ADJUST_STATUS_ adjustStatus_ = ADJUST_SUCCESS;
     UINT32 measurementParams_ = 0, unknownParams_ = 0, unknownsCount_ = 0;
     int degreesofFreedom_ = 0;
-    double maxCorr_ = 0.0, chiSquared_ = 0.0, sigmaZero_ = 0.0;
+    double maxCorr_ = 0.0, chiSquared_ = 0.0, sigmaZero_ = 0.0, sigmaZeroSqRt_ = 0.0;
+    double chiSquaredUpperLimit_ = 0.0, chiSquaredLowerLimit_ = 0.0, globalPelzerReliability_ = 0.0, criticalValue_ = 1.68;
+    UINT32 potentialOutlierCount_ = 0, passFail_ = test_stat_pass;
+    bool isAdjustmentQuestionable_ = false;
     double var_C_ = 0.0, var_F_ = 0.0;
     std::vector<double> iterationCorrections_;
     double adjust_ms_ = 0.0;

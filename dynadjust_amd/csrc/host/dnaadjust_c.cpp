@@ -7,6 +7,7 @@
 
 #include "dna_adjust.hpp"
 #include "dnaio.hpp"
+#include "statfuncs.hpp"
 #include "synth.hpp"
 
 using dynadjust::networkadjust::dna_adjust;
@@ -43,6 +44,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->iteration_threshold = 0.0005f;
     s->free_std_dev = 10.0;
     s->fixed_std_dev = 1.0e-6;
+    s->confidence_interval = 95.0f;
 }
 
 int dnaadj_create(dnaadj_handle** out) {
@@ -82,6 +84,10 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         p.a.fixed_std_dev = s->fixed_std_dev;
         p.a.scale_normals_to_unity = (uint16_t)(s->scale_normals_to_unity ? 1 : 0);
         p.a.device = s->device;
+        if (s->confidence_interval > 0.0f) p.a.confidence_interval = s->confidence_interval;
+        p.o._adj_msr_tstat = (uint16_t)(s->output_tstat ? 1 : 0);
+        if (s->network_name) p.g.network_name = s->network_name;
+        if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);
     });
 }
@@ -100,6 +106,60 @@ int dnaadj_reset(dnaadj_handle* h) {
 int dnaadj_cancel(dnaadj_handle* h) {
     return guarded(h, [&] { h->adj->CancelAdjustment(); });
 }
+
+int dnaadj_generate_statistics(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->GenerateStatistics(); });
+}
+
+int dnaadj_get_statistics(const dnaadj_handle* h, dnaadj_statistics* out) {
+    if (!h || !h->adj || !out) return DNAADJ_EINVAL;
+    const dna_adjust& a = *h->adj;
+    out->chi_squared = a.GetChiSquared();
+    out->sigma_zero = a.GetSigmaZero();
+    out->global_pelzer = a.GetGlobalPelzerRel();
+    out->chi_upper_limit = a.GetChiSquaredUpperLimit();
+    out->chi_lower_limit = a.GetChiSquaredLowerLimit();
+    out->measurement_params = a.GetMeasurementCount();
+    out->unknown_params = a.GetUnknownsCount();
+    out->potential_outliers = a.GetPotentialOutlierCount();
+    out->test_result = a.GetTestResult();
+    out->degrees_of_freedom = a.GetDegreesOfFreedom();
+    return DNAADJ_OK;
+}
+
+uint64_t dnaadj_measurement_record_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetMeasurementRecords().size() : 0; }
+
+int dnaadj_measurement_records(const dnaadj_handle* h, void* records, uint64_t cap_records) {
+    if (!h || !h->adj || !records) return DNAADJ_EINVAL;
+    const auto& r = h->adj->GetMeasurementRecords();
+    if (cap_records < r.size()) return DNAADJ_EINVAL;
+    if (!r.empty()) memcpy(records, r.data(), r.size() * sizeof(r[0]));
+    return DNAADJ_OK;
+}
+
+uint64_t dnaadj_block_prec_adj_msrs_count(const dnaadj_handle* h, uint32_t block) {
+    if (!h || !h->adj || block >= h->adj->blockCount()) return 0;
+    return h->adj->GetBlockPrecAdjMsrs(block).size();
+}
+
+int dnaadj_block_prec_adj_msrs(const dnaadj_handle* h, uint32_t block, double* out, uint64_t cap) {
+    if (!h || !h->adj || block >= h->adj->blockCount() || !out) return DNAADJ_EINVAL;
+    const auto& p = h->adj->GetBlockPrecAdjMsrs(block);
+    if (cap < p.size()) return DNAADJ_EINVAL;
+    if (!p.empty()) memcpy(out, p.data(), p.size() * sizeof(double));
+    return DNAADJ_OK;
+}
+
+int dnaadj_serialise_adjusted_variance_matrices(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->SerialiseAdjustedVarianceMatrices(); });
+}
+
+int dnaadj_update_binary_files(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->UpdateBinaryFiles(); });
+}
+
+double dnastat_normal_quantile(double p) { return dynadjust::stat::normal_quantile(p); }
+double dnastat_chi_squared_quantile(double dof, double p) { return dynadjust::stat::chi_squared_quantile(dof, p); }
 
 uint32_t dnaadj_block_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->blockCount() : 0; }
 uint32_t dnaadj_iterations(const dnaadj_handle* h) { return h && h->adj ? h->adj->CurrentIteration() : 0; }

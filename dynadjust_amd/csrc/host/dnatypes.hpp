@@ -151,6 +151,14 @@ struct stn_appear {
 // include/config/dnaoptions.hpp:50-52
 enum { SimultaneousMode = 0, PhasedMode = 1, Phased_Block_1Mode = 2 };
 
+// include/config/dnatypes-basic.hpp:79-84
+typedef enum _SIGMA_ZERO_STAT_PASS_ { test_stat_pass = 0, test_stat_warning = 1, test_stat_fail = 2 } SIGMA_ZERO_STAT_PASS;
+
+// include/config/dnaconsts.hpp:119-120
+constexpr double UNRELIABLE = 999.99;
+constexpr double STABLE_LIMIT = 700.0;
+constexpr double PRECISION_1E10 = 1.0e-10;
+
 // include/exception/dnaexception.hpp:51-59
 typedef enum _ADJUST_STATUS_ {
     ADJUST_SUCCESS = 0,
@@ -187,14 +195,19 @@ struct adjust_settings {
     double free_std_dev = 10.0;
     double fixed_std_dev = 1.0e-6;   // PRECISION_1E6
     std::string bst_file, bms_file, seg_file;
+    std::string stage_path;          // where <network>-rva.mtx / -pam.mtx go (default: g.output_folder)
     int max_threads = 0;
     // device selection (not in the reference): which GPU this process drives
     int device = 0;
+};
+struct output_settings {
+    UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement
 };
 struct project_settings {
     general_settings g;
     segment_settings s;
     adjust_settings a;
+    output_settings o;
 };
 
 }  // namespace dynadjust

@@ -35,6 +35,10 @@ typedef struct {
     double fixed_std_dev;      /* default 1e-6 */
     int scale_normals_to_unity;
     int device;                /* HIP device ordinal of this process */
+    float confidence_interval; /* a.confidence_interval, default 95 (global test + outlier flag) */
+    int output_tstat;          /* o._adj_msr_tstat: fill measurement_t::TStat in dnaadj_generate_statistics */
+    const char* network_name;  /* g.network_name   -> <output_folder>/<network_name>-rva.mtx / -pam.mtx (may be NULL) */
+    const char* output_folder; /* g.output_folder (may be NULL = ".") */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
@@ -69,6 +73,35 @@ int dnaadj_block_stations(dnaadj_handle* h, uint32_t block, uint32_t* stations);
 int dnaadj_block_estimates(dnaadj_handle* h, uint32_t block, double* xyz);                 /* v_rigorousStations_ */
 int dnaadj_block_variances_packed(dnaadj_handle* h, uint32_t block, double* packed);       /* v_rigorousVariances_ */
 int dnaadj_adjusted_coordinates(dnaadj_handle* h, double* xyz);                            /* 3 per bst station */
+
+/* ---- after the adjustment: statistics and results out ---------------------------------- */
+typedef struct {
+    double chi_squared;        /* GetChiSquared()            dnaadjust.hpp:339 */
+    double sigma_zero;         /* GetSigmaZero()             dnaadjust.hpp:340 */
+    double global_pelzer;      /* GetGlobalPelzerRel()       dnaadjust.hpp:350 */
+    double chi_upper_limit;    /* GetChiSquaredUpperLimit()  dnaadjust.hpp:344 */
+    double chi_lower_limit;    /* GetChiSquaredLowerLimit()  dnaadjust.hpp:347 */
+    uint32_t measurement_params, unknown_params;
+    uint32_t potential_outliers;   /* GetPotentialOutlierCount() dnaadjust.hpp:341 */
+    uint32_t test_result;          /* GetTestResult(): 0 pass, 1 warning, 2 fail  dnaadjust.hpp:353 */
+    int degrees_of_freedom;
+} dnaadj_statistics;
+int dnaadj_generate_statistics(dnaadj_handle* h);                          /* dna_adjust::GenerateStatistics (dnaadjust.cpp:6802) */
+int dnaadj_get_statistics(const dnaadj_handle* h, dnaadj_statistics* out);
+/* the measurement records (measurement_t, 208 bytes each, include/measurement_types/dnameasurement.hpp:133-194) as
+ * the adjustment holds them: after dnaadj_generate_statistics with measAdj, measCorr, measAdjPrec, residualPrec,
+ * NStat, TStat, PelzerRel filled and the variances scaled */
+uint64_t dnaadj_measurement_record_count(const dnaadj_handle* h);
+int dnaadj_measurement_records(const dnaadj_handle* h, void* records, uint64_t cap_records);
+/* v_precAdjMsrsFull_ of a block: 6 doubles (xx xy xz yy yz zz) per GNSS vector in CML order */
+uint64_t dnaadj_block_prec_adj_msrs_count(const dnaadj_handle* h, uint32_t block);
+int dnaadj_block_prec_adj_msrs(const dnaadj_handle* h, uint32_t block, double* out, uint64_t cap);
+int dnaadj_serialise_adjusted_variance_matrices(dnaadj_handle* h);         /* SerialiseAdjustedVarianceMatrices (dnaadjust.cpp:6770) */
+int dnaadj_update_binary_files(dnaadj_handle* h);                          /* UpdateBinaryFiles (dnaadjust.cpp:445) */
+
+/* quantiles used by the global test (the reference takes them from boost::math, dnaadjust.cpp:203-206, :6866-6880) */
+double dnastat_normal_quantile(double p);
+double dnastat_chi_squared_quantile(double dof, double p);
 
 /* ---- per-block steps of the phased chain (dna_adjust::Phased*): what the multi-GPU orchestrator schedules.
  * AdjustPhasedForward / AdjustPhasedReverseCombine (dnaadjust.cpp:2756, 3461) are loops over exactly these. ---- */

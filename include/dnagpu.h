@@ -129,6 +129,14 @@ int dnagpu_block_compute_b(dnagpu_ctx* ctx, int chain, uint32_t blk);
 int dnagpu_block_get_b(dnagpu_ctx* ctx, int chain, uint32_t blk, double* b);
 int dnagpu_block_get_weights(dnagpu_ctx* ctx, int chain, uint32_t blk, double* w6);
 
+/* Post-adjustment statistics of the block's GNSS vectors from the current meas-minus-computed vector (call
+ * dnagpu_block_compute_b first) -- ComputePrecisionAdjMsrs_GX/_Y (dnaadjust.cpp:8009/8037) and the per-vector terms of
+ * ComputeChiSquare_G/_XY (dnaadjust.cpp:8530/8551):
+ *   chi[v]         = b_v . (W b)_v, so that sum_v chi[v] = chi-squared of the block (host sums in CML order);
+ *   prec6[6v..6v+5] = upper triangle (xx xy xz yy yz zz) of A S A^T, S = `variances` (the block's rigorous variances,
+ *                     3*stations of the block); skipped when `variances` is NULL.  Host buffers. */
+int dnagpu_block_msr_statistics(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* variances, double* prec6, double* chi);
+
 /* m <- sum_i A_i^T W_i A_i (measurement contributions only, CML order) */
 int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m);
 /* m[3s..3s+2, 3s..3s+2] += sign * w9 (column-major 3x3) for k stations */

@@ -296,6 +296,7 @@ typedef struct {
     double *jvar, *jvarFwd;      /* v_junctionVariances_, v_junctionVariancesFwd_ (packed 3*n_jsl) */
     double *jestFwd;             /* v_junctionEstimatesFwd_[block]     (3*n_jsl) */
     double *jestRev;             /* v_junctionEstimatesRev_[block]     (3*|JSL(block-1)|) */
+    double* prec;                /* v_precAdjMsrsFull_ (6 per vector) */
 } blk_t;
 
 struct orc_adjustment {
@@ -316,6 +317,7 @@ struct orc_adjustment {
     double maxCorr;
     uint64_t solves;
     double sum_n3;
+    double* msr_field[7];        /* per vector component, see orc_adjust_msr_field */
     char err[512];
 };
 
@@ -667,7 +669,9 @@ void orc_adjust_destroy(orc_adjustment* a) {
         free(B->stations); free(B->first_fwd); free(B->first_rev);
         free(B->N); free(B->NR); free(B->est); free(B->orig); free(B->rig); free(B->rigvar);
         free(B->corr); free(B->corrR); free(B->b); free(B->jvar); free(B->jvarFwd); free(B->jestFwd); free(B->jestRev);
+        free(B->prec);
     }
+    for (int f = 0; f < 7; ++f) free(a->msr_field[f]);
     free(a->blk);
     free(a->W);
     if (a->cl_W)
@@ -986,4 +990,140 @@ const char* orc_adjust_error(const orc_adjustment* a) { return a->err; }
 void orc_adjust_solve_stats(const orc_adjustment* a, uint64_t* solves, double* sum_n3) {
     if (solves) *solves = a->solves;
     if (sum_n3) *sum_n3 = a->sum_n3;
+}
+
+/* ========================================================================== */
+/* post-adjustment statistics                                                  */
+/* ========================================================================== */
+#define ORC_UNRELIABLE 999.99   /* include/config/dnaconsts.hpp:119 */
+#define ORC_STABLE_LIMIT 700.0  /* include/config/dnaconsts.hpp:120 */
+
+int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statistics* out) {
+    const orc_network* net = &a->net;
+    const size_t ncomp = (size_t)net->n_baselines * 3;
+    for (int f = 0; f < 7; ++f) {
+        free(a->msr_field[f]);
+        a->msr_field[f] = (double*)calloc(ncomp + 1, sizeof(double));
+    }
+    double *measAdj = a->msr_field[0], *measCorr = a->msr_field[1], *adjPrec = a->msr_field[2], *resPrec = a->msr_field[3],
+           *nstat = a->msr_field[4], *pelzer = a->msr_field[5], *measPrec = a->msr_field[6];
+    /* a-priori variances as the records hold them after scaling (SetGPSVarianceMatrix, ADJ:4282) */
+    {
+        size_t voff = 0;
+        for (uint32_t c = 0; c < a->n_clusters; ++c) {
+            uint32_t i0 = a->cl_off[c], k = a->cl_off[c + 1] - i0, nc = 3 * k;
+            for (uint32_t j = 0; j < k; ++j)
+                for (int e = 0; e < 3; ++e) {
+                    if (net->n_clusters)
+                        measPrec[3 * (size_t)(i0 + j) + e] = net->cluster_vcv[voff + (size_t)(3 * j + e) * nc + 3 * j + e];
+                    else
+                        measPrec[3 * (size_t)(i0 + j) + e] = net->vcv6[(size_t)(i0 + j) * 6 + sym6(e, e)];
+                }
+            voff += (size_t)nc * nc;
+        }
+    }
+    double chi_total = 0.0;
+    uint32_t outliers = 0, msr_params = 0;
+    for (uint32_t blk = 0; blk < a->n_blocks; ++blk) {
+        blk_t* B = &a->blk[blk];
+        compute_b(a, B, B->rig);                                  /* UpdateAdjustment(false), ADJ:549 */
+        free(B->prec);
+        B->prec = (double*)calloc((size_t)B->m * 2 + 1, sizeof(double));
+        const double* V = B->rigvar;
+        double chi = 0.0;                                         /* ComputeChiSquare (ADJ:7257) starts from zero per block */
+        uint32_t row = 0, prow = 0;
+        for (uint32_t c = 0; c < B->n_cml; ++c) {
+            const uint32_t cl = B->cml[c], i0 = a->cl_off[cl], k = a->cl_off[cl + 1] - i0, nc = 3 * k;
+            /* ComputePrecisionAdjMsrs_GX (ADJ:8009) / _Y (ADJ:8037) */
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint32_t i = i0 + j;
+                const uint32_t s2 = 3 * local_index(B, net->stn2[i]);
+                const int point = net->stn1[i] == 0xffffffffu;
+                const uint32_t s1 = point ? 0 : 3 * local_index(B, net->stn1[i]);
+                for (int r = 0; r < 3; ++r)
+                    for (int q = r; q < 3; ++q, ++prow) {
+                        if (point)
+                            B->prec[prow] = packed_get(V, B->n, s2 + r, s2 + q);
+                        else {
+                            /* Precision_Adjusted_GNSS_bsl (dnatemplatematrixfuncs.hpp:255-297) */
+                            double tmp = (0.0 - packed_get(V, B->n, s1 + r, s1 + q)) + packed_get(V, B->n, s2 + r, s1 + q);
+                            double tmpk = (0.0 - packed_get(V, B->n, s1 + r, s2 + q)) + packed_get(V, B->n, s2 + r, s2 + q);
+                            B->prec[prow] = tmpk - tmp;
+                        }
+                    }
+                /* UpdateMsrRecords_GXY (ADJ:8152) -> UpdateMsrRecord (ADJ:8187), UpdateMsrRecordStats (ADJ:8291) */
+                static const int diag6[3] = {0, 3, 5};
+                for (int e = 0; e < 3; ++e) {
+                    const size_t g = 3 * (size_t)i + e;
+                    measCorr[g] = -B->b[row + 3 * j + e];
+                    measAdj[g] = net->obs[g] + measCorr[g];
+                    adjPrec[g] = B->prec[prow - 6 + diag6[e]];
+                    resPrec[g] = measPrec[g] - adjPrec[g];
+                    if (resPrec[g] < 0.0) resPrec[g] = fabs(resPrec[g]);
+                    pelzer[g] = sqrt(measPrec[g]) / sqrt(resPrec[g]);
+                    if (pelzer[g] < 0.0 || pelzer[g] > ORC_STABLE_LIMIT) pelzer[g] = ORC_UNRELIABLE;
+                    nstat[g] = measCorr[g] / sqrt(resPrec[g]);
+                    if (fabs(nstat[g]) > critical_value) outliers++;
+                }
+            }
+            /* chi-square */
+            const double* r = B->b + row;
+            if (!a->cl_W[cl]) {
+                /* ComputeChiSquare_G (ADJ:8530) */
+                const double* w6 = a->W + (size_t)i0 * 6;
+                double cs = 0.0;
+                for (int rr = 0; rr < 3; ++rr)
+                    for (int cc = 0; cc < 3; ++cc) cs += w6[sym6(rr, cc)] * r[rr] * r[cc];
+                chi += cs;
+            } else {
+                /* ComputeChiSquare_XY (ADJ:8551): (r^T W) r */
+                const double* W = a->cl_W[cl];
+                double tot = 0.0;
+                for (uint32_t col = 0; col < nc; ++col) {
+                    double rv = 0.0;
+                    for (uint32_t rr = 0; rr < nc; ++rr) rv += r[rr] * W[(size_t)col * nc + rr];
+                    tot += rv * r[col];
+                }
+                chi += tot;
+            }
+            row += nc;
+        }
+        chi_total += chi;                                         /* ComputeChiSquareNetwork (ADJ:7315) */
+        msr_params += B->m;
+    }
+    /* ComputeGlobalPelzer (ADJ:8302) / _GXY (ADJ:8396) */
+    double sum = 0.0;
+    uint32_t num = 0;
+    for (uint32_t blk = 0; blk < a->n_blocks; ++blk) {
+        blk_t* B = &a->blk[blk];
+        for (uint32_t c = 0; c < B->n_cml; ++c)
+            for (uint32_t i = a->cl_off[B->cml[c]]; i < a->cl_off[B->cml[c] + 1]; ++i)
+                for (int e = 0; e < 3; ++e) {
+                    double* p = &pelzer[3 * (size_t)i + e];
+                    if (*p > 0.0 && *p < ORC_UNRELIABLE) {
+                        sum += (*p * *p - 1.0);
+                        num++;
+                    } else
+                        *p = ORC_UNRELIABLE;
+                }
+    }
+    /* unknown parameters: 3 per station minus the constrained components (ADJ:647-672) */
+    uint32_t unknowns = 3 * net->n_stations;
+    for (uint32_t s = 0; s < net->n_stations; ++s)
+        for (int c = 0; c < 3; ++c)
+            if (net->constraints[3 * (size_t)s + c] == 'C') unknowns--;
+    out->chi_squared = chi_total;
+    out->measurement_params = msr_params;
+    out->unknown_params = unknowns;
+    out->dof = (int)msr_params - (int)unknowns;                   /* ComputeGlobalNetStat (ADJ:6854) */
+    out->sigma_zero = out->dof != 0 ? chi_total / out->dof : 0.0;
+    out->global_pelzer = num ? sqrt(sum / num) : ORC_UNRELIABLE;
+    out->potential_outliers = outliers;
+    return 0;
+}
+
+const double* orc_adjust_msr_field(const orc_adjustment* a, int field) { return (field >= 0 && field < 7) ? a->msr_field[field] : NULL; }
+const double* orc_adjust_block_prec_adj_msrs(const orc_adjustment* a, uint32_t b, uint32_t* rows) {
+    if (rows) *rows = a->blk[b].m * 2;
+    return a->blk[b].prec;
 }

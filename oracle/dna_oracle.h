@@ -128,6 +128,22 @@ const char* orc_adjust_error(const orc_adjustment* a);
 /* number of Solve() calls and sum of n^3 over them since create */
 void orc_adjust_solve_stats(const orc_adjustment* a, uint64_t* solves, double* sum_n3);
 
+/* ---- post-adjustment statistics: GenerateStatistics (ADJ:6802) for GNSS measurements ----------------------------
+ * UpdateAdjustment(false) (meas-minus-computed from the rigorous estimates, ADJ:549), ComputePrecisionAdjMsrs_GX/_Y
+ * (ADJ:8009/8037), UpdateMsrRecord (ADJ:8187), ComputeChiSquare_G/_XY (ADJ:8530/8551), ComputeGlobalNetStat (ADJ:6854),
+ * ComputeGlobalPelzer (ADJ:8302).  `critical_value` = normal quantile of the confidence interval (ADJ:203-206). */
+typedef struct {
+    double chi_squared, sigma_zero, global_pelzer;
+    uint32_t measurement_params, unknown_params, potential_outliers;
+    int dof;
+} orc_statistics;
+int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statistics* out);
+/* per vector component (3 per vector, network vector order) after orc_adjust_statistics:
+ * field 0 measAdj, 1 measCorr, 2 measAdjPrec, 3 residualPrec, 4 NStat, 5 PelzerRel, 6 a-priori variance */
+const double* orc_adjust_msr_field(const orc_adjustment* a, int field);
+/* v_precAdjMsrsFull_ of a block: 6 values (xx xy xz yy yz zz) per vector, CML order */
+const double* orc_adjust_block_prec_adj_msrs(const orc_adjustment* a, uint32_t block, uint32_t* rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,14 @@ class OrcSettings(C.Structure):
                 ("max_iterations", C.c_uint32), ("scale_normals_to_unity", C.c_int), ("threads", C.c_int)]
 
 
+class OrcStatistics(C.Structure):
+    _fields_ = [("chi_squared", C.c_double), ("sigma_zero", C.c_double), ("global_pelzer", C.c_double),
+                ("measurement_params", C.c_uint32), ("unknown_params", C.c_uint32), ("potential_outliers", C.c_uint32),
+                ("dof", C.c_int)]
+
+
+MSR_FIELDS = ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel", "measPrec")
+
 _lib = None
 
 
@@ -72,6 +80,11 @@ def load():
         lib.orc_adjust_error.restype = C.c_char_p
         lib.orc_adjust_error.argtypes = [C.c_void_p]
         lib.orc_adjust_solve_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), f64p]
+        lib.orc_adjust_statistics.argtypes = [C.c_void_p, C.c_double, C.POINTER(OrcStatistics)]
+        lib.orc_adjust_msr_field.restype = f64p
+        lib.orc_adjust_msr_field.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_adjust_block_prec_adj_msrs.restype = f64p
+        lib.orc_adjust_block_prec_adj_msrs.argtypes = [C.c_void_p, C.c_uint32, u32p]
         _lib = lib
     return _lib
 
@@ -270,6 +283,23 @@ class Adjustment:
         if st == 5:
             raise RuntimeError(self.lib.orc_adjust_error(self.h).decode())
         return st
+
+    def statistics(self, confidence_interval=95.0):
+        """GenerateStatistics: returns (OrcStatistics, {field: array of 3 per vector, network vector order})"""
+        from scipy.stats import norm
+        conf = confidence_interval * 0.01
+        crit = float(norm.ppf(conf + (1.0 - conf) / 2.0))        # dnaadjust.cpp:203-206
+        st = OrcStatistics()
+        rc = self.lib.orc_adjust_statistics(self.h, crit, C.byref(st))
+        assert rc == 0
+        n = 3 * self.net.n_baselines
+        fields = {nm: np.ctypeslib.as_array(self.lib.orc_adjust_msr_field(self.h, f), shape=(n,)).copy() for f, nm in enumerate(MSR_FIELDS)}
+        return st, fields
+
+    def block_prec_adj_msrs(self, b):
+        rows = C.c_uint32()
+        p = self.lib.orc_adjust_block_prec_adj_msrs(self.h, b, C.byref(rows))
+        return np.ctypeslib.as_array(p, shape=(rows.value,)).copy()
 
     def iteration(self):
         if self.lib.orc_adjust_iteration(self.h):

@@ -270,3 +270,141 @@ def test_orchestrator_two_ranks_device_backend(built, orc, tmp_path):
                 assert np.abs(res[f"var_{k}"] - vo).max() / np.abs(vo).max() < TOL_V
     assert seen == set(range(6))
     o.close()
+
+
+def _device_fields(a, bms_path):
+    """per vector component arrays (network vector order) out of the records held by the adjustment"""
+    raw = a.measurement_records()
+    rec = np.frombuffer(raw.tobytes(), dtype=F.MEASUREMENT_DT)
+    comp = rec[(rec["measStart"] < 3) & (~rec["ignore"])]
+    out = {k: np.array(comp[k]) for k in ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "TStat", "PelzerRel")}
+    out["measPrec"] = np.where(comp["measStart"] == 0, comp["term2"], np.where(comp["measStart"] == 1, comp["term3"], comp["term4"]))
+    return out, rec
+
+
+def _compare_statistics(a, o, confidence=95.0):
+    from scipy.stats import chi2
+    a.GenerateStatistics()
+    so, fo = o.statistics(confidence)
+    fd, rec = _device_fields(a, None)
+    assert a.GetDegreesOfFreedom() == so.dof and a.GetMeasurementCount() == so.measurement_params
+    assert abs(a.GetChiSquared() - so.chi_squared) < 1e-9 * max(1.0, so.chi_squared)
+    assert abs(a.GetSigmaZero() - so.sigma_zero) < 1e-9 * max(1.0, so.sigma_zero)
+    assert abs(a.GetGlobalPelzerRel() - so.global_pelzer) < 1e-7
+    assert a.GetPotentialOutlierCount() == so.potential_outliers
+    for k in ("measAdj", "measCorr"):
+        assert np.abs(fd[k] - fo[k]).max() < 1e-8
+    assert np.array_equal(fd["measPrec"], fo["measPrec"])
+    scale = np.abs(fo["measAdjPrec"]).max()
+    assert np.abs(fd["measAdjPrec"] - fo["measAdjPrec"]).max() < 1e-7 * scale
+    assert np.abs(fd["residualPrec"] - fo["residualPrec"]).max() < 1e-7 * scale
+    assert np.abs(fd["NStat"] - fo["NStat"]).max() < 1e-5
+    ok = fo["PelzerRel"] < 100
+    assert np.abs(fd["PelzerRel"][ok] - fo["PelzerRel"][ok]).max() < 1e-5
+    half = (100.0 - confidence) * 0.005
+    dof = so.dof
+    assert abs(a.GetChiSquaredUpperLimit() - chi2.ppf(1 - half, dof) / dof) < 1e-9
+    assert abs(a.GetChiSquaredLowerLimit() - chi2.ppf(half, dof) / dof) < 1e-9
+    s0 = a.GetSigmaZero()
+    assert a.GetTestResult() == (1 if s0 < a.GetChiSquaredLowerLimit() else (2 if s0 > a.GetChiSquaredUpperLimit() else 0))
+    for b in range(a.blockCount()):
+        po = o.block_prec_adj_msrs(b)
+        assert np.abs(a.block_prec_adj_msrs(b) - po).max() < 1e-7 * np.abs(po).max()
+    return fd, rec
+
+
+def test_reference_sample_gnss_network(built, orc, golden_dir, tmp_path):
+    """the device path against the reference's published adjustment of its own sample network
+    (sampleData/gnss-network.* -> gnss.simult.adj.expected) and against the oracle on the same files"""
+    from tests import dnatext as T
+    from tests.test_oracle_adjust import check_against_reference_report
+    base = str(tmp_path / "gnss")
+    stn, cl, adj = T.build_gnss_sample(golden_dir, base)
+    net = orc.Network(base, False)
+    o = orc.Adjustment(net, False)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "gnss", False, output_tstat=True)
+    _compare(a, st, o, ost)
+    assert st == 0 and a.CurrentIteration() == 2
+    fd, rec = _compare_statistics(a, o)
+    V = unpack_lower(a.block_variances_packed(0), 3 * len(stn))
+    stats = {"measurements": a.GetMeasurementCount(), "unknowns": a.GetUnknownsCount(), "dof": a.GetDegreesOfFreedom(),
+             "chi2": a.GetChiSquared(), "sigma0": a.GetSigmaZero(), "pelzer": a.GetGlobalPelzerRel(), "outliers": a.GetPotentialOutlierCount()}
+    check_against_reference_report(adj, [x[0] for x in stn], stn, a.block_estimates(0), V, fd, stats)
+    assert abs(a.GetChiSquaredUpperLimit() - 1.170) < 6e-4 and abs(a.GetChiSquaredLowerLimit() - 0.843) < 6e-4   # report: 0.843 < 1.169 < 1.170
+    assert a.GetTestResult() == 0                                                                                 # "*** PASSED ***"
+    assert np.abs(fd["TStat"] - fd["NStat"] / np.sqrt(a.GetSigmaZero())).max() < 1e-12
+    a.close()
+    o.close()
+
+
+@pytest.mark.parametrize("rows,cols,blocks,phased,xcl,ycl,mt", [
+    (8, 7, 1, False, 0, False, False),
+    (9, 8, 3, True, 12, True, False),
+    (12, 10, 4, True, 1000, False, True),
+])
+def test_statistics_parity_with_oracle(built, orc, tmp_path, rows, cols, blocks, phased, xcl, ycl, mt):
+    adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, blocks, seed=rows, x_clusters=xcl, y_cluster=ycl)
+    net = orc.Network(str(tmp_path / "s"), phased)
+    o = orc.Adjustment(net, phased)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "s", phased, multi_thread=mt, confidence_interval=99.0)
+    _compare(a, st, o, ost)
+    _compare_statistics(a, o, 99.0)
+    a.close()
+    o.close()
+
+
+def _read_mtx_file(path, count):
+    """matrix_2d binary stream records (include/math/dnamatrix_contiguous.cpp:39-91)"""
+    import struct
+    out = []
+    with open(path, "rb") as f:
+        for _ in range(count):
+            mtype, rows, cols, mrows, mcols, pad = struct.unpack("<6I", f.read(24))
+            assert (mrows, mcols, pad) == (rows, cols, 0)
+            n = rows * (rows + 1) // 2 if mtype == 1 else rows * cols
+            data = np.frombuffer(f.read(8 * n), dtype=np.float64)
+            assert struct.unpack("<2I", f.read(8)) == (0, 0)
+            out.append((mtype, rows, cols, data))
+        assert f.read() == b""
+    return out
+
+
+def test_results_out_files(built, orc, tmp_path):
+    """SerialiseAdjustedVarianceMatrices (-rva.mtx / -pam.mtx) and UpdateBinaryFiles (.bst / .bms), dnaadjust.cpp:6770 / :445"""
+    adjust.write_synthetic_network(str(tmp_path), "w", 9, 8, 0, 3, seed=3, x_clusters=6, y_cluster=True)
+    bst0 = F.read_bst(str(tmp_path / "w.bst")).copy()
+    a, st = _device_run(str(tmp_path), "w", True)
+    assert st == 0
+    a.GenerateStatistics()
+    a.SerialiseAdjustedVarianceMatrices()
+    rva = _read_mtx_file(str(tmp_path / "w-rva.mtx"), a.blockCount())
+    pam = _read_mtx_file(str(tmp_path / "w-pam.mtx"), a.blockCount())
+    for b in range(a.blockCount()):
+        n = 3 * len(a.block_stations(b))
+        assert rva[b][:3] == (1, n, n) and np.array_equal(rva[b][3], a.block_variances_packed(b))
+        p = a.block_prec_adj_msrs(b)
+        assert pam[b][:3] == (0, len(p), 1) and np.array_equal(pam[b][3], p) and len(p) > 0
+    fd, rec = _device_fields(a, None)
+    xyz = a.adjusted_coordinates(len(bst0))
+    chi = a.GetChiSquared()
+    a.UpdateBinaryFiles()
+    a.close()
+    # the files now hold the adjusted stations and measurements
+    bst = F.read_bst(str(tmp_path / "w.bst"))
+    bms = F.read_bms(str(tmp_path / "w.bms"))
+    assert np.array_equal(np.frombuffer(bms.tobytes(), dtype=np.uint8), np.frombuffer(rec.tobytes(), dtype=np.uint8))
+    for s in range(len(bst)):
+        got = orc.geo_to_cart(float(bst["currentLatitude"][s]), float(bst["currentLongitude"][s]), float(bst["currentHeight"][s]))
+        # CartToGeo (Lin & Wang, one Newton step, dnatemplategeodesyfuncs.hpp:154-225) is good to ~1e-7 m in height
+        assert np.abs(np.array(got) - xyz[s]).max() < 1e-6
+    assert np.array_equal(bst["initialLatitude"], bst0["initialLatitude"])
+    # a second adjustment from the updated ("reduced") files starts at the solution: same statistics, tiny corrections
+    a2, st2 = _device_run(str(tmp_path), "w", True)
+    assert st2 == 0 and a2.CurrentIteration() == 1 and abs(a2.GetMaxCorrection()) < 1e-5
+    a2.GenerateStatistics()
+    assert abs(a2.GetChiSquared() - chi) < 1e-6 * chi
+    a2.close()

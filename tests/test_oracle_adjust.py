@@ -180,3 +180,85 @@ def test_gnss_clusters(orc, built, tmp_path, rows, cols, blocks, xcl, ycl):
     a.close()
     if blocks > 1:
         _phased_vs_simultaneous(orc, base)
+
+
+def _local_sd(stn, V):
+    """sqrt of the diagonal of R V R^T per station (e, n, up), V = full variance matrix in station order"""
+    out = []
+    for i, s in enumerate(stn):
+        lat, lon = s[2], s[3]
+        R = np.array([[-np.sin(lon), np.cos(lon), 0.0],
+                      [-np.sin(lat) * np.cos(lon), -np.sin(lat) * np.sin(lon), np.cos(lat)],
+                      [np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)]])
+        out.append(np.sqrt(np.diag(R @ V[3 * i:3 * i + 3, 3 * i:3 * i + 3] @ R.T)))
+    return np.array(out)
+
+
+def check_against_reference_report(adj, names, stn, xyz, V, fields, stats):
+    """the reference's own adjustment report of its sample network (gnss.simult.adj.expected: 4-decimal tables, from
+    4-decimal observations, hence the tolerances)"""
+    exp_xyz = np.array([adj["stn"][n]["xyz"] for n in names])
+    assert np.abs(xyz.reshape(-1, 3) - exp_xyz).max() < 2.5e-4
+    exp_sd = np.array([adj["stn"][n]["sd_enu"] for n in names])
+    assert np.abs(_local_sd(stn, V) - exp_sd).max() < 1e-4
+    col = lambda k: np.array([m[k] for m in adj["msr"]])
+    assert np.abs(fields["measAdj"] - col("adjusted")).max() < 2.5e-4
+    assert np.abs(fields["measCorr"] - col("correction")).max() < 2.5e-4
+    assert np.abs(np.sqrt(fields["measPrec"]) - col("meas_sd")).max() < 1e-4
+    assert np.abs(np.sqrt(fields["measAdjPrec"]) - col("adj_sd")).max() < 1e-4
+    assert np.abs(np.sqrt(fields["residualPrec"]) - col("corr_sd")).max() < 1e-4
+    assert np.abs(fields["NStat"] - col("nstat")).max() < 0.06
+    assert stats["measurements"] == adj["measurements"] == 417 and stats["unknowns"] == adj["unknowns"] == 129
+    assert stats["dof"] == adj["dof"] == 288
+    assert abs(stats["chi2"] - adj["chi2"]) < 0.5            # 336.64 in the report
+    assert abs(stats["sigma0"] - adj["sigma0"]) < 2e-3       # 1.169
+    assert abs(stats["pelzer"] - 0.779) < 1e-3               # "Global (Pelzer) Reliability 0.779"
+    assert stats["outliers"] == 10                           # "(10 potential outliers)"
+
+
+def test_reference_sample_gnss_network(orc, golden_dir, tmp_path):
+    """the oracle against the reference's published result for sampleData/gnss-network (129 G, 1 X cluster of 4,
+    1 Y cluster of 6, variance scalars): this pins the restated adjustment end to end."""
+    from tests import dnatext as T
+    base = str(tmp_path / "gnss")
+    stn, cl, adj = T.build_gnss_sample(golden_dir, base)
+    net, a, st = _run(orc, base, False)
+    assert st == 0 and a.iterations() == 2                    # "ITERATION 2 ... SOLUTION Converged"
+    s, f = a.statistics()
+    V = unpack_lower(a.block_variances(0), 3 * len(stn))
+    stats = {"measurements": s.measurement_params, "unknowns": s.unknown_params, "dof": s.dof, "chi2": s.chi_squared,
+             "sigma0": s.sigma_zero, "pelzer": s.global_pelzer, "outliers": s.potential_outliers}
+    check_against_reference_report(adj, [x[0] for x in stn], stn, a.block_estimates(0), V, f, stats)
+    a.close()
+
+
+def test_statistics_phased_equals_simultaneous(orc, built, tmp_path):
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", 9, 7, 0, 3, seed=5, x_clusters=10, y_cluster=True)
+    base = str(tmp_path / "s")
+    ns, s, st_s = _run(orc, base, False)
+    npn, p, st_p = _run(orc, base, True)
+    ss, fs = s.statistics()
+    sp, fp = p.statistics()
+    assert abs(ss.chi_squared - sp.chi_squared) < 1e-6 * ss.chi_squared
+    assert (ss.dof, ss.potential_outliers) == (sp.dof, sp.potential_outliers)
+    assert abs(ss.global_pelzer - sp.global_pelzer) < 1e-6
+    for k in ("measAdj", "measCorr"):
+        assert np.abs(fs[k] - fp[k]).max() < 1e-8
+    for k in ("measAdjPrec", "residualPrec"):
+        assert np.abs(fs[k] - fp[k]).max() < 1e-6 * np.abs(fs[k]).max()   # ~1e-9 relative agreement of the block variances
+    s.close()
+    p.close()
+
+
+def test_quantiles_against_scipy(built):
+    """the quantile functions behind the global test (boost::math in the reference) against scipy"""
+    from scipy.stats import chi2, norm
+    from dynadjust_amd import _lib
+    lib = _lib.load()
+    for p in (1e-9, 1e-4, 0.01, 0.025, 0.3, 0.5, 0.8, 0.975, 0.995, 1 - 1e-7):
+        # (p itself carries half an ulp: 1.1e-16 / pdf in x)
+        assert abs(lib.dnastat_normal_quantile(p) - norm.ppf(p)) < 1e-12 + 4e-16 / norm.pdf(norm.ppf(p))
+        for dof in (1, 2, 3, 7, 30, 288, 5000, 240000):
+            q, r = lib.dnastat_chi_squared_quantile(dof, p), chi2.ppf(p, dof)
+            assert abs(q - r) < 1e-9 * max(r, 1e-3) + 4e-16 / max(chi2.pdf(r, dof), 1e-300), (dof, p, q, r)
