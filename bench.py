@@ -34,6 +34,18 @@ WORKLOADS = {
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk)
 
 
+def traffic_from_profile(workload):
+    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process, so this is
+    the figure of the committed `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
+    (profiles/r01_hbm_traffic.json, made by tools/pmc_traffic_json.py); null for workloads without such a pass."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        rec = json.load(open(path))
+        return rec["hbm_bytes_per_launch"] if rec.get("workload") == workload else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(workload, iterations, solves_per_step, sum_n3_per_step, stations):
     """Runs _cpu_baseline_sample in a clean subprocess: the MKL runtime must not share a process with torch's
     OpenMP runtime (mixing libiomp5 and libgomp silently corrupts dpotrf results), and MKL_THREADING_LAYER=GNU
@@ -136,6 +148,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("DNAGPU_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-events", action="store_true", help="diagnostic: no HIP events around the GEMM launches (roofline.achieved = 0)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -190,7 +203,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    lib.dnagpu_profile_enable(ctx, 1)
+    lib.dnagpu_profile_enable(ctx, 0 if args.no_gemm_events else 1)
     lib.dnagpu_profile_reset(ctx)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -240,7 +253,8 @@ def main():
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": traffic_from_profile(args.workload),
+            "traffic_unit": "bytes per launch (memory-side, FETCH_SIZE x 2 + WRITE_SIZE from the committed rocprofv3 --pmc passes of this workload)",
             "launches_per_step": prof_n.value / args.steps,
             "gemm_ms_per_step": gemm_ms_per_step,
             "issued_tflops": (prof_f.value / 1e12) / (prof_ms.value / 1e3) if prof_ms.value > 0 else 0.0,

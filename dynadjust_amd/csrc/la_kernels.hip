@@ -55,19 +55,33 @@ struct Geo {
     static constexpr int MI = WT / 16;          // MFMA tiles per wave per dimension
 };
 
+// Global -> register staging of one BK=16 operand slab.  The per-thread part of the address is loop invariant
+// (a 32-bit byte offset, computed once); the slab position is wave-uniform and travels in the scalar base, so the
+// main loop issues `global_load_dwordx4 v, v_off, s[base]` with no vector address arithmetic.
 template <bool KC, int TILE>
-__device__ __forceinline__ void stage_load(const double* __restrict__ P, int ld, int r0, int k0, int tid, d2 (&g)[Geo<TILE>::NQ]) {
+__device__ __forceinline__ void stage_offsets(int ld, int tid, uint32_t (&off)[Geo<TILE>::NQ]) {
 #pragma unroll
     for (int q = 0; q < Geo<TILE>::NQ; ++q) {
         int idx = tid + 256 * q;
         if (!KC) {
             int k = idx / (TILE / 2), r2 = idx % (TILE / 2);
-            g[q] = *reinterpret_cast<const d2*>(P + (size_t)(k0 + k) * ld + r0 + 2 * r2);
+            off[q] = (uint32_t)(k * ld + 2 * r2) * 8u;
         } else {
             int k2 = idx & 7, c = idx >> 3;
-            g[q] = *reinterpret_cast<const d2*>(P + (size_t)(r0 + c) * ld + k0 + 2 * k2);
+            off[q] = (uint32_t)(c * ld + 2 * k2) * 8u;
         }
     }
+}
+
+template <bool KC>
+__device__ __forceinline__ const char* stage_base(const double* __restrict__ P, int ld, int r0, int k0) {
+    return reinterpret_cast<const char*>(KC ? P + (size_t)r0 * ld + k0 : P + (size_t)k0 * ld + r0);
+}
+
+template <int TILE>
+__device__ __forceinline__ void stage_load(const char* base, const uint32_t (&off)[Geo<TILE>::NQ], d2 (&g)[Geo<TILE>::NQ]) {
+#pragma unroll
+    for (int q = 0; q < Geo<TILE>::NQ; ++q) g[q] = *reinterpret_cast<const d2*>(base + off[q]);
 }
 
 template <bool KC, int TILE>
@@ -128,62 +142,111 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
         for (int ni = 0; ni < G::MI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
     d2 ga[G::NQ], gb[G::NQ];
+    uint32_t offa[G::NQ], offb[G::NQ];
+    stage_offsets<A_KC, TILE>(a.lda, tid, offa);
+    stage_offsets<B_KC, TILE>(a.ldb, tid, offb);
     const int nk = (kend - kbeg) / 16;
+
+    // MFMA fragments, two register sets: while the 16 MFMAs of k-step kk run, the fragments of kk+1 are on their way
+    double af[2][G::MI], bf[2][G::MI];
+    auto read_frags = [&](const double* As, const double* Bs, int kk, int set) {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi) af[set][mi] = frag_read<A_KC, TILE>(As, kk, wm * G::WT + mi * 16, lane);
+#pragma unroll
+        for (int ni = 0; ni < G::MI; ++ni) bf[set][ni] = frag_read<B_KC, TILE>(Bs, kk, wn * G::WT + ni * 16, lane);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::MI; ++ni)
+                // first operand indexes the result row (= j), second the result
+                // column (= i = lane&15): stores become 128 B contiguous in i.
+                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
+    };
+
     if (nk > 0) {
-        stage_load<A_KC, TILE>(a.A, a.lda, i0, kbeg, tid, ga);
-        stage_load<B_KC, TILE>(a.B, a.ldb, j0, kbeg, tid, gb);
+        stage_load<TILE>(stage_base<A_KC>(a.A, a.lda, i0, kbeg), offa, ga);
+        stage_load<TILE>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg), offb, gb);
         stage_store<A_KC, TILE>(lds, tid, ga);
         stage_store<B_KC, TILE>(lds + G::OPBUF, tid, gb);
     }
     __syncthreads();
+    if (nk > 0) read_frags(lds, lds + G::OPBUF, 0, 0);
 
+    // One barrier per slab, placed BEFORE the last k-step: the slab boundary (barrier skew + LDS latency of the next
+    // slab's first fragments) is covered by that k-step's 16 MFMAs instead of leaving the MFMA pipe idle.
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         const double* As = lds + cur * 2 * G::OPBUF;
         const double* Bs = As + G::OPBUF;
+        double* An = lds + (cur ^ 1) * 2 * G::OPBUF;
         const bool more = (t + 1 < nk);
         if (more) {
-            stage_load<A_KC, TILE>(a.A, a.lda, i0, kbeg + (t + 1) * 16, tid, ga);
-            stage_load<B_KC, TILE>(a.B, a.ldb, j0, kbeg + (t + 1) * 16, tid, gb);
+            stage_load<TILE>(stage_base<A_KC>(a.A, a.lda, i0, kbeg + (t + 1) * 16), offa, ga);
+            stage_load<TILE>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg + (t + 1) * 16), offb, gb);
         }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double af[G::MI], bf[G::MI];
-#pragma unroll
-            for (int mi = 0; mi < G::MI; ++mi) af[mi] = frag_read<A_KC, TILE>(As, kk, wm * G::WT + mi * 16, lane);
-#pragma unroll
-            for (int ni = 0; ni < G::MI; ++ni) bf[ni] = frag_read<B_KC, TILE>(Bs, kk, wn * G::WT + ni * 16, lane);
-#pragma unroll
-            for (int mi = 0; mi < G::MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < G::MI; ++ni)
-                    // first operand indexes the result row (= j), second the result
-                    // column (= i = lane&15): stores become 128 B contiguous in i.
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-        }
+        read_frags(As, Bs, 1, 1);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(As, Bs, 2, 0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(As, Bs, 3, 1);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            double* An = lds + (cur ^ 1) * 2 * G::OPBUF;
             stage_store<A_KC, TILE>(An, tid, ga);
             stage_store<B_KC, TILE>(An + G::OPBUF, tid, gb);
         }
         __syncthreads();
+        if (more) read_frags(An, An + G::OPBUF, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // epilogue: acc[mi][ni][r] = C(i = i0+wm*WT+mi*16+(lane&15), j = j0+wn*WT+ni*16+(lane>>4)+4r)
     const bool mirror = a.mirror && (it != jt);
+    double* cbase = a.C + (size_t)(j0 + wn * G::WT + (lane >> 4)) * a.ldc + i0 + wm * G::WT + (lane & 15);
+    if (a.beta != 0.0) {
+        // C tile read in batches of 8 independent loads before it is combined (not one load-wait per element)
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi) {
+#pragma unroll
+            for (int n2 = 0; n2 < G::MI; n2 += 2) {
+                double cold[2][4];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cold[ni][r] = cbase[(size_t)((n2 + ni) * 16 + 4 * r) * a.ldc + mi * 16];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mi][n2 + ni][r] = a.alpha * acc[mi][n2 + ni][r] + a.beta * cold[ni][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::MI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = a.alpha * acc[mi][ni][r];
+    }
 #pragma unroll
     for (int mi = 0; mi < G::MI; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < G::MI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int i = i0 + wm * G::WT + mi * 16 + (lane & 15);
-                int j = j0 + wn * G::WT + ni * 16 + (lane >> 4) + 4 * r;
-                double* c = a.C + (size_t)j * a.ldc + i;
-                double v = a.alpha * acc[mi][ni][r];
-                if (a.beta != 0.0) v += a.beta * (*c);
-                *c = v;
-                if (mirror) a.C[(size_t)i * a.ldc + j] = v;
+                double v = acc[mi][ni][r];
+                cbase[(size_t)(ni * 16 + 4 * r) * a.ldc + mi * 16] = v;
+                if (mirror) {
+                    int i = i0 + wm * G::WT + mi * 16 + (lane & 15);
+                    int j = j0 + wn * G::WT + ni * 16 + (lane >> 4) + 4 * r;
+                    a.C[(size_t)i * a.ldc + j] = v;
+                }
             }
         }
     }

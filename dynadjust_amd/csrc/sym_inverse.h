@@ -17,8 +17,9 @@ struct GemmProfile {
     double flops = 0.0;      // actual flops issued by gemm launches since reset
     double gemm_ms = 0.0;    // summed event time of gemm launches (after collect())
     uint64_t launches = 0;
-    std::vector<hipEvent_t> pool;  // start/stop pairs
+    std::vector<hipEvent_t> pool;  // start/stop pairs, one pair per run of consecutive gemm launches
     size_t used = 0;
+    bool open = false;       // a run is in progress (start event recorded, stop event pending)
 };
 
 // Workspace shared by every inverse run on one stream ("chain").
@@ -51,6 +52,7 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
 
 // sum the event timings recorded so far (synchronises the stream)
 void gemm_profile_collect(InvWorkspace& ws);
+void gemm_profile_close(InvWorkspace& ws);   // ends the current run of gemm launches (call before enqueuing any other kernel)
 void gemm_profile_reset(InvWorkspace& ws);
 
 }  // namespace dnagpu

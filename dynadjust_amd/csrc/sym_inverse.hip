@@ -73,30 +73,42 @@ hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a) {
     return hipSuccess;
 }
 
+// HIP-event timing of the GEMM launches (bench.py's roofline): one event pair brackets every maximal RUN of
+// consecutive gemm launches on the stream (a run ends when any other kernel is enqueued: gemm_profile_close).
+// Bracketing every single launch cost 3 % of a cfg3 step (1 600 extra barrier packets per inverse); runs cost < 1 %.
+static void profile_event(GemmProfile& p, hipStream_t s) {
+    if (p.used + 1 > p.pool.size()) {
+        hipEvent_t ev;
+        hipEventCreate(&ev);
+        p.pool.push_back(ev);
+    }
+    hipEventRecord(p.pool[p.used++], s);
+}
+
+void gemm_profile_close(InvWorkspace& ws) {
+    GemmProfile& p = ws.prof;
+    if (!p.open) return;
+    profile_event(p, ws.stream);
+    p.open = false;
+}
+
 void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
     if (gemm_attach_order(ws, a) != hipSuccess) return;
     GemmProfile& p = ws.prof;
     if (p.enabled) {
-        if (p.used + 2 > p.pool.size()) {
-            for (int i = 0; i < 2; ++i) {
-                hipEvent_t ev;
-                hipEventCreate(&ev);
-                p.pool.push_back(ev);
-            }
+        if (!p.open) {
+            profile_event(p, ws.stream);
+            p.open = true;
         }
-        hipEventRecord(p.pool[p.used], ws.stream);
-        launch_gemm(a, akc, bkc, ws.stream);
-        hipEventRecord(p.pool[p.used + 1], ws.stream);
-        p.used += 2;
         p.flops += gemm_flops(a);
         p.launches++;
-    } else {
-        launch_gemm(a, akc, bkc, ws.stream);
     }
+    launch_gemm(a, akc, bkc, ws.stream);
 }
 
 void gemm_profile_collect(InvWorkspace& ws) {
     GemmProfile& p = ws.prof;
+    gemm_profile_close(ws);
     hipStreamSynchronize(ws.stream);
     for (size_t i = 0; i + 1 < p.used; i += 2) {
         float ms = 0.f;
@@ -111,6 +123,7 @@ void gemm_profile_reset(InvWorkspace& ws) {
     ws.prof.gemm_ms = 0.0;
     ws.prof.launches = 0;
     ws.prof.used = 0;
+    ws.prof.open = false;
 }
 
 namespace {
@@ -134,7 +147,10 @@ struct Rec {
 
     void node(int o, int s) {
         if (s == 1) {
-            if (!dry) launch_leaf(F, ld, ws.X, ld, o * 128, ws.info, ws.stream);
+            if (!dry) {
+                gemm_profile_close(ws);
+                launch_leaf(F, ld, ws.X, ld, o * 128, ws.info, ws.stream);
+            }
             return;
         }
         int h = s / 2;
@@ -196,6 +212,7 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
     a.mt = T; a.nt = T; a.K = (int)np;
     a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
     dnagpu::gemm(ws, a, 1, 1);
+    gemm_profile_close(ws);
     if (scale_to_unity) launch_scale_sym(F, ws.svec, n, np, 0, ws.stream);
     hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, ws.stream);
 }
