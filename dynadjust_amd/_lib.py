@@ -73,7 +73,8 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()')")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # kernel-tuning experiments (tools/build_variant.sh) load an alternative build of the same library
+    lib = C.CDLL(os.environ.get("DNAGPU_LIB_OVERRIDE") or LIB_PATH, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     i = C.c_int
     u32 = C.c_uint32

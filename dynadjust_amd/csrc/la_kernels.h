@@ -22,6 +22,7 @@ struct GemmArgs {
     const uint32_t* order;  // device table: (it << 16 | jt) per workgroup, 0xffffffff = idle
     int grid;               // number of workgroups (= table length)
     int tile;               // block tile of the launch: 128 (throughput) or 64 (small launches)
+    int k_ascending = 0;    // diagnostic: 1 = walk k upwards also for the k >= i / k >= j ranges (see gemm_f64_dma_kernel)
 };
 
 // launches with fewer 128-tiles than this run on 64x64 block tiles

@@ -22,6 +22,9 @@
 // Flop count n^3/3 + n^3/3 + n^3/3 = the reference's dpotrf + dpotri.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
 #include "la_kernels.h"
 
 namespace dnagpu {
@@ -35,34 +38,44 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 //   A_KC = true : A(i,k) at A[k + i*lda]   (k-contiguous,  "T")
 //   B_KC = false: B(k,j) at B[j + k*ldb]   ("T": B given as its transpose)
 //   B_KC = true : B(k,j) at B[k + j*ldb]   ("N")
-// 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4 MFMA
-// 16x16 accumulators (128 VGPRs).  LDS is double buffered, one barrier per
-// BK=16 slab.  LDS layouts are chosen so that the MFMA fragment reads
-// (ds_read_b64, two 32-lane groups) are bank-conflict free:
-//   R layout  [k][row]      row stride 144 doubles (k+1 lands 32 banks away)
-//   P layout  [k/2][col][2] pair stride 258 doubles (32 lanes read 256 B contiguous)
+// A workgroup owns a TILE x TILE block of C; its WAVES waves form a 2 x (WAVES/2) grid, each wave a
+// (TILE/2) x (TILE/(WAVES/2)) sub-tile of 16x16 MFMA accumulators.  LDS is double buffered, one barrier per
+// BK=16 slab.  LDS layouts are chosen so that the MFMA fragment reads (ds_read_b64, two 32-lane groups) are
+// bank-conflict free:
+//   R layout  [k][row]      row stride TILE+16 doubles (k+1 lands 32 banks away)
+//   P layout  [k/2][col][2] pair stride 2*TILE+2 doubles (32 lanes read 256 B contiguous)
+//
+// Occupancy is the design parameter (probe: tools/probes/mfma_f64_peak.hip).  One wave issues
+// v_mfma_f64_16x16x4_f64 back to back at only 46 % of the pipe's rate (36 of 78.6 TFLOP/s with one wave per SIMD);
+// two waves per SIMD reach 99 % -- but only while BOTH are issuing.  With 4 waves x 64x64 (128 accumulator
+// VGPRs, 2 waves per SIMD) every barrier / LDS / address instruction of one wave halves the SIMD's MFMA rate and
+// the kernel saturates at 89 % busy.  The throughput shape is therefore 8 waves x 64x32 (64 accumulator VGPRs,
+// <= 128 VGPRs per wave, 2 workgroups per CU = 4 waves per SIMD): any three of the four can keep the pipe full.
 // ----------------------------------------------------------------------------
-// Two block-tile sizes share the code: TILE = 128 (4 waves x 64x64, the throughput shape, ~70 TFLOP/s)
-// and TILE = 64 (4 waves x 32x32) for the small nodes of the recursion, where a launch has only a
-// handful of 128-tiles and latency, not throughput, is what matters (4x the workgroups, 1/4 the k-loop time).
-template <int TILE>
+// Shapes: TILE = 128 / 8 waves (throughput), TILE = 128 / 4 waves (kept for comparison, DNAGPU_GEMM_WAVES=4), and
+// TILE = 64 / 4 waves x 32x32 for the small nodes of the recursion, where a launch has only a handful of
+// 128-tiles and latency, not throughput, is what matters (4x the workgroups, 1/4 the k-loop time).
+template <int TILE, int WAVES>
 struct Geo {
+    static constexpr int NT = 64 * WAVES;       // threads per workgroup
     static constexpr int LDR = TILE + 16;       // R layout row stride: k+1 lands 32 banks away
     static constexpr int LDP = 2 * TILE + 2;    // P layout pair stride
     static constexpr int OPBUF = 16 * LDR;      // doubles per operand buffer (>= 8 * LDP)
-    static constexpr int NQ = TILE / 32;        // 16-byte loads per thread per operand slab
-    static constexpr int WT = TILE / 2;         // wave tile
-    static constexpr int MI = WT / 16;          // MFMA tiles per wave per dimension
+    static constexpr int NQ = TILE * 8 / NT;    // 16-byte loads per thread per operand slab
+    static constexpr int WTM = TILE / 2;        // wave tile rows
+    static constexpr int WTN = TILE / (WAVES / 2);   // wave tile columns
+    static constexpr int MI = WTM / 16;         // MFMA tiles per wave along i
+    static constexpr int NI = WTN / 16;         // MFMA tiles per wave along j
 };
 
 // Global -> register staging of one BK=16 operand slab.  The per-thread part of the address is loop invariant
 // (a 32-bit byte offset, computed once); the slab position is wave-uniform and travels in the scalar base, so the
-// main loop issues `global_load_dwordx4 v, v_off, s[base]` with no vector address arithmetic.
-template <bool KC, int TILE>
-__device__ __forceinline__ void stage_offsets(int ld, int tid, uint32_t (&off)[Geo<TILE>::NQ]) {
+// main loop has no vector address arithmetic beyond one 64-bit add per load.
+template <bool KC, int TILE, int WAVES>
+__device__ __forceinline__ void stage_offsets(int ld, int tid, uint32_t (&off)[Geo<TILE, WAVES>::NQ]) {
 #pragma unroll
-    for (int q = 0; q < Geo<TILE>::NQ; ++q) {
-        int idx = tid + 256 * q;
+    for (int q = 0; q < Geo<TILE, WAVES>::NQ; ++q) {
+        int idx = tid + Geo<TILE, WAVES>::NT * q;
         if (!KC) {
             int k = idx / (TILE / 2), r2 = idx % (TILE / 2);
             off[q] = (uint32_t)(k * ld + 2 * r2) * 8u;
@@ -78,38 +91,82 @@ __device__ __forceinline__ const char* stage_base(const double* __restrict__ P, 
     return reinterpret_cast<const char*>(KC ? P + (size_t)r0 * ld + k0 : P + (size_t)k0 * ld + r0);
 }
 
-template <int TILE>
-__device__ __forceinline__ void stage_load(const char* base, const uint32_t (&off)[Geo<TILE>::NQ], d2 (&g)[Geo<TILE>::NQ]) {
+template <int NQ>
+__device__ __forceinline__ void stage_load(const char* base, const uint32_t (&off)[NQ], d2 (&g)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < Geo<TILE>::NQ; ++q) g[q] = *reinterpret_cast<const d2*>(base + off[q]);
+    for (int q = 0; q < NQ; ++q) g[q] = *reinterpret_cast<const d2*>(base + off[q]);
 }
 
-template <bool KC, int TILE>
-__device__ __forceinline__ void stage_store(double* buf, int tid, const d2 (&g)[Geo<TILE>::NQ]) {
+template <bool KC, int TILE, int WAVES>
+__device__ __forceinline__ void stage_store(double* buf, int tid, const d2 (&g)[Geo<TILE, WAVES>::NQ]) {
+    using G = Geo<TILE, WAVES>;
 #pragma unroll
-    for (int q = 0; q < Geo<TILE>::NQ; ++q) {
-        int idx = tid + 256 * q;
+    for (int q = 0; q < G::NQ; ++q) {
+        int idx = tid + G::NT * q;
         if (!KC) {
             int k = idx / (TILE / 2), r2 = idx % (TILE / 2);
-            *reinterpret_cast<d2*>(buf + k * Geo<TILE>::LDR + 2 * r2) = g[q];
+            *reinterpret_cast<d2*>(buf + k * G::LDR + 2 * r2) = g[q];
         } else {
             int k2 = idx & 7, c = idx >> 3;
-            *reinterpret_cast<d2*>(buf + k2 * Geo<TILE>::LDP + 2 * c) = g[q];
+            *reinterpret_cast<d2*>(buf + k2 * G::LDP + 2 * c) = g[q];
         }
     }
 }
 
-template <bool KC, int TILE>
+template <bool KC, int TILE, int WAVES>
 __device__ __forceinline__ double frag_read(const double* buf, int kk, int rbase, int lane) {
     int k = kk * 4 + (lane >> 4);
     int r = rbase + (lane & 15);
-    if (!KC) return buf[k * Geo<TILE>::LDR + r];
-    return buf[(k >> 1) * Geo<TILE>::LDP + r * 2 + (k & 1)];
+    if (!KC) return buf[k * Geo<TILE, WAVES>::LDR + r];
+    return buf[(k >> 1) * Geo<TILE, WAVES>::LDP + r * 2 + (k & 1)];
 }
 
-template <bool A_KC, bool B_KC, int TILE>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
-    using G = Geo<TILE>;
+// ---- global -> LDS without a register round trip (global_load_lds_dwordx4, TILE = 128 only) ---------------------
+// One wave instruction moves 64 lanes x 16 B and lands them CONTIGUOUSLY (lane order) at a wave-uniform LDS address,
+// so the layouts are chosen such that every wave instruction fills one contiguous 1 KiB piece:
+//   R layout (row-contiguous operand): piece = one k-row of 128 doubles, rows LDR apart (as before);
+//   S layout (k-contiguous operand)  : piece = "chunk" of 8 columns x 16 k.  Inside a chunk the 16-byte unit of column c
+//       (0..7) and k-pair k2 (0..7) sits at position c*8 + ((k2 + (c>>1) + 4*(chunk&1)) & 7): lanes 8c..8c+7 still read
+//       one 128 B line of column c (coalesced), and the rotation makes the MFMA fragment reads (16 columns x 4 k per
+//       ds_read_b64) hit 32 different bank pairs per half wave.
+template <bool KC, int TILE, int WAVES>
+__device__ __forceinline__ void dma_offsets(int ld, int wave, int lane, uint32_t (&off)[Geo<TILE, WAVES>::NQ]) {
+#pragma unroll
+    for (int q = 0; q < Geo<TILE, WAVES>::NQ; ++q) {
+        const int piece = wave + WAVES * q;          // k-row (R) or chunk (S), 0..15
+        if (!KC) {
+            off[q] = (uint32_t)(piece * ld + 2 * lane) * 8u;
+        } else {
+            const int c = lane >> 3, x = lane & 7, k2 = (x - (c >> 1) - 4 * (piece & 1)) & 7;
+            off[q] = (uint32_t)((piece * 8 + c) * ld + 2 * k2) * 8u;
+        }
+    }
+}
+
+template <bool KC, int TILE, int WAVES>
+__device__ __forceinline__ void dma_issue(const char* base, const uint32_t (&off)[Geo<TILE, WAVES>::NQ], double* buf, int wave) {
+#pragma unroll
+    for (int q = 0; q < Geo<TILE, WAVES>::NQ; ++q) {
+        const int piece = wave + WAVES * q;
+        double* dst = buf + (KC ? piece * 128 : piece * Geo<TILE, WAVES>::LDR);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[q]),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+// fragment element (row/col r, k) of the S layout
+template <int TILE, int WAVES>
+__device__ __forceinline__ double frag_read_s(const double* buf, int kk, int rbase, int lane) {
+    const int k = kk * 4 + (lane >> 4);
+    const int r = rbase + (lane & 15);
+    const int chunk = r >> 3, c = r & 7;
+    const int x = ((k >> 1) + (c >> 1) + 4 * (chunk & 1)) & 7;
+    return buf[chunk * 128 + (c * 8 + x) * 2 + (k & 1)];
+}
+
+template <bool A_KC, bool B_KC, int TILE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArgs a) {   // 2nd argument: waves per SIMD (2 workgroups per CU)
+    using G = Geo<TILE, WAVES>;
     __shared__ __attribute__((aligned(16))) double lds[4 * G::OPBUF];
     // tile order table built on the host (tile_order.hip): workgroup b runs on XCD b%8,
     // every XCD walks its own work-balanced list of 2-D super-tiles (L2 locality).
@@ -135,86 +192,117 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
     const int wm = wave & 1, wn = wave >> 1;
     const int i0 = it * TILE, j0 = jt * TILE;
 
-    d4 acc[G::MI][G::MI];
+    d4 acc[G::MI][G::NI];
 #pragma unroll
     for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < G::MI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int ni = 0; ni < G::NI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
     d2 ga[G::NQ], gb[G::NQ];
     uint32_t offa[G::NQ], offb[G::NQ];
-    stage_offsets<A_KC, TILE>(a.lda, tid, offa);
-    stage_offsets<B_KC, TILE>(a.ldb, tid, offb);
+    stage_offsets<A_KC, TILE, WAVES>(a.lda, tid, offa);
+    stage_offsets<B_KC, TILE, WAVES>(a.ldb, tid, offb);
     const int nk = (kend - kbeg) / 16;
 
-    // MFMA fragments, two register sets: while the 16 MFMAs of k-step kk run, the fragments of kk+1 are on their way
-    double af[2][G::MI], bf[2][G::MI];
+    // MFMA fragments, two register sets: while the MFMAs of k-step kk run, the fragments of kk+1 are on their way
+    double af[2][G::MI], bf[2][G::NI];
     auto read_frags = [&](const double* As, const double* Bs, int kk, int set) {
 #pragma unroll
-        for (int mi = 0; mi < G::MI; ++mi) af[set][mi] = frag_read<A_KC, TILE>(As, kk, wm * G::WT + mi * 16, lane);
+        for (int mi = 0; mi < G::MI; ++mi) af[set][mi] = frag_read<A_KC, TILE, WAVES>(As, kk, wm * G::WTM + mi * 16, lane);
 #pragma unroll
-        for (int ni = 0; ni < G::MI; ++ni) bf[set][ni] = frag_read<B_KC, TILE>(Bs, kk, wn * G::WT + ni * 16, lane);
+        for (int ni = 0; ni < G::NI; ++ni) bf[set][ni] = frag_read<B_KC, TILE, WAVES>(Bs, kk, wn * G::WTN + ni * 16, lane);
     };
     auto mfmas = [&](int set) {
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < G::MI; ++ni)
+            for (int ni = 0; ni < G::NI; ++ni)
                 // first operand indexes the result row (= j), second the result
                 // column (= i = lane&15): stores become 128 B contiguous in i.
                 acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
     };
 
     if (nk > 0) {
-        stage_load<TILE>(stage_base<A_KC>(a.A, a.lda, i0, kbeg), offa, ga);
-        stage_load<TILE>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg), offb, gb);
-        stage_store<A_KC, TILE>(lds, tid, ga);
-        stage_store<B_KC, TILE>(lds + G::OPBUF, tid, gb);
+        stage_load<G::NQ>(stage_base<A_KC>(a.A, a.lda, i0, kbeg), offa, ga);
+        stage_load<G::NQ>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg), offb, gb);
+        stage_store<A_KC, TILE, WAVES>(lds, tid, ga);
+        stage_store<B_KC, TILE, WAVES>(lds + G::OPBUF, tid, gb);
     }
     __syncthreads();
     if (nk > 0) read_frags(lds, lds + G::OPBUF, 0, 0);
 
     // One barrier per slab, placed BEFORE the last k-step: the slab boundary (barrier skew + LDS latency of the next
-    // slab's first fragments) is covered by that k-step's 16 MFMAs instead of leaving the MFMA pipe idle.
-    for (int t = 0; t < nk; ++t) {
+    // slab's first fragments) is covered by that k-step's MFMAs.
+    //
+    // Issue order inside each k-step (sched_group_barrier): the global loads, fragment reads and LDS stores are spread
+    // between the MFMAs instead of being issued in clusters.  A cluster of 8 global_load_dwordx4 at the top of the slab
+    // alone costs 7 % of the MFMA rate (tools/probes/mfma_f64_feed.hip: 71.6 -> 66.1 TFLOP/s; spread out: 69.1).
+    // The slab body is branch free (the last slab, which stages nothing, is peeled) so that the scheduler can do that.
+    constexpr int NM = G::MI * G::NI;                 // MFMAs per k-step
+    constexpr int NL = 2 * G::NQ;                     // global loads / LDS stores per slab
+    constexpr int NR = G::MI + G::NI;                 // fragment reads per k-step (before ds_read2 merging)
+    auto slab = [&](int t, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
         const int cur = t & 1;
         const double* As = lds + cur * 2 * G::OPBUF;
         const double* Bs = As + G::OPBUF;
         double* An = lds + (cur ^ 1) * 2 * G::OPBUF;
-        const bool more = (t + 1 < nk);
         if (more) {
-            stage_load<TILE>(stage_base<A_KC>(a.A, a.lda, i0, kbeg + (t + 1) * 16), offa, ga);
-            stage_load<TILE>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg + (t + 1) * 16), offb, gb);
+            stage_load<G::NQ>(stage_base<A_KC>(a.A, a.lda, i0, kbeg + (t + 1) * 16), offa, ga);
+            stage_load<G::NQ>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg + (t + 1) * 16), offb, gb);
         }
         read_frags(As, Bs, 1, 1);
         mfmas(0);
+#pragma unroll
+        for (int g = 0; g < NL; ++g) {
+            if (more) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);      // NM/NL MFMA
+        }
         __builtin_amdgcn_sched_barrier(0);
         read_frags(As, Bs, 2, 0);
         mfmas(1);
+#pragma unroll
+        for (int g = 0; g < NR / 2; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / (NR / 2), 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         read_frags(As, Bs, 3, 1);
         mfmas(0);
-        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            stage_store<A_KC, TILE>(An, tid, ga);
-            stage_store<B_KC, TILE>(An + G::OPBUF, tid, gb);
+            stage_store<A_KC, TILE, WAVES>(An, tid, ga);
+            stage_store<B_KC, TILE, WAVES>(An + G::OPBUF, tid, gb);
         }
+#pragma unroll
+        for (int g = 0; g < NL; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);
+            if (more) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 DS write
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         if (more) read_frags(An, An + G::OPBUF, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         mfmas(1);
+#pragma unroll
+        for (int g = 0; g < NR / 2; ++g) {
+            if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / (NR / 2), 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    for (int t = 0; t + 1 < nk; ++t) slab(t, std::true_type{});
+    if (nk > 0) slab(nk - 1, std::false_type{});
 
-    // epilogue: acc[mi][ni][r] = C(i = i0+wm*WT+mi*16+(lane&15), j = j0+wn*WT+ni*16+(lane>>4)+4r)
+    // epilogue: acc[mi][ni][r] = C(i = i0+wm*WTM+mi*16+(lane&15), j = j0+wn*WTN+ni*16+(lane>>4)+4r)
     const bool mirror = a.mirror && (it != jt);
-    double* cbase = a.C + (size_t)(j0 + wn * G::WT + (lane >> 4)) * a.ldc + i0 + wm * G::WT + (lane & 15);
+    double* cbase = a.C + (size_t)(j0 + wn * G::WTN + (lane >> 4)) * a.ldc + i0 + wm * G::WTM + (lane & 15);
     if (a.beta != 0.0) {
         // C tile read in batches of 8 independent loads before it is combined (not one load-wait per element)
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi) {
 #pragma unroll
-            for (int n2 = 0; n2 < G::MI; n2 += 2) {
+            for (int n2 = 0; n2 < G::NI; n2 += 2) {
                 double cold[2][4];
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
@@ -230,21 +318,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < G::MI; ++ni)
+            for (int ni = 0; ni < G::NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mi][ni][r] = a.alpha * acc[mi][ni][r];
     }
 #pragma unroll
     for (int mi = 0; mi < G::MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < G::MI; ++ni) {
+        for (int ni = 0; ni < G::NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double v = acc[mi][ni][r];
                 cbase[(size_t)(ni * 16 + 4 * r) * a.ldc + mi * 16] = v;
                 if (mirror) {
-                    int i = i0 + wm * G::WT + mi * 16 + (lane & 15);
-                    int j = j0 + wn * G::WT + ni * 16 + (lane >> 4) + 4 * r;
+                    int i = i0 + wm * G::WTM + mi * 16 + (lane & 15);
+                    int j = j0 + wn * G::WTN + ni * 16 + (lane >> 4) + 4 * r;
                     a.C[(size_t)i * a.ldc + j] = v;
                 }
             }
@@ -252,25 +340,231 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs a) {
     }
 }
 
-template <int TILE>
-static void launch_gemm_t(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
-    dim3 grid(a.grid), block(256);
+// The throughput kernel: TILE = 128, operands staged with LDS-DMA (no staging registers, no ds_write), two separate
+// LDS buffers (distinct __shared__ objects, so that the compiler knows a DMA into one never aliases the fragment
+// reads of the other and does not serialise them behind vmcnt).
+template <bool A_KC, bool B_KC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(GemmArgs a) {
+    constexpr int TILE = 128;
+    using G = Geo<TILE, WAVES>;
+    __shared__ __attribute__((aligned(16))) double lds0[2 * G::OPBUF];
+    __shared__ __attribute__((aligned(16))) double lds1[2 * G::OPBUF];
+    const uint32_t packed = a.order[blockIdx.x];
+    if (packed == 0xffffffffu) return;
+    const int it = (int)(packed >> 16), jt = (int)(packed & 0xffffu);
+    int kbeg = 0, kend = a.K;
+    switch (a.kmode) {
+        case KM_LE_J: kend = (jt + 1) * 128; break;
+        case KM_GE_J: kbeg = jt * 128; break;
+        case KM_LE_I: kend = (it + 1) * 128; break;
+        case KM_GE_I: kbeg = it * 128; break;
+        default: break;
+    }
+    if (kend > a.K) kend = a.K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int i0 = it * TILE, j0 = jt * TILE;
+
+    d4 acc[G::MI][G::NI];
+#pragma unroll
+    for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    uint32_t offa[G::NQ], offb[G::NQ];
+    dma_offsets<A_KC, TILE, WAVES>(a.lda, wave, lane, offa);
+    dma_offsets<B_KC, TILE, WAVES>(a.ldb, wave, lane, offb);
+    const int nk = (kend - kbeg) / 16;
+
+    double af[2][G::MI], bf[2][G::NI];
+    auto read_frags = [&](const double* As, const double* Bs, int kk, int set) {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+            af[set][mi] = A_KC ? frag_read_s<TILE, WAVES>(As, kk, wm * G::WTM + mi * 16, lane)
+                               : frag_read<false, TILE, WAVES>(As, kk, wm * G::WTM + mi * 16, lane);
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni)
+            bf[set][ni] = B_KC ? frag_read_s<TILE, WAVES>(Bs, kk, wn * G::WTN + ni * 16, lane)
+                               : frag_read<false, TILE, WAVES>(Bs, kk, wn * G::WTN + ni * 16, lane);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
+    };
+    // Triangular ranges that END at a common k (k >= i, k >= j) are walked downwards: the workgroups of a super-tile,
+    // which share operand panels in their XCD's L2, then start together at the common end and stay in step, instead of
+    // each starting at its own first k and drifting apart by (tile distance) x 128 for the whole run.
+    const bool down = (a.kmode == KM_GE_J || a.kmode == KM_GE_I) && !a.k_ascending;
+    auto issue = [&](int t, double* buf) {
+        const int k0 = down ? kend - (t + 1) * 16 : kbeg + t * 16;
+        dma_issue<A_KC, TILE, WAVES>(stage_base<A_KC>(a.A, a.lda, i0, k0), offa, buf, wave);
+        dma_issue<B_KC, TILE, WAVES>(stage_base<B_KC>(a.B, a.ldb, j0, k0), offb, buf + G::OPBUF, wave);
+    };
+
+    if (nk > 0) issue(0, lds0);
+    __syncthreads();
+    if (nk > 0) read_frags(lds0, lds0 + G::OPBUF, 0, 0);
+
+    constexpr int NM = G::MI * G::NI;                 // MFMAs per k-step
+    constexpr int NL = 2 * G::NQ;                     // DMA instructions per slab
+    constexpr int NR = G::MI + G::NI;                 // fragment reads per k-step (before ds_read2 merging)
+    // slab t lives in `cur`; the DMA for slab t+1 goes to `nxt` (free since the barrier of slab t-1); one barrier per
+    // slab, placed before the last k-step (see gemm_f64_kernel)
+    auto slab = [&](int t, const double* cur, double* nxt, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        const double* As = cur;
+        const double* Bs = cur + G::OPBUF;
+        if (more) issue(t + 1, nxt);
+        read_frags(As, Bs, 1, 1);
+        mfmas(0);
+#pragma unroll
+        for (int g = 0; g < NL; ++g) {
+            if (more) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);      // MFMAs
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(As, Bs, 2, 0);
+        mfmas(1);
+#pragma unroll
+        for (int g = 0; g < NR / 2; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / (NR / 2), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(As, Bs, 3, 1);
+        mfmas(0);
+#pragma unroll
+        for (int g = 0; g < NR / 2; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / (NR / 2), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                  // (waits for this wave's DMA: vmcnt(0))
+        if (more) read_frags(nxt, nxt + G::OPBUF, 0, 0);
+        mfmas(1);
+#pragma unroll
+        for (int g = 0; g < NR / 2; ++g) {
+            if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / (NR / 2), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // k ranges are multiples of 128, so the slab count is even: slabs go in (lds0, lds1) pairs, the last pair peeled
+    for (int t = 0; t + 2 < nk; t += 2) {
+        slab(t, lds0, lds1, std::true_type{});
+        slab(t + 1, lds1, lds0, std::true_type{});
+    }
+    if (nk > 0) {
+        slab(nk - 2, lds0, lds1, std::true_type{});
+        slab(nk - 1, lds1, lds0, std::false_type{});
+    }
+
+    // epilogue (as gemm_f64_kernel)
+    const bool mirror = a.mirror && (it != jt);
+    double* cbase = a.C + (size_t)(j0 + wn * G::WTN + (lane >> 4)) * a.ldc + i0 + wm * G::WTM + (lane & 15);
+    if (a.beta != 0.0) {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi) {
+#pragma unroll
+            for (int n2 = 0; n2 < G::NI; n2 += 2) {
+                double cold[2][4];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cold[ni][r] = cbase[(size_t)((n2 + ni) * 16 + 4 * r) * a.ldc + mi * 16];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mi][n2 + ni][r] = a.alpha * acc[mi][n2 + ni][r] + a.beta * cold[ni][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = a.alpha * acc[mi][ni][r];
+    }
+#pragma unroll
+    for (int mi = 0; mi < G::MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = acc[mi][ni][r];
+                cbase[(size_t)(ni * 16 + 4 * r) * a.ldc + mi * 16] = v;
+                if (mirror) {
+                    int i = i0 + wm * G::WTM + mi * 16 + (lane & 15);
+                    int j = j0 + wn * G::WTN + ni * 16 + (lane >> 4) + 4 * r;
+                    a.C[(size_t)i * a.ldc + j] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WAVES>
+static void launch_gemm_dma(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
+    dim3 grid(a.grid), block(64 * WAVES);
     if (!a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, false, TILE>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_dma_kernel<false, false, WAVES>), grid, block, 0, s, a);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true, TILE>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_dma_kernel<false, true, WAVES>), grid, block, 0, s, a);
     else if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f64_kernel<true, true, TILE>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_dma_kernel<true, true, WAVES>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((gemm_f64_kernel<true, false, TILE>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_f64_dma_kernel<true, false, WAVES>), grid, block, 0, s, a);
+}
+
+template <int TILE, int WAVES>
+static void launch_gemm_t(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
+    dim3 grid(a.grid), block(64 * WAVES);
+    if (!a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f64_kernel<false, false, TILE, WAVES>), grid, block, 0, s, a);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true, TILE, WAVES>), grid, block, 0, s, a);
+    else if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f64_kernel<true, true, TILE, WAVES>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_f64_kernel<true, false, TILE, WAVES>), grid, block, 0, s, a);
+}
+
+// DNAGPU_GEMM_VARIANT selects the 128-tile kernel for A/B comparisons: "dma4" (default), "dma8", "reg8", "reg4"
+static int gemm_variant_128() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DNAGPU_GEMM_VARIANT");
+        v = 1;
+        if (e && !strcmp(e, "dma8")) v = 0;
+        if (e && !strcmp(e, "reg8")) v = 2;
+        if (e && !strcmp(e, "reg4")) v = 3;
+    }
+    return v;
 }
 
 void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
     if (a.grid <= 0) return;
-    if (a.tile == 64)
-        launch_gemm_t<64>(a, a_kc, b_kc, s);
-    else
-        launch_gemm_t<128>(a, a_kc, b_kc, s);
+    if (a.tile == 64) {
+        launch_gemm_t<64, 4>(a, a_kc, b_kc, s);
+        return;
+    }
+    static const int k_asc = getenv("DNAGPU_K_ASCENDING") ? 1 : 0;   // diagnostic A/B switch
+    GemmArgs b = a;
+    b.k_ascending = k_asc;
+    switch (gemm_variant_128()) {
+        case 1: launch_gemm_dma<4>(b, a_kc, b_kc, s); break;
+        case 2: launch_gemm_t<128, 8>(b, a_kc, b_kc, s); break;
+        case 3: launch_gemm_t<128, 4>(b, a_kc, b_kc, s); break;
+        default: launch_gemm_dma<8>(b, a_kc, b_kc, s); break;
+    }
 }
 
 // ----------------------------------------------------------------------------
