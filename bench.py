@@ -190,7 +190,7 @@ def main():
 
     a = adjust.DnaAdjust()
     p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode,
-                               multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "0"))), device=local_rank)
+                               multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank)
     a.PrepareAdjustment(p)
     lib = a.lib
     ctx = a.device_context()
@@ -243,7 +243,8 @@ def main():
             "workload": desc,
             "stations": stations, "baselines": info["baselines"], "measurement_rows": info["measurement_rows"], "blocks": blocks,
             "max_block_unknowns": info["max_block_unknowns"], "iterations_to_converge": iters, "solves_per_step": solves,
-            "mode": "phased" if phased else "simultaneous", "parallelism": "1 GPU, one chain" if not p.multi_thread else "1 GPU, two chains",
+            "mode": "phased" if phased else "simultaneous", "parallelism": "1 GPU, one chain" if not p.multi_thread else
+            "1 GPU, two chains (the reference's --multi-thread schedule: forward || reverse passes on two streams, combination solves shared)",
         },
         "cholesky_tflops": (sum_n3 / 1e12) / (ms_per_step / 1e3),
         "roofline": {

@@ -70,4 +70,5 @@ struct dnagpu_ctx {
     int* bad_dev = nullptr;
     std::map<uint32_t, dnagpu::Block> blocks;
     bool profile = false;
+    double profile_ms_acc = 0.0;   // union length of the timed GEMM runs collected so far (dnagpu_profile_get)
 };

@@ -253,20 +253,50 @@ int dnagpu_profile_reset(dnagpu_ctx* ctx) {
         HIPCHK(hipStreamSynchronize(ctx->stream[c]));
         gemm_profile_reset(ctx->ws[c]);
     }
+    ctx->profile_ms_acc = 0.0;
     return DNAGPU_OK;
 }
 int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uint64_t* launches) {
     CHK_CTX();
-    double f = 0, ms = 0;
+    // gemm_ms = length of the UNION of the timed GEMM runs of all chains: with one chain this is the plain sum of
+    // the run durations; with two chains (multi-thread mode) runs of the two streams overlap in time and share the
+    // machine, and summing them would count that time twice.
+    double f = 0;
     uint64_t l = 0;
+    hipEvent_t base = nullptr;
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        gemm_profile_collect(ctx->ws[c]);
-        f += ctx->ws[c].prof.flops;
-        ms += ctx->ws[c].prof.gemm_ms;
-        l += ctx->ws[c].prof.launches;
+        gemm_profile_close(ctx->ws[c]);
+        HIPCHK(hipStreamSynchronize(ctx->stream[c]));
+        if (!base && ctx->ws[c].prof.used) base = ctx->ws[c].prof.pool[0];
     }
+    std::vector<std::pair<float, float>> iv;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        GemmProfile& p = ctx->ws[c].prof;
+        for (size_t i = 0; i + 1 < p.used; i += 2) {
+            float t0 = 0.f, dt = 0.f;
+            hipEventElapsedTime(&t0, base, p.pool[i]);
+            hipEventElapsedTime(&dt, p.pool[i], p.pool[i + 1]);
+            iv.emplace_back(t0, t0 + dt);
+        }
+        p.used = 0;
+        f += p.flops;
+        l += p.launches;
+    }
+    std::sort(iv.begin(), iv.end());
+    double ms = 0.0;
+    float cur_end = -1e30f;
+    for (const auto& x : iv) {
+        if (x.first >= cur_end) {
+            ms += x.second - x.first;
+            cur_end = x.second;
+        } else if (x.second > cur_end) {
+            ms += x.second - cur_end;
+            cur_end = x.second;
+        }
+    }
+    ctx->profile_ms_acc += ms;
     if (gemm_flops) *gemm_flops = f;
-    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_ms) *gemm_ms = ctx->profile_ms_acc;
     if (launches) *launches = l;
     return DNAGPU_OK;
 }

@@ -6,6 +6,7 @@
 // Reference functions restated per step are cited at each function (ADJ = dynadjust/dnaadjust/dnaadjust.cpp).
 #include <cmath>
 #include <condition_variable>
+#include <deque>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -167,12 +168,45 @@ void dna_adjust::AdjustPhasedReverseCombine() {
 // One iteration with the forward chain on chain 0 and the reverse + combine chain on chain 1, each driven by
 // its own host thread (dnaadjust-multi.cpp:365 adjust_forward_thread, :475 adjust_reverse_thread, :593 combine).
 // combine(k) waits until the forward thread has published jfwd[k-1] (concurrent_block_adjustment, dnathreading.hpp:44).
+// Two chains (stream + workspace each) of one GPU, driven by two host threads like the reference's forward and reverse
+// threads (dnaadjust-multi.cpp:92-244); the combination solves, which the reference hands to a third pool
+// (combineAdjustmentQueue, dnaadjust-multi.cpp:428-434), are taken from a ready queue by whichever chain is free:
+// the forward chain once its pass is finished, the reverse chain after its last block.  Two inverses in flight
+// overlap the latency-bound leaves / small GEMMs of one with the large GEMMs of the other (tools/gpu_two_chain_probe.py:
+// 1.11x); every block step is the same code on the same data as the single-chain schedule, so results are identical.
 void dna_adjust::AdjustPhasedMultiThreadIteration() {
     std::mutex m;
     std::condition_variable cv;
     int fwd_done = -1;           // highest block whose forward junctions are complete
-    bool fwd_failed = false;
+    bool failed = false;         // any thread threw: everybody stops waiting
+    bool rev_done = false;       // the reverse pass will queue no further combination solves
+    std::deque<UINT32> ready;    // blocks whose reverse solve is done and whose combination solve is pending
     std::exception_ptr fwd_error, rev_error;
+
+    // combination solves until the queue is empty and the reverse pass is over
+    auto drain = [&](int c) {
+        for (;;) {
+            UINT32 k;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return failed || (!ready.empty() && fwd_done >= (int)ready.front() - 1) || (ready.empty() && rev_done); });
+                if (failed || IsCancelled()) return;
+                if (ready.empty()) return;
+                k = ready.front();
+                ready.pop_front();
+            }
+            double mv = PhasedCombineBlock(c, k);
+            PhasedNoteCorrection(mv);
+            PhasedFinaliseBlock(c, k);
+        }
+    };
+    auto fail = [&] {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            failed = true;
+        }
+        cv.notify_all();
+    };
 
     std::thread fwd([&] {
         try {
@@ -185,39 +219,50 @@ void dna_adjust::AdjustPhasedMultiThreadIteration() {
                 }
                 cv.notify_all();
             }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                fwd_done = (int)blockCount_;
+            }
+            cv.notify_all();
+            drain(0);
         } catch (...) {
             fwd_error = std::current_exception();
-            std::lock_guard<std::mutex> lk(m);
-            fwd_failed = true;
+            fail();
         }
-        {
-            std::lock_guard<std::mutex> lk(m);
-            fwd_done = (int)blockCount_;
-        }
-        cv.notify_all();
     });
     try {
         const int c = 1;
         for (UINT32 kk = blockCount_; kk-- > 0;) {
             if (IsCancelled()) break;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (failed) break;
+            }
             const UINT32 k = kk;
             const blockMeta_t& meta = v_blockMeta_[k];
             if (meta._blockIsolated) continue;
             double mv = PhasedReverseBlock(c, k);
             if (CombineRequired(k)) {
                 {
-                    std::unique_lock<std::mutex> lk(m);
-                    cv.wait(lk, [&] { return fwd_done >= (int)k - 1 || fwd_failed; });
-                    if (fwd_failed) break;
+                    std::lock_guard<std::mutex> lk(m);
+                    ready.push_back(k);
                 }
-                mv = PhasedCombineBlock(c, k);
+                cv.notify_all();
+                continue;
             }
             if (meta._blockLast) continue;
             PhasedNoteCorrection(mv);
             PhasedFinaliseBlock(c, k);
         }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            rev_done = true;
+        }
+        cv.notify_all();
+        drain(c);
     } catch (...) {
         rev_error = std::current_exception();
+        fail();
     }
     fwd.join();
     if (fwd_error) std::rethrow_exception(fwd_error);   // dnaadjust-multi.cpp:182-190

@@ -73,10 +73,12 @@ int dnagpu_cholesky_inverse_packed(dnagpu_ctx* ctx, double* ap, uint32_t n, int 
 int dnagpu_multiply_sym_packed(dnagpu_ctx* ctx, const double* ap, const double* x, double* y, uint32_t n);
 
 /* ---- profiling ------------------------------------------------------------ */
-/* enable/disable per-launch HIP-event timing of the tile-GEMM kernel */
+/* enable/disable HIP-event timing of the tile-GEMM kernel: one event pair on the launch stream around every run of
+ * consecutive GEMM launches */
 int dnagpu_profile_enable(dnagpu_ctx* ctx, int on);
 int dnagpu_profile_reset(dnagpu_ctx* ctx);
-/* gemm_flops: flops actually issued; gemm_ms: summed kernel time; launches */
+/* gemm_flops: flops actually issued; gemm_ms: time during which at least one timed GEMM run was executing (union over
+ * the chains' streams: equals the summed run durations with one chain); launches */
 int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uint64_t* launches);
 
 /* ---- device-resident work matrices ----------------------------------------
