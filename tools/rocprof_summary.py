@@ -25,6 +25,7 @@ def stats(d, out, header):
     per = defaultdict(lambda: [0, 0.0])
     t0, t1 = None, None
     n = 0
+    gemm_iv = []
     for path in _find(d, "kernel_trace.csv"):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -35,10 +36,25 @@ def stats(d, out, header):
                 t0 = s if t0 is None else min(t0, s)
                 t1 = e if t1 is None else max(t1, e)
                 n += 1
+                if "gemm_f64" in row["Kernel_Name"]:
+                    gemm_iv.append((s, e))
     tot = sum(v[1] for v in per.values())
+    # time during which at least one gemm kernel was executing (kernels of two streams overlap in multi-thread mode);
+    # this is what bench.py reports as roofline.gemm_ms_per_step
+    gemm_iv.sort()
+    union, end = 0, None
+    for s, e in gemm_iv:
+        if end is None or s >= end:
+            union += e - s
+            end = e
+        elif e > end:
+            union += e - end
+            end = e
     with open(out, "w") as f:
         f.write("# %s\n" % header)
         f.write("# kernel dispatches: %d, first start -> last end: %.3f s   (durations in microseconds)\n" % (n, (t1 - t0) / 1e9))
+        f.write("# gemm_f64* kernels: %d dispatches, summed duration %.3f s, union of their intervals %.3f s\n"
+                % (len(gemm_iv), sum(e - s for s, e in gemm_iv) / 1e9, union / 1e9))
         f.write("%-112s %7s %14s %12s %7s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, (c, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             f.write("%-112s %7d %14.1f %12.3f %7.2f\n" % (name[:112], c, us, us / c, 100.0 * us / tot))
