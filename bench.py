@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("DNAGPU_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reuse-inverses", action="store_true",
+                    help="phased GNSS-only networks: keep the block inverses of the first iteration in HBM and reuse them "
+                         "(identical results, half the Solve() calls; NOT what the reference does in phased mode, so not the default)")
     ap.add_argument("--no-gemm-events", action="store_true", help="diagnostic: no HIP events around the GEMM launches (roofline.achieved = 0)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
@@ -190,7 +193,8 @@ def main():
 
     a = adjust.DnaAdjust()
     p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode,
-                               multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank)
+                               multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank,
+                               reuse_inverses=phased and args.reuse_inverses)
     a.PrepareAdjustment(p)
     lib = a.lib
     ctx = a.device_context()
@@ -243,7 +247,7 @@ def main():
             "workload": desc,
             "stations": stations, "baselines": info["baselines"], "measurement_rows": info["measurement_rows"], "blocks": blocks,
             "max_block_unknowns": info["max_block_unknowns"], "iterations_to_converge": iters, "solves_per_step": solves,
-            "mode": "phased" if phased else "simultaneous", "parallelism": "1 GPU, one chain" if not p.multi_thread else
+            "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses), "parallelism": "1 GPU, one chain" if not p.multi_thread else
             "1 GPU, two chains (the reference's --multi-thread schedule: forward || reverse passes on two streams, combination solves shared)",
         },
         "cholesky_tflops": (sum_n3 / 1e12) / (ms_per_step / 1e3),

@@ -33,7 +33,7 @@ class DnaAdjSettings(C.Structure):
                 ("adjust_mode", C.c_int), ("multi_thread", C.c_int), ("max_iterations", C.c_int),
                 ("iteration_threshold", C.c_float), ("free_std_dev", C.c_double), ("fixed_std_dev", C.c_double),
                 ("scale_normals_to_unity", C.c_int), ("device", C.c_int), ("confidence_interval", C.c_float),
-                ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p)]
+                ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int)]
 
 
 class DnaAdjStatistics(C.Structure):

@@ -913,18 +913,20 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
     CHK_CTX();
     CHK_CHAIN();
     Block* b = find_block(ctx, blk_from);
-    if (!b || !src || !jm || (k && !idx_from) || 3 * k > jm->n_max || src->n != 3 * b->n_stn)
+    if (!b || !jm || (k && !idx_from) || 3 * k > jm->n_max || (src && src->n != 3 * b->n_stn) || (!src && jm->n != 3 * k))
         return fail(ctx, DNAGPU_EINVAL, "junction_gather: bad arguments");
     for (size_t i = 0; i < k; ++i)
         if (idx_from[i] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "junction_gather: station out of range");
-    jm->n = (uint32_t)(3 * k);
-    jm->np = pad128(jm->n);
-    launch_init_padded(jm->F, jm->n, jm->np, ctx->stream[chain]);
+    if (src) {
+        jm->n = (uint32_t)(3 * k);
+        jm->np = pad128(jm->n);
+        launch_init_padded(jm->F, jm->n, jm->np, ctx->stream[chain]);
+    }
     if (!k) return DNAGPU_OK;
     uint32_t* didx = nullptr;
     int rc = stage_u32(ctx, chain, idx_from, k, &didx);
     if (rc) return rc;
-    launch_junction_gather(src->F, src->np, didx, (uint32_t)k, jm->F, jm->np, ctx->stream[chain]);
+    if (src) launch_junction_gather(src->F, src->np, didx, (uint32_t)k, jm->F, jm->np, ctx->stream[chain]);
     launch_gather_vec3(b->x_est[chain], didx, (uint32_t)k, jm->jest, ctx->stream[chain]);
     return DNAGPU_OK;
 }

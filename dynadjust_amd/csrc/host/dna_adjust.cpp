@@ -32,7 +32,9 @@ void dna_adjust::FreeDevice() {
         if (b.jfwd) dnagpu_matrix_destroy(ctx_, b.jfwd);
         if (b.jrev) dnagpu_matrix_destroy(ctx_, b.jrev);
         if (b.rigvar) dnagpu_matrix_destroy(ctx_, b.rigvar);
-        b.jfwd = b.jrev = b.rigvar = nullptr;
+        if (b.finv) dnagpu_matrix_destroy(ctx_, b.finv);
+        if (b.rinv) dnagpu_matrix_destroy(ctx_, b.rinv);
+        b.jfwd = b.jrev = b.rigvar = b.finv = b.rinv = nullptr;
     }
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
         if (work_[c]) dnagpu_matrix_destroy(ctx_, work_[c]);
@@ -667,6 +669,7 @@ void dna_adjust::ResetAdjustment() {
         Check(dnagpu_block_set_stations(ctx_, b, initial_xyz_[b].data()), b, "ResetAdjustment()");
         for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "ResetAdjustment()");
         blocks_[b].has_rigvar = false;
+        blocks_[b].has_finv = blocks_[b].has_rinv = blocks_[b].has_cinv = false;
     }
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
     currentIteration_ = 0;

@@ -122,6 +122,10 @@ private:
         dnagpu_matrix* jrev = nullptr;        // v_junctionVariances_ (reverse) + v_junctionEstimatesRev_
         dnagpu_matrix* rigvar = nullptr;      // v_rigorousVariances_
         bool has_rigvar = false;
+        // a.reuse_inverses: the inverse of the forward / reverse normals of this block (the combined one is rigvar)
+        dnagpu_matrix* finv = nullptr;
+        dnagpu_matrix* rinv = nullptr;
+        bool has_finv = false, has_rinv = false, has_cinv = false;
         std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_
     };
 
@@ -177,6 +181,10 @@ private:
     void SolveTry(int chain, UINT32 block, dnagpu_matrix* m);
     void AddConstraints(int chain, dnagpu_matrix* m, const constraint_list& c, int sign, UINT32 block);
     void StoreRigorousVariances(int chain, UINT32 block, dnagpu_matrix* W);
+    // the matrix a block step forms its normals in: the chain's work matrix, or with a.reuse_inverses the block's own
+    // resident matrix for that step (kind 0 forward, 1 reverse, 2 combination / rigorous)
+    dnagpu_matrix* StepMatrix(int chain, UINT32 block, int kind);
+    bool ReuseInverses() const { return projectSettings_.a.reuse_inverses != 0; }
     void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
     void Check(int rc, UINT32 block, const char* where);
     void SetmaxCorr(double v) { maxCorr_ = v; }

@@ -21,22 +21,47 @@ void dna_adjust::PhasedNoteCorrection(double mv) {
     if (std::fabs(mv) > std::fabs(maxCorr_)) SetmaxCorr(mv);
 }
 
+// The matrix a block step works in.  Without a.reuse_inverses: the chain's work matrix (the reference's v_normals_).
+// With it: a resident matrix per block and step kind, so that the inverse survives the iteration -- the forward inverse
+// of a last / isolated block and the reverse inverse of a first block ARE that block's rigorous variances and share
+// their matrix with them.
+dnagpu_matrix* dna_adjust::StepMatrix(int c, UINT32 k, int kind) {
+    if (!ReuseInverses()) return work_[c];
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    dnagpu_matrix** slot = &B.rigvar;
+    if (kind == 0 && !(meta._blockLast || meta._blockIsolated)) slot = &B.finv;
+    if (kind == 1 && !meta._blockFirst) slot = &B.rinv;
+    if (!*slot) {
+        std::lock_guard<std::mutex> lk(alloc_mutex_);
+        Check(dnagpu_matrix_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, slot), k, "resident block inverse");
+    }
+    return *slot;
+}
+
 // AdjustPhasedForward body for one block: Solve (ADJ:2812), UpdateEstimatesForward (ADJ:3022),
 // CarryForwardJunctions (ADJ:3065) -> CarryStnEstimatesandVariancesForward (ADJ:998)
 double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
-    dnagpu_matrix* W = work_[c];
+    dnagpu_matrix* W = StepMatrix(c, k, 0);
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
     const bool carried_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
-    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
-    AddConstraints(c, W, B.con_fwd, +1, k);
-    if (carried_in)
-        Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
-              "CarryStnEstimatesandVariancesForward()");
+    const bool reuse = ReuseInverses() && B.has_finv;      // W already holds this step's inverse (earlier iteration)
+    if (!reuse) {
+        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        AddConstraints(c, W, B.con_fwd, +1, k);
+        if (carried_in)
+            Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
+                  "CarryStnEstimatesandVariancesForward()");
+    }
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (carried_in)
         Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
-    SolveTry(c, k, W);
+    if (reuse)
+        Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
+    else
+        SolveTry(c, k, W);
+    B.has_finv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
     Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesForward()");
@@ -49,37 +74,46 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
     if (meta._blockIsolated || meta._blockLast) return mv;
     if (v_blockMeta_[k + 1]._blockIsolated) return mv;
     if (B.jsl_here.empty()) return mv;
-    Check(dnagpu_junction_gather(ctx_, c, k, W, B.jsl_here.data(), B.jsl_here.size(), B.jfwd), k, "CarryStnEstimatesandVariancesForward()");
-    Check(dnagpu_invert(ctx_, c, B.jfwd, 0), k, "CarryStnEstimatesandVariancesForward()");
+    // junction variances (gathered from the inverse and inverted) only change with the inverse; the estimates always
+    Check(dnagpu_junction_gather(ctx_, c, k, reuse ? nullptr : W, B.jsl_here.data(), B.jsl_here.size(), B.jfwd), k,
+          "CarryStnEstimatesandVariancesForward()");
+    if (!reuse) Check(dnagpu_invert(ctx_, c, B.jfwd, 0), k, "CarryStnEstimatesandVariancesForward()");
     return mv;
 }
 
 // AdjustPhasedReverseCombine, reverse part for one block: PrepareAdjustmentReverse (ADJ:3112), Solve (ADJ:3512),
 // UpdateEstimatesReverse (ADJ:3678), CarryReverseJunctions (ADJ:3833) -> CarryStnEstimatesandVariancesReverse (ADJ:1133)
 double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
-    dnagpu_matrix* W = work_[c];
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
     if (meta._blockIsolated) return 0.0;
+    dnagpu_matrix* W = StepMatrix(c, k, 1);
     const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
     const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
+    const bool reuse = ReuseInverses() && B.has_rinv;
     // estimates back to the originals (ADJ:3157 for the last block, ADJ:3863 for the others)
     Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentReverse()");
-    // normals = measurements + junctions carried in reverse + constraints (first appearance in reverse)
-    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
-    if (rev_in)
-        Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
-    AddConstraints(c, W, B.con_rev, +1, k);
+    if (!reuse) {
+        // normals = measurements + junctions carried in reverse + constraints (first appearance in reverse)
+        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        if (rev_in)
+            Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
+        AddConstraints(c, W, B.con_rev, +1, k);
+    }
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
-    SolveTry(c, k, W);
+    if (reuse)
+        Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
+    else
+        SolveTry(c, k, W);
+    B.has_rinv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
     Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesReverse()");
     if (!meta._blockFirst && fwd_in) {
-        Check(dnagpu_junction_gather(ctx_, c, k, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jrev), k,
+        Check(dnagpu_junction_gather(ctx_, c, k, reuse ? nullptr : W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jrev), k,
               "CarryStnEstimatesandVariancesReverse()");
-        Check(dnagpu_invert(ctx_, c, blocks_[k - 1].jrev, 0), k, "CarryStnEstimatesandVariancesReverse()");
+        if (!reuse) Check(dnagpu_invert(ctx_, c, blocks_[k - 1].jrev, 0), k, "CarryStnEstimatesandVariancesReverse()");
     }
     return mv;
 }
@@ -87,47 +121,57 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
 // PrepareAdjustmentCombine (ADJ:3336) -> CarryStnEstimatesandVariancesCombine (ADJ:3196), Solve (ADJ:3556),
 // UpdateEstimatesCombine (ADJ:3718)
 double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
-    dnagpu_matrix* W = work_[c];
+    dnagpu_matrix* W = StepMatrix(c, k, 2);
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
     const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
     const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
+    const bool reuse = ReuseInverses() && B.has_cinv;
     Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentCombine()");
-    // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed in the
-    // same summation order, which gives the same bits
-    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
-    if (rev_in)
-        Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesCombine()");
-    AddConstraints(c, W, B.con_rev, +1, k);
-    if (fwd_in)
-        Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
-              "CarryStnEstimatesandVariancesCombine()");
-    AddConstraints(c, W, B.con_cmb, -1, k);
+    if (!reuse) {
+        // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed in the
+        // same summation order, which gives the same bits
+        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        if (rev_in)
+            Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesCombine()");
+        AddConstraints(c, W, B.con_rev, +1, k);
+        if (fwd_in)
+            Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
+                  "CarryStnEstimatesandVariancesCombine()");
+        AddConstraints(c, W, B.con_cmb, -1, k);
+    }
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
     if (fwd_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
-    SolveTry(c, k, W);
+    if (reuse)
+        Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
+    else
+        SolveTry(c, k, W);
+    B.has_cinv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
     Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesCombine()");
     return mv;
 }
 
-// v_rigorousVariances_[k] = the inverse currently held by the chain's work matrix
+// v_rigorousVariances_[k] = the inverse currently held by W (a copy, unless W already is the block's resident matrix)
 void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
     block_t& B = blocks_[k];
-    if (!B.rigvar) {
-        std::lock_guard<std::mutex> lk(alloc_mutex_);
-        Check(dnagpu_matrix_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, &B.rigvar), k, "rigorous variance matrix");
+    if (W != B.rigvar) {
+        if (!B.rigvar) {
+            std::lock_guard<std::mutex> lk(alloc_mutex_);
+            Check(dnagpu_matrix_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, &B.rigvar), k, "rigorous variance matrix");
+        }
+        Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesFinal()");
     }
-    Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesFinal()");
     B.has_rigvar = true;
 }
 
 // UpdateEstimatesFinal (ADJ:3744) for a block that is not the last of its network
 void dna_adjust::PhasedFinaliseBlock(int c, UINT32 k) {
     Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesFinal()");   // rigorous = estimated
-    StoreRigorousVariances(c, k, work_[c]);
+    // the inverse of the block's last solve: reverse for a first block, combination otherwise
+    StoreRigorousVariances(c, k, StepMatrix(c, k, v_blockMeta_[k]._blockFirst ? 1 : 2));
     Check(dnagpu_block_copy_stations(ctx_, c, k, 0, 2), k, "UpdateEstimatesFinal()");   // original = rigorous
     Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
 }

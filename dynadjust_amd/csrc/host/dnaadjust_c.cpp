@@ -86,6 +86,7 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         p.a.device = s->device;
         if (s->confidence_interval > 0.0f) p.a.confidence_interval = s->confidence_interval;
         p.o._adj_msr_tstat = (uint16_t)(s->output_tstat ? 1 : 0);
+        p.a.reuse_inverses = (uint16_t)(s->reuse_inverses ? 1 : 0);
         if (s->network_name) p.g.network_name = s->network_name;
         if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);

@@ -191,6 +191,11 @@ struct adjust_settings {
     UINT16 multi_thread = 0;
     UINT16 stage = 0;
     UINT16 scale_normals_to_unity = 0;
+    // Not in the reference (device path only): keep every block's forward / reverse / combined inverse resident and
+    // reuse it from the second iteration on.  For a GNSS-only network neither the design nor the weights change between
+    // iterations, so those inverses are bit-identical every time; the reference exploits this in simultaneous mode only
+    // (dnaadjust.cpp:2457).  Costs two more n x n matrices per block in HBM.
+    UINT16 reuse_inverses = 0;
     float iteration_threshold = 0.0005f;
     double free_std_dev = 10.0;
     double fixed_std_dev = 1.0e-6;   // PRECISION_1E6

@@ -39,6 +39,8 @@ typedef struct {
     int output_tstat;          /* o._adj_msr_tstat: fill measurement_t::TStat in dnaadj_generate_statistics */
     const char* network_name;  /* g.network_name   -> <output_folder>/<network_name>-rva.mtx / -pam.mtx (may be NULL) */
     const char* output_folder; /* g.output_folder (may be NULL = ".") */
+    int reuse_inverses;        /* device path only (default 0): phased GNSS-only networks keep the block inverses of the first
+                                  iteration in HBM and reuse them afterwards (identical results, half the solves) */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0

@@ -156,7 +156,9 @@ int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs);
 /* A junction set = k stations; idx_from / idx_to are their block-local station
  * indices in the source and destination block. */
 /* jm (order 3k) <- rows/cols of src (N^-1) at stations idx; jest (3k, device vector
- * owned by the junction matrix) <- estimated coordinates of those stations */
+ * owned by the junction matrix) <- estimated coordinates of those stations.
+ * src == NULL: only the estimates are refreshed, the matrix already held by jm stays (it does not change between the
+ * iterations of a GNSS-only network) */
 int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const dnagpu_matrix* src, const uint32_t* idx_from,
                            size_t k, dnagpu_matrix* jm);
 /* dst[idx,idx] += jm (3x3 blocks), and rhs_extra of blk_to gets the pseudo

@@ -408,3 +408,32 @@ def test_results_out_files(built, orc, tmp_path):
     a2.GenerateStatistics()
     assert abs(a2.GetChiSquared() - chi) < 1e-6 * chi
     a2.close()
+
+
+@pytest.mark.parametrize("mt", [False, True])
+def test_reuse_inverses_is_identical(built, tmp_path, mt):
+    """a.reuse_inverses (device path only): the block inverses of the first iteration are kept and reused -- for a GNSS-only
+    network they are the same bits every iteration, so every result must be IDENTICAL, with half the Solve() calls"""
+    adjust.write_synthetic_network(str(tmp_path), "r", 14, 12, 0, 5, seed=9, x_clusters=20, y_cluster=True, initial_sigma=0.4)
+    runs = []
+    for reuse in (False, True):
+        a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_inverses=reuse)
+        assert st == 0 and a.CurrentIteration() >= 2
+        a.GenerateStatistics()
+        runs.append((a.CurrentIteration(), a.solve_count(), [a.block_estimates(b) for b in range(a.blockCount())],
+                     [a.block_variances_packed(b) for b in range(a.blockCount())], a.GetChiSquared(),
+                     [a.GetIterationCorrection(i + 1) for i in range(a.CurrentIteration())]))
+        a.close()
+    (it0, n0, x0, v0, c0, corr0), (it1, n1, x1, v1, c1, corr1) = runs
+    B = len(x0)
+    assert it0 == it1 and corr0 == corr1 and c0 == c1
+    assert n0 == it0 * (3 * B - 2) and n1 == 3 * B - 2
+    for b in range(B):
+        assert np.array_equal(x0[b], x1[b]) and np.array_equal(v0[b], v1[b])
+    # a second AdjustNetwork on the same object starts over (ResetAdjustment drops the resident inverses)
+    a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_inverses=True)
+    a.ResetAdjustment()
+    assert a.AdjustNetwork() == 0 and a.solve_count() == 3 * B - 2
+    for b in range(B):
+        assert np.array_equal(a.block_estimates(b), x0[b])
+    a.close()
