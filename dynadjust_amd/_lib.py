@@ -46,7 +46,8 @@ class DnaAdjStatistics(C.Structure):
 
 class DnaSynthSpec(C.Structure):
     _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("n_baselines", C.c_uint64), ("n_blocks", C.c_uint32),
-                ("seed", C.c_uint64), ("initial_sigma", C.c_double), ("x_clusters", C.c_uint32), ("y_cluster", C.c_uint32)]
+                ("seed", C.c_uint64), ("initial_sigma", C.c_double), ("x_clusters", C.c_uint32), ("y_cluster", C.c_uint32),
+                ("y_llh", C.c_uint32), ("scalars", C.c_uint32)]
 
 
 class DnaSynthSummary(C.Structure):

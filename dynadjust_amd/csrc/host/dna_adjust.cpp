@@ -10,6 +10,7 @@
 #include <sstream>
 
 #include "geodesy.hpp"
+#include "gnss_vcv.hpp"
 
 namespace dynadjust {
 namespace networkadjust {
@@ -269,33 +270,66 @@ void dna_adjust::ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B) {
         ss << "UpdateNormals(): measurement type '" << type << "' is not handled by the device path yet (GNSS types G, X, Y only).";
         SignalExceptionAdjustment(ss.str(), block);
     }
-    if (type == 'Y' && strncmp(first.coordType, "XYZ", 3) != 0)
-        SignalExceptionAdjustment("UpdateDesignNormalMeasMatrices_Y(): GPS point clusters must be cartesian (XYZ) for the device path.", block);
-    // LoadVarianceScaling (ADJ:4453): the matrix scalar is applied on the fly, partial scalars are not handled yet
+    // a Y cluster may be given as latitude / longitude / height (orthometric "LLH" or ellipsoidal "LLh")
+    const bool llH = type == 'Y' && strncmp(first.coordType, "LLH", 3) == 0;
+    const bool llh = type == 'Y' && strncmp(first.coordType, "LLh", 3) == 0;
+    const bool geographic = llH || llh;
+    if (type == 'Y' && !geographic && strncmp(first.coordType, "XYZ", 3) != 0)
+        SignalExceptionAdjustment("UpdateDesignNormalMeasMatrices_Y(): unknown coordinate type of a GPS point cluster.", block);
+    // LoadVarianceScaling (ADJ:4453-4491).  A "reduced" .bms was written by an earlier adjustment: its variances are
+    // already scaled and propagated (ADJ:4190-4211)
+    const bool reduced = bms_meta_.reduced;
     const double tiny = std::min(PRECISION_1E5, projectSettings_.a.fixed_std_dev);
-    double vScale = first.scale4;
-    if (vScale < tiny) vScale = 1.0;
-    // a "reduced" .bms was written by an earlier adjustment: its variances are already scaled (ADJ:4190-4211)
-    const bool scaleMatrix = !bms_meta_.reduced && std::fabs(vScale - 1.0) > PRECISION_1E5;
-    auto unit = [&](double s) { return s < tiny ? 1.0 : s; };
-    if (!bms_meta_.reduced && (std::fabs(unit(first.scale1) - 1.0) > PRECISION_1E5 || std::fabs(unit(first.scale2) - 1.0) > PRECISION_1E5 ||
-        std::fabs(unit(first.scale3) - 1.0) > PRECISION_1E5))
-        SignalExceptionAdjustment("LoadVarianceScaling(): phi/lambda/height variance scalars are not handled by the device path yet.", block);
+    auto unit = [&](double v) { return v < tiny ? 1.0 : v; };
+    double vScale = unit(first.scale4), pScale = unit(first.scale1), lScale = unit(first.scale2), hScale = unit(first.scale3);
+    const bool scaleMatrix = !reduced && std::fabs(vScale - 1.0) > PRECISION_1E5;
+    const bool scalePartial = !reduced && (std::fabs(pScale - 1.0) > PRECISION_1E5 || std::fabs(lScale - 1.0) > PRECISION_1E5 ||
+                                           std::fabs(hScale - 1.0) > PRECISION_1E5);
+    if (scalePartial && scaleMatrix) {
+        pScale *= vScale;
+        lScale *= vScale;
+        hScale *= vScale;
+    }
     const UINT32 k = (type == 'G') ? 1 : first.vectorCount1;
     if (k == 0) SignalExceptionAdjustment("PrepareAdjustment(): a GNSS cluster without vectors.", block);
     const UINT32 nc = 3 * k;
     std::vector<double> V((size_t)nc * nc, 0.0);   // column-major, both triangles
+    std::vector<double> positions(3 * (size_t)k);  // where each vector's geographic frame is formed (ADJ:4352, ADJ:4572)
+    // G / X: the matrix scalar is applied on the fly (ADJ:4236, ADJ:4360); Y: afterwards (ADJ:4650)
+    const double fly = (type != 'Y' && scaleMatrix) ? vScale : 1.0;
     auto put = [&](UINT32 r, UINT32 c, double v) {
-        if (scaleMatrix) v *= vScale;
+        if (fly != 1.0) v *= fly;
         V[(size_t)c * nc + r] = v;
         V[(size_t)r * nc + c] = v;
     };
     size_t idx = m;
     for (UINT32 j = 0; j < k; ++j) {
         if (idx + 2 >= bmsBinaryRecords_.size()) SignalExceptionAdjustment("PrepareAdjustment(): truncated GNSS cluster.", block);
-        const measurement_t& mx = bmsBinaryRecords_[idx];
-        const measurement_t& my = bmsBinaryRecords_[idx + 1];
-        const measurement_t& mz = bmsBinaryRecords_[idx + 2];
+        measurement_t& mx = bmsBinaryRecords_[idx];
+        measurement_t& my = bmsBinaryRecords_[idx + 1];
+        measurement_t& mz = bmsBinaryRecords_[idx + 2];
+        const station_t& at = bstBinaryRecords_.at(mx.station1);
+        positions[3 * j] = at.currentLatitude;
+        positions[3 * j + 1] = at.currentLongitude;
+        positions[3 * j + 2] = at.currentHeight;
+        if (geographic && !reduced) {
+            // UpdateDesignNormalMeasMatrices_Y (ADJ:6281-6318): the point becomes cartesian once and for all; the
+            // original values stay in preAdjMeas, the original frame in station3
+            double ellipsoidHeight = mz.term1;
+            mx.preAdjMeas = mx.term1;
+            my.preAdjMeas = my.term1;
+            mz.preAdjMeas = mz.term1;
+            if (llH && std::fabs(at.geoidSep) > 1.0e-4) {
+                mz.preAdjCorr = at.geoidSep;
+                ellipsoidHeight += mz.preAdjCorr;
+            }
+            double x, y, z;
+            geodesy::GeoToCart(mx.term1, my.term1, ellipsoidHeight, &x, &y, &z);
+            mx.term1 = x;
+            my.term1 = y;
+            mz.term1 = z;
+            mx.station3 = llH ? 2u : 1u;   // "retain original reference frame" (ADJ:6317); _COORD_TYPE_: LLh_type_i = 1, LLH_type_i = 2
+        }
         B.obs.push_back(mx.term1);
         B.obs.push_back(my.term1);
         B.obs.push_back(mz.term1);
@@ -328,8 +362,30 @@ void dna_adjust::ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B) {
             idx += 3;
         }
     }
-    if (scaleMatrix) {
-        // SetGPSVarianceMatrix (ADJ:4282): the scaled variances replace the ones held in memory, so that the
+    bool changed = fly != 1.0;
+    if (type != 'Y') {
+        if (scalePartial) {
+            gnssvcv::ScaleGPSVCV(V, k, positions, pScale, lScale, hScale, false);       // ADJ:4263 / ADJ:4418
+            changed = true;
+        }
+    } else if (!reduced) {
+        if (scalePartial) {
+            gnssvcv::ScaleGPSVCV(V, k, positions, pScale, lScale, hScale, geographic);  // ADJ:4633
+            changed = true;
+        } else if (geographic) {
+            gnssvcv::PropagateGeoCart(V, k, positions, true);                            // ADJ:4640
+            changed = true;
+        }
+        if (scaleMatrix && !scalePartial) {
+            for (double& v : V) v *= vScale;                                             // ADJ:4650
+            changed = true;
+        }
+    }
+    if (geographic && !reduced) {
+        for (size_t r = m; r < idx; ++r) snprintf(bmsBinaryRecords_[r].coordType, sizeof(bmsBinaryRecords_[r].coordType), "%s", "XYZ");
+    }
+    if (changed) {
+        // SetGPSVarianceMatrix (ADJ:4282): the scaled / propagated variances replace the ones held in memory, so that the
         // statistics (sigma zero, Pelzer reliability, ...) see what the adjustment used
         size_t r = m;
         for (UINT32 j = 0; j < k; ++j) {

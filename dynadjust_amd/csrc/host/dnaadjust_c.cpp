@@ -231,6 +231,8 @@ int dnasynth_write_network(const char* dir, const char* name, const dnasynth_spe
         if (spec->initial_sigma > 0) sp.initial_sigma = spec->initial_sigma;
         sp.x_clusters = spec->x_clusters;
         sp.y_cluster = spec->y_cluster != 0;
+        sp.y_llh = spec->y_llh != 0;
+        sp.scalars = spec->scalars != 0;
         dynadjust::synth::Summary sm;
         dynadjust::synth::write_network(dir, name, sp, &sm);
         if (out) {

@@ -13,6 +13,7 @@
 
 #include "dnaio.hpp"
 #include "geodesy.hpp"
+#include "gnss_vcv.hpp"
 
 namespace dynadjust {
 namespace synth {
@@ -241,12 +242,66 @@ void write_network(const std::string& dir, const std::string& name, const Spec& 
             for (int i = 0; i < 6; ++i)
                 for (int q = 0; q < 6; ++q) Vs[i * 6 + q] = V[(size_t)(6 * off + i) * 12 + 6 * off + q];
         };
+        // sp.y_llh: the point clusters are written the way a geodetic campaign supplies them, latitude / longitude /
+        // height with a variance matrix in that frame (radians^2, m^2): the first with ellipsoidal heights ("LLh"), the
+        // second with orthometric heights ("LLH", reduced with the stations' geoid separation)
+        auto to_geographic = [&](const std::vector<uint32_t>& pts, std::vector<double>& Vs, std::vector<double>& os, bool ortho) {
+            const uint32_t k = (uint32_t)pts.size(), nc = 3 * k;
+            std::vector<double> Vc((size_t)nc * nc), llh(3 * (size_t)k);
+            for (uint32_t i = 0; i < nc; ++i)
+                for (uint32_t q = 0; q < nc; ++q) Vc[(size_t)q * nc + i] = Vs[(size_t)i * nc + q];   // row-major -> column-major
+            for (uint32_t j = 0; j < k; ++j) {
+                station_t& st = bst[pts[j]];
+                if (ortho) st.geoidSep = 7.25f + 0.5f * (float)j;
+                llh[3 * j] = st.currentLatitude;
+                llh[3 * j + 1] = st.currentLongitude;
+                llh[3 * j + 2] = st.currentHeight;
+                double lat, lon, h;
+                CartToGeo(os[3 * j], os[3 * j + 1], os[3 * j + 2], &lat, &lon, &h);
+                os[3 * j] = lat;
+                os[3 * j + 1] = lon;
+                os[3 * j + 2] = ortho ? h - (double)st.geoidSep : h;
+            }
+            gnssvcv::PropagateGeoCart(Vc, k, llh, false);
+            for (uint32_t i = 0; i < nc; ++i)
+                for (uint32_t q = 0; q < nc; ++q) Vs[(size_t)i * nc + q] = 0.5 * (Vc[(size_t)q * nc + i] + Vc[(size_t)i * nc + q]);
+        };
+        auto set_coord_type = [&](size_t rec0, const char* ct) {
+            for (size_t r = rec0; r < bms.size(); ++r) put_str(bms[r].coordType, sizeof(bms[r].coordType), ct);
+        };
         std::vector<double> Vs, os;
         sub(0, Vs, os);
+        size_t rec0 = bms.size();
+        if (sp.y_llh) to_geographic(lo, Vs, os, false);
         emit_cluster('Y', none, lo, os, Vs);
+        if (sp.y_llh) set_coord_type(rec0, "LLh");
         sub(1, Vs, os);
+        rec0 = bms.size();
+        if (sp.y_llh) to_geographic(hi, Vs, os, true);
         emit_cluster('Y', none, hi, os, Vs);
+        if (sp.y_llh) set_coord_type(rec0, "LLH");
         for (uint32_t s : corners) put_str(bst[s].stationConst, sizeof(bst[s].stationConst), "FFF");
+    }
+    if (sp.scalars) {
+        // variance scalars (the DNA format's v-, p-, l-, h-scale columns): every third measurement carries
+        // phi / lambda / height scalars, every fourth a matrix scalar, some both
+        uint32_t q = 0, last_id = 0xffffffffu;
+        double ps = 1.0, ls = 1.0, hs = 1.0, vs = 1.0;
+        for (measurement_t& rec : bms) {
+            if (rec.clusterID != last_id) {
+                last_id = rec.clusterID;
+                ++q;
+                const bool partial = (q % 3 == 1);
+                ps = partial ? 2.0 : 1.0;
+                ls = partial ? 3.0 : 1.0;
+                hs = partial ? 0.5 : 1.0;
+                vs = (q % 4 == 2) ? 4.0 : ((q % 12 == 1) ? 1.5 : 1.0);
+            }
+            rec.scale1 = ps;
+            rec.scale2 = ls;
+            rec.scale3 = hs;
+            rec.scale4 = vs;
+        }
     }
     const uint64_t n_msr = msr_first.size();
 

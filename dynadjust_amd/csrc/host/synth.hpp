@@ -15,6 +15,8 @@ struct Spec {
     double sigma_e = 0.003, sigma_n = 0.003, sigma_up = 0.006;   // baseline noise in the local frame
     uint32_t x_clusters = 0;   // the baselines leaving each of the first x_clusters stations form one 'X' cluster (correlated VCV)
     bool y_cluster = false;    // datum from two 'Y' point clusters over the corner stations instead of CCC constraints
+    bool y_llh = false;        // ... given as latitude / longitude / height ("LLh" and "LLH") with geographic variance matrices
+    bool scalars = false;      // v- / p- / l- / h-scale columns set on part of the measurements
 };
 
 struct Summary {

@@ -138,6 +138,8 @@ typedef struct {
     double initial_sigma;
     uint32_t x_clusters;    /* baselines leaving each of the first x_clusters stations become one 'X' cluster */
     uint32_t y_cluster;     /* 1: datum from 'Y' point clusters over the corner stations (which become FFF) */
+    uint32_t y_llh;         /* 1: those clusters in latitude / longitude / height ("LLh", "LLH") with geographic variances */
+    uint32_t scalars;       /* 1: variance scalars (v, phi, lambda, h) on part of the measurements */
 } dnasynth_spec;
 typedef struct {
     uint64_t stations, baselines, measurement_rows, blocks, max_block_unknowns;

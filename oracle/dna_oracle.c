@@ -231,6 +231,114 @@ void orc_geo_to_cart(double lat, double lon, double h, double* x, double* y, dou
 }
 
 /* ========================================================================== */
+/* GNSS variance matrices in other frames / partially scaled                    */
+/*   FormCarttoGeoRotationMatrix (dnatemplatematrixfuncs.hpp:204-233): Jacobian */
+/*   d(X,Y,Z)/d(lat,lon,h); matrix_2d::sweep (dnamatrix_contiguous.cpp:903-943);*/
+/*   Prpagate_Variances_Geo_Cart (:300-313); ScaleMatrix (:368-375);            */
+/*   ScaleGPSVCV_Cluster (:404-443); PropagateVariances_GeoCart_Cluster (:355). */
+/* The reference builds block-diagonal 3k x 3k rotation matrices and multiplies  */
+/* densely; the products with the zero blocks vanish, so the same sums are done  */
+/* here block by block.  V is column-major 3k x 3k, both triangles.             */
+/* ========================================================================== */
+static void geo_cart_jacobian(double lat, double lon, double h, double J[3][3]) {
+    const double a = 6378137.0, inv_f = 298.257222101;
+    const double f = 1.0 / inv_f;
+    const double e2 = 2.0 * f - f * f;
+    double coslat = cos(lat), sinlat = sin(lat), coslon = cos(lon), sinlon = sin(lon);
+    double term1_a = a * e2;
+    double one_minus_esq = 1.0 - e2;
+    double nu = a / sqrt(1.0 - e2 * sinlat * sinlat);
+    double nu_plus_h = nu + h;
+    double nu_1minuse2_plus_h = nu * one_minus_esq + h;
+    double term1_b = term1_a * sinlat * coslat;
+    double term1_c = pow(1.0 - e2 * sinlat * sinlat, 1.5);
+    J[0][0] = (term1_b * coslat * coslon / term1_c) - (nu_plus_h * sinlat * coslon);
+    J[0][1] = -nu_plus_h * coslat * sinlon;
+    J[0][2] = coslat * coslon;
+    J[1][0] = (term1_b * coslat * sinlon / term1_c) - (nu_plus_h * sinlat * sinlon);
+    J[1][1] = nu_plus_h * coslat * coslon;
+    J[1][2] = coslat * sinlon;
+    J[2][0] = (term1_b * one_minus_esq * sinlat / term1_c) + (nu_1minuse2_plus_h * coslat);
+    J[2][1] = 0.0;
+    J[2][2] = sinlat;
+}
+
+/* matrix_2d::sweep(0, 3) on one 3x3 block (the off-block elements of the reference's big matrix stay zero) */
+static void sweep3(double A[3][3]) {
+    const double eps = 1.0e-8;
+    for (int k = 0; k < 3; ++k) {
+        if (fabs(A[k][k]) < eps) {
+            for (int it = 0; it < 3; ++it) A[it][k] = A[k][it] = 0.0;
+        } else {
+            double d = 1.0 / A[k][k];
+            A[k][k] = d;
+            for (int i = 0; i < 3; ++i)
+                if (i != k) A[i][k] *= -d;
+            for (int j = 0; j < 3; ++j)
+                if (j != k) A[k][j] *= d;
+            for (int i = 0; i < 3; ++i)
+                if (i != k)
+                    for (int j = 0; j < 3; ++j)
+                        if (j != k) A[i][j] += A[i][k] * A[k][j] / d;
+        }
+    }
+}
+
+/* V <- R V R^T with R = blockdiag(R_0 .. R_{k-1}) */
+static void congruence_blocks(double* V, uint32_t k, double (*R)[3][3]) {
+    const uint32_t nc = 3 * k;
+    double* T = (double*)malloc((size_t)nc * nc * sizeof(double));
+    for (uint32_t a = 0; a < k; ++a)          /* T = R V */
+        for (uint32_t col = 0; col < nc; ++col)
+            for (int i = 0; i < 3; ++i) {
+                double sum = 0.0;
+                for (int t = 0; t < 3; ++t) sum += R[a][i][t] * V[(size_t)col * nc + 3 * a + t];
+                T[(size_t)col * nc + 3 * a + i] = sum;
+            }
+    for (uint32_t b = 0; b < k; ++b)          /* V = T R^T */
+        for (uint32_t row = 0; row < nc; ++row)
+            for (int j = 0; j < 3; ++j) {
+                double sum = 0.0;
+                for (int t = 0; t < 3; ++t) sum += T[(size_t)(3 * b + t) * nc + row] * R[b][j][t];
+                V[(size_t)(3 * b + j) * nc + row] = sum;
+            }
+    free(T);
+}
+
+/* PropagateVariances_GeoCart_Cluster: V (geographic: rad, rad, m) -> cartesian (geo_to_cart != 0) or back;
+ * llh: lat, lon, h of the position the rotation is formed at, 3 per vector */
+void orc_propagate_geo_cart(double* V, uint32_t k, const double* llh, int geo_to_cart) {
+    double(*R)[3][3] = (double(*)[3][3])malloc((size_t)k * sizeof(double[3][3]));
+    for (uint32_t a = 0; a < k; ++a) {
+        geo_cart_jacobian(llh[3 * a], llh[3 * a + 1], llh[3 * a + 2], R[a]);
+        if (!geo_to_cart) sweep3(R[a]);
+    }
+    congruence_blocks(V, k, R);
+    free(R);
+}
+
+/* ScaleGPSVCV_Cluster: phi / lambda / height variance scalars applied in the geographic frame.
+ * v_is_geographic != 0: V is already geographic (a Y cluster given in LLH), no initial propagation. */
+void orc_scale_gps_vcv(double* V, uint32_t k, const double* llh, double pScale, double lScale, double hScale, int v_is_geographic) {
+    const uint32_t nc = 3 * k;
+    double(*R)[3][3] = (double(*)[3][3])malloc((size_t)k * sizeof(double[3][3]));
+    double(*Ri)[3][3] = (double(*)[3][3])malloc((size_t)k * sizeof(double[3][3]));
+    for (uint32_t a = 0; a < k; ++a) {
+        geo_cart_jacobian(llh[3 * a], llh[3 * a + 1], llh[3 * a + 2], R[a]);
+        memcpy(Ri[a], R[a], sizeof(double[3][3]));
+        sweep3(Ri[a]);
+    }
+    if (!v_is_geographic) congruence_blocks(V, k, Ri);
+    /* ScaleMatrix: V <- S V S^T, S = diag(sqrt(p), sqrt(l), sqrt(h), ...) */
+    const double sc[3] = {sqrt(pScale), sqrt(lScale), sqrt(hScale)};
+    for (uint32_t col = 0; col < nc; ++col)
+        for (uint32_t row = 0; row < nc; ++row) V[(size_t)col * nc + row] = (sc[row % 3] * V[(size_t)col * nc + row]) * sc[col % 3];
+    congruence_blocks(V, k, R);
+    free(R);
+    free(Ri);
+}
+
+/* ========================================================================== */
 /* measurement weights: ADJ:4214-4309 -> ADJ:8472 (dpotrf 'U' + dpotri 'U', 3x3) */
 /* The formulas below are the 3x3 instance of U^T U factorisation, inversion of */
 /* U and U^-1 U^-T, written in the same operation order as the device kernel.    */

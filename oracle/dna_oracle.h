@@ -52,6 +52,11 @@ int orc_inverse_normals_packed(double* ap, uint32_t n, int scale_to_unity);
 /* ---- geodesy --------------------------------------------------------------------- */
 /* GeoToCart (include/functions/dnatemplategeodesyfuncs.hpp:78-90), GRS80 */
 void orc_geo_to_cart(double lat, double lon, double h, double* x, double* y, double* z);
+/* GNSS variance matrices (column-major 3k x 3k, both triangles) between the geographic and the cartesian frame and
+ * the phi / lambda / height variance scalars: PropagateVariances_GeoCart_Cluster and ScaleGPSVCV_Cluster
+ * (include/functions/dnatemplatematrixfuncs.hpp:355-443); llh = lat, lon, h (radians, metres) per vector */
+void orc_propagate_geo_cart(double* V, uint32_t k, const double* llh, int geo_to_cart);
+void orc_scale_gps_vcv(double* V, uint32_t k, const double* llh, double pScale, double lScale, double hScale, int v_is_geographic);
 
 /* ---- measurement weights ------------------------------------------------------- */
 /* W = V^-1 for a GNSS baseline: LoadVarianceMatrix_G (ADJ:4214) + FormInverseVarianceMatrix

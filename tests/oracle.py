@@ -56,6 +56,8 @@ def load():
         lib.orc_multiply_sym_packed.argtypes = [f64p, f64p, f64p, C.c_uint32]
         lib.orc_geo_to_cart.argtypes = [C.c_double] * 3 + [f64p] * 3
         lib.orc_weight_3x3.argtypes = [f64p, f64p]
+        lib.orc_propagate_geo_cart.argtypes = [f64p, C.c_uint32, f64p, C.c_int]
+        lib.orc_scale_gps_vcv.argtypes = [f64p, C.c_uint32, f64p, C.c_double, C.c_double, C.c_double, C.c_int]
         lib.orc_adjust_create.restype = C.c_void_p
         lib.orc_adjust_create.argtypes = [C.POINTER(OrcNetwork), C.POINTER(OrcSettings), C.c_int]
         lib.orc_adjust_destroy.argtypes = [C.c_void_p]
@@ -126,6 +128,26 @@ def geo_to_cart(lat, lon, h):
     return x.value, y.value, z.value
 
 
+def propagate_geo_cart(V, llh, geo_to_cart=True):
+    """PropagateVariances_GeoCart_Cluster on a 3k x 3k matrix (numpy, any order); llh = k x 3 (lat, lon, h)"""
+    lib = load()
+    k = V.shape[0] // 3
+    v = np.asfortranarray(V, dtype=np.float64).copy(order="F")
+    p = np.ascontiguousarray(llh, dtype=np.float64)
+    lib.orc_propagate_geo_cart(_p(v, f64p), k, _p(p, f64p), int(geo_to_cart))
+    return v
+
+
+def scale_gps_vcv(V, llh, pscale, lscale, hscale, v_is_geographic=False):
+    """ScaleGPSVCV_Cluster"""
+    lib = load()
+    k = V.shape[0] // 3
+    v = np.asfortranarray(V, dtype=np.float64).copy(order="F")
+    p = np.ascontiguousarray(llh, dtype=np.float64)
+    lib.orc_scale_gps_vcv(_p(v, f64p), k, _p(p, f64p), float(pscale), float(lscale), float(hscale), int(v_is_geographic))
+    return v
+
+
 def weight_3x3(v6):
     lib = load()
     v = np.ascontiguousarray(v6, dtype=np.float64)
@@ -150,14 +172,18 @@ class Network:
         self.n_clusters = 0
         self.cluster_off = np.zeros(1, dtype=np.uint32)
         self.cluster_vcv = np.zeros(1)
-        if np.all(bms["measType"] == b"G"):
+        self._llh = np.stack([bst["currentLatitude"], bst["currentLongitude"], bst["currentHeight"]], axis=1).astype(np.float64)
+        self._geoid = np.asarray(bst["geoidSep"], dtype=np.float64)
+        unit = lambda a: np.where(np.asarray(a) < 1e-6, 1.0, a)
+        partial = any(np.any(np.abs(unit(bms[k]) - 1.0) > 1e-5) for k in ("scale1", "scale2", "scale3"))
+        if np.all(bms["measType"] == b"G") and not partial:
             starts = np.nonzero((bms["measStart"] == 0) & (~bms["ignore"]))[0]
             self.bl_of_record = {int(m): i for i, m in enumerate(starts)}
             self.n_baselines = len(starts)
             self.stn1 = np.ascontiguousarray(bms["station1"][starts], dtype=np.uint32)
             self.stn2 = np.ascontiguousarray(bms["station2"][starts], dtype=np.uint32)
             self.obs = np.ascontiguousarray(np.stack([bms["term1"][starts], bms["term1"][starts + 1], bms["term1"][starts + 2]], axis=1)).ravel()
-            vs = bms["scale4"][starts]
+            vs = np.where(bms["scale4"][starts] < 1e-6, 1.0, bms["scale4"][starts])
             v6 = np.stack([bms["term2"][starts], bms["term2"][starts + 1], bms["term3"][starts + 1],
                            bms["term2"][starts + 2], bms["term3"][starts + 2], bms["term4"][starts + 2]], axis=1)
             scale = np.where(np.abs(vs - 1.0) > 1e-5, vs, 1.0)
@@ -180,26 +206,44 @@ class Network:
             self.net_id = np.zeros(1, dtype=np.uint32)
 
     def _parse_clusters(self, bms):
-        """G / X / Y records -> vectors + clusters (the .bms layout of LoadVarianceMatrix_G/_X/_Y, dnaadjust.cpp:4214-4560)"""
+        """G / X / Y records -> vectors + clusters: the .bms layout and the scaling / frame rules of
+        LoadVarianceScaling, LoadVarianceMatrix_G/_X/_Y (dnaadjust.cpp:4453, 4214, 4312, 4494) and, for point clusters
+        given in latitude / longitude / height, UpdateDesignNormalMeasMatrices_Y (dnaadjust.cpp:6281-6318)"""
         stn1, stn2, obs, vcv, off = [], [], [], [], [0]
         self.bl_of_record = {}
         i, n = 0, len(bms)
+        tiny = 1e-6                                   # min(PRECISION_1E5, fixed_std_dev)
         while i < n:
             t = bytes(bms["measType"][i])
             assert t in (b"G", b"X", b"Y") and bms["measStart"][i] == 0 and not bms["ignore"][i]
             self.bl_of_record[i] = len(off) - 1      # cml entries become cluster indices
             k = 1 if t == b"G" else int(bms["vectorCount1"][i])
-            vs = float(bms["scale4"][i])
-            scale = vs if abs(vs - 1.0) > 1e-5 and vs >= 1e-6 else 1.0
+            unit = lambda v: 1.0 if v < tiny else float(v)
+            vs, ps, ls, hs = (unit(float(bms[f][i])) for f in ("scale4", "scale1", "scale2", "scale3"))
+            scale_matrix = abs(vs - 1.0) > 1e-5
+            scale_partial = abs(ps - 1.0) > 1e-5 or abs(ls - 1.0) > 1e-5 or abs(hs - 1.0) > 1e-5
+            if scale_partial and scale_matrix:
+                ps, ls, hs = ps * vs, ls * vs, hs * vs
+            ctype = bytes(bms["coordType"][i]).rstrip(b"\x00").strip()
+            geographic = t == b"Y" and ctype in (b"LLH", b"LLh")
             V = np.zeros((3 * k, 3 * k))
+            pos = np.zeros((k, 3))
             for j in range(k):
                 r0 = 3 * j
-                obs += [float(bms["term1"][i]), float(bms["term1"][i + 1]), float(bms["term1"][i + 2])]
+                o = [float(bms["term1"][i]), float(bms["term1"][i + 1]), float(bms["term1"][i + 2])]
+                s1 = int(bms["station1"][i])
+                pos[j] = self._llh[s1]
+                if geographic:
+                    hgt = o[2]
+                    if ctype == b"LLH" and abs(self._geoid[s1]) > 1e-4:
+                        hgt += float(self._geoid[s1])
+                    o = list(geo_to_cart(o[0], o[1], hgt))
+                obs += o
                 if t == b"Y":
                     stn1.append(0xffffffff)
-                    stn2.append(int(bms["station1"][i]))
+                    stn2.append(s1)
                 else:
-                    stn1.append(int(bms["station1"][i]))
+                    stn1.append(s1)
                     stn2.append(int(bms["station2"][i]))
                 V[r0, r0] = bms["term2"][i]
                 V[r0, r0 + 1] = bms["term2"][i + 1]
@@ -215,7 +259,19 @@ class Network:
                         V[r0 + r, c0:c0 + 3] = [bms["term1"][i + r], bms["term2"][i + r], bms["term3"][i + r]]
                     i += 3
             V = np.triu(V) + np.triu(V, 1).T
-            vcv.append((V * scale if scale != 1.0 else V).ravel(order="F"))
+            if t != b"Y":
+                if scale_matrix:
+                    V = V * vs                        # "on the fly" (dnaadjust.cpp:4236, 4360)
+                if scale_partial:
+                    V = scale_gps_vcv(V, pos, ps, ls, hs, False)
+            else:
+                if scale_partial:
+                    V = scale_gps_vcv(V, pos, ps, ls, hs, geographic)
+                elif geographic:
+                    V = propagate_geo_cart(V, pos, True)
+                if scale_matrix and not scale_partial:
+                    V = V * vs                        # dnaadjust.cpp:4650
+            vcv.append(np.asarray(V).ravel(order="F"))
             off.append(len(stn1))
         self.n_baselines = len(stn1)
         self.stn1 = np.asarray(stn1, dtype=np.uint32)

@@ -437,3 +437,25 @@ def test_reuse_inverses_is_identical(built, tmp_path, mt):
     for b in range(B):
         assert np.array_equal(a.block_estimates(b), x0[b])
     a.close()
+
+
+@pytest.mark.parametrize("blocks,phased,ycl", [(1, False, True), (3, True, True), (4, True, False)])
+def test_scalars_and_llh_point_clusters_parity(built, orc, tmp_path, blocks, phased, ycl):
+    """variance scalars (LoadVarianceScaling, ScaleGPSVCV[_Cluster]) and Y clusters in latitude / longitude / height
+    (PropagateVariances_GeoCart_Cluster, GeoToCart of the points): facade against oracle, including the statistics,
+    which read the scaled variances back from the records (SetGPSVarianceMatrix)"""
+    adjust.write_synthetic_network(str(tmp_path), "s", 10, 8, 0, blocks, seed=2, x_clusters=14, y_cluster=ycl, y_llh=ycl, scalars=True)
+    net = orc.Network(str(tmp_path / "s"), phased)
+    o = orc.Adjustment(net, phased)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "s", phased)
+    _compare(a, st, o, ost)
+    fd, rec = _compare_statistics(a, o)
+    if ycl:
+        y = rec[(rec["measType"] == b"Y") & (rec["measStart"] == 0)]
+        assert {bytes(c).rstrip(b"\x00") for c in y["coordType"]} == {b"XYZ"}          # converted once and for all (ADJ:6313)
+        assert set(int(v) for v in y["station3"]) == {1, 2}                              # LLh_type_i, LLH_type_i retained
+        assert np.all(np.abs(y["preAdjMeas"]) < 4.0) and np.all(np.abs(y["term1"]) > 1e6)  # radians kept, metres now
+    a.close()
+    o.close()

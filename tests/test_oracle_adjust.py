@@ -262,3 +262,79 @@ def test_quantiles_against_scipy(built):
         for dof in (1, 2, 3, 7, 30, 288, 5000, 240000):
             q, r = lib.dnastat_chi_squared_quantile(dof, p), chi2.ppf(p, dof)
             assert abs(q - r) < 1e-9 * max(r, 1e-3) + 4e-16 / max(chi2.pdf(r, dof), 1e-300), (dof, p, q, r)
+
+
+def test_vcv_frames_and_scalars(orc):
+    """PropagateVariances_GeoCart_Cluster / ScaleGPSVCV_Cluster (dnatemplatematrixfuncs.hpp:355-443) restated in the oracle,
+    against independent formulas: the Jacobian of GeoToCart by central differences, and the fact that scaling in the
+    geographic frame is a scaling along the local north / east / up axes (the metric factors of J commute with the
+    diagonal scalars): V' = (R S R^T) V (R S R^T)^T."""
+    rng = np.random.default_rng(3)
+    k = 3
+    llh = np.array([[-0.64, 2.55, 210.0], [-0.63, 2.56, 890.0], [-0.65, 2.54, 15.0]])
+    A = rng.standard_normal((3 * k, 3 * k + 2))
+    V = A @ A.T * 1e-5
+    J = np.zeros((3 * k, 3 * k))
+    R = np.zeros((3 * k, 3 * k))
+    for a in range(k):
+        lat, lon, h = llh[a]
+        for c, d in enumerate((1e-7, 1e-7, 1e-2)):
+            p, m = llh[a].copy(), llh[a].copy()
+            p[c] += d
+            m[c] -= d
+            J[3 * a:3 * a + 3, 3 * a + c] = (np.array(orc.geo_to_cart(*p)) - np.array(orc.geo_to_cart(*m))) / (2 * d)
+        # columns: north, east, up unit vectors
+        R[3 * a:3 * a + 3, 3 * a:3 * a + 3] = np.array([
+            [-np.sin(lat) * np.cos(lon), -np.sin(lon), np.cos(lat) * np.cos(lon)],
+            [-np.sin(lat) * np.sin(lon), np.cos(lon), np.cos(lat) * np.sin(lon)],
+            [np.cos(lat), 0.0, np.sin(lat)]])
+    Vg = A @ A.T * np.outer(np.tile([1e-9, 1e-9, 1e-2], k), np.tile([1e-9, 1e-9, 1e-2], k))   # a geographic-frame matrix
+    got = orc.propagate_geo_cart(Vg, llh, True)
+    ref = J @ Vg @ J.T
+    assert np.abs(got - ref).max() < 1e-6 * np.abs(ref).max()
+    back = orc.propagate_geo_cart(got, llh, False)
+    assert np.abs(back - Vg).max() / np.abs(Vg).max() < 1e-9
+    p, l, hh = 2.0, 3.0, 0.5
+    S = np.diag(np.tile(np.sqrt([p, l, hh]), k))
+    M = R @ S @ R.T
+    ref = M @ V @ M.T
+    got = orc.scale_gps_vcv(V, llh, p, l, hh, False)
+    assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max()
+    assert np.abs(got - got.T).max() < 1e-12 * np.abs(got).max()
+    # already geographic input: only the second half of the chain
+    got = orc.scale_gps_vcv(Vg, llh, p, l, hh, True)
+    ref = J @ S @ Vg @ S @ J.T
+    assert np.abs(got - ref).max() < 1e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("blocks,ycl", [(1, True), (3, True), (2, False)])
+def test_gnss_scalars_and_llh_point_clusters(orc, built, tmp_path, blocks, ycl):
+    """variance scalars (v, phi, lambda, h) on G / X / Y and Y clusters supplied as latitude / longitude / height"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", 8, 6, 0, blocks, seed=21, x_clusters=9, y_cluster=ycl, y_llh=ycl, scalars=True)
+    base = str(tmp_path / "s")
+    bms = F.read_bms(base + ".bms")
+    if ycl:
+        assert {bytes(c).rstrip(b"\x00") for c in bms["coordType"][bms["measType"] == b"Y"]} == {b"LLh", b"LLH"}
+    assert np.any(bms["scale1"] != 1.0) and np.any(bms["scale4"] != 1.0)
+    net, a, st = _run(orc, base, False)
+    assert st == 0
+    x, V = _dense_solution(net)
+    assert np.abs(a.block_estimates(0) - x).max() < 2e-8
+    if ycl:
+        truth = np.fromfile(base + ".truth", dtype=np.float64)
+        assert np.abs(a.block_estimates(0) - truth).max() < 0.08      # the LLH -> XYZ conversion of the datum points worked
+    # the scalars act: without them the solution differs
+    plain = bms.copy()
+    for kf in ("scale1", "scale2", "scale3", "scale4"):
+        plain[kf] = 1.0
+    F.write_bms(str(tmp_path / "p.bms"), plain)
+    for ext in ("bst", "asl", "seg"):
+        import shutil
+        shutil.copy(base + "." + ext, str(tmp_path / ("p." + ext)))
+    netp, ap, stp = _run(orc, str(tmp_path / "p"), False)
+    assert np.abs(ap.block_estimates(0) - a.block_estimates(0)).max() > 1e-6
+    a.close()
+    ap.close()
+    if blocks > 1:
+        _phased_vs_simultaneous(orc, base)
