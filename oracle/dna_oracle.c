@@ -404,7 +404,9 @@ typedef struct {
     double *jvar, *jvarFwd;      /* v_junctionVariances_, v_junctionVariancesFwd_ (packed 3*n_jsl) */
     double *jestFwd;             /* v_junctionEstimatesFwd_[block]     (3*n_jsl) */
     double *jestRev;             /* v_junctionEstimatesRev_[block]     (3*|JSL(block-1)|) */
-    double* prec;                /* v_precAdjMsrsFull_ (6 per vector) */
+    double* prec;                /* v_precAdjMsrsFull_ (6 per vector, 1 per terrestrial measurement) */
+    double* trow;                /* design rows of the block's terrestrial measurements (9 each, CML order), from compute_b */
+    uint32_t n_trow;
 } blk_t;
 
 struct orc_adjustment {
@@ -426,6 +428,13 @@ struct orc_adjustment {
     uint64_t solves;
     double sum_n3;
     double* msr_field[7];        /* per vector component, see orc_adjust_msr_field */
+    /* terrestrial measurements */
+    uint32_t n_tm;
+    double* t_val;               /* term1: the measurement after its one-time reductions (E, M: re-derived every evaluation) */
+    double* t_pre;               /* preAdjMeas: as supplied */
+    double* t_corr;              /* preAdjCorr */
+    double* geo;                 /* lat, lon, h per station: the bst "current" geodetic coordinates */
+    double* tm_field[8];
     char err[512];
 };
 
@@ -536,10 +545,347 @@ static void cluster_contribution(orc_adjustment* a, blk_t* B, uint32_t c, double
     free(st);
 }
 
-/* UpdateNormals (ADJ:1364) for a GNSS block */
+/* ========================================================================== */
+/* terrestrial measurements: UpdateDesignNormalMeasMatrices_A/_BK/_CEM/_E/_M/_S/ */
+/* _V/_Z/_L/_H/_HR/_R (ADJ:4754-6054) and the geometry they call                */
+/* (include/functions/dnatemplategeodesyfuncs.hpp:627-1220)                      */
+/* ========================================================================== */
+#define ORC_PI 3.14159265358979323846
+#define ORC_TWO_PI (2.0 * ORC_PI)
+#define ORC_HALF_PI (0.5 * ORC_PI)
+#define ORC_E4_SEC_DEFLECTION (0.0001 * (ORC_PI / 648000.0)) /* dnaconsts.hpp:110 */
+
+static void grs80(double* a_, double* e2_) {
+    const double inv_f = 298.257222101, f = 1.0 / inv_f;
+    *a_ = 6378137.0;
+    *e2_ = 2.0 * f - f * f;
+}
+static double prime_vertical(double lat) {
+    double a_, e2;
+    grs80(&a_, &e2);
+    return a_ / sqrt(1.0 - e2 * (sin(lat) * sin(lat)));
+}
+static void nu_rho(double lat, double* nu, double* rho) {
+    double a_, e2;
+    grs80(&a_, &e2);
+    double del = sqrt(1.0 - e2 * (sin(lat) * sin(lat)));
+    *nu = a_ / del;
+    *rho = a_ * ((1.0 - e2) / (del * del * del));
+}
+/* atan_2 (dnatemplatecalcfuncs.hpp:350) */
+static double atan_2(double x, double y) {
+    double theta = atan(x / y);
+    if (y < 0) return theta + ORC_PI;
+    return x > 0 ? theta : theta + ORC_TWO_PI;
+}
+static void local_elements(const double* X1, const double* X2, double lat, double lon, double* e, double* n, double* up) {
+    double dX = X2[0] - X1[0], dY = X2[1] - X1[1], dZ = X2[2] - X1[2];
+    double sin_lat = sin(lat), cos_lat = cos(lat), sin_lon = sin(lon), cos_lon = cos(lon);
+    *e = -sin_lon * dX + cos_lon * dY;
+    *n = -sin_lat * cos_lon * dX - sin_lat * sin_lon * dY + cos_lat * dZ;
+    if (up) *up = cos_lat * cos_lon * dX + cos_lat * sin_lon * dY + sin_lat * dZ;
+}
+/* Direction (geodesyfuncs:679-720) */
+static double direction_en(double e, double n) {
+    double d = fabs(e) < fabs(n) ? atan_2(e, n) : ORC_HALF_PI - atan_2(n, e);
+    if (d < 0) d += ORC_TWO_PI;
+    return d;
+}
+static double direction(const double* X1, const double* X2, double lat, double lon, double* e, double* n) {
+    local_elements(X1, X2, lat, lon, e, n, NULL);
+    return direction_en(*e, *n);
+}
+static void height_offset(double h, double lat, double lon, double* d) { /* CartesianElementsFromInstrumentHeight */
+    d[0] = cos(lat) * cos(lon) * h;
+    d[1] = cos(lat) * sin(lon) * h;
+    d[2] = sin(lat) * h;
+}
+/* local e, n, up of the line instrument -> target (ZenithDistance / VerticalAngle, geodesyfuncs:786-907) */
+static void sight_line(const double* X1, const double* X2, double lat1, double lon1, double lat2, double lon2, double ih, double th,
+                       double* e, double* n, double* up) {
+    double di[3], dt[3], Xa[3] = {0, 0, 0}, Xb[3];
+    height_offset(ih, lat1, lon1, di);
+    height_offset(th, lat2, lon2, dt);
+    for (int c = 0; c < 3; ++c) Xb[c] = X2[c] - X1[c] + dt[c] - di[c];
+    local_elements(Xa, Xb, lat1, lon1, e, n, up);
+}
+static double zenith_distance(const double* X1, const double* X2, double lat1, double lon1, double lat2, double lon2, double ih, double th,
+                              double* e, double* n, double* up) {
+    sight_line(X1, X2, lat1, lon1, lat2, lon2, ih, th, e, n, up);
+    return atan2(sqrt((*e) * (*e) + (*n) * (*n)), *up);
+}
+static double ellipsoid_height(const double* X, double lat, double* nu, double* Zn) { /* geodesyfuncs:909 */
+    double a_, e2;
+    grs80(&a_, &e2);
+    *nu = prime_vertical(lat);
+    *Zn = e2 * (*nu) * sin(lat);
+    return sqrt(X[0] * X[0] + X[1] * X[1] + (X[2] + (*Zn)) * (X[2] + (*Zn))) - (*nu);
+}
+static double chord_distance(const double* X1, const double* X2, double lat1, double lat2, double h1, double h2, double* d) { /* :957 */
+    double a_, e2;
+    grs80(&a_, &e2);
+    double nu1 = prime_vertical(lat1), nu2 = prime_vertical(lat2);
+    double s1 = nu1 / (nu1 + h1), s2 = nu2 / (nu2 + h2);
+    double Zn1 = e2 * nu1 * sin(lat1), Zn2 = e2 * nu2 * sin(lat2);
+    double x1 = X1[0] * s1, y1 = X1[1] * s1, z1 = (X1[2] + Zn1) * s1 - Zn1;
+    double x2 = X2[0] * s2, y2 = X2[1] * s2, z2 = (X2[2] + Zn2) * s2 - Zn2;
+    d[0] = x2 - x1;
+    d[1] = y2 - y1;
+    d[2] = z2 - z1;
+    return sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+}
+static double radius_in_chord_direction(const double* X1, const double* X2, double lat1, double lon1, double lat2) { /* :983 */
+    double nu, rho, e, n;
+    nu_rho((lat1 + lat2) / 2.0, &nu, &rho);
+    double dir = direction(X1, X2, lat1, lon1, &e, &n);
+    double c = cos(dir), sn = sin(dir);
+    return rho * nu / ((nu * c * c) + (rho * sn * sn));
+}
+static double msl_arc_to_ellipsoid_chord(double arc, double lat1, double lat2, double N1, double N2) { /* :1100, :1061, :1086 */
+    double nu, rho;
+    nu_rho((lat1 + lat2) / 2.0, &nu, &rho);
+    double r = sqrt(nu * rho) + (N1 + N2) / 2.0;
+    double msl_chord = 2.0 * r * sin(arc / 2.0 / r);
+    double c = msl_chord * msl_chord;
+    c -= (N2 - N1) * (N2 - N1);
+    double R = sqrt(nu * rho);
+    c /= 1.0 + N1 / R;
+    c /= 1.0 + N2 / R;
+    return sqrt(c);
+}
+static double ellipsoid_chord_to_msl_arc(double chord, double lat1, double lat2, double N1, double N2) { /* :1135 */
+    double nu, rho;
+    nu_rho((lat1 + lat2) / 2.0, &nu, &rho);
+    double R = sqrt(nu * rho);
+    double c = chord * chord;
+    c *= 1.0 + N1 / R;
+    c *= 1.0 + N2 / R;
+    c += (N2 - N1) * (N2 - N1);
+    double msl_chord = sqrt(c);
+    double r = R + (N1 + N2) / 2.0;
+    return asin(msl_chord / 2.0 / r) * 2.0 * r;
+}
+
+static int tm_station_count(char type) {
+    switch (type) {
+        case 'A': return 3;
+        case 'H': case 'R': return 1;
+        default: return 2;
+    }
+}
+
+/* computed measurement and design row at the cartesian coordinates X1..X3 with the current geodetic station data.
+ * For E and M the ellipsoid chord equivalent of the supplied arc is (re)derived into a->t_val first (ADJ:5254, ADJ:5412). */
+static void tm_evaluate(orc_adjustment* a, uint32_t t, const double* X1, const double* X2, const double* X3, double* comp, double* row) {
+    const orc_network* net = &a->net;
+    const char type = net->t_type[t];
+    const uint32_t g1 = net->t_stn[3 * (size_t)t], g2 = net->t_stn[3 * (size_t)t + 1];
+    const double lat1 = a->geo[3 * (size_t)g1], lon1 = a->geo[3 * (size_t)g1 + 1];
+    const double cos_lat = cos(lat1), sin_lat = sin(lat1), cos_long = cos(lon1), sin_long = sin(lon1);
+    for (int i = 0; i < 9; ++i) row[i] = 0.0;
+    switch (type) {
+        case 'A': {
+            double e12, n12, e13, n13;
+            double d12 = direction(X1, X2, lat1, lon1, &e12, &n12);
+            double d13 = direction(X1, X3, lat1, lon1, &e13, &n13);
+            if (d12 > d13) d13 += ORC_TWO_PI;                                     /* HorizontalAngle, :733 */
+            *comp = d13 - d12;
+            double slc = sin_lat * cos_long, sls = sin_lat * sin_long;
+            double c12 = cos(d12) * cos(d12) / (n12 * n12), c13 = cos(d13) * cos(d13) / (n13 * n13);
+            row[0] = c13 * (n13 * sin_long - e13 * slc) - c12 * (n12 * sin_long - e12 * slc);
+            row[1] = c13 * (-n13 * cos_long - e13 * sls) - c12 * (-n12 * cos_long - e12 * sls);
+            row[2] = c13 * e13 * cos_lat - c12 * e12 * cos_lat;
+            row[3] = c12 * (n12 * sin_long - e12 * slc);
+            row[4] = c12 * (-n12 * cos_long - e12 * sls);
+            row[5] = c12 * e12 * cos_lat;
+            row[6] = -c13 * (n13 * sin_long - e13 * slc);
+            row[7] = -c13 * (-n13 * cos_long - e13 * sls);
+            row[8] = -c13 * e13 * cos_lat;
+            break;
+        }
+        case 'B': case 'K': {
+            double e12, n12;
+            *comp = direction(X1, X2, lat1, lon1, &e12, &n12);
+            double slc = sin_lat * cos_long, sls = sin_lat * sin_long;
+            double c12 = cos(*comp) * cos(*comp) / (n12 * n12);
+            double dx = c12 * (n12 * sin_long - e12 * slc), dy = c12 * (-n12 * cos_long - e12 * sls), dz = c12 * e12 * cos_lat;
+            row[0] = dx; row[1] = dy; row[2] = dz;                                /* AddMsrtoDesign_BCEKMSVZ (ADJ:4710) */
+            row[3] = -dx; row[4] = -dy; row[5] = -dz;
+            break;
+        }
+        case 'C': case 'E': case 'M': {
+            const double lat2 = a->geo[3 * (size_t)g2];
+            if (type == 'E')
+                a->t_val[t] = 2.0 * radius_in_chord_direction(X1, X2, lat1, lon1, lat2) *
+                              sin(a->t_pre[t] / 2.0 / radius_in_chord_direction(X1, X2, lat1, lon1, lat2));
+            if (type == 'M') a->t_val[t] = msl_arc_to_ellipsoid_chord(a->t_pre[t], lat1, lat2, net->stn_geoid[g1], net->stn_geoid[g2]);
+            if (type != 'C') a->t_corr[t] = a->t_val[t] - a->t_pre[t];
+            double d[3];
+            *comp = chord_distance(X1, X2, lat1, lat2, a->geo[3 * (size_t)g1 + 2], a->geo[3 * (size_t)g2 + 2], d);
+            for (int c = 0; c < 3; ++c) {
+                row[c] = -d[c] / (*comp);
+                row[3 + c] = d[c] / (*comp);
+            }
+            break;
+        }
+        case 'S': {
+            double di[3], dt[3], d[3];
+            height_offset(net->t_ih[t], lat1, lon1, di);
+            height_offset(net->t_th[t], lat1, lon1, dt);                          /* (sic: station 1's position, ADJ:5466) */
+            for (int c = 0; c < 3; ++c) d[c] = X2[c] - X1[c] + dt[c] - di[c];
+            *comp = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            for (int c = 0; c < 3; ++c) {
+                row[c] = -d[c] / (*comp);
+                row[3 + c] = d[c] / (*comp);
+            }
+            break;
+        }
+        case 'V': case 'Z': {
+            const double lat2 = a->geo[3 * (size_t)g2], lon2 = a->geo[3 * (size_t)g2 + 1];
+            double e, n, up, dx, dy, dz;
+            double zen = zenith_distance(X1, X2, lat1, lon1, lat2, lon2, net->t_ih[t], net->t_th[t], &e, &n, &up);
+            double e2n2 = e * e + n * n, se = sqrt(e2n2);
+            if (type == 'V') {
+                *comp = zen;
+                double se2n2_up2 = se / (up * up), up_se2n2 = up * se, cos2v = cos(*comp) * cos(*comp);
+                dx = cos2v * (((e * sin_long + n * sin_lat * cos_long) / up_se2n2) + cos_lat * cos_long * se2n2_up2);
+                dy = cos2v * (((-e * cos_long + n * sin_lat * sin_long) / up_se2n2) + cos_lat * sin_long * se2n2_up2);
+                dz = cos2v * ((-n * cos_lat / up_se2n2) + sin_lat * se2n2_up2);
+            } else {
+                *comp = atan2(up, se);                                            /* VerticalAngle, :777 */
+                double se_d = se / e2n2, up_d = up / (se * e2n2), cos2v = cos(*comp) * cos(*comp);
+                dx = cos2v * ((-cos_lat * cos_long * se_d) - ((e * sin_long + n * sin_lat * cos_long) * up_d));
+                dy = cos2v * ((-cos_lat * sin_long * se_d) + ((e * cos_long - n * sin_lat * sin_long) * up_d));
+                dz = cos2v * ((-sin_lat * se_d) + (n * cos_lat * up_d));
+            }
+            row[0] = dx; row[1] = dy; row[2] = dz;
+            row[3] = -dx; row[4] = -dy; row[5] = -dz;
+            break;
+        }
+        case 'L': {
+            const double lat2 = a->geo[3 * (size_t)g2];
+            double nu1, nu2, Zn1, Zn2;
+            double h2 = ellipsoid_height(X2, lat2, &nu2, &Zn2);
+            double h1 = ellipsoid_height(X1, lat1, &nu1, &Zn1);
+            *comp = h2 - h1;
+            row[0] = -X1[0] / (nu1 + h1);
+            row[1] = -X1[1] / (nu1 + h1);
+            row[2] = -(X1[2] + Zn1) / (nu1 + h1);
+            row[3] = X2[0] / (nu2 + h2);
+            row[4] = X2[1] / (nu2 + h2);
+            row[5] = (X2[2] + Zn2) / (nu2 + h2);
+            break;
+        }
+        case 'H': case 'R': {
+            double nu1, Zn1;
+            *comp = ellipsoid_height(X1, lat1, &nu1, &Zn1);
+            row[0] = X1[0] / (nu1 + *comp);
+            row[1] = X1[1] / (nu1 + *comp);
+            row[2] = (X1[2] + Zn1) / (nu1 + *comp);
+            break;
+        }
+        default: *comp = 0.0;
+    }
+    (void)X3;
+}
+
+/* the one-time reductions applied when the matrices are first built (buildnewMatrices && !rebuildingDesign_):
+ * deflection of the vertical (A ADJ:4790-4845, K ADJ:4940-4970, V ADJ:5523-5547, Z ADJ:5632-5656) and geoid
+ * separation (L ADJ:5746-5753, H ADJ:5977-5984) */
+static void tm_reduce(orc_adjustment* a, uint32_t t, const double* X1, const double* X2, const double* X3) {
+    const orc_network* net = &a->net;
+    const char type = net->t_type[t];
+    const uint32_t g1 = net->t_stn[3 * (size_t)t], g2 = net->t_stn[3 * (size_t)t + 1], g3 = net->t_stn[3 * (size_t)t + 2];
+    const double lat1 = a->geo[3 * (size_t)g1], lon1 = a->geo[3 * (size_t)g1 + 1];
+    const double dV = net->stn_defl[2 * (size_t)g1], dM = net->stn_defl[2 * (size_t)g1 + 1];
+    const int defl = fabs(dV) > ORC_E4_SEC_DEFLECTION || fabs(dM) > ORC_E4_SEC_DEFLECTION;
+    double e, n, up;
+    a->t_pre[t] = a->t_val[t];                                                    /* InitialiseMeasurement (ADJ:3928) */
+    a->t_corr[t] = 0.0;
+    switch (type) {
+        case 'A':
+            if (defl) {
+                double e12, n12, e13, n13;
+                double d12 = direction(X1, X2, lat1, lon1, &e12, &n12), d13 = direction(X1, X3, lat1, lon1, &e13, &n13);
+                if (d12 > d13) d13 += ORC_TWO_PI;
+                double z12 = zenith_distance(X1, X2, lat1, lon1, a->geo[3 * (size_t)g2], a->geo[3 * (size_t)g2 + 1], net->t_ih[t], net->t_th[t], &e, &n, &up);
+                double z13 = zenith_distance(X1, X3, lat1, lon1, a->geo[3 * (size_t)g3], a->geo[3 * (size_t)g3 + 1], net->t_ih[t], net->t_th[t], &e, &n, &up);
+                /* HzAngleDeflectionCorrection (:1202) */
+                a->t_corr[t] = (dM * sin(d13) - dV * cos(d13)) / tan(z13) - (dM * sin(d12) - dV * cos(d12)) / tan(z12);
+                a->t_val[t] -= a->t_corr[t];
+            }
+            break;
+        case 'K':
+            if (defl) {
+                double az = direction(X1, X2, lat1, lon1, &e, &n);
+                double zen = zenith_distance(X1, X2, lat1, lon1, a->geo[3 * (size_t)g2], a->geo[3 * (size_t)g2 + 1], net->t_ih[t], net->t_th[t], &e, &n, &up);
+                a->t_corr[t] = dV * tan(lat1) + ((dM * sin(az) - dV * cos(az)) / tan(zen));   /* LaplaceCorrection (:1181) */
+                a->t_val[t] -= a->t_corr[t];
+            }
+            break;
+        case 'V': case 'Z':
+            if (defl) {
+                double az = direction(X1, X2, lat1, lon1, &e, &n);
+                a->t_corr[t] = dM * cos(az) + dV * sin(az);                        /* ZenithDeflectionCorrection (:1189) */
+                if (type == 'V') a->t_val[t] += a->t_corr[t];
+                else a->t_val[t] -= a->t_corr[t];
+            }
+            break;
+        case 'L':
+            if (fabs(net->stn_geoid[g1]) > 1.0e-4 || fabs(net->stn_geoid[g2]) > 1.0e-4) {
+                a->t_corr[t] = net->stn_geoid[g2] - net->stn_geoid[g1];
+                a->t_val[t] += a->t_corr[t];
+            }
+            break;
+        case 'H':
+            if (fabs(net->stn_geoid[g1]) > 1.0e-4) {
+                a->t_corr[t] = net->stn_geoid[g1];
+                a->t_val[t] += a->t_corr[t];
+            }
+            break;
+        default: break;
+    }
+}
+
+/* cml entry -> terrestrial measurement index, or -1 for a GNSS cluster */
+static inline int64_t tm_index(const orc_adjustment* a, uint32_t entry) { return entry >= a->n_clusters ? (int64_t)entry - a->n_clusters : -1; }
+static inline uint32_t entry_rows(const orc_adjustment* a, uint32_t entry) {
+    return entry >= a->n_clusters ? 1u : 3u * (a->cl_off[entry + 1] - a->cl_off[entry]);
+}
+/* block-local coordinates of the measurement's stations */
+static void tm_block_coords(const orc_adjustment* a, const blk_t* B, uint32_t t, const double* est, uint32_t* loc, const double** X) {
+    static const double zero3[3] = {0, 0, 0};
+    int ns = tm_station_count(a->net.t_type[t]);
+    for (int s = 0; s < 3; ++s) {
+        if (s < ns) {
+            loc[s] = local_index(B, a->net.t_stn[3 * (size_t)t + s]);
+            X[s] = est + 3 * (size_t)loc[s];
+        } else {
+            loc[s] = 0;
+            X[s] = zero3;
+        }
+    }
+}
+
+/* UpdateNormals (ADJ:1364): GNSS measurements, and UpdateNormals_A / _BCEKLMSVZ / _HIJPQR (ADJ:1524-1662) with the
+ * design rows stored by compute_b */
 static void update_normals(orc_adjustment* a, blk_t* B) {
+    uint32_t trow = 0;
     for (uint32_t c = 0; c < B->n_cml; ++c) {
         uint32_t cl = B->cml[c];
+        int64_t t = tm_index(a, cl);
+        if (t >= 0) {
+            const double* row = B->trow + 9 * (size_t)trow++;
+            const double w = 1.0 / a->net.t_var[t];                               /* UpdateAtVinv (ADJ:1288) */
+            const int ns = tm_station_count(a->net.t_type[t]);
+            uint32_t loc[3];
+            for (int q = 0; q < ns; ++q) loc[q] = 3 * local_index(B, a->net.t_stn[3 * (size_t)t + q]);
+            for (int p = 0; p < ns; ++p)
+                for (int q = 0; q < ns; ++q)
+                    for (int cc = 0; cc < 3; ++cc)
+                        for (int r = 0; r < 3; ++r) lower_add(B->N, B->n, loc[p] + r, loc[q] + cc, (w * row[3 * p + r]) * row[3 * q + cc]);
+            continue;
+        }
         uint32_t i = a->cl_off[cl];
         if (!a->cl_W[cl]) {
             uint32_t s1 = 3 * local_index(B, a->net.stn1[i]);
@@ -553,9 +899,27 @@ static void update_normals(orc_adjustment* a, blk_t* B) {
 /* FillDesignNormalMeasurementsMatrices(false) (ADJ:3888) -> UpdateDesignMeasMatrices_GX (ADJ:5283):
  * b = term1 - (x2 - x1), AddMsrtoMeasMinusComp (ADJ:4719) */
 static void compute_b(orc_adjustment* a, blk_t* B, const double* est) {
-    uint32_t row = 0;
+    uint32_t row = 0, trow = 0;
     for (uint32_t c = 0; c < B->n_cml; ++c) {
         uint32_t cl = B->cml[c];
+        int64_t t = tm_index(a, cl);
+        if (t >= 0) {
+            /* the type's UpdateDesignNormalMeasMatrices_* + AddMsrtoMeasMinusComp (ADJ:4719) */
+            uint32_t loc[3];
+            const double* X[3];
+            double comp;
+            tm_block_coords(a, B, (uint32_t)t, est, loc, X);
+            tm_evaluate(a, (uint32_t)t, X[0], X[1], X[2], &comp, B->trow + 9 * (size_t)trow++);
+            double mmc = a->t_val[t] - comp;
+            switch (a->net.t_type[t]) {
+                case 'A': case 'B': case 'K':
+                    if (mmc < -5.5) mmc += ORC_TWO_PI;
+                    else if (mmc > 5.5) mmc -= ORC_TWO_PI;
+                default: break;
+            }
+            B->b[row++] = mmc;
+            continue;
+        }
         for (uint32_t i = a->cl_off[cl]; i < a->cl_off[cl + 1]; ++i, row += 3) {
             uint32_t s2 = 3 * local_index(B, a->net.stn2[i]);
             if (a->net.stn1[i] == 0xffffffffu) {
@@ -566,6 +930,46 @@ static void compute_b(orc_adjustment* a, blk_t* B, const double* est) {
                 for (int k = 0; k < 3; ++k) B->b[row + k] = a->net.obs[3 * (size_t)i + k] - (est[s2 + k] - est[s1 + k]);
             }
         }
+    }
+}
+
+/* UpdateGeographicCoords (ADJ:8734) / UpdateGeographicCoordsPhased (ADJ:8711): the station records take the geodetic
+ * coordinates of the block's estimates (first appearance only); CartToGeo = dnatemplategeodesyfuncs.hpp:154-225 */
+static void cart_to_geo(const double* X, double* lat, double* lon, double* h) {
+    double a_, e2;
+    grs80(&a_, &e2);
+    const double b_ = a_ * (1.0 - 1.0 / 298.257222101);
+    double x = X[0], y = X[1], z = X[2];
+    double p2 = x * x + y * y, p = sqrt(p2), a2 = a_ * a_, b2 = b_ * b_, Z2 = z * z;
+    double a2Z2 = a2 * Z2, b2p2 = b2 * p2, A = a2Z2 + b2p2;
+    double m0 = (a_ * b_ * sqrt(A) * A - a2 * b2 * A) / (2. * ((a2 * a2Z2) + (b2 * b2p2)));
+    double twom, a2twom, b2twom, f, df, m = m0;
+    for (int i = 0; i < 5; ++i) {
+        m = m0;
+        twom = m * 2.;
+        a2twom = a2 + twom;
+        b2twom = b2 + twom;
+        f = (a2 * p2 / (a2twom * a2twom)) + (b2 * Z2 / (b2twom * b2twom)) - 1.;
+        if (fabs(f) < 1.0e-12) break;
+        df = -4. * ((a2 * p2 / (a2twom * a2twom * a2twom)) + (b2 * Z2 / (b2twom * b2twom * b2twom)));
+        m0 = m - (f / df);
+        m = m0;
+    }
+    twom = m * 2.;
+    double p_E = a2 * p / (a2 + twom), Z_E = b2 * z / (b2 + twom);
+    *lat = atan(a2 * Z_E / (b2 * p_E));
+    *lon = atan(y / x);
+    if (x < 0.0 && y > 0.0) *lon += ORC_PI;
+    else if (x < 0.0 && y < 0.0) *lon = -(ORC_PI - *lon);
+    *h = sqrt(((p - p_E) * (p - p_E)) + ((z - Z_E) * (z - Z_E)));
+    if ((p + fabs(z)) < (p_E + fabs(Z_E))) *h *= -1.;
+}
+static void update_geographic(orc_adjustment* a, const blk_t* B, const double* est) {
+    if (!a->n_tm) return;
+    for (uint32_t p = 0; p < B->n_stn; ++p) {
+        if (!B->first_fwd[p]) continue;
+        double* g = a->geo + 3 * (size_t)B->stations[p];
+        cart_to_geo(est + 3 * (size_t)p, &g[0], &g[1], &g[2]);
     }
 }
 
@@ -627,8 +1031,20 @@ static int solve(orc_adjustment* a, blk_t* B, int compute_inverse, uint32_t bloc
     /* At_Vinv_m = AtVinv * measMinusComp (ADJ:6659-6660); AtVinv is never materialised */
     double* rhs = (double*)calloc(n ? n : 1, sizeof(double));
     uint32_t brow = 0;
+    uint32_t trow = 0;
     for (uint32_t c = 0; c < B->n_cml; ++c) {
         uint32_t cl = B->cml[c];
+        int64_t t = tm_index(a, cl);
+        if (t >= 0) {
+            const double* row = B->trow + 9 * (size_t)trow++;
+            const double wb = (1.0 / a->net.t_var[t]) * B->b[brow++];
+            const int ns = tm_station_count(a->net.t_type[t]);
+            for (int q = 0; q < ns; ++q) {
+                uint32_t l = 3 * local_index(B, a->net.t_stn[3 * (size_t)t + q]);
+                for (int r = 0; r < 3; ++r) rhs[l + r] += row[3 * q + r] * wb;
+            }
+            continue;
+        }
         uint32_t i = a->cl_off[cl];
         const double* bb = B->b + brow;
         brow += 3 * (a->cl_off[cl + 1] - i);
@@ -778,7 +1194,10 @@ void orc_adjust_destroy(orc_adjustment* a) {
         free(B->N); free(B->NR); free(B->est); free(B->orig); free(B->rig); free(B->rigvar);
         free(B->corr); free(B->corrR); free(B->b); free(B->jvar); free(B->jvarFwd); free(B->jestFwd); free(B->jestRev);
         free(B->prec);
+        free(B->trow);
     }
+    free(a->t_val); free(a->t_pre); free(a->t_corr); free(a->geo);
+    for (int f = 0; f < 8; ++f) free(a->tm_field[f]);
     for (int f = 0; f < 7; ++f) free(a->msr_field[f]);
     free(a->blk);
     free(a->W);
@@ -800,6 +1219,17 @@ int orc_adjust_prepare(orc_adjustment* a) {
     a->cl_off = (uint32_t*)malloc(((size_t)a->n_clusters + 1) * sizeof(uint32_t));
     a->cl_W = (double**)calloc((size_t)a->n_clusters + 1, sizeof(double*));
     for (uint32_t c = 0; c <= a->n_clusters; ++c) a->cl_off[c] = net->n_clusters ? net->cluster_off[c] : c;
+    /* terrestrial measurements and the geodetic station data they need */
+    a->n_tm = net->n_tmsr;
+    if (a->n_tm) {
+        a->t_val = (double*)malloc(a->n_tm * sizeof(double));
+        a->t_pre = (double*)malloc(a->n_tm * sizeof(double));
+        a->t_corr = (double*)calloc(a->n_tm, sizeof(double));
+        memcpy(a->t_val, net->t_value, a->n_tm * sizeof(double));
+        memcpy(a->t_pre, net->t_value, a->n_tm * sizeof(double));
+        a->geo = (double*)malloc(3 * (size_t)net->n_stations * sizeof(double));
+        memcpy(a->geo, net->stn_llh, 3 * (size_t)net->n_stations * sizeof(double));
+    }
     /* measurement weights: LoadVarianceMatrix_G / _X / _Y (ADJ:4214 / 4312 / 4494) + FormInverseVarianceMatrix (ADJ:8472) */
     a->W = (double*)calloc((size_t)net->n_baselines * 6 + 1, sizeof(double));
     size_t voff = 0;
@@ -836,8 +1266,11 @@ int orc_adjust_prepare(orc_adjustment* a) {
     if (!a->phased) {
         a->simul_stations = (uint32_t*)malloc((net->n_stations + 1) * sizeof(uint32_t));
         for (uint32_t s = 0; s < net->n_stations; ++s) a->simul_stations[s] = s;
-        a->simul_cml = (uint32_t*)malloc(((size_t)a->n_clusters + 1) * sizeof(uint32_t));
-        for (uint32_t i = 0; i < a->n_clusters; ++i) a->simul_cml[i] = i;
+        a->simul_cml = (uint32_t*)malloc(((size_t)a->n_clusters + a->n_tm + 1) * sizeof(uint32_t));
+        for (uint32_t i = 0; i < a->n_clusters + a->n_tm; ++i) a->simul_cml[i] = i;
+        /* (an explicit order may come with the network: cml_off/cml of "block 0") */
+        if (net->n_blocks == 1 && net->cml_off && net->cml_off[1] == a->n_clusters + a->n_tm)
+            memcpy(a->simul_cml, net->cml, (a->n_clusters + a->n_tm) * sizeof(uint32_t));
     }
     uint32_t prev_net = 999999;
     for (uint32_t b = 0; b < a->n_blocks; ++b) {
@@ -862,13 +1295,18 @@ int orc_adjust_prepare(orc_adjustment* a) {
             B->stations = (uint32_t*)malloc((B->n_stn + 1) * sizeof(uint32_t));
             memcpy(B->stations, a->simul_stations, B->n_stn * sizeof(uint32_t));
             B->n_jsl = 0;
-            B->n_cml = a->n_clusters;
+            B->n_cml = a->n_clusters + a->n_tm;
             B->cml = a->simul_cml;
             B->first = B->last = B->isolated = 1;
         }
         B->n = 3 * B->n_stn;
         B->m = 0;
-        for (uint32_t q = 0; q < B->n_cml; ++q) B->m += 3 * (a->cl_off[B->cml[q] + 1] - a->cl_off[B->cml[q]]);
+        B->n_trow = 0;
+        for (uint32_t q = 0; q < B->n_cml; ++q) {
+            B->m += entry_rows(a, B->cml[q]);
+            if (tm_index(a, B->cml[q]) >= 0) B->n_trow++;
+        }
+        B->trow = (double*)calloc(9 * (size_t)B->n_trow + 1, sizeof(double));
         B->first_fwd = (uint8_t*)calloc(B->n_stn + 1, 1);
         B->first_rev = (uint8_t*)calloc(B->n_stn + 1, 1);
     }
@@ -917,7 +1355,16 @@ int orc_adjust_prepare(orc_adjustment* a) {
         /* PopulateEstimatedStationMatrix (ADJ:632) */
         for (uint32_t p = 0; p < B->n_stn; ++p)
             for (int c = 0; c < 3; ++c) B->est[3 * p + c] = B->orig[3 * p + c] = B->rig[3 * p + c] = net->xyz0[3 * (size_t)B->stations[p] + c];
-        /* FillDesignNormalMeasurementsMatrices(true) (ADJ:913): b, AtVinv, N */
+        /* FillDesignNormalMeasurementsMatrices(true) (ADJ:913): one-time reductions of the terrestrial measurements, b,
+         * AtVinv, N */
+        for (uint32_t q = 0; q < B->n_cml; ++q) {
+            int64_t t = tm_index(a, B->cml[q]);
+            if (t < 0) continue;
+            uint32_t loc[3];
+            const double* X[3];
+            tm_block_coords(a, B, (uint32_t)t, B->est, loc, X);
+            tm_reduce(a, (uint32_t)t, X[0], X[1], X[2]);
+        }
         compute_b(a, B, B->est);
         update_normals(a, B);
         /* back up (ADJ:2955), then constraints (ADJ:2961-2970) */
@@ -933,15 +1380,22 @@ static int adjust_simultaneous(orc_adjustment* a) {
     a->iterations = 0;
     for (uint32_t i = 0; i < a->set.max_iterations; ++i) {
         a->iterations++;
-        if (solve(a, B, a->iterations < 2, 0)) return ORC_ADJUST_EXCEPTION_RAISED;       /* ADJ:2457 */
+        if (solve(a, B, a->iterations < 2 || a->n_tm, 0)) return ORC_ADJUST_EXCEPTION_RAISED;   /* ADJ:2457 */
         for (uint32_t k = 0; k < B->n; ++k) B->est[k] += B->corr[k];                      /* ADJ:2463 */
         a->maxCorr = max_value(B->corr, B->n);                                            /* ADJ:2466 */
         if (a->iterations <= 64) a->max_corr_hist[a->iterations - 1] = a->maxCorr;
         if (!(fabs(a->maxCorr) > a->set.iteration_threshold)) break;                      /* ADJ:2477 */
         int last = (i + 1 >= a->set.max_iterations);
-        /* UpdateAdjustment(!last) (ADJ:473): new meas-minus-computed; normals untouched (GNSS only) */
-        (void)last;
+        /* UpdateAdjustment(!last) (ADJ:473): geodetic coordinates of the stations (non-GPS networks, ADJ:541-545), new
+         * meas-minus-computed and design; the normals are re-formed only if the network has non-GPS measurements and
+         * another iteration follows (ADJ:557, ADJ:582-590) */
+        update_geographic(a, B, B->est);
         compute_b(a, B, B->est);
+        if (a->n_tm && !last) {
+            memset(B->N, 0, psize(B->n) * sizeof(double));
+            update_normals(a, B);
+            if (add_constraints(a, B, CON_SIM)) return ORC_ADJUST_EXCEPTION_RAISED;
+        }
     }
     memcpy(B->rig, B->est, B->n * sizeof(double));
     memcpy(B->rigvar, B->N, psize(B->n) * sizeof(double));                                 /* ADJ:2536 */
@@ -1037,6 +1491,7 @@ static int phased_update_adjustment(orc_adjustment* a) {
             memcpy(B->est, B->rig, B->n * sizeof(double));
             memcpy(B->orig, B->rig, B->n * sizeof(double));
         }
+        update_geographic(a, B, B->est);                                                 /* ADJ:530-531 */
         compute_b(a, B, B->est);
         memset(B->N, 0, psize(B->n) * sizeof(double));
         update_normals(a, B);
@@ -1130,17 +1585,78 @@ int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statisti
             voff += (size_t)nc * nc;
         }
     }
+    for (int f = 0; f < 8; ++f) {
+        free(a->tm_field[f]);
+        a->tm_field[f] = (double*)calloc((size_t)a->n_tm + 1, sizeof(double));
+    }
     double chi_total = 0.0;
     uint32_t outliers = 0, msr_params = 0;
     for (uint32_t blk = 0; blk < a->n_blocks; ++blk) {
         blk_t* B = &a->blk[blk];
-        compute_b(a, B, B->rig);                                  /* UpdateAdjustment(false), ADJ:549 */
+        update_geographic(a, B, B->rig);                          /* UpdateAdjustment(false): ADJ:496-531, ADJ:541-545 */
+        compute_b(a, B, B->rig);                                  /* ... and ADJ:549 */
         free(B->prec);
         B->prec = (double*)calloc((size_t)B->m * 2 + 1, sizeof(double));
         const double* V = B->rigvar;
         double chi = 0.0;                                         /* ComputeChiSquare (ADJ:7257) starts from zero per block */
-        uint32_t row = 0, prow = 0;
+        uint32_t row = 0, prow = 0, trow = 0;
         for (uint32_t c = 0; c < B->n_cml; ++c) {
+            const int64_t t = tm_index(a, B->cml[c]);
+            if (t >= 0) {
+                /* ComputePrecisionAdjMsrs_A / _BCEKLMSVZ / _HIJPQR (ADJ:7877-8007): a S a^T */
+                const double* dr = B->trow + 9 * (size_t)trow++;
+                const int ns = tm_station_count(net->t_type[t]);
+                uint32_t loc[3];
+                for (int q = 0; q < ns; ++q) loc[q] = 3 * local_index(B, net->t_stn[3 * (size_t)t + q]);
+                double part[9], prec = 0.0;
+                for (int s_ = 0; s_ < ns; ++s_)
+                    for (int i = 0; i < 3; ++i) {
+                        double acc = 0.0;
+                        for (int j = 0; j < ns; ++j)
+                            for (int e = 0; e < 3; ++e) acc += dr[3 * j + e] * packed_get(V, B->n, loc[j] + e, loc[s_] + i);
+                        part[3 * s_ + i] = acc;
+                    }
+                for (int s_ = 0; s_ < ns; ++s_)
+                    for (int i = 0; i < 3; ++i) prec += part[3 * s_ + i] * dr[3 * s_ + i];
+                B->prec[prow++] = prec;
+                /* UpdateMsrRecord (ADJ:8187) */
+                double corr = -B->b[row], adj = a->t_val[t] + corr;
+                switch (net->t_type[t]) {
+                    case 'E': {
+                        const uint32_t g1 = net->t_stn[3 * (size_t)t], g2 = net->t_stn[3 * (size_t)t + 1];
+                        const double* X1 = B->rig + loc[0];
+                        const double* X2 = B->rig + loc[1];
+                        double r = radius_in_chord_direction(X1, X2, a->geo[3 * (size_t)g1], a->geo[3 * (size_t)g1 + 1], a->geo[3 * (size_t)g2]);
+                        adj = asin(adj / 2.0 / r) * 2.0 * r;
+                        break;
+                    }
+                    case 'M': {
+                        const uint32_t g1 = net->t_stn[3 * (size_t)t], g2 = net->t_stn[3 * (size_t)t + 1];
+                        adj = ellipsoid_chord_to_msl_arc(adj, a->geo[3 * (size_t)g1], a->geo[3 * (size_t)g2], net->stn_geoid[g1], net->stn_geoid[g2]);
+                        break;
+                    }
+                    case 'H': case 'L': case 'V': adj -= a->t_corr[t]; break;
+                    case 'A': case 'K': case 'Z': adj += a->t_corr[t]; break;
+                    default: break;
+                }
+                const double mp = net->t_var[t];
+                double rp = mp - prec;
+                if (rp < 0.0) rp = fabs(rp);
+                double pz = sqrt(mp) / sqrt(rp);
+                if (pz < 0.0 || pz > ORC_STABLE_LIMIT) pz = ORC_UNRELIABLE;
+                a->tm_field[0][t] = adj;
+                a->tm_field[1][t] = corr;
+                a->tm_field[2][t] = prec;
+                a->tm_field[3][t] = rp;
+                a->tm_field[4][t] = corr / sqrt(rp);
+                a->tm_field[5][t] = pz;
+                a->tm_field[6][t] = mp;
+                a->tm_field[7][t] = a->t_corr[t];
+                if (fabs(a->tm_field[4][t]) > critical_value) outliers++;
+                chi += B->b[row] * B->b[row] / net->t_var[t];     /* ComputeChiSquare_ABCEHIJKLMPQRSVZ (ADJ:8430) */
+                row += 1;
+                continue;
+            }
             const uint32_t cl = B->cml[c], i0 = a->cl_off[cl], k = a->cl_off[cl + 1] - i0, nc = 3 * k;
             /* ComputePrecisionAdjMsrs_GX (ADJ:8009) / _Y (ADJ:8037) */
             for (uint32_t j = 0; j < k; ++j) {
@@ -1204,7 +1720,17 @@ int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statisti
     uint32_t num = 0;
     for (uint32_t blk = 0; blk < a->n_blocks; ++blk) {
         blk_t* B = &a->blk[blk];
-        for (uint32_t c = 0; c < B->n_cml; ++c)
+        for (uint32_t c = 0; c < B->n_cml; ++c) {
+            const int64_t t = tm_index(a, B->cml[c]);
+            if (t >= 0) {
+                double* p = &a->tm_field[5][t];                                /* ADJ:8338: "< STABLE_LIMIT" for these types */
+                if (*p > 0.0 && *p < ORC_STABLE_LIMIT) {
+                    sum += (*p * *p - 1.0);
+                    num++;
+                } else
+                    *p = ORC_UNRELIABLE;
+                continue;
+            }
             for (uint32_t i = a->cl_off[B->cml[c]]; i < a->cl_off[B->cml[c] + 1]; ++i)
                 for (int e = 0; e < 3; ++e) {
                     double* p = &pelzer[3 * (size_t)i + e];
@@ -1214,6 +1740,7 @@ int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statisti
                     } else
                         *p = ORC_UNRELIABLE;
                 }
+        }
     }
     /* unknown parameters: 3 per station minus the constrained components (ADJ:647-672) */
     uint32_t unknowns = 3 * net->n_stations;
@@ -1232,6 +1759,11 @@ int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statisti
 
 const double* orc_adjust_msr_field(const orc_adjustment* a, int field) { return (field >= 0 && field < 7) ? a->msr_field[field] : NULL; }
 const double* orc_adjust_block_prec_adj_msrs(const orc_adjustment* a, uint32_t b, uint32_t* rows) {
-    if (rows) *rows = a->blk[b].m * 2;
+    if (rows) *rows = (a->blk[b].m - a->blk[b].n_trow) * 2 + a->blk[b].n_trow;
     return a->blk[b].prec;
+}
+const double* orc_adjust_tmsr_field(const orc_adjustment* a, int field) { return (field >= 0 && field < 8) ? a->tm_field[field] : NULL; }
+const double* orc_adjust_station_llh(const orc_adjustment* a) { return a->geo; }
+void orc_tmsr_evaluate(orc_adjustment* a, uint32_t t, const double* xyz9, double* computed, double* row9) {
+    tm_evaluate(a, t, xyz9, xyz9 + 3, xyz9 + 6, computed, row9);
 }

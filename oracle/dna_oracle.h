@@ -88,6 +88,21 @@ typedef struct {
     uint32_t n_clusters;
     const uint32_t* cluster_off;
     const double* cluster_vcv;
+    /* optional terrestrial measurements (one design row each).  cml entries >= (n_clusters ? n_clusters : n_baselines)
+     * denote terrestrial measurement (entry - that count).  Types: A horizontal angle (3 stations: at, to, to),
+     * B geodetic azimuth, K astronomic azimuth, C chord, E ellipsoid arc, M MSL arc, S slope distance, V zenith distance,
+     * Z vertical angle, L level difference (2 stations), H orthometric height, R ellipsoidal height (1 station).
+     * Angles in radians, variances in radians^2 / m^2. */
+    uint32_t n_tmsr;
+    const char* t_type;
+    const uint32_t* t_stn;     /* 3 per measurement: station1, station2, station3 (unused: 0) */
+    const double* t_value;     /* measurement_t::term1 */
+    const double* t_var;       /* term2 */
+    const double* t_ih;        /* term3: instrument height */
+    const double* t_th;        /* term4: target height */
+    const double* stn_llh;     /* 3 per station: currentLatitude, currentLongitude, currentHeight (station_t) */
+    const double* stn_geoid;   /* geoidSep */
+    const double* stn_defl;    /* 2 per station: verticalDef (deflection in the prime vertical), meridianDef */
 } orc_network;
 
 typedef struct {
@@ -146,6 +161,13 @@ int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statisti
 /* per vector component (3 per vector, network vector order) after orc_adjust_statistics:
  * field 0 measAdj, 1 measCorr, 2 measAdjPrec, 3 residualPrec, 4 NStat, 5 PelzerRel, 6 a-priori variance */
 const double* orc_adjust_msr_field(const orc_adjustment* a, int field);
+/* the same fields for the terrestrial measurements (one value each, order of t_type), plus field 7 = preAdjCorr */
+const double* orc_adjust_tmsr_field(const orc_adjustment* a, int field);
+/* geodetic coordinates (lat, lon, h per station) as last updated by UpdateGeographicCoords (ADJ:8711/8734) */
+const double* orc_adjust_station_llh(const orc_adjustment* a);
+/* computed value and design row (9 partials: dX,dY,dZ of station1, station2, station3) of terrestrial measurement t at
+ * arbitrary cartesian coordinates (3 x 3 doubles) with the CURRENT geodetic station data; for derivative checks */
+void orc_tmsr_evaluate(orc_adjustment* a, uint32_t t, const double* xyz9, double* computed, double* row9);
 /* v_precAdjMsrsFull_ of a block: 6 values (xx xy xz yy yz zz) per vector, CML order */
 const double* orc_adjust_block_prec_adj_msrs(const orc_adjustment* a, uint32_t block, uint32_t* rows);
 

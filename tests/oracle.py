@@ -16,7 +16,9 @@ class OrcNetwork(C.Structure):
     _fields_ = [("n_stations", C.c_uint32), ("xyz0", f64p), ("constraints", C.c_char_p), ("n_baselines", C.c_uint32),
                 ("stn1", u32p), ("stn2", u32p), ("obs", f64p), ("vcv6", f64p), ("n_blocks", C.c_uint32),
                 ("isl_off", u32p), ("isl", u32p), ("jsl_off", u32p), ("jsl", u32p), ("cml_off", u32p), ("cml", u32p),
-                ("net_id", u32p), ("n_clusters", C.c_uint32), ("cluster_off", u32p), ("cluster_vcv", f64p)]
+                ("net_id", u32p), ("n_clusters", C.c_uint32), ("cluster_off", u32p), ("cluster_vcv", f64p),
+                ("n_tmsr", C.c_uint32), ("t_type", C.c_char_p), ("t_stn", u32p), ("t_value", f64p), ("t_var", f64p),
+                ("t_ih", f64p), ("t_th", f64p), ("stn_llh", f64p), ("stn_geoid", f64p), ("stn_defl", f64p)]
 
 
 class OrcSettings(C.Structure):
@@ -30,6 +32,8 @@ class OrcStatistics(C.Structure):
                 ("dof", C.c_int)]
 
 
+TERRESTRIAL_TYPES = b"ABCEHKLMRSVZ"
+TMSR_FIELDS = ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel", "measPrec", "preAdjCorr")
 MSR_FIELDS = ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel", "measPrec")
 
 _lib = None
@@ -85,6 +89,11 @@ def load():
         lib.orc_adjust_statistics.argtypes = [C.c_void_p, C.c_double, C.POINTER(OrcStatistics)]
         lib.orc_adjust_msr_field.restype = f64p
         lib.orc_adjust_msr_field.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_adjust_tmsr_field.restype = f64p
+        lib.orc_adjust_tmsr_field.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_adjust_station_llh.restype = f64p
+        lib.orc_adjust_station_llh.argtypes = [C.c_void_p]
+        lib.orc_tmsr_evaluate.argtypes = [C.c_void_p, C.c_uint32, f64p, C.POINTER(C.c_double), f64p]
         lib.orc_adjust_block_prec_adj_msrs.restype = f64p
         lib.orc_adjust_block_prec_adj_msrs.argtypes = [C.c_void_p, C.c_uint32, u32p]
         _lib = lib
@@ -173,10 +182,14 @@ class Network:
         self.cluster_off = np.zeros(1, dtype=np.uint32)
         self.cluster_vcv = np.zeros(1)
         self._llh = np.stack([bst["currentLatitude"], bst["currentLongitude"], bst["currentHeight"]], axis=1).astype(np.float64)
-        self._geoid = np.asarray(bst["geoidSep"], dtype=np.float64)
+        self._geoid = np.ascontiguousarray(bst["geoidSep"], dtype=np.float64)
+        self._vdef = np.ascontiguousarray(bst["verticalDef"], dtype=np.float64)
+        self._mdef = np.ascontiguousarray(bst["meridianDef"], dtype=np.float64)
         unit = lambda a: np.where(np.asarray(a) < 1e-6, 1.0, a)
         partial = any(np.any(np.abs(unit(bms[k]) - 1.0) > 1e-5) for k in ("scale1", "scale2", "scale3"))
-        if np.all(bms["measType"] == b"G") and not partial:
+        terr = np.isin(bms["measType"], [bytes([c]) for c in TERRESTRIAL_TYPES])
+        self.n_tmsr = 0
+        if np.all(bms["measType"] == b"G") and not partial and not np.any(terr):
             starts = np.nonzero((bms["measStart"] == 0) & (~bms["ignore"]))[0]
             self.bl_of_record = {int(m): i for i, m in enumerate(starts)}
             self.n_baselines = len(starts)
@@ -204,6 +217,11 @@ class Network:
             self.isl_off = self.jsl_off = self.cml_off = z
             self.isl = self.jsl = self.cml = np.zeros(1, dtype=np.uint32)
             self.net_id = np.zeros(1, dtype=np.uint32)
+            if self.n_tmsr:
+                # record order, like BuildSimultaneousLists of the facade
+                order = [self.bl_of_record[r] for r in sorted(self.bl_of_record)]
+                self.cml = np.asarray(order, dtype=np.uint32)
+                self.cml_off = np.asarray([0, len(order)], dtype=np.uint32)
 
     def _parse_clusters(self, bms):
         """G / X / Y records -> vectors + clusters: the .bms layout and the scaling / frame rules of
@@ -213,9 +231,21 @@ class Network:
         self.bl_of_record = {}
         i, n = 0, len(bms)
         tiny = 1e-6                                   # min(PRECISION_1E5, fixed_std_dev)
+        tm = {"type": [], "stn": [], "value": [], "var": [], "ih": [], "th": [], "record": []}
         while i < n:
             t = bytes(bms["measType"][i])
-            assert t in (b"G", b"X", b"Y") and bms["measStart"][i] == 0 and not bms["ignore"][i]
+            if t[0] in TERRESTRIAL_TYPES:
+                assert bms["measStart"][i] == 0 and not bms["ignore"][i]
+                tm["type"].append(t)
+                tm["stn"].append([int(bms["station1"][i]), int(bms["station2"][i]), int(bms["station3"][i])])
+                tm["value"].append(float(bms["term1"][i]))
+                tm["var"].append(float(bms["term2"][i]))
+                tm["ih"].append(float(bms["term3"][i]))
+                tm["th"].append(float(bms["term4"][i]))
+                tm["record"].append(i)
+                i += 1
+                continue
+            assert t in (b"G", b"X", b"Y") and bms["measStart"][i] == 0 and not bms["ignore"][i], t
             self.bl_of_record[i] = len(off) - 1      # cml entries become cluster indices
             k = 1 if t == b"G" else int(bms["vectorCount1"][i])
             unit = lambda v: 1.0 if v < tiny else float(v)
@@ -280,7 +310,23 @@ class Network:
         self.vcv6 = np.zeros(6 * self.n_baselines)
         self.n_clusters = len(off) - 1
         self.cluster_off = np.asarray(off, dtype=np.uint32)
-        self.cluster_vcv = np.ascontiguousarray(np.concatenate(vcv))
+        self.cluster_vcv = np.ascontiguousarray(np.concatenate(vcv)) if vcv else np.zeros(1)
+        # terrestrial measurements: cml entry = n_clusters + index
+        self.n_tmsr = len(tm["type"])
+        if self.n_tmsr:
+            assert self.n_clusters > 0 or self.n_baselines == 0
+            self.t_type = b"".join(tm["type"])
+            self.t_stn = np.asarray(tm["stn"], dtype=np.uint32).ravel()
+            self.t_value = np.asarray(tm["value"])
+            self.t_var = np.asarray(tm["var"])
+            self.t_ih = np.asarray(tm["ih"])
+            self.t_th = np.asarray(tm["th"])
+            self.t_record = np.asarray(tm["record"])
+            for q, r in enumerate(tm["record"]):
+                self.bl_of_record[r] = self.n_clusters + q
+            if self.n_clusters == 0:
+                # the oracle tells clusters from terrestrial entries by n_clusters (or n_baselines)
+                self.cluster_off = np.zeros(1, dtype=np.uint32)
 
     @staticmethod
     def _csr(lists):
@@ -309,6 +355,14 @@ class Network:
         n.n_clusters = self.n_clusters
         n.cluster_off = _p(self.cluster_off, u32p)
         n.cluster_vcv = _p(self.cluster_vcv, f64p)
+        n.n_tmsr = self.n_tmsr
+        if self.n_tmsr:
+            self._defl = np.ascontiguousarray(np.stack([self._vdef, self._mdef], axis=1)).ravel()
+            self._llh_flat = np.ascontiguousarray(self._llh).ravel()
+            n.t_type = self.t_type
+            n.t_stn, n.t_value, n.t_var = _p(self.t_stn, u32p), _p(self.t_value, f64p), _p(self.t_var, f64p)
+            n.t_ih, n.t_th = _p(self.t_ih, f64p), _p(self.t_th, f64p)
+            n.stn_llh, n.stn_geoid, n.stn_defl = _p(self._llh_flat, f64p), _p(self._geoid, f64p), _p(self._defl, f64p)
         return n
 
 
@@ -351,6 +405,21 @@ class Adjustment:
         n = 3 * self.net.n_baselines
         fields = {nm: np.ctypeslib.as_array(self.lib.orc_adjust_msr_field(self.h, f), shape=(n,)).copy() for f, nm in enumerate(MSR_FIELDS)}
         return st, fields
+
+    def tmsr_fields(self):
+        n = self.net.n_tmsr
+        return {nm: np.ctypeslib.as_array(self.lib.orc_adjust_tmsr_field(self.h, f), shape=(max(n, 1),))[:n].copy()
+                for f, nm in enumerate(TMSR_FIELDS)}
+
+    def station_llh(self):
+        return np.ctypeslib.as_array(self.lib.orc_adjust_station_llh(self.h), shape=(self.net.n_stations, 3)).copy()
+
+    def tmsr_evaluate(self, t, xyz9):
+        x = np.ascontiguousarray(xyz9, dtype=np.float64)
+        comp = C.c_double()
+        row = np.zeros(9)
+        self.lib.orc_tmsr_evaluate(self.h, t, _p(x, f64p), C.byref(comp), _p(row, f64p))
+        return comp.value, row
 
     def block_prec_adj_msrs(self, b):
         rows = C.c_uint32()
