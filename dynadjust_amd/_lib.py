@@ -112,6 +112,12 @@ def load():
     _sig(lib, "dnagpu_block_get_b", i, [vp, i, u32, c_f64p])
     _sig(lib, "dnagpu_block_get_weights", i, [vp, i, u32, c_f64p])
     _sig(lib, "dnagpu_block_msr_statistics", i, [vp, i, u32, vp, c_f64p, c_f64p])
+    _sig(lib, "dnagpu_block_set_station_geo", i, [vp, u32, c_f64p, c_f64p, c_f64p])
+    _sig(lib, "dnagpu_block_set_terrestrial", i, [vp, u32, u32, C.c_char_p, c_u32p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_u32p, c_u32p, u32])
+    _sig(lib, "dnagpu_block_update_geodetic", i, [vp, i, u32])
+    _sig(lib, "dnagpu_block_get_station_llh", i, [vp, i, u32, c_f64p])
+    _sig(lib, "dnagpu_block_get_terrestrial", i, [vp, i, u32, c_f64p, c_f64p])
+    _sig(lib, "dnagpu_block_terrestrial_precisions", i, [vp, i, u32, vp, c_f64p])
     _sig(lib, "dnagpu_form_normals", i, [vp, i, u32, vp])
     _sig(lib, "dnagpu_add_diag3x3", i, [vp, i, vp, c_u32p, c_f64p, sz, i])
     _sig(lib, "dnagpu_form_rhs", i, [vp, i, u32])
@@ -197,7 +203,8 @@ EXPORTED_DNAGPU = [
     "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
-    "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
+    "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
+    "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
     "dnagpu_junction_gather", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",

@@ -9,7 +9,13 @@ void launch_cluster_blocks(const double* F, uint32_t np, uint32_t k, double* wbl
 void launch_diag_weights(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, double* w6, uint32_t n_vec, hipStream_t s);
 void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s);
 void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pent, const double* wblk, double* F,
-                         uint32_t np, uint32_t n_pairs, hipStream_t s);
+                         uint32_t np, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift, hipStream_t s);
+void launch_geodetic(const double* xe, double* llh, uint32_t n_stn, hipStream_t s);
+void launch_tmsr_eval(const uint8_t* type, const uint32_t* stn, const double* val, const double* pre, const double* var, const double* ih,
+                      const double* th, const uint32_t* blk0, const uint32_t* vec0, const double* xe, const double* llh, const double* geoid,
+                      const double* defl, double* tb, double* trow, double* tblk, double* wb, uint32_t n_bl, uint32_t n_t, hipStream_t s);
+void launch_tmsr_stats(const uint8_t* type, const uint32_t* stn, const double* trow, const double* S, uint32_t nps, double* prec, uint32_t n_t,
+                       hipStream_t s);
 void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s);
 void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const double* b, double* wb,
                      uint32_t n_vec, const uint32_t* ioff, const uint32_t* inc, double* rhs, uint32_t n_stn, hipStream_t s);

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "adjust_kernels.h"
+#include "terrestrial.h"
 
 #pragma clang fp contract(off)
 
@@ -92,7 +93,8 @@ __global__ void compute_b_kernel(const uint32_t* __restrict__ s1, const uint32_t
 // (CML order) of +-W_block(ei, ej); a contribution = (index of a 3x3 weight block) << 1 | negative
 __global__ void form_normals_kernel(const uint32_t* __restrict__ prow, const uint32_t* __restrict__ pcol,
                                     const uint32_t* __restrict__ poff, const uint32_t* __restrict__ pent,
-                                    const double* __restrict__ wblk, double* __restrict__ F, uint32_t np, uint32_t n_pairs) {
+                                    const double* __restrict__ wblk, double* __restrict__ F, uint32_t np, uint32_t n_pairs,
+                                    uint32_t n_gnss_blk, uint32_t terr_shift) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_pairs * 9) return;
     uint32_t p = t / 9, e = t - p * 9;
@@ -103,7 +105,11 @@ __global__ void form_normals_kernel(const uint32_t* __restrict__ prow, const uin
     uint32_t k0 = poff[p], k1 = poff[p + 1];
     for (uint32_t k = k0; k < k1; ++k) {
         uint32_t ent = pent[k];
-        double w = wblk[(size_t)(ent >> 1) * 9 + e];
+        // blocks of terrestrial measurements change with the estimates and exist once per chain: they follow the
+        // (constant) GNSS weight blocks, chain c's copy terr_shift = c * n_terrestrial_blocks further on
+        uint32_t blk = ent >> 1;
+        if (blk >= n_gnss_blk) blk += terr_shift;
+        double w = wblk[(size_t)blk * 9 + e];
         s += (ent & 1u) ? -w : w;
     }
     F[(size_t)(3 * c + ej) * np + 3 * r + ei] = s;
@@ -166,6 +172,86 @@ __global__ void msr_stats_kernel(const uint32_t* __restrict__ s1, const uint32_t
             }
             prec6[(size_t)v * 6 + q] = p;
         }
+}
+
+// ---- terrestrial measurements (one design row each; terrestrial.h) -----------------------------------------------------
+// station records -> geodetic coordinates of the current estimates (UpdateGeographicCoords, dnaadjust.cpp:8711/8734)
+__global__ void geodetic_kernel(const double* __restrict__ xe, double* __restrict__ llh, uint32_t n_stn) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_stn) return;
+    dnagpu::tm::cart_to_geo(xe + 3 * (size_t)s, &llh[3 * (size_t)s], &llh[3 * (size_t)s + 1], &llh[3 * (size_t)s + 2]);
+}
+
+__device__ __forceinline__ dnagpu::tm::StationGeo load_geo(const double* llh, const double* geoid, const double* defl, uint32_t s) {
+    dnagpu::tm::StationGeo g;
+    g.lat = llh[3 * (size_t)s];
+    g.lon = llh[3 * (size_t)s + 1];
+    g.h = llh[3 * (size_t)s + 2];
+    g.geoid = geoid[s];
+    g.defl_v = defl[2 * (size_t)s];
+    g.defl_m = defl[2 * (size_t)s + 1];
+    return g;
+}
+
+// One thread per terrestrial measurement (FillDesignNormalMeasurementsMatrices for these types): computed value,
+// meas-minus-computed, design row, then everything the formation kernels consume -- the 3x3 blocks w a_p^T a_q of its
+// station pairs (p, q with local(p) >= local(q), the enumeration the host used for the pair lists) and the vectors
+// a_p w b per station ("virtual" W b vectors behind the GNSS ones).
+__global__ void tmsr_eval_kernel(const uint8_t* __restrict__ type, const uint32_t* __restrict__ stn, const double* __restrict__ val,
+                                 const double* __restrict__ pre, const double* __restrict__ var, const double* __restrict__ ih,
+                                 const double* __restrict__ th, const uint32_t* __restrict__ blk0, const uint32_t* __restrict__ vec0,
+                                 const double* __restrict__ xe, const double* __restrict__ llh, const double* __restrict__ geoid,
+                                 const double* __restrict__ defl, double* __restrict__ tb, double* __restrict__ trow,
+                                 double* __restrict__ tblk, double* __restrict__ wb, uint32_t n_bl, uint32_t n_t) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_t) return;
+    const char ty = (char)type[t];
+    const int ns = dnagpu::tm::station_count(ty);
+    uint32_t l[3] = {stn[3 * (size_t)t], stn[3 * (size_t)t + 1], stn[3 * (size_t)t + 2]};
+    if (ns < 2) l[1] = l[0];
+    if (ns < 3) l[2] = l[0];
+    const double* X1 = xe + 3 * (size_t)l[0];
+    const double* X2 = xe + 3 * (size_t)l[1];
+    const double* X3 = xe + 3 * (size_t)l[2];
+    const dnagpu::tm::StationGeo g1 = load_geo(llh, geoid, defl, l[0]), g2 = load_geo(llh, geoid, defl, l[1]);
+    double row[9];
+    const double value = dnagpu::tm::working_value(ty, val[t], pre[t], X1, X2, g1, g2);
+    const double comp = dnagpu::tm::evaluate(ty, X1, X2, X3, g1, g2, ih[t], th[t], row);
+    const double b = dnagpu::tm::meas_minus_comp(ty, value, comp);
+    tb[t] = b;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) trow[9 * (size_t)t + i] = row[i];
+    const double w = 1.0 / var[t];
+    const double wbv = w * b;
+    for (int q = 0; q < ns; ++q)
+        for (int r = 0; r < 3; ++r) wb[3 * ((size_t)n_bl + vec0[t] + q) + r] = row[3 * q + r] * wbv;
+    uint32_t idx = blk0[t];
+    for (int p = 0; p < ns; ++p)
+        for (int q = 0; q < ns; ++q) {
+            if (p != q && !(l[p] > l[q])) continue;
+            double* o = tblk + 9 * (size_t)idx++;
+            for (int e = 0; e < 9; ++e) o[e] = (w * row[3 * p + e % 3]) * row[3 * q + e / 3];
+        }
+}
+
+// precision of the adjusted terrestrial measurements: a S a^T (ComputePrecisionAdjMsrs_A / _BCEKLMSVZ / _HIJPQR,
+// dnaadjust.cpp:7877-8007); S read from its lower triangle
+__global__ void tmsr_stats_kernel(const uint8_t* __restrict__ type, const uint32_t* __restrict__ stn, const double* __restrict__ trow,
+                                  const double* __restrict__ S, uint32_t nps, double* __restrict__ prec, uint32_t n_t) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_t) return;
+    const int ns = dnagpu::tm::station_count((char)type[t]);
+    auto sym = [&](uint32_t r, uint32_t c) { return r >= c ? S[(size_t)c * nps + r] : S[(size_t)r * nps + c]; };
+    const double* dr = trow + 9 * (size_t)t;
+    double acc = 0.0;
+    for (int s_ = 0; s_ < ns; ++s_)
+        for (int i = 0; i < 3; ++i) {
+            double part = 0.0;
+            for (int j = 0; j < ns; ++j)
+                for (int e = 0; e < 3; ++e) part += dr[3 * j + e] * sym(3 * stn[3 * (size_t)t + j] + e, 3 * stn[3 * (size_t)t + s_] + i);
+            acc += part * dr[3 * s_ + i];
+        }
+    prec[t] = acc;
 }
 
 // rhs(3s+c) = sum over incident vectors (CML order) of +-(W b)_c
@@ -282,9 +368,26 @@ void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs,
     hipLaunchKernelGGL(compute_b_kernel, dim3((n_bl * 3 + 255) / 256), dim3(256), 0, s, s1, s2, obs, xe, b, n_bl);
 }
 void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pent, const double* wblk, double* F,
-                         uint32_t np, uint32_t n_pairs, hipStream_t s) {
+                         uint32_t np, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift, hipStream_t s) {
     if (!n_pairs) return;
-    hipLaunchKernelGGL(form_normals_kernel, dim3((n_pairs * 9 + 255) / 256), dim3(256), 0, s, prow, pcol, poff, pent, wblk, F, np, n_pairs);
+    hipLaunchKernelGGL(form_normals_kernel, dim3((n_pairs * 9 + 255) / 256), dim3(256), 0, s, prow, pcol, poff, pent, wblk, F, np, n_pairs,
+                       n_gnss_blk, terr_shift);
+}
+void launch_geodetic(const double* xe, double* llh, uint32_t n_stn, hipStream_t s) {
+    if (!n_stn) return;
+    hipLaunchKernelGGL(geodetic_kernel, dim3((n_stn + 127) / 128), dim3(128), 0, s, xe, llh, n_stn);
+}
+void launch_tmsr_eval(const uint8_t* type, const uint32_t* stn, const double* val, const double* pre, const double* var, const double* ih,
+                      const double* th, const uint32_t* blk0, const uint32_t* vec0, const double* xe, const double* llh, const double* geoid,
+                      const double* defl, double* tb, double* trow, double* tblk, double* wb, uint32_t n_bl, uint32_t n_t, hipStream_t s) {
+    if (!n_t) return;
+    hipLaunchKernelGGL(tmsr_eval_kernel, dim3((n_t + 63) / 64), dim3(64), 0, s, type, stn, val, pre, var, ih, th, blk0, vec0, xe, llh, geoid,
+                       defl, tb, trow, tblk, wb, n_bl, n_t);
+}
+void launch_tmsr_stats(const uint8_t* type, const uint32_t* stn, const double* trow, const double* S, uint32_t nps, double* prec, uint32_t n_t,
+                       hipStream_t s) {
+    if (!n_t) return;
+    hipLaunchKernelGGL(tmsr_stats_kernel, dim3((n_t + 63) / 64), dim3(64), 0, s, type, stn, trow, S, nps, prec, n_t);
 }
 void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s) {
     if (!k) return;

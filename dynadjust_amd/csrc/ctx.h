@@ -46,6 +46,18 @@ struct Block {
     uint32_t *inc_off = nullptr, *inc = nullptr;
     // scratch for max-correction reduction (value, index) per chain
     double* red[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    // terrestrial measurements (one design row each; csrc/terrestrial.h).  Their 3x3 blocks w a_p^T a_q and vectors
+    // a_p w b change with the estimates: one copy per chain, behind the GNSS weight blocks / W b vectors
+    uint32_t n_t = 0, n_tblk = 0, n_tvec = 0;
+    uint8_t* t_type = nullptr;
+    uint32_t *t_stn = nullptr, *t_blk0 = nullptr, *t_vec0 = nullptr;
+    double *t_val = nullptr, *t_pre = nullptr, *t_var = nullptr, *t_ih = nullptr, *t_th = nullptr;
+    double *s_llh = nullptr, *s_geoid = nullptr, *s_defl = nullptr;     // station records: geodetic position, N, deflections
+    double* tb[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};                 // n_t: measured - computed
+    double* trow[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};               // 9 n_t: design rows
+    // host copies kept until the pair / incidence lists are built (dnagpu_block_set_clusters)
+    std::vector<uint8_t> h_ttype;
+    std::vector<uint32_t> h_tstn, h_tpos, h_cpos;
 };
 
 }  // namespace dnagpu

@@ -8,6 +8,7 @@
 #include "adjust_kernels.h"
 #include "ctx.h"
 #include "la_kernels.h"
+#include "terrestrial.h"
 #include "sym_inverse.h"
 
 using namespace dnagpu;
@@ -126,7 +127,9 @@ Block* find_block(dnagpu_ctx* ctx, uint32_t blk) {
 void free_block(Block& b) {
     void* ptrs[] = {b.x_orig, b.x_est[0], b.x_est[1], b.x_rig, b.rhs[0], b.rhs[1], b.corr[0], b.corr[1], b.s1, b.s2, b.obs, b.Wblk,
                     b.vec_wrow, b.vec_c0, b.vec_k, b.wb[0], b.wb[1],
-                    b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc, b.red[0], b.red[1]};
+                    b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc, b.red[0], b.red[1],
+                    b.t_type, b.t_stn, b.t_blk0, b.t_vec0, b.t_val, b.t_pre, b.t_var, b.t_ih, b.t_th, b.s_llh, b.s_geoid, b.s_defl,
+                    b.tb[0], b.tb[1], b.trow[0], b.trow[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     b = Block();
@@ -535,6 +538,90 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz) 
     return DNAGPU_OK;
 }
 
+int dnagpu_block_set_station_geo(dnagpu_ctx* ctx, uint32_t blk, const double* llh, const double* geoid, const double* defl) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b || (b->n_stn && (!llh || !geoid || !defl))) return fail(ctx, DNAGPU_EINVAL, "block_set_station_geo: bad arguments");
+    const size_t ns = std::max<size_t>(b->n_stn, 1);
+    if (!b->s_llh) {
+        HIPCHK(hipMalloc(&b->s_llh, 3 * ns * sizeof(double)));
+        HIPCHK(hipMalloc(&b->s_geoid, ns * sizeof(double)));
+        HIPCHK(hipMalloc(&b->s_defl, 2 * ns * sizeof(double)));
+    }
+    if (!b->n_stn) return DNAGPU_OK;
+    HIPCHK(hipMemcpy(b->s_llh, llh, 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->s_geoid, geoid, (size_t)b->n_stn * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->s_defl, defl, 2 * (size_t)b->n_stn * sizeof(double), hipMemcpyHostToDevice));
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, const char* type, const uint32_t* stn3, const double* value,
+                                 const double* pre_adj_meas, const double* variance, const double* inst_height, const double* targ_height,
+                                 const uint32_t* cml_pos, const uint32_t* cluster_cml_pos, uint32_t n_clusters) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b || (n_t && (!type || !stn3 || !value || !pre_adj_meas || !variance || !inst_height || !targ_height || !cml_pos)))
+        return fail(ctx, DNAGPU_EINVAL, "block_set_terrestrial: bad arguments");
+    std::vector<uint32_t> blk0(n_t), vec0(n_t);
+    uint32_t nb = 0, nv = 0;
+    for (uint32_t t = 0; t < n_t; ++t) {
+        if (!dnagpu::tm::is_terrestrial(type[t])) return fail(ctx, DNAGPU_EINVAL, "block_set_terrestrial: measurement type not handled");
+        const int ns = dnagpu::tm::station_count(type[t]);
+        for (int q = 0; q < ns; ++q) {
+            if (stn3[3 * (size_t)t + q] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "block_set_terrestrial: station index out of range");
+            for (int r = 0; r < q; ++r)
+                if (stn3[3 * (size_t)t + q] == stn3[3 * (size_t)t + r])
+                    return fail(ctx, DNAGPU_EINVAL, "block_set_terrestrial: a measurement names one station twice");
+        }
+        if (!(variance[t] > 0.0)) return fail(ctx, DNAGPU_EINVAL, "block_set_terrestrial: non-positive variance");
+        blk0[t] = nb;
+        vec0[t] = nv;
+        nb += (uint32_t)(ns * (ns + 1) / 2);
+        nv += (uint32_t)ns;
+    }
+    for (void* p : {(void*)b->t_type, (void*)b->t_stn, (void*)b->t_blk0, (void*)b->t_vec0, (void*)b->t_val, (void*)b->t_pre, (void*)b->t_var,
+                    (void*)b->t_ih, (void*)b->t_th, (void*)b->tb[0], (void*)b->tb[1], (void*)b->trow[0], (void*)b->trow[1]})
+        if (p) hipFree(p);
+    b->t_type = nullptr;
+    b->t_stn = b->t_blk0 = b->t_vec0 = nullptr;
+    b->t_val = b->t_pre = b->t_var = b->t_ih = b->t_th = nullptr;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) b->tb[c] = b->trow[c] = nullptr;
+    b->n_t = n_t;
+    b->n_tblk = nb;
+    b->n_tvec = nv;
+    b->h_ttype.assign(type, type + n_t);
+    b->h_tstn.assign(stn3, stn3 + 3 * (size_t)n_t);
+    b->h_tpos.assign(cml_pos, cml_pos + n_t);
+    b->h_cpos.clear();
+    if (cluster_cml_pos) b->h_cpos.assign(cluster_cml_pos, cluster_cml_pos + n_clusters);
+    // the W b vectors of the GNSS measurements are followed by the terrestrial ones
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        if (b->wb[c]) hipFree(b->wb[c]);
+        b->wb[c] = nullptr;
+        HIPCHK(hipMalloc(&b->wb[c], std::max<size_t>((size_t)b->n_bl + nv, 1) * 3 * sizeof(double)));
+    }
+    if (!n_t) return DNAGPU_OK;
+    auto upv = [&](void** dev, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dev, bytes);
+        if (e == hipSuccess) e = hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIPCHK(upv((void**)&b->t_type, type, n_t));
+    HIPCHK(upv((void**)&b->t_stn, stn3, 3 * (size_t)n_t * sizeof(uint32_t)));
+    HIPCHK(upv((void**)&b->t_blk0, blk0.data(), n_t * sizeof(uint32_t)));
+    HIPCHK(upv((void**)&b->t_vec0, vec0.data(), n_t * sizeof(uint32_t)));
+    HIPCHK(upv((void**)&b->t_val, value, n_t * sizeof(double)));
+    HIPCHK(upv((void**)&b->t_pre, pre_adj_meas, n_t * sizeof(double)));
+    HIPCHK(upv((void**)&b->t_var, variance, n_t * sizeof(double)));
+    HIPCHK(upv((void**)&b->t_ih, inst_height, n_t * sizeof(double)));
+    HIPCHK(upv((void**)&b->t_th, targ_height, n_t * sizeof(double)));
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        HIPCHK(hipMalloc(&b->tb[c], n_t * sizeof(double)));
+        HIPCHK(hipMalloc(&b->trow[c], 9 * (size_t)n_t * sizeof(double)));
+    }
+    return DNAGPU_OK;
+}
+
 int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
                               uint32_t n_clusters, const uint32_t* cluster_off, const double* vcv) {
     CHK_CTX();
@@ -572,10 +659,13 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     // sign(a) sign(a') W(j, j'); the mirrored (a < a') case is produced by the pair (j', j).
     struct Ent {
         uint64_t key;
+        uint32_t pos;   // position of the measurement in the block's CML (contributions are summed in that order)
         uint32_t ent;
     };
     std::vector<Ent> ents;
-    ents.reserve((size_t)m * 3);
+    ents.reserve((size_t)m * 3 + (size_t)b->n_t * 3);
+    const bool have_cpos = b->h_cpos.size() == n_clusters && n_clusters > 0;
+    auto cluster_pos = [&](uint32_t c) { return have_cpos ? b->h_cpos[c] : c; };
     for (uint32_t c = 0; c < n_clusters; ++c) {
         const uint32_t v0 = cluster_off[c], k = cluster_off[c + 1] - v0;
         for (uint32_t j = 0; j < k; ++j)
@@ -590,12 +680,24 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
                     for (int y = 0; y < 2; ++y) {
                         if (eb[y] == DNAGPU_NO_STATION) continue;
                         if (ea[x] < eb[y]) continue;
-                        ents.push_back({(uint64_t)ea[x] * ns + eb[y], (blkidx << 1) | (uint32_t)(x != y)});
+                        ents.push_back({(uint64_t)ea[x] * ns + eb[y], cluster_pos(c), (blkidx << 1) | (uint32_t)(x != y)});
                     }
                 }
             }
     }
-    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
+    // terrestrial measurements: one 3x3 block w a_p^T a_q per station pair with local(p) >= local(q), enumerated as
+    // tmsr_eval_kernel writes them; block indices continue after the GNSS weight blocks
+    for (uint32_t t = 0, tb = 0; t < b->n_t; ++t) {
+        const int nst = dnagpu::tm::station_count((char)b->h_ttype[t]);
+        const uint32_t* l = &b->h_tstn[3 * (size_t)t];
+        for (int pp = 0; pp < nst; ++pp)
+            for (int qq = 0; qq < nst; ++qq) {
+                if (pp != qq && !(l[pp] > l[qq])) continue;
+                ents.push_back({(uint64_t)l[pp] * ns + l[qq], b->h_tpos[t], ((n_wblk + tb) << 1)});
+                ++tb;
+            }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key != y.key ? x.key < y.key : x.pos < y.pos; });
     std::vector<uint32_t> prow, pcol, poff, pent(ents.size());
     for (size_t k = 0; k < ents.size(); ++k) {
         if (k == 0 || ents[k].key != ents[k - 1].key) {
@@ -607,20 +709,28 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     }
     poff.push_back((uint32_t)ents.size());
     // incidence per station (CML order): vector * 2 + (1 if the station is the vector's second / only station)
-    std::vector<uint32_t> ioff(ns + 1, 0), inc;
-    for (uint32_t i = 0; i < m; ++i) {
-        if (stn1[i] != DNAGPU_NO_STATION) ioff[stn1[i] + 1]++;
-        ioff[stn2[i] + 1]++;
+    // (terrestrial measurements add "virtual" vectors a_p w b behind the GNSS ones, always with a positive sign)
+    struct Inc {
+        uint32_t stn, pos, ent;
+    };
+    std::vector<Inc> incs;
+    incs.reserve((size_t)m * 2 + b->n_tvec);
+    for (uint32_t c = 0; c < n_clusters; ++c)
+        for (uint32_t i = cluster_off[c]; i < cluster_off[c + 1]; ++i) {
+            if (stn1[i] != DNAGPU_NO_STATION) incs.push_back({stn1[i], cluster_pos(c), i * 2u});
+            incs.push_back({stn2[i], cluster_pos(c), i * 2u + 1u});
+        }
+    for (uint32_t t = 0, tv = 0; t < b->n_t; ++t) {
+        const int nst = dnagpu::tm::station_count((char)b->h_ttype[t]);
+        for (int q = 0; q < nst; ++q, ++tv) incs.push_back({b->h_tstn[3 * (size_t)t + q], b->h_tpos[t], (m + tv) * 2u + 1u});
+    }
+    std::stable_sort(incs.begin(), incs.end(), [](const Inc& x, const Inc& y) { return x.stn != y.stn ? x.stn < y.stn : x.pos < y.pos; });
+    std::vector<uint32_t> ioff(ns + 1, 0), inc(incs.size());
+    for (size_t k = 0; k < incs.size(); ++k) {
+        ioff[incs[k].stn + 1]++;
+        inc[k] = incs[k].ent;
     }
     for (uint32_t s = 0; s < ns; ++s) ioff[s + 1] += ioff[s];
-    inc.assign(ioff[ns], 0);
-    {
-        std::vector<uint32_t> cur(ioff.begin(), ioff.end() - 1);
-        for (uint32_t i = 0; i < m; ++i) {
-            if (stn1[i] != DNAGPU_NO_STATION) inc[cur[stn1[i]]++] = i * 2u;
-            inc[cur[stn2[i]]++] = i * 2u + 1u;
-        }
-    }
 
     for (void* p : {(void*)b->pair_row, (void*)b->pair_col, (void*)b->pair_off, (void*)b->pair_ent, (void*)b->inc_off, (void*)b->inc,
                     (void*)b->Wblk})
@@ -641,7 +751,7 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     HIPCHK(up(&b->pair_ent, pent));
     HIPCHK(up(&b->inc_off, ioff));
     HIPCHK(up(&b->inc, inc));
-    HIPCHK(hipMalloc(&b->Wblk, std::max<size_t>(n_wblk, 1) * 9 * sizeof(double)));
+    HIPCHK(hipMalloc(&b->Wblk, std::max<size_t>((size_t)n_wblk + (size_t)DNAGPU_NUM_CHAINS * b->n_tblk, 1) * 9 * sizeof(double)));
     if (!m) return DNAGPU_OK;
     HIPCHK(hipMemcpy(b->s1, stn1, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->s2, stn2, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -769,13 +879,68 @@ int dnagpu_block_copy_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, int dst
     return DNAGPU_OK;
 }
 
+static int d2h_early(dnagpu_ctx* ctx, int chain, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return DNAGPU_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream[chain]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
 int dnagpu_block_compute_b(dnagpu_ctx* ctx, int chain, uint32_t blk) {
     CHK_CTX();
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
     if (!b) return fail(ctx, DNAGPU_EINVAL, "block_compute_b: unknown block");
     launch_compute_b(b->s1, b->s2, b->obs, b->x_est[chain], b->b[chain], b->n_bl, ctx->stream[chain]);
+    if (b->n_t) {
+        if (!b->s_llh || !b->Wblk) return fail(ctx, DNAGPU_EINVAL, "block_compute_b: station records / measurement lists not set");
+        launch_tmsr_eval(b->t_type, b->t_stn, b->t_val, b->t_pre, b->t_var, b->t_ih, b->t_th, b->t_blk0, b->t_vec0, b->x_est[chain], b->s_llh,
+                         b->s_geoid, b->s_defl, b->tb[chain], b->trow[chain],
+                         b->Wblk + ((size_t)b->n_wblk + (size_t)chain * b->n_tblk) * 9, b->wb[chain], b->n_bl, b->n_t, ctx->stream[chain]);
+    }
     return DNAGPU_OK;
+}
+
+int dnagpu_block_update_geodetic(dnagpu_ctx* ctx, int chain, uint32_t blk) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !b->s_llh) return fail(ctx, DNAGPU_EINVAL, "block_update_geodetic: unknown block or no station records");
+    launch_geodetic(b->x_est[chain], b->s_llh, b->n_stn, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_get_station_llh(dnagpu_ctx* ctx, int chain, uint32_t blk, double* llh) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !b->s_llh || (!llh && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_station_llh: bad arguments");
+    return d2h_early(ctx, chain, llh, b->s_llh, 3 * (size_t)b->n_stn * sizeof(double));
+}
+
+int dnagpu_block_get_terrestrial(dnagpu_ctx* ctx, int chain, uint32_t blk, double* meas_minus_comp, double* design_rows) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b) return fail(ctx, DNAGPU_EINVAL, "block_get_terrestrial: unknown block");
+    if (!b->n_t) return DNAGPU_OK;
+    int rc = DNAGPU_OK;
+    if (meas_minus_comp) rc = d2h_early(ctx, chain, meas_minus_comp, b->tb[chain], (size_t)b->n_t * sizeof(double));
+    if (!rc && design_rows) rc = d2h_early(ctx, chain, design_rows, b->trow[chain], 9 * (size_t)b->n_t * sizeof(double));
+    return rc;
+}
+
+int dnagpu_block_terrestrial_precisions(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* variances, double* prec) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !variances || variances->n != 3 * b->n_stn || (b->n_t && !prec))
+        return fail(ctx, DNAGPU_EINVAL, "block_terrestrial_precisions: bad arguments");
+    if (!b->n_t) return DNAGPU_OK;
+    int rc = ensure_scr_f64(ctx, chain, b->n_t);
+    if (rc) return rc;
+    launch_tmsr_stats(b->t_type, b->t_stn, b->trow[chain], variances->F, variances->np, ctx->scr_f64[chain], b->n_t, ctx->stream[chain]);
+    return d2h_early(ctx, chain, prec, ctx->scr_f64[chain], (size_t)b->n_t * sizeof(double));
 }
 
 static int d2h(dnagpu_ctx* ctx, int chain, void* dst, const void* src, size_t bytes) {
@@ -848,7 +1013,8 @@ int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
     m->n = 3 * b->n_stn;
     m->np = pad128(m->n);
     launch_init_padded(m->F, m->n, m->np, ctx->stream[chain]);
-    launch_form_normals(b->pair_row, b->pair_col, b->pair_off, b->pair_ent, b->Wblk, m->F, m->np, b->n_pairs, ctx->stream[chain]);
+    launch_form_normals(b->pair_row, b->pair_col, b->pair_off, b->pair_ent, b->Wblk, m->F, m->np, b->n_pairs, b->n_wblk,
+                        (uint32_t)chain * b->n_tblk, ctx->stream[chain]);
     return DNAGPU_OK;
 }
 

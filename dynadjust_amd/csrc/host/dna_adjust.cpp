@@ -11,6 +11,7 @@
 
 #include "geodesy.hpp"
 #include "gnss_vcv.hpp"
+#include "../terrestrial.h"
 
 namespace dynadjust {
 namespace networkadjust {
@@ -112,7 +113,7 @@ void dna_adjust::BuildSimultaneousLists() {
         const measurement_t& r = bmsBinaryRecords_[m];
         if (r.ignore) continue;
         if (r.measStart > 2) continue;    // covariance rows (measurement_processor.cpp:79-83)
-        rows++;                           // every X / Y / Z element is one design row
+        rows++;                           // every X / Y / Z element (and every terrestrial measurement) is one design row
         if (r.measStart != 0) continue;   // only the first element starts a measurement
         if (r.measType == 'X' || r.measType == 'Y') {
             // only the first vector of a cluster enters the CML (measurement_processor.cpp:86-122)
@@ -417,10 +418,51 @@ void dna_adjust::ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B) {
     B.cluster_off.push_back((UINT32)B.stn1.size());
 }
 
+// One terrestrial measurement (types A B C E H K L M R S V Z): station indices, variance, instrument / target height,
+// and the one-time reductions the reference applies when the matrices are first built (InitialiseMeasurement ADJ:3913;
+// deflection of the vertical and geoid separation in the type's UpdateDesignNormalMeasMatrices_*, see terrestrial.h)
+void dna_adjust::ParseTerrestrialMeasurement(UINT32 block, UINT32 m, block_t& B, const std::vector<double>& xyz) {
+    measurement_t& rec = bmsBinaryRecords_[m];
+    const char type = rec.measType;
+    if (rec.measStart != 0) SignalExceptionAdjustment("PrepareAdjustment(): malformed terrestrial measurement record.", block);
+    if (!(rec.term2 > 0.0)) SignalExceptionAdjustment("PrepareAdjustment(): a measurement with a non-positive variance.", block);
+    const int nst = dnagpu::tm::station_count(type);
+    const UINT32 gl[3] = {rec.station1, rec.station2, rec.station3};
+    UINT32 loc[3] = {0, 0, 0};
+    dnagpu::tm::StationGeo g[3];
+    const double* X[3];
+    static const double zero3[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < 3; ++q) {
+        X[q] = zero3;
+        g[q] = dnagpu::tm::StationGeo{0, 0, 0, 0, 0, 0};
+        if (q >= nst) continue;
+        loc[q] = LocalIndex(block, gl[q]);
+        const station_t& st = bstBinaryRecords_.at(gl[q]);
+        g[q] = dnagpu::tm::StationGeo{st.currentLatitude, st.currentLongitude, st.currentHeight, (double)st.geoidSep, st.verticalDef, st.meridianDef};
+        X[q] = &xyz[3 * (size_t)loc[q]];
+    }
+    if (bms_meta_.reduced)
+        rec.term1 = rec.preAdjMeas;   // a file written by an earlier adjustment: start again from the supplied value (ADJ:3922-3924)
+    else
+        rec.preAdjMeas = rec.term1;
+    double value = rec.term1;
+    rec.preAdjCorr = dnagpu::tm::reduce(type, &value, X[0], X[1], X[2], g[0], g[1], g[2], rec.term3, rec.term4);
+    rec.term1 = value;
+    B.t_type.push_back(type);
+    for (int q = 0; q < 3; ++q) B.t_stn.push_back(loc[q]);
+    B.t_rec.push_back(m);
+    B.t_val.push_back(rec.term1);
+    B.t_pre.push_back(rec.preAdjMeas);
+    B.t_var.push_back(rec.term2);
+    B.t_ih.push_back(rec.term3);
+    B.t_th.push_back(rec.term4);
+}
+
 // PrepareAdjustmentBlock (ADJ:2873) for every block: host lists + device upload
 void dna_adjust::PrepareBlocks() {
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
     blocks_.assign(blockCount_, block_t());
+    containsNonGPS_ = false;
     initial_xyz_.assign(blockCount_, {});
     max_unknowns_ = 0;
     max_junction_ = 0;
@@ -452,10 +494,17 @@ void dna_adjust::PrepareBlocks() {
         const std::vector<UINT32>& cml = v_CML_[b];
         B.cluster_off.assign(1, 0);
         for (UINT32 m : cml) {
-            if ((size_t)m + 2 >= bmsBinaryRecords_.size())
-                SignalExceptionAdjustment("PrepareAdjustment(): measurement index out of range.", b);
+            if ((size_t)m >= bmsBinaryRecords_.size()) SignalExceptionAdjustment("PrepareAdjustment(): measurement index out of range.", b);
             if (bmsBinaryRecords_[m].ignore) continue;   // InitialiseandValidateMsrPointer
-            ParseGnssMeasurement(b, m, B);
+            const UINT32 pos = (UINT32)(B.c_pos.size() + B.t_pos.size());
+            if (dnagpu::tm::is_terrestrial(bmsBinaryRecords_[m].measType)) {
+                ParseTerrestrialMeasurement(b, m, B, xyz);
+                B.t_pos.push_back(pos);
+                containsNonGPS_ = true;
+            } else {
+                ParseGnssMeasurement(b, m, B);
+                B.c_pos.push_back(pos);
+            }
         }
         // constraint lists (ADJ:1884-2037)
         for (UINT32 p = 0; p < ns; ++p) {
@@ -485,6 +534,23 @@ void dna_adjust::PrepareBlocks() {
         // device
         Check(dnagpu_block_create(ctx_, b, ns, (UINT32)B.stn1.size()), b, "PrepareAdjustment(): block allocation");
         Check(dnagpu_block_set_stations(ctx_, b, xyz.data()), b, "PrepareAdjustment(): stations");
+        {
+            // station records the terrestrial measurement models read (current geodetic position, N, deflections)
+            std::vector<double> llh(3 * (size_t)ns), geoid(ns), defl(2 * (size_t)ns);
+            for (UINT32 p = 0; p < ns; ++p) {
+                const station_t& st = bstBinaryRecords_[plist[p]];
+                llh[3 * p] = st.currentLatitude;
+                llh[3 * p + 1] = st.currentLongitude;
+                llh[3 * p + 2] = st.currentHeight;
+                geoid[p] = st.geoidSep;
+                defl[2 * p] = st.verticalDef;
+                defl[2 * p + 1] = st.meridianDef;
+            }
+            Check(dnagpu_block_set_station_geo(ctx_, b, llh.data(), geoid.data(), defl.data()), b, "PrepareAdjustment(): station records");
+        }
+        Check(dnagpu_block_set_terrestrial(ctx_, b, (UINT32)B.t_type.size(), B.t_type.data(), B.t_stn.data(), B.t_val.data(), B.t_pre.data(),
+                                           B.t_var.data(), B.t_ih.data(), B.t_th.data(), B.t_pos.data(), B.c_pos.data(), (UINT32)B.c_pos.size()),
+              b, "PrepareAdjustment(): terrestrial measurements");
         Check(dnagpu_block_set_clusters(ctx_, b, B.stn1.data(), B.stn2.data(), B.obs.data(), (UINT32)B.cluster_off.size() - 1,
                                         B.cluster_off.data(), B.vcv.data()),
               b, "PrepareAdjustment(): measurements");
@@ -603,12 +669,15 @@ void dna_adjust::AdjustSimultaneous() {
         if (IsCancelled()) break;
         ++currentIteration_;
         currentBlock_ = 0;
-        if (currentIteration_ < 2) {
+        // the inverse is only formed again if the network has non-GPS measurements, whose design follows the estimates
+        // (SolveTry(CurrentIteration() < 2 || ContainsNonGPS()), ADJ:2457; UpdateNormals in UpdateAdjustment, ADJ:582-590)
+        const bool invert = currentIteration_ < 2 || containsNonGPS_;
+        if (invert) {
             Check(dnagpu_form_normals(ctx_, c, 0, W), 0, "UpdateNormals()");
             AddConstraints(c, W, B.con_sim, +1, 0);
         }
         Check(dnagpu_form_rhs(ctx_, c, 0), 0, "Solve()");
-        if (currentIteration_ < 2)
+        if (invert)
             SolveTry(c, 0, W);
         else
             Check(dnagpu_solve_corrections(ctx_, c, 0, W), 0, "Solve()");
@@ -654,6 +723,9 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
         // v_estimatedStationsR_ = v_rigorousStations_ ADJ:569; v_estimatedStations_ = v_estimatedStationsR_ ADJ:3799)
         for (int c = 0; c < chains; ++c) {
             if (phased) Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
+            // non-GPS networks: the station records follow the estimates, the design of the next iteration is formed
+            // in their local frames (UpdateGeographicCoords[Phased], ADJ:496-531, ADJ:541-545)
+            if (containsNonGPS_) Check(dnagpu_block_update_geodetic(ctx_, c, b), b, "UpdateGeographicCoords()");
             Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
         }
     }
@@ -775,6 +847,7 @@ void dna_adjust::ComputeStatistics() {
         for (UINT32 m : v_CML_[b]) {
             if (bmsBinaryRecords_[m].ignore || bmsBinaryRecords_[m].measStart != 0) continue;
             const char type = bmsBinaryRecords_[m].measType;
+            if (dnagpu::tm::is_terrestrial(type)) continue;   // below
             const UINT32 k = (type == 'G') ? 1 : bmsBinaryRecords_[m].vectorCount1;
             size_t r = m;
             for (UINT32 j = 0; j < k; ++j, ++v) {
@@ -791,6 +864,53 @@ void dna_adjust::ComputeStatistics() {
         // ComputeChiSquare (ADJ:7257): the per-vector terms b.(W b) summed in CML order
         double cs = 0.0;
         for (size_t i = 0; i < nv; ++i) cs += chi[i];
+        // terrestrial measurements: a S a^T from the device, the rest of UpdateMsrRecord (ADJ:8187) here
+        const size_t nt = B.t_type.size();
+        if (nt) {
+            std::vector<double> tprec(nt), tb(nt), llh(3 * v_parameterStationList_[b].size()), xr;
+            Check(dnagpu_block_terrestrial_precisions(ctx_, 0, b, var, tprec.data()), b, "ComputePrecisionAdjMsrs()");
+            Check(dnagpu_block_get_terrestrial(ctx_, 0, b, tb.data(), nullptr), b, "UpdateMsrRecords()");
+            Check(dnagpu_block_get_station_llh(ctx_, 0, b, llh.data()), b, "UpdateMsrRecords()");
+            GetBlockStations(b, 1, xr);
+            for (size_t t = 0; t < nt; ++t) {
+                measurement_t& rec = bmsBinaryRecords_[B.t_rec[t]];
+                const char type = B.t_type[t];
+                const UINT32* l = &B.t_stn[3 * t];
+                auto geo = [&](UINT32 p) {
+                    const station_t& st = bstBinaryRecords_[v_parameterStationList_[b][p]];
+                    return dnagpu::tm::StationGeo{llh[3 * p], llh[3 * p + 1], llh[3 * p + 2], (double)st.geoidSep, st.verticalDef, st.meridianDef};
+                };
+                const dnagpu::tm::StationGeo g1 = geo(l[0]), g2 = geo(dnagpu::tm::station_count(type) > 1 ? l[1] : l[0]);
+                const double* X1 = &xr[3 * (size_t)l[0]];
+                const double* X2 = &xr[3 * (size_t)(dnagpu::tm::station_count(type) > 1 ? l[1] : l[0])];
+                // E and M work with the ellipsoid chord derived from the supplied arc (ADJ:5254, ADJ:5412)
+                rec.term1 = dnagpu::tm::working_value(type, rec.term1, rec.preAdjMeas, X1, X2, g1, g2);
+                if (type == 'E' || type == 'M') rec.preAdjCorr = rec.term1 - rec.preAdjMeas;
+                UpdateMsrRecord(rec, -tb[t], tprec[t], rec.term2);
+                switch (type) {   // "Recompute measurements using the original types" (ADJ:8211-8268)
+                    case 'E': rec.measAdj = dnagpu::tm::ellipsoid_chord_to_arc(rec.measAdj, X1, X2, g1, g2); break;
+                    case 'M': rec.measAdj = dnagpu::tm::ellipsoid_chord_to_msl_arc(rec.measAdj, g1, g2); break;
+                    case 'H': case 'L': case 'V': rec.measAdj -= rec.preAdjCorr; break;
+                    case 'A': case 'K': case 'Z': rec.measAdj += rec.preAdjCorr; break;
+                    default: break;
+                }
+                cs += tb[t] * tb[t] / rec.term2;   // ComputeChiSquare_ABCEHIJKLMPQRSVZ (ADJ:8430)
+            }
+            // v_precAdjMsrsFull_ runs in CML order: 6 values per GNSS vector, 1 per terrestrial measurement (ADJ:7792-7875)
+            std::vector<double> merged;
+            merged.reserve(6 * nv + nt);
+            size_t ci = 0, ti = 0;
+            while (ci < B.c_pos.size() || ti < nt) {
+                if (ti >= nt || (ci < B.c_pos.size() && B.c_pos[ci] < B.t_pos[ti])) {
+                    for (UINT32 vv = B.cluster_off[ci]; vv < B.cluster_off[ci + 1]; ++vv)
+                        merged.insert(merged.end(), prec6.begin() + 6 * (size_t)vv, prec6.begin() + 6 * (size_t)vv + 6);
+                    ++ci;
+                } else {
+                    merged.push_back(tprec[ti++]);
+                }
+            }
+            B.prec_adj_msrs.swap(merged);
+        }
         chiSquared += cs;
     }
     chiSquared_ = chiSquared;                                                        // ComputeChiSquareNetwork (ADJ:7315)
@@ -810,7 +930,9 @@ void dna_adjust::ComputeStatistics() {
     double sum = 0.0;
     UINT32 numMsr = 0;
     ForEachMeasurementComponent([&](measurement_t& rec) {
-        if (rec.PelzerRel > 0.0 && rec.PelzerRel < UNRELIABLE) {
+        // (ADJ:8338 for the single-row types, ADJ:8408 for G / X / Y)
+        const double limit = dnagpu::tm::is_terrestrial(rec.measType) ? STABLE_LIMIT : UNRELIABLE;
+        if (rec.PelzerRel > 0.0 && rec.PelzerRel < limit) {
             sum += (rec.PelzerRel * rec.PelzerRel - 1.0);
             numMsr++;
         } else
@@ -854,6 +976,10 @@ void dna_adjust::ForEachMeasurementComponent(const std::function<void(measuremen
         for (UINT32 m : v_CML_[b]) {
             if (bmsBinaryRecords_[m].ignore || bmsBinaryRecords_[m].measStart != 0) continue;
             const char type = bmsBinaryRecords_[m].measType;
+            if (dnagpu::tm::is_terrestrial(type)) {
+                fn(bmsBinaryRecords_[m]);
+                continue;
+            }
             const UINT32 k = (type == 'G') ? 1 : bmsBinaryRecords_[m].vectorCount1;
             size_t r = m;
             for (UINT32 j = 0; j < k; ++j) {
@@ -908,7 +1034,7 @@ void dna_adjust::SerialiseAdjustedVarianceMatrices() {
         rva.write(reinterpret_cast<const char*>(packed.data()), (std::streamsize)(packed.size() * sizeof(double)));
         write_mtx_trailer(rva);
         const std::vector<double>& prec = blocks_[b].prec_adj_msrs;
-        const UINT32 rows = (UINT32)(6 * blocks_[b].stn1.size());   // v_measurementVarianceCount_ (ADJ:10513-10560)
+        const UINT32 rows = (UINT32)(6 * blocks_[b].stn1.size() + blocks_[b].t_type.size());   // v_measurementVarianceCount_ (ADJ:10513-10560)
         write_mtx_header(pam, 0 /* mtx_full */, rows, 1);
         if (prec.size() == rows)
             pam.write(reinterpret_cast<const char*>(prec.data()), (std::streamsize)(prec.size() * sizeof(double)));

@@ -126,7 +126,13 @@ private:
         dnagpu_matrix* finv = nullptr;
         dnagpu_matrix* rinv = nullptr;
         bool has_finv = false, has_rinv = false, has_cinv = false;
-        std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_
+        std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_ (6 per GNSS vector, then 1 per terrestrial measurement)
+        // terrestrial measurements of the block (CML order among themselves)
+        std::vector<char> t_type;
+        std::vector<UINT32> t_stn;            // 3 per measurement, block-local
+        std::vector<UINT32> t_rec;            // record index in bmsBinaryRecords_
+        std::vector<double> t_val, t_pre, t_var, t_ih, t_th;
+        std::vector<UINT32> t_pos, c_pos;     // CML position of every terrestrial measurement / GNSS cluster
     };
 
     void LoadNetworkFiles();
@@ -135,6 +141,7 @@ private:
     void CreateStnAppearanceList();
     void PrepareBlocks();
     void ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B);
+    void ParseTerrestrialMeasurement(UINT32 block, UINT32 m, block_t& B, const std::vector<double>& xyz);
     void FormConstraintStationVarianceMatrix(UINT32 stn, double w9[9]) const;   // ADJ:2041
     UINT32 LocalIndex(UINT32 block, UINT32 stn) const;
 
@@ -184,7 +191,7 @@ private:
     // the matrix a block step forms its normals in: the chain's work matrix, or with a.reuse_inverses the block's own
     // resident matrix for that step (kind 0 forward, 1 reverse, 2 combination / rigorous)
     dnagpu_matrix* StepMatrix(int chain, UINT32 block, int kind);
-    bool ReuseInverses() const { return projectSettings_.a.reuse_inverses != 0; }
+    bool ReuseInverses() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
     void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
     void Check(int rc, UINT32 block, const char* where);
     void SetmaxCorr(double v) { maxCorr_ = v; }
@@ -219,6 +226,7 @@ private:
     double chiSquaredUpperLimit_ = 0.0, chiSquaredLowerLimit_ = 0.0, globalPelzerReliability_ = 0.0, criticalValue_ = 1.68;
     UINT32 potentialOutlierCount_ = 0, passFail_ = test_stat_pass;
     bool isAdjustmentQuestionable_ = false;
+    bool containsNonGPS_ = false;   // MsrTally::ContainsNonGPS: the design changes with the estimates
     double var_C_ = 0.0, var_F_ = 0.0;
     std::vector<double> iterationCorrections_;
     double adjust_ms_ = 0.0;

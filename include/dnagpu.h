@@ -112,6 +112,31 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz);
  * (XX, XY, YY, XZ, YZ, ZZ), already v-scaled.  Computes W = V^-1 on device. */
 int dnagpu_block_set_baselines(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn1, const uint32_t* stn2, const double* obs,
                                const double* vcv6);
+/* ---- terrestrial measurements (one design row each; types A B C E H K L M R S V Z) ------------------------------
+ * The reference evaluates them in UpdateDesignNormalMeasMatrices_A/_BK/_CEM/_E/_M/_S/_V/_Z/_L/_H/_HR/_R
+ * (dnaadjust.cpp:4754-6054) every time the design is filled, i.e. at PrepareAdjustment and in every UpdateAdjustment;
+ * here dnagpu_block_compute_b does that: computed values, meas-minus-computed, design rows and everything the
+ * formation kernels consume.  Call order for a block: create, set_stations, set_station_geo, set_terrestrial,
+ * set_clusters (which builds the pair / incidence lists over both kinds of measurement), compute_b. */
+/* station records of the block: llh = lat, lon, ellipsoidal height (radians, m; station_t::current*), geoid =
+ * geoidSep, defl = 2 per station: verticalDef (prime vertical), meridianDef (radians) */
+int dnagpu_block_set_station_geo(dnagpu_ctx* ctx, uint32_t blk, const double* llh, const double* geoid, const double* defl);
+/* type[t]; stn3 = station1, station2, station3 (block-local, unused = 0); value = term1 after its one-time reductions;
+ * pre_adj_meas = the measurement as supplied (E, M are re-derived from it); variance = term2; instrument / target
+ * height = term3 / term4; cml_pos[t] = position of the measurement in the block's CML, cluster_cml_pos[c] likewise
+ * for the GNSS clusters given to dnagpu_block_set_clusters afterwards (NULL: cluster c is at position c) */
+int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, const char* type, const uint32_t* stn3, const double* value,
+                                 const double* pre_adj_meas, const double* variance, const double* inst_height, const double* targ_height,
+                                 const uint32_t* cml_pos, const uint32_t* cluster_cml_pos, uint32_t n_clusters);
+/* station records <- geodetic coordinates of the chain's current estimates (UpdateGeographicCoords[Phased],
+ * dnaadjust.cpp:8711/8734); the design of the next compute_b uses them */
+int dnagpu_block_update_geodetic(dnagpu_ctx* ctx, int chain, uint32_t blk);
+int dnagpu_block_get_station_llh(dnagpu_ctx* ctx, int chain, uint32_t blk, double* llh);
+/* meas-minus-computed (n_t) and design rows (9 n_t: dX dY dZ of station 1, 2, 3) of the last compute_b; either may be NULL */
+int dnagpu_block_get_terrestrial(dnagpu_ctx* ctx, int chain, uint32_t blk, double* meas_minus_comp, double* design_rows);
+/* precision of the adjusted measurements a S a^T (ComputePrecisionAdjMsrs_A/_BCEKLMSVZ/_HIJPQR, dnaadjust.cpp:7877-8007) */
+int dnagpu_block_terrestrial_precisions(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* variances, double* prec);
+
 /* General GNSS measurements: `n_baselines` vectors of 3 design rows each, grouped into clusters that share a dense
  * variance matrix ('G' = cluster of one baseline, 'X' = baseline cluster, 'Y' = point cluster; UpdateDesignNormalMeasMatrices_G
  * / _X / _Y, dnaadjust.cpp:5353 / 6056 / 6249).  stn1[v] = first (negative) station or DNAGPU_NO_STATION for a point,
