@@ -252,7 +252,7 @@ def main():
         },
         "cholesky_tflops": (sum_n3 / 1e12) / (ms_per_step / 1e3),
         "roofline": {
-            "kernel": "gemm_f64_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)",
+            "kernel": "gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,

@@ -14,10 +14,10 @@ def parse(path, counter):
         if not line.startswith(" ") and not line.startswith("#"):
             cur = line.strip()
         m = re.match(r"\s+dispatches (\d+)", line)
-        if m and cur and "gemm_f64_kernel" in cur:
+        if m and cur and "gemm_f64_" in cur:
             n += int(m.group(1))
         m = re.match(r"\s+%s\s+sum ([0-9.e+-]+)" % counter, line)
-        if m and cur and "gemm_f64_kernel" in cur:
+        if m and cur and "gemm_f64_" in cur:
             tot += float(m.group(1))
     return tot, n
 
@@ -27,7 +27,7 @@ if __name__ == "__main__":
     f, nf = parse(fetch_txt, "FETCH_SIZE")
     w, nw = parse(write_txt, "WRITE_SIZE")
     assert nf == nw and nf > 0
-    rec = {"workload": workload, "kernel": "gemm_f64_kernel (all instantiations)", "launches": nf,
+    rec = {"workload": workload, "kernel": "gemm_f64_dma_kernel + gemm_f64_kernel (all instantiations of the tile GEMM)", "launches": nf,
            "fetch_size_kib_sum": f, "write_size_kib_sum": w, "fetch_correction": 2.0,
            "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / nf,
            "source": [fetch_txt, write_txt]}

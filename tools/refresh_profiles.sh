@@ -19,6 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $c | tr A-Z a-z)
   python $R/tools/rocprof_summary.py pmc /tmp/pmc_$c $O/r01_cfg3_pmc_$lc.txt "rocprofv3 --pmc $c --kernel-trace -- $CMD   (round 1, cfg3)"
 done
+python $R/tools/pmc_traffic_json.py $O/r01_cfg3_pmc_fetch_size.txt $O/r01_cfg3_pmc_write_size.txt $O/r01_hbm_traffic.json cfg3 > /dev/null
 { echo "# python tools/gpu_gemm_bench.py on 1 x MI355X (round 1): per-variant throughput of the fp64 tile GEMM, HIP-event timed, 3 launches each"
   echo "# fp64 MFMA peak 78.6 TFLOP/s; operands pseudo-random full-range mantissas"
   for v in dma4 dma8 reg4 reg8; do echo "== DNAGPU_GEMM_VARIANT=$v"; DNAGPU_GEMM_VARIANT=$v python $R/tools/gpu_gemm_bench.py 2>/dev/null; done; } > $O/r01_gemm_variants.txt
