@@ -28,4 +28,8 @@ void launch_gather_vec3(const double* x, const uint32_t* idx, uint32_t k, double
 void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, hipStream_t s);
 void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, const double* jest,
                          hipStream_t s);
+void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, const double* rhs, double* dst, uint32_t ldd, uint32_t npp,
+                          hipStream_t s);
+void launch_schur_extract(const double* T, uint32_t ldt, uint32_t nj, uint32_t npj, double* S, double* S2, double* r, hipStream_t s);
+void launch_schur_estimates(const double* xe, const uint32_t* idx, uint32_t k, const double* delta, double* jest, hipStream_t s);
 }  // namespace dnagpu

@@ -409,6 +409,70 @@ void launch_msr_stats(const double* wblk, const uint32_t* vec_wrow, const uint32
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s) {
     hipLaunchKernelGGL(update_estimates_kernel, dim3(1), dim3(1024), 0, s, xe, corr, n, out_val, out_idx);
 }
+// ---- junction carry by partial elimination (dnagpu_schur_carry) ----------------------------------------------------
+// dst (ldd, npp x npp, lower tiles) = the normals with the unknowns re-ordered by `map`: map[i] >= 0 is the unknown of src
+// (lower triangle valid, lds) that sits at row / column i; -1 marks identity padding; -2 the single row that carries the
+// right-hand side, which the elimination then reduces like any other row (forward substitution for free).
+// One workgroup per 128 x 128 tile of the lower tile triangle; the strict upper part of diagonal tiles is zeroed.
+__global__ __launch_bounds__(256) void schur_permute_kernel(const double* __restrict__ src, uint32_t lds, const int32_t* __restrict__ map,
+                                                            const double* __restrict__ rhs, double* __restrict__ dst, uint32_t ldd) {
+    const uint32_t tr = blockIdx.x, tc = blockIdx.y;
+    if (tc > tr) return;
+    const uint32_t il = threadIdx.x & 127;
+    const uint32_t i = tr * 128 + il;
+    const int32_t mi = map[i];
+    for (uint32_t jl = threadIdx.x >> 7; jl < 128; jl += 2) {
+        const uint32_t j = tc * 128 + jl;
+        const int32_t mj = map[j];
+        double v = 0.0;
+        if (i >= j) {
+            if (mi >= 0 && mj >= 0) {
+                const uint32_t r = mi > mj ? mi : mj, c = mi > mj ? mj : mi;
+                v = src[(size_t)c * lds + r];
+            } else if (mi == -2) {
+                v = mj >= 0 ? rhs[mj] : 0.0;
+            } else if (mi == -1 && i == j) {
+                v = 1.0;
+            }
+        }
+        dst[(size_t)j * ldd + i] = v;
+    }
+}
+
+// T (ldt): trailing block after the elimination -- rows / columns 0..nj-1 the Schur complement (lower), row nj the reduced
+// right-hand side.  S and S2 (npj x npj, identity padded, both triangles) receive the complement, r the reduced rhs.
+__global__ void schur_extract_kernel(const double* __restrict__ T, uint32_t ldt, uint32_t nj, uint32_t npj, double* __restrict__ S,
+                                     double* __restrict__ S2, double* __restrict__ r) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (i >= npj) return;
+    double v = i == j ? 1.0 : 0.0;
+    if (i < nj && j < nj) v = i >= j ? T[(size_t)j * ldt + i] : T[(size_t)i * ldt + j];
+    S[(size_t)j * npj + i] = v;
+    S2[(size_t)j * npj + i] = v;
+    if (i == 0) r[j] = j < nj ? T[(size_t)j * ldt + nj] : 0.0;
+}
+
+// junction estimates = block estimates + corrections of the junction unknowns
+__global__ void schur_estimates_kernel(const double* __restrict__ xe, const uint32_t* __restrict__ idx, uint32_t k,
+                                       const double* __restrict__ delta, double* __restrict__ jest) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * k) return;
+    jest[t] = xe[3 * idx[t / 3] + t % 3] + delta[t];
+}
+
+void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, const double* rhs, double* dst, uint32_t ldd, uint32_t npp,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(schur_permute_kernel, dim3(npp / 128, npp / 128), dim3(256), 0, s, src, lds, map, rhs, dst, ldd);
+}
+void launch_schur_extract(const double* T, uint32_t ldt, uint32_t nj, uint32_t npj, double* S, double* S2, double* r, hipStream_t s) {
+    hipLaunchKernelGGL(schur_extract_kernel, dim3((npj + 255) / 256, npj), dim3(256), 0, s, T, ldt, nj, npj, S, S2, r);
+}
+void launch_schur_estimates(const double* xe, const uint32_t* idx, uint32_t k, const double* delta, double* jest, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(schur_estimates_kernel, dim3((3 * k + 255) / 256), dim3(256), 0, s, xe, idx, k, delta, jest);
+}
+
 void launch_junction_gather(const double* S, uint32_t nps, const uint32_t* idx, uint32_t k, double* J, uint32_t npj, hipStream_t s) {
     if (!k) return;
     hipLaunchKernelGGL(junction_gather_kernel, dim3((3 * k + 255) / 256, 3 * k), dim3(256), 0, s, S, nps, idx, k, J, npj);

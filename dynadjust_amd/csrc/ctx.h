@@ -55,6 +55,10 @@ struct Block {
     double *s_llh = nullptr, *s_geoid = nullptr, *s_defl = nullptr;     // station records: geodetic position, N, deflections
     double* tb[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};                 // n_t: measured - computed
     double* trow[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};               // 9 n_t: design rows
+    // dnagpu_schur_carry: unknown order with the carried junction stations last, per junction list seen (forward / reverse)
+    std::vector<uint32_t> h_schur_idx[2];
+    uint32_t* schur_idx[2] = {nullptr, nullptr};
+    int32_t* schur_map[2] = {nullptr, nullptr};
     // host copies kept until the pair / incidence lists are built (dnagpu_block_set_clusters)
     std::vector<uint8_t> h_ttype;
     std::vector<uint32_t> h_tstn, h_tpos, h_cpos;

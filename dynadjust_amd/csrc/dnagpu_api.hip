@@ -129,7 +129,7 @@ void free_block(Block& b) {
                     b.vec_wrow, b.vec_c0, b.vec_k, b.wb[0], b.wb[1],
                     b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc, b.red[0], b.red[1],
                     b.t_type, b.t_stn, b.t_blk0, b.t_vec0, b.t_val, b.t_pre, b.t_var, b.t_ih, b.t_th, b.s_llh, b.s_geoid, b.s_defl,
-                    b.tb[0], b.tb[1], b.trow[0], b.trow[1]};
+                    b.tb[0], b.tb[1], b.trow[0], b.trow[1], b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     b = Block();
@@ -313,7 +313,8 @@ int dnagpu_matrix_create(dnagpu_ctx* ctx, uint32_t n_max, dnagpu_matrix** out) {
     if (!m) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
     m->n_max = n_max;
     m->np_max = pad128(n_max);
-    hipError_t e = hipMalloc(&m->F, (size_t)m->np_max * m->np_max * sizeof(double));
+    // one spare tile row: dnagpu_schur_carry keeps (np + 128) x np panels here
+    hipError_t e = hipMalloc(&m->F, ((size_t)m->np_max + 128) * m->np_max * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&m->jest, (size_t)m->np_max * sizeof(double));
     if (e != hipSuccess) {
         if (m->F) hipFree(m->F);
@@ -1095,6 +1096,65 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
     if (src) launch_junction_gather(src->F, src->np, didx, (uint32_t)k, jm->F, jm->np, ctx->stream[chain]);
     launch_gather_vec3(b->x_est[chain], didx, (uint32_t)k, jm->jest, ctx->stream[chain]);
     return DNAGPU_OK;
+}
+
+int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !m || !jm || !k || !idx_out || k > b->n_stn || 3 * k > jm->n_max || m->n != 3 * b->n_stn)
+        return fail(ctx, DNAGPU_EINVAL, "schur_carry: bad arguments");
+    const uint32_t n = m->n, nj = (uint32_t)(3 * k), ni = n - nj;
+    const uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1), npp = nip + njp;
+    if ((size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur_carry: matrix capacity");
+    // unknown order: inner stations (block order), padding, carried junction stations (list order), the rhs row, padding
+    int slot = -1;
+    for (int q = 0; q < 2; ++q)
+        if (b->schur_map[q] && b->h_schur_idx[q].size() == k && std::equal(idx_out, idx_out + k, b->h_schur_idx[q].begin())) slot = q;
+    if (slot < 0) {
+        std::vector<uint8_t> out(b->n_stn, 0);
+        for (size_t i = 0; i < k; ++i) {
+            if (idx_out[i] >= b->n_stn || out[idx_out[i]]) return fail(ctx, DNAGPU_EINVAL, "schur_carry: bad junction station list");
+            out[idx_out[i]] = 1;
+        }
+        std::vector<int32_t> map(npp, -1);
+        uint32_t pos = 0;
+        for (uint32_t s = 0; s < b->n_stn; ++s)
+            if (!out[s])
+                for (int c = 0; c < 3; ++c) map[pos++] = (int32_t)(3 * s + c);
+        for (size_t i = 0; i < k; ++i)
+            for (int c = 0; c < 3; ++c) map[nip + 3 * i + c] = (int32_t)(3 * idx_out[i] + c);
+        map[nip + nj] = -2;
+        slot = b->schur_map[0] ? 1 : 0;
+        HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+        if (b->schur_map[slot]) hipFree(b->schur_map[slot]);
+        if (b->schur_idx[slot]) hipFree(b->schur_idx[slot]);
+        b->schur_map[slot] = nullptr;
+        b->schur_idx[slot] = nullptr;
+        HIPCHK(hipMalloc(&b->schur_map[slot], (size_t)(n + 384) * sizeof(int32_t)));
+        HIPCHK(hipMalloc(&b->schur_idx[slot], k * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(b->schur_map[slot], map.data(), (size_t)npp * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->schur_idx[slot], idx_out, k * sizeof(uint32_t), hipMemcpyHostToDevice));
+        b->h_schur_idx[slot].assign(idx_out, idx_out + k);
+    }
+    int rc = ensure_ws(ctx, chain, npp);
+    if (!rc) rc = ensure_symv(ctx, chain, njp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    launch_schur_permute(m->F, m->np, b->schur_map[slot], b->rhs[chain], ws.W, npp, npp, st);
+    sym_schur_async(ws, ws.W, (int)npp, m->F, (int)npp, (int)(nip / 128), (int)(njp / 128));
+    // the complement IS the weight matrix of the junction stations; its inverse (their variances) gives their corrections
+    jm->n = nj;
+    jm->np = pad128(nj);
+    const uint32_t npj = jm->np;
+    launch_schur_extract(ws.W + (size_t)nip * npp + nip, npp, nj, npj, jm->F, m->F, ws.svec, st);
+    sym_inverse_async(ws, m->F, nj, npj, false, /*reset_info=*/false);
+    launch_symv(m->F, ws.svec, b->corr[chain], ctx->symv_part[chain], nj, npj, SYMV_CHUNKS, st);
+    launch_schur_estimates(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, b->corr[chain], jm->jest, st);
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info(ctx, chain);
 }
 
 int dnagpu_junction_scatter(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const uint32_t* idx_to, size_t k, const dnagpu_matrix* jm) {

@@ -635,6 +635,7 @@ void dna_adjust::SolveTry(int chain, UINT32 block, dnagpu_matrix* m) {
     {
         std::lock_guard<std::mutex> lk(corr_mutex_);
         solve_flops_ += n * n * n;
+        algorithmic_flops_ += n * n * n;
         solve_count_++;
     }
     Check(dnagpu_solve_corrections(ctx_, chain, block, m), block, "Solve()");
@@ -648,6 +649,8 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     iterationCorrections_.clear();
     solve_flops_ = 0.0;
     solve_count_ = 0;
+    elimination_count_ = 0;
+    algorithmic_flops_ = 0.0;
     const double t0 = now_ms();
     switch (projectSettings_.a.adjust_mode) {
         case SimultaneousMode: AdjustSimultaneous(); break;
@@ -805,6 +808,8 @@ void dna_adjust::ResetAdjustment() {
     iterationCorrections_.clear();
     solve_flops_ = 0.0;
     solve_count_ = 0;
+    elimination_count_ = 0;
+    algorithmic_flops_ = 0.0;
     cancel_.store(false);
     adjustStatus_ = ADJUST_SUCCESS;
 }

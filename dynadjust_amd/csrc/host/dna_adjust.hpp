@@ -102,6 +102,8 @@ public:
     void ResetAdjustment();
     double solveFlops() const { return solve_flops_; }   // sum of n^3 over Solve() calls (reference-equivalent)
     UINT32 solveCount() const { return solve_count_; }
+    UINT32 eliminationCount() const { return elimination_count_; }
+    double algorithmicFlops() const { return algorithmic_flops_; }
     dnagpu_ctx* deviceContext() const { return ctx_; }
 
 private:
@@ -192,6 +194,8 @@ private:
     // resident matrix for that step (kind 0 forward, 1 reverse, 2 combination / rigorous)
     dnagpu_matrix* StepMatrix(int chain, UINT32 block, int kind);
     bool ReuseInverses() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
+    bool SchurCarry() const { return projectSettings_.a.schur_carry != 0 && !ReuseInverses() && !projectSettings_.a.scale_normals_to_unity; }
+    void CarryByElimination(int chain, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
     void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
     void Check(int rc, UINT32 block, const char* where);
     void SetmaxCorr(double v) { maxCorr_ = v; }
@@ -232,6 +236,8 @@ private:
     double adjust_ms_ = 0.0;
     double solve_flops_ = 0.0;
     UINT32 solve_count_ = 0;
+    double algorithmic_flops_ = 0.0;  // n^3 per inverse, the elimination's own count per dnagpu_schur_carry step
+    UINT32 elimination_count_ = 0;   // of those, steps done by dnagpu_schur_carry (a.schur_carry)
 
     std::mutex corr_mutex_, alloc_mutex_;   // multi-thread mode: maxCorr_/solve counters, lazy allocations
     dnagpu_ctx* ctx_ = nullptr;

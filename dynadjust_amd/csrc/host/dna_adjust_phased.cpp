@@ -39,6 +39,19 @@ dnagpu_matrix* dna_adjust::StepMatrix(int c, UINT32 k, int kind) {
     return *slot;
 }
 
+// A forward / reverse step whose solution only feeds the next block: Solve() + CarryStnEstimatesandVariances...() as one
+// partial elimination (include/dnagpu.h, dnagpu_schur_carry).  Counted as a Solve() in the reference-equivalent totals.
+void dna_adjust::CarryByElimination(int c, UINT32 k, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm) {
+    Check(dnagpu_schur_carry(ctx_, c, k, W, out.data(), out.size(), jm), k, "Solve()");
+    const double n = 3.0 * (double)v_parameterStationList_[k].size(), nj = 3.0 * (double)out.size(), ni = n - nj;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    solve_flops_ += n * n * n;
+    // Cholesky of the inner part, its panel under the junction rows, the complement's update, the complement's inverse
+    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + nj * nj * nj;
+    solve_count_++;
+    elimination_count_++;
+}
+
 // AdjustPhasedForward body for one block: Solve (ADJ:2812), UpdateEstimatesForward (ADJ:3022),
 // CarryForwardJunctions (ADJ:3065) -> CarryStnEstimatesandVariancesForward (ADJ:998)
 double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
@@ -57,6 +70,13 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (carried_in)
         Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
+    const bool carries = !(meta._blockIsolated || meta._blockLast) && !v_blockMeta_[k + 1]._blockIsolated && !B.jsl_here.empty();
+    if (SchurCarry() && carries) {
+        // only the junction stations' weights and estimates leave this step (the block's own estimates are set again from
+        // the originals before its reverse / combination solve, ADJ:3863)
+        CarryByElimination(c, k, W, B.jsl_here, B.jfwd);
+        return 0.0;
+    }
     if (reuse)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else
@@ -102,6 +122,12 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
     }
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
+    if (SchurCarry() && fwd_in) {
+        // only a first block keeps its reverse solution (ADJ:3744); the others are combined afterwards, or, for the last
+        // block, already rigorous from the forward pass (ADJ:3748-3756): their reverse solution is only carried on (ADJ:3833)
+        CarryByElimination(c, k, W, B.jslprev_here, blocks_[k - 1].jrev);
+        return 0.0;
+    }
     if (reuse)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else

@@ -45,6 +45,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->free_std_dev = 10.0;
     s->fixed_std_dev = 1.0e-6;
     s->confidence_interval = 95.0f;
+    s->schur_carry = 1;
 }
 
 int dnaadj_create(dnaadj_handle** out) {
@@ -87,6 +88,7 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         if (s->confidence_interval > 0.0f) p.a.confidence_interval = s->confidence_interval;
         p.o._adj_msr_tstat = (uint16_t)(s->output_tstat ? 1 : 0);
         p.a.reuse_inverses = (uint16_t)(s->reuse_inverses ? 1 : 0);
+        p.a.schur_carry = (uint16_t)(s->schur_carry ? 1 : 0);
         if (s->network_name) p.g.network_name = s->network_name;
         if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);
@@ -172,6 +174,8 @@ int dnaadj_degrees_of_freedom(const dnaadj_handle* h) { return h && h->adj ? h->
 double dnaadj_adjust_time_ms(const dnaadj_handle* h) { return h && h->adj ? h->adj->adjustTime() : 0.0; }
 double dnaadj_solve_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveFlops() : 0.0; }
 uint32_t dnaadj_solve_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveCount() : 0; }
+double dnaadj_algorithmic_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->algorithmicFlops() : 0.0; }
+uint32_t dnaadj_elimination_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->eliminationCount() : 0; }
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block) {
     if (!h || !h->adj || block >= h->adj->blockCount()) return 0;

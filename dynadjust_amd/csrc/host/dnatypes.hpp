@@ -196,6 +196,10 @@ struct adjust_settings {
     // iterations, so those inverses are bit-identical every time; the reference exploits this in simultaneous mode only
     // (dnaadjust.cpp:2457).  Costs two more n x n matrices per block in HBM.
     UINT16 reuse_inverses = 0;
+    // Not in the reference (device path only): a forward / reverse step that only feeds the next block (every one but the
+    // last forward and the first reverse step of a network) needs the junction stations' weight matrix and estimates, not
+    // the block inverse: the inner unknowns are eliminated (dnagpu_schur_carry) instead of Solve()'s full inverse.
+    UINT16 schur_carry = 1;
     float iteration_threshold = 0.0005f;
     double free_std_dev = 10.0;
     double fixed_std_dev = 1.0e-6;   // PRECISION_1E6

@@ -48,7 +48,13 @@ void inv_workspace_free(InvWorkspace& ws);
 // F: np x np (ld = np) device buffer, lower triangle valid, identity padding beyond n.
 // On return F holds the inverse in BOTH triangles.  Asynchronous on ws.stream; the
 // dpotrf-style info is copied to ws.info_host (valid after stream sync).
-void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity);
+void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity, bool reset_info = true);
+
+// Partial elimination for the junction carry (dnagpu_schur_carry).  F: (ti + tj) x (ti + tj) tiles, ld, lower tiles valid;
+// the leading ti tile rows / columns are eliminated (Cholesky panels into P, ldp; the inverses of the diagonal blocks
+// into ws.X) and the trailing tj x tj tiles of F become the Schur complement  F22 - F21 F11^-1 F12  (lower tiles).
+// Resets ws.info; a non-positive pivot in the eliminated part is reported like dpotrf.  The caller copies ws.info back.
+void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj);
 
 // sum the event timings recorded so far (synchronises the stream)
 void gemm_profile_collect(InvWorkspace& ws);

@@ -1,5 +1,7 @@
 #include "sym_inverse.h"
 #include "la_kernels.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace dnagpu {
 
@@ -128,15 +130,17 @@ void gemm_profile_reset(InvWorkspace& ws) {
 
 namespace {
 
+// The recursion over 128-tiles.  F (ld): the matrix, factored in place; X (ldx): L^-1; P (ldp): the L21 panels.
 struct Rec {
     InvWorkspace& ws;
-    double* F;
-    int ld;
+    double* F; int ld;
+    double* X; int ldx;
+    double* P; int ldp;
     bool dry;  // planning pass: only build the tile-order tables, launch nothing
 
     double* f(int rt, int ct) { return F + (size_t)ct * 128 * ld + (size_t)rt * 128; }
-    double* x(int rt, int ct) { return ws.X + (size_t)ct * 128 * ld + (size_t)rt * 128; }
-    double* w(int rt, int ct) { return ws.W + (size_t)ct * 128 * ld + (size_t)rt * 128; }
+    double* x(int rt, int ct) { return X + (size_t)ct * 128 * ldx + (size_t)rt * 128; }
+    double* w(int rt, int ct) { return P + (size_t)ct * 128 * ldp + (size_t)rt * 128; }
 
     void gemm(InvWorkspace& w_, GemmArgs a, int akc, int bkc) {
         if (dry)
@@ -145,48 +149,77 @@ struct Rec {
             dnagpu::gemm(w_, a, akc, bkc);
     }
 
+    // W21 = A21 * X11^T (L21 = A21 L11^-T) for the r tile rows below the h x h block at o, then A22 -= W21 * W21^T (lower tiles)
+    void eliminate(int o, int h, int r) {
+        GemmArgs a;
+        a.A = f(o + h, o); a.lda = ld;
+        a.B = x(o, o); a.ldb = ldx;
+        a.C = w(o + h, o); a.ldc = ldp;
+        a.mt = r; a.nt = h; a.K = h * 128;
+        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_LE_J; a.lower = 0; a.mirror = 0;
+        gemm(ws, a, 0, 0);
+        a.A = w(o + h, o); a.lda = ldp;
+        a.B = w(o + h, o); a.ldb = ldp;
+        a.C = f(o + h, o + h); a.ldc = ld;
+        a.mt = r; a.nt = r; a.K = h * 128;
+        a.alpha = -1.0; a.beta = 1.0; a.kmode = KM_FULL; a.lower = 1; a.mirror = 0;
+        gemm(ws, a, 0, 0);
+    }
+
+    // Cholesky factor and its inverse of the s x s tile block at o: F keeps T21 = L21 L11^-1 below the diagonal, X = L^-1
     void node(int o, int s) {
         if (s == 1) {
             if (!dry) {
                 gemm_profile_close(ws);
-                launch_leaf(F, ld, ws.X, ld, o * 128, ws.info, ws.stream);
+                launch_leaf(F, ld, X, ldx, o * 128, ws.info, ws.stream);
             }
             return;
         }
         int h = s / 2;
         int r = s - h;
         node(o, h);
-        GemmArgs a;
-        // W21 = A21 * X11^T   (L21 = A21 L11^-T)
-        a.A = f(o + h, o); a.lda = ld;
-        a.B = x(o, o); a.ldb = ld;
-        a.C = w(o + h, o); a.ldc = ld;
-        a.mt = r; a.nt = h; a.K = h * 128;
-        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_LE_J; a.lower = 0; a.mirror = 0;
-        gemm(ws, a, 0, 0);
-        // A22 -= W21 * W21^T  (lower tiles)
-        a.A = w(o + h, o); a.B = w(o + h, o); a.C = f(o + h, o + h);
-        a.mt = r; a.nt = r; a.K = h * 128;
-        a.alpha = -1.0; a.beta = 1.0; a.kmode = KM_FULL; a.lower = 1; a.mirror = 0;
-        gemm(ws, a, 0, 0);
+        eliminate(o, h, r);
         node(o + h, r);
+        GemmArgs a;
         // T21 = W21 * X11  -> stored where A21 was
-        a.A = w(o + h, o); a.B = x(o, o); a.C = f(o + h, o);
+        a.A = w(o + h, o); a.lda = ldp;
+        a.B = x(o, o); a.ldb = ldx;
+        a.C = f(o + h, o); a.ldc = ld;
         a.mt = r; a.nt = h; a.K = h * 128;
         a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
         gemm(ws, a, 0, 1);
         // X21 = -X22 * T21
-        a.A = x(o + h, o + h); a.B = f(o + h, o); a.C = x(o + h, o);
+        a.A = x(o + h, o + h); a.lda = ldx;
+        a.B = f(o + h, o); a.ldb = ld;
+        a.C = x(o + h, o); a.ldc = ldx;
         a.mt = r; a.nt = h; a.K = r * 128;
         a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
         gemm(ws, a, 0, 1);
+    }
+
+    // Eliminates the first ti tile rows / columns; the trailing tj x tj tiles receive every update and are never factored:
+    // they end as the Schur complement.  Each step factors (and inverts, for the panel solve) a leading h x h block of what
+    // is left; potrf + trtri of the block is 2/3 h^3 against h^2 r + h r^2 for the panel, so the blocks stay a fraction
+    // `split` of the remainder: total 0.381 / 0.351 / 0.342 / 0.338 n^3 at split 1/2, 1/3, 1/4, 1/5 (a Cholesky factorisation
+    // alone is n^3/3).  Measured on cfg3 (n = 20 k): 7.18 / 6.97 / 6.89 / 6.82 / 6.79 s per step at 0.5 / 0.33 / 0.25 / 0.2 / 0.15
+    // (smaller blocks = more, smaller launches): 0.2, override DNAGPU_SCHUR_SPLIT.
+    void schur(int ti, int tj, double split) {
+        int o = 0, si = ti;
+        while (si > 0) {
+            int h = si <= 12 ? si : std::max(1, std::min(si, (int)(si * split + 0.5)));
+            node(o, h);
+            int r = si - h + tj;
+            if (r > 0) eliminate(o, h, r);
+            o += h;
+            si -= h;
+        }
     }
 };
 
 }  // namespace
 
-void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity) {
-    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
+void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity, bool reset_info) {
+    if (reset_info) hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
     if (scale_to_unity) {
         launch_diag_rsqrt(F, ws.svec, n, np, ws.stream);
         launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
@@ -195,14 +228,14 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
     if (!ws.planned.count(T)) {
         // first inverse of this order: build every tile-order table before the first launch
         // so that the blocking table uploads never sit between kernels
-        Rec plan{ws, F, (int)np, true};
+        Rec plan{ws, F, (int)np, ws.X, (int)np, ws.W, (int)np, true};
         plan.node(0, T);
         GemmArgs l;
         l.mt = T; l.nt = T; l.K = (int)np; l.kmode = KM_GE_I; l.lower = 1;
         gemm_attach_order(ws, l);
         ws.planned.insert(T);
     }
-    Rec rec{ws, F, (int)np, false};
+    Rec rec{ws, F, (int)np, ws.X, (int)np, ws.W, (int)np, false};
     rec.node(0, T);
     // Ninv = X^T X  (lauum), both triangles
     GemmArgs a;
@@ -215,6 +248,30 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
     gemm_profile_close(ws);
     if (scale_to_unity) launch_scale_sym(F, ws.svec, n, np, 0, ws.stream);
     hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, ws.stream);
+}
+
+double schur_split() {
+    static double v = [] {
+        const char* e = getenv("DNAGPU_SCHUR_SPLIT");
+        double x = e ? atof(e) : 0.0;
+        return (x > 0.0 && x <= 1.0) ? x : 0.2;
+    }();
+    return v;
+}
+
+void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj) {
+    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);
+    const int ldx = ti * 128;
+    const double split = schur_split();
+    const int key = (1 << 30) | (ti << 12) | tj;
+    if (!ws.planned.count(key)) {
+        Rec plan{ws, F, ld, ws.X, ldx, P, ldp, true};
+        plan.schur(ti, tj, split);
+        ws.planned.insert(key);
+    }
+    Rec rec{ws, F, ld, ws.X, ldx, P, ldp, false};
+    rec.schur(ti, tj, split);
+    gemm_profile_close(ws);
 }
 
 }  // namespace dnagpu

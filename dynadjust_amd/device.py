@@ -218,6 +218,13 @@ class DeviceContext:
         self._chk(self.lib.dnagpu_junction_gather(self.h, chain, blk_from, src.h, p, ix.size, jm.h))
         jm.n = 3 * ix.size
 
+    def schur_carry(self, blk, m, idx_out, jm, chain=0):
+        """jm <- Schur complement of the other unknowns of m onto the listed stations, junction estimates <- estimates +
+        corrections (dnagpu_schur_carry); m is destroyed"""
+        ix, p = _u32(idx_out)
+        self._chk(self.lib.dnagpu_schur_carry(self.h, chain, blk, m.h, p, ix.size, jm.h))
+        jm.n = 3 * ix.size
+
     def junction_scatter(self, dst, idx_to, jm, chain=0):
         ix, p = _u32(idx_to)
         self._chk(self.lib.dnagpu_junction_scatter(self.h, chain, dst.h, p, ix.size, jm.h))

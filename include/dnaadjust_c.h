@@ -41,6 +41,11 @@ typedef struct {
     const char* output_folder; /* g.output_folder (may be NULL = ".") */
     int reuse_inverses;        /* device path only (default 0): phased GNSS-only networks keep the block inverses of the first
                                   iteration in HBM and reuse them afterwards (identical results, half the solves) */
+    int schur_carry;           /* device path only (default 1): forward / reverse steps whose solution is only carried to the next
+                                  block eliminate the inner unknowns instead of inverting the block (dnagpu_schur_carry; same
+                                  carried weights and estimates up to rounding, ~0.35 n^3 instead of n^3 flops).  0 = every step
+                                  inverts its block like the reference's Solve().  Ignored with reuse_inverses or
+                                  scale_normals_to_unity */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
@@ -67,7 +72,9 @@ uint32_t dnaadj_unknowns_count(const dnaadj_handle* h);                /* GetUnk
 int dnaadj_degrees_of_freedom(const dnaadj_handle* h);                 /* GetDegreesOfFreedom() */
 double dnaadj_adjust_time_ms(const dnaadj_handle* h);                  /* adjustTime() */
 double dnaadj_solve_flops(const dnaadj_handle* h);                     /* sum n^3 over Solve() calls */
+double dnaadj_algorithmic_flops(const dnaadj_handle* h);               /* n^3 per inverse; n_i^3/3 + n_i^2 n_j + n_i n_j^2 + n_j^3 per elimination step */
 uint32_t dnaadj_solve_count(const dnaadj_handle* h);
+uint32_t dnaadj_elimination_count(const dnaadj_handle* h);             /* of those, carry-only steps done by elimination (schur_carry) */
 uint32_t dnaadj_station_count(const dnaadj_handle* h);
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block);

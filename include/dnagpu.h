@@ -186,6 +186,17 @@ int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs);
  * iterations of a GNSS-only network) */
 int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const dnagpu_matrix* src, const uint32_t* idx_from,
                            size_t k, dnagpu_matrix* jm);
+/* The carry of a forward / reverse step WITHOUT the block inverse.  The reference solves the whole block
+ * (dna_adjust::Solve, dnaadjust.cpp:6586: n^3 flops), gathers the junction block of N^-1, inverts it
+ * (CarryStnEstimatesandVariancesForward / ...Reverse, dnaadjust.cpp:998-1128, 1133-1281) and carries that weight matrix
+ * plus the junction estimates; nothing else of a forward / reverse solution is used unless the block is the last / first
+ * of its network.  ((N^-1)_JJ)^-1 is the Schur complement  N_JJ - N_JI N_II^-1 N_IJ  and the junction corrections solve
+ * S dx_J = rhs_J - N_JI N_II^-1 rhs_I : both come out of eliminating the inner unknowns only (~0.35 n^3 flops).
+ * m: the block's normals (lower triangle; contents are destroyed), rhs as left by dnagpu_form_rhs / dnagpu_junction_rhs.
+ * jm (order 3k) <- S, jest <- estimated coordinates + corrections of the k listed stations: exactly what
+ * dnagpu_junction_gather + dnagpu_invert leave there after a full solve, up to rounding.  The block's estimates and
+ * corrections are NOT updated.  DNAGPU_ENOTPOSDEF like dnagpu_invert. */
+int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm);
 /* dst[idx,idx] += jm (3x3 blocks), and rhs_extra of blk_to gets the pseudo
  * measurement part:  rhs[idx] += jm * (jest - estimated_to[idx])  is applied
  * by dnagpu_junction_rhs at solve time. */

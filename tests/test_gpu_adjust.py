@@ -417,7 +417,7 @@ def test_reuse_inverses_is_identical(built, tmp_path, mt):
     adjust.write_synthetic_network(str(tmp_path), "r", 14, 12, 0, 5, seed=9, x_clusters=20, y_cluster=True, initial_sigma=0.4)
     runs = []
     for reuse in (False, True):
-        a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_inverses=reuse)
+        a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_inverses=reuse, schur_carry=False)
         assert st == 0 and a.CurrentIteration() >= 2
         a.GenerateStatistics()
         runs.append((a.CurrentIteration(), a.solve_count(), [a.block_estimates(b) for b in range(a.blockCount())],
@@ -459,3 +459,37 @@ def test_scalars_and_llh_point_clusters_parity(built, orc, tmp_path, blocks, pha
         assert np.all(np.abs(y["preAdjMeas"]) < 4.0) and np.all(np.abs(y["term1"]) > 1e6)  # radians kept, metres now
     a.close()
     o.close()
+
+
+@pytest.mark.parametrize("mt,blocks,terr", [(False, 5, False), (True, 5, False), (False, 2, False), (True, 3, True)])
+def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr):
+    """a.schur_carry (device path only, default on): the forward / reverse steps whose solution is only carried to the next
+    block eliminate their inner unknowns instead of inverting the block.  Same estimates, variances and statistics as the
+    reference's schedule of full solves (and as the oracle), with 2 (B - 1) of the 3 B - 2 solves per iteration replaced."""
+    if terr:
+        from tests import terrestrial_net as T
+        T.build_mixed_network(str(tmp_path / "c"), 6, 4, blocks, seed=11)
+    else:
+        adjust.write_synthetic_network(str(tmp_path), "c", 16, 12, 0, blocks, seed=4, x_clusters=12, y_cluster=True, initial_sigma=0.3)
+    runs = []
+    for schur in (False, True):
+        a, st = _device_run(str(tmp_path), "c", True, multi_thread=mt, schur_carry=schur)
+        assert st == 0
+        a.GenerateStatistics()
+        runs.append((a.CurrentIteration(), a.solve_count(), a.elimination_count(), [a.block_estimates(b) for b in range(a.blockCount())],
+                     [a.block_variances_packed(b) for b in range(a.blockCount())], a.GetChiSquared(), a.GetMaxCorrection()))
+        if schur:
+            net = orc.Network(str(tmp_path / "c"), True)
+            o = orc.Adjustment(net, True)
+            o.prepare()
+            _compare(a, st, o, o.run())
+            o.close()
+        a.close()
+    (it0, n0, e0, x0, v0, c0, mc0), (it1, n1, e1, x1, v1, c1, mc1) = runs
+    B = len(x0)
+    assert B == blocks and it0 == it1 and n0 == n1 == it0 * (3 * B - 2)
+    assert e0 == 0 and e1 == it1 * 2 * (B - 1)
+    assert abs(c0 - c1) < 1e-7 * c0 and abs(mc0 - mc1) < 1e-9
+    for b in range(B):
+        assert np.abs(x0[b] - x1[b]).max() < 1e-8
+        assert np.abs(v0[b] - v1[b]).max() < 1e-8 * np.abs(v0[b]).max()

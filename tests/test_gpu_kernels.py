@@ -155,3 +155,99 @@ def test_bad_arguments_are_rejected(gpu_ctx):
     gpu_ctx.block_destroy(0)
     with pytest.raises(DnaGpuError):
         gpu_ctx.block_compute_b(77)
+
+
+@pytest.mark.parametrize("rows,cols,strips,pick", [(9, 8, 3, "jsl"), (40, 30, 2, "jsl"), (40, 30, 2, "scattered"), (12, 11, 2, "all_but_one"),
+                                                   (43, 43, 2, "one")])
+def test_schur_carry_equals_solve_gather_invert(gpu_ctx, built, orc, tmp_path, rows, cols, strips, pick):
+    """dnagpu_schur_carry (partial elimination of the inner unknowns) against the reference's sequence Solve ->
+    gather the junction block of N^-1 -> invert it (CarryStnEstimatesandVariancesForward, dnaadjust.cpp:998-1128), on the
+    device and in numpy.  Sizes straddle the 128-tile boundaries (n = 3 * stations of the first strip + junction row)."""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, strips, seed=rows + cols)
+    net = orc.Network(str(tmp_path / "s"), True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    st0, cml0, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    n0 = 3 * len(st0)
+    loc0 = {int(s): i for i, s in enumerate(st0)}
+    if pick == "jsl":
+        stn = [loc0[int(s)] for s in net.jsl[net.jsl_off[0]:net.jsl_off[1]]]
+    elif pick == "scattered":
+        stn = list(range(1, len(st0), 7))[::-1]                   # any order, interleaved with the inner stations
+    elif pick == "all_but_one":
+        stn = list(range(1, len(st0)))
+    else:
+        stn = [len(st0) // 2]
+    idx = np.array(stn, dtype=np.uint32)
+    rws = (3 * idx[:, None] + np.arange(3)).ravel()
+    N0 = unpack_lower(a.block_normals(0), n0)
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    rhs = gpu_ctx.block_get_rhs(0, len(st0))
+    x0 = gpu_ctx.block_get_stations(0, 1, len(st0))
+    # the reference's sequence on the device
+    m = gpu_ctx.matrix(n0)
+    m.upload_packed(a.block_normals(0), n0)
+    m.invert()
+    gpu_ctx.solve_corrections(0, m)
+    corr = gpu_ctx.block_get_corrections(0, len(st0))
+    jm = gpu_ctx.matrix(3 * len(idx))
+    gpu_ctx.junction_gather(0, m, idx, jm)
+    jm.invert()
+    W_ref = unpack_lower(jm.download_packed(), 3 * len(idx))
+    # elimination
+    m.upload_packed(a.block_normals(0), n0)
+    js = gpu_ctx.matrix(3 * len(idx))
+    gpu_ctx.schur_carry(0, m, idx, js)
+    W = unpack_lower(js.download_packed(), 3 * len(idx))
+    est = gpu_ctx.junction_get_estimates(js)
+    scale = np.abs(W_ref).max()
+    assert np.abs(W - W_ref).max() < 1e-9 * scale, np.abs(W - W_ref).max() / scale
+    assert np.abs(est - (x0[rws] + corr[rws])).max() < 1e-9
+    assert np.array_equal(gpu_ctx.block_get_stations(0, 1, len(st0)), x0)          # the block's estimates are untouched
+    # numpy: Schur complement and the reduced system
+    inner = np.setdiff1d(np.arange(n0), rws)
+    S = N0[np.ix_(rws, rws)] - N0[np.ix_(rws, inner)] @ np.linalg.solve(N0[np.ix_(inner, inner)], N0[np.ix_(inner, rws)]) if len(inner) else N0[np.ix_(rws, rws)]
+    assert np.abs(W - S).max() < 1e-9 * scale
+    d = np.linalg.solve(N0, rhs)
+    assert np.abs(est - (x0[rws] + d[rws])).max() < 1e-9
+    # a second call with another station list (the reverse direction's) and back again: both orders stay cached
+    idx2 = np.array(sorted(set(range(len(st0))) - set(stn))[:max(1, len(st0) // 5)], dtype=np.uint32)
+    j2 = gpu_ctx.matrix(3 * len(idx2))
+    m.upload_packed(a.block_normals(0), n0)
+    gpu_ctx.schur_carry(0, m, idx2, j2)
+    r2 = (3 * idx2[:, None] + np.arange(3)).ravel()
+    assert np.abs(gpu_ctx.junction_get_estimates(j2) - (x0[r2] + d[r2])).max() < 1e-9
+    m.upload_packed(a.block_normals(0), n0)
+    gpu_ctx.schur_carry(0, m, idx, js)
+    assert np.array_equal(unpack_lower(js.download_packed(), 3 * len(idx)), W)      # deterministic
+    for q in (m, jm, js, j2):
+        q.close()
+    gpu_ctx.block_destroy(0)
+
+
+def test_schur_carry_reports_a_singular_block(gpu_ctx, built, orc, tmp_path):
+    """an unknown without any weight (zero row / column) among the eliminated ones -> dpotrf-style failure, same text as
+    dnagpu_invert (MatrixInversionFailure, dnamatrix_contiguous.cpp:983)"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", 9, 8, 0, 2, seed=3)
+    net = orc.Network(str(tmp_path / "s"), True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    st0, cml0, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    n0 = 3 * len(st0)
+    N = unpack_lower(a.block_normals(0), n0)
+    N[7, :] = 0.0
+    N[:, 7] = 0.0
+    m = gpu_ctx.matrix(n0)
+    m.upload_packed(pack_lower(N), n0)
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    jm = gpu_ctx.matrix(3)
+    with pytest.raises(Exception) as e:
+        gpu_ctx.schur_carry(0, m, np.array([0], dtype=np.uint32), jm)
+    assert "singular" in str(e.value)
+    m.close()
+    jm.close()
+    gpu_ctx.block_destroy(0)
