@@ -168,13 +168,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the adjustment path has no CPU fallback")
+    # DNAGPU_DIST_BACKEND=gloo: test harness for the N > 1 code path on a box with fewer GPUs than ranks (ranks share
+    # devices, payloads travel through host memory); the driver's runs use nccl (= RCCL), one GPU per rank
+    dist_backend = os.environ.get("DNAGPU_DIST_BACKEND", "nccl")
+    if dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from dynadjust_amd import adjust
     from dynadjust_amd.device import DeviceContext  # noqa: F401  (fails loudly if the HIP library is missing)
@@ -186,7 +194,7 @@ def main():
 
     if world > 1:
         from dynadjust_amd import parallel
-        result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank)
+        result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)
         if rank == 0:
             result["config"]["workload"] = desc
             print(json.dumps(result), flush=True)

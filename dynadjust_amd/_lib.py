@@ -127,6 +127,8 @@ def load():
     _sig(lib, "dnagpu_block_get_rhs", i, [vp, i, u32, c_f64p])
     _sig(lib, "dnagpu_junction_gather", i, [vp, i, u32, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_schur_carry", i, [vp, i, u32, vp, c_u32p, sz, vp])
+    _sig(lib, "dnagpu_block_reduce", i, [vp, i, u32, vp, c_u32p, sz, vp])
+    _sig(lib, "dnagpu_block_load_reduced", i, [vp, i, u32, u32, c_u32p, sz, vp, vp])
     _sig(lib, "dnagpu_junction_scatter", i, [vp, i, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_junction_rhs", i, [vp, i, u32, c_u32p, sz, vp])
     _sig(lib, "dnagpu_junction_get_estimates", i, [vp, i, vp, c_f64p])
@@ -185,6 +187,17 @@ def load():
     _sig(lib, "dnaadj_phased_note_correction", i, [vp, C.c_double])
     _sig(lib, "dnaadj_phased_end_iteration", i, [vp, ip])
     _sig(lib, "dnaadj_phased_finish", i, [vp, ip])
+    _sig(lib, "dnaadj_condensed_schedule", i, [vp])
+    _sig(lib, "dnaadj_condensed_payload_doubles", sz, [vp, u32])
+    _sig(lib, "dnaadj_phased_condense_block", i, [vp, u32])
+    _sig(lib, "dnaadj_phased_condensed_forward", i, [vp, u32])
+    _sig(lib, "dnaadj_phased_condensed_reverse", i, [vp, u32])
+    _sig(lib, "dnaadj_phased_rigorous_block", i, [vp, u32, C.POINTER(C.c_double)])
+    _sig(lib, "dnaadj_phased_condense_blocks", i, [vp, c_u32p, sz])
+    _sig(lib, "dnaadj_phased_condensed_chains", i, [vp])
+    _sig(lib, "dnaadj_phased_rigorous_blocks", i, [vp, c_u32p, sz])
+    _sig(lib, "dnaadj_condensed_export", i, [vp, u32, vp])
+    _sig(lib, "dnaadj_condensed_import", i, [vp, u32, vp])
     _sig(lib, "dnaadj_junction_export", i, [vp, i, u32, vp])
     _sig(lib, "dnaadj_junction_import", i, [vp, i, u32, vp])
     _sig(lib, "dnaadj_block_get_coords", i, [vp, u32, i, c_f64p])
@@ -209,7 +222,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
     "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
-    "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
+    "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
 ]
 
@@ -224,7 +237,10 @@ EXPORTED_DNAADJ = [
     "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",
     "dnaadj_block_flags", "dnaadj_junction_unknowns", "dnaadj_junction_payload_doubles", "dnaadj_phased_begin_iteration",
     "dnaadj_phased_forward_block", "dnaadj_phased_reverse_block", "dnaadj_phased_combine_block", "dnaadj_phased_finalise_block",
-    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_junction_export",
+    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_condensed_schedule", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
+    "dnaadj_phased_condensed_forward", "dnaadj_phased_condensed_reverse", "dnaadj_phased_rigorous_block", "dnaadj_phased_condense_blocks", "dnaadj_phased_condensed_chains",
+    "dnaadj_phased_rigorous_blocks", "dnaadj_condensed_export",
+    "dnaadj_condensed_import", "dnaadj_junction_export",
     "dnaadj_junction_import", "dnaadj_block_get_coords", "dnaadj_block_set_coords", "dnaadj_block_recompute_b",
     "dnasynth_write_network", "dnaio_file_summary", "dnaio_seg_summary", "dnaio_sizeof_station", "dnaio_sizeof_measurement",
 ]

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/dnagpu.h"
@@ -85,6 +86,7 @@ struct dnagpu_ctx {
     uint32_t* red_idx_host[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
     int* bad_dev = nullptr;
     std::map<uint32_t, dnagpu::Block> blocks;
+    std::mutex schur_mutex;        // the per-block unknown orders of dnagpu_schur_carry are created on first use, by either chain's thread
     bool profile = false;
     double profile_ms_acc = 0.0;   // union length of the timed GEMM runs collected so far (dnagpu_profile_get)
 };

@@ -1098,23 +1098,27 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
     return DNAGPU_OK;
 }
 
-int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm) {
-    CHK_CTX();
-    CHK_CHAIN();
-    Block* b = find_block(ctx, blk);
-    if (!b || !m || !jm || !k || !idx_out || k > b->n_stn || 3 * k > jm->n_max || m->n != 3 * b->n_stn)
-        return fail(ctx, DNAGPU_EINVAL, "schur_carry: bad arguments");
+}  // extern "C"
+
+namespace {
+// The elimination behind dnagpu_schur_carry / dnagpu_block_reduce: the unknowns of the k listed stations are moved behind
+// all others (plus one row that carries the right-hand side) and the others are eliminated.  On return (stream ordered)
+// T points at the trailing block inside the chain's W workspace: rows / columns 0..3k-1 hold the Schur complement (lower),
+// row 3k the reduced right-hand side; ldt its leading dimension.  m (the normals) is destroyed.
+int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, const double** T, uint32_t* ldt,
+                    int* slot_out) {
     const uint32_t n = m->n, nj = (uint32_t)(3 * k), ni = n - nj;
     const uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1), npp = nip + njp;
-    if ((size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur_carry: matrix capacity");
-    // unknown order: inner stations (block order), padding, carried junction stations (list order), the rhs row, padding
+    if ((size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur: matrix capacity");
+    // unknown order: the other stations (block order), padding, the listed stations (list order), the rhs row, padding
     int slot = -1;
+    std::unique_lock<std::mutex> lk(ctx->schur_mutex);
     for (int q = 0; q < 2; ++q)
         if (b->schur_map[q] && b->h_schur_idx[q].size() == k && std::equal(idx_out, idx_out + k, b->h_schur_idx[q].begin())) slot = q;
     if (slot < 0) {
         std::vector<uint8_t> out(b->n_stn, 0);
         for (size_t i = 0; i < k; ++i) {
-            if (idx_out[i] >= b->n_stn || out[idx_out[i]]) return fail(ctx, DNAGPU_EINVAL, "schur_carry: bad junction station list");
+            if (idx_out[i] >= b->n_stn || out[idx_out[i]]) return fail(ctx, DNAGPU_EINVAL, "schur: bad station list");
             out[idx_out[i]] = 1;
         }
         std::vector<int32_t> map(npp, -1);
@@ -1126,35 +1130,102 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
             for (int c = 0; c < 3; ++c) map[nip + 3 * i + c] = (int32_t)(3 * idx_out[i] + c);
         map[nip + nj] = -2;
         slot = b->schur_map[0] ? 1 : 0;
-        HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+        HIPCHK(hipDeviceSynchronize());     // the other chain may be reading the slot that is replaced
         if (b->schur_map[slot]) hipFree(b->schur_map[slot]);
         if (b->schur_idx[slot]) hipFree(b->schur_idx[slot]);
         b->schur_map[slot] = nullptr;
         b->schur_idx[slot] = nullptr;
-        HIPCHK(hipMalloc(&b->schur_map[slot], (size_t)(n + 384) * sizeof(int32_t)));
+        HIPCHK(hipMalloc(&b->schur_map[slot], (size_t)npp * sizeof(int32_t)));
         HIPCHK(hipMalloc(&b->schur_idx[slot], k * sizeof(uint32_t)));
         HIPCHK(hipMemcpy(b->schur_map[slot], map.data(), (size_t)npp * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(b->schur_idx[slot], idx_out, k * sizeof(uint32_t), hipMemcpyHostToDevice));
         b->h_schur_idx[slot].assign(idx_out, idx_out + k);
     }
+    const int32_t* map_dev = b->schur_map[slot];
+    lk.unlock();
     int rc = ensure_ws(ctx, chain, npp);
-    if (!rc) rc = ensure_symv(ctx, chain, njp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    gemm_profile_close(ws);
+    launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], ws.W, npp, npp, ctx->stream[chain]);
+    sym_schur_async(ws, ws.W, (int)npp, m->F, (int)npp, (int)(nip / 128), (int)(njp / 128));
+    *T = ws.W + (size_t)nip * npp + nip;
+    *ldt = npp;
+    *slot_out = slot;
+    return DNAGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !m || !jm || !k || !idx_out || k > b->n_stn || 3 * k > jm->n_max || m->n != 3 * b->n_stn)
+        return fail(ctx, DNAGPU_EINVAL, "schur_carry: bad arguments");
+    const uint32_t nj = (uint32_t)(3 * k), npj = pad128(nj);
+    int rc = ensure_symv(ctx, chain, npj);
+    if (rc) return rc;
+    const double* T = nullptr;
+    uint32_t ldt = 0;
+    int slot = 0;
+    rc = schur_eliminate(ctx, chain, b, m, idx_out, k, &T, &ldt, &slot);
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
     hipStream_t st = ctx->stream[chain];
-    gemm_profile_close(ws);
-    launch_schur_permute(m->F, m->np, b->schur_map[slot], b->rhs[chain], ws.W, npp, npp, st);
-    sym_schur_async(ws, ws.W, (int)npp, m->F, (int)npp, (int)(nip / 128), (int)(njp / 128));
     // the complement IS the weight matrix of the junction stations; its inverse (their variances) gives their corrections
     jm->n = nj;
-    jm->np = pad128(nj);
-    const uint32_t npj = jm->np;
-    launch_schur_extract(ws.W + (size_t)nip * npp + nip, npp, nj, npj, jm->F, m->F, ws.svec, st);
+    jm->np = npj;
+    launch_schur_extract(T, ldt, nj, npj, jm->F, m->F, ws.svec, st);
     sym_inverse_async(ws, m->F, nj, npj, false, /*reset_info=*/false);
     launch_symv(m->F, ws.svec, b->corr[chain], ctx->symv_part[chain], nj, npj, SYMV_CHUNKS, st);
     launch_schur_estimates(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, b->corr[chain], jm->jest, st);
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
+}
+
+int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !m || !red || !k || !idx_keep || k > b->n_stn || 3 * k > red->n_max || m->n != 3 * b->n_stn)
+        return fail(ctx, DNAGPU_EINVAL, "block_reduce: bad arguments");
+    const double* T = nullptr;
+    uint32_t ldt = 0;
+    int slot = 0;
+    int rc = schur_eliminate(ctx, chain, b, m, idx_keep, k, &T, &ldt, &slot);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    red->n = (uint32_t)(3 * k);
+    red->np = pad128(red->n);
+    launch_schur_extract(T, ldt, red->n, red->np, red->F, m->F, red->jest, st);
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info(ctx, chain);
+}
+
+int dnagpu_block_load_reduced(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k,
+                              const dnagpu_matrix* red, dnagpu_matrix* m) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* rb = find_block(ctx, rblk);
+    Block* sb = find_block(ctx, src_blk);
+    if (!rb || !sb || !red || !m || !idx_keep || rb->n_stn != k || red->n != 3 * k || red->n > m->n_max)
+        return fail(ctx, DNAGPU_EINVAL, "block_load_reduced: bad arguments");
+    for (size_t i = 0; i < k; ++i)
+        if (idx_keep[i] >= sb->n_stn) return fail(ctx, DNAGPU_EINVAL, "block_load_reduced: station out of range");
+    hipStream_t st = ctx->stream[chain];
+    uint32_t* didx = nullptr;
+    int rc = stage_u32(ctx, chain, idx_keep, k, &didx);
+    if (rc) return rc;
+    m->n = red->n;
+    m->np = red->np;
+    HIPCHK(hipMemcpyAsync(m->F, red->F, (size_t)red->np * red->np * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(rb->rhs[chain], red->jest, (size_t)red->n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    launch_gather_vec3(sb->x_orig, didx, (uint32_t)k, rb->x_est[chain], st);
+    return DNAGPU_OK;
 }
 
 int dnagpu_junction_scatter(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const uint32_t* idx_to, size_t k, const dnagpu_matrix* jm) {

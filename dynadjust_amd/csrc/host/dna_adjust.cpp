@@ -36,7 +36,8 @@ void dna_adjust::FreeDevice() {
         if (b.rigvar) dnagpu_matrix_destroy(ctx_, b.rigvar);
         if (b.finv) dnagpu_matrix_destroy(ctx_, b.finv);
         if (b.rinv) dnagpu_matrix_destroy(ctx_, b.rinv);
-        b.jfwd = b.jrev = b.rigvar = b.finv = b.rinv = nullptr;
+        if (b.red) dnagpu_matrix_destroy(ctx_, b.red);
+        b.jfwd = b.jrev = b.rigvar = b.finv = b.rinv = b.red = nullptr;
     }
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
         if (work_[c]) dnagpu_matrix_destroy(ctx_, work_[c]);
@@ -564,6 +565,7 @@ void dna_adjust::PrepareBlocks() {
             // v_rigorousVariances_ is allocated when the block is finalised (only on the rank / chain that owns it)
         }
     }
+    PrepareCondensedBlocks();
     Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
 }
 
@@ -650,6 +652,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     solve_flops_ = 0.0;
     solve_count_ = 0;
     elimination_count_ = 0;
+    condense_count_ = 0;
     algorithmic_flops_ = 0.0;
     const double t0 = now_ms();
     switch (projectSettings_.a.adjust_mode) {
@@ -744,7 +747,9 @@ void dna_adjust::AdjustPhased() {
         if (IsCancelled()) break;
         maxCorr_ = 0.0;
         ++currentIteration_;
-        if (projectSettings_.a.multi_thread) {
+        if (CondensedSchedule()) {
+            AdjustPhasedCondensedIteration();
+        } else if (projectSettings_.a.multi_thread) {
             AdjustPhasedMultiThreadIteration();
         } else {
             AdjustPhasedForward();
@@ -809,6 +814,7 @@ void dna_adjust::ResetAdjustment() {
     solve_flops_ = 0.0;
     solve_count_ = 0;
     elimination_count_ = 0;
+    condense_count_ = 0;
     algorithmic_flops_ = 0.0;
     cancel_.store(false);
     adjustStatus_ = ADJUST_SUCCESS;

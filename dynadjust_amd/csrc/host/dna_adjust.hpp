@@ -103,6 +103,7 @@ public:
     double solveFlops() const { return solve_flops_; }   // sum of n^3 over Solve() calls (reference-equivalent)
     UINT32 solveCount() const { return solve_count_; }
     UINT32 eliminationCount() const { return elimination_count_; }
+    UINT32 condenseCount() const { return condense_count_; }
     double algorithmicFlops() const { return algorithmic_flops_; }
     dnagpu_ctx* deviceContext() const { return ctx_; }
 
@@ -128,6 +129,12 @@ private:
         dnagpu_matrix* finv = nullptr;
         dnagpu_matrix* rinv = nullptr;
         bool has_finv = false, has_rinv = false, has_cinv = false;
+        // a.schur_carry, condensed schedule: the block reduced to the stations it shares with its neighbours
+        std::vector<UINT32> keep;             // block-local indices of jslprev_here + jsl_here stations, ascending
+        std::vector<UINT32> c_prev, c_next;   // jslprev_here / jsl_here as positions in keep (same order as those lists)
+        constraint_list con_inner;            // constraints of the eliminated stations (first appearance in both directions)
+        constraint_list ccon_fwd, ccon_rev;   // con_fwd / con_rev of the kept stations, positions in keep
+        dnagpu_matrix* red = nullptr;         // Schur complement onto keep + reduced right-hand side (dnagpu_block_reduce)
         std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_ (6 per GNSS vector, then 1 per terrestrial measurement)
         // terrestrial measurements of the block (CML order among themselves)
         std::vector<char> t_type;
@@ -152,6 +159,8 @@ private:
     void AdjustPhasedForward();          // ADJ:2756
     void AdjustPhasedReverseCombine();   // ADJ:3461
     void AdjustPhasedMultiThreadIteration();   // dnaadjust-multi.cpp:92-244 (forward || reverse chains)
+    void AdjustPhasedCondensedIteration();     // a.schur_carry: condense every block, chains on the condensed blocks, rigorous solves
+    void PrepareCondensedBlocks();
 public:
     // ---- per-block steps of the phased chain; the drivers above and the multi-GPU orchestrator
     //      (dynadjust_amd/parallel.py through dnaadjust_c.h) are built from these ----------------
@@ -163,6 +172,24 @@ public:
     double PhasedCombineBlock(int chain, UINT32 k);
     // UpdateEstimatesFinal (ADJ:3744): rigorous = estimated, rigorous variances = current inverse, original = rigorous
     void PhasedFinaliseBlock(int chain, UINT32 k);
+    // ---- condensed schedule (a.schur_carry): the steps of one iteration ---------------------------------
+    bool CondensedSchedule() const { return SchurCarry() && condensed_ok_; }
+    // (A) independent per block: eliminate every station the block shares with no other block
+    void CondenseBlock(int chain, UINT32 k);
+    // (B) the forward and the reverse chain on the condensed blocks: jfwd[k] / jrev[k-1] exactly as the block-level chain leaves them
+    void CondensedForwardBlock(int chain, UINT32 k);
+    void CondensedReverseBlock(int chain, UINT32 k);
+    // (C) independent per block: the solve whose result is rigorous (forward for a last / isolated block, reverse for a
+    // first block, combination otherwise) + UpdateEstimatesFinal; returns the signed largest correction
+    double RigorousBlock(int chain, UINT32 k);
+    // the same for lists of blocks, spread over both chains with a.multi_thread; (B) as a whole
+    void CondenseBlocks(const std::vector<UINT32>& blocks);
+    void CondensedChains();
+    void RigorousBlocks(const std::vector<UINT32>& blocks);
+    // condensed block k as one buffer: np*np matrix + np vector, np = pad128(3 * kept stations)
+    size_t CondensedPayloadDoubles(UINT32 k) const;
+    void ExportCondensed(UINT32 k, double* dst);
+    void ImportCondensed(UINT32 k, const double* src);
     // start of an iteration on this process: maxCorr = 0 (+ iteration counter)
     void PhasedBeginIteration();
     void PhasedNoteCorrection(double mv);   // maxCorr_ update rule of ADJ:3036 / ADJ:3786
@@ -195,7 +222,11 @@ private:
     dnagpu_matrix* StepMatrix(int chain, UINT32 block, int kind);
     bool ReuseInverses() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
     bool SchurCarry() const { return projectSettings_.a.schur_carry != 0 && !ReuseInverses() && !projectSettings_.a.scale_normals_to_unity; }
-    void CarryByElimination(int chain, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
+    void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
+    bool condensed_ok_ = false;
+    std::atomic<bool> chain_failed_{false};
+    void OnEveryChain(const std::function<void(int)>& body);
+    void ForBlocks(const std::vector<UINT32>& blocks, const std::function<void(int, UINT32)>& step);
     void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
     void Check(int rc, UINT32 block, const char* where);
     void SetmaxCorr(double v) { maxCorr_ = v; }
@@ -237,6 +268,7 @@ private:
     double solve_flops_ = 0.0;
     UINT32 solve_count_ = 0;
     double algorithmic_flops_ = 0.0;  // n^3 per inverse, the elimination's own count per dnagpu_schur_carry step
+    UINT32 condense_count_ = 0;      // dnagpu_block_reduce steps (condensed schedule)
     UINT32 elimination_count_ = 0;   // of those, steps done by dnagpu_schur_carry (a.schur_carry)
 
     std::mutex corr_mutex_, alloc_mutex_;   // multi-thread mode: maxCorr_/solve counters, lazy allocations

@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -41,11 +42,13 @@ dnagpu_matrix* dna_adjust::StepMatrix(int c, UINT32 k, int kind) {
 
 // A forward / reverse step whose solution only feeds the next block: Solve() + CarryStnEstimatesandVariances...() as one
 // partial elimination (include/dnagpu.h, dnagpu_schur_carry).  Counted as a Solve() in the reference-equivalent totals.
-void dna_adjust::CarryByElimination(int c, UINT32 k, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm) {
-    Check(dnagpu_schur_carry(ctx_, c, k, W, out.data(), out.size(), jm), k, "Solve()");
-    const double n = 3.0 * (double)v_parameterStationList_[k].size(), nj = 3.0 * (double)out.size(), ni = n - nj;
+// dev_block: the device block the elimination runs on (block k itself, or its condensed twin); k: the block whose Solve() it replaces.
+void dna_adjust::CarryByElimination(int c, UINT32 dev_block, UINT32 k, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm) {
+    Check(dnagpu_schur_carry(ctx_, c, dev_block, W, out.data(), out.size(), jm), k, "Solve()");
+    const double nref = 3.0 * (double)v_parameterStationList_[k].size();
+    const double n = dev_block == k ? nref : 3.0 * (double)blocks_[k].keep.size(), nj = 3.0 * (double)out.size(), ni = n - nj;
     std::lock_guard<std::mutex> lk(corr_mutex_);
-    solve_flops_ += n * n * n;
+    solve_flops_ += nref * nref * nref;
     // Cholesky of the inner part, its panel under the junction rows, the complement's update, the complement's inverse
     algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + nj * nj * nj;
     solve_count_++;
@@ -74,7 +77,7 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
     if (SchurCarry() && carries) {
         // only the junction stations' weights and estimates leave this step (the block's own estimates are set again from
         // the originals before its reverse / combination solve, ADJ:3863)
-        CarryByElimination(c, k, W, B.jsl_here, B.jfwd);
+        CarryByElimination(c, k, k, W, B.jsl_here, B.jfwd);
         return 0.0;
     }
     if (reuse)
@@ -125,7 +128,7 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
     if (SchurCarry() && fwd_in) {
         // only a first block keeps its reverse solution (ADJ:3744); the others are combined afterwards, or, for the last
         // block, already rigorous from the forward pass (ADJ:3748-3756): their reverse solution is only carried on (ADJ:3833)
-        CarryByElimination(c, k, W, B.jslprev_here, blocks_[k - 1].jrev);
+        CarryByElimination(c, k, k, W, B.jslprev_here, blocks_[k - 1].jrev);
         return 0.0;
     }
     if (reuse)
@@ -337,6 +340,214 @@ void dna_adjust::AdjustPhasedMultiThreadIteration() {
     fwd.join();
     if (fwd_error) std::rethrow_exception(fwd_error);   // dnaadjust-multi.cpp:182-190
     if (rev_error) std::rethrow_exception(rev_error);
+}
+
+// ---- the condensed schedule (a.schur_carry) ------------------------------------------------------------------------------
+// What leaves a forward / reverse step of the reference is the weight matrix and the estimates of the junction stations
+// (CarryStnEstimatesandVariancesForward / ...Reverse, ADJ:998-1281).  A station that block k shares with no other block
+// enters neither: eliminating those stations from block k's own normals (measurements + their constraints) commutes with
+// everything the chains add, because carried junction weights, pseudo measurements and the direction dependent constraints
+// (ADJ:1884-2037) only touch shared stations.  So every block is condensed ONCE per iteration, independently of all others,
+// to a system in its shared stations; the two chains run on those small systems (same steps, same order, same results up
+// to rounding) and every block then needs exactly one full inverse: the one whose result is rigorous.  Per iteration
+// B eliminations (~n^3/3) + B inverses (n^3) instead of the reference's 3B - 2 inverses, and both large phases are
+// independent per block: they shard over chains and GPUs without a dependency (dynadjust_amd/parallel.py).
+
+// lists for the condensed schedule; condensed_ok_ = false falls back to the block-level chains
+void dna_adjust::PrepareCondensedBlocks() {
+    condensed_ok_ = false;
+    if (projectSettings_.a.adjust_mode == SimultaneousMode || !projectSettings_.a.schur_carry) return;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        block_t& B = blocks_[k];
+        const UINT32 ns = (UINT32)v_parameterStationList_[k].size();
+        std::vector<int> pos(ns, -1);
+        for (UINT32 s : B.jslprev_here) pos[s] = 0;
+        if (!v_blockMeta_[k]._blockLast && !v_blockMeta_[k]._blockIsolated)
+            for (UINT32 s : B.jsl_here) pos[s] = 0;
+        B.keep.clear();
+        for (UINT32 s = 0; s < ns; ++s)
+            if (pos[s] == 0) {
+                pos[s] = (int)B.keep.size();
+                B.keep.push_back(s);
+            }
+        B.c_prev.clear();
+        B.c_next.clear();
+        for (UINT32 s : B.jslprev_here) B.c_prev.push_back((UINT32)pos[s]);
+        for (UINT32 s : B.jsl_here)
+            if (pos[s] >= 0) B.c_next.push_back((UINT32)pos[s]);
+        B.con_inner = constraint_list();
+        B.ccon_fwd = constraint_list();
+        B.ccon_rev = constraint_list();
+        auto split = [&](const constraint_list& src, constraint_list& kept, constraint_list* inner) {
+            for (size_t i = 0; i < src.stn.size(); ++i) {
+                const UINT32 s = src.stn[i];
+                constraint_list* dst = pos[s] >= 0 ? &kept : inner;
+                if (!dst) continue;
+                dst->stn.push_back(pos[s] >= 0 ? (UINT32)pos[s] : s);
+                dst->w9.insert(dst->w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
+            }
+        };
+        constraint_list inner_rev;
+        split(B.con_fwd, B.ccon_fwd, &B.con_inner);
+        split(B.con_rev, B.ccon_rev, &inner_rev);
+        // a station of one block only appears first in that block, whichever way the blocks are walked
+        if (B.con_inner.stn != inner_rev.stn || B.con_inner.w9 != inner_rev.w9) return;
+        if (B.con_inner.stn.size() + B.keep.size() != ns) return;
+        if (B.keep.empty()) continue;
+        Check(dnagpu_block_create(ctx_, blockCount_ + k, (UINT32)B.keep.size(), 0), k, "PrepareAdjustment(): condensed block");
+        Check(dnagpu_matrix_create(ctx_, (UINT32)B.keep.size() * 3, &B.red), k, "PrepareAdjustment(): condensed block");
+    }
+    condensed_ok_ = true;
+}
+
+void dna_adjust::CondenseBlock(int c, UINT32 k) {
+    block_t& B = blocks_[k];
+    if (B.keep.empty()) return;
+    dnagpu_matrix* W = work_[c];
+    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+    AddConstraints(c, W, B.con_inner, +1, k);
+    Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+    Check(dnagpu_block_reduce(ctx_, c, k, W, B.keep.data(), B.keep.size(), B.red), k, "Solve()");
+    const double nk = 3.0 * (double)B.keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    condense_count_++;
+}
+
+// PhasedForwardBlock on the condensed block: same additions, same order
+void dna_adjust::CondensedForwardBlock(int c, UINT32 k) {
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    if (meta._blockIsolated || meta._blockLast || v_blockMeta_[k + 1]._blockIsolated || B.c_next.empty()) return;
+    const bool carried_in = !meta._blockFirst && !B.c_prev.empty();
+    dnagpu_matrix* W = work_[c];
+    const UINT32 cb = blockCount_ + k;
+    Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, W), k, "UpdateNormals()");
+    AddConstraints(c, W, B.ccon_fwd, +1, k);
+    if (carried_in) {
+        Check(dnagpu_junction_scatter(ctx_, c, W, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesForward()");
+        Check(dnagpu_junction_rhs(ctx_, c, cb, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "Solve()");
+    }
+    CarryByElimination(c, cb, k, W, B.c_next, B.jfwd);
+}
+
+// PhasedReverseBlock on the condensed block
+void dna_adjust::CondensedReverseBlock(int c, UINT32 k) {
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    if (meta._blockIsolated || meta._blockFirst || B.c_prev.empty()) return;
+    const bool rev_in = !meta._blockLast && !B.c_next.empty();
+    dnagpu_matrix* W = work_[c];
+    const UINT32 cb = blockCount_ + k;
+    Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, W), k, "UpdateNormals()");
+    if (rev_in) Check(dnagpu_junction_scatter(ctx_, c, W, B.c_next.data(), B.c_next.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
+    AddConstraints(c, W, B.ccon_rev, +1, k);
+    if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, cb, B.c_next.data(), B.c_next.size(), B.jrev), k, "Solve()");
+    CarryByElimination(c, cb, k, W, B.c_prev, blocks_[k - 1].jrev);
+}
+
+double dna_adjust::RigorousBlock(int c, UINT32 k) {
+    const blockMeta_t& meta = v_blockMeta_[k];
+    if (meta._blockLast || meta._blockIsolated) return PhasedForwardBlock(c, k);   // notes its correction and stores the variances itself
+    double mv = meta._blockFirst ? PhasedReverseBlock(c, k) : PhasedCombineBlock(c, k);
+    PhasedNoteCorrection(mv);
+    PhasedFinaliseBlock(c, k);
+    return mv;
+}
+
+// body(chain) on every chain in use (a.multi_thread: two host threads, one per chain); the first exception is rethrown
+void dna_adjust::OnEveryChain(const std::function<void(int)>& body) {
+    if (!projectSettings_.a.multi_thread) {
+        body(0);
+        return;
+    }
+    std::mutex m;
+    std::exception_ptr error;
+    auto guarded = [&](int c) {
+        try {
+            body(c);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(m);
+            if (!error) error = std::current_exception();
+            chain_failed_ = true;
+        }
+    };
+    chain_failed_ = false;
+    std::thread other([&] { guarded(1); });
+    guarded(0);
+    other.join();
+    if (error) std::rethrow_exception(error);
+}
+
+// independent per-block steps: a queue served by every chain
+void dna_adjust::ForBlocks(const std::vector<UINT32>& blocks, const std::function<void(int, UINT32)>& step) {
+    std::mutex m;
+    size_t next = 0;
+    OnEveryChain([&](int c) {
+        for (;;) {
+            UINT32 k;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (chain_failed_ || IsCancelled() || next >= blocks.size()) return;
+                k = blocks[next++];
+            }
+            currentBlock_ = k;
+            step(c, k);
+        }
+    });
+}
+
+void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks) {
+    forward_ = true;
+    ForBlocks(blocks, [&](int c, UINT32 k) { CondenseBlock(c, k); });
+}
+
+// the forward chain on chain 0 beside the reverse chain on chain 1 (one after the other without a.multi_thread)
+void dna_adjust::CondensedChains() {
+    const bool two = projectSettings_.a.multi_thread != 0;
+    OnEveryChain([&](int c) {
+        if (c == 0)
+            for (UINT32 k = 0; k < blockCount_ && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
+        if (c == 1 || !two)
+            for (UINT32 kk = blockCount_; kk-- > 0 && !IsCancelled() && !chain_failed_;) CondensedReverseBlock(c, kk);
+    });
+}
+
+void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks) {
+    forward_ = false;
+    isCombining_ = true;
+    ForBlocks(blocks, [&](int c, UINT32 k) { RigorousBlock(c, k); });
+    isCombining_ = false;
+}
+
+// One iteration on this process: (A) every block condensed, (B) the chains, (C) every block's rigorous solve
+void dna_adjust::AdjustPhasedCondensedIteration() {
+    std::vector<UINT32> all(blockCount_);
+    for (UINT32 k = 0; k < blockCount_; ++k) all[k] = k;
+    CondenseBlocks(all);
+    if (IsCancelled()) return;
+    CondensedChains();
+    if (IsCancelled()) return;
+    RigorousBlocks(all);
+}
+
+size_t dna_adjust::CondensedPayloadDoubles(UINT32 k) const {
+    size_t n = blocks_.at(k).keep.size() * 3;
+    if (!n) return 0;
+    size_t np = ((n + 127) / 128) * 128;
+    return np * np + np;
+}
+
+void dna_adjust::ExportCondensed(UINT32 k, double* dst) {
+    block_t& B = blocks_.at(k);
+    if (!B.red) return;
+    Check(dnagpu_matrix_export(ctx_, 0, B.red, dst, CondensedPayloadDoubles(k)), k, "ExportCondensed()");
+}
+
+void dna_adjust::ImportCondensed(UINT32 k, const double* src) {
+    block_t& B = blocks_.at(k);
+    if (!B.red) return;
+    Check(dnagpu_matrix_import(ctx_, 0, B.red, src, (UINT32)B.keep.size() * 3), k, "ImportCondensed()");
 }
 
 void dna_adjust::PhasedBeginIteration() {

@@ -357,6 +357,37 @@ int dnaadj_phased_end_iteration(dnaadj_handle* h, int* iterate) {
 int dnaadj_phased_finish(dnaadj_handle* h, int* status) {
     return guarded(h, [&] { h->adj->PhasedFinish(); if (status) *status = (int)h->adj->GetStatus(); });
 }
+int dnaadj_condensed_schedule(const dnaadj_handle* h) { return (h && h->adj && h->adj->CondensedSchedule()) ? 1 : 0; }
+size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block) {
+    return (h && h->adj && block < h->adj->blockCount()) ? h->adj->CondensedPayloadDoubles(block) : 0;
+}
+int dnaadj_phased_condense_block(dnaadj_handle* h, uint32_t block) {
+    return guarded(h, [&] { h->adj->CondenseBlock(0, block); });
+}
+int dnaadj_phased_condensed_forward(dnaadj_handle* h, uint32_t block) {
+    return guarded(h, [&] { h->adj->CondensedForwardBlock(0, block); });
+}
+int dnaadj_phased_condensed_reverse(dnaadj_handle* h, uint32_t block) {
+    return guarded(h, [&] { h->adj->CondensedReverseBlock(0, block); });
+}
+int dnaadj_phased_rigorous_block(dnaadj_handle* h, uint32_t block, double* mv) {
+    return guarded(h, [&] { double v = h->adj->RigorousBlock(0, block); if (mv) *mv = v; });
+}
+int dnaadj_phased_condense_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n) {
+    return guarded(h, [&] { h->adj->CondenseBlocks(std::vector<uint32_t>(blocks, blocks + n)); });
+}
+int dnaadj_phased_condensed_chains(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->CondensedChains(); });
+}
+int dnaadj_phased_rigorous_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n) {
+    return guarded(h, [&] { h->adj->RigorousBlocks(std::vector<uint32_t>(blocks, blocks + n)); });
+}
+int dnaadj_condensed_export(dnaadj_handle* h, uint32_t block, double* buf) {
+    return guarded(h, [&] { h->adj->ExportCondensed(block, buf); });
+}
+int dnaadj_condensed_import(dnaadj_handle* h, uint32_t block, const double* buf) {
+    return guarded(h, [&] { h->adj->ImportCondensed(block, buf); });
+}
 int dnaadj_junction_export(dnaadj_handle* h, int kind, uint32_t block, double* buf) {
     return guarded(h, [&] { h->adj->ExportJunction(kind, block, buf); });
 }

@@ -1,6 +1,20 @@
-"""Multi-GPU schedule of the phased adjustment: one process per GPU, torch.distributed.
+"""Multi-GPU schedules of the phased adjustment: one process per GPU, torch.distributed.
 
-The phased blocks form a chain (forward k -> k+1, reverse k -> k-1, combine(k) needs both), so the path shards the
+1. The condensed schedule (default; settings.schur_carry, dna_adjust_phased.cpp "the condensed schedule").  Per iteration:
+
+  (A) every block is condensed to the stations it shares with its neighbours -- one partial elimination (~n^3/3) per block,
+      no dependency between blocks: block k runs on rank owner(k)
+  exchange  the condensed systems ((3 * shared stations)^2 + 3 * shared stations doubles, padded to 128 -- 30 MB for a 317-station
+      junction row) are broadcast by their owners (async broadcasts, one per block): a real collective, the only data-path one
+  (B) the reference's forward and reverse chains, on the condensed blocks: a few thousand unknowns each, run redundantly
+      on every rank (identical arithmetic, identical results; cheaper than shipping the junction matrices a second time)
+  (C) the one full inverse per block whose result is rigorous (forward for a last block, reverse for a first block,
+      combination otherwise), again on rank owner(k), no dependency between blocks
+  sync      rigorous coordinates: one all_reduce(sum) of a 3*stations vector; largest correction: one all_gather
+
+  Both large phases shard by block, so B blocks scale to min(B, N) GPUs; the chain (B) is the serial remainder.
+
+2. The reference's schedule (settings.schur_carry = 0): the phased blocks form a chain (forward k -> k+1, reverse k -> k-1, combine(k) needs both), so the path shards the
 way the reference's multi-thread mode does (dnaadjust-multi.cpp:92-244): a forward chain, a reverse chain and the
 combination solves.  Per iteration:
 
@@ -93,6 +107,50 @@ class DeviceBlockBackend:
         self._chk(self.lib.dnaadj_phased_finish(self.h, C.byref(st)))
         return st.value
 
+    # ---- condensed schedule ----
+    def condensed(self):
+        return bool(self.lib.dnaadj_condensed_schedule(self.h))
+
+    def condense_block(self, k):
+        self._chk(self.lib.dnaadj_phased_condense_block(self.h, k))
+
+    def condensed_forward(self, k):
+        self._chk(self.lib.dnaadj_phased_condensed_forward(self.h, k))
+
+    def condensed_reverse(self, k):
+        self._chk(self.lib.dnaadj_phased_condensed_reverse(self.h, k))
+
+    def rigorous_block(self, k):
+        return self._step(self.lib.dnaadj_phased_rigorous_block, k)
+
+    # lists of blocks: spread over the two chains of this GPU when settings.multi_thread is on
+    def condense_blocks(self, blocks):
+        a = np.ascontiguousarray(blocks, dtype=np.uint32)
+        self._chk(self.lib.dnaadj_phased_condense_blocks(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size))
+
+    def condensed_chains(self):
+        self._chk(self.lib.dnaadj_phased_condensed_chains(self.h))
+
+    def rigorous_blocks(self, blocks):
+        a = np.ascontiguousarray(blocks, dtype=np.uint32)
+        self._chk(self.lib.dnaadj_phased_rigorous_blocks(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size))
+
+    def condensed_tensor(self, k):
+        key = ("c", k)
+        if key not in self._buf:
+            n = self.lib.dnaadj_condensed_payload_doubles(self.h, k)
+            self._buf[key] = self.torch.empty(n, dtype=self.torch.float64, device=self.comm_device) if n else None
+        return self._buf[key]
+
+    def export_condensed(self, k):
+        t = self.condensed_tensor(k)
+        if t is not None:
+            self._chk(self.lib.dnaadj_condensed_export(self.h, k, C.c_void_p(t.data_ptr())))
+        return t
+
+    def import_condensed(self, k, t):
+        self._chk(self.lib.dnaadj_condensed_import(self.h, k, C.c_void_p(t.data_ptr())))
+
     def junction_tensor(self, kind, k):
         """communication buffer for the junction payload of block k (device tensor with NCCL, host tensor with gloo)"""
         key = (kind, k)
@@ -140,9 +198,89 @@ class PhasedSchedule:
         return self.combine_owner[k]
 
 
+def _host_wait(works, dev):
+    """Work.wait() on an NCCL work only orders torch's current stream behind the collective; the block steps run on the
+    library's own HIP streams, so the host has to see the end of the transfer before the payload is imported."""
+    for w in works:
+        w.wait()
+    if getattr(dev, "type", "cpu") == "cuda":
+        import torch
+        torch.cuda.current_stream(dev).synchronize()
+
+
+def block_owners(costs, world):
+    """static, identical on every rank: longest-processing-time-first over the per-block cost (n^3)"""
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for k in sorted(range(len(costs)), key=lambda k: (-costs[k], k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[k] = r
+        load[r] += costs[k]
+    return owner
+
+
+def _sync_coordinates(backend, dist, rank, world, owner_of, offs, dev):
+    """rigorous coordinates of every block and the largest correction, on every rank"""
+    import torch
+    B = backend.n_blocks
+    flat = np.zeros(int(offs[B]), dtype=np.float64)
+    for k in range(B):
+        if owner_of(k) == rank:
+            flat[offs[k]:offs[k + 1]] = backend.get_coords(k)
+    t = torch.from_numpy(flat).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    flat = t.cpu().numpy()
+    for k in range(B):
+        if owner_of(k) != rank:
+            backend.set_coords(k, flat[offs[k]:offs[k + 1]])
+    mine = torch.tensor([backend.max_correction()], dtype=torch.float64, device=dev)
+    allc = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    for c in allc:
+        backend.note_correction(float(c.item()))
+
+
+def run_phased_condensed(backend, dist, rank, world, max_iterations=10):
+    """the condensed schedule across `world` ranks; returns (status, iterations, per-iteration corrections, owners)"""
+    B = backend.n_blocks
+    owner = block_owners([float(backend.n_stations(k)) ** 3 for k in range(B)], world)
+    offs = np.zeros(B + 1, dtype=np.int64)
+    for k in range(B):
+        offs[k + 1] = offs[k] + 3 * backend.n_stations(k)
+    corrections = []
+    for _ in range(max_iterations):
+        backend.begin_iteration()
+        mine = [k for k in range(B) if owner[k] == rank]
+        # (A) + exchange: one broadcast per block from its owner, all in flight together
+        backend.condense_blocks(mine)
+        if world > 1:
+            pending = []
+            for k in range(B):
+                t = backend.export_condensed(k) if owner[k] == rank else backend.condensed_tensor(k)
+                if t is not None:
+                    pending.append((k, t, dist.broadcast(t, src=owner[k], async_op=True)))
+            _host_wait([w for _, _, w in pending], backend.comm_device)
+            for k, t, _ in pending:
+                if owner[k] != rank:
+                    backend.import_condensed(k, t)
+        # (B) the two chains on the condensed blocks, everywhere
+        backend.condensed_chains()
+        # (C)
+        backend.rigorous_blocks(mine)
+        if world > 1:
+            _sync_coordinates(backend, dist, rank, world, lambda k: owner[k], offs, backend.comm_device)
+        corrections.append(backend.max_correction())
+        if not backend.end_iteration():
+            break
+    status = backend.finish()
+    return status, len(corrections), corrections, owner
+
+
 def run_phased(backend, dist, rank, world, max_iterations=10):
     """AdjustPhased (dnaadjust.cpp:2579) across `world` ranks; returns (status, iterations, per-iteration corrections)."""
     import torch
+    if getattr(backend, "condensed", lambda: False)():
+        return run_phased_condensed(backend, dist, rank, world, max_iterations)[:3]
     flags = [backend.flags(k) for k in range(backend.n_blocks)]
     sch = PhasedSchedule(flags, world)
     B = sch.B
@@ -181,8 +319,7 @@ def run_phased(backend, dist, rank, world, max_iterations=10):
                         ops.append(dist.P2POp(dist.irecv, t, src))
                         recvs.append((kind, blk, t))
             if ops:
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
+                _host_wait(dist.batch_isend_irecv(ops), dev)
             for kind, blk, t in recvs:
                 backend.import_junction(kind, blk, t)
         # ---- phase 2: combination solves -----------------------------------------------------------------
@@ -193,21 +330,7 @@ def run_phased(backend, dist, rank, world, max_iterations=10):
                 backend.finalise_block(k)
         # ---- rigorous coordinates and the largest correction, on every rank -------------------------------
         if world > 1:
-            flat = np.zeros(int(offs[B]), dtype=np.float64)
-            for k in range(B):
-                if sch.final_owner(k) == rank:
-                    flat[offs[k]:offs[k + 1]] = backend.get_coords(k)
-            t = torch.from_numpy(flat).to(dev)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            flat = t.cpu().numpy()
-            for k in range(B):
-                if sch.final_owner(k) != rank:
-                    backend.set_coords(k, flat[offs[k]:offs[k + 1]])
-            mine = torch.tensor([backend.max_correction()], dtype=torch.float64, device=dev)
-            allc = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-            dist.all_gather(allc, mine)
-            for c in allc:
-                backend.note_correction(float(c.item()))
+            _sync_coordinates(backend, dist, rank, world, sch.final_owner, offs, dev)
         corrections.append(backend.max_correction())
         if not backend.end_iteration():
             break
@@ -215,16 +338,21 @@ def run_phased(backend, dist, rank, world, max_iterations=10):
     return status, len(corrections), corrections
 
 
-def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank):
+def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank, dist_backend="nccl"):
     """bench.py --gpus N (N > 1): the same network on N ranks, strong scaling; rank 0 returns the JSON dict."""
     import torch
     from . import adjust
     if not phased:
         raise SystemExit("the simultaneous adjustment does not shard: run it with --gpus 1")
-    dev = torch.device("cuda", local_rank)
-    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank)
+    dev = torch.device("cuda", local_rank) if dist_backend == "nccl" else torch.device("cpu")   # where the payloads live
+    import os
+    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank,
+                               multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
+                               schur_carry=not getattr(args, "reference_schedule", False))
     be = DeviceBlockBackend(p, dev)
     a = be.adj
+    lib, ctx = a.lib, a.device_context()
+    condensed = be.condensed()
 
     def one_step():
         a.ResetAdjustment()
@@ -235,22 +363,51 @@ def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank)
 
     for _ in range(args.warmup):
         one_step()
+    lib.dnagpu_profile_enable(ctx, 1)
+    lib.dnagpu_profile_reset(ctx)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     its = 0
     for _ in range(args.steps):
         its = one_step()
+    lib.dnagpu_sync(ctx)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    sol = torch.tensor([a.solve_flops(), float(a.solve_count())], dtype=torch.float64, device=dev)
-    dist.all_reduce(sol, op=dist.ReduceOp.SUM)
+    prof_f, prof_ms, prof_n = C.c_double(), C.c_double(), C.c_uint64()
+    lib.dnagpu_profile_get(ctx, C.byref(prof_f), C.byref(prof_ms), C.byref(prof_n))
+    lib.dnagpu_profile_enable(ctx, 0)
+    # per rank: algorithmic flops of its own steps (the chains on the condensed blocks run on every rank: their < 0.5 % is
+    # counted on every rank), HIP-event time of its GEMM launches; the reference-equivalent count (n^3 per Solve() of the
+    # reference's schedule) is the same on every rank with the condensed schedule and split over the ranks otherwise
+    mine = torch.tensor([a.algorithmic_flops(), prof_ms.value, float(a.solve_count()), a.solve_flops()], dtype=torch.float64, device=dev)
+    allv = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    allv = [v.cpu().numpy() for v in allv]
     dt = float(dt.item())
     stations = a.lib.dnaadj_station_count(a.h)
     out = None
     if rank == 0:
+        alg = sum(float(v[0]) for v in allv)
+        # the reference's own work for this adjustment: a Solve() (n^3) per block in the forward pass, one in the reverse pass
+        # unless the block is isolated, one combination solve for every intermediate block -- per iteration
+        solves, ref = 0, 0.0
+        for k in range(be.n_blocks):
+            f, l, i = be.flags(k)
+            m = 1 + (0 if i else 1) + (0 if (f or l or i) else 1)
+            solves += its * m
+            ref += its * m * (3.0 * be.n_stations(k)) ** 3
+        busiest = max(range(world), key=lambda r: allv[r][1])
+        gemm_ms = float(allv[busiest][1])
+        # the flop counters restart with every step (ResetAdjustment), the event time accumulates over the timed steps
+        achieved = (float(allv[busiest][0]) / 1e12) / (gemm_ms / args.steps / 1e3) if gemm_ms > 0 else 0.0
+        par = (f"condensed schedule: blocks condensed and solved rigorously on their owner rank ({be.n_blocks} blocks over {world} ranks, "
+               f"{'two chains' if p.multi_thread else 'one chain'} per GPU), condensed systems broadcast over RCCL, chains on the condensed "
+               "blocks on every rank") if condensed else (
+               f"forward chain on rank 0, reverse chain on rank 1, combination solves round-robin over {world} ranks; "
+               "junction matrices point-to-point over RCCL")
         out = {
             "metric": "stations adjusted/sec + Cholesky TFLOP/s, phased adjustment, 1/2/4/8 MI355X",
             "value": stations * args.steps / dt,
@@ -265,10 +422,15 @@ def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank)
             "dtype": "f64",
             "data": "synthetic",
             "config": {"stations": stations, "blocks": be.n_blocks, "iterations_to_converge": its, "mode": "phased",
-                       "solves_per_step": int(sol[1].item()),
-                       "parallelism": f"forward chain on rank 0, reverse chain on rank 1, combination solves round-robin over {world} ranks; "
-                                      "junction matrices point-to-point over RCCL"},
-            "cholesky_tflops": (float(sol[0].item()) / 1e12) / (dt / args.steps),
+                       "solves_per_step": solves, "schur_carry": condensed, "parallelism": par},
+            "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
+            "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
+            "roofline": {
+                "kernel": "gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
+                "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6, "traffic": None,
+                "rank": busiest, "gemm_ms_per_step": gemm_ms / args.steps,
+                "note": "busiest rank: algorithmic flops of its steps / HIP-event time of its GEMM launches",
+            },
         }
     be.close()
     return out

@@ -126,6 +126,27 @@ int dnaadj_phased_note_correction(dnaadj_handle* h, double max_corr);
 int dnaadj_phased_end_iteration(dnaadj_handle* h, int* iterate);       /* convergence test + UpdateAdjustment */
 int dnaadj_phased_finish(dnaadj_handle* h, int* status);               /* ValidateandFinaliseAdjustment */
 /* kind 0 = forward (v_junctionVariancesFwd_/v_junctionEstimatesFwd_ of `block`), 1 = reverse; buf may be device memory */
+/* The condensed schedule (settings.schur_carry; dna_adjust_phased.cpp): per iteration
+ *   (A) dnaadj_phased_condense_block(k) for every block, in any order, on any process   -- eliminates the stations of block k
+ *       that no other block holds; the result (dnaadj_condensed_export / _import) must reach every process that runs (B)
+ *   (B) dnaadj_phased_condensed_forward(k), k ascending, and dnaadj_phased_condensed_reverse(k), k descending: the two
+ *       chains of the reference on the condensed blocks; they leave the junction weights / estimates of every block
+ *   (C) dnaadj_phased_rigorous_block(k) for every block, in any order, on any process that ran (B): the one full solve per
+ *       block whose result is rigorous, finalised and noted for the convergence test
+ * dnaadj_condensed_schedule() tells whether the prepared adjustment supports it (phased, schur_carry, no reuse_inverses /
+ * scale_normals_to_unity). */
+int dnaadj_condensed_schedule(const dnaadj_handle* h);
+size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block);
+int dnaadj_phased_condense_block(dnaadj_handle* h, uint32_t block);
+int dnaadj_phased_condensed_forward(dnaadj_handle* h, uint32_t block);
+int dnaadj_phased_condensed_reverse(dnaadj_handle* h, uint32_t block);
+int dnaadj_phased_rigorous_block(dnaadj_handle* h, uint32_t block, double* max_corr);
+/* the same for lists of blocks / both chains at once: with settings.multi_thread the work is spread over the two device chains */
+int dnaadj_phased_condense_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n);
+int dnaadj_phased_condensed_chains(dnaadj_handle* h);
+int dnaadj_phased_rigorous_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n);
+int dnaadj_condensed_export(dnaadj_handle* h, uint32_t block, double* buf);
+int dnaadj_condensed_import(dnaadj_handle* h, uint32_t block, const double* buf);
 int dnaadj_junction_export(dnaadj_handle* h, int kind, uint32_t block, double* buf);
 int dnaadj_junction_import(dnaadj_handle* h, int kind, uint32_t block, const double* buf);
 /* which: 0 original, 1 estimated, 2 rigorous */

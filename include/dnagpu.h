@@ -197,6 +197,16 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
  * dnagpu_junction_gather + dnagpu_invert leave there after a full solve, up to rounding.  The block's estimates and
  * corrections are NOT updated.  DNAGPU_ENOTPOSDEF like dnagpu_invert. */
 int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm);
+/* The same elimination as a stand-alone step: red (order 3k) <- Schur complement of all other unknowns of m onto the k
+ * listed stations (list order), red's attached vector <- the reduced right-hand side.  With the stations a block shares
+ * with its neighbours as the list, this condenses the block to its junction stations ONCE per iteration, independently of
+ * every other block; the forward and the reverse chain of dna_adjust::AdjustPhased then run on the condensed blocks
+ * (a few thousand unknowns each) and produce the very junction weights and estimates the block-level chain would. */
+int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red);
+/* Start a chain step on a condensed block: m <- red, rhs(rblk) <- red's vector, estimated(rblk) <- original(src_blk)[idx_keep].
+ * rblk: a block created with k stations and no measurements. */
+int dnagpu_block_load_reduced(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k,
+                              const dnagpu_matrix* red, dnagpu_matrix* m);
 /* dst[idx,idx] += jm (3x3 blocks), and rhs_extra of blk_to gets the pseudo
  * measurement part:  rhs[idx] += jm * (jest - estimated_to[idx])  is applied
  * by dnagpu_junction_rhs at solve time. */

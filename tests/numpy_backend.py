@@ -6,7 +6,7 @@ import torch
 
 
 class NumpyBlockBackend:
-    def __init__(self, net, fixed_std_dev=1e-6, free_std_dev=10.0, threshold=float(np.float32(0.0005)), max_iterations=10):
+    def __init__(self, net, fixed_std_dev=1e-6, free_std_dev=10.0, threshold=float(np.float32(0.0005)), max_iterations=10, condensed=True):
         self.comm_device = torch.device("cpu")
         self.net = net
         self.n_blocks = B = net.n_blocks
@@ -47,7 +47,8 @@ class NumpyBlockBackend:
             self.W.append(np.linalg.inv(V))
         for k in range(B):
             self._compute_b(k)
-        self.jfwd, self.jrev = {}, {}
+        self.jfwd, self.jrev, self.red = {}, {}, {}
+        self.condensed_ = condensed
         self.maxcorr = 0.0
         self.iteration = 0
         self.history = []
@@ -208,6 +209,121 @@ class NumpyBlockBackend:
         n = self._njs(k)
         a = t.numpy().copy()
         (self.jfwd if kind == 0 else self.jrev)[k] = (a[:n * n].reshape(n, n), a[n * n:])
+
+    # ---- the condensed schedule (parallel.run_phased_condensed), dense numpy restatement -------------------------------
+    def condensed(self):
+        return self.condensed_
+
+    def _kept(self, k):
+        """stations block k shares with its neighbours, in block order; positions of JSL(k-1) / JSL(k) among them"""
+        f, l, i = self.flags_[k]
+        d = self.blk[k]
+        prev = [] if (f or i) else self.blk[k - 1]["jsl"]
+        nxt = [] if (l or i) else d["jsl"]
+        keep = sorted(set(d["loc"][s] for s in prev) | set(d["loc"][s] for s in nxt))
+        pos = {p: q for q, p in enumerate(keep)}
+        return keep, [pos[d["loc"][s]] for s in prev], [pos[d["loc"][s]] for s in nxt]
+
+    @staticmethod
+    def _unk(stations):
+        return np.array([3 * p + c for p in stations for c in range(3)], dtype=np.int64)
+
+    def condense_block(self, k):
+        d = self.blk[k]
+        keep, _, _ = self._kept(k)
+        if not keep:
+            return
+        N, rhs = self._normals(k)
+        inner = [p for p in range(len(d["st"])) if p not in set(keep)]
+        for p in inner:      # a station of one block only appears first in it in both directions
+            assert d["first_fwd"][p] and d["first_rev"][p]
+            N[3 * p:3 * p + 3, 3 * p:3 * p + 3] += self._weight(int(d["st"][p])) * np.eye(3)
+        rk, ri = self._unk(keep), self._unk(inner)
+        if len(ri):
+            X = np.linalg.solve(N[np.ix_(ri, ri)], np.column_stack([N[np.ix_(ri, rk)], rhs[ri]]))
+            S = N[np.ix_(rk, rk)] - N[np.ix_(rk, ri)] @ X[:, :-1]
+            r = rhs[rk] - N[np.ix_(rk, ri)] @ X[:, -1]
+        else:
+            S, r = N[np.ix_(rk, rk)], rhs[rk]
+        self.red[k] = (S, r)
+
+    def _condensed_step(self, k, direction):
+        """one chain step on the condensed block: returns (weights, estimates) of the stations carried on"""
+        f, l, i = self.flags_[k]
+        d = self.blk[k]
+        keep, cprev, cnext = self._kept(k)
+        S, r = self.red[k]
+        S, r = S.copy(), r.copy()
+        x0 = d["orig"][self._unk(keep)]
+        which = "first_fwd" if direction == "fwd" else "first_rev"
+        for q, p in enumerate(keep):
+            if d[which][p]:
+                S[3 * q:3 * q + 3, 3 * q:3 * q + 3] += self._weight(int(d["st"][p])) * np.eye(3)
+        cin, payload, cout = (cprev, self.jfwd.get(k - 1), cnext) if direction == "fwd" else (cnext, self.jrev.get(k), cprev)
+        if cin and payload is not None:
+            WJ, est = payload
+            rr = self._unk(cin)
+            S[np.ix_(rr, rr)] += WJ
+            r[rr] += WJ @ (est - x0[rr])
+        ro = self._unk(cout)
+        re = self._unk([q for q in range(len(keep)) if q not in set(cout)])
+        if len(re):
+            X = np.linalg.solve(S[np.ix_(re, re)], np.column_stack([S[np.ix_(re, ro)], r[re]]))
+            W = S[np.ix_(ro, ro)] - S[np.ix_(ro, re)] @ X[:, :-1]
+            ro_rhs = r[ro] - S[np.ix_(ro, re)] @ X[:, -1]
+        else:
+            W, ro_rhs = S[np.ix_(ro, ro)], r[ro]
+        return W, x0[ro] + np.linalg.solve(W, ro_rhs)
+
+    def condensed_forward(self, k):
+        f, l, i = self.flags_[k]
+        if i or l or not self.blk[k]["jsl"] or self.flags_[k + 1][2]:
+            return
+        self.jfwd[k] = self._condensed_step(k, "fwd")
+
+    def condensed_reverse(self, k):
+        f, l, i = self.flags_[k]
+        if i or f or not self.blk[k - 1]["jsl"]:
+            return
+        self.jrev[k - 1] = self._condensed_step(k, "rev")
+
+    def rigorous_block(self, k):
+        f, l, i = self.flags_[k]
+        if l or i:
+            return self.forward_block(k)
+        mv = self.reverse_block(k) if f else self.combine_block(k)
+        self.note_correction(mv)
+        self.finalise_block(k)
+        return mv
+
+    def condense_blocks(self, blocks):
+        for k in blocks:
+            self.condense_block(k)
+
+    def condensed_chains(self):
+        for k in range(self.n_blocks):
+            self.condensed_forward(k)
+        for k in range(self.n_blocks - 1, -1, -1):
+            self.condensed_reverse(k)
+
+    def rigorous_blocks(self, blocks):
+        for k in blocks:
+            self.rigorous_block(k)
+
+    def condensed_tensor(self, k):
+        n = 3 * len(self._kept(k)[0])
+        return torch.empty(n * n + n, dtype=torch.float64) if n else None
+
+    def export_condensed(self, k):
+        if k not in self.red:
+            return None
+        S, r = self.red[k]
+        return torch.from_numpy(np.concatenate([S.ravel(), r]))
+
+    def import_condensed(self, k, t):
+        n = 3 * len(self._kept(k)[0])
+        a = t.numpy().copy()
+        self.red[k] = (a[:n * n].reshape(n, n), a[n * n:])
 
     def get_coords(self, k):
         return self.blk[k]["rig"].copy()

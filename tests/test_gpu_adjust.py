@@ -202,14 +202,17 @@ def test_multi_thread_mode_matches_oracle(built, orc, tmp_path):
     o.close()
 
 
-def test_orchestrator_single_rank_equals_facade(built, tmp_path):
-    """dynadjust_amd/parallel.run_phased on one rank drives the same per-block steps as AdjustPhased"""
+@pytest.mark.parametrize("schur", [True, False])
+def test_orchestrator_single_rank_equals_facade(built, tmp_path, schur):
+    """dynadjust_amd/parallel.run_phased on one rank drives the same per-block steps as AdjustPhased: the condensed
+    schedule (a.schur_carry, default) and the reference's"""
     from dynadjust_amd import parallel
     import torch
     adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 5, seed=9)
-    f, st_f = _device_run(str(tmp_path), "n", True)
-    p = adjust.ProjectSettings("n", str(tmp_path), adjust_mode=adjust.PhasedMode)
+    f, st_f = _device_run(str(tmp_path), "n", True, schur_carry=schur)
+    p = adjust.ProjectSettings("n", str(tmp_path), adjust_mode=adjust.PhasedMode, schur_carry=schur)
     be = parallel.DeviceBlockBackend(p, torch.device("cpu"))
+    assert be.condensed() == schur
     st, its, corr = parallel.run_phased(be, None, 0, 1)
     assert st == st_f and its == f.CurrentIteration()
     for b in range(f.blockCount()):
@@ -219,7 +222,7 @@ def test_orchestrator_single_rank_equals_facade(built, tmp_path):
     f.close()
 
 
-def _two_rank_worker(rank, world, port, folder, outdir):
+def _two_rank_worker(rank, world, port, folder, outdir, schur):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
@@ -228,14 +231,18 @@ def _two_rank_worker(rank, world, port, folder, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dynadjust_amd import adjust as adj, parallel
-    p = adj.ProjectSettings("n", folder, adjust_mode=adj.PhasedMode)
+    p = adj.ProjectSettings("n", folder, adjust_mode=adj.PhasedMode, schur_carry=schur)
     be = parallel.DeviceBlockBackend(p, torch.device("cpu"))     # both ranks share the box's single GPU; payloads via host
     st, its, corr = parallel.run_phased(be, dist, rank, world)
-    sch = parallel.PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world)
+    if schur:
+        owner = parallel.block_owners([float(be.n_stations(k)) ** 3 for k in range(be.n_blocks)], world)
+        final_owner = lambda k: owner[k]
+    else:
+        final_owner = parallel.PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world).final_owner
     res = {"status": st, "iterations": its}
     for k in range(be.n_blocks):
         res[f"coords_{k}"] = be.get_coords(k)
-        if sch.final_owner(k) == rank:
+        if final_owner(k) == rank:
             res[f"var_{k}"] = be.adj.block_variances_packed(k)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
     dist.barrier()
@@ -243,9 +250,11 @@ def _two_rank_worker(rank, world, port, folder, outdir):
     dist.destroy_process_group()
 
 
-def test_orchestrator_two_ranks_device_backend(built, orc, tmp_path):
-    """the real device backend under a 2-rank schedule (gloo transport, both processes on this box's GPU):
-    junction export/import, combination solves on the 'other' rank, coordinate all_reduce"""
+@pytest.mark.parametrize("schur", [True, False])
+def test_orchestrator_two_ranks_device_backend(built, orc, tmp_path, schur):
+    """the real device backend under both 2-rank schedules (gloo transport, both processes on this box's GPU).  Condensed:
+    blocks condensed and solved by their owners, condensed systems broadcast, chains everywhere.  Reference: junction
+    export/import, combination solves on the 'other' rank.  Both: coordinate all_reduce"""
     import socket
     import torch.multiprocessing as mp
     adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 6, seed=10)
@@ -257,7 +266,7 @@ def test_orchestrator_two_ranks_device_backend(built, orc, tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), str(tmp_path), schur), nprocs=2, join=True)
     seen = set()
     for r in range(2):
         res = np.load(str(tmp_path / f"rank{r}.npz"))

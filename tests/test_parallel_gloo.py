@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, base, outdir):
+def _worker(rank, world, port, base, outdir, condensed):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,21 +30,28 @@ def _worker(rank, world, port, base, outdir):
     from tests import oracle
     from tests.numpy_backend import NumpyBlockBackend
     net = oracle.Network(base, True)
-    be = NumpyBlockBackend(net)
+    be = NumpyBlockBackend(net, condensed=condensed)
     status, its, corr = parallel.run_phased(be, dist, rank, world)
-    sch = parallel.PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world)
+    if condensed:
+        owner = parallel.block_owners([float(be.n_stations(k)) ** 3 for k in range(be.n_blocks)], world)
+        final_owner = lambda k: owner[k]
+    else:
+        final_owner = parallel.PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world).final_owner
     res = {"status": status, "iterations": its, "corrections": np.array(corr)}
     for k in range(be.n_blocks):
         res[f"coords_{k}"] = be.blk[k]["rig"]          # every rank must hold the rigorous coordinates of every block
-        if sch.final_owner(k) == rank:
+        if final_owner(k) == rank:
             res[f"owned_var_{k}"] = be.blk[k]["rigvar"]
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,blocks", [(2, 5), (3, 6), (2, 2)])
-def test_distributed_schedule_matches_single_process(built, orc, tmp_path, world, blocks):
+@pytest.mark.parametrize("world,blocks,condensed", [(2, 5, True), (3, 6, True), (2, 2, True), (2, 5, False), (3, 6, False), (2, 2, False)])
+def test_distributed_schedule_matches_single_process(built, orc, tmp_path, world, blocks, condensed):
+    """both multi-rank schedules -- the condensed one (every block reduced to its shared stations, chains on the reduced
+    blocks, one rigorous solve per block; the default) and the reference's (forward chain || reverse chain, combination
+    solves spread) -- against the oracle's single-process phased adjustment"""
     from dynadjust_amd import adjust
     from dynadjust_amd.device import unpack_lower
     adjust.write_synthetic_network(str(tmp_path), "n", 12, 6, 0, blocks, seed=3 + blocks)
@@ -53,7 +60,7 @@ def test_distributed_schedule_matches_single_process(built, orc, tmp_path, world
     o = orc.Adjustment(net, True)
     o.prepare()
     ost = o.run()
-    mp.spawn(_worker, args=(world, _free_port(), base, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), base, str(tmp_path), condensed), nprocs=world, join=True)
     owned = set()
     for r in range(world):
         res = np.load(str(tmp_path / f"rank{r}.npz"))
@@ -82,3 +89,12 @@ def test_schedule_roles():
     assert s1.rev_rank == 0 and set(s1.combine_owner.values()) == {0}
     iso = PhasedSchedule([(True, True, True), (True, False, False), (False, True, False)], 2)
     assert iso.intermediate == [] and iso.final_owner(0) == 0 and iso.final_owner(1) == 1 and iso.final_owner(2) == 0
+
+
+def test_block_owners_balance():
+    from dynadjust_amd.parallel import block_owners
+    assert block_owners([1.0] * 16, 8) == [0, 1, 2, 3, 4, 5, 6, 7] * 2
+    assert block_owners([1.0] * 5, 1) == [0] * 5
+    o = block_owners([8.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], 2)
+    assert o[0] == 0 and o.count(1) == 8                       # the big block alone, the small ones together
+    assert block_owners([3.0, 2.0, 2.0], 4) == [0, 1, 2]
