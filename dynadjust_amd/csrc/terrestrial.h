@@ -36,10 +36,12 @@ struct StationGeo {
     double lat, lon, h, geoid, defl_v, defl_m;
 };
 
-TM_HD int station_count(char type) { return type == 'A' ? 3 : ((type == 'H' || type == 'R') ? 1 : 2); }
+TM_HD bool single_station(char type) { return type == 'H' || type == 'R' || type == 'I' || type == 'J' || type == 'P' || type == 'Q'; }
+TM_HD int station_count(char type) { return type == 'A' ? 3 : (single_station(type) ? 1 : 2); }
 TM_HD bool is_terrestrial(char type) {
     switch (type) {
-        case 'A': case 'B': case 'C': case 'E': case 'H': case 'K': case 'L': case 'M': case 'R': case 'S': case 'V': case 'Z': return true;
+        case 'A': case 'B': case 'C': case 'E': case 'H': case 'I': case 'J': case 'K': case 'L': case 'M': case 'P': case 'Q': case 'R': case 'S':
+        case 'V': case 'Z': return true;
         default: return false;
     }
 }
@@ -285,6 +287,29 @@ TM_HD double evaluate(char type, const double* X1, const double* X2, const doubl
             row[2] = (X1[2] + Zn1) / (nu1 + comp);
             break;
         }
+        case 'I': case 'P': {
+            // latitude has no closed form in X, Y, Z: forward differences with a 0.1 mm step (PartialD_Latitude_F / PartialD_Latitude,
+            // dnatemplategeodesyfuncs.hpp:282-320; UpdateDesignNormalMeasMatrices_IP, dnaadjust.cpp:5861)
+            double lon, h;
+            cart_to_geo(X1, &comp, &lon, &h);
+            for (int i = 0; i < 3; ++i) {
+                double Xi[3] = {X1[0], X1[1], X1[2]}, lat_i;
+                Xi[i] += 1.0e-4;
+                cart_to_geo(Xi, &lat_i, &lon, &h);
+                row[i] = (lat_i - comp) / 1.0e-4;
+            }
+            break;
+        }
+        case 'J': case 'Q': {
+            // the computed longitude is the station record's, the row  -+ xy / (x^2+y^2)^1.5 / cos|sin(longitude)
+            // (UpdateDesignNormalMeasMatrices_JQ, dnaadjust.cpp:5931)
+            comp = g1.lon;
+            const double p2 = X1[0] * X1[0] + X1[1] * X1[1];
+            const double t = X1[0] * X1[1] / pow(p2, 1.5);
+            row[0] = t * -1. / cos_long;
+            row[1] = t / sin_long;
+            break;
+        }
         default: break;
     }
     return comp;
@@ -302,7 +327,7 @@ TM_HD double meas_minus_comp(char type, double value, double comp) {
 
 // One-time reduction applied when the matrices are first built: returns preAdjCorr and the reduced term1 through
 // *value (deflection of the vertical: A dnaadjust.cpp:4790-4845, K :4940-4970, V :5523-5547, Z :5632-5656; geoid
-// separation: L :5746-5753, H :5977-5984)
+// separation: L :5746-5753, H :5977-5984; I :5797, J :5828)
 TM_HD double reduce(char type, double* value, const double* X1, const double* X2, const double* X3, const StationGeo& g1, const StationGeo& g2,
                     const StationGeo& g3, double ih, double th) {
     const bool defl = fabs(g1.defl_v) > E4_SEC_DEFLECTION || fabs(g1.defl_m) > E4_SEC_DEFLECTION;
@@ -346,6 +371,18 @@ TM_HD double reduce(char type, double* value, const double* X1, const double* X2
             if (fabs(g1.geoid) > 1.0e-4) {
                 corr = g1.geoid;
                 *value += corr;
+            }
+            break;
+        case 'I':   // astronomic -> geodetic latitude: deflection in the prime meridian (dnaadjust.cpp:5797-5804)
+            if (fabs(g1.defl_m) > E4_SEC_DEFLECTION) {
+                corr = g1.defl_m;
+                *value -= corr;
+            }
+            break;
+        case 'J':   // astronomic -> geodetic longitude: deflection in the prime vertical x sec(latitude) (dnaadjust.cpp:5828-5835)
+            if (fabs(g1.defl_v) > E4_SEC_DEFLECTION) {
+                corr = g1.defl_v / cos(g1.lat);
+                *value -= corr;
             }
             break;
         default: break;

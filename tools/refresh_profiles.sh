@@ -9,17 +9,17 @@ python $R/bench.py --steps 2 --warmup 1 2> $O/bench_cfg3.err | tail -1 > $O/r01_
 python $R/bench.py --workload cfg2 --steps 3 --warmup 1 2> $O/bench_cfg2.err | tail -1 > $O/r01_bench_cfg2.json
 CMD="python bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/kt.log 2>&1
-python $R/tools/rocprof_summary.py stats /tmp/kt $O/r01_cfg3_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- $CMD   (round 1, cfg3: 100 172 stations / 16 blocks, two chains, 1 x MI355X)"
+python $R/tools/rocprof_summary.py stats /tmp/kt $O/r01_cfg3_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- $CMD   (round 1, cfg3: 100 172 stations / 16 blocks, condensed schedule, two chains, 1 x MI355X)"
 DNAGPU_MULTI_THREAD=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/kt1.log 2>&1
 python $R/tools/rocprof_summary.py stats /tmp/kt1 $O/r01_cfg3_kernel_stats_one_chain.txt "DNAGPU_MULTI_THREAD=0 rocprofv3 --kernel-trace --stats -- $CMD   (round 1, cfg3, ONE chain: kernel durations without overlap)"
-tail -1 $O/kt1.log > $O/r01_bench_cfg3_one_chain.json
-tail -1 $O/kt.log > $O/r01_bench_cfg3_profiled_step.json
+grep '^{"metric"' $O/kt1.log | tail -1 > $O/r01_bench_cfg3_one_chain.json
+grep '^{"metric"' $O/kt.log | tail -1 > $O/r01_bench_cfg3_profiled_step.json
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   lc=$(echo $c | tr A-Z a-z)
   python $R/tools/rocprof_summary.py pmc /tmp/pmc_$c $O/r01_cfg3_pmc_$lc.txt "rocprofv3 --pmc $c --kernel-trace -- $CMD   (round 1, cfg3)"
 done
-python $R/tools/pmc_traffic_json.py $O/r01_cfg3_pmc_fetch_size.txt $O/r01_cfg3_pmc_write_size.txt $O/r01_hbm_traffic.json cfg3 > /dev/null
+(cd $O && python $R/tools/pmc_traffic_json.py r01_cfg3_pmc_fetch_size.txt r01_cfg3_pmc_write_size.txt r01_hbm_traffic.json cfg3 > /dev/null)
 { echo "# python tools/gpu_gemm_bench.py on 1 x MI355X (round 1): per-variant throughput of the fp64 tile GEMM, HIP-event timed, 3 launches each"
   echo "# fp64 MFMA peak 78.6 TFLOP/s; operands pseudo-random full-range mantissas"
   for v in dma4 dma8 reg4 reg8; do echo "== DNAGPU_GEMM_VARIANT=$v"; DNAGPU_GEMM_VARIANT=$v python $R/tools/gpu_gemm_bench.py 2>/dev/null; done; } > $O/r01_gemm_variants.txt
