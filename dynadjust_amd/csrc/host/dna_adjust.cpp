@@ -902,7 +902,7 @@ void dna_adjust::ComputeStatistics() {
                     case 'E': rec.measAdj = dnagpu::tm::ellipsoid_chord_to_arc(rec.measAdj, X1, X2, g1, g2); break;
                     case 'M': rec.measAdj = dnagpu::tm::ellipsoid_chord_to_msl_arc(rec.measAdj, g1, g2); break;
                     case 'H': case 'L': case 'V': rec.measAdj -= rec.preAdjCorr; break;
-                    case 'A': case 'K': case 'Z': rec.measAdj += rec.preAdjCorr; break;
+                    case 'A': case 'I': case 'J': case 'K': case 'Z': rec.measAdj += rec.preAdjCorr; break;
                     default: break;
                 }
                 cs += tb[t] * tb[t] / rec.term2;   // ComputeChiSquare_ABCEHIJKLMPQRSVZ (ADJ:8430)

@@ -669,10 +669,12 @@ static double ellipsoid_chord_to_msl_arc(double chord, double lat1, double lat2,
 static int tm_station_count(char type) {
     switch (type) {
         case 'A': return 3;
-        case 'H': case 'R': return 1;
+        case 'H': case 'R': case 'I': case 'J': case 'P': case 'Q': return 1;
         default: return 2;
     }
 }
+
+static void cart_to_geo(const double* X, double* lat, double* lon, double* h);
 
 /* computed measurement and design row at the cartesian coordinates X1..X3 with the current geodetic station data.
  * For E and M the ellipsoid chord equivalent of the supplied arc is (re)derived into a->t_val first (ADJ:5254, ADJ:5412). */
@@ -784,6 +786,31 @@ static void tm_evaluate(orc_adjustment* a, uint32_t t, const double* X1, const d
             row[2] = (X1[2] + Zn1) / (nu1 + *comp);
             break;
         }
+        case 'I': case 'P': {
+            /* UpdateDesignNormalMeasMatrices_IP (ADJ:5861): latitude of the estimates (CartToLat), row by "mechanical
+             * differentiation": (lat(x + 1e-4 on one element) - lat) / 1e-4 (dnatemplategeodesyfuncs.hpp:282-320) */
+            double lo, hh, lat0;
+            cart_to_geo(X1, &lat0, &lo, &hh);
+            for (int e = 0; e < 3; ++e) {
+                double Y[3] = {X1[0], X1[1], X1[2]}, la;
+                Y[e] += 1.0e-4;
+                cart_to_geo(Y, &la, &lo, &hh);
+                row[e] = (la - lat0) / 1.0e-4;
+            }
+            *comp = lat0;
+            break;
+        }
+        case 'J': case 'Q': {
+            /* UpdateDesignNormalMeasMatrices_JQ (ADJ:5931): computed = the station record's longitude;
+             * term = x y / (x^2 + y^2)^1.5, d/dX = -term / cos(lon), d/dY = term / sin(lon), d/dZ = 0 */
+            const double x = X1[0], y = X1[1];
+            const double term = x * y / pow(x * x + y * y, 1.5);
+            *comp = lon1;
+            row[0] = term * -1. / cos(lon1);
+            row[1] = term / sin(lon1);
+            row[2] = 0.0;
+            break;
+        }
         default: *comp = 0.0;
     }
     (void)X3;
@@ -841,6 +868,18 @@ static void tm_reduce(orc_adjustment* a, uint32_t t, const double* X1, const dou
             if (fabs(net->stn_geoid[g1]) > 1.0e-4) {
                 a->t_corr[t] = net->stn_geoid[g1];
                 a->t_val[t] += a->t_corr[t];
+            }
+            break;
+        case 'I':   /* ADJ:5797-5804: deflection in the prime meridian */
+            if (fabs(dM) > ORC_E4_SEC_DEFLECTION) {
+                a->t_corr[t] = dM;
+                a->t_val[t] -= a->t_corr[t];
+            }
+            break;
+        case 'J':   /* ADJ:5828-5835: deflection in the prime vertical times sec(latitude) */
+            if (fabs(dV) > ORC_E4_SEC_DEFLECTION) {
+                a->t_corr[t] = dV / cos(lat1);
+                a->t_val[t] -= a->t_corr[t];
             }
             break;
         default: break;
@@ -1636,7 +1675,7 @@ int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statisti
                         break;
                     }
                     case 'H': case 'L': case 'V': adj -= a->t_corr[t]; break;
-                    case 'A': case 'K': case 'Z': adj += a->t_corr[t]; break;
+                    case 'A': case 'I': case 'J': case 'K': case 'Z': adj += a->t_corr[t]; break;
                     default: break;
                 }
                 const double mp = net->t_var[t];

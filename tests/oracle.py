@@ -32,7 +32,7 @@ class OrcStatistics(C.Structure):
                 ("dof", C.c_int)]
 
 
-TERRESTRIAL_TYPES = b"ABCEHKLMRSVZ"
+TERRESTRIAL_TYPES = b"ABCEHIJKLMPQRSVZ"
 TMSR_FIELDS = ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel", "measPrec", "preAdjCorr")
 MSR_FIELDS = ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel", "measPrec")
 

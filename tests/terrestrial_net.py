@@ -1,4 +1,4 @@
-"""Test-side generator of small mixed networks: terrestrial measurements (A B K C E M S V Z L H R) over a station grid, a few
+"""Test-side generator of small mixed networks: terrestrial measurements (A B K C E M S V Z L H R I J P Q) over a station grid, a few
 GNSS baselines and a GNSS point cluster for the datum, written as .bst/.bms/.asl/.seg with a strip segmentation.
 
 The "truth" measurements are computed here with formulas written independently of the oracle and of the product
@@ -172,10 +172,24 @@ class Builder:
             c12 = (dM * math.sin(a12) - dV * math.cos(a12)) / math.tan(z12)
             c13 = (dM * math.sin(a13) - dV * math.cos(a13)) / math.tan(z13)
             v = ((a13 - a12) % (2 * math.pi)) + (c13 - c12)
+        elif t == "P":
+            sd = sd or 0.0004 * sec                 # ~ 12 mm on the ground
+            v = self.llh[s1][0]
+        elif t == "Q":
+            sd = sd or 0.0005 * sec
+            v = self.llh[s1][1]
+        elif t == "I":
+            # astronomic latitude = geodetic + meridian component of the deflection
+            sd = sd or 0.0004 * sec
+            v = self.llh[s1][0] + dM
+        elif t == "J":
+            # astronomic longitude = geodetic + prime-vertical component x sec(latitude)
+            sd = sd or 0.0005 * sec
+            v = self.llh[s1][1] + dV / math.cos(self.llh[s1][0])
         else:
             raise ValueError(t)
         v += sd * rng.standard_normal()
-        nstn = 3 if t == "A" else (1 if t in "HR" else 2)
+        nstn = 3 if t == "A" else (1 if t in "HRIJPQ" else 2)
         self.recs.append(self._rec(t, s1, s2 or 0, s3 or 0, v, sd * sd, ih, th, nstn))
         self.owner.append(min(x for x in (s1, s2, s3) if x is not None))
         for x in (s1, s2, s3):
@@ -305,7 +319,7 @@ def build_mixed_network(base, rows=6, cols=5, blocks=1, seed=1, types="SVZLHRBKA
                 b.add("A", s, nb[0], nb[1], ih=ih(), th=ih())
                 if len(nb) == 3:
                     b.add("A", s, nb[2], nb[0], ih=ih(), th=ih())
-            for ty in "HR":
+            for ty in "HRIJPQ":
                 if ty in types and rng.random() < 0.4:
                     b.add(ty, s)
     for r in range(rows - 1):

@@ -1,4 +1,4 @@
-"""Device path against the CPU oracle on mixed terrestrial + GNSS networks (types A B K C E M S V Z L H R):
+"""Device path against the CPU oracle on mixed terrestrial + GNSS networks (types A B K C E M S V Z L H R I J P Q):
 coordinates within 1e-8 m... of a NON-linear problem iterated by both sides with the same rules, variances within 1e-8
 relative, statistics, geodetic station records; one chain, two chains, phased and simultaneous."""
 import numpy as np
@@ -26,10 +26,11 @@ def _oracle_run(orc, base, phased):
     return net, o, o.run()
 
 
-def _compare(a, st, o, ost, tol_x=1e-8, tol_v=1e-8):
+def _compare(a, st, o, ost, tol_x=1e-8, tol_v=1e-8, row_noise=0.0):
     assert st == ost and a.CurrentIteration() == o.iterations()
     for i in range(o.iterations()):
-        assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < 1e-8
+        # (a correction computed through rows with relative noise e is off by up to e times its size)
+        assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < 1e-8 + row_noise * abs(o.max_correction(i + 1))
     for b in range(a.blockCount()):
         assert np.array_equal(a.block_stations(b), o.block_stations(b))
         assert np.abs(a.block_estimates(b) - o.block_estimates(b)).max() < tol_x
@@ -40,23 +41,29 @@ def _compare(a, st, o, ost, tol_x=1e-8, tol_v=1e-8):
 @pytest.mark.parametrize("rows,cols,blocks,phased,mt,types", [
     (5, 4, 1, False, False, "SL"),
     (5, 4, 1, False, False, "SVZLHRBKACEM"),
-    (6, 5, 3, True, False, "SVZLHRBKACEM"),
-    (8, 5, 4, True, True, "SVZLHRBKACEM"),
+    (6, 5, 3, True, False, "SVZLHRBKACEMIJPQ"),
+    (5, 5, 2, True, False, "SLIJPQ"),
+    (8, 5, 4, True, True, "SVZLHRBKACEMIJPQ"),
 ])
 def test_terrestrial_parity_with_oracle(built, orc, tmp_path, rows, cols, blocks, phased, mt, types):
     b, (bst, bms) = T.build_mixed_network(str(tmp_path / "t"), rows, cols, blocks, seed=rows + blocks, types=types)
     net, o, ost = _oracle_run(orc, str(tmp_path / "t"), phased)
     a, st = _device_run(str(tmp_path), "t", phased, multi_thread=mt)
     assert st == 0 and a.CurrentIteration() >= 2
-    _compare(a, st, o, ost)
+    # I / P: the reference's design row is a forward difference of the latitude over 0.1 mm (PartialD_Latitude,
+    # dnatemplategeodesyfuncs.hpp:282): two latitudes 1.5e-11 rad apart, each good to one ulp (1.1e-16), i.e. 1e-5 relative
+    # noise in the row that depends on the last bit of atan().  Device and host libm differ there, as two builds of the
+    # reference would: those networks agree to the row noise, the others to 1e-8
+    noisy = any(t in types for t in "IP")
+    _compare(a, st, o, ost, tol_x=1e-7 if noisy else 1e-8, tol_v=1e-5 if noisy else 1e-8, row_noise=1e-5 if noisy else 0.0)
     assert np.abs(a.adjusted_coordinates(len(bst)) - b.truth).max() < 0.03
     # statistics
     a.GenerateStatistics()
     so, fo = o.statistics()
     to = o.tmsr_fields()
     assert a.GetMeasurementCount() == so.measurement_params and a.GetDegreesOfFreedom() == so.dof
-    assert abs(a.GetChiSquared() - so.chi_squared) < 1e-7 * so.chi_squared
-    assert abs(a.GetGlobalPelzerRel() - so.global_pelzer) < 1e-6
+    assert abs(a.GetChiSquared() - so.chi_squared) < (1e-5 if noisy else 1e-7) * so.chi_squared
+    assert abs(a.GetGlobalPelzerRel() - so.global_pelzer) < (1e-4 if noisy else 1e-6)
     assert a.GetPotentialOutlierCount() == so.potential_outliers
     rec = np.frombuffer(a.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
     tr = rec[net.t_record]
@@ -64,11 +71,12 @@ def test_terrestrial_parity_with_oracle(built, orc, tmp_path, rows, cols, blocks
     assert np.abs(tr["measCorr"] - to["measCorr"]).max() < 2e-8
     assert np.abs(tr["measAdj"] - to["measAdj"]).max() < 2e-8
     assert np.abs(tr["preAdjCorr"] - to["preAdjCorr"]).max() < 1e-12
-    assert np.abs(tr["measAdjPrec"] - to["measAdjPrec"]).max() < 1e-7 * np.abs(to["measAdjPrec"]).max()
-    assert np.abs(tr["NStat"] - to["NStat"]).max() < 1e-4
+    ptol = 2e-5 if noisy else 1e-7
+    assert np.abs(tr["measAdjPrec"] - to["measAdjPrec"]).max() < ptol * np.abs(to["measAdjPrec"]).max()
+    assert np.abs(tr["NStat"] - to["NStat"]).max() < (1e-3 if noisy else 1e-4)
     for k in range(a.blockCount()):
         po = o.block_prec_adj_msrs(k)
-        assert np.abs(a.block_prec_adj_msrs(k) - po).max() < 1e-7 * np.abs(po).max()
+        assert np.abs(a.block_prec_adj_msrs(k) - po).max() < ptol * np.abs(po).max()
     a.close()
     o.close()
 

@@ -18,13 +18,13 @@ def _run(orc, base, phased, **kw):
 def test_design_rows_are_the_derivatives(orc, tmp_path):
     """every design row against central differences of the computed measurement (station geodetic data held fixed, as in
     the reference, where the bst latitude / longitude only change between iterations)"""
-    b, (bst, bms) = T.build_mixed_network(str(tmp_path / "d"), 4, 4, 1, seed=4)
+    b, (bst, bms) = T.build_mixed_network(str(tmp_path / "d"), 4, 4, 1, seed=4, types="SVZLHRBKACEMIJPQ")
     net, a, st = _run(orc, str(tmp_path / "d"), False, max_iterations=1)
     seen = set()
     for t in range(net.n_tmsr):
         ty = chr(net.t_type[t])
         stn = net.t_stn[3 * t:3 * t + 3]
-        ns = 3 if ty == "A" else (1 if ty in "HR" else 2)
+        ns = 3 if ty == "A" else (1 if ty in "HRIJPQ" else 2)
         X = np.zeros(9)
         for q in range(ns):
             X[3 * q:3 * q + 3] = b.init[stn[q]]
@@ -38,15 +38,24 @@ def test_design_rows_are_the_derivatives(orc, tmp_path):
             # C / E / M: the reference's row is -d/|d| of the chord between the points REDUCED to the ellipsoid and leaves
             # out the reduction factor nu/(nu+h) ~ 1 - 3e-5 (dnaadjust.cpp:5068-5071): an approximate Jacobian by design
             rel = 1e-4 if ty in "CEM" else 2e-8
+            if ty in "JQ":
+                # the computed longitude is the station RECORD's (constant in X, Y, Z; dnaadjust.cpp:5936): the row is the
+                # analytic d(longitude)/d(X, Y), checked against atan2 instead
+                lon = lambda x: np.arctan2(x[1], x[0])
+                num = (lon(xp) - lon(xm)) / (xp[i] - xm[i])
+                rel = 1e-6
+            if ty in "IP":
+                rel = 1e-6                          # the reference's row is itself a forward difference with a 0.1 mm step
             assert abs(num - row[i]) < rel * max(1.0, abs(row[i])) + 2e-10, (ty, i, num, row[i])
         assert np.all(row[3 * ns:] == 0.0)
         seen.add(ty)
-    assert seen == set("SVZLHRBKACEM")
+    assert seen == set("SVZLHRBKACEMIJPQ")
     a.close()
 
 
 @pytest.mark.parametrize("types,defl,geoid", [("SL", False, False), ("SLHR", False, True), ("SVZ", True, False), ("SLBKA", True, False),
-                                              ("CEMSL", False, True), ("SVZLHRBKACEM", True, True)])
+                                              ("CEMSL", False, True), ("SVZLHRBKACEM", True, True), ("SLPQ", False, False),
+                                              ("SLIJ", True, False), ("SVZLHRBKACEMIJPQ", True, True)])
 def test_adjustment_recovers_the_truth(orc, tmp_path, types, defl, geoid):
     b, _ = T.build_mixed_network(str(tmp_path / "n"), 5, 4, 1, seed=7, types=types, defl=defl, geoid=geoid)
     net, a, st = _run(orc, str(tmp_path / "n"), False)
