@@ -1012,45 +1012,73 @@ static void update_geographic(orc_adjustment* a, const blk_t* B, const double* e
     }
 }
 
-/* FormConstraintStationVarianceMatrix (ADJ:2041): CCC / FFF only */
-static int constraint_weight(const orc_adjustment* a, uint32_t stn, double* w) {
-    const char* c = a->net.constraints + 3 * (size_t)stn;
+/* FormConstraintStationVarianceMatrix (ADJ:2041-2137): the 3x3 weight matrix of a station's constraint.  CCC / FFF:
+ * 1/var on the diagonal.  Mixed codes: variances per axis of the LOCAL frame -- for geographic station records the first
+ * character is the latitude (north), the second the longitude (east); otherwise first = east / X, second = north / Y; third =
+ * up -- propagated to cartesian with the station's current latitude / longitude (unless the record is cartesian), then inverted. */
+static int constraint_matrix(const orc_adjustment* a, uint32_t stn, double W[3][3]) {
+    const orc_network* net = &a->net;
+    const char* c = net->constraints + 3 * (size_t)stn;
+    memset(W, 0, 9 * sizeof(double));
     if (c[0] == 'C' && c[1] == 'C' && c[2] == 'C') {
-        *w = 1. / a->var_C;
+        W[0][0] = W[1][1] = W[2][2] = 1. / a->var_C;
         return 0;
     }
     if (c[0] == 'F' && c[1] == 'F' && c[2] == 'F') {
-        *w = 1. / a->var_F;
+        W[0][0] = W[1][1] = W[2][2] = 1. / a->var_F;
         return 0;
     }
-    return -1;
+    if (!net->stn_type || !net->stn_llh) return -1;
+    const int type = net->stn_type[stn];          /* 0 XYZ, 1 LLh, 2 LLH, 3 UTM (dnatypes-structs.hpp) */
+    const int geographic = type == 1 || type == 2;
+    const double v0 = c[0] == 'F' ? a->var_F : a->var_C, v1 = c[1] == 'F' ? a->var_F : a->var_C, v2 = c[2] == 'F' ? a->var_F : a->var_C;
+    double vl[3];
+    vl[geographic ? 1 : 0] = v0;
+    vl[geographic ? 0 : 1] = v1;
+    vl[2] = v2;
+    double V[6];                                   /* packed lower, order 3 */
+    if (type == 0) {
+        V[0] = vl[0]; V[1] = 0; V[2] = 0; V[3] = vl[1]; V[4] = 0; V[5] = vl[2];
+    } else {
+        const double* g = a->geo ? a->geo + 3 * (size_t)stn : net->stn_llh + 3 * (size_t)stn;
+        const double sl = sin(g[0]), cl = cos(g[0]), so = sin(g[1]), co = cos(g[1]);
+        /* columns: east, north, up in cartesian components (PropagateVariances_LocalCart, local -> cart) */
+        const double R[3][3] = {{-so, -sl * co, cl * co}, {co, -sl * so, cl * so}, {0.0, cl, sl}};
+        for (int col = 0; col < 3; ++col)
+            for (int r = col; r < 3; ++r) {
+                double s = 0.0;
+                for (int k = 0; k < 3; ++k) s += R[r][k] * vl[k] * R[col][k];
+                V[orc_packed_index(3, r, col)] = s;
+            }
+    }
+    if (orc_inverse_normals_packed(V, 3, 0)) return -2;      /* FormInverseVarianceMatrix */
+    for (int col = 0; col < 3; ++col)
+        for (int r = col; r < 3; ++r) W[r][col] = W[col][r] = V[orc_packed_index(3, r, col)];
+    return 0;
 }
 
-/* blockadd / blocksubtract of the (diagonal) 3x3 constraint weight, packed dest */
-static void add_constraint(double* N, uint32_t n, uint32_t s, double w, double sign) {
+/* blockadd / blocksubtract of the 3x3 constraint weight, packed dest */
+static void add_constraint(double* N, uint32_t n, uint32_t s, double W[3][3], double sign) {
     for (int col = 0; col < 3; ++col)
-        for (int r = 0; r < 3; ++r) {
-            if (s + r < s + col) continue;
-            N[orc_packed_index(n, s + r, s + col)] += sign * (r == col ? w : 0.0);
-        }
+        for (int r = col; r < 3; ++r) N[orc_packed_index(n, s + r, s + col)] += sign * W[r][col];
 }
 
 /* AddConstraintStationstoNormals{Forward ADJ:1884, Reverse :1923, Combine :1960, Simultaneous :2010} */
 enum { CON_FWD, CON_REV, CON_CMB, CON_SIM };
 static int add_constraints(orc_adjustment* a, blk_t* B, int which) {
     for (uint32_t p = 0; p < B->n_stn; ++p) {
-        double w, sign = 1.0;
+        double W[3][3], sign = 1.0;
         if (which == CON_FWD && !B->first_fwd[p]) continue;
         if (which == CON_REV && !B->first_rev[p]) continue;
         if (which == CON_CMB) {
             if (B->first_fwd[p]) continue;
             sign = -1.0;
         }
-        if (constraint_weight(a, B->stations[p], &w)) {
-            snprintf(a->err, sizeof(a->err), "oracle: mixed station constraints are not restated (station %u)", B->stations[p]);
+        if (constraint_matrix(a, B->stations[p], W)) {
+            snprintf(a->err, sizeof(a->err), "oracle: the constraint of station %u needs the station type and position (stn_type, stn_llh)", B->stations[p]);
             return -1;
         }
-        add_constraint(B->N, B->n, 3 * p, w, sign);
+        add_constraint(B->N, B->n, 3 * p, W, sign);
     }
     return 0;
 }

@@ -67,7 +67,7 @@ int orc_weight_3x3(const double* v6, double* w6);
 typedef struct {
     uint32_t n_stations;
     const double* xyz0;        /* 3 per station: initial cartesian coordinates */
-    const char* constraints;   /* 3 chars per station, 'C' or 'F' (CCC / FFF supported) */
+    const char* constraints;   /* 3 chars per station, 'C' or 'F' (mixed codes need stn_type and stn_llh) */
     uint32_t n_baselines;
     const uint32_t* stn1;      /* global station index */
     const uint32_t* stn2;
@@ -103,6 +103,7 @@ typedef struct {
     const double* stn_llh;     /* 3 per station: currentLatitude, currentLongitude, currentHeight (station_t) */
     const double* stn_geoid;   /* geoidSep */
     const double* stn_defl;    /* 2 per station: verticalDef (deflection in the prime vertical), meridianDef */
+    const uint16_t* stn_type;  /* station_t::suppliedStationType (0 XYZ, 1 LLh, 2 LLH, 3 UTM): mixed constraint codes only; may be NULL */
 } orc_network;
 
 typedef struct {

@@ -18,7 +18,7 @@ class OrcNetwork(C.Structure):
                 ("isl_off", u32p), ("isl", u32p), ("jsl_off", u32p), ("jsl", u32p), ("cml_off", u32p), ("cml", u32p),
                 ("net_id", u32p), ("n_clusters", C.c_uint32), ("cluster_off", u32p), ("cluster_vcv", f64p),
                 ("n_tmsr", C.c_uint32), ("t_type", C.c_char_p), ("t_stn", u32p), ("t_value", f64p), ("t_var", f64p),
-                ("t_ih", f64p), ("t_th", f64p), ("stn_llh", f64p), ("stn_geoid", f64p), ("stn_defl", f64p)]
+                ("t_ih", f64p), ("t_th", f64p), ("stn_llh", f64p), ("stn_geoid", f64p), ("stn_defl", f64p), ("stn_type", C.POINTER(C.c_uint16))]
 
 
 class OrcSettings(C.Structure):
@@ -183,6 +183,7 @@ class Network:
         self.cluster_vcv = np.zeros(1)
         self._llh = np.stack([bst["currentLatitude"], bst["currentLongitude"], bst["currentHeight"]], axis=1).astype(np.float64)
         self._geoid = np.ascontiguousarray(bst["geoidSep"], dtype=np.float64)
+        self._supplied_type = np.ascontiguousarray(bst["suppliedStationType"], dtype=np.uint16)
         self._vdef = np.ascontiguousarray(bst["verticalDef"], dtype=np.float64)
         self._mdef = np.ascontiguousarray(bst["meridianDef"], dtype=np.float64)
         unit = lambda a: np.where(np.asarray(a) < 1e-6, 1.0, a)
@@ -235,7 +236,10 @@ class Network:
         while i < n:
             t = bytes(bms["measType"][i])
             if t[0] in TERRESTRIAL_TYPES:
-                assert bms["measStart"][i] == 0 and not bms["ignore"][i]
+                assert bms["measStart"][i] == 0
+                if bms["ignore"][i]:                  # an ignored measurement is in no block's measurement list
+                    i += 1
+                    continue
                 tm["type"].append(t)
                 tm["stn"].append([int(bms["station1"][i]), int(bms["station2"][i]), int(bms["station3"][i])])
                 tm["value"].append(float(bms["term1"][i]))
@@ -245,7 +249,11 @@ class Network:
                 tm["record"].append(i)
                 i += 1
                 continue
-            assert t in (b"G", b"X", b"Y") and bms["measStart"][i] == 0 and not bms["ignore"][i], t
+            assert t in (b"G", b"X", b"Y") and bms["measStart"][i] == 0, t
+            if bms["ignore"][i]:
+                for _ in range(1 if t == b"G" else int(bms["vectorCount1"][i])):
+                    i += 3 + (0 if t == b"G" else 3 * int(bms["vectorCount2"][i]))
+                continue
             self.bl_of_record[i] = len(off) - 1      # cml entries become cluster indices
             k = 1 if t == b"G" else int(bms["vectorCount1"][i])
             unit = lambda v: 1.0 if v < tiny else float(v)
@@ -356,9 +364,12 @@ class Network:
         n.cluster_off = _p(self.cluster_off, u32p)
         n.cluster_vcv = _p(self.cluster_vcv, f64p)
         n.n_tmsr = self.n_tmsr
+        self._llh_flat = np.ascontiguousarray(self._llh).ravel()
+        self._stn_type = np.ascontiguousarray(self._supplied_type, dtype=np.uint16)
+        n.stn_llh = _p(self._llh_flat, f64p)
+        n.stn_type = _p(self._stn_type, C.POINTER(C.c_uint16))
         if self.n_tmsr:
             self._defl = np.ascontiguousarray(np.stack([self._vdef, self._mdef], axis=1)).ravel()
-            self._llh_flat = np.ascontiguousarray(self._llh).ravel()
             n.t_type = self.t_type
             n.t_stn, n.t_value, n.t_var = _p(self.t_stn, u32p), _p(self.t_value, f64p), _p(self.t_var, f64p)
             n.t_ih, n.t_th = _p(self.t_ih, f64p), _p(self.t_th, f64p)

@@ -88,3 +88,58 @@ def test_reuse_inverses_is_ignored_for_non_gps_networks(built, tmp_path):
     B = a.blockCount()
     assert st == 0 and a.solve_count() == a.CurrentIteration() * (3 * B - 2)
     a.close()
+
+
+@pytest.mark.parametrize("phased,mt", [(False, False), (True, False), (True, True)])
+def test_reference_urban_sample_on_the_device(built, golden_dir, tmp_path, phased, mt):
+    """The reference's urban sample (248 angles, 427 slope distances, 287 zenith distances, levelling, azimuths, GNSS
+    baselines and an LLH point cluster, mixed station constraints, deflections, geoid) through the facade, the way the
+    published report was made: adjust, UpdateBinaryFiles, adjust again from the updated (reduced) files -- against
+    urban.phased.adj.expected: summary figures, all 149 adjusted positions with their standard deviations, and the full
+    adjusted-measurement table (1182 rows: adjusted value, correction, precision, N-stat, Pelzer, pre-adjustment correction)"""
+    from tests import urban_net as U
+    from tests.test_oracle_terrestrial import _check_urban_tables
+    from tests.dnatext import cart_to_geo
+    from dynadjust_amd.device import unpack_lower
+    base = str(tmp_path / "urban")
+    stations, msrs, rep, bst, bms, first_of = U.build_urban_sample(golden_dir, base, blocks=2)
+    for run in range(2):
+        a, st = _device_run(str(tmp_path), "urban", phased, multi_thread=mt)
+        assert st == 0
+        a.GenerateStatistics()
+        if run == 0:
+            a.UpdateBinaryFiles()
+            a.close()
+    assert a.GetMeasurementCount() == rep["measurements"] and a.GetUnknownsCount() == rep["unknowns"] and a.GetDegreesOfFreedom() == rep["dof"]
+    assert abs(a.GetChiSquared() - rep["chi2"]) < 0.2 and abs(a.GetSigmaZero() - rep["sigma0"]) < 8e-4
+    assert abs(a.GetGlobalPelzerRel() - rep["pelzer"]) < 6e-4 and a.GetPotentialOutlierCount() == rep["outliers"]
+    assert a.CurrentIteration() == 1                      # like the report: nothing moves any more
+    bs = [a.block_stations(k) for k in range(a.blockCount())]
+    be = [a.block_estimates(k) for k in range(a.blockCount())]
+    sd = []
+    for k in range(a.blockCount()):
+        V = unpack_lower(a.block_variances_packed(k), 3 * len(bs[k]))
+        out = np.zeros((len(bs[k]), 3))
+        for p in range(len(bs[k])):
+            lat, lon, _ = cart_to_geo(*be[k][3 * p:3 * p + 3])
+            R = np.array([[-np.sin(lon), np.cos(lon), 0.0],
+                          [-np.sin(lat) * np.cos(lon), -np.sin(lat) * np.sin(lon), np.cos(lat)],
+                          [np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)]])
+            out[p] = np.sqrt(np.diag(R @ V[3 * p:3 * p + 3, 3 * p:3 * p + 3] @ R.T))
+        sd.append(out)
+    rec = np.frombuffer(a.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
+    names = ("measAdj", "measCorr", "measAdjPrec", "NStat", "PelzerRel", "preAdjCorr")
+    t_record = [first_of[c] for c, m in enumerate(msrs) if m["type"] not in "GXY" and not m["ignore"]]
+    tf = {nm: rec[nm][t_record] for nm in names}
+    vec_of_record, rows3 = {}, []
+    for c, m in enumerate(msrs):
+        if m["type"] not in "GXY" or m["ignore"]:
+            continue
+        vec_of_record[first_of[c]] = len(rows3) // 3
+        q = first_of[c]
+        for j in range(len(m["vectors"])):
+            rows3 += [q, q + 1, q + 2]
+            q += 3 + 3 * int(rec["vectorCount2"][q]) * (m["type"] != "G")
+    gf = {nm: rec[nm][rows3] for nm in names}
+    _check_urban_tables(rep, stations, msrs, first_of, t_record, bs, be, sd, tf, gf, vec_of_record)
+    a.close()
