@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--reference-schedule", action="store_true",
                     help="every forward / reverse step inverts its block like the reference's Solve() (a.schur_carry = 0) instead of "
                          "eliminating the inner unknowns of the steps that are only carried on")
+    ap.add_argument("--no-keep-factors", action="store_true",
+                    help="condensed schedule without the retained factors (a.keep_factors = 0): every rigorous solve forms and inverts its block again")
     ap.add_argument("--no-gemm-events", action="store_true", help="diagnostic: no HIP events around the GEMM launches (roofline.achieved = 0)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
@@ -205,7 +207,7 @@ def main():
     a = adjust.DnaAdjust()
     p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode,
                                multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank,
-                               reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule)
+                               reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors)
     a.PrepareAdjustment(p)
     lib = a.lib
     ctx = a.device_context()
@@ -261,7 +263,8 @@ def main():
             "stations": stations, "baselines": info["baselines"], "measurement_rows": info["measurement_rows"], "blocks": blocks,
             "max_block_unknowns": info["max_block_unknowns"], "iterations_to_converge": iters, "solves_per_step": solves,
             "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses),
-            "schur_carry": bool(elims), "eliminations_per_step": elims, "parallelism": "1 GPU, one chain" if not p.multi_thread else
+            "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
+            "completions_per_step": a.completion_count(), "parallelism": "1 GPU, one chain" if not p.multi_thread else
             "1 GPU, two chains (the reference's --multi-thread schedule: forward || reverse passes on two streams, combination solves shared)",
         },
         "cholesky_tflops": (alg / 1e12) / (ms_per_step / 1e3),

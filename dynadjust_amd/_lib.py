@@ -33,7 +33,7 @@ class DnaAdjSettings(C.Structure):
                 ("adjust_mode", C.c_int), ("multi_thread", C.c_int), ("max_iterations", C.c_int),
                 ("iteration_threshold", C.c_float), ("free_std_dev", C.c_double), ("fixed_std_dev", C.c_double),
                 ("scale_normals_to_unity", C.c_int), ("device", C.c_int), ("confidence_interval", C.c_float),
-                ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int), ("schur_carry", C.c_int)]
+                ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int), ("schur_carry", C.c_int), ("keep_factors", C.c_int)]
 
 
 class DnaAdjStatistics(C.Structure):
@@ -127,7 +127,11 @@ def load():
     _sig(lib, "dnagpu_block_get_rhs", i, [vp, i, u32, c_f64p])
     _sig(lib, "dnagpu_junction_gather", i, [vp, i, u32, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_schur_carry", i, [vp, i, u32, vp, c_u32p, sz, vp])
-    _sig(lib, "dnagpu_block_reduce", i, [vp, i, u32, vp, c_u32p, sz, vp])
+    _sig(lib, "dnagpu_block_reduce", i, [vp, i, u32, vp, c_u32p, sz, vp, vp])
+    _sig(lib, "dnagpu_mem_info", i, [vp, C.POINTER(sz), C.POINTER(sz)])
+    _sig(lib, "dnagpu_partial_create", i, [vp, u32, u32, C.POINTER(vp)])
+    _sig(lib, "dnagpu_partial_destroy", None, [vp, vp])
+    _sig(lib, "dnagpu_partial_complete", i, [vp, i, vp, vp, vp])
     _sig(lib, "dnagpu_block_load_reduced", i, [vp, i, u32, u32, c_u32p, sz, vp, vp])
     _sig(lib, "dnagpu_junction_scatter", i, [vp, i, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_junction_rhs", i, [vp, i, u32, c_u32p, sz, vp])
@@ -156,6 +160,7 @@ def load():
     _sig(lib, "dnaadj_solve_flops", C.c_double, [vp])
     _sig(lib, "dnaadj_solve_count", u32, [vp])
     _sig(lib, "dnaadj_elimination_count", u32, [vp])
+    _sig(lib, "dnaadj_completion_count", u32, [vp])
     _sig(lib, "dnaadj_algorithmic_flops", C.c_double, [vp])
     _sig(lib, "dnaadj_station_count", u32, [vp])
     _sig(lib, "dnaadj_block_station_count", u32, [vp, u32])
@@ -222,7 +227,8 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
     "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
-    "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
+    "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_mem_info", "dnagpu_partial_create", "dnagpu_partial_destroy", "dnagpu_partial_complete",
+    "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
 ]
 
@@ -230,7 +236,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_default_settings", "dnaadj_create", "dnaadj_destroy", "dnaadj_last_error", "dnaadj_prepare", "dnaadj_adjust",
     "dnaadj_cancel", "dnaadj_reset", "dnaadj_block_count", "dnaadj_iterations", "dnaadj_max_correction", "dnaadj_iteration_correction",
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
-    "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
+    "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_completion_count", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
     "dnaadj_generate_statistics", "dnaadj_get_statistics", "dnaadj_measurement_record_count", "dnaadj_measurement_records",
     "dnaadj_block_prec_adj_msrs_count", "dnaadj_block_prec_adj_msrs", "dnaadj_serialise_adjusted_variance_matrices",

@@ -461,6 +461,35 @@ __global__ void schur_estimates_kernel(const double* __restrict__ xe, const uint
     jest[t] = xe[3 * idx[t / 3] + t % 3] + delta[t];
 }
 
+// dnagpu_partial_complete: the kept block (kk, npk x npk, both triangles) goes back behind the eliminated part: trailing
+// njp x njp block of the retained matrix, identity beyond the nj kept unknowns (the row that carried the rhs included)
+__global__ void partial_set_trailing_kernel(double* __restrict__ T, uint32_t ldt, uint32_t njp, const double* __restrict__ kk, uint32_t npk,
+                                            uint32_t nj) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (i >= njp) return;
+    T[(size_t)j * ldt + i] = (i < nj && j < nj) ? kk[(size_t)j * npk + i] : (i == j ? 1.0 : 0.0);
+}
+
+// inverse in the elimination's unknown order (F, ldf) -> natural order (inv, np; already identity padded)
+__global__ __launch_bounds__(256) void unpermute_kernel(const double* __restrict__ F, uint32_t ldf, const int32_t* __restrict__ map,
+                                                        double* __restrict__ inv, uint32_t np) {
+    const uint32_t i = blockIdx.x * 128 + (threadIdx.x & 127);
+    const int32_t mi = map[i];
+    for (uint32_t jl = threadIdx.x >> 7; jl < 128; jl += 2) {
+        const uint32_t j = blockIdx.y * 128 + jl;
+        const int32_t mj = map[j];
+        if (mi >= 0 && mj >= 0) inv[(size_t)mj * np + mi] = F[(size_t)j * ldf + i];
+    }
+}
+
+void launch_partial_set_trailing(double* T, uint32_t ldt, uint32_t njp, const double* kk, uint32_t npk, uint32_t nj, hipStream_t s) {
+    hipLaunchKernelGGL(partial_set_trailing_kernel, dim3((njp + 255) / 256, njp), dim3(256), 0, s, T, ldt, njp, kk, npk, nj);
+}
+void launch_unpermute(const double* F, uint32_t ldf, uint32_t npp, const int32_t* map, double* inv, uint32_t np, hipStream_t s) {
+    hipLaunchKernelGGL(unpermute_kernel, dim3(npp / 128, npp / 128), dim3(256), 0, s, F, ldf, map, inv, np);
+}
+
 void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, const double* rhs, double* dst, uint32_t ldd, uint32_t npp,
                           hipStream_t s) {
     hipLaunchKernelGGL(schur_permute_kernel, dim3(npp / 128, npp / 128), dim3(256), 0, s, src, lds, map, rhs, dst, ldd);

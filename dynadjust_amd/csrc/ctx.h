@@ -16,6 +16,17 @@ struct dnagpu_matrix {
     uint32_t n = 0, np = 0;  // current logical order / padded order
 };
 
+// State of a block between dnagpu_block_reduce(..., keep) and dnagpu_partial_complete: see include/dnagpu.h
+struct dnagpu_partial {
+    double* F = nullptr;     // (n_cap)^2: permuted normals -> factor pieces -> inverse in the elimination's order
+    double* X = nullptr;     // (n_cap)^2: L^-1
+    double* WK = nullptr;    // k_cap x n_cap: L_KI
+    int32_t* map = nullptr;  // n_cap: elimination order -> natural unknown (-1 padding, -2 the rhs row)
+    uint32_t n_cap = 0, k_cap = 0;               // capacities (padded orders)
+    uint32_t n = 0, nj = 0, nip = 0, njp = 0, npp = 0;
+    bool valid = false;
+};
+
 namespace dnagpu {
 
 struct Block {

@@ -220,6 +220,15 @@ void dnagpu_destroy(dnagpu_ctx* ctx) {
 const char* dnagpu_last_error(const dnagpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int dnagpu_last_info(const dnagpu_ctx* ctx) { return ctx ? ctx->last_info : 0; }
 
+int dnagpu_mem_info(dnagpu_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    CHK_CTX();
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return DNAGPU_OK;
+}
+
 int dnagpu_sync(dnagpu_ctx* ctx) {
     CHK_CTX();
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) HIPCHK(hipStreamSynchronize(ctx->stream[c]));
@@ -1106,7 +1115,7 @@ namespace {
 // T points at the trailing block inside the chain's W workspace: rows / columns 0..3k-1 hold the Schur complement (lower),
 // row 3k the reduced right-hand side; ldt its leading dimension.  m (the normals) is destroyed.
 int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, const double** T, uint32_t* ldt,
-                    int* slot_out) {
+                    int* slot_out, dnagpu_partial* keep = nullptr) {
     const uint32_t n = m->n, nj = (uint32_t)(3 * k), ni = n - nj;
     const uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1), npp = nip + njp;
     if ((size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur: matrix capacity");
@@ -1147,9 +1156,26 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
     gemm_profile_close(ws);
-    launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], ws.W, npp, npp, ctx->stream[chain]);
-    sym_schur_async(ws, ws.W, (int)npp, m->F, (int)npp, (int)(nip / 128), (int)(njp / 128));
-    *T = ws.W + (size_t)nip * npp + nip;
+    if (keep) {
+        if (npp > keep->n_cap || njp > keep->k_cap) return fail(ctx, DNAGPU_EINVAL, "schur: retained factor capacity");
+        hipStream_t st = ctx->stream[chain];
+        keep->valid = false;
+        keep->n = n; keep->nj = nj; keep->nip = nip; keep->njp = njp; keep->npp = npp;
+        launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], keep->F, npp, npp, st);
+        HIPCHK(hipMemcpyAsync(keep->map, map_dev, (size_t)npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        sym_schur_keep_async(ws, keep->F, keep->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+        if (nip)   // the panel L_KI (kept rows x eliminated columns) out of the chain's panel workspace
+            HIPCHK(hipMemcpy2DAsync(keep->WK, (size_t)njp * sizeof(double), ws.W + nip, (size_t)npp * sizeof(double), (size_t)njp * sizeof(double), nip,
+                                    hipMemcpyDeviceToDevice, st));
+        // the row that carried the right-hand side rode along as a passenger: it is no unknown, its panel entries go
+        if (nip) HIPCHK(hipMemset2DAsync(keep->WK + nj, (size_t)njp * sizeof(double), 0, sizeof(double), nip, st));
+        keep->valid = true;
+        *T = keep->F + (size_t)nip * npp + nip;
+    } else {
+        launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], ws.W, npp, npp, ctx->stream[chain]);
+        sym_schur_async(ws, ws.W, (int)npp, m->F, (int)npp, (int)(nip / 128), (int)(njp / 128));
+        *T = ws.W + (size_t)nip * npp + nip;
+    }
     *ldt = npp;
     *slot_out = slot;
     return DNAGPU_OK;
@@ -1185,7 +1211,63 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
     return check_info(ctx, chain);
 }
 
-int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red) {
+int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_partial** out) {
+    CHK_CTX();
+    if (!out || !k_max || k_max > n_max) return fail(ctx, DNAGPU_EINVAL, "partial_create: bad arguments");
+    *out = nullptr;
+    dnagpu_partial* p = new (std::nothrow) dnagpu_partial();
+    if (!p) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    p->k_cap = pad128(k_max + 1);
+    p->n_cap = pad128(n_max - k_max ? n_max - k_max : 1) + p->k_cap;
+    hipError_t e = hipMalloc(&p->F, (size_t)p->n_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->WK, (size_t)p->k_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
+    if (e != hipSuccess) {
+        dnagpu_partial_destroy(ctx, p);
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "retained factor allocation", e);
+    }
+    *out = p;
+    return DNAGPU_OK;
+}
+
+void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p) {
+    if (!p) return;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+    }
+    if (p->F) hipFree(p->F);
+    if (p->X) hipFree(p->X);
+    if (p->WK) hipFree(p->WK);
+    if (p->map) hipFree(p->map);
+    delete p;
+}
+
+int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk, dnagpu_matrix* inv) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!pf || !pf->valid || !kk || !inv || kk->n != pf->nj || pf->n > inv->n_max)
+        return fail(ctx, DNAGPU_EINVAL, "partial_complete: bad arguments");
+    int rc = ensure_ws(ctx, chain, pf->npp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    pf->valid = false;       // F is consumed
+    launch_partial_set_trailing(pf->F + (size_t)pf->nip * pf->npp + pf->nip, pf->npp, pf->njp, kk->F, kk->np, pf->nj, st);
+    sym_complete_async(ws, pf->F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128));
+    inv->n = pf->n;
+    inv->np = pad128(pf->n);
+    launch_init_padded(inv->F, inv->n, inv->np, st);
+    launch_unpermute(pf->F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info(ctx, chain);
+}
+
+int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red,
+                        dnagpu_partial* keep) {
     CHK_CTX();
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
@@ -1194,7 +1276,7 @@ int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
     const double* T = nullptr;
     uint32_t ldt = 0;
     int slot = 0;
-    int rc = schur_eliminate(ctx, chain, b, m, idx_keep, k, &T, &ldt, &slot);
+    int rc = schur_eliminate(ctx, chain, b, m, idx_keep, k, &T, &ldt, &slot, keep);
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
     hipStream_t st = ctx->stream[chain];

@@ -37,11 +37,14 @@ void dna_adjust::FreeDevice() {
         if (b.finv) dnagpu_matrix_destroy(ctx_, b.finv);
         if (b.rinv) dnagpu_matrix_destroy(ctx_, b.rinv);
         if (b.red) dnagpu_matrix_destroy(ctx_, b.red);
+        if (b.part) dnagpu_partial_destroy(ctx_, b.part);
+        b.part = nullptr;
         b.jfwd = b.jrev = b.rigvar = b.finv = b.rinv = b.red = nullptr;
     }
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
         if (work_[c]) dnagpu_matrix_destroy(ctx_, work_[c]);
-        work_[c] = nullptr;
+        if (kwork_[c]) dnagpu_matrix_destroy(ctx_, kwork_[c]);
+        work_[c] = kwork_[c] = nullptr;
     }
     dnagpu_destroy(ctx_);
     ctx_ = nullptr;
@@ -653,6 +656,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     solve_count_ = 0;
     elimination_count_ = 0;
     condense_count_ = 0;
+    completion_count_ = 0;
     algorithmic_flops_ = 0.0;
     const double t0 = now_ms();
     switch (projectSettings_.a.adjust_mode) {
@@ -815,6 +819,7 @@ void dna_adjust::ResetAdjustment() {
     solve_count_ = 0;
     elimination_count_ = 0;
     condense_count_ = 0;
+    completion_count_ = 0;
     algorithmic_flops_ = 0.0;
     cancel_.store(false);
     adjustStatus_ = ADJUST_SUCCESS;

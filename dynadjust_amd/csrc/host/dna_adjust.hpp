@@ -104,6 +104,7 @@ public:
     UINT32 solveCount() const { return solve_count_; }
     UINT32 eliminationCount() const { return elimination_count_; }
     UINT32 condenseCount() const { return condense_count_; }
+    UINT32 completionCount() const { return completion_count_; }
     double algorithmicFlops() const { return algorithmic_flops_; }
     dnagpu_ctx* deviceContext() const { return ctx_; }
 
@@ -133,7 +134,9 @@ private:
         std::vector<UINT32> keep;             // block-local indices of jslprev_here + jsl_here stations, ascending
         std::vector<UINT32> c_prev, c_next;   // jslprev_here / jsl_here as positions in keep (same order as those lists)
         constraint_list con_inner;            // constraints of the eliminated stations (first appearance in both directions)
-        constraint_list ccon_fwd, ccon_rev;   // con_fwd / con_rev of the kept stations, positions in keep
+        constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
+        dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
+        bool part_allowed = false, part_valid = false;
         dnagpu_matrix* red = nullptr;         // Schur complement onto keep + reduced right-hand side (dnagpu_block_reduce)
         std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_ (6 per GNSS vector, then 1 per terrestrial measurement)
         // terrestrial measurements of the block (CML order among themselves)
@@ -222,6 +225,8 @@ private:
     dnagpu_matrix* StepMatrix(int chain, UINT32 block, int kind);
     bool ReuseInverses() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
     bool SchurCarry() const { return projectSettings_.a.schur_carry != 0 && !ReuseInverses() && !projectSettings_.a.scale_normals_to_unity; }
+    // kind: 0 forward (last block), 1 reverse (first block), 2 combination
+    void CompleteFromPartial(int chain, UINT32 block, int kind, dnagpu_matrix* W);
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
     bool condensed_ok_ = false;
     std::atomic<bool> chain_failed_{false};
@@ -268,12 +273,14 @@ private:
     double solve_flops_ = 0.0;
     UINT32 solve_count_ = 0;
     double algorithmic_flops_ = 0.0;  // n^3 per inverse, the elimination's own count per dnagpu_schur_carry step
+    UINT32 completion_count_ = 0;    // rigorous solves that completed a kept factor (a.keep_factors)
     UINT32 condense_count_ = 0;      // dnagpu_block_reduce steps (condensed schedule)
     UINT32 elimination_count_ = 0;   // of those, steps done by dnagpu_schur_carry (a.schur_carry)
 
     std::mutex corr_mutex_, alloc_mutex_;   // multi-thread mode: maxCorr_/solve counters, lazy allocations
     dnagpu_ctx* ctx_ = nullptr;
     dnagpu_matrix* work_[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    dnagpu_matrix* kwork_[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};   // the kept block of a fused rigorous solve
     UINT32 max_unknowns_ = 0, max_junction_ = 0;
 };
 

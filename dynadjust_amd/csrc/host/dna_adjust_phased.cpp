@@ -63,7 +63,8 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
     const blockMeta_t& meta = v_blockMeta_[k];
     const bool carried_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
     const bool reuse = ReuseInverses() && B.has_finv;      // W already holds this step's inverse (earlier iteration)
-    if (!reuse) {
+    const bool fused = B.part_valid && (meta._blockLast && !meta._blockIsolated) && CondensedSchedule();
+    if (!reuse && !fused) {
         Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
         AddConstraints(c, W, B.con_fwd, +1, k);
         if (carried_in)
@@ -80,7 +81,8 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
         CarryByElimination(c, k, k, W, B.jsl_here, B.jfwd);
         return 0.0;
     }
-    if (reuse)
+    if (fused) CompleteFromPartial(c, k, 0, W);
+    if (reuse || fused)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else
         SolveTry(c, k, W);
@@ -114,9 +116,10 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
     const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
     const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
     const bool reuse = ReuseInverses() && B.has_rinv;
+    const bool fused = B.part_valid && meta._blockFirst && CondensedSchedule();
     // estimates back to the originals (ADJ:3157 for the last block, ADJ:3863 for the others)
     Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentReverse()");
-    if (!reuse) {
+    if (!reuse && !fused) {
         // normals = measurements + junctions carried in reverse + constraints (first appearance in reverse)
         Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
         if (rev_in)
@@ -131,7 +134,8 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
         CarryByElimination(c, k, k, W, B.jslprev_here, blocks_[k - 1].jrev);
         return 0.0;
     }
-    if (reuse)
+    if (fused) CompleteFromPartial(c, k, 1, W);
+    if (reuse || fused)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else
         SolveTry(c, k, W);
@@ -156,8 +160,9 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
     const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
     const bool reuse = ReuseInverses() && B.has_cinv;
+    const bool fused = B.part_valid && CondensedSchedule();
     Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentCombine()");
-    if (!reuse) {
+    if (!reuse && !fused) {
         // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed in the
         // same summation order, which gives the same bits
         Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
@@ -172,7 +177,8 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
     if (fwd_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
-    if (reuse)
+    if (fused) CompleteFromPartial(c, k, 2, W);
+    if (reuse || fused)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else
         SolveTry(c, k, W);
@@ -387,9 +393,12 @@ void dna_adjust::PrepareCondensedBlocks() {
                 dst->w9.insert(dst->w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
             }
         };
-        constraint_list inner_rev;
+        constraint_list inner_rev, inner_cmb;
+        B.ccon_cmb = constraint_list();
         split(B.con_fwd, B.ccon_fwd, &B.con_inner);
         split(B.con_rev, B.ccon_rev, &inner_rev);
+        split(B.con_cmb, B.ccon_cmb, &inner_cmb);
+        if (!inner_cmb.stn.empty()) return;     // (a station seen in an earlier block is shared, hence kept)
         // a station of one block only appears first in that block, whichever way the blocks are walked
         if (B.con_inner.stn != inner_rev.stn || B.con_inner.w9 != inner_rev.w9) return;
         if (B.con_inner.stn.size() + B.keep.size() != ns) return;
@@ -398,6 +407,29 @@ void dna_adjust::PrepareCondensedBlocks() {
         Check(dnagpu_matrix_create(ctx_, (UINT32)B.keep.size() * 3, &B.red), k, "PrepareAdjustment(): condensed block");
     }
     condensed_ok_ = true;
+    if (!projectSettings_.a.keep_factors || !SchurCarry()) return;
+    // a.keep_factors: which blocks may keep their factor (2 n^2 + 3 k n doubles each) without starving what is allocated
+    // later -- every block's rigorous variance matrix and the chains' workspaces (work matrix + X + W per chain)
+    size_t free_b = 0, total_b = 0, max_keep = 0;
+    Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
+    auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
+    double later = 8.0e9;
+    for (UINT32 k = 0; k < blockCount_; ++k) later += sq(3.0 * (double)v_parameterStationList_[k].size());
+    later += 3.0 * (projectSettings_.a.multi_thread ? 2.0 : 1.0) * sq((double)max_unknowns_);
+    double budget = (double)free_b - later;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        block_t& B = blocks_[k];
+        if (B.keep.empty()) continue;
+        const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size();
+        const double need = 2.0 * sq(n) + (nk + 256.0) * (n + 256.0) * 8.0;
+        if (need > budget) continue;
+        budget -= need;
+        B.part_allowed = true;
+        max_keep = std::max(max_keep, B.keep.size());
+    }
+    const int chains = projectSettings_.a.multi_thread ? 2 : 1;
+    if (max_keep)
+        for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &kwork_[c]), 0, "PrepareAdjustment(): kept-block work matrix");
 }
 
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
@@ -407,11 +439,56 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
     AddConstraints(c, W, B.con_inner, +1, k);
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
-    Check(dnagpu_block_reduce(ctx_, c, k, W, B.keep.data(), B.keep.size(), B.red), k, "Solve()");
+    if (B.part_allowed && !B.part) {
+        std::lock_guard<std::mutex> lk(alloc_mutex_);
+        if (dnagpu_partial_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, (UINT32)B.keep.size() * 3, &B.part) != DNAGPU_OK) {
+            B.part = nullptr;          // no room after all: this block inverts its normals in the rigorous step as before
+            B.part_allowed = false;
+        }
+    }
+    B.part_valid = false;
+    Check(dnagpu_block_reduce(ctx_, c, k, W, B.keep.data(), B.keep.size(), B.red, B.part), k, "Solve()");
+    B.part_valid = B.part != nullptr;
     const double nk = 3.0 * (double)B.keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
-    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    // a Cholesky factorisation of the eliminated part (plus its triangular inverse when the factor is kept), the panel under
+    // the kept rows, the complement's update
+    algorithmic_flops_ += (B.part ? 2.0 : 1.0) * ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
     condense_count_++;
+}
+
+// The rigorous solve of a block whose condensing step kept its factor (a.keep_factors): the kept block gets exactly what the
+// forward (kind 0) / reverse (1) / combination (2) solve adds to the shared stations, in the same order, and the retained
+// factor is completed to the inverse of the whole block -- W holds what SolveTry's dnagpu_invert would have left
+void dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W) {
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    const bool rev_in = !meta._blockLast && !B.c_next.empty();
+    const bool fwd_in = !meta._blockFirst && !B.c_prev.empty();
+    dnagpu_matrix* K = kwork_[c];
+    Check(dnagpu_block_load_reduced(ctx_, c, blockCount_ + k, k, B.keep.data(), B.keep.size(), B.red, K), k, "UpdateNormals()");
+    if (kind == 0) {
+        AddConstraints(c, K, B.ccon_fwd, +1, k);
+        if (fwd_in)
+            Check(dnagpu_junction_scatter(ctx_, c, K, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesForward()");
+    } else {
+        if (rev_in) Check(dnagpu_junction_scatter(ctx_, c, K, B.c_next.data(), B.c_next.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
+        AddConstraints(c, K, B.ccon_rev, +1, k);
+        if (kind == 2) {
+            if (fwd_in)
+                Check(dnagpu_junction_scatter(ctx_, c, K, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesCombine()");
+            AddConstraints(c, K, B.ccon_cmb, -1, k);
+        }
+    }
+    Check(dnagpu_partial_complete(ctx_, c, B.part, K, W), k, "Solve()");
+    B.part_valid = false;
+    const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    solve_flops_ += n * n * n;
+    solve_count_++;
+    // factor + invert the kept block, the two panel products of the kept rows, X^T X
+    algorithmic_flops_ += nk * nk * nk + nk * ni * ni + nk * nk * ni + n * n * n / 3.0;
+    completion_count_++;
 }
 
 // PhasedForwardBlock on the condensed block: same additions, same order

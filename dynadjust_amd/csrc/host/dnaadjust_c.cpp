@@ -46,6 +46,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->fixed_std_dev = 1.0e-6;
     s->confidence_interval = 95.0f;
     s->schur_carry = 1;
+    s->keep_factors = 1;
 }
 
 int dnaadj_create(dnaadj_handle** out) {
@@ -89,6 +90,7 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         p.o._adj_msr_tstat = (uint16_t)(s->output_tstat ? 1 : 0);
         p.a.reuse_inverses = (uint16_t)(s->reuse_inverses ? 1 : 0);
         p.a.schur_carry = (uint16_t)(s->schur_carry ? 1 : 0);
+        p.a.keep_factors = (uint16_t)(s->keep_factors ? 1 : 0);
         if (s->network_name) p.g.network_name = s->network_name;
         if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);
@@ -175,6 +177,7 @@ double dnaadj_adjust_time_ms(const dnaadj_handle* h) { return h && h->adj ? h->a
 double dnaadj_solve_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveFlops() : 0.0; }
 uint32_t dnaadj_solve_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveCount() : 0; }
 double dnaadj_algorithmic_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->algorithmicFlops() : 0.0; }
+uint32_t dnaadj_completion_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->completionCount() : 0; }
 uint32_t dnaadj_elimination_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->eliminationCount() : 0; }
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block) {

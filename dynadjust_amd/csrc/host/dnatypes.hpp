@@ -200,6 +200,9 @@ struct adjust_settings {
     // last forward and the first reverse step of a network) needs the junction stations' weight matrix and estimates, not
     // the block inverse: the inner unknowns are eliminated (dnagpu_schur_carry) instead of Solve()'s full inverse.
     UINT16 schur_carry = 1;
+    // with schur_carry: the condensing step of a block keeps its factor resident and the block's rigorous solve completes it
+    // (dnagpu_block_reduce(keep) + dnagpu_partial_complete) instead of forming and inverting the block's normals again
+    UINT16 keep_factors = 1;
     float iteration_threshold = 0.0005f;
     double free_std_dev = 10.0;
     double fixed_std_dev = 1.0e-6;   // PRECISION_1E6

@@ -56,6 +56,15 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
 // Resets ws.info; a non-positive pivot in the eliminated part is reported like dpotrf.  The caller copies ws.info back.
 void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj);
 
+// The same elimination with everything kept that a later completion to the full inverse needs (dnagpu_partial): the whole
+// leading part is factored AND inverted (F: T21 pieces, X: L_II^-1, both ld), the panel L_KI of the trailing rows is left in
+// ws.W (rows ti*128.., ld) for the caller to save, the trailing tiles of F become the Schur complement.  2/3 n_i^3 instead of
+// ~0.34 n_i^3 flops -- the completion then costs n^3/3 + O(n_i^2 n_k) instead of a new n^3 inverse.
+void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti, int tj);
+// F: trailing tj x tj tiles hold the (updated) kept block; X, F leading parts as sym_schur_keep_async left them; WK: the saved
+// panel L_KI (tj*128 x ti*128, ldwk).  On return F = inverse of the whole matrix, both triangles, in the elimination's order.
+void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj);
+
 // sum the event timings recorded so far (synchronises the stream)
 void gemm_profile_collect(InvWorkspace& ws);
 void gemm_profile_close(InvWorkspace& ws);   // ends the current run of gemm launches (call before enqueuing any other kernel)

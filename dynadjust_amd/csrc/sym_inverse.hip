@@ -259,6 +259,53 @@ double schur_split() {
     return v;
 }
 
+void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti, int tj) {
+    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);
+    const int key = (1 << 29) | (ti << 12) | tj;
+    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
+        Rec rec{ws, F, ld, X, ld, ws.W, ld, pass == 0};
+        if (ti > 0) rec.node(0, ti);
+        if (ti > 0 && tj > 0) rec.eliminate(0, ti, tj);
+    }
+    ws.planned.insert(key);
+    gemm_profile_close(ws);
+}
+
+void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj) {
+    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);
+    const int key = (1 << 28) | (ti << 12) | tj;
+    const int T = ti + tj;
+    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
+        Rec rec{ws, F, ld, X, ld, ws.W, ld, pass == 0};
+        rec.node(ti, tj);
+        GemmArgs a;
+        if (ti > 0) {
+            // T_KI = L_KI * X_II -> the kept rows of F;  X_KI = -X_KK * T_KI
+            a.A = WK; a.lda = ldwk;
+            a.B = rec.x(0, 0); a.ldb = ld;
+            a.C = rec.f(ti, 0); a.ldc = ld;
+            a.mt = tj; a.nt = ti; a.K = ti * 128;
+            a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
+            rec.gemm(ws, a, 0, 1);
+            a.A = rec.x(ti, ti); a.lda = ld;
+            a.B = rec.f(ti, 0); a.ldb = ld;
+            a.C = rec.x(ti, 0); a.ldc = ld;
+            a.mt = tj; a.nt = ti; a.K = tj * 128;
+            a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
+            rec.gemm(ws, a, 0, 1);
+        }
+        // inverse = X^T X, both triangles
+        a.A = X; a.lda = ld;
+        a.B = X; a.ldb = ld;
+        a.C = F; a.ldc = ld;
+        a.mt = T; a.nt = T; a.K = T * 128;
+        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
+        rec.gemm(ws, a, 1, 1);
+    }
+    ws.planned.insert(key);
+    gemm_profile_close(ws);
+}
+
 void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj) {
     hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);
     const int ldx = ti * 128;

@@ -225,6 +225,26 @@ class DeviceContext:
         self._chk(self.lib.dnagpu_schur_carry(self.h, chain, blk, m.h, p, ix.size, jm.h))
         jm.n = 3 * ix.size
 
+    def block_reduce(self, blk, m, idx_keep, red, keep=None, chain=0):
+        """red <- Schur complement of the other unknowns of m onto the listed stations + reduced rhs (dnagpu_block_reduce);
+        keep: handle from partial_create, retains the factor for partial_complete"""
+        ix, p = _u32(idx_keep)
+        self._chk(self.lib.dnagpu_block_reduce(self.h, chain, blk, m.h, p, ix.size, red.h, keep))
+        red.n = 3 * ix.size
+
+    def partial_create(self, n_max, k_max):
+        h = C.c_void_p()
+        self._chk(self.lib.dnagpu_partial_create(self.h, n_max, k_max, C.byref(h)))
+        return h
+
+    def partial_destroy(self, h):
+        self.lib.dnagpu_partial_destroy(self.h, h)
+
+    def partial_complete(self, pf, kk, inv, n, chain=0):
+        """inv (order n, natural unknown order) <- inverse of the block whose kept part is now kk"""
+        self._chk(self.lib.dnagpu_partial_complete(self.h, chain, pf, kk.h, inv.h))
+        inv.n = n
+
     def junction_scatter(self, dst, idx_to, jm, chain=0):
         ix, p = _u32(idx_to)
         self._chk(self.lib.dnagpu_junction_scatter(self.h, chain, dst.h, p, ix.size, jm.h))

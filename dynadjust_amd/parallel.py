@@ -348,7 +348,8 @@ def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank,
     import os
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank,
                                multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
-                               schur_carry=not getattr(args, "reference_schedule", False))
+                               schur_carry=not getattr(args, "reference_schedule", False),
+                               keep_factors=not getattr(args, "no_keep_factors", False))
     be = DeviceBlockBackend(p, dev)
     a = be.adj
     lib, ctx = a.lib, a.device_context()
@@ -422,7 +423,8 @@ def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"stations": stations, "blocks": be.n_blocks, "iterations_to_converge": its, "mode": "phased",
-                       "solves_per_step": solves, "schur_carry": condensed, "parallelism": par},
+                       "solves_per_step": solves, "schur_carry": condensed,
+                       "keep_factors": bool(a.completion_count()), "parallelism": par},
             "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
             "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
             "roofline": {

@@ -46,6 +46,10 @@ typedef struct {
                                   carried weights and estimates up to rounding, ~0.35 n^3 instead of n^3 flops).  0 = every step
                                   inverts its block like the reference's Solve().  Ignored with reuse_inverses or
                                   scale_normals_to_unity */
+    int keep_factors;          /* device path only (default 1; needs schur_carry): the condensing step keeps its factor in HBM (two
+                                  n x n matrices per block, as far as memory allows) and the rigorous solve of the block completes
+                                  it instead of inverting the block's normals again: ~1.0 instead of ~1.36 inverse-equivalents
+                                  per block and iteration, same results up to rounding */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
@@ -74,6 +78,7 @@ double dnaadj_adjust_time_ms(const dnaadj_handle* h);                  /* adjust
 double dnaadj_solve_flops(const dnaadj_handle* h);                     /* sum n^3 over Solve() calls */
 double dnaadj_algorithmic_flops(const dnaadj_handle* h);               /* n^3 per inverse; n_i^3/3 + n_i^2 n_j + n_i n_j^2 + n_j^3 per elimination step */
 uint32_t dnaadj_solve_count(const dnaadj_handle* h);
+uint32_t dnaadj_completion_count(const dnaadj_handle* h);              /* of those, rigorous solves that completed a kept factor (keep_factors) */
 uint32_t dnaadj_elimination_count(const dnaadj_handle* h);             /* of those, carry-only steps done by elimination (schur_carry) */
 uint32_t dnaadj_station_count(const dnaadj_handle* h);
 

@@ -63,6 +63,8 @@ void dnagpu_destroy(dnagpu_ctx* ctx);
 const char* dnagpu_last_error(const dnagpu_ctx* ctx);
 int dnagpu_last_info(const dnagpu_ctx* ctx);
 int dnagpu_device_count(void);
+/* free / total device memory in bytes (hipMemGetInfo) */
+int dnagpu_mem_info(dnagpu_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* wait for every stream of the ctx */
 int dnagpu_sync(dnagpu_ctx* ctx);
 
@@ -85,6 +87,7 @@ int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uin
  * A work matrix is an np x np (np = ceil(n/128)*128) column-major buffer that
  * holds N, then N^-1.  Each chain owns one; junction matrices get their own. */
 typedef struct dnagpu_matrix dnagpu_matrix;
+typedef struct dnagpu_partial dnagpu_partial;   /* a block between dnagpu_block_reduce(keep) and dnagpu_partial_complete */
 int dnagpu_matrix_create(dnagpu_ctx* ctx, uint32_t n_max, dnagpu_matrix** out);
 void dnagpu_matrix_destroy(dnagpu_ctx* ctx, dnagpu_matrix* m);
 /* logical order n (<= n_max) + zero fill + identity padding */
@@ -202,7 +205,17 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
  * with its neighbours as the list, this condenses the block to its junction stations ONCE per iteration, independently of
  * every other block; the forward and the reverse chain of dna_adjust::AdjustPhased then run on the condensed blocks
  * (a few thousand unknowns each) and produce the very junction weights and estimates the block-level chain would. */
-int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red);
+int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red,
+                        dnagpu_partial* keep /* may be NULL */);
+/* With `keep`, the elimination leaves everything a later completion needs in HBM -- the factor of the eliminated part, its
+ * inverse and the panel under the kept rows (2 n^2 + 3k n doubles) -- at 2/3 n_i^3 instead of ~0.34 n_i^3 flops.
+ * dnagpu_partial_complete then turns  [ N_II  . ; N_KI  kk ]  (kk: the kept block as the chains left it: reduced block +
+ * carried junction weights + constraints, order 3k, the list order of the reduce) into its full inverse `inv`, in the block's
+ * natural unknown order, for n^3/3 + O(n_i^2 k) flops -- instead of forming the block's normals again and inverting them
+ * (dna_adjust::Solve, n^3).  The retained state is consumed. */
+int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_partial** out);
+void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p);
+int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk, dnagpu_matrix* inv);
 /* Start a chain step on a condensed block: m <- red, rhs(rblk) <- red's vector, estimated(rblk) <- original(src_blk)[idx_keep].
  * rblk: a block created with k stations and no measurements. */
 int dnagpu_block_load_reduced(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k,

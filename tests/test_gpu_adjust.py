@@ -481,10 +481,12 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
     else:
         adjust.write_synthetic_network(str(tmp_path), "c", 16, 12, 0, blocks, seed=4, x_clusters=12, y_cluster=True, initial_sigma=0.3)
     runs = []
-    for schur in (False, True):
-        a, st = _device_run(str(tmp_path), "c", True, multi_thread=mt, schur_carry=schur)
+    for schur, keep in ((False, False), (True, False), (True, True)):
+        a, st = _device_run(str(tmp_path), "c", True, multi_thread=mt, schur_carry=schur, keep_factors=keep)
         assert st == 0
         a.GenerateStatistics()
+        # a.keep_factors: every block's rigorous solve completes the factor its condensing step kept
+        assert a.completion_count() == (a.CurrentIteration() * a.blockCount() if keep else 0)
         runs.append((a.CurrentIteration(), a.solve_count(), a.elimination_count(), [a.block_estimates(b) for b in range(a.blockCount())],
                      [a.block_variances_packed(b) for b in range(a.blockCount())], a.GetChiSquared(), a.GetMaxCorrection()))
         if schur:
@@ -494,11 +496,12 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
             _compare(a, st, o, o.run())
             o.close()
         a.close()
-    (it0, n0, e0, x0, v0, c0, mc0), (it1, n1, e1, x1, v1, c1, mc1) = runs
+    (it0, n0, e0, x0, v0, c0, mc0) = runs[0]
     B = len(x0)
-    assert B == blocks and it0 == it1 and n0 == n1 == it0 * (3 * B - 2)
-    assert e0 == 0 and e1 == it1 * 2 * (B - 1)
-    assert abs(c0 - c1) < 1e-7 * c0 and abs(mc0 - mc1) < 1e-9
-    for b in range(B):
-        assert np.abs(x0[b] - x1[b]).max() < 1e-8
-        assert np.abs(v0[b] - v1[b]).max() < 1e-8 * np.abs(v0[b]).max()
+    for (it1, n1, e1, x1, v1, c1, mc1) in runs[1:]:
+        assert B == blocks and it0 == it1 and n0 == n1 == it0 * (3 * B - 2)
+        assert e0 == 0 and e1 == it1 * 2 * (B - 1)
+        assert abs(c0 - c1) < 1e-7 * c0 and abs(mc0 - mc1) < 1e-9
+        for b in range(B):
+            assert np.abs(x0[b] - x1[b]).max() < 1e-8
+            assert np.abs(v0[b] - v1[b]).max() < 1e-8 * np.abs(v0[b]).max()

@@ -251,3 +251,57 @@ def test_schur_carry_reports_a_singular_block(gpu_ctx, built, orc, tmp_path):
     m.close()
     jm.close()
     gpu_ctx.block_destroy(0)
+
+
+@pytest.mark.parametrize("rows,cols,pick", [(9, 8, "jsl"), (40, 30, "jsl"), (40, 30, "scattered"), (43, 43, "one"), (12, 11, "all")])
+def test_reduce_keep_and_complete(gpu_ctx, built, orc, tmp_path, rows, cols, pick):
+    """dnagpu_block_reduce with a retained factor + dnagpu_partial_complete: the kept block is changed (what the junction
+    chains add) and the full inverse of the changed matrix comes back in natural order -- against numpy, and the reduced
+    system against the plain reduce"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, 2, seed=rows)
+    net = orc.Network(str(tmp_path / "s"), True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    st0, cml0, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    ns = len(st0)
+    n0 = 3 * ns
+    loc0 = {int(s): i for i, s in enumerate(st0)}
+    stn = {"jsl": [loc0[int(s)] for s in net.jsl[net.jsl_off[0]:net.jsl_off[1]]], "scattered": list(range(1, ns, 7))[::-1],
+           "one": [ns // 2], "all": list(range(ns))}[pick]
+    idx = np.array(stn, dtype=np.uint32)
+    rws = (3 * idx[:, None] + np.arange(3)).ravel()
+    N0 = unpack_lower(a.block_normals(0), n0)
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    m = gpu_ctx.matrix(n0)
+    red0, red1 = gpu_ctx.matrix(3 * len(idx)), gpu_ctx.matrix(3 * len(idx))
+    m.upload_packed(a.block_normals(0), n0)
+    gpu_ctx.block_reduce(0, m, idx, red0)
+    pf = gpu_ctx.partial_create(n0, 3 * len(idx))
+    m.upload_packed(a.block_normals(0), n0)
+    gpu_ctx.block_reduce(0, m, idx, red1, keep=pf)
+    S0 = unpack_lower(red0.download_packed(), 3 * len(idx))
+    S1 = unpack_lower(red1.download_packed(), 3 * len(idx))
+    assert np.abs(S0 - S1).max() < 1e-10 * np.abs(S0).max()
+    assert np.abs(gpu_ctx.junction_get_estimates(red0) - gpu_ctx.junction_get_estimates(red1)).max() < 1e-9 * max(1.0, np.abs(gpu_ctx.junction_get_estimates(red0)).max())
+    # what the chains do to the kept block: a symmetric positive update
+    rng = np.random.default_rng(rows)
+    G = rng.standard_normal((3 * len(idx), 3 * len(idx)))
+    D = G @ G.T * np.abs(np.diag(S1)).mean() * 0.1
+    kk = gpu_ctx.matrix(3 * len(idx))
+    kk.upload_packed(pack_lower(S1 + D), 3 * len(idx))
+    inv = gpu_ctx.matrix(n0)
+    gpu_ctx.partial_complete(pf, kk, inv, n0)
+    got = unpack_lower(inv.download_packed(), n0)
+    M = N0.copy()
+    M[np.ix_(rws, rws)] += D
+    ref = np.linalg.inv(M)
+    assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    # the retained state is consumed
+    with pytest.raises(Exception):
+        gpu_ctx.partial_complete(pf, kk, inv, n0)
+    gpu_ctx.partial_destroy(pf)
+    for q in (m, red0, red1, kk, inv):
+        q.close()
+    gpu_ctx.block_destroy(0)
