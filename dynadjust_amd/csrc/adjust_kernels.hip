@@ -461,6 +461,55 @@ __global__ void schur_estimates_kernel(const double* __restrict__ xe, const uint
     jest[t] = xe[3 * idx[t / 3] + t % 3] + delta[t];
 }
 
+// dnagpu_partial_reduce_rhs: right-hand side in the elimination's order
+__global__ void gather_map_kernel(const double* __restrict__ rhs, const int32_t* __restrict__ map, uint32_t npp, double* __restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npp) return;
+    const int32_t m = map[p];
+    out[p] = m >= 0 ? rhs[m] : 0.0;
+}
+// part[c][i] = sum over the columns j of chunk c (j <= i only when `lower`) of A(i, j) x(j), i < rows; deterministic like symv
+__global__ __launch_bounds__(256) void gemv_partial_kernel(const double* __restrict__ A, uint32_t lda, uint32_t rows, uint32_t cols,
+                                                           const double* __restrict__ x, double* __restrict__ part, uint32_t cols_per_chunk,
+                                                           int lower) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    if (i >= rows) return;
+    uint32_t j0 = c * cols_per_chunk, j1 = j0 + cols_per_chunk;
+    if (j1 > cols) j1 = cols;
+    if (lower && j1 > i + 1) j1 = i + 1;
+    double a0 = 0.0, a1 = 0.0;
+    uint32_t j = j0;
+    for (; j + 2 <= j1; j += 2) {
+        a0 += A[(size_t)j * lda + i] * x[j];
+        a1 += A[(size_t)(j + 1) * lda + i] * x[j + 1];
+    }
+    if (j < j1) a0 += A[(size_t)j * lda + i] * x[j];
+    part[(size_t)c * rows + i] = a0 + a1;
+}
+// out[i] = (base ? base[i] : 0) + sign * sum_c part[c][i], i < n_out (part rows = rows)
+__global__ void gemv_finish_kernel(const double* __restrict__ part, uint32_t rows, uint32_t nchunks, const double* __restrict__ base, double sign,
+                                   double* __restrict__ out, uint32_t n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    double s = 0.0;
+    for (uint32_t c = 0; c < nchunks; ++c) s += part[(size_t)c * rows + i];
+    out[i] = (base ? base[i] : 0.0) + sign * s;
+}
+void launch_gather_map(const double* rhs, const int32_t* map, uint32_t npp, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(gather_map_kernel, dim3((npp + 255) / 256), dim3(256), 0, s, rhs, map, npp, out);
+}
+void launch_gemv(const double* A, uint32_t lda, uint32_t rows, uint32_t cols, const double* x, double* part, uint32_t nchunks, int lower,
+                 const double* base, double sign, double* out, uint32_t n_out, hipStream_t s) {
+    if (!rows || !cols) {
+        hipLaunchKernelGGL(gemv_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, part, rows, 0u, base, sign, out, n_out);
+        return;
+    }
+    const uint32_t cpc = (cols + nchunks - 1) / nchunks;
+    hipLaunchKernelGGL(gemv_partial_kernel, dim3((rows + 255) / 256, nchunks), dim3(256), 0, s, A, lda, rows, cols, x, part, cpc, lower);
+    hipLaunchKernelGGL(gemv_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, part, rows, nchunks, base, sign, out, n_out);
+}
+
 // dnagpu_partial_complete: the kept block (kk, npk x npk, both triangles) goes back behind the eliminated part: trailing
 // njp x njp block of the retained matrix, identity beyond the nj kept unknowns (the row that carried the rhs included)
 __global__ void partial_set_trailing_kernel(double* __restrict__ T, uint32_t ldt, uint32_t njp, const double* __restrict__ kk, uint32_t npk,

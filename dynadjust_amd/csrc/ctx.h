@@ -24,7 +24,8 @@ struct dnagpu_partial {
     int32_t* map = nullptr;  // n_cap: elimination order -> natural unknown (-1 padding, -2 the rhs row)
     uint32_t n_cap = 0, k_cap = 0;               // capacities (padded orders)
     uint32_t n = 0, nj = 0, nip = 0, njp = 0, npp = 0;
-    bool valid = false;
+    bool valid = false;      // reduce done, completion pending (F live)
+    bool completed = false;  // completion done: X (the eliminated part's inverse factor) and WK still describe the block
 };
 
 namespace dnagpu {

@@ -1160,6 +1160,7 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
         if (npp > keep->n_cap || njp > keep->k_cap) return fail(ctx, DNAGPU_EINVAL, "schur: retained factor capacity");
         hipStream_t st = ctx->stream[chain];
         keep->valid = false;
+        keep->completed = false;
         keep->n = n; keep->nj = nj; keep->nip = nip; keep->njp = njp; keep->npp = npp;
         launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], keep->F, npp, npp, st);
         HIPCHK(hipMemcpyAsync(keep->map, map_dev, (size_t)npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -1255,6 +1256,7 @@ int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, cons
     hipStream_t st = ctx->stream[chain];
     gemm_profile_close(ws);
     pf->valid = false;       // F is consumed
+    pf->completed = true;
     launch_partial_set_trailing(pf->F + (size_t)pf->nip * pf->npp + pf->nip, pf->npp, pf->njp, kk->F, kk->np, pf->nj, st);
     sym_complete_async(ws, pf->F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128));
     inv->n = pf->n;
@@ -1264,6 +1266,27 @@ int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, cons
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
+}
+
+int dnagpu_partial_reduce_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_partial* pf, dnagpu_matrix* red) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !pf || !pf->completed || !red || red->n != pf->nj || 3 * b->n_stn != pf->n)
+        return fail(ctx, DNAGPU_EINVAL, "partial_reduce_rhs: bad arguments");
+    int rc = ensure_ws(ctx, chain, pf->npp);
+    if (!rc) rc = ensure_symv(ctx, chain, pf->npp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    double* rp = ws.svec;                 // rhs in the elimination's order
+    double* y = b->corr[chain];           // L_II^-1 rhs_I (n_i <= 3 n_stn values)
+    launch_gather_map(b->rhs[chain], pf->map, pf->npp, rp, st);
+    const uint32_t ni = pf->n - pf->nj;
+    launch_gemv(pf->X, pf->npp, ni, ni, rp, ctx->symv_part[chain], SYMV_CHUNKS, 1, nullptr, 1.0, y, ni, st);
+    launch_gemv(pf->WK, pf->njp, pf->njp, ni, y, ctx->symv_part[chain], SYMV_CHUNKS, 0, rp + pf->nip, -1.0, red->jest, pf->nj, st);
+    return DNAGPU_OK;
 }
 
 int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red,

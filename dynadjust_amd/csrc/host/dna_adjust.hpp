@@ -137,6 +137,7 @@ private:
         constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
         bool part_allowed = false, part_valid = false;
+        bool inverse_kept = false;            // CondensedReuse(): rigvar holds this adjustment's inverse, part its factor
         dnagpu_matrix* red = nullptr;         // Schur complement onto keep + reduced right-hand side (dnagpu_block_reduce)
         std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_ (6 per GNSS vector, then 1 per terrestrial measurement)
         // terrestrial measurements of the block (CML order among themselves)
@@ -223,8 +224,15 @@ private:
     // the matrix a block step forms its normals in: the chain's work matrix, or with a.reuse_inverses the block's own
     // resident matrix for that step (kind 0 forward, 1 reverse, 2 combination / rigorous)
     dnagpu_matrix* StepMatrix(int chain, UINT32 block, int kind);
-    bool ReuseInverses() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
-    bool SchurCarry() const { return projectSettings_.a.schur_carry != 0 && !ReuseInverses() && !projectSettings_.a.scale_normals_to_unity; }
+    // a.reuse_inverses asks for the inverses of iteration 1 to be reused (GNSS-only networks: nothing but the right-hand sides
+    // changes).  With the condensed schedule and kept factors that is CondensedReuse(): later iterations only reduce right-hand
+    // sides, run the chains on the condensed blocks and multiply by the resident rigorous variances.  Otherwise ReuseInverses():
+    // the reference's schedule with one resident inverse per block step.
+    bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
+    bool CondensedWanted() const { return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity; }
+    bool ReuseInverses() const { return ReuseRequested() && !(CondensedWanted() && projectSettings_.a.keep_factors != 0); }
+    bool SchurCarry() const { return CondensedWanted() && !ReuseInverses(); }
+    bool CondensedReuse() const { return ReuseRequested() && CondensedSchedule() && projectSettings_.a.keep_factors != 0; }
     // kind: 0 forward (last block), 1 reverse (first block), 2 combination
     void CompleteFromPartial(int chain, UINT32 block, int kind, dnagpu_matrix* W);
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);

@@ -27,6 +27,7 @@ void dna_adjust::PhasedNoteCorrection(double mv) {
 // of a last / isolated block and the reverse inverse of a first block ARE that block's rigorous variances and share
 // their matrix with them.
 dnagpu_matrix* dna_adjust::StepMatrix(int c, UINT32 k, int kind) {
+    if (CondensedReuse() && blocks_[k].inverse_kept) return blocks_[k].rigvar;     // the rigorous solve multiplies by it again
     if (!ReuseInverses()) return work_[c];
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
@@ -62,8 +63,8 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
     const bool carried_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
-    const bool reuse = ReuseInverses() && B.has_finv;      // W already holds this step's inverse (earlier iteration)
-    const bool fused = B.part_valid && (meta._blockLast && !meta._blockIsolated) && CondensedSchedule();
+    const bool reuse = (ReuseInverses() && B.has_finv) || (CondensedReuse() && B.inverse_kept);   // W already holds this step's inverse (earlier iteration)
+    const bool fused = !reuse && B.part_valid && (meta._blockLast && !meta._blockIsolated) && CondensedSchedule();
     if (!reuse && !fused) {
         Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
         AddConstraints(c, W, B.con_fwd, +1, k);
@@ -115,8 +116,8 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
     dnagpu_matrix* W = StepMatrix(c, k, 1);
     const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
     const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
-    const bool reuse = ReuseInverses() && B.has_rinv;
-    const bool fused = B.part_valid && meta._blockFirst && CondensedSchedule();
+    const bool reuse = (ReuseInverses() && B.has_rinv) || (CondensedReuse() && B.inverse_kept && meta._blockFirst);
+    const bool fused = !reuse && B.part_valid && meta._blockFirst && CondensedSchedule();
     // estimates back to the originals (ADJ:3157 for the last block, ADJ:3863 for the others)
     Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentReverse()");
     if (!reuse && !fused) {
@@ -159,8 +160,8 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     const blockMeta_t& meta = v_blockMeta_[k];
     const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
     const bool fwd_in = !meta._blockFirst && !B.jslprev_here.empty();
-    const bool reuse = ReuseInverses() && B.has_cinv;
-    const bool fused = B.part_valid && CondensedSchedule();
+    const bool reuse = (ReuseInverses() && B.has_cinv) || (CondensedReuse() && B.inverse_kept);
+    const bool fused = !reuse && B.part_valid && CondensedSchedule();
     Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentCombine()");
     if (!reuse && !fused) {
         // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed in the
@@ -435,6 +436,12 @@ void dna_adjust::PrepareCondensedBlocks() {
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
     if (B.keep.empty()) return;
+    if (CondensedReuse() && B.inverse_kept) {
+        // same normals as in the iteration that kept the factor: only the right-hand side is reduced again
+        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+        Check(dnagpu_partial_reduce_rhs(ctx_, c, k, B.part, B.red), k, "Solve()");
+        return;
+    }
     dnagpu_matrix* W = work_[c];
     Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
     AddConstraints(c, W, B.con_inner, +1, k);
@@ -482,6 +489,7 @@ void dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W
     }
     Check(dnagpu_partial_complete(ctx_, c, B.part, K, W), k, "Solve()");
     B.part_valid = false;
+    B.inverse_kept = CondensedReuse();     // (W is copied to / is the block's rigorous variance matrix by the caller)
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
     solve_flops_ += n * n * n;

@@ -216,6 +216,11 @@ int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
 int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_partial** out);
 void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p);
 int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk, dnagpu_matrix* inv);
+/* After a completion the factor of the eliminated part is still there.  When the block's normals do not change between
+ * iterations (GNSS-only network), the reduced right-hand side of the next iteration is  rhs_K - L_KI (L_II^-1 rhs_I) : two
+ * matrix-vector products with the kept X = L_II^-1 and the kept panel instead of a new elimination.  red's vector <- that; red's
+ * matrix (the Schur complement) is left as it is. */
+int dnagpu_partial_reduce_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_partial* pf, dnagpu_matrix* red);
 /* Start a chain step on a condensed block: m <- red, rhs(rblk) <- red's vector, estimated(rblk) <- original(src_blk)[idx_keep].
  * rblk: a block created with k stations and no measurements. */
 int dnagpu_block_load_reduced(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k,

@@ -12,7 +12,9 @@ timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o p --output-format csv
 python $R/tools/rocprof_summary.py stats /tmp/kt $O/r01_cfg3_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- $CMD   (round 1, cfg3: 100 172 stations / 16 blocks, condensed schedule, two chains, 1 x MI355X)"
 DNAGPU_MULTI_THREAD=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/kt1.log 2>&1
 python $R/tools/rocprof_summary.py stats /tmp/kt1 $O/r01_cfg3_kernel_stats_one_chain.txt "DNAGPU_MULTI_THREAD=0 rocprofv3 --kernel-trace --stats -- $CMD   (round 1, cfg3, ONE chain: kernel durations without overlap)"
-grep '^{"metric"' $O/kt1.log | tail -1 > $O/r01_bench_cfg3_one_chain.json
+DNAGPU_MULTI_THREAD=0 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r01_bench_cfg3_one_chain.json   # (the profiled run above has no warm-up: first-touch allocations inside)
+python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --reuse-inverses 2>/dev/null | tail -1 > $O/r01_bench_cfg3_reuse_inverses.json
+python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --reference-schedule 2>/dev/null | tail -1 > $O/r01_bench_cfg3_reference_schedule.json
 grep '^{"metric"' $O/kt.log | tail -1 > $O/r01_bench_cfg3_profiled_step.json
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1
