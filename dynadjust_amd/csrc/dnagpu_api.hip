@@ -1286,6 +1286,7 @@ int dnagpu_partial_reduce_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const dn
     const uint32_t ni = pf->n - pf->nj;
     launch_gemv(pf->X, pf->npp, ni, ni, rp, ctx->symv_part[chain], SYMV_CHUNKS, 1, nullptr, 1.0, y, ni, st);
     launch_gemv(pf->WK, pf->njp, pf->njp, ni, y, ctx->symv_part[chain], SYMV_CHUNKS, 0, rp + pf->nip, -1.0, red->jest, pf->nj, st);
+    HIPCHK(hipStreamSynchronize(st));     // red is read next by whichever chain runs the condensed block
     return DNAGPU_OK;
 }
 

@@ -137,6 +137,7 @@ private:
         constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
         bool part_allowed = false, part_valid = false;
+        bool inverse_pending = false;
         bool inverse_kept = false;            // CondensedReuse(): rigvar holds this adjustment's inverse, part its factor
         dnagpu_matrix* red = nullptr;         // Schur complement onto keep + reduced right-hand side (dnagpu_block_reduce)
         std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_ (6 per GNSS vector, then 1 per terrestrial measurement)

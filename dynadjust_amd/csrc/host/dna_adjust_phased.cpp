@@ -201,6 +201,10 @@ void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
         Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesFinal()");
     }
     B.has_rigvar = true;
+    if (B.inverse_pending) {
+        B.inverse_pending = false;
+        B.inverse_kept = true;
+    }
 }
 
 // UpdateEstimatesFinal (ADJ:3744) for a block that is not the last of its network
@@ -489,7 +493,7 @@ void dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W
     }
     Check(dnagpu_partial_complete(ctx_, c, B.part, K, W), k, "Solve()");
     B.part_valid = false;
-    B.inverse_kept = CondensedReuse();     // (W is copied to / is the block's rigorous variance matrix by the caller)
+    B.inverse_pending = CondensedReuse();  // kept once StoreRigorousVariances has copied W into the block's own matrix
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
     solve_flops_ += n * n * n;

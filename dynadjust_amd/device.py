@@ -245,6 +245,10 @@ class DeviceContext:
         self._chk(self.lib.dnagpu_partial_complete(self.h, chain, pf, kk.h, inv.h))
         inv.n = n
 
+    def partial_reduce_rhs(self, blk, pf, red, chain=0):
+        self._chk(self.lib.dnagpu_partial_reduce_rhs(self.h, chain, blk, pf, red.h))
+        self.sync()
+
     def junction_scatter(self, dst, idx_to, jm, chain=0):
         ix, p = _u32(idx_to)
         self._chk(self.lib.dnagpu_junction_scatter(self.h, chain, dst.h, p, ix.size, jm.h))

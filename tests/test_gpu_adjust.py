@@ -440,7 +440,7 @@ def test_reuse_inverses_is_identical(built, tmp_path, mt):
     for b in range(B):
         assert np.array_equal(x0[b], x1[b]) and np.array_equal(v0[b], v1[b])
     # a second AdjustNetwork on the same object starts over (ResetAdjustment drops the resident inverses)
-    a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_inverses=True)
+    a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_inverses=True, schur_carry=False)
     a.ResetAdjustment()
     assert a.AdjustNetwork() == 0 and a.solve_count() == 3 * B - 2
     for b in range(B):
@@ -505,3 +505,27 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
         for b in range(B):
             assert np.abs(x0[b] - x1[b]).max() < 1e-8
             assert np.abs(v0[b] - v1[b]).max() < 1e-8 * np.abs(v0[b]).max()
+
+
+@pytest.mark.parametrize("mt", [False, True])
+def test_condensed_reuse_across_iterations(built, tmp_path, mt):
+    """a.reuse_inverses with the condensed schedule and kept factors: from the second iteration on a block is neither condensed
+    nor inverted again -- reduced right-hand sides from the kept factor, chains on the condensed blocks, products with the
+    resident rigorous variances.  Same results (the matrices of a GNSS-only network do not change between iterations)."""
+    adjust.write_synthetic_network(str(tmp_path), "r", 14, 12, 0, 5, seed=9, x_clusters=20, y_cluster=True, initial_sigma=0.4)
+    runs = []
+    for reuse in (False, True):
+        a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_inverses=reuse)
+        assert st == 0 and a.CurrentIteration() >= 2
+        a.GenerateStatistics()
+        runs.append((a.CurrentIteration(), a.completion_count(), [a.block_estimates(b) for b in range(a.blockCount())],
+                     [a.block_variances_packed(b) for b in range(a.blockCount())], a.GetChiSquared(),
+                     [a.GetIterationCorrection(i + 1) for i in range(a.CurrentIteration())]))
+        a.close()
+    (it0, n0, x0, v0, c0, corr0), (it1, n1, x1, v1, c1, corr1) = runs
+    B = len(x0)
+    assert it0 == it1 and n0 == it0 * B and n1 == B            # one completion per block in all, not per iteration
+    assert abs(c0 - c1) < 1e-9 * c0 and np.abs(np.array(corr0) - np.array(corr1)).max() < 1e-10
+    for b in range(B):
+        assert np.abs(x0[b] - x1[b]).max() < 1e-9
+        assert np.array_equal(v0[b], v1[b])                     # the very inverse of iteration 1

@@ -301,6 +301,17 @@ def test_reduce_keep_and_complete(gpu_ctx, built, orc, tmp_path, rows, cols, pic
     # the retained state is consumed
     with pytest.raises(Exception):
         gpu_ctx.partial_complete(pf, kk, inv, n0)
+    # ... but the factor of the eliminated part still reduces new right-hand sides (next iteration of a GNSS-only network)
+    x = gpu_ctx.block_get_stations(0, 1, ns)
+    gpu_ctx.block_put_stations(0, 1, x + 0.01 * rng.standard_normal(x.shape))
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    gpu_ctx.partial_reduce_rhs(0, pf, red1)
+    m.upload_packed(a.block_normals(0), n0)
+    gpu_ctx.block_reduce(0, m, idx, red0)
+    r_new, r_ref = gpu_ctx.junction_get_estimates(red1), gpu_ctx.junction_get_estimates(red0)
+    assert np.abs(r_new - r_ref).max() < 1e-9 * max(1.0, np.abs(r_ref).max()), np.abs(r_new - r_ref).max()
+    assert np.array_equal(unpack_lower(red1.download_packed(), 3 * len(idx)), S1)          # the complement is left alone
     gpu_ctx.partial_destroy(pf)
     for q in (m, red0, red1, kk, inv):
         q.close()
