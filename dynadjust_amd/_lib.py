@@ -114,6 +114,7 @@ def load():
     _sig(lib, "dnagpu_block_msr_statistics", i, [vp, i, u32, vp, c_f64p, c_f64p])
     _sig(lib, "dnagpu_block_set_station_geo", i, [vp, u32, c_f64p, c_f64p, c_f64p])
     _sig(lib, "dnagpu_block_set_terrestrial", i, [vp, u32, u32, C.c_char_p, c_u32p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_u32p, c_u32p, u32])
+    _sig(lib, "dnagpu_block_set_direction_sets", i, [vp, u32, u32, c_u32p, c_f64p])
     _sig(lib, "dnagpu_block_update_geodetic", i, [vp, i, u32])
     _sig(lib, "dnagpu_block_get_station_llh", i, [vp, i, u32, c_f64p])
     _sig(lib, "dnagpu_block_get_terrestrial", i, [vp, i, u32, c_f64p, c_f64p])
@@ -226,7 +227,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
-    "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
+    "dnagpu_block_set_direction_sets", "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
     "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_mem_info", "dnagpu_partial_create", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",

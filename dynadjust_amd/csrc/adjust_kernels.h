@@ -16,6 +16,9 @@ void launch_tmsr_eval(const uint8_t* type, const uint32_t* stn, const double* va
                       const double* defl, double* tb, double* trow, double* tblk, double* wb, uint32_t n_bl, uint32_t n_t, hipStream_t s);
 void launch_tmsr_stats(const uint8_t* type, const uint32_t* stn, const double* trow, const double* S, uint32_t nps, double* prec, uint32_t n_t,
                        hipStream_t s);
+void launch_dsets(const uint32_t* ra, const uint32_t* rb, const uint32_t* pq, const uint32_t* wi, const double* wts, const double* trow,
+                  double* out, uint32_t n_blocks, const uint32_t* row0, const uint32_t* kk, const uint32_t* woff, const double* tb,
+                  const uint32_t* vec0, double* wb, uint32_t n_bl, uint32_t n_t, hipStream_t s);
 void launch_add_diag3x3(double* F, uint32_t np, const uint32_t* stn, const double* w9, uint32_t k, double sign, hipStream_t s);
 void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const double* b, double* wb,
                      uint32_t n_vec, const uint32_t* ioff, const uint32_t* inc, double* rhs, uint32_t n_stn, hipStream_t s);

@@ -221,6 +221,7 @@ __global__ void tmsr_eval_kernel(const uint8_t* __restrict__ type, const uint32_
     tb[t] = b;
 #pragma unroll
     for (int i = 0; i < 9; ++i) trow[9 * (size_t)t + i] = row[i];
+    if (ty == 'D') return;     // one angle of a direction set: blocks and vectors come from the set's dense weights (dset kernels)
     const double w = 1.0 / var[t];
     const double wbv = w * b;
     for (int q = 0; q < ns; ++q)
@@ -232,6 +233,37 @@ __global__ void tmsr_eval_kernel(const uint8_t* __restrict__ type, const uint32_
             double* o = tblk + 9 * (size_t)idx++;
             for (int e = 0; e < 9; ++e) o[e] = (w * row[3 * p + e % 3]) * row[3 * q + e / 3];
         }
+}
+
+// Direction sets: N += A^T W A and rhs += A^T W b with the set's dense W (UpdateAtVinv_D / UpdateNormals_D, dnaadjust.cpp:1328, 1540).
+// One thread per block (rows a, b of a set, station slots p, q): W_ab a_{a,p}^T a_{b,q}; then one thread per row: a_{a,p}^T sum_b W_ab b_b
+__global__ void dset_blocks_kernel(const uint32_t* __restrict__ ra, const uint32_t* __restrict__ rb, const uint32_t* __restrict__ pq,
+                                   const uint32_t* __restrict__ wi, const double* __restrict__ wts, const double* __restrict__ trow,
+                                   double* __restrict__ out, uint32_t n) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double w = wts[wi[e]];
+    const double* a = trow + 9 * (size_t)ra[e] + 3 * (pq[e] & 3u);
+    const double* b = trow + 9 * (size_t)rb[e] + 3 * (pq[e] >> 2);
+    double* o = out + 9 * (size_t)e;
+    for (int i = 0; i < 9; ++i) o[i] = (w * a[i % 3]) * b[i / 3];
+}
+__global__ void dset_vectors_kernel(const uint32_t* __restrict__ row0, const uint32_t* __restrict__ kk, const uint32_t* __restrict__ woff,
+                                    const double* __restrict__ wts, const double* __restrict__ tb, const double* __restrict__ trow,
+                                    const uint32_t* __restrict__ vec0, double* __restrict__ wb, uint32_t n_bl, uint32_t n_t) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_t || kk[t] == 0) return;
+    const uint32_t k = kk[t], a = t - row0[t];
+    double s = 0.0;
+    for (uint32_t b = 0; b < k; ++b) s += wts[woff[t] + a + (size_t)b * k] * tb[row0[t] + b];
+    for (int q = 0; q < 3; ++q)
+        for (int r = 0; r < 3; ++r) wb[3 * ((size_t)n_bl + vec0[t] + q) + r] = trow[9 * (size_t)t + 3 * q + r] * s;
+}
+void launch_dsets(const uint32_t* ra, const uint32_t* rb, const uint32_t* pq, const uint32_t* wi, const double* wts, const double* trow,
+                  double* out, uint32_t n_blocks, const uint32_t* row0, const uint32_t* kk, const uint32_t* woff, const double* tb,
+                  const uint32_t* vec0, double* wb, uint32_t n_bl, uint32_t n_t, hipStream_t s) {
+    if (n_blocks) hipLaunchKernelGGL(dset_blocks_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, s, ra, rb, pq, wi, wts, trow, out, n_blocks);
+    hipLaunchKernelGGL(dset_vectors_kernel, dim3((n_t + 255) / 256), dim3(256), 0, s, row0, kk, woff, wts, tb, trow, vec0, wb, n_bl, n_t);
 }
 
 // precision of the adjusted terrestrial measurements: a S a^T (ComputePrecisionAdjMsrs_A / _BCEKLMSVZ / _HIJPQR,

@@ -68,6 +68,14 @@ struct Block {
     double *s_llh = nullptr, *s_geoid = nullptr, *s_defl = nullptr;     // station records: geodetic position, N, deflections
     double* tb[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};                 // n_t: measured - computed
     double* trow[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};               // 9 n_t: design rows
+    // direction sets (type D): rows of a set share a dense weight matrix; their normal-equation blocks couple every pair of
+    // station slots of the set (dnagpu_block_set_direction_sets)
+    uint32_t n_dsblk = 0;                                  // blocks of all sets, stored behind the per-measurement ones
+    uint32_t *ds_a = nullptr, *ds_b = nullptr, *ds_pq = nullptr, *ds_w = nullptr;   // per block: rows a, b; slots p | q << 2; weight index
+    uint32_t *ds_row0 = nullptr, *ds_k = nullptr, *ds_woff = nullptr;               // per terrestrial row: first row / size / weight offset of its set (k = 0: none)
+    double* ds_wts = nullptr;
+    struct DsEnt { uint64_t key; uint32_t pos, blk; };
+    std::vector<DsEnt> h_ds_ents;
     // dnagpu_schur_carry: unknown order with the carried junction stations last, per junction list seen (forward / reverse)
     std::vector<uint32_t> h_schur_idx[2];
     uint32_t* schur_idx[2] = {nullptr, nullptr};

@@ -129,7 +129,7 @@ void free_block(Block& b) {
                     b.vec_wrow, b.vec_c0, b.vec_k, b.wb[0], b.wb[1],
                     b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc, b.red[0], b.red[1],
                     b.t_type, b.t_stn, b.t_blk0, b.t_vec0, b.t_val, b.t_pre, b.t_var, b.t_ih, b.t_th, b.s_llh, b.s_geoid, b.s_defl,
-                    b.tb[0], b.tb[1], b.trow[0], b.trow[1], b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1]};
+                    b.tb[0], b.tb[1], b.trow[0], b.trow[1], b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     b = Block();
@@ -586,7 +586,7 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
         if (!(variance[t] > 0.0)) return fail(ctx, DNAGPU_EINVAL, "block_set_terrestrial: non-positive variance");
         blk0[t] = nb;
         vec0[t] = nv;
-        nb += (uint32_t)(ns * (ns + 1) / 2);
+        if (type[t] != 'D') nb += (uint32_t)(ns * (ns + 1) / 2);     // (a direction set's blocks: dnagpu_block_set_direction_sets)
         nv += (uint32_t)ns;
     }
     for (void* p : {(void*)b->t_type, (void*)b->t_stn, (void*)b->t_blk0, (void*)b->t_vec0, (void*)b->t_val, (void*)b->t_pre, (void*)b->t_var,
@@ -599,6 +599,12 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
     b->n_t = n_t;
     b->n_tblk = nb;
     b->n_tvec = nv;
+    b->n_dsblk = 0;
+    b->h_ds_ents.clear();
+    for (void* p : {(void*)b->ds_a, (void*)b->ds_b, (void*)b->ds_pq, (void*)b->ds_w, (void*)b->ds_row0, (void*)b->ds_k, (void*)b->ds_woff, (void*)b->ds_wts})
+        if (p) hipFree(p);
+    b->ds_a = b->ds_b = b->ds_pq = b->ds_w = b->ds_row0 = b->ds_k = b->ds_woff = nullptr;
+    b->ds_wts = nullptr;
     b->h_ttype.assign(type, type + n_t);
     b->h_tstn.assign(stn3, stn3 + 3 * (size_t)n_t);
     b->h_tpos.assign(cml_pos, cml_pos + n_t);
@@ -629,6 +635,65 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
         HIPCHK(hipMalloc(&b->tb[c], n_t * sizeof(double)));
         HIPCHK(hipMalloc(&b->trow[c], 9 * (size_t)n_t * sizeof(double)));
     }
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_sets, const uint32_t* set_off, const double* weights) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b || (n_sets && (!set_off || !weights))) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: bad arguments");
+    const uint32_t n_t = b->n_t, ns = b->n_stn;
+    std::vector<uint32_t> row0(n_t, 0), kk(n_t, 0), woff(n_t, 0), ea, eb, epq, ew;
+    std::vector<uint8_t> in_set(n_t, 0);
+    b->h_ds_ents.clear();
+    size_t wtot = 0;
+    for (uint32_t s = 0; s < n_sets; ++s) {
+        if (set_off[s + 1] <= set_off[s] || set_off[s + 1] > n_t) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: bad set offsets");
+        const uint32_t r0 = set_off[s], k = set_off[s + 1] - r0;
+        for (uint32_t a = 0; a < k; ++a) {
+            if (b->h_ttype[r0 + a] != 'D' || in_set[r0 + a] || b->h_tpos[r0 + a] != b->h_tpos[r0])
+                return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: the rows of a set are consecutive type D entries of one measurement");
+            in_set[r0 + a] = 1;
+            row0[r0 + a] = r0;
+            kk[r0 + a] = k;
+            woff[r0 + a] = (uint32_t)wtot;
+        }
+        // every ordered pair of station slots (row a, p), (row b, q) whose stations satisfy stn(a,p) >= stn(b,q): one block
+        for (uint32_t a = 0; a < k; ++a)
+            for (int p = 0; p < 3; ++p)
+                for (uint32_t c = 0; c < k; ++c)
+                    for (int q = 0; q < 3; ++q) {
+                        const uint32_t sa = b->h_tstn[3 * (size_t)(r0 + a) + p], sb = b->h_tstn[3 * (size_t)(r0 + c) + q];
+                        if (sa < sb) continue;
+                        b->h_ds_ents.push_back({(uint64_t)sa * ns + sb, b->h_tpos[r0], (uint32_t)ea.size()});
+                        ea.push_back(r0 + a);
+                        eb.push_back(r0 + c);
+                        epq.push_back((uint32_t)p | ((uint32_t)q << 2));
+                        ew.push_back((uint32_t)(wtot + a + (size_t)c * k));
+                    }
+        wtot += (size_t)k * k;
+    }
+    for (uint32_t t = 0; t < n_t; ++t)
+        if (b->h_ttype[t] == 'D' && !in_set[t]) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: a type D entry belongs to no set");
+    auto up32 = [&](uint32_t** dev, const std::vector<uint32_t>& v) -> hipError_t {
+        hipError_t e = hipMalloc((void**)dev, std::max<size_t>(v.size(), 1) * sizeof(uint32_t));
+        if (e == hipSuccess && !v.empty()) e = hipMemcpy(*dev, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        return e;
+    };
+    for (void* p : {(void*)b->ds_a, (void*)b->ds_b, (void*)b->ds_pq, (void*)b->ds_w, (void*)b->ds_row0, (void*)b->ds_k, (void*)b->ds_woff, (void*)b->ds_wts})
+        if (p) hipFree(p);
+    b->ds_a = b->ds_b = b->ds_pq = b->ds_w = b->ds_row0 = b->ds_k = b->ds_woff = nullptr;
+    b->ds_wts = nullptr;
+    HIPCHK(up32(&b->ds_a, ea));
+    HIPCHK(up32(&b->ds_b, eb));
+    HIPCHK(up32(&b->ds_pq, epq));
+    HIPCHK(up32(&b->ds_w, ew));
+    HIPCHK(up32(&b->ds_row0, row0));
+    HIPCHK(up32(&b->ds_k, kk));
+    HIPCHK(up32(&b->ds_woff, woff));
+    HIPCHK(hipMalloc(&b->ds_wts, std::max<size_t>(wtot, 1) * sizeof(double)));
+    if (wtot) HIPCHK(hipMemcpy(b->ds_wts, weights, wtot * sizeof(double), hipMemcpyHostToDevice));
+    b->n_dsblk = (uint32_t)ea.size();
     return DNAGPU_OK;
 }
 
@@ -698,6 +763,10 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     // terrestrial measurements: one 3x3 block w a_p^T a_q per station pair with local(p) >= local(q), enumerated as
     // tmsr_eval_kernel writes them; block indices continue after the GNSS weight blocks
     for (uint32_t t = 0, tb = 0; t < b->n_t; ++t) {
+        if (b->h_ttype[t] == 'D') {
+            if (b->n_dsblk == 0 && b->h_ds_ents.empty()) return fail(ctx, DNAGPU_EINVAL, "block_set_clusters: type D entries without dnagpu_block_set_direction_sets");
+            continue;
+        }
         const int nst = dnagpu::tm::station_count((char)b->h_ttype[t]);
         const uint32_t* l = &b->h_tstn[3 * (size_t)t];
         for (int pp = 0; pp < nst; ++pp)
@@ -707,6 +776,8 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
                 ++tb;
             }
     }
+    // direction sets: their blocks sit behind the per-measurement terrestrial ones
+    for (const auto& d : b->h_ds_ents) ents.push_back({d.key, d.pos, ((n_wblk + b->n_tblk + d.blk) << 1)});
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key != y.key ? x.key < y.key : x.pos < y.pos; });
     std::vector<uint32_t> prow, pcol, poff, pent(ents.size());
     for (size_t k = 0; k < ents.size(); ++k) {
@@ -761,7 +832,7 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     HIPCHK(up(&b->pair_ent, pent));
     HIPCHK(up(&b->inc_off, ioff));
     HIPCHK(up(&b->inc, inc));
-    HIPCHK(hipMalloc(&b->Wblk, std::max<size_t>((size_t)n_wblk + (size_t)DNAGPU_NUM_CHAINS * b->n_tblk, 1) * 9 * sizeof(double)));
+    HIPCHK(hipMalloc(&b->Wblk, std::max<size_t>((size_t)n_wblk + (size_t)DNAGPU_NUM_CHAINS * ((size_t)b->n_tblk + b->n_dsblk), 1) * 9 * sizeof(double)));
     if (!m) return DNAGPU_OK;
     HIPCHK(hipMemcpy(b->s1, stn1, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->s2, stn2, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -906,7 +977,12 @@ int dnagpu_block_compute_b(dnagpu_ctx* ctx, int chain, uint32_t blk) {
         if (!b->s_llh || !b->Wblk) return fail(ctx, DNAGPU_EINVAL, "block_compute_b: station records / measurement lists not set");
         launch_tmsr_eval(b->t_type, b->t_stn, b->t_val, b->t_pre, b->t_var, b->t_ih, b->t_th, b->t_blk0, b->t_vec0, b->x_est[chain], b->s_llh,
                          b->s_geoid, b->s_defl, b->tb[chain], b->trow[chain],
-                         b->Wblk + ((size_t)b->n_wblk + (size_t)chain * b->n_tblk) * 9, b->wb[chain], b->n_bl, b->n_t, ctx->stream[chain]);
+                         b->Wblk + ((size_t)b->n_wblk + (size_t)chain * ((size_t)b->n_tblk + b->n_dsblk)) * 9, b->wb[chain], b->n_bl, b->n_t,
+                         ctx->stream[chain]);
+        if (b->ds_k)
+            launch_dsets(b->ds_a, b->ds_b, b->ds_pq, b->ds_w, b->ds_wts, b->trow[chain],
+                         b->Wblk + ((size_t)b->n_wblk + (size_t)chain * ((size_t)b->n_tblk + b->n_dsblk) + b->n_tblk) * 9, b->n_dsblk, b->ds_row0,
+                         b->ds_k, b->ds_woff, b->tb[chain], b->t_vec0, b->wb[chain], b->n_bl, b->n_t, ctx->stream[chain]);
     }
     return DNAGPU_OK;
 }
@@ -1024,7 +1100,7 @@ int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
     m->np = pad128(m->n);
     launch_init_padded(m->F, m->n, m->np, ctx->stream[chain]);
     launch_form_normals(b->pair_row, b->pair_col, b->pair_off, b->pair_ent, b->Wblk, m->F, m->np, b->n_pairs, b->n_wblk,
-                        (uint32_t)chain * b->n_tblk, ctx->stream[chain]);
+                        (uint32_t)chain * (b->n_tblk + b->n_dsblk), ctx->stream[chain]);
     return DNAGPU_OK;
 }
 

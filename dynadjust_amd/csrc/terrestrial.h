@@ -37,10 +37,12 @@ struct StationGeo {
 };
 
 TM_HD bool single_station(char type) { return type == 'H' || type == 'R' || type == 'I' || type == 'J' || type == 'P' || type == 'Q'; }
-TM_HD int station_count(char type) { return type == 'A' ? 3 : (single_station(type) ? 1 : 2); }
+// 'D' here is one angle of a direction set: the difference of two consecutive directions, an 'A' measurement whose
+// weight is a row of the set's dense weight matrix (UpdateDesignNormalMeasMatrices_D, dnaadjust.cpp:5082)
+TM_HD int station_count(char type) { return (type == 'A' || type == 'D') ? 3 : (single_station(type) ? 1 : 2); }
 TM_HD bool is_terrestrial(char type) {
     switch (type) {
-        case 'A': case 'B': case 'C': case 'E': case 'H': case 'I': case 'J': case 'K': case 'L': case 'M': case 'P': case 'Q': case 'R': case 'S':
+        case 'A': case 'B': case 'C': case 'D': case 'E': case 'H': case 'I': case 'J': case 'K': case 'L': case 'M': case 'P': case 'Q': case 'R': case 'S':
         case 'V': case 'Z': return true;
         default: return false;
     }
@@ -195,7 +197,7 @@ TM_HD double evaluate(char type, const double* X1, const double* X2, const doubl
     for (int i = 0; i < 9; ++i) row[i] = 0.0;
     double comp = 0.0;
     switch (type) {
-        case 'A': {
+        case 'A': case 'D': {
             double e12, n12, e13, n13;
             const double d12 = direction(X1, X2, g1.lat, g1.lon, &e12, &n12);
             double d13 = direction(X1, X3, g1.lat, g1.lon, &e13, &n13);
@@ -318,7 +320,7 @@ TM_HD double evaluate(char type, const double* X1, const double* X2, const doubl
 // measured minus computed with the angle wrap of AddMsrtoMeasMinusComp (dnaadjust.cpp:4719)
 TM_HD double meas_minus_comp(char type, double value, double comp) {
     double mmc = value - comp;
-    if (type == 'A' || type == 'B' || type == 'K') {
+    if (type == 'A' || type == 'B' || type == 'D' || type == 'K') {
         if (mmc < -5.5) mmc += TWO_PI;
         else if (mmc > 5.5) mmc -= TWO_PI;
     }
@@ -333,7 +335,7 @@ TM_HD double reduce(char type, double* value, const double* X1, const double* X2
     const bool defl = fabs(g1.defl_v) > E4_SEC_DEFLECTION || fabs(g1.defl_m) > E4_SEC_DEFLECTION;
     double corr = 0.0, e, n, up;
     switch (type) {
-        case 'A':
+        case 'A': case 'D':
             if (defl) {
                 double e12, n12, e13, n13;
                 const double d12 = direction(X1, X2, g1.lat, g1.lon, &e12, &n12);

@@ -133,6 +133,13 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
                                  const uint32_t* cml_pos, const uint32_t* cluster_cml_pos, uint32_t n_clusters);
 /* station records <- geodetic coordinates of the chain's current estimates (UpdateGeographicCoords[Phased],
  * dnaadjust.cpp:8711/8734); the design of the next compute_b uses them */
+/* Direction sets (type D; UpdateDesignNormalMeasMatrices_D dnaadjust.cpp:5082, LoadVarianceMatrix_D :4059, UpdateAtVinv_D :1328,
+ * UpdateNormals_D :1540).  The angles between consecutive directions of a set are entries of type 'D' in
+ * dnagpu_block_set_terrestrial (modelled like 'A'), consecutive and with the same cml_pos; instead of a variance of their own
+ * they share the set's dense weight matrix (the inverse of the tridiagonal variance matrix of the differences).
+ * set_off[n_sets + 1]: first terrestrial entry of each set; weights: the k x k matrices, column-major, one after the other.
+ * Call between dnagpu_block_set_terrestrial and dnagpu_block_set_clusters whenever type 'D' entries exist. */
+int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_sets, const uint32_t* set_off, const double* weights);
 int dnagpu_block_update_geodetic(dnagpu_ctx* ctx, int chain, uint32_t blk);
 int dnagpu_block_get_station_llh(dnagpu_ctx* ctx, int chain, uint32_t blk, double* llh);
 /* meas-minus-computed (n_t) and design rows (9 n_t: dX dY dZ of station 1, 2, 3) of the last compute_b; either may be NULL */
