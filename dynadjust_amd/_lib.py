@@ -114,7 +114,7 @@ def load():
     _sig(lib, "dnagpu_block_msr_statistics", i, [vp, i, u32, vp, c_f64p, c_f64p])
     _sig(lib, "dnagpu_block_set_station_geo", i, [vp, u32, c_f64p, c_f64p, c_f64p])
     _sig(lib, "dnagpu_block_set_terrestrial", i, [vp, u32, u32, C.c_char_p, c_u32p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_u32p, c_u32p, u32])
-    _sig(lib, "dnagpu_block_set_direction_sets", i, [vp, u32, u32, c_u32p, c_f64p])
+    _sig(lib, "dnagpu_block_set_direction_sets", i, [vp, u32, u32, c_u32p, c_u32p, c_f64p])
     _sig(lib, "dnagpu_block_update_geodetic", i, [vp, i, u32])
     _sig(lib, "dnagpu_block_get_station_llh", i, [vp, i, u32, c_f64p])
     _sig(lib, "dnagpu_block_get_terrestrial", i, [vp, i, u32, c_f64p, c_f64p])

@@ -638,18 +638,19 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
     return DNAGPU_OK;
 }
 
-int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_sets, const uint32_t* set_off, const double* weights) {
+int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_sets, const uint32_t* set_first, const uint32_t* set_size,
+                                    const double* weights) {
     CHK_CTX();
     Block* b = find_block(ctx, blk);
-    if (!b || (n_sets && (!set_off || !weights))) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: bad arguments");
+    if (!b || (n_sets && (!set_first || !set_size || !weights))) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: bad arguments");
     const uint32_t n_t = b->n_t, ns = b->n_stn;
     std::vector<uint32_t> row0(n_t, 0), kk(n_t, 0), woff(n_t, 0), ea, eb, epq, ew;
     std::vector<uint8_t> in_set(n_t, 0);
     b->h_ds_ents.clear();
     size_t wtot = 0;
     for (uint32_t s = 0; s < n_sets; ++s) {
-        if (set_off[s + 1] <= set_off[s] || set_off[s + 1] > n_t) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: bad set offsets");
-        const uint32_t r0 = set_off[s], k = set_off[s + 1] - r0;
+        if (!set_size[s] || (uint64_t)set_first[s] + set_size[s] > n_t) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: bad set range");
+        const uint32_t r0 = set_first[s], k = set_size[s];
         for (uint32_t a = 0; a < k; ++a) {
             if (b->h_ttype[r0 + a] != 'D' || in_set[r0 + a] || b->h_tpos[r0 + a] != b->h_tpos[r0])
                 return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: the rows of a set are consecutive type D entries of one measurement");

@@ -117,6 +117,15 @@ void dna_adjust::BuildSimultaneousLists() {
         const measurement_t& r = bmsBinaryRecords_[m];
         if (r.ignore) continue;
         if (r.measStart > 2) continue;    // covariance rows (measurement_processor.cpp:79-83)
+        if (r.measType == 'D') {
+            // direction sets: the record of the reference direction enters the CML, one design row per angle
+            // (measurement_processor.cpp:92-110); the records of the other directions carry no counts of their own
+            if (r.measStart == 0 && r.vectorCount1 >= 1) {
+                v_CML_[0].push_back(m);
+                rows += r.vectorCount2 > 0 ? r.vectorCount2 - 1 : 1;
+            }
+            continue;
+        }
         rows++;                           // every X / Y / Z element (and every terrestrial measurement) is one design row
         if (r.measStart != 0) continue;   // only the first element starts a measurement
         if (r.measType == 'X' || r.measType == 'Y') {
@@ -462,6 +471,100 @@ void dna_adjust::ParseTerrestrialMeasurement(UINT32 block, UINT32 m, block_t& B,
     B.t_th.push_back(rec.term4);
 }
 
+// One direction set (type D): the record of the reference direction followed by vectorCount1 - 1 direction records
+// (CDnaDirectionSet::WriteBinaryMsr, dnadirectionset.cpp:430).  UpdateDesignNormalMeasMatrices_D (ADJ:5082): the angles between
+// consecutive non-ignored directions are 'A' measurements (instrument, earlier target, later target; the heights of the earlier
+// direction's record); LoadVarianceMatrix_D (ADJ:4059): the differences of independent directions have the tridiagonal variance
+// matrix  V_aa = s_a^2 + s_a+1^2,  V_a,a+1 = -s_a+1^2, whose inverse weights the whole set.  The derived angle, its variance and
+// covariance live in the later direction's record (scale1, scale2, scale3; preAdjMeas = the angle before the deflection correction).
+UINT32 dna_adjust::ParseDirectionSet(UINT32 block, UINT32 m, block_t& B, const std::vector<double>& xyz) {
+    measurement_t& ro = bmsBinaryRecords_[m];
+    const UINT32 total = ro.vectorCount1;
+    if (ro.measStart != 0 || total < 2 || (size_t)m + total > bmsBinaryRecords_.size())
+        SignalExceptionAdjustment("PrepareAdjustment(): malformed direction set.", block);
+    std::vector<UINT32> recs(1, m);
+    for (UINT32 j = 1; j < total; ++j) {
+        const measurement_t& d = bmsBinaryRecords_[m + j];
+        if (d.measType != 'D') SignalExceptionAdjustment("PrepareAdjustment(): malformed direction set.", block);
+        if (!d.ignore) recs.push_back(m + j);
+    }
+    const UINT32 k = (UINT32)recs.size() - 1;
+    if (k < 1 || ro.vectorCount2 != k + 1) SignalExceptionAdjustment("PrepareAdjustment(): a direction set without a second direction.", block);
+    B.dset_first.push_back((UINT32)B.t_type.size());
+    B.dset_size.push_back(k);
+    std::vector<double> V((size_t)k * k, 0.0);
+    auto geo_of = [&](UINT32 g) {
+        const station_t& st = bstBinaryRecords_.at(g);
+        return dnagpu::tm::StationGeo{st.currentLatitude, st.currentLongitude, st.currentHeight, (double)st.geoidSep, st.verticalDef, st.meridianDef};
+    };
+    const UINT32 inst = LocalIndex(block, ro.station1);
+    for (UINT32 a = 0; a < k; ++a) {
+        const measurement_t& ra = bmsBinaryRecords_[recs[a]];
+        measurement_t& rb = bmsBinaryRecords_[recs[a + 1]];
+        if (!(ra.term2 > 0.0) || !(rb.term2 > 0.0)) SignalExceptionAdjustment("PrepareAdjustment(): a measurement with a non-positive variance.", block);
+        const UINT32 l2 = LocalIndex(block, ra.station2), l3 = LocalIndex(block, rb.station2);
+        double angle;
+        if (bms_meta_.reduced) {
+            angle = rb.preAdjMeas;                                   // ADJ:5133-5136, variances as stored (GetDirectionsVarianceMatrix)
+            V[a + (size_t)a * k] = rb.scale2;
+            if (a + 1 < k) V[a + (size_t)(a + 1) * k] = V[(a + 1) + (size_t)a * k] = rb.scale3;
+        } else {
+            angle = rb.term1 - ra.term1;                             // ADJ:5140-5144
+            if (angle < 0) angle += dnagpu::tm::TWO_PI;
+            if (angle > dnagpu::tm::TWO_PI) angle -= dnagpu::tm::TWO_PI;
+            V[a + (size_t)a * k] = ra.term2 + rb.term2;
+            if (a + 1 < k) V[a + (size_t)(a + 1) * k] = V[(a + 1) + (size_t)a * k] = -rb.term2;
+            rb.scale2 = V[a + (size_t)a * k];                        // SetDirectionsVarianceMatrix
+            rb.scale3 = a + 1 < k ? -rb.term2 : 0.0;
+        }
+        rb.preAdjMeas = angle;
+        double value = angle;
+        rb.preAdjCorr = dnagpu::tm::reduce('A', &value, &xyz[3 * (size_t)inst], &xyz[3 * (size_t)l2], &xyz[3 * (size_t)l3], geo_of(ro.station1),
+                                           geo_of(ra.station2), geo_of(rb.station2), ra.term3, ra.term4);
+        rb.scale1 = value;
+        B.t_type.push_back('D');
+        B.t_stn.push_back(inst);
+        B.t_stn.push_back(l2);
+        B.t_stn.push_back(l3);
+        B.t_rec.push_back(recs[a + 1]);
+        B.t_val.push_back(value);
+        B.t_pre.push_back(angle);
+        B.t_var.push_back(rb.scale2);
+        B.t_ih.push_back(ra.term3);
+        B.t_th.push_back(ra.term4);
+    }
+    // FormInverseVarianceMatrix: Cholesky inverse of the k x k matrix
+    std::vector<double> L(V);
+    for (UINT32 j = 0; j < k; ++j) {
+        double d = L[j + (size_t)j * k];
+        for (UINT32 q = 0; q < j; ++q) d -= L[j + (size_t)q * k] * L[j + (size_t)q * k];
+        if (!(d > 0.0)) SignalExceptionAdjustment("Matrix inversion failed, the matrix is singular.", block);
+        d = std::sqrt(d);
+        L[j + (size_t)j * k] = d;
+        for (UINT32 i = j + 1; i < k; ++i) {
+            double s = L[i + (size_t)j * k];
+            for (UINT32 q = 0; q < j; ++q) s -= L[i + (size_t)q * k] * L[j + (size_t)q * k];
+            L[i + (size_t)j * k] = s / d;
+        }
+    }
+    std::vector<double> Li((size_t)k * k, 0.0);       // L^-1, lower
+    for (UINT32 j = 0; j < k; ++j) {
+        Li[j + (size_t)j * k] = 1.0 / L[j + (size_t)j * k];
+        for (UINT32 i = j + 1; i < k; ++i) {
+            double s = 0.0;
+            for (UINT32 q = j; q < i; ++q) s -= L[i + (size_t)q * k] * Li[q + (size_t)j * k];
+            Li[i + (size_t)j * k] = s / L[i + (size_t)i * k];
+        }
+    }
+    for (UINT32 i = 0; i < k; ++i)
+        for (UINT32 j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (UINT32 q = std::max(i, j); q < k; ++q) s += Li[q + (size_t)i * k] * Li[q + (size_t)j * k];
+            B.dset_w.push_back(s);          // (symmetric: row / column order does not matter)
+        }
+    return k;
+}
+
 // PrepareAdjustmentBlock (ADJ:2873) for every block: host lists + device upload
 void dna_adjust::PrepareBlocks() {
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
@@ -501,7 +604,11 @@ void dna_adjust::PrepareBlocks() {
             if ((size_t)m >= bmsBinaryRecords_.size()) SignalExceptionAdjustment("PrepareAdjustment(): measurement index out of range.", b);
             if (bmsBinaryRecords_[m].ignore) continue;   // InitialiseandValidateMsrPointer
             const UINT32 pos = (UINT32)(B.c_pos.size() + B.t_pos.size());
-            if (dnagpu::tm::is_terrestrial(bmsBinaryRecords_[m].measType)) {
+            if (bmsBinaryRecords_[m].measType == 'D') {
+                const UINT32 k = ParseDirectionSet(b, m, B, xyz);
+                B.t_pos.insert(B.t_pos.end(), k, pos);     // one measurement, k design rows
+                containsNonGPS_ = true;
+            } else if (dnagpu::tm::is_terrestrial(bmsBinaryRecords_[m].measType)) {
                 ParseTerrestrialMeasurement(b, m, B, xyz);
                 B.t_pos.push_back(pos);
                 containsNonGPS_ = true;
@@ -555,6 +662,9 @@ void dna_adjust::PrepareBlocks() {
         Check(dnagpu_block_set_terrestrial(ctx_, b, (UINT32)B.t_type.size(), B.t_type.data(), B.t_stn.data(), B.t_val.data(), B.t_pre.data(),
                                            B.t_var.data(), B.t_ih.data(), B.t_th.data(), B.t_pos.data(), B.c_pos.data(), (UINT32)B.c_pos.size()),
               b, "PrepareAdjustment(): terrestrial measurements");
+        if (!B.dset_first.empty())
+            Check(dnagpu_block_set_direction_sets(ctx_, b, (UINT32)B.dset_first.size(), B.dset_first.data(), B.dset_size.data(), B.dset_w.data()), b,
+                  "PrepareAdjustment(): direction sets");
         Check(dnagpu_block_set_clusters(ctx_, b, B.stn1.data(), B.stn2.data(), B.obs.data(), (UINT32)B.cluster_off.size() - 1,
                                         B.cluster_off.data(), B.vcv.data()),
               b, "PrepareAdjustment(): measurements");
@@ -901,6 +1011,19 @@ void dna_adjust::ComputeStatistics() {
                 const dnagpu::tm::StationGeo g1 = geo(l[0]), g2 = geo(dnagpu::tm::station_count(type) > 1 ? l[1] : l[0]);
                 const double* X1 = &xr[3 * (size_t)l[0]];
                 const double* X2 = &xr[3 * (size_t)(dnagpu::tm::station_count(type) > 1 ? l[1] : l[0])];
+                if (type == 'D') {
+                    // an angle of a direction set, kept in the later direction's record: derived angle scale1, variance scale2
+                    // (UpdateMsrRecords_D ADJ:8121, UpdateMsrRecord ADJ:8194-8199, :8255-8261; ComputeChiSquare_D ADJ:8440 uses the
+                    // angle's own variance, not the set's weight matrix)
+                    const double direction = rec.term1;
+                    rec.term1 = rec.scale1;
+                    UpdateMsrRecord(rec, -tb[t], tprec[t], rec.scale2);
+                    rec.term1 = direction;
+                    if (rec.measAdj > dnagpu::tm::TWO_PI) rec.measAdj -= dnagpu::tm::TWO_PI;
+                    rec.measAdj += rec.preAdjCorr;
+                    cs += tb[t] * tb[t] / rec.scale2;
+                    continue;
+                }
                 // E and M work with the ellipsoid chord derived from the supplied arc (ADJ:5254, ADJ:5412)
                 rec.term1 = dnagpu::tm::working_value(type, rec.term1, rec.preAdjMeas, X1, X2, g1, g2);
                 if (type == 'E' || type == 'M') rec.preAdjCorr = rec.term1 - rec.preAdjMeas;
@@ -994,6 +1117,11 @@ void dna_adjust::ForEachMeasurementComponent(const std::function<void(measuremen
         for (UINT32 m : v_CML_[b]) {
             if (bmsBinaryRecords_[m].ignore || bmsBinaryRecords_[m].measStart != 0) continue;
             const char type = bmsBinaryRecords_[m].measType;
+            if (type == 'D') {      // the angles live in the records of the non-ignored directions after the first
+                for (UINT32 j = 1; j < bmsBinaryRecords_[m].vectorCount1; ++j)
+                    if (!bmsBinaryRecords_[m + j].ignore) fn(bmsBinaryRecords_[m + j]);
+                continue;
+            }
             if (dnagpu::tm::is_terrestrial(type)) {
                 fn(bmsBinaryRecords_[m]);
                 continue;

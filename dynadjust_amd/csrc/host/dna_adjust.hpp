@@ -147,6 +147,9 @@ private:
         std::vector<UINT32> t_rec;            // record index in bmsBinaryRecords_
         std::vector<double> t_val, t_pre, t_var, t_ih, t_th;
         std::vector<UINT32> t_pos, c_pos;     // CML position of every terrestrial measurement / GNSS cluster
+        // direction sets: rows dset_first[s] .. + dset_size[s] - 1 of the terrestrial lists are the angles of set s (type 'D')
+        std::vector<UINT32> dset_first, dset_size;
+        std::vector<double> dset_w;           // their dense weight matrices (k x k, column-major), one after the other
     };
 
     void LoadNetworkFiles();
@@ -156,6 +159,7 @@ private:
     void PrepareBlocks();
     void ParseGnssMeasurement(UINT32 block, UINT32 m, block_t& B);
     void ParseTerrestrialMeasurement(UINT32 block, UINT32 m, block_t& B, const std::vector<double>& xyz);
+    UINT32 ParseDirectionSet(UINT32 block, UINT32 m, block_t& B, const std::vector<double>& xyz);   // returns the number of angles
     void FormConstraintStationVarianceMatrix(UINT32 stn, double w9[9]) const;   // ADJ:2041
     UINT32 LocalIndex(UINT32 block, UINT32 stn) const;
 

@@ -137,9 +137,11 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
  * UpdateNormals_D :1540).  The angles between consecutive directions of a set are entries of type 'D' in
  * dnagpu_block_set_terrestrial (modelled like 'A'), consecutive and with the same cml_pos; instead of a variance of their own
  * they share the set's dense weight matrix (the inverse of the tridiagonal variance matrix of the differences).
- * set_off[n_sets + 1]: first terrestrial entry of each set; weights: the k x k matrices, column-major, one after the other.
+ * set_first / set_size: first terrestrial entry and number of angles k of each set; weights: the k x k matrices, column-major,
+ * one after the other.
  * Call between dnagpu_block_set_terrestrial and dnagpu_block_set_clusters whenever type 'D' entries exist. */
-int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_sets, const uint32_t* set_off, const double* weights);
+int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_sets, const uint32_t* set_first, const uint32_t* set_size,
+                                    const double* weights);
 int dnagpu_block_update_geodetic(dnagpu_ctx* ctx, int chain, uint32_t blk);
 int dnagpu_block_get_station_llh(dnagpu_ctx* ctx, int chain, uint32_t blk, double* llh);
 /* meas-minus-computed (n_t) and design rows (9 n_t: dX dY dZ of station 1, 2, 3) of the last compute_b; either may be NULL */

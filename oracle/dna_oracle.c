@@ -668,7 +668,7 @@ static double ellipsoid_chord_to_msl_arc(double chord, double lat1, double lat2,
 
 static int tm_station_count(char type) {
     switch (type) {
-        case 'A': return 3;
+        case 'A': case 'D': return 3;   /* 'D': one angle of a direction set, see dset_* below */
         case 'H': case 'R': case 'I': case 'J': case 'P': case 'Q': return 1;
         default: return 2;
     }
@@ -686,7 +686,7 @@ static void tm_evaluate(orc_adjustment* a, uint32_t t, const double* X1, const d
     const double cos_lat = cos(lat1), sin_lat = sin(lat1), cos_long = cos(lon1), sin_long = sin(lon1);
     for (int i = 0; i < 9; ++i) row[i] = 0.0;
     switch (type) {
-        case 'A': {
+        case 'A': case 'D': {
             double e12, n12, e13, n13;
             double d12 = direction(X1, X2, lat1, lon1, &e12, &n12);
             double d13 = direction(X1, X3, lat1, lon1, &e13, &n13);
@@ -830,7 +830,7 @@ static void tm_reduce(orc_adjustment* a, uint32_t t, const double* X1, const dou
     a->t_pre[t] = a->t_val[t];                                                    /* InitialiseMeasurement (ADJ:3928) */
     a->t_corr[t] = 0.0;
     switch (type) {
-        case 'A':
+        case 'A': case 'D':
             if (defl) {
                 double e12, n12, e13, n13;
                 double d12 = direction(X1, X2, lat1, lon1, &e12, &n12), d13 = direction(X1, X3, lat1, lon1, &e13, &n13);
@@ -886,6 +886,18 @@ static void tm_reduce(orc_adjustment* a, uint32_t t, const double* X1, const dou
     }
 }
 
+/* direction sets: set of terrestrial measurement t (type 'D'), offset of its k x k weight matrix */
+static uint32_t dset_of(const orc_adjustment* a, uint32_t t) {
+    uint32_t s = 0;
+    while (s + 1 < a->net.n_dsets && !(t >= a->net.dset_first[s] && t < a->net.dset_first[s] + a->net.dset_size[s])) ++s;
+    return s;
+}
+static size_t dset_woff(const orc_adjustment* a, uint32_t s) {
+    size_t o = 0;
+    for (uint32_t q = 0; q < s; ++q) o += (size_t)a->net.dset_size[q] * a->net.dset_size[q];
+    return o;
+}
+
 /* cml entry -> terrestrial measurement index, or -1 for a GNSS cluster */
 static inline int64_t tm_index(const orc_adjustment* a, uint32_t entry) { return entry >= a->n_clusters ? (int64_t)entry - a->n_clusters : -1; }
 static inline uint32_t entry_rows(const orc_adjustment* a, uint32_t entry) {
@@ -913,6 +925,31 @@ static void update_normals(orc_adjustment* a, blk_t* B) {
     for (uint32_t c = 0; c < B->n_cml; ++c) {
         uint32_t cl = B->cml[c];
         int64_t t = tm_index(a, cl);
+        if (t >= 0 && a->net.t_type[t] == 'D') {
+            /* UpdateAtVinv_D (ADJ:1328) + UpdateNormals_D (ADJ:1540): A^T W A over the whole set, W dense (LoadVarianceMatrix_D);
+             * the k angles of a set are consecutive entries, the set is added when its first angle comes up */
+            const uint32_t s0 = dset_of(a, (uint32_t)t);
+            if (a->net.dset_first[s0] == (uint32_t)t) {
+                const uint32_t k = a->net.dset_size[s0];
+                const double* Wd = a->net.dset_w + dset_woff(a, s0);
+                for (uint32_t x = 0; x < k; ++x)
+                    for (uint32_t y = 0; y < k; ++y) {
+                        const double w = Wd[x + (size_t)y * k];
+                        const double* rx = B->trow + 9 * (size_t)(trow + x);
+                        const double* ry = B->trow + 9 * (size_t)(trow + y);
+                        for (int p = 0; p < 3; ++p)
+                            for (int q = 0; q < 3; ++q) {
+                                const uint32_t lp = 3 * local_index(B, a->net.t_stn[3 * (size_t)(t + x) + p]);
+                                const uint32_t lq = 3 * local_index(B, a->net.t_stn[3 * (size_t)(t + y) + q]);
+                                for (int cc = 0; cc < 3; ++cc)
+                                    for (int r = 0; r < 3; ++r)
+                                        if (lp + r >= lq + cc) lower_add(B->N, B->n, lp + r, lq + cc, (w * rx[3 * p + r]) * ry[3 * q + cc]);
+                            }
+                    }
+            }
+            trow++;
+            continue;
+        }
         if (t >= 0) {
             const double* row = B->trow + 9 * (size_t)trow++;
             const double w = 1.0 / a->net.t_var[t];                               /* UpdateAtVinv (ADJ:1288) */
@@ -951,7 +988,7 @@ static void compute_b(orc_adjustment* a, blk_t* B, const double* est) {
             tm_evaluate(a, (uint32_t)t, X[0], X[1], X[2], &comp, B->trow + 9 * (size_t)trow++);
             double mmc = a->t_val[t] - comp;
             switch (a->net.t_type[t]) {
-                case 'A': case 'B': case 'K':
+                case 'A': case 'B': case 'D': case 'K':
                     if (mmc < -5.5) mmc += ORC_TWO_PI;
                     else if (mmc > 5.5) mmc -= ORC_TWO_PI;
                 default: break;
@@ -1102,6 +1139,21 @@ static int solve(orc_adjustment* a, blk_t* B, int compute_inverse, uint32_t bloc
     for (uint32_t c = 0; c < B->n_cml; ++c) {
         uint32_t cl = B->cml[c];
         int64_t t = tm_index(a, cl);
+        if (t >= 0 && a->net.t_type[t] == 'D') {
+            /* At_Vinv_m of a direction set: a_x^T sum_y W_xy b_y */
+            const uint32_t s0 = dset_of(a, (uint32_t)t);
+            const uint32_t first = a->net.dset_first[s0], k = a->net.dset_size[s0], x = (uint32_t)t - first;
+            const double* Wd = a->net.dset_w + dset_woff(a, s0);
+            double wb = 0.0;
+            for (uint32_t y = 0; y < k; ++y) wb += Wd[x + (size_t)y * k] * B->b[brow - x + y];
+            const double* row = B->trow + 9 * (size_t)trow++;
+            brow++;
+            for (int q = 0; q < 3; ++q) {
+                uint32_t l = 3 * local_index(B, a->net.t_stn[3 * (size_t)t + q]);
+                for (int r = 0; r < 3; ++r) rhs[l + r] += row[3 * q + r] * wb;
+            }
+            continue;
+        }
         if (t >= 0) {
             const double* row = B->trow + 9 * (size_t)trow++;
             const double wb = (1.0 / a->net.t_var[t]) * B->b[brow++];
@@ -1704,6 +1756,10 @@ int orc_adjust_statistics(orc_adjustment* a, double critical_value, orc_statisti
                     }
                     case 'H': case 'L': case 'V': adj -= a->t_corr[t]; break;
                     case 'A': case 'I': case 'J': case 'K': case 'Z': adj += a->t_corr[t]; break;
+                    case 'D':   /* UpdateMsrRecord (ADJ:8194-8199, 8255-8261) */
+                        if (adj > ORC_TWO_PI) adj -= ORC_TWO_PI;
+                        adj += a->t_corr[t];
+                        break;
                     default: break;
                 }
                 const double mp = net->t_var[t];

@@ -103,6 +103,13 @@ typedef struct {
     const double* stn_llh;     /* 3 per station: currentLatitude, currentLongitude, currentHeight (station_t) */
     const double* stn_geoid;   /* geoidSep */
     const double* stn_defl;    /* 2 per station: verticalDef (deflection in the prime vertical), meridianDef */
+    /* direction sets (type D): the angles between consecutive directions are terrestrial measurements of type 'D', consecutive
+     * in t_* and in the measurement lists; set s covers entries dset_first[s] .. + dset_size[s] - 1 and has the dense weight matrix
+     * dset_w (k x k, column-major, sets one after the other) = inverse of the variance matrix of the differences (ADJ:4059) */
+    uint32_t n_dsets;
+    const uint32_t* dset_first;
+    const uint32_t* dset_size;
+    const double* dset_w;
     const uint16_t* stn_type;  /* station_t::suppliedStationType (0 XYZ, 1 LLh, 2 LLH, 3 UTM): mixed constraint codes only; may be NULL */
 } orc_network;
 

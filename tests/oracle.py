@@ -18,7 +18,8 @@ class OrcNetwork(C.Structure):
                 ("isl_off", u32p), ("isl", u32p), ("jsl_off", u32p), ("jsl", u32p), ("cml_off", u32p), ("cml", u32p),
                 ("net_id", u32p), ("n_clusters", C.c_uint32), ("cluster_off", u32p), ("cluster_vcv", f64p),
                 ("n_tmsr", C.c_uint32), ("t_type", C.c_char_p), ("t_stn", u32p), ("t_value", f64p), ("t_var", f64p),
-                ("t_ih", f64p), ("t_th", f64p), ("stn_llh", f64p), ("stn_geoid", f64p), ("stn_defl", f64p), ("stn_type", C.POINTER(C.c_uint16))]
+                ("t_ih", f64p), ("t_th", f64p), ("stn_llh", f64p), ("stn_geoid", f64p), ("stn_defl", f64p),
+                ("n_dsets", C.c_uint32), ("dset_first", u32p), ("dset_size", u32p), ("dset_w", f64p), ("stn_type", C.POINTER(C.c_uint16))]
 
 
 class OrcSettings(C.Structure):
@@ -188,7 +189,7 @@ class Network:
         self._mdef = np.ascontiguousarray(bst["meridianDef"], dtype=np.float64)
         unit = lambda a: np.where(np.asarray(a) < 1e-6, 1.0, a)
         partial = any(np.any(np.abs(unit(bms[k]) - 1.0) > 1e-5) for k in ("scale1", "scale2", "scale3"))
-        terr = np.isin(bms["measType"], [bytes([c]) for c in TERRESTRIAL_TYPES])
+        terr = np.isin(bms["measType"], [bytes([c]) for c in TERRESTRIAL_TYPES + b"D"])
         self.n_tmsr = 0
         if np.all(bms["measType"] == b"G") and not partial and not np.any(terr):
             starts = np.nonzero((bms["measStart"] == 0) & (~bms["ignore"]))[0]
@@ -209,7 +210,8 @@ class Network:
             self.n_blocks = len(ISL)
             self.isl_off, self.isl = self._csr(ISL)
             self.jsl_off, self.jsl = self._csr(JSL)
-            cml_bl = [np.array([self.bl_of_record[int(m)] for m in c], dtype=np.uint32) for c in CML]
+            # (a direction set is one measurement of k angles: k consecutive entries)
+            cml_bl = [np.array([e for m in c for e in self._entries(int(m))], dtype=np.uint32) for c in CML]
             self.cml_off, self.cml = self._csr(cml_bl)
             self.net_id = np.ascontiguousarray(nets, dtype=np.uint32)
         else:
@@ -220,9 +222,13 @@ class Network:
             self.net_id = np.zeros(1, dtype=np.uint32)
             if self.n_tmsr:
                 # record order, like BuildSimultaneousLists of the facade
-                order = [self.bl_of_record[r] for r in sorted(self.bl_of_record)]
+                order = [e for r in sorted(self.bl_of_record) for e in self._entries(r)]
                 self.cml = np.asarray(order, dtype=np.uint32)
                 self.cml_off = np.asarray([0, len(order)], dtype=np.uint32)
+
+    def _entries(self, record):
+        e = self.bl_of_record[record]
+        return list(range(e[0], e[0] + e[1])) if isinstance(e, tuple) else [e]
 
     def _parse_clusters(self, bms):
         """G / X / Y records -> vectors + clusters: the .bms layout and the scaling / frame rules of
@@ -233,8 +239,44 @@ class Network:
         i, n = 0, len(bms)
         tiny = 1e-6                                   # min(PRECISION_1E5, fixed_std_dev)
         tm = {"type": [], "stn": [], "value": [], "var": [], "ih": [], "th": [], "record": []}
+        dsets, dset_records = [], {}
         while i < n:
             t = bytes(bms["measType"][i])
+            if t == b"D":
+                # direction set (UpdateDesignNormalMeasMatrices_D dnaadjust.cpp:5082, LoadVarianceMatrix_D :4059): the record of the
+                # reference direction + vectorCount1 - 1 direction records; angles between consecutive non-ignored directions,
+                # variance matrix of the differences of independent directions, derived values stored with the later direction
+                assert bms["measStart"][i] == 0
+                total = int(bms["vectorCount1"][i])
+                if bms["ignore"][i]:
+                    i += total
+                    continue
+                recs = [i] + [j for j in range(i + 1, i + total) if not bms["ignore"][j]]
+                k = len(recs) - 1
+                assert k >= 1 and int(bms["vectorCount2"][i]) == k + 1
+                first = len(tm["type"])
+                V = np.zeros((k, k))
+                for a in range(k):
+                    ra, rb = recs[a], recs[a + 1]
+                    ang = float(bms["term1"][rb]) - float(bms["term1"][ra])
+                    if ang < 0:
+                        ang += 2 * np.pi
+                    if ang > 2 * np.pi:
+                        ang -= 2 * np.pi
+                    V[a, a] = float(bms["term2"][ra]) + float(bms["term2"][rb])
+                    if a + 1 < k:
+                        V[a, a + 1] = V[a + 1, a] = -float(bms["term2"][rb])
+                    tm["type"].append(b"D")
+                    tm["stn"].append([int(bms["station1"][i]), int(bms["station2"][ra]), int(bms["station2"][rb])])
+                    tm["value"].append(ang)
+                    tm["var"].append(V[a, a])
+                    tm["ih"].append(float(bms["term3"][ra]))     # the angle's record is a copy of the earlier direction's
+                    tm["th"].append(float(bms["term4"][ra]))
+                    tm["record"].append(rb)
+                dsets.append((first, k, np.linalg.inv(V)))
+                dset_records[i] = (first, k)
+                i += total
+                continue
             if t[0] in TERRESTRIAL_TYPES:
                 assert bms["measStart"][i] == 0
                 if bms["ignore"][i]:                  # an ignored measurement is in no block's measurement list
@@ -331,7 +373,14 @@ class Network:
             self.t_th = np.asarray(tm["th"])
             self.t_record = np.asarray(tm["record"])
             for q, r in enumerate(tm["record"]):
-                self.bl_of_record[r] = self.n_clusters + q
+                if tm["type"][q] != b"D":
+                    self.bl_of_record[r] = self.n_clusters + q
+            for r, (first, k) in dset_records.items():
+                self.bl_of_record[r] = (self.n_clusters + first, k)
+            self.dset_first = np.asarray([d[0] for d in dsets] if dsets else [0], dtype=np.uint32)
+            self.dset_size = np.asarray([d[1] for d in dsets] if dsets else [0], dtype=np.uint32)
+            self.dset_w = np.ascontiguousarray(np.concatenate([d[2].ravel(order="F") for d in dsets])) if dsets else np.zeros(1)
+            self.n_dsets = len(dsets)
             if self.n_clusters == 0:
                 # the oracle tells clusters from terrestrial entries by n_clusters (or n_baselines)
                 self.cluster_off = np.zeros(1, dtype=np.uint32)
@@ -369,6 +418,9 @@ class Network:
         n.stn_llh = _p(self._llh_flat, f64p)
         n.stn_type = _p(self._stn_type, C.POINTER(C.c_uint16))
         if self.n_tmsr:
+            n.n_dsets = getattr(self, "n_dsets", 0)
+            if n.n_dsets:
+                n.dset_first, n.dset_size, n.dset_w = _p(self.dset_first, u32p), _p(self.dset_size, u32p), _p(self.dset_w, f64p)
             self._defl = np.ascontiguousarray(np.stack([self._vdef, self._mdef], axis=1)).ravel()
             n.t_type = self.t_type
             n.t_stn, n.t_value, n.t_var = _p(self.t_stn, u32p), _p(self.t_value, f64p), _p(self.t_var, f64p)

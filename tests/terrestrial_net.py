@@ -196,6 +196,34 @@ class Builder:
             if x is not None:
                 self.counts[x] += 1
 
+    def add_directions(self, inst, targets, sd=None):
+        """a direction set: one round of horizontal directions from `inst` with an unknown orientation of the circle.  What the
+        theodolite reads refers to the plumb line: geodetic azimuth + (xi sin az - eta cos az) cot z, plus the orientation"""
+        rng = self.rng
+        sec = math.pi / 648000.0
+        sd = sd or 2.0 * sec
+        dV, dM = self.vdef[inst], self.mdef[inst]
+        omega = rng.uniform(0.0, 2 * math.pi)
+        cid = self.cid
+        self.cid += 1
+        for j, t in enumerate(targets):
+            az = self.azimuth(inst, t)
+            z = self.zenith(inst, t, 0.0, 0.0)
+            v = (az + (dM * math.sin(az) - dV * math.cos(az)) / math.tan(z) + omega + sd * rng.standard_normal()) % (2 * math.pi)
+            r = self._rec("D", inst, t, 0, v, sd * sd, 0.0, 0.0, 2)
+            r["clusterID"] = cid
+            if j == 0:
+                r["measStart"] = 0
+                r["vectorCount1"] = len(targets)       # directions of the set, the first included
+                r["vectorCount2"] = len(targets)       # ... of which not ignored
+            else:
+                r["measStart"] = 1
+            self.recs.append(r)
+            self.owner.append(min([inst] + list(targets)))
+            self.counts[t] += 1
+        self.counts[inst] += 1
+        self.cid = cid + 1
+
     def add_baseline(self, s1, s2, sd=0.003):
         d = self.truth[s2] - self.truth[s1] + sd * self.rng.standard_normal(3)
         V = np.eye(3) * sd * sd
@@ -277,7 +305,9 @@ class Builder:
             k = strip(self.owner[i])
             CML[k].append(i)
             stns = [int(r["station1"])]
-            if r["measurementStations"] >= 2 and r["measType"] != b"Y":
+            if r["measType"] == b"D":
+                stns += [int(bms["station2"][i + j]) for j in range(int(r["vectorCount1"]))]
+            elif r["measurementStations"] >= 2 and r["measType"] != b"Y":
                 stns.append(int(r["station2"]))
             if r["measurementStations"] >= 3:
                 stns.append(int(r["station3"]))
@@ -322,6 +352,11 @@ def build_mixed_network(base, rows=6, cols=5, blocks=1, seed=1, types="SVZLHRBKA
             for ty in "HRIJPQ":
                 if ty in types and rng.random() < 0.4:
                     b.add(ty, s)
+            if "D" in types and len(nb) >= 2:
+                back = [x for x in (s - 1, s - cols) if x >= 0 and (x // cols == s // cols or x == s - cols) and (s // cols) - (x // cols) <= 0]
+                tg = nb + [x for x in back if x // cols == s // cols]      # neighbours of this and the next row only: two strips at most
+                rng.shuffle(tg)
+                b.add_directions(s, tg)
     for r in range(rows - 1):
         b.add_baseline(r * cols, (r + 1) * cols)
     for s in (0, cols - 1, (rows - 1) * cols, rows * cols - 1):

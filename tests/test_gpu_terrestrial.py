@@ -1,4 +1,4 @@
-"""Device path against the CPU oracle on mixed terrestrial + GNSS networks (types A B K C E M S V Z L H R I J P Q):
+"""Device path against the CPU oracle on mixed terrestrial + GNSS networks (types A B K C E M S V Z L H R I J P Q and direction sets D):
 coordinates within 1e-8 m... of a NON-linear problem iterated by both sides with the same rules, variances within 1e-8
 relative, statistics, geodetic station records; one chain, two chains, phased and simultaneous."""
 import numpy as np
@@ -43,6 +43,9 @@ def _compare(a, st, o, ost, tol_x=1e-8, tol_v=1e-8, row_noise=0.0):
     (5, 4, 1, False, False, "SVZLHRBKACEM"),
     (6, 5, 3, True, False, "SVZLHRBKACEMIJPQ"),
     (5, 5, 2, True, False, "SLIJPQ"),
+    (5, 4, 1, False, False, "SLD"),
+    (6, 5, 3, True, False, "SLVD"),
+    (8, 5, 4, True, True, "SVZLHRBKACEMD"),
     (8, 5, 4, True, True, "SVZLHRBKACEMIJPQ"),
 ])
 def test_terrestrial_parity_with_oracle(built, orc, tmp_path, rows, cols, blocks, phased, mt, types):

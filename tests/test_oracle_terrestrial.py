@@ -202,3 +202,140 @@ def test_reference_urban_sample(orc, golden_dir, tmp_path, phased):
     vec_of_record = {int(r): int(net.cluster_off[c]) for r, c in net.bl_of_record.items() if c < net.n_clusters}
     _check_urban_tables(rep, stations, msrs, first_of, net.t_record, bs, be, sd, a.tmsr_fields(), f, vec_of_record)
     a.close()
+
+
+# ---- direction sets (type D) ---------------------------------------------------------------------------------------------
+def _azimuth(X1, X2, lat, lon):
+    """independent of the oracle: geodetic azimuth of X1 -> X2 in the local frame at (lat, lon)"""
+    e, n, _ = T.enu_axes(lat, lon)
+    d = np.asarray(X2) - np.asarray(X1)
+    return np.arctan2(d @ e, d @ n)
+
+
+def test_direction_set_normals_equal_the_orientation_model(orc, tmp_path):
+    """The reference turns a round of k+1 directions into k angles between consecutive directions with the tridiagonal variance
+    matrix of the differences (UpdateDesignNormalMeasMatrices_D / LoadVarianceMatrix_D).  That must be the classical model --
+    every direction an azimuth plus one common orientation unknown -- with the orientation eliminated:
+        A^T W A = G^T S^-1 G - (G^T S^-1 1)(1^T S^-1 G) / (1^T S^-1 1),   G = rows of the azimuth derivatives.
+    A (the oracle's design rows) and W (the harness' restatement of LoadVarianceMatrix_D) against G by central differences."""
+    b, (bst, bms) = T.build_mixed_network(str(tmp_path / "d"), 4, 4, 1, seed=5, types="SLD")
+    net, a, st = _run(orc, str(tmp_path / "d"), False, max_iterations=1)
+    assert net.n_dsets >= 4
+    woff = 0
+    for s in range(net.n_dsets):
+        first, k = int(net.dset_first[s]), int(net.dset_size[s])
+        W = net.dset_w[woff:woff + k * k].reshape(k, k, order="F")
+        woff += k * k
+        stn = [net.t_stn[3 * (first + x):3 * (first + x) + 3] for x in range(k)]
+        inst = int(stn[0][0])
+        targets = [int(stn[0][1])] + [int(stn[x][2]) for x in range(k)]
+        assert all(int(stn[x][1]) == targets[x] and int(stn[x][0]) == inst for x in range(k))
+        order = [inst] + sorted(set(targets))
+        col = {g: 3 * i for i, g in enumerate(order)}
+        n = 3 * len(order)
+        A = np.zeros((k, n))
+        for x in range(k):
+            X = np.concatenate([b.init[g] for g in stn[x]])
+            _, row = a.tmsr_evaluate(first + x, X)
+            for q in range(3):
+                A[x, col[int(stn[x][q])]:col[int(stn[x][q])] + 3] += row[3 * q:3 * q + 3]
+        lat, lon = bst["currentLatitude"][inst], bst["currentLongitude"][inst]
+        G = np.zeros((k + 1, n))
+        for i, t in enumerate(targets):
+            for which, g in ((0, inst), (1, t)):
+                for c in range(3):
+                    P = [b.init[inst].copy(), b.init[t].copy()]
+                    P[which][c] += 1e-3
+                    up = _azimuth(P[0], P[1], lat, lon)
+                    P[which][c] -= 2e-3
+                    dn = _azimuth(P[0], P[1], lat, lon)
+                    G[i, col[g] + c] += (up - dn) / 2e-3
+        recs = [r for r in range(len(bms)) if bms["measType"][r] == b"D" and int(bms["station1"][r]) == inst and int(bms["clusterID"][r]) == int(bms["clusterID"][net.t_record[first]])]
+        Sinv = np.diag(1.0 / bms["term2"][recs])
+        one = np.ones(k + 1)
+        lhs = A.T @ W @ A
+        rhs = G.T @ Sinv @ G - np.outer(G.T @ Sinv @ one, one @ Sinv @ G) / (one @ Sinv @ one)
+        assert np.abs(lhs - rhs).max() < 2e-6 * np.abs(rhs).max(), (s, np.abs(lhs - rhs).max() / np.abs(rhs).max())
+    a.close()
+
+
+@pytest.mark.parametrize("types,seed", [("SLD", 7), ("SLD", 8), ("SVZLHRBKACEMD", 3)])
+def test_direction_sets_recover_the_truth(orc, tmp_path, types, seed):
+    b, _ = T.build_mixed_network(str(tmp_path / "n"), 5, 4, 1, seed=seed, types=types)
+    net, a, st = _run(orc, str(tmp_path / "n"), False)
+    assert st == 0 and net.n_dsets > 5
+    assert np.abs(a.block_estimates(0).reshape(-1, 3) - b.truth).max() < 0.02
+    s, f = a.statistics()
+    assert 0.55 < s.sigma_zero < 1.6, s.sigma_zero
+    a.close()
+
+
+def test_two_direction_set_is_an_angle(orc, tmp_path):
+    """a set of two directions is one horizontal angle with the summed variance: same adjustment as the 'A' measurement"""
+    from tests import dnaformats as F
+    b = T.Builder(4, 4, 1, seed=2)
+    for s in range(16):
+        for t in (s + 1, s + 4):
+            if t < 16 and (t != s + 1 or (s + 1) % 4):
+                b.add("S", s, t, ih=1.5, th=1.5)
+                b.add("L", s, t)
+    pairs = [(5, 1, 6), (6, 2, 10), (9, 5, 13), (10, 6, 11), (1, 0, 5)]
+    for inst, t0, t1 in pairs:
+        b.add_directions(inst, [t0, t1])
+    for s in (0, 3, 12, 15):
+        b.add_point(s)
+    bst, bms = b.write(str(tmp_path / "d"))
+    # the same observations as angles
+    recs = []
+    i = 0
+    while i < len(bms):
+        r = bms[i:i + 1].copy()
+        if r["measType"][0] == b"D":
+            nxt = bms[i + 1]
+            ang = (float(nxt["term1"]) - float(r["term1"][0])) % (2 * np.pi)
+            r["measType"] = b"A"
+            r["station3"] = nxt["station2"]
+            r["measurementStations"] = 3
+            r["term1"] = r["preAdjMeas"] = ang
+            r["term2"] = float(r["term2"][0]) + float(nxt["term2"])
+            r["vectorCount1"] = r["vectorCount2"] = 0
+            recs.append(r)
+            i += 2
+            continue
+        recs.append(r)
+        i += 1
+    bms2 = np.zeros(len(recs), dtype=F.MEASUREMENT_DT)
+    for q, r in enumerate(recs):
+        bms2[q] = r[0]
+    F.write_bst(str(tmp_path / "a.bst"), bst)
+    F.write_bms(str(tmp_path / "a.bms"), bms2)
+    import shutil
+    shutil.copy(str(tmp_path / "d.asl"), str(tmp_path / "a.asl"))
+    nd, ad, sd_ = _run(orc, str(tmp_path / "d"), False)
+    na, aa, sa = _run(orc, str(tmp_path / "a"), False)
+    assert sd_ == 0 and sa == 0 and ad.iterations() == aa.iterations()
+    assert np.abs(ad.block_estimates(0) - aa.block_estimates(0)).max() < 1e-9
+    Vd, Va = ad.block_variances(0), aa.block_variances(0)
+    assert np.abs(Vd - Va).max() < 1e-9 * np.abs(Va).max()
+    s1, _ = ad.statistics()
+    s2, _ = aa.statistics()
+    assert abs(s1.chi_squared - s2.chi_squared) < 1e-8 * s2.chi_squared and s1.dof == s2.dof
+    ad.close()
+    aa.close()
+
+
+@pytest.mark.parametrize("blocks", [2, 3])
+def test_phased_is_rigorous_with_direction_sets(orc, tmp_path, blocks):
+    b, _ = T.build_mixed_network(str(tmp_path / "p"), 6, 4, blocks, seed=13, types="SLVD")
+    ns, s, st_s = _run(orc, str(tmp_path / "p"), False)
+    npn, p, st_p = _run(orc, str(tmp_path / "p"), True)
+    assert st_s == 0 and st_p == 0
+    xs = s.block_estimates(0).reshape(-1, 3)
+    for k in range(p.n_blocks):
+        stn = p.block_stations(k)
+        assert np.abs(p.block_estimates(k).reshape(-1, 3) - xs[stn]).max() < 2e-6
+    ss, _ = s.statistics()
+    sp, _ = p.statistics()
+    assert abs(ss.chi_squared - sp.chi_squared) < 1e-3 * ss.chi_squared and ss.dof == sp.dof
+    s.close()
+    p.close()
