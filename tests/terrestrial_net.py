@@ -206,18 +206,24 @@ class Builder:
         omega = rng.uniform(0.0, 2 * math.pi)
         cid = self.cid
         self.cid += 1
+        # now and then one direction of a larger round is flagged "ignore" (a blunder far off its true value): the set then
+        # skips it (dnaadjust.cpp:5119-5130) and vectorCount2 counts the others
+        dropped = int(rng.integers(1, len(targets))) if (len(targets) >= 4 and rng.random() < 0.5) else -1
         for j, t in enumerate(targets):
             az = self.azimuth(inst, t)
             z = self.zenith(inst, t, 0.0, 0.0)
             v = (az + (dM * math.sin(az) - dV * math.cos(az)) / math.tan(z) + omega + sd * rng.standard_normal()) % (2 * math.pi)
+            if j == dropped:
+                v = (v + 0.3) % (2 * math.pi)
             r = self._rec("D", inst, t, 0, v, sd * sd, 0.0, 0.0, 2)
             r["clusterID"] = cid
             if j == 0:
                 r["measStart"] = 0
-                r["vectorCount1"] = len(targets)       # directions of the set, the first included
-                r["vectorCount2"] = len(targets)       # ... of which not ignored
+                r["vectorCount1"] = len(targets)                            # directions of the set, the first included
+                r["vectorCount2"] = len(targets) - (1 if dropped > 0 else 0)   # ... of which not ignored
             else:
                 r["measStart"] = 1
+                r["ignore"] = j == dropped
             self.recs.append(r)
             self.owner.append(min([inst] + list(targets)))
             self.counts[t] += 1

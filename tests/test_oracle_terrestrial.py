@@ -250,7 +250,9 @@ def test_direction_set_normals_equal_the_orientation_model(orc, tmp_path):
                     P[which][c] -= 2e-3
                     dn = _azimuth(P[0], P[1], lat, lon)
                     G[i, col[g] + c] += (up - dn) / 2e-3
-        recs = [r for r in range(len(bms)) if bms["measType"][r] == b"D" and int(bms["station1"][r]) == inst and int(bms["clusterID"][r]) == int(bms["clusterID"][net.t_record[first]])]
+        recs = [r for r in range(len(bms)) if bms["measType"][r] == b"D" and not bms["ignore"][r] and
+                int(bms["clusterID"][r]) == int(bms["clusterID"][net.t_record[first]])]
+        assert [int(bms["station2"][r]) for r in recs] == targets           # (ignored directions are skipped)
         Sinv = np.diag(1.0 / bms["term2"][recs])
         one = np.ones(k + 1)
         lhs = A.T @ W @ A
