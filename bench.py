@@ -265,7 +265,7 @@ def main():
             "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses),
             "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
             "completions_per_step": a.completion_count(), "parallelism": "1 GPU, one chain" if not p.multi_thread else
-            "1 GPU, two chains (the reference's --multi-thread schedule: forward || reverse passes on two streams, combination solves shared)",
+            "1 GPU, %s chains (multi_thread: the independent block steps of the condensed schedule are served by every chain; the two junction chains run side by side)" % os.environ.get("DNAGPU_CHAINS", "4"),
         },
         "cholesky_tflops": (alg / 1e12) / (ms_per_step / 1e3),
         # the same wall time priced at the reference's own work (n^3 for each of its Solve() calls): what a CPU or GPU

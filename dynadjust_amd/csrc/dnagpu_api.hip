@@ -125,11 +125,13 @@ Block* find_block(dnagpu_ctx* ctx, uint32_t blk) {
 }
 
 void free_block(Block& b) {
-    void* ptrs[] = {b.x_orig, b.x_est[0], b.x_est[1], b.x_rig, b.rhs[0], b.rhs[1], b.corr[0], b.corr[1], b.s1, b.s2, b.obs, b.Wblk,
-                    b.vec_wrow, b.vec_c0, b.vec_k, b.wb[0], b.wb[1],
-                    b.b[0], b.b[1], b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc, b.red[0], b.red[1],
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c)
+        for (void* p : {(void*)b.x_est[c], (void*)b.rhs[c], (void*)b.corr[c], (void*)b.wb[c], (void*)b.b[c], (void*)b.red[c], (void*)b.tb[c], (void*)b.trow[c]})
+            if (p) hipFree(p);
+    void* ptrs[] = {b.x_orig, b.x_rig, b.s1, b.s2, b.obs, b.Wblk,
+                    b.vec_wrow, b.vec_c0, b.vec_k, b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc,
                     b.t_type, b.t_stn, b.t_blk0, b.t_vec0, b.t_val, b.t_pre, b.t_var, b.t_ih, b.t_th, b.s_llh, b.s_geoid, b.s_defl,
-                    b.tb[0], b.tb[1], b.trow[0], b.trow[1], b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1]};
+                    b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     b = Block();
@@ -590,8 +592,11 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
         nv += (uint32_t)ns;
     }
     for (void* p : {(void*)b->t_type, (void*)b->t_stn, (void*)b->t_blk0, (void*)b->t_vec0, (void*)b->t_val, (void*)b->t_pre, (void*)b->t_var,
-                    (void*)b->t_ih, (void*)b->t_th, (void*)b->tb[0], (void*)b->tb[1], (void*)b->trow[0], (void*)b->trow[1]})
+                    (void*)b->t_ih, (void*)b->t_th})
         if (p) hipFree(p);
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c)
+        for (void* p : {(void*)b->tb[c], (void*)b->trow[c]})
+            if (p) hipFree(p);
     b->t_type = nullptr;
     b->t_stn = b->t_blk0 = b->t_vec0 = nullptr;
     b->t_val = b->t_pre = b->t_var = b->t_ih = b->t_th = nullptr;

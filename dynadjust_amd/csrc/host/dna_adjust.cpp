@@ -582,7 +582,7 @@ void dna_adjust::PrepareBlocks() {
         ctx_ = nullptr;
         SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
     }
-    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    const int chains = NumChains();
     for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, max_unknowns_, &work_[c]), 0, "PrepareAdjustment(): work matrix");
 
     for (UINT32 b = 0; b < blockCount_; ++b) {
@@ -691,6 +691,7 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     adjustStatus_ = ADJUST_SUCCESS;
     FreeDevice();
     projectSettings_ = projectSettings;
+    if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
     if (projectSettings_.a.stage) projectSettings_.a.stage = 0;   // HBM replaces the staged (memory mapped) mode
     // InitialiseAdjustment (ADJ:232-245)
     var_C_ = projectSettings_.a.fixed_std_dev * projectSettings_.a.fixed_std_dev;
@@ -832,7 +833,7 @@ void dna_adjust::ValidateandFinaliseAdjustment() {
 void dna_adjust::UpdateAdjustment(bool iterate) {
     isPreparing_ = true;
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
-    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    const int chains = NumChains();
     for (UINT32 b = 0; b < blockCount_; ++b) {
         if (IsCancelled()) break;
         if (phased && v_blockMeta_[b]._blockLast) {
@@ -915,7 +916,7 @@ void dna_adjust::GetAdjustedCoordinates(std::vector<double>& xyz) {
 void dna_adjust::ResetAdjustment() {
     if (!ctx_) SignalExceptionAdjustment("ResetAdjustment(): PrepareAdjustment() has not been called.", 0);
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
-    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    const int chains = NumChains();
     for (UINT32 b = 0; b < blockCount_; ++b) {
         Check(dnagpu_block_set_stations(ctx_, b, initial_xyz_[b].data()), b, "ResetAdjustment()");
         for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "ResetAdjustment()");

@@ -233,6 +233,10 @@ private:
     // changes).  With the condensed schedule and kept factors that is CondensedReuse(): later iterations only reduce right-hand
     // sides, run the chains on the condensed blocks and multiply by the resident rigorous variances.  Otherwise ReuseInverses():
     // the reference's schedule with one resident inverse per block step.
+    // device chains (stream + workspaces) in use: one, or with a.multi_thread DNAGPU_NUM_CHAINS (the independent block steps of
+    // the condensed schedule are served by all of them; cfg3: 4.07 / 3.96 / 3.88 s per step with 2 / 3 / 4; DNAGPU_CHAINS overrides)
+    int NumChains() const { return (projectSettings_.a.adjust_mode != SimultaneousMode && projectSettings_.a.multi_thread) ? mt_chains_ : 1; }
+    int mt_chains_ = DNAGPU_NUM_CHAINS;
     bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
     bool CondensedWanted() const { return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity; }
     bool ReuseInverses() const { return ReuseRequested() && !(CondensedWanted() && projectSettings_.a.keep_factors != 0); }

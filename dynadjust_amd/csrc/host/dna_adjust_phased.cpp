@@ -420,7 +420,7 @@ void dna_adjust::PrepareCondensedBlocks() {
     auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
     double later = 8.0e9;
     for (UINT32 k = 0; k < blockCount_; ++k) later += sq(3.0 * (double)v_parameterStationList_[k].size());
-    later += 3.0 * (projectSettings_.a.multi_thread ? 2.0 : 1.0) * sq((double)max_unknowns_);
+    later += 3.0 * (double)NumChains() * sq((double)max_unknowns_);
     double budget = (double)free_b - later;
     for (UINT32 k = 0; k < blockCount_; ++k) {
         block_t& B = blocks_[k];
@@ -432,7 +432,7 @@ void dna_adjust::PrepareCondensedBlocks() {
         B.part_allowed = true;
         max_keep = std::max(max_keep, B.keep.size());
     }
-    const int chains = projectSettings_.a.multi_thread ? 2 : 1;
+    const int chains = NumChains();
     if (max_keep)
         for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &kwork_[c]), 0, "PrepareAdjustment(): kept-block work matrix");
 }
@@ -546,7 +546,8 @@ double dna_adjust::RigorousBlock(int c, UINT32 k) {
 
 // body(chain) on every chain in use (a.multi_thread: two host threads, one per chain); the first exception is rethrown
 void dna_adjust::OnEveryChain(const std::function<void(int)>& body) {
-    if (!projectSettings_.a.multi_thread) {
+    const int chains = NumChains();
+    if (chains == 1) {
         body(0);
         return;
     }
@@ -562,9 +563,10 @@ void dna_adjust::OnEveryChain(const std::function<void(int)>& body) {
         }
     };
     chain_failed_ = false;
-    std::thread other([&] { guarded(1); });
+    std::vector<std::thread> others;
+    for (int c = 1; c < chains; ++c) others.emplace_back([&guarded, c] { guarded(c); });
     guarded(0);
-    other.join();
+    for (std::thread& t : others) t.join();
     if (error) std::rethrow_exception(error);
 }
 
@@ -593,7 +595,7 @@ void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks) {
 
 // the forward chain on chain 0 beside the reverse chain on chain 1 (one after the other without a.multi_thread)
 void dna_adjust::CondensedChains() {
-    const bool two = projectSettings_.a.multi_thread != 0;
+    const bool two = NumChains() > 1;
     OnEveryChain([&](int c) {
         if (c == 0)
             for (UINT32 k = 0; k < blockCount_ && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
@@ -685,7 +687,7 @@ void dna_adjust::SetBlockStationsAll(UINT32 k, const double* xyz) {
 
 void dna_adjust::RecomputeMeasMinusComp(UINT32 k) {
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
-    const int chains = (phased && projectSettings_.a.multi_thread) ? 2 : 1;
+    const int chains = NumChains();
     for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, k), k, "FillDesignNormalMeasurementsMatrices()");
 }
 

@@ -405,7 +405,7 @@ def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank,
         # the flop counters restart with every step (ResetAdjustment), the event time accumulates over the timed steps
         achieved = (float(allv[busiest][0]) / 1e12) / (gemm_ms / args.steps / 1e3) if gemm_ms > 0 else 0.0
         par = (f"condensed schedule: blocks condensed and solved rigorously on their owner rank ({be.n_blocks} blocks over {world} ranks, "
-               f"{'two chains' if p.multi_thread else 'one chain'} per GPU), condensed systems broadcast over RCCL, chains on the condensed "
+               f"{os.environ.get('DNAGPU_CHAINS', '4') + ' chains' if p.multi_thread else 'one chain'} per GPU), condensed systems broadcast over RCCL, chains on the condensed "
                "blocks on every rank") if condensed else (
                f"forward chain on rank 0, reverse chain on rank 1, combination solves round-robin over {world} ranks; "
                "junction matrices point-to-point over RCCL")

@@ -55,7 +55,7 @@ typedef struct dnagpu_ctx dnagpu_ctx;
 #define DNAGPU_ENOTPOSDEF (-4) /* dpotrf-style failure; column in dnagpu_last_info() */
 #define DNAGPU_ENODEVICE (-5)
 
-#define DNAGPU_NUM_CHAINS 2
+#define DNAGPU_NUM_CHAINS 4
 
 /* ---- context ------------------------------------------------------------ */
 int dnagpu_create(int device, dnagpu_ctx** out);
