@@ -205,6 +205,13 @@ def load():
     _sig(lib, "dnaadj_phased_rigorous_blocks", i, [vp, c_u32p, sz])
     _sig(lib, "dnaadj_condensed_export", i, [vp, u32, vp])
     _sig(lib, "dnaadj_condensed_import", i, [vp, u32, vp])
+    _sig(lib, "dnaadj_statistics_prepare", i, [vp])
+    _sig(lib, "dnaadj_statistics_blocks", i, [vp, c_u32p, sz])
+    _sig(lib, "dnaadj_statistics_get_partial", i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)])
+    _sig(lib, "dnaadj_statistics_set_partial", i, [vp, C.c_double, u32])
+    _sig(lib, "dnaadj_record_statistics_get", i, [vp, c_f64p, C.c_uint64])
+    _sig(lib, "dnaadj_record_statistics_set", i, [vp, c_f64p, C.c_uint64])
+    _sig(lib, "dnaadj_statistics_finish", i, [vp])
     _sig(lib, "dnaadj_junction_export", i, [vp, i, u32, vp])
     _sig(lib, "dnaadj_junction_import", i, [vp, i, u32, vp])
     _sig(lib, "dnaadj_block_get_coords", i, [vp, u32, i, c_f64p])
@@ -248,7 +255,9 @@ EXPORTED_DNAADJ = [
     "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_condensed_schedule", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
     "dnaadj_phased_condensed_forward", "dnaadj_phased_condensed_reverse", "dnaadj_phased_rigorous_block", "dnaadj_phased_condense_blocks", "dnaadj_phased_condensed_chains",
     "dnaadj_phased_rigorous_blocks", "dnaadj_condensed_export",
-    "dnaadj_condensed_import", "dnaadj_junction_export",
+    "dnaadj_condensed_import", "dnaadj_statistics_prepare", "dnaadj_statistics_blocks", "dnaadj_statistics_get_partial",
+    "dnaadj_statistics_set_partial", "dnaadj_record_statistics_get", "dnaadj_record_statistics_set", "dnaadj_statistics_finish",
+    "dnaadj_junction_export",
     "dnaadj_junction_import", "dnaadj_block_get_coords", "dnaadj_block_set_coords", "dnaadj_block_recompute_b",
     "dnasynth_write_network", "dnaio_file_summary", "dnaio_seg_summary", "dnaio_sizeof_station", "dnaio_sizeof_measurement",
 ]

@@ -948,19 +948,57 @@ void dna_adjust::GenerateStatistics() {
                                 std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
 }
 
+// Exchange of the per-record results between processes: 9 doubles per record -- touched (1 / 0), measAdj, measCorr, measAdjPrec,
+// residualPrec, NStat, PelzerRel, preAdjCorr, term1 -- zero for records this process did not compute, so that a sum over the
+// processes holds every record once
+void dna_adjust::GetRecordStatistics(double* out9) const {
+    for (size_t i = 0; i < bmsBinaryRecords_.size(); ++i) {
+        double* o = out9 + 9 * i;
+        const measurement_t& r = bmsBinaryRecords_[i];
+        const bool t = i < record_touched_.size() && record_touched_[i];
+        const double v[9] = {1.0, r.measAdj, r.measCorr, r.measAdjPrec, r.residualPrec, r.NStat, r.PelzerRel, r.preAdjCorr, r.term1};
+        for (int q = 0; q < 9; ++q) o[q] = t ? v[q] : 0.0;
+    }
+}
+void dna_adjust::SetRecordStatistics(const double* in9) {
+    record_touched_.assign(bmsBinaryRecords_.size(), 0);
+    for (size_t i = 0; i < bmsBinaryRecords_.size(); ++i) {
+        const double* v = in9 + 9 * i;
+        if (v[0] < 0.5) continue;
+        measurement_t& r = bmsBinaryRecords_[i];
+        r.measAdj = v[1]; r.measCorr = v[2]; r.measAdjPrec = v[3]; r.residualPrec = v[4];
+        r.NStat = v[5]; r.PelzerRel = v[6]; r.preAdjCorr = v[7]; r.term1 = v[8];
+        record_touched_[i] = 1;
+    }
+}
+
 // ADJ:7116-7147 for GNSS measurements.  The per-vector gathers from the rigorous variances (still resident in HBM)
 // and the W.b products run on the device (dnagpu_block_msr_statistics); the O(measurements) scalar bookkeeping of
 // UpdateMsrRecord (ADJ:8187) happens here on the records held in memory.
 void dna_adjust::ComputeStatistics() {
-    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
+    StatisticsBegin();
+    for (UINT32 b = 0; b < blockCount_; ++b) StatisticsBlock(b);
+    StatisticsFinish();
+}
+
+// The three parts of ComputeStatistics, separately callable so that one process per GPU can each do the blocks whose rigorous
+// variances it holds (dynadjust_amd/parallel.py, distributed_statistics): per-run initialisation ...
+void dna_adjust::StatisticsBegin() {
     // critical value of the normal distribution for the outlier flag (InitialiseAdjustment, ADJ:203-206)
     double conf = projectSettings_.a.confidence_interval * 0.01;
     conf += (1.0 - conf) / 2.0;
     criticalValue_ = stat::normal_quantile(conf);
     potentialOutlierCount_ = 0;
+    chiSquared_ = 0.0;
+    record_touched_.assign(bmsBinaryRecords_.size(), 0);
+}
+
+// ... one block: precisions of the adjusted measurements from its rigorous variances, the per-record statistics, its chi-square terms ...
+void dna_adjust::StatisticsBlock(UINT32 b) {
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
     double chiSquared = 0.0;
     std::vector<double> prec6, chi, bvec;
-    for (UINT32 b = 0; b < blockCount_; ++b) {
+    {
         block_t& B = blocks_[b];
         const size_t nv = B.stn1.size();
         dnagpu_matrix* var = phased ? (B.has_rigvar ? B.rigvar : nullptr) : work_[0];
@@ -1055,7 +1093,12 @@ void dna_adjust::ComputeStatistics() {
         }
         chiSquared += cs;
     }
-    chiSquared_ = chiSquared;                                                        // ComputeChiSquareNetwork (ADJ:7315)
+    chiSquared_ += chiSquared;                                                       // ComputeChiSquareNetwork (ADJ:7315)
+}
+
+// ... and what needs every record and the network's chi-square: sigma zero, T statistics, global Pelzer reliability, the global test
+void dna_adjust::StatisticsFinish() {
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
     // ComputeGlobalNetStat (ADJ:6854)
     degreesofFreedom_ = (int)measurementParams_ - (int)unknownParams_;
     sigmaZero_ = sigmaZeroSqRt_ = 0.0;
@@ -1101,6 +1144,8 @@ void dna_adjust::ComputeStatistics() {
 
 // UpdateMsrRecord (ADJ:8187) + UpdateMsrRecordStats (ADJ:8291) for one X / Y / Z element of a GNSS measurement
 void dna_adjust::UpdateMsrRecord(measurement_t& rec, double measCorr, double measAdjPrec, double measPrec) {
+    const size_t index = (size_t)(&rec - bmsBinaryRecords_.data());
+    if (index < record_touched_.size()) record_touched_[index] = 1;
     rec.measCorr = measCorr;
     rec.measAdj = rec.term1 + rec.measCorr;
     rec.measAdjPrec = measAdjPrec;

@@ -199,6 +199,17 @@ public:
     size_t CondensedPayloadDoubles(UINT32 k) const;
     void ExportCondensed(UINT32 k, double* dst);
     void ImportCondensed(UINT32 k, const double* src);
+    // ---- GenerateStatistics in parts (one process per GPU: every process does the blocks whose rigorous variances it holds) ----
+    void StatisticsPrepare() { UpdateAdjustment(false); StatisticsBegin(); }
+    void StatisticsBegin();
+    void StatisticsBlock(UINT32 block);
+    void StatisticsFinish();
+    double PartialChiSquared() const { return chiSquared_; }
+    UINT32 PartialOutlierCount() const { return potentialOutlierCount_; }
+    void SetPartials(double chi_squared, UINT32 outliers) { chiSquared_ = chi_squared; potentialOutlierCount_ = outliers; }
+    size_t RecordCount() const { return bmsBinaryRecords_.size(); }
+    void GetRecordStatistics(double* out9) const;
+    void SetRecordStatistics(const double* in9);
     // start of an iteration on this process: maxCorr = 0 (+ iteration counter)
     void PhasedBeginIteration();
     void PhasedNoteCorrection(double mv);   // maxCorr_ update rule of ADJ:3036 / ADJ:3786
@@ -246,6 +257,7 @@ private:
     void CompleteFromPartial(int chain, UINT32 block, int kind, dnagpu_matrix* W);
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
     bool condensed_ok_ = false;
+    std::vector<unsigned char> record_touched_;   // records whose statistics this process computed (UpdateMsrRecord)
     std::atomic<bool> chain_failed_{false};
     void OnEveryChain(const std::function<void(int)>& body);
     void ForBlocks(const std::vector<UINT32>& blocks, const std::function<void(int, UINT32)>& step);

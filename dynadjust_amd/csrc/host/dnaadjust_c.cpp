@@ -391,6 +391,29 @@ int dnaadj_condensed_export(dnaadj_handle* h, uint32_t block, double* buf) {
 int dnaadj_condensed_import(dnaadj_handle* h, uint32_t block, const double* buf) {
     return guarded(h, [&] { h->adj->ImportCondensed(block, buf); });
 }
+int dnaadj_statistics_prepare(dnaadj_handle* h) { return guarded(h, [&] { h->adj->StatisticsPrepare(); }); }
+int dnaadj_statistics_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n) {
+    return guarded(h, [&] { for (size_t i = 0; i < n; ++i) h->adj->StatisticsBlock(blocks[i]); });
+}
+int dnaadj_statistics_get_partial(const dnaadj_handle* h, double* chi_squared, uint32_t* outliers) {
+    if (!h || !h->adj) return DNAADJ_EINVAL;
+    if (chi_squared) *chi_squared = h->adj->PartialChiSquared();
+    if (outliers) *outliers = h->adj->PartialOutlierCount();
+    return DNAADJ_OK;
+}
+int dnaadj_statistics_set_partial(dnaadj_handle* h, double chi_squared, uint32_t outliers) {
+    return guarded(h, [&] { h->adj->SetPartials(chi_squared, outliers); });
+}
+int dnaadj_record_statistics_get(const dnaadj_handle* h, double* out9, uint64_t cap_records) {
+    if (!h || !h->adj || !out9 || cap_records < h->adj->RecordCount()) return DNAADJ_EINVAL;
+    h->adj->GetRecordStatistics(out9);
+    return DNAADJ_OK;
+}
+int dnaadj_record_statistics_set(dnaadj_handle* h, const double* in9, uint64_t n_records) {
+    if (!h || !h->adj || !in9 || n_records != h->adj->RecordCount()) return DNAADJ_EINVAL;
+    return guarded(h, [&] { h->adj->SetRecordStatistics(in9); });
+}
+int dnaadj_statistics_finish(dnaadj_handle* h) { return guarded(h, [&] { h->adj->StatisticsFinish(); }); }
 int dnaadj_junction_export(dnaadj_handle* h, int kind, uint32_t block, double* buf) {
     return guarded(h, [&] { h->adj->ExportJunction(kind, block, buf); });
 }

@@ -240,6 +240,32 @@ def _sync_coordinates(backend, dist, rank, world, owner_of, offs, dev):
         backend.note_correction(float(c.item()))
 
 
+def distributed_statistics(backend, dist, rank, world, owner_of):
+    """dna_adjust::GenerateStatistics when the rigorous variances are spread over the ranks: every rank computes the precisions
+    of the adjusted measurements, the per-record statistics and the chi-square terms of the blocks it owns; one all_reduce(sum)
+    of (chi-square, outliers) and one of the per-record arrays give every rank the whole picture; the global figures follow."""
+    import torch
+    adj = backend.adj
+    lib, h = backend.lib, backend.h
+    backend._chk(lib.dnaadj_statistics_prepare(h))
+    mine = np.ascontiguousarray([k for k in range(backend.n_blocks) if owner_of(k) == rank], dtype=np.uint32)
+    backend._chk(lib.dnaadj_statistics_blocks(h, mine.ctypes.data_as(C.POINTER(C.c_uint32)), mine.size))
+    if world > 1:
+        chi, out = C.c_double(), C.c_uint32()
+        lib.dnaadj_statistics_get_partial(h, C.byref(chi), C.byref(out))
+        n = adj.lib.dnaadj_measurement_record_count(h)
+        rec = np.zeros((n, 9), dtype=np.float64)
+        backend._chk(lib.dnaadj_record_statistics_get(h, rec.ctypes.data_as(C.POINTER(C.c_double)), n))
+        dev = backend.comm_device
+        t = torch.from_numpy(np.concatenate([[chi.value, float(out.value)], rec.ravel()])).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        a = t.cpu().numpy()
+        backend._chk(lib.dnaadj_statistics_set_partial(h, float(a[0]), int(round(a[1]))))
+        rec = np.ascontiguousarray(a[2:].reshape(n, 9))
+        backend._chk(lib.dnaadj_record_statistics_set(h, rec.ctypes.data_as(C.POINTER(C.c_double)), n))
+    backend._chk(lib.dnaadj_statistics_finish(h))
+
+
 def run_phased_condensed(backend, dist, rank, world, max_iterations=10):
     """the condensed schedule across `world` ranks; returns (status, iterations, per-iteration corrections, owners)"""
     B = backend.n_blocks

@@ -152,6 +152,18 @@ int dnaadj_phased_condensed_chains(dnaadj_handle* h);
 int dnaadj_phased_rigorous_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n);
 int dnaadj_condensed_export(dnaadj_handle* h, uint32_t block, double* buf);
 int dnaadj_condensed_import(dnaadj_handle* h, uint32_t block, const double* buf);
+/* GenerateStatistics across processes (each holds the rigorous variances of its own blocks): _prepare on every process;
+ * _blocks(own blocks); sum the partial chi-square / outlier counts and the per-record arrays (9 doubles per .bms record:
+ * touched, measAdj, measCorr, measAdjPrec, residualPrec, NStat, PelzerRel, preAdjCorr, term1; zero where not computed here) over
+ * the processes and hand the sums back (_set_partial, _record_statistics_set); _finish on every process.  Afterwards the
+ * getters of dnaadj_get_statistics / dnaadj_measurement_records answer as after dnaadj_generate_statistics on one process. */
+int dnaadj_statistics_prepare(dnaadj_handle* h);
+int dnaadj_statistics_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n);
+int dnaadj_statistics_get_partial(const dnaadj_handle* h, double* chi_squared, uint32_t* outliers);
+int dnaadj_statistics_set_partial(dnaadj_handle* h, double chi_squared, uint32_t outliers);
+int dnaadj_record_statistics_get(const dnaadj_handle* h, double* out9, uint64_t cap_records);
+int dnaadj_record_statistics_set(dnaadj_handle* h, const double* in9, uint64_t n_records);
+int dnaadj_statistics_finish(dnaadj_handle* h);
 int dnaadj_junction_export(dnaadj_handle* h, int kind, uint32_t block, double* buf);
 int dnaadj_junction_import(dnaadj_handle* h, int kind, uint32_t block, const double* buf);
 /* which: 0 original, 1 estimated, 2 rigorous */

@@ -240,6 +240,12 @@ def _two_rank_worker(rank, world, port, folder, outdir, schur):
     else:
         final_owner = parallel.PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world).final_owner
     res = {"status": st, "iterations": its}
+    # GenerateStatistics with the rigorous variances spread over the ranks
+    parallel.distributed_statistics(be, dist, rank, world, final_owner)
+    a = be.adj
+    res["stats"] = np.array([a.GetChiSquared(), a.GetSigmaZero(), a.GetGlobalPelzerRel(), float(a.GetPotentialOutlierCount()),
+                             float(a.GetDegreesOfFreedom()), float(a.GetTestResult())])
+    res["records"] = np.frombuffer(a.measurement_records().tobytes(), dtype=np.uint8)
     for k in range(be.n_blocks):
         res[f"coords_{k}"] = be.get_coords(k)
         if final_owner(k) == rank:
@@ -267,9 +273,21 @@ def test_orchestrator_two_ranks_device_backend(built, orc, tmp_path, schur):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), str(tmp_path), schur), nprocs=2, join=True)
+    # one process, the facade's own GenerateStatistics
+    f, st_f = _device_run(str(tmp_path), "n", True, schur_carry=schur)
+    f.GenerateStatistics()
+    fstats = np.array([f.GetChiSquared(), f.GetSigmaZero(), f.GetGlobalPelzerRel(), float(f.GetPotentialOutlierCount()),
+                       float(f.GetDegreesOfFreedom()), float(f.GetTestResult())])
+    frec = np.frombuffer(f.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
+    f.close()
     seen = set()
     for r in range(2):
         res = np.load(str(tmp_path / f"rank{r}.npz"))
+        # every rank ends with the whole network's statistics and every record's fields
+        assert np.abs(res["stats"] - fstats).max() < 1e-9 * max(1.0, np.abs(fstats).max())
+        rrec = np.frombuffer(res["records"].tobytes(), dtype=F.MEASUREMENT_DT)
+        for nm in ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel"):
+            assert np.abs(rrec[nm] - frec[nm]).max() <= 1e-9 * max(1.0, np.abs(frec[nm]).max()), nm
         assert int(res["status"]) == ost and int(res["iterations"]) == o.iterations()
         for k in range(6):
             assert np.abs(res[f"coords_{k}"] - o.block_estimates(k)).max() < TOL_X
