@@ -29,6 +29,10 @@ WORKLOADS = {
     # name: (rows, cols, baselines, blocks, phased, description)
     "cfg3": (316, 317, 266666, 16, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, 16 blocks"),
     "cfg2": (100, 100, 26666, 1, False, "synthetic 10k-station / 80k-measurement network, simultaneous adjustment"),
+    # BASELINE.json configs[3]: needs the rigorous variances of 128 blocks of n ~ 27 000 (0.75 TB): 4 or more GPUs
+    "cfg4": (1000, 1000, 2666666, 128, True, "synthetic 1M-station / 8M-measurement network, phased adjustment, 128 blocks"),
+    # 16 of cfg4's 128 strips: the same block size (n ~ 27 000, 1000-station junction rows) on one GPU
+    "cfg4_slice": (125, 1000, 333333, 16, True, "synthetic 125k-station / 1M-measurement network, phased adjustment, 16 blocks of cfg4's size"),
     "small": (60, 60, 9600, 4, True, "synthetic 3.6k-station / 28.8k-measurement network, phased adjustment, 4 blocks (smoke size)"),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk)
