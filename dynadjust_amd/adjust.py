@@ -13,6 +13,7 @@ from ._lib import DnaAdjSettings, DnaAdjStatistics, DnaSynthSpec, DnaSynthSummar
 
 SimultaneousMode = 0
 PhasedMode = 1
+Phased_Block_1Mode = 2
 
 ADJUST_SUCCESS = 0
 ADJUST_MAX_ITERATIONS_EXCEEDED = 1

@@ -774,6 +774,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     switch (projectSettings_.a.adjust_mode) {
         case SimultaneousMode: AdjustSimultaneous(); break;
         case PhasedMode: AdjustPhased(); break;
+        case Phased_Block_1Mode: AdjustPhasedBlock1(); break;
         default: SignalExceptionAdjustment("AdjustNetwork(): Unknown adjustment type", 0);
     }
     Check(dnagpu_sync(ctx_), 0, "AdjustNetwork()");
@@ -854,6 +855,30 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
     // no further iterations: the station records take the adjusted coordinates (ADJ:496-531, ADJ:541-545)
     if (!iterate && !IsCancelled()) UpdateGeographicCoords();
     isPreparing_ = false;
+}
+
+// AdjustPhasedBlock1 (ADJ:2675): one reverse pass (AdjustPhasedReverse, ADJ:3594) -- every block solved in isolation with the
+// junctions carried from the blocks after it, so that the first block of the network comes out rigorous; the other blocks
+// keep the estimates and variances of their reverse solve (UpdateEstimatesFinal is called for all of them, ADJ:3667)
+void dna_adjust::AdjustPhasedBlock1() {
+    currentIteration_ = 1;
+    maxCorr_ = 0.0;
+    forward_ = false;
+    double first_corr = 0.0;
+    for (UINT32 kk = blockCount_; kk-- > 0;) {
+        if (IsCancelled()) break;
+        const UINT32 k = kk;
+        currentBlock_ = k;
+        if (v_blockMeta_[k]._blockIsolated) continue;          // PrepareAdjustmentReverse: nothing to do for a single block
+        const double mv = PhasedReverseBlock(0, k);
+        if (k == 0) first_corr = mv;
+        PhasedFinaliseBlock(0, k);
+    }
+    maxCorr_ = first_corr;                                      // "largest correction for block 1 only" (ADJ:2705)
+    iterationCorrections_.push_back(maxCorr_);
+    if (std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold) adjustStatus_ = ADJUST_THRESHOLD_EXCEEDED;
+    if (!IsCancelled()) UpdateGeographicCoords();
+    ValidateandFinaliseAdjustment();
 }
 
 // ADJ:2579-2670

@@ -165,6 +165,7 @@ private:
 
     void AdjustSimultaneous();           // ADJ:2413
     void AdjustPhased();                 // ADJ:2579
+    void AdjustPhasedBlock1();           // ADJ:2675
     void AdjustPhasedForward();          // ADJ:2756
     void AdjustPhasedReverseCombine();   // ADJ:3461
     void AdjustPhasedMultiThreadIteration();   // dnaadjust-multi.cpp:92-244 (forward || reverse chains)
@@ -249,7 +250,9 @@ private:
     int NumChains() const { return (projectSettings_.a.adjust_mode != SimultaneousMode && projectSettings_.a.multi_thread) ? mt_chains_ : 1; }
     int mt_chains_ = DNAGPU_NUM_CHAINS;
     bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
-    bool CondensedWanted() const { return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity; }
+    bool CondensedWanted() const {
+        return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity && projectSettings_.a.adjust_mode == PhasedMode;
+    }
     bool ReuseInverses() const { return ReuseRequested() && !(CondensedWanted() && projectSettings_.a.keep_factors != 0); }
     bool SchurCarry() const { return CondensedWanted() && !ReuseInverses(); }
     bool CondensedReuse() const { return ReuseRequested() && CondensedSchedule() && projectSettings_.a.keep_factors != 0; }
@@ -284,7 +287,8 @@ private:
     std::vector<std::vector<double>> initial_xyz_;   // per block, for ResetAdjustment
 
     UINT32 blockCount_ = 1;
-    UINT32 currentBlock_ = 0, currentIteration_ = 0;
+    std::atomic<UINT32> currentBlock_{0};   // written by every chain's thread, read by the progress thread (CurrentBlock())
+    UINT32 currentIteration_ = 0;
     bool isPreparing_ = false, isAdjusting_ = false, forward_ = true, isCombining_ = false;
     bool allStationsFixed_ = false, exceptionRaised_ = false;
     std::atomic<bool> cancel_{false};

@@ -547,3 +547,23 @@ def test_condensed_reuse_across_iterations(built, tmp_path, mt):
     for b in range(B):
         assert np.abs(x0[b] - x1[b]).max() < 1e-9
         assert np.array_equal(v0[b], v1[b])                     # the very inverse of iteration 1
+
+
+def test_phased_block_1_mode(built, tmp_path):
+    """Phased_Block_1Mode (AdjustPhasedBlock1, dnaadjust.cpp:2675): one reverse pass; block 1 is rigorous -- exactly what the first
+    iteration of the full phased adjustment gives it -- the other blocks keep their reverse solution"""
+    adjust.write_synthetic_network(str(tmp_path), "b", 24, 10, 0, 4, seed=6, x_clusters=8)
+    p = adjust.ProjectSettings("b", str(tmp_path), adjust_mode=adjust.Phased_Block_1Mode)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    st = a.AdjustNetwork()
+    assert a.CurrentIteration() == 1 and st in (adjust.ADJUST_SUCCESS, adjust.ADJUST_THRESHOLD_EXCEEDED)
+    f, st_f = _device_run(str(tmp_path), "b", True, max_iterations=1, schur_carry=False)
+    assert np.array_equal(a.block_estimates(0), f.block_estimates(0))
+    assert np.array_equal(a.block_variances_packed(0), f.block_variances_packed(0))
+    assert abs(a.GetMaxCorrection()) > 0.0
+    # the last block's reverse solution has not seen the other blocks: it differs from the rigorous one
+    last = a.blockCount() - 1
+    assert np.abs(a.block_estimates(last) - f.block_estimates(last)).max() > 1e-6
+    a.close()
+    f.close()
