@@ -178,6 +178,7 @@ def load():
     _sig(lib, "dnaadj_block_prec_adj_msrs_count", u64, [vp, u32])
     _sig(lib, "dnaadj_block_prec_adj_msrs", i, [vp, u32, c_f64p, u64])
     _sig(lib, "dnaadj_serialise_adjusted_variance_matrices", i, [vp])
+    _sig(lib, "dnaadj_deserialise_adjusted_variance_matrices", i, [vp])
     _sig(lib, "dnaadj_update_binary_files", i, [vp])
     _sig(lib, "dnastat_normal_quantile", C.c_double, [C.c_double])
     _sig(lib, "dnastat_chi_squared_quantile", C.c_double, [C.c_double, C.c_double])
@@ -249,7 +250,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
     "dnaadj_generate_statistics", "dnaadj_get_statistics", "dnaadj_measurement_record_count", "dnaadj_measurement_records",
     "dnaadj_block_prec_adj_msrs_count", "dnaadj_block_prec_adj_msrs", "dnaadj_serialise_adjusted_variance_matrices",
-    "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",
+    "dnaadj_deserialise_adjusted_variance_matrices", "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",
     "dnaadj_block_flags", "dnaadj_junction_unknowns", "dnaadj_junction_payload_doubles", "dnaadj_phased_begin_iteration",
     "dnaadj_phased_forward_block", "dnaadj_phased_reverse_block", "dnaadj_phased_combine_block", "dnaadj_phased_finalise_block",
     "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_condensed_schedule", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",

@@ -183,6 +183,9 @@ class DnaAdjust:
         """<output_folder>/<network_name>-rva.mtx and -pam.mtx (dnaadjust.cpp:6770)"""
         self._chk(self.lib.dnaadj_serialise_adjusted_variance_matrices(self.h))
 
+    def DeSerialiseAdjustedVarianceMatrices(self):
+        self._chk(self.lib.dnaadj_deserialise_adjusted_variance_matrices(self.h))
+
     def UpdateBinaryFiles(self):
         """rewrites the .bst / .bms with the adjusted values (dnaadjust.cpp:445)"""
         self._chk(self.lib.dnaadj_update_binary_files(self.h))

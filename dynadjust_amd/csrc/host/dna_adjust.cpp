@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
 #include <sstream>
 
 #include "geodesy.hpp"
@@ -888,6 +889,7 @@ void dna_adjust::AdjustPhased() {
         if (IsCancelled()) break;
         maxCorr_ = 0.0;
         ++currentIteration_;
+        const double it_t0 = now_ms();
         if (CondensedSchedule()) {
             AdjustPhasedCondensedIteration();
         } else if (projectSettings_.a.multi_thread) {
@@ -899,6 +901,7 @@ void dna_adjust::AdjustPhased() {
         }
         if (IsCancelled()) break;
         iterationCorrections_.push_back(maxCorr_);
+        NoteIterationDone(it_t0);
         bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
         if (!iterate) break;
         UpdateAdjustment(iterate);
@@ -1262,6 +1265,77 @@ void dna_adjust::SerialiseAdjustedVarianceMatrices() {
         write_mtx_trailer(pam);
     }
     if (!rva || !pam) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): write failed", 0);
+}
+
+// ADJ:6720-6767: the inverse of SerialiseAdjustedVarianceMatrices -- `dnaadjust --report-results` prints an earlier adjustment
+// from these files without adjusting again.  PrepareAdjustment must have run (block sizes, device blocks).
+void dna_adjust::DeSerialiseAdjustedVarianceMatrices() {
+    if (!ctx_) SignalExceptionAdjustment("DeSerialiseAdjustedVarianceMatrices(): PrepareAdjustment() has not been called.", 0);
+    const std::string folder = projectSettings_.a.stage_path.empty() ? projectSettings_.g.output_folder : projectSettings_.a.stage_path;
+    const std::string base = folder + "/" + projectSettings_.g.network_name + "-";
+    std::ifstream rva(base + "rva.mtx", std::ios::in | std::ios::binary);
+    std::ifstream pam(base + "pam.mtx", std::ios::in | std::ios::binary);
+    if (!rva || !pam) SignalExceptionAdjustment("DeSerialiseAdjustedVarianceMatrices(): cannot open " + base + "rva.mtx / pam.mtx", 0);
+    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
+    std::vector<double> packed;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        UINT32 hdr[6], tail[2];
+        const UINT32 n = (UINT32)v_parameterStationList_[b].size() * 3;
+        rva.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
+        if (!rva || hdr[0] != 1 || hdr[1] != n || hdr[2] != n)
+            SignalExceptionAdjustment("DeSerialiseAdjustedVarianceMatrices(): " + base + "rva.mtx does not match the dimensions of the network.", b);
+        packed.resize((size_t)n * (n + 1) / 2);
+        rva.read(reinterpret_cast<char*>(packed.data()), (std::streamsize)(packed.size() * sizeof(double)));
+        rva.read(reinterpret_cast<char*>(tail), sizeof(tail));
+        dnagpu_matrix** slot = phased ? &blocks_[b].rigvar : &work_[0];
+        if (!*slot) Check(dnagpu_matrix_create(ctx_, n, slot), b, "rigorous variance matrix");
+        Check(dnagpu_matrix_upload_packed(ctx_, 0, *slot, packed.data(), n), b, "DeSerialiseAdjustedVarianceMatrices()");
+        blocks_[b].has_rigvar = true;
+        pam.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
+        const UINT32 rows = (UINT32)(6 * blocks_[b].stn1.size() + blocks_[b].t_type.size());
+        if (!pam || hdr[0] != 0 || hdr[1] != rows || hdr[2] != 1)
+            SignalExceptionAdjustment("DeSerialiseAdjustedVarianceMatrices(): " + base + "pam.mtx does not match the dimensions of the network.", b);
+        blocks_[b].prec_adj_msrs.resize(rows);
+        pam.read(reinterpret_cast<char*>(blocks_[b].prec_adj_msrs.data()), (std::streamsize)(rows * sizeof(double)));
+        pam.read(reinterpret_cast<char*>(tail), sizeof(tail));
+        if (!rva || !pam) SignalExceptionAdjustment("DeSerialiseAdjustedVarianceMatrices(): read failed", b);
+    }
+}
+
+// ADJ:10628: the number of blocks of a segmentation file, before anything is prepared
+void dna_adjust::LoadSegmentationFileParameters(const std::string& seg_filename) {
+    try {
+        iostreams::seg_data_t seg;
+        iostreams::read_seg(seg_filename, seg, nullptr);
+        blockCount_ = seg.blockCount;
+    } catch (const std::runtime_error& e) {
+        SignalExceptionAdjustment(e.what(), 0);
+    }
+}
+
+void dna_adjust::NoteIterationDone(double t0_ms) {
+    std::lock_guard<std::mutex> lk(msg_mutex_);
+    if (iterationMs_.size() < currentIteration_) iterationMs_.resize(currentIteration_, 0.0);
+    iterationMs_[currentIteration_ - 1] = now_ms() - t0_ms;
+    iterationQueue_.push_back(currentIteration_);
+}
+
+bool dna_adjust::NewMessagesAvailable() {
+    std::lock_guard<std::mutex> lk(msg_mutex_);
+    return !iterationQueue_.empty();
+}
+bool dna_adjust::GetMessageIteration(UINT32& iteration) {
+    std::lock_guard<std::mutex> lk(msg_mutex_);
+    if (iterationQueue_.empty()) return false;
+    iteration = iterationQueue_.front();
+    iterationQueue_.pop_front();
+    return true;
+}
+std::string dna_adjust::GetIterationTime(const UINT32& iteration) const {
+    if (iteration == 0 || iteration > iterationMs_.size()) return std::string();
+    std::stringstream ss;
+    ss << std::fixed << std::setprecision(3) << iterationMs_[iteration - 1] / 1000.0 << "s";
+    return ss.str();
 }
 
 // ADJ:445-470: the station and measurement records (adjusted coordinates, adjusted measurements and their

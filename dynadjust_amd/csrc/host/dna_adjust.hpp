@@ -5,6 +5,7 @@
 // (include/dnagpu.h); this class only schedules blocks and keeps host-side metadata.
 #pragma once
 #include <atomic>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -78,6 +79,17 @@ public:
     inline bool GetAllFixed() const { return allStationsFixed_; }
     inline bool ExceptionRaised() const { return exceptionRaised_; }
     inline double adjustTime() const { return adjust_ms_; }
+    // progress-thread interface of dnaadjustprogress.cpp: iterations finished since the last poll, their wall times
+    // (iterationQueue_ / iterationTimes_ in the reference, dnaadjust.hpp:364-380)
+    bool NewMessagesAvailable();
+    bool GetMessageIteration(UINT32& iteration);
+    std::string GetIterationTime(const UINT32& iteration) const;
+    inline int64_t LastBlockElapsedMs() const { return lastBlockElapsedMs_; }
+    inline void SetExceptionRaised() { exceptionRaised_ = true; }                  // dnaadjust.hpp:271
+    void LoadSegmentationFileParameters(const std::string& seg_filename);           // ADJ:10628: block count of a .seg file
+    void DeSerialiseAdjustedVarianceMatrices();                                     // ADJ:6720: -rva.mtx / -pam.mtx back into the blocks
+    void NoteIterationDone(double t0_ms);
+    void CloseOutputFiles() {}                                                      // the report streams belong to the reference's printer
     inline UINT32 CurrentBlockStationCount() const {
         return currentBlock_ < v_parameterStationList_.size() ? (UINT32)v_parameterStationList_[currentBlock_].size() : 0;
     }
@@ -303,6 +315,10 @@ private:
     double var_C_ = 0.0, var_F_ = 0.0;
     std::vector<double> iterationCorrections_;
     double adjust_ms_ = 0.0;
+    std::atomic<int64_t> lastBlockElapsedMs_{0};
+    std::mutex msg_mutex_;
+    std::deque<UINT32> iterationQueue_;
+    std::vector<double> iterationMs_;
     double solve_flops_ = 0.0;
     UINT32 solve_count_ = 0;
     double algorithmic_flops_ = 0.0;  // n^3 per inverse, the elimination's own count per dnagpu_schur_carry step

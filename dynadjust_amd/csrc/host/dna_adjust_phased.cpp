@@ -4,6 +4,7 @@
 //                                                        (reference dnaadjust-multi.cpp:92-244, 365-641)
 //   the multi-GPU orchestrator (dynadjust_amd/parallel.py) calls the same steps through include/dnaadjust_c.h
 // Reference functions restated per step are cited at each function (ADJ = dynadjust/dnaadjust/dnaadjust.cpp).
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
@@ -583,7 +584,9 @@ void dna_adjust::ForBlocks(const std::vector<UINT32>& blocks, const std::functio
                 k = blocks[next++];
             }
             currentBlock_ = k;
+            const auto t0 = std::chrono::steady_clock::now();
             step(c, k);
+            lastBlockElapsedMs_ = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
         }
     });
 }

@@ -159,6 +159,9 @@ int dnaadj_serialise_adjusted_variance_matrices(dnaadj_handle* h) {
     return guarded(h, [&] { h->adj->SerialiseAdjustedVarianceMatrices(); });
 }
 
+int dnaadj_deserialise_adjusted_variance_matrices(dnaadj_handle* h) {
+    return guarded(h, [&] { h->adj->DeSerialiseAdjustedVarianceMatrices(); });
+}
 int dnaadj_update_binary_files(dnaadj_handle* h) {
     return guarded(h, [&] { h->adj->UpdateBinaryFiles(); });
 }

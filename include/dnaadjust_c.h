@@ -111,6 +111,7 @@ int dnaadj_measurement_records(const dnaadj_handle* h, void* records, uint64_t c
 uint64_t dnaadj_block_prec_adj_msrs_count(const dnaadj_handle* h, uint32_t block);
 int dnaadj_block_prec_adj_msrs(const dnaadj_handle* h, uint32_t block, double* out, uint64_t cap);
 int dnaadj_serialise_adjusted_variance_matrices(dnaadj_handle* h);         /* SerialiseAdjustedVarianceMatrices (dnaadjust.cpp:6770) */
+int dnaadj_deserialise_adjusted_variance_matrices(dnaadj_handle* h);       /* DeSerialiseAdjustedVarianceMatrices (dnaadjust.cpp:6720) */
 int dnaadj_update_binary_files(dnaadj_handle* h);                          /* UpdateBinaryFiles (dnaadjust.cpp:445) */
 
 /* quantiles used by the global test (the reference takes them from boost::math, dnaadjust.cpp:203-206, :6866-6880) */

@@ -567,3 +567,32 @@ def test_phased_block_1_mode(built, tmp_path):
     assert np.abs(a.block_estimates(last) - f.block_estimates(last)).max() > 1e-6
     a.close()
     f.close()
+
+
+def test_deserialise_adjusted_variance_matrices(built, tmp_path):
+    """-rva.mtx / -pam.mtx written by one adjustment and read back by another dna_adjust (dnaadjust --report-results,
+    DeSerialiseAdjustedVarianceMatrices dnaadjust.cpp:6720)"""
+    adjust.write_synthetic_network(str(tmp_path), "s", 14, 9, 0, 3, seed=12, x_clusters=6)
+    a, st = _device_run(str(tmp_path), "s", True)
+    a.GenerateStatistics()
+    a.SerialiseAdjustedVarianceMatrices()
+    v = [a.block_variances_packed(b) for b in range(a.blockCount())]
+    p = [a.block_prec_adj_msrs(b) for b in range(a.blockCount())]
+    a.close()
+    b = adjust.DnaAdjust()
+    b.PrepareAdjustment(adjust.ProjectSettings("s", str(tmp_path), adjust_mode=adjust.PhasedMode))
+    b.DeSerialiseAdjustedVarianceMatrices()
+    for k in range(b.blockCount()):
+        assert np.array_equal(b.block_variances_packed(k), v[k])
+        assert np.array_equal(b.block_prec_adj_msrs(k), p[k])
+    b.close()
+    # files of another network are refused
+    adjust.write_synthetic_network(str(tmp_path), "t", 10, 9, 0, 3, seed=12)
+    os.replace(str(tmp_path / "s-rva.mtx"), str(tmp_path / "t-rva.mtx"))
+    os.replace(str(tmp_path / "s-pam.mtx"), str(tmp_path / "t-pam.mtx"))
+    c = adjust.DnaAdjust()
+    c.PrepareAdjustment(adjust.ProjectSettings("t", str(tmp_path), adjust_mode=adjust.PhasedMode))
+    with pytest.raises(adjust.NetAdjustException) as e:
+        c.DeSerialiseAdjustedVarianceMatrices()
+    assert "does not match the dimensions" in str(e.value)
+    c.close()
