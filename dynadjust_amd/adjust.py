@@ -34,7 +34,7 @@ class ProjectSettings:
     def __init__(self, network_name=None, folder=".", adjust_mode=SimultaneousMode, multi_thread=False,
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
                  scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None,
-                 reuse_inverses=False, schur_carry=True, keep_factors=True):
+                 reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
         self.network_name = network_name          # g.network_name
         self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
@@ -42,6 +42,7 @@ class ProjectSettings:
         self.output_tstat = output_tstat          # o._adj_msr_tstat
         self.reuse_inverses = reuse_inverses      # device path only: block inverses stay resident across iterations
         self.schur_carry = schur_carry            # device path only: carry-only steps eliminate instead of inverting
+        self.stage = stage                        # a.stage: rigorous variances in page-locked host memory
         self.keep_factors = keep_factors          # device path only: rigorous solves complete the condensing step's factor
         if network_name is not None:
             self.set_filenames(os.path.join(folder, network_name))
@@ -102,6 +103,7 @@ class DnaAdjust:
         s.reuse_inverses = int(bool(getattr(p, "reuse_inverses", False)))
         s.schur_carry = int(bool(getattr(p, "schur_carry", True)))
         s.keep_factors = int(bool(getattr(p, "keep_factors", True)))
+        s.stage = int(bool(getattr(p, "stage", False)))
         s.adjust_mode = int(p.adjust_mode)
         s.multi_thread = int(bool(p.multi_thread))
         s.max_iterations = int(p.max_iterations)

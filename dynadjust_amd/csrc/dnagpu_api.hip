@@ -222,6 +222,20 @@ void dnagpu_destroy(dnagpu_ctx* ctx) {
 const char* dnagpu_last_error(const dnagpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int dnagpu_last_info(const dnagpu_ctx* ctx) { return ctx ? ctx->last_info : 0; }
 
+int dnagpu_host_alloc(dnagpu_ctx* ctx, size_t bytes, void** out) {
+    CHK_CTX();
+    if (!out) return fail(ctx, DNAGPU_EINVAL, "host_alloc: null out");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 8);
+    if (e != hipSuccess) return fail(ctx, DNAGPU_ENOMEM, "page-locked host allocation", e);
+    return DNAGPU_OK;
+}
+void dnagpu_host_free(dnagpu_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx) hipSetDevice(ctx->device);
+    hipHostFree(p);
+}
+
 int dnagpu_mem_info(dnagpu_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
     CHK_CTX();
     size_t f = 0, t = 0;

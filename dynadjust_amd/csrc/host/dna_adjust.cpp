@@ -38,6 +38,8 @@ void dna_adjust::FreeDevice() {
         if (b.finv) dnagpu_matrix_destroy(ctx_, b.finv);
         if (b.rinv) dnagpu_matrix_destroy(ctx_, b.rinv);
         if (b.red) dnagpu_matrix_destroy(ctx_, b.red);
+        if (b.rig_host) dnagpu_host_free(ctx_, b.rig_host);
+        b.rig_host = nullptr;
         if (b.part) dnagpu_partial_destroy(ctx_, b.part);
         b.part = nullptr;
         b.jfwd = b.jrev = b.rigvar = b.finv = b.rinv = b.red = nullptr;
@@ -679,6 +681,7 @@ void dna_adjust::PrepareBlocks() {
             // v_rigorousVariances_ is allocated when the block is finalised (only on the rank / chain that owns it)
         }
     }
+    DecideStaging();
     PrepareCondensedBlocks();
     Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
 }
@@ -693,7 +696,7 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     FreeDevice();
     projectSettings_ = projectSettings;
     if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
-    if (projectSettings_.a.stage) projectSettings_.a.stage = 0;   // HBM replaces the staged (memory mapped) mode
+    staged_ = projectSettings_.a.stage != 0;   // staged: rigorous variances in page-locked host memory (PrepareCondensedBlocks may switch it on)
     // InitialiseAdjustment (ADJ:232-245)
     var_C_ = projectSettings_.a.fixed_std_dev * projectSettings_.a.fixed_std_dev;
     var_F_ = projectSettings_.a.free_std_dev * projectSettings_.a.free_std_dev;
@@ -919,6 +922,10 @@ void dna_adjust::GetBlockRigorousVariancesPacked(UINT32 block, std::vector<doubl
     if (!ctx_ || block >= blockCount_) throw std::runtime_error("GetBlockRigorousVariancesPacked(): no such block");
     size_t n = 3 * v_parameterStationList_[block].size();
     packed.resize(n * (n + 1) / 2);
+    if (projectSettings_.a.adjust_mode != SimultaneousMode && Staged() && blocks_[block].rig_host && blocks_[block].has_rigvar) {
+        memcpy(packed.data(), blocks_[block].rig_host, packed.size() * sizeof(double));
+        return;
+    }
     dnagpu_matrix* m = (projectSettings_.a.adjust_mode == SimultaneousMode) ? work_[0] : blocks_[block].rigvar;
     if (!m) throw std::runtime_error("GetBlockRigorousVariancesPacked(): this process holds no rigorous variances for the block");
     Check(dnagpu_matrix_download_packed(ctx_, 0, m, packed.data()), block, "GetBlockRigorousVariancesPacked()");
@@ -1030,6 +1037,12 @@ void dna_adjust::StatisticsBlock(UINT32 b) {
         block_t& B = blocks_[b];
         const size_t nv = B.stn1.size();
         dnagpu_matrix* var = phased ? (B.has_rigvar ? B.rigvar : nullptr) : work_[0];
+        if (phased && Staged() && B.has_rigvar && B.rig_host) {
+            // staged: the block's rigorous variances come back from host memory into the work matrix (lower triangle: all the
+            // statistics kernels read)
+            var = work_[0];
+            Check(dnagpu_matrix_upload_packed(ctx_, 0, var, B.rig_host, (UINT32)v_parameterStationList_[b].size() * 3), b, "ComputePrecisionAdjMsrs()");
+        }
         if (!var) SignalExceptionAdjustment("ComputePrecisionAdjMsrs(): this process holds no rigorous variances for the block.", b);
         prec6.assign(6 * nv + 1, 0.0);
         chi.assign(nv + 1, 0.0);
@@ -1287,9 +1300,15 @@ void dna_adjust::DeSerialiseAdjustedVarianceMatrices() {
         packed.resize((size_t)n * (n + 1) / 2);
         rva.read(reinterpret_cast<char*>(packed.data()), (std::streamsize)(packed.size() * sizeof(double)));
         rva.read(reinterpret_cast<char*>(tail), sizeof(tail));
-        dnagpu_matrix** slot = phased ? &blocks_[b].rigvar : &work_[0];
-        if (!*slot) Check(dnagpu_matrix_create(ctx_, n, slot), b, "rigorous variance matrix");
-        Check(dnagpu_matrix_upload_packed(ctx_, 0, *slot, packed.data(), n), b, "DeSerialiseAdjustedVarianceMatrices()");
+        if (phased && Staged()) {
+            if (!blocks_[b].rig_host)
+                Check(dnagpu_host_alloc(ctx_, packed.size() * sizeof(double), (void**)&blocks_[b].rig_host), b, "rigorous variance matrix (host)");
+            memcpy(blocks_[b].rig_host, packed.data(), packed.size() * sizeof(double));
+        } else {
+            dnagpu_matrix** slot = phased ? &blocks_[b].rigvar : &work_[0];
+            if (!*slot) Check(dnagpu_matrix_create(ctx_, n, slot), b, "rigorous variance matrix");
+            Check(dnagpu_matrix_upload_packed(ctx_, 0, *slot, packed.data(), n), b, "DeSerialiseAdjustedVarianceMatrices()");
+        }
         blocks_[b].has_rigvar = true;
         pam.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
         const UINT32 rows = (UINT32)(6 * blocks_[b].stn1.size() + blocks_[b].t_type.size());

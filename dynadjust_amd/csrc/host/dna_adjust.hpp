@@ -137,6 +137,7 @@ private:
         dnagpu_matrix* jfwd = nullptr;        // v_junctionVariancesFwd_ + v_junctionEstimatesFwd_
         dnagpu_matrix* jrev = nullptr;        // v_junctionVariances_ (reverse) + v_junctionEstimatesRev_
         dnagpu_matrix* rigvar = nullptr;      // v_rigorousVariances_
+        double* rig_host = nullptr;           // staged: v_rigorousVariances_ packed (lower, column-major) in page-locked host memory
         bool has_rigvar = false;
         // a.reuse_inverses: the inverse of the forward / reverse normals of this block (the combined one is rigvar)
         dnagpu_matrix* finv = nullptr;
@@ -183,6 +184,7 @@ private:
     void AdjustPhasedMultiThreadIteration();   // dnaadjust-multi.cpp:92-244 (forward || reverse chains)
     void AdjustPhasedCondensedIteration();     // a.schur_carry: condense every block, chains on the condensed blocks, rigorous solves
     void PrepareCondensedBlocks();
+    void DecideStaging();
 public:
     // ---- per-block steps of the phased chain; the drivers above and the multi-GPU orchestrator
     //      (dynadjust_amd/parallel.py through dnaadjust_c.h) are built from these ----------------
@@ -261,7 +263,7 @@ private:
     // the condensed schedule are served by all of them; cfg3: 4.07 / 3.96 / 3.88 s per step with 2 / 3 / 4; DNAGPU_CHAINS overrides)
     int NumChains() const { return (projectSettings_.a.adjust_mode != SimultaneousMode && projectSettings_.a.multi_thread) ? mt_chains_ : 1; }
     int mt_chains_ = DNAGPU_NUM_CHAINS;
-    bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_; }
+    bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_ && !staged_; }
     bool CondensedWanted() const {
         return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity && projectSettings_.a.adjust_mode == PhasedMode;
     }
@@ -272,6 +274,13 @@ private:
     void CompleteFromPartial(int chain, UINT32 block, int kind, dnagpu_matrix* W);
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
     bool condensed_ok_ = false;
+    // a.stage (the reference's --staged-adjustment keeps its block matrices in memory-mapped files): the rigorous variance
+    // matrices live in page-locked host memory instead of HBM; switched on by itself when they would not fit
+    bool staged_ = false;
+    bool Staged() const { return staged_; }
+public:
+    bool IsStaged() const { return staged_; }
+private:
     std::vector<unsigned char> record_touched_;   // records whose statistics this process computed (UpdateMsrRecord)
     std::atomic<bool> chain_failed_{false};
     void OnEveryChain(const std::function<void(int)>& body);

@@ -91,6 +91,7 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         p.a.reuse_inverses = (uint16_t)(s->reuse_inverses ? 1 : 0);
         p.a.schur_carry = (uint16_t)(s->schur_carry ? 1 : 0);
         p.a.keep_factors = (uint16_t)(s->keep_factors ? 1 : 0);
+        p.a.stage = (uint16_t)(s->stage ? 1 : 0);
         if (s->network_name) p.g.network_name = s->network_name;
         if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);
@@ -363,6 +364,7 @@ int dnaadj_phased_end_iteration(dnaadj_handle* h, int* iterate) {
 int dnaadj_phased_finish(dnaadj_handle* h, int* status) {
     return guarded(h, [&] { h->adj->PhasedFinish(); if (status) *status = (int)h->adj->GetStatus(); });
 }
+int dnaadj_staged(const dnaadj_handle* h) { return (h && h->adj && h->adj->IsStaged()) ? 1 : 0; }
 int dnaadj_condensed_schedule(const dnaadj_handle* h) { return (h && h->adj && h->adj->CondensedSchedule()) ? 1 : 0; }
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block) {
     return (h && h->adj && block < h->adj->blockCount()) ? h->adj->CondensedPayloadDoubles(block) : 0;

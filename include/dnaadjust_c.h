@@ -46,6 +46,8 @@ typedef struct {
                                   carried weights and estimates up to rounding, ~0.35 n^3 instead of n^3 flops).  0 = every step
                                   inverts its block like the reference's Solve().  Ignored with reuse_inverses or
                                   scale_normals_to_unity */
+    int stage;                 /* a.stage (--staged-adjustment): the rigorous variance matrices are kept in page-locked host memory
+                                  instead of HBM (packed lower triangles); switches itself on when they would not fit on the device */
     int keep_factors;          /* device path only (default 1; needs schur_carry): the condensing step keeps its factor in HBM (two
                                   n x n matrices per block, as far as memory allows) and the rigorous solve of the block completes
                                   it instead of inverting the block's normals again: ~1.0 instead of ~1.36 inverse-equivalents
@@ -141,6 +143,7 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status);               /* Valida
  *       block whose result is rigorous, finalised and noted for the convergence test
  * dnaadj_condensed_schedule() tells whether the prepared adjustment supports it (phased, schur_carry, no reuse_inverses /
  * scale_normals_to_unity). */
+int dnaadj_staged(const dnaadj_handle* h);     /* 1 when the prepared adjustment keeps its rigorous variances in host memory */
 int dnaadj_condensed_schedule(const dnaadj_handle* h);
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block);
 int dnaadj_phased_condense_block(dnaadj_handle* h, uint32_t block);

@@ -63,6 +63,9 @@ void dnagpu_destroy(dnagpu_ctx* ctx);
 const char* dnagpu_last_error(const dnagpu_ctx* ctx);
 int dnagpu_last_info(const dnagpu_ctx* ctx);
 int dnagpu_device_count(void);
+/* page-locked host memory (full-rate, asynchronous transfers): the spill area of matrices that do not fit in HBM */
+int dnagpu_host_alloc(dnagpu_ctx* ctx, size_t bytes, void** out);
+void dnagpu_host_free(dnagpu_ctx* ctx, void* p);
 /* free / total device memory in bytes (hipMemGetInfo) */
 int dnagpu_mem_info(dnagpu_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* wait for every stream of the ctx */

@@ -596,3 +596,24 @@ def test_deserialise_adjusted_variance_matrices(built, tmp_path):
         c.DeSerialiseAdjustedVarianceMatrices()
     assert "does not match the dimensions" in str(e.value)
     c.close()
+
+
+@pytest.mark.parametrize("mt", [False, True])
+def test_staged_rigorous_variances_in_host_memory(built, orc, tmp_path, mt):
+    """a.stage: the rigorous variance matrices leave HBM for page-locked host memory (what the reference's staged adjustment does
+    with memory-mapped files); identical results, statistics and result files included"""
+    adjust.write_synthetic_network(str(tmp_path), "g", 16, 10, 0, 4, seed=21, x_clusters=10, y_cluster=True)
+    runs = []
+    for stage in (False, True):
+        a, st = _device_run(str(tmp_path), "g", True, multi_thread=mt, stage=stage, output_folder=str(tmp_path))
+        assert st == 0 and bool(a.lib.dnaadj_staged(a.h)) == stage
+        a.GenerateStatistics()
+        a.SerialiseAdjustedVarianceMatrices()
+        runs.append(([a.block_estimates(b) for b in range(a.blockCount())], [a.block_variances_packed(b) for b in range(a.blockCount())],
+                     a.GetChiSquared(), a.GetGlobalPelzerRel(), np.frombuffer(a.measurement_records().tobytes(), dtype=np.uint8).copy(),
+                     open(str(tmp_path / "g-rva.mtx"), "rb").read(), open(str(tmp_path / "g-pam.mtx"), "rb").read()))
+        a.close()
+    (x0, v0, c0, p0, r0, f0, g0), (x1, v1, c1, p1, r1, f1, g1) = runs
+    for b in range(len(x0)):
+        assert np.array_equal(x0[b], x1[b]) and np.array_equal(v0[b], v1[b])
+    assert c0 == c1 and p0 == p1 and np.array_equal(r0, r1) and f0 == f1 and g0 == g1
