@@ -16,6 +16,8 @@ DNAGPU_MULTI_THREAD=0 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline 
 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --reuse-inverses 2>/dev/null | tail -1 > $O/r01_bench_cfg3_reuse_inverses.json
 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --reference-schedule 2>/dev/null | tail -1 > $O/r01_bench_cfg3_reference_schedule.json
 grep '^{"metric"' $O/kt.log | tail -1 > $O/r01_bench_cfg3_profiled_step.json
+DNAGPU_MULTI_THREAD=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
+python $R/tools/rocprof_summary.py pmc /tmp/pmc_mfma $O/r01_cfg3_pmc_mfma_util.txt "DNAGPU_MULTI_THREAD=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- $CMD   (round 1, cfg3, one chain: MFMA pipe utilisation per kernel)"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   lc=$(echo $c | tr A-Z a-z)

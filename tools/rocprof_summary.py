@@ -79,6 +79,11 @@ def pmc(d, out, header):
             for c in counters:
                 if c in vals:
                     f.write("    %-14s sum %.6e   per dispatch %.6e\n" % (c, vals[c], vals[c] / n))
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and vals.get("GRBM_GUI_ACTIVE", 0) > 0:
+                # rocprofv3's own derived metric: MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM).  The csv
+                # rows of GRBM_GUI_ACTIVE are per XCD and summed here, hence / 8; 1024 SIMDs (256 CU x 4)
+                f.write("    MfmaUtil       %.1f %%   (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD x 1024 SIMD))\n" %
+                        (100.0 * vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)))
 
 
 if __name__ == "__main__":
