@@ -1,7 +1,7 @@
 // Leaf of the recursive inverse: one 128x128 diagonal tile, one workgroup (8 waves).
 // Reads the lower triangle of A(o:o+128, o:o+128), factors it (L L^T) and writes X = L^-1
-// (lower, zeros above the diagonal) to the X buffer.  The tile lives in LDS (129 KiB of the
-// CU's 160 KiB).  Both phases are blocked by 16-column panels:
+// (lower, zeros above the diagonal) to the X buffer.  The tile lives in LDS as its lower 16x16 blocks (76.5 KiB of the
+// CU's 160 KiB: room for a tile-GEMM workgroup beside it).  Both phases are blocked by 16-column panels:
 //   phase A (Cholesky), per panel kb
 //     [wave 0]   factor the 16x16 diagonal block D and invert it, entirely in registers
 //                (one row / column per lane, v_readlane broadcasts, v_rsq_f64 + Newton)
@@ -21,8 +21,6 @@ namespace dnagpu {
 
 namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int LS = 129;  // row stride of the tile in LDS
-constexpr int PS = 17;   // row stride of the 16x16 diagonal-block inverses
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -45,25 +43,32 @@ __device__ __forceinline__ d4 mma16(const double* a, int ars, int acs, const dou
     return acc;
 }
 
-__device__ __forceinline__ d4 tile_load(const double* S, int r0, int c0, int lane) {
+// The tile lives in LDS as its 36 lower 16x16 blocks (block (bi, bj), bi >= bj, at (bi (bi + 1) / 2 + bj) * BS, rows BR apart):
+// 76.5 KiB instead of 149 KiB for the square tile + separate diagonal inverses, so that a leaf can share a CU with one workgroup
+// of the tile GEMM (72 KiB).  Measured: same 69 us alone, and the same step time with four chains in flight (the GPU is busy
+// with GEMMs 99 % of the wall time either way) -- kept for the footprint.
+constexpr int BR = 17;        // row stride inside a block (odd: conflict-free column reads)
+constexpr int BS = 16 * BR;   // doubles per block
+__device__ __forceinline__ double* blk(double* S, int bi, int bj) { return S + (bi * (bi + 1) / 2 + bj) * BS; }
+
+__device__ __forceinline__ d4 tile_load(const double* B, int lane) {
     const int lo = lane & 15, hi = lane >> 4;
     d4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = S[(r0 + hi + 4 * r) * LS + c0 + lo];
+    for (int r = 0; r < 4; ++r) v[r] = B[(hi + 4 * r) * BR + lo];
     return v;
 }
 
-__device__ __forceinline__ void tile_store(double* S, int r0, int c0, int lane, d4 v) {
+__device__ __forceinline__ void tile_store(double* B, int lane, d4 v) {
     const int lo = lane & 15, hi = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[(r0 + hi + 4 * r) * LS + c0 + lo] = v[r];
+    for (int r = 0; r < 4; ++r) B[(hi + 4 * r) * BR + lo] = v[r];
 }
 }  // namespace
 
 __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
                                                                int ldx, int o, int* info) {
-    __shared__ double S[128 * LS];
-    __shared__ double Xd[8 * 16 * PS];  // D^-1 of every diagonal block
+    __shared__ double S[36 * BS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -72,21 +77,24 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
 
     for (int c = q; c < 128; c += 4) {
+        if ((row >> 4) < (c >> 4)) continue;
         double v = A[(size_t)(o + c) * lda + o + row];
-        S[row * LS + c] = (row >= c) ? v : 0.0;
+        blk(S, row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] = (row >= c) ? v : 0.0;
     }
     __syncthreads();
 
     // ------------------------------- phase A: Cholesky -------------------------------
+    // diagonal block kb: factored by wave 0 in registers; what stays in LDS is its INVERSE D^-1 (the factor itself is not
+    // needed again: the panel below it is solved with D^-T, the trailing update uses the panel, X's diagonal block is D^-1)
 #pragma unroll 1
     for (int kb = 0; kb < 8; ++kb) {
         const int p0 = 16 * kb;
-        double* xd = Xd + kb * 16 * PS;
+        double* xd = blk(S, kb, kb);
         if (wave == 0) {
             const int i = lane & 15;
             double d[16], invs[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) d[j] = S[(p0 + i) * LS + p0 + j];
+            for (int j = 0; j < 16; ++j) d[j] = xd[i * BR + j];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 double pk = readlane_f64(d[k], k);
@@ -110,11 +118,6 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (lane < 16) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (j <= i) S[(p0 + i) * LS + p0 + j] = d[j];
-            }
             // lane j solves column j of D X = I:  x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii
             double x[16];
 #pragma unroll
@@ -130,15 +133,15 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
             }
             if (lane < 16) {
 #pragma unroll
-                for (int ii = 0; ii < 16; ++ii) xd[ii * PS + i] = x[ii];  // X(ii, i); zero above the diagonal
+                for (int ii = 0; ii < 16; ++ii) xd[ii * BR + i] = x[ii];  // X(ii, i); zero above the diagonal
             }
         }
         __syncthreads();
         // panel slabs below the diagonal block: P = A_panel * D^-T, one slab per wave
         if (wave < 7 - kb) {
-            const int r0 = p0 + 16 + 16 * wave;
-            d4 acc = mma16(S + r0 * LS + p0, LS, 1, xd, 1, PS, zero, 1.0, lane);
-            tile_store(S, r0, p0, lane, acc);
+            double* P = blk(S, kb + 1 + wave, kb);
+            d4 acc = mma16(P, BR, 1, xd, 1, BR, zero, 1.0, lane);
+            tile_store(P, lane, acc);
         }
         __syncthreads();
         // trailing update: tiles (ti, tj), kb < tj <= ti, round-robin over the waves
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
             for (int ti = 0; ti < nt; ++ti)
                 for (int tj = 0; tj <= ti; ++tj, ++t) {
                     if ((t & 7) != wave) continue;
-                    const int r0 = p0 + 16 + 16 * ti, c0 = p0 + 16 + 16 * tj;
-                    d4 acc = tile_load(S, r0, c0, lane);
-                    acc = mma16(S + r0 * LS + p0, LS, 1, S + c0 * LS + p0, 1, LS, acc, -1.0, lane);
-                    tile_store(S, r0, c0, lane, acc);
+                    double* C = blk(S, kb + 1 + ti, kb + 1 + tj);
+                    d4 acc = tile_load(C, lane);
+                    acc = mma16(blk(S, kb + 1 + ti, kb), BR, 1, blk(S, kb + 1 + tj, kb), 1, BR, acc, -1.0, lane);
+                    tile_store(C, lane, acc);
                 }
         }
         __syncthreads();
@@ -160,45 +163,42 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
     // ------------------------------- phase B: X = L^-1 -------------------------------
 #pragma unroll 1
     for (int kb = 0; kb < 8; ++kb) {
-        const int p0 = 16 * kb;
-        const double* xd = Xd + kb * 16 * PS;
-        // row block kb, columns left of the panel: M_k <- D^-1 * M_k ; the diagonal block becomes D^-1
-        for (int tj = wave; tj <= kb; tj += 8) {
-            if (tj < kb) {
-                d4 acc = mma16(xd, PS, 1, S + p0 * LS + 16 * tj, LS, 1, zero, 1.0, lane);
-                tile_store(S, p0, 16 * tj, lane, acc);
-            } else {
-                const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(p0 + hi + 4 * r) * LS + p0 + lo] = xd[(hi + 4 * r) * PS + lo];
-            }
+        const double* xd = blk(S, kb, kb);
+        // row block kb, columns left of the panel: M_k <- D^-1 * M_k (the diagonal block already is D^-1)
+        for (int tj = wave; tj < kb; tj += 8) {
+            double* M = blk(S, kb, tj);
+            d4 acc = mma16(xd, BR, 1, M, BR, 1, zero, 1.0, lane);
+            tile_store(M, lane, acc);
         }
         __syncthreads();
         // slabs below: M(i, :kb) -= L(i,kb) M_k ;  M(i,kb) = -L(i,kb) D^-1   (one slab per wave: L(i,kb) is read
         // by the wave that finally overwrites it)
         if (wave < 7 - kb) {
-            const int r0 = p0 + 16 + 16 * wave;
+            const int bi = kb + 1 + wave;
             const int lo = lane & 15, hi = lane >> 4;
+            double* Lk = blk(S, bi, kb);
             double lf[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lf[kk] = S[(r0 + lo) * LS + p0 + 4 * kk + hi];
+            for (int kk = 0; kk < 4; ++kk) lf[kk] = Lk[lo * BR + 4 * kk + hi];
             for (int tj = 0; tj < kb; ++tj) {
-                d4 acc = tile_load(S, r0, 16 * tj, lane);
+                double* C = blk(S, bi, tj);
+                const double* Mk = blk(S, kb, tj);
+                d4 acc = tile_load(C, lane);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], S[(p0 + 4 * kk + hi) * LS + 16 * tj + lo], acc, 0, 0, 0);
-                tile_store(S, r0, 16 * tj, lane, acc);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], Mk[(4 * kk + hi) * BR + lo], acc, 0, 0, 0);
+                tile_store(C, lane, acc);
             }
             d4 acc = zero;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], xd[(4 * kk + hi) * PS + lo], acc, 0, 0, 0);
-            tile_store(S, r0, p0, lane, acc);
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], xd[(4 * kk + hi) * BR + lo], acc, 0, 0, 0);
+            tile_store(Lk, lane, acc);
         }
         __syncthreads();
     }
 
     for (int c = q; c < 128; c += 4) {
-        double v = (row >= c) ? S[row * LS + c] : 0.0;
+        double v = (row >= c) ? blk(S, row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] : 0.0;
         X[(size_t)(o + c) * ldx + o + row] = v;
     }
 }
