@@ -289,6 +289,19 @@ def main():
             "issued_tflops": (prof_f.value / 1e12) / (prof_ms.value / 1e3) if prof_ms.value > 0 else 0.0,
         },
     }
+    # outside the timed region: the adjusted network against what the synthetic measurements were drawn from -- size-independent
+    # evidence, at the bench's full size, that the fast schedule adjusts correctly (sigma zero ~ 1: residuals match the stated
+    # variances; every station within a few standard deviations of its true position; constrained corners unmoved)
+    try:
+        import numpy as np
+        a.GenerateStatistics()
+        truth = np.fromfile(os.path.join(d, "net.truth"), dtype=np.float64).reshape(-1, 3)
+        xyz = a.adjusted_coordinates(stations)
+        out["check"] = {"sigma_zero": a.GetSigmaZero(), "degrees_of_freedom": a.GetDegreesOfFreedom(),
+                        "max_abs_error_vs_truth_m": float(np.abs(xyz - truth).max()), "global_test": int(a.GetTestResult()),
+                        "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()]}
+    except Exception as e:                       # diagnostic only
+        out["check"] = {"error": str(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, iters, solves, sum_n3, stations)
     print(json.dumps(out), flush=True)
