@@ -150,6 +150,7 @@ private:
         constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
         bool part_allowed = false, part_valid = false;
+        bool rig_direct = false;              // this iteration's rigorous solve works in rigvar itself (no copy afterwards)
         bool inverse_pending = false;
         bool inverse_kept = false;            // CondensedReuse(): rigvar holds this adjustment's inverse, part its factor
         dnagpu_matrix* red = nullptr;         // Schur complement onto keep + reduced right-hand side (dnagpu_block_reduce)

@@ -29,6 +29,17 @@ void dna_adjust::PhasedNoteCorrection(double mv) {
 // their matrix with them.
 dnagpu_matrix* dna_adjust::StepMatrix(int c, UINT32 k, int kind) {
     if (CondensedReuse() && blocks_[k].inverse_kept) return blocks_[k].rigvar;     // the rigorous solve multiplies by it again
+    if (CondensedSchedule() && (blocks_[k].part_valid || blocks_[k].rig_direct) && !Staged()) {
+        // the completion of a kept factor writes the inverse straight into the block's rigorous variance matrix (and
+        // UpdateEstimatesFinal finds it there)
+        block_t& B = blocks_[k];
+        B.rig_direct = true;
+        if (!B.rigvar) {
+            std::lock_guard<std::mutex> lk(alloc_mutex_);
+            Check(dnagpu_matrix_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, &B.rigvar), k, "rigorous variance matrix");
+        }
+        return B.rigvar;
+    }
     if (!ReuseInverses()) return work_[c];
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
@@ -463,6 +474,7 @@ void dna_adjust::PrepareCondensedBlocks() {
 
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
+    B.rig_direct = false;
     if (B.keep.empty()) return;
     if (CondensedReuse() && B.inverse_kept) {
         // same normals as in the iteration that kept the factor: only the right-hand side is reduced again
