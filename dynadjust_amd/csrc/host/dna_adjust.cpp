@@ -585,6 +585,15 @@ void dna_adjust::PrepareBlocks() {
         ctx_ = nullptr;
         SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
     }
+    {
+        // a chain costs three matrices of the largest block's order (work matrix, X, W): no more chains than blocks, and
+        // no more than half of the free HBM for all of them together
+        size_t free_b = 0, total_b = 0;
+        Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
+        const double per_chain = 3.0 * ((double)max_unknowns_ + 256.0) * ((double)max_unknowns_ + 256.0) * 8.0;
+        while (mt_chains_ > 1 && ((UINT32)mt_chains_ > blockCount_ || per_chain * mt_chains_ > 0.5 * (double)free_b)) --mt_chains_;
+        if (mt_chains_ < 2 && blockCount_ > 1 && 2.0 * per_chain <= 0.5 * (double)free_b) mt_chains_ = 2;   // the two junction chains
+    }
     const int chains = NumChains();
     for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, max_unknowns_, &work_[c]), 0, "PrepareAdjustment(): work matrix");
 
@@ -695,6 +704,7 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     adjustStatus_ = ADJUST_SUCCESS;
     FreeDevice();
     projectSettings_ = projectSettings;
+    mt_chains_ = DNAGPU_NUM_CHAINS;
     if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
     staged_ = projectSettings_.a.stage != 0;   // staged: rigorous variances in page-locked host memory (PrepareCondensedBlocks may switch it on)
     // InitialiseAdjustment (ADJ:232-245)
@@ -895,7 +905,7 @@ void dna_adjust::AdjustPhased() {
         const double it_t0 = now_ms();
         if (CondensedSchedule()) {
             AdjustPhasedCondensedIteration();
-        } else if (projectSettings_.a.multi_thread) {
+        } else if (projectSettings_.a.multi_thread && NumChains() >= 2) {
             AdjustPhasedMultiThreadIteration();
         } else {
             AdjustPhasedForward();
