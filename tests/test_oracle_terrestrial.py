@@ -90,7 +90,7 @@ def test_phased_is_rigorous_with_terrestrial_measurements(orc, tmp_path, blocks)
 
 
 # ---- the reference's own urban sample (terrestrial + GNSS, mixed constraints, deflections, geoid) ------------------------
-def _urban(orc, golden_dir, tmp_path, phased):
+def _urban(orc, golden_dir, tmp_path, phased, sample="gda94", blocks=2):
     """The published report is the output of a SECOND run of dnaadjust on the project: its first iteration moves no station by
     more than 2.6e-5 m (urban.phased.adj.expected:41-43) while the Corr(e, n, up) columns show centimetres against the station
     file -- the first run had written its adjusted coordinates back (UpdateBinaryFiles).  The one-time reductions (deflection
@@ -99,7 +99,7 @@ def _urban(orc, golden_dir, tmp_path, phased):
     from tests import urban_net as U, dnaformats as F
     from tests.dnatext import cart_to_geo
     base = str(tmp_path / "urban")
-    stations, msrs, rep, bst, bms, first_of = U.build_urban_sample(golden_dir, base, blocks=2)
+    stations, msrs, rep, bst, bms, first_of = U.build_urban_sample(golden_dir, base, blocks=blocks, sample=sample)
     for run in range(2):
         net = orc.Network(base, phased)
         a = orc.Adjustment(net, phased)
@@ -118,7 +118,7 @@ def _urban(orc, golden_dir, tmp_path, phased):
     return stations, msrs, rep, bst, bms, first_of, net, a, st
 
 
-def _check_urban_tables(rep, stations, msrs, first_of, t_record, block_stations, block_estimates, block_sd_enu, tf, gf, vec_of_record):
+def _check_urban_tables(rep, stations, msrs, first_of, t_record, block_stations, block_estimates, block_sd_enu, tf, gf, vec_of_record, loose=1.0):
     """adjusted coordinates and the measurement table of urban.phased.adj.expected.  Tolerances: the report prints 4 decimals
     (metres / arc seconds); our inputs carry N to 1e-4 m and the deflections to 1e-3" (that is what the sample publishes), which
     a 5 m sight line turns into a few hundredths of an arc second of zenith distance"""
@@ -133,7 +133,9 @@ def _check_urban_tables(rep, stations, msrs, first_of, t_record, block_stations,
     assert worst < 3e-4, worst
     from tests.urban_net import SEC
     trec = {int(r): k for k, r in enumerate(t_record)}
-    tol_corr = {"V": 0.06 * SEC, "Z": 0.06 * SEC, "A": 5e-3 * SEC, "B": 5e-3 * SEC, "K": 5e-3 * SEC}
+    # loose: the GDA2020 variant starts from station and GNSS files transformed by an older dnareftran than the one behind the
+    # report (the reference itself compares this report at 1e-2 instead of 1e-3, CMakeLists.txt:1191)
+    tol_corr = {"V": 0.06 * SEC * loose, "Z": 0.06 * SEC * loose, "A": 5e-3 * SEC * loose, "B": 5e-3 * SEC * loose, "K": 5e-3 * SEC * loose}
     rows, q, seen = rep["msr"], 0, set()
     for c, m in enumerate(msrs):
         if m["ignore"]:
@@ -169,12 +171,13 @@ def _check_urban_tables(rep, stations, msrs, first_of, t_record, block_stations,
     assert q == len(rows) == 1182 and seen == set("ABHKLMSVZ")
 
 
-@pytest.mark.parametrize("phased", [False, True])
-def test_reference_urban_sample(orc, golden_dir, tmp_path, phased):
+@pytest.mark.parametrize("phased,sample,blocks", [(False, "gda94", 2), (True, "gda94", 2), (True, "gda2020", 3)])
+def test_reference_urban_sample(orc, golden_dir, tmp_path, phased, sample, blocks):
     """sampleData/urban-network.* adjusted by the oracle against the reference's published report urban.phased.adj.expected
     (the reference's own test compares at 1e-3, CMakeLists.txt:1190): summary figures, every adjusted coordinate and its
     standard deviations.  Simultaneous and phased (our own 2-block cut) must both land on it: the phased result is rigorous."""
-    stations, msrs, rep, bst, bms, first_of, net, a, st = _urban(orc, golden_dir, tmp_path, phased)
+    # (the GDA2020 variant: the reference's third test, urban_mt.phased-mt.adj.expected -- the network after dnareftran, 3 blocks)
+    stations, msrs, rep, bst, bms, first_of, net, a, st = _urban(orc, golden_dir, tmp_path, phased, sample, blocks)
     assert st == 0
     s, f = a.statistics()
     assert s.measurement_params == rep["measurements"] == 1182
@@ -200,7 +203,8 @@ def test_reference_urban_sample(orc, golden_dir, tmp_path, phased):
             out[p] = np.sqrt(np.diag(R @ V[3 * p:3 * p + 3, 3 * p:3 * p + 3] @ R.T))
         sd.append(out)
     vec_of_record = {int(r): int(net.cluster_off[c]) for r, c in net.bl_of_record.items() if c < net.n_clusters}
-    _check_urban_tables(rep, stations, msrs, first_of, net.t_record, bs, be, sd, a.tmsr_fields(), f, vec_of_record)
+    _check_urban_tables(rep, stations, msrs, first_of, net.t_record, bs, be, sd, a.tmsr_fields(), f, vec_of_record,
+                        loose=6.0 if sample == "gda2020" else 1.0)
     a.close()
 
 

@@ -174,12 +174,30 @@ def read_report(path):
     return out
 
 
-def build_urban_sample(golden_dir, base, blocks=2):
+SAMPLES = {
+    # the reference's test 2 (CMakeLists.txt:1062-1070): GDA94 as supplied, sequential phased adjustment, 2 blocks
+    "gda94": ("urban-network.stn", "urban-network.msr", "urban.phased.adj.expected"),
+    # its test 3 (CMakeLists.txt:1076-1083): the same network after dnareftran -r gda2020 (stations and GNSS measurements moved to
+    # GDA2020: the transformed files the reference itself exported), multi-thread phased adjustment, 3 blocks
+    "gda2020": ("urban.GDA2020.1.1.2020.stn", "urban.GDA2020.1.1.2020.msr", "urban_mt.phased-mt.adj.expected"),
+}
+
+
+def build_urban_sample(golden_dir, base, blocks=2, sample="gda94"):
     """the sample as .bst/.bms/.asl/.seg at `base`; returns (stations, measurements, report, bst, bms, cml_of_record)"""
-    stations = read_stations(os.path.join(golden_dir, "urban-network.stn"))
-    msrs = read_measurements(os.path.join(golden_dir, "urban-network.msr"))
+    f_stn, f_msr, f_rep = SAMPLES[sample]
+    stations = read_stations(os.path.join(golden_dir, f_stn))
+    if sample == "gda2020":
+        # The exported GDA2020 station file (reftran 1.0.3, 2020) also moved the orthometric heights by the change of the
+        # ellipsoidal height between the frames (-0.089 m); the build that produced the expected report (1.2.9, 2025) left them
+        # as supplied -- its H(Ortho) column equals the GDA94 run's.  Constrained stations are held at their supplied heights,
+        # so the heights come from the supplied file, the horizontal position from the transformed one.
+        supplied = {s["name"]: s["height"] for s in read_stations(os.path.join(golden_dir, "urban-network.stn"))}
+        for s in stations:
+            s["height"] = supplied[s["name"]]
+    msrs = read_measurements(os.path.join(golden_dir, f_msr))
     geo = read_geo(os.path.join(golden_dir, "urban-network.geo"))
-    rep = read_report(os.path.join(golden_dir, "urban.phased.adj.expected"))
+    rep = read_report(os.path.join(golden_dir, f_rep))
     index = {s["name"]: n for n, s in enumerate(stations)}
     n = len(stations)
     bst = np.zeros(n, dtype=F.STATION_DT)
