@@ -617,3 +617,27 @@ def test_staged_rigorous_variances_in_host_memory(built, orc, tmp_path, mt):
     for b in range(len(x0)):
         assert np.array_equal(x0[b], x1[b]) and np.array_equal(v0[b], v1[b])
     assert c0 == c1 and p0 == p1 and np.array_equal(r0, r1) and f0 == f1 and g0 == g1
+
+
+def test_bench_contract_small_workload(built):
+    """bench.py end to end on the smoke-size workload: ONE JSON line with the contract's keys, roofline and check blocks"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "check"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "stations/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["stations"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert 0.5 < d["check"]["sigma_zero"] < 1.5 and d["check"]["max_abs_error_vs_truth_m"] < 0.2
