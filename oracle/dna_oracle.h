@@ -14,7 +14,11 @@
  * oracle/_ref exists.  The restatement is pinned against (a) the known-answer
  * vectors of the reference's tests/test_matrix.cpp (tests/golden/matrix_golden.json),
  * (b) LAPACK dpotrf/dpotri from the MKL runtime in the image -- the very routines
- * matrix_2d::cholesky_inverse calls -- and (c) phased == simultaneous consistency.
+ * matrix_2d::cholesky_inverse calls --, (c) phased == simultaneous consistency, and END TO END (d) the three sample reports
+ * the reference publishes with its test suite: gnss.simult.adj.expected (43 stations, 417 GNSS measurement rows),
+ * urban.phased.adj.expected and urban_mt.phased-mt.adj.expected (149 stations, 1 182 rows of eleven measurement types) --
+ * every adjusted coordinate, standard deviation, adjusted measurement, correction, N-statistic and pre-adjustment
+ * correction to the printed precision (tests/test_oracle_adjust.py, tests/test_oracle_terrestrial.py; data under tests/golden/).
  */
 #ifndef DNA_ORACLE_H_
 #define DNA_ORACLE_H_
