@@ -641,3 +641,26 @@ def test_bench_contract_small_workload(built):
         assert k in rf, k
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert 0.5 < d["check"]["sigma_zero"] < 1.5 and d["check"]["max_abs_error_vs_truth_m"] < 0.2
+
+
+@pytest.mark.parametrize("blocks,mt", [(1, False), (3, False), (4, True)])
+def test_mixed_station_constraints_on_the_device(built, orc, tmp_path, blocks, mt):
+    """CCF / CFF / FFC / CFC / FCC station constraints on geographic, projection and cartesian station records
+    (FormConstraintStationVarianceMatrix, dnaadjust.cpp:2041-2137): facade against oracle (itself checked against numpy)"""
+    adjust.write_synthetic_network(str(tmp_path), "m", 9, 6, 0, blocks, seed=31, x_clusters=6)
+    base = str(tmp_path / "m")
+    bst = F.read_bst(base + ".bst").copy()
+    for s, (code, typ) in {3: (b"CCF", 2), 8: (b"FFC", 1), 14: (b"CFF", 3), 20: (b"CFC", 3), 27: (b"FCC", 0), 33: (b"FFC", 0), 50: (b"CCF", 3)}.items():
+        bst["stationConst"][s] = code
+        bst["suppliedStationType"][s] = typ
+    F.write_bst(base + ".bst", bst)
+    phased = blocks > 1
+    net = orc.Network(base, phased)
+    o = orc.Adjustment(net, phased)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "m", phased, multi_thread=mt)
+    _compare(a, st, o, ost)
+    assert a.GetUnknownsCount() == 3 * 54 - sum(c.count(b"C") for c in [bytes(x[:3]) for x in bst["stationConst"]])
+    a.close()
+    o.close()

@@ -143,12 +143,28 @@ def _dense_solution(net, fixed_std_dev=1e-6, free_std_dev=10.0):
         V = net.cluster_vcv[voff:voff + nc * nc].reshape(nc, nc, order="F")
         voff += nc * nc
         W[3 * i0:3 * i1, 3 * i0:3 * i1] = np.linalg.inv(V)
-    Wc = np.zeros(n)
+    Wc = np.zeros((n, n))
     for s in range(net.n_stations):
         cst = net.constraints[3 * s:3 * s + 3]
-        assert cst in (b"CCC", b"FFF")
-        Wc[3 * s:3 * s + 3] = 1.0 / (fixed_std_dev if cst == b"CCC" else free_std_dev) ** 2
-    N = A.T @ W @ A + np.diag(Wc)
+        v = [(fixed_std_dev if c == ord("C") else free_std_dev) ** 2 for c in cst]
+        if cst in (b"CCC", b"FFF"):
+            Wc[3 * s:3 * s + 3, 3 * s:3 * s + 3] = np.eye(3) / v[0]
+            continue
+        # mixed codes (FormConstraintStationVarianceMatrix, dnaadjust.cpp:2041): per-axis variances in the local frame --
+        # (latitude, longitude, up) for geographic records, (east, north, up) for projection records, x / y / z for cartesian
+        # ones -- rotated to cartesian with the record's position, then inverted
+        t = int(net._supplied_type[s])
+        if t == 0:
+            V = np.diag(v)
+        else:
+            e_, n_, u_ = (v[1], v[0], v[2]) if t in (1, 2) else (v[0], v[1], v[2])
+            lat, lon = net._llh[s][0], net._llh[s][1]
+            R = np.array([[-np.sin(lon), -np.sin(lat) * np.cos(lon), np.cos(lat) * np.cos(lon)],
+                          [np.cos(lon), -np.sin(lat) * np.sin(lon), np.cos(lat) * np.sin(lon)],
+                          [0.0, np.cos(lat), np.sin(lat)]])
+            V = R @ np.diag([e_, n_, u_]) @ R.T
+        Wc[3 * s:3 * s + 3, 3 * s:3 * s + 3] = np.linalg.inv(V)
+    N = A.T @ W @ A + Wc
     x = net.xyz0.copy()
     for _ in range(10):
         dx = np.linalg.solve(N, A.T @ W @ (net.obs - A @ x))
@@ -338,3 +354,31 @@ def test_gnss_scalars_and_llh_point_clusters(orc, built, tmp_path, blocks, ycl):
     ap.close()
     if blocks > 1:
         _phased_vs_simultaneous(orc, base)
+
+
+@pytest.mark.parametrize("blocks", [1, 3])
+def test_mixed_station_constraints(orc, built, tmp_path, blocks):
+    """CCF / CFF / FFC / CFC station constraints on geographic, projection and cartesian station records
+    (FormConstraintStationVarianceMatrix, dnaadjust.cpp:2041-2137): the oracle against the dense numpy solution"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "m", 7, 6, 0, blocks, seed=31, x_clusters=6)
+    base = str(tmp_path / "m")
+    bst = F.read_bst(base + ".bst").copy()
+    for s, (code, typ) in {3: (b"CCF", 2), 8: (b"FFC", 1), 14: (b"CFF", 3), 20: (b"CFC", 3), 27: (b"FCC", 0), 33: (b"FFC", 0)}.items():
+        bst["stationConst"][s] = code
+        bst["suppliedStationType"][s] = typ
+    F.write_bst(base + ".bst", bst)
+    net, a, st = _run(orc, base, blocks > 1)
+    assert st == 0
+    x, V = _dense_solution(net)
+    for k in range(a.n_blocks):
+        stn = a.block_stations(k)
+        idx = (3 * stn[:, None] + np.arange(3)).ravel()
+        assert np.abs(a.block_estimates(k) - x[idx]).max() < 2e-8
+        Vb = unpack_lower(a.block_variances(k), 3 * len(stn))
+        assert np.abs(Vb - V[np.ix_(idx, idx)]).max() < 1e-7 * np.abs(V).max()
+    # the constrained components do not move, the free ones do
+    x0 = net.xyz0.reshape(-1, 3)
+    moved = np.abs(x.reshape(-1, 3) - x0)
+    assert moved[27, 1:].max() < 1e-6 and moved[27, 0] > 1e-4          # FCC on a cartesian record: Y and Z held
+    a.close()
