@@ -960,7 +960,6 @@ void dna_adjust::GetAdjustedCoordinates(std::vector<double>& xyz) {
 
 void dna_adjust::ResetAdjustment() {
     if (!ctx_) SignalExceptionAdjustment("ResetAdjustment(): PrepareAdjustment() has not been called.", 0);
-    const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
     const int chains = NumChains();
     for (UINT32 b = 0; b < blockCount_; ++b) {
         Check(dnagpu_block_set_stations(ctx_, b, initial_xyz_[b].data()), b, "ResetAdjustment()");
