@@ -664,3 +664,20 @@ def test_mixed_station_constraints_on_the_device(built, orc, tmp_path, blocks, m
     assert a.GetUnknownsCount() == 3 * 54 - sum(c.count(b"C") for c in [bytes(x[:3]) for x in bst["stationConst"]])
     a.close()
     o.close()
+
+
+def test_multi_chain_runs_are_reproducible(built, tmp_path):
+    """four chains, host threads taking blocks from a queue: whichever chain serves a block, the bits are the same -- three runs
+    of the same adjustment (and the one-chain run) give identical coordinates, variances and statistics"""
+    adjust.write_synthetic_network(str(tmp_path), "q", 40, 16, 0, 8, seed=17, x_clusters=10, y_cluster=True)
+    ref = None
+    for mt in (True, True, True, False):
+        a, st = _device_run(str(tmp_path), "q", True, multi_thread=mt)
+        assert st == 0
+        a.GenerateStatistics()
+        cur = ([a.block_estimates(b).tobytes() for b in range(a.blockCount())], [a.block_variances_packed(b).tobytes() for b in range(a.blockCount())],
+               a.GetChiSquared(), a.GetGlobalPelzerRel())
+        a.close()
+        if ref is None:
+            ref = cur
+        assert cur == ref
