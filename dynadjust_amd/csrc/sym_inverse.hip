@@ -54,7 +54,11 @@ static double gemm_flops(const GemmArgs& a) {
 
 hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a) {
     long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
-    a.tile = total < SMALL_LAUNCH_TILES ? 64 : 128;
+    static const long small_tiles = [] {
+        const char* e = getenv("DNAGPU_SMALL_TILES");
+        return e ? atol(e) : (long)SMALL_LAUNCH_TILES;
+    }();
+    a.tile = total < small_tiles ? 64 : 128;
     uint64_t key = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
                    ((uint64_t)(a.K / 16) << 40);
     auto it = ws.order_cache.find(key);
