@@ -102,3 +102,24 @@ def test_missing_and_corrupt_files(built, tmp_path):
     old.write_bytes(b"VERSION          1.1CREATED ON2020-01-01CREATED BY    IMPORT" + b"\x00" * 200)
     rc = built.dnaio_file_summary(None, str(old).encode(), None, None, None, None, err, 512)
     assert rc != 0 and b"predates observation_epoch" in err.value
+
+
+def test_utm_conversion_matches_the_reference_report(golden_dir):
+    """tests/urban_net.py's MGA -> geographic conversion (Krueger series) against the reference's own (Redfearn, dnaimport): the
+    horizontally constrained stations of the urban sample keep their supplied position, which the report prints as latitude /
+    longitude to 1e-9 degrees"""
+    import math
+    from tests import urban_net as U, dnatext as T
+    st = {s["name"]: s for s in U.read_stations(os.path.join(golden_dir, "urban-network.stn"))}
+    txt = open(os.path.join(golden_dir, "urban.phased.adj.expected")).read().split("\n")
+    i = next(n for n, l in enumerate(txt) if l.startswith("Adjusted Coordinates")) + 5
+    seen = 0
+    while txt[i].strip():
+        f = txt[i][20:].split()
+        if f[0] in ("CCC", "CCF"):
+            s = st[txt[i][:20].strip()]
+            lat, lon = math.radians(T.dms_to_deg(float(f[1]))), math.radians(T.dms_to_deg(float(f[2])))
+            assert abs(s["lat"] - lat) * 6.4e6 < 2e-4 and abs(s["lon"] - lon) * 6.4e6 * math.cos(lat) < 2e-4
+            seen += 1
+        i += 1
+    assert seen == 2
