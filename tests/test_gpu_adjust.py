@@ -681,3 +681,29 @@ def test_multi_chain_runs_are_reproducible(built, tmp_path):
         if ref is None:
             ref = cur
         assert cur == ref
+
+
+@pytest.mark.parametrize("mt", [False, True])
+def test_cancel_adjustment(built, tmp_path, mt):
+    """CancelAdjustment() (the reference's SIGINT handler, dnaadjustwrapper.cpp): an adjustment cancelled before its first block
+    stops with ADJUST_CANCELLED; one cancelled from another thread while it runs stops at the next block (or had already
+    finished); the object adjusts normally afterwards"""
+    import threading
+    import time
+    adjust.write_synthetic_network(str(tmp_path), "k", 120, 40, 0, 12, seed=5)
+    p = adjust.ProjectSettings("k", str(tmp_path), adjust_mode=adjust.PhasedMode, multi_thread=mt)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    a.CancelAdjustment()
+    assert a.AdjustNetwork() == adjust.ADJUST_CANCELLED
+    a.ResetAdjustment()
+    out = {}
+    t = threading.Thread(target=lambda: out.setdefault("st", a.AdjustNetwork()))
+    t.start()
+    time.sleep(0.002)
+    a.CancelAdjustment()
+    t.join(timeout=120)
+    assert not t.is_alive() and out["st"] in (adjust.ADJUST_CANCELLED, adjust.ADJUST_SUCCESS)
+    a.ResetAdjustment()
+    assert a.AdjustNetwork() == adjust.ADJUST_SUCCESS
+    a.close()
