@@ -705,6 +705,8 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     FreeDevice();
     projectSettings_ = projectSettings;
     mt_chains_ = DNAGPU_NUM_CHAINS;
+    profileTimings_ = getenv("DYNADJUST_PROFILE") != nullptr;
+    profileUpdateNormalsNs_ = profileStageLoadNs_ = profileStageStoreNs_ = 0;
     if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
     staged_ = projectSettings_.a.stage != 0;   // staged: rigorous variances in page-locked host memory (PrepareCondensedBlocks may switch it on)
     // InitialiseAdjustment (ADJ:232-245)
@@ -793,6 +795,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     }
     Check(dnagpu_sync(ctx_), 0, "AdjustNetwork()");
     adjust_ms_ = now_ms() - t0;
+    PrintPerformanceProfile();
     return adjustStatus_;
 }
 
@@ -1050,7 +1053,9 @@ void dna_adjust::StatisticsBlock(UINT32 b) {
             // staged: the block's rigorous variances come back from host memory into the work matrix (lower triangle: all the
             // statistics kernels read)
             var = work_[0];
+            const auto t0 = std::chrono::steady_clock::now();
             Check(dnagpu_matrix_upload_packed(ctx_, 0, var, B.rig_host, (UINT32)v_parameterStationList_[b].size() * 3), b, "ComputePrecisionAdjMsrs()");
+            profileStageLoadNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         }
         if (!var) SignalExceptionAdjustment("ComputePrecisionAdjMsrs(): this process holds no rigorous variances for the block.", b);
         prec6.assign(6 * nv + 1, 0.0);
@@ -1328,6 +1333,17 @@ void dna_adjust::DeSerialiseAdjustedVarianceMatrices() {
         pam.read(reinterpret_cast<char*>(tail), sizeof(tail));
         if (!rva || !pam) SignalExceptionAdjustment("DeSerialiseAdjustedVarianceMatrices(): read failed", b);
     }
+}
+
+// ADJ:2562: printed to stderr when DYNADJUST_PROFILE is set
+void dna_adjust::PrintPerformanceProfile() const {
+    if (!profileTimings_) return;
+    auto ms = [](uint64_t ns) { return (double)ns / 1.0e6; };
+    std::stringstream ss;
+    ss << "DynAdjust profile timings:" << std::fixed << std::setprecision(3) << " update_normals=" << ms(profileUpdateNormalsNs_.load()) << "ms"
+       << " stage_load=" << ms(profileStageLoadNs_.load()) << "ms"
+       << " stage_store=" << ms(profileStageStoreNs_.load()) << "ms";
+    fprintf(stderr, "%s\n", ss.str().c_str());
 }
 
 // ADJ:10628: the number of blocks of a segmentation file, before anything is prepared

@@ -326,6 +326,12 @@ private:
     std::vector<double> iterationCorrections_;
     double adjust_ms_ = 0.0;
     std::atomic<int64_t> lastBlockElapsedMs_{0};
+    // DYNADJUST_PROFILE (ADJ:53-56, PrintPerformanceProfile ADJ:2562): host-side time spent issuing the formation of the normals, and
+    // in the staged mode's loads / stores of the rigorous variances
+    bool profileTimings_ = false;
+    std::atomic<uint64_t> profileUpdateNormalsNs_{0}, profileStageLoadNs_{0}, profileStageStoreNs_{0};
+    void PrintPerformanceProfile() const;
+    void FormNormals(int chain, UINT32 block, dnagpu_matrix* W);
     std::mutex msg_mutex_;
     std::deque<UINT32> iterationQueue_;
     std::vector<double> iterationMs_;

@@ -18,6 +18,14 @@
 namespace dynadjust {
 namespace networkadjust {
 
+// UpdateNormals (ADJ:1364) on the device; timed like the reference's DYNADJUST_PROFILE counter (ADJ:1366, ADJ:1449-1455)
+void dna_adjust::FormNormals(int c, UINT32 k, dnagpu_matrix* W) {
+    const auto t0 = std::chrono::steady_clock::now();
+    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+    if (profileTimings_)
+        profileUpdateNormalsNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void dna_adjust::PhasedNoteCorrection(double mv) {
     std::lock_guard<std::mutex> lk(corr_mutex_);
     if (std::fabs(mv) > std::fabs(maxCorr_)) SetmaxCorr(mv);
@@ -78,7 +86,7 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
     const bool reuse = (ReuseInverses() && B.has_finv) || (CondensedReuse() && B.inverse_kept);   // W already holds this step's inverse (earlier iteration)
     const bool fused = !reuse && B.part_valid && (meta._blockLast && !meta._blockIsolated) && CondensedSchedule();
     if (!reuse && !fused) {
-        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        FormNormals(c, k, W);
         AddConstraints(c, W, B.con_fwd, +1, k);
         if (carried_in)
             Check(dnagpu_junction_scatter(ctx_, c, W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k,
@@ -134,7 +142,7 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
     Check(dnagpu_block_copy_stations(ctx_, c, k, 1, 0), k, "PrepareAdjustmentReverse()");
     if (!reuse && !fused) {
         // normals = measurements + junctions carried in reverse + constraints (first appearance in reverse)
-        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        FormNormals(c, k, W);
         if (rev_in)
             Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
         AddConstraints(c, W, B.con_rev, +1, k);
@@ -178,7 +186,7 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     if (!reuse && !fused) {
         // the reference restores the backed-up reverse normals (ADJ:3245); here they are re-formed in the
         // same summation order, which gives the same bits
-        Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+        FormNormals(c, k, W);
         if (rev_in)
             Check(dnagpu_junction_scatter(ctx_, c, W, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "CarryStnEstimatesandVariancesCombine()");
         AddConstraints(c, W, B.con_rev, +1, k);
@@ -212,7 +220,9 @@ void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
             std::lock_guard<std::mutex> lk(alloc_mutex_);
             Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
         }
+        const auto t0 = std::chrono::steady_clock::now();
         Check(dnagpu_matrix_download_packed(ctx_, c, W, B.rig_host), k, "UpdateEstimatesFinal()");
+        profileStageStoreNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         B.has_rigvar = true;
         B.inverse_pending = false;
         return;
@@ -483,7 +493,7 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
         return;
     }
     dnagpu_matrix* W = work_[c];
-    Check(dnagpu_form_normals(ctx_, c, k, W), k, "UpdateNormals()");
+    FormNormals(c, k, W);
     AddConstraints(c, W, B.con_inner, +1, k);
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (B.part_allowed && !B.part) {
