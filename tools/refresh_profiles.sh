@@ -28,4 +28,5 @@ done
   echo "# fp64 MFMA peak 78.6 TFLOP/s; operands pseudo-random full-range mantissas"
   for v in dma4 dma8 reg4 reg8; do echo "== DNAGPU_GEMM_VARIANT=$v"; DNAGPU_GEMM_VARIANT=$v python $R/tools/gpu_gemm_bench.py 2>/dev/null; done; } > $O/r01_gemm_variants.txt
 { echo "# tools/probes/mfma_f64_peak.hip"; $R/variants/mfma_peak; echo "# tools/probes/mfma_f64_feed.hip"; $R/variants/mfma_feed; echo "# tools/gpu_two_chain_probe.py"; python $R/tools/gpu_two_chain_probe.py; } > $O/r01_mfma_probes.txt 2>&1
+{ echo "# python tools/gpu_inverse_bench.py on 1 x MI355X (round 1), through the C-ABI, best of 3 timed repetitions, one chain"; python $R/tools/gpu_inverse_bench.py 2>/dev/null; } > $O/r01_inverse_rates.txt
 ls -la $O
