@@ -181,10 +181,14 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # DNAGPU_FORCE_DISTRIBUTED=1: run the N > 1 code path (RCCL process group, device-resident payloads, collectives) with
+    # however many ranks there are -- with one rank on a 1-GPU box it is the only way to exercise the NCCL transport there
+    distributed = world > 1 or bool(int(os.environ.get("DNAGPU_FORCE_DISTRIBUTED", "0")))
+    if distributed:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if dist_backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -198,7 +202,7 @@ def main():
     info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, blocks)
     stations = info["stations"]
 
-    if world > 1:
+    if distributed:
         from dynadjust_amd import parallel
         result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)
         if rank == 0:

@@ -198,6 +198,13 @@ class PhasedSchedule:
         return self.combine_owner[k]
 
 
+def _exchanging(world):
+    """collectives run when there is more than one rank -- or when DNAGPU_FORCE_DISTRIBUTED=1 asks for the whole N > 1 path
+    (export, collective, import) with however many ranks there are: the way to exercise the RCCL transport on a 1-GPU box"""
+    import os
+    return world > 1 or bool(int(os.environ.get("DNAGPU_FORCE_DISTRIBUTED", "0")))
+
+
 def _host_wait(works, dev):
     """Work.wait() on an NCCL work only orders torch's current stream behind the collective; the block steps run on the
     library's own HIP streams, so the host has to see the end of the transfer before the payload is imported."""
@@ -250,7 +257,7 @@ def distributed_statistics(backend, dist, rank, world, owner_of):
     backend._chk(lib.dnaadj_statistics_prepare(h))
     mine = np.ascontiguousarray([k for k in range(backend.n_blocks) if owner_of(k) == rank], dtype=np.uint32)
     backend._chk(lib.dnaadj_statistics_blocks(h, mine.ctypes.data_as(C.POINTER(C.c_uint32)), mine.size))
-    if world > 1:
+    if _exchanging(world):
         chi, out = C.c_double(), C.c_uint32()
         lib.dnaadj_statistics_get_partial(h, C.byref(chi), C.byref(out))
         n = adj.lib.dnaadj_measurement_record_count(h)
@@ -279,7 +286,7 @@ def run_phased_condensed(backend, dist, rank, world, max_iterations=10):
         mine = [k for k in range(B) if owner[k] == rank]
         # (A) + exchange: one broadcast per block from its owner, all in flight together
         backend.condense_blocks(mine)
-        if world > 1:
+        if _exchanging(world):
             pending = []
             for k in range(B):
                 t = backend.export_condensed(k) if owner[k] == rank else backend.condensed_tensor(k)
@@ -287,13 +294,13 @@ def run_phased_condensed(backend, dist, rank, world, max_iterations=10):
                     pending.append((k, t, dist.broadcast(t, src=owner[k], async_op=True)))
             _host_wait([w for _, _, w in pending], backend.comm_device)
             for k, t, _ in pending:
-                if owner[k] != rank:
+                if owner[k] != rank or world == 1:       # (world == 1: forced exchange, re-importing its own payload)
                     backend.import_condensed(k, t)
         # (B) the two chains on the condensed blocks, everywhere
         backend.condensed_chains()
         # (C)
         backend.rigorous_blocks(mine)
-        if world > 1:
+        if _exchanging(world):
             _sync_coordinates(backend, dist, rank, world, lambda k: owner[k], offs, backend.comm_device)
         corrections.append(backend.max_correction())
         if not backend.end_iteration():
@@ -331,7 +338,7 @@ def run_phased(backend, dist, rank, world, max_iterations=10):
                     backend.note_correction(mv)
                     backend.finalise_block(k)
         # ---- exchange the junction payloads of the combination solves ----------------------------------
-        if world > 1:
+        if _exchanging(world):
             ops, recvs = [], []
             for k in sch.intermediate:
                 o = sch.combine_owner[k]
@@ -355,7 +362,7 @@ def run_phased(backend, dist, rank, world, max_iterations=10):
                 backend.note_correction(mv)
                 backend.finalise_block(k)
         # ---- rigorous coordinates and the largest correction, on every rank -------------------------------
-        if world > 1:
+        if _exchanging(world):
             _sync_coordinates(backend, dist, rank, world, sch.final_owner, offs, dev)
         corrections.append(backend.max_correction())
         if not backend.end_iteration():
@@ -460,5 +467,22 @@ def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank,
                 "note": "busiest rank: algorithmic flops of its steps / HIP-event time of its GEMM launches",
             },
         }
+    # after the timed region: statistics across the ranks and the distance from the truth the generator kept
+    try:
+        if condensed:
+            owner = block_owners([float(be.n_stations(k)) ** 3 for k in range(be.n_blocks)], world)
+            final_owner = lambda k: owner[k]
+        else:
+            final_owner = PhasedSchedule([be.flags(k) for k in range(be.n_blocks)], world).final_owner
+        distributed_statistics(be, dist, rank, world, final_owner)
+        if out is not None:
+            truth = np.fromfile(os.path.join(folder, name + ".truth"), dtype=np.float64).reshape(-1, 3)
+            xyz = a.adjusted_coordinates(stations)
+            out["check"] = {"sigma_zero": a.GetSigmaZero(), "degrees_of_freedom": a.GetDegreesOfFreedom(),
+                            "max_abs_error_vs_truth_m": float(np.abs(xyz - truth).max()), "global_test": int(a.GetTestResult()),
+                            "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()]}
+    except Exception as e:                       # diagnostic only
+        if out is not None:
+            out["check"] = {"error": str(e)}
     be.close()
     return out

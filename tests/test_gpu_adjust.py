@@ -643,6 +643,38 @@ def test_bench_contract_small_workload(built):
     assert 0.5 < d["check"]["sigma_zero"] < 1.5 and d["check"]["max_abs_error_vs_truth_m"] < 0.2
 
 
+@pytest.mark.parametrize("extra", [[], ["--reference-schedule"]])
+def test_bench_distributed_path_over_rccl(built, extra):
+    """bench.py's N > 1 path with the NCCL (= RCCL) backend and device-resident payloads, forced onto the one rank a 1-GPU
+    box has: process group on cuda:0, condensed / junction payloads exported into device tensors, broadcast, all_reduce and
+    all_gather through RCCL, the JSON of the distributed leg -- same answer as the single-process bench"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DNAGPU_FORCE_DISTRIBUTED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = []
+    for e in (env, dict(os.environ)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "small", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, cwd=root, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        out.append(json.loads(lines[0]))
+    d, s = out
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["stations"] == s["config"]["stations"]
+    assert d["config"]["iterations_to_converge"] == s["config"]["iterations_to_converge"]
+    assert abs(d["check"]["sigma_zero"] - s["check"]["sigma_zero"]) < 1e-9
+
+
 @pytest.mark.parametrize("blocks,mt", [(1, False), (3, False), (4, True)])
 def test_mixed_station_constraints_on_the_device(built, orc, tmp_path, blocks, mt):
     """CCF / CFF / FFC / CFC / FCC station constraints on geographic, projection and cartesian station records
