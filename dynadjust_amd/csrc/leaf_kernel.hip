@@ -19,6 +19,14 @@
 
 namespace dnagpu {
 
+// tools/leaf_probe.hip compiles this file with -DDNAGPU_LEAF_PROBE: thread 0 leaves the shader clock at the phase boundaries
+#ifdef DNAGPU_LEAF_PROBE
+__device__ unsigned long long leaf_probe[64];
+#define LEAF_PROBE(i) do { if (threadIdx.x == 0) leaf_probe[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LEAF_PROBE(i) do { } while (0)
+#endif
+
 namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -69,6 +77,7 @@ __device__ __forceinline__ void tile_store(double* B, int lane, d4 v) {
 __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
                                                                int ldx, int o, int* info) {
     __shared__ double S[36 * BS];
+    __shared__ double LT[256];   // the factor of the current diagonal block, transposed (wave 0 only)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -76,6 +85,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
     const int q = tid >> 7;  // 0..3
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
 
+    LEAF_PROBE(0);
     // all 32 loads of a thread are in flight together (a rolled loop would pay the memory latency 32 times: 20 us of a 68 us leaf)
     {
         double v[32];
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
         }
     }
     __syncthreads();
+    LEAF_PROBE(1);
 
     // ------------------------------- phase A: Cholesky -------------------------------
     // diagonal block kb: factored by wave 0 in registers; what stays in LDS is its INVERSE D^-1 (the factor itself is not
@@ -102,13 +113,14 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
         if (wave == 0) {
             const int i = lane & 15;
             double d[16], invs[16];
+            int bad = 16;
 #pragma unroll
             for (int j = 0; j < 16; ++j) d[j] = xd[i * BR + j];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 double pk = readlane_f64(d[k], k);
-                if (!(pk > 0.0)) {
-                    if (lane == 0) atomicMin(info, o + p0 + k + 1);
+                if (!(pk > 0.0)) {          // (uniform: a scalar select; reported once per block, below)
+                    bad = bad < k ? bad : k;
                     pk = 1.0;
                 }
                 // y = pk^-1/2 (v_rsq_f64 + 2 Newton steps), r = pk^1/2 with one correction
@@ -127,24 +139,42 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // lane j solves column j of D X = I:  x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii
-            double x[16];
-#pragma unroll
-            for (int ii = 0; ii < 16; ++ii) {
-                double s = (ii == i) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < ii; ++k) {
-                    double lik = readlane_f64(d[k], ii);
-                    s = fma(-lik, x[k], s);
-                }
-                x[ii] = s * invs[ii];
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (bad < 16 && lane == 0) atomicMin(info, o + p0 + bad + 1);
+            // lane j solves column j of D X = I:  x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii.  Every lane needs every L_ik:
+            // they go through LDS (one row per lane out, broadcast reads back) -- as v_readlane values they were kept in
+            // 240 SGPRs from the factorisation above and spilled (the diagonal blocks were 57 % of the leaf)
             if (lane < 16) {
 #pragma unroll
-                for (int ii = 0; ii < 16; ++ii) xd[ii * BR + i] = x[ii];  // X(ii, i); zero above the diagonal
+                for (int k = 0; k < 16; ++k) LT[k * 16 + i] = d[k];       // LT(k, i) = L(i, k)
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double x[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) x[ii] = (ii == i) ? 1.0 : 0.0;
+            // column k of L is read one step ahead of its use (and no further: the registers are the GEMM's neighbours')
+            double lc[16], ln[16];
+#pragma unroll
+            for (int ii = 1; ii < 16; ++ii) lc[ii] = LT[ii];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+#pragma unroll
+                for (int ii = k + 2; ii < 16; ++ii) ln[ii] = LT[(k + 1) * 16 + ii];
+                x[k] *= invs[k];
+#pragma unroll
+                for (int ii = k + 1; ii < 16; ++ii) x[ii] = fma(-lc[ii], x[k], x[ii]);   // (same order of operations as row by row)
+#pragma unroll
+                for (int ii = k + 2; ii < 16; ++ii) lc[ii] = ln[ii];
+                asm volatile("" ::: "memory");      // (keeps the reads of column k + 2 out of this step)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (all four copies of lane i store: under "if (lane < 16)" the compiler sinks the whole substitution below the
+            // branch and keeps every column of L in registers until then)
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) xd[ii * BR + i] = x[ii];  // X(ii, i); zero above the diagonal
         }
+        LEAF_PROBE(2 + 3 * kb);
         __syncthreads();
         // panel slabs below the diagonal block: P = A_panel * D^-T, one slab per wave
         if (wave < 7 - kb) {
@@ -153,6 +183,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
             tile_store(P, lane, acc);
         }
         __syncthreads();
+        LEAF_PROBE(3 + 3 * kb);
         // trailing update: tiles (ti, tj), kb < tj <= ti, round-robin over the waves
         {
             const int nt = 7 - kb;  // tile rows below the panel
@@ -167,6 +198,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
                 }
         }
         __syncthreads();
+        LEAF_PROBE(4 + 3 * kb);
     }
 
     // ------------------------------- phase B: X = L^-1 -------------------------------
@@ -204,6 +236,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
             tile_store(Lk, lane, acc);
         }
         __syncthreads();
+        LEAF_PROBE(26 + kb);
     }
 
 #pragma unroll 8
@@ -211,6 +244,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
         double v = (row >= c) ? blk(S, row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] : 0.0;
         X[(size_t)(o + c) * ldx + o + row] = v;
     }
+    LEAF_PROBE(34);
 }
 
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s) {
