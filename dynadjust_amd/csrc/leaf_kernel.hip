@@ -76,8 +76,11 @@ __device__ __forceinline__ void tile_store(double* B, int lane, d4 v) {
 
 __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
                                                                int ldx, int o, int* info) {
-    __shared__ double S[36 * BS];
-    __shared__ double LT[256];   // the factor of the current diagonal block, transposed (wave 0 only)
+    // LT: the factor of the current diagonal block, transposed (wave 0 only) -- first, so that its constant addresses fit the
+    // 16-bit offset field of the ds instructions (behind S they took a register each)
+    __shared__ double SH[256 + 36 * BS];
+    double* const LT = SH;
+    double* const S = SH + 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -112,10 +115,21 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
         double* xd = blk(S, kb, kb);
         if (wave == 0) {
             const int i = lane & 15;
-            double d[16], invs[16];
+            double d[16];
             int bad = 16;
 #pragma unroll
             for (int j = 0; j < 16; ++j) d[j] = xd[i * BR + j];
+            // Right-looking, one column per step.  The pivot chain (pivot -> rsqrt -> scaled column -> next pivot) only needs the
+            // updates of the next two columns at once: those two multipliers come by v_readlane; the others travel through LDS
+            // (column k written by its lanes, read back as broadcasts) and are applied one step later, after the next pivot's
+            // Newton iterations.  Every d[j] still receives its updates in ascending k: same bits as one column at a time.
+            // The same multipliers drive the forward substitution D X = I (lane j solves column j:
+            // x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii) in the same steps -- as v_readlane values in a loop of its own they
+            // were kept in 240 SGPRs and spilled: the diagonal blocks were 57 % of the leaf.
+            double lp[16];                      // column k - 1 of L, rows k + 2 .. 15 (in flight during step k)
+            double x[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) x[ii] = (ii == i) ? 1.0 : 0.0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 double pk = readlane_f64(d[k], k);
@@ -130,45 +144,33 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
                 y = y * fma(-h * y, y, 1.5);
                 double r = pk * y;
                 r = fma(fma(-r, r, pk), 0.5 * y, r);
-                invs[k] = y;
-                d[k] = (i == k) ? r : d[k] * y;
+                __builtin_amdgcn_sched_barrier(0);   // (a late update hoisted above the Newton steps would wait for LDS there)
+                // the late updates of column k - 1 (rows k + 2 ..; rows k, k + 1 were done in step k - 1)
+                if (k > 0) {
 #pragma unroll
-                for (int j = k + 1; j < 16; ++j) {
+                    for (int j = k + 2; j < 16; ++j) {
+                        d[j] = fma(-d[k - 1], lp[j], d[j]);
+                        x[j] = fma(-lp[j], x[k - 1], x[j]);
+                        asm volatile("" : "+v"(x[j]));                   // (here, not sunk to the store below with lp[] kept alive)
+                    }
+                }
+                d[k] = (i == k) ? r : d[k] * y;
+                LT[k * 16 + i] = d[k];                                   // LT(k, i) = L(i, k): all four copies of lane i write it
+                x[k] *= y;
+#pragma unroll
+                for (int j = k + 1; j < 16 && j <= k + 2; ++j) {
                     double ljk = readlane_f64(d[k], j);
                     d[j] = fma(-d[k], ljk, d[j]);
+                    x[j] = fma(-ljk, x[k], x[j]);
+                    asm volatile("" : "+v"(x[j]));
                 }
+                asm volatile("" ::: "memory");                           // (LDS is in order within a wave: no wait needed)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = k + 3; j < 16; ++j) lp[j] = LT[k * 16 + j];
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (bad < 16 && lane == 0) atomicMin(info, o + p0 + bad + 1);
-            // lane j solves column j of D X = I:  x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii.  Every lane needs every L_ik:
-            // they go through LDS (one row per lane out, broadcast reads back) -- as v_readlane values they were kept in
-            // 240 SGPRs from the factorisation above and spilled (the diagonal blocks were 57 % of the leaf)
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) LT[k * 16 + i] = d[k];       // LT(k, i) = L(i, k)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double x[16];
-#pragma unroll
-            for (int ii = 0; ii < 16; ++ii) x[ii] = (ii == i) ? 1.0 : 0.0;
-            // column k of L is read one step ahead of its use (and no further: the registers are the GEMM's neighbours')
-            double lc[16], ln[16];
-#pragma unroll
-            for (int ii = 1; ii < 16; ++ii) lc[ii] = LT[ii];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-#pragma unroll
-                for (int ii = k + 2; ii < 16; ++ii) ln[ii] = LT[(k + 1) * 16 + ii];
-                x[k] *= invs[k];
-#pragma unroll
-                for (int ii = k + 1; ii < 16; ++ii) x[ii] = fma(-lc[ii], x[k], x[ii]);   // (same order of operations as row by row)
-#pragma unroll
-                for (int ii = k + 2; ii < 16; ++ii) lc[ii] = ln[ii];
-                asm volatile("" ::: "memory");      // (keeps the reads of column k + 2 out of this step)
-                __builtin_amdgcn_sched_barrier(0);
-            }
             // (all four copies of lane i store: under "if (lane < 16)" the compiler sinks the whole substitution below the
             // branch and keeps every column of L in registers until then)
 #pragma unroll
