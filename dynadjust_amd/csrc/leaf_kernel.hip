@@ -1,10 +1,10 @@
 // Leaf of the recursive inverse: one 128x128 diagonal tile, one workgroup (8 waves).
 // Reads the lower triangle of A(o:o+128, o:o+128), factors it (L L^T) and writes X = L^-1
-// (lower, zeros above the diagonal) to the X buffer.  The tile lives in LDS as its lower 16x16 blocks (76.5 KiB of the
+// (lower, zeros above the diagonal) to the X buffer.  The tile lives in LDS as its lower 16x16 blocks (78.5 KiB of the
 // CU's 160 KiB: room for a tile-GEMM workgroup beside it).  Both phases are blocked by 16-column panels:
 //   phase A (Cholesky), per panel kb
-//     [wave 0]   factor the 16x16 diagonal block D and invert it, entirely in registers
-//                (one row / column per lane, v_readlane broadcasts, v_rsq_f64 + Newton)
+//     [wave 0]   factor the 16x16 diagonal block D and invert it: one row / column per lane in registers, v_rsq_f64 +
+//                Newton, the two multipliers the pivot chain needs at once by v_readlane, the others as LDS broadcasts
 //     [waves]    P = A_panel * D^-T            one 16-row slab per wave, 4 MFMA f64 16x16x4
 //     [waves]    A_trail -= P P^T              16x16 tiles round-robin over the waves
 //   phase B (X = L^-1, in place), per panel kb -- the D^-1 of phase A are reused
@@ -53,7 +53,7 @@ __device__ __forceinline__ d4 mma16(const double* a, int ars, int acs, const dou
 
 // The tile lives in LDS as its 36 lower 16x16 blocks (block (bi, bj), bi >= bj, at (bi (bi + 1) / 2 + bj) * BS, rows BR apart):
 // 76.5 KiB instead of 149 KiB for the square tile + separate diagonal inverses, so that a leaf can share a CU with one workgroup
-// of the tile GEMM (72 KiB).  Measured: same 69 us alone, and the same step time with four chains in flight (the GPU is busy
+// of the tile GEMM (72 KiB).  Measured: same duration alone, and the same step time with four chains in flight (the GPU is busy
 // with GEMMs 99 % of the wall time either way) -- kept for the footprint.
 constexpr int BR = 17;        // row stride inside a block (odd: conflict-free column reads)
 constexpr int BS = 16 * BR;   // doubles per block
