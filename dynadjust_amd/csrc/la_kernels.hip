@@ -198,11 +198,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
 #pragma unroll
         for (int ni = 0; ni < G::NI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    d2 ga[G::NQ], gb[G::NQ];
+    // Staging registers: a ring of RS slabs.  A 64-tile slab is 16 MFMAs per wave (0.43 us at the MFMA rate) against a
+    // global-load latency of 0.7-1 us: three slabs in flight (12 more registers per operand) instead of one keep the loop off
+    // the memory latency.  Measured gain: small (36 workgroups, K = 512: 25 -> 23 us; 136 workgroups, K = 1024: 49 -> 44 us) --
+    // these launches are bound by the MFMA rate of the few CUs they occupy (13.7 us of the 23), not by the loads.
+    // Slab s lives in ring slot s % RS from its load (issued at the start of slab s - RS) to its LDS store (during slab s - 1).
+    constexpr int RS = (TILE == 64) ? 3 : 1;
+    d2 ga[RS][G::NQ], gb[RS][G::NQ];
     uint32_t offa[G::NQ], offb[G::NQ];
     stage_offsets<A_KC, TILE, WAVES>(a.lda, tid, offa);
     stage_offsets<B_KC, TILE, WAVES>(a.ldb, tid, offb);
     const int nk = (kend - kbeg) / 16;
+    // (slabs beyond the last one are clamped to it: loaded again, stored to the idle buffer, never used -- the slab body stays
+    // branch free)
+    auto load_slab = [&](int sl, auto slot_tag) {
+        constexpr int slot = decltype(slot_tag)::value;
+        const int k0 = kbeg + (sl < nk ? sl : nk - 1) * 16;
+        stage_load<G::NQ>(stage_base<A_KC>(a.A, a.lda, i0, k0), offa, ga[slot]);
+        stage_load<G::NQ>(stage_base<B_KC>(a.B, a.ldb, j0, k0), offb, gb[slot]);
+    };
 
     // MFMA fragments, two register sets: while the MFMAs of k-step kk run, the fragments of kk+1 are on their way
     double af[2][G::MI], bf[2][G::NI];
@@ -223,10 +237,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
     };
 
     if (nk > 0) {
-        stage_load<G::NQ>(stage_base<A_KC>(a.A, a.lda, i0, kbeg), offa, ga);
-        stage_load<G::NQ>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg), offb, gb);
-        stage_store<A_KC, TILE, WAVES>(lds, tid, ga);
-        stage_store<B_KC, TILE, WAVES>(lds + G::OPBUF, tid, gb);
+        load_slab(0, std::integral_constant<int, 0>{});
+        if (RS > 1) load_slab(1, std::integral_constant<int, 1 % RS>{});
+        if (RS > 2) load_slab(2, std::integral_constant<int, 2 % RS>{});
+        stage_store<A_KC, TILE, WAVES>(lds, tid, ga[0]);
+        stage_store<B_KC, TILE, WAVES>(lds + G::OPBUF, tid, gb[0]);
     }
     __syncthreads();
     if (nk > 0) read_frags(lds, lds + G::OPBUF, 0, 0);
@@ -241,16 +256,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
     constexpr int NM = G::MI * G::NI;                 // MFMAs per k-step
     constexpr int NL = 2 * G::NQ;                     // global loads / LDS stores per slab
     constexpr int NR = G::MI + G::NI;                 // fragment reads per k-step (before ds_read2 merging)
-    auto slab = [&](int t, auto more_tag) {
-        constexpr bool more = decltype(more_tag)::value;
+    auto slab = [&](int t, auto slot_tag) {
+        constexpr bool more = true;
+        constexpr int slot = decltype(slot_tag)::value;      // t % RS: free since slab t went to LDS; slab t + RS moves in
+        constexpr int nxt = (slot + 1) % RS;                 // slab t + 1: goes to LDS during this slab
         const int cur = t & 1;
         const double* As = lds + cur * 2 * G::OPBUF;
         const double* Bs = As + G::OPBUF;
         double* An = lds + (cur ^ 1) * 2 * G::OPBUF;
-        if (more) {
-            stage_load<G::NQ>(stage_base<A_KC>(a.A, a.lda, i0, kbeg + (t + 1) * 16), offa, ga);
-            stage_load<G::NQ>(stage_base<B_KC>(a.B, a.ldb, j0, kbeg + (t + 1) * 16), offb, gb);
-        }
+        load_slab(t + RS, slot_tag);
         read_frags(As, Bs, 1, 1);
         mfmas(0);
 #pragma unroll
@@ -270,10 +284,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
         __builtin_amdgcn_sched_barrier(0);
         read_frags(As, Bs, 3, 1);
         mfmas(0);
-        if (more) {
-            stage_store<A_KC, TILE, WAVES>(An, tid, ga);
-            stage_store<B_KC, TILE, WAVES>(An + G::OPBUF, tid, gb);
-        }
+        stage_store<A_KC, TILE, WAVES>(An, tid, ga[nxt]);
+        stage_store<B_KC, TILE, WAVES>(An + G::OPBUF, tid, gb[nxt]);
 #pragma unroll
         for (int g = 0; g < NL; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -291,8 +303,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int t = 0; t + 1 < nk; ++t) slab(t, std::true_type{});
-    if (nk > 0) slab(nk - 1, std::false_type{});
+    {
+        int t = 0;
+        for (; t + RS <= nk; t += RS) {
+            slab(t, std::integral_constant<int, 0>{});
+            if (RS > 1) slab(t + 1, std::integral_constant<int, 1 % RS>{});
+            if (RS > 2) slab(t + 2, std::integral_constant<int, 2 % RS>{});
+        }
+        if (RS > 1 && t < nk) slab(t, std::integral_constant<int, 0>{});
+        if (RS > 2 && t + 1 < nk) slab(t + 1, std::integral_constant<int, 1 % RS>{});
+    }
 
     // epilogue: acc[mi][ni][r] = C(i = i0+wm*WTM+mi*16+(lane&15), j = j0+wn*WTN+ni*16+(lane>>4)+4r)
     const bool mirror = a.mirror && (it != jt);
