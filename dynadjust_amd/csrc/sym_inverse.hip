@@ -1,3 +1,7 @@
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <cstdio>
 #include "sym_inverse.h"
 #include "la_kernels.h"
 #include <algorithm>
@@ -108,6 +112,22 @@ void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
         }
         p.flops += gemm_flops(a);
         p.launches++;
+    }
+    // DNAGPU_GEMM_HISTOGRAM=1: launch shapes (tile, workgroups, K) counted and printed when the process ends (diagnostic)
+    static const bool hist = getenv("DNAGPU_GEMM_HISTOGRAM") != nullptr;
+    if (hist) {
+        struct Hist {
+            std::mutex m;
+            std::map<std::tuple<int, int, int>, long> n;
+            ~Hist() {
+                for (auto& kv : n)
+                    fprintf(stderr, "gemm tile=%d workgroups=%d K=%d launches=%ld\n", std::get<0>(kv.first), std::get<1>(kv.first),
+                            std::get<2>(kv.first), kv.second);
+            }
+        };
+        static Hist h;
+        std::lock_guard<std::mutex> g(h.m);
+        h.n[std::make_tuple(a.tile, a.grid, a.K)]++;
     }
     launch_gemm(a, akc, bkc, ws.stream);
 }
