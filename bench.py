@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--reuse-inverses", action="store_true",
                     help="phased GNSS-only networks: keep the block inverses of the first iteration in HBM and reuse them "
                          "(identical results, half the Solve() calls; NOT what the reference does in phased mode, so not the default)")
+    ap.add_argument("--stage", action="store_true",
+                    help="the reference's --staged-adjustment: rigorous variance matrices leave HBM for page-locked host memory "
+                         "(switches itself on when they do not fit; this flag forces it for measurements)")
     ap.add_argument("--reference-schedule", action="store_true",
                     help="every forward / reverse step inverts its block like the reference's Solve() (a.schur_carry = 0) instead of "
                          "eliminating the inner unknowns of the steps that are only carried on")
@@ -215,7 +218,8 @@ def main():
     a = adjust.DnaAdjust()
     p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode,
                                multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank,
-                               reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors)
+                               reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors,
+                               stage=phased and args.stage)
     a.PrepareAdjustment(p)
     lib = a.lib
     ctx = a.device_context()

@@ -96,6 +96,8 @@ def load():
     _sig(lib, "dnagpu_matrix_reset", i, [vp, i, vp, u32])
     _sig(lib, "dnagpu_matrix_upload_packed", i, [vp, i, vp, c_f64p, u32])
     _sig(lib, "dnagpu_matrix_download_packed", i, [vp, i, vp, c_f64p])
+    _sig(lib, "dnagpu_matrix_download_packed_async", i, [vp, i, vp, c_f64p])
+    _sig(lib, "dnagpu_copies_sync", i, [vp])
     _sig(lib, "dnagpu_matrix_copy", i, [vp, i, vp, vp])
     _sig(lib, "dnagpu_matrix_export", i, [vp, i, vp, vp, sz])
     _sig(lib, "dnagpu_matrix_import", i, [vp, i, vp, vp, u32])
@@ -234,7 +236,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_device_count", "dnagpu_create", "dnagpu_destroy", "dnagpu_last_error", "dnagpu_last_info", "dnagpu_sync",
     "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset",
     "dnagpu_profile_get", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
-    "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
+    "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_download_packed_async", "dnagpu_copies_sync", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",

@@ -106,6 +106,13 @@ struct dnagpu_ctx {
     uint32_t* red_idx_host[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
     int* bad_dev = nullptr;
     std::map<uint32_t, dnagpu::Block> blocks;
+    // dnagpu_matrix_download_packed_async: per chain a copy stream, a device staging buffer (the packed triangle) and the events
+    // that order pack -> copy -> next pack; created on first use
+    hipStream_t copy_stream[DNAGPU_NUM_CHAINS] = {};
+    hipEvent_t pack_done[DNAGPU_NUM_CHAINS] = {}, copy_done[DNAGPU_NUM_CHAINS] = {};
+    double* stage_buf[DNAGPU_NUM_CHAINS] = {};
+    size_t stage_cap[DNAGPU_NUM_CHAINS] = {};
+    bool copy_pending[DNAGPU_NUM_CHAINS] = {};
     std::mutex schur_mutex;        // the per-block unknown orders of dnagpu_schur_carry are created on first use, by either chain's thread
     bool profile = false;
     double profile_ms_acc = 0.0;   // union length of the timed GEMM runs collected so far (dnagpu_profile_get)

@@ -214,6 +214,10 @@ void dnagpu_destroy(dnagpu_ctx* ctx) {
         if (ctx->red_idx_host[c]) hipHostFree(ctx->red_idx_host[c]);
         if (ctx->ev[c]) hipEventDestroy(ctx->ev[c]);
         if (ctx->stream[c]) hipStreamDestroy(ctx->stream[c]);
+        if (ctx->stage_buf[c]) hipFree(ctx->stage_buf[c]);
+        if (ctx->pack_done[c]) hipEventDestroy(ctx->pack_done[c]);
+        if (ctx->copy_done[c]) hipEventDestroy(ctx->copy_done[c]);
+        if (ctx->copy_stream[c]) hipStreamDestroy(ctx->copy_stream[c]);
     }
     if (ctx->bad_dev) hipFree(ctx->bad_dev);
     delete ctx;
@@ -248,6 +252,11 @@ int dnagpu_mem_info(dnagpu_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
 int dnagpu_sync(dnagpu_ctx* ctx) {
     CHK_CTX();
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) HIPCHK(hipStreamSynchronize(ctx->stream[c]));
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c)
+        if (ctx->copy_stream[c]) {
+            HIPCHK(hipStreamSynchronize(ctx->copy_stream[c]));
+            ctx->copy_pending[c] = false;
+        }
     return DNAGPU_OK;
 }
 
@@ -399,6 +408,53 @@ int dnagpu_matrix_download_packed(dnagpu_ctx* ctx, int chain, const dnagpu_matri
     launch_pack_lower(m->F, ctx->ws[chain].X, m->n, m->np, ctx->stream[chain]);
     if (cnt) HIPCHK(hipMemcpyAsync(ap, ctx->ws[chain].X, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
     HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || (!ap && m->n)) return fail(ctx, DNAGPU_EINVAL, "matrix_download_packed_async: bad arguments");
+    const size_t cnt = (size_t)m->n * (m->n + 1) / 2;
+    if (!cnt) return DNAGPU_OK;
+    if (!ctx->copy_stream[chain]) {
+        if (hipStreamCreateWithFlags(&ctx->copy_stream[chain], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->pack_done[chain], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->copy_done[chain], hipEventDisableTiming) != hipSuccess)
+            return dnagpu_matrix_download_packed(ctx, chain, m, ap);
+    }
+    if (ctx->stage_cap[chain] < cnt) {
+        HIPCHK(hipStreamSynchronize(ctx->copy_stream[chain]));
+        ctx->copy_pending[chain] = false;
+        if (ctx->stage_buf[chain]) hipFree(ctx->stage_buf[chain]);
+        ctx->stage_buf[chain] = nullptr;
+        ctx->stage_cap[chain] = 0;
+        if (hipMalloc(&ctx->stage_buf[chain], cnt * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->stage_buf[chain] = nullptr;
+            return dnagpu_matrix_download_packed(ctx, chain, m, ap);   // no room for the staging buffer: the chain waits for its copy
+        }
+        ctx->stage_cap[chain] = cnt;
+    }
+    // the previous copy out of this buffer must have left before it is packed again
+    if (ctx->copy_pending[chain]) HIPCHK(hipStreamWaitEvent(ctx->stream[chain], ctx->copy_done[chain], 0));
+    launch_pack_lower(m->F, ctx->stage_buf[chain], m->n, m->np, ctx->stream[chain]);
+    HIPCHK(hipEventRecord(ctx->pack_done[chain], ctx->stream[chain]));
+    HIPCHK(hipStreamWaitEvent(ctx->copy_stream[chain], ctx->pack_done[chain], 0));
+    HIPCHK(hipMemcpyAsync(ap, ctx->stage_buf[chain], cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream[chain]));
+    HIPCHK(hipEventRecord(ctx->copy_done[chain], ctx->copy_stream[chain]));
+    ctx->copy_pending[chain] = true;
+    return DNAGPU_OK;
+}
+
+int dnagpu_copies_sync(dnagpu_ctx* ctx) {
+    CHK_CTX();
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        if (!ctx->copy_stream[c]) continue;
+        HIPCHK(hipStreamSynchronize(ctx->stream[c]));        // (a pack that was only just enqueued)
+        HIPCHK(hipStreamSynchronize(ctx->copy_stream[c]));
+        ctx->copy_pending[c] = false;
+    }
     return DNAGPU_OK;
 }
 

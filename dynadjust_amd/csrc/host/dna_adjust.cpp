@@ -906,6 +906,9 @@ void dna_adjust::AdjustPhased() {
         maxCorr_ = 0.0;
         ++currentIteration_;
         const double it_t0 = now_ms();
+        // staged mode: the previous iteration's copies to host memory overlap UpdateAdjustment and, with the condensed schedule,
+        // the condensing and chain phases as well -- they only have to be home before the same buffers are written again
+        if (!CondensedSchedule()) FinishStagedCopies();
         if (CondensedSchedule()) {
             AdjustPhasedCondensedIteration();
         } else if (projectSettings_.a.multi_thread && NumChains() >= 2) {
@@ -922,7 +925,13 @@ void dna_adjust::AdjustPhased() {
         if (!iterate) break;
         UpdateAdjustment(iterate);
     }
+    FinishStagedCopies();
     ValidateandFinaliseAdjustment();
+}
+
+// staged mode: the rigorous variance matrices of the iteration are on their way to host memory on the chains' copy streams
+void dna_adjust::FinishStagedCopies() {
+    if (ctx_ && Staged()) Check(dnagpu_copies_sync(ctx_), 0, "SerialiseBlockToMappedFile()");
 }
 
 void dna_adjust::GetBlockRigorousStations(UINT32 block, std::vector<double>& xyz) {

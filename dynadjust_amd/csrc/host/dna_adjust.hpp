@@ -213,6 +213,7 @@ public:
     void RigorousBlocks(const std::vector<UINT32>& blocks);
     // condensed block k as one buffer: np*np matrix + np vector, np = pad128(3 * kept stations)
     size_t CondensedPayloadDoubles(UINT32 k) const;
+    void FinishStagedCopies();   // staged mode: waits for the rigorous variance matrices on their way to host memory
     void ExportCondensed(UINT32 k, double* dst);
     void ImportCondensed(UINT32 k, const double* src);
     // ---- GenerateStatistics in parts (one process per GPU: every process does the blocks whose rigorous variances it holds) ----

@@ -221,7 +221,8 @@ void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
             Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
         }
         const auto t0 = std::chrono::steady_clock::now();
-        Check(dnagpu_matrix_download_packed(ctx_, c, W, B.rig_host), k, "UpdateEstimatesFinal()");
+        // (on a copy stream: the chain goes on with its next block; AdjustPhased waits for the copies at the end of the iteration)
+        Check(dnagpu_matrix_download_packed_async(ctx_, c, W, B.rig_host), k, "UpdateEstimatesFinal()");
         profileStageStoreNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         B.has_rigvar = true;
         B.inverse_pending = false;
@@ -653,6 +654,7 @@ void dna_adjust::CondensedChains() {
 }
 
 void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks) {
+    FinishStagedCopies();          // (the previous iteration's: their host buffers are about to be written again)
     forward_ = false;
     isCombining_ = true;
     ForBlocks(blocks, [&](int c, UINT32 k) { RigorousBlock(c, k); });
@@ -690,6 +692,7 @@ void dna_adjust::ImportCondensed(UINT32 k, const double* src) {
 }
 
 void dna_adjust::PhasedBeginIteration() {
+    if (!CondensedSchedule()) FinishStagedCopies();
     maxCorr_ = 0.0;
     ++currentIteration_;
 }
@@ -702,7 +705,10 @@ bool dna_adjust::PhasedEndIteration() {
     return iterate;
 }
 
-void dna_adjust::PhasedFinish() { ValidateandFinaliseAdjustment(); }
+void dna_adjust::PhasedFinish() {
+    FinishStagedCopies();
+    ValidateandFinaliseAdjustment();
+}
 
 size_t dna_adjust::JunctionPayloadDoubles(UINT32 k) const {
     size_t n = (size_t)v_JSL_.at(k).size() * 3;

@@ -379,7 +379,7 @@ int dnaadj_phased_condensed_reverse(dnaadj_handle* h, uint32_t block) {
     return guarded(h, [&] { h->adj->CondensedReverseBlock(0, block); });
 }
 int dnaadj_phased_rigorous_block(dnaadj_handle* h, uint32_t block, double* mv) {
-    return guarded(h, [&] { double v = h->adj->RigorousBlock(0, block); if (mv) *mv = v; });
+    return guarded(h, [&] { h->adj->FinishStagedCopies(); double v = h->adj->RigorousBlock(0, block); if (mv) *mv = v; });
 }
 int dnaadj_phased_condense_blocks(dnaadj_handle* h, const uint32_t* blocks, size_t n) {
     return guarded(h, [&] { h->adj->CondenseBlocks(std::vector<uint32_t>(blocks, blocks + n)); });

@@ -97,6 +97,13 @@ void dnagpu_matrix_destroy(dnagpu_ctx* ctx, dnagpu_matrix* m);
 int dnagpu_matrix_reset(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, uint32_t n);
 int dnagpu_matrix_upload_packed(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* ap, uint32_t n);
 int dnagpu_matrix_download_packed(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap);
+/* The same, without holding the chain: the triangle is packed into a per-chain device staging buffer on the chain's stream and
+ * leaves on a copy stream of its own; the chain's next kernels overlap the transfer.  `ap` must be page-locked (dnagpu_host_alloc)
+ * and is complete after dnagpu_copies_sync() or dnagpu_sync().  Falls back to the synchronous call when the staging buffer does
+ * not fit.  (The reference's --staged-adjustment writes each block's matrices to its memory-mapped file inside
+ * SerialiseBlockToMappedFile, dnaadjust-stage.cpp: on the path of the next block.) */
+int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap);
+int dnagpu_copies_sync(dnagpu_ctx* ctx);
 int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dnagpu_matrix* src);
 /* raw copies of a matrix together with its attached junction estimates: np*np doubles (ld = np) followed by np
  * doubles, np = ceil(n/128)*128; dst / src may be host or device memory (this is the payload of the inter-GPU
