@@ -25,6 +25,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.
+# Four chain streams fill them: with RCCL's stream (N > 1) or the staged mode's copy streams beside them, the forward and the
+# reverse chain of the condensed schedule landed on one queue (chain phase 27 -> 48 ms per iteration).  Must be set before the
+# HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 WORKLOADS = {
     # name: (rows, cols, baselines, blocks, phased, description)
     "cfg3": (316, 317, 266666, 16, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, 16 blocks"),

@@ -75,6 +75,8 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()')")
     # kernel-tuning experiments (tools/build_variant.sh) load an alternative build of the same library
+    # (only effective if the HIP runtime has not started in this process yet: see bench.py / INTEGRATION.md)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = C.CDLL(os.environ.get("DNAGPU_LIB_OVERRIDE") or LIB_PATH, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     i = C.c_int

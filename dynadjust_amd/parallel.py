@@ -281,11 +281,15 @@ def run_phased_condensed(backend, dist, rank, world, max_iterations=10):
     for k in range(B):
         offs[k + 1] = offs[k] + 3 * backend.n_stations(k)
     corrections = []
+    import os
+    timing = bool(int(os.environ.get("DNAGPU_DIST_TIMING", "0")))     # diagnostic: where an iteration's wall time goes, per rank
     for _ in range(max_iterations):
+        tm = [time.perf_counter()]
         backend.begin_iteration()
         mine = [k for k in range(B) if owner[k] == rank]
         # (A) + exchange: one broadcast per block from its owner, all in flight together
         backend.condense_blocks(mine)
+        tm.append(time.perf_counter())
         if _exchanging(world):
             pending = []
             for k in range(B):
@@ -296,14 +300,24 @@ def run_phased_condensed(backend, dist, rank, world, max_iterations=10):
             for k, t, _ in pending:
                 if owner[k] != rank or world == 1:       # (world == 1: forced exchange, re-importing its own payload)
                     backend.import_condensed(k, t)
+        tm.append(time.perf_counter())
         # (B) the two chains on the condensed blocks, everywhere
         backend.condensed_chains()
+        tm.append(time.perf_counter())
         # (C)
         backend.rigorous_blocks(mine)
+        tm.append(time.perf_counter())
         if _exchanging(world):
             _sync_coordinates(backend, dist, rank, world, lambda k: owner[k], offs, backend.comm_device)
         corrections.append(backend.max_correction())
-        if not backend.end_iteration():
+        tm.append(time.perf_counter())
+        more = backend.end_iteration()
+        tm.append(time.perf_counter())
+        if timing:
+            names = ("condense", "exchange", "chains", "rigorous", "coordinates", "end_iteration")
+            print("rank %d iteration %d: " % (rank, len(corrections)) +
+                  ", ".join("%s %.1f ms" % (n, 1e3 * (tm[i + 1] - tm[i])) for i, n in enumerate(names)), flush=True)
+        if not more:
             break
     status = backend.finish()
     return status, len(corrections), corrections, owner
