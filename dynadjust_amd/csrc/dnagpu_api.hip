@@ -1,4 +1,5 @@
 // Implementation of the C-ABI declared in include/dnagpu.h.
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -158,6 +159,11 @@ int check_info(dnagpu_ctx* ctx, int chain) {
     ctx->last_info = 0;
     return DNAGPU_OK;
 }
+
+// HIP serialises streams that share one of its GPU_MAX_HW_QUEUES (default 4) hardware queues; the four chain streams fill them,
+// and RCCL's or the staged mode's copy streams beside them made two chains share a queue.  Raised
+// when the library is loaded -- effective unless the process started the HIP runtime before, or set the variable itself.
+__attribute__((constructor)) void dnagpu_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 }  // namespace
 
