@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
     double* const S = SH + 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches instead of exec masks)
     const int row = tid & 127;
     const int q = tid >> 7;  // 0..3
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
@@ -186,18 +186,49 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
         }
         __syncthreads();
         LEAF_PROBE(3 + 3 * kb);
-        // trailing update: tiles (ti, tj), kb < tj <= ti, round-robin over the waves
+        // trailing update: tiles (ti, tj), kb < tj <= ti, dealt round-robin to the waves; a wave has the operands of its next
+        // tile on their way from LDS while the MFMAs of the current one run
         {
             const int nt = 7 - kb;  // tile rows below the panel
-            int t = 0;
-            for (int ti = 0; ti < nt; ++ti)
-                for (int tj = 0; tj <= ti; ++tj, ++t) {
-                    if ((t & 7) != wave) continue;
-                    double* C = blk(S, kb + 1 + ti, kb + 1 + tj);
-                    d4 acc = tile_load(C, lane);
-                    acc = mma16(blk(S, kb + 1 + ti, kb), BR, 1, blk(S, kb + 1 + tj, kb), 1, BR, acc, -1.0, lane);
-                    tile_store(C, lane, acc);
+            const int T = nt * (nt + 1) / 2;
+            const int lo = lane & 15, hi = lane >> 4;
+            auto fetch = [&](int t, d4& c, double (&a)[4], double (&b)[4], double*& C) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                C = blk(S, kb + 1 + ti, kb + 1 + tj);
+                c = tile_load(C, lane);
+                const double* A = blk(S, kb + 1 + ti, kb);
+                const double* B = blk(S, kb + 1 + tj, kb);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    a[kk] = A[lo * BR + 4 * kk + hi];
+                    b[kk] = B[lo * BR + 4 * kk + hi];
                 }
+            };
+            int t = wave;
+            d4 c = zero;
+            double av[4], bv[4];
+            double* C = nullptr;
+            if (t < T) fetch(t, c, av, bv, C);
+            while (t < T) {
+                const int tn = t + 8;
+                d4 cn = zero;
+                double an[4] = {0.0, 0.0, 0.0, 0.0}, bn[4] = {0.0, 0.0, 0.0, 0.0};
+                double* Cn = nullptr;
+                if (tn < T) fetch(tn, cn, an, bn, Cn);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk], c, 0, 0, 0);
+                tile_store(C, lane, c);
+                c = cn;
+                C = Cn;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    av[kk] = an[kk];
+                    bv[kk] = bn[kk];
+                }
+                t = tn;
+            }
         }
         __syncthreads();
         LEAF_PROBE(4 + 3 * kb);
