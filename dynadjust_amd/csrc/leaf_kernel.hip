@@ -9,8 +9,9 @@
 //     [waves]    A_trail -= P P^T              16x16 tiles round-robin over the waves
 //   phase B (X = L^-1, in place), per panel kb -- the D^-1 of phase A are reused
 //     [waves]    M(kb, :kb) = D^-1 * M(kb, :kb)
-//     [waves]    M(i, :kb) -= L(i,kb) * M(kb, :kb);  M(i,kb) = -L(i,kb) * D^-1     (slab i per wave)
-// 5 barriers per panel instead of 4 per column.  A non-positive or NaN pivot records
+//     [waves]    M(i, :kb) -= L(i,kb) * M(kb, :kb)     16x16 tiles round-robin over the waves
+//     [waves]    M(i,kb) = -L(i,kb) * D^-1             one tile per wave
+// 6 barriers per panel instead of 4 per column.  A non-positive or NaN pivot records
 // info = global column + 1 (dpotrf's info; the facade turns it into the reference's
 // "Matrix inversion failed, the matrix is singular.", dnamatrix_contiguous.cpp:983).
 #include <hip/hip_runtime.h>
@@ -245,24 +246,55 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
             tile_store(M, lane, acc);
         }
         __syncthreads();
-        // slabs below: M(i, :kb) -= L(i,kb) M_k ;  M(i,kb) = -L(i,kb) D^-1   (one slab per wave: L(i,kb) is read
-        // by the wave that finally overwrites it)
-        if (wave < 7 - kb) {
-            const int bi = kb + 1 + wave;
+        // tiles below and left of the panel: M(i, tj) -= L(i,kb) M_k(tj), (7 - kb) kb of them, dealt round-robin to the waves
+        // (a slab per wave left one wave with 7 tiles in a row at kb = 6), the next tile's operands in flight during the MFMAs
+        {
             const int lo = lane & 15, hi = lane >> 4;
-            double* Lk = blk(S, bi, kb);
+            const int T = (7 - kb) * kb;
+            auto fetch = [&](int t, d4& c, double (&a)[4], double (&b)[4], double*& C) {
+                const int bi = kb + 1 + t / kb, tj = t % kb;
+                C = blk(S, bi, tj);
+                c = tile_load(C, lane);
+                const double* Lk = blk(S, bi, kb);
+                const double* Mk = blk(S, kb, tj);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    a[kk] = Lk[lo * BR + 4 * kk + hi];
+                    b[kk] = Mk[(4 * kk + hi) * BR + lo];
+                }
+            };
+            int t = wave;
+            d4 c = zero;
+            double av[4], bv[4];
+            double* C = nullptr;
+            if (t < T) fetch(t, c, av, bv, C);
+            while (t < T) {
+                const int tn = t + 8;
+                d4 cn = zero;
+                double an[4] = {0.0, 0.0, 0.0, 0.0}, bn[4] = {0.0, 0.0, 0.0, 0.0};
+                double* Cn = nullptr;
+                if (tn < T) fetch(tn, cn, an, bn, Cn);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk], c, 0, 0, 0);
+                tile_store(C, lane, c);
+                c = cn;
+                C = Cn;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    av[kk] = an[kk];
+                    bv[kk] = bn[kk];
+                }
+                t = tn;
+            }
+        }
+        __syncthreads();
+        // the panel's own column: M(i,kb) = -L(i,kb) D^-1 over L(i,kb), one tile per wave, after every reader of L(i,kb)
+        if (wave < 7 - kb) {
+            const int lo = lane & 15, hi = lane >> 4;
+            double* Lk = blk(S, kb + 1 + wave, kb);
             double lf[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) lf[kk] = Lk[lo * BR + 4 * kk + hi];
-            for (int tj = 0; tj < kb; ++tj) {
-                double* C = blk(S, bi, tj);
-                const double* Mk = blk(S, kb, tj);
-                d4 acc = tile_load(C, lane);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], Mk[(4 * kk + hi) * BR + lo], acc, 0, 0, 0);
-                tile_store(C, lane, acc);
-            }
             d4 acc = zero;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], xd[(4 * kk + hi) * BR + lo], acc, 0, 0, 0);
