@@ -116,54 +116,50 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
         double* xd = blk(S, kb, kb);
         if (wave == 0) {
             const int i = lane & 15;
-            double d[16];
+            const bool is_d = lane < 16;
             int bad = 16;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) d[j] = xd[i * BR + j];
             // Right-looking, one column per step.  The pivot chain (pivot -> rsqrt -> scaled column -> next pivot) only needs the
             // updates of the next two columns at once: those two multipliers come by v_readlane; the others travel through LDS
             // (column k written by its lanes, read back as broadcasts) and are applied one step later, after the next pivot's
-            // Newton iterations.  Every d[j] still receives its updates in ascending k: same bits as one column at a time.
+            // Newton iterations.  Every element still receives its updates in ascending k: same bits as one column at a time.
             // The same multipliers drive the forward substitution D X = I (lane j solves column j:
             // x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii) in the same steps -- as v_readlane values in a loop of its own they
             // were kept in 240 SGPRs and spilled: the diagonal blocks were 57 % of the leaf.
-            double lp[16];                      // column k - 1 of L, rows k + 2 .. 15 (in flight during step k)
-            double x[16];
+            // Factor and substitution share their instructions: u[] is row i of the block in lanes 0..15 and column i of X in
+            // the other lanes (three copies), and both obey u[j] -= L(j,k) u[k], u[k] *= 1 / L(k,k).
+            double u[16];
 #pragma unroll
-            for (int ii = 0; ii < 16; ++ii) x[ii] = (ii == i) ? 1.0 : 0.0;
+            for (int j = 0; j < 16; ++j) u[j] = is_d ? xd[i * BR + j] : (j == i ? 1.0 : 0.0);
+            double lp[16];                      // column k - 1 of L, rows k + 2 .. 15 (in flight during step k)
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                double pk = readlane_f64(d[k], k);
+                double pk = readlane_f64(u[k], k);
                 if (!(pk > 0.0)) {          // (uniform: a scalar select; reported once per block, below)
                     bad = bad < k ? bad : k;
                     pk = 1.0;
                 }
-                // y = pk^-1/2 (v_rsq_f64 + 2 Newton steps), r = pk^1/2 with one correction
+                // y = pk^-1/2 (v_rsq_f64 + 2 Newton steps).  The diagonal element L(k,k) itself is never needed: the panel below
+                // is solved with D^-1, and every later step reads the column's rows below k only
                 double y = __builtin_amdgcn_rsq(pk);
                 const double h = 0.5 * pk;
                 y = y * fma(-h * y, y, 1.5);
                 y = y * fma(-h * y, y, 1.5);
-                double r = pk * y;
-                r = fma(fma(-r, r, pk), 0.5 * y, r);
                 __builtin_amdgcn_sched_barrier(0);   // (a late update hoisted above the Newton steps would wait for LDS there)
                 // the late updates of column k - 1 (rows k + 2 ..; rows k, k + 1 were done in step k - 1)
                 if (k > 0) {
 #pragma unroll
                     for (int j = k + 2; j < 16; ++j) {
-                        d[j] = fma(-d[k - 1], lp[j], d[j]);
-                        x[j] = fma(-lp[j], x[k - 1], x[j]);
-                        asm volatile("" : "+v"(x[j]));                   // (here, not sunk to the store below with lp[] kept alive)
+                        u[j] = fma(-lp[j], u[k - 1], u[j]);
+                        asm volatile("" : "+v"(u[j]));                   // (here, not sunk to the store below with lp[] kept alive)
                     }
                 }
-                d[k] = (i == k) ? r : d[k] * y;
-                LT[k * 16 + i] = d[k];                                   // LT(k, i) = L(i, k): all four copies of lane i write it
-                x[k] *= y;
+                u[k] *= y;
+                if (is_d) LT[k * 16 + i] = u[k];                         // LT(k, i) = L(i, k)
 #pragma unroll
                 for (int j = k + 1; j < 16 && j <= k + 2; ++j) {
-                    double ljk = readlane_f64(d[k], j);
-                    d[j] = fma(-d[k], ljk, d[j]);
-                    x[j] = fma(-ljk, x[k], x[j]);
-                    asm volatile("" : "+v"(x[j]));
+                    double ljk = readlane_f64(u[k], j);
+                    u[j] = fma(-ljk, u[k], u[j]);
+                    asm volatile("" : "+v"(u[j]));
                 }
                 asm volatile("" ::: "memory");                           // (LDS is in order within a wave: no wait needed)
                 __builtin_amdgcn_wave_barrier();
@@ -172,10 +168,10 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (bad < 16 && lane == 0) atomicMin(info, o + p0 + bad + 1);
-            // (all four copies of lane i store: under "if (lane < 16)" the compiler sinks the whole substitution below the
-            // branch and keeps every column of L in registers until then)
+            if (!is_d) {
 #pragma unroll
-            for (int ii = 0; ii < 16; ++ii) xd[ii * BR + i] = x[ii];  // X(ii, i); zero above the diagonal
+                for (int ii = 0; ii < 16; ++ii) xd[ii * BR + i] = u[ii];  // X(ii, i); zero above the diagonal
+            }
         }
         LEAF_PROBE(2 + 3 * kb);
         __syncthreads();
