@@ -37,9 +37,9 @@ struct Block {
     // dnaadjust.hpp:1340-1348) so that the forward and the reverse/combine chain can
     // work on the same block concurrently
     double *x_orig = nullptr, *x_rig = nullptr;
-    double *x_est[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    double *rhs[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    double *corr[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    double *x_est[DNAGPU_NUM_CHAINS] = {};
+    double *rhs[DNAGPU_NUM_CHAINS] = {};
+    double *corr[DNAGPU_NUM_CHAINS] = {};
     // baselines, SoA
     uint32_t *s1 = nullptr, *s2 = nullptr;
     double *obs = nullptr;  // 3*n_bl
@@ -48,8 +48,8 @@ struct Block {
     double *Wblk = nullptr;
     uint32_t n_wblk = 0;
     uint32_t *vec_wrow = nullptr, *vec_c0 = nullptr, *vec_k = nullptr;   // per vector: first block of its row, first vector and size of its cluster
-    double *wb[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};                  // 3*n_bl: W b per vector
-    double *b[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};  // 3*n_bl, measured - computed
+    double *wb[DNAGPU_NUM_CHAINS] = {};                  // 3*n_bl: W b per vector
+    double *b[DNAGPU_NUM_CHAINS] = {};  // 3*n_bl, measured - computed
     // deterministic formation structure: station-pair blocks (row >= col), each
     // with the CML-ordered list of contributing baselines
     uint32_t n_pairs = 0;
@@ -58,7 +58,7 @@ struct Block {
     // per-station incidence (CML order) for the rhs: entry = baseline*2 + (1 if station is stn2)
     uint32_t *inc_off = nullptr, *inc = nullptr;
     // scratch for max-correction reduction (value, index) per chain
-    double* red[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    double* red[DNAGPU_NUM_CHAINS] = {};
     // terrestrial measurements (one design row each; csrc/terrestrial.h).  Their 3x3 blocks w a_p^T a_q and vectors
     // a_p w b change with the estimates: one copy per chain, behind the GNSS weight blocks / W b vectors
     uint32_t n_t = 0, n_tblk = 0, n_tvec = 0;
@@ -66,8 +66,8 @@ struct Block {
     uint32_t *t_stn = nullptr, *t_blk0 = nullptr, *t_vec0 = nullptr;
     double *t_val = nullptr, *t_pre = nullptr, *t_var = nullptr, *t_ih = nullptr, *t_th = nullptr;
     double *s_llh = nullptr, *s_geoid = nullptr, *s_defl = nullptr;     // station records: geodetic position, N, deflections
-    double* tb[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};                 // n_t: measured - computed
-    double* trow[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};               // 9 n_t: design rows
+    double* tb[DNAGPU_NUM_CHAINS] = {};                 // n_t: measured - computed
+    double* trow[DNAGPU_NUM_CHAINS] = {};               // 9 n_t: design rows
     // direction sets (type D): rows of a set share a dense weight matrix; their normal-equation blocks couple every pair of
     // station slots of the set (dnagpu_block_set_direction_sets)
     uint32_t n_dsblk = 0;                                  // blocks of all sets, stored behind the per-measurement ones
@@ -78,8 +78,9 @@ struct Block {
     std::vector<DsEnt> h_ds_ents;
     // dnagpu_schur_carry: unknown order with the carried junction stations last, per junction list seen (forward / reverse)
     std::vector<uint32_t> h_schur_idx[2];
-    uint32_t* schur_idx[2] = {nullptr, nullptr};
-    int32_t* schur_map[2] = {nullptr, nullptr};
+    uint32_t* schur_idx[2] = {};
+    int32_t* schur_map[2] = {};
+    std::vector<void*> retired;        // replaced schur_map / schur_idx lists, freed with the block
     // host copies kept until the pair / incidence lists are built (dnagpu_block_set_clusters)
     std::vector<uint8_t> h_ttype;
     std::vector<uint32_t> h_tstn, h_tpos, h_cpos;
@@ -89,21 +90,22 @@ struct Block {
 
 struct dnagpu_ctx {
     int device = 0;
+    std::mutex err_mutex;          // err / last_info: written by whichever chain's host thread fails (dnagpu_api.hip note_error)
     std::string err;
     int last_info = 0;
-    hipStream_t stream[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    hipEvent_t ev[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    hipStream_t stream[DNAGPU_NUM_CHAINS] = {};
+    hipEvent_t ev[DNAGPU_NUM_CHAINS] = {};
     dnagpu::InvWorkspace ws[DNAGPU_NUM_CHAINS];
-    double* symv_part[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    uint32_t symv_cap[DNAGPU_NUM_CHAINS] = {0, 0};
+    double* symv_part[DNAGPU_NUM_CHAINS] = {};
+    uint32_t symv_cap[DNAGPU_NUM_CHAINS] = {};
     // small per-chain staging buffers for index lists / 3x3 weights / vectors
-    uint32_t* scr_u32[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    size_t scr_u32_cap[DNAGPU_NUM_CHAINS] = {0, 0};
-    double* scr_f64[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    size_t scr_f64_cap[DNAGPU_NUM_CHAINS] = {0, 0};
+    uint32_t* scr_u32[DNAGPU_NUM_CHAINS] = {};
+    size_t scr_u32_cap[DNAGPU_NUM_CHAINS] = {};
+    double* scr_f64[DNAGPU_NUM_CHAINS] = {};
+    size_t scr_f64_cap[DNAGPU_NUM_CHAINS] = {};
     // pinned host landing zone for (max correction, row)
-    double* red_val_host[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    uint32_t* red_idx_host[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
+    double* red_val_host[DNAGPU_NUM_CHAINS] = {};
+    uint32_t* red_idx_host[DNAGPU_NUM_CHAINS] = {};
     int* bad_dev = nullptr;
     std::map<uint32_t, dnagpu::Block> blocks;
     // dnagpu_matrix_download_packed_async: per chain a copy stream, a device staging buffer (the packed triangle) and the events

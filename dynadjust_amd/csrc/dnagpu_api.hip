@@ -19,6 +19,23 @@ namespace {
 constexpr uint32_t SYMV_CHUNKS = 32;
 constexpr int INFO_SENTINEL = 0x7f7f7f7f;
 
+// Error text and dpotrf-style info are kept twice: per host thread (every chain of a context is driven by its own host thread,
+// and two chains may fail together) and in the context, under a mutex, for any other thread that asks afterwards.
+thread_local std::string tls_err;
+thread_local int tls_info = 0;
+thread_local const dnagpu_ctx* tls_ctx = nullptr;
+thread_local bool tls_unread = false;
+
+void note_error(dnagpu_ctx* ctx, const char* text, int info) {
+    tls_err = text;
+    tls_info = info;
+    tls_ctx = ctx;
+    tls_unread = true;
+    std::lock_guard<std::mutex> lk(ctx->err_mutex);
+    ctx->err = text;
+    ctx->last_info = info;
+}
+
 int fail(dnagpu_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
     if (ctx) {
         char buf[512];
@@ -26,7 +43,7 @@ int fail(dnagpu_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
             snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
         else
             snprintf(buf, sizeof(buf), "%s", what);
-        ctx->err = buf;
+        note_error(ctx, buf, 0);
     }
     return code;
 }
@@ -135,6 +152,7 @@ void free_block(Block& b) {
                     b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    for (void* p : b.retired) hipFree(p);
     b = Block();
 }
 
@@ -148,22 +166,31 @@ double* station_vec(Block& b, int which, int chain) {
 }
 
 int check_info(dnagpu_ctx* ctx, int chain) {
+    // an enqueue that failed (table allocation, launch, copy) leaves `info` at its sentinel: it is reported first
+    const char* where = nullptr;
+    hipError_t e = inv_take_error(ctx->ws[chain], &where);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, where ? where : "inverse", e);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(ctx, DNAGPU_EHIP, "kernel launch", e);   // (launches of this thread)
     int info = *ctx->ws[chain].info_host;
     if (info != INFO_SENTINEL) {
-        ctx->last_info = info;
         char buf[128];
         snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (leading minor %d)", info);
-        ctx->err = buf;
+        note_error(ctx, buf, info);
         return DNAGPU_ENOTPOSDEF;
     }
-    ctx->last_info = 0;
+    tls_info = 0;
     return DNAGPU_OK;
 }
 
 // HIP serialises streams that share one of its GPU_MAX_HW_QUEUES (default 4) hardware queues; the four chain streams fill them,
 // and RCCL's or the staged mode's copy streams beside them made two chains share a queue.  Raised
 // when the library is loaded -- effective unless the process started the HIP runtime before, or set the variable itself.
-__attribute__((constructor)) void dnagpu_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// Opt-in (DNAGPU_SET_HW_QUEUES=1): a drop-in library does not change its host's environment by itself; the host sets
+// GPU_MAX_HW_QUEUES=16 before the HIP runtime starts (bench.py and the test harness do).
+__attribute__((constructor)) void dnagpu_hw_queues() {
+    const char* e = getenv("DNAGPU_SET_HW_QUEUES");
+    if (e && atoi(e) != 0) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
 
 }  // namespace
 
@@ -229,8 +256,26 @@ void dnagpu_destroy(dnagpu_ctx* ctx) {
     delete ctx;
 }
 
-const char* dnagpu_last_error(const dnagpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-int dnagpu_last_info(const dnagpu_ctx* ctx) { return ctx ? ctx->last_info : 0; }
+// the calling thread's own failure on this context if it has one it has not read yet, else the context's latest
+const char* dnagpu_last_error(const dnagpu_ctx* ctx) {
+    if (!ctx) return "null context";
+    if (!(tls_ctx == ctx && tls_unread)) {
+        dnagpu_ctx* c = const_cast<dnagpu_ctx*>(ctx);
+        std::lock_guard<std::mutex> lk(c->err_mutex);
+        tls_err = c->err;
+        tls_info = c->last_info;
+        tls_ctx = ctx;
+    }
+    tls_unread = false;
+    return tls_err.c_str();
+}
+int dnagpu_last_info(const dnagpu_ctx* ctx) {
+    if (!ctx) return 0;
+    if (tls_ctx == ctx) return tls_info;
+    dnagpu_ctx* c = const_cast<dnagpu_ctx*>(ctx);
+    std::lock_guard<std::mutex> lk(c->err_mutex);
+    return c->last_info;
+}
 
 int dnagpu_host_alloc(dnagpu_ctx* ctx, size_t bytes, void** out) {
     CHK_CTX();
@@ -284,6 +329,13 @@ int dnagpu_chain_wait(dnagpu_ctx* ctx, int waiter, int signaller) {
 }
 
 /* ---- profiling ------------------------------------------------------------ */
+int dnagpu_debug_fail_allocation(long nth) {
+    dnagpu::fault_inject_reset(nth);
+    return DNAGPU_OK;
+}
+
+long dnagpu_debug_set_small_tiles(long tiles) { return dnagpu::small_tiles_set(tiles); }
+
 int dnagpu_profile_enable(dnagpu_ctx* ctx, int on) {
     CHK_CTX();
     ctx->profile = on != 0;
@@ -424,10 +476,21 @@ int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu
     const size_t cnt = (size_t)m->n * (m->n + 1) / 2;
     if (!cnt) return DNAGPU_OK;
     if (!ctx->copy_stream[chain]) {
-        if (hipStreamCreateWithFlags(&ctx->copy_stream[chain], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->pack_done[chain], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->copy_done[chain], hipEventDisableTiming) != hipSuccess)
+        // created into locals and committed together: a half-made set must not look usable to the next call
+        hipStream_t cs = nullptr;
+        hipEvent_t pd = nullptr, cd = nullptr;
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&pd, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&cd, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (cd) hipEventDestroy(cd);
+            if (pd) hipEventDestroy(pd);
+            if (cs) hipStreamDestroy(cs);
             return dnagpu_matrix_download_packed(ctx, chain, m, ap);
+        }
+        ctx->copy_stream[chain] = cs;
+        ctx->pack_done[chain] = pd;
+        ctx->copy_done[chain] = cd;
     }
     if (ctx->stage_cap[chain] < cnt) {
         HIPCHK(hipStreamSynchronize(ctx->copy_stream[chain]));
@@ -952,10 +1015,9 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
         if (dtmp) hipFree(dtmp);
         if (e != hipSuccess) return fail(ctx, DNAGPU_EHIP, "block_set_clusters: weights", e);
         if (bad != 0x7fffffff) {
-            ctx->last_info = bad + 1;
             char buf[160];
             snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (variance matrix of measurement %d)", bad);
-            ctx->err = buf;
+            note_error(ctx, buf, bad + 1);
             return DNAGPU_ENOTPOSDEF;
         }
     }
@@ -1297,9 +1359,10 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
             for (int c = 0; c < 3; ++c) map[nip + 3 * i + c] = (int32_t)(3 * idx_out[i] + c);
         map[nip + nj] = -2;
         slot = b->schur_map[0] ? 1 : 0;
-        HIPCHK(hipDeviceSynchronize());     // the other chain may be reading the slot that is replaced
-        if (b->schur_map[slot]) hipFree(b->schur_map[slot]);
-        if (b->schur_idx[slot]) hipFree(b->schur_idx[slot]);
+        // another chain's thread may hold the replaced slot's pointers for a launch it has not enqueued yet: the old lists are
+        // retired, not freed (a few kB each; a block sees at most a handful of station lists), and go with the block
+        if (b->schur_map[slot]) b->retired.push_back(b->schur_map[slot]);
+        if (b->schur_idx[slot]) b->retired.push_back(b->schur_idx[slot]);
         b->schur_map[slot] = nullptr;
         b->schur_idx[slot] = nullptr;
         HIPCHK(hipMalloc(&b->schur_map[slot], (size_t)npp * sizeof(int32_t)));

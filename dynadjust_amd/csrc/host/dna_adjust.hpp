@@ -345,8 +345,8 @@ private:
 
     std::mutex corr_mutex_, alloc_mutex_;   // multi-thread mode: maxCorr_/solve counters, lazy allocations
     dnagpu_ctx* ctx_ = nullptr;
-    dnagpu_matrix* work_[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};
-    dnagpu_matrix* kwork_[DNAGPU_NUM_CHAINS] = {nullptr, nullptr};   // the kept block of a fused rigorous solve
+    dnagpu_matrix* work_[DNAGPU_NUM_CHAINS] = {};
+    dnagpu_matrix* kwork_[DNAGPU_NUM_CHAINS] = {};   // the kept block of a fused rigorous solve
     UINT32 max_unknowns_ = 0, max_junction_ = 0;
 };
 

@@ -35,7 +35,17 @@ struct InvWorkspace {
     // workgroup->tile tables per launch shape (see tile_order.hip), device resident
     std::map<uint64_t, std::pair<uint32_t*, int>> order_cache;
     std::set<int> planned;  // matrix orders (in tiles) whose tables are all built
+    // First HIP error of a planning pass, table upload, memset / copy or kernel launch enqueued through this workspace since
+    // the last inv_take_error(): the asynchronous drivers below keep enqueuing nothing further once it is set, and the C-ABI
+    // turns it into DNAGPU_ENOMEM / DNAGPU_EHIP instead of trusting `info_host` (a skipped GEMM leaves info at "no failure").
+    hipError_t err = hipSuccess;
+    const char* err_where = nullptr;
 };
+
+// returns the latched error (and where it happened) and clears it
+hipError_t inv_take_error(InvWorkspace& ws, const char** where);
+// latches e (if it is the first) -- also used by the callers for their own enqueues on ws.stream
+void inv_note_error(InvWorkspace& ws, hipError_t e, const char* where);
 
 struct GemmArgs;
 // fills a.order / a.grid from the cache (building + uploading the table on first use)
@@ -69,5 +79,11 @@ void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const do
 void gemm_profile_collect(InvWorkspace& ws);
 void gemm_profile_close(InvWorkspace& ws);   // ends the current run of gemm launches (call before enqueuing any other kernel)
 void gemm_profile_reset(InvWorkspace& ws);
+
+// DNAGPU_FAULT_INJECT=<n>: the n-th tile-table allocation of the process fails with hipErrorOutOfMemory (tests/test_gpu_matrix.py:
+// a failed allocation in the middle of an inverse must surface as DNAGPU_ENOMEM, never as a silently skipped launch)
+void fault_inject_reset(long nth);
+// threshold (in 128-tiles per launch) below which a launch uses the 64-tile kernel; negative restores the default; returns the old value
+long small_tiles_set(long v);
 
 }  // namespace dnagpu

@@ -6,6 +6,7 @@
 #include "la_kernels.h"
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 
 namespace dnagpu {
 
@@ -35,6 +36,32 @@ void inv_workspace_free(InvWorkspace& ws) {
     ws = InvWorkspace();
 }
 
+void inv_note_error(InvWorkspace& ws, hipError_t e, const char* where) {
+    if (e != hipSuccess && ws.err == hipSuccess) {
+        ws.err = e;
+        ws.err_where = where;
+    }
+}
+
+hipError_t inv_take_error(InvWorkspace& ws, const char** where) {
+    hipError_t e = ws.err;
+    if (where) *where = ws.err_where;
+    ws.err = hipSuccess;
+    ws.err_where = nullptr;
+    return e;
+}
+
+// fault injection for the error-path tests: countdown to a failing table allocation
+static std::atomic<long> g_fault_countdown{[] {
+    const char* e = getenv("DNAGPU_FAULT_INJECT");
+    return e ? atol(e) : 0L;
+}()};
+void fault_inject_reset(long nth) { g_fault_countdown.store(nth); }
+static hipError_t table_malloc(uint32_t** dev, size_t bytes) {
+    if (g_fault_countdown.load() > 0 && g_fault_countdown.fetch_sub(1) == 1) return hipErrorOutOfMemory;
+    return hipMalloc(dev, bytes);
+}
+
 static double gemm_flops(const GemmArgs& a) {
     // sum over launched tiles of 2*128*128*klen(tile)
     double f = 0.0;
@@ -56,25 +83,41 @@ static double gemm_flops(const GemmArgs& a) {
     return f;
 }
 
+// launches with fewer 128-tiles than this run on 64 x 64 block tiles (DNAGPU_SMALL_TILES, dnagpu_debug_set_small_tiles: 0 sends
+// every launch through the 128-tile throughput kernel -- how the tests compare THAT kernel with the oracle at small orders)
+static std::atomic<long> g_small_tiles{[] {
+    const char* e = getenv("DNAGPU_SMALL_TILES");
+    return e ? atol(e) : (long)SMALL_LAUNCH_TILES;
+}()};
+long small_tiles_set(long v) {
+    long old = g_small_tiles.load();
+    g_small_tiles.store(v < 0 ? (long)SMALL_LAUNCH_TILES : v);
+    return old;
+}
+
 hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a) {
     long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
-    static const long small_tiles = [] {
-        const char* e = getenv("DNAGPU_SMALL_TILES");
-        return e ? atol(e) : (long)SMALL_LAUNCH_TILES;
-    }();
-    a.tile = total < small_tiles ? 64 : 128;
+    a.tile = total < g_small_tiles.load() ? 64 : 128;
     uint64_t key = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
-                   ((uint64_t)(a.K / 16) << 40);
+                   ((uint64_t)(a.tile == 64 ? 1 : 0) << 37) | ((uint64_t)(a.K / 16) << 40);
     auto it = ws.order_cache.find(key);
     if (it == ws.order_cache.end()) {
         std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower, a.tile);
         uint32_t* dev = nullptr;
         if (!tab.empty()) {
-            hipError_t e = hipMalloc(&dev, tab.size() * sizeof(uint32_t));
-            if (e != hipSuccess) return e;
+            hipError_t e = table_malloc(&dev, tab.size() * sizeof(uint32_t));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                inv_note_error(ws, e, "tile-order table allocation");
+                return e;
+            }
             // synchronous copy: the table is immutable afterwards
             e = hipMemcpy(dev, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) return e;
+            if (e != hipSuccess) {
+                hipFree(dev);
+                inv_note_error(ws, e, "tile-order table upload");
+                return e;
+            }
         }
         it = ws.order_cache.emplace(key, std::make_pair(dev, (int)tab.size())).first;
     }
@@ -103,7 +146,8 @@ void gemm_profile_close(InvWorkspace& ws) {
 }
 
 void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
-    if (gemm_attach_order(ws, a) != hipSuccess) return;
+    // (after a latched error nothing further is enqueued: the result is void anyway and the caller reports the error)
+    if (ws.err != hipSuccess || gemm_attach_order(ws, a) != hipSuccess) return;
     GemmProfile& p = ws.prof;
     if (p.enabled) {
         if (!p.open) {
@@ -130,6 +174,7 @@ void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
         h.n[std::make_tuple(a.tile, a.grid, a.K)]++;
     }
     launch_gemm(a, akc, bkc, ws.stream);
+    inv_note_error(ws, hipGetLastError(), "tile GEMM launch");
 }
 
 void gemm_profile_collect(InvWorkspace& ws) {
@@ -193,9 +238,10 @@ struct Rec {
     // Cholesky factor and its inverse of the s x s tile block at o: F keeps T21 = L21 L11^-1 below the diagonal, X = L^-1
     void node(int o, int s) {
         if (s == 1) {
-            if (!dry) {
+            if (!dry && ws.err == hipSuccess) {
                 gemm_profile_close(ws);
                 launch_leaf(F, ld, X, ldx, o * 128, ws.info, ws.stream);
+                inv_note_error(ws, hipGetLastError(), "leaf launch");
             }
             return;
         }
@@ -243,7 +289,7 @@ struct Rec {
 }  // namespace
 
 void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity, bool reset_info) {
-    if (reset_info) hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
+    if (reset_info) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
     if (scale_to_unity) {
         launch_diag_rsqrt(F, ws.svec, n, np, ws.stream);
         launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
@@ -257,6 +303,7 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
         GemmArgs l;
         l.mt = T; l.nt = T; l.K = (int)np; l.kmode = KM_GE_I; l.lower = 1;
         gemm_attach_order(ws, l);
+        if (ws.err != hipSuccess) return;      // (not marked as planned: the next call plans again)
         ws.planned.insert(T);
     }
     Rec rec{ws, F, (int)np, ws.X, (int)np, ws.W, (int)np, false};
@@ -271,7 +318,8 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
     dnagpu::gemm(ws, a, 1, 1);
     gemm_profile_close(ws);
     if (scale_to_unity) launch_scale_sym(F, ws.svec, n, np, 0, ws.stream);
-    hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, ws.stream);
+    inv_note_error(ws, hipGetLastError(), "inverse: scaling launch");
+    inv_note_error(ws, hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, ws.stream), "info copy");
 }
 
 double schur_split() {
@@ -284,19 +332,20 @@ double schur_split() {
 }
 
 void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti, int tj) {
-    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
     const int key = (1 << 29) | (ti << 12) | tj;
     for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
         Rec rec{ws, F, ld, X, ld, ws.W, ld, pass == 0};
         if (ti > 0) rec.node(0, ti);
         if (ti > 0 && tj > 0) rec.eliminate(0, ti, tj);
+        if (ws.err != hipSuccess) return;
     }
     ws.planned.insert(key);
     gemm_profile_close(ws);
 }
 
 void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj) {
-    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
     const int key = (1 << 28) | (ti << 12) | tj;
     const int T = ti + tj;
     for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
@@ -325,19 +374,21 @@ void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const do
         a.mt = T; a.nt = T; a.K = T * 128;
         a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
         rec.gemm(ws, a, 1, 1);
+        if (ws.err != hipSuccess) return;
     }
     ws.planned.insert(key);
     gemm_profile_close(ws);
 }
 
 void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj) {
-    hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream);
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
     const int ldx = ti * 128;
     const double split = schur_split();
     const int key = (1 << 30) | (ti << 12) | tj;
     if (!ws.planned.count(key)) {
         Rec plan{ws, F, ld, ws.X, ldx, P, ldp, true};
         plan.schur(ti, tj, split);
+        if (ws.err != hipSuccess) return;
         ws.planned.insert(key);
     }
     Rec rec{ws, F, ld, ws.X, ldx, P, ldp, false};

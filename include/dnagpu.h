@@ -86,6 +86,14 @@ int dnagpu_profile_reset(dnagpu_ctx* ctx);
  * the chains' streams: equals the summed run durations with one chain); launches */
 int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uint64_t* launches);
 
+/* ---- diagnostics ------------------------------------------------------------ */
+/* Error-path testing: the nth (1-based) internal table allocation from now on fails as if the device were out of memory
+ * (0 = off).  An inverse / elimination that hits it returns DNAGPU_ENOMEM -- never DNAGPU_OK with a skipped launch. */
+int dnagpu_debug_fail_allocation(long nth);
+/* Launches with fewer than `tiles` 128 x 128 tiles use the 64-tile latency kernel (default 160); 0 sends every launch through the
+ * 128-tile throughput kernel (gemm_f64_dma_kernel), a negative value restores the default.  Returns the previous value. */
+long dnagpu_debug_set_small_tiles(long tiles);
+
 /* ---- device-resident work matrices ----------------------------------------
  * A work matrix is an np x np (np = ceil(n/128)*128) column-major buffer that
  * holds N, then N^-1.  Each chain owns one; junction matrices get their own. */

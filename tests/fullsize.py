@@ -1,0 +1,33 @@
+"""Full-size parity records: a fixed sample of every block's result (all coordinates, the variance matrix's diagonal and a
+few of its columns) that is small enough to commit, taken the same way from the CPU oracle and from the device path.
+Used by tools/make_fullsize_golden.py (writes tests/golden/<workload>_oracle.npz on a host with enough memory for the
+oracle) and by tests/test_gpu_fullsize.py (compares the device path with it at BASELINE.json's full sizes)."""
+import numpy as np
+
+# name: (rows, cols, baselines, blocks, phased) -- the bench's workloads (bench.py WORKLOADS)
+WORKLOADS = {
+    "cfg3": (316, 317, 266666, 16, True),
+    "cfg2": (100, 100, 26666, 1, False),
+}
+SEED = 20260928
+ROW_STRIDE = 8          # rows kept of every sampled column
+
+
+def sample_columns(n):
+    """columns of a block's variance matrix that are kept: spread over the matrix, never 0 (a constrained corner)"""
+    return sorted({min(n - 1, max(1, (n * p) // 97)) for p in (11, 43, 83)})
+
+
+def sample_packed(ap, n):
+    """ap: packed lower triangle, column-major (matrix_2d::packed_index).  Returns (diagonal, columns x rows[::ROW_STRIDE])"""
+    ap = np.asarray(ap)
+    j = np.arange(n, dtype=np.int64)
+    col0 = j * n - j * (j - 1) // 2              # index of element (j, j)
+    diag = ap[col0].copy()
+    rows = np.arange(0, n, ROW_STRIDE, dtype=np.int64)
+    cols = []
+    for c in sample_columns(n):
+        lo = np.minimum(rows, c)
+        hi = np.maximum(rows, c)
+        cols.append(ap[col0[lo] + (hi - lo)])
+    return diag, np.stack(cols)

@@ -1,0 +1,170 @@
+"""Parity at BASELINE.json's full sizes (configs[1] cfg2: one block of n = 30 000; configs[2] cfg3: 100 172 stations, 16 blocks
+of n ~ 20 000), where nearly all flops go through the 128-tile throughput kernel (gemm_f64_dma_kernel):
+
+  * cfg3 on the device against the committed record of the CPU oracle's run of the same network (tests/golden/cfg3_oracle.npz,
+    made by tools/make_fullsize_golden.py: every coordinate, every variance diagonal, sampled variance columns);
+  * cfg3, condensed schedule (a.schur_carry, kept factors) against the reference's forward / reverse / combine schedule on the
+    device: every coordinate, every element of every block's variance matrix;
+  * cfg2 against the oracle run live (one n = 30 000 dpotrf + dpotri with the MKL runtime on the host);
+  * cfg4-sized blocks (n ~ 27 000, 1 000-station junction rows): staged / budget-limited paths at the real size.
+
+Tolerances (BASELINE.json): coordinates 1e-8 m; variances 1e-8 of the block's largest element."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from dynadjust_amd import adjust
+from tests import fullsize
+
+pytestmark = pytest.mark.gpu
+
+TOL_X = 1e-8
+TOL_V = 1e-8
+
+
+def _write(tmp_path, workload):
+    rows, cols, nbl, blocks, phased = fullsize.WORKLOADS[workload]
+    info = adjust.write_synthetic_network(str(tmp_path), "net", rows, cols, nbl, blocks, seed=fullsize.SEED)
+    return info, phased
+
+
+def _run(tmp_path, phased, **kw):
+    p = adjust.ProjectSettings("net", str(tmp_path), adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode, **kw)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    st = a.AdjustNetwork()
+    return a, st
+
+
+def _record(path, rec):
+    """parity figures of this run, for profiles/ (gpurun_out/ is merged back from the GPU box)"""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        json.dump(rec, open(os.path.join(out, path), "w"), indent=1)
+    except OSError:
+        pass
+
+
+def test_cfg3_against_the_oracle_record(built, golden_dir, tmp_path):
+    path = os.path.join(golden_dir, "cfg3_oracle.npz")
+    assert os.path.exists(path), "tests/golden/cfg3_oracle.npz is missing: tools/make_fullsize_golden.py cfg3"
+    g = np.load(path)
+    meta = json.loads(bytes(g["meta"]).decode())
+    info, phased = _write(tmp_path, "cfg3")
+    assert info["stations"] == meta["stations"]
+    a, st = _run(tmp_path, phased, multi_thread=True)
+    assert st == meta["status"] and a.CurrentIteration() == meta["iterations"]
+    dcorr = max(abs(a.GetIterationCorrection(i + 1) - c) for i, c in enumerate(meta["corrections"]))
+    assert dcorr < TOL_X
+    dx = dv = dvc = 0.0
+    for b in range(a.blockCount()):
+        assert np.array_equal(a.block_stations(b), g[f"stations_{b}"])
+        est = a.block_estimates(b)
+        dx = max(dx, float(np.abs(est - g[f"estimates_{b}"]).max()))
+        diag, cols = fullsize.sample_packed(a.block_variances_packed(b), est.size)
+        scale = float(np.abs(g[f"vdiag_{b}"]).max())
+        dv = max(dv, float(np.abs(diag - g[f"vdiag_{b}"]).max()) / scale)
+        dvc = max(dvc, float(np.abs(cols - g[f"vcols_{b}"]).max()) / scale)
+    a.GenerateStatistics()
+    rec = {"workload": "cfg3", "stations": info["stations"], "blocks": a.blockCount(), "iterations": a.CurrentIteration(),
+           "schedule": "condensed + kept factors, four chains", "max_abs_dx_m": dx, "max_rel_dvar_diagonal": dv,
+           "max_rel_dvar_sampled_columns": dvc, "max_abs_dcorrection_m": dcorr,
+           "sigma_zero_device": a.GetSigmaZero(), "sigma_zero_oracle": meta["sigma_zero"],
+           "chi_squared_device": a.GetChiSquared(), "chi_squared_oracle": meta["chi_squared"],
+           "oracle": {k: meta[k] for k in ("oracle_seconds", "oracle_threads", "oracle_tflops", "lapack", "cpu_count") if k in meta}}
+    _record("parity_cfg3.json", rec)
+    assert dx < TOL_X and dv < TOL_V and dvc < TOL_V, rec
+    assert a.GetDegreesOfFreedom() == meta["dof"]
+    assert abs(a.GetChiSquared() - meta["chi_squared"]) / meta["chi_squared"] < 1e-7
+    a.close()
+
+
+def test_cfg3_condensed_schedule_equals_reference_schedule(built, tmp_path):
+    """a.schur_carry = 1 (condensed blocks, kept factors, four chains) against a.schur_carry = 0 (every forward / reverse /
+    combination step a full inverse, the reference's schedule), both on the device at full size: every element"""
+    info, phased = _write(tmp_path, "cfg3")
+    a, st = _run(tmp_path, phased, multi_thread=True, schur_carry=True)
+    assert st == adjust.ADJUST_SUCCESS and a.elimination_count() > 0 and a.completion_count() > 0
+    B = a.blockCount()
+    est = [a.block_estimates(b) for b in range(B)]
+    var = [a.block_variances_packed(b) for b in range(B)]
+    its = a.CurrentIteration()
+    a.close()
+    r, st = _run(tmp_path, phased, multi_thread=True, schur_carry=False)
+    assert st == adjust.ADJUST_SUCCESS and r.elimination_count() == 0 and r.CurrentIteration() == its
+    dx = dv = 0.0
+    for b in range(B):
+        dx = max(dx, float(np.abs(r.block_estimates(b) - est[b]).max()))
+        v = r.block_variances_packed(b)
+        dv = max(dv, float(np.abs(v - var[b]).max() / np.abs(v).max()))
+        var[b] = None
+    _record("parity_cfg3_schedules.json", {"workload": "cfg3", "max_abs_dx_m": dx, "max_rel_dvar": dv, "iterations": its,
+                                           "compared": "condensed + kept factors vs reference schedule, every element"})
+    assert dx < TOL_X and dv < TOL_V, (dx, dv)
+    r.close()
+
+
+def test_cfg2_against_the_oracle(built, orc, tmp_path):
+    """BASELINE.json configs[1]: 10 000 stations, simultaneous, one n = 30 000 inverse -- against the oracle with the MKL
+    runtime (the LAPACK the reference links), every coordinate and every variance element"""
+    info, phased = _write(tmp_path, "cfg2")
+    if not orc.use_mkl(True):
+        pytest.skip("needs the MKL runtime: the built-in Cholesky takes hours at n = 30 000")
+    try:
+        orc.load().orc_set_threads(min(os.cpu_count() or 1, 64))
+        net = orc.Network(str(tmp_path / "net"), phased)
+        o = orc.Adjustment(net, phased)
+        o.prepare()
+        ost = o.run()
+    finally:
+        orc.use_mkl(False)
+    a, st = _run(tmp_path, phased)
+    assert st == ost and a.CurrentIteration() == o.iterations()
+    for i in range(o.iterations()):
+        assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < TOL_X
+    assert np.array_equal(a.block_stations(0), o.block_stations(0))
+    dx = float(np.abs(a.block_estimates(0) - o.block_estimates(0)).max())
+    vo = o.block_variances(0)
+    dv = float(np.abs(a.block_variances_packed(0) - vo).max() / np.abs(vo).max())
+    _record("parity_cfg2.json", {"workload": "cfg2", "unknowns": int(a.GetUnknownsCount()), "max_abs_dx_m": dx, "max_rel_dvar": dv,
+                                 "iterations": a.CurrentIteration()})
+    assert dx < TOL_X and dv < TOL_V, (dx, dv)
+    a.close()
+    o.close()
+
+
+def test_cfg4_sized_blocks(built, tmp_path):
+    """4 of cfg4's 128 strips (n ~ 27 000 per block, 1 000-station junction rows) on one GPU: the condensed schedule with the
+    kept-factor budget and the staging decision at the real block size.  Size-independent properties: phased (condensed)
+    == reference schedule on the device to 1e-8 m; staged == resident bit for bit; sigma-zero inside its 95 % limits."""
+    rows, cols, nbl, blocks = 32, 1000, 85000, 4
+    adjust.write_synthetic_network(str(tmp_path), "net", rows, cols, nbl, blocks, seed=fullsize.SEED)
+    a, st = _run(tmp_path, True, multi_thread=True)
+    assert st == adjust.ADJUST_SUCCESS
+    B = a.blockCount()
+    est = [a.block_estimates(b) for b in range(B)]
+    vdiag = [fullsize.sample_packed(a.block_variances_packed(b), est[b].size) for b in range(B)]
+    a.GenerateStatistics()
+    assert a.GetChiSquaredLowerLimit() < a.GetSigmaZero() < a.GetChiSquaredUpperLimit()
+    a.close()
+    s, st = _run(tmp_path, True, multi_thread=True, stage=True)
+    assert st == adjust.ADJUST_SUCCESS
+    for b in range(B):
+        assert np.array_equal(s.block_estimates(b), est[b])
+        d, c = fullsize.sample_packed(s.block_variances_packed(b), est[b].size)
+        assert np.array_equal(d, vdiag[b][0]) and np.array_equal(c, vdiag[b][1])
+    s.close()
+    r, st = _run(tmp_path, True, multi_thread=True, schur_carry=False)
+    assert st == adjust.ADJUST_SUCCESS
+    dx = dv = 0.0
+    for b in range(B):
+        dx = max(dx, float(np.abs(r.block_estimates(b) - est[b]).max()))
+        d, c = fullsize.sample_packed(r.block_variances_packed(b), est[b].size)
+        scale = float(np.abs(d).max())
+        dv = max(dv, float(np.abs(d - vdiag[b][0]).max()) / scale, float(np.abs(c - vdiag[b][1]).max()) / scale)
+    _record("parity_cfg4_blocks.json", {"blocks": B, "unknowns_per_block": int(est[1].size), "max_abs_dx_m": dx, "max_rel_dvar": dv})
+    assert dx < TOL_X and dv < TOL_V, (dx, dv)
+    r.close()

@@ -74,6 +74,83 @@ def test_edge_sizes_against_oracle(gpu_ctx, orc, n):
     assert np.abs(gpu_ctx.multiply_sym_packed(ap, x, n) - orc.multiply_sym_packed(ap, x, n)).max() < 1e-11 * max(1.0, np.abs(M @ x).max())
 
 
+def _dense_spd(n, seed):
+    """dense, well-conditioned-but-not-trivial SPD matrix: a random Gram matrix of rank n/8 (every off-diagonal panel full)
+    plus a diagonal that spans three decades"""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, max(8, n // 8)))
+    M = A @ A.T / A.shape[1]
+    M[np.diag_indices(n)] += 10.0 ** rng.uniform(-1.0, 2.0, n)
+    return M
+
+
+@pytest.fixture
+def big_tiles_only(built):
+    """every GEMM launch of the inverse goes through the 128-tile throughput kernel (gemm_f64_dma_kernel), whatever its size"""
+    old = built.dnagpu_debug_set_small_tiles(0)
+    yield
+    built.dnagpu_debug_set_small_tiles(old)
+
+
+@pytest.mark.parametrize("n", [129, 255, 257, 640, 1000, 1500])
+def test_throughput_kernel_against_oracle_at_small_orders(gpu_ctx, orc, big_tiles_only, n):
+    """DNAGPU_SMALL_TILES = 0: the LDS-DMA kernel -- swizzled S layout, descending k walk, tile tables -- runs the launches the
+    64-tile kernel normally takes, at orders where the scalar oracle answers at once; element-wise comparison"""
+    M = _dense_spd(n, n)
+    ap = pack_lower(M)
+    ref, info = orc.cholesky_inverse_packed(ap, n)
+    assert info == 0
+    inv = gpu_ctx.cholesky_inverse_packed(ap, n)
+    assert np.abs(inv - ref).max() / np.abs(ref).max() < 1e-11
+    inv_s = gpu_ctx.cholesky_inverse_packed(ap, n, True)
+    assert np.abs(inv_s - ref).max() / np.abs(ref).max() < 1e-11
+
+
+@pytest.mark.parametrize("n", [2304, 4096, 6016])
+def test_dense_inverse_against_oracle_beyond_the_small_launch_threshold(gpu_ctx, orc, n):
+    """n >= 2 304 (T = 18: 171 lower tiles > SMALL_LAUNCH_TILES = 160): the top-level launches of the recursion run on the
+    128-tile kernel in its normal configuration.  Dense SPD input, element-wise against the oracle (LAPACK = the MKL runtime
+    the reference links; the oracle's built-in Cholesky where MKL is absent -- a minute at n = 6 016)"""
+    M = _dense_spd(n, n)
+    ap = pack_lower(M)
+    have_mkl = orc.use_mkl(True)
+    try:
+        ref, info = orc.cholesky_inverse_packed(ap, n)
+    finally:
+        orc.use_mkl(False)
+    assert info == 0
+    inv = gpu_ctx.cholesky_inverse_packed(ap, n)
+    err = np.abs(inv - ref).max() / np.abs(ref).max()
+    assert err < 1e-11, (err, have_mkl)
+    # and against the definition, independent of any LAPACK: N^-1 N = I on probe vectors
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(n)
+    y = unpack_lower(inv, n) @ (M @ x)
+    assert np.abs(y - x).max() < 1e-10
+
+
+def test_failed_allocation_inside_an_inverse_is_reported(built):
+    """a tile-table allocation failing in the middle of the recursion must come back as DNAGPU_ENOMEM (never DNAGPU_OK with a
+    skipped launch), and the context must work again afterwards"""
+    from dynadjust_amd.device import DeviceContext
+    ctx = DeviceContext(0)                       # fresh context: empty table cache
+    try:
+        n = 700
+        M = _dense_spd(n, 5)
+        ap = pack_lower(M)
+        for nth in (1, 3, 7):
+            built.dnagpu_debug_fail_allocation(nth)
+            with pytest.raises(DnaGpuError) as e:
+                ctx.cholesky_inverse_packed(ap, n)
+            assert e.value.code == -2 and "allocation" in str(e.value)
+        built.dnagpu_debug_fail_allocation(0)
+        inv = unpack_lower(ctx.cholesky_inverse_packed(ap, n), n)
+        assert np.abs(inv @ M - np.eye(n)).max() < 1e-10
+    finally:
+        built.dnagpu_debug_fail_allocation(0)
+        ctx.close()
+
+
 def test_empty_matrix(gpu_ctx):
     assert gpu_ctx.cholesky_inverse_packed(np.zeros(0), 0).size == 0
 

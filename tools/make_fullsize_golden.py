@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Full-size golden record of the CPU oracle (oracle/dna_oracle.c with the MKL runtime: the restated reference path) on one of
+the bench's workloads:
+
+    python tools/make_fullsize_golden.py cfg3 [out.npz]
+
+cfg3 (100 172 stations, 16 blocks of n ~ 20 000, 92 Solve() calls of n^3 flops) needs ~80 GB of host memory and 7.4e14 flops:
+run it where those exist (the GPU box's host: `gpurun -- python tools/make_fullsize_golden.py cfg3 gpurun_out/cfg3_oracle.npz`),
+then commit the result as tests/golden/<workload>_oracle.npz.  tests/test_gpu_fullsize.py compares the device path with it.
+The record: every adjusted coordinate, the diagonal of every block's rigorous variance matrix, three of its columns (every
+8th row), iteration count, per-iteration largest corrections, chi-squared / sigma-zero / degrees of freedom, and how long the
+oracle took on how many threads."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+
+import numpy as np
+
+
+def main():
+    workload = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tests", "golden", f"{workload}_oracle.npz")
+    threads = int(os.environ.get("ORACLE_THREADS", "0")) or min(os.cpu_count() or 1, 64)
+    from dynadjust_amd import adjust
+    from tests import fullsize, oracle
+    rows, cols, nbl, blocks, phased = fullsize.WORKLOADS[workload]
+    d = tempfile.mkdtemp(prefix="dnagpu_golden_")
+    info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, blocks, seed=fullsize.SEED)
+    if not oracle.use_mkl(True):
+        raise SystemExit("the MKL runtime is needed at this size")
+    oracle.load().orc_set_threads(threads)
+    net = oracle.Network(os.path.join(d, "net"), phased)
+    o = oracle.Adjustment(net, phased, threads=threads)
+    o.prepare()
+    t0 = time.perf_counter()
+    status = o.run()
+    dt = time.perf_counter() - t0
+    solves, n3 = o.solve_stats()
+    rec = {"status": status, "iterations": o.iterations(), "stations": info["stations"], "blocks": o.n_blocks,
+           "corrections": [o.max_correction(i + 1) for i in range(o.iterations())]}
+    arrays = {}
+    for b in range(o.n_blocks):
+        stn = o.block_stations(b)
+        est = o.block_estimates(b)
+        n = est.size
+        diag, colsamp = fullsize.sample_packed(o.block_variances(b), n)
+        arrays[f"stations_{b}"] = stn.astype(np.uint32)
+        arrays[f"estimates_{b}"] = est
+        arrays[f"vdiag_{b}"] = diag
+        arrays[f"vcols_{b}"] = colsamp
+    st, _ = o.statistics()
+    rec.update(chi_squared=st.chi_squared, sigma_zero=st.sigma_zero, dof=st.dof, oracle_seconds=dt, oracle_threads=threads,
+               oracle_solves=int(solves), oracle_sum_n3=n3, oracle_tflops=n3 / dt / 1e12, cpu_count=os.cpu_count(),
+               lapack="MKL runtime (libmkl_rt)")
+    arrays["meta"] = np.frombuffer(json.dumps(rec).encode(), dtype=np.uint8)
+    np.savez(out, **arrays)
+    print(json.dumps(rec), flush=True)
+    o.close()
+
+
+if __name__ == "__main__":
+    main()
