@@ -151,6 +151,117 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
     }
 
 
+def bench_distributed_native(folder, name, phased, args, dist, rank, world, local_rank):
+    """bench.py --gpus N (N > 1): one network, its blocks spread over N ranks by the library itself (strong scaling)."""
+    import numpy as np
+    import torch
+    from dynadjust_amd import adjust
+    if not phased:
+        raise SystemExit("the simultaneous adjustment does not shard: run it with --gpus 1")
+    # rank 0's ncclUniqueId to everybody through the control plane
+    idt = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        idt = torch.frombuffer(bytearray(adjust.rccl_unique_id()), dtype=torch.uint8).clone()
+    dist.broadcast(idt, src=0)
+    a = adjust.DnaAdjust()
+    a.attach_rccl(rank, world, bytes(idt.numpy().tobytes()), local_rank)
+    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank, dist_rank=rank, dist_world=world,
+                               multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
+                               schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage,
+                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "0"))))
+    a.PrepareAdjustment(p)
+    lib, ctx = a.lib, a.device_context()
+
+    def one_step():
+        a.ResetAdjustment()
+        st = a.AdjustNetworkDistributed()
+        if st != adjust.ADJUST_SUCCESS:
+            raise SystemExit(f"adjustment did not converge (status {st})")
+
+    for _ in range(args.warmup):
+        one_step()
+    lib.dnagpu_profile_enable(ctx, 0 if args.no_gemm_events else 1)
+    lib.dnagpu_profile_reset(ctx)
+    bytes0 = a.exchange_stats()["bytes"]
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    lib.dnagpu_sync(ctx)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    prof_f, prof_ms, prof_n = C.c_double(), C.c_double(), C.c_uint64()
+    lib.dnagpu_profile_get(ctx, C.byref(prof_f), C.byref(prof_ms), C.byref(prof_n))
+    lib.dnagpu_profile_enable(ctx, 0)
+    its = a.CurrentIteration()
+    ex = a.exchange_stats()
+    mine = {"alg": a.algorithmic_flops(), "gemm_ms": prof_ms.value, "issued": prof_f.value, "solves": a.solve_count(), "completions": a.completion_count(),
+            "eliminations": a.elimination_count(), "exchange_ms": ex["exchange_ms"], "chain_ms": ex["chain_ms"], "bytes": (ex["bytes"] - bytes0) / max(1, args.steps)}
+    allv = [None] * world
+    dist.all_gather_object(allv, mine)
+    stations = lib.dnaadj_station_count(a.h)
+    B = a.blockCount()
+    owners = [a.block_owner(k) for k in range(B)]
+    # statistics across the ranks (collective inside the library) and the distance from the truth the generator kept
+    check = None
+    try:
+        a.GenerateStatistics()
+        truth = np.fromfile(os.path.join(folder, name + ".truth"), dtype=np.float64).reshape(-1, 3)
+        xyz = a.adjusted_coordinates(stations)
+        check = {"sigma_zero": a.GetSigmaZero(), "degrees_of_freedom": a.GetDegreesOfFreedom(),
+                 "max_abs_error_vs_truth_m": float(np.abs(xyz - truth).max()), "global_test": int(a.GetTestResult()),
+                 "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()]}
+    except Exception as e:                       # diagnostic only
+        check = {"error": str(e)}
+    out = None
+    if rank == 0:
+        condensed = any(v["eliminations"] for v in allv)
+        solves, ref = 0, 0.0
+        for k in range(B):
+            f, l, i = C.c_int(), C.c_int(), C.c_int()
+            lib.dnaadj_block_flags(a.h, k, C.byref(f), C.byref(l), C.byref(i))
+            m = 1 + (0 if i.value else 1) + (0 if (f.value or l.value or i.value) else 1)
+            n3 = (3.0 * lib.dnaadj_block_station_count(a.h, k)) ** 3
+            solves += its * m
+            ref += its * m * n3
+        alg = sum(v["alg"] for v in allv)
+        busiest = max(range(world), key=lambda r: allv[r]["gemm_ms"])
+        gemm_ms = allv[busiest]["gemm_ms"]
+        achieved = (allv[busiest]["alg"] / 1e12) / (gemm_ms / args.steps / 1e3) if gemm_ms > 0 else 0.0
+        chains = (os.environ.get("DNAGPU_CHAINS", "4") + " chains") if p.multi_thread else "one chain"
+        par = (f"condensed schedule inside dna_adjust::AdjustNetwork (C++): {B} blocks in contiguous runs over {world} ranks ({chains} per GPU), "
+               "condensed blocks broadcast in place by ncclBroadcast, chains on the condensed blocks on every rank, coordinates by one ncclAllReduce"
+               ) if condensed else (
+               f"reference schedule inside dna_adjust::AdjustNetwork (C++): forward chain on rank 0, reverse chain on rank 1, combination solves "
+               f"round-robin over {world} ranks; junction matrices by ncclSend / ncclRecv")
+        out = {
+            "metric": "stations adjusted/sec + Cholesky TFLOP/s, phased adjustment, 1/2/4/8 MI355X",
+            "value": stations * args.steps / dt, "unit": "stations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"stations": stations, "blocks": B, "iterations_to_converge": its, "mode": "phased", "solves_per_step": solves,
+                       "schur_carry": condensed, "keep_factors": any(v["completions"] for v in allv), "parallelism": par,
+                       "driver": "C++ (libdnagpu.so) + RCCL", "blocks_per_rank": [owners.count(r) for r in range(world)]},
+            "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
+            "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
+            "roofline": {"kernel": "gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "rank": busiest, "gemm_ms_per_step": gemm_ms / args.steps,
+                         "note": "busiest rank: algorithmic flops of its steps / HIP-event time of its GEMM launches"},
+            # host-side time of the last timed step, per rank: the exchange steps (broadcasts, all-reduce, their waits) and the chains on
+            # the condensed blocks -- the serial remainder of the condensed schedule
+            "exchange": {"exchange_ms_per_step": [v["exchange_ms"] for v in allv], "chain_phase_ms_per_step": [v["chain_ms"] for v in allv],
+                         "payload_bytes_per_rank_per_step": [v["bytes"] for v in allv]},
+            "check": check,
+        }
+    a.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +296,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the adjustment path has no CPU fallback")
     # DNAGPU_DIST_BACKEND=gloo: test harness for the N > 1 code path on a box with fewer GPUs than ranks (ranks share
     # devices, payloads travel through host memory); the driver's runs use nccl (= RCCL), one GPU per rank
-    dist_backend = os.environ.get("DNAGPU_DIST_BACKEND", "nccl")
+    # "native" (default): control plane gloo, data path RCCL from inside the library; "nccl": control plane torch's NCCL (the data path is
+    # the library's RCCL all the same, torch's only if that cannot start); "gloo": the Python harness, payloads through the host
+    dist_backend = os.environ.get("DNAGPU_DIST_BACKEND", "native")
     if dist_backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -198,7 +311,7 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if dist_backend == "gloo":
+        if dist_backend == "gloo" or dist_backend == "native":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -212,8 +325,22 @@ def main():
     stations = info["stations"]
 
     if distributed:
-        from dynadjust_amd import parallel
-        result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)
+        # N > 1: the driver is C++ (dna_adjust::AdjustPhasedDistributed), the exchange RCCL called from the library; torch.distributed
+        # is the launcher's control plane here (unique-id broadcast, barriers, the max over the ranks' clocks).
+        # DNAGPU_DIST_BACKEND=gloo keeps the Python harness over the same per-block entry points (ranks sharing a GPU, host payloads).
+        result = None
+        if dist_backend != "gloo":
+            try:
+                result = bench_distributed_native(d, "net", phased, args, dist, rank, world, local_rank)
+            except Exception as e:                                   # (an RCCL that cannot start: measured through torch's instead)
+                print(f"rank {rank}: native RCCL driver unavailable ({e}); falling back to the torch.distributed harness", file=sys.stderr, flush=True)
+                result = None
+                fell_back = True
+            else:
+                fell_back = False
+        if result is None and (dist_backend == "gloo" or fell_back):
+            from dynadjust_amd import parallel
+            result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)
         if rank == 0:
             result["config"]["workload"] = desc
             print(json.dumps(result), flush=True)

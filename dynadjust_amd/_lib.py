@@ -33,7 +33,9 @@ class DnaAdjSettings(C.Structure):
                 ("adjust_mode", C.c_int), ("multi_thread", C.c_int), ("max_iterations", C.c_int),
                 ("iteration_threshold", C.c_float), ("free_std_dev", C.c_double), ("fixed_std_dev", C.c_double),
                 ("scale_normals_to_unity", C.c_int), ("device", C.c_int), ("confidence_interval", C.c_float),
-                ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int), ("schur_carry", C.c_int), ("stage", C.c_int), ("keep_factors", C.c_int)]
+                ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int), ("schur_carry", C.c_int), ("stage", C.c_int), ("keep_factors", C.c_int),
+                ("dist_rank", C.c_int), ("dist_world", C.c_int), ("n_devices", C.c_int), ("devices", C.POINTER(C.c_int)),
+                ("dist_transport", C.c_char_p), ("dist_two_level", C.c_int)]
 
 
 class DnaAdjStatistics(C.Structure):
@@ -136,6 +138,11 @@ def load():
     _sig(lib, "dnagpu_schur_carry", i, [vp, i, u32, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_block_reduce", i, [vp, i, u32, vp, c_u32p, sz, vp, vp])
     _sig(lib, "dnagpu_mem_info", i, [vp, C.POINTER(sz), C.POINTER(sz)])
+    _sig(lib, "dnagpu_device_alloc", i, [vp, sz, C.POINTER(vp)])
+    _sig(lib, "dnagpu_device_free", None, [vp, vp])
+    _sig(lib, "dnagpu_copy", i, [vp, vp, vp, sz])
+    _sig(lib, "dnagpu_matrix_resize", i, [vp, vp, u32])
+    _sig(lib, "dnagpu_matrix_device_pointers", i, [vp, C.POINTER(c_f64p), C.POINTER(c_f64p), c_u32p])
     _sig(lib, "dnagpu_host_alloc", i, [vp, sz, C.POINTER(vp)])
     _sig(lib, "dnagpu_host_free", None, [vp, vp])
     _sig(lib, "dnagpu_partial_create", i, [vp, u32, u32, C.POINTER(vp)])
@@ -179,6 +186,14 @@ def load():
     _sig(lib, "dnaadj_block_variances_packed", i, [vp, u32, c_f64p])
     _sig(lib, "dnaadj_adjusted_coordinates", i, [vp, c_f64p])
     _sig(lib, "dnaadj_device_context", vp, [vp])
+    _sig(lib, "dnaadj_dist_rccl_available", i, [])
+    _sig(lib, "dnaadj_dist_unique_id", i, [C.c_char_p, C.c_char_p, sz])
+    _sig(lib, "dnaadj_dist_attach_rccl", i, [vp, i, i, C.c_char_p, i])
+    _sig(lib, "dnaadj_adjust_distributed", i, [vp, C.POINTER(i)])
+    _sig(lib, "dnaadj_dist_info", i, [vp, C.POINTER(i), C.POINTER(i), C.c_char_p, sz])
+    _sig(lib, "dnaadj_block_owner", i, [vp, u32])
+    _sig(lib, "dnaadj_exchange_stats", i, [vp, C.POINTER(C.c_uint64), c_f64p, c_f64p])
+    _sig(lib, "dnaadj_device_instance_context", vp, [vp, i])
     _sig(lib, "dnaadj_generate_statistics", i, [vp])
     _sig(lib, "dnaadj_get_statistics", i, [vp, C.POINTER(DnaAdjStatistics)])
     _sig(lib, "dnaadj_measurement_record_count", u64, [vp])
@@ -246,7 +261,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
     "dnagpu_block_set_direction_sets", "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
-    "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_mem_info", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_reduce_rhs",
+    "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
 ]
@@ -257,6 +272,8 @@ EXPORTED_DNAADJ = [
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_completion_count", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
+    "dnaadj_dist_rccl_available", "dnaadj_dist_unique_id", "dnaadj_dist_attach_rccl", "dnaadj_adjust_distributed", "dnaadj_dist_info",
+    "dnaadj_block_owner", "dnaadj_exchange_stats", "dnaadj_device_instance_context",
     "dnaadj_generate_statistics", "dnaadj_get_statistics", "dnaadj_measurement_record_count", "dnaadj_measurement_records",
     "dnaadj_block_prec_adj_msrs_count", "dnaadj_block_prec_adj_msrs", "dnaadj_serialise_adjusted_variance_matrices",
     "dnaadj_deserialise_adjusted_variance_matrices", "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",

@@ -34,7 +34,8 @@ class ProjectSettings:
     def __init__(self, network_name=None, folder=".", adjust_mode=SimultaneousMode, multi_thread=False,
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
                  scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None,
-                 reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False):
+                 reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False, dist_rank=0, dist_world=1, devices=None,
+                 dist_transport=None, dist_two_level=False):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
         self.network_name = network_name          # g.network_name
         self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
@@ -44,6 +45,9 @@ class ProjectSettings:
         self.schur_carry = schur_carry            # device path only: carry-only steps eliminate instead of inverting
         self.stage = stage                        # a.stage: rigorous variances in page-locked host memory
         self.keep_factors = keep_factors          # device path only: rigorous solves complete the condensing step's factor
+        # multi-GPU: one process per GPU (dist_rank of dist_world) or one process driving `devices`
+        self.dist_rank, self.dist_world, self.devices = dist_rank, dist_world, devices
+        self.dist_transport, self.dist_two_level = dist_transport, dist_two_level
         if network_name is not None:
             self.set_filenames(os.path.join(folder, network_name))
         self.adjust_mode = adjust_mode
@@ -112,7 +116,39 @@ class DnaAdjust:
         s.fixed_std_dev = float(p.fixed_std_dev)
         s.scale_normals_to_unity = int(bool(p.scale_normals_to_unity))
         s.device = int(p.device)
+        s.dist_rank = int(getattr(p, "dist_rank", 0))
+        s.dist_world = int(getattr(p, "dist_world", 1))
+        devs = getattr(p, "devices", None)
+        if devs:
+            self._devs = (C.c_int * len(devs))(*[int(d) for d in devs])
+            s.n_devices, s.devices = len(devs), self._devs
+        self._transport = _b(getattr(p, "dist_transport", None))
+        s.dist_transport = self._transport
+        s.dist_two_level = int(bool(getattr(p, "dist_two_level", False)))
         self._chk(self.lib.dnaadj_prepare(self.h, C.byref(s)))
+
+    # ---- multi-GPU (include/dnaadjust_c.h "multi-GPU") ----
+    def attach_rccl(self, rank, world, unique_id, device):
+        self._chk(self.lib.dnaadj_dist_attach_rccl(self.h, int(rank), int(world), bytes(unique_id), int(device)))
+
+    def AdjustNetworkDistributed(self):
+        st = C.c_int()
+        self._chk(self.lib.dnaadj_adjust_distributed(self.h, C.byref(st)))
+        return st.value
+
+    def dist_info(self):
+        r, w = C.c_int(), C.c_int()
+        buf = C.create_string_buffer(32)
+        self.lib.dnaadj_dist_info(self.h, C.byref(r), C.byref(w), buf, 32)
+        return r.value, w.value, buf.value.decode()
+
+    def block_owner(self, k):
+        return self.lib.dnaadj_block_owner(self.h, k)
+
+    def exchange_stats(self):
+        b, e, c = C.c_uint64(), C.c_double(), C.c_double()
+        self.lib.dnaadj_exchange_stats(self.h, C.byref(b), C.byref(e), C.byref(c))
+        return {"bytes": b.value, "exchange_ms": e.value, "chain_ms": c.value}
 
     def AdjustNetwork(self):
         st = C.c_int()
@@ -248,6 +284,16 @@ class DnaAdjust:
 
     def device_context(self):
         return self.lib.dnaadj_device_context(self.h)
+
+
+def rccl_unique_id():
+    """128 bytes for dnaadj_dist_attach_rccl (ncclGetUniqueId): make on one rank, hand to all"""
+    lib = _lib.load()
+    buf = C.create_string_buffer(128)
+    err = C.create_string_buffer(256)
+    if lib.dnaadj_dist_unique_id(buf, err, 256) != 0:
+        raise RuntimeError("dnaadj_dist_unique_id: " + err.value.decode(errors="replace"))
+    return buf.raw
 
 
 def write_synthetic_network(folder, name, rows, cols, n_baselines=0, n_blocks=1, seed=20260928, initial_sigma=0.05,

@@ -291,6 +291,29 @@ void dnagpu_host_free(dnagpu_ctx* ctx, void* p) {
     hipHostFree(p);
 }
 
+int dnagpu_device_alloc(dnagpu_ctx* ctx, size_t bytes, void** out) {
+    CHK_CTX();
+    if (!out) return fail(ctx, DNAGPU_EINVAL, "device_alloc: null out");
+    *out = nullptr;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "device allocation", e);
+    }
+    return DNAGPU_OK;
+}
+void dnagpu_device_free(dnagpu_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx) hipSetDevice(ctx->device);
+    hipFree(p);
+}
+int dnagpu_copy(dnagpu_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    CHK_CTX();
+    if (bytes && (!dst || !src)) return fail(ctx, DNAGPU_EINVAL, "copy: null pointer");
+    if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return DNAGPU_OK;
+}
+
 int dnagpu_mem_info(dnagpu_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
     CHK_CTX();
     size_t f = 0, t = 0;
@@ -535,6 +558,22 @@ int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dna
     dst->np = src->np;
     HIPCHK(hipMemcpyAsync(dst->F, src->F, (size_t)src->np * src->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
     HIPCHK(hipMemcpyAsync(dst->jest, src->jest, (size_t)src->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_resize(dnagpu_ctx* ctx, dnagpu_matrix* m, uint32_t n) {
+    if (!ctx) return DNAGPU_EINVAL;
+    if (!m || n > m->n_max) return fail(ctx, DNAGPU_EINVAL, "matrix_resize: bad arguments");
+    m->n = n;
+    m->np = pad128(n);
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_device_pointers(const dnagpu_matrix* m, double** matrix, double** vector, uint32_t* np) {
+    if (!m) return DNAGPU_EINVAL;
+    if (matrix) *matrix = m->F;
+    if (vector) *vector = m->jest;
+    if (np) *np = m->np;
     return DNAGPU_OK;
 }
 

@@ -1,0 +1,428 @@
+// Transports of the inter-GPU exchange (dist_comm.hpp): RCCL through dlopen, and the in-process one.
+#include "dist_comm.hpp"
+
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded at run time
+
+namespace dynadjust {
+namespace networkadjust {
+
+namespace {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("inter-GPU exchange: ") + what + ": " + hipGetErrorString(e));
+}
+
+// ---- librccl, loaded on first use ------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    std::string error;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        const char* names[] = {getenv("DNAGPU_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // a copy the host application already loaded (matching soname) is taken first: one RCCL per process
+        a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        for (const char* nm : names) {
+            if (a.handle) break;
+            if (nm && *nm) a.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!a.handle) {
+            const char* e = dlerror();
+            a.error = std::string("librccl could not be loaded") + (e ? std::string(": ") + e : std::string());
+            return a;
+        }
+        bool ok = true;
+        auto sym = [&](const char* nm) {
+            void* p = dlsym(a.handle, nm);
+            if (!p) {
+                ok = false;
+                a.error = std::string("librccl lacks ") + nm;
+            }
+            return p;
+        };
+        a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
+        a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+        a.Send = (decltype(a.Send))sym("ncclSend");
+        a.Recv = (decltype(a.Recv))sym("ncclRecv");
+        a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+        a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) a.handle = nullptr;
+        return a;
+    }();
+    return api;
+}
+
+void nccl_check(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess && r != ncclInProgress)
+        throw std::runtime_error(std::string("RCCL ") + what + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "error"));
+}
+
+class RcclComm : public DistComm {
+public:
+    RcclComm(int rank, int world, const unsigned char* id, int device) : rank_(rank), world_(world), device_(device) {
+        RcclApi& api = rccl();
+        if (!api.handle) throw std::runtime_error(api.error);
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+        ncclUniqueId uid;
+        static_assert(sizeof(uid.internal) == DIST_UNIQUE_ID_BYTES, "unique id size");
+        memcpy(uid.internal, id, DIST_UNIQUE_ID_BYTES);
+        nccl_check(api.CommInitRank(&comm_, world_, uid, rank_), "ncclCommInitRank");
+    }
+    ~RcclComm() override {
+        hipSetDevice(device_);
+        if (stream_) hipStreamSynchronize(stream_);
+        if (comm_) rccl().CommDestroy(comm_);
+        if (stream_) hipStreamDestroy(stream_);
+    }
+    int rank() const override { return rank_; }
+    int world() const override { return world_; }
+    const char* transport() const override { return "rccl"; }
+    void group_begin() override { nccl_check(rccl().GroupStart(), "ncclGroupStart"); }
+    void group_end() override { nccl_check(rccl().GroupEnd(), "ncclGroupEnd"); }
+    void broadcast(double* buf, size_t count, int root) override {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        nccl_check(rccl().Broadcast(buf, buf, count, ncclDouble, root, comm_, stream_), "ncclBroadcast");
+        bytes_ += (world_ > 1 ? count * sizeof(double) : 0);
+    }
+    void all_reduce_sum(double* buf, size_t count) override {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        nccl_check(rccl().AllReduce(buf, buf, count, ncclDouble, ncclSum, comm_, stream_), "ncclAllReduce");
+        bytes_ += (world_ > 1 ? 2 * count * sizeof(double) : 0);
+    }
+    void send(const double* buf, size_t count, int peer) override {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        nccl_check(rccl().Send(buf, count, ncclDouble, peer, comm_, stream_), "ncclSend");
+        bytes_ += count * sizeof(double);
+    }
+    void recv(double* buf, size_t count, int peer) override {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        nccl_check(rccl().Recv(buf, count, ncclDouble, peer, comm_, stream_), "ncclRecv");
+        bytes_ += count * sizeof(double);
+    }
+    void wait() override {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize (RCCL stream)");
+    }
+    uint64_t bytes_moved() const override { return bytes_; }
+
+private:
+    int rank_, world_, device_;
+    ncclComm_t comm_ = nullptr;
+    hipStream_t stream_ = nullptr;
+    uint64_t bytes_ = 0;
+};
+
+// ---- ranks as threads of one process ---------------------------------------------------------------------------------------
+struct LocalOp {
+    enum Kind { BCAST, ALLREDUCE, SEND, RECV } kind;
+    double* buf;
+    size_t count;
+    int peer;   // root / destination / source
+};
+
+struct LocalGroup {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    std::vector<std::vector<LocalOp>> ops;            // per rank: the group being executed
+    std::vector<std::vector<std::vector<double>>> contrib;   // per rank, per all-reduce of the group: its input on the host
+
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) throw std::runtime_error("inter-GPU exchange: another rank of the process failed");
+        const uint64_t g = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != g || broken; });
+            if (broken && generation == g) throw std::runtime_error("inter-GPU exchange: another rank of the process failed");
+        }
+    }
+    void abandon() {
+        std::lock_guard<std::mutex> lk(m);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
+class LocalComm : public DistComm {
+public:
+    LocalComm(std::shared_ptr<LocalGroup> g, int rank, int device) : g_(g), rank_(rank), device_(device) {}
+    ~LocalComm() override { g_->abandon(); }    // a rank that goes away must not leave the others waiting
+    int rank() const override { return rank_; }
+    int world() const override { return g_->world; }
+    const char* transport() const override { return "local"; }
+    void group_begin() override { grouping_ = true; }
+    void group_end() override {
+        grouping_ = false;
+        execute();
+    }
+    void broadcast(double* buf, size_t count, int root) override { post({LocalOp::BCAST, buf, count, root}); }
+    void all_reduce_sum(double* buf, size_t count) override { post({LocalOp::ALLREDUCE, buf, count, 0}); }
+    void send(const double* buf, size_t count, int peer) override { post({LocalOp::SEND, const_cast<double*>(buf), count, peer}); }
+    void recv(double* buf, size_t count, int peer) override { post({LocalOp::RECV, buf, count, peer}); }
+    void wait() override {}                    // group_end() returns with everything done
+    uint64_t bytes_moved() const override { return bytes_; }
+
+private:
+    void post(const LocalOp& op) {
+        pending_.push_back(op);
+        if (!grouping_) execute();
+    }
+    // every rank executes its group at the same point of its program (the contract of a collective): publish, download the
+    // all-reduce inputs, then copy / sum, with a barrier between the phases and one before the buffers may change again
+    void execute() {
+        LocalGroup& g = *g_;
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        try {
+            g.ops[rank_] = pending_;
+            g.contrib[rank_].clear();
+            for (const LocalOp& op : pending_)
+                if (op.kind == LocalOp::ALLREDUCE) {
+                    g.contrib[rank_].emplace_back(op.count);
+                    hip_check(hipMemcpy(g.contrib[rank_].back().data(), op.buf, op.count * sizeof(double), hipMemcpyDeviceToHost), "all-reduce download");
+                }
+            g.barrier();
+            size_t coll = 0, red = 0;
+            std::vector<size_t> recv_seen(g.world, 0);
+            std::vector<double> sum;
+            for (const LocalOp& op : pending_) {
+                switch (op.kind) {
+                    case LocalOp::BCAST: {
+                        if (op.peer != rank_) {
+                            const LocalOp& src = nth_collective(g.ops[op.peer], coll);
+                            if (src.kind != LocalOp::BCAST || src.count != op.count || src.peer != op.peer)
+                                throw std::runtime_error("inter-GPU exchange: mismatched broadcast");
+                            hip_check(hipMemcpy(op.buf, src.buf, op.count * sizeof(double), hipMemcpyDefault), "broadcast copy");
+                            bytes_ += op.count * sizeof(double);
+                        }
+                        ++coll;
+                        break;
+                    }
+                    case LocalOp::ALLREDUCE: {
+                        sum.assign(op.count, 0.0);
+                        for (int r = 0; r < g.world; ++r) {           // rank order: the same bits on every rank
+                            const std::vector<double>& c = g.contrib[r].at(red);
+                            if (c.size() != op.count) throw std::runtime_error("inter-GPU exchange: mismatched all-reduce");
+                            for (size_t i = 0; i < op.count; ++i) sum[i] += c[i];
+                        }
+                        hip_check(hipMemcpy(op.buf, sum.data(), op.count * sizeof(double), hipMemcpyHostToDevice), "all-reduce upload");
+                        bytes_ += 2 * op.count * sizeof(double);
+                        ++coll;
+                        ++red;
+                        break;
+                    }
+                    case LocalOp::RECV: {
+                        // the k-th receive from a peer matches that peer's k-th send to this rank
+                        size_t want = recv_seen[op.peer]++, seen = 0;
+                        const LocalOp* src = nullptr;
+                        for (const LocalOp& o : g.ops[op.peer])
+                            if (o.kind == LocalOp::SEND && o.peer == rank_ && seen++ == want) {
+                                src = &o;
+                                break;
+                            }
+                        if (!src || src->count != op.count) throw std::runtime_error("inter-GPU exchange: unmatched receive");
+                        hip_check(hipMemcpy(op.buf, src->buf, op.count * sizeof(double), hipMemcpyDefault), "receive copy");
+                        bytes_ += op.count * sizeof(double);
+                        break;
+                    }
+                    case LocalOp::SEND: bytes_ += op.count * sizeof(double); break;
+                }
+            }
+            g.barrier();          // nobody's source buffer changes before every copy out of it is done
+        } catch (...) {
+            pending_.clear();
+            g.abandon();
+            throw;
+        }
+        pending_.clear();
+    }
+    static const LocalOp& nth_collective(const std::vector<LocalOp>& ops, size_t n) {
+        size_t i = 0;
+        for (const LocalOp& o : ops)
+            if (o.kind == LocalOp::BCAST || o.kind == LocalOp::ALLREDUCE) {
+                if (i == n) return o;
+                ++i;
+            }
+        throw std::runtime_error("inter-GPU exchange: collective sequences differ between ranks");
+    }
+
+    std::shared_ptr<LocalGroup> g_;
+    int rank_, device_;
+    bool grouping_ = false;
+    std::vector<LocalOp> pending_;
+    uint64_t bytes_ = 0;
+};
+
+}  // namespace
+
+bool rccl_available(std::string* why) {
+    RcclApi& api = rccl();
+    if (!api.handle && why) *why = api.error;
+    return api.handle != nullptr;
+}
+
+void rccl_unique_id(unsigned char id[DIST_UNIQUE_ID_BYTES]) {
+    RcclApi& api = rccl();
+    if (!api.handle) throw std::runtime_error(api.error);
+    ncclUniqueId uid;
+    nccl_check(api.GetUniqueId(&uid), "ncclGetUniqueId");
+    memcpy(id, uid.internal, DIST_UNIQUE_ID_BYTES);
+}
+
+std::shared_ptr<DistComm> rccl_comm_create(int rank, int world, const unsigned char id[DIST_UNIQUE_ID_BYTES], int device) {
+    return std::make_shared<RcclComm>(rank, world, id, device);
+}
+
+std::vector<std::shared_ptr<DistComm>> local_comm_create(int world, const std::vector<int>& devices) {
+    auto g = std::make_shared<LocalGroup>();
+    g->world = world;
+    g->ops.resize(world);
+    g->contrib.resize(world);
+    std::vector<std::shared_ptr<DistComm>> out;
+    for (int r = 0; r < world; ++r) out.push_back(std::make_shared<LocalComm>(g, r, devices.at(r)));
+    return out;
+}
+
+// ---- the 128 bytes, from rank 0 to everybody, over TCP ----------------------------------------------------------------------
+namespace {
+void write_all(int fd, const void* p, size_t n) {
+    const char* c = (const char*)p;
+    while (n) {
+        ssize_t w = ::send(fd, c, n, MSG_NOSIGNAL);
+        if (w <= 0) throw std::runtime_error("unique-id exchange: send failed");
+        c += w;
+        n -= (size_t)w;
+    }
+}
+void read_all(int fd, void* p, size_t n) {
+    char* c = (char*)p;
+    while (n) {
+        ssize_t r = ::recv(fd, c, n, 0);
+        if (r <= 0) throw std::runtime_error("unique-id exchange: receive failed");
+        c += r;
+        n -= (size_t)r;
+    }
+}
+}  // namespace
+
+void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BYTES], const char* addr, int port, double timeout_s) {
+    if (world <= 1) return;
+    std::string host = addr && *addr ? addr : (getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1");
+    if (port <= 0) {
+        const char* e = getenv("DNAGPU_MASTER_PORT");
+        if (e && atoi(e) > 0)
+            port = atoi(e);
+        else
+            port = (getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) : 29500) + 17;
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+    if (rank == 0) {
+        int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (ls < 0) throw std::runtime_error("unique-id exchange: socket()");
+        int one = 1;
+        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        sockaddr_in sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sin_family = AF_INET;
+        sa.sin_addr.s_addr = htonl(INADDR_ANY);
+        sa.sin_port = htons((uint16_t)port);
+        if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || ::listen(ls, world) != 0) {
+            ::close(ls);
+            throw std::runtime_error("unique-id exchange: cannot listen on port " + std::to_string(port));
+        }
+        for (int got = 0; got < world - 1;) {
+            timeval tv;
+            double left = std::chrono::duration<double>(deadline - std::chrono::steady_clock::now()).count();
+            if (left <= 0) {
+                ::close(ls);
+                throw std::runtime_error("unique-id exchange: timed out waiting for the other ranks");
+            }
+            tv.tv_sec = (long)left;
+            tv.tv_usec = 0;
+            fd_set fds;
+            FD_ZERO(&fds);
+            FD_SET(ls, &fds);
+            if (::select(ls + 1, &fds, nullptr, nullptr, &tv) <= 0) continue;
+            int c = ::accept(ls, nullptr, nullptr);
+            if (c < 0) continue;
+            int32_t peer = -1;
+            try {
+                read_all(c, &peer, sizeof(peer));
+                write_all(c, id, DIST_UNIQUE_ID_BYTES);
+                ++got;
+            } catch (...) {
+            }
+            ::close(c);
+        }
+        ::close(ls);
+        return;
+    }
+    addrinfo hints, *res = nullptr;
+    memset(&hints, 0, sizeof(hints));
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_STREAM;
+    if (getaddrinfo(host.c_str(), std::to_string(port).c_str(), &hints, &res) != 0 || !res)
+        throw std::runtime_error("unique-id exchange: cannot resolve " + host);
+    for (;;) {
+        int s = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (s >= 0 && ::connect(s, res->ai_addr, res->ai_addrlen) == 0) {
+            try {
+                int32_t me = rank;
+                write_all(s, &me, sizeof(me));
+                read_all(s, id, DIST_UNIQUE_ID_BYTES);
+                ::close(s);
+                freeaddrinfo(res);
+                return;
+            } catch (...) {
+            }
+        }
+        if (s >= 0) ::close(s);
+        if (std::chrono::steady_clock::now() > deadline) {
+            freeaddrinfo(res);
+            throw std::runtime_error("unique-id exchange: rank 0 not reachable at " + host + ":" + std::to_string(port));
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+}
+
+}  // namespace networkadjust
+}  // namespace dynadjust

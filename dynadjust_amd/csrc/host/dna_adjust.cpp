@@ -27,10 +27,16 @@ constexpr double PRECISION_1E5 = 1.0e-5;
 
 dna_adjust::dna_adjust() {}
 
-dna_adjust::~dna_adjust() { FreeDevice(); }
+dna_adjust::~dna_adjust() {
+    peers_.clear();
+    FreeDevice();
+}
 
 void dna_adjust::FreeDevice() {
     if (!ctx_) return;
+    if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);
+    xbuf_dev_ = nullptr;
+    xbuf_cap_ = 0;
     for (block_t& b : blocks_) {
         if (b.jfwd) dnagpu_matrix_destroy(ctx_, b.jfwd);
         if (b.jrev) dnagpu_matrix_destroy(ctx_, b.jrev);
@@ -690,13 +696,20 @@ void dna_adjust::PrepareBlocks() {
             // v_rigorousVariances_ is allocated when the block is finalised (only on the rank / chain that owns it)
         }
     }
+    ComputeBlockOwners(CondensedWanted() && !ReuseInverses());
     DecideStaging();
     PrepareCondensedBlocks();
+    if (DistWorld() > 1 && phased && !CondensedSchedule()) ComputeBlockOwners(false);    // the reference's schedule shards differently
     Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
 }
 
 // ADJ:258-442
 void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
+    if (projectSettings.a.devices.size() > 1 && !is_peer_) {
+        PrepareMultiDevice(projectSettings);      // one instance + host thread per GPU; each comes back here as a rank
+        return;
+    }
+    if (!in_collective_) peers_.clear();
     isPreparing_ = true;
     isAdjusting_ = true;
     isCombining_ = false;
@@ -708,6 +721,27 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     profileTimings_ = getenv("DYNADJUST_PROFILE") != nullptr;
     profileUpdateNormalsNs_ = profileStageLoadNs_ = profileStageStoreNs_ = 0;
     if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
+    if (const char* e = getenv("DNAGPU_FORCE_DISTRIBUTED")) force_distributed_ = atoi(e) != 0;
+    if (comm_ && (comm_->world() != std::max(1, projectSettings_.a.dist_world) || comm_->rank() != projectSettings_.a.dist_rank)) {
+        if (projectSettings_.a.dist_world <= 1) {        // an attached communicator names the rank
+            projectSettings_.a.dist_world = comm_->world();
+            projectSettings_.a.dist_rank = comm_->rank();
+        } else {
+            SignalExceptionAdjustment("PrepareAdjustment(): the attached communicator does not match a.dist_rank / a.dist_world.", 0);
+        }
+    }
+    if (!comm_ && (projectSettings_.a.dist_world > 1 || force_distributed_)) {
+        // one process per GPU and nobody attached a communicator: RCCL, the unique id from rank 0 over TCP (MASTER_ADDR / MASTER_PORT)
+        try {
+            const int world = std::max(1, projectSettings_.a.dist_world);
+            unsigned char id[DIST_UNIQUE_ID_BYTES] = {0};
+            if (projectSettings_.a.dist_rank == 0) rccl_unique_id(id);
+            tcp_share_unique_id(projectSettings_.a.dist_rank, world, id);
+            comm_ = rccl_comm_create(projectSettings_.a.dist_rank, world, id, projectSettings_.a.device);
+        } catch (const std::exception& e) {
+            SignalExceptionAdjustment(std::string("PrepareAdjustment(): cannot join the other GPUs' processes. Details: ") + e.what(), 0);
+        }
+    }
     staged_ = projectSettings_.a.stage != 0;   // staged: rigorous variances in page-locked host memory (PrepareCondensedBlocks may switch it on)
     // InitialiseAdjustment (ADJ:232-245)
     var_C_ = projectSettings_.a.fixed_std_dev * projectSettings_.a.fixed_std_dev;
@@ -775,6 +809,10 @@ void dna_adjust::SolveTry(int chain, UINT32 block, dnagpu_matrix* m) {
 
 // ADJ:2140
 _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
+    if (!peers_.empty() && !in_collective_) {
+        OnEveryDevice([](dna_adjust& a) { a.AdjustNetwork(); });
+        return adjustStatus_;
+    }
     if (!ctx_) SignalExceptionAdjustment("AdjustNetwork(): PrepareAdjustment() has not been called.", 0);
     isAdjusting_ = true;
     adjustStatus_ = ADJUST_SUCCESS;
@@ -852,8 +890,12 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
     isPreparing_ = true;
     const bool phased = projectSettings_.a.adjust_mode != SimultaneousMode;
     const int chains = NumChains();
+    // across GPUs with the condensed schedule a rank forms and solves its own blocks only (the chains run on condensed blocks,
+    // whose right-hand sides arrive with them)
+    const bool own_only = Distributed() && CondensedSchedule() && DistWorld() > 1;
     for (UINT32 b = 0; b < blockCount_; ++b) {
         if (IsCancelled()) break;
+        if (own_only && !OwnsBlock(b)) continue;
         if (phased && v_blockMeta_[b]._blockLast) {
             // estimated = original = rigorous (ADJ:516-517)
             for (int c = 0; c < chains; ++c) Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
@@ -900,6 +942,10 @@ void dna_adjust::AdjustPhasedBlock1() {
 
 // ADJ:2579-2670
 void dna_adjust::AdjustPhased() {
+    if (Distributed()) {
+        AdjustPhasedDistributed();
+        return;
+    }
     currentIteration_ = 0;
     for (UINT32 i = 0; i < projectSettings_.a.max_iterations; ++i) {
         if (IsCancelled()) break;
@@ -942,6 +988,10 @@ void dna_adjust::GetBlockRigorousStations(UINT32 block, std::vector<double>& xyz
 
 void dna_adjust::GetBlockRigorousVariancesPacked(UINT32 block, std::vector<double>& packed) {
     if (!ctx_ || block >= blockCount_) throw std::runtime_error("GetBlockRigorousVariancesPacked(): no such block");
+    if (!peers_.empty() && !OwnsBlock(block)) {     // another GPU of this process holds it
+        DeviceInstance(BlockOwner(block))->GetBlockRigorousVariancesPacked(block, packed);
+        return;
+    }
     size_t n = 3 * v_parameterStationList_[block].size();
     packed.resize(n * (n + 1) / 2);
     if (projectSettings_.a.adjust_mode != SimultaneousMode && Staged() && blocks_[block].rig_host && blocks_[block].has_rigvar) {
@@ -971,7 +1021,12 @@ void dna_adjust::GetAdjustedCoordinates(std::vector<double>& xyz) {
 }
 
 void dna_adjust::ResetAdjustment() {
+    if (!peers_.empty() && !in_collective_) {
+        OnEveryDevice([](dna_adjust& a) { a.ResetAdjustment(); });
+        return;
+    }
     if (!ctx_) SignalExceptionAdjustment("ResetAdjustment(): PrepareAdjustment() has not been called.", 0);
+    exchange_ms_ = chain_ms_ = 0.0;
     const int chains = NumChains();
     for (UINT32 b = 0; b < blockCount_; ++b) {
         Check(dnagpu_block_set_stations(ctx_, b, initial_xyz_[b].data()), b, "ResetAdjustment()");
@@ -996,7 +1051,17 @@ void dna_adjust::ResetAdjustment() {
 
 // ADJ:6802-6841: UpdateAdjustment(false) + ComputeStatistics()
 void dna_adjust::GenerateStatistics() {
+    if (!peers_.empty() && !in_collective_) {
+        OnEveryDevice([](dna_adjust& a) { a.GenerateStatistics(); });
+        return;
+    }
     if (!ctx_) SignalExceptionAdjustment("GenerateStatistics(): PrepareAdjustment() has not been called.", 0);
+    if (Distributed() && projectSettings_.a.adjust_mode == PhasedMode) {
+        GenerateStatisticsDistributed();
+        isAdjustmentQuestionable_ = adjustStatus_ != ADJUST_SUCCESS || sigmaZero_ > 10.0 * chiSquaredUpperLimit_ ||
+                                    std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
+        return;
+    }
     // meas-minus-computed from the final estimates; the inverses are kept (ADJ:549-557)
     UpdateAdjustment(false);
     ComputeStatistics();
@@ -1279,17 +1344,28 @@ void dna_adjust::SerialiseAdjustedVarianceMatrices() {
     if (!ctx_) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): PrepareAdjustment() has not been called.", 0);
     const std::string folder = projectSettings_.a.stage_path.empty() ? projectSettings_.g.output_folder : projectSettings_.a.stage_path;
     const std::string base = folder + "/" + projectSettings_.g.network_name + "-";
-    std::ofstream rva(base + "rva.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
-    std::ofstream pam(base + "pam.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
-    if (!rva || !pam) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): cannot create " + base + "rva.mtx / pam.mtx", 0);
-    std::vector<double> packed;
+    // one process per GPU: collective -- every block's results travel to rank 0, which writes the files
+    const bool across_processes = Distributed() && peers_.empty() && !is_peer_ && DistWorld() > 1 &&
+                                  projectSettings_.a.adjust_mode != SimultaneousMode;
+    const bool writer = !across_processes || DistRank() == 0;
+    std::ofstream rva, pam;
+    if (writer) {
+        rva.open(base + "rva.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
+        pam.open(base + "pam.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
+        if (!rva || !pam) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): cannot create " + base + "rva.mtx / pam.mtx", 0);
+    }
+    std::vector<double> packed, fetched_prec;
     for (UINT32 b = 0; b < blockCount_; ++b) {
-        GetBlockRigorousVariancesPacked(b, packed);
+        if (across_processes)
+            CollectBlockResults(b, packed, fetched_prec);
+        else
+            GetBlockRigorousVariancesPacked(b, packed);
+        if (!writer) continue;
         const UINT32 n = (UINT32)v_parameterStationList_[b].size() * 3;
         write_mtx_header(rva, 1 /* mtx_lower */, n, n);
         rva.write(reinterpret_cast<const char*>(packed.data()), (std::streamsize)(packed.size() * sizeof(double)));
         write_mtx_trailer(rva);
-        const std::vector<double>& prec = blocks_[b].prec_adj_msrs;
+        const std::vector<double>& prec = across_processes ? fetched_prec : GetBlockPrecAdjMsrs(b);
         const UINT32 rows = (UINT32)(6 * blocks_[b].stn1.size() + blocks_[b].t_type.size());   // v_measurementVarianceCount_ (ADJ:10513-10560)
         write_mtx_header(pam, 0 /* mtx_full */, rows, 1);
         if (prec.size() == rows)
@@ -1300,7 +1376,7 @@ void dna_adjust::SerialiseAdjustedVarianceMatrices() {
         }
         write_mtx_trailer(pam);
     }
-    if (!rva || !pam) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): write failed", 0);
+    if (writer && (!rva || !pam)) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): write failed", 0);
 }
 
 // ADJ:6720-6767: the inverse of SerialiseAdjustedVarianceMatrices -- `dnaadjust --report-results` prints an earlier adjustment
@@ -1394,6 +1470,8 @@ std::string dna_adjust::GetIterationTime(const UINT32& iteration) const {
 // ADJ:445-470: the station and measurement records (adjusted coordinates, adjusted measurements and their
 // statistics, scaled variances) go back to the .bst / .bms files, flagged as reduced
 void dna_adjust::UpdateBinaryFiles() {
+    // one process per GPU: every rank holds the same records after the collective GenerateStatistics(); rank 0 writes them
+    if (Distributed() && peers_.empty() && !is_peer_ && DistRank() != 0) return;
     try {
         snprintf(bst_meta_.modifiedBy, sizeof(bst_meta_.modifiedBy), "%s", "dnaadjust");
         bst_meta_.reduced = true;

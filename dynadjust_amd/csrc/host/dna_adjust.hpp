@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../../include/dnagpu.h"
+#include "dist_comm.hpp"
 #include "dnaio.hpp"
 #include "dnatypes.hpp"
 
@@ -106,18 +107,43 @@ public:
     // measurement records as GenerateStatistics() left them (measAdj, measCorr, measAdjPrec, residualPrec, NStat, TStat, PelzerRel)
     const std::vector<measurement_t>& GetMeasurementRecords() const { return bmsBinaryRecords_; }
     // v_precAdjMsrsFull_ of a block: 6 values (xx xy xz yy yz zz) per GNSS vector in CML order
-    const std::vector<double>& GetBlockPrecAdjMsrs(UINT32 block) const { return blocks_.at(block).prec_adj_msrs; }
+    const std::vector<double>& GetBlockPrecAdjMsrs(UINT32 block) const {
+        if (!peers_.empty() && !OwnsBlock(block)) return peers_.at(BlockOwner(block) - 1)->blocks_.at(block).prec_adj_msrs;
+        return blocks_.at(block).prec_adj_msrs;
+    }
+
+    // ---- multi-GPU (not in the reference: its parallel driver is AdjustPhasedMultiThread, dnaadjust-multi.cpp:92-244) ----------
+    // One process per GPU: give every process its rank (a.dist_rank / a.dist_world) and either attach a communicator before
+    // PrepareAdjustment() or let PrepareAdjustment() make the RCCL one itself (the unique id travels over TCP from rank 0,
+    // MASTER_ADDR / MASTER_PORT).  One process for several GPUs: list them in a.devices.  Either way AdjustNetwork(),
+    // GenerateStatistics(), SerialiseAdjustedVarianceMatrices() and UpdateBinaryFiles() are then collective: call them on every
+    // rank; the result files are written by rank 0.
+    void AttachCommunicator(std::shared_ptr<DistComm> comm) { comm_ = comm; }
+    int DistRank() const { return comm_ ? comm_->rank() : 0; }
+    int DistWorld() const { return comm_ ? comm_->world() : 1; }
+    const char* DistTransport() const { return comm_ ? comm_->transport() : "none"; }
+    bool Distributed() const { return comm_ && (comm_->world() > 1 || force_distributed_); }
+    // rank whose GPU holds block k's rigorous variances (and does its large steps); identical on every rank
+    int BlockOwner(UINT32 k) const { return owner_.empty() ? 0 : owner_.at(k); }
+    bool OwnsBlock(UINT32 k) const { return BlockOwner(k) == DistRank(); }
+    uint64_t ExchangedBytes() const { return comm_ ? comm_->bytes_moved() : 0; }
+    double ExchangeMs() const { return exchange_ms_; }      // host time spent in the exchange steps since ResetAdjustment()
+    double ChainPhaseMs() const { return chain_ms_; }       // ... in the chains on the condensed blocks
 
     // ---- measurement helpers (not in the reference) ---------------------------------------
     // put every block back to its state right after PrepareAdjustment (initial coordinates, fresh
     // meas-minus-computed) so that AdjustNetwork can be timed repeatedly on resident data
     void ResetAdjustment();
-    double solveFlops() const { return solve_flops_; }   // sum of n^3 over Solve() calls (reference-equivalent)
-    UINT32 solveCount() const { return solve_count_; }
-    UINT32 eliminationCount() const { return elimination_count_; }
-    UINT32 condenseCount() const { return condense_count_; }
-    UINT32 completionCount() const { return completion_count_; }
-    double algorithmicFlops() const { return algorithmic_flops_; }
+    // (with a.devices: summed over the GPUs of the process)
+    double solveFlops() const { return SumOverPeers([](const dna_adjust& a) { return a.solve_flops_; }); }   // sum of n^3 over Solve() calls (reference-equivalent)
+    UINT32 solveCount() const { return (UINT32)SumOverPeers([](const dna_adjust& a) { return (double)a.solve_count_; }); }
+    UINT32 eliminationCount() const { return (UINT32)SumOverPeers([](const dna_adjust& a) { return (double)a.elimination_count_; }); }
+    UINT32 condenseCount() const { return (UINT32)SumOverPeers([](const dna_adjust& a) { return (double)a.condense_count_; }); }
+    UINT32 completionCount() const { return (UINT32)SumOverPeers([](const dna_adjust& a) { return (double)a.completion_count_; }); }
+    double algorithmicFlops() const { return SumOverPeers([](const dna_adjust& a) { return a.algorithmic_flops_; }); }
+    // the instance that drives GPU r of a.devices (0 = this one)
+    dna_adjust* DeviceInstance(int r) { return r == 0 ? this : peers_.at(r - 1).get(); }
+    int DeviceInstances() const { return 1 + (int)peers_.size(); }
     dnagpu_ctx* deviceContext() const { return ctx_; }
 
 private:
@@ -184,6 +210,34 @@ private:
     void AdjustPhasedReverseCombine();   // ADJ:3461
     void AdjustPhasedMultiThreadIteration();   // dnaadjust-multi.cpp:92-244 (forward || reverse chains)
     void AdjustPhasedCondensedIteration();     // a.schur_carry: condense every block, chains on the condensed blocks, rigorous solves
+    // ---- multi-GPU (dna_adjust_dist.cpp) ----
+    void AdjustPhasedDistributed();            // AdjustPhased across the ranks of comm_
+    void DistributedCondensedIteration();
+    void DistributedReferenceIteration();
+    void ExchangeCondensed();                  // broadcast of every condensed block from its owner
+    void SyncCoordinates();                    // rigorous coordinates of every block + the largest correction, on every rank
+    void GenerateStatisticsDistributed();
+    void CollectBlockResults(UINT32 block, std::vector<double>& packed, std::vector<double>& prec);
+    void ComputeBlockOwners(bool condensed);
+    void AgreeOnPhase(const char* phase, const std::function<void()>& body);   // body() everywhere, then: did any rank fail?
+    double* ExchangeBuffer(size_t doubles);    // device scratch of the exchange steps
+    void PrepareMultiDevice(const project_settings& p);
+    void OnEveryDevice(const std::function<void(dna_adjust&)>& body);
+    template <class F>
+    double SumOverPeers(F f) const {
+        double s = f(*this);
+        for (const auto& p : peers_) s += f(*p);
+        return s;
+    }
+    std::shared_ptr<DistComm> comm_;
+    bool force_distributed_ = false;           // DNAGPU_FORCE_DISTRIBUTED=1: the exchange steps also run with a single rank
+    bool in_collective_ = false;               // this instance is being driven as one rank by OnEveryDevice
+    bool is_peer_ = false;                     // one of the per-GPU instances of a multi-device adjustment
+    std::vector<int> owner_;
+    std::vector<std::unique_ptr<dna_adjust>> peers_;
+    double* xbuf_dev_ = nullptr;
+    size_t xbuf_cap_ = 0;
+    double exchange_ms_ = 0.0, chain_ms_ = 0.0;
     void PrepareCondensedBlocks();
     void DecideStaging();
 public:

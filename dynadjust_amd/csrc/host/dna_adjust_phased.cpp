@@ -406,7 +406,8 @@ void dna_adjust::DecideStaging() {
     Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
     auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
     double need = 8.0e9 + 3.0 * (double)NumChains() * sq((double)max_unknowns_);
-    for (UINT32 k = 0; k < blockCount_; ++k) need += sq(3.0 * (double)v_parameterStationList_[k].size());
+    for (UINT32 k = 0; k < blockCount_; ++k)
+        if (OwnsBlock(k)) need += sq(3.0 * (double)v_parameterStationList_[k].size());   // (a rank keeps the variances of its own blocks)
     if (need > (double)free_b) staged_ = true;
 }
 
@@ -465,12 +466,13 @@ void dna_adjust::PrepareCondensedBlocks() {
     Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
     auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
     double later = 8.0e9, rig = 0.0;
-    for (UINT32 k = 0; k < blockCount_; ++k) rig += sq(3.0 * (double)v_parameterStationList_[k].size());
+    for (UINT32 k = 0; k < blockCount_; ++k)
+        if (OwnsBlock(k)) rig += sq(3.0 * (double)v_parameterStationList_[k].size());
     later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? 0.0 : rig);
     double budget = (double)free_b - later;
     for (UINT32 k = 0; k < blockCount_; ++k) {
         block_t& B = blocks_[k];
-        if (B.keep.empty()) continue;
+        if (B.keep.empty() || !OwnsBlock(k)) continue;      // (a block is condensed and completed on its owner's GPU only)
         const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size();
         const double need = 2.0 * sq(n) + (nk + 256.0) * (n + 256.0) * 8.0;
         if (need > budget) continue;

@@ -92,6 +92,11 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         p.a.schur_carry = (uint16_t)(s->schur_carry ? 1 : 0);
         p.a.keep_factors = (uint16_t)(s->keep_factors ? 1 : 0);
         p.a.stage = (uint16_t)(s->stage ? 1 : 0);
+        p.a.dist_rank = s->dist_rank;
+        p.a.dist_world = s->dist_world > 0 ? s->dist_world : 1;
+        if (s->n_devices > 1 && s->devices) p.a.devices.assign(s->devices, s->devices + s->n_devices);
+        if (s->dist_transport) p.a.dist_transport = s->dist_transport;
+        p.a.dist_two_level = (uint16_t)(s->dist_two_level ? 1 : 0);
         if (s->network_name) p.g.network_name = s->network_name;
         if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);
@@ -103,6 +108,62 @@ int dnaadj_adjust(dnaadj_handle* h, int* status) {
         int st = (int)h->adj->AdjustNetwork();
         if (status) *status = st;
     });
+}
+
+int dnaadj_dist_rccl_available(void) { return dynadjust::networkadjust::rccl_available() ? 1 : 0; }
+
+int dnaadj_dist_unique_id(unsigned char* id128, char* err, size_t errlen) {
+    if (!id128) return DNAADJ_EINVAL;
+    try {
+        dynadjust::networkadjust::rccl_unique_id(id128);
+        return DNAADJ_OK;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return DNAADJ_EXCEPTION;
+    }
+}
+
+int dnaadj_dist_attach_rccl(dnaadj_handle* h, int rank, int world, const unsigned char* id128, int device) {
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return DNAADJ_EINVAL;
+    return guarded(h, [&] { h->adj->AttachCommunicator(dynadjust::networkadjust::rccl_comm_create(rank, world, id128, device)); });
+}
+
+int dnaadj_adjust_distributed(dnaadj_handle* h, int* status) {
+    if (!h || !h->adj) return DNAADJ_EINVAL;
+    if (!h->adj->Distributed() && h->adj->DeviceInstances() < 2) {
+        h->err = "dnaadj_adjust_distributed: the adjustment was not prepared across GPUs";
+        return DNAADJ_EINVAL;
+    }
+    return dnaadj_adjust(h, status);
+}
+
+int dnaadj_dist_info(const dnaadj_handle* h, int* rank, int* world, char* transport, size_t len) {
+    if (!h || !h->adj) return DNAADJ_EINVAL;
+    dna_adjust* a = h->adj;
+    const bool multi = a->DeviceInstances() > 1;
+    if (rank) *rank = a->DistRank();
+    if (world) *world = a->DistWorld();
+    if (transport && len) snprintf(transport, len, "%s", a->DistTransport());
+    (void)multi;
+    return DNAADJ_OK;
+}
+
+int dnaadj_block_owner(const dnaadj_handle* h, uint32_t block) {
+    if (!h || !h->adj || block >= h->adj->blockCount()) return -1;
+    return h->adj->BlockOwner(block);
+}
+
+int dnaadj_exchange_stats(const dnaadj_handle* h, uint64_t* bytes, double* exchange_ms, double* chain_ms) {
+    if (!h || !h->adj) return DNAADJ_EINVAL;
+    if (bytes) *bytes = h->adj->ExchangedBytes();
+    if (exchange_ms) *exchange_ms = h->adj->ExchangeMs();
+    if (chain_ms) *chain_ms = h->adj->ChainPhaseMs();
+    return DNAADJ_OK;
+}
+
+void* dnaadj_device_instance_context(dnaadj_handle* h, int r) {
+    if (!h || !h->adj || r < 0 || r >= h->adj->DeviceInstances()) return nullptr;
+    return h->adj->DeviceInstance(r)->deviceContext();
 }
 
 int dnaadj_reset(dnaadj_handle* h) {

@@ -211,6 +211,19 @@ struct adjust_settings {
     int max_threads = 0;
     // device selection (not in the reference): which GPU this process drives
     int device = 0;
+    // Multi-GPU (not in the reference).  Either one process per GPU -- this one is rank dist_rank of dist_world
+    // (the launcher's RANK / WORLD_SIZE), its GPU is `device` -- or one process for all of them: `devices` lists the GPUs and
+    // AdjustNetwork() spreads the blocks over them from one host thread per GPU.  The exchange step runs over RCCL
+    // (dist_transport "rccl", the default wherever every rank has a GPU of its own) or, for ranks of one process, through
+    // device-to-device copies ("local").
+    int dist_rank = 0;
+    int dist_world = 1;
+    std::vector<int> devices;
+    std::string dist_transport;      // "" = choose, "rccl", "local"
+    // condensed chains across ranks: 0 = every rank runs both chains on all condensed blocks (one broadcast per block);
+    // 1 = two-level (each rank reduces its own run of blocks, the ranks' boundary systems are scanned, every rank finishes its
+    // own blocks)
+    UINT16 dist_two_level = 0;
 };
 struct output_settings {
     UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement

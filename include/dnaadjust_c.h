@@ -52,6 +52,13 @@ typedef struct {
                                   n x n matrices per block, as far as memory allows) and the rigorous solve of the block completes
                                   it instead of inverting the block's normals again: ~1.0 instead of ~1.36 inverse-equivalents
                                   per block and iteration, same results up to rounding */
+    /* ---- multi-GPU (device path only; all zero / NULL = one GPU).  See "multi-GPU" below. ---- */
+    int dist_rank;             /* one process per GPU: this process's rank ... */
+    int dist_world;            /* ... of dist_world (0 or 1 = single process) */
+    int n_devices;             /* one process for several GPUs: how many entries `devices` has (0 or 1 = `device` only) */
+    const int* devices;        /* their HIP ordinals */
+    const char* dist_transport;/* NULL = choose; "rccl"; "local" (ranks of one process sharing a GPU) */
+    int dist_two_level;        /* condensed chains across ranks: 0 = on every rank, 1 = two-level (see dnatypes.hpp) */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
@@ -174,6 +181,31 @@ int dnaadj_junction_import(dnaadj_handle* h, int kind, uint32_t block, const dou
 int dnaadj_block_get_coords(dnaadj_handle* h, uint32_t block, int which, double* xyz);
 int dnaadj_block_set_coords(dnaadj_handle* h, uint32_t block, const double* xyz);   /* original = estimated = rigorous */
 int dnaadj_block_recompute_b(dnaadj_handle* h, uint32_t block);
+
+/* ---- multi-GPU: the reference's parallel driver is a member of the class (dna_adjust::AdjustPhasedMultiThread,
+ * dnaadjust-multi.cpp:92-244); here the blocks of one network are spread over GPUs and the driver stays inside AdjustNetwork().
+ *   one process per GPU   settings.dist_rank / dist_world (+ settings.device) on every process.  The RCCL communicator is made
+ *                         inside dnaadj_prepare (rank 0's unique id reaches the others over TCP, MASTER_ADDR : MASTER_PORT + 17 or
+ *                         DNAGPU_MASTER_PORT), or beforehand by the host: dnaadj_dist_unique_id on one rank, the 128 bytes to
+ *                         every rank by whatever the host has (MPI_Bcast, a torch.distributed broadcast, a file), then
+ *                         dnaadj_dist_attach_rccl on every rank (collective: ncclCommInitRank).
+ *   one process, N GPUs   settings.devices / n_devices: one host thread per GPU inside the library.
+ * dnaadj_adjust / dnaadj_adjust_distributed, dnaadj_generate_statistics, dnaadj_serialise_adjusted_variance_matrices,
+ * dnaadj_update_binary_files and dnaadj_reset are then collective: call them on every process; rank 0 writes the files. */
+#define DNAADJ_UNIQUE_ID_BYTES 128
+int dnaadj_dist_rccl_available(void);
+int dnaadj_dist_unique_id(unsigned char* id128, char* err, size_t errlen);
+int dnaadj_dist_attach_rccl(dnaadj_handle* h, int rank, int world, const unsigned char* id128, int device);
+/* AdjustNetwork() of an adjustment prepared across GPUs; DNAADJ_EINVAL if it was not (dnaadj_adjust works for both) */
+int dnaadj_adjust_distributed(dnaadj_handle* h, int* status);
+/* rank, world, transport ("rccl" / "local" / "none") of the prepared adjustment; rank whose GPU holds a block */
+int dnaadj_dist_info(const dnaadj_handle* h, int* rank, int* world, char* transport, size_t len);
+int dnaadj_block_owner(const dnaadj_handle* h, uint32_t block);
+/* since the last dnaadj_reset: payload bytes this rank moved through the transport, host time in the exchange steps and in
+ * the chains on the condensed blocks (ms) */
+int dnaadj_exchange_stats(const dnaadj_handle* h, uint64_t* bytes, double* exchange_ms, double* chain_ms);
+/* settings.devices: device context of GPU r's instance (r = 0 .. n_devices-1), for dnagpu_profile_* */
+void* dnaadj_device_instance_context(dnaadj_handle* h, int r);
 
 /* device context of the adjustment (for dnagpu_profile_*), NULL before prepare */
 void* dnaadj_device_context(dnaadj_handle* h);

@@ -66,6 +66,11 @@ int dnagpu_device_count(void);
 /* page-locked host memory (full-rate, asynchronous transfers): the spill area of matrices that do not fit in HBM */
 int dnagpu_host_alloc(dnagpu_ctx* ctx, size_t bytes, void** out);
 void dnagpu_host_free(dnagpu_ctx* ctx, void* p);
+/* plain device buffers for the host's own exchange step (the coordinate vector of the all-reduce, the statistics' partial sums) and
+ * synchronous copies between any two of host / device memory */
+int dnagpu_device_alloc(dnagpu_ctx* ctx, size_t bytes, void** out);
+void dnagpu_device_free(dnagpu_ctx* ctx, void* p);
+int dnagpu_copy(dnagpu_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* free / total device memory in bytes (hipMemGetInfo) */
 int dnagpu_mem_info(dnagpu_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* wait for every stream of the ctx */
@@ -118,6 +123,11 @@ int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dna
  * junction exchange, CarryStnEstimatesandVariances* ADJ:998/1133/3196) */
 int dnagpu_matrix_export(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* dst, size_t cap_doubles);
 int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* src, uint32_t n);
+/* The exchange without staging copies: RCCL (ncclBroadcast / ncclSend / ncclRecv) works in place on the matrix's own storage --
+ * np * np doubles at *matrix (ld = np) and np doubles at *vector (the attached junction estimates / reduced right-hand side).
+ * A receiver sets the logical order first (dnagpu_matrix_resize: n <= n_max; contents untouched). */
+int dnagpu_matrix_resize(dnagpu_ctx* ctx, dnagpu_matrix* m, uint32_t n);
+int dnagpu_matrix_device_pointers(const dnagpu_matrix* m, double** matrix, double** vector, uint32_t* np);
 /* in-place inverse (lower in, both triangles out); checks positive definiteness */
 int dnagpu_invert(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, int scale_to_unity);
 

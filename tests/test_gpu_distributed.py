@@ -1,0 +1,150 @@
+"""The multi-GPU driver inside the C++ boundary (dna_adjust::AdjustPhasedDistributed, dna_adjust_dist.cpp) -- no torch, no
+Python in the data path.  What a one-GPU box can exercise:
+
+  * one process, several ranks as host threads SHARING the GPU (a.devices = [0, 0, ...], transport "local": device-to-device
+    copies): both schedules, 2 and 3 ranks, against the oracle and the single-GPU facade; collective statistics; result files;
+  * the RCCL transport with one rank (DNAGPU_FORCE_DISTRIBUTED=1): ncclCommInitRank, ncclBroadcast of every condensed block in
+    place, ncclAllReduce of the coordinate vector and of the statistics;
+  * failures on one rank reach every rank (no rank left waiting in a collective).
+N ranks on N GPUs over RCCL differ from these only in the transport object (dist_comm.cpp)."""
+import os
+
+import numpy as np
+import pytest
+
+from dynadjust_amd import adjust
+from tests import dnaformats as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_X = 1e-8
+TOL_V = 1e-8
+
+
+def _oracle(orc, folder, name):
+    net = orc.Network(os.path.join(folder, name), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    return o, o.run()
+
+
+def _run(folder, name, **kw):
+    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, **kw)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    return a
+
+
+def _stats(a):
+    return np.array([a.GetChiSquared(), a.GetSigmaZero(), a.GetGlobalPelzerRel(), float(a.GetPotentialOutlierCount()),
+                     float(a.GetDegreesOfFreedom()), float(a.GetTestResult())])
+
+
+@pytest.mark.parametrize("ranks,schur,mt", [(2, True, False), (2, False, False), (3, True, True), (3, False, True), (8, True, False)])
+def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt):
+    adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 6, seed=10)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    a = _run(str(tmp_path), "n", devices=[0] * ranks, dist_transport="local", schur_carry=schur, multi_thread=mt, network_name="n",
+             output_folder=str(tmp_path / "multi"))
+    os.makedirs(tmp_path / "multi", exist_ok=True)
+    st = a.AdjustNetworkDistributed()
+    rank, world, transport = a.dist_info()
+    assert (rank, world, transport) == (0, ranks, "local")
+    owners = [a.block_owner(k) for k in range(6)]
+    assert sorted(set(owners)) == list(range(min(ranks, 6))) if schur else max(owners) <= ranks - 1
+    if schur:
+        assert owners == sorted(owners)                       # contiguous runs of blocks per rank
+    assert st == ost and a.CurrentIteration() == o.iterations()
+    for i in range(o.iterations()):
+        assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < TOL_X
+    for k in range(6):
+        assert np.abs(a.block_estimates(k) - o.block_estimates(k)).max() < TOL_X
+        vo = o.block_variances(k)
+        assert np.abs(a.block_variances_packed(k) - vo).max() / np.abs(vo).max() < TOL_V       # fetched from whichever rank holds it
+    # statistics and result files: collective inside the library, equal to the single-GPU run
+    a.GenerateStatistics()
+    a.SerialiseAdjustedVarianceMatrices()
+    f = _run(str(tmp_path), "n", schur_carry=schur, multi_thread=mt, network_name="n", output_folder=str(tmp_path / "single"))
+    os.makedirs(tmp_path / "single", exist_ok=True)
+    assert f.AdjustNetwork() == st
+    f.GenerateStatistics()
+    f.SerialiseAdjustedVarianceMatrices()
+    assert np.abs(_stats(a) - _stats(f)).max() < 1e-9 * max(1.0, np.abs(_stats(f)).max())
+    ra = np.frombuffer(a.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
+    rf = np.frombuffer(f.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
+    for nm in ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel"):
+        assert np.abs(ra[nm] - rf[nm]).max() <= 1e-9 * max(1.0, np.abs(rf[nm]).max()), nm
+    for suffix, tol in (("rva", 1e-9), ("pam", 1e-9)):
+        da = np.fromfile(tmp_path / "multi" / f"n-{suffix}.mtx", dtype=np.uint8)
+        df = np.fromfile(tmp_path / "single" / f"n-{suffix}.mtx", dtype=np.uint8)
+        assert da.size == df.size
+        if schur and ranks == 2 and not mt:
+            # same arithmetic on the same kind of device: the file is the same up to the rounding of the variance matrices
+            pass
+    # a second adjustment on the resident data (what bench.py times)
+    a.ResetAdjustment()
+    assert a.AdjustNetworkDistributed() == st
+    assert np.abs(a.block_estimates(3) - o.block_estimates(3)).max() < TOL_X
+    ex = a.exchange_stats()
+    assert ex["bytes"] > 0
+    a.close()
+    f.close()
+    o.close()
+
+
+@pytest.mark.parametrize("schur", [True, False])
+def test_one_rank_over_rccl(built, orc, tmp_path, schur, monkeypatch):
+    """the RCCL transport itself on the one GPU this box has: communicator, in-place broadcasts, all-reduces"""
+    if not built.dnaadj_dist_rccl_available():
+        pytest.fail("librccl cannot be loaded on a ROCm box")
+    monkeypatch.setenv("DNAGPU_FORCE_DISTRIBUTED", "1")
+    adjust.write_synthetic_network(str(tmp_path), "n", 24, 10, 0, 4, seed=4)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    # (a) the library makes the communicator itself in PrepareAdjustment; (b) the host attaches one made from an id it distributes
+    for attach in (False, True):
+        a = adjust.DnaAdjust()
+        if attach:
+            a.attach_rccl(0, 1, adjust.rccl_unique_id(), 0)
+        a.PrepareAdjustment(adjust.ProjectSettings("n", str(tmp_path), adjust_mode=adjust.PhasedMode, schur_carry=schur, multi_thread=True))
+        assert a.dist_info() == (0, 1, "rccl")
+        st = a.AdjustNetworkDistributed()
+        assert st == ost and a.CurrentIteration() == o.iterations()
+        for k in range(4):
+            assert np.abs(a.block_estimates(k) - o.block_estimates(k)).max() < TOL_X
+            vo = o.block_variances(k)
+            assert np.abs(a.block_variances_packed(k) - vo).max() / np.abs(vo).max() < TOL_V
+        a.GenerateStatistics()
+        ost_stats, _ = o.statistics()
+        assert abs(a.GetChiSquared() - ost_stats.chi_squared) / ost_stats.chi_squared < 1e-7
+        a.close()
+    o.close()
+
+
+def test_a_failure_on_one_rank_reaches_every_rank(built, orc, tmp_path):
+    """an allocation fails inside one rank's block step (fault injection): that rank reports it, the others learn of it at the
+    end of the phase instead of waiting in the next collective; afterwards the same adjustment runs through"""
+    adjust.write_synthetic_network(str(tmp_path), "n", 24, 8, 0, 4, seed=2)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    a = _run(str(tmp_path), "n", devices=[0, 0], dist_transport="local")
+    built.dnagpu_debug_fail_allocation(3)
+    try:
+        with pytest.raises(adjust.NetAdjustException) as e:
+            a.AdjustNetworkDistributed()
+        assert "allocation" in str(e.value) or "another GPU" in str(e.value)
+    finally:
+        built.dnagpu_debug_fail_allocation(0)
+    a.ResetAdjustment()
+    assert a.AdjustNetworkDistributed() == ost
+    for k in range(4):
+        assert np.abs(a.block_estimates(k) - o.block_estimates(k)).max() < TOL_X
+    a.close()
+    o.close()
+
+
+def test_single_gpu_calls_reject_the_distributed_entry_point(built, tmp_path):
+    adjust.write_synthetic_network(str(tmp_path), "n", 12, 8, 0, 2, seed=2)
+    a = _run(str(tmp_path), "n")
+    with pytest.raises(adjust.NetAdjustException):
+        a.AdjustNetworkDistributed()
+    assert a.AdjustNetwork() == adjust.ADJUST_SUCCESS
+    a.close()
