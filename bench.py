@@ -67,7 +67,7 @@ def cpu_baseline(workload, iterations, solves_per_step, sum_n3_per_step, station
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload,
            "--cpu-args", json.dumps([iterations, solves_per_step, sum_n3_per_step, stations])]
     try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode == 0 and line:
             return json.loads(line[-1])
@@ -77,77 +77,144 @@ def cpu_baseline(workload, iterations, solves_per_step, sum_n3_per_step, station
 
 
 def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step, stations):
-    """The CPU restatement (oracle/, LAPACK = MKL runtime when present) timed on this host's cores on a bounded
-    sample: one forward + reverse sweep over a 2-block strip of the workload's grid, sized for ~20 s of CPU work;
-    extrapolated to the workload linearly in sum(n^3) of its Solve() calls.  The LAPACK thread count is
-    auto-tuned first (a container's visible core count often exceeds its CPU quota)."""
+    """The CPU restatement (oracle/) timed on this host's cores in the reference's own parallel schedule.
+
+    1. LAPACK: the MKL runtime (what the reference links) and the OpenBLAS inside the scipy wheel are probed with dpotrf + dpotri at
+       n = 8 192 over thread counts up to every visible core; the faster library and its best thread count are used.
+    2. Sample: a strip of the workload's grid at the workload's REAL block size (cfg3: 3 blocks of n ~ 20 000; cfg2: the whole
+       n = 30 000 block) -- bounded by the block count, not by shrinking n.
+    3. Schedule (phased): the reference's --multi-thread mode (dnaadjust-multi.cpp:92-244): forward pass on one thread, reverse +
+       combination pass on a second, each calling LAPACK with half of the tuned threads (MKL_Set_Num_Threads_Local); timed as
+       two adjustments of the same strip side by side, the second already past its forward pass.  Without per-thread control
+       (OpenBLAS) or when it is slower, the sequential schedule on all tuned threads.
+    Extrapolated to the workload linearly in sum n^3 of its Solve() calls."""
+    import threading
     import numpy as np
     from dynadjust_amd import adjust
     from tests import oracle
     rows, cols, nbl, blocks, phased, _ = WORKLOADS[workload]
-    have_mkl = oracle.use_mkl(True)
     lib = oracle.load()
     cores = os.cpu_count() or 1
-    threads, rate = 1, None
-    if have_mkl:
-        n = 3000
-        rng = np.random.default_rng(0)
-        A = rng.standard_normal((n, 64))
-        M0 = np.asfortranarray(A @ A.T + np.eye(n) * n)
-        best = None
-        cand = sorted({c for c in (cores, cores // 2, cores // 4, 64, 32, 16, 8) if 1 <= c <= cores}, reverse=True)
+    probe_n = 8192
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((probe_n, 64))
+    M0 = np.asfortranarray(A @ A.T + np.eye(probe_n) * probe_n)
+    del A
+
+    def probe(t):
+        lib.orc_set_threads(t)
+        M = M0.copy(order="F")
+        t0 = time.perf_counter()
+        lib.orc_potrf_lower(probe_n, M.ctypes.data_as(oracle.f64p), probe_n)
+        lib.orc_potri_lower(probe_n, M.ctypes.data_as(oracle.f64p), probe_n)
+        return time.perf_counter() - t0
+
+    cand = sorted({c for c in (cores, cores // 2, cores // 4, 96, 64, 48, 32, 16, 8) if 1 <= c <= cores}, reverse=True)
+    libs = [("MKL runtime (libmkl_rt)", oracle.MKL), ("OpenBLAS (scipy wheel)", oracle.scipy_openblas_path())]
+    only = os.environ.get("DNAGPU_CPU_LAPACK")            # diagnostic: "mkl" / "openblas" pins the library
+    if only:
+        libs = [l for l in libs if only.lower() in l[0].lower()]
+    probes, best = {}, None
+    for name, path in libs:
+        if not path or not oracle.use_lapack(path):
+            continue
+        probe(cand[-1])                                  # (first call: thread pool start-up)
         for t in cand:
-            lib.orc_set_threads(t)
-            M = M0.copy(order="F")
-            t0 = time.perf_counter()
-            lib.orc_potrf_lower(n, M.ctypes.data_as(oracle.f64p), n)
-            lib.orc_potri_lower(n, M.ctypes.data_as(oracle.f64p), n)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[1]:
-                best = (t, dt)
-        threads, rate = best[0], n ** 3 / best[1]
+            dt = probe(t)
+            probes[f"{name} x{t}"] = round(probe_n ** 3 / dt / 1e12, 3)
+            if best is None or dt < best[2]:
+                best = (name, path, dt, t)
+    del M0
+    if best is None:
+        oracle.use_lapack(None)
+        name, path, threads, probe_rate = "built-in scalar Cholesky", None, 1, None
+    else:
+        name, path, _, threads = best
+        probe_rate = probe_n ** 3 / best[2]
+        oracle.use_lapack(path)
         lib.orc_set_threads(threads)
     d = tempfile.mkdtemp(prefix="dnagpu_cpu_")
     if phased:
-        rows_s, nb_s = max(4, 2 * rows // blocks), 2
+        nb_s = 3 if path else 2
+        rows_s = max(4, (rows // blocks) * nb_s)
+        cols_s = cols if path else min(cols, 40)
     else:
-        rows_s, nb_s = rows, 1
-    cols_s = cols
-    if have_mkl:
-        # 4 Solve() calls of n ~ 3*(rows_s/2 + 1)*cols_s unknowns; keep the sample near 20 s at the tuned rate
-        budget = 20.0 * rate
-        n_blk = 3 * (rows_s // nb_s + 1) * cols_s
-        solves_s = 4 if phased else 1
-        if solves_s * n_blk ** 3 > budget:
-            n_target = (budget / solves_s) ** (1.0 / 3.0)
-            cols_s = max(8, int(cols_s * n_target / n_blk))
-    else:
-        # without a threaded LAPACK the built-in scalar Cholesky sets the pace
-        rows_s, cols_s = max(4, min(rows_s, 12)), min(cols, 60)
+        nb_s, rows_s, cols_s = 1, rows, cols
+        if not path:
+            rows_s, cols_s = min(rows, 24), min(cols, 24)
     info = adjust.write_synthetic_network(d, "cpu", rows_s, cols_s, 0, nb_s)
-    net = oracle.Network(os.path.join(d, "cpu"), phased)
-    o = oracle.Adjustment(net, phased, threads=threads if have_mkl else 0)
-    o.prepare()
+
+    def new_adjustment():
+        net = oracle.Network(os.path.join(d, "cpu"), phased)
+        o = oracle.Adjustment(net, phased, threads=threads if path else 0)
+        o.prepare()
+        return o
+
+    schedule, dt, n3, solves, note, mt_rate = "sequential", None, 0.0, 0, "", None
+    if phased and path and threads >= 2 and lib.orc_set_threads_local(0) == 0:
+        # the reference's multi-thread schedule: forward || reverse + combination
+        f, r = new_adjustment(), new_adjustment()
+        if lib.orc_adjust_forward_pass(r.h):               # (untimed: r must stand where a reverse pass starts)
+            raise RuntimeError(lib.orc_adjust_error(r.h).decode())
+        s0, n0 = r.solve_stats()
+        half = max(1, threads // 2)
+        errs = []
+
+        def run(fn, h):
+            lib.orc_set_threads_local(half)
+            if fn(h):
+                errs.append(lib.orc_adjust_error(h).decode())
+
+        tf = threading.Thread(target=run, args=(lib.orc_adjust_forward_pass, f.h))
+        tr = threading.Thread(target=run, args=(lib.orc_adjust_reverse_pass, r.h))
+        t0 = time.perf_counter()
+        tf.start(); tr.start(); tf.join(); tr.join()
+        dt_mt = time.perf_counter() - t0
+        if errs:
+            raise RuntimeError(errs[0])
+        sf, nf = f.solve_stats()
+        sr, nr = r.solve_stats()
+        solves_mt, n3_mt = sf + (sr - s0), nf + (nr - n0)
+        f.close(); r.close()
+        schedule, dt, n3, solves = "multi-thread", dt_mt, n3_mt, solves_mt
+        mt_rate = n3_mt / dt_mt
+        note = f"forward || reverse+combination on two threads x {half} LAPACK threads"
+    # the sequential schedule on all tuned threads (the only one without per-thread LAPACK control)
+    o = new_adjustment()
+    lib.orc_set_threads(threads) if path else None
     t0 = time.perf_counter()
     o.iteration()
-    dt = time.perf_counter() - t0
-    solves, n3 = o.solve_stats()
+    dt_seq = time.perf_counter() - t0
+    s_seq, n3_seq = o.solve_stats()
     o.close()
-    oracle.use_mkl(False)
+    seq_rate = n3_seq / dt_seq
+    if dt is None or n3 / dt < seq_rate:
+        note = (f"multi-thread schedule measured slower ({n3 / dt / 1e12:.3f} TFLOP/s) than " if dt else "") + f"sequential passes on {threads} LAPACK threads"
+        if dt:
+            note += ")"
+        schedule, dt, n3, solves = "sequential", dt_seq, n3_seq, s_seq
+    oracle.use_lapack(None)
     cpu_flops = n3 / dt
     projected = sum_n3_per_step / cpu_flops
+    n_blk = int(round((n3_seq / max(1, s_seq)) ** (1.0 / 3.0)))
     return {
         "value": stations / projected,
         "unit": "stations/s",
         "cores": threads,
         "cores_visible": cores,
         "kind": "port",
-        "lapack": f"MKL runtime (libmkl_rt, {threads} threads, tuned)" if have_mkl else "built-in scalar Cholesky",
-        "sample": (f"one forward+reverse sweep of the CPU restatement over a {nb_s}-block, {info['stations']}-station strip of the workload's grid "
-                   f"({solves} Solve() calls, sum n^3 = {n3:.3e}) in {dt:.2f} s = {cpu_flops / 1e12:.3f} TFLOP/s reference-equivalent; "
-                   f"extrapolated linearly in sum n^3 to the workload's {solves_per_step} Solve() calls per step"),
+        "schedule": schedule,
+        "lapack": f"{name}, {threads} threads (best of the dpotrf+dpotri probe at n = {probe_n})",
+        "lapack_probe_tflops": probes,
+        "probe_tflops_at_choice": None if probe_rate is None else probe_rate / 1e12,
+        "sample": (f"one iteration of the CPU restatement over a {nb_s}-block, {info['stations']}-station strip of the workload's grid at the workload's "
+                   f"block size (n ~ {n_blk} per Solve(), {solves} Solve() calls, sum n^3 = {n3:.3e}) in {dt:.2f} s = {cpu_flops / 1e12:.3f} TFLOP/s "
+                   f"reference-equivalent, schedule: {schedule} ({note}); sequential: {seq_rate / 1e12:.3f} TFLOP/s; extrapolated linearly in sum n^3 "
+                   f"to the workload's {solves_per_step} Solve() calls per step"),
         "seconds_sample": dt,
         "tflops_reference_equivalent": cpu_flops / 1e12,
+        "tflops_sequential_schedule": seq_rate / 1e12,
+        "tflops_multi_thread_schedule": None if mt_rate is None else mt_rate / 1e12,
     }
 
 

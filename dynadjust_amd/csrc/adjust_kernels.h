@@ -28,6 +28,8 @@ void launch_msr_stats(const double* wblk, const uint32_t* vec_wrow, const uint32
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s);
 void launch_junction_gather(const double* S, uint32_t nps, const uint32_t* idx, uint32_t k, double* J, uint32_t npj, hipStream_t s);
 void launch_gather_vec3(const double* x, const uint32_t* idx, uint32_t k, double* out, hipStream_t s);
+void launch_scatter_add_vec3(double* y, const uint32_t* idx, uint32_t k, const double* v, hipStream_t s);
+void launch_copy_vec3_indexed(double* y, const uint32_t* dst, const double* x, const uint32_t* src, uint32_t k, hipStream_t s);
 void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, hipStream_t s);
 void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, const double* jest,
                          hipStream_t s);

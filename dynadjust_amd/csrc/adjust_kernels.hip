@@ -355,6 +355,20 @@ __global__ void gather_vec3_kernel(const double* __restrict__ x, const uint32_t*
     out[t] = x[3 * idx[t / 3] + t % 3];
 }
 
+// y[3 idx[a] + e] += v[3 a + e]
+__global__ void scatter_add_vec3_kernel(double* __restrict__ y, const uint32_t* __restrict__ idx, uint32_t k, const double* __restrict__ v) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * k) return;
+    y[3 * idx[t / 3] + t % 3] += v[t];
+}
+// y[3 dst[a] + e] = x[3 src[a] + e]
+__global__ void copy_vec3_indexed_kernel(double* __restrict__ y, const uint32_t* __restrict__ dst, const double* __restrict__ x,
+                                         const uint32_t* __restrict__ src, uint32_t k) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * k) return;
+    y[3 * dst[t / 3] + t % 3] = x[3 * src[t / 3] + t % 3];
+}
+
 // D(3 idx[a]+ei, 3 idx[b]+ej) += J(3a+ei, 3b+ej) on the lower triangle of D
 __global__ void junction_scatter_kernel(double* __restrict__ D, uint32_t npd, const uint32_t* __restrict__ idx, uint32_t k,
                                         const double* __restrict__ J, uint32_t npj) {
@@ -603,6 +617,14 @@ void launch_junction_gather(const double* S, uint32_t nps, const uint32_t* idx, 
 void launch_gather_vec3(const double* x, const uint32_t* idx, uint32_t k, double* out, hipStream_t s) {
     if (!k) return;
     hipLaunchKernelGGL(gather_vec3_kernel, dim3((3 * k + 255) / 256), dim3(256), 0, s, x, idx, k, out);
+}
+void launch_scatter_add_vec3(double* y, const uint32_t* idx, uint32_t k, const double* v, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(scatter_add_vec3_kernel, dim3((3 * k + 255) / 256), dim3(256), 0, s, y, idx, k, v);
+}
+void launch_copy_vec3_indexed(double* y, const uint32_t* dst, const double* x, const uint32_t* src, uint32_t k, hipStream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(copy_vec3_indexed_kernel, dim3((3 * k + 255) / 256), dim3(256), 0, s, y, dst, x, src, k);
 }
 void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, hipStream_t s) {
     if (!k) return;

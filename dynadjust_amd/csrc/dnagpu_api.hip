@@ -1623,6 +1623,41 @@ int dnagpu_junction_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk_to, const uint3
     return DNAGPU_OK;
 }
 
+int dnagpu_block_add_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* idx, size_t k, const dnagpu_matrix* jm, int zero_first) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !jm || (k && !idx) || jm->n != 3 * k) return fail(ctx, DNAGPU_EINVAL, "block_add_rhs: bad arguments");
+    for (size_t i = 0; i < k; ++i)
+        if (idx[i] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "block_add_rhs: station out of range");
+    if (zero_first) HIPCHK(hipMemsetAsync(b->rhs[chain], 0, (size_t)3 * b->n_stn * sizeof(double), ctx->stream[chain]));
+    if (!k) return DNAGPU_OK;
+    uint32_t* didx = nullptr;
+    int rc = stage_u32(ctx, chain, idx, k, &didx);
+    if (rc) return rc;
+    launch_scatter_add_vec3(b->rhs[chain], didx, (uint32_t)k, jm->jest, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_gather_stations(dnagpu_ctx* ctx, int chain, uint32_t dst_blk, const uint32_t* dst_pos, uint32_t src_blk, const uint32_t* src_idx,
+                                 size_t k) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* d = find_block(ctx, dst_blk);
+    Block* sb = find_block(ctx, src_blk);
+    if (!d || !sb || (k && (!dst_pos || !src_idx))) return fail(ctx, DNAGPU_EINVAL, "block_gather_stations: bad arguments");
+    for (size_t i = 0; i < k; ++i)
+        if (dst_pos[i] >= d->n_stn || src_idx[i] >= sb->n_stn) return fail(ctx, DNAGPU_EINVAL, "block_gather_stations: station out of range");
+    if (!k) return DNAGPU_OK;
+    std::vector<uint32_t> both(dst_pos, dst_pos + k);
+    both.insert(both.end(), src_idx, src_idx + k);
+    uint32_t* didx = nullptr;
+    int rc = stage_u32(ctx, chain, both.data(), 2 * k, &didx);
+    if (rc) return rc;
+    launch_copy_vec3_indexed(d->x_est[chain], didx, sb->x_orig, didx + k, (uint32_t)k, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
 int dnagpu_junction_get_estimates(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* jm, double* est) {
     CHK_CTX();
     CHK_CHAIN();

@@ -34,6 +34,7 @@ dna_adjust::~dna_adjust() {
 
 void dna_adjust::FreeDevice() {
     if (!ctx_) return;
+    FreeTwoLevel();
     if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);
     xbuf_dev_ = nullptr;
     xbuf_cap_ = 0;
@@ -700,6 +701,7 @@ void dna_adjust::PrepareBlocks() {
     DecideStaging();
     PrepareCondensedBlocks();
     if (DistWorld() > 1 && phased && !CondensedSchedule()) ComputeBlockOwners(false);    // the reference's schedule shards differently
+    PrepareTwoLevel();
     Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
 }
 

@@ -229,6 +229,31 @@ private:
         for (const auto& p : peers_) s += f(*p);
         return s;
     }
+    // ---- two-level condensed chains (a.dist_two_level; dna_adjust_dist.cpp) ----
+    struct seg_step_t {                     // one merge of the run's running system with the next condensed block
+        UINT32 dev_block = 0, n_stn = 0;    // station-less device block of the assembled system
+        std::vector<UINT32> pos_prev, pos_blk, keep;
+        constraint_list con;                // constraints of stations that leave the system inside the run
+    };
+    struct segment_t {                      // the run of blocks of one rank, condensed to the stations of its two ends
+        UINT32 a = 0, b = 0;
+        std::vector<UINT32> stations;       // global station ids, ascending
+        std::vector<UINT32> posL, posR;     // the junction stations towards the previous / next run (junction list order)
+        std::vector<UINT32> dstA, srcA, dstB, srcB;   // where the stations' coordinates come from: block a / block b
+        constraint_list con_fwd, con_rev;   // direction dependent constraints of the end stations
+        dnagpu_matrix* S = nullptr;
+        UINT32 dev_block = 0;
+        std::vector<seg_step_t> steps;      // (own run only)
+        dnagpu_matrix* M[2] = {nullptr, nullptr};
+    };
+    std::vector<segment_t> segs_;
+    bool two_level_ok_ = false;
+    void PrepareTwoLevel();
+    void FreeTwoLevel();
+    void ReduceOwnRun();                       // level 1
+    void ExchangeRuns();
+    void ScanRuns();                           // level 2
+    void OwnRunChains();                       // level 3
     std::shared_ptr<DistComm> comm_;
     bool force_distributed_ = false;           // DNAGPU_FORCE_DISTRIBUTED=1: the exchange steps also run with a single rank
     bool in_collective_ = false;               // this instance is being driven as one rank by OnEveryDevice

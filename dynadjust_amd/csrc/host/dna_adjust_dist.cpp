@@ -183,12 +183,274 @@ void dna_adjust::SyncCoordinates() {
     exchange_ms_ += wall_ms() - t0;
 }
 
+// ---- two-level condensed chains ------------------------------------------------------------------------------------------------
+// With every rank running both chains on all condensed blocks, the chain phase is 2 (B - 1) sequential steps everywhere and every
+// condensed block travels to every rank (cfg4: 128 blocks x 288 MB per iteration).  Ranks own contiguous runs of blocks, so:
+//   level 1  every rank condenses its own run once more, to the junction stations of the run's two ends: the run's condensed blocks
+//            are merged one after the other and the stations no longer needed are eliminated (dnagpu_block_reduce)
+//   exchange one such system per rank (not per block) is broadcast
+//   level 2  every rank runs the forward and the reverse chain over the W run systems: W - 1 steps each way; they leave the junction
+//            weights / estimates at every run boundary -- exactly what the block-level chains carry across it
+//   level 3  every rank runs both chains over its own blocks only, from the boundary values of level 2
+// Depth B / W + W + B / W instead of B; the same additions in the same order inside every run, so the results agree with the
+// one-level chains to rounding.
+void dna_adjust::FreeTwoLevel() {
+    for (segment_t& g : segs_) {
+        if (g.S) dnagpu_matrix_destroy(ctx_, g.S);
+        for (dnagpu_matrix*& m : g.M)
+            if (m) dnagpu_matrix_destroy(ctx_, m);
+    }
+    segs_.clear();
+    two_level_ok_ = false;
+}
+
+void dna_adjust::PrepareTwoLevel() {
+    FreeTwoLevel();
+    const int W = DistWorld(), me = DistRank();
+    if (W < 2 || !projectSettings_.a.dist_two_level || !CondensedSchedule() || ReuseRequested()) return;
+    // one contiguous network, every rank a run of at least one block
+    if (!v_blockMeta_[0]._blockFirst || !v_blockMeta_[blockCount_ - 1]._blockLast) return;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        const blockMeta_t& m = v_blockMeta_[k];
+        if (m._blockIsolated || (m._blockFirst && k != 0) || (m._blockLast && k != blockCount_ - 1)) return;
+        if (blocks_[k].keep.empty() || !blocks_[k].red) return;
+    }
+    std::vector<int> first(W, -1), last(W, -1);
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        const int r = BlockOwner(k);
+        if (first[r] < 0) first[r] = (int)k;
+        if (last[r] >= 0 && last[r] != (int)k - 1) return;       // runs must be contiguous
+        last[r] = (int)k;
+    }
+    for (int r = 0; r < W; ++r)
+        if (first[r] < 0) return;
+    auto gid = [&](UINT32 k, UINT32 keep_pos) { return v_parameterStationList_[k][blocks_[k].keep[keep_pos]]; };
+    auto position = [](const std::vector<UINT32>& sorted, UINT32 g) {
+        auto it = std::lower_bound(sorted.begin(), sorted.end(), g);
+        return (it != sorted.end() && *it == g) ? (long)(it - sorted.begin()) : -1L;
+    };
+    segs_.assign(W, segment_t());
+    for (int r = 0; r < W; ++r) {
+        segment_t& g = segs_[r];
+        g.a = (UINT32)first[r];
+        g.b = (UINT32)last[r];
+        const block_t& A = blocks_[g.a];
+        const block_t& Bk = blocks_[g.b];
+        std::vector<UINT32> L, R;
+        for (UINT32 p : A.c_prev) L.push_back(gid(g.a, p));
+        if (g.b + 1 < blockCount_)
+            for (UINT32 p : Bk.c_next) R.push_back(gid(g.b, p));
+        if ((r > 0 && L.empty()) || (r + 1 < W && R.empty())) {
+            segs_.clear();
+            return;
+        }
+        g.stations = L;
+        g.stations.insert(g.stations.end(), R.begin(), R.end());
+        std::sort(g.stations.begin(), g.stations.end());
+        g.stations.erase(std::unique(g.stations.begin(), g.stations.end()), g.stations.end());
+        for (UINT32 s : L) g.posL.push_back((UINT32)position(g.stations, s));
+        for (UINT32 s : R) g.posR.push_back((UINT32)position(g.stations, s));
+        std::set<UINT32> inL(L.begin(), L.end());
+        for (UINT32 q = 0; q < g.stations.size(); ++q) {
+            const UINT32 s = g.stations[q];
+            if (inL.count(s)) {
+                g.dstA.push_back(q);
+                g.srcA.push_back(LocalIndex(g.a, s));
+            } else {
+                g.dstB.push_back(q);
+                g.srcB.push_back(LocalIndex(g.b, s));
+            }
+        }
+        for (UINT32 k = g.a; k <= g.b; ++k) {
+            auto pick = [&](const constraint_list& src, constraint_list& dst) {
+                for (size_t i = 0; i < src.stn.size(); ++i) {
+                    const long q = position(g.stations, gid(k, src.stn[i]));
+                    if (q < 0) continue;
+                    dst.stn.push_back((UINT32)q);
+                    dst.w9.insert(dst.w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
+                }
+            };
+            pick(blocks_[k].ccon_fwd, g.con_fwd);
+            pick(blocks_[k].ccon_rev, g.con_rev);
+        }
+        g.dev_block = 3 * blockCount_ + (UINT32)r;
+        Check(dnagpu_block_create(ctx_, g.dev_block, (UINT32)g.stations.size(), 0), g.a, "PrepareAdjustment(): run system");
+        Check(dnagpu_matrix_create(ctx_, (UINT32)g.stations.size() * 3, &g.S), g.a, "PrepareAdjustment(): run system");
+    }
+    // the merges of the own run
+    segment_t& g = segs_[me];
+    std::vector<UINT32> prev;
+    for (UINT32 p = 0; p < blocks_[g.a].keep.size(); ++p) prev.push_back(gid(g.a, p));
+    size_t max_keep = 0;
+    for (UINT32 k = g.a + 1; k <= g.b; ++k) {
+        seg_step_t st;
+        std::vector<UINT32> blk;
+        for (UINT32 p = 0; p < blocks_[k].keep.size(); ++p) blk.push_back(gid(k, p));
+        std::vector<UINT32> U = prev;
+        U.insert(U.end(), blk.begin(), blk.end());
+        std::sort(U.begin(), U.end());
+        U.erase(std::unique(U.begin(), U.end()), U.end());
+        for (UINT32 s : prev) st.pos_prev.push_back((UINT32)position(U, s));
+        for (UINT32 s : blk) st.pos_blk.push_back((UINT32)position(U, s));
+        // stations that stay: the run's first junction row and block k's junction row towards k + 1
+        std::vector<UINT32> stay;
+        for (UINT32 p : blocks_[g.a].c_prev) stay.push_back(gid(g.a, p));
+        if (k + 1 < blockCount_)
+            for (UINT32 p : blocks_[k].c_next) stay.push_back(gid(k, p));
+        std::sort(stay.begin(), stay.end());
+        stay.erase(std::unique(stay.begin(), stay.end()), stay.end());
+        for (UINT32 s : stay) st.keep.push_back((UINT32)position(U, s));
+        // constraints of the stations that leave inside the run: where the forward chain adds them (first appearance)
+        for (UINT32 kk : (k == g.a + 1 ? std::vector<UINT32>{g.a, k} : std::vector<UINT32>{k})) {
+            const constraint_list& src = blocks_[kk].ccon_fwd;
+            for (size_t i = 0; i < src.stn.size(); ++i) {
+                const UINT32 s = gid(kk, src.stn[i]);
+                if (position(g.stations, s) >= 0) continue;
+                st.con.stn.push_back((UINT32)position(U, s));
+                st.con.w9.insert(st.con.w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
+            }
+        }
+        st.n_stn = (UINT32)U.size();
+        st.dev_block = 2 * blockCount_ + k;
+        Check(dnagpu_block_create(ctx_, st.dev_block, st.n_stn, 0), k, "PrepareAdjustment(): run merge");
+        max_keep = std::max(max_keep, stay.size());
+        prev = stay;
+        g.steps.push_back(std::move(st));
+    }
+    if (g.a != g.b && prev != g.stations) {       // (the last merge must leave exactly the run's end stations)
+        FreeTwoLevel();
+        return;
+    }
+    if (g.steps.size() > 1)
+        for (dnagpu_matrix*& m : g.M) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &m), g.a, "PrepareAdjustment(): run merge");
+    two_level_ok_ = true;
+}
+
+// level 1: the own run condensed to its end stations
+void dna_adjust::ReduceOwnRun() {
+    segment_t& g = segs_[DistRank()];
+    const int c = 0;
+    if (g.a == g.b) {
+        Check(dnagpu_matrix_copy(ctx_, c, g.S, blocks_[g.a].red), g.a, "Solve()");
+        Check(dnagpu_chain_sync(ctx_, c), g.a, "Solve()");
+        return;
+    }
+    const dnagpu_matrix* prev = blocks_[g.a].red;
+    for (size_t i = 0; i < g.steps.size(); ++i) {
+        const seg_step_t& st = g.steps[i];
+        const UINT32 k = g.a + 1 + (UINT32)i;
+        currentBlock_ = k;
+        dnagpu_matrix* Wm = work_[c];
+        Check(dnagpu_matrix_reset(ctx_, c, Wm, 3 * st.n_stn), k, "UpdateNormals()");
+        Check(dnagpu_junction_scatter(ctx_, c, Wm, st.pos_prev.data(), st.pos_prev.size(), prev), k, "UpdateNormals()");
+        Check(dnagpu_junction_scatter(ctx_, c, Wm, st.pos_blk.data(), st.pos_blk.size(), blocks_[k].red), k, "UpdateNormals()");
+        Check(dnagpu_block_add_rhs(ctx_, c, st.dev_block, st.pos_prev.data(), st.pos_prev.size(), prev, 1), k, "Solve()");
+        Check(dnagpu_block_add_rhs(ctx_, c, st.dev_block, st.pos_blk.data(), st.pos_blk.size(), blocks_[k].red, 0), k, "Solve()");
+        AddConstraints(c, Wm, st.con, +1, k);
+        dnagpu_matrix* out = (i + 1 == g.steps.size()) ? g.S : g.M[i & 1];
+        Check(dnagpu_block_reduce(ctx_, c, st.dev_block, Wm, st.keep.data(), st.keep.size(), out, nullptr), k, "Solve()");
+        prev = out;
+        const double nk = 3.0 * (double)st.keep.size(), ni = 3.0 * (double)st.n_stn - nk;
+        std::lock_guard<std::mutex> lk(corr_mutex_);
+        algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    }
+}
+
+void dna_adjust::ExchangeRuns() {
+    const double t0 = wall_ms();
+    comm_->group_begin();
+    for (int r = 0; r < DistWorld(); ++r) {
+        segment_t& g = segs_[r];
+        Check(dnagpu_matrix_resize(ctx_, g.S, (UINT32)g.stations.size() * 3), g.a, "exchange");
+        double *F = nullptr, *v = nullptr;
+        UINT32 np = 0;
+        dnagpu_matrix_device_pointers(g.S, &F, &v, &np);
+        comm_->broadcast(F, (size_t)np * np, r);
+        comm_->broadcast(v, np, r);
+    }
+    comm_->group_end();
+    comm_->wait();
+    exchange_ms_ += wall_ms() - t0;
+}
+
+// level 2: the two chains over the runs (every rank, identical arithmetic): jfwd at the last block of every run but the last,
+// jrev at the block before every run but the first
+void dna_adjust::ScanRuns() {
+    const int W = DistWorld();
+    const bool two = NumChains() > 1;
+    auto load = [&](int c, segment_t& g) {
+        dnagpu_matrix* Wm = work_[c];
+        Check(dnagpu_block_gather_stations(ctx_, c, g.dev_block, g.dstA.data(), g.a, g.srcA.data(), g.dstA.size()), g.a, "UpdateNormals()");
+        Check(dnagpu_block_gather_stations(ctx_, c, g.dev_block, g.dstB.data(), g.b, g.srcB.data(), g.dstB.size()), g.b, "UpdateNormals()");
+        Check(dnagpu_matrix_copy(ctx_, c, Wm, g.S), g.a, "UpdateNormals()");
+        std::vector<UINT32> all(g.stations.size());
+        std::iota(all.begin(), all.end(), 0u);
+        Check(dnagpu_block_add_rhs(ctx_, c, g.dev_block, all.data(), all.size(), g.S, 1), g.a, "Solve()");
+        return Wm;
+    };
+    auto carry = [&](int c, segment_t& g, dnagpu_matrix* Wm, const std::vector<UINT32>& out, dnagpu_matrix* jm, UINT32 k) {
+        Check(dnagpu_schur_carry(ctx_, c, g.dev_block, Wm, out.data(), out.size(), jm), k, "Solve()");
+        const double n = 3.0 * (double)g.stations.size(), nj = 3.0 * (double)out.size(), ni = n - nj;
+        std::lock_guard<std::mutex> lk(corr_mutex_);
+        algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + nj * nj * nj;
+    };
+    OnEveryChain([&](int c) {
+        if (c == 0)
+            for (int r = 0; r + 1 < W && !IsCancelled() && !chain_failed_; ++r) {
+                segment_t& g = segs_[r];
+                dnagpu_matrix* Wm = load(c, g);
+                AddConstraints(c, Wm, g.con_fwd, +1, g.a);
+                if (r > 0) {
+                    Check(dnagpu_junction_scatter(ctx_, c, Wm, g.posL.data(), g.posL.size(), blocks_[g.a - 1].jfwd), g.a, "CarryStnEstimatesandVariancesForward()");
+                    Check(dnagpu_junction_rhs(ctx_, c, g.dev_block, g.posL.data(), g.posL.size(), blocks_[g.a - 1].jfwd), g.a, "Solve()");
+                }
+                carry(c, g, Wm, g.posR, blocks_[g.b].jfwd, g.b);
+            }
+        if (c == 1 || !two)
+            for (int r = W - 1; r >= 1 && !IsCancelled() && !chain_failed_; --r) {
+                segment_t& g = segs_[r];
+                dnagpu_matrix* Wm = load(c, g);
+                if (r + 1 < W) Check(dnagpu_junction_scatter(ctx_, c, Wm, g.posR.data(), g.posR.size(), blocks_[g.b].jrev), g.b, "CarryStnEstimatesandVariancesReverse()");
+                AddConstraints(c, Wm, g.con_rev, +1, g.b);
+                if (r + 1 < W) Check(dnagpu_junction_rhs(ctx_, c, g.dev_block, g.posR.data(), g.posR.size(), blocks_[g.b].jrev), g.b, "Solve()");
+                carry(c, g, Wm, g.posL, blocks_[g.a - 1].jrev, g.a);
+            }
+    });
+}
+
+// level 3: both chains over the own blocks, from the boundary values of level 2
+void dna_adjust::OwnRunChains() {
+    const segment_t& g = segs_[DistRank()];
+    const bool two = NumChains() > 1;
+    OnEveryChain([&](int c) {
+        if (c == 0)
+            for (UINT32 k = g.a; k < g.b && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
+        if (c == 1 || !two)
+            for (UINT32 k = g.b; k > g.a && !IsCancelled() && !chain_failed_; --k) CondensedReverseBlock(c, k);
+    });
+}
+
 void dna_adjust::DistributedCondensedIteration() {
     std::vector<UINT32> mine;
     for (UINT32 k = 0; k < blockCount_; ++k)
         if (OwnsBlock(k)) mine.push_back(k);
     AgreeOnPhase("condensing the blocks", [&] { CondenseBlocks(mine); });
     if (IsCancelled()) return;
+    if (two_level_ok_) {
+        double t0 = wall_ms();
+        AgreeOnPhase("junction chains (own run)", [&] { ReduceOwnRun(); });
+        chain_ms_ += wall_ms() - t0;
+        ExchangeRuns();
+        t0 = wall_ms();
+        AgreeOnPhase("junction chains", [&] {
+            ScanRuns();
+            OwnRunChains();
+        });
+        chain_ms_ += wall_ms() - t0;
+        if (IsCancelled()) return;
+        AgreeOnPhase("rigorous block solutions", [&] { RigorousBlocks(mine); });
+        return;
+    }
     ExchangeCondensed();
     const double t0 = wall_ms();
     AgreeOnPhase("junction chains", [&] { CondensedChains(); });

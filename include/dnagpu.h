@@ -269,6 +269,16 @@ int dnagpu_junction_scatter(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, cons
                             const dnagpu_matrix* jm);
 /* rhs(blk_to)[idx] += jm * (jest(jm) - estimated(blk_to)[idx]) */
 int dnagpu_junction_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk_to, const uint32_t* idx_to, size_t k, const dnagpu_matrix* jm);
+/* Condensed systems as normal-equation pairs (matrix, right-hand side), for the two-level chain across GPUs (a run of condensed
+ * blocks reduced to the stations of its two ends):
+ *   dnagpu_block_add_rhs          rhs(blk)[idx] (+)= the vector attached to jm (3k doubles: a reduced right-hand side), optionally
+ *                                 after zeroing the whole right-hand side of blk; with dnagpu_matrix_reset + dnagpu_junction_scatter
+ *                                 this assembles two overlapping condensed systems into one, which dnagpu_block_reduce condenses again
+ *   dnagpu_block_gather_stations  estimated(dst_blk)[dst_pos] <- original(src_blk)[src_idx]: the linearisation point of a
+ *                                 station-less block that stands for such a system (what dnagpu_block_load_reduced does from one source) */
+int dnagpu_block_add_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* idx, size_t k, const dnagpu_matrix* jm, int zero_first);
+int dnagpu_block_gather_stations(dnagpu_ctx* ctx, int chain, uint32_t dst_blk, const uint32_t* dst_pos, uint32_t src_blk, const uint32_t* src_idx,
+                                 size_t k);
 /* read / write the junction estimates attached to a junction matrix (3k doubles) */
 int dnagpu_junction_get_estimates(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* jm, double* est);
 int dnagpu_junction_put_estimates(dnagpu_ctx* ctx, int chain, dnagpu_matrix* jm, const double* est, size_t k);

@@ -40,8 +40,13 @@ int orc_set_lapack(const char* lib) {
     if (!lib || !*lib) return 0;
     void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
     if (!h) return -1;
+    /* MKL / reference LAPACK export dpotrf_; the OpenBLAS that ships inside scipy prefixes its symbols */
     lapack_potrf_t f = (lapack_potrf_t)dlsym(h, "dpotrf_");
     lapack_potrf_t g = (lapack_potrf_t)dlsym(h, "dpotri_");
+    if (!f || !g) {
+        f = (lapack_potrf_t)dlsym(h, "scipy_dpotrf_");
+        g = (lapack_potrf_t)dlsym(h, "scipy_dpotri_");
+    }
     if (!f || !g) {
         dlclose(h);
         return -2;
@@ -58,9 +63,24 @@ const char* orc_lapack_name(void) { return lapack_name; }
 /* thread count of the external LAPACK (MKL_Set_Num_Threads when the MKL runtime is loaded) */
 int orc_set_threads(int n) {
     if (!ext_handle || n <= 0) return -1;
-    void (*setn)(int) = (void (*)(int))dlsym(ext_handle, "MKL_Set_Num_Threads");
-    if (!setn) return -2;
-    setn(n);
+    static const char* names[] = {"MKL_Set_Num_Threads", "scipy_openblas_set_num_threads", "openblas_set_num_threads", "scipy_goto_set_num_threads"};
+    for (unsigned q = 0; q < sizeof(names) / sizeof(names[0]); ++q) {
+        void (*setn)(int) = (void (*)(int))dlsym(ext_handle, names[q]);
+        if (setn) {
+            setn(n);
+            return 0;
+        }
+    }
+    return -2;
+}
+
+/* thread count for LAPACK calls made by the CALLING thread only (MKL_Set_Num_Threads_Local): the reference's --multi-thread
+ * mode runs its forward and its reverse pass on two threads that each call the BLAS (dnaadjust-multi.cpp:92-244) */
+int orc_set_threads_local(int n) {      /* n = 0: back to the global setting */
+    if (!ext_handle || n < 0) return -1;
+    int (*setl)(int) = (int (*)(int))dlsym(ext_handle, "MKL_Set_Num_Threads_Local");
+    if (!setl) return -2;
+    setl(n);
     return 0;
 }
 
@@ -1618,6 +1638,18 @@ static int phased_update_adjustment(orc_adjustment* a) {
         if (add_constraints(a, B, CON_FWD)) return -1;
     }
     return 0;
+}
+
+/* the two passes of an iteration on their own: the CPU baseline runs them side by side on two adjustments (bench.py), the way
+ * the reference's multi-thread mode overlaps its forward pass with its reverse + combination pass */
+int orc_adjust_forward_pass(orc_adjustment* a) {
+    if (!a->phased) return -1;
+    a->maxCorr = 0.0;
+    return phased_forward(a);
+}
+int orc_adjust_reverse_pass(orc_adjustment* a) {
+    if (!a->phased) return -1;
+    return phased_reverse_combine(a);
 }
 
 int orc_adjust_iteration(orc_adjustment* a) {

@@ -38,6 +38,7 @@ size_t orc_packed_index(uint32_t n, uint32_t i, uint32_t j);
 int orc_set_lapack(const char* lib);
 const char* orc_lapack_name(void);
 int orc_set_threads(int n);
+int orc_set_threads_local(int n);
 /* dpotrf('L') / dpotri('L') on a full column-major matrix, lda >= n; return LAPACK info */
 int orc_potrf_lower(uint32_t n, double* a, uint32_t lda);
 int orc_potri_lower(uint32_t n, double* a, uint32_t lda);
@@ -142,6 +143,8 @@ int orc_adjust_prepare(orc_adjustment* a);
 int orc_adjust_run(orc_adjustment* a);
 /* one forward + reverse/combine sweep only (used by the CPU-baseline timer) */
 int orc_adjust_iteration(orc_adjustment* a);
+int orc_adjust_forward_pass(orc_adjustment* a);   /* AdjustPhasedForward only */
+int orc_adjust_reverse_pass(orc_adjustment* a);   /* AdjustPhasedReverseCombine only (after a forward pass) */
 
 uint32_t orc_adjust_iterations(const orc_adjustment* a);
 double orc_adjust_max_correction(const orc_adjustment* a, uint32_t iteration /* 1-based */);

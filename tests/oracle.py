@@ -52,6 +52,9 @@ def load():
         lib.orc_set_lapack.argtypes = [C.c_char_p]
         lib.orc_lapack_name.restype = C.c_char_p
         lib.orc_set_threads.argtypes = [C.c_int]
+        lib.orc_set_threads_local.argtypes = [C.c_int]
+        lib.orc_adjust_forward_pass.argtypes = [C.c_void_p]
+        lib.orc_adjust_reverse_pass.argtypes = [C.c_void_p]
         lib.orc_potrf_lower.argtypes = [C.c_uint32, f64p, C.c_uint32]
         lib.orc_potri_lower.argtypes = [C.c_uint32, f64p, C.c_uint32]
         lib.orc_cholesky_inverse_packed.argtypes = [f64p, C.c_uint32]
@@ -99,6 +102,26 @@ def load():
         lib.orc_adjust_block_prec_adj_msrs.argtypes = [C.c_void_p, C.c_uint32, u32p]
         _lib = lib
     return _lib
+
+
+def scipy_openblas_path():
+    """the OpenBLAS inside the scipy wheel (LP64, symbols prefixed scipy_): a second host LAPACK for the CPU baseline's probe"""
+    import glob
+    try:
+        import scipy
+    except ImportError:
+        return None
+    hits = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas-*.so"))
+    return hits[0] if hits else None
+
+
+def use_lapack(path):
+    lib = load()
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+    if path and os.path.exists(path):
+        return lib.orc_set_lapack(path.encode()) == 0
+    lib.orc_set_lapack(None)
+    return False
 
 
 def use_mkl(enable=True):

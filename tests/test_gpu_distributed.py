@@ -92,6 +92,35 @@ def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt
     o.close()
 
 
+@pytest.mark.parametrize("ranks,blocks,mt", [(2, 6, False), (3, 8, True), (4, 8, True), (4, 4, False), (5, 9, True)])
+def test_two_level_chains(built, orc, tmp_path, ranks, blocks, mt):
+    """a.dist_two_level: every rank condenses its own run of blocks to the run's end stations, the run systems are exchanged
+    (one per rank instead of one per block), the chains run over the runs and then inside every run.  Same results as the
+    one-level chains and the oracle; fewer bytes through the transport."""
+    adjust.write_synthetic_network(str(tmp_path), "n", 5 * blocks, 11, 0, blocks, seed=3 + blocks)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    res = {}
+    for two in (False, True):
+        a = _run(str(tmp_path), "n", devices=[0] * ranks, dist_transport="local", multi_thread=mt, dist_two_level=two)
+        st = a.AdjustNetworkDistributed()
+        assert st == ost and a.CurrentIteration() == o.iterations()
+        for i in range(o.iterations()):
+            assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < TOL_X
+        for k in range(blocks):
+            assert np.abs(a.block_estimates(k) - o.block_estimates(k)).max() < TOL_X, (two, k)
+            vo = o.block_variances(k)
+            assert np.abs(a.block_variances_packed(k) - vo).max() / np.abs(vo).max() < TOL_V, (two, k)
+        a.GenerateStatistics()
+        res[two] = (a.GetChiSquared(), a.exchange_stats()["bytes"], a.algorithmic_flops())
+        a.close()
+    ostat, _ = o.statistics()
+    for two in (False, True):
+        assert abs(res[two][0] - ostat.chi_squared) / ostat.chi_squared < 1e-7
+    if blocks > ranks:
+        assert res[True][1] < res[False][1]          # one system per rank instead of one per block
+    o.close()
+
+
 @pytest.mark.parametrize("schur", [True, False])
 def test_one_rank_over_rccl(built, orc, tmp_path, schur, monkeypatch):
     """the RCCL transport itself on the one GPU this box has: communicator, in-place broadcasts, all-reduces"""
