@@ -286,6 +286,17 @@ class DnaAdjust:
         return self.lib.dnaadj_device_context(self.h)
 
 
+def import_dna_text(stn_file, msr_file, out_base):
+    """DNA text station / measurement files -> out_base.bst / .bms / .asl (GNSS measurements aligned to the stations' frame)"""
+    from ._lib import DnaImportSummary
+    lib = _lib.load()
+    out = DnaImportSummary()
+    err = C.create_string_buffer(512)
+    if lib.dnaimport_text(os.fsencode(stn_file), os.fsencode(msr_file), os.fsencode(out_base), C.byref(out), err, 512) != 0:
+        raise RuntimeError("dnaimport_text: " + err.value.decode(errors="replace"))
+    return {k: getattr(out, k) for k, _ in DnaImportSummary._fields_}
+
+
 def rccl_unique_id():
     """128 bytes for dnaadj_dist_attach_rccl (ncclGetUniqueId): make on one rank, hand to all"""
     lib = _lib.load()

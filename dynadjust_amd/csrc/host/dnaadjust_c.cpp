@@ -6,6 +6,7 @@
 #include <string>
 
 #include "dna_adjust.hpp"
+#include "dnaimport_lite.hpp"
 #include "dnaio.hpp"
 #include "statfuncs.hpp"
 #include "synth.hpp"
@@ -108,6 +109,25 @@ int dnaadj_adjust(dnaadj_handle* h, int* status) {
         int st = (int)h->adj->AdjustNetwork();
         if (status) *status = st;
     });
+}
+
+int dnaimport_text(const char* stn_file, const char* msr_file, const char* out_base, dnaimport_summary* out, char* err, size_t errlen) {
+    if (!stn_file || !msr_file || !out_base) return DNAADJ_EINVAL;
+    try {
+        dynadjust::import::import_summary s;
+        dynadjust::import::import_dna_text(stn_file, msr_file, out_base, &s);
+        if (out) {
+            out->stations = s.stations;
+            out->records = s.records;
+            out->vectors = s.vectors;
+            out->clusters = s.clusters;
+            out->vectors_transformed = s.vectors_transformed;
+        }
+        return DNAADJ_OK;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return DNAADJ_EXCEPTION;
+    }
 }
 
 int dnaadj_dist_rccl_available(void) { return dynadjust::networkadjust::rccl_available() ? 1 : 0; }

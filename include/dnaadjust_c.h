@@ -210,6 +210,15 @@ void* dnaadj_device_instance_context(dnaadj_handle* h, int r);
 /* device context of the adjustment (for dnagpu_profile_*), NULL before prepare */
 void* dnaadj_device_context(dnaadj_handle* h);
 
+/* ---- DNA text files in: <stn>, <msr> (DNA v3 fixed-column text; stations LLH / LLh / XYZ, GNSS measurements G / X / Y)
+ * -> <out_base>.bst / .bms / .asl in dnaimport's record layout.  GNSS measurements given in another frame / epoch than the
+ * stations (ITRF1997 ... ITRF2020 -> GDA2020) are aligned the way dnareftran does it: both ends of a baseline transformed as
+ * points with the published 14-parameter set at the measurement's epoch, then differenced (dnareftran.cpp:1740-1835). ---- */
+typedef struct {
+    uint64_t stations, records, vectors, clusters, vectors_transformed;
+} dnaimport_summary;
+int dnaimport_text(const char* stn_file, const char* msr_file, const char* out_base, dnaimport_summary* out, char* err, size_t errlen);
+
 /* ---- synthetic networks: writes <dir>/<name>.{bst,bms,asl,seg,truth} ---- */
 typedef struct {
     uint32_t rows, cols;

@@ -208,6 +208,20 @@ def write_binary_network(base, stations, clusters, measured=None):
     return bst, bms
 
 
+def build_gnss_sample_with_the_product_importer(golden_dir, base):
+    """the same network through the product's own importer (dnaimport_text, include/dnaadjust_c.h): .stn / .msr -> .bst / .bms / .asl
+    with the ITRF2008 / ITRF2014 baselines aligned to GDA2020 the way dnareftran does -- nothing is lifted from the report.
+    Returns (stations, clusters, expected) like build_gnss_sample."""
+    import os
+    from dynadjust_amd import adjust
+    summary = adjust.import_dna_text(os.path.join(golden_dir, "gnss-network.stn"), os.path.join(golden_dir, "gnss-network.msr"), base)
+    assert summary["stations"] == 43 and summary["vectors_transformed"] > 100
+    stn = read_stn(os.path.join(golden_dir, "gnss-network.stn"))
+    cl = read_msr(os.path.join(golden_dir, "gnss-network.msr"))
+    adj = read_adj(os.path.join(golden_dir, "gnss.simult.adj.expected"))
+    return stn, cl, adj
+
+
 def build_gnss_sample(golden_dir, base):
     """the reference's sample GNSS network as .bst/.bms/.asl files at `base`.  The observations are the "Measured" column
     of gnss.simult.adj.expected rather than the .msr values: dnaimport transformed the ITRF2008/ITRF2014 baselines to the

@@ -340,13 +340,17 @@ def _compare_statistics(a, o, confidence=95.0):
     return fd, rec
 
 
-def test_reference_sample_gnss_network(built, orc, golden_dir, tmp_path):
+@pytest.mark.parametrize("importer", ["product", "test"])
+def test_reference_sample_gnss_network(built, orc, golden_dir, tmp_path, importer):
     """the device path against the reference's published adjustment of its own sample network
-    (sampleData/gnss-network.* -> gnss.simult.adj.expected) and against the oracle on the same files"""
+    (sampleData/gnss-network.* -> gnss.simult.adj.expected) and against the oracle on the same files.
+    importer "product": the .stn / .msr text goes through the product's importer (dnaimport_text: DNA reader + the frame alignment of
+    dnareftran) -- the whole way from the reference's sample files to its report without anything taken from the report;
+    "test": the test-only reader with the observations of the report's "Measured" column (round 1)"""
     from tests import dnatext as T
     from tests.test_oracle_adjust import check_against_reference_report
     base = str(tmp_path / "gnss")
-    stn, cl, adj = T.build_gnss_sample(golden_dir, base)
+    stn, cl, adj = (T.build_gnss_sample_with_the_product_importer if importer == "product" else T.build_gnss_sample)(golden_dir, base)
     net = orc.Network(base, False)
     o = orc.Adjustment(net, False)
     o.prepare()

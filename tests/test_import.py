@@ -1,0 +1,88 @@
+"""The product-side importer (dnaimport_text, include/dnaadjust_c.h; host/dnaimport_lite.cpp): DNA text station / measurement files to
+the binary files the adjustment reads, GNSS measurements aligned to the stations' frame like dnareftran does.  Host code only: runs
+without a GPU.  Pinned on the reference's own sample: the transformed observations are the "Measured" column of the reference's
+report (printed to 1e-4 m), which the raw .msr values miss by up to 1.8 mm."""
+import os
+
+import numpy as np
+import pytest
+
+from dynadjust_amd import adjust
+from tests import dnaformats as F
+from tests import dnatext as T
+
+
+def test_sample_network_matches_the_reference_report(built, golden_dir, tmp_path):
+    base = str(tmp_path / "net")
+    s = adjust.import_dna_text(os.path.join(golden_dir, "gnss-network.stn"), os.path.join(golden_dir, "gnss-network.msr"), base)
+    assert s == {"stations": 43, "records": 480, "vectors": 139, "clusters": 131, "vectors_transformed": 133}
+    adj = T.read_adj(os.path.join(golden_dir, "gnss.simult.adj.expected"))
+    bms = F.read_bms(base + ".bms")
+    obs = bms["term1"][bms["measStart"] < 3]
+    measured = np.array([m["measured"] for m in adj["msr"]])
+    assert obs.size == measured.size == 417
+    assert np.abs(obs - measured).max() < 0.5e-4 + 1e-9           # the report prints four decimals
+    raw = np.array([x for c in T.read_msr(os.path.join(golden_dir, "gnss-network.msr")) for v in c["vectors"] for x in v[2]])
+    assert np.abs(raw - measured).max() > 1.5e-3                  # the alignment matters: ITRF2008 @ 2015 / ITRF2014 @ 2018 -> GDA2020
+    # same records as the test-only writer lays out (types, stations, cluster bookkeeping, variances, scalars)
+    ref_base = str(tmp_path / "ref")
+    stn, cl, _ = T.build_gnss_sample(golden_dir, ref_base)
+    ref = F.read_bms(ref_base + ".bms")
+    for f in ("measType", "measStart", "station1", "station2", "vectorCount1", "vectorCount2", "clusterID", "scale1", "scale2", "scale3", "scale4",
+              "term2", "term3", "term4", "ignore"):
+        assert np.array_equal(bms[f], ref[f]), f
+    cov = bms["measStart"] >= 3
+    assert np.array_equal(bms["term1"][cov], ref["term1"][cov])
+    bst, rbst = F.read_bst(base + ".bst"), F.read_bst(ref_base + ".bst")
+    for f in ("stationName", "stationConst"):
+        assert np.array_equal(bst[f], rbst[f])
+    for f in ("currentLatitude", "currentLongitude"):
+        assert np.abs(bst[f] - rbst[f]).max() < 1e-12
+    assert np.abs(bst["currentHeight"] - rbst["currentHeight"]).max() < 1e-5       # (XYZ stations: the reference's CartToGeo against an iterated one)
+    assert np.array_equal(np.asarray(F.read_asl(base + ".asl")), np.asarray(F.read_asl(ref_base + ".asl")))
+
+
+def test_frame_alignment_formulas(built):
+    """decimal year and 14-parameter transformation against hand-computed values"""
+    import ctypes as C
+    # a baseline of 100 km rotates by the ITRF2014 -> GDA2020 plate rotation over 2 years: |d| ~ 100 km x 2.2 mas/yr x 2 yr ~ 2 mm
+    stn = "A                   FFF XYZ       -4000000.0000        3000000.0000       -3000000.0000    \n" \
+          "B                   FFF XYZ       -3950000.0000        3050000.0000       -3070000.0000    \n"
+    msr = ("G A                   B                                             1.00      1.00      1.00      1.00            ITRF2014          01.01.2018\n"
+           "                                                                        50000.0000 1.0e-06\n"
+           "                                                                        50000.0000 0.0 1.0e-06\n"
+           "                                                                       -70000.0000 0.0 0.0 1.0e-06\n")
+    import tempfile
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "a.stn"), "w").write("!#=DNA 3.01 STN    01.01.2020       GDA2020    01.01.2020         2\n" + stn)
+    open(os.path.join(d, "a.msr"), "w").write("!#=DNA 3.01 MSR    01.01.2020       GDA2020    01.01.2020         1\n" + msr)
+    adjust.import_dna_text(os.path.join(d, "a.stn"), os.path.join(d, "a.msr"), os.path.join(d, "a"))
+    bms = F.read_bms(os.path.join(d, "a.bms"))
+    dt = (2018.0 + 0.5 / 365.0) - 2020.0
+    mas = np.pi / 180 / 3600 / 1000
+    rx, ry, rz = (np.array([1.50379, 1.18346, 1.20716]) * dt * mas)
+    R = np.array([[1, rz, -ry], [-rz, 1, rx], [ry, -rx, 1]])
+    exp = R @ np.array([50000.0, 50000.0, -70000.0])
+    assert np.abs(bms["term1"][:3] - exp).max() < 1e-9
+    assert 1e-3 < np.abs(exp - np.array([50000.0, 50000.0, -70000.0])).max() < 3e-3
+
+
+@pytest.mark.parametrize("stn,msr,message", [
+    ("A                   FFF UTM        500000.0000        6000000.0000            10.0000    \n", "", "not supported"),
+    ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
+     "S A                   A                                     100.0 0.01\n", "not supported"),
+    ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
+     "G A                   NOWHERE                                       1.00      1.00      1.00      1.00             GDA2020          01.01.2020\n"
+     "   1.0 1e-6\n   1.0 0 1e-6\n   1.0 0 0 1e-6\n", "is not in the station file"),
+    ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n"
+     "B                   FFF LLH      -36.3348253617      145.5841006771            172.1933    \n",
+     "G A                   B                                             1.00      1.00      1.00      1.00               WGS84          01.01.2020\n"
+     "                                                                  1.0 1e-6\n                                                                  1.0 0 1e-6\n"
+     "                                                                  1.0 0 0 1e-6\n", "no transformation"),
+])
+def test_import_errors(built, tmp_path, stn, msr, message):
+    open(tmp_path / "e.stn", "w").write("!#=DNA 3.01 STN    01.01.2020       GDA2020    01.01.2020         1\n" + stn)
+    open(tmp_path / "e.msr", "w").write("!#=DNA 3.01 MSR    01.01.2020       GDA2020    01.01.2020         1\n" + msr)
+    with pytest.raises(RuntimeError) as e:
+        adjust.import_dna_text(str(tmp_path / "e.stn"), str(tmp_path / "e.msr"), str(tmp_path / "e"))
+    assert message in str(e.value)

@@ -232,12 +232,15 @@ def check_against_reference_report(adj, names, stn, xyz, V, fields, stats):
     assert stats["outliers"] == 10                           # "(10 potential outliers)"
 
 
-def test_reference_sample_gnss_network(orc, golden_dir, tmp_path):
+@pytest.mark.parametrize("importer", ["product", "test"])
+def test_reference_sample_gnss_network(orc, built, golden_dir, tmp_path, importer):
     """the oracle against the reference's published result for sampleData/gnss-network (129 G, 1 X cluster of 4,
-    1 Y cluster of 6, variance scalars): this pins the restated adjustment end to end."""
+    1 Y cluster of 6, variance scalars): this pins the restated adjustment end to end.  "product": the sample's .stn / .msr
+    through the product's importer (DNA text reader + frame alignment, host/dnaimport_lite.cpp; no GPU involved);
+    "test": the test-only reader with the report's "Measured" column as observations."""
     from tests import dnatext as T
     base = str(tmp_path / "gnss")
-    stn, cl, adj = T.build_gnss_sample(golden_dir, base)
+    stn, cl, adj = (T.build_gnss_sample_with_the_product_importer if importer == "product" else T.build_gnss_sample)(golden_dir, base)
     net, a, st = _run(orc, base, False)
     assert st == 0 and a.iterations() == 2                    # "ITERATION 2 ... SOLUTION Converged"
     s, f = a.statistics()
