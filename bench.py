@@ -47,13 +47,29 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma
 def traffic_from_profile(workload):
     """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process, so this is
     the figure of the committed `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
-    (profiles/r01_hbm_traffic.json, made by tools/pmc_traffic_json.py); null for workloads without such a pass."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        rec = json.load(open(path))
-        return rec["hbm_bytes_per_launch"] if rec.get("workload") == workload else None
-    except (OSError, ValueError, KeyError):
-        return None
+    (profiles/r0N_hbm_traffic.json, made by tools/pmc_traffic_json.py); null for workloads without such a pass."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # newest round first
+        try:
+            rec = json.load(open(path))
+            if rec.get("workload") == workload:
+                return rec["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def one_chain_frac_from_profile(workload):
+    """end-to-end roofline fraction of the committed one-chain run of this workload (no overlap between block steps):
+    profiles/r0N_bench_<workload>_one_chain.json, newest round first; null without one"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}_one_chain.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+            return rec["cholesky_tflops"] / FP64_MFMA_PEAK_TFLOPS
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def cpu_baseline(workload, iterations, solves_per_step, sum_n3_per_step, stations):
@@ -490,6 +506,11 @@ def main():
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            # `achieved` prices the time during which a GEMM was executing (union over the chains' streams) and so leaves out exactly the
+            # latency-bound remainder (leaves, launch gaps); the same flops over the WHOLE step, and the committed one-chain run
+            # (nothing overlapped: profiles/), say what that remainder costs
+            "frac_end_to_end": (alg / 1e12) / (ms_per_step / 1e3) / FP64_MFMA_PEAK_TFLOPS,
+            "frac_one_chain": one_chain_frac_from_profile(args.workload),
             "traffic": traffic_from_profile(args.workload),
             "traffic_unit": "bytes per launch (memory-side, FETCH_SIZE x 2 + WRITE_SIZE from the committed rocprofv3 --pmc passes of this workload)",
             "launches_per_step": prof_n.value / args.steps,

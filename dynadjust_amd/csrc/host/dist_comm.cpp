@@ -115,12 +115,12 @@ public:
     void broadcast(double* buf, size_t count, int root) override {
         hip_check(hipSetDevice(device_), "hipSetDevice");
         nccl_check(rccl().Broadcast(buf, buf, count, ncclDouble, root, comm_, stream_), "ncclBroadcast");
-        bytes_ += (world_ > 1 ? count * sizeof(double) : 0);
+        bytes_ += count * sizeof(double);        // (payload offered to the transport, whatever the number of ranks)
     }
     void all_reduce_sum(double* buf, size_t count) override {
         hip_check(hipSetDevice(device_), "hipSetDevice");
         nccl_check(rccl().AllReduce(buf, buf, count, ncclDouble, ncclSum, comm_, stream_), "ncclAllReduce");
-        bytes_ += (world_ > 1 ? 2 * count * sizeof(double) : 0);
+        bytes_ += 2 * count * sizeof(double);
     }
     void send(const double* buf, size_t count, int peer) override {
         hip_check(hipSetDevice(device_), "hipSetDevice");

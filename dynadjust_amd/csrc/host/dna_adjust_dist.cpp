@@ -20,6 +20,8 @@
 #include <chrono>
 #include <cmath>
 #include <exception>
+#include <cstdlib>
+#include <mutex>
 #include <numeric>
 #include <set>
 #include <thread>
@@ -437,16 +439,26 @@ void dna_adjust::DistributedCondensedIteration() {
     AgreeOnPhase("condensing the blocks", [&] { CondenseBlocks(mine); });
     if (IsCancelled()) return;
     if (two_level_ok_) {
-        double t0 = wall_ms();
-        AgreeOnPhase("junction chains (own run)", [&] { ReduceOwnRun(); });
-        chain_ms_ += wall_ms() - t0;
+        // DNAGPU_LOCAL_EXCLUSIVE=1 (measurement aid for ranks that share one GPU, tools/gpu_chain_phase.py): the chain work of the
+        // ranks of this process runs one rank at a time and is timed inside the lock -- what a rank with a GPU of its own would spend
+        static std::mutex exclusive;
+        static const bool one_at_a_time = getenv("DNAGPU_LOCAL_EXCLUSIVE") && atoi(getenv("DNAGPU_LOCAL_EXCLUSIVE")) != 0;
+        auto timed = [&](const std::function<void()>& body) {
+            std::unique_lock<std::mutex> lk(exclusive, std::defer_lock);
+            if (one_at_a_time) lk.lock();
+            const double t0 = wall_ms();
+            body();
+            Check(dnagpu_sync(ctx_), 0, "AdjustNetwork()");
+            chain_ms_ += wall_ms() - t0;
+        };
+        AgreeOnPhase("junction chains (own run)", [&] { timed([&] { ReduceOwnRun(); }); });
         ExchangeRuns();
-        t0 = wall_ms();
         AgreeOnPhase("junction chains", [&] {
-            ScanRuns();
-            OwnRunChains();
+            timed([&] {
+                ScanRuns();
+                OwnRunChains();
+            });
         });
-        chain_ms_ += wall_ms() - t0;
         if (IsCancelled()) return;
         AgreeOnPhase("rigorous block solutions", [&] { RigorousBlocks(mine); });
         return;
