@@ -560,6 +560,7 @@ void launch_gather_map(const double* rhs, const int32_t* map, uint32_t npp, doub
 }
 void launch_gemv(const double* A, uint32_t lda, uint32_t rows, uint32_t cols, const double* x, double* part, uint32_t nchunks, int lower,
                  const double* base, double sign, double* out, uint32_t n_out, hipStream_t s) {
+    if (!n_out) return;      // (nothing to produce: a zero-sized grid is an invalid launch configuration)
     if (!rows || !cols) {
         hipLaunchKernelGGL(gemv_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, part, rows, 0u, base, sign, out, n_out);
         return;

@@ -184,13 +184,12 @@ int orc_cholesky_inverse_packed(double* ap, uint32_t n) {
     if (n < 1) return 0;
     double* full = (double*)malloc((size_t)n * n * sizeof(double));
     if (!full) return -1;
-    for (uint32_t j = 0; j < n; ++j)
-        for (uint32_t i = j; i < n; ++i) full[(size_t)j * n + i] = ap[orc_packed_index(n, i, j)];
+    /* column j of the packed lower triangle (rows j..n-1) is contiguous in both layouts */
+    for (uint32_t j = 0; j < n; ++j) memcpy(full + (size_t)j * n + j, ap + orc_packed_index(n, j, j), (size_t)(n - j) * sizeof(double));
     int info = orc_potrf_lower(n, full, n);
     if (!info) info = orc_potri_lower(n, full, n);
     if (!info)
-        for (uint32_t j = 0; j < n; ++j)
-            for (uint32_t i = j; i < n; ++i) ap[orc_packed_index(n, i, j)] = full[(size_t)j * n + i];
+        for (uint32_t j = 0; j < n; ++j) memcpy(ap + orc_packed_index(n, j, j), full + (size_t)j * n + j, (size_t)(n - j) * sizeof(double));
     free(full);
     return info;
 }

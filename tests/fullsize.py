@@ -8,6 +8,9 @@ import numpy as np
 WORKLOADS = {
     "cfg3": (316, 317, 266666, 16, True),
     "cfg2": (100, 100, 26666, 1, False),
+    # a quarter of cfg3: 4 of its 16 strips at the same block size (n ~ 20 000, 317-station junction rows) -- the oracle's run of
+    # it fits a 64 GB host (cfg3 itself needs ~80 GB and 7.4e14 flops on the CPU)
+    "cfg3q": (79, 317, 66666, 4, True),
 }
 SEED = 20260928
 ROW_STRIDE = 8          # rows kept of every sampled column

@@ -133,22 +133,23 @@ def test_failed_allocation_inside_an_inverse_is_reported(built):
     """a tile-table allocation failing in the middle of the recursion must come back as DNAGPU_ENOMEM (never DNAGPU_OK with a
     skipped launch), and the context must work again afterwards"""
     from dynadjust_amd.device import DeviceContext
-    ctx = DeviceContext(0)                       # fresh context: empty table cache
-    try:
-        n = 700
-        M = _dense_spd(n, 5)
-        ap = pack_lower(M)
-        for nth in (1, 3, 7):
+    n = 700
+    M = _dense_spd(n, 5)
+    ap = pack_lower(M)
+    for nth in (1, 3, 7):
+        ctx = DeviceContext(0)                   # fresh context: empty table cache, so the nth table allocation does happen
+        try:
             built.dnagpu_debug_fail_allocation(nth)
             with pytest.raises(DnaGpuError) as e:
                 ctx.cholesky_inverse_packed(ap, n)
             assert e.value.code == -2 and "allocation" in str(e.value)
-        built.dnagpu_debug_fail_allocation(0)
-        inv = unpack_lower(ctx.cholesky_inverse_packed(ap, n), n)
-        assert np.abs(inv @ M - np.eye(n)).max() < 1e-10
-    finally:
-        built.dnagpu_debug_fail_allocation(0)
-        ctx.close()
+            built.dnagpu_debug_fail_allocation(0)
+            # the same context, afterwards: the tables that were missing are built now
+            inv = unpack_lower(ctx.cholesky_inverse_packed(ap, n), n)
+            assert np.abs(inv @ M - np.eye(n)).max() < 1e-10
+        finally:
+            built.dnagpu_debug_fail_allocation(0)
+            ctx.close()
 
 
 def test_empty_matrix(gpu_ctx):

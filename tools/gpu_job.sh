@@ -1,12 +1,15 @@
 #!/bin/bash
-# one gpurun job: golden record of the oracle (host cores) beside the GPU tests
+# one gpurun job (edit per need): tests with durations, chain-phase tool, bench lines
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-free -g | head -2 > gpurun_out/host.txt; nproc >> gpurun_out/host.txt
-( ORACLE_THREADS=${ORACLE_THREADS:-64} timeout 2400 python tools/make_fullsize_golden.py cfg3 gpurun_out/cfg3_oracle.npz > gpurun_out/golden_cfg3.log 2>&1 ) &
-GOLD=$!
-timeout 900 python -m pytest tests/test_gpu_matrix.py -x -q > gpurun_out/t_matrix.log 2>&1
-timeout 1500 python -m pytest tests/test_gpu_fullsize.py -x -q -k "not oracle_record" > gpurun_out/t_fullsize.log 2>&1
-timeout 1500 python -m pytest tests -x -q -m gpu --deselect tests/test_gpu_fullsize.py --deselect tests/test_gpu_matrix.py > gpurun_out/t_all.log 2>&1
-wait $GOLD
-tail -3 gpurun_out/t_matrix.log gpurun_out/t_fullsize.log gpurun_out/t_all.log gpurun_out/golden_cfg3.log
+export GPU_MAX_HW_QUEUES=16
+timeout 1500 python -m pytest tests -q -m gpu --durations=25 -x > gpurun_out/t_all.log 2>&1
+echo "tests rc=$?" > gpurun_out/job.status
+timeout 600 python tools/gpu_chain_phase.py > gpurun_out/chain_phase.log 2>&1
+timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench_cfg3.json 2> gpurun_out/bench_cfg3.err
+for t in 160 384 768; do
+  DNAGPU_SMALL_TILES=$t DNAGPU_MULTI_THREAD=0 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_one_chain_small$t.json
+  DNAGPU_SMALL_TILES=$t timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_four_chains_small$t.json
+done
+tail -n 30 gpurun_out/t_all.log
+cat gpurun_out/job.status
