@@ -16,6 +16,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ORC_PROFILE=1: where an adjustment's wall time goes (printed by orc_profile_print) */
+#include <time.h>
+enum { T_LAPACK, T_PACK, T_SYMV, T_COPY, T_CARRY, T_RHS, T_COUNT };
+static double orc_t[T_COUNT];
+static const char* orc_t_name[T_COUNT] = {"dpotrf+dpotri", "pack/unpack", "N^-1 rhs (packed symv)", "matrix copies", "junction carry", "rhs formation"};
+static double orc_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void orc_profile_print(void) {
+    for (int i = 0; i < T_COUNT; ++i) fprintf(stderr, "oracle: %-26s %9.3f s\n", orc_t_name[i], orc_t[i]);
+}
+void orc_profile_reset(void) {
+    for (int i = 0; i < T_COUNT; ++i) orc_t[i] = 0.0;
+}
+
 /* ========================================================================== */
 /* L2: matrix_2d                                                               */
 /* ========================================================================== */
@@ -185,12 +202,17 @@ int orc_cholesky_inverse_packed(double* ap, uint32_t n) {
     double* full = (double*)malloc((size_t)n * n * sizeof(double));
     if (!full) return -1;
     /* column j of the packed lower triangle (rows j..n-1) is contiguous in both layouts */
+    double t0 = orc_now();
     for (uint32_t j = 0; j < n; ++j) memcpy(full + (size_t)j * n + j, ap + orc_packed_index(n, j, j), (size_t)(n - j) * sizeof(double));
+    double t1 = orc_now();
     int info = orc_potrf_lower(n, full, n);
     if (!info) info = orc_potri_lower(n, full, n);
+    double t2 = orc_now();
     if (!info)
         for (uint32_t j = 0; j < n; ++j) memcpy(ap + orc_packed_index(n, j, j), full + (size_t)j * n + j, (size_t)(n - j) * sizeof(double));
     free(full);
+    orc_t[T_PACK] += (t1 - t0) + (orc_now() - t2);
+    orc_t[T_LAPACK] += t2 - t1;
     return info;
 }
 
@@ -1152,6 +1174,7 @@ static int solve(orc_adjustment* a, blk_t* B, int compute_inverse, uint32_t bloc
         }
     }
     /* At_Vinv_m = AtVinv * measMinusComp (ADJ:6659-6660); AtVinv is never materialised */
+    const double trhs0 = orc_now();
     double* rhs = (double*)calloc(n ? n : 1, sizeof(double));
     uint32_t brow = 0;
     uint32_t trow = 0;
@@ -1209,7 +1232,10 @@ static int solve(orc_adjustment* a, blk_t* B, int compute_inverse, uint32_t bloc
         }
     }
     /* corrections = N^-1 * At_Vinv_m (multiply_sym, ADJ:6665) */
+    double ts0 = orc_now();
+    orc_t[T_RHS] += ts0 - trhs0;
     orc_multiply_sym_packed(B->N, rhs, B->corr, n);
+    orc_t[T_SYMV] += orc_now() - ts0;
     free(rhs);
     return 0;
 }
@@ -1561,9 +1587,11 @@ static int phased_forward(orc_adjustment* a) {
         if (B->isolated || B->last) continue;
         blk_t* Nx = &a->blk[k + 1];
         if (Nx->isolated) continue;
+        const double tc0 = orc_now();
         if (gather_junctions(a, B, B->N, B->est, B->jsl, B->n_jsl, B->jvar, B->jestFwd)) return -1;
         memcpy(B->jvarFwd, B->jvar, psize(3 * B->n_jsl) * sizeof(double));                 /* ADJ:1051 */
         attach_junctions(Nx, B->jsl, B->n_jsl, B->jvar, B->jestFwd);
+        orc_t[T_CARRY] += orc_now() - tc0;
     }
     return 0;
 }

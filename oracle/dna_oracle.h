@@ -39,6 +39,8 @@ int orc_set_lapack(const char* lib);
 const char* orc_lapack_name(void);
 int orc_set_threads(int n);
 int orc_set_threads_local(int n);
+void orc_profile_print(void);   /* accumulated wall time per part of the adjustment, to stderr */
+void orc_profile_reset(void);
 /* dpotrf('L') / dpotri('L') on a full column-major matrix, lda >= n; return LAPACK info */
 int orc_potrf_lower(uint32_t n, double* a, uint32_t lda);
 int orc_potri_lower(uint32_t n, double* a, uint32_t lda);
