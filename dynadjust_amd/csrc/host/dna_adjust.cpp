@@ -688,20 +688,12 @@ void dna_adjust::PrepareBlocks() {
                                         B.cluster_off.data(), B.vcv.data()),
               b, "PrepareAdjustment(): measurements");
         for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "PrepareAdjustment(): meas-minus-computed");
-        if (phased) {
-            UINT32 nj = (UINT32)v_JSL_[b].size() * 3;
-            if (nj) {
-                Check(dnagpu_matrix_create(ctx_, nj, &B.jfwd), b, "PrepareAdjustment(): junction matrix");
-                Check(dnagpu_matrix_create(ctx_, nj, &B.jrev), b, "PrepareAdjustment(): junction matrix");
-            }
-            // v_rigorousVariances_ is allocated when the block is finalised (only on the rank / chain that owns it)
-        }
+        // junction matrices: AllocateChainData (once it is known which blocks this rank works on);
+        // v_rigorousVariances_ is allocated when the block is finalised (only on the rank / chain that owns it)
     }
     ComputeBlockOwners(CondensedWanted() && !ReuseInverses());
     DecideStaging();
-    PrepareCondensedBlocks();
-    if (DistWorld() > 1 && phased && !CondensedSchedule()) ComputeBlockOwners(false);    // the reference's schedule shards differently
-    PrepareTwoLevel();
+    PrepareCondensedBlocks();     // (+ ownership under the reference's schedule, the two-level plan, junction matrices / condensed blocks)
     Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
 }
 
@@ -719,7 +711,7 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     adjustStatus_ = ADJUST_SUCCESS;
     FreeDevice();
     projectSettings_ = projectSettings;
-    mt_chains_ = DNAGPU_NUM_CHAINS;
+    mt_chains_ = DNAGPU_DEFAULT_CHAINS;
     profileTimings_ = getenv("DYNADJUST_PROFILE") != nullptr;
     profileUpdateNormalsNs_ = profileStageLoadNs_ = profileStageStoreNs_ = 0;
     if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
@@ -920,7 +912,7 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
 
 // AdjustPhasedBlock1 (ADJ:2675): one reverse pass (AdjustPhasedReverse, ADJ:3594) -- every block solved in isolation with the
 // junctions carried from the blocks after it, so that the first block of the network comes out rigorous; the other blocks
-// keep the estimates and variances of their reverse solve (UpdateEstimatesFinal is called for all of them, ADJ:3667)
+// but the last keep the estimates and variances of their reverse solve (UpdateEstimatesFinal, ADJ:3667)
 void dna_adjust::AdjustPhasedBlock1() {
     currentIteration_ = 1;
     maxCorr_ = 0.0;
@@ -933,7 +925,9 @@ void dna_adjust::AdjustPhasedBlock1() {
         if (v_blockMeta_[k]._blockIsolated) continue;          // PrepareAdjustmentReverse: nothing to do for a single block
         const double mv = PhasedReverseBlock(0, k);
         if (k == 0) first_corr = mv;
-        PhasedFinaliseBlock(0, k);
+        // UpdateEstimatesFinal returns at once for the last block of a network in this mode (ADJ:3750-3753): its rigorous
+        // coordinates and variances stay as PrepareAdjustment left them
+        if (!v_blockMeta_[k]._blockLast) PhasedFinaliseBlock(0, k);
     }
     maxCorr_ = first_corr;                                      // "largest correction for block 1 only" (ADJ:2705)
     iterationCorrections_.push_back(maxCorr_);

@@ -264,6 +264,7 @@ private:
     size_t xbuf_cap_ = 0;
     double exchange_ms_ = 0.0, chain_ms_ = 0.0;
     void PrepareCondensedBlocks();
+    void AllocateChainData();
     void DecideStaging();
 public:
     // ---- per-block steps of the phased chain; the drivers above and the multi-GPU orchestrator
@@ -343,7 +344,7 @@ private:
     // device chains (stream + workspaces) in use: one, or with a.multi_thread DNAGPU_NUM_CHAINS (the independent block steps of
     // the condensed schedule are served by all of them; cfg3: 4.07 / 3.96 / 3.88 s per step with 2 / 3 / 4; DNAGPU_CHAINS overrides)
     int NumChains() const { return (projectSettings_.a.adjust_mode != SimultaneousMode && projectSettings_.a.multi_thread) ? mt_chains_ : 1; }
-    int mt_chains_ = DNAGPU_NUM_CHAINS;
+    int mt_chains_ = DNAGPU_DEFAULT_CHAINS;
     bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_ && !staged_; }
     bool CondensedWanted() const {
         return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity && projectSettings_.a.adjust_mode == PhasedMode;

@@ -215,7 +215,7 @@ void dna_adjust::PrepareTwoLevel() {
     for (UINT32 k = 0; k < blockCount_; ++k) {
         const blockMeta_t& m = v_blockMeta_[k];
         if (m._blockIsolated || (m._blockFirst && k != 0) || (m._blockLast && k != blockCount_ - 1)) return;
-        if (blocks_[k].keep.empty() || !blocks_[k].red) return;
+        if (blocks_[k].keep.empty()) return;
     }
     std::vector<int> first(W, -1), last(W, -1);
     for (UINT32 k = 0; k < blockCount_; ++k) {

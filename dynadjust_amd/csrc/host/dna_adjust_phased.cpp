@@ -412,9 +412,36 @@ void dna_adjust::DecideStaging() {
 }
 
 // lists for the condensed schedule; condensed_ok_ = false falls back to the block-level chains
+// Junction matrices (jfwd / jrev of every block with a junction list) and, for the condensed schedule, the condensed block and its
+// station-less device block.  With two-level chains across GPUs a rank only ever touches those of its own run and of the blocks
+// that end a run (cfg4: 24 of 128 blocks -- 3.5 GB instead of 55 GB per rank).
+void dna_adjust::AllocateChainData() {
+    if (projectSettings_.a.adjust_mode == SimultaneousMode) return;
+    if (DistWorld() > 1 && !CondensedSchedule()) ComputeBlockOwners(false);     // the reference's schedule shards differently
+    std::vector<char> ends(blockCount_, 0);
+    if (two_level_ok_)
+        for (const segment_t& g : segs_) ends[g.b] = 1;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        block_t& B = blocks_[k];
+        const bool mine = !two_level_ok_ || OwnsBlock(k);
+        const UINT32 nj = (UINT32)v_JSL_[k].size() * 3;
+        if (nj && (mine || ends[k])) {
+            if (!B.jfwd) Check(dnagpu_matrix_create(ctx_, nj, &B.jfwd), k, "PrepareAdjustment(): junction matrix");
+            if (!B.jrev) Check(dnagpu_matrix_create(ctx_, nj, &B.jrev), k, "PrepareAdjustment(): junction matrix");
+        }
+        if (condensed_ok_ && mine && !B.keep.empty() && !B.red) {
+            Check(dnagpu_block_create(ctx_, blockCount_ + k, (UINT32)B.keep.size(), 0), k, "PrepareAdjustment(): condensed block");
+            Check(dnagpu_matrix_create(ctx_, (UINT32)B.keep.size() * 3, &B.red), k, "PrepareAdjustment(): condensed block");
+        }
+    }
+}
+
 void dna_adjust::PrepareCondensedBlocks() {
     condensed_ok_ = false;
-    if (projectSettings_.a.adjust_mode == SimultaneousMode || !projectSettings_.a.schur_carry) return;
+    if (projectSettings_.a.adjust_mode == SimultaneousMode || !projectSettings_.a.schur_carry) {
+        AllocateChainData();
+        return;
+    }
     for (UINT32 k = 0; k < blockCount_; ++k) {
         block_t& B = blocks_[k];
         const UINT32 ns = (UINT32)v_parameterStationList_[k].size();
@@ -450,15 +477,19 @@ void dna_adjust::PrepareCondensedBlocks() {
         split(B.con_fwd, B.ccon_fwd, &B.con_inner);
         split(B.con_rev, B.ccon_rev, &inner_rev);
         split(B.con_cmb, B.ccon_cmb, &inner_cmb);
-        if (!inner_cmb.stn.empty()) return;     // (a station seen in an earlier block is shared, hence kept)
+        bool fits = inner_cmb.stn.empty();      // (a station seen in an earlier block is shared, hence kept)
         // a station of one block only appears first in that block, whichever way the blocks are walked
-        if (B.con_inner.stn != inner_rev.stn || B.con_inner.w9 != inner_rev.w9) return;
-        if (B.con_inner.stn.size() + B.keep.size() != ns) return;
-        if (B.keep.empty()) continue;
-        Check(dnagpu_block_create(ctx_, blockCount_ + k, (UINT32)B.keep.size(), 0), k, "PrepareAdjustment(): condensed block");
-        Check(dnagpu_matrix_create(ctx_, (UINT32)B.keep.size() * 3, &B.red), k, "PrepareAdjustment(): condensed block");
+        fits = fits && B.con_inner.stn == inner_rev.stn && B.con_inner.w9 == inner_rev.w9;
+        fits = fits && B.con_inner.stn.size() + B.keep.size() == ns;
+        if (!fits) {                            // falls back to the block-level chains
+            AllocateChainData();
+            return;
+        }
     }
     condensed_ok_ = true;
+    // what the chains need on the device -- junction matrices, condensed blocks -- for the blocks this rank works on
+    PrepareTwoLevel();
+    AllocateChainData();
     if (!projectSettings_.a.keep_factors || !SchurCarry()) return;
     // a.keep_factors: which blocks may keep their factor (2 n^2 + 3 k n doubles each) without starving what is allocated
     // later -- every block's rigorous variance matrix and the chains' workspaces (work matrix + X + W per chain)

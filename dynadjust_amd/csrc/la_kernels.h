@@ -26,7 +26,8 @@ struct GemmArgs {
 };
 
 // launches with fewer 128-tiles than this run on 64x64 block tiles
-constexpr int SMALL_LAUNCH_TILES = 160;
+// (cfg3, r02: 160 / 384 / 768 -> 3.83 / 3.79 / 3.77 s per step with four chains, 4.38 / 4.33 / 4.35 s with one)
+constexpr int SMALL_LAUNCH_TILES = 512;
 
 // Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).

@@ -55,7 +55,8 @@ typedef struct dnagpu_ctx dnagpu_ctx;
 #define DNAGPU_ENOTPOSDEF (-4) /* dpotrf-style failure; column in dnagpu_last_info() */
 #define DNAGPU_ENODEVICE (-5)
 
-#define DNAGPU_NUM_CHAINS 4
+#define DNAGPU_NUM_CHAINS 8        /* chains a context provides */
+#define DNAGPU_DEFAULT_CHAINS 4    /* chains the facade uses by itself (DNAGPU_CHAINS = 2 .. DNAGPU_NUM_CHAINS overrides) */
 
 /* ---- context ------------------------------------------------------------ */
 int dnagpu_create(int device, dnagpu_ctx** out);

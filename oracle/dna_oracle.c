@@ -1710,6 +1710,42 @@ static int adjust_phased(orc_adjustment* a) {
 
 int orc_adjust_run(orc_adjustment* a) { return a->phased ? adjust_phased(a) : adjust_simultaneous(a); }
 
+/* AdjustPhasedBlock1 (ADJ:2675-2717) = one AdjustPhasedReverse (ADJ:3594-3671): every block solved "in isolation" with the junctions
+ * carried from the blocks after it, so that block 1 comes out rigorous; UpdateEstimatesFinal (ADJ:3744) for every block but the
+ * last (which returns at once in this mode, ADJ:3750-3753); the largest correction is block 1's only (ADJ:2705) */
+int orc_adjust_run_block1(orc_adjustment* a) {
+    if (!a->phased) return ORC_ADJUST_EXCEPTION_RAISED;
+    a->iterations = 1;
+    a->maxCorr = 0.0;
+    for (uint32_t kk = a->n_blocks; kk-- > 0;) {
+        blk_t* B = &a->blk[kk];
+        if (B->isolated) continue;                                                        /* PrepareAdjustmentReverse: nothing to do */
+        if (B->last) {
+            memcpy(B->N, B->NR, psize(B->n) * sizeof(double));                             /* ADJ:3112-3168 */
+            memcpy(B->est, B->orig, B->n * sizeof(double));
+            if (add_constraints(a, B, CON_REV)) return ORC_ADJUST_EXCEPTION_RAISED;
+        }
+        if (solve(a, B, 1, kk)) return ORC_ADJUST_EXCEPTION_RAISED;                        /* ADJ:3639 */
+        for (uint32_t i = 0; i < B->n; ++i) B->est[i] += B->corr[i];                       /* UpdateEstimatesReverse */
+        if (!B->first) {                                                                   /* CarryReverseJunctions (ADJ:3833) */
+            blk_t* Nx = &a->blk[kk - 1];
+            memcpy(Nx->N, Nx->NR, psize(Nx->n) * sizeof(double));
+            memcpy(Nx->est, Nx->orig, Nx->n * sizeof(double));
+            if (gather_junctions(a, B, B->N, B->est, Nx->jsl, Nx->n_jsl, Nx->jvar, B->jestRev)) return ORC_ADJUST_EXCEPTION_RAISED;
+            attach_junctions(Nx, Nx->jsl, Nx->n_jsl, Nx->jvar, B->jestRev);
+            if (add_constraints(a, Nx, CON_REV)) return ORC_ADJUST_EXCEPTION_RAISED;
+        }
+        if (B->last) continue;                                                             /* UpdateEstimatesFinal returns (ADJ:3750-3753) */
+        if (B->first) shrink_pseudo(B, 1);
+        memcpy(B->rig, B->est, B->n * sizeof(double));
+        memcpy(B->rigvar, B->N, psize(B->n) * sizeof(double));
+        memcpy(B->orig, B->rig, B->n * sizeof(double));
+    }
+    a->maxCorr = max_value(a->blk[0].corr, a->blk[0].n);                                   /* ADJ:2705 */
+    a->max_corr_hist[0] = a->maxCorr;
+    return fabs(a->maxCorr) > a->set.iteration_threshold ? 2 /* ADJUST_THRESHOLD_EXCEEDED */ : ORC_ADJUST_SUCCESS;
+}
+
 uint32_t orc_adjust_iterations(const orc_adjustment* a) { return a->iterations; }
 double orc_adjust_max_correction(const orc_adjustment* a, uint32_t it) {
     return (it >= 1 && it <= a->iterations && it <= 64) ? a->max_corr_hist[it - 1] : 0.0;

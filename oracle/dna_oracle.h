@@ -144,6 +144,7 @@ int orc_adjust_prepare(orc_adjustment* a);
 /* AdjustNetwork (ADJ:2140) -> AdjustSimultaneous (ADJ:2413) | AdjustPhased (ADJ:2579) */
 int orc_adjust_run(orc_adjustment* a);
 /* one forward + reverse/combine sweep only (used by the CPU-baseline timer) */
+int orc_adjust_run_block1(orc_adjustment* a);     /* Phased_Block_1Mode: AdjustPhasedBlock1 (one reverse pass) */
 int orc_adjust_iteration(orc_adjustment* a);
 int orc_adjust_forward_pass(orc_adjustment* a);   /* AdjustPhasedForward only */
 int orc_adjust_reverse_pass(orc_adjustment* a);   /* AdjustPhasedReverseCombine only (after a forward pass) */

@@ -71,6 +71,7 @@ def load():
         lib.orc_adjust_destroy.argtypes = [C.c_void_p]
         lib.orc_adjust_prepare.argtypes = [C.c_void_p]
         lib.orc_adjust_run.argtypes = [C.c_void_p]
+        lib.orc_adjust_run_block1.argtypes = [C.c_void_p]
         lib.orc_adjust_iteration.argtypes = [C.c_void_p]
         lib.orc_adjust_iterations.restype = C.c_uint32
         lib.orc_adjust_iterations.argtypes = [C.c_void_p]
@@ -476,6 +477,13 @@ class Adjustment:
 
     def run(self):
         st = self.lib.orc_adjust_run(self.h)
+        if st == 5:
+            raise RuntimeError(self.lib.orc_adjust_error(self.h).decode())
+        return st
+
+    def run_block1(self):
+        """Phased_Block_1Mode (AdjustPhasedBlock1)"""
+        st = self.lib.orc_adjust_run_block1(self.h)
         if st == 5:
             raise RuntimeError(self.lib.orc_adjust_error(self.h).decode())
         return st

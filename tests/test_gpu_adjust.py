@@ -340,6 +340,21 @@ def _compare_statistics(a, o, confidence=95.0):
     return fd, rec
 
 
+def _against_oracle(orc, base, iterations, estimates, variances, corrections):
+    """results of a device run (lists per block) against the oracle's adjustment of the same files"""
+    net = orc.Network(base, True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    assert o.run() == 0 and o.iterations() == iterations
+    for i, c in enumerate(corrections):
+        assert abs(c - o.max_correction(i + 1)) < 1e-8
+    for b in range(len(estimates)):
+        assert np.abs(estimates[b] - o.block_estimates(b)).max() < TOL_X
+        vo = o.block_variances(b)
+        assert np.abs(variances[b] - vo).max() / np.abs(vo).max() < TOL_V
+    o.close()
+
+
 @pytest.mark.parametrize("importer", ["product", "test"])
 def test_reference_sample_gnss_network(built, orc, golden_dir, tmp_path, importer):
     """the device path against the reference's published adjustment of its own sample network
@@ -442,7 +457,7 @@ def test_results_out_files(built, orc, tmp_path):
 
 
 @pytest.mark.parametrize("mt", [False, True])
-def test_reuse_inverses_is_identical(built, tmp_path, mt):
+def test_reuse_inverses_is_identical(built, orc, tmp_path, mt):
     """a.reuse_inverses (device path only): the block inverses of the first iteration are kept and reused -- for a GNSS-only
     network they are the same bits every iteration, so every result must be IDENTICAL, with half the Solve() calls"""
     adjust.write_synthetic_network(str(tmp_path), "r", 14, 12, 0, 5, seed=9, x_clusters=20, y_cluster=True, initial_sigma=0.4)
@@ -459,6 +474,7 @@ def test_reuse_inverses_is_identical(built, tmp_path, mt):
     B = len(x0)
     assert it0 == it1 and corr0 == corr1 and c0 == c1
     assert n0 == it0 * (3 * B - 2) and n1 == 3 * B - 2
+    _against_oracle(orc, str(tmp_path / "r"), it1, x1, v1, corr1)
     for b in range(B):
         assert np.array_equal(x0[b], x1[b]) and np.array_equal(v0[b], v1[b])
     # a second AdjustNetwork on the same object starts over (ResetAdjustment drops the resident inverses)
@@ -530,7 +546,7 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
 
 
 @pytest.mark.parametrize("mt", [False, True])
-def test_condensed_reuse_across_iterations(built, tmp_path, mt):
+def test_condensed_reuse_across_iterations(built, orc, tmp_path, mt):
     """a.reuse_inverses with the condensed schedule and kept factors: from the second iteration on a block is neither condensed
     nor inverted again -- reduced right-hand sides from the kept factor, chains on the condensed blocks, products with the
     resident rigorous variances.  Same results (the matrices of a GNSS-only network do not change between iterations)."""
@@ -547,30 +563,43 @@ def test_condensed_reuse_across_iterations(built, tmp_path, mt):
     (it0, n0, x0, v0, c0, corr0), (it1, n1, x1, v1, c1, corr1) = runs
     B = len(x0)
     assert it0 == it1 and n0 == it0 * B and n1 == B            # one completion per block in all, not per iteration
+    _against_oracle(orc, str(tmp_path / "r"), it1, x1, v1, corr1)
     assert abs(c0 - c1) < 1e-9 * c0 and np.abs(np.array(corr0) - np.array(corr1)).max() < 1e-10
     for b in range(B):
         assert np.abs(x0[b] - x1[b]).max() < 1e-9
         assert np.array_equal(v0[b], v1[b])                     # the very inverse of iteration 1
 
 
-def test_phased_block_1_mode(built, tmp_path):
+def test_phased_block_1_mode(built, orc, tmp_path):
     """Phased_Block_1Mode (AdjustPhasedBlock1, dnaadjust.cpp:2675): one reverse pass; block 1 is rigorous -- exactly what the first
-    iteration of the full phased adjustment gives it -- the other blocks keep their reverse solution"""
+    iteration of the full phased adjustment gives it -- the blocks between keep their reverse solution, the last block is not
+    finalised at all (UpdateEstimatesFinal returns for it, ADJ:3750).  Against the oracle's restatement of the mode, block by block."""
     adjust.write_synthetic_network(str(tmp_path), "b", 24, 10, 0, 4, seed=6, x_clusters=8)
+    net = orc.Network(str(tmp_path / "b"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run_block1()
     p = adjust.ProjectSettings("b", str(tmp_path), adjust_mode=adjust.Phased_Block_1Mode)
     a = adjust.DnaAdjust()
     a.PrepareAdjustment(p)
     st = a.AdjustNetwork()
-    assert a.CurrentIteration() == 1 and st in (adjust.ADJUST_SUCCESS, adjust.ADJUST_THRESHOLD_EXCEEDED)
+    assert a.CurrentIteration() == 1 and st == ost and st in (adjust.ADJUST_SUCCESS, adjust.ADJUST_THRESHOLD_EXCEEDED)
+    assert abs(a.GetMaxCorrection() - o.max_correction(1)) < 1e-8 and abs(a.GetMaxCorrection()) > 0.0
+    last = a.blockCount() - 1
+    for b in range(a.blockCount()):
+        assert np.abs(a.block_estimates(b) - o.block_estimates(b)).max() < TOL_X, b
+        if b != last:
+            vo = o.block_variances(b)
+            assert np.abs(a.block_variances_packed(b) - vo).max() / np.abs(vo).max() < TOL_V, b
+    # block 1 equals the first iteration of the full phased adjustment (reference schedule) bit for bit
     f, st_f = _device_run(str(tmp_path), "b", True, max_iterations=1, schur_carry=False)
     assert np.array_equal(a.block_estimates(0), f.block_estimates(0))
     assert np.array_equal(a.block_variances_packed(0), f.block_variances_packed(0))
-    assert abs(a.GetMaxCorrection()) > 0.0
-    # the last block's reverse solution has not seen the other blocks: it differs from the rigorous one
-    last = a.blockCount() - 1
-    assert np.abs(a.block_estimates(last) - f.block_estimates(last)).max() > 1e-6
+    # a block in between has only seen the blocks after it: it differs from the rigorous solution
+    assert np.abs(a.block_estimates(last - 1) - f.block_estimates(last - 1)).max() > 1e-6
     a.close()
     f.close()
+    o.close()
 
 
 def test_deserialise_adjusted_variance_matrices(built, tmp_path):

@@ -44,7 +44,7 @@ def _stats(a):
 def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt):
     adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 6, seed=10)
     o, ost = _oracle(orc, str(tmp_path), "n")
-    a = _run(str(tmp_path), "n", devices=[0] * ranks, dist_transport="local", schur_carry=schur, multi_thread=mt, network_name="n",
+    a = _run(str(tmp_path), "n", devices=[0] * ranks, dist_transport="local", schur_carry=schur, multi_thread=mt,
              output_folder=str(tmp_path / "multi"))
     os.makedirs(tmp_path / "multi", exist_ok=True)
     st = a.AdjustNetworkDistributed()
@@ -64,7 +64,7 @@ def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt
     # statistics and result files: collective inside the library, equal to the single-GPU run
     a.GenerateStatistics()
     a.SerialiseAdjustedVarianceMatrices()
-    f = _run(str(tmp_path), "n", schur_carry=schur, multi_thread=mt, network_name="n", output_folder=str(tmp_path / "single"))
+    f = _run(str(tmp_path), "n", schur_carry=schur, multi_thread=mt, output_folder=str(tmp_path / "single"))
     os.makedirs(tmp_path / "single", exist_ok=True)
     assert f.AdjustNetwork() == st
     f.GenerateStatistics()
