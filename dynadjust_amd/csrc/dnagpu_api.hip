@@ -78,6 +78,7 @@ int ensure_ws(dnagpu_ctx* ctx, int chain, uint32_t np) {
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "inverse workspace allocation", e);
     }
     ws.prof.enabled = prof;
+    ws.fuse = ctx->fuse;
     return DNAGPU_OK;
 }
 
@@ -172,6 +173,11 @@ int check_info(dnagpu_ctx* ctx, int chain) {
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, where ? where : "inverse", e);
     if ((e = hipGetLastError()) != hipSuccess) return fail(ctx, DNAGPU_EHIP, "kernel launch", e);   // (launches of this thread)
     int info = *ctx->ws[chain].info_host;
+    if (info == INFO_BARRIER_TIMEOUT) {
+        // a workgroup of a fused launch waited ~2 s for the others (la_kernels.h): the result is void; counter and expectation restart
+        gemm_fused_reset(ctx->ws[chain]);
+        return fail(ctx, DNAGPU_EHIP, "device-wide barrier of a fused GEMM launch timed out");
+    }
     if (info != INFO_SENTINEL) {
         char buf[128];
         snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (leading minor %d)", info);
@@ -358,6 +364,28 @@ int dnagpu_debug_fail_allocation(long nth) {
 }
 
 long dnagpu_debug_set_small_tiles(long tiles) { return dnagpu::small_tiles_set(tiles); }
+
+int dnagpu_set_fused_launches(dnagpu_ctx* ctx, int on) {
+    if (!ctx) return DNAGPU_EINVAL;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        gemm_flush(ctx->ws[c]);
+        ctx->ws[c].fuse = on != 0;
+        ctx->fuse = on != 0;
+    }
+    return DNAGPU_OK;
+}
+
+int dnagpu_fused_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* products) {
+    if (!ctx) return DNAGPU_EINVAL;
+    uint64_t l = 0, o = 0;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        l += ctx->ws[c].fused_launches;
+        o += ctx->ws[c].fused_ops;
+    }
+    if (launches) *launches = l;
+    if (products) *products = o;
+    return DNAGPU_OK;
+}
 
 int dnagpu_profile_enable(dnagpu_ctx* ctx, int on) {
     CHK_CTX();

@@ -592,6 +592,7 @@ void dna_adjust::PrepareBlocks() {
         ctx_ = nullptr;
         SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
     }
+    if (shares_device_) dnagpu_set_fused_launches(ctx_, 0);
     {
         // a chain costs three matrices of the largest block's order (work matrix, X, W): no more chains than blocks, and
         // no more than half of the free HBM for all of them together

@@ -257,6 +257,7 @@ private:
     std::shared_ptr<DistComm> comm_;
     bool force_distributed_ = false;           // DNAGPU_FORCE_DISTRIBUTED=1: the exchange steps also run with a single rank
     bool in_collective_ = false;               // this instance is being driven as one rank by OnEveryDevice
+    bool shares_device_ = false;               // another instance of this process drives the same GPU
     bool is_peer_ = false;                     // one of the per-GPU instances of a multi-device adjustment
     std::vector<int> owner_;
     std::vector<std::unique_ptr<dna_adjust>> peers_;

@@ -701,6 +701,7 @@ void dna_adjust::PrepareMultiDevice(const project_settings& p) {
             ps.a.dist_rank = r;
             ps.a.dist_world = N;
             a.comm_ = transport == "local" ? local[r] : rccl_comm_create(r, N, id, devs[r]);
+            a.shares_device_ = !distinct;          // several contexts on one GPU: no fused (mutually waiting) launches
             a.PrepareAdjustment(ps);
         });
     } catch (...) {

@@ -25,6 +25,37 @@ struct GemmArgs {
     int k_ascending = 0;    // diagnostic: 1 = walk k upwards also for the k >= i / k >= j ranges (see gemm_f64_dma_kernel)
 };
 
+// ---- fused small launches ---------------------------------------------------------------------------------------------------
+// The bottom of the recursion issues long runs of dependent GEMM launches of a handful of tiles each: between two leaves of a
+// node of 8 tiles there are up to 6 of them, each bound by launch latency (9-15 us for 3 us of MFMA work).  A run of such
+// launches becomes ONE launch of a persistent kernel: its workgroups walk the list of products, 64 x 64 tiles dealt round-robin,
+// and meet at a device-wide barrier (an atomic counter in HBM, release / acquire at agent scope) where the kernel boundary was.
+struct FusedOp {
+    const double* A;
+    const double* B;
+    double* C;
+    int lda, ldb, ldc;
+    int mt, nt;      // 128-wide tiles (the kernel works on 64-wide ones)
+    int K;
+    double alpha, beta;
+    int kmode, lower, mirror;
+    int akc, bkc;    // operand layouts (A_KC / B_KC of the tile kernel)
+};
+constexpr int FUSED_MAX_OPS = 20;
+// Workgroups of a fused launch = the largest tile count of its products, at most this; products with more 64-tiles keep a launch of
+// their own.  All workgroups of a fused launch must be resident together (they wait for each other): 64 x 8 chains = 512 = what the
+// chip holds of this kernel (2 workgroups per CU), so even eight chains in their fused launches at once cannot starve each other.
+constexpr int FUSED_MAX_GRID = 64;
+struct FusedArgs {
+    int nops;
+    unsigned long long* counter;   // device word, only ever incremented; `base` = its value when this launch starts
+    unsigned long long base;
+    int* info;                     // a barrier that is not reached within ~2 s leaves DNAGPU_INFO_BARRIER_TIMEOUT here and the kernel exits
+    FusedOp op[FUSED_MAX_OPS];
+};
+constexpr int INFO_BARRIER_TIMEOUT = -9;
+void launch_gemm_fused(const FusedArgs& f, int grid, hipStream_t s);
+
 // launches with fewer 128-tiles than this run on 64x64 block tiles
 // (cfg3, r02: 160 / 384 / 768 -> 3.83 / 3.79 / 3.77 s per step with four chains, 4.38 / 4.33 / 4.35 s with one)
 constexpr int SMALL_LAUNCH_TILES = 512;

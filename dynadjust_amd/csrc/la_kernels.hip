@@ -164,15 +164,11 @@ __device__ __forceinline__ double frag_read_s(const double* buf, int kk, int rba
     return buf[chunk * 128 + (c * 8 + x) * 2 + (k & 1)];
 }
 
-template <bool A_KC, bool B_KC, int TILE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArgs a) {   // 2nd argument: waves per SIMD (2 workgroups per CU)
+// One TILE x TILE tile of C (it, jt in units of TILE) by the calling workgroup of 64 * WAVES threads; `lds`: 4 * OPBUF doubles.
+// A: the launch's arguments (order / grid unused here).  The caller separates consecutive tiles of one workgroup by a barrier.
+template <bool A_KC, bool B_KC, int TILE, int WAVES, class Args>
+__device__ __forceinline__ void gemm_tile_body(const Args& a, const int it, const int jt, double* lds) {
     using G = Geo<TILE, WAVES>;
-    __shared__ __attribute__((aligned(16))) double lds[4 * G::OPBUF];
-    // tile order table built on the host (tile_order.hip): workgroup b runs on XCD b%8,
-    // every XCD walks its own work-balanced list of 2-D super-tiles (L2 locality).
-    const uint32_t packed = a.order[blockIdx.x];
-    if (packed == 0xffffffffu) return;
-    const int it = (int)(packed >> 16), jt = (int)(packed & 0xffffu);
 
     // triangular operands restrict the k range in units of the 128-wide blocks of the recursion
     const int bi = (it * TILE) / 128, bj = (jt * TILE) / 128;
@@ -358,6 +354,84 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
             }
         }
     }
+}
+
+template <bool A_KC, bool B_KC, int TILE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArgs a) {   // 2nd argument: waves per SIMD (2 workgroups per CU)
+    using G = Geo<TILE, WAVES>;
+    __shared__ __attribute__((aligned(16))) double lds[4 * G::OPBUF];
+    // tile order table built on the host (tile_order.hip): workgroup b runs on XCD b%8,
+    // every XCD walks its own work-balanced list of 2-D super-tiles (L2 locality).
+    const uint32_t packed = a.order[blockIdx.x];
+    if (packed == 0xffffffffu) return;
+    gemm_tile_body<A_KC, B_KC, TILE, WAVES>(a, (int)(packed >> 16), (int)(packed & 0xffffu), lds);
+}
+
+// ---- fused small launches (la_kernels.h) -------------------------------------------------------------------------------------
+// Device-wide barrier between two products of a fused launch.  Every workgroup arrives once per barrier; the counter never
+// goes back, so barrier b of a launch that started at `base` is passed when the counter reaches base + (b + 1) * workgroups.
+// Release / acquire at agent scope: the tiles a workgroup wrote are visible to every XCD's L2 before it arrives, and nothing
+// it reads afterwards comes from a stale line.
+__device__ __forceinline__ bool fused_grid_barrier(unsigned long long* counter, unsigned long long target, int* info) {
+    __shared__ int timed_out;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        timed_out = 0;
+        __atomic_thread_fence(__ATOMIC_RELEASE);                    // (agent scope is the default of the HIP fence builtins below)
+        __threadfence();
+        atomicAdd(counter, 1ULL);
+        long spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1L << 24)) {                              // ~2 s: another workgroup never arrived
+                atomicMin(info, INFO_BARRIER_TIMEOUT);
+                timed_out = 1;
+                break;
+            }
+        }
+        __threadfence();
+    }
+    __syncthreads();
+    __threadfence();                                                // every wave: its later loads must miss the old lines
+    return timed_out == 0;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f64_fused_kernel(FusedArgs f) {
+    using G = Geo<64, 4>;
+    __shared__ __attribute__((aligned(16))) double lds[4 * G::OPBUF];
+    const int nwg = (int)gridDim.x;
+    for (int o = 0; o < f.nops; ++o) {
+        const FusedOp& a = f.op[o];
+        const int mt = 2 * a.mt, nt = 2 * a.nt;
+        const int total = a.lower ? mt * (mt + 1) / 2 : mt * nt;
+        for (int t = (int)blockIdx.x; t < total; t += nwg) {
+            int it, jt;
+            if (a.lower) {
+                it = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while ((it + 1) * (it + 2) / 2 <= t) ++it;
+                while (it * (it + 1) / 2 > t) --it;
+                jt = t - it * (it + 1) / 2;
+            } else {
+                it = t % mt;
+                jt = t / mt;
+            }
+            __syncthreads();        // the previous tile's last fragment reads
+            if (!a.akc && !a.bkc)
+                gemm_tile_body<false, false, 64, 4>(a, it, jt, lds);
+            else if (!a.akc && a.bkc)
+                gemm_tile_body<false, true, 64, 4>(a, it, jt, lds);
+            else if (a.akc && a.bkc)
+                gemm_tile_body<true, true, 64, 4>(a, it, jt, lds);
+            else
+                gemm_tile_body<true, false, 64, 4>(a, it, jt, lds);
+        }
+        if (o + 1 < f.nops && !fused_grid_barrier(f.counter, f.base + (unsigned long long)(o + 1) * (unsigned long long)nwg, f.info)) return;
+    }
+}
+
+void launch_gemm_fused(const FusedArgs& f, int grid, hipStream_t s) {
+    if (f.nops <= 0 || grid <= 0) return;
+    hipLaunchKernelGGL(gemm_f64_fused_kernel, dim3(grid), dim3(256), 0, s, f);
 }
 
 // The throughput kernel: TILE = 128, operands staged with LDS-DMA (no staging registers, no ds_write), two separate

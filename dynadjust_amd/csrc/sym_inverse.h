@@ -9,6 +9,7 @@
 #include <map>
 #include <set>
 #include <vector>
+#include "la_kernels.h"
 
 namespace dnagpu {
 
@@ -40,7 +41,18 @@ struct InvWorkspace {
     // turns it into DNAGPU_ENOMEM / DNAGPU_EHIP instead of trusting `info_host` (a skipped GEMM leaves info at "no failure").
     hipError_t err = hipSuccess;
     const char* err_where = nullptr;
+    // fused small launches (la_kernels.h): products waiting to go out as one launch, the barrier counter and its expected value
+    bool fuse = true;              // (off for contexts that share their GPU with other contexts of the process: dnagpu_set_fused_launches)
+    std::vector<FusedOp> pending;
+    unsigned long long* sync_ctr = nullptr;
+    unsigned long long sync_base = 0;
+    uint64_t fused_launches = 0, fused_ops = 0;
 };
+
+// sends the waiting small products out as one launch (called before anything else is enqueued on ws.stream)
+void gemm_flush(InvWorkspace& ws);
+// after a device-side barrier time-out: counter and expectation back to zero (stream must be idle)
+void gemm_fused_reset(InvWorkspace& ws);
 
 // returns the latched error (and where it happened) and clears it
 hipError_t inv_take_error(InvWorkspace& ws, const char** where);

@@ -19,6 +19,9 @@ hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t st
     if ((e = hipMalloc(&ws.W, bytes)) != hipSuccess) return e;
     if ((e = hipMalloc(&ws.svec, (size_t)np_cap * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&ws.info, sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&ws.sync_ctr, sizeof(unsigned long long))) != hipSuccess) return e;
+    if ((e = hipMemset(ws.sync_ctr, 0, sizeof(unsigned long long))) != hipSuccess) return e;
+    ws.sync_base = 0;
     if ((e = hipHostMalloc(&ws.info_host, sizeof(int))) != hipSuccess) return e;
     *ws.info_host = 0;
     return hipSuccess;
@@ -29,6 +32,7 @@ void inv_workspace_free(InvWorkspace& ws) {
     if (ws.W) hipFree(ws.W);
     if (ws.svec) hipFree(ws.svec);
     if (ws.info) hipFree(ws.info);
+    if (ws.sync_ctr) hipFree(ws.sync_ctr);
     if (ws.info_host) hipHostFree(ws.info_host);
     for (hipEvent_t ev : ws.prof.pool) hipEventDestroy(ev);
     for (auto& kv : ws.order_cache)
@@ -138,7 +142,47 @@ static void profile_event(GemmProfile& p, hipStream_t s) {
     hipEventRecord(p.pool[p.used++], s);
 }
 
+// DNAGPU_FUSE=0: every small product its own launch again (A/B comparisons)
+static bool fuse_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("DNAGPU_FUSE");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+
+void gemm_flush(InvWorkspace& ws) {
+    if (ws.pending.empty()) return;
+    if (ws.err == hipSuccess) {
+        FusedArgs f;
+        f.nops = (int)ws.pending.size();
+        f.counter = ws.sync_ctr;
+        f.base = ws.sync_base;
+        f.info = ws.info;
+        int grid = 1;
+        for (int i = 0; i < f.nops; ++i) {
+            f.op[i] = ws.pending[i];
+            const long mt = 2L * f.op[i].mt, nt = 2L * f.op[i].nt;
+            const long tiles = f.op[i].lower ? mt * (mt + 1) / 2 : mt * nt;
+            grid = (int)std::max<long>(grid, tiles);
+        }
+        launch_gemm_fused(f, grid, ws.stream);
+        inv_note_error(ws, hipGetLastError(), "fused GEMM launch");
+        ws.sync_base += (unsigned long long)grid * (unsigned long long)(f.nops - 1);
+        ws.fused_launches++;
+        ws.fused_ops += (uint64_t)f.nops;
+    }
+    ws.pending.clear();
+}
+
+void gemm_fused_reset(InvWorkspace& ws) {
+    ws.pending.clear();
+    if (ws.sync_ctr) hipMemset(ws.sync_ctr, 0, sizeof(unsigned long long));
+    ws.sync_base = 0;
+}
+
 void gemm_profile_close(InvWorkspace& ws) {
+    gemm_flush(ws);
     GemmProfile& p = ws.prof;
     if (!p.open) return;
     profile_event(p, ws.stream);
@@ -173,6 +217,21 @@ void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
         std::lock_guard<std::mutex> g(h.m);
         h.n[std::make_tuple(a.tile, a.grid, a.K)]++;
     }
+    const long tiles64 = a.lower ? (2L * a.mt) * (2L * a.mt + 1) / 2 : 4L * a.mt * a.nt;
+    if (a.tile == 64 && tiles64 <= FUSED_MAX_GRID && ws.fuse && fuse_enabled() && ws.sync_ctr) {
+        // a small product: waits for its neighbours (gemm_flush sends the run out as one launch)
+        FusedOp op;
+        op.A = a.A; op.B = a.B; op.C = a.C;
+        op.lda = a.lda; op.ldb = a.ldb; op.ldc = a.ldc;
+        op.mt = a.mt; op.nt = a.nt; op.K = a.K;
+        op.alpha = a.alpha; op.beta = a.beta;
+        op.kmode = a.kmode; op.lower = a.lower; op.mirror = a.mirror;
+        op.akc = akc; op.bkc = bkc;
+        ws.pending.push_back(op);
+        if (ws.pending.size() >= (size_t)FUSED_MAX_OPS) gemm_flush(ws);
+        return;
+    }
+    gemm_flush(ws);
     launch_gemm(a, akc, bkc, ws.stream);
     inv_note_error(ws, hipGetLastError(), "tile GEMM launch");
 }
