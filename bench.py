@@ -251,7 +251,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank, dist_rank=rank, dist_world=world,
                                multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
                                schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage,
-                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "0"))))
+                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))))
     a.PrepareAdjustment(p)
     lib, ctx = a.lib, a.device_context()
 

@@ -48,6 +48,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->confidence_interval = 95.0f;
     s->schur_carry = 1;
     s->keep_factors = 1;
+    s->dist_two_level = 1;
 }
 
 int dnaadj_create(dnaadj_handle** out) {

@@ -220,10 +220,10 @@ struct adjust_settings {
     int dist_world = 1;
     std::vector<int> devices;
     std::string dist_transport;      // "" = choose, "rccl", "local"
-    // condensed chains across ranks: 0 = every rank runs both chains on all condensed blocks (one broadcast per block);
-    // 1 = two-level (each rank reduces its own run of blocks, the ranks' boundary systems are scanned, every rank finishes its
-    // own blocks)
-    UINT16 dist_two_level = 0;
+    // condensed chains across ranks: 1 (default) = two-level where possible (each rank reduces its own run of blocks, the ranks'
+    // boundary systems are scanned, every rank finishes its own blocks); 0 = every rank runs both chains on all condensed blocks
+    // (one broadcast per block)
+    UINT16 dist_two_level = 1;
 };
 struct output_settings {
     UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement

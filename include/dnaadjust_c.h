@@ -58,7 +58,8 @@ typedef struct {
     int n_devices;             /* one process for several GPUs: how many entries `devices` has (0 or 1 = `device` only) */
     const int* devices;        /* their HIP ordinals */
     const char* dist_transport;/* NULL = choose; "rccl"; "local" (ranks of one process sharing a GPU) */
-    int dist_two_level;        /* condensed chains across ranks: 0 = on every rank, 1 = two-level (see dnatypes.hpp) */
+    int dist_two_level;        /* condensed chains across ranks (default 1): 1 = two-level where the blocks are one contiguous network and every
+                                  rank owns a run (see dnatypes.hpp; cfg4-sized junction rows: 0.29 s instead of 1.75 s per iteration), 0 = on every rank */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
