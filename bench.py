@@ -260,6 +260,8 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
         st = a.AdjustNetworkDistributed()
         if st != adjust.ADJUST_SUCCESS:
             raise SystemExit(f"adjustment did not converge (status {st})")
+        if args.variance_propagation:
+            a.GenerateStatistics()
 
     for _ in range(args.warmup):
         one_step()
@@ -328,7 +330,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
             "data": "synthetic",
             "config": {"stations": stations, "blocks": B, "iterations_to_converge": its, "mode": "phased", "solves_per_step": solves,
                        "schur_carry": condensed, "keep_factors": any(v["completions"] for v in allv), "parallelism": par,
-                       "driver": "C++ (libdnagpu.so) + RCCL", "blocks_per_rank": [owners.count(r) for r in range(world)]},
+                       "driver": "C++ (libdnagpu.so) + RCCL", "variance_propagation_in_step": bool(args.variance_propagation), "blocks_per_rank": [owners.count(r) for r in range(world)]},
             "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
             "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
             "roofline": {"kernel": "gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
@@ -363,6 +365,10 @@ def main():
                          "eliminating the inner unknowns of the steps that are only carried on")
     ap.add_argument("--no-keep-factors", action="store_true",
                     help="condensed schedule without the retained factors (a.keep_factors = 0): every rigorous solve forms and inverts its block again")
+    ap.add_argument("--variance-propagation", action="store_true",
+                    help="BASELINE.json configs[4]: the timed step also propagates the rigorous variances to every adjusted measurement "
+                         "(GenerateStatistics: precisions of the adjusted measurements A S A^T from the resident variance matrices, chi-square, "
+                         "sigma-zero, N-statistics) -- with `--workload cfg4` on 8 GPUs that is configs[4]")
     ap.add_argument("--no-gemm-events", action="store_true", help="diagnostic: no HIP events around the GEMM launches (roofline.achieved = 0)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
@@ -445,11 +451,15 @@ def main():
         st = a.AdjustNetwork()
         if st != adjust.ADJUST_SUCCESS:
             raise SystemExit(f"adjustment did not converge (status {st})")
+        if args.variance_propagation:
+            a.GenerateStatistics()
 
     for _ in range(args.warmup):
         one_step()
     lib.dnagpu_profile_enable(ctx, 0 if args.no_gemm_events else 1)
     lib.dnagpu_profile_reset(ctx)
+    fl0, fp0 = C.c_uint64(), C.c_uint64()
+    lib.dnagpu_fused_stats(ctx, C.byref(fl0), C.byref(fp0))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -457,6 +467,8 @@ def main():
     lib.dnagpu_sync(ctx)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    fl1, fp1 = C.c_uint64(), C.c_uint64()
+    lib.dnagpu_fused_stats(ctx, C.byref(fl1), C.byref(fp1))
     prof_f, prof_ms, prof_n = C.c_double(), C.c_double(), C.c_uint64()
     lib.dnagpu_profile_get(ctx, C.byref(prof_f), C.byref(prof_ms), C.byref(prof_n))
     lib.dnagpu_profile_enable(ctx, 0)
@@ -492,7 +504,7 @@ def main():
             "max_block_unknowns": info["max_block_unknowns"], "iterations_to_converge": iters, "solves_per_step": solves,
             "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses),
             "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
-            "completions_per_step": a.completion_count(), "parallelism": "1 GPU, one chain" if not p.multi_thread else
+            "completions_per_step": a.completion_count(), "variance_propagation_in_step": bool(args.variance_propagation), "parallelism": "1 GPU, one chain" if not p.multi_thread else
             "1 GPU, %s chains (multi_thread: the independent block steps of the condensed schedule are served by every chain; the two junction chains run side by side)" % os.environ.get("DNAGPU_CHAINS", "4"),
         },
         "cholesky_tflops": (alg / 1e12) / (ms_per_step / 1e3),
@@ -513,7 +525,11 @@ def main():
             "frac_one_chain": one_chain_frac_from_profile(args.workload),
             "traffic": traffic_from_profile(args.workload),
             "traffic_unit": "bytes per launch (memory-side, FETCH_SIZE x 2 + WRITE_SIZE from the committed rocprofv3 --pmc passes of this workload)",
+            # tile-GEMM products per step; of them `fused_products_per_step` went out in `fused_launches_per_step` launches of the
+            # persistent kernel (runs of dependent small products, device-wide barriers in between) instead of one launch each
             "launches_per_step": prof_n.value / args.steps,
+            "fused_products_per_step": (fp1.value - fp0.value) / args.steps,
+            "fused_launches_per_step": (fl1.value - fl0.value) / args.steps,
             "gemm_ms_per_step": gemm_ms_per_step,
             "issued_tflops": (prof_f.value / 1e12) / (prof_ms.value / 1e3) if prof_ms.value > 0 else 0.0,
         },

@@ -234,6 +234,8 @@ int dnagpu_create(int device, dnagpu_ctx** out) {
         dnagpu_destroy(ctx);
         return DNAGPU_ENOMEM;
     }
+    if (const char* e = getenv("DNAGPU_FUSE")) ctx->fuse = atoi(e) != 0;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) ctx->ws[c].fuse = ctx->fuse;
     *out = ctx;
     return DNAGPU_OK;
 }

@@ -30,6 +30,11 @@ struct GemmArgs {
 // node of 8 tiles there are up to 6 of them, each bound by launch latency (9-15 us for 3 us of MFMA work).  A run of such
 // launches becomes ONE launch of a persistent kernel: its workgroups walk the list of products, 64 x 64 tiles dealt round-robin,
 // and meet at a device-wide barrier (an atomic counter in HBM, release / acquire at agent scope) where the kernel boundary was.
+// MEASURED (round 2, profiles/r02_fused_launches.txt): bit-identical results, but no gain -- n = 6 144 inverse 8.68 ms fused against
+// 8.45 ms, cfg3 one chain 4.38 s against 4.35 s, four chains 3.90 s against 3.79 s.  A barrier (L2 write-back + invalidate on
+// every XCD, the atomic round trip) costs what a kernel boundary costs, and workgroups that wait for each other must all be
+// resident before the first barrier is passed -- with other chains' 1 ms tiles filling the chip that wait is longer than the launch
+// latencies saved.  Off by default (dnagpu_set_fused_launches / DNAGPU_FUSE=1 switch it on).
 struct FusedOp {
     const double* A;
     const double* B;

@@ -42,7 +42,7 @@ struct InvWorkspace {
     hipError_t err = hipSuccess;
     const char* err_where = nullptr;
     // fused small launches (la_kernels.h): products waiting to go out as one launch, the barrier counter and its expected value
-    bool fuse = true;              // (off for contexts that share their GPU with other contexts of the process: dnagpu_set_fused_launches)
+    bool fuse = false;             // opt-in (dnagpu_set_fused_launches, DNAGPU_FUSE=1): measured no gain, see la_kernels.h
     std::vector<FusedOp> pending;
     unsigned long long* sync_ctr = nullptr;
     unsigned long long sync_base = 0;

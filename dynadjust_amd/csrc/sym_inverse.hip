@@ -142,15 +142,6 @@ static void profile_event(GemmProfile& p, hipStream_t s) {
     hipEventRecord(p.pool[p.used++], s);
 }
 
-// DNAGPU_FUSE=0: every small product its own launch again (A/B comparisons)
-static bool fuse_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("DNAGPU_FUSE");
-        return !e || atoi(e) != 0;
-    }();
-    return on;
-}
-
 void gemm_flush(InvWorkspace& ws) {
     if (ws.pending.empty()) return;
     if (ws.err == hipSuccess) {
@@ -218,7 +209,7 @@ void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
         h.n[std::make_tuple(a.tile, a.grid, a.K)]++;
     }
     const long tiles64 = a.lower ? (2L * a.mt) * (2L * a.mt + 1) / 2 : 4L * a.mt * a.nt;
-    if (a.tile == 64 && tiles64 <= FUSED_MAX_GRID && ws.fuse && fuse_enabled() && ws.sync_ctr) {
+    if (a.tile == 64 && tiles64 <= FUSED_MAX_GRID && ws.fuse && ws.sync_ctr) {
         // a small product: waits for its neighbours (gemm_flush sends the run out as one launch)
         FusedOp op;
         op.A = a.A; op.B = a.B; op.C = a.C;

@@ -99,8 +99,8 @@ int dnagpu_debug_fail_allocation(long nth);
 /* Launches with fewer than `tiles` 128 x 128 tiles use the 64-tile latency kernel (default 160); 0 sends every launch through the
  * 128-tile throughput kernel (gemm_f64_dma_kernel), a negative value restores the default.  Returns the previous value. */
 long dnagpu_debug_set_small_tiles(long tiles);
-/* Small products of the recursion (fewer tiles than the threshold above) go out in runs: one launch of a persistent kernel per run,
- * device-wide barriers between the products (DNAGPU_FUSE=0: one launch each).  Totals since the context was created. */
+/* Opt-in experiment (off by default: measured no gain, la_kernels.h): runs of dependent small products of the recursion as ONE launch of a
+ * persistent kernel, device-wide barriers between the products (DNAGPU_FUSE=1 or dnagpu_set_fused_launches).  Totals since the context was created. */
 int dnagpu_fused_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* products);
 /* The workgroups of a fused launch wait for each other, so all of them must be resident: fine for the chains of one context (up to
  * 8 x 64 workgroups = what the GPU holds), not for many contexts driving one GPU at once -- those switch it off (on = 0). */

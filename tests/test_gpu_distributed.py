@@ -69,11 +69,11 @@ def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt
     assert f.AdjustNetwork() == st
     f.GenerateStatistics()
     f.SerialiseAdjustedVarianceMatrices()
-    assert np.abs(_stats(a) - _stats(f)).max() < 1e-9 * max(1.0, np.abs(_stats(f)).max())
+    assert np.abs(_stats(a) - _stats(f)).max() < 1e-7 * max(1.0, np.abs(_stats(f)).max())    # (chi-square: a sum over 3 000 squared residuals)
     ra = np.frombuffer(a.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
     rf = np.frombuffer(f.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
     for nm in ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel"):
-        assert np.abs(ra[nm] - rf[nm]).max() <= 1e-9 * max(1.0, np.abs(rf[nm]).max()), nm
+        assert np.abs(ra[nm] - rf[nm]).max() <= 1e-7 * max(1.0, np.abs(rf[nm]).max()), nm
     for suffix, tol in (("rva", 1e-9), ("pam", 1e-9)):
         da = np.fromfile(tmp_path / "multi" / f"n-{suffix}.mtx", dtype=np.uint8)
         df = np.fromfile(tmp_path / "single" / f"n-{suffix}.mtx", dtype=np.uint8)
