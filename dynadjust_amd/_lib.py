@@ -196,6 +196,7 @@ def load():
     _sig(lib, "dnaadj_adjusted_coordinates", i, [vp, c_f64p])
     _sig(lib, "dnaadj_device_context", vp, [vp])
     _sig(lib, "dnaimport_text", i, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(DnaImportSummary), C.c_char_p, sz])
+    _sig(lib, "dnaimport_text_geo", i, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(DnaImportSummary), C.c_char_p, sz])
     _sig(lib, "dnaadj_dist_rccl_available", i, [])
     _sig(lib, "dnaadj_dist_unique_id", i, [C.c_char_p, C.c_char_p, sz])
     _sig(lib, "dnaadj_dist_attach_rccl", i, [vp, i, i, C.c_char_p, i])
@@ -282,7 +283,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_completion_count", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
-    "dnaimport_text", "dnaadj_dist_rccl_available", "dnaadj_dist_unique_id", "dnaadj_dist_attach_rccl", "dnaadj_adjust_distributed", "dnaadj_dist_info",
+    "dnaimport_text", "dnaimport_text_geo", "dnaadj_dist_rccl_available", "dnaadj_dist_unique_id", "dnaadj_dist_attach_rccl", "dnaadj_adjust_distributed", "dnaadj_dist_info",
     "dnaadj_block_owner", "dnaadj_exchange_stats", "dnaadj_device_instance_context",
     "dnaadj_generate_statistics", "dnaadj_get_statistics", "dnaadj_measurement_record_count", "dnaadj_measurement_records",
     "dnaadj_block_prec_adj_msrs_count", "dnaadj_block_prec_adj_msrs", "dnaadj_serialise_adjusted_variance_matrices",

@@ -286,13 +286,15 @@ class DnaAdjust:
         return self.lib.dnaadj_device_context(self.h)
 
 
-def import_dna_text(stn_file, msr_file, out_base):
-    """DNA text station / measurement files -> out_base.bst / .bms / .asl (GNSS measurements aligned to the stations' frame)"""
+def import_dna_text(stn_file, msr_file, out_base, geo_file=None):
+    """DNA text station / measurement files (+ optional DNA geoid file) -> out_base.bst / .bms / .asl (GNSS measurements aligned to the
+    stations' frame)"""
     from ._lib import DnaImportSummary
     lib = _lib.load()
     out = DnaImportSummary()
     err = C.create_string_buffer(512)
-    if lib.dnaimport_text(os.fsencode(stn_file), os.fsencode(msr_file), os.fsencode(out_base), C.byref(out), err, 512) != 0:
+    if lib.dnaimport_text_geo(os.fsencode(stn_file), os.fsencode(msr_file), os.fsencode(geo_file) if geo_file else None, os.fsencode(out_base),
+                              C.byref(out), err, 512) != 0:
         raise RuntimeError("dnaimport_text: " + err.value.decode(errors="replace"))
     return {k: getattr(out, k) for k, _ in DnaImportSummary._fields_}
 

@@ -113,10 +113,15 @@ int dnaadj_adjust(dnaadj_handle* h, int* status) {
 }
 
 int dnaimport_text(const char* stn_file, const char* msr_file, const char* out_base, dnaimport_summary* out, char* err, size_t errlen) {
+    return dnaimport_text_geo(stn_file, msr_file, nullptr, out_base, out, err, errlen);
+}
+
+int dnaimport_text_geo(const char* stn_file, const char* msr_file, const char* geo_file, const char* out_base, dnaimport_summary* out, char* err,
+                       size_t errlen) {
     if (!stn_file || !msr_file || !out_base) return DNAADJ_EINVAL;
     try {
         dynadjust::import::import_summary s;
-        dynadjust::import::import_dna_text(stn_file, msr_file, out_base, &s);
+        dynadjust::import::import_dna_text(stn_file, msr_file, out_base, &s, geo_file ? geo_file : "");
         if (out) {
             out->stations = s.stations;
             out->records = s.records;

@@ -81,6 +81,27 @@ bool comment_or_blank(const std::string& l) { return l.empty() || l[0] == '*' ||
 
 }  // namespace
 
+void utm_to_geographic(double easting, double northing, int zone, double* lat, double* lon) {
+    const double a = geodesy::GRS80_A, f = 1.0 / geodesy::GRS80_INV_F, k0 = 0.9996, fe = 500000.0, fn = 10000000.0;
+    const double n = f / (2.0 - f), n2 = n * n, n3 = n2 * n, n4 = n3 * n;
+    const double A = a / (1.0 + n) * (1.0 + n2 / 4.0 + n4 / 64.0 + n4 * n2 / 256.0);
+    const double beta[4] = {n / 2 - 2 * n2 / 3 + 37 * n3 / 96 - n4 / 360, n2 / 48 + n3 / 15 - 437 * n4 / 1440, 17 * n3 / 480 - 37 * n4 / 840,
+                            4397 * n4 / 161280};
+    const double delta[4] = {2 * n - 2 * n2 / 3 - 2 * n3 + 116 * n4 / 45, 7 * n2 / 3 - 8 * n3 / 5 - 227 * n4 / 45, 56 * n3 / 15 - 136 * n4 / 35,
+                             4279 * n4 / 630};
+    const double xi = (northing - fn) / (k0 * A), eta = (easting - fe) / (k0 * A);
+    double xi1 = xi, eta1 = eta;
+    for (int j = 0; j < 4; ++j) {
+        xi1 -= beta[j] * std::sin(2 * (j + 1) * xi) * std::cosh(2 * (j + 1) * eta);
+        eta1 -= beta[j] * std::cos(2 * (j + 1) * xi) * std::sinh(2 * (j + 1) * eta);
+    }
+    const double chi = std::asin(std::sin(xi1) / std::cosh(eta1));
+    double phi = chi;
+    for (int j = 0; j < 4; ++j) phi += delta[j] * std::sin(2 * (j + 1) * chi);
+    *lat = phi;
+    *lon = (zone * 6 - 183) * PI / 180.0 + std::atan2(std::sinh(eta1), std::cos(xi1));
+}
+
 bool helmert_to_gda2020(const std::string& frame, double p[14], double* reference_epoch) {
     struct set_t {
         const char* frame;
@@ -128,7 +149,8 @@ void transform_point_to_gda2020(const double p[14], double reference_epoch, doub
     }
 }
 
-void import_dna_text(const std::string& stn_file, const std::string& msr_file, const std::string& out_base, import_summary* summary) {
+void import_dna_text(const std::string& stn_file, const std::string& msr_file, const std::string& out_base, import_summary* summary,
+                     const std::string& geo_file) {
     import_summary sum;
     // ---- stations ---------------------------------------------------------------------------------------------------------
     std::ifstream sf(stn_file);
@@ -153,7 +175,8 @@ void import_dna_text(const std::string& stn_file, const std::string& msr_file, c
         memset(&st, 0, sizeof(st));
         const std::string name = field(line, 0, 20), con = field(line, 20, 3), type = field(line, 24, 3);
         if (name.empty() || con.size() != 3) throw std::runtime_error(stn_file + ": malformed station line: " + line);
-        const std::vector<double> v = numbers(line.size() > 27 ? line.substr(27, 60) : std::string());
+        // (a UTM record carries its zone behind the three coordinate columns)
+        const std::vector<double> v = numbers(line.size() > 27 ? (type == "UTM" ? line.substr(27) : line.substr(27, 60)) : std::string());
         if (v.size() < 3) throw std::runtime_error(stn_file + ": station " + name + " has no coordinates");
         double lat, lon, h;
         if (type == "LLH" || type == "LLh") {
@@ -166,17 +189,31 @@ void import_dna_text(const std::string& stn_file, const std::string& msr_file, c
             geodesy::CartToGeo(v[0], v[1], v[2], &lat, &lon, &h);
             st.suppliedStationType = XYZ_type_i;
             st.suppliedHeightRefFrame = ELLIPSOIDAL_type_i;
+        } else if (type == "UTM") {
+            if (v.size() < 4) throw std::runtime_error(stn_file + ": UTM station " + name + " has no zone");
+            utm_to_geographic(v[0], v[1], (int)v[3], &lat, &lon);
+            h = v[2];
+            st.suppliedStationType = UTM_type_i;
+            st.suppliedHeightRefFrame = ORTHOMETRIC_type_i;
+            st.zone = (short)v[3];
         } else {
-            throw std::runtime_error(stn_file + ": station coordinate type '" + type + "' is not supported by this importer (LLH, LLh, XYZ)");
+            throw std::runtime_error(stn_file + ": station coordinate type '" + type + "' is not supported by this importer (LLH, LLh, XYZ, UTM)");
         }
         put(st.stationName, sizeof(st.stationName), name);
         put(st.stationNameOrig, sizeof(st.stationNameOrig), name);
         put(st.stationConst, sizeof(st.stationConst), con);
-        put(st.stationType, sizeof(st.stationType), "LLH");
+        put(st.stationType, sizeof(st.stationType), type == "UTM" ? "UTM" : "LLH");
         st.initialLatitude = st.currentLatitude = lat;
         st.initialLongitude = st.currentLongitude = lon;
         st.initialHeight = st.currentHeight = h;
-        put(st.description, sizeof(st.description), line.size() > 87 ? trim(line.substr(87)) : std::string());
+        {
+            std::string desc = line.size() > 87 ? trim(line.substr(87)) : std::string();
+            if (type == "UTM") {                     // "<zone> <description>"
+                size_t sp = desc.find(' ');
+                desc = sp == std::string::npos ? std::string() : trim(desc.substr(sp));
+            }
+            put(st.description, sizeof(st.description), desc);
+        }
         st.fileOrder = st.nameOrder = (UINT32)stations.size();
         auto code = epsg_codes().find(sum.station_frame);
         put(st.epsgCode, sizeof(st.epsgCode), code == epsg_codes().end() ? std::string("7843") : code->second);
@@ -185,6 +222,27 @@ void import_dna_text(const std::string& stn_file, const std::string& msr_file, c
         stations.push_back(st);
     }
     if (stations.empty()) throw std::runtime_error(stn_file + ": no stations");
+    if (!geo_file.empty()) {
+        // dnageoid (dnageoid.cpp:815 writes this file): N and the deflections per station; orthometric heights become ellipsoidal
+        std::ifstream gf(geo_file);
+        if (!gf) throw std::runtime_error("cannot open " + geo_file);
+        const double sec = PI / 648000.0;
+        while (std::getline(gf, line)) {
+            if (line.empty() || line[0] == '#' || line[0] == '!' || line[0] == '*' || trim(line).empty()) continue;
+            const std::string name = field(line, 0, 41);
+            const std::vector<double> v = numbers(line.size() > 41 ? line.substr(41) : std::string());
+            auto it = index.find(name);
+            if (it == index.end() || v.size() < 3) continue;
+            station_t& st = stations[it->second];
+            st.geoidSep = (float)v[0];
+            st.meridianDef = v[1] * sec;
+            st.verticalDef = v[2] * sec;
+            if (st.suppliedHeightRefFrame == ORTHOMETRIC_type_i) {
+                st.initialHeight += v[0];
+                st.currentHeight += v[0];
+            }
+        }
+    }
     // ---- measurements -----------------------------------------------------------------------------------------------------
     std::ifstream mf(msr_file);
     if (!mf) throw std::runtime_error("cannot open " + msr_file);
@@ -215,9 +273,64 @@ void import_dna_text(const std::string& stn_file, const std::string& msr_file, c
     while (i < lines.size()) {
         const std::string& head = lines[i];
         const char t = head[0];
-        if (t != 'G' && t != 'X' && t != 'Y')
-            throw std::runtime_error(msr_file + ": measurement type '" + std::string(1, t) + "' is not supported by this importer (GNSS types G, X, Y)");
         const bool ignore = head.size() > 1 && head[1] == '*';
+        if (t != 'G' && t != 'X' && t != 'Y') {
+            // one-line terrestrial measurement (dnaimport: term1 = value, term2 = variance, term3 / term4 = instrument / target height)
+            static const std::string supported = "ABCEHKLMRSVZ", angular = "ABKVZ", with_heights = "SVZ";
+            if (supported.find(t) == std::string::npos)
+                throw std::runtime_error(msr_file + ": measurement type '" + std::string(1, t) + "' is not supported by this importer");
+            std::vector<std::string> names = {field(head, 2, 20), field(head, 22, 20), field(head, 42, 20)};
+            std::vector<UINT32> ids;
+            for (const std::string& nm : names)
+                if (!nm.empty()) ids.push_back(station_of(nm));
+            std::istringstream ts(head.size() > 62 ? head.substr(62) : std::string());
+            std::vector<std::string> tok;
+            std::string w;
+            while (ts >> w) tok.push_back(w);
+            double value = 0.0, sd = 0.0;
+            size_t used = 0;
+            const double sec = PI / 648000.0;
+            if (angular.find(t) != std::string::npos) {
+                if (tok.size() < 4) throw std::runtime_error(msr_file + ": malformed angular measurement: " + head);
+                const double sgn = tok[0][0] == '-' ? -1.0 : 1.0;
+                value = sgn * (std::fabs(atof(tok[0].c_str())) + atof(tok[1].c_str()) / 60.0 + atof(tok[2].c_str()) / 3600.0) * PI / 180.0;
+                sd = atof(tok[3].c_str()) * sec;
+                used = 4;
+            } else {
+                if (tok.size() < 2) throw std::runtime_error(msr_file + ": malformed measurement: " + head);
+                value = atof(tok[0].c_str());
+                sd = atof(tok[1].c_str());
+                used = 2;
+            }
+            const size_t need = (t == 'A') ? 3 : (std::string("HRIJPQ").find(t) != std::string::npos ? 1 : 2);
+            if (ids.size() != need) throw std::runtime_error(msr_file + ": wrong number of stations: " + head);
+            measurement_t m;
+            memset(&m, 0, sizeof(m));
+            m.measType = t;
+            m.measurementStations = (char)ids.size();
+            auto code = epsg_codes().find(sum.station_frame);
+            put(m.epsgCode, sizeof(m.epsgCode), code == epsg_codes().end() ? std::string("7843") : code->second);
+            put(m.epoch, sizeof(m.epoch), sum.station_epoch);
+            put(m.coordType, sizeof(m.coordType), "XYZ");
+            m.ignore = ignore;
+            m.station1 = ids[0];
+            m.station2 = ids.size() > 1 ? ids[1] : 0;
+            m.station3 = ids.size() > 2 ? ids[2] : 0;
+            m.clusterID = m.fileOrder = ++cluster_id;
+            m.scale1 = m.scale2 = m.scale3 = m.scale4 = 1.0;
+            m.term1 = m.preAdjMeas = value;
+            m.term2 = sd * sd;
+            if (with_heights.find(t) != std::string::npos && tok.size() >= used + 2) {
+                m.term3 = atof(tok[used].c_str());
+                m.term4 = atof(tok[used + 1].c_str());
+            }
+            recs.push_back(m);
+            if (!ignore)
+                for (UINT32 id : ids) counts[id]++;
+            sum.clusters++;
+            ++i;
+            continue;
+        }
         const bool point = t == 'Y';
         const std::string coord_type = point ? field(head, 22, 20) : std::string("XYZ");
         UINT32 k = 1;
@@ -271,6 +384,10 @@ void import_dna_text(const std::string& stn_file, const std::string& msr_file, c
                 for (int c = 0; c <= r; ++c) V[c][r] = V[r][c] = v[1 + c];
             }
             i += 4;
+            if (point && (coord_type == "LLH" || coord_type == "LLh")) {     // latitude / longitude as ddd.mmssss
+                obs[0] = dms_to_radians(obs[0]);
+                obs[1] = dms_to_radians(obs[1]);
+            }
             if (transform && !ignore) {
                 if (point) {
                     if (coord_type != "XYZ") throw std::runtime_error(msr_file + ": only cartesian point clusters can be transformed by this importer");

@@ -34,8 +34,19 @@ double decimal_year(const std::string& ddmmyyyy);
 // (epoch - reference epoch) (ReduceParameters / Transform_7parameter, dnatemplatematrixfuncs.hpp:729-806)
 void transform_point_to_gda2020(const double params14[14], double reference_epoch, double epoch, const double in[3], double out[3]);
 
-// Throws std::runtime_error on malformed input, unknown stations, unsupported measurement types (terrestrial) or frames.
-void import_dna_text(const std::string& stn_file, const std::string& msr_file, const std::string& out_base, import_summary* summary = nullptr);
+// MGA / UTM grid coordinates -> latitude, longitude (radians): Krueger series on GRS80 (GDA technical manual), southern hemisphere
+void utm_to_geographic(double easting, double northing, int zone, double* lat, double* lon);
+
+// Throws std::runtime_error on malformed input, unknown stations, unsupported measurement types or frames.
+//   stations      LLH / LLh (ddd.mmssss), XYZ, UTM (easting northing height zone)
+//   measurements  GNSS: G, X, Y (cartesian, or LLH / LLh point clusters); terrestrial: A (horizontal angle), B / K (geodetic / astronomic
+//                 azimuth), C / E / M (chord, ellipsoid arc, MSL arc), S (slope distance), V / Z (zenith distance, vertical angle), L (height
+//                 difference), H / R (orthometric / ellipsoidal height) -- angles d m s with standard deviations in seconds, lengths in
+//                 metres; S, V, Z carry instrument and target heights (dnaimport: term1 value, term2 variance, term3 / term4 heights)
+//   geo_file      optional DNA geoid file (dnageoid's export: station, N [m], deflections in the meridian / prime vertical [seconds]):
+//                 geoid separation and deflections into the station records, orthometric station heights (LLH, UTM) to ellipsoidal
+void import_dna_text(const std::string& stn_file, const std::string& msr_file, const std::string& out_base, import_summary* summary = nullptr,
+                     const std::string& geo_file = std::string());
 
 }  // namespace import
 }  // namespace dynadjust

@@ -219,6 +219,10 @@ typedef struct {
     uint64_t stations, records, vectors, clusters, vectors_transformed;
 } dnaimport_summary;
 int dnaimport_text(const char* stn_file, const char* msr_file, const char* out_base, dnaimport_summary* out, char* err, size_t errlen);
+/* the same with a DNA geoid file (station, N, deflections: what dnageoid exports; may be NULL) and the terrestrial measurement types
+ * A B C E H K L M R S V Z, UTM stations, LLH point clusters: the reference's urban sample (sampleData/urban-network.{stn,msr,geo}) */
+int dnaimport_text_geo(const char* stn_file, const char* msr_file, const char* geo_file, const char* out_base, dnaimport_summary* out, char* err,
+                       size_t errlen);
 
 /* ---- synthetic networks: writes <dir>/<name>.{bst,bms,asl,seg,truth} ---- */
 typedef struct {

@@ -42,6 +42,49 @@ def test_sample_network_matches_the_reference_report(built, golden_dir, tmp_path
     assert np.array_equal(np.asarray(F.read_asl(base + ".asl")), np.asarray(F.read_asl(ref_base + ".asl")))
 
 
+def test_urban_sample_equals_the_test_side_import(built, golden_dir, tmp_path):
+    """the reference's urban sample (UTM stations, 1 112 measurements of types A B G H K L M S V Y Z, 17 ignored, a 4-point LLH
+    cluster, the exported geoid file) through the product's importer: the same station and measurement records, field by field, as
+    the test-side importer whose files the oracle and the device adjust onto the reference's urban.phased.adj.expected
+    (tests/test_oracle_terrestrial.py, tests/test_gpu_terrestrial.py).  One documented difference: the geoid separation comes from
+    the .geo file (3 decimals) here, refined to 4 decimals from the report's h - H columns there."""
+    from tests import urban_net as U
+    g = golden_dir
+    s = adjust.import_dna_text(os.path.join(g, "urban-network.stn"), os.path.join(g, "urban-network.msr"), str(tmp_path / "p"),
+                               os.path.join(g, "urban-network.geo"))
+    assert s["stations"] == 149 and s["clusters"] == 1112 and s["vectors_transformed"] == 0
+    stations, msrs, rep, bst, bms, first_of = U.build_urban_sample(g, str(tmp_path / "t"))
+    pb, pm = F.read_bst(str(tmp_path / "p.bst")), F.read_bms(str(tmp_path / "p.bms"))
+    assert len(pb) == len(bst) == 149 and len(pm) == len(bms)
+    for f in ("stationName", "stationConst", "suppliedStationType"):
+        assert np.array_equal(pb[f], bst[f]), f
+    for f in ("currentLatitude", "currentLongitude", "meridianDef", "verticalDef"):
+        assert np.abs(pb[f] - bst[f]).max() < 1e-14, f
+    assert np.abs(pb["geoidSep"].astype(float) - bst["geoidSep"].astype(float)).max() < 5.1e-4          # .geo: 3 decimals
+    assert np.abs((pb["currentHeight"] - pb["geoidSep"]) - (bst["currentHeight"] - bst["geoidSep"])).max() < 1e-6   # the supplied H
+    for f in ("measType", "measStart", "ignore", "station1", "station2", "station3", "vectorCount1", "vectorCount2", "clusterID",
+              "measurementStations", "term2", "term3", "term4", "scale4"):
+        assert np.array_equal(pm[f], bms[f]), f
+    for f in ("term1", "preAdjMeas"):
+        assert np.abs(pm[f] - bms[f]).max() < 1e-14, f
+    assert np.array_equal(np.asarray(F.read_asl(str(tmp_path / "p.asl"))), np.asarray(F.read_asl(str(tmp_path / "t.asl"))))
+
+
+def test_utm_against_the_test_side_series(built):
+    import ctypes as C
+    from tests import urban_net as U
+    lat, lon = U.utm_to_geo(320236.2750, 5813988.8399, 55)
+    import tempfile
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "u.stn"), "w").write("!#=DNA 3.01 STN    01.01.2020       GDA2020    01.01.2020         1\n"
+                                              "1                   FFF UTM         320236.2750        5813988.8399             31.4770 55 1   \n")
+    open(os.path.join(d, "u.msr"), "w").write("!#=DNA 3.01 MSR    01.01.2020       GDA2020    01.01.2020         0\n")
+    adjust.import_dna_text(os.path.join(d, "u.stn"), os.path.join(d, "u.msr"), os.path.join(d, "u"))
+    bst = F.read_bst(os.path.join(d, "u.bst"))
+    assert abs(bst["currentLatitude"][0] - lat) < 1e-14 and abs(bst["currentLongitude"][0] - lon) < 1e-14
+    assert -0.67 < lat < -0.65 and 2.5 < lon < 2.55          # Melbourne
+
+
 def test_frame_alignment_formulas(built):
     """decimal year and 14-parameter transformation against hand-computed values"""
     import ctypes as C
@@ -68,9 +111,9 @@ def test_frame_alignment_formulas(built):
 
 
 @pytest.mark.parametrize("stn,msr,message", [
-    ("A                   FFF UTM        500000.0000        6000000.0000            10.0000    \n", "", "not supported"),
+    ("A                   FFF ENU        500000.0000        6000000.0000            10.0000    \n", "", "not supported"),
     ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
-     "S A                   A                                     100.0 0.01\n", "not supported"),
+     "D A                   A                                                           100.0 0.01\n", "not supported"),
     ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
      "G A                   NOWHERE                                       1.00      1.00      1.00      1.00             GDA2020          01.01.2020\n"
      "   1.0 1e-6\n   1.0 0 1e-6\n   1.0 0 0 1e-6\n", "is not in the station file"),
