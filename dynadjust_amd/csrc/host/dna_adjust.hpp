@@ -86,6 +86,10 @@ public:
     bool GetMessageIteration(UINT32& iteration);
     std::string GetIterationTime(const UINT32& iteration) const;
     inline int64_t LastBlockElapsedMs() const { return lastBlockElapsedMs_; }
+    // dnaadjust.hpp:333-334 (--max-blas-threads): the BLAS of the reference runs on host cores; here the dense work runs on the device, so
+    // the value is kept for the caller and otherwise unused
+    static void SetMaxBlasThreads(int n) { max_blas_threads_ = n; }
+    static int GetMaxBlasThreads() { return max_blas_threads_; }
     inline void SetExceptionRaised() { exceptionRaised_ = true; }                  // dnaadjust.hpp:271
     void LoadSegmentationFileParameters(const std::string& seg_filename);           // ADJ:10628: block count of a .seg file
     void DeSerialiseAdjustedVarianceMatrices();                                     // ADJ:6720: -rva.mtx / -pam.mtx back into the blocks
@@ -377,6 +381,7 @@ private:
     }
     void FreeDevice();
 
+    static inline int max_blas_threads_ = 0;
     project_settings projectSettings_;
     std::vector<station_t> bstBinaryRecords_;
     std::vector<measurement_t> bmsBinaryRecords_;

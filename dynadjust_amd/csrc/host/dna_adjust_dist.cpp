@@ -209,7 +209,8 @@ void dna_adjust::FreeTwoLevel() {
 void dna_adjust::PrepareTwoLevel() {
     FreeTwoLevel();
     const int W = DistWorld(), me = DistRank();
-    if (W < 2 || !projectSettings_.a.dist_two_level || !CondensedSchedule() || ReuseRequested()) return;
+    // (every condition below is the same on every rank: nothing that depends on a rank's free memory)
+    if (W < 2 || !projectSettings_.a.dist_two_level || !CondensedSchedule() || projectSettings_.a.reuse_inverses != 0) return;
     // one contiguous network, every rank a run of at least one block
     if (!v_blockMeta_[0]._blockFirst || !v_blockMeta_[blockCount_ - 1]._blockLast) return;
     for (UINT32 k = 0; k < blockCount_; ++k) {
