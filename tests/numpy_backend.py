@@ -331,3 +331,197 @@ class NumpyBlockBackend:
     def set_coords(self, k, xyz):
         d = self.blk[k]
         d["orig"], d["est"], d["rig"] = xyz.copy(), xyz.copy(), xyz.copy()
+
+
+# ---- two-level condensed chains (dna_adjust_dist.cpp: ReduceOwnRun / ExchangeRuns / ScanRuns / OwnRunChains), dense numpy restatement ----
+def contiguous_owners(costs, world):
+    """dna_adjust::ComputeBlockOwners(condensed): contiguous runs, the largest run's cost as small as possible"""
+    B = len(costs)
+
+    def parts(cap):
+        n, load = 1, 0.0
+        for c in costs:
+            if load + c > cap and load > 0.0:
+                n, load = n + 1, 0.0
+            load += c
+        return n
+    lo, hi = max(costs), sum(costs)
+    for _ in range(80):
+        mid = 0.5 * (lo + hi)
+        if parts(mid) <= world:
+            hi = mid
+        else:
+            lo = mid
+    cap = hi * (1.0 + 1e-12)
+    owner, r, load = [], 0, 0.0
+    for k, c in enumerate(costs):
+        if load + c > cap and load > 0.0 and r + 1 < world:
+            r, load = r + 1, 0.0
+        if B - k <= world - 1 - r and load > 0.0 and r + 1 < world:
+            r, load = r + 1, 0.0
+        owner.append(r)
+        load += c
+    return owner
+
+
+class TwoLevelMixin:
+    """added to NumpyBlockBackend below: a run of condensed blocks reduced to the stations of its two ends, the chains over the runs,
+    the chains inside a run"""
+
+    def _gid(self, k, keep_pos_list):
+        return [int(self.blk[k]["st"][p]) for p in keep_pos_list]
+
+    def run_ends(self, a, b):
+        """global ids of the junction stations towards the previous run (JSL(a-1) order) and the next run (JSL(b) order)"""
+        L = [] if self.flags_[a][0] else list(self.blk[a - 1]["jsl"])
+        R = [] if self.flags_[b][1] else list(self.blk[b]["jsl"])
+        return L, R
+
+    def _system_of_block(self, k):
+        keep, _, _ = self._kept(k)
+        S, r = self.red[k]
+        return self._gid(k, keep), S.copy(), r.copy()
+
+    @staticmethod
+    def _merge(sys1, sys2):
+        g1, S1, r1 = sys1
+        g2, S2, r2 = sys2
+        U = sorted(set(g1) | set(g2))
+        pos = {g: i for i, g in enumerate(U)}
+        n = 3 * len(U)
+        S, r = np.zeros((n, n)), np.zeros(n)
+        for g, Sx, rx in ((g1, S1, r1), (g2, S2, r2)):
+            idx = np.array([3 * pos[s] + c for s in g for c in range(3)], dtype=np.int64)
+            S[np.ix_(idx, idx)] += Sx
+            r[idx] += rx
+        return U, S, r
+
+    @staticmethod
+    def _eliminate(system, stay):
+        g, S, r = system
+        stay = [s for s in g if s in set(stay)]
+        rk = np.array([3 * g.index(s) + c for s in stay for c in range(3)], dtype=np.int64)
+        ri = np.array([3 * i + c for i, s in enumerate(g) if s not in set(stay) for c in range(3)], dtype=np.int64)
+        if len(ri) == 0:
+            return stay, S[np.ix_(rk, rk)], r[rk]
+        X = np.linalg.solve(S[np.ix_(ri, ri)], np.column_stack([S[np.ix_(ri, rk)], r[ri]]))
+        return stay, S[np.ix_(rk, rk)] - S[np.ix_(rk, ri)] @ X[:, :-1], r[rk] - S[np.ix_(rk, ri)] @ X[:, -1]
+
+    def _add_first_constraints(self, system, blocks, which, only=None, exclude=None):
+        """direction dependent constraint of every station of `system` whose first appearance (forward / reverse) is in one of `blocks`"""
+        g, S, r = system
+        for k in blocks:
+            d = self.blk[k]
+            for p, s in enumerate(d["st"]):
+                s = int(s)
+                if s not in g or not d[which][p]:
+                    continue
+                if only is not None and s not in only:
+                    continue
+                if exclude is not None and s in exclude:
+                    continue
+                q = 3 * g.index(s)
+                S[q:q + 3, q:q + 3] += self._weight(s) * np.eye(3)
+
+    def reduce_run(self, a, b):
+        """level 1: (stations, S, r) of the run a..b on the stations of its two ends"""
+        L, R = self.run_ends(a, b)
+        ends = set(L) | set(R)
+        system = self._system_of_block(a)
+        for k in range(a + 1, b + 1):
+            system = self._merge(system, self._system_of_block(k))
+            # stations that leave inside the run take their constraint where the forward chain adds it (first appearance)
+            self._add_first_constraints(system, [a, k] if k == a + 1 else [k], "first_fwd", exclude=ends)
+            nxt = [] if self.flags_[k][1] else list(self.blk[k]["jsl"])
+            system = self._eliminate(system, set(L) | set(nxt))
+        g, S, r = system
+        assert set(g) == ends, (sorted(g), sorted(ends))
+        return system
+
+    def _x0(self, stations, a, b):
+        out = np.zeros(3 * len(stations))
+        for i, s in enumerate(stations):
+            k = a if s in self.blk[a]["loc"] else b
+            p = self.blk[k]["loc"][s]
+            out[3 * i:3 * i + 3] = self.blk[k]["orig"][3 * p:3 * p + 3]
+        return out
+
+    def scan_runs(self, runs, systems):
+        """level 2: forward and reverse chain over the runs; leaves jfwd at the last block of every run but the last and jrev at
+        the block before every run but the first"""
+        W = len(runs)
+        for direction in ("fwd", "rev"):
+            order = range(0, W - 1) if direction == "fwd" else range(W - 1, 0, -1)
+            for r in order:
+                a, b = runs[r]
+                L, R = self.run_ends(a, b)
+                g, S, rr = systems[r]
+                g, S, rr = list(g), S.copy(), rr.copy()
+                x0 = self._x0(g, a, b)
+                self._add_first_constraints((g, S, rr), range(a, b + 1), "first_fwd" if direction == "fwd" else "first_rev")
+                cin, payload, cout = (L, self.jfwd.get(a - 1), R) if direction == "fwd" else (R, self.jrev.get(b), L)
+                if cin and payload is not None:
+                    WJ, est = payload
+                    idx = np.array([3 * g.index(s) + c for s in cin for c in range(3)], dtype=np.int64)
+                    S[np.ix_(idx, idx)] += WJ
+                    rr[idx] += WJ @ (est - x0[idx])
+                stay, Wm, rhs = self._eliminate((g, S, rr), cout)
+                # (junction list order, as the block-level chains keep their matrices)
+                perm = np.array([3 * stay.index(s) + c for s in cout for c in range(3)], dtype=np.int64)
+                Wm, rhs = Wm[np.ix_(perm, perm)], rhs[perm]
+                x0o = self._x0(cout, a, b)
+                out = (Wm, x0o + np.linalg.solve(Wm, rhs))
+                if direction == "fwd":
+                    self.jfwd[b] = out
+                else:
+                    self.jrev[a - 1] = out
+
+    def own_chains(self, a, b):
+        for k in range(a, b):
+            self.condensed_forward(k)
+        for k in range(b, a, -1):
+            self.condensed_reverse(k)
+
+
+for _name in ("_gid", "run_ends", "_system_of_block", "_merge", "_eliminate", "_add_first_constraints", "reduce_run", "_x0", "scan_runs",
+              "own_chains"):
+    setattr(NumpyBlockBackend, _name, TwoLevelMixin.__dict__[_name])
+
+
+def run_two_level(be, dist, rank, world, max_iterations=10):
+    """the condensed schedule with two-level chains across `world` gloo ranks (the message pattern of dna_adjust_dist.cpp:
+    one broadcast per RANK of the run's system, coordinates by all_reduce); returns (status, iterations, corrections, owners)"""
+    from dynadjust_amd import parallel
+    B = be.n_blocks
+    owner = contiguous_owners([float(be.n_stations(k)) ** 3 for k in range(B)], world)
+    runs = [(owner.index(r), B - 1 - owner[::-1].index(r)) for r in range(world)]
+    offs = np.zeros(B + 1, dtype=np.int64)
+    for k in range(B):
+        offs[k + 1] = offs[k] + 3 * be.n_stations(k)
+    corrections = []
+    for _ in range(max_iterations):
+        be.begin_iteration()
+        a, b = runs[rank]
+        mine = list(range(a, b + 1))
+        be.condense_blocks(mine)
+        own = be.reduce_run(a, b)                                          # level 1
+        systems, pending = [], []
+        for r, (ra, rb) in enumerate(runs):                                # exchange: one system per rank
+            L, R = be.run_ends(ra, rb)
+            g = sorted(set(L) | set(R))
+            n = 3 * len(g)
+            t = torch.from_numpy(np.concatenate([own[1].ravel(), own[2]])) if r == rank else torch.empty(n * n + n, dtype=torch.float64)
+            assert r != rank or own[0] == g
+            pending.append((g, n, t, dist.broadcast(t, src=r, async_op=True)))
+        for g, n, t, w in pending:
+            w.wait()
+            arr = t.numpy()
+            systems.append((g, arr[:n * n].reshape(n, n).copy(), arr[n * n:].copy()))
+        be.scan_runs(runs, systems)                                        # level 2 (every rank)
+        be.own_chains(a, b)                                                # level 3
+        be.rigorous_blocks(mine)
+        parallel._sync_coordinates(be, dist, rank, world, lambda k: owner[k], offs, be.comm_device)
+        corrections.append(be.max_correction())
+        if not be.end_iteration():
+            break
+    return be.finish(), len(corrections), corrections, owner

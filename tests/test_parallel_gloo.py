@@ -78,6 +78,68 @@ def test_distributed_schedule_matches_single_process(built, orc, tmp_path, world
     o.close()
 
 
+def _two_level_worker(rank, world, port, base, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import oracle
+    from tests.numpy_backend import NumpyBlockBackend, run_two_level
+    be = NumpyBlockBackend(oracle.Network(base, True))
+    status, its, corr, owner = run_two_level(be, dist, rank, world)
+    res = {"status": status, "iterations": its, "corrections": np.array(corr), "owner": np.array(owner)}
+    for k in range(be.n_blocks):
+        res[f"coords_{k}"] = be.blk[k]["rig"]
+        if owner[k] == rank:
+            res[f"owned_var_{k}"] = be.blk[k]["rigvar"]
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,blocks", [(2, 5), (3, 7), (3, 3)])
+def test_two_level_chains_match_single_process(built, orc, tmp_path, world, blocks):
+    """the two-level chains of the C++ multi-GPU driver (dna_adjust_dist.cpp: every rank reduces its own run of condensed blocks to
+    the stations of the run's ends, ONE system per rank is broadcast, the chains run over the runs and then inside every run), restated
+    densely in numpy and run under gloo: same coordinates and variances as the oracle's single-process phased adjustment"""
+    from dynadjust_amd import adjust
+    from dynadjust_amd.device import unpack_lower
+    adjust.write_synthetic_network(str(tmp_path), "n", 3 * blocks, 6, 0, blocks, seed=11 + blocks)
+    base = str(tmp_path / "n")
+    net = orc.Network(base, True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    mp.spawn(_two_level_worker, args=(world, _free_port(), base, str(tmp_path)), nprocs=world, join=True)
+    owned = set()
+    for r in range(world):
+        res = np.load(str(tmp_path / f"rank{r}.npz"))
+        owner = list(res["owner"])
+        assert owner == sorted(owner) and set(owner) == set(range(world))          # contiguous runs, every rank one
+        assert int(res["status"]) == ost and int(res["iterations"]) == o.iterations()
+        for i in range(o.iterations()):
+            assert abs(res["corrections"][i] - o.max_correction(i + 1)) < 1e-8
+        for k in range(blocks):
+            assert np.abs(res[f"coords_{k}"] - o.block_estimates(k)).max() < 1e-8
+            if f"owned_var_{k}" in res:
+                owned.add(k)
+                V = unpack_lower(o.block_variances(k), 3 * len(o.block_stations(k)))
+                assert np.abs(res[f"owned_var_{k}"] - V).max() / np.abs(V).max() < 1e-8
+    assert owned == set(range(blocks))
+    o.close()
+
+
+def test_contiguous_owners():
+    from tests.numpy_backend import contiguous_owners
+    assert contiguous_owners([1.0] * 16, 8) == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7]
+    assert contiguous_owners([1.0] * 5, 1) == [0] * 5
+    assert contiguous_owners([8.0, 1, 1, 1, 1, 1, 1, 1, 1], 2) == [0] + [1] * 8
+    o = contiguous_owners([1.0] * 6, 8)
+    assert o == [0, 1, 2, 3, 4, 5]                                   # more ranks than blocks: one block each
+    o = contiguous_owners([0.5, 1, 1, 1, 1, 1, 1, 0.5], 3)
+    assert o == sorted(o) and set(o) == {0, 1, 2}
+
+
 def test_schedule_roles():
     from dynadjust_amd.parallel import PhasedSchedule
     flags = [(True, False, False)] + [(False, False, False)] * 6 + [(False, True, False)]
