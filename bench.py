@@ -356,6 +356,17 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     return out
 
 
+def emit(result):
+    """the ONE JSON line, last on stdout: whatever C libraries left in their stdio buffers (RCCL's version banner is printed through
+    C stdio and would otherwise surface at exit, after the line) goes out first"""
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,7 +452,7 @@ def main():
             result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)
         if rank == 0:
             result["config"]["workload"] = desc
-            print(json.dumps(result), flush=True)
+            emit(result)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -558,7 +569,7 @@ def main():
         out["check"] = {"error": str(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, iters, solves, sum_n3, stations)
-    print(json.dumps(out), flush=True)
+    emit(out)
     a.close()
 
 

@@ -145,6 +145,12 @@ class DnaAdjust:
     def block_owner(self, k):
         return self.lib.dnaadj_block_owner(self.h, k)
 
+    def inverse_exchange_stats(self):
+        """intra-block distributed inverse (simultaneous adjustment on several GPUs): split launches, bytes received (this rank)"""
+        n, b = C.c_uint64(), C.c_double()
+        self.lib.dnagpu_inverse_exchange_stats(self.device_context(), C.byref(n), C.byref(b))
+        return {"split_launches": n.value, "bytes_received": b.value}
+
     def exchange_stats(self):
         b, e, c = C.c_uint64(), C.c_double(), C.c_double()
         self.lib.dnaadj_exchange_stats(self.h, C.byref(b), C.byref(e), C.byref(c))

@@ -116,6 +116,9 @@ struct dnagpu_ctx {
     size_t stage_cap[DNAGPU_NUM_CHAINS] = {};
     bool copy_pending[DNAGPU_NUM_CHAINS] = {};
     std::mutex schur_mutex;        // the per-block unknown orders of dnagpu_schur_carry are created on first use, by either chain's thread
+    int dist_rank = 0, dist_world = 1;            // intra-block distributed inverse (dnagpu_set_inverse_exchange)
+    dnagpu_exchange_fn exchange = nullptr;
+    void* exchange_user = nullptr;
     bool fuse = false;             // fused small launches (dnagpu_set_fused_launches; DNAGPU_FUSE=1 at creation)
     bool profile = false;
     double profile_ms_acc = 0.0;   // union length of the timed GEMM runs collected so far (dnagpu_profile_get)

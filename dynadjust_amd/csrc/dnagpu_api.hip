@@ -79,6 +79,10 @@ int ensure_ws(dnagpu_ctx* ctx, int chain, uint32_t np) {
     }
     ws.prof.enabled = prof;
     ws.fuse = ctx->fuse;
+    ws.dist_rank = ctx->dist_rank;
+    ws.dist_world = ctx->dist_world;
+    ws.exchange = ctx->exchange;
+    ws.exchange_user = ctx->exchange_user;
     return DNAGPU_OK;
 }
 
@@ -628,6 +632,30 @@ int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const dou
     HIPCHK(hipMemcpyAsync(m->F, src, (size_t)m->np * m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
     HIPCHK(hipMemcpyAsync(m->jest, src + (size_t)m->np * m->np, (size_t)m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
     HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_set_inverse_exchange(dnagpu_ctx* ctx, int rank, int world, dnagpu_exchange_fn fn, void* user) {
+    if (!ctx) return DNAGPU_EINVAL;
+    if (world > 1 && fn && (rank < 0 || rank >= world)) return fail(ctx, DNAGPU_EINVAL, "set_inverse_exchange: bad rank");
+    ctx->dist_rank = (world > 1 && fn) ? rank : 0;
+    ctx->dist_world = (world > 1 && fn) ? world : 1;
+    ctx->exchange = (world > 1) ? fn : nullptr;
+    ctx->exchange_user = user;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        InvWorkspace& ws = ctx->ws[c];
+        ws.dist_rank = ctx->dist_rank;
+        ws.dist_world = ctx->dist_world;
+        ws.exchange = ctx->exchange;
+        ws.exchange_user = ctx->exchange_user;
+    }
+    return DNAGPU_OK;
+}
+
+int dnagpu_inverse_exchange_stats(dnagpu_ctx* ctx, uint64_t* split_launches, double* bytes_received) {
+    if (!ctx) return DNAGPU_EINVAL;
+    if (split_launches) *split_launches = ctx->ws[0].split_launches;
+    if (bytes_received) *bytes_received = ctx->ws[0].exchanged_bytes;
     return DNAGPU_OK;
 }
 

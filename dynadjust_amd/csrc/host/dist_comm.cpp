@@ -136,6 +136,16 @@ public:
         hip_check(hipSetDevice(device_), "hipSetDevice");
         hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize (RCCL stream)");
     }
+    void broadcast_parts_on(hipStream_t stream, int nparts, double* const* bufs, const size_t* counts) override {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        nccl_check(rccl().GroupStart(), "ncclGroupStart");
+        for (int q = 0; q < nparts; ++q) {
+            if (!counts[q]) continue;
+            nccl_check(rccl().Broadcast(bufs[q], bufs[q], counts[q], ncclDouble, q, comm_, stream), "ncclBroadcast");
+            if (q != rank_) bytes_ += counts[q] * sizeof(double);
+        }
+        nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    }
     uint64_t bytes_moved() const override { return bytes_; }
 
 private:
@@ -200,6 +210,14 @@ public:
     void send(const double* buf, size_t count, int peer) override { post({LocalOp::SEND, const_cast<double*>(buf), count, peer}); }
     void recv(double* buf, size_t count, int peer) override { post({LocalOp::RECV, buf, count, peer}); }
     void wait() override {}                    // group_end() returns with everything done
+    void broadcast_parts_on(hipStream_t stream, int nparts, double* const* bufs, const size_t* counts) override {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");     // this rank's part is complete
+        group_begin();
+        for (int q = 0; q < nparts; ++q)
+            if (counts[q]) broadcast(bufs[q], counts[q], q);
+        group_end();
+    }
     uint64_t bytes_moved() const override { return bytes_; }
 
 private:

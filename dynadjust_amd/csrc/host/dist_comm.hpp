@@ -40,6 +40,10 @@ public:
     virtual void send(const double* buf, size_t count, int peer) = 0;
     virtual void recv(double* buf, size_t count, int peer) = 0;
     virtual void wait() = 0;
+    // Part q (bufs[q], counts[q] doubles) is produced by rank q; afterwards every rank holds all parts.  Ordered with the caller's
+    // stream: enqueued on it (RCCL: one ncclBroadcast per part, one group) or completed before returning (local: the stream is
+    // synchronised first).  The exchange of the intra-block distributed inverse (dnagpu_set_inverse_exchange).
+    virtual void broadcast_parts_on(hipStream_t stream, int nparts, double* const* bufs, const size_t* counts) = 0;
     // bytes this rank moved through the transport since creation (sent + received payload, for the exchange model)
     virtual uint64_t bytes_moved() const = 0;
 };

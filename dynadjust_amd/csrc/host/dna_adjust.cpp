@@ -593,6 +593,10 @@ void dna_adjust::PrepareBlocks() {
         SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
     }
     if (shares_device_) dnagpu_set_fused_launches(ctx_, 0);
+    // several GPUs, one block (simultaneous adjustment): every GPU holds the block, the inverse itself is distributed -- large
+    // launches split by tile columns, the parts exchanged over the communicator (dnagpu_set_inverse_exchange)
+    if (comm_ && comm_->world() > 1 && projectSettings_.a.adjust_mode == SimultaneousMode)
+        Check(dnagpu_set_inverse_exchange(ctx_, comm_->rank(), comm_->world(), &dna_adjust::ExchangeTrampoline, this), 0, "PrepareAdjustment()");
     {
         // a chain costs three matrices of the largest block's order (work matrix, X, W): no more chains than blocks, and
         // no more than half of the free HBM for all of them together
@@ -1341,6 +1345,8 @@ void dna_adjust::SerialiseAdjustedVarianceMatrices() {
     if (!ctx_) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): PrepareAdjustment() has not been called.", 0);
     const std::string folder = projectSettings_.a.stage_path.empty() ? projectSettings_.g.output_folder : projectSettings_.a.stage_path;
     const std::string base = folder + "/" + projectSettings_.g.network_name + "-";
+    // (simultaneous adjustment on several GPUs: every rank holds the same results, rank 0 writes)
+    if (Distributed() && projectSettings_.a.adjust_mode == SimultaneousMode && DistRank() != 0) return;
     // one process per GPU: collective -- every block's results travel to rank 0, which writes the files
     const bool across_processes = Distributed() && peers_.empty() && !is_peer_ && DistWorld() > 1 &&
                                   projectSettings_.a.adjust_mode != SimultaneousMode;

@@ -216,6 +216,7 @@ private:
     void AdjustPhasedCondensedIteration();     // a.schur_carry: condense every block, chains on the condensed blocks, rigorous solves
     // ---- multi-GPU (dna_adjust_dist.cpp) ----
     void AdjustPhasedDistributed();            // AdjustPhased across the ranks of comm_
+    static int ExchangeTrampoline(void* self, void* stream, int nparts, double* const* bufs, const size_t* counts);
     void DistributedCondensedIteration();
     void DistributedReferenceIteration();
     void ExchangeCondensed();                  // broadcast of every condensed block from its owner

@@ -103,6 +103,17 @@ void dna_adjust::ComputeBlockOwners(bool condensed) {
     }
 }
 
+// the exchange of the intra-block distributed inverse (dnagpu_set_inverse_exchange): no exception may cross the C boundary
+int dna_adjust::ExchangeTrampoline(void* self, void* stream, int nparts, double* const* bufs, const size_t* counts) {
+    dna_adjust* a = static_cast<dna_adjust*>(self);
+    try {
+        a->comm_->broadcast_parts_on((hipStream_t)stream, nparts, bufs, counts);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
 double* dna_adjust::ExchangeBuffer(size_t doubles) {
     if (xbuf_cap_ < doubles) {
         if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);

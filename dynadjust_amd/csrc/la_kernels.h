@@ -67,7 +67,9 @@ constexpr int SMALL_LAUNCH_TILES = 512;
 
 // Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).
-std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile);
+// jt_lo / jt_hi (128-tiles, -1 = all): only the tiles of these columns (one rank's share of a split launch)
+std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo = -1, int jt_hi = -1);
+std::vector<int> split_tile_columns(int mt, int nt, int K, int kmode, int lower, int world);
 
 void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s);

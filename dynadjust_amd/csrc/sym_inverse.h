@@ -33,14 +33,24 @@ struct InvWorkspace {
     uint32_t np_cap = 0;
     hipStream_t stream = nullptr;
     GemmProfile prof;
-    // workgroup->tile tables per launch shape (see tile_order.hip), device resident
-    std::map<uint64_t, std::pair<uint32_t*, int>> order_cache;
+    // workgroup->tile tables per launch shape (see tile_order.hip) and tile-column range (0xffffffff: all columns), device resident
+    std::map<std::pair<uint64_t, uint32_t>, std::pair<uint32_t*, int>> order_cache;
     std::set<int> planned;  // matrix orders (in tiles) whose tables are all built
     // First HIP error of a planning pass, table upload, memset / copy or kernel launch enqueued through this workspace since
     // the last inv_take_error(): the asynchronous drivers below keep enqueuing nothing further once it is set, and the C-ABI
     // turns it into DNAGPU_ENOMEM / DNAGPU_EHIP instead of trusting `info_host` (a skipped GEMM leaves info at "no failure").
     hipError_t err = hipSuccess;
     const char* err_where = nullptr;
+    // Intra-block distributed inverse (dnagpu_set_inverse_exchange): `dist_world` GPUs hold the same matrices; every large launch is
+    // split by tile columns, each rank computes its columns, `exchange` makes every rank's part known to all (part q comes from rank
+    // q; enqueued on, or completed before returning to, the given stream).  Leaves and small launches are done by everybody.
+    int dist_rank = 0, dist_world = 1;
+    int (*exchange)(void* user, void* stream, int nparts, double* const* bufs, const size_t* counts) = nullptr;
+    void* exchange_user = nullptr;
+    double* dist_stage = nullptr;
+    size_t dist_stage_cap = 0;
+    uint64_t split_launches = 0;
+    double exchanged_bytes = 0.0;
     // fused small launches (la_kernels.h): products waiting to go out as one launch, the barrier counter and its expected value
     bool fuse = false;             // opt-in (dnagpu_set_fused_launches, DNAGPU_FUSE=1): measured no gain, see la_kernels.h
     std::vector<FusedOp> pending;
@@ -61,7 +71,7 @@ void inv_note_error(InvWorkspace& ws, hipError_t e, const char* where);
 
 struct GemmArgs;
 // fills a.order / a.grid from the cache (building + uploading the table on first use)
-hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a);
+hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo = -1, int jt_hi = -1);
 
 // returns hipSuccess or an error; allocates for matrices up to np_cap (multiple of 128)
 hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t stream);

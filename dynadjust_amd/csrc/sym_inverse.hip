@@ -33,6 +33,7 @@ void inv_workspace_free(InvWorkspace& ws) {
     if (ws.svec) hipFree(ws.svec);
     if (ws.info) hipFree(ws.info);
     if (ws.sync_ctr) hipFree(ws.sync_ctr);
+    if (ws.dist_stage) hipFree(ws.dist_stage);
     if (ws.info_host) hipHostFree(ws.info_host);
     for (hipEvent_t ev : ws.prof.pool) hipEventDestroy(ev);
     for (auto& kv : ws.order_cache)
@@ -99,14 +100,15 @@ long small_tiles_set(long v) {
     return old;
 }
 
-hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a) {
+hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo, int jt_hi) {
     long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
     a.tile = total < g_small_tiles.load() ? 64 : 128;
-    uint64_t key = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
-                   ((uint64_t)(a.tile == 64 ? 1 : 0) << 37) | ((uint64_t)(a.K / 16) << 40);
+    const uint64_t shape = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
+                           ((uint64_t)(a.tile == 64 ? 1 : 0) << 37) | ((uint64_t)(a.K / 16) << 40);
+    const auto key = std::make_pair(shape, jt_lo < 0 ? 0xffffffffu : ((uint32_t)jt_lo << 16) | (uint32_t)jt_hi);
     auto it = ws.order_cache.find(key);
     if (it == ws.order_cache.end()) {
-        std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower, a.tile);
+        std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower, a.tile, jt_lo, jt_hi);
         uint32_t* dev = nullptr;
         if (!tab.empty()) {
             hipError_t e = table_malloc(&dev, tab.size() * sizeof(uint32_t));
@@ -180,7 +182,78 @@ void gemm_profile_close(InvWorkspace& ws) {
     p.open = false;
 }
 
+// One large launch across the GPUs of an intra-block distributed inverse: every rank computes the tile columns of its range, packs
+// them (the rows that the launch writes, column by column) into its part of the staging buffer, all parts travel to all ranks
+// (ws.exchange: one broadcast per rank, on this stream), the others' parts are unpacked into the matrix.  A mirrored launch (LAUUM)
+// writes its lower tiles only and the upper triangle is filled by every rank afterwards.
+static bool gemm_split(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
+    const int W = ws.dist_world, me = ws.dist_rank;
+    const long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
+    if (W < 2 || !ws.exchange || total < g_small_tiles.load()) return false;
+    gemm_flush(ws);
+    const std::vector<int> lo = split_tile_columns(a.mt, a.nt, a.K, a.kmode, a.lower, W);
+    const bool mirror = a.mirror != 0;
+    a.mirror = 0;
+    // the parts: rows [row0, mt * 128) of columns [lo[q], lo[q + 1]) * 128
+    std::vector<size_t> off(W + 1, 0), counts(W), rows(W), row0(W), cols(W);
+    for (int q = 0; q < W; ++q) {
+        row0[q] = a.lower ? (size_t)lo[q] * 128 : 0;
+        rows[q] = (size_t)a.mt * 128 - row0[q];
+        cols[q] = (size_t)(lo[q + 1] - lo[q]) * 128;
+        counts[q] = rows[q] * cols[q];
+        off[q + 1] = off[q] + counts[q];
+    }
+    if (ws.dist_stage_cap < off[W]) {
+        hipStreamSynchronize(ws.stream);
+        if (ws.dist_stage) hipFree(ws.dist_stage);
+        ws.dist_stage = nullptr;
+        ws.dist_stage_cap = 0;
+        const size_t want = std::max(off[W], (size_t)ws.np_cap * ws.np_cap);
+        hipError_t e = hipMalloc(&ws.dist_stage, want * sizeof(double));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            inv_note_error(ws, e, "staging buffer of the distributed inverse");
+            return true;
+        }
+        ws.dist_stage_cap = want;
+    }
+    if (ws.err != hipSuccess) return true;
+    if (lo[me + 1] > lo[me]) {
+        GemmArgs mine = a;
+        if (gemm_attach_order(ws, mine, lo[me], lo[me + 1]) != hipSuccess) return true;
+        GemmProfile& p = ws.prof;
+        if (p.enabled) {
+            if (!p.open) {
+                profile_event(p, ws.stream);
+                p.open = true;
+            }
+            p.flops += gemm_flops(a) / W;
+            p.launches++;
+        }
+        launch_gemm(mine, akc, bkc, ws.stream);
+        inv_note_error(ws, hipGetLastError(), "tile GEMM launch");
+    }
+    gemm_profile_close(ws);
+    auto region = [&](int q) { return a.C + (size_t)lo[q] * 128 * a.ldc + row0[q]; };
+    if (counts[me])
+        inv_note_error(ws, hipMemcpy2DAsync(ws.dist_stage + off[me], rows[me] * sizeof(double), region(me), (size_t)a.ldc * sizeof(double),
+                                            rows[me] * sizeof(double), cols[me], hipMemcpyDeviceToDevice, ws.stream), "pack");
+    std::vector<double*> bufs(W);
+    for (int q = 0; q < W; ++q) bufs[q] = ws.dist_stage + off[q];
+    if (ws.err == hipSuccess && ws.exchange(ws.exchange_user, (void*)ws.stream, W, bufs.data(), counts.data()) != 0)
+        inv_note_error(ws, hipErrorUnknown, "exchange of the distributed inverse");
+    for (int q = 0; q < W && ws.err == hipSuccess; ++q)
+        if (q != me && counts[q])
+            inv_note_error(ws, hipMemcpy2DAsync(region(q), (size_t)a.ldc * sizeof(double), ws.dist_stage + off[q], rows[q] * sizeof(double),
+                                                rows[q] * sizeof(double), cols[q], hipMemcpyDeviceToDevice, ws.stream), "unpack");
+    if (mirror && ws.err == hipSuccess) launch_symmetrize(a.C, (uint32_t)a.mt * 128, (uint32_t)a.ldc, ws.stream);
+    ws.split_launches++;
+    ws.exchanged_bytes += (double)(off[W] - counts[me]) * sizeof(double);
+    return true;
+}
+
 void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
+    if (ws.dist_world > 1 && ws.err == hipSuccess && gemm_split(ws, a, akc, bkc)) return;
     // (after a latched error nothing further is enqueued: the result is void anyway and the caller reports the error)
     if (ws.err != hipSuccess || gemm_attach_order(ws, a) != hipSuccess) return;
     GemmProfile& p = ws.prof;

@@ -30,14 +30,38 @@ static inline int klen(int it, int jt, int K, int kmode, int tile) {
     return ke > kb ? ke - kb : 0;
 }
 
-std::vector<uint32_t> build_tile_order(int mt128, int nt128, int K, int kmode, int lower, int tile) {
+// Columns (in 128-tiles) [lo[q], lo[q + 1]) of a launch for each of `world` ranks, balanced by the work of their tiles: the
+// intra-block distributed inverse gives every rank the tile columns of one range (sym_inverse.hip)
+std::vector<int> split_tile_columns(int mt128, int nt128, int K, int kmode, int lower, int world) {
+    std::vector<double> w(nt128, 0.0);
+    double total = 0.0;
+    for (int jt = 0; jt < nt128; ++jt) {
+        for (int it = lower ? jt : 0; it < mt128; ++it) w[jt] += klen(it, jt, K, kmode, 128) + 16;
+        total += w[jt];
+    }
+    std::vector<int> lo(world + 1, nt128);
+    lo[0] = 0;
+    double acc = 0.0;
+    int q = 1;
+    for (int jt = 0; jt < nt128 && q < world; ++jt) {
+        acc += w[jt];
+        while (q < world && acc >= total * q / world) lo[q++] = jt + 1;
+    }
+    for (; q < world; ++q) lo[q] = nt128;
+    return lo;
+}
+
+std::vector<uint32_t> build_tile_order(int mt128, int nt128, int K, int kmode, int lower, int tile, int jt_lo128, int jt_hi128) {
     std::vector<uint32_t> out;
     const int mt = mt128 * (128 / tile), nt = nt128 * (128 / tile);
-    long total = lower ? (long)mt * (mt + 1) / 2 : (long)mt * nt;
+    const int jlo = jt_lo128 < 0 ? 0 : jt_lo128 * (128 / tile), jhi = jt_hi128 < 0 ? nt : jt_hi128 * (128 / tile);
+    long total = 0;
+    for (int it = 0; it < mt; ++it)
+        for (int jt = jlo; jt < jhi && jt <= (lower ? it : nt - 1); ++jt) ++total;
     if (total <= 0) return out;
     if (total <= 8) {
         for (int it = 0; it < mt; ++it)
-            for (int jt = 0; jt <= (lower ? it : nt - 1); ++jt) out.push_back(((uint32_t)it << 16) | (uint32_t)jt);
+            for (int jt = jlo; jt < jhi && jt <= (lower ? it : nt - 1); ++jt) out.push_back(((uint32_t)it << 16) | (uint32_t)jt);
         return out;
     }
     int T = std::max(mt, nt);
@@ -55,6 +79,7 @@ std::vector<uint32_t> build_tile_order(int mt128, int nt128, int K, int kmode, i
             for (int it = si * G; it < std::min(mt, (si + 1) * G); ++it)
                 for (int jt = sj * G; jt < std::min(nt, (sj + 1) * G); ++jt) {
                     if (lower && jt > it) continue;
+                    if (jt < jlo || jt >= jhi) continue;
                     w += klen(it, jt, K, kmode, tile) + 16;  // + fixed per-tile cost
                     ++cnt;
                 }
@@ -73,6 +98,7 @@ std::vector<uint32_t> build_tile_order(int mt128, int nt128, int K, int kmode, i
         for (int jt = s.sj * G; jt < std::min(nt, (s.sj + 1) * G); ++jt)
             for (int it = s.si * G; it < std::min(mt, (s.si + 1) * G); ++it) {
                 if (lower && jt > it) continue;
+                if (jt < jlo || jt >= jhi) continue;
                 lists[x].push_back(((uint32_t)it << 16) | (uint32_t)jt);
             }
     }

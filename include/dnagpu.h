@@ -135,6 +135,16 @@ int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const dou
  * A receiver sets the logical order first (dnagpu_matrix_resize: n <= n_max; contents untouched). */
 int dnagpu_matrix_resize(dnagpu_ctx* ctx, dnagpu_matrix* m, uint32_t n);
 int dnagpu_matrix_device_pointers(const dnagpu_matrix* m, double** matrix, double** vector, uint32_t* np);
+/* Intra-block distributed inverse (networks with fewer blocks than GPUs, e.g. the simultaneous adjustment's one block): `world` contexts,
+ * one per GPU, are given the same matrices and call dnagpu_invert together.  Every large launch of the recursion is split by tile
+ * columns; a rank computes its columns and `exchange` hands every rank's part to all the others: part q (bufs[q], counts[q] doubles,
+ * device memory of this context) is produced by rank q -- the callee broadcasts it from rank q, either enqueued on `stream` (a
+ * hipStream_t; RCCL: one ncclBroadcast per part in one group) or completed before it returns.  Returns 0 / nonzero.  Leaves and
+ * small launches are computed by every rank, so all contexts end with the same inverse.  world <= 1 or fn == NULL switches it off. */
+typedef int (*dnagpu_exchange_fn)(void* user, void* stream, int nparts, double* const* bufs, const size_t* counts);
+int dnagpu_set_inverse_exchange(dnagpu_ctx* ctx, int rank, int world, dnagpu_exchange_fn fn, void* user);
+/* launches that were split and bytes received through the exchange since the context was created (chain 0) */
+int dnagpu_inverse_exchange_stats(dnagpu_ctx* ctx, uint64_t* split_launches, double* bytes_received);
 /* in-place inverse (lower in, both triangles out); checks positive definiteness */
 int dnagpu_invert(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, int scale_to_unity);
 

@@ -1,15 +1,11 @@
 #!/bin/bash
-# one gpurun job (edit per need): full suite, smoke, default bench, profile refresh
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export GPU_MAX_HW_QUEUES=16
-timeout 1500 python -m pytest tests -q -m gpu --durations=8 > gpurun_out/t_all.log 2>&1
-echo "all rc=$?" > gpurun_out/job.status
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
-echo "smoke rc=$?" >> gpurun_out/job.status
-timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-echo "bench rc=$?" >> gpurun_out/job.status
-TAG=r02 timeout 2400 bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-echo "refresh rc=$?" >> gpurun_out/job.status
-tail -n 4 gpurun_out/t_all.log gpurun_out/smoke.log
+timeout 900 python -m pytest tests/test_gpu_distributed.py -q -x --durations=6 > gpurun_out/t_dist.log 2>&1
+echo "dist rc=$?" > gpurun_out/job.status
+timeout 900 python tools/gpu_intra_block_probe.py > gpurun_out/intra_block.log 2>&1
+echo "intra rc=$?" >> gpurun_out/job.status
+DNAGPU_FORCE_DISTRIBUTED=1 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/rccl1.err | tail -1 > gpurun_out/bench_cfg3_rccl_one_rank.json
+tail -n 6 gpurun_out/t_dist.log gpurun_out/intra_block.log
 cat gpurun_out/job.status
