@@ -285,6 +285,9 @@ private:
                     case LocalOp::SEND: bytes_ += op.count * sizeof(double); break;
                 }
             }
+            // (a device-to-device hipMemcpy is ordered on the null stream but may return before it has run: the chains' streams do
+            // not wait for the null stream, so the copies are completed here -- large parts lost this race, small ones never did)
+            hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize (copies)");
             g.barrier();          // nobody's source buffer changes before every copy out of it is done
         } catch (...) {
             pending_.clear();
