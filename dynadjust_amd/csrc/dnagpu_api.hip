@@ -371,6 +371,16 @@ int dnagpu_debug_fail_allocation(long nth) {
 
 long dnagpu_debug_set_small_tiles(long tiles) { return dnagpu::small_tiles_set(tiles); }
 
+long dnagpu_debug_set_pair_tiles(long tiles) { return dnagpu::pair_tiles_set(tiles); }
+
+long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo, int jt_hi, uint32_t* out, long cap, int* per_workgroup) {
+    int pairs = 0;
+    std::vector<uint32_t> t = dnagpu::build_tile_order(mt, nt, K, kmode, lower, tile, jt_lo, jt_hi, &pairs);
+    if (per_workgroup) *per_workgroup = pairs ? 2 : 1;
+    for (long i = 0; out && i < cap && i < (long)t.size(); ++i) out[i] = t[i];
+    return (long)t.size();
+}
+
 int dnagpu_set_fused_launches(dnagpu_ctx* ctx, int on) {
     if (!ctx) return DNAGPU_EINVAL;
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
@@ -1744,10 +1754,12 @@ extern "C" int dnagpu_bench_gemm(dnagpu_ctx* ctx, int variant, int mt, int nt, i
     if (mt <= 0 || nt <= 0 || K <= 0 || K % 16 || reps <= 0) return fail(ctx, DNAGPU_EINVAL, "bench_gemm: bad arguments");
     size_t M = (size_t)mt * 128, N = (size_t)nt * 128;
     size_t ld = std::max(std::max(M, N), (size_t)K);
+    size_t cols = ld;
+    if (const char* pad = getenv("DNAGPU_BENCH_LDPAD")) ld += (size_t)atoi(pad);      // leading dimension != a multiple of 128: the set-conflict probe
     double *A = nullptr, *B = nullptr, *Cc = nullptr;
-    HIPCHK(hipMalloc(&A, ld * ld * sizeof(double)));
-    HIPCHK(hipMalloc(&B, ld * ld * sizeof(double)));
-    HIPCHK(hipMalloc(&Cc, ld * ld * sizeof(double)));
+    HIPCHK(hipMalloc(&A, ld * cols * sizeof(double)));
+    HIPCHK(hipMalloc(&B, ld * cols * sizeof(double)));
+    HIPCHK(hipMalloc(&Cc, ld * cols * sizeof(double)));
     // pseudo-random fill (full-range mantissas: zero fill would flatter the clocks)
     std::vector<double> h(ld * 1024);
     uint64_t s = 88172645463325252ull;
@@ -1755,12 +1767,12 @@ extern "C" int dnagpu_bench_gemm(dnagpu_ctx* ctx, int variant, int mt, int nt, i
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         v = (double)(int64_t)(s >> 11) / 9007199254740992.0 - 0.5;
     }
-    for (size_t off = 0; off < ld * ld; off += h.size()) {
-        size_t cnt = std::min(h.size(), ld * ld - off);
+    for (size_t off = 0; off < ld * cols; off += h.size()) {
+        size_t cnt = std::min(h.size(), ld * cols - off);
         hipMemcpy(A + off, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
         hipMemcpy(B + off, h.data() + 7, (cnt - 7) * sizeof(double), hipMemcpyHostToDevice);
     }
-    hipMemset(Cc, 0, ld * ld * sizeof(double));
+    hipMemset(Cc, 0, ld * cols * sizeof(double));
     GemmArgs a;
     a.A = A; a.B = B; a.C = Cc; a.lda = a.ldb = a.ldc = (int)ld;
     a.mt = mt; a.nt = nt; a.K = K; a.alpha = 1.0; a.beta = 0.0; a.kmode = kmode; a.lower = lower; a.mirror = 0;

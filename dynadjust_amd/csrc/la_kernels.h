@@ -19,7 +19,9 @@ struct GemmArgs {
     int kmode;   // KMode: restricts the k range per tile (triangular operands)
     int lower;   // 1: only tiles it >= jt (square problems)
     int mirror;  // 1: also store C(j,i) for off-diagonal tiles
-    const uint32_t* order;  // device table: (it << 16 | jt) per workgroup, 0xffffffff = idle
+    const uint32_t* order;  // device table: (it << 16 | jt) per workgroup, 0xffffffff = idle; bit 15 (128-tile launches only): walk k
+                            // from the tile's own end of the range towards the end all tiles share
+    int pairs = 0;          // 1: two table entries per workgroup (the second may be idle), computed one after the other
     int grid;               // number of workgroups (= table length)
     int tile;               // block tile of the launch: 128 (throughput) or 64 (small launches)
     int k_ascending = 0;    // diagnostic: 1 = walk k upwards also for the k >= i / k >= j ranges (see gemm_f64_dma_kernel)
@@ -68,7 +70,9 @@ constexpr int SMALL_LAUNCH_TILES = 512;
 // Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).
 // jt_lo / jt_hi (128-tiles, -1 = all): only the tiles of these columns (one rank's share of a split launch)
-std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo = -1, int jt_hi = -1);
+std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo = -1, int jt_hi = -1, int* pairs = nullptr);
+long pair_tiles_set(long tiles);   // launches of at least this many 128-tiles walk their tiles in pairs (tile_order.hip); 0 = never (default); returns the old value
+bool gemm_128_takes_pairs();   // the LDS-DMA kernel does; the register-staged diagnostic variants do not
 std::vector<int> split_tile_columns(int mt, int nt, int K, int kmode, int lower, int world);
 
 void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);

@@ -443,9 +443,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
     using G = Geo<TILE, WAVES>;
     __shared__ __attribute__((aligned(16))) double lds0[2 * G::OPBUF];
     __shared__ __attribute__((aligned(16))) double lds1[2 * G::OPBUF];
-    const uint32_t packed = a.order[blockIdx.x];
-    if (packed == 0xffffffffu) return;
-    const int it = (int)(packed >> 16), jt = (int)(packed & 0xffffu);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    uint32_t offa[G::NQ], offb[G::NQ];
+    dma_offsets<A_KC, TILE, WAVES>(a.lda, wave, lane, offa);
+    dma_offsets<B_KC, TILE, WAVES>(a.ldb, wave, lane, offb);
+    // One table entry per workgroup, or two (a.pairs): a workgroup then computes two tiles one after the other, the second one
+    // walked TOWARDS the k all tiles have in common (bit 15 of the entry), see tile_order.hip.
+    const int nparts = a.pairs ? 2 : 1;
+#pragma nounroll
+    for (int part = 0; part < nparts; ++part) {
+    const uint32_t packed = a.order[(size_t)blockIdx.x * nparts + part];
+    if (packed == 0xffffffffu) break;
+    const int it = (int)(packed >> 16), jt = (int)(packed & 0x7fffu);
+    const bool flip = (packed & 0x8000u) != 0;
     int kbeg = 0, kend = a.K;
     switch (a.kmode) {
         case KM_LE_J: kend = (jt + 1) * 128; break;
@@ -455,12 +468,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
         default: break;
     }
     if (kend > a.K) kend = a.K;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
     const int i0 = it * TILE, j0 = jt * TILE;
+    if (part) __syncthreads();       // the first tile's last fragment reads are done before the next DMA lands
 
     d4 acc[G::MI][G::NI];
 #pragma unroll
@@ -468,9 +477,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
 #pragma unroll
         for (int ni = 0; ni < G::NI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    uint32_t offa[G::NQ], offb[G::NQ];
-    dma_offsets<A_KC, TILE, WAVES>(a.lda, wave, lane, offa);
-    dma_offsets<B_KC, TILE, WAVES>(a.ldb, wave, lane, offb);
     const int nk = (kend - kbeg) / 16;
 
     double af[2][G::MI], bf[2][G::NI];
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
     // Triangular ranges that END at a common k (k >= i, k >= j) are walked downwards: the workgroups of a super-tile,
     // which share operand panels in their XCD's L2, then start together at the common end and stay in step, instead of
     // each starting at its own first k and drifting apart by (tile distance) x 128 for the whole run.
-    const bool down = (a.kmode == KM_GE_J || a.kmode == KM_GE_I) && !a.k_ascending;
+    const bool down = ((a.kmode == KM_GE_J || a.kmode == KM_GE_I) && !a.k_ascending) != flip;
     auto issue = [&](int t, double* buf) {
         const int k0 = down ? kend - (t + 1) * 16 : kbeg + t * 16;
         dma_issue<A_KC, TILE, WAVES>(stage_base<A_KC>(a.A, a.lda, i0, k0), offa, buf, wave);
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
             }
         }
     }
+    }   // part
 }
 
 template <int WAVES>
@@ -643,6 +650,8 @@ static int gemm_variant_128() {
     }
     return v;
 }
+
+bool gemm_128_takes_pairs() { return gemm_variant_128() <= 1; }
 
 void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
     if (a.grid <= 0) return;

@@ -108,7 +108,8 @@ hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo, int jt_hi
     const auto key = std::make_pair(shape, jt_lo < 0 ? 0xffffffffu : ((uint32_t)jt_lo << 16) | (uint32_t)jt_hi);
     auto it = ws.order_cache.find(key);
     if (it == ws.order_cache.end()) {
-        std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower, a.tile, jt_lo, jt_hi);
+        int pairs = 0;
+        std::vector<uint32_t> tab = build_tile_order(a.mt, a.nt, a.K, a.kmode, a.lower, a.tile, jt_lo, jt_hi, &pairs);
         uint32_t* dev = nullptr;
         if (!tab.empty()) {
             hipError_t e = table_malloc(&dev, tab.size() * sizeof(uint32_t));
@@ -125,10 +126,12 @@ hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo, int jt_hi
                 return e;
             }
         }
-        it = ws.order_cache.emplace(key, std::make_pair(dev, (int)tab.size())).first;
+        // (a table with two entries per workgroup carries its grid negated)
+        it = ws.order_cache.emplace(key, std::make_pair(dev, pairs ? -(int)(tab.size() / 2) : (int)tab.size())).first;
     }
     a.order = it->second.first;
-    a.grid = it->second.second;
+    a.grid = it->second.second < 0 ? -it->second.second : it->second.second;
+    a.pairs = it->second.second < 0 ? 1 : 0;
     return hipSuccess;
 }
 

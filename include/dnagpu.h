@@ -99,6 +99,13 @@ int dnagpu_debug_fail_allocation(long nth);
 /* Launches with fewer than `tiles` 128 x 128 tiles use the 64-tile latency kernel (default 160); 0 sends every launch through the
  * 128-tile throughput kernel (gemm_f64_dma_kernel), a negative value restores the default.  Returns the previous value. */
 long dnagpu_debug_set_small_tiles(long tiles);
+/* Opt-in experiment (off: measured no gain, tile_order.hip): launches of at least `tiles` 128-tiles with a triangular k range give every
+ * workgroup two tiles of complementary length (0 = never, the default).  Takes effect for tables built afterwards.  Returns the previous value. */
+long dnagpu_debug_set_pair_tiles(long tiles);
+/* The workgroup -> tile table a launch of this shape would use (host computation, no device needed): `out` receives up to `cap`
+ * entries (it << 16 | jt, bit 15 = k walked towards the common end, 0xffffffff = idle), *per_workgroup = 1 or 2 entries per workgroup;
+ * jt_lo / jt_hi = -1 or the column range of one rank of a split launch.  Returns the number of entries the table has. */
+long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo, int jt_hi, uint32_t* out, long cap, int* per_workgroup);
 /* Opt-in experiment (off by default: measured no gain, la_kernels.h): runs of dependent small products of the recursion as ONE launch of a
  * persistent kernel, device-wide barriers between the products (DNAGPU_FUSE=1 or dnagpu_set_fused_launches).  Totals since the context was created. */
 int dnagpu_fused_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* products);
