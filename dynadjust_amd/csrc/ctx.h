@@ -17,14 +17,15 @@ struct dnagpu_matrix {
 };
 
 // State of a block between dnagpu_block_reduce(..., keep) and dnagpu_partial_complete: see include/dnagpu.h
+// (the permuted normals -> factor pieces -> inverse in the elimination's order never outlive a call: they live in the chain's X workspace)
 struct dnagpu_partial {
-    double* F = nullptr;     // (n_cap)^2: permuted normals -> factor pieces -> inverse in the elimination's order
-    double* X = nullptr;     // (n_cap)^2: L^-1
+    double* X = nullptr;     // (n_cap)^2: L^-1 -- own storage, or the storage of `store` (dnagpu_partial_create_in)
+    dnagpu_matrix* store = nullptr;   // the matrix whose storage X borrows between the elimination and the completion
     double* WK = nullptr;    // k_cap x n_cap: L_KI
     int32_t* map = nullptr;  // n_cap: elimination order -> natural unknown (-1 padding, -2 the rhs row)
     uint32_t n_cap = 0, k_cap = 0;               // capacities (padded orders)
     uint32_t n = 0, nj = 0, nip = 0, njp = 0, npp = 0;
-    bool valid = false;      // reduce done, completion pending (F live)
+    bool valid = false;      // reduce done, completion pending
     bool completed = false;  // completion done: X (the eliminated part's inverse factor) and WK still describe the block
 };
 

@@ -1490,16 +1490,20 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
         keep->valid = false;
         keep->completed = false;
         keep->n = n; keep->nj = nj; keep->nip = nip; keep->njp = njp; keep->npp = npp;
-        launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], keep->F, npp, npp, st);
+        // the matrix being factored lives in the chain's X workspace (free here: the kept L^-1 has a home of its own); nothing of
+        // it is needed after this call but the Schur complement, which the caller extracts at once
+        double* F = ws.X;
+        if (keep->store) keep->store->n = 0;       // (its storage now holds the factor's inverse, not a matrix)
+        launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], F, npp, npp, st);
         HIPCHK(hipMemcpyAsync(keep->map, map_dev, (size_t)npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        sym_schur_keep_async(ws, keep->F, keep->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+        sym_schur_keep_async(ws, F, keep->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
         if (nip)   // the panel L_KI (kept rows x eliminated columns) out of the chain's panel workspace
             HIPCHK(hipMemcpy2DAsync(keep->WK, (size_t)njp * sizeof(double), ws.W + nip, (size_t)npp * sizeof(double), (size_t)njp * sizeof(double), nip,
                                     hipMemcpyDeviceToDevice, st));
         // the row that carried the right-hand side rode along as a passenger: it is no unknown, its panel entries go
         if (nip) HIPCHK(hipMemset2DAsync(keep->WK + nj, (size_t)njp * sizeof(double), 0, sizeof(double), nip, st));
         keep->valid = true;
-        *T = keep->F + (size_t)nip * npp + nip;
+        *T = F + (size_t)nip * npp + nip;
     } else {
         launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], ws.W, npp, npp, ctx->stream[chain]);
         sym_schur_async(ws, ws.W, (int)npp, m->F, (int)npp, (int)(nip / 128), (int)(njp / 128));
@@ -1548,9 +1552,32 @@ int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagp
     if (!p) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
     p->k_cap = pad128(k_max + 1);
     p->n_cap = pad128(n_max - k_max ? n_max - k_max : 1) + p->k_cap;
-    hipError_t e = hipMalloc(&p->F, (size_t)p->n_cap * p->n_cap * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
+    hipError_t e = hipMalloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&p->WK, (size_t)p->k_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
+    if (e != hipSuccess) {
+        dnagpu_partial_destroy(ctx, p);
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "retained factor allocation", e);
+    }
+    *out = p;
+    return DNAGPU_OK;
+}
+
+int dnagpu_partial_create_in(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_matrix* store, dnagpu_partial** out) {
+    CHK_CTX();
+    if (!out || !store || !k_max || k_max > n_max) return fail(ctx, DNAGPU_EINVAL, "partial_create_in: bad arguments");
+    *out = nullptr;
+    dnagpu_partial* p = new (std::nothrow) dnagpu_partial();
+    if (!p) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    p->k_cap = pad128(k_max + 1);
+    p->n_cap = pad128(n_max - k_max ? n_max - k_max : 1) + p->k_cap;
+    if ((size_t)p->n_cap * p->n_cap > ((size_t)store->np_max + 128) * store->np_max) {
+        delete p;
+        return fail(ctx, DNAGPU_EINVAL, "partial_create_in: the matrix is too small (create it with n_max + 256)");
+    }
+    p->store = store;
+    p->X = store->F;
+    hipError_t e = hipMalloc(&p->WK, (size_t)p->k_cap * p->n_cap * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
     if (e != hipSuccess) {
         dnagpu_partial_destroy(ctx, p);
@@ -1566,8 +1593,7 @@ void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p) {
         hipSetDevice(ctx->device);
         hipDeviceSynchronize();
     }
-    if (p->F) hipFree(p->F);
-    if (p->X) hipFree(p->X);
+    if (p->X && !p->store) hipFree(p->X);
     if (p->WK) hipFree(p->WK);
     if (p->map) hipFree(p->map);
     delete p;
@@ -1583,14 +1609,17 @@ int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, cons
     InvWorkspace& ws = ctx->ws[chain];
     hipStream_t st = ctx->stream[chain];
     gemm_profile_close(ws);
-    pf->valid = false;       // F is consumed
-    pf->completed = true;
-    launch_partial_set_trailing(pf->F + (size_t)pf->nip * pf->npp + pf->nip, pf->npp, pf->njp, kk->F, kk->np, pf->nj, st);
-    sym_complete_async(ws, pf->F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128));
+    pf->valid = false;       // consumed
+    pf->completed = pf->store == nullptr;      // (borrowed storage goes back to its matrix: nothing left for dnagpu_partial_reduce_rhs)
+    // the matrix being completed lives in the chain's X workspace: only its trailing block (set here) is read, and the result
+    // leaves it through the un-permutation -- which may overwrite the kept L^-1 (inv == the matrix that lent its storage)
+    double* F = ws.X;
+    launch_partial_set_trailing(F + (size_t)pf->nip * pf->npp + pf->nip, pf->npp, pf->njp, kk->F, kk->np, pf->nj, st);
+    sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128));
     inv->n = pf->n;
     inv->np = pad128(pf->n);
     launch_init_padded(inv->F, inv->n, inv->np, st);
-    launch_unpermute(pf->F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
+    launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);

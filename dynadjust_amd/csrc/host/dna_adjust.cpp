@@ -1408,7 +1408,7 @@ void dna_adjust::DeSerialiseAdjustedVarianceMatrices() {
             memcpy(blocks_[b].rig_host, packed.data(), packed.size() * sizeof(double));
         } else {
             dnagpu_matrix** slot = phased ? &blocks_[b].rigvar : &work_[0];
-            if (!*slot) Check(dnagpu_matrix_create(ctx_, n, slot), b, "rigorous variance matrix");
+            if (!*slot) Check(dnagpu_matrix_create(ctx_, phased ? RigvarCapacity(b) : n, slot), b, "rigorous variance matrix");
             Check(dnagpu_matrix_upload_packed(ctx_, 0, *slot, packed.data(), n), b, "DeSerialiseAdjustedVarianceMatrices()");
         }
         blocks_[b].has_rigvar = true;

@@ -180,6 +180,7 @@ private:
         constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
         bool part_allowed = false, part_valid = false;
+        bool part_in_rigvar = false;          // the factor's inverse waits in rigvar's storage (dnagpu_partial_create_in): rigvar has n + 256
         bool rig_direct = false;              // this iteration's rigorous solve works in rigvar itself (no copy afterwards)
         bool inverse_pending = false;
         bool inverse_kept = false;            // CondensedReuse(): rigvar holds this adjustment's inverse, part its factor
@@ -351,6 +352,8 @@ private:
     // the condensed schedule are served by all of them; cfg3: 4.07 / 3.96 / 3.88 s per step with 2 / 3 / 4; DNAGPU_CHAINS overrides)
     int NumChains() const { return (projectSettings_.a.adjust_mode != SimultaneousMode && projectSettings_.a.multi_thread) ? mt_chains_ : 1; }
     int mt_chains_ = DNAGPU_DEFAULT_CHAINS;
+    // order the rigorous variance matrix of block k is created with (spare rows when it lends its storage to the kept factor)
+    UINT32 RigvarCapacity(UINT32 k) const { return (UINT32)v_parameterStationList_[k].size() * 3 + (blocks_[k].part_in_rigvar ? 256u : 0u); }
     bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_ && !staged_; }
     bool CondensedWanted() const {
         return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity && projectSettings_.a.adjust_mode == PhasedMode;

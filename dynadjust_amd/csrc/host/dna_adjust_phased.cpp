@@ -44,7 +44,7 @@ dnagpu_matrix* dna_adjust::StepMatrix(int c, UINT32 k, int kind) {
         B.rig_direct = true;
         if (!B.rigvar) {
             std::lock_guard<std::mutex> lk(alloc_mutex_);
-            Check(dnagpu_matrix_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, &B.rigvar), k, "rigorous variance matrix");
+            Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
         }
         return B.rigvar;
     }
@@ -231,7 +231,7 @@ void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
     if (W != B.rigvar) {
         if (!B.rigvar) {
             std::lock_guard<std::mutex> lk(alloc_mutex_);
-            Check(dnagpu_matrix_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, &B.rigvar), k, "rigorous variance matrix");
+            Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
         }
         Check(dnagpu_matrix_copy(ctx_, c, B.rigvar, W), k, "UpdateEstimatesFinal()");
     }
@@ -491,8 +491,13 @@ void dna_adjust::PrepareCondensedBlocks() {
     PrepareTwoLevel();
     AllocateChainData();
     if (!projectSettings_.a.keep_factors || !SchurCarry()) return;
-    // a.keep_factors: which blocks may keep their factor (2 n^2 + 3 k n doubles each) without starving what is allocated
-    // later -- every block's rigorous variance matrix and the chains' workspaces (work matrix + X + W per chain)
+    // a.keep_factors: which blocks may keep their factor without starving what is allocated later -- every block's rigorous
+    // variance matrix and the chains' workspaces (work matrix + X + W per chain).  The factor's inverse (n^2 doubles) waits in the
+    // block's rigorous variance matrix, which is dead from the start of an iteration until the completion writes it
+    // (dnagpu_partial_create_in): then a kept factor costs the panel under the kept rows (3 k n doubles) and every block keeps
+    // its own.  With resident variances in host memory (staged) or factors that outlive the iteration (a.reuse_inverses) it
+    // needs storage of its own, n^2 + 3 k n doubles.
+    const bool lend = !Staged() && !ReuseRequested();
     size_t free_b = 0, total_b = 0, max_keep = 0;
     Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
     auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
@@ -505,10 +510,12 @@ void dna_adjust::PrepareCondensedBlocks() {
         block_t& B = blocks_[k];
         if (B.keep.empty() || !OwnsBlock(k)) continue;      // (a block is condensed and completed on its owner's GPU only)
         const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size();
-        const double need = 2.0 * sq(n) + (nk + 256.0) * (n + 256.0) * 8.0;
+        const bool in_rigvar = lend && !B.rigvar;   // (a matrix that exists already has no spare rows)
+        const double need = (in_rigvar ? 2.0 * 256.0 * (n + 512.0) * 8.0 : sq(n)) + (nk + 256.0) * (n + 256.0) * 8.0;
         if (need > budget) continue;
         budget -= need;
         B.part_allowed = true;
+        B.part_in_rigvar = in_rigvar;
         max_keep = std::max(max_keep, B.keep.size());
     }
     const int chains = NumChains();
@@ -532,12 +539,21 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (B.part_allowed && !B.part) {
         std::lock_guard<std::mutex> lk(alloc_mutex_);
-        if (dnagpu_partial_create(ctx_, (UINT32)v_parameterStationList_[k].size() * 3, (UINT32)B.keep.size() * 3, &B.part) != DNAGPU_OK) {
+        const UINT32 n = (UINT32)v_parameterStationList_[k].size() * 3, nk = (UINT32)B.keep.size() * 3;
+        int rc;
+        if (B.part_in_rigvar) {
+            if (!B.rigvar) Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
+            rc = dnagpu_partial_create_in(ctx_, n, nk, B.rigvar, &B.part);
+        } else {
+            rc = dnagpu_partial_create(ctx_, n, nk, &B.part);
+        }
+        if (rc != DNAGPU_OK) {
             B.part = nullptr;          // no room after all: this block inverts its normals in the rigorous step as before
             B.part_allowed = false;
         }
     }
     B.part_valid = false;
+    if (B.part && B.part_in_rigvar) B.has_rigvar = false;      // (its storage holds the factor until the rigorous solve of this iteration)
     Check(dnagpu_block_reduce(ctx_, c, k, W, B.keep.data(), B.keep.size(), B.red, B.part), k, "Solve()");
     B.part_valid = B.part != nullptr;
     const double nk = 3.0 * (double)B.keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;

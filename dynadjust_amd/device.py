@@ -237,6 +237,12 @@ class DeviceContext:
         self._chk(self.lib.dnagpu_partial_create(self.h, n_max, k_max, C.byref(h)))
         return h
 
+    def partial_create_in(self, n_max, k_max, store):
+        """the factor's inverse lives in `store` (a matrix created with n_max + 256) between block_reduce and partial_complete"""
+        h = C.c_void_p()
+        self._chk(self.lib.dnagpu_partial_create_in(self.h, n_max, k_max, store.h, C.byref(h)))
+        return h
+
     def partial_destroy(self, h):
         self.lib.dnagpu_partial_destroy(self.h, h)
 

@@ -269,12 +269,17 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
 int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red,
                         dnagpu_partial* keep /* may be NULL */);
 /* With `keep`, the elimination leaves everything a later completion needs in HBM -- the factor of the eliminated part, its
- * inverse and the panel under the kept rows (2 n^2 + 3k n doubles) -- at 2/3 n_i^3 instead of ~0.34 n_i^3 flops.
+ * inverse and the panel under the kept rows (n^2 + 3k n doubles) -- at 2/3 n_i^3 instead of ~0.34 n_i^3 flops.
  * dnagpu_partial_complete then turns  [ N_II  . ; N_KI  kk ]  (kk: the kept block as the chains left it: reduced block +
  * carried junction weights + constraints, order 3k, the list order of the reduce) into its full inverse `inv`, in the block's
  * natural unknown order, for n^3/3 + O(n_i^2 k) flops -- instead of forming the block's normals again and inverting them
  * (dna_adjust::Solve, n^3).  The retained state is consumed. */
 int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_partial** out);
+/* The same without storage of its own for the factor's inverse: between the elimination and the completion it lives in `store` -- a
+ * matrix created with n_max + 256 whose content is void meanwhile (typically the block's rigorous variance matrix, which is dead from
+ * the start of an iteration until the completion writes it: `inv` of dnagpu_partial_complete may be `store` itself).  Costs the panel
+ * (3k n doubles) and nothing else; dnagpu_partial_reduce_rhs is not available afterwards.  `store` must outlive the partial. */
+int dnagpu_partial_create_in(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_matrix* store, dnagpu_partial** out);
 void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p);
 int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk, dnagpu_matrix* inv);
 /* After a completion the factor of the eliminated part is still there.  When the block's normals do not change between

@@ -253,6 +253,54 @@ def test_schur_carry_reports_a_singular_block(gpu_ctx, built, orc, tmp_path):
     gpu_ctx.block_destroy(0)
 
 
+@pytest.mark.parametrize("rows,cols,pick", [(9, 8, "jsl"), (40, 30, "jsl"), (40, 30, "scattered"), (43, 43, "one")])
+def test_kept_factor_in_the_storage_of_the_result(gpu_ctx, built, orc, tmp_path, rows, cols, pick):
+    """dnagpu_partial_create_in: the factor's inverse waits in the matrix that later receives the completed inverse (the block's rigorous
+    variance matrix is dead between the start of an iteration and its rigorous solve) -- same bits as with storage of its own, the
+    matrix reports itself empty meanwhile, and the lender may be the result"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, 2, seed=rows)
+    net = orc.Network(str(tmp_path / "s"), True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    st0, _, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    ns = len(st0)
+    n0 = 3 * ns
+    loc0 = {int(s): i for i, s in enumerate(st0)}
+    stn = {"jsl": [loc0[int(s)] for s in net.jsl[net.jsl_off[0]:net.jsl_off[1]]], "scattered": list(range(1, ns, 7))[::-1], "one": [ns // 2]}[pick]
+    idx = np.array(stn, dtype=np.uint32)
+    nk = 3 * len(idx)
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    m = gpu_ctx.matrix(n0)
+    red, kk = gpu_ctx.matrix(nk), gpu_ctx.matrix(nk)
+    results = []
+    for own in (True, False):
+        store = gpu_ctx.matrix(n0 + 256)
+        inv = gpu_ctx.matrix(n0) if own else store
+        pf = gpu_ctx.partial_create(n0, nk) if own else gpu_ctx.partial_create_in(n0, nk, store)
+        m.upload_packed(a.block_normals(0), n0)
+        gpu_ctx.block_reduce(0, m, idx, red, keep=pf)
+        S = unpack_lower(red.download_packed(), nk)
+        kk.upload_packed(pack_lower(S + np.eye(nk) * np.abs(np.diag(S)).mean() * 0.05), nk)
+        gpu_ctx.partial_complete(pf, kk, inv, n0)
+        results.append(inv.download_packed().copy())
+        if not own:
+            with pytest.raises(Exception):                      # nothing is left of the factor: the storage went back to its matrix
+                gpu_ctx.partial_reduce_rhs(0, pf, red)
+        gpu_ctx.partial_destroy(pf)
+        store.close()
+        if own:
+            inv.close()
+    assert np.array_equal(results[0], results[1])
+    tiny = gpu_ctx.matrix(max(3, n0 // 2))                       # a lender that cannot hold the factor is refused
+    with pytest.raises(Exception):
+        gpu_ctx.partial_create_in(n0, nk, tiny)
+    for q in (m, red, kk, tiny):
+        q.close()
+    gpu_ctx.block_destroy(0)
+
+
 @pytest.mark.parametrize("rows,cols,pick", [(9, 8, "jsl"), (40, 30, "jsl"), (40, 30, "scattered"), (43, 43, "one"), (12, 11, "all")])
 def test_reduce_keep_and_complete(gpu_ctx, built, orc, tmp_path, rows, cols, pick):
     """dnagpu_block_reduce with a retained factor + dnagpu_partial_complete: the kept block is changed (what the junction
