@@ -274,9 +274,72 @@ void import_dna_text(const std::string& stn_file, const std::string& msr_file, c
         const std::string& head = lines[i];
         const char t = head[0];
         const bool ignore = head.size() > 1 && head[1] == '*';
+        auto epsg_of_stations = [&]() {
+            auto code = epsg_codes().find(sum.station_frame);
+            return code == epsg_codes().end() ? std::string("7843") : code->second;
+        };
+        // "ddd mm ss.sss  sd(seconds)" after the station columns -> radians, radians
+        auto angle_and_sd = [&](const std::string& rec, double* value, double* sd) -> size_t {
+            std::istringstream ts(rec.size() > 62 ? rec.substr(62) : std::string());
+            std::vector<std::string> tok;
+            std::string w;
+            while (ts >> w) tok.push_back(w);
+            if (tok.size() < 4) throw std::runtime_error(msr_file + ": malformed angular measurement: " + rec);
+            const double sgn = tok[0][0] == '-' ? -1.0 : 1.0;
+            *value = sgn * (std::fabs(atof(tok[0].c_str())) + atof(tok[1].c_str()) / 60.0 + atof(tok[2].c_str()) / 3600.0) * PI / 180.0;
+            *sd = atof(tok[3].c_str()) * PI / 648000.0;
+            return tok.size();
+        };
+        if (t == 'D') {
+            // a set of directions (dnainterop.cpp:3060-3160 ParseDNAMSRDirections): the first line carries the instrument, the reference
+            // direction's target and the number of further directions, one line per further direction follows with its target in the
+            // third station column.  Binary (read back by dnaadjust.cpp:5100-5160): one record per direction, the first with
+            // vectorCount1 = all directions of the set, vectorCount2 = those not ignored (each counting the first one)
+            const UINT32 inst = station_of(field(head, 2, 20)), ro = station_of(field(head, 22, 20));
+            const std::vector<double> c = numbers(field(head, 42, 20));
+            if (c.empty() || c[0] < 1) throw std::runtime_error(msr_file + ": direction set without a direction count: " + head);
+            const UINT32 k = (UINT32)c[0];
+            if (i + k >= lines.size()) throw std::runtime_error(msr_file + ": direction set cut short: " + head);
+            ++cluster_id;
+            const size_t first = recs.size();
+            UINT32 live = 1;
+            for (UINT32 d = 0; d <= k; ++d) {
+                const std::string& rec = lines[i + d];
+                if (d && rec[0] != 'D' && rec[0] != ' ') throw std::runtime_error(msr_file + ": expected a direction of the set: " + rec);
+                const bool sub_ignore = d ? (rec.size() > 1 && rec[1] == '*') : false;
+                double value = 0.0, sd = 0.0;
+                angle_and_sd(rec, &value, &sd);
+                measurement_t m;
+                memset(&m, 0, sizeof(m));
+                m.measType = 'D';
+                m.measStart = d ? 1 : 0;
+                m.measurementStations = 2;
+                put(m.epsgCode, sizeof(m.epsgCode), epsg_of_stations());
+                put(m.epoch, sizeof(m.epoch), sum.station_epoch);
+                put(m.coordType, sizeof(m.coordType), "XYZ");
+                m.ignore = d ? sub_ignore : ignore;
+                m.station1 = inst;
+                m.station2 = d ? station_of(field(rec, 42, 20)) : ro;
+                m.clusterID = m.fileOrder = cluster_id;
+                m.scale1 = m.scale2 = m.scale3 = m.scale4 = 1.0;
+                m.term1 = m.preAdjMeas = value;
+                m.term2 = sd * sd;
+                recs.push_back(m);
+                if (d && !sub_ignore) ++live;
+                if (!ignore) counts[m.station2]++;
+            }
+            if (live < 2 && !ignore) throw std::runtime_error(msr_file + ": a direction set without a second direction that is not ignored: " + head);
+            recs[first].vectorCount1 = k + 1;
+            recs[first].vectorCount2 = live;
+            if (!ignore) counts[inst]++;
+            sum.clusters++;
+            i += k + 1;
+            continue;
+        }
         if (t != 'G' && t != 'X' && t != 'Y') {
-            // one-line terrestrial measurement (dnaimport: term1 = value, term2 = variance, term3 / term4 = instrument / target height)
-            static const std::string supported = "ABCEHKLMRSVZ", angular = "ABKVZ", with_heights = "SVZ";
+            // one-line terrestrial measurement (dnaimport: term1 = value, term2 = variance, term3 / term4 = instrument / target height);
+            // I / J (astronomic latitude / longitude) and P / Q (geodetic) are angles at one station
+            static const std::string supported = "ABCEHIJKLMPQRSVZ", angular = "ABIJKPQVZ", with_heights = "SVZ";
             if (supported.find(t) == std::string::npos)
                 throw std::runtime_error(msr_file + ": measurement type '" + std::string(1, t) + "' is not supported by this importer");
             std::vector<std::string> names = {field(head, 2, 20), field(head, 22, 20), field(head, 42, 20)};

@@ -40,9 +40,10 @@ void utm_to_geographic(double easting, double northing, int zone, double* lat, d
 // Throws std::runtime_error on malformed input, unknown stations, unsupported measurement types or frames.
 //   stations      LLH / LLh (ddd.mmssss), XYZ, UTM (easting northing height zone)
 //   measurements  GNSS: G, X, Y (cartesian, or LLH / LLh point clusters); terrestrial: A (horizontal angle), B / K (geodetic / astronomic
-//                 azimuth), C / E / M (chord, ellipsoid arc, MSL arc), S (slope distance), V / Z (zenith distance, vertical angle), L (height
-//                 difference), H / R (orthometric / ellipsoidal height) -- angles d m s with standard deviations in seconds, lengths in
-//                 metres; S, V, Z carry instrument and target heights (dnaimport: term1 value, term2 variance, term3 / term4 heights)
+//                 azimuth), C / E / M (chord, ellipsoid arc, MSL arc), D (direction sets), S (slope distance), V / Z (zenith distance,
+//                 vertical angle), L (height difference), H / R (orthometric / ellipsoidal height), I / J (astronomic latitude / longitude),
+//                 P / Q (geodetic latitude / longitude) -- angles d m s with standard deviations in seconds, lengths in metres; S, V, Z
+//                 carry instrument and target heights (dnaimport: term1 value, term2 variance, term3 / term4 heights)
 //   geo_file      optional DNA geoid file (dnageoid's export: station, N [m], deflections in the meridian / prime vertical [seconds]):
 //                 geoid separation and deflections into the station records, orthometric station heights (LLH, UTM) to ellipsoidal
 void import_dna_text(const std::string& stn_file, const std::string& msr_file, const std::string& out_base, import_summary* summary = nullptr,

@@ -84,6 +84,34 @@ def test_terrestrial_parity_with_oracle(built, orc, tmp_path, rows, cols, blocks
     o.close()
 
 
+@pytest.mark.parametrize("phased,blocks", [(False, 1), (True, 3)])
+def test_direction_sets_and_coordinates_from_text_files(built, orc, tmp_path, phased, blocks):
+    """the measurement types no reference sample contains -- direction sets with ignored directions, I / J / P / Q -- from DNA text through
+    the PRODUCT's importer (host/dnaimport_lite.cpp) to the device, against the oracle on the same imported files, and against the truth
+    the synthetic observations were drawn from"""
+    import shutil
+    from tests.test_import import _write_dna_text
+    types = "SVZLHRBCEMDJQ"            # (no A / K: the synthetic ones carry instrument heights the DNA format has no columns for;
+    b, (bst, bms) = T.build_mixed_network(str(tmp_path / "t"), 6, 5, blocks, seed=7, types=types)     # no I / P: their row noise, see above)
+    assert (bms["measType"] == b"D").sum() > 20 and ((bms["measType"] == b"D") & (bms["ignore"] != 0)).any()
+    _write_dna_text(bst, bms, str(tmp_path / "t.stn"), str(tmp_path / "t.msr"))
+    s = adjust.import_dna_text(str(tmp_path / "t.stn"), str(tmp_path / "t.msr"), str(tmp_path / "p"))
+    assert s["records"] == len(bms)
+    shutil.copy(str(tmp_path / "t.seg"), str(tmp_path / "p.seg"))       # same records in the same order: the segmentation carries over
+    # geoid and deflections come from a .geo file in a real import; here from the synthetic station records
+    pb = F.read_bst(str(tmp_path / "p.bst")).copy()
+    for f in ("geoidSep", "verticalDef", "meridianDef"):
+        pb[f] = bst[f]
+    F.write_bst(str(tmp_path / "p.bst"), pb)
+    net, o, ost = _oracle_run(orc, str(tmp_path / "p"), phased)
+    a, st = _device_run(str(tmp_path), "p", phased)
+    assert st == 0 and a.CurrentIteration() >= 2
+    _compare(a, st, o, ost)
+    assert np.abs(a.adjusted_coordinates(len(bst)) - b.truth).max() < 0.03
+    a.close()
+    o.close()
+
+
 def test_reuse_inverses_is_ignored_for_non_gps_networks(built, tmp_path):
     """the design of terrestrial measurements follows the estimates: inverses cannot be kept"""
     T.build_mixed_network(str(tmp_path / "r"), 6, 4, 3, seed=2, types="SVZL")

@@ -70,6 +70,112 @@ def test_urban_sample_equals_the_test_side_import(built, golden_dir, tmp_path):
     assert np.array_equal(np.asarray(F.read_asl(str(tmp_path / "p.asl"))), np.asarray(F.read_asl(str(tmp_path / "t.asl"))))
 
 
+def _dms(rad, decimals=9):
+    """radians -> ("-ddd", "mm", "ss.sssssssss") of the DNA measurement columns"""
+    sgn = "-" if rad < 0 else ""
+    a = abs(rad) * 180.0 / np.pi
+    d = int(a)
+    m = int((a - d) * 60.0)
+    sec = ((a - d) * 60.0 - m) * 60.0
+    if round(sec, decimals) >= 60.0:
+        sec = 0.0
+        m += 1
+    if m >= 60:
+        m -= 60
+        d += 1
+    return "%s%d" % (sgn, d), "%02d" % m, "%0*.*f" % (decimals + 3, decimals, sec)
+
+
+def _ddmmss(rad):
+    """radians -> ddd.mmsssss... of the DNA station columns"""
+    d, m, sec = _dms(rad, 8)
+    return "%s.%s%s" % (d, m, sec.replace(".", ""))
+
+
+def _write_dna_text(bst, bms, stn_path, msr_path):
+    """the binary network of tests/terrestrial_net.py as DNA v3.01 text files (what dnaimport would be given)"""
+    name = lambda i: bst["stationName"][i].decode().rstrip("\0").strip()
+    with open(stn_path, "w") as f:
+        f.write("!#=DNA 3.01 STN    01.01.2020       GDA2020    01.01.2020 %9d\n" % len(bst))
+        for i in range(len(bst)):
+            f.write("%-20s%-3s %-3s%20s%20s%20.6f\n" % (name(i), bst["stationConst"][i].decode().rstrip("\0"), "LLh", _ddmmss(bst["currentLatitude"][i]),
+                                                    _ddmmss(bst["currentLongitude"][i]), bst["currentHeight"][i]))
+    sec = np.pi / 648000.0
+    col = lambda t, ig, a="", b="", c="": "%s%s%-20s%-20s%-20s" % (t, "*" if ig else " ", a, b, c)
+    with open(msr_path, "w") as f:
+        f.write("!#=DNA 3.01 MSR    01.01.2020       GDA2020    01.01.2020 %9d\n" % len(bms))
+        i = 0
+        while i < len(bms):
+            r = bms[i]
+            t = r["measType"].decode()
+            if t == "D":
+                k = int(r["vectorCount1"])
+                d, m, sx = _dms(r["term1"])
+                f.write(col("D", r["ignore"], name(r["station1"]), name(r["station2"]), str(k - 1)) + " %s %s %s %.9f\n" % (d, m, sx, np.sqrt(r["term2"]) / sec))
+                for q in bms[i + 1:i + k]:
+                    d, m, sx = _dms(q["term1"])
+                    f.write(col("D", q["ignore"], "", "", name(q["station2"])) + " %s %s %s %.9f\n" % (d, m, sx, np.sqrt(q["term2"]) / sec))
+                i += k
+            elif t in "GY":
+                x, y, z = bms[i], bms[i + 1], bms[i + 2]
+                if t == "G":
+                    f.write(col("G", r["ignore"], name(r["station1"]), name(r["station2"])) + "\n")
+                else:
+                    f.write(col("Y", r["ignore"], name(r["station1"]), "XYZ", "1") + "\n")
+                pad = " " * 62
+                f.write(pad + " %.9f %.12e\n" % (x["term1"], x["term2"]))
+                f.write(pad + " %.9f %.12e %.12e\n" % (y["term1"], y["term2"], y["term3"]))
+                f.write(pad + " %.9f %.12e %.12e %.12e\n" % (z["term1"], z["term2"], z["term3"], z["term4"]))
+                i += 3
+            else:
+                stn = [name(r["station1"])] + ([name(r["station2"])] if r["measurementStations"] >= 2 else []) + ([name(r["station3"])] if r["measurementStations"] >= 3 else [])
+                if t in "ABIJKPQVZ":
+                    d, m, sx = _dms(r["term1"])
+                    val = "%s %s %s %.9f" % (d, m, sx, np.sqrt(r["term2"]) / sec)
+                else:
+                    val = "%.9f %.9f" % (r["term1"], np.sqrt(r["term2"]))
+                if t in "SVZ":
+                    val += " %.6f %.6f" % (r["term3"], r["term4"])
+                f.write(col(t, r["ignore"], *stn) + " " + val + "\n")
+                i += 1
+
+
+def test_every_measurement_type_through_the_text_files(built, tmp_path):
+    """a synthetic network with all 17 terrestrial types -- direction sets (with ignored directions) and the single-station I / J / P / Q
+    included, which the reference's samples do not contain -- written as DNA text and imported by the product: the records the
+    adjustment reads (types, stations, set bookkeeping, values, variances, instrument / target heights) equal those of the directly
+    written binary network that the oracle and the device adjust (tests/test_gpu_terrestrial.py)"""
+    from tests import terrestrial_net as TN
+    b, (bst, bms) = TN.build_mixed_network(str(tmp_path / "t"), rows=6, cols=5, blocks=1, seed=4, types="SVZLHRBKACEMDIJPQ")
+    types = set(x.decode() for x in bms["measType"])
+    assert types == set("SVZLHRBKACEMDIJPQGY")
+    assert (bms["ignore"] != 0).any()                                  # a dropped direction somewhere
+    _write_dna_text(bst, bms, str(tmp_path / "t.stn"), str(tmp_path / "t.msr"))
+    s = adjust.import_dna_text(str(tmp_path / "t.stn"), str(tmp_path / "t.msr"), str(tmp_path / "p"))
+    assert s["stations"] == len(bst) and s["records"] == len(bms) and s["vectors_transformed"] == 0
+    pb, pm = F.read_bst(str(tmp_path / "p.bst")), F.read_bms(str(tmp_path / "p.bms"))
+    assert np.abs(pb["currentLatitude"] - bst["currentLatitude"]).max() < 1e-12 and np.abs(pb["currentLongitude"] - bst["currentLongitude"]).max() < 1e-12
+    assert np.abs(pb["currentHeight"] - bst["currentHeight"]).max() < 1e-6
+    for f in ("measType", "measStart", "station1", "station2", "station3", "ignore", "measurementStations"):
+        assert np.array_equal(pm[f], bms[f]), f
+    dset = bms["measType"] == b"D"
+    for f in ("vectorCount1", "vectorCount2", "clusterID"):
+        assert np.array_equal(pm[f][dset], bms[f][dset]), f
+    ang = np.isin(bms["measType"], [x.encode() for x in "ABDIJKPQVZ"])
+    assert np.abs(pm["term1"][ang] - bms["term1"][ang]).max() < 1e-13              # 1e-9 seconds of arc
+    assert np.abs(pm["term1"][~ang] - bms["term1"][~ang]).max() < 1e-8
+    heights = np.isin(bms["measType"], [b"S", b"V", b"Z"])                     # term3 / term4: instrument / target height, six decimals
+    for f in ("term3", "term4"):
+        assert np.abs(pm[f][heights] - bms[f][heights]).max() < 1e-6, f
+    gnss = np.isin(bms["measType"], [b"G", b"Y"])                             # term3 / term4: covariances (the synthetic A / K records carry
+    for f, rows in (("term2", np.ones(len(bms), bool)), ("term3", gnss), ("term4", gnss)):     # heights the DNA format has no columns for)
+        a, e = pm[f][rows], bms[f][rows]
+        assert np.array_equal(a == 0, e == 0), f
+        nz = e != 0
+        assert np.abs(a[nz] / e[nz] - 1.0).max() < 1e-6, f                    # variances: from standard deviations printed to 1e-9
+    assert np.array_equal(np.asarray(F.read_asl(str(tmp_path / "p.asl"))), np.asarray(F.read_asl(str(tmp_path / "t.asl"))))
+
+
 def test_utm_against_the_test_side_series(built):
     import ctypes as C
     from tests import urban_net as U
@@ -113,7 +219,12 @@ def test_frame_alignment_formulas(built):
 @pytest.mark.parametrize("stn,msr,message", [
     ("A                   FFF ENU        500000.0000        6000000.0000            10.0000    \n", "", "not supported"),
     ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
-     "D A                   A                                                           100.0 0.01\n", "not supported"),
+     "T A                   A                                                           100.0 0.01\n", "not supported"),
+    ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
+     "D A                   A                                                           100 00 00.0 1.0\n", "without a direction count"),
+    ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
+     "D A                   A                   2                    100 00 00.0 1.0\n"
+     "D                                         A                    120 00 00.0 1.0\n", "cut short"),
     ("A                   FFF LLH      -36.3348253617      145.5741006771            172.1933    \n",
      "G A                   NOWHERE                                       1.00      1.00      1.00      1.00             GDA2020          01.01.2020\n"
      "   1.0 1e-6\n   1.0 0 1e-6\n   1.0 0 0 1e-6\n", "is not in the station file"),
