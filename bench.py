@@ -259,7 +259,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     a.attach_rccl(rank, world, bytes(idt.numpy().tobytes()), local_rank)
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank, dist_rank=rank, dist_world=world,
                                multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
-                               schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage,
+                               schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage, defer_variances=not args.variances_every_iteration,
                                dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))))
     a.PrepareAdjustment(p)
     lib, ctx = a.lib, a.device_context()
@@ -338,7 +338,8 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"stations": stations, "blocks": B, "iterations_to_converge": its, "mode": "phased", "solves_per_step": solves,
-                       "schur_carry": condensed, "keep_factors": any(v["completions"] for v in allv), "parallelism": par,
+                       "schur_carry": condensed, "keep_factors": any(v["completions"] for v in allv),
+                       "variance_matrices": "after the last iteration" if (not args.variances_every_iteration and any(v["completions"] for v in allv)) else "every iteration", "parallelism": par,
                        "driver": "C++ (libdnagpu.so) + RCCL", "variance_propagation_in_step": bool(args.variance_propagation), "blocks_per_rank": [owners.count(r) for r in range(world)]},
             "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
             "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
@@ -385,6 +386,9 @@ def main():
                          "eliminating the inner unknowns of the steps that are only carried on")
     ap.add_argument("--no-keep-factors", action="store_true",
                     help="condensed schedule without the retained factors (a.keep_factors = 0): every rigorous solve forms and inverts its block again")
+    ap.add_argument("--variances-every-iteration", action="store_true",
+                    help="a.defer_variances = 0: every rigorous solve forms its block's inverse like dna_adjust::Solve (default: the iterations "
+                         "take their corrections from the completed factors and the rigorous variance matrices are formed once, after the last one)")
     ap.add_argument("--variance-propagation", action="store_true",
                     help="BASELINE.json configs[4]: the timed step also propagates the rigorous variances to every adjusted measurement "
                          "(GenerateStatistics: precisions of the adjusted measurements A S A^T from the resident variance matrices, chi-square, "
@@ -461,6 +465,7 @@ def main():
     p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode,
                                multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank,
                                reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors,
+                               defer_variances=not args.variances_every_iteration,
                                stage=phased and args.stage)
     a.PrepareAdjustment(p)
     lib = a.lib
@@ -524,6 +529,7 @@ def main():
             "max_block_unknowns": info["max_block_unknowns"], "iterations_to_converge": iters, "solves_per_step": solves,
             "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses),
             "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
+            "variance_matrices": "after the last iteration" if (a.completion_count() and not args.variances_every_iteration and not args.reuse_inverses) else "every iteration",
             "completions_per_step": a.completion_count(), "variance_propagation_in_step": bool(args.variance_propagation), "parallelism": "1 GPU, one chain" if not p.multi_thread else
             "1 GPU, %s chains (multi_thread: the independent block steps of the condensed schedule are served by every chain; the two junction chains run side by side)" % os.environ.get("DNAGPU_CHAINS", "4"),
         },

@@ -35,7 +35,7 @@ class DnaAdjSettings(C.Structure):
                 ("scale_normals_to_unity", C.c_int), ("device", C.c_int), ("confidence_interval", C.c_float),
                 ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int), ("schur_carry", C.c_int), ("stage", C.c_int), ("keep_factors", C.c_int),
                 ("dist_rank", C.c_int), ("dist_world", C.c_int), ("n_devices", C.c_int), ("devices", C.POINTER(C.c_int)),
-                ("dist_transport", C.c_char_p), ("dist_two_level", C.c_int)]
+                ("dist_transport", C.c_char_p), ("dist_two_level", C.c_int), ("defer_variances", C.c_int)]
 
 
 class DnaAdjStatistics(C.Structure):
@@ -161,6 +161,9 @@ def load():
     _sig(lib, "dnagpu_partial_destroy", None, [vp, vp])
     _sig(lib, "dnagpu_partial_complete", i, [vp, i, vp, vp, vp])
     _sig(lib, "dnagpu_partial_reduce_rhs", i, [vp, i, u32, vp, vp])
+    _sig(lib, "dnagpu_partial_complete_factor", i, [vp, i, vp, vp])
+    _sig(lib, "dnagpu_partial_solve", i, [vp, i, u32, vp])
+    _sig(lib, "dnagpu_partial_finish", i, [vp, i, vp, vp])
     _sig(lib, "dnagpu_block_load_reduced", i, [vp, i, u32, u32, c_u32p, sz, vp, vp])
     _sig(lib, "dnagpu_junction_scatter", i, [vp, i, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_block_add_rhs", i, [vp, i, u32, c_u32p, sz, vp, i])
@@ -277,7 +280,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
     "dnagpu_block_set_direction_sets", "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
-    "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_reduce_rhs",
+    "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
 ]

@@ -555,6 +555,43 @@ __global__ void gemv_finish_kernel(const double* __restrict__ part, uint32_t row
     for (uint32_t c = 0; c < nchunks; ++c) s += part[(size_t)c * rows + i];
     out[i] = (base ? base[i] : 0.0) + sign * s;
 }
+// out[j] = sum over i >= j of A(i, j) y(i), j < n: the transposed product with a lower triangular matrix (column-major, so a wave
+// walks ONE column: 64 lanes x 8 B contiguous).  One wave per column, lane partial sums in a fixed order, butterfly reduction:
+// deterministic.  HBM-bound: n^2 / 2 x 8 B.
+__global__ __launch_bounds__(256) void gemv_t_lower_kernel(const double* __restrict__ A, uint32_t lda, uint32_t n, const double* __restrict__ y,
+                                                           double* __restrict__ out) {
+    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (j >= n) return;
+    const double* col = A + (size_t)j * lda;
+    double a0 = 0.0, a1 = 0.0;
+    uint32_t i = (j & ~63u) + lane;          // aligned start: 512 B segments
+    if (i < j) i += 64;
+    for (; i + 64 < n; i += 128) {
+        a0 += col[i] * y[i];
+        a1 += col[i + 64] * y[i + 64];
+    }
+    if (i < n) a0 += col[i] * y[i];
+    double v = a0 + a1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) out[j] = v;
+}
+// out[map[p]] = v[p] for the positions that carry an unknown
+__global__ void scatter_map_kernel(const double* __restrict__ v, const int32_t* __restrict__ map, uint32_t npp, double* __restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npp) return;
+    const int32_t m = map[p];
+    if (m >= 0) out[m] = v[p];
+}
+void launch_gemv_t_lower(const double* A, uint32_t lda, uint32_t n, const double* y, double* out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(gemv_t_lower_kernel, dim3((n + 3) / 4), dim3(256), 0, s, A, lda, n, y, out);
+}
+void launch_scatter_map(const double* v, const int32_t* map, uint32_t npp, double* out, hipStream_t s) {
+    if (!npp) return;
+    hipLaunchKernelGGL(scatter_map_kernel, dim3((npp + 255) / 256), dim3(256), 0, s, v, map, npp, out);
+}
 void launch_gather_map(const double* rhs, const int32_t* map, uint32_t npp, double* out, hipStream_t s) {
     hipLaunchKernelGGL(gather_map_kernel, dim3((npp + 255) / 256), dim3(256), 0, s, rhs, map, npp, out);
 }

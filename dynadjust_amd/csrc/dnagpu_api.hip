@@ -1489,6 +1489,7 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
         hipStream_t st = ctx->stream[chain];
         keep->valid = false;
         keep->completed = false;
+        keep->factored = false;
         keep->n = n; keep->nj = nj; keep->nip = nip; keep->njp = njp; keep->npp = npp;
         // the matrix being factored lives in the chain's X workspace (free here: the kept L^-1 has a home of its own); nothing of
         // it is needed after this call but the Schur complement, which the caller extracts at once
@@ -1621,6 +1622,69 @@ int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, cons
     launch_init_padded(inv->F, inv->n, inv->np, st);
     launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info(ctx, chain);
+}
+
+int dnagpu_partial_complete_factor(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!pf || !pf->valid || !kk || kk->n != pf->nj) return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor: bad arguments");
+    int rc = ensure_ws(ctx, chain, pf->npp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    pf->valid = false;
+    pf->completed = false;
+    double* F = ws.X;        // scratch: the kept block's factorisation and the T_KI panel pass through it
+    launch_partial_set_trailing(F + (size_t)pf->nip * pf->npp + pf->nip, pf->npp, pf->njp, kk->F, kk->np, pf->nj, st);
+    sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128), 1);
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    rc = check_info(ctx, chain);
+    pf->factored = rc == DNAGPU_OK;
+    return rc;
+}
+
+int dnagpu_partial_solve(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_partial* pf) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !pf || !pf->factored || 3 * b->n_stn != pf->n) return fail(ctx, DNAGPU_EINVAL, "partial_solve: bad arguments");
+    int rc = ensure_ws(ctx, chain, pf->npp);
+    if (!rc) rc = ensure_symv(ctx, chain, pf->npp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    // corrections = N^-1 rhs = P (X^T (X (P^T rhs))): two triangular matrix-vector products in the elimination's order
+    double* rp = ws.svec;                                           // P^T rhs, then the result
+    double* y = ctx->symv_part[chain] + (size_t)SYMV_CHUNKS * pf->npp - pf->npp;     // (the last chunk row of the partial sums: free once they are added up)
+    launch_gather_map(b->rhs[chain], pf->map, pf->npp, rp, st);
+    launch_gemv(pf->X, pf->npp, pf->npp, pf->npp, rp, ctx->symv_part[chain], SYMV_CHUNKS - 1, 1, nullptr, 1.0, y, pf->npp, st);
+    launch_gemv_t_lower(pf->X, pf->npp, pf->npp, y, rp, st);
+    launch_scatter_map(rp, pf->map, pf->npp, b->corr[chain], st);
+    return DNAGPU_OK;
+}
+
+int dnagpu_partial_finish(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, dnagpu_matrix* inv) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!pf || !pf->factored || !inv || pf->n > inv->n_max) return fail(ctx, DNAGPU_EINVAL, "partial_finish: bad arguments");
+    int rc = ensure_ws(ctx, chain, pf->npp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    pf->factored = false;
+    pf->completed = pf->store == nullptr;
+    double* F = ws.X;
+    sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128), 2);
+    inv->n = pf->n;
+    inv->np = pad128(pf->n);
+    launch_init_padded(inv->F, inv->n, inv->np, st);
+    launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
 }

@@ -822,7 +822,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     condense_count_ = 0;
     completion_count_ = 0;
     algorithmic_flops_ = 0.0;
-    for (block_t& b : blocks_) b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = false;
+    for (block_t& b : blocks_) b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
     const double t0 = now_ms();
     switch (projectSettings_.a.adjust_mode) {
         case SimultaneousMode: AdjustSimultaneous(); break;
@@ -972,6 +972,7 @@ void dna_adjust::AdjustPhased() {
         if (!iterate) break;
         UpdateAdjustment(iterate);
     }
+    if (!IsCancelled()) FinishDeferredVariances();
     FinishStagedCopies();
     ValidateandFinaliseAdjustment();
 }
@@ -1034,7 +1035,7 @@ void dna_adjust::ResetAdjustment() {
         for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "ResetAdjustment()");
         blocks_[b].has_rigvar = false;
         blocks_[b].has_finv = blocks_[b].has_rinv = blocks_[b].has_cinv = false;
-        blocks_[b].inverse_kept = blocks_[b].inverse_pending = blocks_[b].part_valid = blocks_[b].rig_direct = false;
+        blocks_[b].inverse_kept = blocks_[b].inverse_pending = blocks_[b].part_valid = blocks_[b].rig_direct = blocks_[b].var_deferred = false;
     }
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
     currentIteration_ = 0;

@@ -180,6 +180,7 @@ private:
         constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
         bool part_allowed = false, part_valid = false;
+        bool var_deferred = false;            // a.defer_variances: this iteration's inverse exists as the completed factor in `part` only
         bool part_in_rigvar = false;          // the factor's inverse waits in rigvar's storage (dnagpu_partial_create_in): rigvar has n + 256
         bool rig_direct = false;              // this iteration's rigorous solve works in rigvar itself (no copy afterwards)
         bool inverse_pending = false;
@@ -362,7 +363,11 @@ private:
     bool SchurCarry() const { return CondensedWanted() && !ReuseInverses(); }
     bool CondensedReuse() const { return ReuseRequested() && CondensedSchedule() && projectSettings_.a.keep_factors != 0; }
     // kind: 0 forward (last block), 1 reverse (first block), 2 combination
-    void CompleteFromPartial(int chain, UINT32 block, int kind, dnagpu_matrix* W);
+    // returns true when the block's corrections are already there (a.defer_variances: taken from the completed factor, W untouched)
+    bool CompleteFromPartial(int chain, UINT32 block, int kind, dnagpu_matrix* W);
+    // a.defer_variances: the inverses that the iterations left as completed factors (block_t::var_deferred), once the iterations have ended
+    bool DeferVariances() const { return projectSettings_.a.defer_variances != 0 && !ReuseRequested(); }
+    void FinishDeferredVariances();
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
     bool condensed_ok_ = false;
     // a.stage (the reference's --staged-adjustment keeps its block matrices in memory-mapped files): the rigorous variance

@@ -102,8 +102,10 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
         CarryByElimination(c, k, k, W, B.jsl_here, B.jfwd);
         return 0.0;
     }
-    if (fused) CompleteFromPartial(c, k, 0, W);
-    if (reuse || fused)
+    const bool solved = fused && CompleteFromPartial(c, k, 0, W);
+    if (solved)
+        ;       // (a.defer_variances: the corrections came from the completed factor)
+    else if (reuse || fused)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else
         SolveTry(c, k, W);
@@ -155,8 +157,10 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
         CarryByElimination(c, k, k, W, B.jslprev_here, blocks_[k - 1].jrev);
         return 0.0;
     }
-    if (fused) CompleteFromPartial(c, k, 1, W);
-    if (reuse || fused)
+    const bool solved = fused && CompleteFromPartial(c, k, 1, W);
+    if (solved)
+        ;       // (a.defer_variances: the corrections came from the completed factor)
+    else if (reuse || fused)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else
         SolveTry(c, k, W);
@@ -198,8 +202,10 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
     if (fwd_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
-    if (fused) CompleteFromPartial(c, k, 2, W);
-    if (reuse || fused)
+    const bool solved = fused && CompleteFromPartial(c, k, 2, W);
+    if (solved)
+        ;       // (a.defer_variances: the corrections came from the completed factor)
+    else if (reuse || fused)
         Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
     else
         SolveTry(c, k, W);
@@ -213,6 +219,10 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
 // v_rigorousVariances_[k] = the inverse currently held by W (a copy, unless W already is the block's resident matrix)
 void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
     block_t& B = blocks_[k];
+    if (B.var_deferred) {           // a.defer_variances: W holds nothing yet -- FinishDeferredVariances comes back here
+        B.has_rigvar = false;
+        return;
+    }
     if (Staged()) {
         // the inverse leaves HBM: packed on the device, copied to the block's page-locked host buffer
         const size_t n = v_parameterStationList_[k].size() * 3;
@@ -526,6 +536,7 @@ void dna_adjust::PrepareCondensedBlocks() {
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
     B.rig_direct = false;
+    B.var_deferred = false;         // (a factor left from the previous iteration is overwritten by this one's)
     if (B.keep.empty()) return;
     if (CondensedReuse() && B.inverse_kept) {
         // same normals as in the iteration that kept the factor: only the right-hand side is reduced again
@@ -567,7 +578,7 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
 // The rigorous solve of a block whose condensing step kept its factor (a.keep_factors): the kept block gets exactly what the
 // forward (kind 0) / reverse (1) / combination (2) solve adds to the shared stations, in the same order, and the retained
 // factor is completed to the inverse of the whole block -- W holds what SolveTry's dnagpu_invert would have left
-void dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W) {
+bool dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W) {
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
     const bool rev_in = !meta._blockLast && !B.c_next.empty();
@@ -587,16 +598,52 @@ void dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W
             AddConstraints(c, K, B.ccon_cmb, -1, k);
         }
     }
-    Check(dnagpu_partial_complete(ctx_, c, B.part, K, W), k, "Solve()");
+    const bool defer = DeferVariances();
+    if (defer) {
+        // the factor of the whole block, and the corrections from it; the inverse waits for the end of the iterations
+        Check(dnagpu_partial_complete_factor(ctx_, c, B.part, K), k, "Solve()");
+        Check(dnagpu_partial_solve(ctx_, c, k, B.part), k, "Solve()");
+        B.var_deferred = true;
+    } else {
+        Check(dnagpu_partial_complete(ctx_, c, B.part, K, W), k, "Solve()");
+    }
     B.part_valid = false;
     B.inverse_pending = CondensedReuse();  // kept once StoreRigorousVariances has copied W into the block's own matrix
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
     solve_flops_ += n * n * n;
     solve_count_++;
-    // factor + invert the kept block, the two panel products of the kept rows, X^T X
-    algorithmic_flops_ += nk * nk * nk + nk * ni * ni + nk * nk * ni + n * n * n / 3.0;
+    // factor + invert the kept block, the two panel products of the kept rows, X^T X (now, or in FinishDeferredVariances)
+    algorithmic_flops_ += nk * nk * nk + nk * ni * ni + nk * nk * ni + (defer ? 0.0 : n * n * n / 3.0);
     completion_count_++;
+    return defer;
+}
+
+// a.defer_variances: X^T X for every block whose last rigorous solve left its inverse as a completed factor
+void dna_adjust::FinishDeferredVariances() {
+    std::vector<UINT32> todo;
+    for (UINT32 k = 0; k < blockCount_; ++k)
+        if (OwnsBlock(k) && blocks_[k].var_deferred && blocks_[k].part) todo.push_back(k);
+    if (todo.empty()) return;
+    FinishStagedCopies();
+    ForBlocks(todo, [&](int c, UINT32 k) {
+        block_t& B = blocks_[k];
+        dnagpu_matrix* W = work_[c];
+        if (!Staged()) {
+            if (!B.rigvar) {
+                std::lock_guard<std::mutex> lk(alloc_mutex_);
+                Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
+            }
+            W = B.rigvar;
+        }
+        Check(dnagpu_partial_finish(ctx_, c, B.part, W), k, "Solve()");
+        B.var_deferred = false;
+        StoreRigorousVariances(c, k, W);
+        Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
+        const double n = 3.0 * (double)v_parameterStationList_[k].size();
+        std::lock_guard<std::mutex> lk(corr_mutex_);
+        algorithmic_flops_ += n * n * n / 3.0;
+    });
 }
 
 // PhasedForwardBlock on the condensed block: same additions, same order
@@ -755,6 +802,10 @@ bool dna_adjust::PhasedEndIteration() {
 }
 
 void dna_adjust::PhasedFinish() {
+    if (Distributed())
+        AgreeOnPhase("rigorous variance matrices", [&] { if (!IsCancelled()) FinishDeferredVariances(); });
+    else if (!IsCancelled())
+        FinishDeferredVariances();
     FinishStagedCopies();
     ValidateandFinaliseAdjustment();
 }

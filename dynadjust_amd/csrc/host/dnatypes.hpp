@@ -224,6 +224,10 @@ struct adjust_settings {
     // boundary systems are scanned, every rank finishes its own blocks); 0 = every rank runs both chains on all condensed blocks
     // (one broadcast per block)
     UINT16 dist_two_level = 1;
+    // condensed schedule with kept factors: an iteration takes its corrections from the completed FACTOR of every block (two triangular
+    // matrix-vector products) and the inverses -- the rigorous variance matrices, n^3 / 3 per block -- are formed once, after the last
+    // iteration, instead of in every iteration.  Same results (the variances are those of the last iteration's normals either way).
+    UINT16 defer_variances = 1;
 };
 struct output_settings {
     UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement

@@ -95,7 +95,8 @@ void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, in
 void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti, int tj);
 // F: trailing tj x tj tiles hold the (updated) kept block; X, F leading parts as sym_schur_keep_async left them; WK: the saved
 // panel L_KI (tj*128 x ti*128, ldwk).  On return F = inverse of the whole matrix, both triangles, in the elimination's order.
-void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj);
+// what: 1 = the factor only (X = L^-1 of the whole matrix complete; F is scratch), 2 = the inverse X^T X -> F only (after a 1), 3 = both
+void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj, int what = 3);
 
 // sum the event timings recorded so far (synchronises the stream)
 void gemm_profile_collect(InvWorkspace& ws);

@@ -470,36 +470,40 @@ void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti
     gemm_profile_close(ws);
 }
 
-void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
-    const int key = (1 << 28) | (ti << 12) | tj;
+void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj, int what) {
+    if (what & 1) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
+    const int key = (1 << 28) | ((what & 3) << 26) | (ti << 12) | tj;
     const int T = ti + tj;
     for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
         Rec rec{ws, F, ld, X, ld, ws.W, ld, pass == 0};
-        rec.node(ti, tj);
         GemmArgs a;
-        if (ti > 0) {
-            // T_KI = L_KI * X_II -> the kept rows of F;  X_KI = -X_KK * T_KI
-            a.A = WK; a.lda = ldwk;
-            a.B = rec.x(0, 0); a.ldb = ld;
-            a.C = rec.f(ti, 0); a.ldc = ld;
-            a.mt = tj; a.nt = ti; a.K = ti * 128;
-            a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
-            rec.gemm(ws, a, 0, 1);
-            a.A = rec.x(ti, ti); a.lda = ld;
-            a.B = rec.f(ti, 0); a.ldb = ld;
-            a.C = rec.x(ti, 0); a.ldc = ld;
-            a.mt = tj; a.nt = ti; a.K = tj * 128;
-            a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
-            rec.gemm(ws, a, 0, 1);
+        if (what & 1) {
+            rec.node(ti, tj);
+            if (ti > 0) {
+                // T_KI = L_KI * X_II -> the kept rows of F;  X_KI = -X_KK * T_KI
+                a.A = WK; a.lda = ldwk;
+                a.B = rec.x(0, 0); a.ldb = ld;
+                a.C = rec.f(ti, 0); a.ldc = ld;
+                a.mt = tj; a.nt = ti; a.K = ti * 128;
+                a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
+                rec.gemm(ws, a, 0, 1);
+                a.A = rec.x(ti, ti); a.lda = ld;
+                a.B = rec.f(ti, 0); a.ldb = ld;
+                a.C = rec.x(ti, 0); a.ldc = ld;
+                a.mt = tj; a.nt = ti; a.K = tj * 128;
+                a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
+                rec.gemm(ws, a, 0, 1);
+            }
         }
-        // inverse = X^T X, both triangles
-        a.A = X; a.lda = ld;
-        a.B = X; a.ldb = ld;
-        a.C = F; a.ldc = ld;
-        a.mt = T; a.nt = T; a.K = T * 128;
-        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
-        rec.gemm(ws, a, 1, 1);
+        if (what & 2) {
+            // inverse = X^T X, both triangles
+            a.A = X; a.lda = ld;
+            a.B = X; a.ldb = ld;
+            a.C = F; a.ldc = ld;
+            a.mt = T; a.nt = T; a.K = T * 128;
+            a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
+            rec.gemm(ws, a, 1, 1);
+        }
         if (ws.err != hipSuccess) return;
     }
     ws.planned.insert(key);

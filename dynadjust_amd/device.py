@@ -251,6 +251,18 @@ class DeviceContext:
         self._chk(self.lib.dnagpu_partial_complete(self.h, chain, pf, kk.h, inv.h))
         inv.n = n
 
+    def partial_complete_factor(self, pf, kk, chain=0):
+        self._chk(self.lib.dnagpu_partial_complete_factor(self.h, chain, pf, kk.h))
+
+    def partial_solve(self, blk, pf, chain=0):
+        """corrections(blk) <- N^-1 rhs(blk) from the completed factor"""
+        self._chk(self.lib.dnagpu_partial_solve(self.h, chain, blk, pf))
+        self.sync()
+
+    def partial_finish(self, pf, inv, n, chain=0):
+        self._chk(self.lib.dnagpu_partial_finish(self.h, chain, pf, inv.h))
+        inv.n = n
+
     def partial_reduce_rhs(self, blk, pf, red, chain=0):
         self._chk(self.lib.dnagpu_partial_reduce_rhs(self.h, chain, blk, pf, red.h))
         self.sync()

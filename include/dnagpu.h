@@ -282,6 +282,15 @@ int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagp
 int dnagpu_partial_create_in(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_matrix* store, dnagpu_partial** out);
 void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p);
 int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk, dnagpu_matrix* inv);
+/* The completion in two halves.  An iteration of the adjustment needs the block's solution, not its inverse: the reference obtains the
+ * one through the other (dna_adjust::Solve: N^-1, then N^-1 rhs), and only the inverse of the LAST iteration is a result (the rigorous
+ * variances).  dnagpu_partial_complete_factor turns the kept state into X = L^-1 of the whole block (the kept block factored and
+ * inverted, the two panel products: ~0.08 n^3); dnagpu_partial_solve gives  corrections(blk) = X^T (X rhs(blk))  -- two triangular
+ * matrix-vector products, what dnagpu_solve_corrections computes from the inverse --; dnagpu_partial_finish, once the iterations
+ * have ended, forms  inv = X^T X  (n^3 / 3) in the block's natural order.  factor + finish == dnagpu_partial_complete. */
+int dnagpu_partial_complete_factor(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk);
+int dnagpu_partial_solve(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_partial* pf);
+int dnagpu_partial_finish(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, dnagpu_matrix* inv);
 /* After a completion the factor of the eliminated part is still there.  When the block's normals do not change between
  * iterations (GNSS-only network), the reduced right-hand side of the next iteration is  rhs_K - L_KI (L_II^-1 rhs_I) : two
  * matrix-vector products with the kept X = L_II^-1 and the kept panel instead of a new elimination.  red's vector <- that; red's

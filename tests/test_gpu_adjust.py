@@ -519,8 +519,10 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
     else:
         adjust.write_synthetic_network(str(tmp_path), "c", 16, 12, 0, blocks, seed=4, x_clusters=12, y_cluster=True, initial_sigma=0.3)
     runs = []
-    for schur, keep in ((False, False), (True, False), (True, True)):
-        a, st = _device_run(str(tmp_path), "c", True, multi_thread=mt, schur_carry=schur, keep_factors=keep)
+    # ... a.keep_factors: the rigorous solve completes the factor the condensing step kept; a.defer_variances (default): the iterations
+    # take their corrections from the completed factor and the inverses are formed once, at the end
+    for schur, keep, defer in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+        a, st = _device_run(str(tmp_path), "c", True, multi_thread=mt, schur_carry=schur, keep_factors=keep, defer_variances=defer)
         assert st == 0
         a.GenerateStatistics()
         # a.keep_factors: every block's rigorous solve completes the factor its condensing step kept

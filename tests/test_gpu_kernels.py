@@ -301,6 +301,71 @@ def test_kept_factor_in_the_storage_of_the_result(gpu_ctx, built, orc, tmp_path,
     gpu_ctx.block_destroy(0)
 
 
+@pytest.mark.parametrize("rows,cols,pick,lend", [(9, 8, "jsl", False), (40, 30, "jsl", True), (40, 30, "scattered", False), (43, 43, "one", True)])
+def test_completion_in_two_halves(gpu_ctx, built, orc, tmp_path, rows, cols, pick, lend):
+    """dnagpu_partial_complete_factor + dnagpu_partial_solve + dnagpu_partial_finish: the solution of an iteration from the completed
+    factor (two triangular matrix-vector products) equals inverse x right-hand side, and the inverse formed afterwards is the one
+    dnagpu_partial_complete gives -- bit for bit (same launches in the same order)"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, 2, seed=rows)
+    net = orc.Network(str(tmp_path / "s"), True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    st0, _, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    ns = len(st0)
+    n0 = 3 * ns
+    loc0 = {int(s): i for i, s in enumerate(st0)}
+    stn = {"jsl": [loc0[int(s)] for s in net.jsl[net.jsl_off[0]:net.jsl_off[1]]], "scattered": list(range(1, ns, 7))[::-1], "one": [ns // 2]}[pick]
+    idx = np.array(stn, dtype=np.uint32)
+    nk = 3 * len(idx)
+    rws = (3 * idx[:, None] + np.arange(3)).ravel()
+    N0 = unpack_lower(a.block_normals(0), n0)
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    m = gpu_ctx.matrix(n0)
+    red, kk = gpu_ctx.matrix(nk), gpu_ctx.matrix(nk)
+    out = []
+    for halves in (False, True):
+        store = gpu_ctx.matrix(n0 + 256)
+        inv = store if lend else gpu_ctx.matrix(n0)
+        pf = gpu_ctx.partial_create_in(n0, nk, store) if lend else gpu_ctx.partial_create(n0, nk)
+        m.upload_packed(a.block_normals(0), n0)
+        gpu_ctx.block_reduce(0, m, idx, red, keep=pf)
+        S = unpack_lower(red.download_packed(), nk)
+        D = np.eye(nk) * np.abs(np.diag(S)).mean() * 0.05
+        kk.upload_packed(pack_lower(S + D), nk)
+        if halves:
+            gpu_ctx.partial_complete_factor(pf, kk)
+            gpu_ctx.partial_solve(0, pf)
+            x_factor = gpu_ctx.block_get_corrections(0, ns)
+            with pytest.raises(Exception):
+                gpu_ctx.partial_complete_factor(pf, kk)            # the reduce's state is consumed
+            gpu_ctx.partial_finish(pf, inv, n0)
+            with pytest.raises(Exception):
+                gpu_ctx.partial_finish(pf, inv, n0)                # ... and so is the factor
+        else:
+            gpu_ctx.partial_complete(pf, kk, inv, n0)
+        out.append(inv.download_packed().copy())
+        if halves:
+            gpu_ctx.solve_corrections(0, inv)
+            gpu_ctx.sync()
+            x_inverse = gpu_ctx.block_get_corrections(0, ns)
+            scale = max(1e-30, np.abs(x_inverse).max())
+            assert np.abs(x_factor - x_inverse).max() < 1e-11 * scale, np.abs(x_factor - x_inverse).max() / scale
+            M = N0.copy()
+            M[np.ix_(rws, rws)] += D
+            ref = np.linalg.inv(M)
+            assert np.abs(unpack_lower(out[-1], n0) - ref).max() < 1e-9 * np.abs(ref).max()
+        gpu_ctx.partial_destroy(pf)
+        store.close()
+        if not lend:
+            inv.close()
+    assert np.array_equal(out[0], out[1])
+    for q in (m, red, kk):
+        q.close()
+    gpu_ctx.block_destroy(0)
+
+
 @pytest.mark.parametrize("rows,cols,pick", [(9, 8, "jsl"), (40, 30, "jsl"), (40, 30, "scattered"), (43, 43, "one"), (12, 11, "all")])
 def test_reduce_keep_and_complete(gpu_ctx, built, orc, tmp_path, rows, cols, pick):
     """dnagpu_block_reduce with a retained factor + dnagpu_partial_complete: the kept block is changed (what the junction
