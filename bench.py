@@ -259,7 +259,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     a.attach_rccl(rank, world, bytes(idt.numpy().tobytes()), local_rank)
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank, dist_rank=rank, dist_world=world,
                                multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
-                               schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage, defer_variances=not args.variances_every_iteration,
+                               schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage, defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
                                dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))))
     a.PrepareAdjustment(p)
     lib, ctx = a.lib, a.device_context()
@@ -465,7 +465,7 @@ def main():
     p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode,
                                multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank,
                                reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors,
-                               defer_variances=not args.variances_every_iteration,
+                               defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
                                stage=phased and args.stage)
     a.PrepareAdjustment(p)
     lib = a.lib

@@ -35,7 +35,7 @@ class ProjectSettings:
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
                  scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None,
                  reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False, dist_rank=0, dist_world=1, devices=None,
-                 dist_transport=None, dist_two_level=True, defer_variances=True):
+                 dist_transport=None, dist_two_level=True, defer_variances=2):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
         self.network_name = network_name          # g.network_name
         self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
@@ -126,7 +126,7 @@ class DnaAdjust:
         self._transport = _b(getattr(p, "dist_transport", None))
         s.dist_transport = self._transport
         s.dist_two_level = int(bool(getattr(p, "dist_two_level", True)))
-        s.defer_variances = int(bool(getattr(p, "defer_variances", True)))
+        s.defer_variances = int(getattr(p, "defer_variances", 2))
         self._chk(self.lib.dnaadj_prepare(self.h, C.byref(s)))
 
     # ---- multi-GPU (include/dnaadjust_c.h "multi-GPU") ----

@@ -38,6 +38,8 @@ void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, c
 void launch_gather_map(const double* rhs, const int32_t* map, uint32_t npp, double* out, hipStream_t s);
 void launch_scatter_map(const double* v, const int32_t* map, uint32_t npp, double* out, hipStream_t s);
 void launch_gemv_t_lower(const double* A, uint32_t lda, uint32_t n, const double* y, double* out, hipStream_t s);
+void launch_gemv_t(const double* A, uint32_t lda, uint32_t rows, uint32_t cols, const double* y, const double* base, double sign, double* out,
+                   hipStream_t s);
 void launch_gemv(const double* A, uint32_t lda, uint32_t rows, uint32_t cols, const double* x, double* part, uint32_t nchunks, int lower,
                  const double* base, double sign, double* out, uint32_t n_out, hipStream_t s);
 void launch_partial_set_trailing(double* T, uint32_t ldt, uint32_t njp, const double* kk, uint32_t npk, uint32_t nj, hipStream_t s);

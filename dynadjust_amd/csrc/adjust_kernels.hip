@@ -577,6 +577,26 @@ __global__ __launch_bounds__(256) void gemv_t_lower_kernel(const double* __restr
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) out[j] = v;
 }
+// out[j] = base[j] + sign * sum over i < rows of A(i, j) y(i), j < cols: the transposed product with a rectangular panel, same scheme
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, uint32_t lda, uint32_t rows, uint32_t cols,
+                                                     const double* __restrict__ y, const double* __restrict__ base, double sign,
+                                                     double* __restrict__ out) {
+    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (j >= cols) return;
+    const double* col = A + (size_t)j * lda;
+    double a0 = 0.0, a1 = 0.0;
+    uint32_t i = lane;
+    for (; i + 64 < rows; i += 128) {
+        a0 += col[i] * y[i];
+        a1 += col[i + 64] * y[i + 64];
+    }
+    if (i < rows) a0 += col[i] * y[i];
+    double v = a0 + a1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) out[j] = (base ? base[j] : 0.0) + sign * v;
+}
 // out[map[p]] = v[p] for the positions that carry an unknown
 __global__ void scatter_map_kernel(const double* __restrict__ v, const int32_t* __restrict__ map, uint32_t npp, double* __restrict__ out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -587,6 +607,11 @@ __global__ void scatter_map_kernel(const double* __restrict__ v, const int32_t* 
 void launch_gemv_t_lower(const double* A, uint32_t lda, uint32_t n, const double* y, double* out, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(gemv_t_lower_kernel, dim3((n + 3) / 4), dim3(256), 0, s, A, lda, n, y, out);
+}
+void launch_gemv_t(const double* A, uint32_t lda, uint32_t rows, uint32_t cols, const double* y, const double* base, double sign, double* out,
+                   hipStream_t s) {
+    if (!cols) return;
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((cols + 3) / 4), dim3(256), 0, s, A, lda, rows, cols, y, base, sign, out);
 }
 void launch_scatter_map(const double* v, const int32_t* map, uint32_t npp, double* out, hipStream_t s) {
     if (!npp) return;

@@ -27,6 +27,7 @@ struct dnagpu_partial {
     uint32_t n = 0, nj = 0, nip = 0, njp = 0, npp = 0;
     bool valid = false;      // reduce done, completion pending
     bool completed = false;  // completion done: X (the eliminated part's inverse factor) and WK still describe the block
+    bool spine = false;      // light form (dnagpu_partial_create_spine): X holds the elimination's block factor (sym_inverse.h: sym_spine_async), no WK
     bool factored = false;   // dnagpu_partial_complete_factor done: X = L^-1 of the WHOLE block (elimination order); the inverse itself is pending
 };
 

@@ -1497,12 +1497,17 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
         if (keep->store) keep->store->n = 0;       // (its storage now holds the factor's inverse, not a matrix)
         launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], F, npp, npp, st);
         HIPCHK(hipMemcpyAsync(keep->map, map_dev, (size_t)npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        sym_schur_keep_async(ws, F, keep->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
-        if (nip)   // the panel L_KI (kept rows x eliminated columns) out of the chain's panel workspace
+        if (keep->spine)
+            sym_spine_async(ws, F, keep->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+        else
+            sym_schur_keep_async(ws, F, keep->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+        if (nip && !keep->spine)   // the panel L_KI (kept rows x eliminated columns) out of the chain's panel workspace
             HIPCHK(hipMemcpy2DAsync(keep->WK, (size_t)njp * sizeof(double), ws.W + nip, (size_t)npp * sizeof(double), (size_t)njp * sizeof(double), nip,
                                     hipMemcpyDeviceToDevice, st));
         // the row that carried the right-hand side rode along as a passenger: it is no unknown, its panel entries go
-        if (nip) HIPCHK(hipMemset2DAsync(keep->WK + nj, (size_t)njp * sizeof(double), 0, sizeof(double), nip, st));
+        if (nip && !keep->spine) HIPCHK(hipMemset2DAsync(keep->WK + nj, (size_t)njp * sizeof(double), 0, sizeof(double), nip, st));
+        // (light form: the passenger row sits in the panels of X, row nip + nj of every block column; it is cleared there)
+        if (nip && keep->spine) HIPCHK(hipMemset2DAsync(keep->X + nip + nj, (size_t)npp * sizeof(double), 0, sizeof(double), nip, st));
         keep->valid = true;
         *T = F + (size_t)nip * npp + nip;
     } else {
@@ -1588,6 +1593,34 @@ int dnagpu_partial_create_in(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dn
     return DNAGPU_OK;
 }
 
+int dnagpu_partial_create_spine(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_matrix* store, dnagpu_partial** out) {
+    CHK_CTX();
+    if (!out || !k_max || k_max > n_max) return fail(ctx, DNAGPU_EINVAL, "partial_create_spine: bad arguments");
+    *out = nullptr;
+    dnagpu_partial* p = new (std::nothrow) dnagpu_partial();
+    if (!p) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    p->k_cap = pad128(k_max + 1);
+    p->n_cap = pad128(n_max - k_max ? n_max - k_max : 1) + p->k_cap;
+    if (store && (size_t)p->n_cap * p->n_cap > ((size_t)store->np_max + 128) * store->np_max) {
+        delete p;
+        return fail(ctx, DNAGPU_EINVAL, "partial_create_spine: the matrix is too small (create it with n_max + 256)");
+    }
+    p->store = store;
+    p->spine = true;
+    hipError_t e = hipSuccess;
+    if (store)
+        p->X = store->F;
+    else
+        e = hipMalloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
+    if (e != hipSuccess) {
+        dnagpu_partial_destroy(ctx, p);
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "retained factor allocation", e);
+    }
+    *out = p;
+    return DNAGPU_OK;
+}
+
 void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p) {
     if (!p) return;
     if (ctx) {
@@ -1605,6 +1638,10 @@ int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, cons
     CHK_CHAIN();
     if (!pf || !pf->valid || !kk || !inv || kk->n != pf->nj || pf->n > inv->n_max)
         return fail(ctx, DNAGPU_EINVAL, "partial_complete: bad arguments");
+    if (pf->spine) {
+        int rc2 = dnagpu_partial_complete_factor(ctx, chain, pf, kk);
+        return rc2 ? rc2 : dnagpu_partial_finish(ctx, chain, pf, inv);
+    }
     int rc = ensure_ws(ctx, chain, pf->npp);
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
@@ -1639,7 +1676,10 @@ int dnagpu_partial_complete_factor(dnagpu_ctx* ctx, int chain, dnagpu_partial* p
     pf->completed = false;
     double* F = ws.X;        // scratch: the kept block's factorisation and the T_KI panel pass through it
     launch_partial_set_trailing(F + (size_t)pf->nip * pf->npp + pf->nip, pf->npp, pf->njp, kk->F, kk->np, pf->nj, st);
-    sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128), 1);
+    if (pf->spine)
+        sym_spine_kept_async(ws, F, pf->X, (int)pf->npp, (int)(pf->nip / 128), (int)(pf->njp / 128));
+    else
+        sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128), 1);
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     rc = check_info(ctx, chain);
@@ -1662,6 +1702,31 @@ int dnagpu_partial_solve(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_
     double* rp = ws.svec;                                           // P^T rhs, then the result
     double* y = ctx->symv_part[chain] + (size_t)SYMV_CHUNKS * pf->npp - pf->npp;     // (the last chunk row of the partial sums: free once they are added up)
     launch_gather_map(b->rhs[chain], pf->map, pf->npp, rp, st);
+    if (pf->spine) {
+        // blocked substitution with the block factor: forward  y_b = X_bb v_b,  v_below -= L_(below, b) y_b;  the kept block
+        // v_K = X_KK^T (X_KK v_K);  backward  v_b = X_bb^T (y_b - L_(below, b)^T v_below).  ~n^2 doubles read twice, a few launches per block.
+        const uint32_t ld = pf->npp;
+        const std::vector<std::pair<int, int>> blocks = sym_spine_blocks((int)(pf->nip / 128));
+        double* part = ctx->symv_part[chain];
+        for (const auto& bl : blocks) {
+            const uint32_t o = (uint32_t)bl.first * 128, h = (uint32_t)bl.second * 128, below = ld - (o + h);
+            launch_gemv(pf->X + (size_t)o * ld + o, ld, h, h, rp + o, part, SYMV_CHUNKS - 1, 1, nullptr, 1.0, rp + o, h, st);
+            launch_gemv(pf->X + (size_t)o * ld + o + h, ld, below, h, rp + o, part, SYMV_CHUNKS - 1, 0, rp + o + h, -1.0, rp + o + h, below, st);
+        }
+        {
+            const uint32_t o = pf->nip, h = pf->njp;
+            launch_gemv(pf->X + (size_t)o * ld + o, ld, h, h, rp + o, part, SYMV_CHUNKS - 1, 1, nullptr, 1.0, rp + o, h, st);
+            launch_gemv_t_lower(pf->X + (size_t)o * ld + o, ld, h, rp + o, y, st);
+            HIPCHK(hipMemcpyAsync(rp + o, y, (size_t)h * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        for (size_t q = blocks.size(); q-- > 0;) {
+            const uint32_t o = (uint32_t)blocks[q].first * 128, h = (uint32_t)blocks[q].second * 128, below = ld - (o + h);
+            launch_gemv_t(pf->X + (size_t)o * ld + o + h, ld, below, h, rp + o + h, rp + o, -1.0, y, st);
+            launch_gemv_t_lower(pf->X + (size_t)o * ld + o, ld, h, y, rp + o, st);
+        }
+        launch_scatter_map(rp, pf->map, pf->npp, b->corr[chain], st);
+        return DNAGPU_OK;
+    }
     launch_gemv(pf->X, pf->npp, pf->npp, pf->npp, rp, ctx->symv_part[chain], SYMV_CHUNKS - 1, 1, nullptr, 1.0, y, pf->npp, st);
     launch_gemv_t_lower(pf->X, pf->npp, pf->npp, y, rp, st);
     launch_scatter_map(rp, pf->map, pf->npp, b->corr[chain], st);
@@ -1680,11 +1745,19 @@ int dnagpu_partial_finish(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, dnagpu
     pf->factored = false;
     pf->completed = pf->store == nullptr;
     double* F = ws.X;
-    sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128), 2);
+    if (pf->spine) {
+        pf->completed = false;
+        sym_spine_finish_async(ws, F, pf->X, (int)pf->npp, (int)(pf->nip / 128), (int)(pf->njp / 128));
+    } else {
+        sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128), 2);
+    }
     inv->n = pf->n;
     inv->np = pad128(pf->n);
     launch_init_padded(inv->F, inv->n, inv->np, st);
     launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
+    // (nothing here factors anything: `info` is put to "no failure" for check_info, which then reports enqueue / launch errors only)
+    HIPCHK(hipMemsetAsync(ws.info, 0x7f, sizeof(int), st));
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
 }

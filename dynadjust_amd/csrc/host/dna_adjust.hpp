@@ -181,6 +181,7 @@ private:
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
         bool part_allowed = false, part_valid = false;
         bool var_deferred = false;            // a.defer_variances: this iteration's inverse exists as the completed factor in `part` only
+        bool part_spine = false;              // a.defer_variances = 2: the kept factor in its light form (dnagpu_partial_create_spine)
         bool part_in_rigvar = false;          // the factor's inverse waits in rigvar's storage (dnagpu_partial_create_in): rigvar has n + 256
         bool rig_direct = false;              // this iteration's rigorous solve works in rigvar itself (no copy afterwards)
         bool inverse_pending = false;

@@ -16,6 +16,7 @@
 // one group); the combination solves (combine thread, dnaadjust-multi.cpp:593) go round-robin over all ranks.
 //
 // One process per GPU, or one process with one host thread per GPU (a.devices): the same code, rank by rank.
+#include <cstdio>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -133,6 +134,9 @@ void dna_adjust::AgreeOnPhase(const char* phase, const std::function<void()>& bo
     std::exception_ptr mine;
     try {
         body();
+    } catch (const std::exception& e) {
+        mine = std::current_exception();
+        if (getenv("DNAGPU_DEBUG_PHASES")) fprintf(stderr, "rank %d, %s: %s\n", DistRank(), phase, e.what());
     } catch (...) {
         mine = std::current_exception();
     }

@@ -521,11 +521,13 @@ void dna_adjust::PrepareCondensedBlocks() {
         if (B.keep.empty() || !OwnsBlock(k)) continue;      // (a block is condensed and completed on its owner's GPU only)
         const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size();
         const bool in_rigvar = lend && !B.rigvar;   // (a matrix that exists already has no spare rows)
-        const double need = (in_rigvar ? 2.0 * 256.0 * (n + 512.0) * 8.0 : sq(n)) + (nk + 256.0) * (n + 256.0) * 8.0;
+        const bool spine = DeferVariances() && projectSettings_.a.defer_variances >= 2;      // (the light form keeps its panels inside X)
+        const double need = (in_rigvar ? 2.0 * 256.0 * (n + 512.0) * 8.0 : sq(n)) + (spine ? 0.0 : (nk + 256.0) * (n + 256.0) * 8.0);
         if (need > budget) continue;
         budget -= need;
         B.part_allowed = true;
         B.part_in_rigvar = in_rigvar;
+        B.part_spine = spine;
         max_keep = std::max(max_keep, B.keep.size());
     }
     const int chains = NumChains();
@@ -554,9 +556,9 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
         int rc;
         if (B.part_in_rigvar) {
             if (!B.rigvar) Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
-            rc = dnagpu_partial_create_in(ctx_, n, nk, B.rigvar, &B.part);
+            rc = B.part_spine ? dnagpu_partial_create_spine(ctx_, n, nk, B.rigvar, &B.part) : dnagpu_partial_create_in(ctx_, n, nk, B.rigvar, &B.part);
         } else {
-            rc = dnagpu_partial_create(ctx_, n, nk, &B.part);
+            rc = B.part_spine ? dnagpu_partial_create_spine(ctx_, n, nk, nullptr, &B.part) : dnagpu_partial_create(ctx_, n, nk, &B.part);
         }
         if (rc != DNAGPU_OK) {
             B.part = nullptr;          // no room after all: this block inverts its normals in the rigorous step as before
@@ -571,7 +573,7 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     std::lock_guard<std::mutex> lk(corr_mutex_);
     // a Cholesky factorisation of the eliminated part (plus its triangular inverse when the factor is kept), the panel under
     // the kept rows, the complement's update
-    algorithmic_flops_ += (B.part ? 2.0 : 1.0) * ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    algorithmic_flops_ += ((B.part && !B.part_spine) ? 2.0 : 1.0) * ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
     condense_count_++;
 }
 
@@ -614,7 +616,8 @@ bool dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W
     solve_flops_ += n * n * n;
     solve_count_++;
     // factor + invert the kept block, the two panel products of the kept rows, X^T X (now, or in FinishDeferredVariances)
-    algorithmic_flops_ += nk * nk * nk + nk * ni * ni + nk * nk * ni + (defer ? 0.0 : n * n * n / 3.0);
+    // (light form: only the kept block is factored and inverted here; the panel products wait with the inverse of the factor)
+    algorithmic_flops_ += B.part_spine ? nk * nk * nk * 2.0 / 3.0 : nk * nk * nk + nk * ni * ni + nk * nk * ni + (defer ? 0.0 : n * n * n / 3.0);
     completion_count_++;
     return defer;
 }
@@ -640,9 +643,11 @@ void dna_adjust::FinishDeferredVariances() {
         B.var_deferred = false;
         StoreRigorousVariances(c, k, W);
         Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
-        const double n = 3.0 * (double)v_parameterStationList_[k].size();
+        const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
         std::lock_guard<std::mutex> lk(corr_mutex_);
-        algorithmic_flops_ += n * n * n / 3.0;
+        // X^T X, and in the light form the inverse of the factor first (its diagonal blocks exist: ~ the eliminated part's trtri
+        // with the kept rows riding along)
+        algorithmic_flops_ += n * n * n / 3.0 + (B.part_spine ? ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk : 0.0);
     });
 }
 

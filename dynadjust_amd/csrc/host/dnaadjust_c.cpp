@@ -49,7 +49,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->schur_carry = 1;
     s->keep_factors = 1;
     s->dist_two_level = 1;
-    s->defer_variances = 1;
+    s->defer_variances = 2;
 }
 
 int dnaadj_create(dnaadj_handle** out) {
@@ -100,7 +100,7 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         if (s->n_devices > 1 && s->devices) p.a.devices.assign(s->devices, s->devices + s->n_devices);
         if (s->dist_transport) p.a.dist_transport = s->dist_transport;
         p.a.dist_two_level = (uint16_t)(s->dist_two_level ? 1 : 0);
-        p.a.defer_variances = (uint16_t)(s->defer_variances ? 1 : 0);
+        p.a.defer_variances = (uint16_t)(s->defer_variances < 0 ? 0 : s->defer_variances > 2 ? 2 : s->defer_variances);
         if (s->network_name) p.g.network_name = s->network_name;
         if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);

@@ -227,7 +227,10 @@ struct adjust_settings {
     // condensed schedule with kept factors: an iteration takes its corrections from the completed FACTOR of every block (two triangular
     // matrix-vector products) and the inverses -- the rigorous variance matrices, n^3 / 3 per block -- are formed once, after the last
     // iteration, instead of in every iteration.  Same results (the variances are those of the last iteration's normals either way).
-    UINT16 defer_variances = 1;
+    // 2 (default): the light form on top -- the condensing step stops at the factor (~0.34 n_i^3 instead of 2/3 n_i^3), the iterations
+    // substitute block by block, and the inverse of the factor is paid once, with the variance matrices, after the last iteration.
+    // 1: the condensing step inverts the eliminated part's factor in every iteration (needed by nothing but the final inverse).
+    UINT16 defer_variances = 2;
 };
 struct output_settings {
     UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement

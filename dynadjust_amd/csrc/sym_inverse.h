@@ -8,6 +8,7 @@
 #include <string>
 #include <map>
 #include <set>
+#include <utility>
 #include <vector>
 #include "la_kernels.h"
 
@@ -97,6 +98,16 @@ void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti
 // panel L_KI (tj*128 x ti*128, ldwk).  On return F = inverse of the whole matrix, both triangles, in the elimination's order.
 // what: 1 = the factor only (X = L^-1 of the whole matrix complete; F is scratch), 2 = the inverse X^T X -> F only (after a 1), 3 = both
 void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj, int what = 3);
+
+// The kept factor in its light form (a.defer_variances = 2): sym_spine_async eliminates like sym_schur_async (~0.34 n_i^3) but leaves the
+// factor in S (ld) -- inverses of the diagonal blocks of the elimination's block sequence (sym_spine_blocks) on the diagonal, the panels
+// L_(below, b) below them; F's trailing tiles become the Schur complement.  sym_spine_kept_async factors and inverts the (updated)
+// trailing tj x tj block of F into S's trailing block: S then solves any right-hand side by blocked substitution.  sym_spine_finish_async
+// turns S into L^-1 (n^3 / 3) and F into the inverse X^T X (n^3 / 3), both triangles.
+void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj);
+void sym_spine_kept_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj);
+void sym_spine_finish_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj);
+std::vector<std::pair<int, int>> sym_spine_blocks(int ti);      // (first tile, tiles) of the diagonal blocks, in elimination order
 
 // sum the event timings recorded so far (synchronises the stream)
 void gemm_profile_collect(InvWorkspace& ws);

@@ -399,15 +399,76 @@ struct Rec {
     // `split` of the remainder: total 0.381 / 0.351 / 0.342 / 0.338 n^3 at split 1/2, 1/3, 1/4, 1/5 (a Cholesky factorisation
     // alone is n^3/3).  Measured on cfg3 (n = 20 k): 7.18 / 6.97 / 6.89 / 6.82 / 6.79 s per step at 0.5 / 0.33 / 0.25 / 0.2 / 0.15
     // (smaller blocks = more, smaller launches): 0.2, override DNAGPU_SCHUR_SPLIT.
+    static int spine_step(int si, double split) { return si <= 12 ? si : std::max(1, std::min(si, (int)(si * split + 0.5))); }
     void schur(int ti, int tj, double split) {
         int o = 0, si = ti;
         while (si > 0) {
-            int h = si <= 12 ? si : std::max(1, std::min(si, (int)(si * split + 0.5)));
+            int h = spine_step(si, split);
             node(o, h);
             int r = si - h + tj;
             if (r > 0) eliminate(o, h, r);
             o += h;
             si -= h;
+        }
+    }
+
+    // The same elimination with its factor KEPT in X (ldx) as one block lower triangular matrix: the diagonal blocks hold the INVERSES
+    // of the factor's diagonal blocks (what node() leaves in X anyway), the blocks below them the factor's panels L_(below, b) -- at the
+    // very place where the corresponding block of L^-1 goes once spine_finish() runs.  (The panels of the levels INSIDE a diagonal
+    // block still go to P: they are dead when node() returns.)
+    void spine(int ti, int tj, double split) {
+        int o = 0, si = ti;
+        while (si > 0) {
+            int h = spine_step(si, split);
+            node(o, h);
+            int r = si - h + tj;
+            if (r > 0) {
+                GemmArgs a;
+                a.A = f(o + h, o); a.lda = ld;
+                a.B = x(o, o); a.ldb = ldx;
+                a.C = x(o + h, o); a.ldc = ldx;
+                a.mt = r; a.nt = h; a.K = h * 128;
+                a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_LE_J; a.lower = 0; a.mirror = 0;
+                gemm(ws, a, 0, 0);
+                a.A = x(o + h, o); a.lda = ldx;
+                a.B = x(o + h, o); a.ldb = ldx;
+                a.C = f(o + h, o + h); a.ldc = ld;
+                a.mt = r; a.nt = r; a.K = h * 128;
+                a.alpha = -1.0; a.beta = 1.0; a.kmode = KM_FULL; a.lower = 1; a.mirror = 0;
+                gemm(ws, a, 0, 0);
+            }
+            o += h;
+            si -= h;
+        }
+    }
+    // ... and from that to L^-1 of the whole (ti + tj) x (ti + tj) matrix, the trailing tj x tj block of X holding the inverse of ITS
+    // factor already: block column by block column from the last to the first,  T = L_(below, b) X_bb,  X_(below, b) = -X_(below, below) T
+    // -- the two products node() issues when it returns from its right child, n^3 / 3 flops in all.
+    void spine_finish(int ti, int tj, double split) {
+        std::vector<std::pair<int, int>> blocks;
+        for (int o = 0, si = ti; si > 0;) {
+            int h = spine_step(si, split);
+            blocks.emplace_back(o, h);
+            o += h;
+            si -= h;
+        }
+        const int T = ti + tj;
+        for (size_t q = blocks.size(); q-- > 0;) {
+            const int o = blocks[q].first, h = blocks[q].second, r = T - (o + h);
+            if (r <= 0) continue;
+            GemmArgs a;
+            a.A = x(o + h, o); a.lda = ldx;
+            a.B = x(o, o); a.ldb = ldx;
+            a.C = f(o + h, o); a.ldc = ld;
+            a.mt = r; a.nt = h; a.K = h * 128;
+            a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
+            gemm(ws, a, 0, 1);
+            a.A = x(o + h, o + h); a.lda = ldx;
+            a.B = f(o + h, o); a.ldb = ld;
+            a.C = x(o + h, o); a.ldc = ldx;
+            a.mt = r; a.nt = h; a.K = r * 128;
+            a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
+            gemm(ws, a, 0, 1);
         }
     }
 };
@@ -508,6 +569,63 @@ void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const do
     }
     ws.planned.insert(key);
     gemm_profile_close(ws);
+}
+
+void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
+    const double split = schur_split();
+    const int key = (1 << 24) | (0 << 22) | (ti << 12) | tj;
+    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
+        Rec rec{ws, F, ld, S, ld, ws.W, ld, pass == 0};
+        rec.spine(ti, tj, split);
+        if (ws.err != hipSuccess) return;
+    }
+    ws.planned.insert(key);
+    gemm_profile_close(ws);
+}
+
+void sym_spine_kept_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
+    const int key = (1 << 24) | (1 << 22) | (ti << 12) | tj;
+    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
+        Rec rec{ws, F, ld, S, ld, ws.W, ld, pass == 0};
+        rec.node(ti, tj);
+        if (ws.err != hipSuccess) return;
+    }
+    ws.planned.insert(key);
+    gemm_profile_close(ws);
+}
+
+void sym_spine_finish_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
+    const double split = schur_split();
+    const int key = (1 << 24) | (2 << 22) | (ti << 12) | tj;
+    const int T = ti + tj;
+    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
+        Rec rec{ws, F, ld, S, ld, ws.W, ld, pass == 0};
+        rec.spine_finish(ti, tj, split);
+        GemmArgs a;
+        a.A = S; a.lda = ld;
+        a.B = S; a.ldb = ld;
+        a.C = F; a.ldc = ld;
+        a.mt = T; a.nt = T; a.K = T * 128;
+        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
+        rec.gemm(ws, a, 1, 1);
+        if (ws.err != hipSuccess) return;
+    }
+    ws.planned.insert(key);
+    gemm_profile_close(ws);
+}
+
+std::vector<std::pair<int, int>> sym_spine_blocks(int ti) {
+    std::vector<std::pair<int, int>> blocks;
+    const double split = schur_split();
+    for (int o = 0, si = ti; si > 0;) {
+        int h = si <= 12 ? si : std::max(1, std::min(si, (int)(si * split + 0.5)));
+        blocks.emplace_back(o, h);
+        o += h;
+        si -= h;
+    }
+    return blocks;
 }
 
 void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj) {

@@ -243,6 +243,12 @@ class DeviceContext:
         self._chk(self.lib.dnagpu_partial_create_in(self.h, n_max, k_max, store.h, C.byref(h)))
         return h
 
+    def partial_create_spine(self, n_max, k_max, store):
+        """light form: the elimination's block factor in `store`, no inverse of the eliminated part until partial_finish"""
+        h = C.c_void_p()
+        self._chk(self.lib.dnagpu_partial_create_spine(self.h, n_max, k_max, store.h, C.byref(h)))
+        return h
+
     def partial_destroy(self, h):
         self.lib.dnagpu_partial_destroy(self.h, h)
 

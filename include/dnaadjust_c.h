@@ -60,8 +60,9 @@ typedef struct {
     const char* dist_transport;/* NULL = choose; "rccl"; "local" (ranks of one process sharing a GPU) */
     int dist_two_level;        /* condensed chains across ranks (default 1): 1 = two-level where the blocks are one contiguous network and every
                                   rank owns a run (see dnatypes.hpp; cfg4-sized junction rows: 0.29 s instead of 1.75 s per iteration), 0 = on every rank */
-    int defer_variances;       /* condensed schedule with kept factors (default 1): the corrections of an iteration come from every block's
+    int defer_variances;       /* condensed schedule with kept factors (default 2): the corrections of an iteration come from every block's
                                   completed factor and the inverses (rigorous variance matrices) are formed once, after the last iteration;
+                                  2 = the condensing step also stops at the factor (no inverse of the eliminated part until the end),
                                   0 = an inverse per block and iteration like dna_adjust::Solve */
 } dnaadj_settings;
 

@@ -281,6 +281,11 @@ int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagp
  * (3k n doubles) and nothing else; dnagpu_partial_reduce_rhs is not available afterwards.  `store` must outlive the partial. */
 int dnagpu_partial_create_in(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_matrix* store, dnagpu_partial** out);
 void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p);
+/* The light form: the elimination stops at the factor (~0.34 n_i^3 instead of 2/3 n_i^3 -- no inverse of the eliminated part is formed), kept
+ * in `store` as one block lower triangular matrix (inverses of the diagonal blocks, panels below them).  dnagpu_partial_complete_factor then
+ * only factors the kept block, dnagpu_partial_solve substitutes block by block, and dnagpu_partial_finish pays for the inverse of the
+ * factor as well (2/3 n^3 in all) -- once, after the last iteration.  No panel copy; `store` = NULL gives it storage of its own (n^2). */
+int dnagpu_partial_create_spine(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_matrix* store, dnagpu_partial** out);
 int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk, dnagpu_matrix* inv);
 /* The completion in two halves.  An iteration of the adjustment needs the block's solution, not its inverse: the reference obtains the
  * one through the other (dna_adjust::Solve: N^-1, then N^-1 rhs), and only the inverse of the LAST iteration is a result (the rigorous

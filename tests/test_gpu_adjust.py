@@ -520,8 +520,8 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
         adjust.write_synthetic_network(str(tmp_path), "c", 16, 12, 0, blocks, seed=4, x_clusters=12, y_cluster=True, initial_sigma=0.3)
     runs = []
     # ... a.keep_factors: the rigorous solve completes the factor the condensing step kept; a.defer_variances (default): the iterations
-    # take their corrections from the completed factor and the inverses are formed once, at the end
-    for schur, keep, defer in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+    # take their corrections from the completed factor and the inverses are formed once, at the end (2: the light form of the factor)
+    for schur, keep, defer in ((False, False, 0), (True, False, 0), (True, True, 0), (True, True, 1), (True, True, 2)):
         a, st = _device_run(str(tmp_path), "c", True, multi_thread=mt, schur_carry=schur, keep_factors=keep, defer_variances=defer)
         assert st == 0
         a.GenerateStatistics()

@@ -301,6 +301,70 @@ def test_kept_factor_in_the_storage_of_the_result(gpu_ctx, built, orc, tmp_path,
     gpu_ctx.block_destroy(0)
 
 
+@pytest.mark.parametrize("rows,cols,pick", [(9, 8, "jsl"), (40, 30, "jsl"), (40, 30, "scattered"), (43, 43, "one"), (60, 50, "jsl")])
+def test_light_kept_factor(gpu_ctx, built, orc, tmp_path, rows, cols, pick):
+    """dnagpu_partial_create_spine: the elimination keeps its block factor only (no inverse of the eliminated part); the kept block is
+    factored (complete_factor), right-hand sides are solved by blocked substitution (partial_solve), and the inverse of the whole block is
+    formed at the end (partial_finish) -- against numpy, and against the full-form partial"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, 2, seed=rows)
+    net = orc.Network(str(tmp_path / "s"), True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    st0, _, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    ns = len(st0)
+    n0 = 3 * ns
+    loc0 = {int(s): i for i, s in enumerate(st0)}
+    stn = {"jsl": [loc0[int(s)] for s in net.jsl[net.jsl_off[0]:net.jsl_off[1]]], "scattered": list(range(1, ns, 7))[::-1], "one": [ns // 2]}[pick]
+    idx = np.array(stn, dtype=np.uint32)
+    nk = 3 * len(idx)
+    rws = (3 * idx[:, None] + np.arange(3)).ravel()
+    N0 = unpack_lower(a.block_normals(0), n0)
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    m = gpu_ctx.matrix(n0)
+    red0, red, kk = gpu_ctx.matrix(nk), gpu_ctx.matrix(nk), gpu_ctx.matrix(nk)
+    m.upload_packed(a.block_normals(0), n0)
+    gpu_ctx.block_reduce(0, m, idx, red0)                                   # the plain elimination: same complement, same reduced rhs
+    eye = gpu_ctx.matrix(n0)                                                # the block's right-hand side, read back through I * rhs
+    eye.upload_packed(pack_lower(np.eye(n0)), n0)
+    gpu_ctx.solve_corrections(0, eye)
+    gpu_ctx.sync()
+    rhs = gpu_ctx.block_get_corrections(0, ns).ravel().copy()
+    eye.close()
+    store = gpu_ctx.matrix(n0 + 256)
+    pf = gpu_ctx.partial_create_spine(n0, nk, store)
+    for rep in range(2):                                                    # (twice: the second elimination overwrites the first one's factor)
+        m.upload_packed(a.block_normals(0), n0)
+        gpu_ctx.block_reduce(0, m, idx, red, keep=pf)
+        S = unpack_lower(red.download_packed(), nk)
+        S0 = unpack_lower(red0.download_packed(), nk)
+        assert np.abs(S - S0).max() < 1e-10 * np.abs(S0).max()
+        assert np.abs(gpu_ctx.junction_get_estimates(red) - gpu_ctx.junction_get_estimates(red0)).max() < 1e-9 * max(1.0, np.abs(gpu_ctx.junction_get_estimates(red0)).max())
+        D = np.eye(nk) * np.abs(np.diag(S)).mean() * (0.05 + 0.02 * rep)
+        kk.upload_packed(pack_lower(S + D), nk)
+        gpu_ctx.partial_complete_factor(pf, kk)
+        gpu_ctx.partial_solve(0, pf)
+        x_factor = gpu_ctx.block_get_corrections(0, ns)
+        M = N0.copy()
+        M[np.ix_(rws, rws)] += D
+        ref = np.linalg.inv(M)
+        x_ref = (ref @ rhs).reshape(x_factor.shape)
+        scale = max(1e-30, np.abs(x_ref).max())
+        assert np.abs(x_factor - x_ref).max() < 1e-9 * scale, np.abs(x_factor - x_ref).max() / scale
+    with pytest.raises(Exception):
+        gpu_ctx.partial_reduce_rhs(0, pf, red)                              # (needs the inverse of the eliminated part: the full form only)
+    gpu_ctx.partial_finish(pf, store, n0)                                   # the lender receives the inverse
+    got = unpack_lower(store.download_packed(), n0)
+    assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    with pytest.raises(Exception):
+        gpu_ctx.partial_finish(pf, store, n0)
+    gpu_ctx.partial_destroy(pf)
+    for q in (m, red0, red, kk, store):
+        q.close()
+    gpu_ctx.block_destroy(0)
+
+
 @pytest.mark.parametrize("rows,cols,pick,lend", [(9, 8, "jsl", False), (40, 30, "jsl", True), (40, 30, "scattered", False), (43, 43, "one", True)])
 def test_completion_in_two_halves(gpu_ctx, built, orc, tmp_path, rows, cols, pick, lend):
     """dnagpu_partial_complete_factor + dnagpu_partial_solve + dnagpu_partial_finish: the solution of an iteration from the completed
