@@ -1001,7 +1001,9 @@ void dna_adjust::GetBlockRigorousVariancesPacked(UINT32 block, std::vector<doubl
         return;
     }
     dnagpu_matrix* m = (projectSettings_.a.adjust_mode == SimultaneousMode) ? work_[0] : blocks_[block].rigvar;
-    if (!m) throw std::runtime_error("GetBlockRigorousVariancesPacked(): this process holds no rigorous variances for the block");
+    // (between the condensing step of an iteration and the end of the adjustment the matrix's storage holds the block's kept factor)
+    if (!m || (projectSettings_.a.adjust_mode != SimultaneousMode && !blocks_[block].has_rigvar))
+        throw std::runtime_error("GetBlockRigorousVariancesPacked(): this process holds no rigorous variances for the block");
     Check(dnagpu_matrix_download_packed(ctx_, 0, m, packed.data()), block, "GetBlockRigorousVariancesPacked()");
 }
 

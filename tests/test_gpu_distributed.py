@@ -75,7 +75,10 @@ def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt
     ra = np.frombuffer(a.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
     rf = np.frombuffer(f.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
     for nm in ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel"):
-        assert np.abs(ra[nm] - rf[nm]).max() <= 1e-7 * max(1.0, np.abs(rf[nm]).max()), nm
+        # (N-statistic and Pelzer's reliability divide by the residual's precision, a difference of two nearly equal variances for a
+        # poorly controlled measurement: rounding differences between the two schedules are amplified there)
+        tol = 1e-6 if nm in ("NStat", "PelzerRel") else 1e-7
+        assert np.abs(ra[nm] - rf[nm]).max() <= tol * max(1.0, np.abs(rf[nm]).max()), (nm, float(np.abs(ra[nm] - rf[nm]).max()))
     for suffix, tol in (("rva", 1e-9), ("pam", 1e-9)):
         da = np.fromfile(tmp_path / "multi" / f"n-{suffix}.mtx", dtype=np.uint8)
         df = np.fromfile(tmp_path / "single" / f"n-{suffix}.mtx", dtype=np.uint8)
