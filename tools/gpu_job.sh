@@ -1,8 +1,11 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
-s=$(date +%s)
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/driver_like.out 2> gpurun_out/driver_like.err
-echo "rc=$? wall=$(( $(date +%s) - s )) s"
-tail -1 gpurun_out/driver_like.out | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['ms_per_step'], j['value'], j['roofline']['frac'], j['roofline'].get('traffic'), j['cpu_baseline']['value'], j['config'].get('variance_matrices'))"
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+export GPU_MAX_HW_QUEUES=16
+run() { python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('$1', j['ms_per_step'], j['roofline']['frac'])"; }
+run base
+DNAGPU_CHAINS=3 run chains3
+DNAGPU_CHAINS=5 run chains5
+DNAGPU_CHAINS=6 run chains6
+DNAGPU_CHAINS=8 run chains8
+DNAGPU_SMALL_TILES=256 run small256
+DNAGPU_SMALL_TILES=1024 run small1024
