@@ -1,11 +1,10 @@
 #!/bin/bash
+# the job of the moment for `gpurun -- bash tools/gpu_job.sh` (edited per measurement; this is the round-end check)
 cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
 export GPU_MAX_HW_QUEUES=16
-run() { python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('$1', j['ms_per_step'], j['roofline']['frac'])"; }
-run base
-DNAGPU_CHAINS=3 run chains3
-DNAGPU_CHAINS=5 run chains5
-DNAGPU_CHAINS=6 run chains6
-DNAGPU_CHAINS=8 run chains8
-DNAGPU_SMALL_TILES=256 run small256
-DNAGPU_SMALL_TILES=1024 run small1024
+timeout 1500 python -m pytest tests -q -m gpu --durations=8 > gpurun_out/t_all.log 2>&1
+echo "all rc=$?" > gpurun_out/job.status
+tail -n 14 gpurun_out/t_all.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/job.status
+tail -2 gpurun_out/smoke.log; cat gpurun_out/job.status

@@ -17,6 +17,11 @@ python $R/tools/rocprof_summary.py stats /tmp/kt1 $O/${TAG}_cfg3_kernel_stats_on
 DNAGPU_MULTI_THREAD=0 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_one_chain.json   # (the profiled run above has no warm-up: first-touch allocations inside)
 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --reuse-inverses 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_reuse_inverses.json
 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --reference-schedule 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_reference_schedule.json
+python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --variances-every-iteration 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_variances_every_iteration.json
+python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stage 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_staged.json
+python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --variance-propagation 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_variance_propagation.json
+DNAGPU_FORCE_DISTRIBUTED=1 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_rccl_one_rank.json
+python $R/bench.py --workload cfg4_slice --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg4_slice.json
 grep '^{"metric"' $O/kt.log | tail -1 > $O/${TAG}_bench_cfg3_profiled_step.json
 DNAGPU_MULTI_THREAD=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
 python $R/tools/rocprof_summary.py pmc /tmp/pmc_mfma $O/${TAG}_cfg3_pmc_mfma_util.txt "DNAGPU_MULTI_THREAD=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- $CMD   (${TAG}, cfg3, one chain: MFMA pipe utilisation per kernel)"
