@@ -95,6 +95,14 @@ std::vector<uint32_t> build_tile_order(int mt128, int nt128, int K, int kmode, i
     }
     int T = std::max(mt, nt);
     int G = T >= 64 ? 8 : T >= 32 ? 4 : T >= 16 ? 2 : 1;
+    // Short k ranges: a tile lives a few hundred microseconds, its operand panels are small, and what counts is that the eight XCDs
+    // finish together -- patches of 2 x 2 deal the work finer (measured on the elimination's launches, K = 1 500 ... 3 600: 62.7 ->
+    // 63.6 TFLOP/s, cfg3 one chain 3.17 -> 3.10 s).  Long ranges keep the 8 x 8 patches: there the fabric reads are the risk (the
+    // LAUUM, K = n).
+    static const int g_env = getenv("DNAGPU_PATCH") ? atoi(getenv("DNAGPU_PATCH")) : 0;      // probe: patch edge for every launch
+    static const int k_short = getenv("DNAGPU_PATCH_SHORT_K") ? atoi(getenv("DNAGPU_PATCH_SHORT_K")) : 6144;
+    if (K < k_short) G = std::min(G, 2);
+    if (g_env > 0) G = g_env;
     static const int row_major_env = getenv("DNAGPU_TILE_ROWS") ? atoi(getenv("DNAGPU_TILE_ROWS")) : -1;     // probe: 0 columns always, 1 rows always
     const bool by_rows = row_major_env >= 0 ? row_major_env != 0 : (kmode == KM_LE_I || kmode == KM_GE_I);
     // the decision to pair is taken on the WHOLE launch (not on a rank's column range), so that every table of a shape agrees

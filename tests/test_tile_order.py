@@ -48,7 +48,8 @@ def test_every_tile_once_and_pairs_complementary(paired, mt, nt, lower, kmode):
     K = max(mt, nt) * 128
     tab, per = table(built, mt, nt, K, km, lower)
     whole = mt * (mt + 1) // 2 if lower else mt * nt
-    assert per == (2 if (km != 0 and whole >= 1024 and max(mt, nt) >= 32) else 1)
+    # (launches with a short k range are dealt in 2 x 2 patches and never paired)
+    assert per == (2 if (km != 0 and whole >= 1024 and max(mt, nt) >= 32 and K >= 6144) else 1)
     assert len(tab) % (8 * per) == 0 or len(tab) <= 8
     seen = {}
     for e in tab:

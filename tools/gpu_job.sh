@@ -1,10 +1,12 @@
 #!/bin/bash
-# the job of the moment for `gpurun -- bash tools/gpu_job.sh` (edited per measurement; this is the round-end check)
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
 export GPU_MAX_HW_QUEUES=16
-timeout 1500 python -m pytest tests -q -m gpu --durations=8 > gpurun_out/t_all.log 2>&1
-echo "all rc=$?" > gpurun_out/job.status
-tail -n 14 gpurun_out/t_all.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/job.status
-tail -2 gpurun_out/smoke.log; cat gpurun_out/job.status
+run() { python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('$1', j['ms_per_step'], j['roofline']['frac'])"; }
+run short6144
+DNAGPU_PATCH_SHORT_K=0 run short0
+DNAGPU_PATCH_SHORT_K=12288 run short12288
+DNAGPU_PATCH_SHORT_K=4096 run short4096
+DNAGPU_MULTI_THREAD=0 run one_short6144
+DNAGPU_MULTI_THREAD=0 DNAGPU_PATCH_SHORT_K=0 run one_short0
+DNAGPU_MULTI_THREAD=0 DNAGPU_PATCH_SHORT_K=12288 run one_short12288
+python tools/gpu_inverse_bench.py 2>/dev/null | tail -4
