@@ -103,12 +103,12 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
         return 0.0;
     }
     const bool solved = fused && CompleteFromPartial(c, k, 0, W);
-    if (solved)
-        ;       // (a.defer_variances: the corrections came from the completed factor)
-    else if (reuse || fused)
-        Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
-    else
-        SolveTry(c, k, W);
+    if (!solved) {      // (a.defer_variances: the corrections came from the kept factor already)
+        if (reuse || fused)
+            Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
+        else
+            SolveTry(c, k, W);
+    }
     B.has_finv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
@@ -158,12 +158,12 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
         return 0.0;
     }
     const bool solved = fused && CompleteFromPartial(c, k, 1, W);
-    if (solved)
-        ;       // (a.defer_variances: the corrections came from the completed factor)
-    else if (reuse || fused)
-        Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
-    else
-        SolveTry(c, k, W);
+    if (!solved) {      // (a.defer_variances: the corrections came from the kept factor already)
+        if (reuse || fused)
+            Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
+        else
+            SolveTry(c, k, W);
+    }
     B.has_rinv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
@@ -203,12 +203,12 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jsl_here.data(), B.jsl_here.size(), B.jrev), k, "Solve()");
     if (fwd_in) Check(dnagpu_junction_rhs(ctx_, c, k, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jfwd), k, "Solve()");
     const bool solved = fused && CompleteFromPartial(c, k, 2, W);
-    if (solved)
-        ;       // (a.defer_variances: the corrections came from the completed factor)
-    else if (reuse || fused)
-        Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
-    else
-        SolveTry(c, k, W);
+    if (!solved) {      // (a.defer_variances: the corrections came from the kept factor already)
+        if (reuse || fused)
+            Check(dnagpu_solve_corrections(ctx_, c, k, W), k, "Solve()");
+        else
+            SolveTry(c, k, W);
+    }
     B.has_cinv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
