@@ -121,10 +121,23 @@ def test_multiple_networks_and_isolated_blocks(built, orc, tmp_path):
     o.close()
 
 
-def test_iteration_limit_and_threshold(built, orc, golden_dir):
+def test_iteration_limit_and_threshold(built, orc, golden_dir, tmp_path):
     a, st = _device_run(golden_dir, "tiny_net", True, max_iterations=1)
     assert st == adjust.ADJUST_MAX_ITERATIONS_EXCEEDED and a.CurrentIteration() == 1
     a.close()
+    # an adjustment that runs out of iterations still ends with the variance matrices of its last iteration (they are formed after the
+    # loop, a.defer_variances): same status, estimates and variances as the oracle stopped at the same point
+    adjust.write_synthetic_network(str(tmp_path), "m", 14, 12, 0, 3, seed=5, initial_sigma=2.0)
+    for limit in (1, 2):
+        net = orc.Network(str(tmp_path / "m"), True)
+        o = orc.Adjustment(net, True, max_iterations=limit)
+        o.prepare()
+        ost = o.run()
+        a, st = _device_run(str(tmp_path), "m", True, max_iterations=limit)
+        assert st == ost and (limit > 1 or st == adjust.ADJUST_MAX_ITERATIONS_EXCEEDED)
+        _compare(a, st, o, ost)
+        a.close()
+        o.close()
     a, st = _device_run(golden_dir, "tiny_net", True, iteration_threshold=10.0)
     assert st == adjust.ADJUST_SUCCESS and a.CurrentIteration() == 1
     a.close()
