@@ -35,6 +35,9 @@ void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uin
                          hipStream_t s);
 void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, const double* rhs, double* dst, uint32_t ldd, uint32_t npp,
                           hipStream_t s);
+void launch_form_ordered(double* F, uint32_t ld, uint32_t npp, const int32_t* map, const uint32_t* spos, const uint32_t* prow, const uint32_t* pcol,
+                         const uint32_t* poff, const uint32_t* pent, const double* wblk, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift,
+                         const uint32_t* con_stn, const double* con_w9, uint32_t n_con, const double* rhs, uint32_t rhs_row, hipStream_t s);
 void launch_gather_map(const double* rhs, const int32_t* map, uint32_t npp, double* out, hipStream_t s);
 void launch_scatter_map(const double* v, const int32_t* map, uint32_t npp, double* out, hipStream_t s);
 void launch_gemv_t_lower(const double* A, uint32_t lda, uint32_t n, const double* y, double* out, hipStream_t s);

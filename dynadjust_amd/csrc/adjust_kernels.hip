@@ -126,6 +126,73 @@ __global__ void add_diag3x3_kernel(double* __restrict__ F, uint32_t np, const ui
     F[(size_t)(3 * s + ej) * np + 3 * s + ei] += sign * w9[(size_t)q * 9 + ej * 3 + ei];
 }
 
+// ---- the normals formed directly in the unknown order of the condensing step's elimination (dnagpu_block_form_reduce): what
+// form_normals_kernel + add_diag3x3_kernel + schur_permute_kernel give, without the pass over the matrix in between.  spos[s] = position of
+// station s's first unknown in that order (a station's three unknowns stay together and in order); lower triangle of F (ld).
+__global__ __launch_bounds__(256) void init_ordered_kernel(double* __restrict__ F, uint32_t ld, const int32_t* __restrict__ map) {
+    const uint32_t tr = blockIdx.x, tc = blockIdx.y;
+    if (tc > tr) return;
+    const uint32_t i = tr * 128 + (threadIdx.x & 127);
+    const bool pad = map[i] == -1;
+    for (uint32_t jl = threadIdx.x >> 7; jl < 128; jl += 2) {
+        const uint32_t j = tc * 128 + jl;
+        F[(size_t)j * ld + i] = (i == j && pad) ? 1.0 : 0.0;
+    }
+}
+__global__ void form_normals_ordered_kernel(const uint32_t* __restrict__ prow, const uint32_t* __restrict__ pcol, const uint32_t* __restrict__ poff,
+                                            const uint32_t* __restrict__ pent, const double* __restrict__ wblk, double* __restrict__ F, uint32_t ld,
+                                            const uint32_t* __restrict__ spos, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pairs * 9) return;
+    uint32_t p = t / 9, e = t - p * 9;
+    int ei = e % 3, ej = e / 3;
+    uint32_t r = prow[p], c = pcol[p];
+    if (r == c && ei < ej) return;
+    double s = 0.0;
+    uint32_t k0 = poff[p], k1 = poff[p + 1];
+    for (uint32_t k = k0; k < k1; ++k) {       // (same terms in the same order as form_normals_kernel: same bits)
+        uint32_t ent = pent[k];
+        uint32_t blk = ent >> 1;
+        if (blk >= n_gnss_blk) blk += terr_shift;
+        double w = wblk[(size_t)blk * 9 + e];
+        s += (ent & 1u) ? -w : w;
+    }
+    const uint32_t pr = spos[r] + ei, pc = spos[c] + ej;
+    if (pr >= pc)
+        F[(size_t)pc * ld + pr] = s;
+    else
+        F[(size_t)pr * ld + pc] = s;
+}
+__global__ void add_diag3x3_ordered_kernel(double* __restrict__ F, uint32_t ld, const uint32_t* __restrict__ spos, const uint32_t* __restrict__ stn,
+                                           const double* __restrict__ w9, uint32_t k, double sign) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * 9) return;
+    uint32_t q = t / 9, e = t - q * 9;
+    int ei = e % 3, ej = e / 3;
+    if (ei < ej) return;
+    const uint32_t s0 = spos[stn[q]];
+    F[(size_t)(s0 + ej) * ld + s0 + ei] += sign * w9[(size_t)q * 9 + ej * 3 + ei];
+}
+// the right-hand side as the passenger row `row` of F (row > every unknown's position)
+__global__ void rhs_row_kernel(double* __restrict__ F, uint32_t ld, uint32_t row, const int32_t* __restrict__ map, const double* __restrict__ rhs,
+                               uint32_t npp) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npp) return;
+    const int32_t m = map[p];
+    if (m >= 0) F[(size_t)p * ld + row] = rhs[m];
+}
+void launch_form_ordered(double* F, uint32_t ld, uint32_t npp, const int32_t* map, const uint32_t* spos, const uint32_t* prow, const uint32_t* pcol,
+                         const uint32_t* poff, const uint32_t* pent, const double* wblk, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift,
+                         const uint32_t* con_stn, const double* con_w9, uint32_t n_con, const double* rhs, uint32_t rhs_row, hipStream_t s) {
+    hipLaunchKernelGGL(init_ordered_kernel, dim3(npp / 128, npp / 128), dim3(256), 0, s, F, ld, map);
+    if (n_pairs)
+        hipLaunchKernelGGL(form_normals_ordered_kernel, dim3((n_pairs * 9 + 255) / 256), dim3(256), 0, s, prow, pcol, poff, pent, wblk, F, ld, spos,
+                           n_pairs, n_gnss_blk, terr_shift);
+    if (n_con)
+        hipLaunchKernelGGL(add_diag3x3_ordered_kernel, dim3((n_con * 9 + 255) / 256), dim3(256), 0, s, F, ld, spos, con_stn, con_w9, n_con, 1.0);
+    hipLaunchKernelGGL(rhs_row_kernel, dim3((npp + 255) / 256), dim3(256), 0, s, F, ld, rhs_row, map, rhs, npp);
+}
+
 // wb(v) = sum_j' W(v, j') b(j') over the vectors j' of v's cluster (the AtVinv columns of the cluster times b)
 __global__ void cluster_wb_kernel(const double* __restrict__ wblk, const uint32_t* __restrict__ vec_wrow, const uint32_t* __restrict__ vec_c0,
                                   const uint32_t* __restrict__ vec_k, const double* __restrict__ b, double* __restrict__ wb, uint32_t n_vec) {
@@ -508,7 +575,7 @@ __global__ void schur_extract_kernel(const double* __restrict__ T, uint32_t ldt,
     double v = i == j ? 1.0 : 0.0;
     if (i < nj && j < nj) v = i >= j ? T[(size_t)j * ldt + i] : T[(size_t)i * ldt + j];
     S[(size_t)j * npj + i] = v;
-    S2[(size_t)j * npj + i] = v;
+    if (S2) S2[(size_t)j * npj + i] = v;
     if (i == 0) r[j] = j < nj ? T[(size_t)j * ldt + nj] : 0.0;
 }
 

@@ -83,6 +83,7 @@ struct Block {
     std::vector<uint32_t> h_schur_idx[2];
     uint32_t* schur_idx[2] = {};
     int32_t* schur_map[2] = {};
+    uint32_t* schur_spos[2] = {};      // station -> position of its first unknown in that order
     std::vector<void*> retired;        // replaced schur_map / schur_idx lists, freed with the block
     // host copies kept until the pair / incidence lists are built (dnagpu_block_set_clusters)
     std::vector<uint8_t> h_ttype;

@@ -154,7 +154,7 @@ void free_block(Block& b) {
     void* ptrs[] = {b.x_orig, b.x_rig, b.s1, b.s2, b.obs, b.Wblk,
                     b.vec_wrow, b.vec_c0, b.vec_k, b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc,
                     b.t_type, b.t_stn, b.t_blk0, b.t_vec0, b.t_val, b.t_pre, b.t_var, b.t_ih, b.t_th, b.s_llh, b.s_geoid, b.s_defl,
-                    b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1]};
+                    b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1], b.schur_spos[0], b.schur_spos[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (void* p : b.retired) hipFree(p);
@@ -1441,11 +1441,17 @@ namespace {
 // all others (plus one row that carries the right-hand side) and the others are eliminated.  On return (stream ordered)
 // T points at the trailing block inside the chain's W workspace: rows / columns 0..3k-1 hold the Schur complement (lower),
 // row 3k the reduced right-hand side; ldt its leading dimension.  m (the normals) is destroyed.
+// `form` (with `keep`, m = nullptr): the normals are formed here, directly in the elimination's order, with these constraints added
+struct FormInOrder {
+    const uint32_t* con_stn;      // host
+    const double* con_w9;         // host
+    size_t n_con;
+};
 int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, const double** T, uint32_t* ldt,
-                    int* slot_out, dnagpu_partial* keep = nullptr) {
-    const uint32_t n = m->n, nj = (uint32_t)(3 * k), ni = n - nj;
+                    int* slot_out, dnagpu_partial* keep = nullptr, const FormInOrder* form = nullptr) {
+    const uint32_t n = form ? 3 * b->n_stn : m->n, nj = (uint32_t)(3 * k), ni = n - nj;
     const uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1), npp = nip + njp;
-    if ((size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur: matrix capacity");
+    if (!form && (size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur: matrix capacity");
     // unknown order: the other stations (block order), padding, the listed stations (list order), the rhs row, padding
     int slot = -1;
     std::unique_lock<std::mutex> lk(ctx->schur_mutex);
@@ -1458,28 +1464,39 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
             out[idx_out[i]] = 1;
         }
         std::vector<int32_t> map(npp, -1);
+        std::vector<uint32_t> spos(b->n_stn, 0);
         uint32_t pos = 0;
         for (uint32_t s = 0; s < b->n_stn; ++s)
-            if (!out[s])
+            if (!out[s]) {
+                spos[s] = pos;
                 for (int c = 0; c < 3; ++c) map[pos++] = (int32_t)(3 * s + c);
-        for (size_t i = 0; i < k; ++i)
+            }
+        for (size_t i = 0; i < k; ++i) {
+            spos[idx_out[i]] = nip + 3 * (uint32_t)i;
             for (int c = 0; c < 3; ++c) map[nip + 3 * i + c] = (int32_t)(3 * idx_out[i] + c);
+        }
         map[nip + nj] = -2;
         slot = b->schur_map[0] ? 1 : 0;
         // another chain's thread may hold the replaced slot's pointers for a launch it has not enqueued yet: the old lists are
         // retired, not freed (a few kB each; a block sees at most a handful of station lists), and go with the block
         if (b->schur_map[slot]) b->retired.push_back(b->schur_map[slot]);
         if (b->schur_idx[slot]) b->retired.push_back(b->schur_idx[slot]);
+        if (b->schur_spos[slot]) b->retired.push_back(b->schur_spos[slot]);
         b->schur_map[slot] = nullptr;
         b->schur_idx[slot] = nullptr;
+        b->schur_spos[slot] = nullptr;
         HIPCHK(hipMalloc(&b->schur_map[slot], (size_t)npp * sizeof(int32_t)));
         HIPCHK(hipMalloc(&b->schur_idx[slot], k * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&b->schur_spos[slot], (size_t)b->n_stn * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(b->schur_spos[slot], spos.data(), (size_t)b->n_stn * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(b->schur_map[slot], map.data(), (size_t)npp * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(b->schur_idx[slot], idx_out, k * sizeof(uint32_t), hipMemcpyHostToDevice));
         b->h_schur_idx[slot].assign(idx_out, idx_out + k);
     }
     const int32_t* map_dev = b->schur_map[slot];
+    const uint32_t* spos_dev = b->schur_spos[slot];
     lk.unlock();
+    if (form && !keep) return fail(ctx, DNAGPU_EINVAL, "schur: forming in order needs a retained factor");
     int rc = ensure_ws(ctx, chain, npp);
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
@@ -1495,7 +1512,21 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
         // it is needed after this call but the Schur complement, which the caller extracts at once
         double* F = ws.X;
         if (keep->store) keep->store->n = 0;       // (its storage now holds the factor's inverse, not a matrix)
-        launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], F, npp, npp, st);
+        if (form) {
+            uint32_t* dstn = nullptr;
+            double* dw = nullptr;
+            if (form->n_con) {
+                for (size_t i = 0; i < form->n_con; ++i)
+                    if (form->con_stn[i] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "schur: constraint station out of range");
+                int rs = stage_u32(ctx, chain, form->con_stn, form->n_con, &dstn);
+                if (!rs) rs = stage_f64(ctx, chain, form->con_w9, form->n_con * 9, &dw);
+                if (rs) return rs;
+            }
+            launch_form_ordered(F, npp, npp, map_dev, spos_dev, b->pair_row, b->pair_col, b->pair_off, b->pair_ent, b->Wblk, b->n_pairs, b->n_wblk,
+                                (uint32_t)chain * (b->n_tblk + b->n_dsblk), dstn, dw, (uint32_t)form->n_con, b->rhs[chain], nip + nj, st);
+        } else {
+            launch_schur_permute(m->F, m->np, map_dev, b->rhs[chain], F, npp, npp, st);
+        }
         HIPCHK(hipMemcpyAsync(keep->map, map_dev, (size_t)npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         if (keep->spine)
             sym_spine_async(ws, F, keep->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
@@ -1801,6 +1832,29 @@ int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
     red->n = (uint32_t)(3 * k);
     red->np = pad128(red->n);
     launch_schur_extract(T, ldt, red->n, red->np, red->F, m->F, red->jest, st);
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info(ctx, chain);
+}
+
+int dnagpu_block_form_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* con_stn, const double* con_w9, size_t n_con,
+                             const uint32_t* idx_keep, size_t k, dnagpu_matrix* red, dnagpu_partial* keep) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !red || !keep || !k || !idx_keep || k > b->n_stn || 3 * k > red->n_max || (n_con && (!con_stn || !con_w9)))
+        return fail(ctx, DNAGPU_EINVAL, "block_form_reduce: bad arguments");
+    const double* T = nullptr;
+    uint32_t ldt = 0;
+    int slot = 0;
+    FormInOrder form{con_stn, con_w9, n_con};
+    int rc = schur_eliminate(ctx, chain, b, nullptr, idx_keep, k, &T, &ldt, &slot, keep, &form);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    red->n = (uint32_t)(3 * k);
+    red->np = pad128(red->n);
+    launch_schur_extract(T, ldt, red->n, red->np, red->F, nullptr, red->jest, st);
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);

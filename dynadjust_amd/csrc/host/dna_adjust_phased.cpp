@@ -547,8 +547,6 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
         return;
     }
     dnagpu_matrix* W = work_[c];
-    FormNormals(c, k, W);
-    AddConstraints(c, W, B.con_inner, +1, k);
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     if (B.part_allowed && !B.part) {
         std::lock_guard<std::mutex> lk(alloc_mutex_);
@@ -567,7 +565,19 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     }
     B.part_valid = false;
     if (B.part && B.part_in_rigvar) B.has_rigvar = false;      // (its storage holds the factor until the rigorous solve of this iteration)
-    Check(dnagpu_block_reduce(ctx_, c, k, W, B.keep.data(), B.keep.size(), B.red, B.part), k, "Solve()");
+    if (B.part) {
+        // the normals are formed where the elimination works on them, in its unknown order: no matrix in the block's own order, no
+        // pass to re-order it (dnagpu_block_form_reduce = UpdateNormals + AddConstraintStationstoNormals + the reduction)
+        const auto t0 = std::chrono::steady_clock::now();
+        Check(dnagpu_block_form_reduce(ctx_, c, k, B.con_inner.stn.data(), B.con_inner.w9.data(), B.con_inner.stn.size(), B.keep.data(), B.keep.size(),
+                                       B.red, B.part), k, "Solve()");
+        if (profileTimings_)
+            profileUpdateNormalsNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        FormNormals(c, k, W);
+        AddConstraints(c, W, B.con_inner, +1, k);
+        Check(dnagpu_block_reduce(ctx_, c, k, W, B.keep.data(), B.keep.size(), B.red, nullptr), k, "Solve()");
+    }
     B.part_valid = B.part != nullptr;
     const double nk = 3.0 * (double)B.keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);

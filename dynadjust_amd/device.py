@@ -232,6 +232,14 @@ class DeviceContext:
         self._chk(self.lib.dnagpu_block_reduce(self.h, chain, blk, m.h, p, ix.size, red.h, keep))
         red.n = 3 * ix.size
 
+    def block_form_reduce(self, blk, con_stn, con_w9, idx_keep, red, keep, chain=0):
+        """form_normals + add_diag3x3(+1) + block_reduce(keep) in one step, the normals formed directly in the elimination's order"""
+        ix, p = _u32(idx_keep)
+        cs, pcs = _u32(con_stn)
+        cw, pcw = _f64(con_w9)
+        self._chk(self.lib.dnagpu_block_form_reduce(self.h, chain, blk, pcs, pcw, cs.size, p, ix.size, red.h, keep))
+        red.n = 3 * ix.size
+
     def partial_create(self, n_max, k_max):
         h = C.c_void_p()
         self._chk(self.lib.dnagpu_partial_create(self.h, n_max, k_max, C.byref(h)))

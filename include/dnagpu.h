@@ -268,6 +268,12 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
  * (a few thousand unknowns each) and produce the very junction weights and estimates the block-level chain would. */
 int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_keep, size_t k, dnagpu_matrix* red,
                         dnagpu_partial* keep /* may be NULL */);
+/* The same for a block whose factor is kept (`keep` required), WITHOUT a formed matrix to start from: the normals of the block's current
+ * estimates (what dnagpu_form_normals builds) plus the listed constraint blocks (dnagpu_add_diag3x3, sign +1) are formed directly in the
+ * unknown order the elimination works in, the right-hand side (dnagpu_form_rhs before this call) as its passenger row -- one pass over
+ * the matrix less than form + add + reduce.  Same bits as that sequence. */
+int dnagpu_block_form_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* con_stn, const double* con_w9, size_t n_con,
+                             const uint32_t* idx_keep, size_t k, dnagpu_matrix* red, dnagpu_partial* keep);
 /* With `keep`, the elimination leaves everything a later completion needs in HBM -- the factor of the eliminated part, its
  * inverse and the panel under the kept rows (n^2 + 3k n doubles) -- at 2/3 n_i^3 instead of ~0.34 n_i^3 flops.
  * dnagpu_partial_complete then turns  [ N_II  . ; N_KI  kk ]  (kk: the kept block as the chains left it: reduced block +

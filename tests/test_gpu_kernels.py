@@ -365,6 +365,58 @@ def test_light_kept_factor(gpu_ctx, built, orc, tmp_path, rows, cols, pick):
     gpu_ctx.block_destroy(0)
 
 
+@pytest.mark.parametrize("rows,cols,pick,spine", [(9, 8, "jsl", True), (40, 30, "jsl", True), (40, 30, "scattered", False), (43, 43, "one", True)])
+def test_normals_formed_in_elimination_order(gpu_ctx, built, orc, tmp_path, rows, cols, pick, spine):
+    """dnagpu_block_form_reduce against dnagpu_form_normals + dnagpu_add_diag3x3 + dnagpu_block_reduce: the same condensed block, reduced
+    right-hand side, solution and final inverse, bit for bit -- the same terms summed in the same order, only written somewhere else"""
+    from dynadjust_amd import adjust
+    adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, 2, seed=rows)
+    net = orc.Network(str(tmp_path / "s"), True)
+    a = orc.Adjustment(net, True)
+    a.prepare()
+    st0, _, _, _ = _upload_block(gpu_ctx, net, a, 0, blk_id=0)
+    ns = len(st0)
+    n0 = 3 * ns
+    loc0 = {int(s): i for i, s in enumerate(st0)}
+    stn = {"jsl": [loc0[int(s)] for s in net.jsl[net.jsl_off[0]:net.jsl_off[1]]], "scattered": list(range(1, ns, 7))[::-1], "one": [ns // 2]}[pick]
+    idx = np.array(stn, dtype=np.uint32)
+    nk = 3 * len(idx)
+    rng = np.random.default_rng(rows)
+    con_stn = np.array(sorted(rng.choice(ns, size=min(5, ns), replace=False)), dtype=np.uint32)
+    con_w9 = np.concatenate([(lambda g: (g @ g.T + np.eye(3)).ravel())(rng.standard_normal((3, 3))) * 1e3 for _ in con_stn])
+    gpu_ctx.block_compute_b(0)
+    gpu_ctx.form_rhs(0)
+    m = gpu_ctx.matrix(n0)
+    kk = gpu_ctx.matrix(nk)
+    outs = []
+    for ordered in (False, True):
+        red = gpu_ctx.matrix(nk)
+        store = gpu_ctx.matrix(n0 + 256)
+        pf = gpu_ctx.partial_create_spine(n0, nk, store) if spine else gpu_ctx.partial_create_in(n0, nk, store)
+        if ordered:
+            gpu_ctx.block_form_reduce(0, con_stn, con_w9, idx, red, pf)
+        else:
+            gpu_ctx.form_normals(0, m, ns)
+            gpu_ctx.add_diag3x3(m, con_stn, con_w9)
+            gpu_ctx.block_reduce(0, m, idx, red, keep=pf)
+        S = red.download_packed().copy()
+        r = gpu_ctx.junction_get_estimates(red).copy()
+        kk.upload_packed(S, nk)
+        gpu_ctx.partial_complete_factor(pf, kk)
+        gpu_ctx.partial_solve(0, pf)
+        x = gpu_ctx.block_get_corrections(0, ns).copy()
+        gpu_ctx.partial_finish(pf, store, n0)
+        outs.append((S, r, x, store.download_packed().copy()))
+        gpu_ctx.partial_destroy(pf)
+        store.close()
+        red.close()
+    for u, v in zip(outs[0], outs[1]):
+        assert np.array_equal(u, v)
+    for q in (m, kk):
+        q.close()
+    gpu_ctx.block_destroy(0)
+
+
 @pytest.mark.parametrize("rows,cols,pick,lend", [(9, 8, "jsl", False), (40, 30, "jsl", True), (40, 30, "scattered", False), (43, 43, "one", True)])
 def test_completion_in_two_halves(gpu_ctx, built, orc, tmp_path, rows, cols, pick, lend):
     """dnagpu_partial_complete_factor + dnagpu_partial_solve + dnagpu_partial_finish: the solution of an iteration from the completed
