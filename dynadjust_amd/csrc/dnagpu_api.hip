@@ -1687,7 +1687,7 @@ int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, cons
     sym_complete_async(ws, F, pf->X, (int)pf->npp, pf->WK, (int)pf->njp, (int)(pf->nip / 128), (int)(pf->njp / 128));
     inv->n = pf->n;
     inv->np = pad128(pf->n);
-    launch_init_padded(inv->F, inv->n, inv->np, st);
+    launch_init_padding(inv->F, inv->n, inv->np, st);      // (the un-permutation writes every element of the n x n part)
     launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1784,7 +1784,7 @@ int dnagpu_partial_finish(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, dnagpu
     }
     inv->n = pf->n;
     inv->np = pad128(pf->n);
-    launch_init_padded(inv->F, inv->n, inv->np, st);
+    launch_init_padding(inv->F, inv->n, inv->np, st);      // (the un-permutation writes every element of the n x n part)
     launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
     // (nothing here factors anything: `info` is put to "no failure" for check_info, which then reports enqueue / launch errors only)
     HIPCHK(hipMemsetAsync(ws.info, 0x7f, sizeof(int), st));

@@ -80,6 +80,7 @@ void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info,
 void launch_unpack_lower(const double* ap, double* F, uint32_t n, uint32_t np, hipStream_t s);
 void launch_pack_lower(const double* F, double* ap, uint32_t n, uint32_t np, hipStream_t s);
 void launch_init_padded(double* F, uint32_t n, uint32_t np, hipStream_t s);
+void launch_init_padding(double* F, uint32_t n, uint32_t np, hipStream_t s);   // rows / columns n .. np - 1 only
 void launch_diag_rsqrt(const double* F, double* s, uint32_t n, uint32_t np, hipStream_t st);
 void launch_scale_sym(double* F, const double* s, uint32_t n, uint32_t np, int lower_only, hipStream_t st);
 void launch_symmetrize(double* F, uint32_t n, uint32_t np, hipStream_t s);

@@ -707,6 +707,14 @@ __global__ void init_padded_kernel(double* __restrict__ F, uint32_t n, uint32_t 
     uint32_t j = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) F[(size_t)j * np + i] = (i == j && j >= n) ? 1.0 : 0.0;
 }
+// the same for the padding only (rows and columns n .. np - 1): for a matrix whose n x n part is about to be written in full
+__global__ void init_padding_kernel(double* __restrict__ F, uint32_t n, uint32_t np) {
+    uint32_t j = blockIdx.x;
+    for (uint32_t i = (j >= n ? 0 : n) + threadIdx.x; i < np; i += blockDim.x) F[(size_t)j * np + i] = (i == j) ? 1.0 : 0.0;
+}
+void launch_init_padding(double* F, uint32_t n, uint32_t np, hipStream_t s) {
+    if (np > n) hipLaunchKernelGGL(init_padding_kernel, dim3(np), dim3(128), 0, s, F, n, np);
+}
 void launch_init_padded(double* F, uint32_t n, uint32_t np, hipStream_t s) {
     hipLaunchKernelGGL(init_padded_kernel, dim3(np), dim3(256), 0, s, F, n, np);
 }
