@@ -8,5 +8,3 @@ echo "all rc=$?" > gpurun_out/job.status
 tail -n 6 gpurun_out/t_all.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/job.status
 tail -2 gpurun_out/smoke.log; cat gpurun_out/job.status
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('bench', j['ms_per_step'], j['roofline']['frac'])"
-DNAGPU_MULTI_THREAD=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('one chain', j['ms_per_step'], j['roofline']['frac'])"
