@@ -243,6 +243,144 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
     }
 
 
+def _solves_of_reference_schedule(a, lib, its):
+    """Solve() calls (and their n^3) the reference's forward / reverse / combination schedule would have made"""
+    solves, ref = 0, 0.0
+    for k in range(a.blockCount()):
+        f, l, i = C.c_int(), C.c_int(), C.c_int()
+        lib.dnaadj_block_flags(a.h, k, C.byref(f), C.byref(l), C.byref(i))
+        m = 1 + (0 if i.value else 1) + (0 if (f.value or l.value or i.value) else 1)
+        n3 = (3.0 * lib.dnaadj_block_station_count(a.h, k)) ** 3
+        solves += its * m
+        ref += its * m * n3
+    return solves, ref
+
+
+def _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, per_rank, owners, check, driver, transport, rccl_ranks, multi_thread):
+    """the JSON line of an N > 1 run from the per-rank records (alg, gemm_ms, issued, solves, completions, eliminations, exchange_ms,
+    chain_ms, bytes), whichever way the ranks were started"""
+    condensed = any(v["eliminations"] for v in per_rank)
+    alg = sum(v["alg"] for v in per_rank)
+    busiest = max(range(world), key=lambda r: per_rank[r]["gemm_ms"])
+    gemm_ms = per_rank[busiest]["gemm_ms"]
+    achieved = (per_rank[busiest]["alg"] / 1e12) / (gemm_ms / args.steps / 1e3) if gemm_ms > 0 else 0.0
+    chains = (os.environ.get("DNAGPU_CHAINS", "4") + " chains") if multi_thread else "one chain"
+    par = (f"condensed schedule inside dna_adjust::AdjustNetwork (C++): {B} blocks in contiguous runs over {world} ranks ({chains} per GPU), "
+           "condensed blocks broadcast in place by ncclBroadcast, chains on the condensed blocks on every rank, coordinates by one ncclAllReduce"
+           ) if condensed else (
+           f"reference schedule inside dna_adjust::AdjustNetwork (C++): forward chain on rank 0, reverse chain on rank 1, combination solves "
+           f"round-robin over {world} ranks; junction matrices by ncclSend / ncclRecv")
+    return {
+        "metric": "stations adjusted/sec + Cholesky TFLOP/s, phased adjustment, 1/2/4/8 MI355X",
+        "value": stations * args.steps / dt, "unit": "stations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"stations": stations, "blocks": B, "iterations_to_converge": its, "mode": "phased", "solves_per_step": solves,
+                   "schur_carry": condensed, "keep_factors": any(v["completions"] for v in per_rank),
+                   "variance_matrices": "after the last iteration" if (not args.variances_every_iteration and any(v["completions"] for v in per_rank)) else "every iteration", "parallelism": par,
+                   # who drove the ranks, what carried the exchange, and how many ranks the RCCL communicator itself counts (ncclCommCount; 0 = not RCCL)
+                   "driver": driver, "transport": transport, "rccl_ranks": rccl_ranks,
+                   "variance_propagation_in_step": bool(args.variance_propagation), "blocks_per_rank": [owners.count(r) for r in range(world)]},
+        "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
+        "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
+        "roofline": {"kernel": "tile_dag_kernel / gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
+                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "rank": busiest, "gemm_ms_per_step": gemm_ms / args.steps,
+                     "note": "busiest rank: algorithmic flops of its steps / HIP-event time of its GEMM launches"},
+        # host-side time of the last timed step, per rank: the exchange steps (broadcasts, all-reduce, their waits) and the chains on
+        # the condensed blocks -- the serial remainder of the condensed schedule
+        "exchange": {"exchange_ms_per_step": [v["exchange_ms"] for v in per_rank], "chain_phase_ms_per_step": [v["chain_ms"] for v in per_rank],
+                     "payload_bytes_per_rank_per_step": [v["bytes"] for v in per_rank]},
+        "check": check,
+    }
+
+
+def _check_block(a, folder, name, stations):
+    import numpy as np
+    try:
+        a.GenerateStatistics()
+        truth = np.fromfile(os.path.join(folder, name + ".truth"), dtype=np.float64).reshape(-1, 3)
+        xyz = a.adjusted_coordinates(stations)
+        return {"sigma_zero": a.GetSigmaZero(), "degrees_of_freedom": a.GetDegreesOfFreedom(),
+                "max_abs_error_vs_truth_m": float(np.abs(xyz - truth).max()), "global_test": int(a.GetTestResult()),
+                "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()]}
+    except Exception as e:                       # diagnostic only
+        return {"error": str(e)}
+
+
+def bench_one_process(folder, name, phased, args, devices, transport):
+    """bench.py --gpus N without a launcher (WORLD_SIZE unset): ONE process drives the N GPUs, the mode dnaadjustwrapper linked to
+    libdnagpu.so gets (a.devices -> one dna_adjust instance and one host thread per GPU inside the library, RCCL communicators made
+    by the threads; dna_adjust_dist.cpp "one process, several GPUs").  The reference's parallel driver starts its threads inside the
+    class the same way (dnaadjust-multi.cpp:92-244)."""
+    import torch
+    from dynadjust_amd import adjust
+    if not phased:
+        raise SystemExit("the simultaneous adjustment has one block: nothing to spread over GPUs by block; run it with --gpus 1")
+    world = len(devices)
+    a = adjust.DnaAdjust()
+    multi_thread = bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1")))
+    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, devices=devices, dist_transport=transport, multi_thread=multi_thread,
+                               schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage,
+                               defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
+                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))))
+    a.PrepareAdjustment(p)
+    lib = a.lib
+    ctxs = [a.device_instance_context(r) for r in range(world)]
+
+    def sync_all():
+        for c in ctxs:
+            lib.dnagpu_sync(c)
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def one_step():
+        a.ResetAdjustment()
+        st = a.AdjustNetworkDistributed()
+        if st != adjust.ADJUST_SUCCESS:
+            raise SystemExit(f"adjustment did not converge (status {st})")
+        if args.variance_propagation:
+            a.GenerateStatistics()
+
+    for _ in range(args.warmup):
+        one_step()
+    for c in ctxs:
+        lib.dnagpu_profile_enable(c, 0 if args.no_gemm_events else 1)
+        lib.dnagpu_profile_reset(c)
+    bytes0 = [a.device_instance_stats(r)["exchanged_bytes"] for r in range(world)]
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    per_rank = []
+    for r, c in enumerate(ctxs):
+        prof_f, prof_ms, prof_n = C.c_double(), C.c_double(), C.c_uint64()
+        lib.dnagpu_profile_get(c, C.byref(prof_f), C.byref(prof_ms), C.byref(prof_n))
+        lib.dnagpu_profile_enable(c, 0)
+        st = a.device_instance_stats(r)
+        per_rank.append({"alg": st["algorithmic_flops"], "gemm_ms": prof_ms.value, "issued": prof_f.value, "solves": st["solves"],
+                         "completions": st["completions"], "eliminations": st["eliminations"], "exchange_ms": st["exchange_ms"],
+                         "chain_ms": st["chain_ms"], "bytes": (st["exchanged_bytes"] - bytes0[r]) / max(1, args.steps)})
+    its = a.CurrentIteration()
+    stations = lib.dnaadj_station_count(a.h)
+    B = a.blockCount()
+    owners = [a.block_owner(k) for k in range(B)]
+    solves, ref = _solves_of_reference_schedule(a, lib, its)
+    st0 = a.device_instance_stats(0)
+    _, _, tr = a.dist_info()
+    out = _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, per_rank, owners, _check_block(a, folder, name, stations),
+                          "C++ (libdnagpu.so): one process, one dna_adjust instance + host thread per GPU (a.devices)", tr, st0["rccl_ranks"], multi_thread)
+    out["config"]["devices"] = list(devices)
+    if len(set(devices)) < world:
+        out["config"]["ranks_share_gpus"] = True     # DNAGPU_BENCH_SHARE_GPU=1: a code-path check on a box with fewer GPUs, NOT a scaling measurement
+        out["n_gpus"] = len(set(devices))
+        out["config"]["ranks"] = world
+    a.close()
+    return out
+
+
 def bench_distributed_native(folder, name, phased, args, dist, rank, world, local_rank):
     """bench.py --gpus N (N > 1): one network, its blocks spread over N ranks by the library itself (strong scaling)."""
     import numpy as np
@@ -294,67 +432,34 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     its = a.CurrentIteration()
     ex = a.exchange_stats()
     mine = {"alg": a.algorithmic_flops(), "gemm_ms": prof_ms.value, "issued": prof_f.value, "solves": a.solve_count(), "completions": a.completion_count(),
-            "eliminations": a.elimination_count(), "exchange_ms": ex["exchange_ms"], "chain_ms": ex["chain_ms"], "bytes": (ex["bytes"] - bytes0) / max(1, args.steps)}
+            "eliminations": a.elimination_count(), "exchange_ms": ex["exchange_ms"], "chain_ms": ex["chain_ms"], "bytes": (ex["bytes"] - bytes0) / max(1, args.steps),
+            "rccl_ranks": a.device_instance_stats(0)["rccl_ranks"]}
     allv = [None] * world
     dist.all_gather_object(allv, mine)
     stations = lib.dnaadj_station_count(a.h)
     B = a.blockCount()
     owners = [a.block_owner(k) for k in range(B)]
     # statistics across the ranks (collective inside the library) and the distance from the truth the generator kept
-    check = None
-    try:
-        a.GenerateStatistics()
-        truth = np.fromfile(os.path.join(folder, name + ".truth"), dtype=np.float64).reshape(-1, 3)
-        xyz = a.adjusted_coordinates(stations)
-        check = {"sigma_zero": a.GetSigmaZero(), "degrees_of_freedom": a.GetDegreesOfFreedom(),
-                 "max_abs_error_vs_truth_m": float(np.abs(xyz - truth).max()), "global_test": int(a.GetTestResult()),
-                 "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()]}
-    except Exception as e:                       # diagnostic only
-        check = {"error": str(e)}
+    check = _check_block(a, folder, name, stations)
     out = None
     if rank == 0:
-        condensed = any(v["eliminations"] for v in allv)
-        solves, ref = 0, 0.0
-        for k in range(B):
-            f, l, i = C.c_int(), C.c_int(), C.c_int()
-            lib.dnaadj_block_flags(a.h, k, C.byref(f), C.byref(l), C.byref(i))
-            m = 1 + (0 if i.value else 1) + (0 if (f.value or l.value or i.value) else 1)
-            n3 = (3.0 * lib.dnaadj_block_station_count(a.h, k)) ** 3
-            solves += its * m
-            ref += its * m * n3
-        alg = sum(v["alg"] for v in allv)
-        busiest = max(range(world), key=lambda r: allv[r]["gemm_ms"])
-        gemm_ms = allv[busiest]["gemm_ms"]
-        achieved = (allv[busiest]["alg"] / 1e12) / (gemm_ms / args.steps / 1e3) if gemm_ms > 0 else 0.0
-        chains = (os.environ.get("DNAGPU_CHAINS", "4") + " chains") if p.multi_thread else "one chain"
-        par = (f"condensed schedule inside dna_adjust::AdjustNetwork (C++): {B} blocks in contiguous runs over {world} ranks ({chains} per GPU), "
-               "condensed blocks broadcast in place by ncclBroadcast, chains on the condensed blocks on every rank, coordinates by one ncclAllReduce"
-               ) if condensed else (
-               f"reference schedule inside dna_adjust::AdjustNetwork (C++): forward chain on rank 0, reverse chain on rank 1, combination solves "
-               f"round-robin over {world} ranks; junction matrices by ncclSend / ncclRecv")
-        out = {
-            "metric": "stations adjusted/sec + Cholesky TFLOP/s, phased adjustment, 1/2/4/8 MI355X",
-            "value": stations * args.steps / dt, "unit": "stations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"stations": stations, "blocks": B, "iterations_to_converge": its, "mode": "phased", "solves_per_step": solves,
-                       "schur_carry": condensed, "keep_factors": any(v["completions"] for v in allv),
-                       "variance_matrices": "after the last iteration" if (not args.variances_every_iteration and any(v["completions"] for v in allv)) else "every iteration", "parallelism": par,
-                       "driver": "C++ (libdnagpu.so) + RCCL", "variance_propagation_in_step": bool(args.variance_propagation), "blocks_per_rank": [owners.count(r) for r in range(world)]},
-            "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
-            "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
-            "roofline": {"kernel": "gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
-                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "rank": busiest, "gemm_ms_per_step": gemm_ms / args.steps,
-                         "note": "busiest rank: algorithmic flops of its steps / HIP-event time of its GEMM launches"},
-            # host-side time of the last timed step, per rank: the exchange steps (broadcasts, all-reduce, their waits) and the chains on
-            # the condensed blocks -- the serial remainder of the condensed schedule
-            "exchange": {"exchange_ms_per_step": [v["exchange_ms"] for v in allv], "chain_phase_ms_per_step": [v["chain_ms"] for v in allv],
-                         "payload_bytes_per_rank_per_step": [v["bytes"] for v in allv]},
-            "check": check,
-        }
+        solves, ref = _solves_of_reference_schedule(a, lib, its)
+        _, _, tr = a.dist_info()
+        out = _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, allv, owners, check,
+                              "C++ (libdnagpu.so): one process per GPU (torchrun ranks), RCCL called from the library", tr, min(v["rccl_ranks"] for v in allv),
+                              p.multi_thread)
     a.close()
     return out
+
+
+def _so_hash():
+    """first 16 hex digits of the SHA-256 of the libdnagpu.so this run loaded (the GPU box runs the binary built in the build container)"""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "dynadjust_amd", "libdnagpu.so"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def emit(result):
@@ -402,32 +507,30 @@ def main():
         return
 
     import torch
+    launched = "WORLD_SIZE" in os.environ          # started by a launcher (torchrun: the driver's N > 1 runs), one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the adjustment path has no CPU fallback")
-    # DNAGPU_DIST_BACKEND=gloo: test harness for the N > 1 code path on a box with fewer GPUs than ranks (ranks share
-    # devices, payloads travel through host memory); the driver's runs use nccl (= RCCL), one GPU per rank
-    # "native" (default): control plane gloo, data path RCCL from inside the library; "nccl": control plane torch's NCCL (the data path is
-    # the library's RCCL all the same, torch's only if that cannot start); "gloo": the Python harness, payloads through the host
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if launched and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # DNAGPU_BENCH_SHARE_GPU=1 (code-path checks on a box with fewer GPUs than ranks): ranks share devices, transport "local" inside the
+    # library; the JSON line says so (`ranks_share_gpus`) and reports the devices actually used as n_gpus.  Never the default.
+    share = bool(int(os.environ.get("DNAGPU_BENCH_SHARE_GPU", "0")))
+    n_dev = torch.cuda.device_count()
+    if args.gpus > n_dev and not share:
+        raise SystemExit(f"--gpus {args.gpus}: this node shows {n_dev} GPU(s) (DNAGPU_BENCH_SHARE_GPU=1 lets ranks share devices for a code-path check)")
+    # DNAGPU_DIST_BACKEND (launched runs): "native" (default) = control plane gloo, data path the library's own RCCL; "nccl" = control
+    # plane torch's NCCL, data path still the library's RCCL; "gloo" = the Python TEST harness (tests/parallel_harness.py) with host
+    # payloads and ranks that may share a GPU -- only when asked for, and the JSON line's config.driver says so.
     dist_backend = os.environ.get("DNAGPU_DIST_BACKEND", "native")
-    if dist_backend == "gloo":
-        local_rank %= torch.cuda.device_count()
+    if dist_backend == "gloo" or share:
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
-    dist = None
-    # DNAGPU_FORCE_DISTRIBUTED=1: run the N > 1 code path (RCCL process group, device-resident payloads, collectives) with
-    # however many ranks there are -- with one rank on a 1-GPU box it is the only way to exercise the NCCL transport there
-    distributed = world > 1 or bool(int(os.environ.get("DNAGPU_FORCE_DISTRIBUTED", "0")))
-    if distributed:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if dist_backend == "gloo" or dist_backend == "native":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    print(f"libdnagpu.so sha256[:16] = {_so_hash()}", file=sys.stderr, flush=True)
 
     from dynadjust_amd import adjust
     from dynadjust_amd.device import DeviceContext  # noqa: F401  (fails loudly if the HIP library is missing)
@@ -437,25 +540,41 @@ def main():
     info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, blocks)
     stations = info["stations"]
 
+    if not launched and args.gpus > 1:
+        # no launcher: this process drives all N GPUs itself (a.devices; RCCL between the library's per-GPU threads)
+        devices = [r % n_dev for r in range(args.gpus)]
+        result = bench_one_process(d, "net", phased, args, devices, "local" if len(set(devices)) < len(devices) else None)
+        result["config"]["workload"] = desc
+        result["config"]["libdnagpu_sha16"] = _so_hash()
+        emit(result)
+        return
+
+    # DNAGPU_FORCE_DISTRIBUTED=1: run the N > 1 code path (RCCL communicator, device-resident payloads, collectives) with
+    # however many ranks there are -- with one rank on a 1-GPU box it is the only way to exercise the RCCL transport there
+    distributed = world > 1 or bool(int(os.environ.get("DNAGPU_FORCE_DISTRIBUTED", "0")))
     if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if dist_backend in ("gloo", "native"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         # N > 1: the driver is C++ (dna_adjust::AdjustPhasedDistributed), the exchange RCCL called from the library; torch.distributed
-        # is the launcher's control plane here (unique-id broadcast, barriers, the max over the ranks' clocks).
-        # DNAGPU_DIST_BACKEND=gloo keeps the Python harness over the same per-block entry points (ranks sharing a GPU, host payloads).
-        result = None
-        if dist_backend != "gloo":
-            try:
-                result = bench_distributed_native(d, "net", phased, args, dist, rank, world, local_rank)
-            except Exception as e:                                   # (an RCCL that cannot start: measured through torch's instead)
-                print(f"rank {rank}: native RCCL driver unavailable ({e}); falling back to the torch.distributed harness", file=sys.stderr, flush=True)
-                result = None
-                fell_back = True
-            else:
-                fell_back = False
-        if result is None and (dist_backend == "gloo" or fell_back):
-            from dynadjust_amd import parallel
-            result = parallel.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)
+        # is the launcher's control plane here (unique-id broadcast, barriers, the max over the ranks' clocks).  A library whose RCCL
+        # cannot start is FATAL: no silent change of driver.
+        if dist_backend == "gloo":
+            from tests import parallel_harness
+            result = parallel_harness.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)
+            if rank == 0:
+                result["config"]["driver"] = "Python TEST harness (tests/parallel_harness.py, DNAGPU_DIST_BACKEND=gloo): per-block C entry points, host payloads"
+                result["config"]["transport"] = "gloo"
+                result["config"]["rccl_ranks"] = 0
+        else:
+            result = bench_distributed_native(d, "net", phased, args, dist, rank, world, local_rank)
         if rank == 0:
             result["config"]["workload"] = desc
+            result["config"]["libdnagpu_sha16"] = _so_hash()
             emit(result)
         dist.barrier()
         dist.destroy_process_group()
@@ -530,6 +649,7 @@ def main():
             "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses),
             "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
             "variance_matrices": "after the last iteration" if (a.completion_count() and not args.variances_every_iteration and not args.reuse_inverses) else "every iteration",
+            "libdnagpu_sha16": _so_hash(),
             "completions_per_step": a.completion_count(), "variance_propagation_in_step": bool(args.variance_propagation), "parallelism": "1 GPU, one chain" if not p.multi_thread else
             "1 GPU, %s chains (multi_thread: the independent block steps of the condensed schedule are served by every chain; the two junction chains run side by side)" % os.environ.get("DNAGPU_CHAINS", "4"),
         },

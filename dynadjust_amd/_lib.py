@@ -46,6 +46,13 @@ class DnaAdjStatistics(C.Structure):
                 ("degrees_of_freedom", C.c_int)]
 
 
+class DnaAdjInstanceStats(C.Structure):
+    """dnaadj_instance_stats (include/dnaadjust_c.h)"""
+    _fields_ = [("rank", C.c_int), ("device", C.c_int), ("rccl_ranks", C.c_int), ("solves", C.c_uint32), ("eliminations", C.c_uint32),
+                ("completions", C.c_uint32), ("algorithmic_flops", C.c_double), ("solve_flops", C.c_double), ("exchanged_bytes", C.c_uint64),
+                ("exchange_ms", C.c_double), ("chain_ms", C.c_double)]
+
+
 class DnaSynthSpec(C.Structure):
     _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("n_baselines", C.c_uint64), ("n_blocks", C.c_uint32),
                 ("seed", C.c_uint64), ("initial_sigma", C.c_double), ("x_clusters", C.c_uint32), ("y_cluster", C.c_uint32),
@@ -104,6 +111,9 @@ def load():
     _sig(lib, "dnagpu_debug_tile_order", C.c_long, [C.c_int] * 8 + [C.POINTER(C.c_uint32), C.c_long, C.POINTER(C.c_int)])
     _sig(lib, "dnagpu_fused_stats", i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
     _sig(lib, "dnagpu_set_fused_launches", i, [vp, i])
+    _sig(lib, "dnagpu_debug_set_tile_dag", i, [i])
+    _sig(lib, "dnagpu_tile_dag_stats", i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+    _sig(lib, "dnagpu_debug_tile_dag_selftest", i, [i, i, i, i, C.c_uint64, c_f64p])
     _sig(lib, "dnagpu_profile_reset", i, [vp])
     _sig(lib, "dnagpu_profile_get", i, [vp, c_f64p, c_f64p, C.POINTER(C.c_uint64)])
     _sig(lib, "dnagpu_matrix_create", i, [vp, u32, C.POINTER(vp)])
@@ -215,6 +225,8 @@ def load():
     _sig(lib, "dnaadj_block_owner", i, [vp, u32])
     _sig(lib, "dnaadj_exchange_stats", i, [vp, C.POINTER(C.c_uint64), c_f64p, c_f64p])
     _sig(lib, "dnaadj_device_instance_context", vp, [vp, i])
+    _sig(lib, "dnaadj_device_instance_stats", i, [vp, i, C.POINTER(DnaAdjInstanceStats)])
+    _sig(lib, "dnaadj_debug_cancel_instance", i, [vp, i])
     _sig(lib, "dnaadj_generate_statistics", i, [vp])
     _sig(lib, "dnaadj_get_statistics", i, [vp, C.POINTER(DnaAdjStatistics)])
     _sig(lib, "dnaadj_measurement_record_count", u64, [vp])
@@ -274,7 +286,7 @@ def load():
 
 EXPORTED_DNAGPU = [
     "dnagpu_device_count", "dnagpu_create", "dnagpu_destroy", "dnagpu_last_error", "dnagpu_last_info", "dnagpu_sync",
-    "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset", "dnagpu_debug_fail_allocation", "dnagpu_debug_set_small_tiles", "dnagpu_debug_tile_order", "dnagpu_debug_set_pair_tiles", "dnagpu_fused_stats", "dnagpu_set_fused_launches",
+    "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset", "dnagpu_debug_fail_allocation", "dnagpu_debug_set_small_tiles", "dnagpu_debug_tile_order", "dnagpu_debug_set_pair_tiles", "dnagpu_fused_stats", "dnagpu_set_fused_launches", "dnagpu_debug_set_tile_dag", "dnagpu_tile_dag_stats", "dnagpu_debug_tile_dag_selftest",
     "dnagpu_profile_get", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
     "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_download_packed_async", "dnagpu_copies_sync", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
@@ -294,7 +306,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_completion_count", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
     "dnaimport_text", "dnaimport_text_geo", "dnaadj_dist_rccl_available", "dnaadj_dist_unique_id", "dnaadj_dist_attach_rccl", "dnaadj_adjust_distributed", "dnaadj_dist_info",
-    "dnaadj_block_owner", "dnaadj_exchange_stats", "dnaadj_device_instance_context",
+    "dnaadj_block_owner", "dnaadj_exchange_stats", "dnaadj_device_instance_context", "dnaadj_device_instance_stats", "dnaadj_debug_cancel_instance",
     "dnaadj_generate_statistics", "dnaadj_get_statistics", "dnaadj_measurement_record_count", "dnaadj_measurement_records",
     "dnaadj_block_prec_adj_msrs_count", "dnaadj_block_prec_adj_msrs", "dnaadj_serialise_adjusted_variance_matrices",
     "dnaadj_deserialise_adjusted_variance_matrices", "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import DnaAdjSettings, DnaAdjStatistics, DnaSynthSpec, DnaSynthSummary, c_f64p, c_u32p
+from ._lib import DnaAdjInstanceStats, DnaAdjSettings, DnaAdjStatistics, DnaSynthSpec, DnaSynthSummary, c_f64p, c_u32p
 
 SimultaneousMode = 0
 PhasedMode = 1
@@ -157,6 +157,17 @@ class DnaAdjust:
         b, e, c = C.c_uint64(), C.c_double(), C.c_double()
         self.lib.dnaadj_exchange_stats(self.h, C.byref(b), C.byref(e), C.byref(c))
         return {"bytes": b.value, "exchange_ms": e.value, "chain_ms": c.value}
+
+    def device_instance_context(self, r):
+        """a.devices: the device context of GPU r's instance (dnagpu_profile_*)"""
+        return self.lib.dnaadj_device_instance_context(self.h, int(r))
+
+    def device_instance_stats(self, r):
+        """a.devices: what GPU r's instance did since the last ResetAdjustment (dnaadj_instance_stats as a dict)"""
+        st = DnaAdjInstanceStats()
+        if self.lib.dnaadj_device_instance_stats(self.h, int(r), C.byref(st)) != 0:
+            raise NetAdjustException("dnaadj_device_instance_stats: no such instance")
+        return {k: getattr(st, k) for k, _ in DnaAdjInstanceStats._fields_}
 
     def AdjustNetwork(self):
         st = C.c_int()

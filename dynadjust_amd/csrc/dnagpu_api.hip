@@ -381,6 +381,25 @@ long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int ti
     return (long)t.size();
 }
 
+int dnagpu_debug_set_tile_dag(int on) { return dnagpu::dag_mode_set(on ? 1 : 0); }
+
+int dnagpu_tile_dag_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* tasks) {
+    if (!ctx) return DNAGPU_EINVAL;
+    uint64_t l = 0, t = 0;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        l += ctx->ws[c].dag_launches;
+        t += ctx->ws[c].dag_tasks;
+    }
+    if (launches) *launches = l;
+    if (tasks) *tasks = t;
+    return DNAGPU_OK;
+}
+
+int dnagpu_debug_tile_dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats6) {
+    if (kind < 1 || kind > 7 || ti < 0 || tj < 0 || ti + tj < 1 || ti + tj > 64) return DNAGPU_EINVAL;
+    return dnagpu::dag_selftest(kind, ti, tj, what, seed, stats6);
+}
+
 int dnagpu_set_fused_launches(dnagpu_ctx* ctx, int on) {
     if (!ctx) return DNAGPU_EINVAL;
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {

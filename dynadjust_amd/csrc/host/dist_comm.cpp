@@ -35,6 +35,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -71,6 +72,7 @@ RcclApi& rccl() {
         a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
         a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
         a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
         a.Send = (decltype(a.Send))sym("ncclSend");
@@ -110,6 +112,10 @@ public:
     int rank() const override { return rank_; }
     int world() const override { return world_; }
     const char* transport() const override { return "rccl"; }
+    int communicator_ranks() const override {
+        int n = 0;
+        return (comm_ && rccl().CommCount && rccl().CommCount(comm_, &n) == ncclSuccess) ? n : 0;
+    }
     void group_begin() override { nccl_check(rccl().GroupStart(), "ncclGroupStart"); }
     void group_end() override { nccl_check(rccl().GroupEnd(), "ncclGroupEnd"); }
     void broadcast(double* buf, size_t count, int root) override {

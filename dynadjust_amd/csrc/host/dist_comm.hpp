@@ -31,6 +31,7 @@ public:
     virtual int rank() const = 0;
     virtual int world() const = 0;
     virtual const char* transport() const = 0;
+    virtual int communicator_ranks() const { return 0; }   // ncclCommCount of the RCCL communicator (0: not RCCL)
     // Collectives on device buffers of this rank's device.  Calls between group_begin() and group_end() are issued together
     // (one ncclGroup); all of them are complete, for the host and for every stream, when wait() returns.
     virtual void group_begin() = 0;

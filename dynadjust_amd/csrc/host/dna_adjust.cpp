@@ -1050,6 +1050,7 @@ void dna_adjust::ResetAdjustment() {
     completion_count_ = 0;
     algorithmic_flops_ = 0.0;
     cancel_.store(false);
+    cancel_agreed_ = false;
     adjustStatus_ = ADJUST_SUCCESS;
 }
 

@@ -55,8 +55,15 @@ public:
     void SerialiseAdjustedVarianceMatrices();                          // ADJ:6770 (<net>-rva.mtx)
     void UpdateBinaryFiles();                                          // ADJ:445
 
-    inline void CancelAdjustment() { cancel_.store(true); }            // dnaadjust.hpp:262
+    // dnaadjust.hpp:262.  With a.devices the other GPUs' instances of this process hear of it at once; across processes the ranks
+    // agree on it at the next phase boundary (AgreeOnPhase), so that all of them leave the iteration at the same point
+    inline void CancelAdjustment() {
+        cancel_.store(true);
+        for (const auto& p : peers_) p->cancel_.store(true);
+    }
     inline bool IsCancelled() const { return cancel_.load(); }
+    // test hook: the cancellation reaches THIS instance only, the way a signal reaches one process of a multi-process adjustment
+    inline void CancelThisRankOnly() { cancel_.store(true); }
     inline UINT32 CurrentIteration() const { return currentIteration_; }
     inline UINT32 CurrentBlock() const { return currentBlock_; }
     inline bool IsPreparing() const { return isPreparing_; }
@@ -126,6 +133,8 @@ public:
     int DistRank() const { return comm_ ? comm_->rank() : 0; }
     int DistWorld() const { return comm_ ? comm_->world() : 1; }
     const char* DistTransport() const { return comm_ ? comm_->transport() : "none"; }
+    int CommunicatorRanks() const { return comm_ ? comm_->communicator_ranks() : 0; }
+    int deviceOrdinal() const { return projectSettings_.a.device; }
     bool Distributed() const { return comm_ && (comm_->world() > 1 || force_distributed_); }
     // rank whose GPU holds block k's rigorous variances (and does its large steps); identical on every rank
     int BlockOwner(UINT32 k) const { return owner_.empty() ? 0 : owner_.at(k); }
@@ -145,6 +154,12 @@ public:
     UINT32 condenseCount() const { return (UINT32)SumOverPeers([](const dna_adjust& a) { return (double)a.condense_count_; }); }
     UINT32 completionCount() const { return (UINT32)SumOverPeers([](const dna_adjust& a) { return (double)a.completion_count_; }); }
     double algorithmicFlops() const { return SumOverPeers([](const dna_adjust& a) { return a.algorithmic_flops_; }); }
+    // this instance's own share of the above (one rank of a multi-GPU adjustment)
+    double ownAlgorithmicFlops() const { return algorithmic_flops_; }
+    double ownSolveFlops() const { return solve_flops_; }
+    UINT32 ownSolveCount() const { return solve_count_; }
+    UINT32 ownEliminationCount() const { return elimination_count_; }
+    UINT32 ownCompletionCount() const { return completion_count_; }
     // the instance that drives GPU r of a.devices (0 = this one)
     dna_adjust* DeviceInstance(int r) { return r == 0 ? this : peers_.at(r - 1).get(); }
     int DeviceInstances() const { return 1 + (int)peers_.size(); }
@@ -411,6 +426,7 @@ private:
     bool isPreparing_ = false, isAdjusting_ = false, forward_ = true, isCombining_ = false;
     bool allStationsFixed_ = false, exceptionRaised_ = false;
     std::atomic<bool> cancel_{false};
+    bool cancel_agreed_ = false;               // multi-GPU: a cancellation every rank knows of (set by AgreeOnPhase only)
     _ADJUST_STATUS_ adjustStatus_ = ADJUST_SUCCESS;
     UINT32 measurementParams_ = 0, unknownParams_ = 0, unknownsCount_ = 0;
     int degreesofFreedom_ = 0;

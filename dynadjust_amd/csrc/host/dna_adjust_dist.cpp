@@ -140,17 +140,25 @@ void dna_adjust::AgreeOnPhase(const char* phase, const std::function<void()>& bo
     } catch (...) {
         mine = std::current_exception();
     }
-    double others = 0.0;
+    double others = 0.0, cancelled = 0.0;
     try {
-        double* flag = ExchangeBuffer(1);
-        double v = mine ? 1.0 : 0.0;
-        Check(dnagpu_copy(ctx_, flag, &v, sizeof(double)), 0, "exchange");
-        comm_->all_reduce_sum(flag, 1);
+        // two words: "I failed" and "I was cancelled" -- the sums tell every rank the same thing at the same point of the schedule
+        double* flag = ExchangeBuffer(2);
+        double v[2] = {mine ? 1.0 : 0.0, IsCancelled() ? 1.0 : 0.0};
+        Check(dnagpu_copy(ctx_, flag, v, sizeof(v)), 0, "exchange");
+        comm_->all_reduce_sum(flag, 2);
         comm_->wait();
-        Check(dnagpu_copy(ctx_, &v, flag, sizeof(double)), 0, "exchange");
-        others = v - (mine ? 1.0 : 0.0);
+        Check(dnagpu_copy(ctx_, v, flag, sizeof(v)), 0, "exchange");
+        others = v[0] - (mine ? 1.0 : 0.0);
+        cancelled = v[1];
     } catch (...) {
         if (!mine) throw;
+    }
+    if (cancelled > 0.5) {
+        // CancelAdjustment() reached (at least) one rank: from here on every rank is cancelled, and -- unlike cancel_, which a signal
+        // handler may set on one rank at any moment -- cancel_agreed_ changes at agreements only, so the ranks leave the loops together
+        cancel_.store(true);
+        cancel_agreed_ = true;
     }
     if (mine) std::rethrow_exception(mine);
     if (others > 0.5) SignalExceptionAdjustment(std::string("AdjustNetwork(): the adjustment failed on another GPU (") + phase + ").", currentBlock_);
@@ -159,16 +167,24 @@ void dna_adjust::AgreeOnPhase(const char* phase, const std::function<void()>& bo
 // every condensed block travels from its owner to every rank: matrix and reduced right-hand side, in place, one group
 void dna_adjust::ExchangeCondensed() {
     const double t0 = wall_ms();
+    // everything that can fail locally (device allocations inside resize) happens and is agreed on BEFORE a collective is posted:
+    // a rank that threw between group_begin and group_end would leave the others in ncclBroadcast for good
+    struct part_t { double *F, *v; UINT32 np; int root; };
+    std::vector<part_t> parts;
+    AgreeOnPhase("exchange of the condensed blocks (preparation)", [&] {
+        for (UINT32 k = 0; k < blockCount_; ++k) {
+            block_t& B = blocks_[k];
+            if (!B.red) continue;
+            Check(dnagpu_matrix_resize(ctx_, B.red, (UINT32)B.keep.size() * 3), k, "exchange");
+            part_t q{nullptr, nullptr, 0, BlockOwner(k)};
+            dnagpu_matrix_device_pointers(B.red, &q.F, &q.v, &q.np);
+            parts.push_back(q);
+        }
+    });
     comm_->group_begin();
-    for (UINT32 k = 0; k < blockCount_; ++k) {
-        block_t& B = blocks_[k];
-        if (!B.red) continue;
-        Check(dnagpu_matrix_resize(ctx_, B.red, (UINT32)B.keep.size() * 3), k, "exchange");
-        double *F = nullptr, *v = nullptr;
-        UINT32 np = 0;
-        dnagpu_matrix_device_pointers(B.red, &F, &v, &np);
-        comm_->broadcast(F, (size_t)np * np, BlockOwner(k));
-        comm_->broadcast(v, np, BlockOwner(k));
+    for (const part_t& q : parts) {
+        comm_->broadcast(q.F, (size_t)q.np * q.np, q.root);
+        comm_->broadcast(q.v, q.np, q.root);
     }
     comm_->group_end();
     comm_->wait();
@@ -183,19 +199,24 @@ void dna_adjust::SyncCoordinates() {
     for (UINT32 k = 0; k < blockCount_; ++k) off[k + 1] = off[k] + 3 * v_parameterStationList_[k].size();
     const size_t total = off[blockCount_] + (size_t)W;
     std::vector<double> flat(total, 0.0), bx;
-    for (UINT32 k = 0; k < blockCount_; ++k)
-        if (OwnsBlock(k)) {
-            GetBlockStations(k, 2, bx);
-            std::copy(bx.begin(), bx.end(), flat.begin() + off[k]);
-        }
-    flat[off[blockCount_] + me] = maxCorr_;
-    double* dev = ExchangeBuffer(total);
-    Check(dnagpu_copy(ctx_, dev, flat.data(), total * sizeof(double)), 0, "exchange");
+    double* dev = nullptr;
+    AgreeOnPhase("coordinates (preparation)", [&] {
+        for (UINT32 k = 0; k < blockCount_; ++k)
+            if (OwnsBlock(k)) {
+                GetBlockStations(k, 2, bx);
+                std::copy(bx.begin(), bx.end(), flat.begin() + off[k]);
+            }
+        flat[off[blockCount_] + me] = maxCorr_;
+        dev = ExchangeBuffer(total);
+        Check(dnagpu_copy(ctx_, dev, flat.data(), total * sizeof(double)), 0, "exchange");
+    });
     comm_->all_reduce_sum(dev, total);
     comm_->wait();
-    Check(dnagpu_copy(ctx_, flat.data(), dev, total * sizeof(double)), 0, "exchange");
-    for (UINT32 k = 0; k < blockCount_; ++k)
-        if (!OwnsBlock(k)) SetBlockStationsAll(k, flat.data() + off[k]);
+    AgreeOnPhase("coordinates", [&] {
+        Check(dnagpu_copy(ctx_, flat.data(), dev, total * sizeof(double)), 0, "exchange");
+        for (UINT32 k = 0; k < blockCount_; ++k)
+            if (!OwnsBlock(k)) SetBlockStationsAll(k, flat.data() + off[k]);
+    });
     for (int r = 0; r < W; ++r) PhasedNoteCorrection(flat[off[blockCount_] + r]);
     exchange_ms_ += wall_ms() - t0;
 }
@@ -376,15 +397,19 @@ void dna_adjust::ReduceOwnRun() {
 
 void dna_adjust::ExchangeRuns() {
     const double t0 = wall_ms();
+    struct part_t { double *F, *v; UINT32 np; };
+    std::vector<part_t> parts(DistWorld());
+    AgreeOnPhase("exchange of the run systems (preparation)", [&] {        // (see ExchangeCondensed)
+        for (int r = 0; r < DistWorld(); ++r) {
+            segment_t& g = segs_[r];
+            Check(dnagpu_matrix_resize(ctx_, g.S, (UINT32)g.stations.size() * 3), g.a, "exchange");
+            dnagpu_matrix_device_pointers(g.S, &parts[r].F, &parts[r].v, &parts[r].np);
+        }
+    });
     comm_->group_begin();
     for (int r = 0; r < DistWorld(); ++r) {
-        segment_t& g = segs_[r];
-        Check(dnagpu_matrix_resize(ctx_, g.S, (UINT32)g.stations.size() * 3), g.a, "exchange");
-        double *F = nullptr, *v = nullptr;
-        UINT32 np = 0;
-        dnagpu_matrix_device_pointers(g.S, &F, &v, &np);
-        comm_->broadcast(F, (size_t)np * np, r);
-        comm_->broadcast(v, np, r);
+        comm_->broadcast(parts[r].F, (size_t)parts[r].np * parts[r].np, r);
+        comm_->broadcast(parts[r].v, parts[r].np, r);
     }
     comm_->group_end();
     comm_->wait();
@@ -453,7 +478,7 @@ void dna_adjust::DistributedCondensedIteration() {
     for (UINT32 k = 0; k < blockCount_; ++k)
         if (OwnsBlock(k)) mine.push_back(k);
     AgreeOnPhase("condensing the blocks", [&] { CondenseBlocks(mine); });
-    if (IsCancelled()) return;
+    if (cancel_agreed_) return;
     if (two_level_ok_) {
         // DNAGPU_LOCAL_EXCLUSIVE=1 (measurement aid for ranks that share one GPU, tools/gpu_chain_phase.py): the chain work of the
         // ranks of this process runs one rank at a time and is timed inside the lock -- what a rank with a GPU of its own would spend
@@ -475,7 +500,7 @@ void dna_adjust::DistributedCondensedIteration() {
                 OwnRunChains();
             });
         });
-        if (IsCancelled()) return;
+        if (cancel_agreed_) return;
         AgreeOnPhase("rigorous block solutions", [&] { RigorousBlocks(mine); });
         return;
     }
@@ -483,7 +508,7 @@ void dna_adjust::DistributedCondensedIteration() {
     const double t0 = wall_ms();
     AgreeOnPhase("junction chains", [&] { CondensedChains(); });
     chain_ms_ += wall_ms() - t0;
-    if (IsCancelled()) return;
+    if (cancel_agreed_) return;
     AgreeOnPhase("rigorous block solutions", [&] { RigorousBlocks(mine); });
 }
 
@@ -521,7 +546,7 @@ void dna_adjust::DistributedReferenceIteration() {
             }
         }
     });
-    if (IsCancelled()) return;
+    if (cancel_agreed_) return;
     // the junction payloads of the combination solves: jfwd[k-1] from the forward rank, jrev[k] from the reverse rank
     const double t0 = wall_ms();
     std::vector<junction_msg> msgs;
@@ -531,21 +556,27 @@ void dna_adjust::DistributedReferenceIteration() {
         if (fwd_rank != o) msgs.push_back({0, k - 1, fwd_rank, o});
         if (rev_rank != o) msgs.push_back({1, k, rev_rank, o});
     }
+    struct xfer_t { double *F, *v; UINT32 np; int peer; bool send; };
+    std::vector<xfer_t> xfers;
+    AgreeOnPhase("exchange of the junction matrices (preparation)", [&] {       // (see ExchangeCondensed)
+        for (const junction_msg& g : msgs) {
+            if (g.src != me && g.dst != me) continue;
+            dnagpu_matrix* jm = g.kind == 0 ? blocks_[g.block].jfwd : blocks_[g.block].jrev;
+            if (!jm) continue;
+            if (g.dst == me) Check(dnagpu_matrix_resize(ctx_, jm, JunctionUnknowns(g.block)), g.block, "exchange");
+            xfer_t x{nullptr, nullptr, 0, g.src == me ? g.dst : g.src, g.src == me};
+            dnagpu_matrix_device_pointers(jm, &x.F, &x.v, &x.np);
+            xfers.push_back(x);
+        }
+    });
     comm_->group_begin();
-    for (const junction_msg& g : msgs) {
-        if (g.src != me && g.dst != me) continue;
-        dnagpu_matrix* jm = g.kind == 0 ? blocks_[g.block].jfwd : blocks_[g.block].jrev;
-        if (!jm) continue;
-        if (g.dst == me) Check(dnagpu_matrix_resize(ctx_, jm, JunctionUnknowns(g.block)), g.block, "exchange");
-        double *F = nullptr, *v = nullptr;
-        UINT32 np = 0;
-        dnagpu_matrix_device_pointers(jm, &F, &v, &np);
-        if (g.src == me) {
-            comm_->send(F, (size_t)np * np, g.dst);
-            comm_->send(v, np, g.dst);
+    for (const xfer_t& x : xfers) {
+        if (x.send) {
+            comm_->send(x.F, (size_t)x.np * x.np, x.peer);
+            comm_->send(x.v, x.np, x.peer);
         } else {
-            comm_->recv(F, (size_t)np * np, g.src);
-            comm_->recv(v, np, g.src);
+            comm_->recv(x.F, (size_t)x.np * x.np, x.peer);
+            comm_->recv(x.v, x.np, x.peer);
         }
     }
     comm_->group_end();
@@ -567,17 +598,21 @@ void dna_adjust::DistributedReferenceIteration() {
 // AdjustPhased (ADJ:2579-2670) across the ranks
 void dna_adjust::AdjustPhasedDistributed() {
     currentIteration_ = 0;
+    cancel_agreed_ = false;
     for (UINT32 i = 0; i < projectSettings_.a.max_iterations; ++i) {
-        if (IsCancelled()) break;
+        // CancelAdjustment() may have reached one rank only (its own process, its own signal): the ranks agree before anyone leaves
+        AgreeOnPhase("start of the iteration", [] {});
+        if (cancel_agreed_) break;
         const double it_t0 = wall_ms();
         PhasedBeginIteration();
         if (CondensedSchedule())
             DistributedCondensedIteration();
         else
             DistributedReferenceIteration();
-        if (IsCancelled()) break;
+        if (cancel_agreed_) break;
         Check(dnagpu_sync(ctx_), 0, "AdjustNetwork()");
         SyncCoordinates();
+        if (cancel_agreed_) break;
         NoteIterationDone(it_t0);
         if (!PhasedEndIteration()) break;
     }
@@ -599,11 +634,14 @@ void dna_adjust::GenerateStatisticsDistributed() {
     host[0] = chiSquared_;
     host[1] = (double)potentialOutlierCount_;
     GetRecordStatistics(host.data() + 2);
-    double* dev = ExchangeBuffer(host.size());
-    Check(dnagpu_copy(ctx_, dev, host.data(), host.size() * sizeof(double)), 0, "exchange");
+    double* dev = nullptr;
+    AgreeOnPhase("statistics (preparation)", [&] {          // (see ExchangeCondensed)
+        dev = ExchangeBuffer(host.size());
+        Check(dnagpu_copy(ctx_, dev, host.data(), host.size() * sizeof(double)), 0, "exchange");
+    });
     comm_->all_reduce_sum(dev, host.size());
     comm_->wait();
-    Check(dnagpu_copy(ctx_, host.data(), dev, host.size() * sizeof(double)), 0, "exchange");
+    AgreeOnPhase("statistics (collection)", [&] { Check(dnagpu_copy(ctx_, host.data(), dev, host.size() * sizeof(double)), 0, "exchange"); });
     SetPartials(host[0], (UINT32)std::llround(host[1]));
     SetRecordStatistics(host.data() + 2);
     StatisticsFinish();
@@ -624,15 +662,23 @@ void dna_adjust::CollectBlockResults(UINT32 b, std::vector<double>& packed, std:
         }
         return;
     }
+    // the two ranks involved prepare (the device buffer, the owner's copy of the matrix out of HBM or the staging area); every rank
+    // takes part in the agreement, so that a failure there leaves nobody in ncclSend / ncclRecv
+    double* dev = nullptr;
+    std::vector<double> tail(rows + 1, 0.0);
+    AgreeOnPhase("collecting the block results (preparation)", [&] {
+        if (me != 0 && me != o) return;
+        dev = ExchangeBuffer(cnt + rows + 1);
+        if (me == o) {
+            GetBlockRigorousVariancesPacked(b, packed);
+            tail[0] = blocks_[b].prec_adj_msrs.size() == rows ? 1.0 : 0.0;
+            if (tail[0] > 0.5) std::copy(blocks_[b].prec_adj_msrs.begin(), blocks_[b].prec_adj_msrs.end(), tail.begin() + 1);
+            Check(dnagpu_copy(ctx_, dev, packed.data(), cnt * sizeof(double)), b, "exchange");
+            Check(dnagpu_copy(ctx_, dev + cnt, tail.data(), tail.size() * sizeof(double)), b, "exchange");
+        }
+    });
     if (me != 0 && me != o) return;
-    double* dev = ExchangeBuffer(cnt + rows + 1);
     if (me == o) {
-        GetBlockRigorousVariancesPacked(b, packed);
-        std::vector<double> tail(rows + 1, 0.0);
-        tail[0] = blocks_[b].prec_adj_msrs.size() == rows ? 1.0 : 0.0;
-        if (tail[0] > 0.5) std::copy(blocks_[b].prec_adj_msrs.begin(), blocks_[b].prec_adj_msrs.end(), tail.begin() + 1);
-        Check(dnagpu_copy(ctx_, dev, packed.data(), cnt * sizeof(double)), b, "exchange");
-        Check(dnagpu_copy(ctx_, dev + cnt, tail.data(), tail.size() * sizeof(double)), b, "exchange");
         comm_->send(dev, cnt + rows + 1, 0);
         comm_->wait();
         packed.clear();
@@ -640,7 +686,6 @@ void dna_adjust::CollectBlockResults(UINT32 b, std::vector<double>& packed, std:
         comm_->recv(dev, cnt + rows + 1, o);
         comm_->wait();
         packed.resize(cnt);
-        std::vector<double> tail(rows + 1);
         Check(dnagpu_copy(ctx_, packed.data(), dev, cnt * sizeof(double)), b, "exchange");
         Check(dnagpu_copy(ctx_, tail.data(), dev + cnt, tail.size() * sizeof(double)), b, "exchange");
         if (tail[0] > 0.5) prec.assign(tail.begin() + 1, tail.end());

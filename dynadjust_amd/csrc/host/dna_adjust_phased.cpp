@@ -810,7 +810,9 @@ void dna_adjust::PhasedBeginIteration() {
 
 bool dna_adjust::PhasedEndIteration() {
     iterationCorrections_.push_back(maxCorr_);
-    bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
+    // (across GPUs only a cancellation every rank has agreed on ends the loop: the next collective needs all of them)
+    const bool cancelled = Distributed() ? cancel_agreed_ : IsCancelled();
+    bool iterate = !cancelled && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
     if (iterate && currentIteration_ >= projectSettings_.a.max_iterations) iterate = false;
     if (iterate) UpdateAdjustment(true);
     return iterate;

@@ -194,6 +194,29 @@ void* dnaadj_device_instance_context(dnaadj_handle* h, int r) {
     return h->adj->DeviceInstance(r)->deviceContext();
 }
 
+int dnaadj_debug_cancel_instance(dnaadj_handle* h, int r) {
+    if (!h || !h->adj || r < 0 || r >= h->adj->DeviceInstances()) return DNAADJ_EINVAL;
+    h->adj->DeviceInstance(r)->CancelThisRankOnly();
+    return DNAADJ_OK;
+}
+
+int dnaadj_device_instance_stats(dnaadj_handle* h, int r, dnaadj_instance_stats* out) {
+    if (!h || !h->adj || !out || r < 0 || r >= h->adj->DeviceInstances()) return DNAADJ_EINVAL;
+    dna_adjust* a = h->adj->DeviceInstance(r);
+    out->rank = a->DistRank();
+    out->device = a->deviceOrdinal();
+    out->algorithmic_flops = a->ownAlgorithmicFlops();
+    out->solve_flops = a->ownSolveFlops();
+    out->solves = a->ownSolveCount();
+    out->eliminations = a->ownEliminationCount();
+    out->completions = a->ownCompletionCount();
+    out->exchanged_bytes = a->ExchangedBytes();
+    out->exchange_ms = a->ExchangeMs();
+    out->chain_ms = a->ChainPhaseMs();
+    out->rccl_ranks = a->CommunicatorRanks();
+    return DNAADJ_OK;
+}
+
 int dnaadj_reset(dnaadj_handle* h) {
     return guarded(h, [&] { h->adj->ResetAdjustment(); });
 }

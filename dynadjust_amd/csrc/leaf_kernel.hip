@@ -17,295 +17,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "la_kernels.h"
+#include "leaf_body.h"
 
 namespace dnagpu {
-
-// tools/leaf_probe.hip compiles this file with -DDNAGPU_LEAF_PROBE: thread 0 leaves the shader clock at the phase boundaries
-#ifdef DNAGPU_LEAF_PROBE
-__device__ unsigned long long leaf_probe[64];
-#define LEAF_PROBE(i) do { if (threadIdx.x == 0) leaf_probe[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define LEAF_PROBE(i) do { } while (0)
-#endif
-
-namespace {
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-
-// acc += sign * A * B for 16x16 operands in LDS: A(i,k) = a[i*ars + k*acs], B(k,j) = b[k*brs + j*bcs].
-// v_mfma_f64_16x16x4_f64: lane l feeds A(l&15, l>>4) and B(l>>4, l&15); acc[r] = D((l>>4) + 4r, l&15).
-__device__ __forceinline__ d4 mma16(const double* a, int ars, int acs, const double* b, int brs, int bcs, d4 acc, double sign, int lane) {
-    const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int k = 4 * kk + hi;
-        double av = sign * a[lo * ars + k * acs];
-        double bv = b[k * brs + lo * bcs];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// The tile lives in LDS as its 36 lower 16x16 blocks (block (bi, bj), bi >= bj, at (bi (bi + 1) / 2 + bj) * BS, rows BR apart):
-// 76.5 KiB instead of 149 KiB for the square tile + separate diagonal inverses, so that a leaf can share a CU with one workgroup
-// of the tile GEMM (72 KiB).  Measured: same duration alone, and the same step time with four chains in flight (the GPU is busy
-// with GEMMs 99 % of the wall time either way) -- kept for the footprint.
-constexpr int BR = 17;        // row stride inside a block (odd: conflict-free column reads)
-constexpr int BS = 16 * BR;   // doubles per block
-__device__ __forceinline__ double* blk(double* S, int bi, int bj) { return S + (bi * (bi + 1) / 2 + bj) * BS; }
-
-__device__ __forceinline__ d4 tile_load(const double* B, int lane) {
-    const int lo = lane & 15, hi = lane >> 4;
-    d4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = B[(hi + 4 * r) * BR + lo];
-    return v;
-}
-
-__device__ __forceinline__ void tile_store(double* B, int lane, d4 v) {
-    const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) B[(hi + 4 * r) * BR + lo] = v[r];
-}
-}  // namespace
 
 __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
                                                                int ldx, int o, int* info) {
     // LT: the factor of the current diagonal block, transposed (wave 0 only) -- first, so that its constant addresses fit the
     // 16-bit offset field of the ds instructions (behind S they took a register each)
-    __shared__ double SH[256 + 36 * BS];
-    double* const LT = SH;
+    __shared__ double SH[256 + 36 * leaf::BS];
     double* const S = SH + 256;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches instead of exec masks)
-    const int row = tid & 127;
-    const int q = tid >> 7;  // 0..3
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-
-    LEAF_PROBE(0);
-    // all 32 loads of a thread are in flight together (a rolled loop would pay the memory latency 32 times: 20 us of a 68 us leaf)
-    {
-        double v[32];
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const int c = q + 4 * t;
-            v[t] = (row >= c) ? A[(size_t)(o + c) * lda + o + row] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const int c = q + 4 * t;
-            if ((row >> 4) >= (c >> 4)) blk(S, row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] = v[t];
-        }
-    }
-    __syncthreads();
-    LEAF_PROBE(1);
-
-    // ------------------------------- phase A: Cholesky -------------------------------
-    // diagonal block kb: factored by wave 0 in registers; what stays in LDS is its INVERSE D^-1 (the factor itself is not
-    // needed again: the panel below it is solved with D^-T, the trailing update uses the panel, X's diagonal block is D^-1)
-#pragma unroll 1
-    for (int kb = 0; kb < 8; ++kb) {
-        const int p0 = 16 * kb;
-        double* xd = blk(S, kb, kb);
-        if (wave == 0) {
-            const int i = lane & 15;
-            const bool is_d = lane < 16;
-            int bad = 16;
-            // Right-looking, one column per step.  The pivot chain (pivot -> rsqrt -> scaled column -> next pivot) only needs the
-            // updates of the next two columns at once: those two multipliers come by v_readlane; the others travel through LDS
-            // (column k written by its lanes, read back as broadcasts) and are applied one step later, after the next pivot's
-            // Newton iterations.  Every element still receives its updates in ascending k: same bits as one column at a time.
-            // The same multipliers drive the forward substitution D X = I (lane j solves column j:
-            // x_i = (delta_ij - sum_{k<i} L_ik x_k) / L_ii) in the same steps -- as v_readlane values in a loop of its own they
-            // were kept in 240 SGPRs and spilled: the diagonal blocks were 57 % of the leaf.
-            // Factor and substitution share their instructions: u[] is row i of the block in lanes 0..15 and column i of X in
-            // the other lanes (three copies), and both obey u[j] -= L(j,k) u[k], u[k] *= 1 / L(k,k).
-            double u[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) u[j] = is_d ? xd[i * BR + j] : (j == i ? 1.0 : 0.0);
-            double lp[16];                      // column k - 1 of L, rows k + 2 .. 15 (in flight during step k)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                double pk = readlane_f64(u[k], k);
-                if (!(pk > 0.0)) {          // (uniform: a scalar select; reported once per block, below)
-                    bad = bad < k ? bad : k;
-                    pk = 1.0;
-                }
-                // y = pk^-1/2 (v_rsq_f64 + 2 Newton steps).  The diagonal element L(k,k) itself is never needed: the panel below
-                // is solved with D^-1, and every later step reads the column's rows below k only
-                double y = __builtin_amdgcn_rsq(pk);
-                const double h = 0.5 * pk;
-                y = y * fma(-h * y, y, 1.5);
-                y = y * fma(-h * y, y, 1.5);
-                __builtin_amdgcn_sched_barrier(0);   // (a late update hoisted above the Newton steps would wait for LDS there)
-                // the late updates of column k - 1 (rows k + 2 ..; rows k, k + 1 were done in step k - 1)
-                if (k > 0) {
-#pragma unroll
-                    for (int j = k + 2; j < 16; ++j) {
-                        u[j] = fma(-lp[j], u[k - 1], u[j]);
-                        asm volatile("" : "+v"(u[j]));                   // (here, not sunk to the store below with lp[] kept alive)
-                    }
-                }
-                u[k] *= y;
-                if (is_d) LT[k * 16 + i] = u[k];                         // LT(k, i) = L(i, k)
-#pragma unroll
-                for (int j = k + 1; j < 16 && j <= k + 2; ++j) {
-                    double ljk = readlane_f64(u[k], j);
-                    u[j] = fma(-ljk, u[k], u[j]);
-                    asm volatile("" : "+v"(u[j]));
-                }
-                asm volatile("" ::: "memory");                           // (LDS is in order within a wave: no wait needed)
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int j = k + 3; j < 16; ++j) lp[j] = LT[k * 16 + j];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (bad < 16 && lane == 0) atomicMin(info, o + p0 + bad + 1);
-            if (!is_d) {
-#pragma unroll
-                for (int ii = 0; ii < 16; ++ii) xd[ii * BR + i] = u[ii];  // X(ii, i); zero above the diagonal
-            }
-        }
-        LEAF_PROBE(2 + 3 * kb);
-        __syncthreads();
-        // panel slabs below the diagonal block: P = A_panel * D^-T, one slab per wave
-        if (wave < 7 - kb) {
-            double* P = blk(S, kb + 1 + wave, kb);
-            d4 acc = mma16(P, BR, 1, xd, 1, BR, zero, 1.0, lane);
-            tile_store(P, lane, acc);
-        }
-        __syncthreads();
-        LEAF_PROBE(3 + 3 * kb);
-        // trailing update: tiles (ti, tj), kb < tj <= ti, dealt round-robin to the waves; a wave has the operands of its next
-        // tile on their way from LDS while the MFMAs of the current one run
-        {
-            const int nt = 7 - kb;  // tile rows below the panel
-            const int T = nt * (nt + 1) / 2;
-            const int lo = lane & 15, hi = lane >> 4;
-            auto fetch = [&](int t, d4& c, double (&a)[4], double (&b)[4], double*& C) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
-                C = blk(S, kb + 1 + ti, kb + 1 + tj);
-                c = tile_load(C, lane);
-                const double* A = blk(S, kb + 1 + ti, kb);
-                const double* B = blk(S, kb + 1 + tj, kb);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    a[kk] = A[lo * BR + 4 * kk + hi];
-                    b[kk] = B[lo * BR + 4 * kk + hi];
-                }
-            };
-            int t = wave;
-            d4 c = zero;
-            double av[4], bv[4];
-            double* C = nullptr;
-            if (t < T) fetch(t, c, av, bv, C);
-            while (t < T) {
-                const int tn = t + 8;
-                d4 cn = zero;
-                double an[4] = {0.0, 0.0, 0.0, 0.0}, bn[4] = {0.0, 0.0, 0.0, 0.0};
-                double* Cn = nullptr;
-                if (tn < T) fetch(tn, cn, an, bn, Cn);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk], c, 0, 0, 0);
-                tile_store(C, lane, c);
-                c = cn;
-                C = Cn;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    av[kk] = an[kk];
-                    bv[kk] = bn[kk];
-                }
-                t = tn;
-            }
-        }
-        __syncthreads();
-        LEAF_PROBE(4 + 3 * kb);
-    }
-
-    // ------------------------------- phase B: X = L^-1 -------------------------------
-#pragma unroll 1
-    for (int kb = 0; kb < 8; ++kb) {
-        const double* xd = blk(S, kb, kb);
-        // row block kb, columns left of the panel: M_k <- D^-1 * M_k (the diagonal block already is D^-1)
-        for (int tj = wave; tj < kb; tj += 8) {
-            double* M = blk(S, kb, tj);
-            d4 acc = mma16(xd, BR, 1, M, BR, 1, zero, 1.0, lane);
-            tile_store(M, lane, acc);
-        }
-        __syncthreads();
-        // tiles below and left of the panel: M(i, tj) -= L(i,kb) M_k(tj), (7 - kb) kb of them, dealt round-robin to the waves
-        // (a slab per wave left one wave with 7 tiles in a row at kb = 6), the next tile's operands in flight during the MFMAs
-        {
-            const int lo = lane & 15, hi = lane >> 4;
-            const int T = (7 - kb) * kb;
-            auto fetch = [&](int t, d4& c, double (&a)[4], double (&b)[4], double*& C) {
-                const int bi = kb + 1 + t / kb, tj = t % kb;
-                C = blk(S, bi, tj);
-                c = tile_load(C, lane);
-                const double* Lk = blk(S, bi, kb);
-                const double* Mk = blk(S, kb, tj);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    a[kk] = Lk[lo * BR + 4 * kk + hi];
-                    b[kk] = Mk[(4 * kk + hi) * BR + lo];
-                }
-            };
-            int t = wave;
-            d4 c = zero;
-            double av[4], bv[4];
-            double* C = nullptr;
-            if (t < T) fetch(t, c, av, bv, C);
-            while (t < T) {
-                const int tn = t + 8;
-                d4 cn = zero;
-                double an[4] = {0.0, 0.0, 0.0, 0.0}, bn[4] = {0.0, 0.0, 0.0, 0.0};
-                double* Cn = nullptr;
-                if (tn < T) fetch(tn, cn, an, bn, Cn);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk], c, 0, 0, 0);
-                tile_store(C, lane, c);
-                c = cn;
-                C = Cn;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    av[kk] = an[kk];
-                    bv[kk] = bn[kk];
-                }
-                t = tn;
-            }
-        }
-        __syncthreads();
-        // the panel's own column: M(i,kb) = -L(i,kb) D^-1 over L(i,kb), one tile per wave, after every reader of L(i,kb)
-        if (wave < 7 - kb) {
-            const int lo = lane & 15, hi = lane >> 4;
-            double* Lk = blk(S, kb + 1 + wave, kb);
-            double lf[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lf[kk] = Lk[lo * BR + 4 * kk + hi];
-            d4 acc = zero;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], xd[(4 * kk + hi) * BR + lo], acc, 0, 0, 0);
-            tile_store(Lk, lane, acc);
-        }
-        __syncthreads();
-        LEAF_PROBE(26 + kb);
-    }
-
-#pragma unroll 8
-    for (int c = q; c < 128; c += 4) {
-        double v = (row >= c) ? blk(S, row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] : 0.0;
-        X[(size_t)(o + c) * ldx + o + row] = v;
-    }
-    LEAF_PROBE(34);
+    leaf::potrf_trtri_tile<8>(A + (size_t)o * lda + o, lda, X + (size_t)o * ldx + o, ldx, o, info, SH, [S](int bi, int bj) { return S + (bi * (bi + 1) / 2 + bj) * leaf::BS; });
 }
 
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s) {

@@ -58,6 +58,11 @@ struct InvWorkspace {
     unsigned long long* sync_ctr = nullptr;
     unsigned long long sync_base = 0;
     uint64_t fused_launches = 0, fused_ops = 0;
+    // tile-DAG path (tile_dag.h): a whole driver call below as one launch
+    bool dag = true;               // dnagpu_set_tile_dag / DNAGPU_DAG=0 switch back to one launch per product
+    uint32_t* dag_state = nullptr;   // this chain's copy of a graph's state words (queues, predecessor counters), restored per launch
+    size_t dag_state_cap = 0;
+    uint64_t dag_launches = 0, dag_tasks = 0;
 };
 
 // sends the waiting small products out as one launch (called before anything else is enqueued on ws.stream)
@@ -113,6 +118,12 @@ std::vector<std::pair<int, int>> sym_spine_blocks(int ti);      // (first tile, 
 void gemm_profile_collect(InvWorkspace& ws);
 void gemm_profile_close(InvWorkspace& ws);   // ends the current run of gemm launches (call before enqueuing any other kernel)
 void gemm_profile_reset(InvWorkspace& ws);
+
+// process-wide switch of the tile-DAG path (DNAGPU_DAG, default 1); returns the old value
+int dag_mode_set(int on);
+// CPU self-test of the tile DAG's dependency analysis (sym_inverse.hip): 0 = every admissible order reproduces the recorded order's bits
+int dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats6);
+double schur_split();
 
 // DNAGPU_FAULT_INJECT=<n>: the n-th tile-table allocation of the process fails with hipErrorOutOfMemory (tests/test_gpu_matrix.py:
 // a failed allocation in the middle of an inverse must surface as DNAGPU_ENOMEM, never as a silently skipped launch)

@@ -1,9 +1,12 @@
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
+#include <cstring>
 #include <cstdio>
 #include "sym_inverse.h"
 #include "la_kernels.h"
+#include "tile_dag.h"
 #include <algorithm>
 #include <cstdlib>
 #include <atomic>
@@ -28,6 +31,7 @@ hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t st
 }
 
 void inv_workspace_free(InvWorkspace& ws) {
+    if (ws.dag_state) hipFree(ws.dag_state);
     if (ws.X) hipFree(ws.X);
     if (ws.W) hipFree(ws.W);
     if (ws.svec) hipFree(ws.svec);
@@ -332,13 +336,16 @@ struct Rec {
     double* X; int ldx;
     double* P; int ldp;
     bool dry;  // planning pass: only build the tile-order tables, launch nothing
+    DagBuilder* rec = nullptr;   // recording pass (tile_dag.h): F / X / P are the builder's symbolic buffers, nothing is launched
 
     double* f(int rt, int ct) { return F + (size_t)ct * 128 * ld + (size_t)rt * 128; }
     double* x(int rt, int ct) { return X + (size_t)ct * 128 * ldx + (size_t)rt * 128; }
     double* w(int rt, int ct) { return P + (size_t)ct * 128 * ldp + (size_t)rt * 128; }
 
     void gemm(InvWorkspace& w_, GemmArgs a, int akc, int bkc) {
-        if (dry)
+        if (rec)
+            rec->add_gemm(a, akc, bkc);
+        else if (dry)
             gemm_attach_order(w_, a);
         else
             dnagpu::gemm(w_, a, akc, bkc);
@@ -364,7 +371,9 @@ struct Rec {
     // Cholesky factor and its inverse of the s x s tile block at o: F keeps T21 = L21 L11^-1 below the diagonal, X = L^-1
     void node(int o, int s) {
         if (s == 1) {
-            if (!dry && ws.err == hipSuccess) {
+            if (rec) {
+                rec->add_leaf(f(o, o), x(o, o), o);
+            } else if (!dry && ws.err == hipSuccess) {
                 gemm_profile_close(ws);
                 launch_leaf(F, ld, X, ldx, o * 128, ws.info, ws.stream);
                 inv_note_error(ws, hipGetLastError(), "leaf launch");
@@ -475,34 +484,183 @@ struct Rec {
 
 }  // namespace
 
+// ---- the tile-DAG path (tile_dag.h): the op sequence of a driver below recorded once per shape, then one launch per call ----
+namespace {
+
+struct DagCache {
+    std::mutex m;
+    std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, long>, std::shared_ptr<DagGraph>> graphs;
+};
+DagCache& dag_cache() {
+    static DagCache* c = new DagCache();     // (never destroyed: device memory must not be freed after the runtime has gone)
+    return *c;
+}
+
+std::atomic<int> g_dag_mode{[] {
+    const char* e = getenv("DNAGPU_DAG");
+    return e ? atoi(e) : 1;
+}()};
+std::atomic<int> g_dag_min_tiles{[] {
+    const char* e = getenv("DNAGPU_DAG_MIN_TILES");
+    return e ? atoi(e) : 2;
+}()};
+// workgroups the diagnostic simulation assumes in flight
+const int g_dag_workers = getenv("DNAGPU_DAG_WORKERS") ? atoi(getenv("DNAGPU_DAG_WORKERS")) : 512;
+
+std::atomic<int> g_dag_trace_serial{0};
+
+enum DagKind { DK_INVERSE = 1, DK_SCHUR = 2, DK_SCHUR_KEEP = 3, DK_COMPLETE = 4, DK_SPINE = 5, DK_SPINE_KEPT = 6, DK_SPINE_FINISH = 7 };
+
+template <class Ops>
+std::shared_ptr<DagGraph> dag_record(InvWorkspace& ws, int ld, int ldx, int ldp, int ldwk, Ops&& ops) {
+    const int lds[DAG_MAX_BUFS] = {ld, ldx, ldp, ldwk > 0 ? ldwk : 128};
+    DagBuilder b(DAG_MAX_BUFS, lds, g_small_tiles.load());
+    Rec rec{ws, b.base(0), ld, b.base(1), ldx, b.base(2), ldp, false, &b};
+    ops(rec, (const double*)b.base(3));
+    return b.finish(g_dag_workers);
+}
+
+// true: the call went out (or was dropped after a latched error) as one DAG launch; false: the caller launches product by product
+template <class Ops>
+bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, int ld, double* X, int ldx, double* P, int ldp, const double* WK,
+             int ldwk, Ops&& ops) {
+    if (!ws.dag || !g_dag_mode.load() || ws.dist_world > 1 || ti + tj < g_dag_min_tiles.load()) return false;
+    if (ws.err != hipSuccess) return true;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_tuple(dev, kind, ti, tj, what, ld, ldx, ldp, ldwk, (int)(schur_split() * 1000.0 + 0.5), 0, g_small_tiles.load());
+    std::shared_ptr<DagGraph> g;
+    {
+        DagCache& c = dag_cache();
+        std::lock_guard<std::mutex> lock(c.m);
+        auto it = c.graphs.find(key);
+        if (it == c.graphs.end()) {
+            g = dag_record(ws, ld, ldx, ldp, ldwk, ops);
+            hipError_t e = dag_upload(*g);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                inv_note_error(ws, e, "tile DAG upload");
+                return true;
+            }
+            static const bool verbose = getenv("DNAGPU_DAG_VERBOSE") != nullptr;
+            if (verbose)
+                fprintf(stderr, "dnagpu: tile DAG kind %d ti %d tj %d: %zu tasks (%u products, %u leaves), %zu successor runs, work %.1f ms / 512 = %.2f ms, "
+                        "critical path %.2f ms, simulated %.2f ms\n", kind, ti, tj, g->tasks.size(), g->n_products, g->n_leaves, g->succ.size(),
+                        g->sim_work_us / 1e3, g->sim_work_us / 512e3, g->critical_path_us / 1e3, g->sim_makespan_us / 1e3);
+            c.graphs.emplace(key, g);
+        } else {
+            g = it->second;
+        }
+    }
+    if (g->tasks.empty()) return true;
+    // (error-path tests, dnagpu_debug_fail_allocation: the per-product path allocates a tile-order table per launch shape; this path
+    //  allocates per graph and per workspace only, so the countdown also runs over its launches)
+    if (g_fault_countdown.load() > 0 && g_fault_countdown.fetch_sub(1) == 1) {
+        inv_note_error(ws, hipErrorOutOfMemory, "tile DAG allocation");
+        return true;
+    }
+    // this chain's copy of the graph's state (queue heads / tails, predecessor counters, queue slots), restored before every launch
+    const size_t words = g->state_init.size();
+    if (ws.dag_state_cap < words) {
+        hipStreamSynchronize(ws.stream);
+        if (ws.dag_state) hipFree(ws.dag_state);
+        ws.dag_state = nullptr;
+        ws.dag_state_cap = 0;
+        const size_t want = std::max<size_t>(words * 2, (size_t)1 << 20);
+        hipError_t e = hipMalloc(&ws.dag_state, want * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            inv_note_error(ws, e, "tile DAG state allocation");
+            return true;
+        }
+        ws.dag_state_cap = want;
+    }
+    gemm_flush(ws);
+    GemmProfile& p = ws.prof;
+    if (p.enabled) {
+        if (!p.open) {
+            profile_event(p, ws.stream);
+            p.open = true;
+        }
+        p.flops += g->flops;
+        p.launches++;
+    }
+    inv_note_error(ws, hipMemcpyAsync(ws.dag_state, g->d_state_init, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ws.stream), "tile DAG state");
+    DagLaunch L;
+    L.tasks = g->d_tasks;
+    L.succ = g->d_succ;
+    L.id2task = g->d_id2task;
+    L.state = ws.dag_state;
+    L.ntasks = (uint32_t)g->tasks.size();
+    L.state_pending = g->state_pending;
+    L.state_slots = g->state_slots;
+    L.state_mail = g->state_mail;
+    for (int q = 0; q <= DAG_QUEUES; ++q) L.slot_base[q] = g->slot_base[q];
+    L.buf0 = F; L.buf1 = X; L.buf2 = P; L.buf3 = const_cast<double*>(WK);
+    L.ld0 = ld; L.ld1 = ldx; L.ld2 = ldp; L.ld3 = ldwk > 0 ? ldwk : 128;
+    L.info = ws.info;
+    // DNAGPU_DAG_TRACE=<prefix>: per-task clocks of every launch, written to <prefix>.<launch>.bin (tools/dag_trace_report.py); diagnostic, synchronous
+    static const char* trace_prefix = getenv("DNAGPU_DAG_TRACE");
+    L.trace = nullptr;
+    if (trace_prefix && hipMalloc(&L.trace, (size_t)L.ntasks * 4 * sizeof(unsigned long long)) == hipSuccess)
+        hipMemsetAsync(L.trace, 0, (size_t)L.ntasks * 4 * sizeof(unsigned long long), ws.stream);
+    launch_tile_dag(L, ws.stream);
+    inv_note_error(ws, hipGetLastError(), "tile DAG launch");
+    if (L.trace) {
+        hipStreamSynchronize(ws.stream);
+        std::vector<unsigned long long> tr((size_t)L.ntasks * 4);
+        hipMemcpy(tr.data(), L.trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        hipFree(L.trace);
+        char name[512];
+        snprintf(name, sizeof(name), "%s.%04d.bin", trace_prefix, g_dag_trace_serial.fetch_add(1));
+        if (FILE* f = fopen(name, "wb")) {
+            const uint64_t hdr[8] = {L.ntasks, (uint64_t)kind, (uint64_t)ti, (uint64_t)tj, (uint64_t)what, sizeof(DagTask), 0, 0};
+            fwrite(hdr, sizeof(hdr), 1, f);
+            fwrite(tr.data(), sizeof(unsigned long long), tr.size(), f);
+            fwrite(g->tasks.data(), sizeof(DagTask), g->tasks.size(), f);
+            fclose(f);
+        }
+    }
+    ws.dag_launches++;
+    ws.dag_tasks += L.ntasks;
+    return true;
+}
+
+// the per-product path: planning pass (tile-order tables) on first use of the shape, then the launches
+template <class Ops>
+void run_products(InvWorkspace& ws, int key, double* F, int ld, double* X, int ldx, double* P, int ldp, const double* WK, Ops&& ops) {
+    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
+        Rec rec{ws, F, ld, X, ldx, P, ldp, pass == 0};
+        ops(rec, WK);
+        if (ws.err != hipSuccess) return;
+    }
+    ws.planned.insert(key);
+}
+
+}  // namespace
+
+int dag_mode_set(int on) { return g_dag_mode.exchange(on); }
+
 void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity, bool reset_info) {
     if (reset_info) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
     if (scale_to_unity) {
         launch_diag_rsqrt(F, ws.svec, n, np, ws.stream);
         launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
     }
-    int T = (int)(np / 128);
-    if (!ws.planned.count(T)) {
-        // first inverse of this order: build every tile-order table before the first launch
-        // so that the blocking table uploads never sit between kernels
-        Rec plan{ws, F, (int)np, ws.X, (int)np, ws.W, (int)np, true};
-        plan.node(0, T);
-        GemmArgs l;
-        l.mt = T; l.nt = T; l.K = (int)np; l.kmode = KM_GE_I; l.lower = 1;
-        gemm_attach_order(ws, l);
-        if (ws.err != hipSuccess) return;      // (not marked as planned: the next call plans again)
-        ws.planned.insert(T);
-    }
-    Rec rec{ws, F, (int)np, ws.X, (int)np, ws.W, (int)np, false};
-    rec.node(0, T);
-    // Ninv = X^T X  (lauum), both triangles
-    GemmArgs a;
-    a.A = ws.X; a.lda = (int)np;
-    a.B = ws.X; a.ldb = (int)np;
-    a.C = F; a.ldc = (int)np;
-    a.mt = T; a.nt = T; a.K = (int)np;
-    a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
-    dnagpu::gemm(ws, a, 1, 1);
+    const int T = (int)(np / 128);
+    // potrf + trtri by the recursion, then Ninv = X^T X (lauum), both triangles
+    auto ops = [&](Rec& rec, const double*) {
+        rec.node(0, T);
+        GemmArgs a;
+        a.A = rec.X; a.lda = rec.ldx;
+        a.B = rec.X; a.ldb = rec.ldx;
+        a.C = rec.F; a.ldc = rec.ld;
+        a.mt = T; a.nt = T; a.K = T * 128;
+        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
+        rec.gemm(ws, a, 1, 1);
+    };
+    if (!run_dag(ws, DK_INVERSE, T, 0, 0, F, (int)np, ws.X, (int)np, ws.W, (int)np, nullptr, 0, ops))
+        run_products(ws, T, F, (int)np, ws.X, (int)np, ws.W, (int)np, nullptr, ops);     // (tables first: the blocking uploads never sit between kernels)
     gemm_profile_close(ws);
     if (scale_to_unity) launch_scale_sym(F, ws.svec, n, np, 0, ws.stream);
     inv_note_error(ws, hipGetLastError(), "inverse: scaling launch");
@@ -520,37 +678,33 @@ double schur_split() {
 
 void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti, int tj) {
     inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
-    const int key = (1 << 29) | (ti << 12) | tj;
-    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
-        Rec rec{ws, F, ld, X, ld, ws.W, ld, pass == 0};
+    auto ops = [&](Rec& rec, const double*) {
         if (ti > 0) rec.node(0, ti);
         if (ti > 0 && tj > 0) rec.eliminate(0, ti, tj);
-        if (ws.err != hipSuccess) return;
-    }
-    ws.planned.insert(key);
+    };
+    if (!run_dag(ws, DK_SCHUR_KEEP, ti, tj, 0, F, ld, X, ld, ws.W, ld, nullptr, 0, ops))
+        run_products(ws, (1 << 29) | (ti << 12) | tj, F, ld, X, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
 void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj, int what) {
     if (what & 1) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
-    const int key = (1 << 28) | ((what & 3) << 26) | (ti << 12) | tj;
     const int T = ti + tj;
-    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
-        Rec rec{ws, F, ld, X, ld, ws.W, ld, pass == 0};
+    auto ops = [&](Rec& rec, const double* wk) {
         GemmArgs a;
         if (what & 1) {
             rec.node(ti, tj);
             if (ti > 0) {
                 // T_KI = L_KI * X_II -> the kept rows of F;  X_KI = -X_KK * T_KI
-                a.A = WK; a.lda = ldwk;
-                a.B = rec.x(0, 0); a.ldb = ld;
-                a.C = rec.f(ti, 0); a.ldc = ld;
+                a.A = wk; a.lda = ldwk;
+                a.B = rec.x(0, 0); a.ldb = rec.ldx;
+                a.C = rec.f(ti, 0); a.ldc = rec.ld;
                 a.mt = tj; a.nt = ti; a.K = ti * 128;
                 a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
                 rec.gemm(ws, a, 0, 1);
-                a.A = rec.x(ti, ti); a.lda = ld;
-                a.B = rec.f(ti, 0); a.ldb = ld;
-                a.C = rec.x(ti, 0); a.ldc = ld;
+                a.A = rec.x(ti, ti); a.lda = rec.ldx;
+                a.B = rec.f(ti, 0); a.ldb = rec.ld;
+                a.C = rec.x(ti, 0); a.ldc = rec.ldx;
                 a.mt = tj; a.nt = ti; a.K = tj * 128;
                 a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
                 rec.gemm(ws, a, 0, 1);
@@ -558,61 +712,51 @@ void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const do
         }
         if (what & 2) {
             // inverse = X^T X, both triangles
-            a.A = X; a.lda = ld;
-            a.B = X; a.ldb = ld;
-            a.C = F; a.ldc = ld;
+            a.A = rec.X; a.lda = rec.ldx;
+            a.B = rec.X; a.ldb = rec.ldx;
+            a.C = rec.F; a.ldc = rec.ld;
             a.mt = T; a.nt = T; a.K = T * 128;
             a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
             rec.gemm(ws, a, 1, 1);
         }
-        if (ws.err != hipSuccess) return;
-    }
-    ws.planned.insert(key);
+    };
+    if (!run_dag(ws, DK_COMPLETE, ti, tj, what & 3, F, ld, X, ld, ws.W, ld, WK, ldwk, ops))
+        run_products(ws, (1 << 28) | ((what & 3) << 26) | (ti << 12) | tj, F, ld, X, ld, ws.W, ld, WK, ops);
     gemm_profile_close(ws);
 }
 
 void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
     inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
     const double split = schur_split();
-    const int key = (1 << 24) | (0 << 22) | (ti << 12) | tj;
-    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
-        Rec rec{ws, F, ld, S, ld, ws.W, ld, pass == 0};
-        rec.spine(ti, tj, split);
-        if (ws.err != hipSuccess) return;
-    }
-    ws.planned.insert(key);
+    auto ops = [&](Rec& rec, const double*) { rec.spine(ti, tj, split); };
+    if (!run_dag(ws, DK_SPINE, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
+        run_products(ws, (1 << 24) | (0 << 22) | (ti << 12) | tj, F, ld, S, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
 void sym_spine_kept_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
     inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
-    const int key = (1 << 24) | (1 << 22) | (ti << 12) | tj;
-    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
-        Rec rec{ws, F, ld, S, ld, ws.W, ld, pass == 0};
-        rec.node(ti, tj);
-        if (ws.err != hipSuccess) return;
-    }
-    ws.planned.insert(key);
+    auto ops = [&](Rec& rec, const double*) { rec.node(ti, tj); };
+    if (!run_dag(ws, DK_SPINE_KEPT, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
+        run_products(ws, (1 << 24) | (1 << 22) | (ti << 12) | tj, F, ld, S, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
 void sym_spine_finish_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
     const double split = schur_split();
-    const int key = (1 << 24) | (2 << 22) | (ti << 12) | tj;
     const int T = ti + tj;
-    for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
-        Rec rec{ws, F, ld, S, ld, ws.W, ld, pass == 0};
+    auto ops = [&](Rec& rec, const double*) {
         rec.spine_finish(ti, tj, split);
         GemmArgs a;
-        a.A = S; a.lda = ld;
-        a.B = S; a.ldb = ld;
-        a.C = F; a.ldc = ld;
+        a.A = rec.X; a.lda = rec.ldx;
+        a.B = rec.X; a.ldb = rec.ldx;
+        a.C = rec.F; a.ldc = rec.ld;
         a.mt = T; a.nt = T; a.K = T * 128;
         a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
         rec.gemm(ws, a, 1, 1);
-        if (ws.err != hipSuccess) return;
-    }
-    ws.planned.insert(key);
+    };
+    if (!run_dag(ws, DK_SPINE_FINISH, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
+        run_products(ws, (1 << 24) | (2 << 22) | (ti << 12) | tj, F, ld, S, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
@@ -632,16 +776,116 @@ void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, in
     inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
     const int ldx = ti * 128;
     const double split = schur_split();
-    const int key = (1 << 30) | (ti << 12) | tj;
-    if (!ws.planned.count(key)) {
-        Rec plan{ws, F, ld, ws.X, ldx, P, ldp, true};
-        plan.schur(ti, tj, split);
-        if (ws.err != hipSuccess) return;
-        ws.planned.insert(key);
-    }
-    Rec rec{ws, F, ld, ws.X, ldx, P, ldp, false};
-    rec.schur(ti, tj, split);
+    auto ops = [&](Rec& rec, const double*) { rec.schur(ti, tj, split); };
+    if (!run_dag(ws, DK_SCHUR, ti, tj, 0, F, ld, ws.X, ldx, P, ldp, nullptr, 0, ops))
+        run_products(ws, (1 << 30) | (ti << 12) | tj, F, ld, ws.X, ldx, P, ldp, nullptr, ops);
     gemm_profile_close(ws);
+}
+
+// CPU self-test of the dependency analysis (no device): the recorded sequence of `kind` for ti + tj tiles is run on host buffers
+// in its recorded order, and then -- from the same inputs, with the device's own counters and queues -- in a random admissible
+// order, in the most out-of-order one the counters admit and in the queues' own order.  Returns the number of orders whose
+// results differ from the recorded order's in any bit (0 = the counters carry every dependency), -1 if an order stalls.
+int dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats) {
+    InvWorkspace ws;      // (never touched by a recording pass)
+    const int T = ti + tj, np = T * 128;
+    const int ld = np, ldx = kind == DK_SCHUR ? std::max(1, ti) * 128 : np, ldp = np, ldwk = std::max(1, tj) * 128;
+    const double split = schur_split();
+    auto ops = [&](Rec& rec, const double* wk) {
+        GemmArgs a;
+        switch (kind) {
+            case DK_INVERSE:
+                rec.node(0, T);
+                break;
+            case DK_SCHUR: rec.schur(ti, tj, split); return;
+            case DK_SCHUR_KEEP:
+                if (ti > 0) rec.node(0, ti);
+                if (ti > 0 && tj > 0) rec.eliminate(0, ti, tj);
+                return;
+            case DK_SPINE: rec.spine(ti, tj, split); return;
+            case DK_SPINE_KEPT: rec.node(ti, tj); return;
+            case DK_SPINE_FINISH: rec.spine_finish(ti, tj, split); break;
+            case DK_COMPLETE:
+                if (what & 1) {
+                    rec.node(ti, tj);
+                    if (ti > 0) {
+                        a.A = wk; a.lda = ldwk;
+                        a.B = rec.x(0, 0); a.ldb = rec.ldx;
+                        a.C = rec.f(ti, 0); a.ldc = rec.ld;
+                        a.mt = tj; a.nt = ti; a.K = ti * 128;
+                        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
+                        rec.gemm(ws, a, 0, 1);
+                        a.A = rec.x(ti, ti); a.lda = rec.ldx;
+                        a.B = rec.f(ti, 0); a.ldb = rec.ld;
+                        a.C = rec.x(ti, 0); a.ldc = rec.ldx;
+                        a.mt = tj; a.nt = ti; a.K = tj * 128;
+                        a.alpha = -1.0; a.beta = 0.0; a.kmode = KM_LE_I; a.lower = 0; a.mirror = 0;
+                        rec.gemm(ws, a, 0, 1);
+                    }
+                }
+                if (!(what & 2)) return;
+                break;
+            default: return;
+        }
+        a.A = rec.X; a.lda = rec.ldx;
+        a.B = rec.X; a.ldb = rec.ldx;
+        a.C = rec.F; a.ldc = rec.ld;
+        a.mt = T; a.nt = T; a.K = T * 128;
+        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_I; a.lower = 1; a.mirror = 1;
+        rec.gemm(ws, a, 1, 1);
+    };
+    const int lds[DAG_MAX_BUFS] = {ld, ldx, ldp, ldwk};
+    std::shared_ptr<DagGraph> graph;
+    {
+        DagBuilder b(DAG_MAX_BUFS, lds, g_small_tiles.load());
+        Rec rec{ws, b.base(0), ld, b.base(1), ldx, b.base(2), ldp, false, &b};
+        ops(rec, (const double*)b.base(3));
+        graph = b.finish(16);
+    }
+    if (stats) {
+        stats[0] = (double)graph->tasks.size();
+        stats[1] = (double)graph->succ.size();
+        stats[2] = graph->flops;
+        stats[3] = graph->sim_makespan_us;
+        stats[4] = graph->critical_path_us;
+        stats[5] = graph->sim_work_us;
+    }
+    // inputs: a diagonally dominant symmetric matrix (both triangles: the sequences read what they were given), benign X / P / WK
+    const size_t sz[DAG_MAX_BUFS] = {(size_t)ld * np, (size_t)ldx * np, (size_t)ldp * np, (size_t)ldwk * np};
+    std::vector<double> init[DAG_MAX_BUFS];
+    uint64_t r = seed * 2862933555777941757ull + 3037000493ull;
+    auto rnd = [&] {
+        r = r * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(r >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    };
+    for (int q = 0; q < DAG_MAX_BUFS; ++q) {
+        init[q].resize(sz[q]);
+        for (double& v : init[q]) v = 0.01 * rnd();
+    }
+    for (int j = 0; j < np; ++j) {
+        for (int i = j + 1; i < np; ++i) init[0][(size_t)i * ld + j] = init[0][(size_t)j * ld + i];
+        init[0][(size_t)j * ld + j] = 4.0 + rnd();
+    }
+    if (kind != DK_INVERSE && kind != DK_SCHUR && kind != DK_SCHUR_KEEP && kind != DK_SPINE)
+        for (int j = 0; j < std::min(np, ldx); ++j) init[1][(size_t)j * ldx + j] = 1.0 + 0.1 * rnd();     // (X: a plausible triangular factor inverse)
+    auto run = [&](const DagGraph& g, int order, std::vector<double> (&out)[DAG_MAX_BUFS]) {
+        double* bp[DAG_MAX_BUFS];
+        for (int q = 0; q < DAG_MAX_BUFS; ++q) {
+            out[q] = init[q];
+            bp[q] = out[q].data();
+        }
+        return dag_execute_host(g, bp, lds, order, seed + (uint64_t)order);
+    };
+    std::vector<double> ref[DAG_MAX_BUFS], got[DAG_MAX_BUFS];
+    if (!run(*graph, 0, ref)) return -1;
+    int differing = 0;
+    for (int order = 1; order <= 3; ++order) {
+        if (!run(*graph, order, got)) return -1;
+        bool same = true;
+        for (int q = 0; q < DAG_MAX_BUFS; ++q) same = same && !memcmp(ref[q].data(), got[q].data(), sz[q] * sizeof(double));
+        if (!same) ++differing;
+    }
+    return differing;
 }
 
 }  // namespace dnagpu

@@ -212,6 +212,20 @@ int dnaadj_exchange_stats(const dnaadj_handle* h, uint64_t* bytes, double* excha
 /* settings.devices: device context of GPU r's instance (r = 0 .. n_devices-1), for dnagpu_profile_* */
 void* dnaadj_device_instance_context(dnaadj_handle* h, int r);
 
+/* settings.devices: what GPU r's instance did since the last dnaadj_reset (the getters above answer for the whole process) */
+typedef struct {
+    int rank, device;                /* its rank in the communicator, its HIP ordinal */
+    int rccl_ranks;                  /* ncclCommCount of its communicator (0: transport "local" / none) */
+    uint32_t solves, eliminations, completions;
+    double algorithmic_flops, solve_flops;
+    uint64_t exchanged_bytes;
+    double exchange_ms, chain_ms;
+} dnaadj_instance_stats;
+int dnaadj_device_instance_stats(dnaadj_handle* h, int r, dnaadj_instance_stats* out);
+/* test hook: CancelAdjustment() as ONE rank of a multi-process adjustment would receive it (a signal to its process): only GPU r's
+ * instance is told; the ranks agree on the cancellation at the next phase boundary and all return ADJUST_CANCELLED */
+int dnaadj_debug_cancel_instance(dnaadj_handle* h, int r);
+
 /* device context of the adjustment (for dnagpu_profile_*), NULL before prepare */
 void* dnaadj_device_context(dnaadj_handle* h);
 

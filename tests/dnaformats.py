@@ -204,3 +204,20 @@ def merge_networks(bases, out_base):
     write_bms(out_base + ".bms", bms)
     write_asl(out_base + ".asl", asl_all)
     write_seg(out_base + ".seg", ISL, JSL, CML, nets, bms)
+
+
+def read_mtx(path, count):
+    """matrix_2d binary stream records of <net>-rva.mtx / -pam.mtx (include/math/dnamatrix_contiguous.cpp:39-91): per matrix
+    6 x u32 (type: 1 = packed lower, rows, cols, mem_rows, mem_cols, pad), the doubles, 2 x u32 footer -> [(type, rows, cols, data)]"""
+    import struct
+    out = []
+    with open(path, "rb") as f:
+        for _ in range(count):
+            mtype, rows, cols, mrows, mcols, pad = struct.unpack("<6I", f.read(24))
+            assert (mrows, mcols, pad) == (rows, cols, 0)
+            n = rows * (rows + 1) // 2 if mtype == 1 else rows * cols
+            data = np.frombuffer(f.read(8 * n), dtype=np.float64)
+            assert struct.unpack("<2I", f.read(8)) == (0, 0)
+            out.append((mtype, rows, cols, data))
+        assert f.read() == b""
+    return out

@@ -491,7 +491,7 @@ for _name in ("_gid", "run_ends", "_system_of_block", "_merge", "_eliminate", "_
 def run_two_level(be, dist, rank, world, max_iterations=10):
     """the condensed schedule with two-level chains across `world` gloo ranks (the message pattern of dna_adjust_dist.cpp:
     one broadcast per RANK of the run's system, coordinates by all_reduce); returns (status, iterations, corrections, owners)"""
-    from dynadjust_amd import parallel
+    from tests import parallel_harness as parallel
     B = be.n_blocks
     owner = contiguous_owners([float(be.n_stations(k)) ** 3 for k in range(B)], world)
     runs = [(owner.index(r), B - 1 - owner[::-1].index(r)) for r in range(world)]

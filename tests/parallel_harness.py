@@ -1,4 +1,7 @@
-"""Multi-GPU schedules of the phased adjustment: one process per GPU, torch.distributed.
+"""TEST HARNESS (round 1's Python orchestrator; the product's multi-GPU driver is C++: csrc/host/dna_adjust_dist.cpp).
+
+Multi-GPU schedules of the phased adjustment over the per-block C entry points: one process per GPU,
+torch.distributed.  Used by tests/test_parallel_gloo.py (numpy backend under gloo), tests/test_gpu_adjust.py and tools/.
 
 1. The condensed schedule (default; settings.schur_carry, dna_adjust_phased.cpp "the condensed schedule").  Per iteration:
 
@@ -44,7 +47,7 @@ class DeviceBlockBackend:
 
     def __init__(self, settings, comm_device):
         import torch
-        from . import adjust
+        from dynadjust_amd import adjust
         self.torch = torch
         self.adj = adjust.DnaAdjust()
         self.adj.PrepareAdjustment(settings)
@@ -388,7 +391,7 @@ def run_phased(backend, dist, rank, world, max_iterations=10):
 def bench_distributed(folder, name, phased, args, dist, rank, world, local_rank, dist_backend="nccl"):
     """bench.py --gpus N (N > 1): the same network on N ranks, strong scaling; rank 0 returns the JSON dict."""
     import torch
-    from . import adjust
+    from dynadjust_amd import adjust
     if not phased:
         raise SystemExit("the simultaneous adjustment does not shard: run it with --gpus 1")
     dev = torch.device("cuda", local_rank) if dist_backend == "nccl" else torch.device("cpu")   # where the payloads live

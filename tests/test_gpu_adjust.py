@@ -219,7 +219,7 @@ def test_multi_thread_mode_matches_oracle(built, orc, tmp_path):
 def test_orchestrator_single_rank_equals_facade(built, tmp_path, schur):
     """dynadjust_amd/parallel.run_phased on one rank drives the same per-block steps as AdjustPhased: the condensed
     schedule (a.schur_carry, default) and the reference's"""
-    from dynadjust_amd import parallel
+    from tests import parallel_harness as parallel
     import torch
     adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 5, seed=9)
     f, st_f = _device_run(str(tmp_path), "n", True, schur_carry=schur)
@@ -243,7 +243,8 @@ def _two_rank_worker(rank, world, port, folder, outdir, schur):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from dynadjust_amd import adjust as adj, parallel
+    from dynadjust_amd import adjust as adj
+    from tests import parallel_harness as parallel
     p = adj.ProjectSettings("n", folder, adjust_mode=adj.PhasedMode, schur_carry=schur)
     be = parallel.DeviceBlockBackend(p, torch.device("cpu"))     # both ranks share the box's single GPU; payloads via host
     st, its, corr = parallel.run_phased(be, dist, rank, world)
@@ -416,20 +417,7 @@ def test_statistics_parity_with_oracle(built, orc, tmp_path, rows, cols, blocks,
     o.close()
 
 
-def _read_mtx_file(path, count):
-    """matrix_2d binary stream records (include/math/dnamatrix_contiguous.cpp:39-91)"""
-    import struct
-    out = []
-    with open(path, "rb") as f:
-        for _ in range(count):
-            mtype, rows, cols, mrows, mcols, pad = struct.unpack("<6I", f.read(24))
-            assert (mrows, mcols, pad) == (rows, cols, 0)
-            n = rows * (rows + 1) // 2 if mtype == 1 else rows * cols
-            data = np.frombuffer(f.read(8 * n), dtype=np.float64)
-            assert struct.unpack("<2I", f.read(8)) == (0, 0)
-            out.append((mtype, rows, cols, data))
-        assert f.read() == b""
-    return out
+_read_mtx_file = F.read_mtx
 
 
 def test_results_out_files(built, orc, tmp_path):

@@ -26,7 +26,7 @@ def _worker(rank, world, port, base, outdir, condensed):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from dynadjust_amd import parallel
+    from tests import parallel_harness as parallel
     from tests import oracle
     from tests.numpy_backend import NumpyBlockBackend
     net = oracle.Network(base, True)
@@ -141,7 +141,7 @@ def test_contiguous_owners():
 
 
 def test_schedule_roles():
-    from dynadjust_amd.parallel import PhasedSchedule
+    from tests.parallel_harness import PhasedSchedule
     flags = [(True, False, False)] + [(False, False, False)] * 6 + [(False, True, False)]
     s = PhasedSchedule(flags, 4)
     assert s.intermediate == [1, 2, 3, 4, 5, 6]
@@ -154,7 +154,7 @@ def test_schedule_roles():
 
 
 def test_block_owners_balance():
-    from dynadjust_amd.parallel import block_owners
+    from tests.parallel_harness import block_owners
     assert block_owners([1.0] * 16, 8) == [0, 1, 2, 3, 4, 5, 6, 7] * 2
     assert block_owners([1.0] * 5, 1) == [0] * 5
     o = block_owners([8.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], 2)

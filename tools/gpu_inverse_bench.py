@@ -29,7 +29,7 @@ def main():
     rng = np.random.default_rng(1)
     print("# n, inverse ms / TFLOP/s (n^3), eliminate ms / TFLOP/s (n^3/3), keep+finish ms / TFLOP/s (n^3)")
     with DeviceContext(0) as ctx:
-        for ns in (2048, 4096, 6656, 10000):
+        for ns in ([int(a) for a in sys.argv[1:]] or [2048, 4096, 6656, 10000]):
             n = 3 * ns
             ap = spd_packed(n, rng)
             m = ctx.matrix(n)

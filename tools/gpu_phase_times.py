@@ -4,7 +4,8 @@ blocks, (C) rigorous solves -- through the same C entry points the multi-GPU orc
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from dynadjust_amd import adjust, parallel
+from dynadjust_amd import adjust
+from tests import parallel_harness as parallel
 import torch
 
 d = tempfile.mkdtemp()

@@ -5,7 +5,8 @@ solved (LPT owners of parallel.block_owners), the chains on all condensed blocks
 import os, sys, time, tempfile
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from dynadjust_amd import adjust, parallel
+from dynadjust_amd import adjust
+from tests import parallel_harness as parallel
 import torch
 
 d = tempfile.mkdtemp()
