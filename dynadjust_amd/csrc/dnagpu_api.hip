@@ -383,6 +383,12 @@ long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int ti
 
 int dnagpu_debug_set_tile_dag(int on) { return dnagpu::dag_mode_set(on ? 1 : 0); }
 
+int dnagpu_set_tile_dag_workers(dnagpu_ctx* ctx, int workers) {
+    if (!ctx || workers < 0) return DNAGPU_EINVAL;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) ctx->ws[c].dag_workers = workers;
+    return DNAGPU_OK;
+}
+
 int dnagpu_tile_dag_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* tasks) {
     if (!ctx) return DNAGPU_EINVAL;
     uint64_t l = 0, t = 0;

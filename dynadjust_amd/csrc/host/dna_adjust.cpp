@@ -37,6 +37,8 @@ void dna_adjust::FreeDevice() {
     FreeTwoLevel();
     if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);
     xbuf_dev_ = nullptr;
+    if (agree_dev_) dnagpu_device_free(ctx_, agree_dev_);
+    agree_dev_ = nullptr;
     xbuf_cap_ = 0;
     for (block_t& b : blocks_) {
         if (b.jfwd) dnagpu_matrix_destroy(ctx_, b.jfwd);
@@ -593,6 +595,14 @@ void dna_adjust::PrepareBlocks() {
         SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
     }
     if (shares_device_) dnagpu_set_fused_launches(ctx_, 0);
+    // Chains that run side by side share the GPU's workgroup slots by agreement: a DAG launch (csrc/tile_dag.h) of one chain keeps
+    // at most its share of persistent workers, so that a chain whose factorisation is waiting on its critical path cannot sit on the
+    // slots the others have work for.  DNAGPU_DAG_WORKERS overrides (0 = every launch may take the whole GPU).
+    {
+        int share = 512 / std::max(1, NumChains() * (shares_device_ ? std::max(1, DistWorld()) : 1));
+        if (const char* e = getenv("DNAGPU_DAG_WORKERS")) share = atoi(e);
+        dnagpu_set_tile_dag_workers(ctx_, std::max(0, share));
+    }
     // several GPUs, one block (simultaneous adjustment): every GPU holds the block, the inverse itself is distributed -- large
     // launches split by tile columns, the parts exchanged over the communicator (dnagpu_set_inverse_exchange)
     if (comm_ && comm_->world() > 1 && projectSettings_.a.adjust_mode == SimultaneousMode)
@@ -844,6 +854,7 @@ void dna_adjust::AdjustSimultaneous() {
     currentIteration_ = 0;
     for (UINT32 i = 0; i < projectSettings_.a.max_iterations; ++i) {
         if (IsCancelled()) break;
+        const double it_t0 = now_ms();
         ++currentIteration_;
         currentBlock_ = 0;
         // the inverse is only formed again if the network has non-GPS measurements, whose design follows the estimates
@@ -863,6 +874,7 @@ void dna_adjust::AdjustSimultaneous() {
         Check(dnagpu_update_estimates(ctx_, c, 0, &mv, &row), 0, "AdjustSimultaneous()");
         maxCorr_ = mv;
         iterationCorrections_.push_back(maxCorr_);
+        NoteIterationDone(it_t0);                       // the progress thread's message of this iteration (ADJ:2471-2472)
         bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
         if (!iterate) break;
         UpdateAdjustment(true);
@@ -1467,6 +1479,55 @@ bool dna_adjust::GetMessageIteration(UINT32& iteration) {
     iterationQueue_.pop_front();
     return true;
 }
+std::string dna_adjust::GetMaxCorrection(const UINT32& iteration) const {
+    if (iteration == 0 || iteration > iterationCorrections_.size()) return std::string();
+    std::stringstream ss;
+    ss << std::fixed << std::setprecision(4) << iterationCorrections_[iteration - 1];
+    return ss.str();
+}
+
+DynAdjustPrinter* dna_adjust::GetPrinter() {
+    if (!printer_) printer_.reset(new DynAdjustPrinter(*this));
+    return printer_.get();
+}
+
+void dna_adjust::CloseOutputFiles() {
+    if (printer_) printer_->Close();
+}
+
+// ADJ:7556: the reference keeps a history of stations whose corrections change sign from iteration to iteration (oscHistory_, filled by
+// UpdateIterationDiagnostics) and lists the worst twenty after an adjustment that did not converge.  The device path keeps no such
+// history (the corrections stay in HBM; only the largest one per iteration comes back): nothing is listed, which is also what
+// the reference prints for an adjustment that converged.
+void dna_adjust::PrintOscillationSummary() {}
+
+// ADJ:7652: the measurements whose N-statistic exceeds the critical value of the chosen confidence interval, largest first
+void dna_adjust::PrintSuspectMeasurementSummary(std::ostream& os, size_t limit) const {
+    if (bmsBinaryRecords_.empty() || limit == 0) return;
+    std::vector<UINT32> idx;
+    for (UINT32 i = 0; i < bmsBinaryRecords_.size(); ++i) {
+        const measurement_t& m = bmsBinaryRecords_[i];
+        if (m.ignore || m.measStart > 2 || !std::isfinite(m.NStat) || !std::isfinite(m.residualPrec) || m.residualPrec <= 0.0) continue;
+        if (std::fabs(m.NStat) > criticalValue_) idx.push_back(i);
+    }
+    if (idx.empty()) return;
+    std::sort(idx.begin(), idx.end(), [&](UINT32 x, UINT32 y) { return std::fabs(bmsBinaryRecords_[x].NStat) > std::fabs(bmsBinaryRecords_[y].NStat); });
+    const size_t shown = std::min(limit, idx.size());
+    auto name = [&](UINT32 s) {
+        return s < bstBinaryRecords_.size() ? std::string(bstBinaryRecords_[s].stationName, strnlen(bstBinaryRecords_[s].stationName, sizeof(bstBinaryRecords_[s].stationName)))
+                                            : std::string("-");
+    };
+    os << std::endl << "+ Suspect measurements (" << idx.size() << " exceed the critical value " << std::fixed << std::setprecision(2) << criticalValue_ << ", showing top " << shown
+       << "):" << std::endl;
+    for (size_t k = 0; k < shown; ++k) {
+        const measurement_t& m = bmsBinaryRecords_[idx[k]];
+        os << "  - " << m.measType << " " << name(m.station1);
+        if (m.measType != 'Y' && m.measType != 'H' && m.measType != 'R' && m.measType != 'I' && m.measType != 'J' && m.measType != 'P' && m.measType != 'Q') os << " -> " << name(m.station2);
+        os << std::fixed << std::setprecision(2) << ", N-stat " << m.NStat << std::setprecision(4) << ", correction " << m.measCorr << ", Pelzer " << std::setprecision(2) << m.PelzerRel
+           << std::endl;
+    }
+}
+
 std::string dna_adjust::GetIterationTime(const UINT32& iteration) const {
     if (iteration == 0 || iteration > iterationMs_.size()) return std::string();
     std::stringstream ss;

@@ -5,7 +5,10 @@
 // (include/dnagpu.h); this class only schedules blocks and keeps host-side metadata.
 #pragma once
 #include <atomic>
+#include <chrono>
+#include <cmath>
 #include <deque>
+#include <iostream>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -17,6 +20,7 @@
 #include "dist_comm.hpp"
 #include "dnaio.hpp"
 #include "dnatypes.hpp"
+#include "dna_printer.hpp"
 
 namespace dynadjust {
 namespace networkadjust {
@@ -31,6 +35,13 @@ private:
     UINT32 block_;
 };
 
+// include/exception/dnaexception.hpp: thrown by the reference when a matrix cannot be allocated (dnaadjustprogress.cpp:81 catches it);
+// here device allocations fail as NetAdjustException with the device layer's message, so this type is only ever caught
+class NetMemoryException : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
+
 // math::MatrixInversionFailure (dnamatrix_contiguous.hpp:198)
 class MatrixInversionFailure : public std::runtime_error {
 public:
@@ -42,6 +53,7 @@ struct block_timing_t {
 };
 
 class dna_adjust {
+    friend class DynAdjustPrinter;        // (the reference's printers are friends too, dnaadjust.hpp:214-215)
 public:
     dna_adjust();
     ~dna_adjust();
@@ -86,9 +98,16 @@ public:
     inline bool IsAdjustmentQuestionable() const { return isAdjustmentQuestionable_; }
     inline bool GetAllFixed() const { return allStationsFixed_; }
     inline bool ExceptionRaised() const { return exceptionRaised_; }
-    inline double adjustTime() const { return adjust_ms_; }
+    inline std::chrono::milliseconds adjustTime() const { return std::chrono::milliseconds((long long)std::llround(adjust_ms_)); }   // dnaadjust.hpp:310
+    inline double adjustTimeMs() const { return adjust_ms_; }
     // progress-thread interface of dnaadjustprogress.cpp: iterations finished since the last poll, their wall times
     // (iterationQueue_ / iterationTimes_ in the reference, dnaadjust.hpp:364-380)
+    // the largest correction of an iteration as the progress thread prints it (dnaadjust.hpp:355-359)
+    std::string GetMaxCorrection(const UINT32& iteration) const;
+    // dnaadjust.hpp:277 / :294-296 -- see dna_printer.hpp for what stands behind the printer
+    DynAdjustPrinter* GetPrinter();
+    void PrintOscillationSummary();
+    void PrintSuspectMeasurementSummary(std::ostream& os = std::cout, size_t limit = 20) const;
     bool NewMessagesAvailable();
     bool GetMessageIteration(UINT32& iteration);
     std::string GetIterationTime(const UINT32& iteration) const;
@@ -101,7 +120,7 @@ public:
     void LoadSegmentationFileParameters(const std::string& seg_filename);           // ADJ:10628: block count of a .seg file
     void DeSerialiseAdjustedVarianceMatrices();                                     // ADJ:6720: -rva.mtx / -pam.mtx back into the blocks
     void NoteIterationDone(double t0_ms);
-    void CloseOutputFiles() {}                                                      // the report streams belong to the reference's printer
+    void CloseOutputFiles();                                                        // dnaadjust.hpp:297: the printer's report streams
     inline UINT32 CurrentBlockStationCount() const {
         return currentBlock_ < v_parameterStationList_.size() ? (UINT32)v_parameterStationList_[currentBlock_].size() : 0;
     }
@@ -285,6 +304,7 @@ private:
     std::vector<int> owner_;
     std::vector<std::unique_ptr<dna_adjust>> peers_;
     double* xbuf_dev_ = nullptr;
+    double* agree_dev_ = nullptr;              // two words of device memory of AgreeOnPhase (its own: it runs between a collective and the read-back of ITS buffer)
     size_t xbuf_cap_ = 0;
     double exchange_ms_ = 0.0, chain_ms_ = 0.0;
     void PrepareCondensedBlocks();
@@ -425,6 +445,7 @@ private:
     UINT32 currentIteration_ = 0;
     bool isPreparing_ = false, isAdjusting_ = false, forward_ = true, isCombining_ = false;
     bool allStationsFixed_ = false, exceptionRaised_ = false;
+    std::unique_ptr<DynAdjustPrinter> printer_;
     std::atomic<bool> cancel_{false};
     bool cancel_agreed_ = false;               // multi-GPU: a cancellation every rank knows of (set by AgreeOnPhase only)
     _ADJUST_STATUS_ adjustStatus_ = ADJUST_SUCCESS;

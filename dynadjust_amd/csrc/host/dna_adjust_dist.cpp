@@ -143,7 +143,12 @@ void dna_adjust::AgreeOnPhase(const char* phase, const std::function<void()>& bo
     double others = 0.0, cancelled = 0.0;
     try {
         // two words: "I failed" and "I was cancelled" -- the sums tell every rank the same thing at the same point of the schedule
-        double* flag = ExchangeBuffer(2);
+        if (!agree_dev_) {
+            void* q = nullptr;
+            Check(dnagpu_device_alloc(ctx_, 2 * sizeof(double), &q), 0, "exchange");
+            agree_dev_ = (double*)q;
+        }
+        double* flag = agree_dev_;
         double v[2] = {mine ? 1.0 : 0.0, IsCancelled() ? 1.0 : 0.0};
         Check(dnagpu_copy(ctx_, flag, v, sizeof(v)), 0, "exchange");
         comm_->all_reduce_sum(flag, 2);

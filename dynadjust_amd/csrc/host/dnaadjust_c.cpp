@@ -289,7 +289,7 @@ double dnaadj_iteration_correction(const dnaadj_handle* h, uint32_t it) { return
 uint32_t dnaadj_measurement_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetMeasurementCount() : 0; }
 uint32_t dnaadj_unknowns_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetUnknownsCount() : 0; }
 int dnaadj_degrees_of_freedom(const dnaadj_handle* h) { return h && h->adj ? h->adj->GetDegreesOfFreedom() : 0; }
-double dnaadj_adjust_time_ms(const dnaadj_handle* h) { return h && h->adj ? h->adj->adjustTime() : 0.0; }
+double dnaadj_adjust_time_ms(const dnaadj_handle* h) { return h && h->adj ? h->adj->adjustTimeMs() : 0.0; }
 double dnaadj_solve_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveFlops() : 0.0; }
 uint32_t dnaadj_solve_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->solveCount() : 0; }
 double dnaadj_algorithmic_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->algorithmicFlops() : 0.0; }

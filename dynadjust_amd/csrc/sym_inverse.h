@@ -60,8 +60,12 @@ struct InvWorkspace {
     uint64_t fused_launches = 0, fused_ops = 0;
     // tile-DAG path (tile_dag.h): a whole driver call below as one launch
     bool dag = true;               // dnagpu_set_tile_dag / DNAGPU_DAG=0 switch back to one launch per product
-    uint32_t* dag_state = nullptr;   // this chain's copy of a graph's state words (queues, predecessor counters), restored per launch
-    size_t dag_state_cap = 0;
+    int dag_workers = 0;           // workgroups per launch (0: the default, 512 = what the GPU holds of this kernel); chains that run side by side share
+    uint32_t* dag_flags = nullptr; // completion flags of the tasks (a flag is raised by writing the launch's epoch: never cleared)
+    size_t dag_flags_cap = 0;
+    uint32_t dag_epoch = 0;
+    unsigned long long* dag_ticket = nullptr;   // the ticket counter and its value at the next launch's start
+    unsigned long long dag_ticket_base = 0;
     uint64_t dag_launches = 0, dag_tasks = 0;
 };
 

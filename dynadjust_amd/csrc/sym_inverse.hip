@@ -31,7 +31,8 @@ hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t st
 }
 
 void inv_workspace_free(InvWorkspace& ws) {
-    if (ws.dag_state) hipFree(ws.dag_state);
+    if (ws.dag_flags) hipFree(ws.dag_flags);
+    if (ws.dag_ticket) hipFree(ws.dag_ticket);
     if (ws.X) hipFree(ws.X);
     if (ws.W) hipFree(ws.W);
     if (ws.svec) hipFree(ws.svec);
@@ -496,15 +497,19 @@ DagCache& dag_cache() {
     return *c;
 }
 
+// Opt-in (DNAGPU_DAG=1 / dnagpu_debug_set_tile_dag): measured (round 3, profiles/r03_dag_schedulers.txt), the DAG path reproduces the
+// per-product path bit for bit and does not beat it -- one chain 3.12 s against 3.07 s per cfg3 step, four chains 2.64 - 2.75 s against
+// 2.55 s: the factorisation is bound by its critical path, and workers that wait on it hold slots the other chains have work for.
 std::atomic<int> g_dag_mode{[] {
     const char* e = getenv("DNAGPU_DAG");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
 }()};
 std::atomic<int> g_dag_min_tiles{[] {
     const char* e = getenv("DNAGPU_DAG_MIN_TILES");
     return e ? atoi(e) : 2;
 }()};
-// workgroups the diagnostic simulation assumes in flight
+// 0 = recorded order, 1 = list-scheduling order (default); workers: workgroups per launch unless the chain says otherwise (InvWorkspace::dag_workers)
+const int g_dag_reorder = getenv("DNAGPU_DAG_ORDER") ? atoi(getenv("DNAGPU_DAG_ORDER")) : 1;
 const int g_dag_workers = getenv("DNAGPU_DAG_WORKERS") ? atoi(getenv("DNAGPU_DAG_WORKERS")) : 512;
 
 std::atomic<int> g_dag_trace_serial{0};
@@ -517,7 +522,7 @@ std::shared_ptr<DagGraph> dag_record(InvWorkspace& ws, int ld, int ldx, int ldp,
     DagBuilder b(DAG_MAX_BUFS, lds, g_small_tiles.load());
     Rec rec{ws, b.base(0), ld, b.base(1), ldx, b.base(2), ldp, false, &b};
     ops(rec, (const double*)b.base(3));
-    return b.finish(g_dag_workers);
+    return b.finish(g_dag_reorder, g_dag_workers);
 }
 
 // true: the call went out (or was dropped after a latched error) as one DAG launch; false: the caller launches product by product
@@ -528,7 +533,7 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
     if (ws.err != hipSuccess) return true;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const auto key = std::make_tuple(dev, kind, ti, tj, what, ld, ldx, ldp, ldwk, (int)(schur_split() * 1000.0 + 0.5), 0, g_small_tiles.load());
+    const auto key = std::make_tuple(dev, kind, ti, tj, what, ld, ldx, ldp, ldwk, (int)(schur_split() * 1000.0 + 0.5), g_dag_reorder, g_small_tiles.load());
     std::shared_ptr<DagGraph> g;
     {
         DagCache& c = dag_cache();
@@ -544,8 +549,8 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
             }
             static const bool verbose = getenv("DNAGPU_DAG_VERBOSE") != nullptr;
             if (verbose)
-                fprintf(stderr, "dnagpu: tile DAG kind %d ti %d tj %d: %zu tasks (%u products, %u leaves), %zu successor runs, work %.1f ms / 512 = %.2f ms, "
-                        "critical path %.2f ms, simulated %.2f ms\n", kind, ti, tj, g->tasks.size(), g->n_products, g->n_leaves, g->succ.size(),
+                fprintf(stderr, "dnagpu: tile DAG kind %d ti %d tj %d: %zu tasks (%u products, %u leaves), %zu dependency runs, work %.1f ms / 512 = %.2f ms, "
+                        "critical path %.2f ms, simulated %.2f ms\n", kind, ti, tj, g->tasks.size(), g->n_products, g->n_leaves, g->deps.size(),
                         g->sim_work_us / 1e3, g->sim_work_us / 512e3, g->critical_path_us / 1e3, g->sim_makespan_us / 1e3);
             c.graphs.emplace(key, g);
         } else {
@@ -559,21 +564,29 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
         inv_note_error(ws, hipErrorOutOfMemory, "tile DAG allocation");
         return true;
     }
-    // this chain's copy of the graph's state (queue heads / tails, predecessor counters, queue slots), restored before every launch
-    const size_t words = g->state_init.size();
-    if (ws.dag_state_cap < words) {
+    // completion flags (raised by writing the launch's epoch: never cleared) and the ticket counter of this chain.  Zeroed on the
+    // chain's own stream: a plain hipMemset runs on the legacy stream, which a non-blocking stream does not wait for -- the first
+    // launch would take tickets from a counter that is zeroed underneath it (seen: 657 of 5 260 tasks never ran)
+    if (ws.dag_flags_cap < g->nids) {
         hipStreamSynchronize(ws.stream);
-        if (ws.dag_state) hipFree(ws.dag_state);
-        ws.dag_state = nullptr;
-        ws.dag_state_cap = 0;
-        const size_t want = std::max<size_t>(words * 2, (size_t)1 << 20);
-        hipError_t e = hipMalloc(&ws.dag_state, want * sizeof(uint32_t));
+        if (ws.dag_flags) hipFree(ws.dag_flags);
+        ws.dag_flags = nullptr;
+        ws.dag_flags_cap = 0;
+        const size_t want = std::max<size_t>((size_t)g->nids * 2, (size_t)1 << 20);
+        hipError_t e = hipMalloc(&ws.dag_flags, want * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(ws.dag_flags, 0, want * sizeof(uint32_t), ws.stream);
+        if (e == hipSuccess && !ws.dag_ticket) {
+            e = hipMalloc(&ws.dag_ticket, sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipMemsetAsync(ws.dag_ticket, 0, sizeof(unsigned long long), ws.stream);
+            ws.dag_ticket_base = 0;
+        }
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            inv_note_error(ws, e, "tile DAG state allocation");
+            inv_note_error(ws, e, "tile DAG flags allocation");
             return true;
         }
-        ws.dag_state_cap = want;
+        ws.dag_flags_cap = want;
+        ws.dag_epoch = 0;
     }
     gemm_flush(ws);
     GemmProfile& p = ws.prof;
@@ -585,17 +598,17 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
         p.flops += g->flops;
         p.launches++;
     }
-    inv_note_error(ws, hipMemcpyAsync(ws.dag_state, g->d_state_init, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ws.stream), "tile DAG state");
     DagLaunch L;
     L.tasks = g->d_tasks;
-    L.succ = g->d_succ;
-    L.id2task = g->d_id2task;
-    L.state = ws.dag_state;
+    L.deps = g->d_deps;
     L.ntasks = (uint32_t)g->tasks.size();
-    L.state_pending = g->state_pending;
-    L.state_slots = g->state_slots;
-    L.state_mail = g->state_mail;
-    for (int q = 0; q <= DAG_QUEUES; ++q) L.slot_base[q] = g->slot_base[q];
+    L.epoch = ++ws.dag_epoch;
+    L.flags = ws.dag_flags;
+    L.ticket = ws.dag_ticket;
+    L.ticket_base = ws.dag_ticket_base;
+    static const int paranoid = getenv("DNAGPU_DAG_PARANOID") ? atoi(getenv("DNAGPU_DAG_PARANOID")) : 0;
+    L.paranoid = paranoid;
+    L.workers = (int)std::min<size_t>(g->tasks.size(), (size_t)std::max(1, ws.dag_workers > 0 ? ws.dag_workers : g_dag_workers));
     L.buf0 = F; L.buf1 = X; L.buf2 = P; L.buf3 = const_cast<double*>(WK);
     L.ld0 = ld; L.ld1 = ldx; L.ld2 = ldp; L.ld3 = ldwk > 0 ? ldwk : 128;
     L.info = ws.info;
@@ -621,6 +634,7 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
             fclose(f);
         }
     }
+    ws.dag_ticket_base += (unsigned long long)L.ntasks + (unsigned long long)L.workers;     // (every worker takes one ticket too many)
     ws.dag_launches++;
     ws.dag_tasks += L.ntasks;
     return true;
@@ -783,9 +797,9 @@ void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, in
 }
 
 // CPU self-test of the dependency analysis (no device): the recorded sequence of `kind` for ti + tj tiles is run on host buffers
-// in its recorded order, and then -- from the same inputs, with the device's own counters and queues -- in a random admissible
-// order, in the most out-of-order one the counters admit and in the queues' own order.  Returns the number of orders whose
-// results differ from the recorded order's in any bit (0 = the counters carry every dependency), -1 if an order stalls.
+// in its recorded order, and then -- from the same inputs -- in the launch order, a random admissible order and the most
+// out-of-order one the completion flags admit.  Returns the number of orders whose results differ from the recorded order's in
+// any bit (0 = the flags carry every dependency), -1 if an order stalls.
 int dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats) {
     InvWorkspace ws;      // (never touched by a recording pass)
     const int T = ti + tj, np = T * 128;
@@ -835,20 +849,26 @@ int dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stat
         rec.gemm(ws, a, 1, 1);
     };
     const int lds[DAG_MAX_BUFS] = {ld, ldx, ldp, ldwk};
-    std::shared_ptr<DagGraph> graph;
+    std::shared_ptr<DagGraph> recorded, scheduled;
     {
         DagBuilder b(DAG_MAX_BUFS, lds, g_small_tiles.load());
         Rec rec{ws, b.base(0), ld, b.base(1), ldx, b.base(2), ldp, false, &b};
         ops(rec, (const double*)b.base(3));
-        graph = b.finish(16);
+        recorded = b.finish(0, 1);
+    }
+    {
+        DagBuilder b(DAG_MAX_BUFS, lds, g_small_tiles.load());
+        Rec rec{ws, b.base(0), ld, b.base(1), ldx, b.base(2), ldp, false, &b};
+        ops(rec, (const double*)b.base(3));
+        scheduled = b.finish(1, 16);
     }
     if (stats) {
-        stats[0] = (double)graph->tasks.size();
-        stats[1] = (double)graph->succ.size();
-        stats[2] = graph->flops;
-        stats[3] = graph->sim_makespan_us;
-        stats[4] = graph->critical_path_us;
-        stats[5] = graph->sim_work_us;
+        stats[0] = (double)recorded->tasks.size();
+        stats[1] = (double)recorded->deps.size();
+        stats[2] = recorded->flops;
+        stats[3] = scheduled->sim_makespan_us;
+        stats[4] = scheduled->critical_path_us;
+        stats[5] = scheduled->sim_work_us;
     }
     // inputs: a diagonally dominant symmetric matrix (both triangles: the sequences read what they were given), benign X / P / WK
     const size_t sz[DAG_MAX_BUFS] = {(size_t)ld * np, (size_t)ldx * np, (size_t)ldp * np, (size_t)ldwk * np};
@@ -877,10 +897,12 @@ int dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stat
         return dag_execute_host(g, bp, lds, order, seed + (uint64_t)order);
     };
     std::vector<double> ref[DAG_MAX_BUFS], got[DAG_MAX_BUFS];
-    if (!run(*graph, 0, ref)) return -1;
+    if (!run(*recorded, 0, ref)) return -1;
     int differing = 0;
-    for (int order = 1; order <= 3; ++order) {
-        if (!run(*graph, order, got)) return -1;
+    const DagGraph* graphs[4] = {scheduled.get(), scheduled.get(), scheduled.get(), recorded.get()};
+    const int orders[4] = {0, 1, 2, 2};
+    for (int v = 0; v < 4; ++v) {
+        if (!run(*graphs[v], orders[v], got)) return -1;
         bool same = true;
         for (int q = 0; q < DAG_MAX_BUFS; ++q) same = same && !memcmp(ref[q].data(), got[q].data(), sz[q] * sizeof(double));
         if (!same) ++differing;

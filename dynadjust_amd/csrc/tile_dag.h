@@ -6,18 +6,23 @@
 // step s + 1 can start before the last tile of step s has ended (round 2: 49.5 TFLOP/s for the elimination against 74 for the tile
 // kernel alone).  Here the same sequence is RECORDED instead (DagBuilder), cut into its tile tasks, the dependencies between the
 // tasks are derived from the tiles they read and write (read-after-write, write-after-read, write-after-write, at 128 x 128
-// granularity -- exact, whatever the recursion does), and one launch runs them all as a dataflow graph:
-//   * every task carries a counter of unfinished predecessors; a task that finishes releases its results (agent scope), decrements
-//     the counters of its successors, and whichever decrement reaches zero puts that successor into a ready queue;
-//   * one workgroup per task: a workgroup takes ONE task out of the ready queues (waiting while they are empty), acquires, runs it
-//     with the very tile code of the per-product kernels (gemm_tile_dma.h, gemm_tile_reg.h, leaf_body.h: same bits), and ends.  A
-//     workgroup never sits on a task that is not ready while another one is, and a slot that frees is re-arbitrated between all
-//     kernels on the GPU, so several chains' graphs share the chip tile by tile;
-//   * sixteen ready queues by critical-path length (longest remaining path first): the leading block of step s + 1 is factored
-//     while the trailing update of step s is still under way (look-ahead), and the last tiles of a product run beside the first
-//     ones of the next;
-//   * no deadlock by construction: a workgroup only ever waits for a queue entry, and as long as tasks remain, one of them has all
-//     its predecessors finished or running.
+// granularity -- exact, whatever the recursion does), and one launch runs them all:
+//   * the tasks form ONE list, ordered by a list-scheduling simulation with critical-path priorities (the leading block of step
+//     s + 1 is factored while the trailing update of step s is still under way -- look-ahead --, a product's last tiles run beside
+//     the next one's first);
+//   * a launch is `workers` persistent workgroups.  A worker takes the next position of the list (an atomic ticket), waits until the
+//     completion flags of that task's predecessors carry this launch's epoch, acquires, runs the task with the very tile code of
+//     the per-product kernels (gemm_tile_dma.h, gemm_tile_reg.h, leaf_body.h: same bits), releases, raises the task's own flag
+//     (a plain store: nobody but its successors' workers looks at it), and goes back for the next ticket;
+//   * the list is a topological order, so a waiting worker only ever waits for tasks whose tickets were taken before its own --
+//     by workers that are running: no deadlock, whatever the dispatch order and however few workers are resident;
+//   * `workers` bounds what a launch can hold of the GPU: chains that run their graphs side by side share the slots by agreement
+//     (512 / chains each) instead of one chain's waiting workers starving the others.
+// Two other schedulers were built and measured first (round 3, profiles/r03_dag_schedulers.txt): one workgroup per task in list
+// order (25 - 35 % of the slot time went to workgroups waiting on a task while later ones were ready -- with one chain there was
+// nothing else to run, with four the waiting workgroups took the others' slots), and a dataflow scheduler (predecessor counters,
+// ready queues by priority, direct hand-off to waiting workgroups: no slot is ever wasted, but every hop on the critical path pays
+// four dependent device-scope read-modify-writes, 13 us median, and the factorisation is critical-path bound: 2.3 x slower).
 // Replaces the dpotrf / dpotri call pair of matrix_2d::cholesky_inverse (dynadjust/include/math/dnamatrix_contiguous.cpp:982-1006).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,10 +34,6 @@
 namespace dnagpu {
 
 constexpr int DAG_MAX_BUFS = 4;
-constexpr int DAG_QUEUES = 16;
-// words of the state image in front of the predecessor counters: queue heads, queue tails, queue bases (+ end), balance, waiters, handoffs
-constexpr uint32_t DAG_STATE_BALANCE = 3 * DAG_QUEUES + 1, DAG_STATE_WAITERS = DAG_STATE_BALANCE + 1, DAG_STATE_HANDOFFS = DAG_STATE_BALANCE + 2;
-constexpr uint32_t DAG_STATE_FIXED = DAG_STATE_BALANCE + 3;
 
 // products: operand layouts NT (akc = 0, bkc = 0), NN (akc = 0, bkc = 1), TN (akc = 1, bkc = 1); + DAG_TILE64: a 64 x 64 tile by the
 // register-staged latency shape (gemm_tile_reg.h) instead of a 128 x 128 tile by the LDS-DMA throughput shape (gemm_tile_dma.h) -- the
@@ -44,10 +45,9 @@ struct DagTask {
     uint32_t a_off, b_off, c_off;   // element offsets of the product's operands in their buffers (leaf: a = the tile in the matrix, c = the tile in X)
     uint16_t it, jt;                // the task's tile of C relative to the product's C, in tiles of its own size (128 or 64)
     uint16_t kb, ke;                // its k range in 128-tiles (leaf: kb = the tile's position on the diagonal, for `info`)
-    uint8_t type, bufs, flags;      // DagTaskType; buffer numbers a | b << 2 | c << 4; DagTaskFlags
-    uint8_t queue;                  // the ready queue it goes to (0 = most urgent)
-    uint32_t id;                    // its number in the recorded order (index of its predecessor counter)
-    uint32_t succ0, nsucc;          // its successors: succ[succ0 .. succ0 + nsucc), runs of recorded numbers
+    uint8_t type, bufs, flags, pad; // DagTaskType; buffer numbers a | b << 2 | c << 4; DagTaskFlags
+    uint32_t id;                    // its number in the recorded order = the index of its completion flag
+    uint32_t dep0, ndep;            // its predecessors: deps[dep0 .. dep0 + ndep), runs of recorded numbers
 };
 static_assert(sizeof(DagTask) == 36, "DagTask layout");
 
@@ -57,32 +57,18 @@ struct DagRun {
     uint16_t count, stride;
 };
 
-// What a launch changes is one array of 32-bit words per chain, restored from the graph's image (state_init) before every launch:
-//   words [0, Q)                        queue heads: entries taken so far
-//   words [Q, 2 Q)                      queue tails: entries put so far
-//   words [2 Q, 3 Q]                    slot_base (constant)
-//   word  DAG_STATE_BALANCE             tasks put into the queues minus workgroups arrived (signed)
-//   words DAG_STATE_WAITERS / HANDOFFS  workgroups that found nothing and wait / tasks handed straight to a waiting workgroup
-//   words [state_pending, + nids)       unfinished predecessors per recorded number
-//   words [state_slots, + ntasks)       the queues' slots (task + 1, 0 = not yet filled), queue q at slot_base[q]
-//   words [state_mail, + ntasks)        mailbox of the w-th waiting workgroup (task + 1)
 struct DagGraph {
     // host copies (kept: the self-test executes them on the CPU)
-    std::vector<DagTask> tasks;     // sorted by queue, inside a queue by remaining path: queue q owns tasks[slot_base[q] .. slot_base[q + 1])
-    std::vector<DagRun> succ;
-    std::vector<uint32_t> id2task;  // recorded number -> index in `tasks` (0xffffffff: no such task)
-    std::vector<uint32_t> state_init;
-    uint32_t slot_base[DAG_QUEUES + 1] = {};
-    uint32_t nids = 0, state_pending = 0, state_slots = 0, state_mail = 0;
+    std::vector<DagTask> tasks;     // in launch order (a topological order)
+    std::vector<DagRun> deps;
+    uint32_t nids = 0;
     double flops = 0.0;             // of the tile products (2 * tile^2 * k per task), as issued
     uint32_t n_products = 0, n_leaves = 0;
-    double sim_makespan_us = 0.0, sim_work_us = 0.0, critical_path_us = 0.0;   // list-scheduling simulation with the duration model (diagnostic)
+    double sim_makespan_us = 0.0, sim_work_us = 0.0, critical_path_us = 0.0;   // of the list-scheduling simulation (duration model)
     // device copies
     int device = -1;
     DagTask* d_tasks = nullptr;
-    DagRun* d_succ = nullptr;
-    uint32_t* d_id2task = nullptr;
-    uint32_t* d_state_init = nullptr;
+    DagRun* d_deps = nullptr;
     ~DagGraph();
 };
 
@@ -95,8 +81,8 @@ public:
     double* base(int b) const;      // the (fake) address the recording pass uses for buffer b
     void add_gemm(const GemmArgs& a, int akc, int bkc);
     void add_leaf(const double* A_tile, double* X_tile, int diag_tile);
-    // workers: concurrent workgroups the diagnostic simulation assumes
-    std::shared_ptr<DagGraph> finish(int workers);
+    // reorder: 0 = recorded order, 1 = list-scheduling order for `workers` concurrent workgroups
+    std::shared_ptr<DagGraph> finish(int reorder, int workers);
 
 private:
     struct Op {
@@ -116,27 +102,27 @@ private:
 
 struct DagLaunch {
     const DagTask* tasks;
-    const DagRun* succ;
-    const uint32_t* id2task;
-    uint32_t* state;                // this chain's copy of the graph's state image
-    uint32_t ntasks, state_pending, state_slots, state_mail;
-    uint32_t slot_base[DAG_QUEUES + 1];
+    const DagRun* deps;
+    uint32_t ntasks;
+    uint32_t epoch;
+    uint32_t* flags;
+    unsigned long long* ticket;     // device word, only ever incremented; `ticket_base` = its value when this launch starts
+    unsigned long long ticket_base;
+    int paranoid;                   // diagnostic (DNAGPU_DAG_PARANOID): every wave acquires again after the barrier
+    int workers;                    // workgroups of the launch (each takes tickets until they run out: ntasks + workers in all)
     double* buf0; double* buf1; double* buf2; double* buf3;
     int ld0, ld1, ld2, ld3;
     int* info;
-    unsigned long long* trace;      // diagnostic (DNAGPU_DAG_TRACE): per task 4 words -- wall clock (100 MHz) at start, with its task in hand, at the end; when its own work was done
+    unsigned long long* trace;      // diagnostic (DNAGPU_DAG_TRACE): per task 4 words -- wall clock (100 MHz) with the ticket, with the predecessors done, at the end; when its own work was done
 };
 void launch_tile_dag(const DagLaunch& L, hipStream_t s);
 
 // uploads g's arrays to the current device (once)
 hipError_t dag_upload(DagGraph& g);
 
-// CPU execution of a graph on host buffers with the device's own protocol (predecessor counters, successor runs, ready queues):
-// the dependency analysis must make every order the counters admit give the bits of the recorded order.
-//   order: 0 = the recorded order (must never meet a task whose counter is not zero), 1 = a random ready task, 2 = always the ready
-//          task recorded LAST (the most out-of-order execution the counters admit), 3 = the queues' own order (most urgent queue
-//          first, first in first out)
-// Returns false on a stall (tasks left, none ready), a counter that goes below zero or a queue that overflows.
+// CPU execution of a graph on host buffers (tests: the dependency analysis must make every order the flags admit give the bits of
+// the recorded order).  order: 0 = the list's own order (must be a topological order of its own flags), 1 = random among the ready
+// tasks, 2 = always the LAST ready task of the list (the most out-of-order execution the flags admit).  Returns false on a stall.
 bool dag_execute_host(const DagGraph& g, double* const buf[DAG_MAX_BUFS], const int ld[DAG_MAX_BUFS], int order, uint64_t seed);
 
 }  // namespace dnagpu

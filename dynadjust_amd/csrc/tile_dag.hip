@@ -106,6 +106,7 @@ inline float task_us(const DagTask& t) {
     const float nk = (float)(t.ke > t.kb ? t.ke - t.kb : 0);
     return (t.type & DAG_TILE64) ? 10.0f * nk : 8.0f + 22.0f * nk;
 }
+constexpr float DAG_HOP_US = 6.0f;
 
 // recorded numbers (sorted, unique) -> arithmetic runs
 void compress(const std::vector<uint32_t>& p, std::vector<DagRun>& out) {
@@ -116,7 +117,7 @@ void compress(const std::vector<uint32_t>& p, std::vector<DagRun>& out) {
             const uint32_t stride = p[i + 1] - p[i];
             if (stride <= 0xffffu) {
                 size_t j = i + 1;
-                while (j < p.size() && p[j] - p[j - 1] == stride && d.count < 64) {       // (one task per lane of the wave that walks the run)
+                while (j < p.size() && p[j] - p[j - 1] == stride && d.count < 64) {       // (one flag per lane of the wave that checks the run)
                     ++d.count;
                     ++j;
                 }
@@ -130,7 +131,7 @@ void compress(const std::vector<uint32_t>& p, std::vector<DagRun>& out) {
 
 }  // namespace
 
-std::shared_ptr<DagGraph> DagBuilder::finish(int workers) {
+std::shared_ptr<DagGraph> DagBuilder::finish(int reorder, int workers) {
     auto g = std::make_shared<DagGraph>();
     TileMap tiles[DAG_MAX_BUFS];
     for (int b = 0; b < DAG_MAX_BUFS; ++b) tiles[b].rows = std::max(1, ld_[b] / 128);
@@ -236,12 +237,23 @@ std::shared_ptr<DagGraph> DagBuilder::finish(int workers) {
     }
     g->nids = nids_;
     const size_t N = T.size();
+    // predecessors as runs of recorded numbers (what the device waits for)
+    for (size_t i = 0; i < N; ++i) {
+        preds.clear();
+        for (uint32_t q = pred_off[i]; q < pred_off[i + 1]; ++q) preds.push_back(T[pred_idx[q]].id);
+        std::sort(preds.begin(), preds.end());
+        T[i].dep0 = (uint32_t)g->deps.size();
+        compress(preds, g->deps);
+        T[i].ndep = (uint32_t)g->deps.size() - T[i].dep0;
+    }
 
-    // ---- critical-path lengths (the priorities) with the duration model ----
+    // ---- launch order: list scheduling with critical-path priorities ----
+    // a successor starts DAG_HOP_US after its last predecessor ended: release, flag, poll, acquire
     std::vector<float> dur(N), bl(N);
     for (size_t i = 0; i < N; ++i) {
-        bl[i] = dur[i] = task_us(T[i]);
-        g->sim_work_us += dur[i];
+        dur[i] = task_us(T[i]) + DAG_HOP_US;
+        bl[i] = dur[i];
+        g->sim_work_us += task_us(T[i]);
     }
     for (size_t i = N; i-- > 0;)
         for (uint32_t q = pred_off[i]; q < pred_off[i + 1]; ++q) {
@@ -249,91 +261,39 @@ std::shared_ptr<DagGraph> DagBuilder::finish(int workers) {
             bl[p] = std::max(bl[p], dur[p] + bl[i]);
         }
     for (size_t i = 0; i < N; ++i) g->critical_path_us = std::max(g->critical_path_us, (double)bl[i]);
-
-    // ---- successors (the device's view of the dependencies) ----
-    std::vector<uint32_t> succ_off(N + 1, 0), succ_idx(pred_idx.size()), indeg(N);
-    for (size_t i = 0; i < N; ++i) {
-        indeg[i] = pred_off[i + 1] - pred_off[i];
-        for (uint32_t q = pred_off[i]; q < pred_off[i + 1]; ++q) succ_off[pred_idx[q] + 1]++;
-    }
-    for (size_t i = 0; i < N; ++i) succ_off[i + 1] += succ_off[i];
-    {
-        std::vector<uint32_t> fill(succ_off.begin(), succ_off.end() - 1);
-        for (size_t i = 0; i < N; ++i)
-            for (uint32_t q = pred_off[i]; q < pred_off[i + 1]; ++q) succ_idx[fill[pred_idx[q]]++] = (uint32_t)i;      // (ascending i: recorded order)
-    }
-
-    // ---- ready queues: sixteen classes of remaining path, the longest first ----
-    const double cp = std::max(1.0, g->critical_path_us);
-    for (size_t i = 0; i < N; ++i) {
-        int q = (int)((1.0 - (double)bl[i] / cp) * DAG_QUEUES);
-        T[i].queue = (uint8_t)std::min(DAG_QUEUES - 1, std::max(0, q));
-    }
     std::vector<uint32_t> order(N);
     for (size_t i = 0; i < N; ++i) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        if (T[x].queue != T[y].queue) return T[x].queue < T[y].queue;
-        return bl[x] > bl[y];
-    });
-    std::vector<uint32_t> rec2task(N);
-    g->tasks.resize(N);
-    g->id2task.assign(nids_, 0xffffffffu);
-    for (size_t k = 0; k < N; ++k) {
-        g->tasks[k] = T[order[k]];
-        rec2task[order[k]] = (uint32_t)k;
-        g->id2task[T[order[k]].id] = (uint32_t)k;
-    }
-    for (int q = 0; q <= DAG_QUEUES; ++q) g->slot_base[q] = 0;
-    for (size_t k = 0; k < N; ++k) g->slot_base[g->tasks[k].queue + 1]++;
-    for (int q = 0; q < DAG_QUEUES; ++q) g->slot_base[q + 1] += g->slot_base[q];
-    std::vector<uint32_t> ids;
-    for (size_t k = 0; k < N; ++k) {
-        const uint32_t i = order[k];
-        ids.clear();
-        for (uint32_t q = succ_off[i]; q < succ_off[i + 1]; ++q) ids.push_back(T[succ_idx[q]].id);
-        std::sort(ids.begin(), ids.end());
-        g->tasks[k].succ0 = (uint32_t)g->succ.size();
-        compress(ids, g->succ);
-        g->tasks[k].nsucc = (uint32_t)g->succ.size() - g->tasks[k].succ0;
-    }
-
-    // ---- the state image a launch starts from ----
-    g->state_pending = DAG_STATE_FIXED;
-    g->state_slots = g->state_pending + nids_;
-    g->state_mail = g->state_slots + (uint32_t)N;
-    g->state_init.assign((size_t)g->state_mail + N, 0u);
-    for (int q = 0; q <= DAG_QUEUES; ++q) g->state_init[2 * DAG_QUEUES + q] = g->slot_base[q];
-    for (size_t i = 0; i < N; ++i) g->state_init[g->state_pending + T[i].id] = indeg[i];
-    for (size_t k = 0; k < N; ++k)
-        if (!indeg[order[k]]) {
-            const int q = g->tasks[k].queue;
-            uint32_t& tail = g->state_init[DAG_QUEUES + q];
-            g->state_init[g->state_slots + g->slot_base[q] + tail] = (uint32_t)k + 1;
-            ++tail;
-            ++g->state_init[DAG_STATE_BALANCE];              // tasks queued and not yet promised to a workgroup
+    if (reorder && N > 1) {
+        std::vector<uint32_t> succ_off(N + 1, 0), succ_idx(pred_idx.size()), indeg(N);
+        for (size_t i = 0; i < N; ++i) {
+            indeg[i] = pred_off[i + 1] - pred_off[i];
+            for (uint32_t q = pred_off[i]; q < pred_off[i + 1]; ++q) succ_off[pred_idx[q] + 1]++;
         }
-
-    // ---- diagnostic: list scheduling on `workers` workgroups with the duration model ----
-    if (N > 1) {
+        for (size_t i = 0; i < N; ++i) succ_off[i + 1] += succ_off[i];
+        {
+            std::vector<uint32_t> fill(succ_off.begin(), succ_off.end() - 1);
+            for (size_t i = 0; i < N; ++i)
+                for (uint32_t q = pred_off[i]; q < pred_off[i + 1]; ++q) succ_idx[fill[pred_idx[q]]++] = (uint32_t)i;
+        }
         struct Ready {
             float bl;
             uint32_t i;
-            bool operator<(const Ready& o) const { return bl != o.bl ? bl < o.bl : i > o.i; }
+            bool operator<(const Ready& o) const { return bl != o.bl ? bl < o.bl : i > o.i; }     // max-heap: longest path first, then recorded order
         };
         std::priority_queue<Ready> ready;
         typedef std::pair<double, uint32_t> Fin;
         std::priority_queue<Fin, std::vector<Fin>, std::greater<Fin>> running;
-        std::vector<uint32_t> left(indeg);
         for (size_t i = 0; i < N; ++i)
-            if (!left[i]) ready.push({bl[i], (uint32_t)i});
+            if (!indeg[i]) ready.push({bl[i], (uint32_t)i});
+        order.clear();
+        order.reserve(N);
         double now = 0.0;
         int free_w = std::max(1, workers);
-        size_t started = 0;
-        while (started < N) {
+        while (order.size() < N) {
             while (free_w > 0 && !ready.empty()) {
                 const uint32_t i = ready.top().i;
                 ready.pop();
-                ++started;
+                order.push_back(i);
                 running.push({now + dur[i], i});
                 --free_w;
             }
@@ -344,7 +304,7 @@ std::shared_ptr<DagGraph> DagBuilder::finish(int workers) {
                 running.pop();
                 ++free_w;
                 for (uint32_t q = succ_off[i]; q < succ_off[i + 1]; ++q)
-                    if (--left[succ_idx[q]] == 0) ready.push({bl[succ_idx[q]], succ_idx[q]});
+                    if (--indeg[succ_idx[q]] == 0) ready.push({bl[succ_idx[q]], succ_idx[q]});
             }
         }
         while (!running.empty()) {
@@ -352,17 +312,23 @@ std::shared_ptr<DagGraph> DagBuilder::finish(int workers) {
             running.pop();
         }
         g->sim_makespan_us = now;
+        if (order.size() != N) {
+            order.resize(N);
+            for (size_t i = 0; i < N; ++i) order[i] = (uint32_t)i;
+        }
     }
+    g->tasks.resize(N);
+    for (size_t k = 0; k < N; ++k) g->tasks[k] = T[order[k]];
     return g;
 }
 
 DagGraph::~DagGraph() {
-    if (d_tasks || d_succ || d_id2task || d_state_init) {
+    if (d_tasks || d_deps) {
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (device >= 0 && device != cur) (void)hipSetDevice(device);
-        for (void* p : {(void*)d_tasks, (void*)d_succ, (void*)d_id2task, (void*)d_state_init})
-            if (p) (void)hipFree(p);
+        if (d_tasks) (void)hipFree(d_tasks);
+        if (d_deps) (void)hipFree(d_deps);
         if (device >= 0 && device != cur) (void)hipSetDevice(cur);
     }
 }
@@ -371,16 +337,11 @@ hipError_t dag_upload(DagGraph& g) {
     if (g.d_tasks) return hipSuccess;
     hipError_t e = hipGetDevice(&g.device);
     if (e != hipSuccess) return e;
-    auto up = [&](auto*& dev, const auto& host) {
-        typedef typename std::remove_reference<decltype(host)>::type::value_type V;
-        hipError_t r = hipMalloc(&dev, std::max<size_t>(1, host.size()) * sizeof(V));
-        if (r == hipSuccess && !host.empty()) r = hipMemcpy(dev, host.data(), host.size() * sizeof(V), hipMemcpyHostToDevice);
-        return r;
-    };
-    if ((e = up(g.d_tasks, g.tasks)) != hipSuccess) return e;
-    if ((e = up(g.d_succ, g.succ)) != hipSuccess) return e;
-    if ((e = up(g.d_id2task, g.id2task)) != hipSuccess) return e;
-    return up(g.d_state_init, g.state_init);
+    if ((e = hipMalloc(&g.d_tasks, std::max<size_t>(1, g.tasks.size()) * sizeof(DagTask))) != hipSuccess) return e;
+    if ((e = hipMalloc(&g.d_deps, std::max<size_t>(1, g.deps.size()) * sizeof(DagRun))) != hipSuccess) return e;
+    if (!g.tasks.empty() && (e = hipMemcpy(g.d_tasks, g.tasks.data(), g.tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if (!g.deps.empty() && (e = hipMemcpy(g.d_deps, g.deps.data(), g.deps.size() * sizeof(DagRun), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -394,88 +355,77 @@ __global__ __launch_bounds__(256, 2) void tile_dag_kernel(DagLaunch L) {
     __shared__ __attribute__((aligned(16))) double lds0[2 * G::OPBUF];
     __shared__ __attribute__((aligned(16))) double lds1[2 * G::OPBUF + 16];
     __shared__ __attribute__((aligned(16))) double lds2[3 * leaf::BS];
-    __shared__ uint32_t s_task;
+    __shared__ uint32_t s_ticket;
     static_assert(2 * G::OPBUF == 256 + 16 * leaf::BS && 2 * G::OPBUF + 16 == 17 * leaf::BS, "leaf blocks in the operand buffers");
     const int tid = threadIdx.x;
-    unsigned long long t_start = 0;
-    if (L.trace && tid == 0) t_start = wall_clock64();
-
-    // ---- take ONE ready task (wave 0) ----
-    // `balance` = tasks put into the queues minus workgroups arrived, changed by ONE atomic per arrival and per ready task, which
-    // puts all of them into one order.  A workgroup that finds it positive has a queue entry to itself (it may have to look twice
-    // until the entry's writer is done); one that finds it <= 0 is the w-th workgroup to wait and the w-th task that becomes ready
-    // while somebody waits is written straight into its own mailbox word -- nobody ever polls a word that others poll too.
-    uint32_t* const heads = L.state;
-    uint32_t* const tails = L.state + DAG_QUEUES;
-    if (tid < 64) {
-        uint32_t task = 0xffffffffu;
-        int old = 0;
-        uint32_t w = 0;
-        if (tid == 0) {
-            old = __hip_atomic_fetch_sub((int*)(L.state + DAG_STATE_BALANCE), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old <= 0) w = __hip_atomic_fetch_add(L.state + DAG_STATE_WAITERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        old = __builtin_amdgcn_readfirstlane(old);
-        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-        long spins = 0;
-        if (old > 0) {
-            for (;;) {
-                uint32_t h = 0, tl = 0;
-                if (tid < DAG_QUEUES) {
-                    h = __hip_atomic_load(heads + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    tl = __hip_atomic_load(tails + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                const unsigned long long avail = __ballot(tid < DAG_QUEUES && (int32_t)(tl - h) > 0);
-                if (avail) {
-                    const int q = __builtin_ctzll(avail);                  // the most urgent queue with an entry
-                    const uint32_t hq = (uint32_t)__builtin_amdgcn_readlane((int)h, q);
-                    int won = 0;
-                    if (tid == 0) won = atomicCAS(heads + q, hq, hq + 1) == hq;
-                    if (__builtin_amdgcn_readfirstlane(won)) {
-                        const uint32_t* slot = L.state + L.state_slots + L.state[2 * DAG_QUEUES + q] + hq;
-                        uint32_t v;
-                        while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(1);
-                        task = v - 1;
-                        break;
-                    }
-                    continue;                                               // another workgroup was faster: look again
-                }
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1L << 22)) {
-                    if (tid == 0) atomicMin(L.info, INFO_BARRIER_TIMEOUT);
-                    break;
-                }
-            }
-        } else {
-            const uint32_t* mail = L.state + L.state_mail + w;
-            uint32_t v;
-            while ((v = __hip_atomic_load(mail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-                __builtin_amdgcn_s_sleep(4);
-                ++spins;
-                // seconds without a task: one never finished (a bug, or a workgroup of this launch that died).  The first workgroup to give
-                // up says so in `info`, the others see that and give up too: the launch ends with a void result instead of hanging
-                if (spins > (1L << 22) || ((spins & 1023) == 0 && __hip_atomic_load(L.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == INFO_BARRIER_TIMEOUT)) {
-                    if (tid == 0) atomicMin(L.info, INFO_BARRIER_TIMEOUT);
-                    break;
-                }
-            }
-            if (v) task = v - 1;
-        }
-        if (tid == 0) s_task = task;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // this CU's L1 forgets what it held of the predecessors' tiles
-    }
+    // A persistent worker: one task per round, until the tickets run out.  Thread 0 takes the next ticket in the SAME block in which it
+    // publishes the finished task, at the end of the round, and a round begins with the barrier: with the two thread-0 blocks on either
+    // side of the loop's back edge the compiler fused them and sent the other lanes round an inner loop of their own -- the waves then
+    // met the barriers a different number of times (a hang on the device; nothing a one-task-per-workgroup kernel would ever show).
+    if (tid == 0) s_ticket = (uint32_t)(atomicAdd(L.ticket, 1ULL) - L.ticket_base);
+    for (;;) {
     __syncthreads();
-    const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_task);
+    const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
     if (ticket >= L.ntasks) return;
-    const DagTask* tp = L.tasks + ticket;
-    const uint32_t a_off = tp->a_off, b_off = tp->b_off, c_off = tp->c_off;
-    const int it = tp->it, jt = tp->jt, kb = tp->kb, ke = tp->ke;
-    const int type = tp->type, bufs = tp->bufs, flags = tp->flags;
-    const uint32_t succ0 = tp->succ0, nsucc = tp->nsucc;
-    if (L.trace && tid == 0) {
-        L.trace[4 * (size_t)ticket] = t_start;
-        L.trace[4 * (size_t)ticket + 1] = wall_clock64();
+    // the task's nine words in ONE round trip (lane l fetches word l), broadcast by readlane
+    static_assert(sizeof(DagTask) == 36, "nine words");
+    uint32_t word = 0;
+    if ((tid & 63) < 9) word = reinterpret_cast<const uint32_t*>(L.tasks + ticket)[tid & 63];
+    auto field = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)word, i); };
+    const uint32_t a_off = field(0), b_off = field(1), c_off = field(2);
+    const int it = (int)(field(3) & 0xffffu), jt = (int)(field(3) >> 16), kb = (int)(field(4) & 0xffffu), ke = (int)(field(4) >> 16);
+    const int type = (int)(field(5) & 0xffu), bufs = (int)((field(5) >> 8) & 0xffu), flags = (int)((field(5) >> 16) & 0xffu);
+    const uint32_t my_flag = field(6), dep0 = field(7), ndep = field(8);
+    if (L.trace && tid == 0) L.trace[4 * (size_t)ticket] = wall_clock64();
+
+    // ---- wait for the predecessors (wave 0).  A run has at most 64 flags: one per lane.  The runs' descriptors come 64 at a time (lane l
+    // fetches run l), the flags of eight runs are on their way before the first is looked at: a check of everything costs two or
+    // three round trips, not two per run -- on the critical path that is the larger part of a hop. ----
+    if (ndep) {
+        if (tid < 64) {
+            long spins = 0;
+            for (;;) {
+                bool ok = true;
+                for (uint32_t r0 = 0; r0 < ndep; r0 += 64) {
+                    uint32_t first = 0, cs = 0;                              // count | stride << 16
+                    if (r0 + (uint32_t)tid < ndep) {
+                        const uint32_t* d = reinterpret_cast<const uint32_t*>(L.deps + dep0 + r0 + tid);
+                        first = d[0];
+                        cs = d[1];
+                    }
+                    const uint32_t nr = ndep - r0 < 64u ? ndep - r0 : 64u;
+                    for (uint32_t j0 = 0; j0 < nr; j0 += 8) {
+                        uint32_t v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            v[j] = L.epoch;
+                            if (j0 + j < nr) {
+                                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)first, j0 + j);
+                                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cs, j0 + j);
+                                if ((uint32_t)tid < (c & 0xffffu))
+                                    v[j] = __hip_atomic_load(L.flags + f + (uint32_t)tid * (c >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ok = ok && v[j] == L.epoch;
+                    }
+                }
+                if (!__ballot(!ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                ++spins;
+                // seconds without a flag: a predecessor never finished.  The first worker to give up says so in `info`, the others see
+                // that and stop waiting too: the launch ends (with a void result) instead of hanging
+                if (spins > (1L << 21) || ((spins & 255) == 0 && __hip_atomic_load(L.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == INFO_BARRIER_TIMEOUT)) {
+                    if (tid == 0) atomicMin(L.info, INFO_BARRIER_TIMEOUT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // this CU's L1 forgets what it held of the predecessors' tiles
+        }
+        __syncthreads();
+        if (L.paranoid) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (diagnostic: every wave, after the barrier)
     }
+    if (L.trace && tid == 0) L.trace[4 * (size_t)ticket + 1] = wall_clock64();
     auto buf = [&](int b) -> double* { return b == 0 ? L.buf0 : (b == 1 ? L.buf1 : (b == 2 ? L.buf2 : L.buf3)); };
     auto ldof = [&](int b) -> int { return b == 0 ? L.ld0 : (b == 1 ? L.ld1 : (b == 2 ? L.ld2 : L.ld3)); };
     const int ab = bufs & 3, bb = (bufs >> 2) & 3, cb = (bufs >> 4) & 3;
@@ -504,53 +454,23 @@ __global__ __launch_bounds__(256, 2) void tile_dag_kernel(DagLaunch L) {
         }
     }
 
-    // ---- publish: every wave's stores have left, then ONE release at agent scope, then the successors hear of it ----
+    // ---- publish: every wave's stores have left, then ONE release at agent scope, then the flag ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < 64) {
-        if (L.trace && tid == 0) L.trace[4 * (size_t)ticket + 3] = wall_clock64();      // the task's own work ends here
+    __syncthreads();                             // (also: every wave is done with the LDS before the next task's operands land in it)
+    if (tid == 0) {
+        if (L.trace) L.trace[4 * (size_t)ticket + 3] = wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // Sixteen runs at a time (a run has at most 64 tasks: one per lane): the decrements of all of them are on their way before
-        // the first answer is looked at -- one round trip to the counters per sixteen runs, not per run
-        uint32_t* const pending = L.state + L.state_pending;
-        for (uint32_t r0 = 0; r0 < nsucc; r0 += 16) {
-            uint32_t was[16], ids[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                was[j] = 0;
-                ids[j] = 0;
-                if (r0 + j < nsucc) {
-                    const DagRun R = L.succ[succ0 + r0 + j];
-                    if ((uint32_t)tid < R.count) {
-                        ids[j] = R.first + (uint32_t)tid * (uint32_t)R.stride;
-                        was[j] = __hip_atomic_fetch_sub(pending + ids[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (was[j] != 1u) continue;
-                // the last predecessor: the successor is ready
-                const uint32_t t = L.id2task[ids[j]];
-                if (__hip_atomic_fetch_add((int*)(L.state + DAG_STATE_BALANCE), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
-                    // a workgroup is waiting: the task goes straight to the next unserved one's mailbox
-                    const uint32_t hnd = __hip_atomic_fetch_add(L.state + DAG_STATE_HANDOFFS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(L.state + L.state_mail + hnd, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    const uint32_t q = L.tasks[t].queue;
-                    const uint32_t pos = __hip_atomic_fetch_add(tails + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(L.state + L.state_slots + L.state[2 * DAG_QUEUES + q] + pos, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if (L.trace && tid == 0) L.trace[4 * (size_t)ticket + 2] = wall_clock64();
+        __hip_atomic_store(L.flags + my_flag, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (L.trace) L.trace[4 * (size_t)ticket + 2] = wall_clock64();
+        s_ticket = (uint32_t)(atomicAdd(L.ticket, 1ULL) - L.ticket_base);      // (the others read the old one before the barrier above)
     }
+    }   // worker loop
 }
 
 void launch_tile_dag(const DagLaunch& L, hipStream_t s) {
-    if (!L.ntasks) return;
-    hipLaunchKernelGGL(tile_dag_kernel, dim3(L.ntasks), dim3(256), 0, s, L);
+    if (!L.ntasks || L.workers <= 0) return;
+    hipLaunchKernelGGL(tile_dag_kernel, dim3(L.workers), dim3(256), 0, s, L);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -626,73 +546,49 @@ void host_task(const DagTask& t, double* const buf[DAG_MAX_BUFS], const int ld[D
 
 bool dag_execute_host(const DagGraph& g, double* const buf[DAG_MAX_BUFS], const int ld[DAG_MAX_BUFS], int order, uint64_t seed) {
     const size_t N = g.tasks.size();
-    std::vector<uint32_t> st(g.state_init);                  // the device's state words, used the way the kernel uses them
-    uint32_t* heads = st.data();
-    uint32_t* tails = st.data() + DAG_QUEUES;
-    const uint32_t* slot_base = st.data() + 2 * DAG_QUEUES;
-    uint32_t* pending = st.data() + g.state_pending;
-    uint32_t* slots = st.data() + g.state_slots;
-    std::vector<uint8_t> ran(N, 0);
+    std::vector<uint8_t> done(g.nids, 0), ran(N, 0);
+    auto is_ready = [&](const DagTask& t) {
+        for (uint32_t d = 0; d < t.ndep; ++d) {
+            const DagRun& D = g.deps[t.dep0 + d];
+            for (uint32_t c = 0; c < D.count; ++c)
+                if (!done[D.first + c * D.stride]) return false;
+        }
+        return true;
+    };
     uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
     auto next = [&] {
         rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
         return rng;
     };
-    std::vector<uint32_t> by_id(N);                          // tasks in recorded order
-    for (size_t k = 0; k < N; ++k) by_id[k] = (uint32_t)k;
-    std::sort(by_id.begin(), by_id.end(), [&](uint32_t x, uint32_t y) { return g.tasks[x].id < g.tasks[y].id; });
-    // ready tasks not yet run, as the queues know them (entries put and not taken)
-    auto finish = [&](uint32_t k) -> bool {
-        const DagTask& t = g.tasks[k];
-        for (uint32_t r = 0; r < t.nsucc; ++r) {
-            const DagRun& R = g.succ[t.succ0 + r];
-            for (uint32_t c = 0; c < R.count; ++c) {
-                const uint32_t id = R.first + c * R.stride;
-                if (id >= g.nids || pending[id] == 0) return false;
-                if (--pending[id] == 0) {
-                    const uint32_t s = g.id2task[id];
-                    if (s == 0xffffffffu) return false;
-                    const uint32_t q = g.tasks[s].queue;
-                    if (slot_base[q] + tails[q] >= slot_base[q + 1]) return false;
-                    slots[slot_base[q] + tails[q]++] = s + 1;
+    size_t n_run = 0;
+    while (n_run < N) {
+        size_t pick = N;
+        if (order == 0) {
+            pick = n_run;
+            if (!is_ready(g.tasks[pick])) return false;       // the list is not a topological order of its own flags
+        } else if (order == 2) {
+            for (size_t i = N; i-- > 0;)
+                if (!ran[i] && is_ready(g.tasks[i])) {
+                    pick = i;
+                    break;
                 }
-            }
-        }
-        return true;
-    };
-    for (size_t n_run = 0; n_run < N; ++n_run) {
-        uint32_t pick = 0xffffffffu;
-        if (order == 3) {
-            for (int q = 0; q < DAG_QUEUES && pick == 0xffffffffu; ++q)
-                if (heads[q] < tails[q]) pick = slots[slot_base[q] + heads[q]++] - 1;
         } else {
-            // every entry between a queue's head and tail that has not run yet is ready
-            std::vector<uint32_t> rd;
-            for (int q = 0; q < DAG_QUEUES; ++q)
-                for (uint32_t p = 0; p < tails[q]; ++p) {
-                    const uint32_t k = slots[slot_base[q] + p] - 1;
-                    if (!ran[k]) rd.push_back(k);
-                }
-            if (order == 0) {
-                pick = by_id[n_run];
-                if (std::find(rd.begin(), rd.end(), pick) == rd.end()) return false;      // the recorded order itself violates a counter
-            } else if (!rd.empty()) {
-                if (order == 2) {
-                    pick = rd[0];
-                    for (uint32_t k : rd)
-                        if (g.tasks[k].id > g.tasks[pick].id) pick = k;
-                } else {
-                    pick = rd[next() % rd.size()];
-                }
+            std::vector<size_t> rd;
+            if (next() & 1) {
+                for (size_t i = 0; i < N && rd.size() < 64; ++i)
+                    if (!ran[i] && is_ready(g.tasks[i])) rd.push_back(i);
+            } else {
+                for (size_t i = N; i-- > 0 && rd.size() < 64;)
+                    if (!ran[i] && is_ready(g.tasks[i])) rd.push_back(i);
             }
+            if (!rd.empty()) pick = rd[next() % rd.size()];
         }
-        if (pick == 0xffffffffu || pick >= N || ran[pick]) return false;       // a stall: tasks left, none ready
+        if (pick == N) return false;                            // nothing ready: a cycle
         host_task(g.tasks[pick], buf, ld);
         ran[pick] = 1;
-        if (!finish(pick)) return false;
+        done[g.tasks[pick].id] = 1;
+        ++n_run;
     }
-    for (size_t i = 0; i < g.nids; ++i)
-        if (pending[i]) return false;
     return true;
 }
 

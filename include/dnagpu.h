@@ -114,16 +114,18 @@ int dnagpu_fused_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* products);
 int dnagpu_set_fused_launches(dnagpu_ctx* ctx, int on);
 
 /* The tile-DAG path (csrc/tile_dag.h, default on; DNAGPU_DAG=0): every inverse / elimination / completion goes out as ONE launch whose
- * workgroups execute the recorded tile tasks of the whole recursion as a dataflow graph (predecessor counters, ready queues ordered
- * by critical-path length) instead of one launch per product and leaf (dpotrf / dpotri of dnamatrix_contiguous.cpp:982-1006).
+ * persistent workgroups execute the recorded tile tasks of the whole recursion, ordered by a list-scheduling simulation and
+ * synchronised by completion flags, instead of one launch per product and leaf (dpotrf / dpotri of dnamatrix_contiguous.cpp:982-1006).
  * dnagpu_debug_set_tile_dag: process-wide switch, returns the previous value.  dnagpu_tile_dag_stats: launches / tasks since the context
  * was created.  dnagpu_debug_tile_dag_selftest: CPU-only check of the dependency analysis for the sequence `kind` (1 inverse, 2 schur,
  * 3 schur-keep, 4 complete(what), 5 spine, 6 spine-kept, 7 spine-finish) on ti + tj tiles: the tasks are executed on host buffers in the
- * recorded order and -- with the device's own counters and queues -- in a random admissible order, the most out-of-order one and the
- * queues' own order; returns how many of those differ from the recorded order in any bit (0 = pass), -1 on a stall.  stats6: tasks,
- * successor runs, flops, simulated makespan,
+ * recorded order and in the launch order, a random admissible order and the most out-of-order one the flags admit; returns how many of
+ * those differ from the recorded order in any bit (0 = pass), -1 on a stall.  stats6: tasks, dependency runs, flops, simulated makespan,
  * critical path, summed task time (microseconds). */
 int dnagpu_debug_set_tile_dag(int on);
+/* workgroups a DAG launch of this context uses (0 = default 512: what the GPU holds of the kernel).  A host that runs c chains side by
+ * side gives each 512 / c, so that one chain's waiting workers cannot take the others' slots */
+int dnagpu_set_tile_dag_workers(dnagpu_ctx* ctx, int workers);
 int dnagpu_tile_dag_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* tasks);
 int dnagpu_debug_tile_dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats6);
 

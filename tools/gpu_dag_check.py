@@ -29,9 +29,9 @@ def main():
             ref = {}
             for dag in (0, 1):
                 ctx.lib.dnagpu_debug_set_tile_dag(dag)
-                for what in ("inverse", "eliminate"):
+                for what in (os.environ.get("DAG_CHECK_WHAT", "inverse,eliminate").split(",")):
                     times = []
-                    for rep in range(3):
+                    for rep in range(int(os.environ.get("DAG_CHECK_REPS", "3"))):
                         m.upload_packed(ap, n)
                         ctx.sync()
                         t0 = time.perf_counter()

@@ -1,11 +1,8 @@
 #!/bin/bash
-# the job of the moment for `gpurun -- bash tools/gpu_job.sh` (edited per measurement)
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out/trace
+mkdir -p gpurun_out
 export GPU_MAX_HW_QUEUES=16
-{ DNAGPU_DAG_TRACE=gpurun_out/trace/bench timeout 600 python tools/gpu_inverse_bench.py 6656
-  python tools/dag_trace_report.py gpurun_out/trace/bench.0003.bin gpurun_out/trace/bench.0007.bin
-  rm -f gpurun_out/trace/*.bin
-} > gpurun_out/dag_trace.log 2>&1
-rm -f gpurun_out/trace/*.bin
-tail -n 90 gpurun_out/dag_trace.log
+timeout 900 python -m pytest tests/test_gpu_distributed.py tests/test_tile_dag.py tests/test_boundary_cpp.py tests/test_gpu_multi.py "tests/test_gpu_adjust.py::test_bench_distributed_path_over_rccl" -q -m gpu --durations=5 > gpurun_out/t_part.log 2>&1
+echo "part rc=$?" > gpurun_out/job.status
+tail -n 40 gpurun_out/t_part.log
+cat gpurun_out/job.status
