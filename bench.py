@@ -47,27 +47,32 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma
 def traffic_from_profile(workload):
     """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process, so this is
     the figure of the committed `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
-    (profiles/r0N_hbm_traffic.json, made by tools/pmc_traffic_json.py); null for workloads without such a pass."""
+    (profiles/r0N_hbm_traffic.json, made by tools/pmc_traffic_json.py) -- quoted only while the device sources still are the ones
+    the passes were made with (their hash is in the record): (bytes, note)"""
     import glob
+    from tools.pmc_traffic_json import csrc_sha16
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # newest round first
         try:
             rec = json.load(open(path))
-            if rec.get("workload") == workload:
-                return rec["hbm_bytes_per_launch"]
+            if rec.get("workload") != workload:
+                continue
+            if rec.get("csrc_sha16") != csrc_sha16():
+                return None, f"{os.path.basename(path)} predates the last change to dynadjust_amd/csrc (tools/refresh_profiles.sh makes a new one): not quoted"
+            return rec["hbm_bytes_per_launch"], f"{os.path.basename(path)} (device sources {rec['csrc_sha16']})"
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, "no PMC pass of this workload under profiles/"
 
 
-def one_chain_frac_from_profile(workload):
-    """end-to-end roofline fraction of the committed one-chain run of this workload (no overlap between block steps):
-    profiles/r0N_bench_<workload>_one_chain.json, newest round first; null without one"""
+def _full_run_record(workload):
+    """profiles/r0N_oracle_<workload>_run.json: the CPU restatement over the whole workload, once, on a GPU box's host (newest round first)"""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}_one_chain.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_oracle_{workload}_run.json")), reverse=True):
         try:
             rec = json.load(open(path))
-            return rec["cholesky_tflops"] / FP64_MFMA_PEAK_TFLOPS
-        except (OSError, ValueError, KeyError):
+            return {"file": os.path.relpath(path, ROOT), "seconds": rec.get("oracle_seconds"), "tflops_reference_equivalent": rec.get("oracle_tflops"),
+                    "threads": rec.get("oracle_threads"), "lapack": rec.get("lapack"), "solves": rec.get("oracle_solves")}
+        except (OSError, ValueError):
             continue
     return None
 
@@ -90,6 +95,85 @@ def cpu_baseline(workload, iterations, solves_per_step, sum_n3_per_step, station
         return {"value": None, "unit": "stations/s", "cores": 0, "kind": "port", "sample": "failed: " + (out.stderr or out.stdout)[-300:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "stations/s", "cores": 0, "kind": "port", "sample": "timed out after 600 s"}
+
+
+def _cpu_baseline_role(role, folder, lapack_path, threads, cores):
+    """One of the two passes of the reference's --multi-thread schedule (dnaadjust-multi.cpp:92-244) as a PROCESS of its own: pinned to
+    `cores`, its LAPACK on `threads` threads.  "fwd" times the forward pass; "rev" runs a forward pass first (untimed: the reverse +
+    combination pass starts from the forward results) and times the reverse + combination pass.  Both wait for <folder>/go so that the
+    timed passes run side by side.  Prints one JSON line."""
+    from tests import oracle
+    if cores:
+        try:
+            os.sched_setaffinity(0, set(cores))
+        except OSError:
+            pass
+    lib = oracle.load()
+    oracle.use_lapack(lapack_path)
+    lib.orc_set_threads(threads)
+    net = oracle.Network(os.path.join(folder, "cpu"), True)
+    o = oracle.Adjustment(net, True, threads=0)
+    o.prepare()
+    s0 = n0 = 0
+    if role == "rev":
+        if lib.orc_adjust_forward_pass(o.h):
+            raise RuntimeError(lib.orc_adjust_error(o.h).decode())
+        s0, n0 = o.solve_stats()
+    open(os.path.join(folder, "ready." + role), "w").close()
+    t_wait = time.perf_counter()
+    while not os.path.exists(os.path.join(folder, "go")):
+        time.sleep(0.005)
+        if time.perf_counter() - t_wait > 600:
+            raise RuntimeError("the other pass never became ready")
+    t0 = time.perf_counter()
+    rc = lib.orc_adjust_forward_pass(o.h) if role == "fwd" else lib.orc_adjust_reverse_pass(o.h)
+    dt = time.perf_counter() - t0
+    if rc:
+        raise RuntimeError(lib.orc_adjust_error(o.h).decode())
+    s1, n1 = o.solve_stats()
+    print(json.dumps({"role": role, "seconds": dt, "solves": int(s1 - s0), "n3": n1 - n0, "t_start": t0, "t_end": t0 + dt}), flush=True)
+    o.close()
+
+
+def _cpu_multi_thread_by_processes(folder, lapack_path, threads):
+    """forward pass || reverse + combination pass as two pinned processes with half of the tuned LAPACK threads each (a LAPACK without
+    per-thread control -- OpenBLAS -- cannot be split inside one process).  Returns (wall seconds, sum n^3, Solve() calls, note)."""
+    import subprocess
+    half = max(1, threads // 2)
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    sets = [avail[:half], avail[half:2 * half]] if len(avail) >= 2 * half else [None, None]
+    for f in ("go", "ready.fwd", "ready.rev"):
+        try:
+            os.remove(os.path.join(folder, f))
+        except OSError:
+            pass
+    env = dict(os.environ, MKL_THREADING_LAYER="GNU", OPENBLAS_NUM_THREADS=str(half), OMP_NUM_THREADS=str(half))
+    procs = []
+    for role, cores in zip(("fwd", "rev"), sets):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-role", role, "--cpu-args", json.dumps([folder, lapack_path, half, cores])]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.perf_counter()
+    while not (os.path.exists(os.path.join(folder, "ready.fwd")) and os.path.exists(os.path.join(folder, "ready.rev"))):
+        if any(p.poll() is not None for p in procs) or time.perf_counter() - t0 > 600:
+            for p in procs:
+                p.kill()
+            raise RuntimeError("a pass of the multi-thread schedule did not start: " + " | ".join((p.stderr.read() or "")[-200:] for p in procs))
+        time.sleep(0.01)
+    open(os.path.join(folder, "go"), "w").close()
+    recs = []
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        line = [l for l in out.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            raise RuntimeError("a pass of the multi-thread schedule failed: " + (err or out)[-300:])
+        recs.append(json.loads(line[-1]))
+    wall = max(r["t_end"] for r in recs) - min(r["t_start"] for r in recs)      # (both clocks are this host's monotonic clock)
+    note = (f"forward pass || reverse + combination pass as two processes pinned to disjoint sets of {half} cores, {half} LAPACK threads each "
+            f"(forward {recs[0]['seconds']:.1f} s, reverse + combination {recs[1]['seconds']:.1f} s)")
+    return wall, recs[0]["n3"] + recs[1]["n3"], recs[0]["solves"] + recs[1]["solves"], note
 
 
 def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step, stations):
@@ -204,6 +288,14 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
         schedule, dt, n3, solves = "multi-thread", dt_mt, n3_mt, solves_mt
         mt_rate = n3_mt / dt_mt
         note = f"forward || reverse+combination on two threads x {half} LAPACK threads"
+    elif phased and path and threads >= 2:
+        # no per-thread control (OpenBLAS): the two passes as two pinned processes
+        try:
+            dt_mt, n3_mt, solves_mt, note = _cpu_multi_thread_by_processes(d, path, threads)
+            schedule, dt, n3, solves = "multi-thread", dt_mt, n3_mt, solves_mt
+            mt_rate = n3_mt / dt_mt
+        except Exception as e:      # noqa: BLE001  (the sequential schedule below is measured either way)
+            note = f"multi-thread schedule not measured ({e}); "
     # the sequential schedule on all tuned threads (the only one without per-thread LAPACK control)
     o = new_adjustment()
     lib.orc_set_threads(threads) if path else None
@@ -213,10 +305,9 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
     s_seq, n3_seq = o.solve_stats()
     o.close()
     seq_rate = n3_seq / dt_seq
+    mt_note = note
     if dt is None or n3 / dt < seq_rate:
-        note = (f"multi-thread schedule measured slower ({n3 / dt / 1e12:.3f} TFLOP/s) than " if dt else "") + f"sequential passes on {threads} LAPACK threads"
-        if dt:
-            note += ")"
+        note = (f"multi-thread schedule measured slower ({n3 / dt / 1e12:.3f} TFLOP/s: {mt_note}) than " if dt else mt_note) + f"sequential passes on {threads} LAPACK threads"
         schedule, dt, n3, solves = "sequential", dt_seq, n3_seq, s_seq
     oracle.use_lapack(None)
     cpu_flops = n3 / dt
@@ -240,6 +331,9 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
         "tflops_reference_equivalent": cpu_flops / 1e12,
         "tflops_sequential_schedule": seq_rate / 1e12,
         "tflops_multi_thread_schedule": None if mt_rate is None else mt_rate / 1e12,
+        "multi_thread_schedule": mt_note or None,
+        # the same restatement run over the WHOLE workload once (committed record: not re-run here, it takes minutes to hours)
+        "full_run_record": _full_run_record(workload),
     }
 
 
@@ -498,10 +592,15 @@ def main():
                     help="BASELINE.json configs[4]: the timed step also propagates the rigorous variances to every adjusted measurement "
                          "(GenerateStatistics: precisions of the adjusted measurements A S A^T from the resident variance matrices, chi-square, "
                          "sigma-zero, N-statistics) -- with `--workload cfg4` on 8 GPUs that is configs[4]")
+    ap.add_argument("--no-one-chain", action="store_true", help="skip the extra one-chain step behind roofline.frac_one_chain")
     ap.add_argument("--no-gemm-events", action="store_true", help="diagnostic: no HIP events around the GEMM launches (roofline.achieved = 0)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-role", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_role:
+        _cpu_baseline_role(args.cpu_baseline_role, *json.loads(args.cpu_args))
+        return
     if args.cpu_baseline_only:
         print(json.dumps(_cpu_baseline_sample(args.workload, *json.loads(args.cpu_args))), flush=True)
         return
@@ -668,8 +767,9 @@ def main():
             # latency-bound remainder (leaves, launch gaps); the same flops over the WHOLE step, and the committed one-chain run
             # (nothing overlapped: profiles/), say what that remainder costs
             "frac_end_to_end": (alg / 1e12) / (ms_per_step / 1e3) / FP64_MFMA_PEAK_TFLOPS,
-            "frac_one_chain": one_chain_frac_from_profile(args.workload),
-            "traffic": traffic_from_profile(args.workload),
+            "frac_one_chain": None,           # filled below: the same step on ONE chain, timed in this run
+            "traffic": traffic_from_profile(args.workload)[0],
+            "traffic_source": traffic_from_profile(args.workload)[1],
             "traffic_unit": "bytes per launch (memory-side, FETCH_SIZE x 2 + WRITE_SIZE from the committed rocprofv3 --pmc passes of this workload)",
             # tile-GEMM products per step; of them `fused_products_per_step` went out in `fused_launches_per_step` launches of the
             # persistent kernel (runs of dependent small products, device-wide barriers in between) instead of one launch each
@@ -693,10 +793,33 @@ def main():
                         "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()]}
     except Exception as e:                       # diagnostic only
         out["check"] = {"error": str(e)}
+    a.close()
+    # what the chains' overlap hides: the same step with ONE chain (nothing overlapped), one warm-up and one timed step, measured here
+    if p.multi_thread and not args.no_one_chain:
+        try:
+            a1 = adjust.DnaAdjust()
+            p1 = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode, multi_thread=False, device=local_rank, reuse_inverses=p.reuse_inverses,
+                                        schur_carry=p.schur_carry, keep_factors=p.keep_factors, defer_variances=p.defer_variances, stage=p.stage)
+            a1.PrepareAdjustment(p1)
+            for timed in (False, True):
+                a1.ResetAdjustment()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if a1.AdjustNetwork() != adjust.ADJUST_SUCCESS:
+                    raise RuntimeError("the one-chain step did not converge")
+                if args.variance_propagation:
+                    a1.GenerateStatistics()
+                lib.dnagpu_sync(a1.device_context())
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+            out["roofline"]["frac_one_chain"] = (a1.algorithmic_flops() / 1e12) / dt1 / FP64_MFMA_PEAK_TFLOPS
+            out["roofline"]["ms_per_step_one_chain"] = dt1 * 1e3
+            a1.close()
+        except Exception as e:                   # diagnostic only
+            out["roofline"]["frac_one_chain_error"] = str(e)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, iters, solves, sum_n3, stations)
     emit(out)
-    a.close()
 
 
 if __name__ == "__main__":

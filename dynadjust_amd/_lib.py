@@ -228,6 +228,7 @@ def load():
     _sig(lib, "dnaadj_device_instance_context", vp, [vp, i])
     _sig(lib, "dnaadj_device_instance_stats", i, [vp, i, C.POINTER(DnaAdjInstanceStats)])
     _sig(lib, "dnaadj_debug_cancel_instance", i, [vp, i])
+    _sig(lib, "dnaadj_debug_tcp_share_unique_id", i, [i, i, C.c_char_p, C.c_char_p, i, C.c_double, C.c_char_p, sz])
     _sig(lib, "dnaadj_generate_statistics", i, [vp])
     _sig(lib, "dnaadj_get_statistics", i, [vp, C.POINTER(DnaAdjStatistics)])
     _sig(lib, "dnaadj_measurement_record_count", u64, [vp])
@@ -307,7 +308,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_completion_count", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
     "dnaimport_text", "dnaimport_text_geo", "dnaadj_dist_rccl_available", "dnaadj_dist_unique_id", "dnaadj_dist_attach_rccl", "dnaadj_adjust_distributed", "dnaadj_dist_info",
-    "dnaadj_block_owner", "dnaadj_exchange_stats", "dnaadj_device_instance_context", "dnaadj_device_instance_stats", "dnaadj_debug_cancel_instance",
+    "dnaadj_block_owner", "dnaadj_exchange_stats", "dnaadj_device_instance_context", "dnaadj_device_instance_stats", "dnaadj_debug_cancel_instance", "dnaadj_debug_tcp_share_unique_id",
     "dnaadj_generate_statistics", "dnaadj_get_statistics", "dnaadj_measurement_record_count", "dnaadj_measurement_records",
     "dnaadj_block_prec_adj_msrs_count", "dnaadj_block_prec_adj_msrs", "dnaadj_serialise_adjusted_variance_matrices",
     "dnaadj_deserialise_adjusted_variance_matrices", "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",

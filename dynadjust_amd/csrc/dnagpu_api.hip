@@ -1503,7 +1503,14 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
         map[nip + nj] = -2;
         slot = b->schur_map[0] ? 1 : 0;
         // another chain's thread may hold the replaced slot's pointers for a launch it has not enqueued yet: the old lists are
-        // retired, not freed (a few kB each; a block sees at most a handful of station lists), and go with the block
+        // retired, not freed at once.  A block that keeps alternating between more than two station lists would pile them up
+        // (a few kB each, every iteration): beyond a handful the oldest go, after the device has finished everything enqueued --
+        // a launch that still uses one of them was enqueued long before (the lists retired LAST stay)
+        if (b->retired.size() >= 12) {
+            HIPCHK(hipDeviceSynchronize());
+            for (size_t i = 0; i + 6 < b->retired.size(); ++i) hipFree(b->retired[i]);
+            b->retired.erase(b->retired.begin(), b->retired.end() - 6);
+        }
         if (b->schur_map[slot]) b->retired.push_back(b->schur_map[slot]);
         if (b->schur_idx[slot]) b->retired.push_back(b->schur_idx[slot]);
         if (b->schur_spos[slot]) b->retired.push_back(b->schur_spos[slot]);

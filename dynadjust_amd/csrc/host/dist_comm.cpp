@@ -371,6 +371,8 @@ void read_all(int fd, void* p, size_t n) {
 }
 }  // namespace
 
+constexpr int32_t UNIQUE_ID_HELLO = 0x444e4131;     // "DNA1": what a rank says first
+
 void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BYTES], const char* addr, int port, double timeout_s) {
     if (world <= 1) return;
     std::string host = addr && *addr ? addr : (getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1");
@@ -390,12 +392,34 @@ void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BY
         sockaddr_in sa;
         memset(&sa, 0, sizeof(sa));
         sa.sin_family = AF_INET;
+        // the rendezvous address names the interface rank 0 listens on (the launcher's MASTER_ADDR: a loopback address keeps the
+        // exchange inside the host); only a name that does not resolve to a local address falls back to every interface
         sa.sin_addr.s_addr = htonl(INADDR_ANY);
+        {
+            addrinfo hints, *res = nullptr;
+            memset(&hints, 0, sizeof(hints));
+            hints.ai_family = AF_INET;
+            hints.ai_socktype = SOCK_STREAM;
+            if (getaddrinfo(host.c_str(), nullptr, &hints, &res) == 0 && res) {
+                sa.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
+                freeaddrinfo(res);
+            }
+        }
         sa.sin_port = htons((uint16_t)port);
-        if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || ::listen(ls, world) != 0) {
+        if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) {
+            sa.sin_addr.s_addr = htonl(INADDR_ANY);
+            if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) {
+                ::close(ls);
+                throw std::runtime_error("unique-id exchange: cannot bind port " + std::to_string(port));
+            }
+        }
+        if (::listen(ls, world) != 0) {
             ::close(ls);
             throw std::runtime_error("unique-id exchange: cannot listen on port " + std::to_string(port));
         }
+        // every rank 1 .. world - 1 is served (a rank that asks again after a failed read is answered again and counted once);
+        // a connection that does not introduce itself as one of them -- a port scan, a health probe -- gets nothing and counts for nothing
+        std::vector<char> served((size_t)world, 0);
         for (int got = 0; got < world - 1;) {
             timeval tv;
             double left = std::chrono::duration<double>(deadline - std::chrono::steady_clock::now()).count();
@@ -404,18 +428,26 @@ void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BY
                 throw std::runtime_error("unique-id exchange: timed out waiting for the other ranks");
             }
             tv.tv_sec = (long)left;
-            tv.tv_usec = 0;
+            tv.tv_usec = (long)((left - (double)tv.tv_sec) * 1e6);
             fd_set fds;
             FD_ZERO(&fds);
             FD_SET(ls, &fds);
             if (::select(ls + 1, &fds, nullptr, nullptr, &tv) <= 0) continue;
             int c = ::accept(ls, nullptr, nullptr);
             if (c < 0) continue;
-            int32_t peer = -1;
+            timeval io = {5, 0};                 // (a silent connection may hold the loop for five seconds, not for good)
+            setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &io, sizeof(io));
+            setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &io, sizeof(io));
+            int32_t hello[2] = {0, -1};
             try {
-                read_all(c, &peer, sizeof(peer));
-                write_all(c, id, DIST_UNIQUE_ID_BYTES);
-                ++got;
+                read_all(c, hello, sizeof(hello));
+                if (hello[0] == UNIQUE_ID_HELLO && hello[1] > 0 && hello[1] < world) {
+                    write_all(c, id, DIST_UNIQUE_ID_BYTES);
+                    if (!served[(size_t)hello[1]]) {
+                        served[(size_t)hello[1]] = 1;
+                        ++got;
+                    }
+                }
             } catch (...) {
             }
             ::close(c);
@@ -433,8 +465,8 @@ void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BY
         int s = ::socket(AF_INET, SOCK_STREAM, 0);
         if (s >= 0 && ::connect(s, res->ai_addr, res->ai_addrlen) == 0) {
             try {
-                int32_t me = rank;
-                write_all(s, &me, sizeof(me));
+                const int32_t hello[2] = {UNIQUE_ID_HELLO, rank};
+                write_all(s, hello, sizeof(hello));
                 read_all(s, id, DIST_UNIQUE_ID_BYTES);
                 ::close(s);
                 freeaddrinfo(res);

@@ -194,6 +194,16 @@ void* dnaadj_device_instance_context(dnaadj_handle* h, int r) {
     return h->adj->DeviceInstance(r)->deviceContext();
 }
 
+int dnaadj_debug_tcp_share_unique_id(int rank, int world, unsigned char* id128, const char* addr, int port, double timeout_s, char* err, size_t errlen) {
+    try {
+        dynadjust::networkadjust::tcp_share_unique_id(rank, world, id128, addr, port, timeout_s);
+        return DNAADJ_OK;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return DNAADJ_EXCEPTION;
+    }
+}
+
 int dnaadj_debug_cancel_instance(dnaadj_handle* h, int r) {
     if (!h || !h->adj || r < 0 || r >= h->adj->DeviceInstances()) return DNAADJ_EINVAL;
     h->adj->DeviceInstance(r)->CancelThisRankOnly();

@@ -71,6 +71,7 @@ constexpr int SMALL_LAUNCH_TILES = 512;
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).
 // jt_lo / jt_hi (128-tiles, -1 = all): only the tiles of these columns (one rank's share of a split launch)
 std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo = -1, int jt_hi = -1, int* pairs = nullptr);
+long pair_tiles_get();
 long pair_tiles_set(long tiles);   // launches of at least this many 128-tiles walk their tiles in pairs (tile_order.hip); 0 = never (default); returns the old value
 bool gemm_128_takes_pairs();   // the LDS-DMA kernel does; the register-staged diagnostic variants do not
 std::vector<int> split_tile_columns(int mt, int nt, int K, int kmode, int lower, int world);

@@ -36,7 +36,7 @@ struct InvWorkspace {
     GemmProfile prof;
     // workgroup->tile tables per launch shape (see tile_order.hip) and tile-column range (0xffffffff: all columns), device resident
     std::map<std::pair<uint64_t, uint32_t>, std::pair<uint32_t*, int>> order_cache;
-    std::set<int> planned;  // matrix orders (in tiles) whose tables are all built
+    std::set<uint64_t> planned;  // driver call shapes (sym_inverse.hip plan_key) whose tile-order tables are all built
     // First HIP error of a planning pass, table upload, memset / copy or kernel launch enqueued through this workspace since
     // the last inv_take_error(): the asynchronous drivers below keep enqueuing nothing further once it is set, and the C-ABI
     // turns it into DNAGPU_ENOMEM / DNAGPU_EHIP instead of trusting `info_host` (a skipped GEMM leaves info at "no failure").

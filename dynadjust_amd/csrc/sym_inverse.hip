@@ -108,8 +108,10 @@ long small_tiles_set(long v) {
 hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo, int jt_hi) {
     long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
     a.tile = total < g_small_tiles.load() ? 64 : 128;
+    // (the pair threshold is part of the key: a table built before dnagpu_debug_set_pair_tiles changed it is not the one wanted after)
+    const long pair_from = pair_tiles_get();
     const uint64_t shape = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
-                           ((uint64_t)(a.tile == 64 ? 1 : 0) << 37) | ((uint64_t)(a.K / 16) << 40);
+                           ((uint64_t)(a.tile == 64 ? 1 : 0) << 37) | ((uint64_t)(pair_from > 0 && total >= pair_from ? 1 : 0) << 38) | ((uint64_t)(a.K / 16) << 40);
     const auto key = std::make_pair(shape, jt_lo < 0 ? 0xffffffffu : ((uint32_t)jt_lo << 16) | (uint32_t)jt_hi);
     auto it = ws.order_cache.find(key);
     if (it == ws.order_cache.end()) {
@@ -640,9 +642,14 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
     return true;
 }
 
+// key of a driver call's shape in InvWorkspace::planned: fields wide enough for any matrix this library can hold (2^24 tiles a side)
+inline uint64_t plan_key(int family, int what, int ti, int tj) {
+    return ((uint64_t)family << 56) | ((uint64_t)(what & 0xf) << 52) | ((uint64_t)(uint32_t)ti << 26) | (uint64_t)(uint32_t)tj;
+}
+
 // the per-product path: planning pass (tile-order tables) on first use of the shape, then the launches
 template <class Ops>
-void run_products(InvWorkspace& ws, int key, double* F, int ld, double* X, int ldx, double* P, int ldp, const double* WK, Ops&& ops) {
+void run_products(InvWorkspace& ws, uint64_t key, double* F, int ld, double* X, int ldx, double* P, int ldp, const double* WK, Ops&& ops) {
     for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
         Rec rec{ws, F, ld, X, ldx, P, ldp, pass == 0};
         ops(rec, WK);
@@ -674,7 +681,7 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
         rec.gemm(ws, a, 1, 1);
     };
     if (!run_dag(ws, DK_INVERSE, T, 0, 0, F, (int)np, ws.X, (int)np, ws.W, (int)np, nullptr, 0, ops))
-        run_products(ws, T, F, (int)np, ws.X, (int)np, ws.W, (int)np, nullptr, ops);     // (tables first: the blocking uploads never sit between kernels)
+        run_products(ws, plan_key(DK_INVERSE, 0, T, 0), F, (int)np, ws.X, (int)np, ws.W, (int)np, nullptr, ops);     // (tables first: the blocking uploads never sit between kernels)
     gemm_profile_close(ws);
     if (scale_to_unity) launch_scale_sym(F, ws.svec, n, np, 0, ws.stream);
     inv_note_error(ws, hipGetLastError(), "inverse: scaling launch");
@@ -697,7 +704,7 @@ void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti
         if (ti > 0 && tj > 0) rec.eliminate(0, ti, tj);
     };
     if (!run_dag(ws, DK_SCHUR_KEEP, ti, tj, 0, F, ld, X, ld, ws.W, ld, nullptr, 0, ops))
-        run_products(ws, (1 << 29) | (ti << 12) | tj, F, ld, X, ld, ws.W, ld, nullptr, ops);
+        run_products(ws, plan_key(DK_SCHUR_KEEP, 0, ti, tj), F, ld, X, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
@@ -735,7 +742,7 @@ void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const do
         }
     };
     if (!run_dag(ws, DK_COMPLETE, ti, tj, what & 3, F, ld, X, ld, ws.W, ld, WK, ldwk, ops))
-        run_products(ws, (1 << 28) | ((what & 3) << 26) | (ti << 12) | tj, F, ld, X, ld, ws.W, ld, WK, ops);
+        run_products(ws, plan_key(DK_COMPLETE, what & 3, ti, tj), F, ld, X, ld, ws.W, ld, WK, ops);
     gemm_profile_close(ws);
 }
 
@@ -744,7 +751,7 @@ void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int
     const double split = schur_split();
     auto ops = [&](Rec& rec, const double*) { rec.spine(ti, tj, split); };
     if (!run_dag(ws, DK_SPINE, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
-        run_products(ws, (1 << 24) | (0 << 22) | (ti << 12) | tj, F, ld, S, ld, ws.W, ld, nullptr, ops);
+        run_products(ws, plan_key(DK_SPINE, 0, ti, tj), F, ld, S, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
@@ -752,7 +759,7 @@ void sym_spine_kept_async(InvWorkspace& ws, double* F, double* S, int ld, int ti
     inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
     auto ops = [&](Rec& rec, const double*) { rec.node(ti, tj); };
     if (!run_dag(ws, DK_SPINE_KEPT, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
-        run_products(ws, (1 << 24) | (1 << 22) | (ti << 12) | tj, F, ld, S, ld, ws.W, ld, nullptr, ops);
+        run_products(ws, plan_key(DK_SPINE_KEPT, 0, ti, tj), F, ld, S, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
@@ -770,7 +777,7 @@ void sym_spine_finish_async(InvWorkspace& ws, double* F, double* S, int ld, int 
         rec.gemm(ws, a, 1, 1);
     };
     if (!run_dag(ws, DK_SPINE_FINISH, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
-        run_products(ws, (1 << 24) | (2 << 22) | (ti << 12) | tj, F, ld, S, ld, ws.W, ld, nullptr, ops);
+        run_products(ws, plan_key(DK_SPINE_FINISH, 0, ti, tj), F, ld, S, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
 }
 
@@ -792,7 +799,7 @@ void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, in
     const double split = schur_split();
     auto ops = [&](Rec& rec, const double*) { rec.schur(ti, tj, split); };
     if (!run_dag(ws, DK_SCHUR, ti, tj, 0, F, ld, ws.X, ldx, P, ldp, nullptr, 0, ops))
-        run_products(ws, (1 << 30) | (ti << 12) | tj, F, ld, ws.X, ldx, P, ldp, nullptr, ops);
+        run_products(ws, plan_key(DK_SCHUR, 0, ti, tj), F, ld, ws.X, ldx, P, ldp, nullptr, ops);
     gemm_profile_close(ws);
 }
 

@@ -57,6 +57,7 @@ std::vector<int> split_tile_columns(int mt128, int nt128, int K, int kmode, int 
 // measured, the pairs raise the L2 hit rates as intended and do not make anything faster (see the end of the comment below).
 // DNAGPU_PAIR_TILES / dnagpu_debug_set_pair_tiles set it.
 static std::atomic<long> g_pair_tiles{getenv("DNAGPU_PAIR_TILES") ? atol(getenv("DNAGPU_PAIR_TILES")) : 0};
+long pair_tiles_get() { return g_pair_tiles.load(); }
 long pair_tiles_set(long tiles) { return g_pair_tiles.exchange(tiles < 0 ? 0 : tiles); }
 static long pair_threshold() { return g_pair_tiles.load(); }
 

@@ -225,6 +225,9 @@ int dnaadj_device_instance_stats(dnaadj_handle* h, int r, dnaadj_instance_stats*
 /* test hook: CancelAdjustment() as ONE rank of a multi-process adjustment would receive it (a signal to its process): only GPU r's
  * instance is told; the ranks agree on the cancellation at the next phase boundary and all return ADJUST_CANCELLED */
 int dnaadj_debug_cancel_instance(dnaadj_handle* h, int r);
+/* test hook: the TCP hand-off of the 128 bytes by itself (what dnaadj_prepare does between processes before ncclCommInitRank): rank 0
+ * listens on addr : port and serves ranks 1 .. world - 1 once each, the others connect and read */
+int dnaadj_debug_tcp_share_unique_id(int rank, int world, unsigned char* id128, const char* addr, int port, double timeout_s, char* err, size_t errlen);
 
 /* device context of the adjustment (for dnagpu_profile_*), NULL before prepare */
 void* dnaadj_device_context(dnaadj_handle* h);

@@ -34,3 +34,32 @@ def sample_packed(ap, n):
         hi = np.maximum(rows, c)
         cols.append(ap[col0[lo] + (hi - lo)])
     return diag, np.stack(cols)
+
+
+QUADRATIC_FORMS = 4
+PREC_STRIDE = 50        # every 50th GNSS vector's adjusted-measurement precision (6 values: xx xy xz yy yz zz)
+
+
+def packed_checksums(ap, n, block):
+    """Sums over EVERY element of a block's packed variance matrix (the sampled diagonal / columns pin a few thousand of its 2e8 elements):
+    the Frobenius norm of the symmetric matrix and QUADRATIC_FORMS quadratic forms x^T S x with seeded x in [-1, 1) -- any element
+    that is wrong by more than the tolerance times the matrix's scale moves at least one of them."""
+    ap = np.asarray(ap)
+    j = np.arange(n, dtype=np.int64)
+    col0 = j * n - j * (j - 1) // 2
+    diag = ap[col0]
+    fro = float(np.sqrt(2.0 * np.dot(ap, ap) - np.dot(diag, diag)))
+    rng = np.random.default_rng(SEED + 1000 * block)
+    X = rng.random((QUADRATIC_FORMS, n)) * 2.0 - 1.0
+    q = np.zeros(QUADRATIC_FORMS)
+    # x^T S x = sum_j x_j ( 2 * S[j+1:, j] . x[j+1:] + S[j, j] x_j ), column by column of the packed triangle
+    for c in range(n):
+        col = ap[col0[c]:col0[c] + n - c]
+        q += X[:, c] * (2.0 * (X[:, c + 1:] @ col[1:]) + col[0] * X[:, c])
+    return fro, q
+
+
+def sample_precisions(prec, n_vectors):
+    """prec: v_precAdjMsrsFull_ of a block (6 values per GNSS vector in CML order) -> the rows of every PREC_STRIDE-th vector"""
+    p = np.asarray(prec)[:6 * n_vectors].reshape(-1, 6)
+    return p[::PREC_STRIDE].copy()

@@ -123,3 +123,62 @@ def test_utm_conversion_matches_the_reference_report(golden_dir):
             seen += 1
         i += 1
     assert seen == 2
+
+
+def test_unique_id_hand_off_over_tcp(built):
+    """what dna_adjust::PrepareAdjustment does between processes before ncclCommInitRank (dist_comm.cpp tcp_share_unique_id): rank 0
+    serves ranks 1 .. world - 1 once each on the rendezvous address; a connection that does not introduce itself as one of them (a
+    port probe), a rank that asks twice and a client that arrives before the server do not disturb it"""
+    import ctypes as C
+    import socket
+    import threading
+    import time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    world = 4
+    secret = bytes(range(128))
+    got, errs = {}, []
+
+    def rank(r, delay=0.0):
+        time.sleep(delay)
+        buf = C.create_string_buffer(secret if r == 0 else b"\0" * 128, 128)
+        err = C.create_string_buffer(256)
+        rc = built.dnaadj_debug_tcp_share_unique_id(r, world, buf, b"127.0.0.1", port, 30.0, err, 256)
+        if rc != 0:
+            errs.append((r, err.value.decode()))
+        got[r] = buf.raw
+
+    threads = [threading.Thread(target=rank, args=(1,))]            # rank 1 is early: it retries until rank 0 listens
+    threads[0].start()
+    time.sleep(0.3)
+    threads += [threading.Thread(target=rank, args=(0,)), threading.Thread(target=rank, args=(2, 0.4)), threading.Thread(target=rank, args=(3, 0.8))]
+    for t in threads[1:]:
+        t.start()
+    time.sleep(0.2)
+    # a stray connection that says nothing useful, and one that poses as rank 2 a second time: neither uses up rank 3's place
+    for payload in (b"GET / HTTP/1.0\r\n\r\n", None):
+        for _ in range(20):
+            try:
+                s = socket.create_connection(("127.0.0.1", port), timeout=2)
+                break
+            except OSError:
+                time.sleep(0.05)
+        else:
+            continue
+        with s:
+            if payload is None:
+                import struct
+                s.sendall(struct.pack("<ii", 0x444e4131, 2))
+                assert len(s.recv(128, socket.MSG_WAITALL)) == 128
+            else:
+                s.sendall(payload)
+                s.settimeout(1.0)
+                try:
+                    assert s.recv(16) == b""
+                except (socket.timeout, ConnectionError):
+                    pass
+    for t in threads:
+        t.join(timeout=60)
+    assert not errs, errs
+    assert all(got[r] == secret for r in range(world))

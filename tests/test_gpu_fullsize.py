@@ -65,25 +65,41 @@ def test_against_the_oracle_record(built, golden_dir, tmp_path, workload):
     assert st == meta["status"] and a.CurrentIteration() == meta["iterations"]
     dcorr = max(abs(a.GetIterationCorrection(i + 1) - c) for i, c in enumerate(meta["corrections"]))
     assert dcorr < TOL_X
-    dx = dv = dvc = 0.0
+    a.GenerateStatistics()          # (also: the precisions of the adjusted measurements from the resident variances, configs[4])
+    dx = dv = dvc = dfro = dquad = dprec = 0.0
+    checksums = "vfro_0" in g.files
     for b in range(a.blockCount()):
         assert np.array_equal(a.block_stations(b), g[f"stations_{b}"])
         est = a.block_estimates(b)
         dx = max(dx, float(np.abs(est - g[f"estimates_{b}"]).max()))
-        diag, cols = fullsize.sample_packed(a.block_variances_packed(b), est.size)
+        var = a.block_variances_packed(b)
+        diag, cols = fullsize.sample_packed(var, est.size)
         scale = float(np.abs(g[f"vdiag_{b}"]).max())
         dv = max(dv, float(np.abs(diag - g[f"vdiag_{b}"]).max()) / scale)
         dvc = max(dvc, float(np.abs(cols - g[f"vcols_{b}"]).max()) / scale)
-    a.GenerateStatistics()
+        if checksums:
+            # sums over EVERY element of the matrix, and the consumer of the variances: A S A^T of every 50th GNSS measurement
+            fro, quad = fullsize.packed_checksums(var, est.size, b)
+            dfro = max(dfro, abs(fro - float(g[f"vfro_{b}"][0])) / float(g[f"vfro_{b}"][0]))
+            dquad = max(dquad, float(np.abs(quad - g[f"vquad_{b}"]).max() / np.abs(g[f"vquad_{b}"]).max()))
+            p_all = a.block_prec_adj_msrs(b)
+            prec = fullsize.sample_precisions(p_all, p_all.size // 6)
+            assert prec.shape == g[f"prec_{b}"].shape
+            dprec = max(dprec, float(np.abs(prec - g[f"prec_{b}"]).max() / np.abs(g[f"prec_{b}"]).max()))
+        del var
     rec = {"workload": workload, "stations": info["stations"], "blocks": a.blockCount(), "iterations": a.CurrentIteration(),
            "schedule": "condensed + kept factors, four chains", "max_abs_dx_m": dx, "max_rel_dvar_diagonal": dv,
            "max_rel_dvar_sampled_columns": dvc, "max_abs_dcorrection_m": dcorr,
+           "every_element": ({"max_rel_dfrobenius": dfro, "max_rel_dquadratic_forms": dquad, "max_rel_dprecision_adjusted_measurements": dprec} if checksums else None),
            "sigma_zero_device": a.GetSigmaZero(), "sigma_zero_oracle": meta["sigma_zero"],
            "chi_squared_device": a.GetChiSquared(), "chi_squared_oracle": meta["chi_squared"],
            "oracle": {k: meta[k] for k in ("oracle_seconds", "oracle_threads", "oracle_tflops", "lapack", "cpu_count") if k in meta}}
     rec["unknowns_per_block"] = [int(g[f"estimates_{b}"].size) for b in range(a.blockCount())]
     _record(f"parity_{workload}.json", rec)
     assert dx < TOL_X and dv < TOL_V and dvc < TOL_V, rec
+    assert dfro < TOL_V and dquad < 1e-7 and dprec < 1e-7, rec          # (a quadratic form sums 2e8 terms of either sign: 1e-7 of the largest form)
+    if workload == "cfg3q":
+        assert checksums, "tests/golden/cfg3q_oracle.npz predates the every-element checksums: python tools/make_fullsize_golden.py cfg3q"
     assert a.GetDegreesOfFreedom() == meta["dof"]
     assert abs(a.GetChiSquared() - meta["chi_squared"]) / meta["chi_squared"] < 1e-7
     a.close()

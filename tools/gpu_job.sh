@@ -2,7 +2,6 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export GPU_MAX_HW_QUEUES=16
-timeout 900 python -m pytest tests/test_gpu_distributed.py tests/test_tile_dag.py tests/test_boundary_cpp.py tests/test_gpu_multi.py "tests/test_gpu_adjust.py::test_bench_distributed_path_over_rccl" -q -m gpu --durations=5 > gpurun_out/t_part.log 2>&1
-echo "part rc=$?" > gpurun_out/job.status
-tail -n 40 gpurun_out/t_part.log
-cat gpurun_out/job.status
+timeout 400 python -m pytest tests/test_boundary_cpp.py -q -m gpu 2>&1 | tail -5
+timeout 1500 python tools/make_fullsize_golden.py cfg3 gpurun_out/cfg3_oracle.npz > gpurun_out/cfg3_golden.log 2>&1
+echo "golden rc=$?"; tail -3 gpurun_out/cfg3_golden.log | cut -c1-600; ls -la gpurun_out/cfg3_oracle.npz

@@ -8,7 +8,8 @@ cfg3 (100 172 stations, 16 blocks of n ~ 20 000, 92 Solve() calls of n^3 flops) 
 run it where those exist (the GPU box's host: `gpurun -- python tools/make_fullsize_golden.py cfg3 gpurun_out/cfg3_oracle.npz`),
 then commit the result as tests/golden/<workload>_oracle.npz.  tests/test_gpu_fullsize.py compares the device path with it.
 The record: every adjusted coordinate, the diagonal of every block's rigorous variance matrix, three of its columns (every
-8th row), iteration count, per-iteration largest corrections, chi-squared / sigma-zero / degrees of freedom, and how long the
+8th row), its Frobenius norm and four seeded quadratic forms (sums over EVERY element), the precisions of every 50th adjusted
+GNSS measurement (configs[4]'s consumer of the variances, ComputePrecisionAdjMsrs ADJ:7784), iteration count, per-iteration largest corrections, chi-squared / sigma-zero / degrees of freedom, and how long the
 oracle took on how many threads."""
 import json
 import os
@@ -69,16 +70,23 @@ def main():
     rec = {"status": status, "iterations": o.iterations(), "stations": info["stations"], "blocks": o.n_blocks,
            "corrections": [o.max_correction(i + 1) for i in range(o.iterations())]}
     arrays = {}
+    st, _ = o.statistics()           # (also fills the precisions of the adjusted measurements, ComputePrecisionAdjMsrs ADJ:7784)
     for b in range(o.n_blocks):
         stn = o.block_stations(b)
         est = o.block_estimates(b)
         n = est.size
-        diag, colsamp = fullsize.sample_packed(o.block_variances(b), n)
+        var = o.block_variances(b)
+        diag, colsamp = fullsize.sample_packed(var, n)
+        fro, quad = fullsize.packed_checksums(var, n, b)
+        prec = o.block_prec_adj_msrs(b)
         arrays[f"stations_{b}"] = stn.astype(np.uint32)
         arrays[f"estimates_{b}"] = est
         arrays[f"vdiag_{b}"] = diag
         arrays[f"vcols_{b}"] = colsamp
-    st, _ = o.statistics()
+        arrays[f"vfro_{b}"] = np.array([fro])
+        arrays[f"vquad_{b}"] = quad
+        arrays[f"prec_{b}"] = fullsize.sample_precisions(prec, prec.size // 6)
+        del var
     rec.update(chi_squared=st.chi_squared, sigma_zero=st.sigma_zero, dof=st.dof, oracle_seconds=dt, oracle_threads=threads,
                oracle_solves=int(solves), oracle_sum_n3=n3, oracle_tflops=n3 / dt / 1e12, cpu_count=os.cpu_count(),
                lapack=lapack_name)
