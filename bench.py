@@ -402,6 +402,20 @@ def _check_block(a, folder, name, stations):
         return {"error": str(e)}
 
 
+def _hbm(lib, ctx):
+    free, total = C.c_size_t(), C.c_size_t()
+    lib.dnagpu_mem_info(ctx, C.byref(free), C.byref(total))
+    return free.value, total.value
+
+
+def _hbm_report(lib, ctxs, after_prepare, staged):
+    """the HBM budget of every rank: free after PrepareAdjustment (blocks, measurements, kept-factor budget decided) and at the end of the timed steps
+    (chain workspaces, rigorous variance matrices or their staging buffers allocated); `staged`: the variance matrices live in page-locked host memory"""
+    end = [_hbm(lib, c) for c in ctxs]
+    return {"total_gb": [round(t / 1e9, 1) for _, t in end], "free_after_prepare_gb": [round(f / 1e9, 1) for f, _ in after_prepare],
+            "free_at_end_gb": [round(f / 1e9, 1) for f, _ in end], "variances_staged_in_host_memory": staged}
+
+
 def bench_one_process(folder, name, phased, args, devices, transport):
     """bench.py --gpus N without a launcher (WORLD_SIZE unset): ONE process drives the N GPUs, the mode dnaadjustwrapper linked to
     libdnagpu.so gets (a.devices -> one dna_adjust instance and one host thread per GPU inside the library, RCCL communicators made
@@ -421,6 +435,7 @@ def bench_one_process(folder, name, phased, args, devices, transport):
     a.PrepareAdjustment(p)
     lib = a.lib
     ctxs = [a.device_instance_context(r) for r in range(world)]
+    hbm = [_hbm(lib, c) for c in ctxs]           # per rank, right after PrepareAdjustment: what the rank's blocks and workspaces left free
 
     def sync_all():
         for c in ctxs:
@@ -467,6 +482,7 @@ def bench_one_process(folder, name, phased, args, devices, transport):
     out = _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, per_rank, owners, _check_block(a, folder, name, stations),
                           "C++ (libdnagpu.so): one process, one dna_adjust instance + host thread per GPU (a.devices)", tr, st0["rccl_ranks"], multi_thread)
     out["config"]["devices"] = list(devices)
+    out["hbm_per_rank"] = _hbm_report(lib, ctxs, hbm, bool(lib.dnaadj_staged(a.h)))
     if len(set(devices)) < world:
         out["config"]["ranks_share_gpus"] = True     # DNAGPU_BENCH_SHARE_GPU=1: a code-path check on a box with fewer GPUs, NOT a scaling measurement
         out["n_gpus"] = len(set(devices))
@@ -495,6 +511,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
                                dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))))
     a.PrepareAdjustment(p)
     lib, ctx = a.lib, a.device_context()
+    hbm0 = _hbm(lib, ctx)
 
     def one_step():
         a.ResetAdjustment()
@@ -527,7 +544,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     ex = a.exchange_stats()
     mine = {"alg": a.algorithmic_flops(), "gemm_ms": prof_ms.value, "issued": prof_f.value, "solves": a.solve_count(), "completions": a.completion_count(),
             "eliminations": a.elimination_count(), "exchange_ms": ex["exchange_ms"], "chain_ms": ex["chain_ms"], "bytes": (ex["bytes"] - bytes0) / max(1, args.steps),
-            "rccl_ranks": a.device_instance_stats(0)["rccl_ranks"]}
+            "rccl_ranks": a.device_instance_stats(0)["rccl_ranks"], "hbm0": hbm0, "hbm1": _hbm(lib, ctx), "staged": bool(lib.dnaadj_staged(a.h))}
     allv = [None] * world
     dist.all_gather_object(allv, mine)
     stations = lib.dnaadj_station_count(a.h)
@@ -542,6 +559,8 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
         out = _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, allv, owners, check,
                               "C++ (libdnagpu.so): one process per GPU (torchrun ranks), RCCL called from the library", tr, min(v["rccl_ranks"] for v in allv),
                               p.multi_thread)
+        out["hbm_per_rank"] = {"total_gb": [round(v["hbm1"][1] / 1e9, 1) for v in allv], "free_after_prepare_gb": [round(v["hbm0"][0] / 1e9, 1) for v in allv],
+                               "free_at_end_gb": [round(v["hbm1"][0] / 1e9, 1) for v in allv], "variances_staged_in_host_memory": any(v["staged"] for v in allv)}
     a.close()
     return out
 

@@ -984,7 +984,14 @@ void dna_adjust::AdjustPhased() {
         if (!iterate) break;
         UpdateAdjustment(iterate);
     }
+    const bool times = getenv("DNAGPU_PHASE_TIMES") != nullptr;
+    if (times) Check(dnagpu_sync(ctx_), 0, "AdjustPhased()");
+    const double tv = now_ms();
     if (!IsCancelled()) FinishDeferredVariances();
+    if (times) {
+        Check(dnagpu_sync(ctx_), 0, "AdjustPhased()");
+        fprintf(stderr, "[phase] variance matrices    %8.1f ms\n", now_ms() - tv);
+    }
     FinishStagedCopies();
     ValidateandFinaliseAdjustment();
 }

@@ -18,6 +18,13 @@
 namespace dynadjust {
 namespace networkadjust {
 
+namespace {
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
 // UpdateNormals (ADJ:1364) on the device; timed like the reference's DYNADJUST_PROFILE counter (ADJ:1366, ADJ:1449-1455)
 void dna_adjust::FormNormals(int c, UINT32 k, dnagpu_matrix* W) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -776,11 +783,25 @@ void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks) {
 void dna_adjust::AdjustPhasedCondensedIteration() {
     std::vector<UINT32> all(blockCount_);
     for (UINT32 k = 0; k < blockCount_; ++k) all[k] = k;
+    // DNAGPU_PHASE_TIMES=1 (diagnostic): the device is drained at the phase boundaries and the wall time of every phase is printed
+    static const bool times = getenv("DNAGPU_PHASE_TIMES") != nullptr;
+    double t0 = 0.0;
+    auto lap = [&](const char* what) {
+        if (!times) return;
+        Check(dnagpu_sync(ctx_), 0, "AdjustPhased()");
+        const double t = now_ms();
+        if (what) fprintf(stderr, "[phase] iteration %u %-10s %8.1f ms\n", (unsigned)currentIteration_, what, t - t0);
+        t0 = t;
+    };
+    lap(nullptr);
     CondenseBlocks(all);
+    lap("condense");
     if (IsCancelled()) return;
     CondensedChains();
+    lap("chains");
     if (IsCancelled()) return;
     RigorousBlocks(all);
+    lap("rigorous");
 }
 
 size_t dna_adjust::CondensedPayloadDoubles(UINT32 k) const {
