@@ -377,7 +377,7 @@ def _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, per_rank, ow
                    "variance_propagation_in_step": bool(args.variance_propagation), "blocks_per_rank": [owners.count(r) for r in range(world)]},
         "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
         "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
-        "roofline": {"kernel": "tile_dag_kernel / gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
+        "roofline": {"kernel": "gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                      "traffic": None, "rank": busiest, "gemm_ms_per_step": gemm_ms / args.steps,
                      "note": "busiest rank: algorithmic flops of its steps / HIP-event time of its GEMM launches"},

@@ -35,7 +35,7 @@ class DnaAdjSettings(C.Structure):
                 ("scale_normals_to_unity", C.c_int), ("device", C.c_int), ("confidence_interval", C.c_float),
                 ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int), ("schur_carry", C.c_int), ("stage", C.c_int), ("keep_factors", C.c_int),
                 ("dist_rank", C.c_int), ("dist_world", C.c_int), ("n_devices", C.c_int), ("devices", C.POINTER(C.c_int)),
-                ("dist_transport", C.c_char_p), ("dist_two_level", C.c_int), ("defer_variances", C.c_int)]
+                ("dist_transport", C.c_char_p), ("dist_two_level", C.c_int), ("defer_variances", C.c_int), ("batch_blocks", C.c_int)]
 
 
 class DnaAdjStatistics(C.Structure):
@@ -168,6 +168,10 @@ def load():
     _sig(lib, "dnagpu_host_alloc", i, [vp, sz, C.POINTER(vp)])
     _sig(lib, "dnagpu_host_free", None, [vp, vp])
     _sig(lib, "dnagpu_block_form_reduce", i, [vp, i, u32, c_u32p, c_f64p, sz, c_u32p, sz, vp, vp])
+    _sig(lib, "dnagpu_batch_reserve", i, [vp, i, u32, u32, i, C.POINTER(C.c_int)])
+    _sig(lib, "dnagpu_block_form_reduce_batched", i, [vp, i, i, c_u32p, vp, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t), vp, vp, C.POINTER(C.c_int)])
+    _sig(lib, "dnagpu_partial_complete_factor_batched", i, [vp, i, i, vp, vp, C.POINTER(C.c_int)])
+    _sig(lib, "dnagpu_partial_finish_batched", i, [vp, i, i, vp, vp])
     _sig(lib, "dnagpu_partial_create", i, [vp, u32, u32, C.POINTER(vp)])
     _sig(lib, "dnagpu_partial_create_in", i, [vp, u32, u32, vp, C.POINTER(vp)])
     _sig(lib, "dnagpu_partial_create_spine", i, [vp, u32, u32, vp, C.POINTER(vp)])
@@ -255,6 +259,7 @@ def load():
     _sig(lib, "dnaadj_phased_finish", i, [vp, ip])
     _sig(lib, "dnaadj_staged", i, [vp])
     _sig(lib, "dnaadj_condensed_schedule", i, [vp])
+    _sig(lib, "dnaadj_batched_block_steps", C.c_uint64, [vp])
     _sig(lib, "dnaadj_condensed_payload_doubles", sz, [vp, u32])
     _sig(lib, "dnaadj_phased_condense_block", i, [vp, u32])
     _sig(lib, "dnaadj_phased_condensed_forward", i, [vp, u32])
@@ -296,7 +301,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
     "dnagpu_block_set_direction_sets", "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
-    "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_block_form_reduce", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_create_spine", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
+    "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_block_reduce", "dnagpu_block_form_reduce", "dnagpu_batch_reserve", "dnagpu_block_form_reduce_batched", "dnagpu_partial_complete_factor_batched", "dnagpu_partial_finish_batched", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_create_spine", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
 ]
@@ -314,7 +319,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_deserialise_adjusted_variance_matrices", "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",
     "dnaadj_block_flags", "dnaadj_junction_unknowns", "dnaadj_junction_payload_doubles", "dnaadj_phased_begin_iteration",
     "dnaadj_phased_forward_block", "dnaadj_phased_reverse_block", "dnaadj_phased_combine_block", "dnaadj_phased_finalise_block",
-    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_staged", "dnaadj_condensed_schedule", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
+    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_staged", "dnaadj_condensed_schedule", "dnaadj_batched_block_steps", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
     "dnaadj_phased_condensed_forward", "dnaadj_phased_condensed_reverse", "dnaadj_phased_rigorous_block", "dnaadj_phased_condense_blocks", "dnaadj_phased_condensed_chains",
     "dnaadj_phased_rigorous_blocks", "dnaadj_condensed_export",
     "dnaadj_condensed_import", "dnaadj_statistics_prepare", "dnaadj_statistics_blocks", "dnaadj_statistics_get_partial",

@@ -35,7 +35,7 @@ class ProjectSettings:
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
                  scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None,
                  reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False, dist_rank=0, dist_world=1, devices=None,
-                 dist_transport=None, dist_two_level=True, defer_variances=2):
+                 dist_transport=None, dist_two_level=True, defer_variances=2, batch_blocks=16):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
         self.network_name = network_name          # g.network_name
         self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
@@ -49,6 +49,7 @@ class ProjectSettings:
         self.dist_rank, self.dist_world, self.devices = dist_rank, dist_world, devices
         self.dist_transport, self.dist_two_level = dist_transport, dist_two_level
         self.defer_variances = defer_variances
+        self.batch_blocks = batch_blocks          # condensed schedule: blocks of one shape as one batch of merged launches (0 / 1 = off)
         if network_name is not None:
             self.set_filenames(os.path.join(folder, network_name))
         self.adjust_mode = adjust_mode
@@ -127,6 +128,7 @@ class DnaAdjust:
         s.dist_transport = self._transport
         s.dist_two_level = int(bool(getattr(p, "dist_two_level", True)))
         s.defer_variances = int(getattr(p, "defer_variances", 2))
+        s.batch_blocks = int(getattr(p, "batch_blocks", 16))
         self._chk(self.lib.dnaadj_prepare(self.h, C.byref(s)))
 
     # ---- multi-GPU (include/dnaadjust_c.h "multi-GPU") ----
@@ -297,6 +299,10 @@ class DnaAdjust:
 
     def completion_count(self):
         return self.lib.dnaadj_completion_count(self.h)
+
+    def batched_block_steps(self):
+        """block steps that went through batched calls (settings.batch_blocks)"""
+        return int(self.lib.dnaadj_batched_block_steps(self.h))
 
     def elimination_count(self):
         return self.lib.dnaadj_elimination_count(self.h)

@@ -18,6 +18,7 @@ namespace {
 
 constexpr uint32_t SYMV_CHUNKS = 32;
 constexpr int INFO_SENTINEL = 0x7f7f7f7f;
+static_assert(DNAGPU_BATCH_MAX == BATCH_MAX, "include/dnagpu.h and la_kernels.h disagree on the batch size");
 
 // Error text and dpotrf-style info are kept twice: per host thread (every chain of a context is driven by its own host thread,
 // and two chains may fail together) and in the context, under a mutex, for any other thread that asks afterwards.
@@ -1472,11 +1473,10 @@ struct FormInOrder {
     const double* con_w9;         // host
     size_t n_con;
 };
-int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, const double** T, uint32_t* ldt,
-                    int* slot_out, dnagpu_partial* keep = nullptr, const FormInOrder* form = nullptr) {
-    const uint32_t n = form ? 3 * b->n_stn : m->n, nj = (uint32_t)(3 * k), ni = n - nj;
-    const uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1), npp = nip + njp;
-    if (!form && (size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur: matrix capacity");
+// The unknown order of an elimination onto the k listed stations -- device lists, cached per block (two slots: a block's forward and
+// reverse lists alternate) -- for a matrix of nip + (nj + 1 padded) = npp rows
+int schur_order(dnagpu_ctx* ctx, Block* b, const uint32_t* idx_out, size_t k, uint32_t nip, uint32_t nj, uint32_t npp, int* slot_out,
+                const int32_t** map_dev, const uint32_t** spos_dev) {
     // unknown order: the other stations (block order), padding, the listed stations (list order), the rhs row, padding
     int slot = -1;
     std::unique_lock<std::mutex> lk(ctx->schur_mutex);
@@ -1525,9 +1525,24 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
         HIPCHK(hipMemcpy(b->schur_idx[slot], idx_out, k * sizeof(uint32_t), hipMemcpyHostToDevice));
         b->h_schur_idx[slot].assign(idx_out, idx_out + k);
     }
-    const int32_t* map_dev = b->schur_map[slot];
-    const uint32_t* spos_dev = b->schur_spos[slot];
-    lk.unlock();
+    *map_dev = b->schur_map[slot];
+    *spos_dev = b->schur_spos[slot];
+    *slot_out = slot;
+    return DNAGPU_OK;
+}
+
+int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, const double** T, uint32_t* ldt,
+                    int* slot_out, dnagpu_partial* keep = nullptr, const FormInOrder* form = nullptr) {
+    const uint32_t n = form ? 3 * b->n_stn : m->n, nj = (uint32_t)(3 * k), ni = n - nj;
+    const uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1), npp = nip + njp;
+    if (!form && (size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur: matrix capacity");
+    int slot = -1;
+    const int32_t* map_dev = nullptr;
+    const uint32_t* spos_dev = nullptr;
+    {
+        int rs = schur_order(ctx, b, idx_out, k, nip, nj, npp, &slot, &map_dev, &spos_dev);
+        if (rs) return rs;
+    }
     if (form && !keep) return fail(ctx, DNAGPU_EINVAL, "schur: forming in order needs a retained factor");
     int rc = ensure_ws(ctx, chain, npp);
     if (rc) return rc;
@@ -1887,6 +1902,256 @@ int dnagpu_block_form_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, const uin
     red->n = (uint32_t)(3 * k);
     red->np = pad128(red->n);
     launch_schur_extract(T, ldt, red->n, red->np, red->F, nullptr, red->jest, st);
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info(ctx, chain);
+}
+
+// ---- batched forms of the large steps of the condensed schedule (include/dnagpu.h) -------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// widest diagonal block of the spine of ti eliminated tiles with tj kept ones: what a member's panel buffer must hold
+uint32_t batch_panel_cols(uint32_t nip, uint32_t njp) {
+    uint32_t h = njp / 128;
+    for (const auto& bl : sym_spine_blocks((int)(nip / 128))) h = std::max<uint32_t>(h, (uint32_t)bl.second);
+    return h * 128;
+}
+
+// workspaces of members 1 .. nb - 1 on this chain (member 0 works in the chain's own X / W)
+int ensure_batch_ws(dnagpu_ctx* ctx, int chain, int nb, uint32_t npp, uint32_t wcols) {
+    int rc = ensure_ws(ctx, chain, npp);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    if (ws.bnp_cap < npp || ws.bw_cols < wcols) {
+        HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+        for (int b = 0; b < BATCH_MAX; ++b) {
+            if (ws.bX[b]) hipFree(ws.bX[b]);
+            if (ws.bW[b]) hipFree(ws.bW[b]);
+            ws.bX[b] = ws.bW[b] = nullptr;
+        }
+        ws.bnp_cap = std::max(ws.bnp_cap, npp);
+        ws.bw_cols = std::max(ws.bw_cols, wcols);
+    }
+    for (int b = 1; b < nb; ++b) {
+        hipError_t e = hipSuccess;
+        if (!ws.bX[b]) e = hipMalloc(&ws.bX[b], (size_t)ws.bnp_cap * ws.bnp_cap * sizeof(double));
+        if (e == hipSuccess && !ws.bW[b]) e = hipMalloc(&ws.bW[b], ((size_t)ws.bw_cols + 128) * ws.bnp_cap * sizeof(double));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            // nothing half allocated stays behind: the caller falls back to one member at a time and needs the memory for that
+            for (int q = 1; q < BATCH_MAX; ++q) {
+                if (ws.bX[q]) hipFree(ws.bX[q]);
+                if (ws.bW[q]) hipFree(ws.bW[q]);
+                ws.bX[q] = ws.bW[q] = nullptr;
+            }
+            return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "batch workspace allocation", e);
+        }
+    }
+    return DNAGPU_OK;
+}
+
+// the batch of a call on `chain`: F = the members' matrices being factored (the chain's X and bX), X = their kept factors, P = panels
+void set_batch(InvWorkspace& ws, int nb, uint32_t npp, dnagpu_partial* const* pf) {
+    InvBatch& bt = ws.batch;
+    bt = InvBatch();
+    bt.nb = nb;
+    double* F[BATCH_MAX];
+    double* X[BATCH_MAX];
+    double* P[BATCH_MAX];
+    for (int b = 0; b < nb; ++b) {
+        F[b] = b ? ws.bX[b] : ws.X;
+        X[b] = pf[b]->X;
+        P[b] = b ? ws.bW[b] : ws.W;
+    }
+    bt.add(F[0], (size_t)npp * npp, F);
+    bt.add(X[0], (size_t)npp * npp, X);
+    bt.add(P[0], ((size_t)ws.bw_cols + 128) * npp, P);
+}
+
+// info of every member after a batched call (stream synchronised): the first failing member is reported like check_info does
+int check_info_batch(dnagpu_ctx* ctx, int chain, int nb, int* failed_member) {
+    InvWorkspace& ws = ctx->ws[chain];
+    if (failed_member) *failed_member = -1;
+    for (int b = 1; b < nb; ++b)
+        if (ws.info_host[b] != INFO_SENTINEL && ws.info_host[0] == INFO_SENTINEL) {
+            ws.info_host[0] = ws.info_host[b];
+            if (failed_member) *failed_member = b;
+            break;
+        }
+    int rc = check_info(ctx, chain);
+    if (rc == DNAGPU_ENOTPOSDEF && failed_member && *failed_member < 0) *failed_member = 0;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dnagpu_batch_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max, uint32_t k_max, int nb_wanted, int* nb_granted) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!nb_granted || nb_wanted < 1 || !k_max || k_max > n_max) return fail(ctx, DNAGPU_EINVAL, "batch_reserve: bad arguments");
+    nb_wanted = std::min(nb_wanted, (int)BATCH_MAX);
+    const uint32_t njp = pad128(k_max + 1), nip = pad128(n_max - k_max ? n_max - k_max : 1), npp = nip + njp;
+    *nb_granted = 1;
+    if (nb_wanted > 1) {
+        int rc = ensure_batch_ws(ctx, chain, nb_wanted, npp, batch_panel_cols(nip, njp));
+        if (rc == DNAGPU_OK) {
+            *nb_granted = nb_wanted;
+            return DNAGPU_OK;
+        }
+        if (rc != DNAGPU_ENOMEM) return rc;      // (out of memory: nothing of the members' workspaces stays allocated)
+    }
+    return ensure_ws(ctx, chain, npp);
+}
+
+int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const uint32_t* blks, const uint32_t* const* con_stn, const double* const* con_w9,
+                                     const size_t* n_con, const uint32_t* const* idx_keep, const size_t* k, dnagpu_matrix* const* red,
+                                     dnagpu_partial* const* keep, int* failed_member) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (failed_member) *failed_member = -1;
+    if (nb < 1 || nb > BATCH_MAX || !blks || !con_stn || !con_w9 || !n_con || !idx_keep || !k || !red || !keep)
+        return fail(ctx, DNAGPU_EINVAL, "block_form_reduce_batched: bad arguments");
+    Block* blk[BATCH_MAX];
+    uint32_t nip = 0, njp = 0, npp = 0;
+    for (int b = 0; b < nb; ++b) {
+        blk[b] = find_block(ctx, blks[b]);
+        if (!blk[b] || !red[b] || !keep[b] || !keep[b]->spine || !k[b] || !idx_keep[b] || k[b] > blk[b]->n_stn || 3 * k[b] > red[b]->n_max ||
+            (n_con[b] && (!con_stn[b] || !con_w9[b])))
+            return fail(ctx, DNAGPU_EINVAL, "block_form_reduce_batched: bad arguments");
+        const uint32_t n = 3 * blk[b]->n_stn, nj = (uint32_t)(3 * k[b]), ni = n - nj;
+        const uint32_t nip_b = ni ? pad128(ni) : 0, njp_b = pad128(nj + 1);
+        if (b == 0) {
+            nip = nip_b; njp = njp_b; npp = nip + njp;
+        } else if (nip_b != nip || njp_b != njp) {
+            return fail(ctx, DNAGPU_EINVAL, "block_form_reduce_batched: the members differ in shape");
+        }
+        if (npp > keep[b]->n_cap || njp > keep[b]->k_cap) return fail(ctx, DNAGPU_EINVAL, "schur: retained factor capacity");
+        for (int q = 0; q < b; ++q)
+            if (blks[q] == blks[b] || keep[q] == keep[b] || red[q] == red[b]) return fail(ctx, DNAGPU_EINVAL, "block_form_reduce_batched: a member listed twice");
+        for (size_t i = 0; i < n_con[b]; ++i)
+            if (con_stn[b][i] >= blk[b]->n_stn) return fail(ctx, DNAGPU_EINVAL, "schur: constraint station out of range");
+    }
+    if (!nip) return fail(ctx, DNAGPU_EINVAL, "block_form_reduce_batched: nothing to eliminate");
+    int rc = ensure_batch_ws(ctx, chain, nb, npp, batch_panel_cols(nip, njp));
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    // every member's normals formed in its elimination order, in its own matrix (schur_eliminate, one member at a time)
+    for (int b = 0; b < nb; ++b) {
+        const uint32_t n = 3 * blk[b]->n_stn, nj = (uint32_t)(3 * k[b]);
+        int slot = -1;
+        const int32_t* map_dev = nullptr;
+        const uint32_t* spos_dev = nullptr;
+        rc = schur_order(ctx, blk[b], idx_keep[b], k[b], nip, nj, npp, &slot, &map_dev, &spos_dev);
+        if (rc) return rc;
+        dnagpu_partial* kp = keep[b];
+        kp->valid = false;
+        kp->completed = false;
+        kp->factored = false;
+        kp->n = n; kp->nj = nj; kp->nip = nip; kp->njp = njp; kp->npp = npp;
+        if (kp->store) kp->store->n = 0;
+        double* F = b ? ws.bX[b] : ws.X;
+        uint32_t* dstn = nullptr;
+        double* dw = nullptr;
+        if (n_con[b]) {
+            rc = stage_u32(ctx, chain, con_stn[b], n_con[b], &dstn);
+            if (!rc) rc = stage_f64(ctx, chain, con_w9[b], n_con[b] * 9, &dw);
+            if (rc) return rc;
+        }
+        Block* B = blk[b];
+        launch_form_ordered(F, npp, npp, map_dev, spos_dev, B->pair_row, B->pair_col, B->pair_off, B->pair_ent, B->Wblk, B->n_pairs, B->n_wblk,
+                            (uint32_t)chain * (B->n_tblk + B->n_dsblk), dstn, dw, (uint32_t)n_con[b], B->rhs[chain], nip + nj, st);
+        HIPCHK(hipMemcpyAsync(kp->map, map_dev, (size_t)npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        if (n_con[b]) HIPCHK(hipStreamSynchronize(st));     // (the staging buffers are the chain's: the next member's lists go through them)
+    }
+    // the elimination of all members in lock step
+    set_batch(ws, nb, npp, keep);
+    sym_spine_async(ws, ws.X, keep[0]->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+    ws.batch = InvBatch();
+    for (int b = 0; b < nb; ++b) {
+        dnagpu_partial* kp = keep[b];
+        const uint32_t nj = kp->nj;
+        const double* F = b ? ws.bX[b] : ws.X;
+        HIPCHK(hipMemset2DAsync(kp->X + nip + nj, (size_t)npp * sizeof(double), 0, sizeof(double), nip, st));     // the passenger row's panel entries
+        kp->valid = true;
+        red[b]->n = nj;
+        red[b]->np = pad128(nj);
+        launch_schur_extract(F + (size_t)nip * npp + nip, npp, red[b]->n, red[b]->np, red[b]->F, nullptr, red[b]->jest, st);
+    }
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info_batch(ctx, chain, nb, failed_member);
+}
+
+int dnagpu_partial_complete_factor_batched(dnagpu_ctx* ctx, int chain, int nb, dnagpu_partial* const* pf, const dnagpu_matrix* const* kk, int* failed_member) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (failed_member) *failed_member = -1;
+    if (nb < 1 || nb > BATCH_MAX || !pf || !kk) return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_batched: bad arguments");
+    for (int b = 0; b < nb; ++b) {
+        if (!pf[b] || !pf[b]->valid || !pf[b]->spine || !kk[b] || kk[b]->n != pf[b]->nj || pf[b]->nip != pf[0]->nip || pf[b]->njp != pf[0]->njp)
+            return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_batched: bad arguments");
+        for (int q = 0; q < b; ++q)
+            if (pf[q] == pf[b]) return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_batched: a member listed twice");
+    }
+    const uint32_t nip = pf[0]->nip, njp = pf[0]->njp, npp = pf[0]->npp;
+    int rc = ensure_batch_ws(ctx, chain, nb, npp, batch_panel_cols(nip, njp));
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    for (int b = 0; b < nb; ++b) {
+        pf[b]->valid = false;
+        pf[b]->completed = false;
+        double* F = b ? ws.bX[b] : ws.X;      // scratch: the kept block's factorisation passes through it
+        launch_partial_set_trailing(F + (size_t)nip * npp + nip, npp, njp, kk[b]->F, kk[b]->np, pf[b]->nj, st);
+    }
+    set_batch(ws, nb, npp, pf);
+    sym_spine_kept_async(ws, ws.X, pf[0]->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+    ws.batch = InvBatch();
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    rc = check_info_batch(ctx, chain, nb, failed_member);
+    for (int b = 0; b < nb; ++b) pf[b]->factored = rc == DNAGPU_OK;
+    return rc;
+}
+
+int dnagpu_partial_finish_batched(dnagpu_ctx* ctx, int chain, int nb, dnagpu_partial* const* pf, dnagpu_matrix* const* inv) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (nb < 1 || nb > BATCH_MAX || !pf || !inv) return fail(ctx, DNAGPU_EINVAL, "partial_finish_batched: bad arguments");
+    for (int b = 0; b < nb; ++b) {
+        if (!pf[b] || !pf[b]->factored || !pf[b]->spine || !inv[b] || pf[b]->n > inv[b]->n_max || pf[b]->nip != pf[0]->nip || pf[b]->njp != pf[0]->njp)
+            return fail(ctx, DNAGPU_EINVAL, "partial_finish_batched: bad arguments");
+        for (int q = 0; q < b; ++q)
+            if (pf[q] == pf[b] || inv[q] == inv[b]) return fail(ctx, DNAGPU_EINVAL, "partial_finish_batched: a member listed twice");
+    }
+    const uint32_t nip = pf[0]->nip, njp = pf[0]->njp, npp = pf[0]->npp;
+    int rc = ensure_batch_ws(ctx, chain, nb, npp, batch_panel_cols(nip, njp));
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    for (int b = 0; b < nb; ++b) {
+        pf[b]->factored = false;
+        pf[b]->completed = false;
+    }
+    set_batch(ws, nb, npp, pf);
+    sym_spine_finish_async(ws, ws.X, pf[0]->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+    ws.batch = InvBatch();
+    for (int b = 0; b < nb; ++b) {
+        const double* F = b ? ws.bX[b] : ws.X;
+        inv[b]->n = pf[b]->n;
+        inv[b]->np = pad128(pf[b]->n);
+        launch_init_padding(inv[b]->F, inv[b]->n, inv[b]->np, st);
+        launch_unpermute(F, npp, npp, pf[b]->map, inv[b]->F, inv[b]->np, st);
+    }
+    HIPCHK(hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), st));
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);

@@ -57,6 +57,8 @@ void dna_adjust::FreeDevice() {
         if (work_[c]) dnagpu_matrix_destroy(ctx_, work_[c]);
         if (kwork_[c]) dnagpu_matrix_destroy(ctx_, kwork_[c]);
         work_[c] = kwork_[c] = nullptr;
+        for (dnagpu_matrix* m : kbatch_[c]) dnagpu_matrix_destroy(ctx_, m);
+        kbatch_[c].clear();
     }
     dnagpu_destroy(ctx_);
     ctx_ = nullptr;

@@ -218,6 +218,7 @@ private:
         bool part_spine = false;              // a.defer_variances = 2: the kept factor in its light form (dnagpu_partial_create_spine)
         bool part_in_rigvar = false;          // the factor's inverse waits in rigvar's storage (dnagpu_partial_create_in): rigvar has n + 256
         bool rig_direct = false;              // this iteration's rigorous solve works in rigvar itself (no copy afterwards)
+        bool prefactored = false;             // a batched rigorous solve has completed the factor already (RigorousBatch)
         bool inverse_pending = false;
         bool inverse_kept = false;            // CondensedReuse(): rigvar holds this adjustment's inverse, part its factor
         dnagpu_matrix* red = nullptr;         // Schur complement onto keep + reduced right-hand side (dnagpu_block_reduce)
@@ -323,6 +324,7 @@ public:
     void PhasedFinaliseBlock(int chain, UINT32 k);
     // ---- condensed schedule (a.schur_carry): the steps of one iteration ---------------------------------
     bool CondensedSchedule() const { return SchurCarry() && condensed_ok_; }
+    uint64_t BatchedBlockSteps() const { return batched_members_.load(); }      // block steps that went through batched calls (a.batch_blocks)
     // (A) independent per block: eliminate every station the block shares with no other block
     void CondenseBlock(int chain, UINT32 k);
     // (B) the forward and the reverse chain on the condensed blocks: jfwd[k] / jrev[k-1] exactly as the block-level chain leaves them
@@ -417,6 +419,22 @@ private:
     std::atomic<bool> chain_failed_{false};
     void OnEveryChain(const std::function<void(int)>& body);
     void ForBlocks(const std::vector<UINT32>& blocks, const std::function<void(int, UINT32)>& step);
+    // a.batch_blocks: blocks of one shape as batches (dnagpu_*_batched).  phase: 0 condensing, 1 rigorous solve, 2 variance matrices
+    int BatchCap() const;
+    bool BatchEligible(UINT32 block, int phase) const;
+    std::vector<std::vector<UINT32>> BatchGroups(const std::vector<UINT32>& blocks, int phase) const;
+    void ForGroups(const std::vector<std::vector<UINT32>>& groups, const std::function<void(int, const std::vector<UINT32>&)>& step);
+    void EnsurePartial(UINT32 block);
+    bool BatchWorkspaces(int chain, const std::vector<UINT32>& blocks);
+    void CondenseBatch(int chain, const std::vector<UINT32>& blocks);
+    void NoteCondensed(UINT32 block);
+    void PrepareKeptBlock(int chain, UINT32 block, int kind, dnagpu_matrix* K);
+    void RigorousBatch(int chain, const std::vector<UINT32>& blocks);
+    void FinishVariancesBlock(int chain, UINT32 block);
+    void FinishVariancesBatch(int chain, const std::vector<UINT32>& blocks);
+    std::vector<dnagpu_matrix*> kbatch_[DNAGPU_NUM_CHAINS];   // the kept blocks of the members of a batched rigorous solve
+    std::atomic<uint64_t> batched_members_{0};
+    int batch_limit_ = 0;                                     // members beyond the first that the memory budget admits (PrepareCondensedBlocks)
     void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
     void Check(int rc, UINT32 block, const char* where);
     void SetmaxCorr(double v) { maxCorr_ = v; }

@@ -10,6 +10,7 @@
 #include <deque>
 #include <exception>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -455,6 +456,7 @@ void dna_adjust::AllocateChainData() {
 
 void dna_adjust::PrepareCondensedBlocks() {
     condensed_ok_ = false;
+    batch_limit_ = 0;
     if (projectSettings_.a.adjust_mode == SimultaneousMode || !projectSettings_.a.schur_carry) {
         AllocateChainData();
         return;
@@ -540,12 +542,16 @@ void dna_adjust::PrepareCondensedBlocks() {
     const int chains = NumChains();
     if (max_keep)
         for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &kwork_[c]), 0, "PrepareAdjustment(): kept-block work matrix");
+    // a.batch_blocks: every member of a batch beyond the first works in a matrix of its own (+ the panels of a diagonal block, a
+    // fifth of it): as many as what is left of the budget admits
+    batch_limit_ = (int)std::max(0.0, std::min(1.0e6, budget / (1.25 * sq((double)max_unknowns_))));
 }
 
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
     B.rig_direct = false;
     B.var_deferred = false;         // (a factor left from the previous iteration is overwritten by this one's)
+    B.prefactored = false;
     if (B.keep.empty()) return;
     if (CondensedReuse() && B.inverse_kept) {
         // same normals as in the iteration that kept the factor: only the right-hand side is reduced again
@@ -555,21 +561,7 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     }
     dnagpu_matrix* W = work_[c];
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
-    if (B.part_allowed && !B.part) {
-        std::lock_guard<std::mutex> lk(alloc_mutex_);
-        const UINT32 n = (UINT32)v_parameterStationList_[k].size() * 3, nk = (UINT32)B.keep.size() * 3;
-        int rc;
-        if (B.part_in_rigvar) {
-            if (!B.rigvar) Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
-            rc = B.part_spine ? dnagpu_partial_create_spine(ctx_, n, nk, B.rigvar, &B.part) : dnagpu_partial_create_in(ctx_, n, nk, B.rigvar, &B.part);
-        } else {
-            rc = B.part_spine ? dnagpu_partial_create_spine(ctx_, n, nk, nullptr, &B.part) : dnagpu_partial_create(ctx_, n, nk, &B.part);
-        }
-        if (rc != DNAGPU_OK) {
-            B.part = nullptr;          // no room after all: this block inverts its normals in the rigorous step as before
-            B.part_allowed = false;
-        }
-    }
+    EnsurePartial(k);
     B.part_valid = false;
     if (B.part && B.part_in_rigvar) B.has_rigvar = false;      // (its storage holds the factor until the rigorous solve of this iteration)
     if (B.part) {
@@ -586,6 +578,30 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
         Check(dnagpu_block_reduce(ctx_, c, k, W, B.keep.data(), B.keep.size(), B.red, nullptr), k, "Solve()");
     }
     B.part_valid = B.part != nullptr;
+    NoteCondensed(k);
+}
+
+// the retained factor of a block that may keep one (PrepareCondensedBlocks), created on first use
+void dna_adjust::EnsurePartial(UINT32 k) {
+    block_t& B = blocks_[k];
+    if (!B.part_allowed || B.part) return;
+    std::lock_guard<std::mutex> lk(alloc_mutex_);
+    const UINT32 n = (UINT32)v_parameterStationList_[k].size() * 3, nk = (UINT32)B.keep.size() * 3;
+    int rc;
+    if (B.part_in_rigvar) {
+        if (!B.rigvar) Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
+        rc = B.part_spine ? dnagpu_partial_create_spine(ctx_, n, nk, B.rigvar, &B.part) : dnagpu_partial_create_in(ctx_, n, nk, B.rigvar, &B.part);
+    } else {
+        rc = B.part_spine ? dnagpu_partial_create_spine(ctx_, n, nk, nullptr, &B.part) : dnagpu_partial_create(ctx_, n, nk, &B.part);
+    }
+    if (rc != DNAGPU_OK) {
+        B.part = nullptr;          // no room after all: this block inverts its normals in the rigorous step as before
+        B.part_allowed = false;
+    }
+}
+
+void dna_adjust::NoteCondensed(UINT32 k) {
+    const block_t& B = blocks_[k];
     const double nk = 3.0 * (double)B.keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
     // a Cholesky factorisation of the eliminated part (plus its triangular inverse when the factor is kept), the panel under
@@ -594,33 +610,138 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     condense_count_++;
 }
 
+// ---- a.batch_blocks: blocks of one shape through the large steps as one batch (include/dnagpu.h, dnagpu_*_batched) ---------------
+int dna_adjust::BatchCap() const {
+    static const int env = getenv("DNAGPU_BATCH") ? atoi(getenv("DNAGPU_BATCH")) : -1;
+    const int v = env >= 0 ? env : (int)projectSettings_.a.batch_blocks;
+    return std::max(1, std::min(std::min(v, 1 + batch_limit_), (int)DNAGPU_BATCH_MAX));
+}
+
+bool dna_adjust::BatchEligible(UINT32 k, int phase) const {
+    const block_t& B = blocks_[k];
+    if (B.keep.empty() || !B.part_allowed || !B.part_spine || ReuseRequested() || !DeferVariances()) return false;
+    if (B.keep.size() >= v_parameterStationList_[k].size()) return false;      // (every station shared: nothing to eliminate, nothing to merge)
+    switch (phase) {
+        case 0: return true;
+        case 1: return B.part != nullptr && B.part_valid && !v_blockMeta_[k]._blockIsolated;
+        default: return B.part != nullptr && B.var_deferred;
+    }
+}
+
+// The blocks in groups of one shape (the padded orders of the eliminated and the kept part: what the merged launches must agree on),
+// at most BatchCap() members each, the largest first; a block that cannot be batched is a group of its own.
+std::vector<std::vector<UINT32>> dna_adjust::BatchGroups(const std::vector<UINT32>& blocks, int phase) const {
+    std::vector<std::vector<UINT32>> groups;
+    const size_t cap = (size_t)BatchCap();
+    std::map<std::pair<UINT32, UINT32>, std::vector<UINT32>> by_shape;
+    for (UINT32 k : blocks) {
+        if (cap < 2 || !BatchEligible(k, phase)) {
+            groups.push_back({k});
+            continue;
+        }
+        const UINT32 n = 3 * (UINT32)v_parameterStationList_[k].size(), nk = 3 * (UINT32)blocks_[k].keep.size();
+        auto pad = [](UINT32 v) { return v == 0 ? 128u : ((v + 127u) / 128u) * 128u; };
+        by_shape[{n > nk ? pad(n - nk) : 0u, pad(nk + 1)}].push_back(k);
+    }
+    for (auto& kv : by_shape)
+        for (size_t i = 0; i < kv.second.size(); i += cap)
+            groups.emplace_back(kv.second.begin() + i, kv.second.begin() + std::min(kv.second.size(), i + cap));
+    std::stable_sort(groups.begin(), groups.end(), [](const std::vector<UINT32>& a, const std::vector<UINT32>& b) { return a.size() > b.size(); });
+    return groups;
+}
+
+// group g runs on chain g % chains, every chain its groups in order: a batch's workspaces belong to a chain, so the large group
+// meets the same chain in every phase and every iteration
+void dna_adjust::ForGroups(const std::vector<std::vector<UINT32>>& groups, const std::function<void(int, const std::vector<UINT32>&)>& step) {
+    const int chains = NumChains();
+    OnEveryChain([&](int c) {
+        for (size_t g = (size_t)c; g < groups.size(); g += (size_t)chains) {
+            if (chain_failed_ || IsCancelled()) return;
+            currentBlock_ = groups[g].front();
+            const auto t0 = std::chrono::steady_clock::now();
+            step(c, groups[g]);
+            lastBlockElapsedMs_ = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        }
+    });
+}
+
+// the workspaces of a batch of these (equally shaped) blocks on chain c; false: they do not fit (the members then go one at a time)
+bool dna_adjust::BatchWorkspaces(int c, const std::vector<UINT32>& ks) {
+    const UINT32 k0 = ks[0];
+    int granted = 1;
+    Check(dnagpu_batch_reserve(ctx_, c, 3 * (UINT32)v_parameterStationList_[k0].size(), 3 * (UINT32)blocks_[k0].keep.size(), (int)ks.size(), &granted), k0,
+          "PrepareAdjustment(): batch workspaces");
+    return granted >= (int)ks.size();
+}
+
+// CondenseBlock for the members of a batch: rhs and retained factor per member, then normals + elimination of all of them merged
+void dna_adjust::CondenseBatch(int c, const std::vector<UINT32>& ks) {
+    std::vector<UINT32> members;
+    for (UINT32 k : ks) {
+        block_t& B = blocks_[k];
+        B.rig_direct = false;
+        B.var_deferred = false;
+        B.prefactored = false;
+        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+        EnsurePartial(k);
+        B.part_valid = false;
+        if (B.part && B.part_in_rigvar) B.has_rigvar = false;
+        if (B.part)
+            members.push_back(k);
+        else
+            CondenseBlock(c, k);       // (no room for its factor after all)
+    }
+    if (members.size() < 2) {
+        for (UINT32 k : members) CondenseBlock(c, k);
+        return;
+    }
+    const int nb = (int)members.size();
+    std::vector<const UINT32*> con_stn(nb), keep(nb);
+    std::vector<const double*> con_w9(nb);
+    std::vector<size_t> n_con(nb), nkeep(nb);
+    std::vector<dnagpu_matrix*> red(nb);
+    std::vector<dnagpu_partial*> part(nb);
+    for (int b = 0; b < nb; ++b) {
+        block_t& B = blocks_[members[b]];
+        con_stn[b] = B.con_inner.stn.data();
+        con_w9[b] = B.con_inner.w9.data();
+        n_con[b] = B.con_inner.stn.size();
+        keep[b] = B.keep.data();
+        nkeep[b] = B.keep.size();
+        red[b] = B.red;
+        part[b] = B.part;
+    }
+    if (!BatchWorkspaces(c, members)) {         // no room for the members' workspaces: one after the other
+        for (UINT32 k : members) CondenseBlock(c, k);
+        return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int failed = -1;
+    const int rc = dnagpu_block_form_reduce_batched(ctx_, c, nb, members.data(), con_stn.data(), con_w9.data(), n_con.data(), keep.data(), nkeep.data(),
+                                                    red.data(), part.data(), &failed);
+    Check(rc, members[failed >= 0 ? failed : 0], "Solve()");
+    if (profileTimings_)
+        profileUpdateNormalsNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    batched_members_ += (uint64_t)nb;
+    for (UINT32 k : members) {
+        blocks_[k].part_valid = true;
+        NoteCondensed(k);
+    }
+}
+
 // The rigorous solve of a block whose condensing step kept its factor (a.keep_factors): the kept block gets exactly what the
 // forward (kind 0) / reverse (1) / combination (2) solve adds to the shared stations, in the same order, and the retained
 // factor is completed to the inverse of the whole block -- W holds what SolveTry's dnagpu_invert would have left
 bool dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W) {
     block_t& B = blocks_[k];
     const blockMeta_t& meta = v_blockMeta_[k];
-    const bool rev_in = !meta._blockLast && !B.c_next.empty();
-    const bool fwd_in = !meta._blockFirst && !B.c_prev.empty();
     dnagpu_matrix* K = kwork_[c];
-    Check(dnagpu_block_load_reduced(ctx_, c, blockCount_ + k, k, B.keep.data(), B.keep.size(), B.red, K), k, "UpdateNormals()");
-    if (kind == 0) {
-        AddConstraints(c, K, B.ccon_fwd, +1, k);
-        if (fwd_in)
-            Check(dnagpu_junction_scatter(ctx_, c, K, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesForward()");
-    } else {
-        if (rev_in) Check(dnagpu_junction_scatter(ctx_, c, K, B.c_next.data(), B.c_next.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
-        AddConstraints(c, K, B.ccon_rev, +1, k);
-        if (kind == 2) {
-            if (fwd_in)
-                Check(dnagpu_junction_scatter(ctx_, c, K, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesCombine()");
-            AddConstraints(c, K, B.ccon_cmb, -1, k);
-        }
-    }
+    if (!B.prefactored) PrepareKeptBlock(c, k, kind, K);
     const bool defer = DeferVariances();
     if (defer) {
         // the factor of the whole block, and the corrections from it; the inverse waits for the end of the iterations
-        Check(dnagpu_partial_complete_factor(ctx_, c, B.part, K), k, "Solve()");
+        if (!B.prefactored) Check(dnagpu_partial_complete_factor(ctx_, c, B.part, K), k, "Solve()");
+        B.prefactored = false;
         Check(dnagpu_partial_solve(ctx_, c, k, B.part), k, "Solve()");
         B.var_deferred = true;
     } else {
@@ -639,6 +760,62 @@ bool dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W
     return defer;
 }
 
+// the kept block of a rigorous solve from a retained factor: the reduced block + what the forward (kind 0) / reverse (1) /
+// combination (2) solve adds to the shared stations, in the same order
+void dna_adjust::PrepareKeptBlock(int c, UINT32 k, int kind, dnagpu_matrix* K) {
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    const bool rev_in = !meta._blockLast && !B.c_next.empty();
+    const bool fwd_in = !meta._blockFirst && !B.c_prev.empty();
+    Check(dnagpu_block_load_reduced(ctx_, c, blockCount_ + k, k, B.keep.data(), B.keep.size(), B.red, K), k, "UpdateNormals()");
+    if (kind == 0) {
+        AddConstraints(c, K, B.ccon_fwd, +1, k);
+        if (fwd_in)
+            Check(dnagpu_junction_scatter(ctx_, c, K, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesForward()");
+    } else {
+        if (rev_in) Check(dnagpu_junction_scatter(ctx_, c, K, B.c_next.data(), B.c_next.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
+        AddConstraints(c, K, B.ccon_rev, +1, k);
+        if (kind == 2) {
+            if (fwd_in)
+                Check(dnagpu_junction_scatter(ctx_, c, K, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesCombine()");
+            AddConstraints(c, K, B.ccon_cmb, -1, k);
+        }
+    }
+}
+
+// The first half of RigorousBlock for the members of a batch: every member's kept block as its rigorous solve builds it, their factors
+// completed merged (the kept blocks are small: launches bound by latency, now with nb times the tiles).  The members' own solves
+// (substitution, estimates, junction carries: RigorousBlock, which finds the factor done) follow on whichever chain is free.
+void dna_adjust::RigorousBatch(int c, const std::vector<UINT32>& ks) {
+    const int nb = (int)ks.size();
+    if (nb >= 2 && BatchWorkspaces(c, ks)) {
+        {
+            std::lock_guard<std::mutex> lk(alloc_mutex_);
+            size_t max_keep = 0;
+            for (const block_t& B : blocks_) max_keep = std::max(max_keep, B.keep.size());
+            while (kbatch_[c].size() < (size_t)nb) {
+                dnagpu_matrix* m = nullptr;
+                Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &m), ks[0], "kept-block work matrix");
+                kbatch_[c].push_back(m);
+            }
+        }
+        std::vector<dnagpu_partial*> part(nb);
+        std::vector<const dnagpu_matrix*> kk(nb);
+        for (int b = 0; b < nb; ++b) {
+            const UINT32 k = ks[b];
+            const blockMeta_t& meta = v_blockMeta_[k];
+            const int kind = meta._blockLast ? 0 : meta._blockFirst ? 1 : 2;
+            PrepareKeptBlock(c, k, kind, kbatch_[c][b]);
+            part[b] = blocks_[k].part;
+            kk[b] = kbatch_[c][b];
+        }
+        int failed = -1;
+        Check(dnagpu_partial_complete_factor_batched(ctx_, c, nb, part.data(), kk.data(), &failed), ks[failed >= 0 ? failed : 0], "Solve()");
+        batched_members_ += (uint64_t)nb;
+        for (UINT32 k : ks) blocks_[k].prefactored = true;
+    }
+}
+
 // a.defer_variances: X^T X for every block whose last rigorous solve left its inverse as a completed factor
 void dna_adjust::FinishDeferredVariances() {
     std::vector<UINT32> todo;
@@ -646,26 +823,63 @@ void dna_adjust::FinishDeferredVariances() {
         if (OwnsBlock(k) && blocks_[k].var_deferred && blocks_[k].part) todo.push_back(k);
     if (todo.empty()) return;
     FinishStagedCopies();
-    ForBlocks(todo, [&](int c, UINT32 k) {
-        block_t& B = blocks_[k];
-        dnagpu_matrix* W = work_[c];
-        if (!Staged()) {
-            if (!B.rigvar) {
-                std::lock_guard<std::mutex> lk(alloc_mutex_);
-                Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
-            }
-            W = B.rigvar;
+    ForGroups(BatchGroups(todo, 2), [&](int c, const std::vector<UINT32>& ks) {
+        if (ks.size() >= 2 && !Staged())
+            FinishVariancesBatch(c, ks);
+        else
+            for (UINT32 k : ks) FinishVariancesBlock(c, k);
+    });
+}
+
+void dna_adjust::FinishVariancesBlock(int c, UINT32 k) {
+    block_t& B = blocks_[k];
+    dnagpu_matrix* W = work_[c];
+    if (!Staged()) {
+        if (!B.rigvar) {
+            std::lock_guard<std::mutex> lk(alloc_mutex_);
+            Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
         }
-        Check(dnagpu_partial_finish(ctx_, c, B.part, W), k, "Solve()");
+        W = B.rigvar;
+    }
+    Check(dnagpu_partial_finish(ctx_, c, B.part, W), k, "Solve()");
+    B.var_deferred = false;
+    StoreRigorousVariances(c, k, W);
+    Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
+    const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    // X^T X, and in the light form the inverse of the factor first (its diagonal blocks exist: ~ the eliminated part's trtri
+    // with the kept rows riding along)
+    algorithmic_flops_ += n * n * n / 3.0 + (B.part_spine ? ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk : 0.0);
+}
+
+void dna_adjust::FinishVariancesBatch(int c, const std::vector<UINT32>& ks) {
+    const int nb = (int)ks.size();
+    if (!BatchWorkspaces(c, ks)) {
+        for (UINT32 k : ks) FinishVariancesBlock(c, k);
+        return;
+    }
+    std::vector<dnagpu_partial*> part(nb);
+    std::vector<dnagpu_matrix*> inv(nb);
+    for (int b = 0; b < nb; ++b) {
+        block_t& B = blocks_[ks[b]];
+        if (!B.rigvar) {
+            std::lock_guard<std::mutex> lk(alloc_mutex_);
+            Check(dnagpu_matrix_create(ctx_, RigvarCapacity(ks[b]), &B.rigvar), ks[b], "rigorous variance matrix");
+        }
+        part[b] = B.part;
+        inv[b] = B.rigvar;
+    }
+    Check(dnagpu_partial_finish_batched(ctx_, c, nb, part.data(), inv.data()), ks[0], "Solve()");
+    batched_members_ += (uint64_t)nb;
+    for (UINT32 k : ks) {
+        block_t& B = blocks_[k];
         B.var_deferred = false;
-        StoreRigorousVariances(c, k, W);
-        Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
+        StoreRigorousVariances(c, k, B.rigvar);
         const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
         std::lock_guard<std::mutex> lk(corr_mutex_);
-        // X^T X, and in the light form the inverse of the factor first (its diagonal blocks exist: ~ the eliminated part's trtri
-        // with the kept rows riding along)
-        algorithmic_flops_ += n * n * n / 3.0 + (B.part_spine ? ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk : 0.0);
-    });
+        algorithmic_flops_ += n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    }
+    Check(dnagpu_chain_sync(ctx_, c), ks[0], "UpdateEstimatesFinal()");
 }
 
 // PhasedForwardBlock on the condensed block: same additions, same order
@@ -757,7 +971,16 @@ void dna_adjust::ForBlocks(const std::vector<UINT32>& blocks, const std::functio
 
 void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks) {
     forward_ = true;
-    ForBlocks(blocks, [&](int c, UINT32 k) { CondenseBlock(c, k); });
+    if (BatchCap() < 2) {
+        ForBlocks(blocks, [&](int c, UINT32 k) { CondenseBlock(c, k); });
+        return;
+    }
+    ForGroups(BatchGroups(blocks, 0), [&](int c, const std::vector<UINT32>& ks) {
+        if (ks.size() >= 2)
+            CondenseBatch(c, ks);
+        else
+            CondenseBlock(c, ks[0]);
+    });
 }
 
 // the forward chain on chain 0 beside the reverse chain on chain 1 (one after the other without a.multi_thread)
@@ -775,7 +998,8 @@ void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks) {
     FinishStagedCopies();          // (the previous iteration's: their host buffers are about to be written again)
     forward_ = false;
     isCombining_ = true;
-    ForBlocks(blocks, [&](int c, UINT32 k) { RigorousBlock(c, k); });
+    if (BatchCap() >= 2) ForGroups(BatchGroups(blocks, 1), [&](int c, const std::vector<UINT32>& ks) { RigorousBatch(c, ks); });
+    if (!IsCancelled()) ForBlocks(blocks, [&](int c, UINT32 k) { RigorousBlock(c, k); });
     isCombining_ = false;
 }
 

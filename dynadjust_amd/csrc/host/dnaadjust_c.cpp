@@ -50,6 +50,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->keep_factors = 1;
     s->dist_two_level = 1;
     s->defer_variances = 2;
+    s->batch_blocks = 16;
 }
 
 int dnaadj_create(dnaadj_handle** out) {
@@ -101,6 +102,7 @@ int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
         if (s->dist_transport) p.a.dist_transport = s->dist_transport;
         p.a.dist_two_level = (uint16_t)(s->dist_two_level ? 1 : 0);
         p.a.defer_variances = (uint16_t)(s->defer_variances < 0 ? 0 : s->defer_variances > 2 ? 2 : s->defer_variances);
+        p.a.batch_blocks = (uint16_t)(s->batch_blocks < 0 ? 0 : s->batch_blocks > 16 ? 16 : s->batch_blocks);
         if (s->network_name) p.g.network_name = s->network_name;
         if (s->output_folder) p.g.output_folder = s->output_folder;
         h->adj->PrepareAdjustment(p);
@@ -488,6 +490,7 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status) {
 }
 int dnaadj_staged(const dnaadj_handle* h) { return (h && h->adj && h->adj->IsStaged()) ? 1 : 0; }
 int dnaadj_condensed_schedule(const dnaadj_handle* h) { return (h && h->adj && h->adj->CondensedSchedule()) ? 1 : 0; }
+uint64_t dnaadj_batched_block_steps(const dnaadj_handle* h) { return (h && h->adj) ? h->adj->BatchedBlockSteps() : 0; }
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block) {
     return (h && h->adj && block < h->adj->blockCount()) ? h->adj->CondensedPayloadDoubles(block) : 0;
 }

@@ -231,6 +231,11 @@ struct adjust_settings {
     // substitute block by block, and the inverse of the factor is paid once, with the variance matrices, after the last iteration.
     // 1: the condensing step inverts the eliminated part's factor in every iteration (needed by nothing but the final inverse).
     UINT16 defer_variances = 2;
+    // blocks of one shape (equal padded orders of the eliminated and the kept part) go through the large steps of the condensed
+    // schedule as ONE batch of up to this many members: merged launches, in lock step (include/dnagpu.h, dnagpu_*_batched).  The
+    // reference's blocks have no such coupling -- its Solve() calls follow each other (ADJ:2812, ADJ:3512, ADJ:3556) -- and every
+    // member's results are the bits of the unbatched calls.  0 / 1: off.  DNAGPU_BATCH overrides.
+    UINT16 batch_blocks = 16;
 };
 struct output_settings {
     UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement

@@ -8,6 +8,12 @@ namespace dnagpu {
 
 enum KMode { KM_FULL = 0, KM_LE_J = 1, KM_GE_J = 2, KM_LE_I = 3, KM_GE_I = 4 };
 
+// A batched launch: the same product (or leaf) on `nb` matrices of one shape, member b's operands at the member-0 addresses plus
+// an element offset of their own (their buffers are separate allocations).  The workgroups of member 1 follow those of member 0
+// in the same launch: no launch boundary, no partly filled last wave between them, and the short launches at the bottom of the
+// recursion have nb times the tiles (sym_inverse.h: InvBatch).
+constexpr int BATCH_MAX = 16;
+
 struct GemmArgs {
     const double* A;
     const double* B;
@@ -25,6 +31,13 @@ struct GemmArgs {
     int grid;               // number of workgroups (= table length)
     int tile;               // block tile of the launch: 128 (throughput) or 64 (small launches)
     int k_ascending = 0;    // diagnostic: 1 = walk k upwards also for the k >= i / k >= j ranges (see gemm_f64_dma_kernel)
+    int nb = 1;             // members of a batched launch (grid.y); member b works on A + dA[b], B + dB[b], C + dC[b]
+    long long dA[BATCH_MAX], dB[BATCH_MAX], dC[BATCH_MAX];
+};
+
+struct LeafBatch {
+    int nb = 1;
+    long long dA[BATCH_MAX], dX[BATCH_MAX];     // member b: A + dA[b], X + dX[b], info[b]
 };
 
 // ---- fused small launches ---------------------------------------------------------------------------------------------------
@@ -77,7 +90,7 @@ bool gemm_128_takes_pairs();   // the LDS-DMA kernel does; the register-staged d
 std::vector<int> split_tile_columns(int mt, int nt, int K, int kmode, int lower, int world);
 
 void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);
-void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s);
+void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s, const LeafBatch* batch = nullptr);
 void launch_unpack_lower(const double* ap, double* F, uint32_t n, uint32_t np, hipStream_t s);
 void launch_pack_lower(const double* F, double* ap, uint32_t n, uint32_t np, hipStream_t s);
 void launch_init_padded(double* F, uint32_t n, uint32_t np, hipStream_t s);

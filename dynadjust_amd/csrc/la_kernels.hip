@@ -55,7 +55,8 @@ namespace dnagpu {
 // One TILE x TILE tile of C (it, jt in units of TILE) of a launch: the k range from the launch's kmode, then reg_tile_product
 // (gemm_tile_reg.h); `lds`: 4 * OPBUF doubles.
 template <bool A_KC, bool B_KC, int TILE, int WAVES, class Args>
-__device__ __forceinline__ void gemm_tile_body(const Args& a, const int it, const int jt, double* lds) {
+__device__ __forceinline__ void gemm_tile_body(const Args& a, const int it, const int jt, double* lds, long long dA = 0, long long dB = 0,
+                                               long long dC = 0) {
     using G = Geo<TILE, WAVES>;
     // triangular operands restrict the k range in units of the 128-wide blocks of the recursion
     const int bi = (it * TILE) / 128, bj = (jt * TILE) / 128;
@@ -68,7 +69,7 @@ __device__ __forceinline__ void gemm_tile_body(const Args& a, const int it, cons
         default: break;
     }
     if (kend > a.K) kend = a.K;
-    reg_tile_product<A_KC, B_KC, TILE, WAVES>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, it * TILE, jt * TILE, kbeg, kend, a.alpha, a.beta,
+    reg_tile_product<A_KC, B_KC, TILE, WAVES>(a.A + dA, a.lda, a.B + dB, a.ldb, a.C + dC, a.ldc, it * TILE, jt * TILE, kbeg, kend, a.alpha, a.beta,
                                               a.mirror && (it != jt), lds, lds + 2 * G::OPBUF);
 }
 
@@ -80,7 +81,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
     // every XCD walks its own work-balanced list of 2-D super-tiles (L2 locality).
     const uint32_t packed = a.order[blockIdx.x];
     if (packed == 0xffffffffu) return;
-    gemm_tile_body<A_KC, B_KC, TILE, WAVES>(a, (int)(packed >> 16), (int)(packed & 0xffffu), lds);
+    long long dA = 0, dB = 0, dC = 0;
+    if (a.nb > 1) {     // a batched launch: this workgroup's member (uniform: scalar loads from the kernel arguments)
+        const int b = (int)blockIdx.y;
+        dA = a.dA[b];
+        dB = a.dB[b];
+        dC = a.dC[b];
+    }
+    gemm_tile_body<A_KC, B_KC, TILE, WAVES>(a, (int)(packed >> 16), (int)(packed & 0xffffu), lds, dA, dB, dC);
 }
 
 // ---- fused small launches (la_kernels.h) -------------------------------------------------------------------------------------
@@ -162,6 +170,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
     // One table entry per workgroup, or two (a.pairs): a workgroup then computes two tiles one after the other, the second one
     // walked TOWARDS the k all tiles have in common (bit 15 of the entry), see tile_order.hip.
     const int nparts = a.pairs ? 2 : 1;
+    long long dA = 0, dB = 0, dC = 0;
+    if (a.nb > 1) {     // a batched launch: this workgroup's member (uniform: scalar loads from the kernel arguments)
+        const int b = (int)blockIdx.y;
+        dA = a.dA[b];
+        dB = a.dB[b];
+        dC = a.dC[b];
+    }
 #pragma nounroll
     for (int part = 0; part < nparts; ++part) {
         const uint32_t packed = a.order[(size_t)blockIdx.x * nparts + part];
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
         // which share operand panels in their XCD's L2, then start together at the common end and stay in step, instead of
         // each starting at its own first k and drifting apart by (tile distance) x 128 for the whole run.
         const bool down = ((a.kmode == KM_GE_J || a.kmode == KM_GE_I) && !a.k_ascending) != flip;
-        dma_tile_product<A_KC, B_KC, WAVES>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, it * TILE, jt * TILE, kbeg, kend, down, a.alpha, a.beta,
+        dma_tile_product<A_KC, B_KC, WAVES>(a.A + dA, a.lda, a.B + dB, a.ldb, a.C + dC, a.ldc, it * TILE, jt * TILE, kbeg, kend, down, a.alpha, a.beta,
                                             a.mirror && (it != jt), lds0, lds1);
     }
 }
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
 
 template <int WAVES>
 static void launch_gemm_dma(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
-    dim3 grid(a.grid), block(64 * WAVES);
+    dim3 grid(a.grid, a.nb), block(64 * WAVES);
     if (!a_kc && !b_kc)
         hipLaunchKernelGGL((gemm_f64_dma_kernel<false, false, WAVES>), grid, block, 0, s, a);
     else if (!a_kc && b_kc)
@@ -203,7 +218,7 @@ static void launch_gemm_dma(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s
 
 template <int TILE, int WAVES>
 static void launch_gemm_t(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
-    dim3 grid(a.grid), block(64 * WAVES);
+    dim3 grid(a.grid, a.nb), block(64 * WAVES);
     if (!a_kc && !b_kc)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false, TILE, WAVES>), grid, block, 0, s, a);
     else if (!a_kc && b_kc)

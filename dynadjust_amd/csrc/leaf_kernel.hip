@@ -22,16 +22,24 @@
 namespace dnagpu {
 
 __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __restrict__ A, int lda, double* __restrict__ X,
-                                                               int ldx, int o, int* info) {
+                                                               int ldx, int o, int* info, LeafBatch batch) {
     // LT: the factor of the current diagonal block, transposed (wave 0 only) -- first, so that its constant addresses fit the
     // 16-bit offset field of the ds instructions (behind S they took a register each)
     __shared__ double SH[256 + 36 * leaf::BS];
     double* const S = SH + 256;
+    if (batch.nb > 1) {     // one workgroup per member of the batch
+        const int b = (int)blockIdx.x;
+        A += batch.dA[b];
+        X += batch.dX[b];
+        info += b;
+    }
     leaf::potrf_trtri_tile<8>(A + (size_t)o * lda + o, lda, X + (size_t)o * ldx + o, ldx, o, info, SH, [S](int bi, int bj) { return S + (bi * (bi + 1) / 2 + bj) * leaf::BS; });
 }
 
-void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s) {
-    hipLaunchKernelGGL(leaf_potrf_trtri_kernel, dim3(1), dim3(512), 0, s, A, lda, X, ldx, o, info);
+void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s, const LeafBatch* batch) {
+    LeafBatch one;
+    const LeafBatch& b = batch ? *batch : one;
+    hipLaunchKernelGGL(leaf_potrf_trtri_kernel, dim3(b.nb), dim3(512), 0, s, A, lda, X, ldx, o, info, b);
 }
 
 }  // namespace dnagpu

@@ -24,13 +24,37 @@ struct GemmProfile {
     bool open = false;       // a run is in progress (start event recorded, stop event pending)
 };
 
+// A batched driver call: the drivers below run on member 0's buffers as always, and every launch they enqueue carries nb members --
+// the same product or leaf on nb matrices of one shape, in lock step (la_kernels.h: GemmArgs::nb).  The buffers a call touches are
+// registered here (member 0's address range, the other members' offsets in doubles); gemm() finds an operand's buffer by its
+// address.  While a batch is set the tile-DAG, fused-launch and split-launch paths are off, and P is addressed relative to the
+// diagonal block being factored (Rec::p_o) so that the members' panel buffers only need that block's columns.
+struct InvBatch {
+    int nb = 1;
+    int nbuf = 0;
+    const double* base[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t span[4] = {0, 0, 0, 0};
+    long long delta[4][BATCH_MAX];
+    void add(const double* member0, size_t doubles, double* const* members) {
+        base[nbuf] = member0;
+        span[nbuf] = doubles;
+        for (int b = 0; b < nb; ++b) delta[nbuf][b] = (long long)(members[b] - member0);
+        ++nbuf;
+    }
+};
+
 // Workspace shared by every inverse run on one stream ("chain").
 struct InvWorkspace {
     double* X = nullptr;     // np_cap^2 : L^-1
     double* W = nullptr;     // np_cap^2 : L21 panels
     double* svec = nullptr;  // np_cap   : diagonal scaling
-    int* info = nullptr;     // device int (dpotrf-style info, 0 = ok)
+    int* info = nullptr;     // device ints (dpotrf-style info, 0 = ok), one per member of a batched call (BATCH_MAX)
     int* info_host = nullptr;  // pinned host copy
+    InvBatch batch;          // nb > 1: the call being enqueued is batched
+    double* bX[BATCH_MAX] = {};   // members 1 .. of a batched call: their matrix being factored (bnp_cap^2) ...
+    double* bW[BATCH_MAX] = {};   // ... and the panels inside a diagonal block (bw_cols x bnp_cap)
+    uint32_t bnp_cap = 0, bw_cols = 0;
+    uint64_t batched_launches = 0;
     uint32_t np_cap = 0;
     hipStream_t stream = nullptr;
     GemmProfile prof;

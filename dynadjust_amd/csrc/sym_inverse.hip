@@ -21,12 +21,12 @@ hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t st
     if ((e = hipMalloc(&ws.X, bytes)) != hipSuccess) return e;
     if ((e = hipMalloc(&ws.W, bytes)) != hipSuccess) return e;
     if ((e = hipMalloc(&ws.svec, (size_t)np_cap * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMalloc(&ws.info, sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&ws.info, BATCH_MAX * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc(&ws.sync_ctr, sizeof(unsigned long long))) != hipSuccess) return e;
     if ((e = hipMemset(ws.sync_ctr, 0, sizeof(unsigned long long))) != hipSuccess) return e;
     ws.sync_base = 0;
-    if ((e = hipHostMalloc(&ws.info_host, sizeof(int))) != hipSuccess) return e;
-    *ws.info_host = 0;
+    if ((e = hipHostMalloc(&ws.info_host, BATCH_MAX * sizeof(int))) != hipSuccess) return e;
+    for (int b = 0; b < BATCH_MAX; ++b) ws.info_host[b] = 0;
     return hipSuccess;
 }
 
@@ -35,6 +35,10 @@ void inv_workspace_free(InvWorkspace& ws) {
     if (ws.dag_ticket) hipFree(ws.dag_ticket);
     if (ws.X) hipFree(ws.X);
     if (ws.W) hipFree(ws.W);
+    for (int b = 0; b < BATCH_MAX; ++b) {
+        if (ws.bX[b]) hipFree(ws.bX[b]);
+        if (ws.bW[b]) hipFree(ws.bW[b]);
+    }
     if (ws.svec) hipFree(ws.svec);
     if (ws.info) hipFree(ws.info);
     if (ws.sync_ctr) hipFree(ws.sync_ctr);
@@ -107,6 +111,8 @@ long small_tiles_set(long v) {
 
 hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo, int jt_hi) {
     long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
+    // (a batched launch decides by one member's tiles, like the unbatched launch whose bits it must reproduce; counting all
+    //  members' tiles -- the 128-tile shape from fewer tiles per member on -- measured no different: 2 479 against 2 483 ms per cfg3 step)
     a.tile = total < g_small_tiles.load() ? 64 : 128;
     // (the pair threshold is part of the key: a table built before dnagpu_debug_set_pair_tiles changed it is not the one wanted after)
     const long pair_from = pair_tiles_get();
@@ -262,7 +268,38 @@ static bool gemm_split(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
     return true;
 }
 
+// the offsets of the batch's members for an operand of member 0 (by the registered buffer its address lies in)
+static bool batch_offsets(const InvBatch& bt, const double* p, long long* d) {
+    for (int q = 0; q < bt.nbuf; ++q)
+        if (p >= bt.base[q] && p < bt.base[q] + bt.span[q]) {
+            for (int b = 0; b < bt.nb; ++b) d[b] = bt.delta[q][b];
+            return true;
+        }
+    return false;
+}
+
 void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
+    if (ws.batch.nb > 1) {
+        if (ws.err != hipSuccess || gemm_attach_order(ws, a) != hipSuccess) return;
+        a.nb = ws.batch.nb;
+        if (!batch_offsets(ws.batch, a.A, a.dA) || !batch_offsets(ws.batch, a.B, a.dB) || !batch_offsets(ws.batch, a.C, a.dC)) {
+            inv_note_error(ws, hipErrorInvalidValue, "batched product: an operand outside the registered buffers");
+            return;
+        }
+        GemmProfile& p = ws.prof;
+        if (p.enabled) {
+            if (!p.open) {
+                profile_event(p, ws.stream);
+                p.open = true;
+            }
+            p.flops += gemm_flops(a) * a.nb;
+            p.launches++;
+        }
+        launch_gemm(a, akc, bkc, ws.stream);
+        inv_note_error(ws, hipGetLastError(), "tile GEMM launch");
+        ws.batched_launches++;
+        return;
+    }
     if (ws.dist_world > 1 && ws.err == hipSuccess && gemm_split(ws, a, akc, bkc)) return;
     // (after a latched error nothing further is enqueued: the result is void anyway and the caller reports the error)
     if (ws.err != hipSuccess || gemm_attach_order(ws, a) != hipSuccess) return;
@@ -343,7 +380,14 @@ struct Rec {
 
     double* f(int rt, int ct) { return F + (size_t)ct * 128 * ld + (size_t)rt * 128; }
     double* x(int rt, int ct) { return X + (size_t)ct * 128 * ldx + (size_t)rt * 128; }
-    double* w(int rt, int ct) { return P + (size_t)ct * 128 * ldp + (size_t)rt * 128; }
+    // (batched calls: P is addressed relative to the diagonal block being factored, see InvBatch)
+    int p_o = 0;
+    double* w(int rt, int ct) { return P + (size_t)(ct - p_o) * 128 * ldp + (size_t)(rt - p_o) * 128; }
+    struct PLocal {     // p_o = o for the lifetime of the object, when the call is batched
+        Rec& r; int old;
+        PLocal(Rec& r_, int o) : r(r_), old(r_.p_o) { if (r.ws.batch.nb > 1) r.p_o = o; }
+        ~PLocal() { r.p_o = old; }
+    };
 
     void gemm(InvWorkspace& w_, GemmArgs a, int akc, int bkc) {
         if (rec)
@@ -378,7 +422,17 @@ struct Rec {
                 rec->add_leaf(f(o, o), x(o, o), o);
             } else if (!dry && ws.err == hipSuccess) {
                 gemm_profile_close(ws);
-                launch_leaf(F, ld, X, ldx, o * 128, ws.info, ws.stream);
+                if (ws.batch.nb > 1) {
+                    LeafBatch lb;
+                    lb.nb = ws.batch.nb;
+                    if (!batch_offsets(ws.batch, F, lb.dA) || !batch_offsets(ws.batch, X, lb.dX)) {
+                        inv_note_error(ws, hipErrorInvalidValue, "batched leaf: a matrix outside the registered buffers");
+                        return;
+                    }
+                    launch_leaf(F, ld, X, ldx, o * 128, ws.info, ws.stream, &lb);
+                } else {
+                    launch_leaf(F, ld, X, ldx, o * 128, ws.info, ws.stream);
+                }
                 inv_note_error(ws, hipGetLastError(), "leaf launch");
             }
             return;
@@ -432,7 +486,10 @@ struct Rec {
         int o = 0, si = ti;
         while (si > 0) {
             int h = spine_step(si, split);
-            node(o, h);
+            {
+                PLocal pl(*this, o);
+                node(o, h);
+            }
             int r = si - h + tj;
             if (r > 0) {
                 GemmArgs a;
@@ -531,7 +588,7 @@ std::shared_ptr<DagGraph> dag_record(InvWorkspace& ws, int ld, int ldx, int ldp,
 template <class Ops>
 bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, int ld, double* X, int ldx, double* P, int ldp, const double* WK,
              int ldwk, Ops&& ops) {
-    if (!ws.dag || !g_dag_mode.load() || ws.dist_world > 1 || ti + tj < g_dag_min_tiles.load()) return false;
+    if (!ws.dag || !g_dag_mode.load() || ws.dist_world > 1 || ws.batch.nb > 1 || ti + tj < g_dag_min_tiles.load()) return false;
     if (ws.err != hipSuccess) return true;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -663,7 +720,7 @@ void run_products(InvWorkspace& ws, uint64_t key, double* F, int ld, double* X, 
 int dag_mode_set(int on) { return g_dag_mode.exchange(on); }
 
 void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity, bool reset_info) {
-    if (reset_info) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
+    if (reset_info) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
     if (scale_to_unity) {
         launch_diag_rsqrt(F, ws.svec, n, np, ws.stream);
         launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
@@ -698,7 +755,7 @@ double schur_split() {
 }
 
 void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
     auto ops = [&](Rec& rec, const double*) {
         if (ti > 0) rec.node(0, ti);
         if (ti > 0 && tj > 0) rec.eliminate(0, ti, tj);
@@ -709,7 +766,7 @@ void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti
 }
 
 void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj, int what) {
-    if (what & 1) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
+    if (what & 1) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
     const int T = ti + tj;
     auto ops = [&](Rec& rec, const double* wk) {
         GemmArgs a;
@@ -747,7 +804,7 @@ void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const do
 }
 
 void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
     const double split = schur_split();
     auto ops = [&](Rec& rec, const double*) { rec.spine(ti, tj, split); };
     if (!run_dag(ws, DK_SPINE, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
@@ -756,8 +813,11 @@ void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int
 }
 
 void sym_spine_kept_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
-    auto ops = [&](Rec& rec, const double*) { rec.node(ti, tj); };
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
+    auto ops = [&](Rec& rec, const double*) {
+        Rec::PLocal pl(rec, ti);
+        rec.node(ti, tj);
+    };
     if (!run_dag(ws, DK_SPINE_KEPT, ti, tj, 0, F, ld, S, ld, ws.W, ld, nullptr, 0, ops))
         run_products(ws, plan_key(DK_SPINE_KEPT, 0, ti, tj), F, ld, S, ld, ws.W, ld, nullptr, ops);
     gemm_profile_close(ws);
@@ -794,7 +854,7 @@ std::vector<std::pair<int, int>> sym_spine_blocks(int ti) {
 }
 
 void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, sizeof(int), ws.stream), "info reset");
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
     const int ldx = ti * 128;
     const double split = schur_split();
     auto ops = [&](Rec& rec, const double*) { rec.schur(ti, tj, split); };

@@ -64,6 +64,9 @@ typedef struct {
                                   completed factor and the inverses (rigorous variance matrices) are formed once, after the last iteration;
                                   2 = the condensing step also stops at the factor (no inverse of the eliminated part until the end),
                                   0 = an inverse per block and iteration like dna_adjust::Solve */
+    int batch_blocks;          /* condensed schedule with kept factors (default 16 = DNAGPU_BATCH_MAX): blocks of one shape go through its large
+                                  steps as one batch of up to this many members -- merged launches, in lock step (include/dnagpu.h,
+                                  dnagpu_*_batched); every member's results are the bits of the unbatched calls.  0 / 1 = off */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
@@ -157,6 +160,9 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status);               /* Valida
  * scale_normals_to_unity). */
 int dnaadj_staged(const dnaadj_handle* h);     /* 1 when the prepared adjustment keeps its rigorous variances in host memory */
 int dnaadj_condensed_schedule(const dnaadj_handle* h);
+/* how many block steps of this instance went through batched calls (settings.batch_blocks) since it was prepared: condensing,
+ * rigorous solve and variance matrices each count a block once per iteration */
+uint64_t dnaadj_batched_block_steps(const dnaadj_handle* h);
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block);
 int dnaadj_phased_condense_block(dnaadj_handle* h, uint32_t block);
 int dnaadj_phased_condensed_forward(dnaadj_handle* h, uint32_t block);

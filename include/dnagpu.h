@@ -290,6 +290,24 @@ int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
  * the matrix less than form + add + reduce.  Same bits as that sequence. */
 int dnagpu_block_form_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* con_stn, const double* con_w9, size_t n_con,
                              const uint32_t* idx_keep, size_t k, dnagpu_matrix* red, dnagpu_partial* keep);
+/* Batched forms of the three large steps of a block with a kept factor in its light form (dnagpu_partial_create_spine), for nb <=
+ * DNAGPU_BATCH_MAX blocks of ONE shape (equal padded orders of the eliminated and of the kept part): the members' launches are merged --
+ * every tile product and every leaf of the recursion is one launch that works on all members, in lock step.  The dependent chain of
+ * launches is as long as for one block, but every launch has nb times the tiles: the short launches at the bottom of the recursion
+ * fill the GPU, and the large ones follow each other without a partly filled last wave (replaces nb x dpotrf / dpotri call sequences of
+ * matrix_2d::cholesky_inverse, dnamatrix_contiguous.cpp:982-1006, that the reference runs one after the other).  Same bits per member
+ * as the unbatched calls.  A member that is not positive definite: DNAGPU_ENOTPOSDEF, *failed_member = its position (may be NULL).
+ * dnagpu_batch_reserve allocates the members' workspaces on `chain` (a matrix + the panels of a diagonal block each) for nb_wanted blocks of
+ * n_max unknowns with k_max kept ones: *nb_granted = nb_wanted, or 1 when they do not fit (nothing stays allocated then beside the chain's
+ * own workspace; the caller runs the blocks one at a time).  The batched calls allocate the same on demand and fail with DNAGPU_ENOMEM. */
+#define DNAGPU_BATCH_MAX 16
+int dnagpu_batch_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max, uint32_t k_max, int nb_wanted, int* nb_granted);
+int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const uint32_t* blks, const uint32_t* const* con_stn,
+                                     const double* const* con_w9, const size_t* n_con, const uint32_t* const* idx_keep, const size_t* k,
+                                     dnagpu_matrix* const* red, dnagpu_partial* const* keep, int* failed_member);
+int dnagpu_partial_complete_factor_batched(dnagpu_ctx* ctx, int chain, int nb, dnagpu_partial* const* pf, const dnagpu_matrix* const* kk,
+                                           int* failed_member);
+int dnagpu_partial_finish_batched(dnagpu_ctx* ctx, int chain, int nb, dnagpu_partial* const* pf, dnagpu_matrix* const* inv);
 /* With `keep`, the elimination leaves everything a later completion needs in HBM -- the factor of the eliminated part, its
  * inverse and the panel under the kept rows (n^2 + 3k n doubles) -- at 2/3 n_i^3 instead of ~0.34 n_i^3 flops.
  * dnagpu_partial_complete then turns  [ N_II  . ; N_KI  kk ]  (kk: the kept block as the chains left it: reduced block +

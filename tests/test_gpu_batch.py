@@ -1,0 +1,82 @@
+"""a.batch_blocks: blocks of one shape through the large steps of the condensed schedule as ONE batch of merged launches
+(include/dnagpu.h dnagpu_*_batched; replaces the reference's Solve() calls following each other, dnaadjust.cpp:2812 / 3512 / 3556).
+Every member must come out with the bits of the unbatched calls."""
+import os
+
+import numpy as np
+import pytest
+
+from dynadjust_amd import adjust
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(folder, name, **kw):
+    p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, **kw)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    st = a.AdjustNetwork()
+    return a, st
+
+
+def _results(a):
+    B = a.blockCount()
+    return ([a.block_estimates(b) for b in range(B)], [a.block_variances_packed(b) for b in range(B)],
+            [a.GetIterationCorrection(i + 1) for i in range(a.CurrentIteration())])
+
+
+@pytest.mark.parametrize("mt", [False, True])
+@pytest.mark.parametrize("rows,cols,blocks", [(48, 40, 6), (60, 90, 5)])
+def test_batched_blocks_have_the_bits_of_unbatched_ones(built, tmp_path, mt, rows, cols, blocks):
+    """strips of equal height: the interior blocks share a shape and go through condensing, rigorous solve and variance matrices
+    as one batch; estimates, variances and corrections are bit-identical to the run with batching off"""
+    adjust.write_synthetic_network(str(tmp_path), "b", rows, cols, 0, blocks, seed=21)
+    a0, st0 = _run(str(tmp_path), "b", multi_thread=mt, batch_blocks=0)
+    assert st0 == 0 and a0.batched_block_steps() == 0
+    x0, v0, c0 = _results(a0)
+    it0 = a0.CurrentIteration()
+    a0.close()
+    a1, st1 = _run(str(tmp_path), "b", multi_thread=mt, batch_blocks=16)
+    assert st1 == 0 and a1.CurrentIteration() == it0
+    # at least the interior blocks were batched in every phase of every iteration
+    assert a1.batched_block_steps() >= 2 * (2 * it0 + 1)
+    x1, v1, c1 = _results(a1)
+    assert c0 == c1
+    for b in range(blocks):
+        assert np.array_equal(x0[b], x1[b])
+        assert np.array_equal(v0[b], v1[b])
+    a1.close()
+
+
+def test_batch_size_is_capped(built, tmp_path):
+    """batch_blocks = 2: groups of at most two members, same bits"""
+    adjust.write_synthetic_network(str(tmp_path), "c", 48, 40, 0, 6, seed=5)
+    runs = []
+    for cap in (0, 2, 3):
+        a, st = _run(str(tmp_path), "c", multi_thread=True, batch_blocks=cap)
+        assert st == 0
+        runs.append(_results(a) + (a.batched_block_steps(),))
+        a.close()
+    assert runs[0][3] == 0 and runs[1][3] > 0 and runs[2][3] > 0
+    for r in runs[1:]:
+        assert r[2] == runs[0][2]
+        for b in range(len(r[0])):
+            assert np.array_equal(r[0][b], runs[0][0][b]) and np.array_equal(r[1][b], runs[0][1][b])
+
+
+def test_a_singular_member_is_reported_with_its_block(built, tmp_path):
+    """a member whose normals are not positive definite: the reference's message (dnamatrix_contiguous.cpp:983 through SolveTry,
+    dnaadjust.cpp:6575-6582), with the member's own block number"""
+    from tests import dnaformats as F
+    adjust.write_synthetic_network(str(tmp_path), "s", 48, 40, 0, 6, seed=8)
+    base = os.path.join(str(tmp_path), "s")
+    # an inner station of block 4 loses every measurement, and the free stations' constraint weight underflows to zero: a zero pivot
+    ISL, JSL, CML, nets = F.read_seg(base + ".seg")
+    msr = F.read_bms(base + ".bms")
+    target = int(ISL[3][len(ISL[3]) // 2])
+    CML[3] = np.array([int(i) for i in CML[3] if int(msr[int(i)]["station1"]) != target and int(msr[int(i)]["station2"]) != target], dtype=np.uint32)
+    F.write_seg(base + ".seg", ISL, JSL, CML, nets, msr)
+    for cap in (0, 16):
+        with pytest.raises(adjust.NetAdjustException) as e:
+            _run(str(tmp_path), "s", multi_thread=True, batch_blocks=cap, free_std_dev=1e200)
+        assert "singular" in str(e.value) and "block 4" in str(e.value), str(e.value)
