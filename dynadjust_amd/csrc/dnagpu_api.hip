@@ -384,6 +384,16 @@ long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int ti
 
 int dnagpu_debug_set_tile_dag(int on) { return dnagpu::dag_mode_set(on ? 1 : 0); }
 
+int dnagpu_debug_set_lookahead(int on, long min_tiles) { return dnagpu::lookahead_set(on ? 1 : 0, min_tiles); }
+
+int dnagpu_lookahead_stats(dnagpu_ctx* ctx, uint64_t* side_launches) {
+    CHK_CTX();
+    uint64_t n = 0;
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) n += ctx->ws[c].la_launches;
+    if (side_launches) *side_launches = n;
+    return DNAGPU_OK;
+}
+
 int dnagpu_set_tile_dag_workers(dnagpu_ctx* ctx, int workers) {
     if (!ctx || workers < 0) return DNAGPU_EINVAL;
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) ctx->ws[c].dag_workers = workers;
@@ -467,6 +477,14 @@ int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uin
             iv.emplace_back(t0, t0 + dt);
         }
         p.used = 0;
+        // (launches on the look-ahead streams, one pair each; every driver call joins them to the chain's stream before it returns)
+        for (size_t i = 0; base && i + 1 < p.side_used; i += 2) {
+            float t0 = 0.f, dt = 0.f;
+            hipEventElapsedTime(&t0, base, p.side_pool[i]);
+            hipEventElapsedTime(&dt, p.side_pool[i], p.side_pool[i + 1]);
+            iv.emplace_back(t0, t0 + dt);
+        }
+        p.side_used = 0;
         f += p.flops;
         l += p.launches;
     }

@@ -22,6 +22,8 @@ struct GemmProfile {
     std::vector<hipEvent_t> pool;  // start/stop pairs, one pair per run of consecutive gemm launches
     size_t used = 0;
     bool open = false;       // a run is in progress (start event recorded, stop event pending)
+    std::vector<hipEvent_t> side_pool;   // start/stop pairs of the launches on the look-ahead streams (one pair per launch)
+    size_t side_used = 0;
 };
 
 // A batched driver call: the drivers below run on member 0's buffers as always, and every launch they enqueue carries nb members --
@@ -51,6 +53,15 @@ struct InvWorkspace {
     int* info = nullptr;     // device ints (dpotrf-style info, 0 = ok), one per member of a batched call (BATCH_MAX)
     int* info_host = nullptr;  // pinned host copy
     InvBatch batch;          // nb > 1: the call being enqueued is batched
+    // Look-ahead (sym_inverse.hip, Rec::trailing): the columns of a trailing update that the next diagonal block does not touch go to a
+    // low-priority side stream, and the chain's own stream goes on with that block -- its leaves and few-tile products, bound by launch
+    // latency, run beside a launch that fills the GPU instead of after it.  Hazards are tracked per launch (address boxes), so the
+    // result is the sequential one, bit for bit.
+    static constexpr int LA_SIDES = 2;
+    hipStream_t side[LA_SIDES] = {nullptr, nullptr};
+    std::vector<hipEvent_t> la_events;   // untimed; reused by every driver call (all of a call's side work is joined before it returns)
+    size_t la_used = 0;
+    uint64_t la_launches = 0;
     double* bX[BATCH_MAX] = {};   // members 1 .. of a batched call: their matrix being factored (bnp_cap^2) ...
     double* bW[BATCH_MAX] = {};   // ... and the panels inside a diagonal block (bw_cols x bnp_cap)
     uint32_t bnp_cap = 0, bw_cols = 0;
@@ -106,6 +117,8 @@ void inv_note_error(InvWorkspace& ws, hipError_t e, const char* where);
 struct GemmArgs;
 // fills a.order / a.grid from the cache (building + uploading the table on first use)
 hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo = -1, int jt_hi = -1);
+// process-wide switch of the look-ahead (DNAGPU_LOOKAHEAD) and the smallest side part in 128-tiles (< 0: unchanged); returns the old switch
+int lookahead_set(int on, long min_tiles = -1);
 
 // returns hipSuccess or an error; allocates for matrices up to np_cap (multiple of 128)
 hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t stream);

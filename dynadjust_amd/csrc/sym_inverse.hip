@@ -45,6 +45,10 @@ void inv_workspace_free(InvWorkspace& ws) {
     if (ws.dist_stage) hipFree(ws.dist_stage);
     if (ws.info_host) hipHostFree(ws.info_host);
     for (hipEvent_t ev : ws.prof.pool) hipEventDestroy(ev);
+    for (hipEvent_t ev : ws.prof.side_pool) hipEventDestroy(ev);
+    for (hipEvent_t ev : ws.la_events) hipEventDestroy(ev);
+    for (hipStream_t st : ws.side)
+        if (st) hipStreamDestroy(st);
     for (auto& kv : ws.order_cache)
         if (kv.second.first) hipFree(kv.second.first);
     ws = InvWorkspace();
@@ -278,6 +282,46 @@ static bool batch_offsets(const InvBatch& bt, const double* p, long long* d) {
     return false;
 }
 
+// One column range [jt_lo, jt_hi) of a lower-triangular launch, on `on` (the chain's stream, or one of its look-ahead streams):
+// the same tiles, computed the same way, as in the whole launch.  count: this part carries the launch's flops in the profile.
+void gemm_part(InvWorkspace& ws, GemmArgs a, int akc, int bkc, hipStream_t on, int jt_lo, int jt_hi, bool count) {
+    if (ws.err != hipSuccess || gemm_attach_order(ws, a, jt_lo, jt_hi) != hipSuccess) return;
+    if (ws.batch.nb > 1) {
+        a.nb = ws.batch.nb;
+        if (!batch_offsets(ws.batch, a.A, a.dA) || !batch_offsets(ws.batch, a.B, a.dB) || !batch_offsets(ws.batch, a.C, a.dC)) {
+            inv_note_error(ws, hipErrorInvalidValue, "batched product: an operand outside the registered buffers");
+            return;
+        }
+        ws.batched_launches++;
+    }
+    GemmProfile& p = ws.prof;
+    const bool side = on != ws.stream;
+    auto side_event = [&] {
+        if (p.side_used + 1 > p.side_pool.size()) {
+            hipEvent_t ev;
+            hipEventCreate(&ev);
+            p.side_pool.push_back(ev);
+        }
+        hipEventRecord(p.side_pool[p.side_used++], on);
+    };
+    if (p.enabled) {
+        if (side) {
+            side_event();
+        } else if (!p.open) {
+            profile_event(p, ws.stream);
+            p.open = true;
+        }
+        if (count) {
+            p.flops += gemm_flops(a) * a.nb;
+            p.launches++;
+        }
+    }
+    launch_gemm(a, akc, bkc, on);
+    inv_note_error(ws, hipGetLastError(), "tile GEMM launch");
+    if (p.enabled && side) side_event();
+    if (side) ws.la_launches++;
+}
+
 void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
     if (ws.batch.nb > 1) {
         if (ws.err != hipSuccess || gemm_attach_order(ws, a) != hipSuccess) return;
@@ -357,6 +401,7 @@ void gemm_profile_collect(InvWorkspace& ws) {
         p.gemm_ms += ms;
     }
     p.used = 0;
+    p.side_used = 0;        // (overlapping intervals: only dnagpu_profile_get's union accounts for them)
 }
 
 void gemm_profile_reset(InvWorkspace& ws) {
@@ -364,7 +409,23 @@ void gemm_profile_reset(InvWorkspace& ws) {
     ws.prof.gemm_ms = 0.0;
     ws.prof.launches = 0;
     ws.prof.used = 0;
+    ws.prof.side_used = 0;
     ws.prof.open = false;
+}
+
+// Opt-in (DNAGPU_LOOKAHEAD=1 / dnagpu_debug_set_lookahead): measured (round 3, profiles/r03_lookahead.txt), bit-identical and no gain --
+// 2 458 against 2 460 ms per cfg3 step, 3 079 against 3 077 with one chain and no batches, 402.8 against 402.1 ms for cfg2: a leaf or a
+// few-tile product behind a launch that holds every workgroup slot waits for a slot until a tile of that launch ends (0.5 - 1 ms at these
+// k), whatever the priorities of the two streams, so the diagonal block advances no faster beside the update than after it.
+static std::atomic<int> g_lookahead{[] {
+    const char* e = getenv("DNAGPU_LOOKAHEAD");
+    return e ? atoi(e) : 0;
+}()};
+// a trailing update is split only if the part that goes to the side stream has at least this many 128-tiles (of one member)
+static std::atomic<long> g_la_min_tiles{getenv("DNAGPU_LOOKAHEAD_MIN_TILES") ? atol(getenv("DNAGPU_LOOKAHEAD_MIN_TILES")) : 1024};
+int lookahead_set(int on, long min_tiles) {
+    if (min_tiles >= 0) g_la_min_tiles.store(min_tiles);
+    return g_lookahead.exchange(on);
 }
 
 namespace {
@@ -389,17 +450,139 @@ struct Rec {
         ~PLocal() { r.p_o = old; }
     };
 
+    // ---- look-ahead (sym_inverse.h) ----
+    // an operand as an address box: which buffer, which element rows / columns of it
+    struct Box {
+        int buf = -1;
+        long r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+        bool meets(const Box& o) const { return buf >= 0 && buf == o.buf && r0 < o.r1 && o.r0 < r1 && c0 < o.c1 && o.c0 < c1; }
+    };
+    Box box_of(const double* p, long rows, long cols) const {
+        // the buffer: the one of F / X / P that starts closest below p (distinct allocations)
+        const double* base[3] = {F, X, P};
+        const int lds[3] = {ld, ldx, ldp};
+        Box b;
+        for (int q = 0; q < 3; ++q)
+            if (base[q] && p >= base[q] && (b.buf < 0 || base[q] > base[b.buf])) b.buf = q;
+        if (b.buf < 0) return b;
+        const long off = (long)(p - base[b.buf]);
+        b.c0 = off / lds[b.buf];
+        b.r0 = off % lds[b.buf];
+        b.r1 = b.r0 + rows;
+        b.c1 = b.c0 + cols;
+        return b;
+    }
+    struct Boxes { Box A, B, C; };
+    // the operands of (tile columns [jlo, jhi) of) a launch; k ranges and the triangle are not looked at: a superset
+    Boxes boxes_of(const GemmArgs& a, int akc, int bkc, int jlo, int jhi) const {
+        const long i0 = a.lower ? (long)jlo * 128 : 0, rows = (long)a.mt * 128 - i0, j0 = (long)jlo * 128, cols = (long)(jhi - jlo) * 128;
+        Boxes b;
+        b.C = a.mirror ? box_of(a.C, (long)a.mt * 128, (long)a.nt * 128) : box_of(a.C + (size_t)j0 * a.ldc + i0, rows, cols);
+        b.A = akc ? box_of(a.A + (size_t)i0 * a.lda, a.K, rows) : box_of(a.A + i0, rows, a.K);
+        b.B = bkc ? box_of(a.B + (size_t)j0 * a.ldb, a.K, cols) : box_of(a.B + j0, cols, a.K);
+        return b;
+    }
+    struct Pending {
+        hipEvent_t done;
+        int side;
+        Boxes b;
+    };
+    std::vector<Pending> pending;
+    static bool conflict(const Boxes& later, const Boxes& earlier) {
+        return later.C.meets(earlier.C) || later.A.meets(earlier.C) || later.B.meets(earlier.C) || later.C.meets(earlier.A) || later.C.meets(earlier.B);
+    }
+    hipEvent_t la_event() {
+        if (ws.la_used + 1 > ws.la_events.size()) {
+            hipEvent_t ev = nullptr;
+            inv_note_error(ws, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "look-ahead event");
+            ws.la_events.push_back(ev);
+        }
+        return ws.la_events[ws.la_used++];
+    }
+    // the chain's stream waits for the side launches that a launch with these operands must not overtake
+    void before_main(const Boxes& b) {
+        for (size_t i = 0; i < pending.size();)
+            if (conflict(b, pending[i].b)) {
+                inv_note_error(ws, hipStreamWaitEvent(ws.stream, pending[i].done, 0), "look-ahead join");
+                pending.erase(pending.begin() + i);
+            } else {
+                ++i;
+            }
+    }
+    void join_all() {
+        for (const Pending& pd : pending) inv_note_error(ws, hipStreamWaitEvent(ws.stream, pd.done, 0), "look-ahead join");
+        pending.clear();
+    }
+    bool la_possible() const { return g_lookahead.load() != 0 && !rec && ws.dist_world == 1 && !ws.fuse; }
+
     void gemm(InvWorkspace& w_, GemmArgs a, int akc, int bkc) {
-        if (rec)
+        if (rec) {
             rec->add_gemm(a, akc, bkc);
-        else if (dry)
+        } else if (dry) {
             gemm_attach_order(w_, a);
-        else
+        } else {
+            if (!pending.empty()) before_main(boxes_of(a, akc, bkc, 0, a.nt));
             dnagpu::gemm(w_, a, akc, bkc);
+        }
+    }
+
+    // A trailing update  C -= W W^T  (r x r lower tiles) after which the chain's next work -- the next diagonal block and its panel --
+    // only touches the first `la` tile columns of C: those go out on the chain's stream, the others on a side stream behind the
+    // panel that produced W.  Whatever touches them later waits for them (before_main).
+    void trailing(GemmArgs a, int la) {
+        const int r = a.mt;
+        const long rest = (long)(r - la) * (r - la + 1) / 2;
+        if (!la_possible() || la <= 0 || la >= r || rest < g_la_min_tiles.load()) {
+            gemm(ws, a, 0, 0);
+            return;
+        }
+        if (dry) {
+            gemm_attach_order(ws, a, 0, la);
+            gemm_attach_order(ws, a, la, r);
+            return;
+        }
+        if (ws.err != hipSuccess) return;
+        int side = -1;
+        for (int q = 0; q < InvWorkspace::LA_SIDES && side < 0; ++q) {
+            bool busy = false;
+            for (const Pending& pd : pending) busy = busy || pd.side == q;
+            if (!busy) side = q;
+        }
+        if (side < 0) side = (int)(ws.la_launches % InvWorkspace::LA_SIDES);
+        if (!ws.side[side]) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo: the numerically greatest = least urgent
+            hipError_t e = hipStreamCreateWithPriority(&ws.side[side], hipStreamNonBlocking, lo);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                ws.side[side] = nullptr;
+                gemm(ws, a, 0, 0);      // no stream to be had: the plain launch
+                return;
+            }
+        }
+        gemm_flush(ws);
+        gemm_profile_close(ws);         // (the event that follows ends a run of GEMM launches on the chain's stream)
+        hipStream_t ss = ws.side[side];
+        // the side part starts when everything up to here -- the panel W -- is done, and after the side launches it collides with
+        hipEvent_t fork = la_event();
+        inv_note_error(ws, hipEventRecord(fork, ws.stream), "look-ahead fork");
+        inv_note_error(ws, hipStreamWaitEvent(ss, fork, 0), "look-ahead fork");
+        const Boxes bb = boxes_of(a, 0, 0, la, r);
+        for (const Pending& pd : pending)
+            if (pd.side != side && (conflict(bb, pd.b) || conflict(pd.b, bb))) inv_note_error(ws, hipStreamWaitEvent(ss, pd.done, 0), "look-ahead order");
+        before_main(boxes_of(a, 0, 0, 0, la));
+        gemm_part(ws, a, 0, 0, ws.stream, 0, la, true);
+        gemm_part(ws, a, 0, 0, ss, la, r, false);
+        Pending pd;
+        pd.done = la_event();
+        pd.side = side;
+        pd.b = bb;
+        inv_note_error(ws, hipEventRecord(pd.done, ss), "look-ahead event");
+        pending.push_back(pd);
     }
 
     // W21 = A21 * X11^T (L21 = A21 L11^-T) for the r tile rows below the h x h block at o, then A22 -= W21 * W21^T (lower tiles)
-    void eliminate(int o, int h, int r) {
+    void eliminate(int o, int h, int r, int la = 0) {
         GemmArgs a;
         a.A = f(o + h, o); a.lda = ld;
         a.B = x(o, o); a.ldb = ldx;
@@ -412,7 +595,7 @@ struct Rec {
         a.C = f(o + h, o + h); a.ldc = ld;
         a.mt = r; a.nt = r; a.K = h * 128;
         a.alpha = -1.0; a.beta = 1.0; a.kmode = KM_FULL; a.lower = 1; a.mirror = 0;
-        gemm(ws, a, 0, 0);
+        trailing(a, la);
     }
 
     // Cholesky factor and its inverse of the s x s tile block at o: F keeps T21 = L21 L11^-1 below the diagonal, X = L^-1
@@ -422,6 +605,12 @@ struct Rec {
                 rec->add_leaf(f(o, o), x(o, o), o);
             } else if (!dry && ws.err == hipSuccess) {
                 gemm_profile_close(ws);
+                if (!pending.empty()) {
+                    Boxes b;
+                    b.A = box_of(f(o, o), 128, 128);
+                    b.C = box_of(x(o, o), 128, 128);
+                    before_main(b);
+                }
                 if (ws.batch.nb > 1) {
                     LeafBatch lb;
                     lb.nb = ws.batch.nb;
@@ -440,7 +629,7 @@ struct Rec {
         int h = s / 2;
         int r = s - h;
         node(o, h);
-        eliminate(o, h, r);
+        eliminate(o, h, r, r / 2);      // (what follows -- the left half of the right block and its panel -- stays in its first r / 2 columns)
         node(o + h, r);
         GemmArgs a;
         // T21 = W21 * X11  -> stored where A21 was
@@ -472,7 +661,7 @@ struct Rec {
             int h = spine_step(si, split);
             node(o, h);
             int r = si - h + tj;
-            if (r > 0) eliminate(o, h, r);
+            if (r > 0) eliminate(o, h, r, si - h > 0 ? spine_step(si - h, split) : 0);
             o += h;
             si -= h;
         }
@@ -504,7 +693,7 @@ struct Rec {
                 a.C = f(o + h, o + h); a.ldc = ld;
                 a.mt = r; a.nt = r; a.K = h * 128;
                 a.alpha = -1.0; a.beta = 1.0; a.kmode = KM_FULL; a.lower = 1; a.mirror = 0;
-                gemm(ws, a, 0, 0);
+                trailing(a, si - h > 0 ? spine_step(si - h, split) : 0);
             }
             o += h;
             si -= h;
@@ -709,7 +898,9 @@ template <class Ops>
 void run_products(InvWorkspace& ws, uint64_t key, double* F, int ld, double* X, int ldx, double* P, int ldp, const double* WK, Ops&& ops) {
     for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
         Rec rec{ws, F, ld, X, ldx, P, ldp, pass == 0};
+        ws.la_used = 0;
         ops(rec, WK);
+        rec.join_all();         // (look-ahead: everything this call put on the side streams is part of it)
         if (ws.err != hipSuccess) return;
     }
     ws.planned.insert(key);

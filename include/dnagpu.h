@@ -123,6 +123,13 @@ int dnagpu_set_fused_launches(dnagpu_ctx* ctx, int on);
  * those differ from the recorded order in any bit (0 = pass), -1 on a stall.  stats6: tasks, dependency runs, flops, simulated makespan,
  * critical path, summed task time (microseconds). */
 int dnagpu_debug_set_tile_dag(int on);
+/* Look-ahead inside a factorisation (opt-in, DNAGPU_LOOKAHEAD=1; measured no gain, profiles/r03_lookahead.txt): the tile columns of a trailing update that the next
+ * diagonal block does not touch run on a low-priority side stream of the chain while the chain's own stream factors that block -- the
+ * latency-bound leaves and few-tile products beside a launch that fills the GPU instead of after it.  Per-launch hazard tracking keeps
+ * the sequential order wherever two launches touch the same tiles: same bits.  min_tiles: the smallest side part worth a stream of its
+ * own, in 128-tiles (< 0: unchanged; default 1024).  Returns the old switch.  dnagpu_lookahead_stats: launches that went to side streams. */
+int dnagpu_debug_set_lookahead(int on, long min_tiles);
+int dnagpu_lookahead_stats(dnagpu_ctx* ctx, uint64_t* side_launches);
 /* workgroups a DAG launch of this context uses (0 = default 512: what the GPU holds of the kernel).  A host that runs c chains side by
  * side gives each 512 / c, so that one chain's waiting workers cannot take the others' slots */
 int dnagpu_set_tile_dag_workers(dnagpu_ctx* ctx, int workers);
