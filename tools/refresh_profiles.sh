@@ -15,6 +15,10 @@ python $R/tools/rocprof_summary.py stats /tmp/kt $O/${TAG}_cfg3_kernel_stats.txt
 DNAGPU_MULTI_THREAD=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o p --output-format csv -- timeout 600 python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-one-chain > $O/kt1.log 2>&1
 python $R/tools/rocprof_summary.py stats /tmp/kt1 $O/${TAG}_cfg3_kernel_stats_one_chain.txt "DNAGPU_MULTI_THREAD=0 rocprofv3 --kernel-trace --stats -- $CMD   (${TAG}, cfg3, ONE chain: kernel durations without overlap)"
 DNAGPU_MULTI_THREAD=0 timeout 600 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_one_chain.json   # (the profiled run above has no warm-up: first-touch allocations inside)
+DNAGPU_BATCH=0 timeout 600 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_unbatched.json
+DNAGPU_PHASE_TIMES=1 timeout 600 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain 2>&1 | grep "^\[phase\]" | tail -7 > $O/${TAG}_cfg3_phase_times.txt
+DNAGPU_MULTI_THREAD=0 DNAGPU_PHASE_TIMES=1 timeout 600 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain 2>&1 | grep "^\[phase\]" | tail -7 > $O/${TAG}_cfg3_phase_times_one_chain.txt
+T0=$SECONDS; timeout 900 python $R/bench.py 2> $O/default_run.err | tail -1 > $O/${TAG}_bench_default_run.json; echo "python bench.py (no flags: cfg3, CPU baseline sample, one-chain step): $((SECONDS - T0)) s wall clock" > $O/${TAG}_bench_default_run_time.txt
 timeout 600 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain --reuse-inverses 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_reuse_inverses.json
 timeout 600 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain --reference-schedule 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_reference_schedule.json
 timeout 600 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain --variances-every-iteration 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_variances_every_iteration.json
