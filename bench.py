@@ -768,7 +768,11 @@ def main():
             "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
             "variance_matrices": "after the last iteration" if (a.completion_count() and not args.variances_every_iteration and not args.reuse_inverses) else "every iteration",
             "libdnagpu_sha16": _so_hash(),
-            "completions_per_step": a.completion_count(), "variance_propagation_in_step": bool(args.variance_propagation), "parallelism": "1 GPU, one chain" if not p.multi_thread else
+            "completions_per_step": a.completion_count(), "variance_propagation_in_step": bool(args.variance_propagation),
+            # blocks of one shape through the large steps as one batch of merged launches (a.batch_blocks): block steps
+            # (condensing, kept-block factorisation, variance matrices: up to 2 per block and iteration + 1 per block) that were batched
+            "batched_block_steps_per_step": a.batched_block_steps(),
+            "parallelism": "1 GPU, one chain" if not p.multi_thread else
             "1 GPU, %s chains (multi_thread: the independent block steps of the condensed schedule are served by every chain; the two junction chains run side by side)" % os.environ.get("DNAGPU_CHAINS", "4"),
         },
         "cholesky_tflops": (alg / 1e12) / (ms_per_step / 1e3),

@@ -1,6 +1,7 @@
 // Implementation of the C-ABI declared in include/dnagpu.h.
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +19,8 @@ namespace {
 
 constexpr uint32_t SYMV_CHUNKS = 32;
 constexpr int INFO_SENTINEL = 0x7f7f7f7f;
+// dnagpu_debug_fail_batch_workspaces(n): the next n allocations of a batch's member workspaces fail as if HBM were full (tests)
+std::atomic<long> g_fail_batch_ws{0};
 static_assert(DNAGPU_BATCH_MAX == BATCH_MAX, "include/dnagpu.h and la_kernels.h disagree on the batch size");
 
 // Error text and dpotrf-style info are kept twice: per host thread (every chain of a context is driven by its own host thread,
@@ -367,6 +370,11 @@ int dnagpu_chain_wait(dnagpu_ctx* ctx, int waiter, int signaller) {
 /* ---- profiling ------------------------------------------------------------ */
 int dnagpu_debug_fail_allocation(long nth) {
     dnagpu::fault_inject_reset(nth);
+    return DNAGPU_OK;
+}
+
+int dnagpu_debug_fail_batch_workspaces(long n) {
+    g_fail_batch_ws.store(n < 0 ? 0 : n);
     return DNAGPU_OK;
 }
 
@@ -1942,6 +1950,15 @@ int ensure_batch_ws(dnagpu_ctx* ctx, int chain, int nb, uint32_t npp, uint32_t w
     int rc = ensure_ws(ctx, chain, npp);
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
+    if (nb > 1 && g_fail_batch_ws.load() > 0 && g_fail_batch_ws.fetch_sub(1) > 0) {
+        HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+        for (int q = 1; q < BATCH_MAX; ++q) {
+            if (ws.bX[q]) hipFree(ws.bX[q]);
+            if (ws.bW[q]) hipFree(ws.bW[q]);
+            ws.bX[q] = ws.bW[q] = nullptr;
+        }
+        return fail(ctx, DNAGPU_ENOMEM, "batch workspace allocation (injected)");
+    }
     if (ws.bnp_cap < npp || ws.bw_cols < wcols) {
         HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
         for (int b = 0; b < BATCH_MAX; ++b) {

@@ -833,6 +833,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     elimination_count_ = 0;
     condense_count_ = 0;
     completion_count_ = 0;
+    batched_members_ = 0;
     algorithmic_flops_ = 0.0;
     for (block_t& b : blocks_) b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
     const double t0 = now_ms();
@@ -1069,6 +1070,7 @@ void dna_adjust::ResetAdjustment() {
     elimination_count_ = 0;
     condense_count_ = 0;
     completion_count_ = 0;
+    batched_members_ = 0;
     algorithmic_flops_ = 0.0;
     cancel_.store(false);
     cancel_agreed_ = false;

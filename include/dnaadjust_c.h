@@ -160,8 +160,8 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status);               /* Valida
  * scale_normals_to_unity). */
 int dnaadj_staged(const dnaadj_handle* h);     /* 1 when the prepared adjustment keeps its rigorous variances in host memory */
 int dnaadj_condensed_schedule(const dnaadj_handle* h);
-/* how many block steps of this instance went through batched calls (settings.batch_blocks) since it was prepared: condensing,
- * rigorous solve and variance matrices each count a block once per iteration */
+/* how many block steps of the last adjustment went through batched calls (settings.batch_blocks): condensing and rigorous solve count a
+ * block once per iteration, the variance matrices once */
 uint64_t dnaadj_batched_block_steps(const dnaadj_handle* h);
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block);
 int dnaadj_phased_condense_block(dnaadj_handle* h, uint32_t block);

@@ -96,6 +96,9 @@ int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uin
 /* Error-path testing: the nth (1-based) internal table allocation from now on fails as if the device were out of memory
  * (0 = off).  An inverse / elimination that hits it returns DNAGPU_ENOMEM -- never DNAGPU_OK with a skipped launch. */
 int dnagpu_debug_fail_allocation(long nth);
+/* tests: the next n allocations of a batch's member workspaces (dnagpu_batch_reserve, dnagpu_*_batched) fail with DNAGPU_ENOMEM as if HBM
+ * were full -- the caller must then run the blocks one at a time, with the same results */
+int dnagpu_debug_fail_batch_workspaces(long n);
 /* Launches with fewer than `tiles` 128 x 128 tiles use the 64-tile latency kernel (default 160); 0 sends every launch through the
  * 128-tile throughput kernel (gemm_f64_dma_kernel), a negative value restores the default.  Returns the previous value. */
 long dnagpu_debug_set_small_tiles(long tiles);

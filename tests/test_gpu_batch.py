@@ -80,3 +80,26 @@ def test_a_singular_member_is_reported_with_its_block(built, tmp_path):
         with pytest.raises(adjust.NetAdjustException) as e:
             _run(str(tmp_path), "s", multi_thread=True, batch_blocks=cap, free_std_dev=1e200)
         assert "singular" in str(e.value) and "block 4" in str(e.value), str(e.value)
+
+
+def test_without_room_for_the_members_the_blocks_go_one_at_a_time(built, tmp_path):
+    """the members' workspaces cannot be allocated (injected): every group falls back to the unbatched calls, same bits, no failure"""
+    adjust.write_synthetic_network(str(tmp_path), "m", 48, 40, 0, 6, seed=13)
+    a0, st0 = _run(str(tmp_path), "m", multi_thread=True, batch_blocks=0)
+    ref = _results(a0)
+    a0.close()
+    built.dnagpu_debug_fail_batch_workspaces(1000)
+    try:
+        a1, st1 = _run(str(tmp_path), "m", multi_thread=True, batch_blocks=16)
+        assert st1 == st0 == 0 and a1.batched_block_steps() == 0
+        got = _results(a1)
+        a1.close()
+    finally:
+        built.dnagpu_debug_fail_batch_workspaces(0)
+    assert got[2] == ref[2]
+    for b in range(len(ref[0])):
+        assert np.array_equal(ref[0][b], got[0][b]) and np.array_equal(ref[1][b], got[1][b])
+    # and with room again the same adjustment is batched
+    a2, st2 = _run(str(tmp_path), "m", multi_thread=True, batch_blocks=16)
+    assert st2 == 0 and a2.batched_block_steps() > 0
+    a2.close()

@@ -1,15 +1,21 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/profiles_new
+mkdir -p $O
 export GPU_MAX_HW_QUEUES=16
-echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-run() { echo "== $*"; env "$@" timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain $EXTRA 2>&1 | grep -E "ms_per_step|rror" | cut -c90-250; }
-EXTRA="" run DNAGPU_SCHUR_SPLIT=0.2
-EXTRA="" run DNAGPU_SCHUR_SPLIT=0.15
-EXTRA="" run DNAGPU_SCHUR_SPLIT=0.1
-EXTRA="" run DNAGPU_SCHUR_SPLIT=0.07
-EXTRA="" run DNAGPU_SCHUR_SPLIT=0.25
-echo "== default run"
-T0=$SECONDS; timeout 900 python bench.py 2> gpurun_out/default_run.err | tail -1 > gpurun_out/r03_bench_default_run.json; echo "python bench.py (no flags: cfg3, 2 timed steps + 1 warm-up, the one-chain step, the CPU baseline sample in both schedules): $((SECONDS - T0)) s wall clock" | tee gpurun_out/r03_bench_default_run_time.txt
-cut -c1-400 gpurun_out/r03_bench_default_run.json
+echo "== full gpu suite"
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6
+TAG=r03
+cd /tmp && export TMPDIR=/tmp
+CMD="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-one-chain"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- timeout 600 python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-one-chain > $O/pmc_$c.log 2>&1
+  lc=$(echo $c | tr A-Z a-z)
+  python $R/tools/rocprof_summary.py pmc /tmp/pmc_$c $O/${TAG}_cfg3_pmc_$lc.txt "rocprofv3 --pmc $c --kernel-trace -- $CMD   (${TAG}, cfg3)"
+done
+(cd $O && python $R/tools/pmc_traffic_json.py ${TAG}_cfg3_pmc_fetch_size.txt ${TAG}_cfg3_pmc_write_size.txt ${TAG}_hbm_traffic.json cfg3 > /dev/null)
+cp $O/${TAG}_hbm_traffic.json $R/profiles/      # (the bench run below quotes it: same sources)
+cd $R
+timeout 600 python bench.py --steps 2 --warmup 1 2> $O/bench_cfg3.err | tail -1 > $O/${TAG}_bench_cfg3.json
+cut -c1-300 $O/${TAG}_bench_cfg3.json; cat $O/${TAG}_hbm_traffic.json
