@@ -5,6 +5,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/dnagpu.h"
 #include "sym_inverse.h"
@@ -107,6 +108,13 @@ struct dnagpu_ctx {
     size_t scr_u32_cap[DNAGPU_NUM_CHAINS] = {};
     double* scr_f64[DNAGPU_NUM_CHAINS] = {};
     size_t scr_f64_cap[DNAGPU_NUM_CHAINS] = {};
+    // index lists that keep coming back (a block's kept / junction stations, every chain step of every iteration): their device copies,
+    // per chain, found by content -- no upload and no stream synchronisation from the second use on (dnagpu_api.hip stage_u32)
+    struct IndexList {
+        std::vector<uint32_t> host;
+        uint32_t* dev = nullptr;
+    };
+    std::unordered_multimap<uint64_t, IndexList> idx_cache[DNAGPU_NUM_CHAINS];
     // pinned host landing zone for (max correction, row)
     double* red_val_host[DNAGPU_NUM_CHAINS] = {};
     uint32_t* red_idx_host[DNAGPU_NUM_CHAINS] = {};
