@@ -5,6 +5,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <stdlib.h>
 #include <unordered_map>
 #include <vector>
 #include "../../include/dnagpu.h"

@@ -96,7 +96,7 @@ int ensure_symv(dnagpu_ctx* ctx, int chain, uint32_t np) {
     if (ctx->symv_part[chain]) hipFree(ctx->symv_part[chain]);
     ctx->symv_part[chain] = nullptr;
     ctx->symv_cap[chain] = 0;
-    HIPCHK(hipMalloc(&ctx->symv_part[chain], (size_t)SYMV_CHUNKS * np * sizeof(double)));
+    HIPCHK(dnagpu::poison_malloc(&ctx->symv_part[chain], (size_t)SYMV_CHUNKS * np * sizeof(double)));
     ctx->symv_cap[chain] = np;
     return DNAGPU_OK;
 }
@@ -108,7 +108,7 @@ int ensure_scr_u32(dnagpu_ctx* ctx, int chain, size_t count) {
     ctx->scr_u32[chain] = nullptr;
     ctx->scr_u32_cap[chain] = 0;
     size_t cap = std::max<size_t>(count, 4096);
-    HIPCHK(hipMalloc(&ctx->scr_u32[chain], cap * sizeof(uint32_t)));
+    HIPCHK(dnagpu::poison_malloc(&ctx->scr_u32[chain], cap * sizeof(uint32_t)));
     ctx->scr_u32_cap[chain] = cap;
     return DNAGPU_OK;
 }
@@ -120,7 +120,7 @@ int ensure_scr_f64(dnagpu_ctx* ctx, int chain, size_t count) {
     ctx->scr_f64[chain] = nullptr;
     ctx->scr_f64_cap[chain] = 0;
     size_t cap = std::max<size_t>(count, 4096);
-    HIPCHK(hipMalloc(&ctx->scr_f64[chain], cap * sizeof(double)));
+    HIPCHK(dnagpu::poison_malloc(&ctx->scr_f64[chain], cap * sizeof(double)));
     ctx->scr_f64_cap[chain] = cap;
     return DNAGPU_OK;
 }
@@ -135,7 +135,8 @@ void free_index_cache(dnagpu_ctx* ctx, int chain) {
 // the chain steps and rigorous solves of the condensed schedule send the same station lists in every iteration, and the upload's
 // stream synchronisation -- 4 - 5 per chain step of ~1.8 ms -- was a tenth of the chain phase
 int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, uint32_t** dev) {
-    if (count >= 64) {
+    static const bool cache_on = !(getenv("DNAGPU_INDEX_CACHE") && atoi(getenv("DNAGPU_INDEX_CACHE")) == 0);     // (diagnostic switch)
+    if (cache_on && count >= 64) {
         uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
         for (size_t i = 0; i < count; ++i) h = (h ^ host[i]) * 1099511628211ull;
         auto& cache = ctx->idx_cache[chain];
@@ -150,7 +151,7 @@ int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, ui
             free_index_cache(ctx, chain);
         }
         uint32_t* d = nullptr;
-        hipError_t e = hipMalloc(&d, count * sizeof(uint32_t));
+        hipError_t e = dnagpu::poison_malloc(&d, count * sizeof(uint32_t));
         if (e == hipSuccess) {
             e = hipMemcpy(d, host, count * sizeof(uint32_t), hipMemcpyHostToDevice);
             if (e == hipSuccess) {
@@ -276,7 +277,7 @@ int dnagpu_create(int device, dnagpu_ctx** out) {
         }
         ctx->ws[c].stream = ctx->stream[c];
     }
-    if (hipMalloc(&ctx->bad_dev, sizeof(int)) != hipSuccess) {
+    if (dnagpu::poison_malloc(&ctx->bad_dev, sizeof(int)) != hipSuccess) {
         dnagpu_destroy(ctx);
         return DNAGPU_ENOMEM;
     }
@@ -350,7 +351,7 @@ int dnagpu_device_alloc(dnagpu_ctx* ctx, size_t bytes, void** out) {
     CHK_CTX();
     if (!out) return fail(ctx, DNAGPU_EINVAL, "device_alloc: null out");
     *out = nullptr;
-    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    hipError_t e = dnagpu::poison_malloc(out, bytes ? bytes : 8);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "device allocation", e);
@@ -564,8 +565,8 @@ int dnagpu_matrix_create(dnagpu_ctx* ctx, uint32_t n_max, dnagpu_matrix** out) {
     m->n_max = n_max;
     m->np_max = pad128(n_max);
     // one spare tile row: dnagpu_schur_carry keeps (np + 128) x np panels here
-    hipError_t e = hipMalloc(&m->F, ((size_t)m->np_max + 128) * m->np_max * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&m->jest, (size_t)m->np_max * sizeof(double));
+    hipError_t e = dnagpu::poison_malloc(&m->F, ((size_t)m->np_max + 128) * m->np_max * sizeof(double));
+    if (e == hipSuccess) e = dnagpu::poison_malloc(&m->jest, (size_t)m->np_max * sizeof(double));
     if (e != hipSuccess) {
         if (m->F) hipFree(m->F);
         delete m;
@@ -656,7 +657,7 @@ int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu
         if (ctx->stage_buf[chain]) hipFree(ctx->stage_buf[chain]);
         ctx->stage_buf[chain] = nullptr;
         ctx->stage_cap[chain] = 0;
-        if (hipMalloc(&ctx->stage_buf[chain], cnt * sizeof(double)) != hipSuccess) {
+        if (dnagpu::poison_malloc(&ctx->stage_buf[chain], cnt * sizeof(double)) != hipSuccess) {
             (void)hipGetLastError();
             ctx->stage_buf[chain] = nullptr;
             return dnagpu_matrix_download_packed(ctx, chain, m, ap);   // no room for the staging buffer: the chain waits for its copy
@@ -835,7 +836,7 @@ int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint
     size_t nb = std::max<size_t>(n_baselines, 1);
     hipError_t e = hipSuccess;
     auto A = [&](void** p, size_t bytes) {
-        if (e == hipSuccess) e = hipMalloc(p, bytes);
+        if (e == hipSuccess) e = dnagpu::poison_malloc(p, bytes);
     };
     A((void**)&b.x_orig, nv);
     A((void**)&b.x_rig, nv);
@@ -893,9 +894,9 @@ int dnagpu_block_set_station_geo(dnagpu_ctx* ctx, uint32_t blk, const double* ll
     if (!b || (b->n_stn && (!llh || !geoid || !defl))) return fail(ctx, DNAGPU_EINVAL, "block_set_station_geo: bad arguments");
     const size_t ns = std::max<size_t>(b->n_stn, 1);
     if (!b->s_llh) {
-        HIPCHK(hipMalloc(&b->s_llh, 3 * ns * sizeof(double)));
-        HIPCHK(hipMalloc(&b->s_geoid, ns * sizeof(double)));
-        HIPCHK(hipMalloc(&b->s_defl, 2 * ns * sizeof(double)));
+        HIPCHK(dnagpu::poison_malloc(&b->s_llh, 3 * ns * sizeof(double)));
+        HIPCHK(dnagpu::poison_malloc(&b->s_geoid, ns * sizeof(double)));
+        HIPCHK(dnagpu::poison_malloc(&b->s_defl, 2 * ns * sizeof(double)));
     }
     if (!b->n_stn) return DNAGPU_OK;
     HIPCHK(hipMemcpy(b->s_llh, llh, 3 * (size_t)b->n_stn * sizeof(double), hipMemcpyHostToDevice));
@@ -956,11 +957,11 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
         if (b->wb[c]) hipFree(b->wb[c]);
         b->wb[c] = nullptr;
-        HIPCHK(hipMalloc(&b->wb[c], std::max<size_t>((size_t)b->n_bl + nv, 1) * 3 * sizeof(double)));
+        HIPCHK(dnagpu::poison_malloc(&b->wb[c], std::max<size_t>((size_t)b->n_bl + nv, 1) * 3 * sizeof(double)));
     }
     if (!n_t) return DNAGPU_OK;
     auto upv = [&](void** dev, const void* src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dev, bytes);
+        hipError_t e = dnagpu::poison_malloc(dev, bytes);
         if (e == hipSuccess) e = hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
@@ -974,8 +975,8 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
     HIPCHK(upv((void**)&b->t_ih, inst_height, n_t * sizeof(double)));
     HIPCHK(upv((void**)&b->t_th, targ_height, n_t * sizeof(double)));
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        HIPCHK(hipMalloc(&b->tb[c], n_t * sizeof(double)));
-        HIPCHK(hipMalloc(&b->trow[c], 9 * (size_t)n_t * sizeof(double)));
+        HIPCHK(dnagpu::poison_malloc(&b->tb[c], n_t * sizeof(double)));
+        HIPCHK(dnagpu::poison_malloc(&b->trow[c], 9 * (size_t)n_t * sizeof(double)));
     }
     return DNAGPU_OK;
 }
@@ -1019,7 +1020,7 @@ int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_se
     for (uint32_t t = 0; t < n_t; ++t)
         if (b->h_ttype[t] == 'D' && !in_set[t]) return fail(ctx, DNAGPU_EINVAL, "block_set_direction_sets: a type D entry belongs to no set");
     auto up32 = [&](uint32_t** dev, const std::vector<uint32_t>& v) -> hipError_t {
-        hipError_t e = hipMalloc((void**)dev, std::max<size_t>(v.size(), 1) * sizeof(uint32_t));
+        hipError_t e = dnagpu::poison_malloc((void**)dev, std::max<size_t>(v.size(), 1) * sizeof(uint32_t));
         if (e == hipSuccess && !v.empty()) e = hipMemcpy(*dev, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         return e;
     };
@@ -1034,7 +1035,7 @@ int dnagpu_block_set_direction_sets(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_se
     HIPCHK(up32(&b->ds_row0, row0));
     HIPCHK(up32(&b->ds_k, kk));
     HIPCHK(up32(&b->ds_woff, woff));
-    HIPCHK(hipMalloc(&b->ds_wts, std::max<size_t>(wtot, 1) * sizeof(double)));
+    HIPCHK(dnagpu::poison_malloc(&b->ds_wts, std::max<size_t>(wtot, 1) * sizeof(double)));
     if (wtot) HIPCHK(hipMemcpy(b->ds_wts, weights, wtot * sizeof(double), hipMemcpyHostToDevice));
     b->n_dsblk = (uint32_t)ea.size();
     return DNAGPU_OK;
@@ -1165,7 +1166,7 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     b->n_wblk = n_wblk;
     auto up = [&](uint32_t** dev, const std::vector<uint32_t>& v) -> hipError_t {
         size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(uint32_t);
-        hipError_t e = hipMalloc((void**)dev, bytes);
+        hipError_t e = dnagpu::poison_malloc((void**)dev, bytes);
         if (e == hipSuccess && !v.empty()) e = hipMemcpy(*dev, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         return e;
     };
@@ -1175,7 +1176,7 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     HIPCHK(up(&b->pair_ent, pent));
     HIPCHK(up(&b->inc_off, ioff));
     HIPCHK(up(&b->inc, inc));
-    HIPCHK(hipMalloc(&b->Wblk, std::max<size_t>((size_t)n_wblk + (size_t)DNAGPU_NUM_CHAINS * ((size_t)b->n_tblk + b->n_dsblk), 1) * 9 * sizeof(double)));
+    HIPCHK(dnagpu::poison_malloc(&b->Wblk, std::max<size_t>((size_t)n_wblk + (size_t)DNAGPU_NUM_CHAINS * ((size_t)b->n_tblk + b->n_dsblk), 1) * 9 * sizeof(double)));
     if (!m) return DNAGPU_OK;
     HIPCHK(hipMemcpy(b->s1, stn1, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->s2, stn2, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1199,8 +1200,8 @@ int dnagpu_block_set_clusters(dnagpu_ctx* ctx, uint32_t blk, const uint32_t* stn
     if (!dst.empty()) {
         double* vtmp = nullptr;
         uint32_t* dtmp = nullptr;
-        HIPCHK(hipMalloc(&vtmp, v6.size() * sizeof(double)));
-        hipError_t e = hipMalloc(&dtmp, dst.size() * sizeof(uint32_t));
+        HIPCHK(dnagpu::poison_malloc(&vtmp, v6.size() * sizeof(double)));
+        hipError_t e = dnagpu::poison_malloc(&dtmp, dst.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpy(vtmp, v6.data(), v6.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(dtmp, dst.data(), dst.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(ctx->bad_dev, &bad, sizeof(int), hipMemcpyHostToDevice);
@@ -1582,9 +1583,9 @@ int schur_order(dnagpu_ctx* ctx, Block* b, const uint32_t* idx_out, size_t k, ui
         b->schur_map[slot] = nullptr;
         b->schur_idx[slot] = nullptr;
         b->schur_spos[slot] = nullptr;
-        HIPCHK(hipMalloc(&b->schur_map[slot], (size_t)npp * sizeof(int32_t)));
-        HIPCHK(hipMalloc(&b->schur_idx[slot], k * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&b->schur_spos[slot], (size_t)b->n_stn * sizeof(uint32_t)));
+        HIPCHK(dnagpu::poison_malloc(&b->schur_map[slot], (size_t)npp * sizeof(int32_t)));
+        HIPCHK(dnagpu::poison_malloc(&b->schur_idx[slot], k * sizeof(uint32_t)));
+        HIPCHK(dnagpu::poison_malloc(&b->schur_spos[slot], (size_t)b->n_stn * sizeof(uint32_t)));
         HIPCHK(hipMemcpy(b->schur_spos[slot], spos.data(), (size_t)b->n_stn * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(b->schur_map[slot], map.data(), (size_t)npp * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(b->schur_idx[slot], idx_out, k * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1701,9 +1702,9 @@ int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagp
     if (!p) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
     p->k_cap = pad128(k_max + 1);
     p->n_cap = pad128(n_max - k_max ? n_max - k_max : 1) + p->k_cap;
-    hipError_t e = hipMalloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&p->WK, (size_t)p->k_cap * p->n_cap * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
+    hipError_t e = dnagpu::poison_malloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = dnagpu::poison_malloc(&p->WK, (size_t)p->k_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = dnagpu::poison_malloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
     if (e != hipSuccess) {
         dnagpu_partial_destroy(ctx, p);
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "retained factor allocation", e);
@@ -1726,8 +1727,8 @@ int dnagpu_partial_create_in(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dn
     }
     p->store = store;
     p->X = store->F;
-    hipError_t e = hipMalloc(&p->WK, (size_t)p->k_cap * p->n_cap * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
+    hipError_t e = dnagpu::poison_malloc(&p->WK, (size_t)p->k_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = dnagpu::poison_malloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
     if (e != hipSuccess) {
         dnagpu_partial_destroy(ctx, p);
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "retained factor allocation", e);
@@ -1754,8 +1755,8 @@ int dnagpu_partial_create_spine(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max,
     if (store)
         p->X = store->F;
     else
-        e = hipMalloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
+        e = dnagpu::poison_malloc(&p->X, (size_t)p->n_cap * p->n_cap * sizeof(double));
+    if (e == hipSuccess) e = dnagpu::poison_malloc(&p->map, (size_t)p->n_cap * sizeof(int32_t));
     if (e != hipSuccess) {
         dnagpu_partial_destroy(ctx, p);
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "retained factor allocation", e);
@@ -2010,8 +2011,8 @@ int ensure_batch_ws(dnagpu_ctx* ctx, int chain, int nb, uint32_t npp, uint32_t w
     }
     for (int b = 1; b < nb; ++b) {
         hipError_t e = hipSuccess;
-        if (!ws.bX[b]) e = hipMalloc(&ws.bX[b], (size_t)ws.bnp_cap * ws.bnp_cap * sizeof(double));
-        if (e == hipSuccess && !ws.bW[b]) e = hipMalloc(&ws.bW[b], ((size_t)ws.bw_cols + 128) * ws.bnp_cap * sizeof(double));
+        if (!ws.bX[b]) e = dnagpu::poison_malloc(&ws.bX[b], (size_t)ws.bnp_cap * ws.bnp_cap * sizeof(double));
+        if (e == hipSuccess && !ws.bW[b]) e = dnagpu::poison_malloc(&ws.bW[b], ((size_t)ws.bw_cols + 128) * ws.bnp_cap * sizeof(double));
         if (e != hipSuccess) {
             (void)hipGetLastError();
             // nothing half allocated stays behind: the caller falls back to one member at a time and needs the memory for that
@@ -2348,9 +2349,9 @@ extern "C" int dnagpu_bench_gemm(dnagpu_ctx* ctx, int variant, int mt, int nt, i
     size_t cols = ld;
     if (const char* pad = getenv("DNAGPU_BENCH_LDPAD")) ld += (size_t)atoi(pad);      // leading dimension != a multiple of 128: the set-conflict probe
     double *A = nullptr, *B = nullptr, *Cc = nullptr;
-    HIPCHK(hipMalloc(&A, ld * cols * sizeof(double)));
-    HIPCHK(hipMalloc(&B, ld * cols * sizeof(double)));
-    HIPCHK(hipMalloc(&Cc, ld * cols * sizeof(double)));
+    HIPCHK(dnagpu::poison_malloc(&A, ld * cols * sizeof(double)));
+    HIPCHK(dnagpu::poison_malloc(&B, ld * cols * sizeof(double)));
+    HIPCHK(dnagpu::poison_malloc(&Cc, ld * cols * sizeof(double)));
     // pseudo-random fill (full-range mantissas: zero fill would flatter the clocks)
     std::vector<double> h(ld * 1024);
     uint64_t s = 88172645463325252ull;

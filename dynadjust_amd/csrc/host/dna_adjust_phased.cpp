@@ -322,6 +322,9 @@ void dna_adjust::AdjustPhasedMultiThreadIteration() {
 
     // combination solves until the queue is empty and the reverse pass is over
     auto drain = [&](int c) {
+        // DNAGPU_COMBINE_CHAIN=<c> (diagnostic): only that chain takes combination solves
+        static const int only = getenv("DNAGPU_COMBINE_CHAIN") ? atoi(getenv("DNAGPU_COMBINE_CHAIN")) : -1;
+        if (only >= 0 && c != only) return;
         for (;;) {
             UINT32 k;
             {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace dnagpu {
@@ -102,5 +103,21 @@ void launch_symv(const double* F, const double* x, double* y, double* part, uint
                  hipStream_t st);
 
 inline uint32_t pad128(uint32_t n) { return n == 0 ? 128u : ((n + 127u) / 128u) * 128u; }
+
+// DNAGPU_POISON_ALLOC=1 (diagnostic): every device allocation of the library is filled with 0xFF bytes -- NaN as a double -- so that a
+// buffer that is read before it was written shows up as NaN in the results instead of as whatever the memory held before (typically
+// the same values from an earlier adjustment of the process: invisible)
+inline hipError_t poison_malloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    static const bool poison = getenv("DNAGPU_POISON_ALLOC") && atoi(getenv("DNAGPU_POISON_ALLOC")) != 0;
+    if (e == hipSuccess && poison && bytes) {
+        e = hipMemset(*p, 0xFF, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    return e;
+}
+template <class T>
+inline hipError_t poison_malloc(T** p, size_t bytes) { return poison_malloc(reinterpret_cast<void**>(p), bytes); }
+
 
 }  // namespace dnagpu

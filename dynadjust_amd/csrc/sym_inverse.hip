@@ -18,11 +18,11 @@ hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t st
     ws.stream = stream;
     size_t bytes = (size_t)np_cap * np_cap * sizeof(double);
     hipError_t e;
-    if ((e = hipMalloc(&ws.X, bytes)) != hipSuccess) return e;
-    if ((e = hipMalloc(&ws.W, bytes)) != hipSuccess) return e;
-    if ((e = hipMalloc(&ws.svec, (size_t)np_cap * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMalloc(&ws.info, BATCH_MAX * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&ws.sync_ctr, sizeof(unsigned long long))) != hipSuccess) return e;
+    if ((e = dnagpu::poison_malloc(&ws.X, bytes)) != hipSuccess) return e;
+    if ((e = dnagpu::poison_malloc(&ws.W, bytes)) != hipSuccess) return e;
+    if ((e = dnagpu::poison_malloc(&ws.svec, (size_t)np_cap * sizeof(double))) != hipSuccess) return e;
+    if ((e = dnagpu::poison_malloc(&ws.info, BATCH_MAX * sizeof(int))) != hipSuccess) return e;
+    if ((e = dnagpu::poison_malloc(&ws.sync_ctr, sizeof(unsigned long long))) != hipSuccess) return e;
     if ((e = hipMemset(ws.sync_ctr, 0, sizeof(unsigned long long))) != hipSuccess) return e;
     ws.sync_base = 0;
     if ((e = hipHostMalloc(&ws.info_host, BATCH_MAX * sizeof(int))) != hipSuccess) return e;
@@ -77,7 +77,7 @@ static std::atomic<long> g_fault_countdown{[] {
 void fault_inject_reset(long nth) { g_fault_countdown.store(nth); }
 static hipError_t table_malloc(uint32_t** dev, size_t bytes) {
     if (g_fault_countdown.load() > 0 && g_fault_countdown.fetch_sub(1) == 1) return hipErrorOutOfMemory;
-    return hipMalloc(dev, bytes);
+    return dnagpu::poison_malloc(dev, bytes);
 }
 
 static double gemm_flops(const GemmArgs& a) {
@@ -229,7 +229,7 @@ static bool gemm_split(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
         ws.dist_stage = nullptr;
         ws.dist_stage_cap = 0;
         const size_t want = std::max(off[W], (size_t)ws.np_cap * ws.np_cap);
-        hipError_t e = hipMalloc(&ws.dist_stage, want * sizeof(double));
+        hipError_t e = dnagpu::poison_malloc(&ws.dist_stage, want * sizeof(double));
         if (e != hipSuccess) {
             (void)hipGetLastError();
             inv_note_error(ws, e, "staging buffer of the distributed inverse");
@@ -821,10 +821,10 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
         ws.dag_flags = nullptr;
         ws.dag_flags_cap = 0;
         const size_t want = std::max<size_t>((size_t)g->nids * 2, (size_t)1 << 20);
-        hipError_t e = hipMalloc(&ws.dag_flags, want * sizeof(uint32_t));
+        hipError_t e = dnagpu::poison_malloc(&ws.dag_flags, want * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemsetAsync(ws.dag_flags, 0, want * sizeof(uint32_t), ws.stream);
         if (e == hipSuccess && !ws.dag_ticket) {
-            e = hipMalloc(&ws.dag_ticket, sizeof(unsigned long long));
+            e = dnagpu::poison_malloc(&ws.dag_ticket, sizeof(unsigned long long));
             if (e == hipSuccess) e = hipMemsetAsync(ws.dag_ticket, 0, sizeof(unsigned long long), ws.stream);
             ws.dag_ticket_base = 0;
         }
@@ -863,7 +863,7 @@ bool run_dag(InvWorkspace& ws, int kind, int ti, int tj, int what, double* F, in
     // DNAGPU_DAG_TRACE=<prefix>: per-task clocks of every launch, written to <prefix>.<launch>.bin (tools/dag_trace_report.py); diagnostic, synchronous
     static const char* trace_prefix = getenv("DNAGPU_DAG_TRACE");
     L.trace = nullptr;
-    if (trace_prefix && hipMalloc(&L.trace, (size_t)L.ntasks * 4 * sizeof(unsigned long long)) == hipSuccess)
+    if (trace_prefix && dnagpu::poison_malloc(&L.trace, (size_t)L.ntasks * 4 * sizeof(unsigned long long)) == hipSuccess)
         hipMemsetAsync(L.trace, 0, (size_t)L.ntasks * 4 * sizeof(unsigned long long), ws.stream);
     launch_tile_dag(L, ws.stream);
     inv_note_error(ws, hipGetLastError(), "tile DAG launch");
@@ -917,6 +917,13 @@ void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, boo
         launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
     }
     const int T = (int)(np / 128);
+    // DNAGPU_POISON_ALLOC=2 (diagnostic): the scratch of an inverse (X: L^-1, W: the panels) starts as NaN -- a tile that is read before
+    // this call wrote it shows up in the result instead of passing as whatever the previous call on this chain left there
+    static const bool poison_scratch = getenv("DNAGPU_POISON_ALLOC") && atoi(getenv("DNAGPU_POISON_ALLOC")) >= 2;
+    if (poison_scratch) {
+        inv_note_error(ws, hipMemsetAsync(ws.X, 0xFF, (size_t)np * np * sizeof(double), ws.stream), "poison");
+        inv_note_error(ws, hipMemsetAsync(ws.W, 0xFF, (size_t)np * np * sizeof(double), ws.stream), "poison");
+    }
     // potrf + trtri by the recursion, then Ninv = X^T X (lauum), both triangles
     auto ops = [&](Rec& rec, const double*) {
         rec.node(0, T);
