@@ -925,6 +925,11 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
             Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
         }
     }
+    // Everything above was enqueued chain by chain; what follows reads across chains -- the reverse thread's chain takes the last block's
+    // originals that chain 0 has just set, any chain the estimates another one restored.  The chains meet here, once per iteration
+    // (found in round 3: under host load the reverse pass of the reference's multi-thread schedule started from the last block's
+    // previous originals now and then -- an 8 cm correction in iteration 2, healed by two further iterations, 1e-8 m left in the result).
+    Check(dnagpu_sync(ctx_), 0, "UpdateAdjustment()");
     // no further iterations: the station records take the adjusted coordinates (ADJ:496-531, ADJ:541-545)
     if (!iterate && !IsCancelled()) UpdateGeographicCoords();
     isPreparing_ = false;

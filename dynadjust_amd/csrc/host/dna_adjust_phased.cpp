@@ -126,6 +126,7 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
         PhasedNoteCorrection(mv);
         Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesForward()");
         StoreRigorousVariances(c, k, W);
+        Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesForward()");      // (like PhasedFinaliseBlock: other chains read the rigorous results next)
     }
     if (meta._blockIsolated || meta._blockLast) return mv;
     if (v_blockMeta_[k + 1]._blockIsolated) return mv;

@@ -74,13 +74,14 @@ def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt
     dxa = [float(np.abs(a.block_estimates(k) - f.block_estimates(k)).max()) for k in range(6)]
     dvf = [float(np.abs(f.block_variances_packed(k) - o.block_variances(k)).max() / np.abs(o.block_variances(k)).max()) for k in range(6)]
     corr = [f.GetIterationCorrection(i + 1) for i in range(f.CurrentIteration())]
-    assert max(dxf) < 10 * TOL_X and max(dvf) < 10 * TOL_V, (dxf, dvf, corr)
+    # (round 3: under host load the reverse thread of the reference's multi-thread schedule now and then started iteration 2 from the last
+    #  block's previous originals -- 8 cm off, healed by two further iterations, 1.4e-7 left in chi-square; UpdateAdjustment now lets the
+    #  chains meet.  The iteration count and the corrections of the single-GPU run are therefore part of the comparison.)
+    assert f.CurrentIteration() == o.iterations(), corr
+    assert max(dxf) < TOL_X and max(dvf) < TOL_V, (dxf, dvf, corr)
     f.GenerateStatistics()
     f.SerialiseAdjustedVarianceMatrices()
-    # chi-square: a sum over 3 000 squared residuals.  Usually the two runs agree to 1e-9 (schur) or to the last bit; 2 of 29 repetitions of
-    # this file behind test_gpu_adjust.py (round 3) had the single-GPU multi-thread run of the reference schedule 1.4e-7 off -- the same
-    # value both times, never in 1 100 stand-alone repetitions (tools/gpu_mt_probe.py): open, DESIGN.md section 7.  The tuple names the block.
-    assert np.abs(_stats(a) - _stats(f)).max() < 1e-6 * max(1.0, np.abs(_stats(f)).max()), (_stats(a), _stats(f), dxf, dxa, dvf, corr)
+    assert np.abs(_stats(a) - _stats(f)).max() < 1e-7 * max(1.0, np.abs(_stats(f)).max()), (_stats(a), _stats(f), dxf, dxa, dvf, corr)    # (chi-square: a sum over 3 000 squared residuals)
     ra = np.frombuffer(a.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
     rf = np.frombuffer(f.measurement_records().tobytes(), dtype=F.MEASUREMENT_DT)
     for nm in ("measAdj", "measCorr", "measAdjPrec", "residualPrec", "NStat", "PelzerRel"):
