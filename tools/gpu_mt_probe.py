@@ -9,6 +9,7 @@ d = tempfile.mkdtemp()
 adjust.write_synthetic_network(d, "n", 30, 12, 0, 6, seed=10)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 keep = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+schur = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False      # 1: the condensed schedule (the default path) instead of the reference schedule
 ref = None
 bad = 0
 for it in range(N):
@@ -18,7 +19,7 @@ for it in range(N):
         a.PrepareAdjustment(adjust.ProjectSettings("n", d, adjust_mode=adjust.PhasedMode, devices=[0, 0, 0], dist_transport="local", schur_carry=False, multi_thread=True, output_folder=d))
         a.AdjustNetworkDistributed(); a.GenerateStatistics()
     f = adjust.DnaAdjust()
-    f.PrepareAdjustment(adjust.ProjectSettings("n", d, adjust_mode=adjust.PhasedMode, schur_carry=False, multi_thread=True, output_folder=d))
+    f.PrepareAdjustment(adjust.ProjectSettings("n", d, adjust_mode=adjust.PhasedMode, schur_carry=schur, multi_thread=True, output_folder=d))
     st = f.AdjustNetwork(); f.GenerateStatistics()
     x = [f.block_estimates(k) for k in range(6)]
     v = [f.block_variances_packed(k) for k in range(6)]
@@ -26,6 +27,8 @@ for it in range(N):
     corr = [f.GetIterationCorrection(i + 1) for i in range(f.CurrentIteration())]
     f.close()
     if a is not None: a.close()
+    if it and it % 100 == 0:
+        print("runs so far:", it, "deviant:", bad, flush=True)       # (a run under `timeout` still leaves its count)
     if ref is None:
         ref = (x, v, chi); continue
     if chi != ref[2] or any(not np.array_equal(x[k], ref[0][k]) for k in range(6)):
