@@ -707,6 +707,7 @@ def main():
     a.PrepareAdjustment(p)
     lib = a.lib
     ctx = a.device_context()
+    hbm_prepared = _hbm(lib, ctx)
 
     def one_step():
         a.ResetAdjustment()
@@ -772,6 +773,10 @@ def main():
             # blocks of one shape through the large steps as one batch of merged launches (a.batch_blocks): block steps
             # (condensing, kept-block factorisation, variance matrices: up to 2 per block and iteration + 1 per block) that were batched
             "batched_block_steps_per_step": a.batched_block_steps(),
+            # the GPU's memory: total, free after PrepareAdjustment (blocks, measurements), free after the timed steps (variance matrices,
+            # kept factors, chain and batch workspaces allocated), and whether the variance matrices were staged to host memory
+            "hbm_gb": {"total": round(hbm_prepared[1] / 1e9, 1), "free_after_prepare": round(hbm_prepared[0] / 1e9, 1),
+                       "free_at_end": round(_hbm(lib, ctx)[0] / 1e9, 1), "variances_staged_in_host_memory": bool(lib.dnaadj_staged(a.h))},
             "parallelism": "1 GPU, one chain" if not p.multi_thread else
             "1 GPU, %s chains (multi_thread: the independent block steps of the condensed schedule are served by every chain; the two junction chains run side by side)" % os.environ.get("DNAGPU_CHAINS", "4"),
         },

@@ -1,13 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export GPU_MAX_HW_QUEUES=16
-pids=""
-for i in $(seq 1 $(nproc)); do timeout 300 python -c "
-while True: pass" & pids="$pids $!"; done
-echo "== condensed schedule (default path, batches, four chains) under CPU load"
-timeout 120 python tools/gpu_mt_probe.py 100000 0 1 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" | tail -6 | cut -c1-420
-echo "== reference schedule, multi-thread, under CPU load (after the fix)"
-timeout 120 python tools/gpu_mt_probe.py 100000 0 0 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" | tail -6 | cut -c1-420
-for p in $pids; do kill $p 2>/dev/null; done
-wait 2>/dev/null
-echo done
+timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain 2>&1 | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['hbm_gb'], d['config']['batched_block_steps_per_step'])"
+timeout 400 python bench.py --workload cfg4_slice --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain 2>&1 | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['hbm_gb'], d['config']['batched_block_steps_per_step'])"
