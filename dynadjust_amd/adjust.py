@@ -304,6 +304,16 @@ class DnaAdjust:
         """block steps that went through batched calls (settings.batch_blocks)"""
         return int(self.lib.dnaadj_batched_block_steps(self.h))
 
+    def memory_plan(self):
+        """PrepareAdjustment's memory plan (dnaadj_memory_plan): where the staged variance matrices go, which blocks keep their factor"""
+        out = (C.c_double * 8)()
+        if self.lib.dnaadj_memory_plan(self.h, out) != 0:
+            return {}
+        return {"staged_variances_host_gb": round(out[0] / 1e9, 2), "staged_variances_packed_in_hbm_gb": round(out[1] / 1e9, 2),
+                "blocks_keeping_their_factor": int(out[2]), "blocks_condensed": int(out[3]), "batch_members_beyond_first": int(out[4]),
+                "host_memory_available_gb": round(out[5] / 1e9, 1),
+                "copied_to_host_gb": round(out[6] / 1e9, 2), "waited_for_copies_ms": round(out[7], 1)}
+
     def elimination_count(self):
         return self.lib.dnaadj_elimination_count(self.h)
 

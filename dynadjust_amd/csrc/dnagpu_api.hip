@@ -675,6 +675,24 @@ int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu
     return DNAGPU_OK;
 }
 
+int dnagpu_matrix_pack_device(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* dev_ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || (!dev_ap && m->n)) return fail(ctx, DNAGPU_EINVAL, "matrix_pack_device: bad arguments");
+    if (m->n) launch_pack_lower(m->F, dev_ap, m->n, m->np, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_matrix_unpack_device(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* dev_ap, uint32_t n) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || n > m->n_max || (!dev_ap && n)) return fail(ctx, DNAGPU_EINVAL, "matrix_unpack_device: bad arguments");
+    m->n = n;
+    m->np = pad128(n);
+    launch_unpack_lower(dev_ap, m->F, n, m->np, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
 int dnagpu_copies_sync(dnagpu_ctx* ctx) {
     CHK_CTX();
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {

@@ -47,7 +47,7 @@ void dna_adjust::FreeDevice() {
         if (b.finv) dnagpu_matrix_destroy(ctx_, b.finv);
         if (b.rinv) dnagpu_matrix_destroy(ctx_, b.rinv);
         if (b.red) dnagpu_matrix_destroy(ctx_, b.red);
-        if (b.rig_host) dnagpu_host_free(ctx_, b.rig_host);
+        if (b.rig_host) (b.rig_on_device ? dnagpu_device_free : dnagpu_host_free)(ctx_, b.rig_host);
         b.rig_host = nullptr;
         if (b.part) dnagpu_partial_destroy(ctx_, b.part);
         b.part = nullptr;
@@ -731,6 +731,7 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     mt_chains_ = DNAGPU_DEFAULT_CHAINS;
     profileTimings_ = getenv("DYNADJUST_PROFILE") != nullptr;
     profileUpdateNormalsNs_ = profileStageLoadNs_ = profileStageStoreNs_ = 0;
+    stageCopiedBytes_ = stageWaitNs_ = 0;
     if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
     if (const char* e = getenv("DNAGPU_FORCE_DISTRIBUTED")) force_distributed_ = atoi(e) != 0;
     if (comm_ && (comm_->world() != std::max(1, projectSettings_.a.dist_world) || comm_->rank() != projectSettings_.a.dist_rank)) {
@@ -834,6 +835,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     condense_count_ = 0;
     completion_count_ = 0;
     batched_members_ = 0;
+    stageCopiedBytes_ = stageWaitNs_ = 0;
     algorithmic_flops_ = 0.0;
     for (block_t& b : blocks_) b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
     const double t0 = now_ms();
@@ -1006,7 +1008,10 @@ void dna_adjust::AdjustPhased() {
 
 // staged mode: the rigorous variance matrices of the iteration are on their way to host memory on the chains' copy streams
 void dna_adjust::FinishStagedCopies() {
-    if (ctx_ && Staged()) Check(dnagpu_copies_sync(ctx_), 0, "SerialiseBlockToMappedFile()");
+    if (!ctx_ || !Staged()) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    Check(dnagpu_copies_sync(ctx_), 0, "SerialiseBlockToMappedFile()");
+    stageWaitNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void dna_adjust::GetBlockRigorousStations(UINT32 block, std::vector<double>& xyz) {
@@ -1024,7 +1029,10 @@ void dna_adjust::GetBlockRigorousVariancesPacked(UINT32 block, std::vector<doubl
     size_t n = 3 * v_parameterStationList_[block].size();
     packed.resize(n * (n + 1) / 2);
     if (projectSettings_.a.adjust_mode != SimultaneousMode && Staged() && blocks_[block].rig_host && blocks_[block].has_rigvar) {
-        memcpy(packed.data(), blocks_[block].rig_host, packed.size() * sizeof(double));
+        if (blocks_[block].rig_on_device)
+            Check(dnagpu_copy(ctx_, packed.data(), blocks_[block].rig_host, packed.size() * sizeof(double)), block, "GetBlockRigorousVariancesPacked()");
+        else
+            memcpy(packed.data(), blocks_[block].rig_host, packed.size() * sizeof(double));
         return;
     }
     dnagpu_matrix* m = (projectSettings_.a.adjust_mode == SimultaneousMode) ? work_[0] : blocks_[block].rigvar;
@@ -1161,7 +1169,10 @@ void dna_adjust::StatisticsBlock(UINT32 b) {
             // statistics kernels read)
             var = work_[0];
             const auto t0 = std::chrono::steady_clock::now();
-            Check(dnagpu_matrix_upload_packed(ctx_, 0, var, B.rig_host, (UINT32)v_parameterStationList_[b].size() * 3), b, "ComputePrecisionAdjMsrs()");
+            if (B.rig_on_device)
+                Check(dnagpu_matrix_unpack_device(ctx_, 0, var, B.rig_host, (UINT32)v_parameterStationList_[b].size() * 3), b, "ComputePrecisionAdjMsrs()");
+            else
+                Check(dnagpu_matrix_upload_packed(ctx_, 0, var, B.rig_host, (UINT32)v_parameterStationList_[b].size() * 3), b, "ComputePrecisionAdjMsrs()");
             profileStageLoadNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         }
         if (!var) SignalExceptionAdjustment("ComputePrecisionAdjMsrs(): this process holds no rigorous variances for the block.", b);
@@ -1436,8 +1447,10 @@ void dna_adjust::DeSerialiseAdjustedVarianceMatrices() {
         rva.read(reinterpret_cast<char*>(tail), sizeof(tail));
         if (phased && Staged()) {
             if (!blocks_[b].rig_host)
-                Check(dnagpu_host_alloc(ctx_, packed.size() * sizeof(double), (void**)&blocks_[b].rig_host), b, "rigorous variance matrix (host)");
-            memcpy(blocks_[b].rig_host, packed.data(), packed.size() * sizeof(double));
+                Check(blocks_[b].rig_on_device ? dnagpu_device_alloc(ctx_, packed.size() * sizeof(double), (void**)&blocks_[b].rig_host)
+                                               : dnagpu_host_alloc(ctx_, packed.size() * sizeof(double), (void**)&blocks_[b].rig_host),
+                      b, "rigorous variance matrix (staged)");
+            Check(dnagpu_copy(ctx_, blocks_[b].rig_host, packed.data(), packed.size() * sizeof(double)), b, "DeSerialiseAdjustedVarianceMatrices()");
         } else {
             dnagpu_matrix** slot = phased ? &blocks_[b].rigvar : &work_[0];
             if (!*slot) Check(dnagpu_matrix_create(ctx_, phased ? RigvarCapacity(b) : n, slot), b, "rigorous variance matrix");

@@ -201,7 +201,8 @@ private:
         dnagpu_matrix* jfwd = nullptr;        // v_junctionVariancesFwd_ + v_junctionEstimatesFwd_
         dnagpu_matrix* jrev = nullptr;        // v_junctionVariances_ (reverse) + v_junctionEstimatesRev_
         dnagpu_matrix* rigvar = nullptr;      // v_rigorousVariances_
-        double* rig_host = nullptr;           // staged: v_rigorousVariances_ packed (lower, column-major) in page-locked host memory
+        double* rig_host = nullptr;           // staged: v_rigorousVariances_ packed (lower, column-major) in page-locked host memory ...
+        bool rig_on_device = false;           // ... or, where the host's memory limit ends (DecideStaging), the same packed image in HBM
         bool has_rigvar = false;
         // a.reuse_inverses: the inverse of the forward / reverse normals of this block (the combined one is rigvar)
         dnagpu_matrix* finv = nullptr;
@@ -411,9 +412,12 @@ private:
     // a.stage (the reference's --staged-adjustment keeps its block matrices in memory-mapped files): the rigorous variance
     // matrices live in page-locked host memory instead of HBM; switched on by itself when they would not fit
     bool staged_ = false;
+    double host_available_ = 0.0;                               // what the host could still give when the plan was made (HostMemoryAvailable)
+    size_t stage_host_bytes_ = 0, stage_device_bytes_ = 0;    // the staged store's plan: packed variance matrices in host / device memory
     bool Staged() const { return staged_; }
 public:
     bool IsStaged() const { return staged_; }
+    void MemoryPlan(double out[8]) const;
 private:
     std::vector<unsigned char> record_touched_;   // records whose statistics this process computed (UpdateMsrRecord)
     std::atomic<bool> chain_failed_{false};
@@ -481,7 +485,7 @@ private:
     // DYNADJUST_PROFILE (ADJ:53-56, PrintPerformanceProfile ADJ:2562): host-side time spent issuing the formation of the normals, and
     // in the staged mode's loads / stores of the rigorous variances
     bool profileTimings_ = false;
-    std::atomic<uint64_t> profileUpdateNormalsNs_{0}, profileStageLoadNs_{0}, profileStageStoreNs_{0};
+    std::atomic<uint64_t> profileUpdateNormalsNs_{0}, profileStageLoadNs_{0}, profileStageStoreNs_{0}, stageCopiedBytes_{0}, stageWaitNs_{0};
     void PrintPerformanceProfile() const;
     void FormNormals(int chain, UINT32 block, dnagpu_matrix* W);
     std::mutex msg_mutex_;

@@ -5,6 +5,9 @@
 //   the multi-GPU orchestrator (dynadjust_amd/parallel.py) calls the same steps through include/dnaadjust_c.h
 // Reference functions restated per step are cited at each function (ADJ = dynadjust/dnaadjust/dnaadjust.cpp).
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
@@ -237,11 +240,19 @@ void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
         const size_t n = v_parameterStationList_[k].size() * 3;
         if (!B.rig_host) {
             std::lock_guard<std::mutex> lk(alloc_mutex_);
-            Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
+            if (B.rig_on_device)
+                Check(dnagpu_device_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (packed, device)");
+            else
+                Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
         }
         const auto t0 = std::chrono::steady_clock::now();
         // (on a copy stream: the chain goes on with its next block; AdjustPhased waits for the copies at the end of the iteration)
-        Check(dnagpu_matrix_download_packed_async(ctx_, c, W, B.rig_host), k, "UpdateEstimatesFinal()");
+        if (B.rig_on_device)
+            Check(dnagpu_matrix_pack_device(ctx_, c, W, B.rig_host), k, "UpdateEstimatesFinal()");
+        else {
+            Check(dnagpu_matrix_download_packed_async(ctx_, c, W, B.rig_host), k, "UpdateEstimatesFinal()");
+            stageCopiedBytes_ += n * (n + 1) / 2 * sizeof(double);
+        }
         profileStageStoreNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         B.has_rigvar = true;
         B.inverse_pending = false;
@@ -421,16 +432,84 @@ void dna_adjust::AdjustPhasedMultiThreadIteration() {
 // B eliminations (~n^3/3) + B inverses (n^3) instead of the reference's 3B - 2 inverses, and both large phases are
 // independent per block: they shard over chains and GPUs without a dependency (dynadjust_amd/parallel.py).
 
-// a.stage, or by itself when the rigorous variance matrices of all blocks plus the chains' workspaces exceed the free HBM
+// What this process may still take of the host's memory: the container's limit (cgroup v2 memory.max - memory.current, v1
+// memory.limit_in_bytes - usage) or MemAvailable, whichever is smaller.  (The pool's GPU boxes show 3 TB in /proc/meminfo inside a
+// 300 GiB cgroup: page-locking past the limit does not fail, it gets the container killed.)
+static double HostMemoryAvailable() {
+    auto read_num = [](const char* path, double& v) {
+        FILE* f = fopen(path, "r");
+        if (!f) return false;
+        char buf[64] = {0};
+        const bool ok = fgets(buf, sizeof(buf), f) != nullptr && buf[0] >= '0' && buf[0] <= '9';
+        fclose(f);
+        if (ok) v = atof(buf);
+        return ok;
+    };
+    double avail = 1.0e18, lim = 0.0, cur = 0.0;
+    if (read_num("/sys/fs/cgroup/memory.max", lim) && read_num("/sys/fs/cgroup/memory.current", cur)) avail = std::min(avail, lim - cur);
+    if (read_num("/sys/fs/cgroup/memory/memory.limit_in_bytes", lim) && read_num("/sys/fs/cgroup/memory/memory.usage_in_bytes", cur) && lim < 1.0e17)
+        avail = std::min(avail, lim - cur);
+    if (FILE* f = fopen("/proc/meminfo", "r")) {
+        char line[128];
+        while (fgets(line, sizeof(line), f))
+            if (!strncmp(line, "MemAvailable:", 13)) avail = std::min(avail, atof(line + 13) * 1024.0);
+        fclose(f);
+    }
+    return std::max(0.0, avail);
+}
+
+// a.stage, or by itself when the rigorous variance matrices of all blocks plus the chains' workspaces exceed the free HBM.
+// Staged variance matrices are packed triangles in page-locked host memory -- as far as the host's memory limit goes (80 % of what
+// is available now, or DNAGPU_HOST_STORE_GB): the blocks past that keep the same packed image in HBM (block_t::rig_on_device; half of a
+// resident matrix), so that a network whose variances fit neither side alone still runs (cfg4 on one GPU: 373 GB).
 void dna_adjust::DecideStaging() {
-    if (projectSettings_.a.adjust_mode == SimultaneousMode || staged_) return;
+    if (projectSettings_.a.adjust_mode == SimultaneousMode) return;
     size_t free_b = 0, total_b = 0;
     Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
     auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
-    double need = 8.0e9 + 3.0 * (double)NumChains() * sq((double)max_unknowns_);
-    for (UINT32 k = 0; k < blockCount_; ++k)
-        if (OwnsBlock(k)) need += sq(3.0 * (double)v_parameterStationList_[k].size());   // (a rank keeps the variances of its own blocks)
-    if (need > (double)free_b) staged_ = true;
+    if (!staged_) {
+        double need = 8.0e9 + 3.0 * (double)NumChains() * sq((double)max_unknowns_);
+        for (UINT32 k = 0; k < blockCount_; ++k)
+            if (OwnsBlock(k)) need += sq(3.0 * (double)v_parameterStationList_[k].size());   // (a rank keeps the variances of its own blocks)
+        if (need > (double)free_b) staged_ = true;
+    }
+    stage_host_bytes_ = stage_device_bytes_ = 0;
+    for (block_t& B : blocks_)
+        if (!B.rig_host) B.rig_on_device = false;
+    if (!staged_) return;
+    host_available_ = HostMemoryAvailable();
+    double host = 0.8 * host_available_;
+    if (const char* e = getenv("DNAGPU_HOST_STORE_GB")) host = atof(e) * 1.0e9;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        if (!OwnsBlock(k)) continue;
+        block_t& B = blocks_[k];
+        const size_t n = v_parameterStationList_[k].size() * 3, bytes = n * (n + 1) / 2 * sizeof(double);
+        if (B.rig_host) {                        // (it exists already: counted where it is)
+            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += bytes;
+            continue;
+        }
+        if ((double)(stage_host_bytes_ + bytes) <= host) {
+            stage_host_bytes_ += bytes;
+        } else {
+            B.rig_on_device = true;
+            stage_device_bytes_ += bytes;
+        }
+    }
+}
+
+void dna_adjust::MemoryPlan(double out[8]) const {
+    out[0] = (double)stage_host_bytes_;
+    out[1] = (double)stage_device_bytes_;
+    out[2] = out[3] = 0.0;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        if (!OwnsBlock(k) || blocks_[k].keep.empty()) continue;
+        out[3] += 1.0;
+        if (blocks_[k].part_allowed) out[2] += 1.0;
+    }
+    out[4] = (double)batch_limit_;
+    out[5] = host_available_;
+    out[6] = (double)stageCopiedBytes_.load();
+    out[7] = (double)stageWaitNs_.load() / 1.0e6;
 }
 
 // lists for the condensed schedule; condensed_ok_ = false falls back to the block-level chains
@@ -527,7 +606,7 @@ void dna_adjust::PrepareCondensedBlocks() {
     double later = 8.0e9, rig = 0.0;
     for (UINT32 k = 0; k < blockCount_; ++k)
         if (OwnsBlock(k)) rig += sq(3.0 * (double)v_parameterStationList_[k].size());
-    later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? 0.0 : rig);
+    later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? (double)stage_device_bytes_ : rig);
     double budget = (double)free_b - later;
     for (UINT32 k = 0; k < blockCount_; ++k) {
         block_t& B = blocks_[k];

@@ -489,6 +489,11 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status) {
     return guarded(h, [&] { h->adj->PhasedFinish(); if (status) *status = (int)h->adj->GetStatus(); });
 }
 int dnaadj_staged(const dnaadj_handle* h) { return (h && h->adj && h->adj->IsStaged()) ? 1 : 0; }
+int dnaadj_memory_plan(const dnaadj_handle* h, double out[8]) {
+    if (!h || !h->adj || !out) return -1;
+    h->adj->MemoryPlan(out);
+    return 0;
+}
 int dnaadj_condensed_schedule(const dnaadj_handle* h) { return (h && h->adj && h->adj->CondensedSchedule()) ? 1 : 0; }
 uint64_t dnaadj_batched_block_steps(const dnaadj_handle* h) { return (h && h->adj) ? h->adj->BatchedBlockSteps() : 0; }
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block) {

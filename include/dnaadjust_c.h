@@ -159,6 +159,12 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status);               /* Valida
  * dnaadj_condensed_schedule() tells whether the prepared adjustment supports it (phased, schur_carry, no reuse_inverses /
  * scale_normals_to_unity). */
 int dnaadj_staged(const dnaadj_handle* h);     /* 1 when the prepared adjustment keeps its rigorous variances in host memory */
+/* the memory plan PrepareAdjustment made (DecideStaging / PrepareCondensedBlocks), own blocks only: out[0] bytes of staged variance matrices in
+ * page-locked host memory, out[1] bytes of them packed in HBM (past the host's memory limit), out[2] blocks that may keep their factor
+ * between the condensing step and the rigorous solve, out[3] blocks that have something to condense, out[4] members beyond the first
+ * a batch of blocks may have, out[5] bytes of host memory the process could still take when the plan was made, out[6] bytes the last adjustment copied to host memory
+ * (staged variance matrices), out[7] milliseconds it waited for those copies (FinishStagedCopies: what did not hide behind the products) */
+int dnaadj_memory_plan(const dnaadj_handle* h, double out[8]);
 int dnaadj_condensed_schedule(const dnaadj_handle* h);
 /* how many block steps of the last adjustment went through batched calls (settings.batch_blocks): condensing and rigorous solve count a
  * block once per iteration, the variance matrices once */

@@ -157,6 +157,13 @@ int dnagpu_matrix_download_packed(dnagpu_ctx* ctx, int chain, const dnagpu_matri
  * SerialiseBlockToMappedFile, dnaadjust-stage.cpp: on the path of the next block.) */
 int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap);
 int dnagpu_copies_sync(dnagpu_ctx* ctx);
+/* The staged store when host memory is the scarce side (a container whose memory limit is below the network's variance matrices, e.g.
+ * cfg4 on one GPU: 373 GB of packed triangles against a 300 GiB cgroup): the same packed lower triangle, column-major, but in a DEVICE
+ * buffer of n(n+1)/2 doubles (dnagpu_device_alloc) -- half of the full square a resident dnagpu_matrix takes.  pack: m -> dev_ap on the
+ * chain's stream (no staging buffer, no copy stream); unpack: dev_ap -> m (order n, identity padding), stream-ordered as well.
+ * (the reference's --staged-adjustment keeps one such packed image per block in its memory-mapped file, dnaadjust-stage.cpp:148-330) */
+int dnagpu_matrix_pack_device(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* dev_ap);
+int dnagpu_matrix_unpack_device(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* dev_ap, uint32_t n);
 int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dnagpu_matrix* src);
 /* raw copies of a matrix together with its attached junction estimates: np*np doubles (ld = np) followed by np
  * doubles, np = ceil(n/128)*128; dst / src may be host or device memory (this is the payload of the inter-GPU

@@ -11,6 +11,9 @@ WORKLOADS = {
     # a quarter of cfg3: 4 of its 16 strips at the same block size (n ~ 20 000, 317-station junction rows) -- the oracle's run of
     # it fits a 64 GB host (cfg3 itself needs ~80 GB and 7.4e14 flops on the CPU)
     "cfg3q": (79, 317, 66666, 4, True),
+    # four of cfg4's 128 strips at cfg4's block geometry: n ~ 27 000 unknowns per block, junction rows of 1 000 stations (J = 3 000),
+    # condensed blocks of 6 000 unknowns -- 20 Solve() calls, ~4e14 flops and ~45 GB on the CPU
+    "cfg4q": (32, 1000, 85000, 4, True),
 }
 SEED = 20260928
 ROW_STRIDE = 8          # rows kept of every sampled column

@@ -655,6 +655,45 @@ def test_staged_rigorous_variances_in_host_memory(built, orc, tmp_path, mt):
     assert c0 == c1 and p0 == p1 and np.array_equal(r0, r1) and f0 == f1 and g0 == g1
 
 
+@pytest.mark.parametrize("host_gb", ["0", "0.00002"])
+def test_staged_store_past_the_host_memory_limit(built, tmp_path, monkeypatch, host_gb):
+    """the staged store where the host's memory limit ends (DecideStaging: the container's cgroup, here DNAGPU_HOST_STORE_GB): the blocks
+    past it keep their packed variance matrix in HBM instead (block_t::rig_on_device).  "0": every block; 20 kB: the first block(s) in
+    host memory, the rest in HBM.  Identical results -- estimates, variances, statistics, the re-read result files -- and the plan
+    says where the bytes are."""
+    adjust.write_synthetic_network(str(tmp_path), "g", 16, 10, 0, 4, seed=21, x_clusters=10, y_cluster=True)
+    runs = []
+    for limit in (None, host_gb):
+        if limit is None:
+            monkeypatch.delenv("DNAGPU_HOST_STORE_GB", raising=False)
+        else:
+            monkeypatch.setenv("DNAGPU_HOST_STORE_GB", limit)
+        a, st = _device_run(str(tmp_path), "g", True, multi_thread=True, stage=True, output_folder=str(tmp_path))
+        assert st == 0 and a.lib.dnaadj_staged(a.h)
+        plan = a.memory_plan()
+        if limit is None:
+            assert plan["staged_variances_packed_in_hbm_gb"] == 0 and plan["staged_variances_host_gb"] > 0
+        elif limit == "0":
+            assert plan["staged_variances_host_gb"] == 0 and plan["staged_variances_packed_in_hbm_gb"] > 0
+        else:
+            assert plan["staged_variances_host_gb"] > 0 and plan["staged_variances_packed_in_hbm_gb"] > 0
+        a.GenerateStatistics()
+        a.SerialiseAdjustedVarianceMatrices()
+        files = (open(str(tmp_path / "g-rva.mtx"), "rb").read(), open(str(tmp_path / "g-pam.mtx"), "rb").read())
+        first = ([a.block_estimates(b) for b in range(a.blockCount())], [a.block_variances_packed(b) for b in range(a.blockCount())],
+                 a.GetChiSquared(), np.frombuffer(a.measurement_records().tobytes(), dtype=np.uint8).copy(), files)
+        a.DeSerialiseAdjustedVarianceMatrices()          # (back into the same store)
+        again = [a.block_variances_packed(b) for b in range(a.blockCount())]
+        for v, w in zip(first[1], again):
+            assert np.array_equal(v, w)
+        runs.append(first)
+        a.close()
+    (x0, v0, c0, r0, f0), (x1, v1, c1, r1, f1) = runs
+    for b in range(len(x0)):
+        assert np.array_equal(x0[b], x1[b]) and np.array_equal(v0[b], v1[b])
+    assert c0 == c1 and np.array_equal(r0, r1) and f0 == f1
+
+
 def test_bench_contract_small_workload(built):
     """bench.py end to end on the smoke-size workload: ONE JSON line with the contract's keys, roofline and check blocks"""
     import json
