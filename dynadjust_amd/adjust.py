@@ -309,7 +309,8 @@ class DnaAdjust:
         out = (C.c_double * 8)()
         if self.lib.dnaadj_memory_plan(self.h, out) != 0:
             return {}
-        return {"staged_variances_host_gb": round(out[0] / 1e9, 2), "staged_variances_packed_in_hbm_gb": round(out[1] / 1e9, 2),
+        return {"staged_variances_host_bytes": int(out[0]), "staged_variances_packed_in_hbm_bytes": int(out[1]),
+                "staged_variances_host_gb": round(out[0] / 1e9, 2), "staged_variances_packed_in_hbm_gb": round(out[1] / 1e9, 2),
                 "blocks_keeping_their_factor": int(out[2]), "blocks_condensed": int(out[3]), "batch_members_beyond_first": int(out[4]),
                 "host_memory_available_gb": round(out[5] / 1e9, 1),
                 "copied_to_host_gb": round(out[6] / 1e9, 2), "waited_for_copies_ms": round(out[7], 1)}

@@ -146,12 +146,12 @@ int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, ui
                 *dev = it->second.dev;
                 return DNAGPU_OK;
             }
-        if (cache.size() >= 512) {       // (never in an adjustment's steady state: a handful of lists per block)
-            HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
-            free_index_cache(ctx, chain);
-        }
+        // a handful of lists per block and chain step: the cap follows the block count (cfg4: 128 blocks + 128 condensed blocks walked by
+        // one chain), and a full cache is NOT flushed -- a flush in every iteration would cost more than the staging buffer it replaced --
+        // the list at hand simply takes the staging buffer below
+        const size_t cap = std::max<size_t>(512, 16 * ctx->blocks.size());
         uint32_t* d = nullptr;
-        hipError_t e = dnagpu::poison_malloc(&d, count * sizeof(uint32_t));
+        hipError_t e = cache.size() >= cap ? hipErrorOutOfMemory : dnagpu::poison_malloc(&d, count * sizeof(uint32_t));
         if (e == hipSuccess) {
             e = hipMemcpy(d, host, count * sizeof(uint32_t), hipMemcpyHostToDevice);
             if (e == hipSuccess) {

@@ -9,8 +9,10 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -22,7 +24,25 @@
 namespace dynadjust {
 namespace networkadjust {
 
+// How long a rank waits in a collective for the others before it gives up (dist_set_collective_timeout; DNAGPU_COLLECTIVE_TIMEOUT_S).
+// The reference's threads cannot lose each other -- they share an address space and unblock their queues with a sentinel
+// (dnaadjust-multi.cpp:36-58, 457-463); ranks on different GPUs can: one that dies inside a kernel never posts its side of the
+// next ncclBroadcast, and hipStreamSynchronize on the others would wait for good.
+static std::atomic<double> g_collective_timeout_s{[] {
+    const char* e = getenv("DNAGPU_COLLECTIVE_TIMEOUT_S");
+    return e && atof(e) > 0.0 ? atof(e) : 600.0;
+}()};
+void dist_set_collective_timeout(double seconds) { g_collective_timeout_s.store(seconds > 0.0 ? seconds : 600.0); }
+double dist_collective_timeout() { return g_collective_timeout_s.load(); }
+
 namespace {
+
+std::string timeout_text(const char* where) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "inter-GPU exchange: no answer from the other GPUs within %.0f s (%s): a rank has failed or left the schedule.",
+             g_collective_timeout_s.load(), where);
+    return buf;
+}
 
 void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string("inter-GPU exchange: ") + what + ": " + hipGetErrorString(e));
@@ -35,6 +55,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -72,6 +93,7 @@ RcclApi& rccl() {
         a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.CommAbort = (decltype(a.CommAbort))dlsym(a.handle, "ncclCommAbort");      // (optional: without it a timed-out communicator is only dropped)
         a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
         a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
         a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
@@ -105,7 +127,7 @@ public:
     }
     ~RcclComm() override {
         hipSetDevice(device_);
-        if (stream_) hipStreamSynchronize(stream_);
+        if (stream_ && comm_) hipStreamSynchronize(stream_);      // (an aborted communicator's stream may never drain)
         if (comm_) rccl().CommDestroy(comm_);
         if (stream_) hipStreamDestroy(stream_);
     }
@@ -138,9 +160,25 @@ public:
         nccl_check(rccl().Recv(buf, count, ncclDouble, peer, comm_, stream_), "ncclRecv");
         bytes_ += count * sizeof(double);
     }
+    // everything enqueued on the RCCL stream is complete -- or the deadline has passed: the communicator is aborted (ncclCommAbort
+    // releases the kernels that spin on a peer that will never answer) and the caller gets an exception instead of a hang; the
+    // adjustment ends with ADJUST_EXCEPTION_RAISED on every rank that is still alive
     void wait() override {
         hip_check(hipSetDevice(device_), "hipSetDevice");
-        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize (RCCL stream)");
+        if (!comm_) throw std::runtime_error("inter-GPU exchange: the communicator was aborted after a time-out");
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spin = 0;; ++spin) {
+            const hipError_t e = hipStreamQuery(stream_);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) hip_check(e, "hipStreamQuery (RCCL stream)");
+            (void)hipGetLastError();
+            if (spin > 4000) std::this_thread::sleep_for(std::chrono::microseconds(spin > 40000 ? 500 : 20));     // (first a pure poll: the usual wait is short)
+            if ((spin & 255) == 255 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > g_collective_timeout_s.load()) {
+                if (rccl().CommAbort) rccl().CommAbort(comm_);
+                comm_ = nullptr;
+                throw std::runtime_error(timeout_text("RCCL"));
+            }
+        }
     }
     void broadcast_parts_on(hipStream_t stream, int nparts, double* const* bufs, const size_t* counts) override {
         hip_check(hipSetDevice(device_), "hipSetDevice");
@@ -188,7 +226,12 @@ struct LocalGroup {
             ++generation;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return generation != g || broken; });
+            const bool in_time = cv.wait_for(lk, std::chrono::duration<double>(g_collective_timeout_s.load()), [&] { return generation != g || broken; });
+            if (!in_time) {                 // a rank never arrived: nobody waits any longer, here or in a later barrier
+                broken = true;
+                cv.notify_all();
+                throw std::runtime_error(timeout_text("ranks of one process"));
+            }
             if (broken && generation == g) throw std::runtime_error("inter-GPU exchange: another rank of the process failed");
         }
     }
@@ -392,16 +435,23 @@ void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BY
         sockaddr_in sa;
         memset(&sa, 0, sizeof(sa));
         sa.sin_family = AF_INET;
-        // the rendezvous address names the interface rank 0 listens on (the launcher's MASTER_ADDR: a loopback address keeps the
-        // exchange inside the host); only a name that does not resolve to a local address falls back to every interface
+        // the rendezvous address names the interface rank 0 listens on when it is a literal address (the launcher's
+        // MASTER_ADDR=127.0.0.1 keeps the exchange inside the host) or a name that resolves to a routable local interface.  A NAME that
+        // resolves to loopback says nothing about the other ranks' view of it -- Debian maps a node's own hostname to 127.0.1.1 in
+        // /etc/hosts while the other nodes resolve the same name to its real address -- so it listens on every interface, as does a
+        // name that does not resolve to a local address at all.
         sa.sin_addr.s_addr = htonl(INADDR_ANY);
         {
+            in_addr literal;
+            const bool is_literal = inet_pton(AF_INET, host.c_str(), &literal) == 1;
             addrinfo hints, *res = nullptr;
             memset(&hints, 0, sizeof(hints));
             hints.ai_family = AF_INET;
             hints.ai_socktype = SOCK_STREAM;
             if (getaddrinfo(host.c_str(), nullptr, &hints, &res) == 0 && res) {
-                sa.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
+                const in_addr got = ((sockaddr_in*)res->ai_addr)->sin_addr;
+                const bool loopback = (ntohl(got.s_addr) >> 24) == 127;
+                if (is_literal || !loopback) sa.sin_addr = got;
                 freeaddrinfo(res);
             }
         }

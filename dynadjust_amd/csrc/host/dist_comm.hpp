@@ -49,6 +49,11 @@ public:
     virtual uint64_t bytes_moved() const = 0;
 };
 
+// Every wait of a transport has a deadline (default 600 s; DNAGPU_COLLECTIVE_TIMEOUT_S): past it the communicator is aborted and the
+// waiting rank throws -- a rank that died cannot hang the others (the reference's sentinel, dnaadjust-multi.cpp:36-58).
+void dist_set_collective_timeout(double seconds);
+double dist_collective_timeout();
+
 // ---- RCCL -----------------------------------------------------------------------------------------------------------------
 // true when librccl could be loaded (DNAGPU_RCCL_LIB overrides the name; an already loaded librccl.so.1 -- e.g. the one a host
 // application such as PyTorch brought -- is reused)

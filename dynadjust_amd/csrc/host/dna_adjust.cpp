@@ -1395,11 +1395,18 @@ void dna_adjust::SerialiseAdjustedVarianceMatrices() {
                                   projectSettings_.a.adjust_mode != SimultaneousMode;
     const bool writer = !across_processes || DistRank() == 0;
     std::ofstream rva, pam;
-    if (writer) {
+    auto open_files = [&] {
+        if (!writer) return;
         rva.open(base + "rva.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
         pam.open(base + "pam.mtx", std::ios::out | std::ios::binary | std::ios::trunc);
         if (!rva || !pam) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): cannot create " + base + "rva.mtx / pam.mtx", 0);
-    }
+    };
+    // (across processes the per-block collection below is collective: a writer that cannot create its files must not leave the other
+    //  ranks waiting in the first block's agreement -- every rank learns of it here)
+    if (across_processes)
+        AgreeOnPhase("creating the result files", open_files);
+    else
+        open_files();
     std::vector<double> packed, fetched_prec;
     for (UINT32 b = 0; b < blockCount_; ++b) {
         if (across_processes)
@@ -1422,7 +1429,13 @@ void dna_adjust::SerialiseAdjustedVarianceMatrices() {
         }
         write_mtx_trailer(pam);
     }
-    if (writer && (!rva || !pam)) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): write failed", 0);
+    auto check_written = [&] {
+        if (writer && (!rva || !pam)) SignalExceptionAdjustment("SerialiseAdjustedVarianceMatrices(): write failed", 0);
+    };
+    if (across_processes)
+        AgreeOnPhase("writing the result files", check_written);
+    else
+        check_written();
 }
 
 // ADJ:6720-6767: the inverse of SerialiseAdjustedVarianceMatrices -- `dnaadjust --report-results` prints an earlier adjustment

@@ -52,6 +52,8 @@ struct block_timing_t {
     double form_ms = 0, invert_ms = 0, other_ms = 0;
 };
 
+void debug_stall_rank(int rank, long nth_agreement, double seconds);   // test hook (dna_adjust_dist.cpp)
+
 class dna_adjust {
     friend class DynAdjustPrinter;        // (the reference's printers are friends too, dnaadjust.hpp:214-215)
 public:
@@ -427,7 +429,8 @@ private:
     int BatchCap() const;
     bool BatchEligible(UINT32 block, int phase) const;
     std::vector<std::vector<UINT32>> BatchGroups(const std::vector<UINT32>& blocks, int phase) const;
-    void ForGroups(const std::vector<std::vector<UINT32>>& groups, const std::function<void(int, const std::vector<UINT32>&)>& step);
+    void ForGroups(std::vector<std::vector<UINT32>> groups, const std::function<void(int, const std::vector<UINT32>&)>& step);
+    void FitGroupsToBudget(std::vector<std::vector<UINT32>>& groups);
     void EnsurePartial(UINT32 block);
     bool BatchWorkspaces(int chain, const std::vector<UINT32>& blocks);
     void CondenseBatch(int chain, const std::vector<UINT32>& blocks);
@@ -438,6 +441,8 @@ private:
     void FinishVariancesBatch(int chain, const std::vector<UINT32>& blocks);
     std::vector<dnagpu_matrix*> kbatch_[DNAGPU_NUM_CHAINS];   // the kept blocks of the members of a batched rigorous solve
     std::atomic<uint64_t> batched_members_{0};
+    double batch_budget_ = 0.0, batch_unit_ = 0.0;            // bytes left for the members' workspaces of all chains together; bytes per member
+    int batch_granted_[DNAGPU_NUM_CHAINS] = {};               // members beyond the first whose workspaces chain c has been charged for
     int batch_limit_ = 0;                                     // members beyond the first that the memory budget admits (PrepareCondensedBlocks)
     void SignalExceptionAdjustment(const std::string& msg, UINT32 block);   // ADJ:10049
     void Check(int rc, UINT32 block, const char* where);

@@ -18,6 +18,7 @@
 // One process per GPU, or one process with one host thread per GPU (a.devices): the same code, rank by rank.
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <exception>
@@ -130,8 +131,23 @@ double* dna_adjust::ExchangeBuffer(size_t doubles) {
 
 // body() on this rank; afterwards all ranks learn whether any of them failed, so that nobody waits in the next collective for a
 // rank that has left (the reference's threads do the same through their shared exception pointers, dnaadjust-multi.cpp:182-190)
+// test hook (dnaadj_debug_stall_rank): rank `g_stall_rank` sleeps `g_stall_seconds` before its n-th agreement -- a rank that hangs
+// in a kernel, as far as the others can tell
+static std::atomic<int> g_stall_rank{-1};
+static std::atomic<long> g_stall_countdown{0};
+static std::atomic<double> g_stall_seconds{0.0};
+void debug_stall_rank(int rank, long nth_agreement, double seconds) {
+    g_stall_rank.store(rank);
+    g_stall_countdown.store(nth_agreement);
+    g_stall_seconds.store(seconds);
+}
+
 void dna_adjust::AgreeOnPhase(const char* phase, const std::function<void()>& body) {
     std::exception_ptr mine;
+    if (g_stall_rank.load() == DistRank() && g_stall_countdown.load() > 0 && g_stall_countdown.fetch_sub(1) == 1) {
+        g_stall_rank.store(-1);
+        std::this_thread::sleep_for(std::chrono::duration<double>(g_stall_seconds.load()));
+    }
     try {
         body();
     } catch (const std::exception& e) {

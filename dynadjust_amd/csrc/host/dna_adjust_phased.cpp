@@ -627,7 +627,13 @@ void dna_adjust::PrepareCondensedBlocks() {
         for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &kwork_[c]), 0, "PrepareAdjustment(): kept-block work matrix");
     // a.batch_blocks: every member of a batch beyond the first works in a matrix of its own (+ the panels of a diagonal block, a
     // fifth of it): as many as what is left of the budget admits
-    batch_limit_ = (int)std::max(0.0, std::min(1.0e6, budget / (1.25 * sq((double)max_unknowns_))));
+    // (the workspaces belong to a chain and the groups of a phase run on all chains at once: what the chains have been granted together
+    //  stays inside this budget -- FitGroupsToBudget; a member also has a kept-block work matrix of its own, kbatch_)
+    if (max_keep) budget -= (double)chains * sq(3.0 * (double)max_keep);           // (the kept-block work matrices just made)
+    batch_unit_ = 1.25 * sq((double)max_unknowns_) + sq(3.0 * (double)max_keep);
+    batch_budget_ = std::max(0.0, budget);
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) batch_granted_[c] = 0;
+    batch_limit_ = (int)std::max(0.0, std::min(1.0e6, batch_budget_ / batch_unit_));
 }
 
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
@@ -733,10 +739,33 @@ std::vector<std::vector<UINT32>> dna_adjust::BatchGroups(const std::vector<UINT3
     return groups;
 }
 
+// The members' workspaces belong to the chain a group runs on (group g: chain g % chains) and stay with it, and all chains work at once:
+// a group larger than what its chain holds already is charged to the one budget PrepareCondensedBlocks left (batch_budget_), and split
+// when that is spent -- the rest runs as a group of its own, later.  (Round 3 gave every chain the whole budget: NumChains() times
+// what was there, at the expense of the variance matrices allocated afterwards.)
+void dna_adjust::FitGroupsToBudget(std::vector<std::vector<UINT32>>& groups) {
+    const int chains = NumChains();
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const int c = (int)(g % (size_t)chains);
+        int extra = (int)groups[g].size() - 1;
+        if (extra <= batch_granted_[c]) continue;
+        const int can = batch_granted_[c] + (batch_unit_ > 0.0 ? (int)std::min(1.0e6, std::floor(batch_budget_ / batch_unit_)) : 0);
+        if (extra > can) {
+            std::vector<UINT32> rest(groups[g].begin() + 1 + can, groups[g].end());
+            groups[g].resize((size_t)(1 + can));
+            groups.push_back(std::move(rest));
+            extra = can;
+        }
+        batch_budget_ -= (double)(extra - batch_granted_[c]) * batch_unit_;
+        batch_granted_[c] = extra;
+    }
+}
+
 // group g runs on chain g % chains, every chain its groups in order: a batch's workspaces belong to a chain, so the large group
 // meets the same chain in every phase and every iteration
-void dna_adjust::ForGroups(const std::vector<std::vector<UINT32>>& groups, const std::function<void(int, const std::vector<UINT32>&)>& step) {
+void dna_adjust::ForGroups(std::vector<std::vector<UINT32>> groups, const std::function<void(int, const std::vector<UINT32>&)>& step) {
     const int chains = NumChains();
+    FitGroupsToBudget(groups);
     OnEveryChain([&](int c) {
         for (size_t g = (size_t)c; g < groups.size(); g += (size_t)chains) {
             if (chain_failed_ || IsCancelled()) return;

@@ -489,6 +489,8 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status) {
     return guarded(h, [&] { h->adj->PhasedFinish(); if (status) *status = (int)h->adj->GetStatus(); });
 }
 int dnaadj_staged(const dnaadj_handle* h) { return (h && h->adj && h->adj->IsStaged()) ? 1 : 0; }
+void dnaadj_dist_set_timeout(double seconds) { dynadjust::networkadjust::dist_set_collective_timeout(seconds); }
+void dnaadj_debug_stall_rank(int rank, long nth_agreement, double seconds) { dynadjust::networkadjust::debug_stall_rank(rank, nth_agreement, seconds); }
 int dnaadj_memory_plan(const dnaadj_handle* h, double out[8]) {
     if (!h || !h->adj || !out) return -1;
     h->adj->MemoryPlan(out);

@@ -166,6 +166,12 @@ int dnaadj_staged(const dnaadj_handle* h);     /* 1 when the prepared adjustment
  * (staged variance matrices), out[7] milliseconds it waited for those copies (FinishStagedCopies: what did not hide behind the products) */
 int dnaadj_memory_plan(const dnaadj_handle* h, double out[8]);
 int dnaadj_condensed_schedule(const dnaadj_handle* h);
+/* Across GPUs every wait for the other ranks has a deadline (default 600 s, DNAGPU_COLLECTIVE_TIMEOUT_S): past it the communicator is
+ * aborted (ncclCommAbort) and AdjustNetwork() ends with ADJUST_EXCEPTION_RAISED on the ranks that are still alive -- the reference's
+ * threads unblock each other with a sentinel (dnaadjust-multi.cpp:36-58, 182-190).  Process-wide. */
+void dnaadj_dist_set_timeout(double seconds);
+/* test hook: rank `rank` sleeps `seconds` before its n-th agreement with the others (a rank hanging in a kernel, seen from outside) */
+void dnaadj_debug_stall_rank(int rank, long nth_agreement, double seconds);
 /* how many block steps of the last adjustment went through batched calls (settings.batch_blocks): condensing and rigorous solve count a
  * block once per iteration, the variance matrices once */
 uint64_t dnaadj_batched_block_steps(const dnaadj_handle* h);

@@ -1,4 +1,4 @@
-"""A dense numpy implementation of the block-step interface of dynadjust_amd/parallel.py, used to exercise the
+"""A dense numpy implementation of the block-step interface of tests/parallel_harness.py, used to exercise the
 multi-rank schedule and its messaging on CPU (gloo).  Test infrastructure only: it restates the same steps as
 dna_adjust::Phased{Forward,Reverse,Combine,Finalise}Block with numpy.linalg on small networks."""
 import numpy as np

@@ -217,7 +217,7 @@ def test_multi_thread_mode_matches_oracle(built, orc, tmp_path):
 
 @pytest.mark.parametrize("schur", [True, False])
 def test_orchestrator_single_rank_equals_facade(built, tmp_path, schur):
-    """dynadjust_amd/parallel.run_phased on one rank drives the same per-block steps as AdjustPhased: the condensed
+    """tests/parallel_harness.run_phased on one rank drives the same per-block steps as AdjustPhased: the condensed
     schedule (a.schur_carry, default) and the reference's"""
     from tests import parallel_harness as parallel
     import torch
@@ -672,11 +672,11 @@ def test_staged_store_past_the_host_memory_limit(built, tmp_path, monkeypatch, h
         assert st == 0 and a.lib.dnaadj_staged(a.h)
         plan = a.memory_plan()
         if limit is None:
-            assert plan["staged_variances_packed_in_hbm_gb"] == 0 and plan["staged_variances_host_gb"] > 0
+            assert plan["staged_variances_packed_in_hbm_bytes"] == 0 and plan["staged_variances_host_bytes"] > 0
         elif limit == "0":
-            assert plan["staged_variances_host_gb"] == 0 and plan["staged_variances_packed_in_hbm_gb"] > 0
+            assert plan["staged_variances_host_bytes"] == 0 and plan["staged_variances_packed_in_hbm_bytes"] > 0
         else:
-            assert plan["staged_variances_host_gb"] > 0 and plan["staged_variances_packed_in_hbm_gb"] > 0
+            assert plan["staged_variances_host_bytes"] > 0 and plan["staged_variances_packed_in_hbm_bytes"] > 0
         a.GenerateStatistics()
         a.SerialiseAdjustedVarianceMatrices()
         files = (open(str(tmp_path / "g-rva.mtx"), "rb").read(), open(str(tmp_path / "g-pam.mtx"), "rb").read())

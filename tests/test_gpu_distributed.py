@@ -186,6 +186,38 @@ def test_a_failure_on_one_rank_reaches_every_rank(built, orc, tmp_path):
     o.close()
 
 
+@pytest.mark.parametrize("schur", [True, False])
+def test_a_rank_that_never_answers_cannot_hang_the_others(built, orc, tmp_path, schur):
+    """one of three ranks stops answering in the middle of an iteration (test hook: it sleeps far longer than the deadline before one of
+    its agreements -- from outside the same as a rank hanging in a kernel).  The others must not wait for it for good: their collective
+    times out (dnaadj_dist_set_timeout), AdjustNetwork() ends with an exception naming the cause, within the deadline plus the late
+    rank's sleep, and the late rank itself finds the exchange abandoned.  (The reference's threads unblock each other with a sentinel,
+    dnaadjust-multi.cpp:36-58, 457-463.)  Afterwards a fresh adjustment of the same network runs through."""
+    import time
+    adjust.write_synthetic_network(str(tmp_path), "n", 24, 8, 0, 4, seed=2)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    a = _run(str(tmp_path), "n", devices=[0, 0, 0], dist_transport="local", schur_carry=schur)
+    built.dnaadj_dist_set_timeout(1.0)
+    built.dnaadj_debug_stall_rank(1, 3, 4.0)
+    t0 = time.perf_counter()
+    try:
+        with pytest.raises(adjust.NetAdjustException) as e:
+            a.AdjustNetworkDistributed()
+        dt = time.perf_counter() - t0
+        assert "no answer from the other GPUs" in str(e.value) or "another rank" in str(e.value) or "another GPU" in str(e.value), str(e.value)
+        assert dt < 30.0, dt
+    finally:
+        built.dnaadj_debug_stall_rank(-1, 0, 0.0)
+        built.dnaadj_dist_set_timeout(600.0)
+    a.close()
+    a = _run(str(tmp_path), "n", devices=[0, 0, 0], dist_transport="local", schur_carry=schur)
+    assert a.AdjustNetworkDistributed() == ost
+    for k in range(4):
+        assert np.abs(a.block_estimates(k) - o.block_estimates(k)).max() < TOL_X
+    a.close()
+    o.close()
+
+
 @pytest.mark.parametrize("schur,who", [(True, 1), (True, None), (False, 2)])
 def test_a_cancellation_is_agreed_across_the_ranks(built, orc, tmp_path, schur, who):
     """CancelAdjustment() while three ranks iterate.  `who` = the one rank that hears of it (the way a signal reaches one process of a

@@ -1,5 +1,11 @@
-"""The N > 1 path on CPU: dynadjust_amd/parallel.py (schedule + junction exchange + coordinate all_reduce) under gloo
-with world sizes 2 and 3 and a numpy block backend, against the CPU oracle's single-process phased adjustment."""
+"""The N > 1 SCHEDULE on CPU: tests/parallel_harness.py (round 1's Python orchestrator over the per-block C entry points: ownership,
+junction / condensed-block exchange, coordinate all_reduce) driving tests/numpy_backend.py (a numpy restatement of the block steps)
+under gloo with world sizes 2 and 3, against the CPU oracle's single-process phased adjustment.
+
+What this pins: the exchange pattern and the algebra of the one- and two-level condensed chains across ranks.  What it does NOT run: the
+product's C++ driver (dna_adjust::AdjustPhasedDistributed, host/dna_adjust_dist.cpp) -- that needs a device; its schedule (block owners,
+run boundaries, message sizes) is pinned device-free by tests/test_dist_plan.py through dnaadj_dist_plan, and its arithmetic on the
+GPU by tests/test_gpu_distributed.py (ranks as threads) and tests/test_gpu_multi.py (RCCL, one rank per GPU)."""
 import os
 import socket
 import sys

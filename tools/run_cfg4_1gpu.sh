@@ -19,8 +19,8 @@ while kill -0 $pid 2>/dev/null; do
     [ "$cur" -gt "$peak" ] && peak=$cur
     if [ "$limit" -gt 0 ] && [ "$cur" -gt $((limit - 20000000000)) ]; then
         echo "memory guard: $cur bytes in use of $limit -- ending the run" >> $out/$tag.err
-        kill -9 $pid
         pkill -9 -P $pid
+        kill -9 $pid
         break
     fi
     sleep 0.5
