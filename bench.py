@@ -135,6 +135,99 @@ def _cpu_baseline_role(role, folder, lapack_path, threads, cores):
     o.close()
 
 
+def _cpu_solve_role(folder, lapack_path, threads, cores, n, idx):
+    """One worker of the combine pool (dnaadjust-multi.cpp:644-710): a Solve()-sized dpotrf + dpotri of order n on `threads` LAPACK threads,
+    pinned to `cores`, started together with the others.  Prints one JSON line."""
+    import numpy as np
+    from tests import oracle
+    if cores:
+        try:
+            os.sched_setaffinity(0, set(cores))
+        except OSError:
+            pass
+    lib = oracle.load()
+    oracle.use_lapack(lapack_path)
+    lib.orc_set_threads(threads)
+    rng = np.random.default_rng(idx)
+    A = rng.standard_normal((n, 32))
+    M = np.asfortranarray(A @ A.T)
+    M[np.diag_indices(n)] += float(n)
+    del A
+    open(os.path.join(folder, f"ready.solve{idx}"), "w").close()
+    t_wait = time.perf_counter()
+    while not os.path.exists(os.path.join(folder, "go.solve")):
+        time.sleep(0.005)
+        if time.perf_counter() - t_wait > 600:
+            raise RuntimeError("the pool never started")
+    t0 = time.perf_counter()
+    lib.orc_potrf_lower(n, M.ctypes.data_as(oracle.f64p), n)
+    lib.orc_potri_lower(n, M.ctypes.data_as(oracle.f64p), n)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"role": "solve", "seconds": dt, "t_start": t0, "t_end": t0 + dt}), flush=True)
+
+
+def _cpu_combine_pool(folder, lapack_path, quota_threads, n, pool):
+    """The reference's combine pool as a throughput bound: `pool` Solve()-sized inversions (order n) side by side, quota_threads / pool
+    LAPACK threads each, as pinned processes -- what K concurrent combination solves can deliver on this host at best (an upper bound
+    on any schedule's reference-equivalent rate, the forward and reverse chains' dependencies ignored).  Returns TFLOP/s (sum n^3 / wall)."""
+    import subprocess
+    t = max(1, quota_threads // pool)
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    for f in os.listdir(folder):
+        if f.startswith("ready.solve") or f == "go.solve":
+            os.remove(os.path.join(folder, f))
+    env = dict(os.environ, MKL_THREADING_LAYER="GNU", OPENBLAS_NUM_THREADS=str(t), OMP_NUM_THREADS=str(t))
+    procs = []
+    for i in range(pool):
+        cores = avail[i * t:(i + 1) * t] if len(avail) >= pool * t else None
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-role", "solve", "--cpu-args", json.dumps([folder, lapack_path, t, cores, n, i])]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.perf_counter()
+    while not all(os.path.exists(os.path.join(folder, f"ready.solve{i}")) for i in range(pool)):
+        if any(p.poll() is not None for p in procs) or time.perf_counter() - t0 > 600:
+            for p in procs:
+                p.kill()
+            raise RuntimeError("a pool worker did not start: " + " | ".join((p.stderr.read() or "")[-200:] for p in procs if p.poll() is not None))
+        time.sleep(0.01)
+    open(os.path.join(folder, "go.solve"), "w").close()
+    recs = []
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        line = [l for l in out.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            raise RuntimeError("a pool worker failed: " + (err or out)[-300:])
+        recs.append(json.loads(line[-1]))
+    wall = max(r["t_end"] for r in recs) - min(r["t_start"] for r in recs)
+    return pool * float(n) ** 3 / wall / 1e12
+
+
+def _cpu_limits():
+    """what the host gives this process: visible cores, the affinity mask, the container's CPU quota (cgroup v2 cpu.max / v1 cfs)"""
+    out = {"cores_visible": os.cpu_count(), "affinity": None, "cgroup_cpu_max": None, "quota_cores": None}
+    try:
+        out["affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        out["cgroup_cpu_max"] = " ".join(txt)
+        if txt[0] != "max":
+            out["quota_cores"] = float(txt[0]) / float(txt[1])
+    except (OSError, IndexError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cgroup_cpu_max"] = f"{int(q)} {int(p)}"
+            if q > 0:
+                out["quota_cores"] = q / p
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def _cpu_multi_thread_by_processes(folder, lapack_path, threads):
     """forward pass || reverse + combination pass as two pinned processes with half of the tuned LAPACK threads each (a LAPACK without
     per-thread control -- OpenBLAS -- cannot be split inside one process).  Returns (wall seconds, sum n^3, Solve() calls, note)."""
@@ -310,27 +403,50 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
         note = (f"multi-thread schedule measured slower ({n3 / dt / 1e12:.3f} TFLOP/s: {mt_note}) than " if dt else mt_note) + f"sequential passes on {threads} LAPACK threads"
         schedule, dt, n3, solves = "sequential", dt_seq, n3_seq, s_seq
     oracle.use_lapack(None)
-    cpu_flops = n3 / dt
-    projected = sum_n3_per_step / cpu_flops
+    # the combine pool (dnaadjust-multi.cpp:644-710: the combination solves of different blocks on hardware_concurrency() workers) as a
+    # throughput bound: K Solve()-sized inversions at once, K x t = the tuned thread count; an upper bound on every schedule of the
+    # reference on this host, so the best of the three is what the GPU is compared with
+    limits = _cpu_limits()
     n_blk = int(round((n3_seq / max(1, s_seq)) ** (1.0 / 3.0)))
+    pool_rates, pool_note = {}, None
+    if phased and path and threads >= 4 and not os.environ.get("DNAGPU_CPU_NO_POOL"):
+        for pool in (2, 4):
+            if threads // pool < 2:
+                continue
+            try:
+                pool_rates[f"{pool} x {threads // pool} threads"] = round(_cpu_combine_pool(d, path, threads, n_blk, pool), 3)
+            except Exception as e:      # noqa: BLE001
+                pool_note = f"combine pool of {pool} not measured ({e})"
+                break
+    strip_schedule, cpu_flops, pool_text = schedule, n3 / dt, ""
+    if pool_rates:
+        best_pool = max(pool_rates, key=pool_rates.get)
+        if pool_rates[best_pool] * 1e12 > cpu_flops:
+            schedule = "combine pool (throughput bound)"
+            cpu_flops = pool_rates[best_pool] * 1e12
+            pool_text = (f"; `value` prices the workload at the combine pool's throughput bound ({best_pool}: concurrent Solve()-sized dpotrf + dpotri of order "
+                         f"{n_blk} as pinned processes, the chains' dependencies ignored: {cpu_flops / 1e12:.3f} TFLOP/s), which beat the strip's schedules")
+    projected = sum_n3_per_step / cpu_flops
     return {
         "value": stations / projected,
         "unit": "stations/s",
         "cores": threads,
         "cores_visible": cores,
+        "host_limits": limits,
         "kind": "port",
         "schedule": schedule,
         "lapack": f"{name}, {threads} threads (best of the dpotrf+dpotri probe at n = {probe_n})",
         "lapack_probe_tflops": probes,
         "probe_tflops_at_choice": None if probe_rate is None else probe_rate / 1e12,
         "sample": (f"one iteration of the CPU restatement over a {nb_s}-block, {info['stations']}-station strip of the workload's grid at the workload's "
-                   f"block size (n ~ {n_blk} per Solve(), {solves} Solve() calls, sum n^3 = {n3:.3e}) in {dt:.2f} s = {cpu_flops / 1e12:.3f} TFLOP/s "
-                   f"reference-equivalent, schedule: {schedule} ({note}); sequential: {seq_rate / 1e12:.3f} TFLOP/s; extrapolated linearly in sum n^3 "
+                   f"block size (n ~ {n_blk} per Solve(), {solves} Solve() calls, sum n^3 = {n3:.3e}) in {dt:.2f} s = {n3 / dt / 1e12:.3f} TFLOP/s "
+                   f"reference-equivalent, schedule: {strip_schedule} ({note}); sequential: {seq_rate / 1e12:.3f} TFLOP/s{pool_text}; extrapolated linearly in sum n^3 "
                    f"to the workload's {solves_per_step} Solve() calls per step"),
         "seconds_sample": dt,
         "tflops_reference_equivalent": cpu_flops / 1e12,
         "tflops_sequential_schedule": seq_rate / 1e12,
         "tflops_multi_thread_schedule": None if mt_rate is None else mt_rate / 1e12,
+        "tflops_combine_pool": pool_rates or pool_note,
         "multi_thread_schedule": mt_note or None,
         # the same restatement run over the WHOLE workload once (committed record: not re-run here, it takes minutes to hours)
         "full_run_record": _full_run_record(workload),
@@ -377,10 +493,14 @@ def _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, per_rank, ow
                    "variance_propagation_in_step": bool(args.variance_propagation), "blocks_per_rank": [owners.count(r) for r in range(world)]},
         "cholesky_tflops": (alg / 1e12) / (dt / args.steps),
         "reference_equivalent_tflops": (ref / 1e12) / (dt / args.steps),
+        # `achieved` / `frac`: the whole job's algorithmic flops over the whole step, per GPU (what the driver's clock supports: exchange, chains and
+        # imbalance included); `*_gemm_busy`: the busiest rank's flops over the HIP-event time of its GEMM launches (the kernel's own rate)
         "roofline": {"kernel": "gemm_f64_dma_kernel (v_mfma_f64_16x16x4_f64 tile GEMM behind potrf/trtri/lauum)", "bound": "mfma",
-                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                     "achieved": (alg / 1e12) / (dt / args.steps) / world, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+                     "frac": (alg / 1e12) / (dt / args.steps) / world / FP64_MFMA_PEAK_TFLOPS,
+                     "achieved_gemm_busy": achieved, "frac_gemm_busy": achieved / FP64_MFMA_PEAK_TFLOPS,
                      "traffic": None, "rank": busiest, "gemm_ms_per_step": gemm_ms / args.steps,
-                     "note": "busiest rank: algorithmic flops of its steps / HIP-event time of its GEMM launches"},
+                     "note": "frac: whole job, end to end, per GPU; *_gemm_busy: busiest rank, algorithmic flops of its steps / HIP-event time of its GEMM launches"},
         # host-side time of the last timed step, per rank: the exchange steps (broadcasts, all-reduce, their waits) and the chains on
         # the condensed blocks -- the serial remainder of the condensed schedule
         "exchange": {"exchange_ms_per_step": [v["exchange_ms"] for v in per_rank], "chain_phase_ms_per_step": [v["chain_ms"] for v in per_rank],
@@ -400,6 +520,30 @@ def _check_block(a, folder, name, stations):
                 "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()]}
     except Exception as e:                       # diagnostic only
         return {"error": str(e)}
+
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_KINDS = ["unpermute_kernel (completed inverse back to the block's unknown order: np^2 read + written)",
+             "init_ordered + form_normals_ordered (normals formed in the elimination's order: lower triangle written once)",
+             "gemv_* substitution from the kept factor (factor read twice per solve)",
+             "symv_* corrections = N^-1 rhs (n x np read once)",
+             "pack_lower (staged store: n^2/2 read + written)"]
+
+
+def _hbm_roofline(lib, ctx):
+    """HBM-bound kernels of the step, measured in the one-chain step (nothing else on the device): algorithmic bytes per launch /
+    HIP-event duration on the launch stream, against the 8 TB/s HBM3E peak (dnagpu_profile_hbm_get)"""
+    b, ms, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_uint64 * 8)()
+    if lib.dnagpu_profile_hbm_get(ctx, b, ms, n, 1) != 0:
+        return None
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "measured_in": "the one-chain step (HIP events on the launch stream)", "kernels": []}
+    for k, name in enumerate(HBM_KINDS):
+        if n[k] == 0 or ms[k] <= 0:
+            continue
+        gbs = b[k] / 1e9 / (ms[k] / 1e3)
+        out["kernels"].append({"kernel": name, "launches": int(n[k]), "algorithmic_gb_per_launch": round(b[k] / 1e9 / n[k], 3),
+                               "avg_ms": round(ms[k] / n[k], 4), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 3)})
+    return out
 
 
 def _hbm(lib, ctx):
@@ -619,6 +763,9 @@ def main():
     ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-role", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_role == "solve":
+        _cpu_solve_role(*json.loads(args.cpu_args))
+        return
     if args.cpu_baseline_role:
         _cpu_baseline_role(args.cpu_baseline_role, *json.loads(args.cpu_args))
         return
@@ -758,7 +905,11 @@ def main():
     # dpotri, the reference-equivalent count of a Solve()) and n_i^3/3 + n_i^2 n_j + n_i n_j^2 + n_j^3 per carry-only step
     # done by elimination, summed over the step, divided by the HIP-event duration of the gemm launches of the step
     gemm_ms_per_step = prof_ms.value / args.steps
-    achieved = (alg / 1e12) / (gemm_ms_per_step / 1e3) if gemm_ms_per_step > 0 else 0.0
+    gemm_busy = (alg / 1e12) / (gemm_ms_per_step / 1e3) if gemm_ms_per_step > 0 else 0.0
+    # `achieved` / `frac`: the step's algorithmic flops over the WHOLE step (the driver's clock supports it); `*_gemm_busy`: the same flops
+    # over the time during which a GEMM was executing (union over the chains' streams, HIP events) -- the kernel's own rate, leaves and
+    # launch gaps left out
+    achieved = (alg / 1e12) / (ms_per_step / 1e3)
     out = {
         "metric": "stations adjusted/sec + Cholesky TFLOP/s, phased adjustment, 1/2/4/8 MI355X",
         "value": value,
@@ -809,10 +960,9 @@ def main():
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            # `achieved` prices the time during which a GEMM was executing (union over the chains' streams) and so leaves out exactly the
-            # latency-bound remainder (leaves, launch gaps); the same flops over the WHOLE step, and the committed one-chain run
-            # (nothing overlapped: profiles/), say what that remainder costs
-            "frac_end_to_end": (alg / 1e12) / (ms_per_step / 1e3) / FP64_MFMA_PEAK_TFLOPS,
+            "achieved_gemm_busy": gemm_busy,
+            "frac_gemm_busy": gemm_busy / FP64_MFMA_PEAK_TFLOPS,
+            "frac_end_to_end": achieved / FP64_MFMA_PEAK_TFLOPS,      # (= frac; the name earlier rounds used)
             "frac_one_chain": None,           # filled below: the same step on ONE chain, timed in this run
             "traffic": traffic_from_profile(args.workload)[0],
             "traffic_source": traffic_from_profile(args.workload)[1],
@@ -847,7 +997,9 @@ def main():
             p1 = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode, multi_thread=False, device=local_rank, reuse_inverses=p.reuse_inverses,
                                         schur_carry=p.schur_carry, keep_factors=p.keep_factors, defer_variances=p.defer_variances, stage=p.stage)
             a1.PrepareAdjustment(p1)
+            ctx1 = a1.device_context()
             for timed in (False, True):
+                lib.dnagpu_profile_hbm_enable(ctx1, 1 if timed else 0)
                 a1.ResetAdjustment()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -860,6 +1012,7 @@ def main():
                 dt1 = time.perf_counter() - t1
             out["roofline"]["frac_one_chain"] = (a1.algorithmic_flops() / 1e12) / dt1 / FP64_MFMA_PEAK_TFLOPS
             out["roofline"]["ms_per_step_one_chain"] = dt1 * 1e3
+            out["roofline_hbm"] = _hbm_roofline(lib, ctx1)
             a1.close()
         except Exception as e:                   # diagnostic only
             out["roofline"]["frac_one_chain_error"] = str(e)

@@ -133,6 +133,17 @@ struct dnagpu_ctx {
     dnagpu_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
     bool fuse = false;             // fused small launches (dnagpu_set_fused_launches; DNAGPU_FUSE=1 at creation)
+    // dnagpu_profile_hbm_*: HIP events around every launch of the large HBM-bound kernels (kinds: dnagpu.h DNAGPU_HBM_*), per chain
+    struct HbmRec {
+        int kind;
+        double bytes;
+        hipEvent_t e0, e1;
+    };
+    bool hbm_profile = false;
+    std::vector<HbmRec> hbm_recs[DNAGPU_NUM_CHAINS];
+    std::vector<hipEvent_t> hbm_free[DNAGPU_NUM_CHAINS];
+    double hbm_bytes[8] = {}, hbm_ms[8] = {};
+    uint64_t hbm_count[8] = {};
     bool profile = false;
     double profile_ms_acc = 0.0;   // union length of the timed GEMM runs collected so far (dnagpu_profile_get)
 };

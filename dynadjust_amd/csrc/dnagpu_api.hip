@@ -125,6 +125,42 @@ int ensure_scr_f64(dnagpu_ctx* ctx, int chain, size_t count) {
     return DNAGPU_OK;
 }
 
+// ---- HBM-side roofline: events around the launches of the large bandwidth-bound kernels (dnagpu_profile_hbm_enable) -------------------
+// The bracketed duration is the kernel's own only when nothing else runs on the device: bench.py collects these in its one-chain step.
+struct HbmTimed {
+    dnagpu_ctx* ctx;
+    int chain;
+    bool on;
+    dnagpu_ctx::HbmRec rec;
+    HbmTimed(dnagpu_ctx* c, int ch, int kind, double bytes) : ctx(c), chain(ch), on(c->hbm_profile && bytes >= 1.0e6) {
+        if (!on) return;
+        rec.kind = kind;
+        rec.bytes = bytes;
+        rec.e0 = rec.e1 = nullptr;
+        auto& fr = ctx->hbm_free[chain];
+        for (hipEvent_t* e : {&rec.e0, &rec.e1}) {
+            if (!fr.empty()) {
+                *e = fr.back();
+                fr.pop_back();
+            } else if (hipEventCreate(e) != hipSuccess) {
+                (void)hipGetLastError();
+                *e = nullptr;
+            }
+        }
+        if (!rec.e0 || !rec.e1) {
+            on = false;
+            return;
+        }
+        gemm_profile_close(ctx->ws[chain]);
+        (void)hipEventRecord(rec.e0, ctx->stream[chain]);
+    }
+    ~HbmTimed() {
+        if (!on) return;
+        (void)hipEventRecord(rec.e1, ctx->stream[chain]);
+        ctx->hbm_recs[chain].push_back(rec);
+    }
+};
+
 void free_index_cache(dnagpu_ctx* ctx, int chain) {
     for (auto& kv : ctx->idx_cache[chain])
         if (kv.second.dev) hipFree(kv.second.dev);
@@ -502,6 +538,41 @@ int dnagpu_profile_reset(dnagpu_ctx* ctx) {
     ctx->profile_ms_acc = 0.0;
     return DNAGPU_OK;
 }
+int dnagpu_profile_hbm_enable(dnagpu_ctx* ctx, int on) {
+    CHK_CTX();
+    ctx->hbm_profile = on != 0;
+    return DNAGPU_OK;
+}
+
+int dnagpu_profile_hbm_get(dnagpu_ctx* ctx, double bytes[8], double ms[8], uint64_t count[8], int reset) {
+    CHK_CTX();
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        if (ctx->hbm_recs[c].empty()) continue;
+        HIPCHK(hipStreamSynchronize(ctx->stream[c]));
+        for (const dnagpu_ctx::HbmRec& r : ctx->hbm_recs[c]) {
+            float dt = 0.f;
+            if (hipEventElapsedTime(&dt, r.e0, r.e1) == hipSuccess && r.kind >= 0 && r.kind < 8) {
+                ctx->hbm_bytes[r.kind] += r.bytes;
+                ctx->hbm_ms[r.kind] += dt;
+                ctx->hbm_count[r.kind]++;
+            }
+            ctx->hbm_free[c].push_back(r.e0);
+            ctx->hbm_free[c].push_back(r.e1);
+        }
+        ctx->hbm_recs[c].clear();
+    }
+    for (int k = 0; k < 8; ++k) {
+        if (bytes) bytes[k] = ctx->hbm_bytes[k];
+        if (ms) ms[k] = ctx->hbm_ms[k];
+        if (count) count[k] = ctx->hbm_count[k];
+        if (reset) {
+            ctx->hbm_bytes[k] = ctx->hbm_ms[k] = 0.0;
+            ctx->hbm_count[k] = 0;
+        }
+    }
+    return DNAGPU_OK;
+}
+
 int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uint64_t* launches) {
     CHK_CTX();
     // gemm_ms = length of the UNION of the timed GEMM runs of all chains: with one chain this is the plain sum of
@@ -666,7 +737,10 @@ int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu
     }
     // the previous copy out of this buffer must have left before it is packed again
     if (ctx->copy_pending[chain]) HIPCHK(hipStreamWaitEvent(ctx->stream[chain], ctx->copy_done[chain], 0));
-    launch_pack_lower(m->F, ctx->stage_buf[chain], m->n, m->np, ctx->stream[chain]);
+    {
+        HbmTimed timed(ctx, chain, DNAGPU_HBM_PACK, 8.0 * (double)m->n * m->n);
+        launch_pack_lower(m->F, ctx->stage_buf[chain], m->n, m->np, ctx->stream[chain]);
+    }
     HIPCHK(hipEventRecord(ctx->pack_done[chain], ctx->stream[chain]));
     HIPCHK(hipStreamWaitEvent(ctx->copy_stream[chain], ctx->pack_done[chain], 0));
     HIPCHK(hipMemcpyAsync(ap, ctx->stage_buf[chain], cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream[chain]));
@@ -679,6 +753,7 @@ int dnagpu_matrix_pack_device(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m
     CHK_CTX();
     CHK_CHAIN();
     if (!m || (!dev_ap && m->n)) return fail(ctx, DNAGPU_EINVAL, "matrix_pack_device: bad arguments");
+    HbmTimed timed(ctx, chain, DNAGPU_HBM_PACK, 8.0 * (double)m->n * m->n);
     if (m->n) launch_pack_lower(m->F, dev_ap, m->n, m->np, ctx->stream[chain]);
     return DNAGPU_OK;
 }
@@ -1499,6 +1574,7 @@ int dnagpu_solve_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, const dna
     if (!m->n) return DNAGPU_OK;
     int rc = ensure_symv(ctx, chain, m->np);
     if (rc) return rc;
+    HbmTimed timed(ctx, chain, DNAGPU_HBM_SYMV, 8.0 * (double)m->n * m->np);
     launch_symv(m->F, b->rhs[chain], b->corr[chain], ctx->symv_part[chain], m->n, m->np, SYMV_CHUNKS, ctx->stream[chain]);
     return DNAGPU_OK;
 }
@@ -1653,6 +1729,7 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
                 if (!rs) rs = stage_f64(ctx, chain, form->con_w9, form->n_con * 9, &dw);
                 if (rs) return rs;
             }
+            HbmTimed timed(ctx, chain, DNAGPU_HBM_FORM_ORDERED, 4.0 * (double)npp * npp);
             launch_form_ordered(F, npp, npp, map_dev, spos_dev, b->pair_row, b->pair_col, b->pair_off, b->pair_ent, b->Wblk, b->n_pairs, b->n_wblk,
                                 (uint32_t)chain * (b->n_tblk + b->n_dsblk), dstn, dw, (uint32_t)form->n_con, b->rhs[chain], nip + nj, st);
         } else {
@@ -1819,7 +1896,10 @@ int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, cons
     inv->n = pf->n;
     inv->np = pad128(pf->n);
     launch_init_padding(inv->F, inv->n, inv->np, st);      // (the un-permutation writes every element of the n x n part)
-    launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
+    {
+        HbmTimed t(ctx, chain, DNAGPU_HBM_UNPERMUTE, 16.0 * (double)inv->np * inv->np);
+        launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
+    }
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
@@ -1863,6 +1943,8 @@ int dnagpu_partial_solve(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_
     // corrections = N^-1 rhs = P (X^T (X (P^T rhs))): two triangular matrix-vector products in the elimination's order
     double* rp = ws.svec;                                           // P^T rhs, then the result
     double* y = ctx->symv_part[chain] + (size_t)SYMV_CHUNKS * pf->npp - pf->npp;     // (the last chunk row of the partial sums: free once they are added up)
+    // (HBM side: the factor -- lower block triangle, npp^2 / 2 doubles -- is read twice)
+    HbmTimed timed(ctx, chain, DNAGPU_HBM_SUBSTITUTION, 8.0 * (double)pf->npp * pf->npp);
     launch_gather_map(b->rhs[chain], pf->map, pf->npp, rp, st);
     if (pf->spine) {
         // blocked substitution with the block factor: forward  y_b = X_bb v_b,  v_below -= L_(below, b) y_b;  the kept block
@@ -1916,7 +1998,10 @@ int dnagpu_partial_finish(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, dnagpu
     inv->n = pf->n;
     inv->np = pad128(pf->n);
     launch_init_padding(inv->F, inv->n, inv->np, st);      // (the un-permutation writes every element of the n x n part)
-    launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
+    {
+        HbmTimed t(ctx, chain, DNAGPU_HBM_UNPERMUTE, 16.0 * (double)inv->np * inv->np);
+        launch_unpermute(F, pf->npp, pf->npp, pf->map, inv->F, inv->np, st);
+    }
     // (nothing here factors anything: `info` is put to "no failure" for check_info, which then reports enqueue / launch errors only)
     HIPCHK(hipMemsetAsync(ws.info, 0x7f, sizeof(int), st));
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2157,8 +2242,11 @@ int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const u
             if (rc) return rc;
         }
         Block* B = blk[b];
-        launch_form_ordered(F, npp, npp, map_dev, spos_dev, B->pair_row, B->pair_col, B->pair_off, B->pair_ent, B->Wblk, B->n_pairs, B->n_wblk,
-                            (uint32_t)chain * (B->n_tblk + B->n_dsblk), dstn, dw, (uint32_t)n_con[b], B->rhs[chain], nip + nj, st);
+        {
+            HbmTimed timed(ctx, chain, DNAGPU_HBM_FORM_ORDERED, 4.0 * (double)npp * npp);
+            launch_form_ordered(F, npp, npp, map_dev, spos_dev, B->pair_row, B->pair_col, B->pair_off, B->pair_ent, B->Wblk, B->n_pairs, B->n_wblk,
+                                (uint32_t)chain * (B->n_tblk + B->n_dsblk), dstn, dw, (uint32_t)n_con[b], B->rhs[chain], nip + nj, st);
+        }
         HIPCHK(hipMemcpyAsync(kp->map, map_dev, (size_t)npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         if (n_con[b]) HIPCHK(hipStreamSynchronize(st));     // (the staging buffers are the chain's: the next member's lists go through them)
     }
@@ -2242,7 +2330,10 @@ int dnagpu_partial_finish_batched(dnagpu_ctx* ctx, int chain, int nb, dnagpu_par
         inv[b]->n = pf[b]->n;
         inv[b]->np = pad128(pf[b]->n);
         launch_init_padding(inv[b]->F, inv[b]->n, inv[b]->np, st);
-        launch_unpermute(F, npp, npp, pf[b]->map, inv[b]->F, inv[b]->np, st);
+        {
+            HbmTimed t(ctx, chain, DNAGPU_HBM_UNPERMUTE, 16.0 * (double)inv[b]->np * inv[b]->np);
+            launch_unpermute(F, npp, npp, pf[b]->map, inv[b]->F, inv[b]->np, st);
+        }
     }
     HIPCHK(hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), st));
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -88,6 +88,20 @@ int dnagpu_multiply_sym_packed(dnagpu_ctx* ctx, const double* ap, const double* 
  * consecutive GEMM launches */
 int dnagpu_profile_enable(dnagpu_ctx* ctx, int on);
 int dnagpu_profile_reset(dnagpu_ctx* ctx);
+/* HBM-side roofline of the large bandwidth-bound kernels: with the switch on, every launch of one of the kinds below that moves at
+ * least 1 MB is bracketed by HIP events on its chain's stream.  dnagpu_profile_hbm_get drains the chains and returns, per kind, the
+ * ALGORITHMIC bytes (what the launch has to move: matrix read / written once), the summed event durations and the launch count since
+ * the last reset.  A bracketed duration is the kernel's own only while nothing else runs on the device: measure with one chain. */
+enum {
+    DNAGPU_HBM_UNPERMUTE = 0,     /* the completed inverse back to the block's unknown order: np^2 read + np^2 written */
+    DNAGPU_HBM_FORM_ORDERED = 1,  /* normals formed in the elimination's order: the lower triangle written once (zero fill + 3x3 blocks) */
+    DNAGPU_HBM_SUBSTITUTION = 2,  /* corrections from a kept factor, all launches of one solve: the factor (np^2 / 2) read twice */
+    DNAGPU_HBM_SYMV = 3,          /* corrections = N^-1 rhs (multiply_sym MAT:1471): n x np read once */
+    DNAGPU_HBM_PACK = 4           /* packed lower triangle out of a square matrix: n^2 / 2 read + n^2 / 2 written */
+};
+int dnagpu_profile_hbm_enable(dnagpu_ctx* ctx, int on);
+int dnagpu_profile_hbm_get(dnagpu_ctx* ctx, double bytes[8], double ms[8], uint64_t count[8], int reset);
+
 /* gemm_flops: flops actually issued; gemm_ms: time during which at least one timed GEMM run was executing (union over
  * the chains' streams: equals the summed run durations with one chain); launches */
 int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uint64_t* launches);

@@ -655,10 +655,10 @@ def test_staged_rigorous_variances_in_host_memory(built, orc, tmp_path, mt):
     assert c0 == c1 and p0 == p1 and np.array_equal(r0, r1) and f0 == f1 and g0 == g1
 
 
-@pytest.mark.parametrize("host_gb", ["0", "0.00002"])
+@pytest.mark.parametrize("host_gb", ["0", "0.0002"])
 def test_staged_store_past_the_host_memory_limit(built, tmp_path, monkeypatch, host_gb):
     """the staged store where the host's memory limit ends (DecideStaging: the container's cgroup, here DNAGPU_HOST_STORE_GB): the blocks
-    past it keep their packed variance matrix in HBM instead (block_t::rig_on_device).  "0": every block; 20 kB: the first block(s) in
+    past it keep their packed variance matrix in HBM instead (block_t::rig_on_device).  "0": every block; 200 kB: the first two blocks in
     host memory, the rest in HBM.  Identical results -- estimates, variances, statistics, the re-read result files -- and the plan
     says where the bytes are."""
     adjust.write_synthetic_network(str(tmp_path), "g", 16, 10, 0, 4, seed=21, x_clusters=10, y_cluster=True)
