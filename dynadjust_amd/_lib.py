@@ -56,7 +56,7 @@ class DnaAdjInstanceStats(C.Structure):
 class DnaSynthSpec(C.Structure):
     _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("n_baselines", C.c_uint64), ("n_blocks", C.c_uint32),
                 ("seed", C.c_uint64), ("initial_sigma", C.c_double), ("x_clusters", C.c_uint32), ("y_cluster", C.c_uint32),
-                ("y_llh", C.c_uint32), ("scalars", C.c_uint32)]
+                ("y_llh", C.c_uint32), ("scalars", C.c_uint32), ("rows_lo", C.c_uint32), ("rows_hi", C.c_uint32), ("ragged", C.c_double)]
 
 
 class DnaImportSummary(C.Structure):

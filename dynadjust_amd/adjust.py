@@ -346,11 +346,12 @@ def rccl_unique_id():
 
 
 def write_synthetic_network(folder, name, rows, cols, n_baselines=0, n_blocks=1, seed=20260928, initial_sigma=0.05,
-                            x_clusters=0, y_cluster=False, y_llh=False, scalars=False):
-    """writes <folder>/<name>.{bst,bms,asl,seg,truth}; returns the summary dict."""
+                            x_clusters=0, y_cluster=False, y_llh=False, scalars=False, ragged=0.0, rows_lo=0, rows_hi=0):
+    """writes <folder>/<name>.{bst,bms,asl,seg,truth}; returns the summary dict.  ragged / rows_lo / rows_hi: uneven
+    strips (include/dnaadjust_c.h dnasynth_spec)."""
     lib = _lib.load()
     spec = DnaSynthSpec(rows, cols, n_baselines, n_blocks, seed, initial_sigma, int(x_clusters), int(bool(y_cluster)), int(bool(y_llh)),
-                        int(bool(scalars)))
+                        int(bool(scalars)), int(rows_lo), int(rows_hi), float(ragged))
     out = DnaSynthSummary()
     err = C.create_string_buffer(512)
     rc = lib.dnasynth_write_network(os.fsencode(folder), os.fsencode(name), C.byref(spec), C.byref(out), err, 512)

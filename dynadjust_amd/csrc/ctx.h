@@ -83,6 +83,7 @@ struct Block {
     std::vector<DsEnt> h_ds_ents;
     // dnagpu_schur_carry: unknown order with the carried junction stations last, per junction list seen (forward / reverse)
     std::vector<uint32_t> h_schur_idx[2];
+    uint32_t h_schur_nip[2] = {0, 0}, h_schur_npp[2] = {0, 0};      // (the padded orders the cached map was laid out for)
     uint32_t* schur_idx[2] = {};
     int32_t* schur_map[2] = {};
     uint32_t* schur_spos[2] = {};      // station -> position of its first unknown in that order

@@ -1641,7 +1641,9 @@ int schur_order(dnagpu_ctx* ctx, Block* b, const uint32_t* idx_out, size_t k, ui
     int slot = -1;
     std::unique_lock<std::mutex> lk(ctx->schur_mutex);
     for (int q = 0; q < 2; ++q)
-        if (b->schur_map[q] && b->h_schur_idx[q].size() == k && std::equal(idx_out, idx_out + k, b->h_schur_idx[q].begin())) slot = q;
+        if (b->schur_map[q] && b->h_schur_nip[q] == nip && b->h_schur_npp[q] == npp && b->h_schur_idx[q].size() == k &&
+            std::equal(idx_out, idx_out + k, b->h_schur_idx[q].begin()))
+            slot = q;
     if (slot < 0) {
         std::vector<uint8_t> out(b->n_stn, 0);
         for (size_t i = 0; i < k; ++i) {
@@ -1684,6 +1686,8 @@ int schur_order(dnagpu_ctx* ctx, Block* b, const uint32_t* idx_out, size_t k, ui
         HIPCHK(hipMemcpy(b->schur_map[slot], map.data(), (size_t)npp * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(b->schur_idx[slot], idx_out, k * sizeof(uint32_t), hipMemcpyHostToDevice));
         b->h_schur_idx[slot].assign(idx_out, idx_out + k);
+        b->h_schur_nip[slot] = nip;
+        b->h_schur_npp[slot] = npp;
     }
     *map_dev = b->schur_map[slot];
     *spos_dev = b->schur_spos[slot];
@@ -1694,7 +1698,14 @@ int schur_order(dnagpu_ctx* ctx, Block* b, const uint32_t* idx_out, size_t k, ui
 int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, const double** T, uint32_t* ldt,
                     int* slot_out, dnagpu_partial* keep = nullptr, const FormInOrder* form = nullptr) {
     const uint32_t n = form ? 3 * b->n_stn : m->n, nj = (uint32_t)(3 * k), ni = n - nj;
-    const uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1), npp = nip + njp;
+    uint32_t nip = ni ? pad128(ni) : 0, njp = pad128(nj + 1);
+    // A light kept factor's capacity IS the shape the block is eliminated in (identity padding up to it): blocks of unequal size that
+    // share a capacity can then go through the batched calls together, and a block gives the same bits batched or alone.
+    if (keep && keep->spine && ni && keep->n_cap - keep->k_cap >= nip && keep->k_cap >= njp) {
+        nip = keep->n_cap - keep->k_cap;
+        njp = keep->k_cap;
+    }
+    const uint32_t npp = nip + njp;
     if (!form && (size_t)npp * nip > ((size_t)m->np_max + 128) * m->np_max) return fail(ctx, DNAGPU_EINVAL, "schur: matrix capacity");
     int slot = -1;
     const int32_t* map_dev = nullptr;
@@ -2201,7 +2212,11 @@ int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const u
             (n_con[b] && (!con_stn[b] || !con_w9[b])))
             return fail(ctx, DNAGPU_EINVAL, "block_form_reduce_batched: bad arguments");
         const uint32_t n = 3 * blk[b]->n_stn, nj = (uint32_t)(3 * k[b]), ni = n - nj;
-        const uint32_t nip_b = ni ? pad128(ni) : 0, njp_b = pad128(nj + 1);
+        uint32_t nip_b = ni ? pad128(ni) : 0, njp_b = pad128(nj + 1);
+        if (ni && keep[b]->n_cap - keep[b]->k_cap >= nip_b && keep[b]->k_cap >= njp_b) {       // (the factor's capacity is the member's shape: schur_eliminate)
+            nip_b = keep[b]->n_cap - keep[b]->k_cap;
+            njp_b = keep[b]->k_cap;
+        }
         if (b == 0) {
             nip = nip_b; njp = njp_b; npp = nip + njp;
         } else if (nip_b != nip || njp_b != njp) {

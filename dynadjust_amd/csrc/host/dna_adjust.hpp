@@ -216,6 +216,7 @@ private:
         constraint_list con_inner;            // constraints of the eliminated stations (first appearance in both directions)
         constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
+        UINT32 shape_ni = 0, shape_nk = 0;    // the padded orders it is eliminated in: its own, or its bucket's (AssignBatchShapes)
         bool part_allowed = false, part_valid = false;
         bool var_deferred = false;            // a.defer_variances: this iteration's inverse exists as the completed factor in `part` only
         bool part_spine = false;              // a.defer_variances = 2: the kept factor in its light form (dnagpu_partial_create_spine)
@@ -395,7 +396,12 @@ private:
     int NumChains() const { return (projectSettings_.a.adjust_mode != SimultaneousMode && projectSettings_.a.multi_thread) ? mt_chains_ : 1; }
     int mt_chains_ = DNAGPU_DEFAULT_CHAINS;
     // order the rigorous variance matrix of block k is created with (spare rows when it lends its storage to the kept factor)
-    UINT32 RigvarCapacity(UINT32 k) const { return (UINT32)v_parameterStationList_[k].size() * 3 + (blocks_[k].part_in_rigvar ? 256u : 0u); }
+    // (a matrix that lends its storage to the block's kept factor holds the factor's padded shape: own order + 256, or the bucket's)
+    UINT32 RigvarCapacity(UINT32 k) const {
+        const UINT32 n = (UINT32)v_parameterStationList_[k].size() * 3;
+        return blocks_[k].part_in_rigvar ? std::max(n + 256u, blocks_[k].shape_ni + blocks_[k].shape_nk) : n;
+    }
+    void AssignBatchShapes();
     bool ReuseRequested() const { return projectSettings_.a.reuse_inverses != 0 && !containsNonGPS_ && !staged_; }
     bool CondensedWanted() const {
         return projectSettings_.a.schur_carry != 0 && !projectSettings_.a.scale_normals_to_unity && projectSettings_.a.adjust_mode == PhasedMode;

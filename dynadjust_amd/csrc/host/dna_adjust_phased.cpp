@@ -593,6 +593,7 @@ void dna_adjust::PrepareCondensedBlocks() {
     PrepareTwoLevel();
     AllocateChainData();
     if (!projectSettings_.a.keep_factors || !SchurCarry()) return;
+    AssignBatchShapes();
     // a.keep_factors: which blocks may keep their factor without starving what is allocated later -- every block's rigorous
     // variance matrix and the chains' workspaces (work matrix + X + W per chain).  The factor's inverse (n^2 doubles) waits in the
     // block's rigorous variance matrix, which is dead from the start of an iteration until the completion writes it
@@ -611,7 +612,9 @@ void dna_adjust::PrepareCondensedBlocks() {
     for (UINT32 k = 0; k < blockCount_; ++k) {
         block_t& B = blocks_[k];
         if (B.keep.empty() || !OwnsBlock(k)) continue;      // (a block is condensed and completed on its owner's GPU only)
-        const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size();
+        const double nk = 3.0 * (double)B.keep.size();
+        // (the factor's own padded shape, which a bucketed block shares with the larger members of its bucket)
+        const double n = std::max(3.0 * (double)v_parameterStationList_[k].size(), (double)(B.shape_ni + B.shape_nk) - 256.0);
         const bool in_rigvar = lend && !B.rigvar;   // (a matrix that exists already has no spare rows)
         const bool spine = DeferVariances() && projectSettings_.a.defer_variances >= 2;      // (the light form keeps its panels inside X)
         const double need = (in_rigvar ? 2.0 * 256.0 * (n + 512.0) * 8.0 : sq(n)) + (spine ? 0.0 : (nk + 256.0) * (n + 256.0) * 8.0);
@@ -670,12 +673,59 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     NoteCondensed(k);
 }
 
+// The padded orders every block with something to condense is eliminated in.  Its own -- ceil128(eliminated unknowns), ceil128(kept
+// unknowns + 1) -- unless small blocks of similar size can share one: the batched calls need members of ONE shape (the recursion runs
+// once for all of them), a real segmentation has no two blocks alike (dnasegment.cpp:235-348), and a small block alone is bound by
+// launch latency, not by its flops.  So blocks whose eliminated part is at most 48 tiles (6 144 unknowns: 28 TFLOP/s alone) are
+// collected in buckets an eighth of their size wide (kept part: the same rule) and every member of a bucket with at least two members
+// takes the bucket's LARGEST member's shape -- identity padding, at most ~40 % more flops for the smallest member, in exchange for
+// up to DNAGPU_BATCH_MAX blocks per launch.  Larger blocks keep their own shape (equal ones still batch, as before).
+void dna_adjust::AssignBatchShapes() {
+    auto pad = [](UINT32 v) { return v == 0 ? 128u : ((v + 127u) / 128u) * 128u; };
+    auto bucket = [](UINT32 padded) {
+        const UINT32 t = padded / 128u;
+        if (t <= 8u || t > 48u) return t;
+        UINT32 step = 1;
+        while (step * 16u <= t) step *= 2u;        // t in [16, 32): 2 tiles, [32, 64): 4
+        return ((t + step - 1u) / step) * step;
+    };
+    static const bool off = getenv("DNAGPU_BATCH_BUCKETS") && atoi(getenv("DNAGPU_BATCH_BUCKETS")) == 0;
+    std::map<std::pair<UINT32, UINT32>, std::vector<UINT32>> members;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        block_t& B = blocks_[k];
+        B.shape_ni = B.shape_nk = 0;
+        if (B.keep.empty() || !OwnsBlock(k)) continue;
+        const UINT32 n = 3 * (UINT32)v_parameterStationList_[k].size(), nk = 3 * (UINT32)B.keep.size();
+        if (nk >= n) continue;
+        B.shape_ni = pad(n - nk);
+        B.shape_nk = pad(nk + 1);
+        if (!off && projectSettings_.a.batch_blocks > 1) members[{bucket(B.shape_ni), bucket(B.shape_nk)}].push_back(k);
+    }
+    for (auto& kv : members) {
+        if (kv.second.size() < 2) continue;
+        UINT32 ni = 0, nk = 0;
+        for (UINT32 k : kv.second) {
+            ni = std::max(ni, blocks_[k].shape_ni);
+            nk = std::max(nk, blocks_[k].shape_nk);
+        }
+        for (UINT32 k : kv.second) {
+            blocks_[k].shape_ni = ni;
+            blocks_[k].shape_nk = nk;
+        }
+    }
+}
+
 // the retained factor of a block that may keep one (PrepareCondensedBlocks), created on first use
 void dna_adjust::EnsurePartial(UINT32 k) {
     block_t& B = blocks_[k];
     if (!B.part_allowed || B.part) return;
     std::lock_guard<std::mutex> lk(alloc_mutex_);
-    const UINT32 n = (UINT32)v_parameterStationList_[k].size() * 3, nk = (UINT32)B.keep.size() * 3;
+    // (capacity = shape: own padded orders, or the bucket's)
+    UINT32 n = (UINT32)v_parameterStationList_[k].size() * 3, nk = (UINT32)B.keep.size() * 3;
+    if (B.part_spine && B.shape_ni && B.shape_nk) {
+        nk = B.shape_nk - 1;
+        n = B.shape_ni + nk;
+    }
     int rc;
     if (B.part_in_rigvar) {
         if (!B.rigvar) Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
@@ -728,9 +778,7 @@ std::vector<std::vector<UINT32>> dna_adjust::BatchGroups(const std::vector<UINT3
             groups.push_back({k});
             continue;
         }
-        const UINT32 n = 3 * (UINT32)v_parameterStationList_[k].size(), nk = 3 * (UINT32)blocks_[k].keep.size();
-        auto pad = [](UINT32 v) { return v == 0 ? 128u : ((v + 127u) / 128u) * 128u; };
-        by_shape[{n > nk ? pad(n - nk) : 0u, pad(nk + 1)}].push_back(k);
+        by_shape[{blocks_[k].shape_ni, blocks_[k].shape_nk}].push_back(k);
     }
     for (auto& kv : by_shape)
         for (size_t i = 0; i < kv.second.size(); i += cap)
@@ -781,7 +829,8 @@ void dna_adjust::ForGroups(std::vector<std::vector<UINT32>> groups, const std::f
 bool dna_adjust::BatchWorkspaces(int c, const std::vector<UINT32>& ks) {
     const UINT32 k0 = ks[0];
     int granted = 1;
-    Check(dnagpu_batch_reserve(ctx_, c, 3 * (UINT32)v_parameterStationList_[k0].size(), 3 * (UINT32)blocks_[k0].keep.size(), (int)ks.size(), &granted), k0,
+    const UINT32 k_max = blocks_[k0].shape_nk - 1, n_max = blocks_[k0].shape_ni + k_max;      // (the members' common shape)
+    Check(dnagpu_batch_reserve(ctx_, c, n_max, k_max, (int)ks.size(), &granted), k0,
           "PrepareAdjustment(): batch workspaces");
     return granted >= (int)ks.size();
 }

@@ -368,6 +368,9 @@ int dnasynth_write_network(const char* dir, const char* name, const dnasynth_spe
         sp.y_cluster = spec->y_cluster != 0;
         sp.y_llh = spec->y_llh != 0;
         sp.scalars = spec->scalars != 0;
+        sp.rows_lo = spec->rows_lo;
+        sp.rows_hi = spec->rows_hi;
+        sp.ragged = spec->ragged;
         dynadjust::synth::Summary sm;
         dynadjust::synth::write_network(dir, name, sp, &sm);
         if (out) {

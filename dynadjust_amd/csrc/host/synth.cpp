@@ -46,13 +46,51 @@ void put_str(char* dst, size_t cap, const char* src) {
 
 void write_network(const std::string& dir, const std::string& name, const Spec& sp, Summary* summary) {
     using namespace geodesy;
-    const uint32_t R = sp.rows, C = sp.cols, B = std::max<uint32_t>(1, sp.n_blocks);
+    const uint32_t R = sp.rows, C = sp.cols;
+    // strip k = grid rows cut[k] .. cut[k + 1] - 1.  Equal strips: row r belongs to strip floor(r * B / R) (every strip floor(R/B) or
+    // ceil(R/B) rows); sp.ragged / sp.rows_hi: uneven heights from a generator of their own (the stream of the stations and measurements --
+    // and with it every committed record of an equal-strip network -- is untouched)
+    std::vector<uint32_t> cut;
+    {
+        SplitMix64 hr(sp.seed ^ 0x5EC7105A11ull);
+        if (sp.rows_hi > 0) {
+            const uint32_t lo = std::max<uint32_t>(1, std::min(sp.rows_lo, sp.rows_hi)), hi = std::max(lo, sp.rows_hi);
+            cut.push_back(0);
+            while (cut.back() < R) {
+                uint32_t h = lo + (uint32_t)(hr.uniform() * (double)(hi - lo + 1));
+                if (h > hi) h = hi;
+                if (R - cut.back() < h + lo) h = R - cut.back();          // (the last strip takes what is left rather than leave a sliver)
+                cut.push_back(cut.back() + h);
+            }
+        } else {
+            const uint32_t Bq = std::max<uint32_t>(1, sp.n_blocks);
+            if (Bq > R) throw std::runtime_error("synth: more blocks than grid rows");
+            if (sp.ragged > 0.0 && Bq > 1) {
+                if (sp.ragged >= 1.0) throw std::runtime_error("synth: ragged must be below 1");
+                std::vector<double> w(Bq);
+                double sum = 0.0;
+                for (double& x : w) sum += (x = 1.0 + sp.ragged * (2.0 * hr.uniform() - 1.0));
+                cut.assign(Bq + 1, 0);
+                double acc = 0.0;
+                for (uint32_t k = 0; k < Bq; ++k) {
+                    acc += w[k];
+                    uint32_t c = (uint32_t)std::llround(acc / sum * (double)R);
+                    c = std::max(c, cut[k] + 1);                          // at least one row each ...
+                    c = std::min(c, R - (Bq - 1 - k));                    // ... and one left for every strip behind
+                    cut[k + 1] = c;
+                }
+                cut[Bq] = R;
+            } else {
+                for (uint32_t k = 0; k <= Bq; ++k) cut.push_back((uint32_t)(((uint64_t)k * R + Bq - 1) / Bq));   // = first r with floor(r * B / R) >= k
+            }
+        }
+    }
+    const uint32_t B = (uint32_t)cut.size() - 1;
     if (R < 2 || C < 2) throw std::runtime_error("synth: the grid needs at least 2 x 2 stations");
     const uint64_t n_stn = (uint64_t)R * C;
     const uint64_t n_cand = (uint64_t)R * (C - 1) + (uint64_t)(R - 1) * C + (uint64_t)(R - 1) * (C - 1);
     uint64_t target = sp.n_baselines ? sp.n_baselines : n_cand;
     if (target > n_cand) throw std::runtime_error("synth: more baselines requested than the grid has E/N/NE neighbours");
-    if (B > R) throw std::runtime_error("synth: more blocks than grid rows");
     const Ellipsoid ell;
     const double deg = 3.14159265358979323846 / 180.0;
     const double lat0 = -36.5 * deg, lon0 = 146.0 * deg, step = 0.01 * deg;
@@ -328,11 +366,10 @@ void write_network(const std::string& dir, const std::string& name, const Spec& 
     seg.JSL.assign(B, {});
     seg.CML.assign(B, {});
     seg.ContiguousNetList.assign(B, 0);
-    // row r belongs to strip floor(r * B / R): every strip gets floor(R/B) or ceil(R/B) rows
-    auto strip_of = [&](uint64_t s) {
-        uint32_t k = (uint32_t)(((s / C) * (uint64_t)B) / R);
-        return k >= B ? B - 1 : k;
-    };
+    std::vector<uint32_t> strip_of_row(R);
+    for (uint32_t k = 0; k < B; ++k)
+        for (uint32_t r = cut[k]; r < cut[k + 1]; ++r) strip_of_row[r] = k;
+    auto strip_of = [&](uint64_t s) { return strip_of_row[(size_t)(s / C)]; };
     for (uint64_t s = 0; s < n_stn; ++s) seg.ISL[strip_of(s)].push_back((UINT32)s);
     for (uint64_t q = 0; q < n_msr; ++q) {
         // a measurement belongs to the strip of the station it leaves; end stations in the next strip are junctions

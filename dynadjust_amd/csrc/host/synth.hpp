@@ -17,6 +17,11 @@ struct Spec {
     bool y_cluster = false;    // datum from two 'Y' point clusters over the corner stations instead of CCC constraints
     bool y_llh = false;        // ... given as latitude / longitude / height ("LLh" and "LLH") with geographic variance matrices
     bool scalars = false;      // v- / p- / l- / h-scale columns set on part of the measurements
+    // Uneven segmentations (dnasegment cuts a real network into blocks of whatever its --max-block-stns / --min-inner-stns thresholds and the
+    // network's shape give, dnasegment.cpp:235-348, 528-700; default threshold 150 stations, dnaoptions.hpp:381-382):
+    double ragged = 0.0;       // strip heights proportional to 1 + ragged * U(-1, 1) instead of equal (0 <= ragged < 1), n_blocks strips
+    uint32_t rows_lo = 0, rows_hi = 0;   // rows_hi > 0: strip heights drawn uniformly from [rows_lo, rows_hi] rows until the grid is used up
+                                         // (n_blocks is then a result, not an input): blocks of rows_lo * cols ... rows_hi * cols stations
 };
 
 struct Summary {

@@ -274,6 +274,11 @@ typedef struct {
     uint32_t y_cluster;     /* 1: datum from 'Y' point clusters over the corner stations (which become FFF) */
     uint32_t y_llh;         /* 1: those clusters in latitude / longitude / height ("LLh", "LLH") with geographic variances */
     uint32_t scalars;       /* 1: variance scalars (v, phi, lambda, h) on part of the measurements */
+    /* uneven segmentations (what dnasegment makes of a real network, dnasegment.cpp:235-348; default threshold 150 stations per block,
+     * dnaoptions.hpp:381-382): ragged in [0, 1): strip heights proportional to 1 + ragged * U(-1, 1); rows_hi > 0: heights drawn from
+     * [rows_lo, rows_hi] rows until the grid is used up -- n_blocks is then a result (dnasynth_summary.blocks) */
+    uint32_t rows_lo, rows_hi;
+    double ragged;
 } dnasynth_spec;
 typedef struct {
     uint64_t stations, baselines, measurement_rows, blocks, max_block_unknowns;

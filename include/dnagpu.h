@@ -355,7 +355,10 @@ void dnagpu_partial_destroy(dnagpu_ctx* ctx, dnagpu_partial* p);
 /* The light form: the elimination stops at the factor (~0.34 n_i^3 instead of 2/3 n_i^3 -- no inverse of the eliminated part is formed), kept
  * in `store` as one block lower triangular matrix (inverses of the diagonal blocks, panels below them).  dnagpu_partial_complete_factor then
  * only factors the kept block, dnagpu_partial_solve substitutes block by block, and dnagpu_partial_finish pays for the inverse of the
- * factor as well (2/3 n^3 in all) -- once, after the last iteration.  No panel copy; `store` = NULL gives it storage of its own (n^2). */
+ * factor as well (2/3 n^3 in all) -- once, after the last iteration.  No panel copy; `store` = NULL gives it storage of its own (n^2).
+ * The capacity is the SHAPE the block is eliminated in: the eliminated part padded (with an identity) to ceil128(n_max - k_max), the kept
+ * part to ceil128(k_max + 1).  A block smaller than its factor's capacity is simply padded further -- blocks of unequal size given one
+ * common capacity thereby share a shape and can go through the batched calls together, each with the bits it would get alone. */
 int dnagpu_partial_create_spine(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_matrix* store, dnagpu_partial** out);
 int dnagpu_partial_complete(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, const dnagpu_matrix* kk, dnagpu_matrix* inv);
 /* The completion in two halves.  An iteration of the adjustment needs the block's solution, not its inverse: the reference obtains the
