@@ -40,7 +40,15 @@ WORKLOADS = {
     # 16 of cfg4's 128 strips: the same block size (n ~ 27 000, 1000-station junction rows) on one GPU
     "cfg4_slice": (125, 1000, 333333, 16, True, "synthetic 125k-station / 1M-measurement network, phased adjustment, 16 blocks of cfg4's size"),
     "small": (60, 60, 9600, 4, True, "synthetic 3.6k-station / 28.8k-measurement network, phased adjustment, 4 blocks (smoke size)"),
+    # uneven segmentations (what dnasegment makes of a real network: no two blocks alike, dnasegment.cpp:235-348):
+    # cfg3 with strip heights drawn +-30 % around the mean (blocks of n ~ 14 000 ... 26 000)
+    "cfg3_ragged": (316, 317, 266666, 16, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, 16 blocks of uneven size (strip heights +-30 %)"),
+    # the same station count cut the way dnasegment's defaults would (150 stations per block and up, dnaoptions.hpp:381-382): strips of 1 ... 10
+    # rows of 150 stations -> ~120 blocks of 150 ... 1 500 inner + 150 junction stations (n = 900 ... 4 950)
+    "smallblocks": (668, 150, 266666, 0, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, ~120 blocks of 150 ... 1 500 inner stations (dnasegment-like cut)"),
 }
+# extra arguments of the generator per workload (dnasynth_spec: ragged, rows_lo, rows_hi)
+WORKLOAD_KW = {"cfg3_ragged": {"ragged": 0.3}, "smallblocks": {"rows_lo": 1, "rows_hi": 10}}
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk)
 
 
@@ -336,7 +344,11 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
         oracle.use_lapack(path)
         lib.orc_set_threads(threads)
     d = tempfile.mkdtemp(prefix="dnagpu_cpu_")
-    if phased:
+    synth_kw = {}
+    if "rows_hi" in WORKLOAD_KW.get(workload, {}) and path:
+        # a small-block segmentation is cheap enough for the CPU to run WHOLE (sum n^3 ~ 1e13 per iteration): no strip, no extrapolation in n
+        nb_s, rows_s, cols_s, synth_kw = 1, rows, cols, WORKLOAD_KW[workload]
+    elif phased:
         nb_s = 3 if path else 2
         rows_s = max(4, (rows // blocks) * nb_s)
         cols_s = cols if path else min(cols, 40)
@@ -344,7 +356,9 @@ def _cpu_baseline_sample(workload, iterations, solves_per_step, sum_n3_per_step,
         nb_s, rows_s, cols_s = 1, rows, cols
         if not path:
             rows_s, cols_s = min(rows, 24), min(cols, 24)
-    info = adjust.write_synthetic_network(d, "cpu", rows_s, cols_s, 0, nb_s)
+    info = adjust.write_synthetic_network(d, "cpu", rows_s, cols_s, 0 if not synth_kw else nbl, nb_s, **synth_kw)
+    if synth_kw:
+        nb_s = info["blocks"]
 
     def new_adjustment():
         net = oracle.Network(os.path.join(d, "cpu"), phased)
@@ -805,7 +819,8 @@ def main():
     rows, cols, nbl, blocks, phased, desc = WORKLOADS[args.workload]
     d = tempfile.mkdtemp(prefix=f"dnagpu_bench_r{rank}_")
     t_w = time.perf_counter()
-    info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, blocks)
+    info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, max(1, blocks), **WORKLOAD_KW.get(args.workload, {}))
+    blocks = info["blocks"]
     synth_s = time.perf_counter() - t_w
     stations = info["stations"]
     print(f"[bench] synthetic network written in {synth_s:.1f} s: {info}", file=sys.stderr, flush=True)
@@ -935,6 +950,7 @@ def main():
             # blocks of one shape through the large steps as one batch of merged launches (a.batch_blocks): block steps
             # (condensing, kept-block factorisation, variance matrices: up to 2 per block and iteration + 1 per block) that were batched
             "batched_block_steps_per_step": a.batched_block_steps(),
+            "batched_fraction_of_flops": (a.batched_flops() / alg) if alg else 0.0,
             # outside the timed region (SURVEY section 8d excludes them from the metric), reported so that they cannot hide: writing the synthetic
             # .bst/.bms/.asl/.seg files, and PrepareAdjustment = reading them + host metadata (pair CSRs, appearance lists) + uploads
             "synth_write_s": round(synth_s, 2), "prepare_s": round(prepare_s, 2),

@@ -304,6 +304,9 @@ class DnaAdjust:
         """block steps that went through batched calls (settings.batch_blocks)"""
         return int(self.lib.dnaadj_batched_block_steps(self.h))
 
+    def batched_flops(self):
+        return float(self.lib.dnaadj_batched_flops(self.h))
+
     def memory_plan(self):
         """PrepareAdjustment's memory plan (dnaadj_memory_plan): where the staged variance matrices go, which blocks keep their factor"""
         out = (C.c_double * 8)()

@@ -835,6 +835,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     condense_count_ = 0;
     completion_count_ = 0;
     batched_members_ = 0;
+    batched_flops_ = 0.0;
     stageCopiedBytes_ = stageWaitNs_ = 0;
     algorithmic_flops_ = 0.0;
     for (block_t& b : blocks_) b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
@@ -1084,6 +1085,7 @@ void dna_adjust::ResetAdjustment() {
     condense_count_ = 0;
     completion_count_ = 0;
     batched_members_ = 0;
+    batched_flops_ = 0.0;
     algorithmic_flops_ = 0.0;
     cancel_.store(false);
     cancel_agreed_ = false;

@@ -328,6 +328,7 @@ public:
     void PhasedFinaliseBlock(int chain, UINT32 k);
     // ---- condensed schedule (a.schur_carry): the steps of one iteration ---------------------------------
     bool CondensedSchedule() const { return SchurCarry() && condensed_ok_; }
+    double BatchedFlops() const { return batched_flops_; }      // algorithmic flops of the block steps that went through batched calls
     uint64_t BatchedBlockSteps() const { return batched_members_.load(); }      // block steps that went through batched calls (a.batch_blocks)
     // (A) independent per block: eliminate every station the block shares with no other block
     void CondenseBlock(int chain, UINT32 k);
@@ -447,6 +448,7 @@ private:
     void FinishVariancesBatch(int chain, const std::vector<UINT32>& blocks);
     std::vector<dnagpu_matrix*> kbatch_[DNAGPU_NUM_CHAINS];   // the kept blocks of the members of a batched rigorous solve
     std::atomic<uint64_t> batched_members_{0};
+    double batched_flops_ = 0.0;
     double batch_budget_ = 0.0, batch_unit_ = 0.0;            // bytes left for the members' workspaces of all chains together; bytes per member
     int batch_granted_[DNAGPU_NUM_CHAINS] = {};               // members beyond the first whose workspaces chain c has been charged for
     int batch_limit_ = 0;                                     // members beyond the first that the memory budget admits (PrepareCondensedBlocks)

@@ -887,6 +887,9 @@ void dna_adjust::CondenseBatch(int c, const std::vector<UINT32>& ks) {
     for (UINT32 k : members) {
         blocks_[k].part_valid = true;
         NoteCondensed(k);
+        const double nk = 3.0 * (double)blocks_[k].keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;
+        std::lock_guard<std::mutex> lk(corr_mutex_);
+        batched_flops_ += ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
     }
 }
 
@@ -1042,6 +1045,7 @@ void dna_adjust::FinishVariancesBatch(int c, const std::vector<UINT32>& ks) {
         const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
         std::lock_guard<std::mutex> lk(corr_mutex_);
         algorithmic_flops_ += n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+        batched_flops_ += n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
     }
     Check(dnagpu_chain_sync(ctx_, c), ks[0], "UpdateEstimatesFinal()");
 }

@@ -500,6 +500,7 @@ int dnaadj_memory_plan(const dnaadj_handle* h, double out[8]) {
     return 0;
 }
 int dnaadj_condensed_schedule(const dnaadj_handle* h) { return (h && h->adj && h->adj->CondensedSchedule()) ? 1 : 0; }
+double dnaadj_batched_flops(const dnaadj_handle* h) { return (h && h->adj) ? h->adj->BatchedFlops() : 0.0; }
 uint64_t dnaadj_batched_block_steps(const dnaadj_handle* h) { return (h && h->adj) ? h->adj->BatchedBlockSteps() : 0; }
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block) {
     return (h && h->adj && block < h->adj->blockCount()) ? h->adj->CondensedPayloadDoubles(block) : 0;

@@ -175,6 +175,7 @@ void dnaadj_debug_stall_rank(int rank, long nth_agreement, double seconds);
 /* how many block steps of the last adjustment went through batched calls (settings.batch_blocks): condensing and rigorous solve count a
  * block once per iteration, the variance matrices once */
 uint64_t dnaadj_batched_block_steps(const dnaadj_handle* h);
+double dnaadj_batched_flops(const dnaadj_handle* h);       /* the algorithmic flops of those steps (of dnaadj_algorithmic_flops) */
 size_t dnaadj_condensed_payload_doubles(const dnaadj_handle* h, uint32_t block);
 int dnaadj_phased_condense_block(dnaadj_handle* h, uint32_t block);
 int dnaadj_phased_condensed_forward(dnaadj_handle* h, uint32_t block);

@@ -48,6 +48,45 @@ def test_batched_blocks_have_the_bits_of_unbatched_ones(built, tmp_path, mt, row
     a1.close()
 
 
+def test_small_blocks_of_unequal_size_share_a_bucket(built, orc, tmp_path):
+    """a dnasegment-like cut (strips of 7 ... 12 rows of 100 stations: ~12 blocks of n = 2 400 ... 3 900, no two alike): blocks whose eliminated
+    part falls into one bucket (AssignBatchShapes: an eighth of their size wide) are padded with an identity up to the bucket's largest
+    member and go through the batched calls together.  Against the oracle (1e-8 m, 1e-8 relative) and against the run without batching
+    (own shapes: the padded ones differ in blocking, so equal to rounding, not bit for bit)."""
+    info = adjust.write_synthetic_network(str(tmp_path), "s", 120, 100, 0, 1, seed=9, rows_lo=7, rows_hi=12)
+    assert info["blocks"] >= 10
+    orc.use_mkl(True)
+    try:
+        net = orc.Network(str(tmp_path / "s"), True)
+        o = orc.Adjustment(net, True)
+        o.prepare()
+        ost = o.run()
+    finally:
+        orc.use_mkl(False)
+    a0, st0 = _run(str(tmp_path), "s", multi_thread=True, batch_blocks=0)
+    assert st0 == ost and a0.batched_block_steps() == 0
+    x0, v0, c0 = _results(a0)
+    a0.close()
+    a1, st1 = _run(str(tmp_path), "s", multi_thread=True, batch_blocks=16)
+    assert st1 == ost and a1.CurrentIteration() == o.iterations()
+    B = a1.blockCount()
+    sizes = {a1.block_estimates(b).size for b in range(B)}
+    assert len(sizes) >= 4                                   # (the blocks really differ)
+    assert a1.batched_block_steps() >= B                     # ... and most of them were batched all the same
+    assert a1.batched_flops() > 0.5 * a1.algorithmic_flops()
+    x1, v1, c1 = _results(a1)
+    for b in range(B):
+        vo = o.block_variances(b)
+        scale = np.abs(vo).max()
+        assert np.abs(x1[b] - o.block_estimates(b)).max() < 1e-8 and np.abs(x0[b] - o.block_estimates(b)).max() < 1e-8
+        assert np.abs(v1[b] - vo).max() / scale < 1e-8 and np.abs(v0[b] - vo).max() / scale < 1e-8
+        assert np.abs(x1[b] - x0[b]).max() < 1e-9 and np.abs(v1[b] - v0[b]).max() / scale < 1e-10
+    for i in range(o.iterations()):
+        assert abs(c1[i] - o.max_correction(i + 1)) < 1e-8
+    a1.close()
+    o.close()
+
+
 def test_batch_size_is_capped(built, tmp_path):
     """batch_blocks = 2: groups of at most two members, same bits"""
     adjust.write_synthetic_network(str(tmp_path), "c", 48, 40, 0, 6, seed=5)

@@ -56,6 +56,21 @@ def test_phased_is_rigorous(orc, built, tmp_path, rows, cols, nbl, blocks):
     _phased_vs_simultaneous(orc, str(tmp_path / "n"))
 
 
+@pytest.mark.parametrize("kw", [{"ragged": 0.6, "n_blocks": 5}, {"rows_lo": 1, "rows_hi": 4}, {"rows_lo": 2, "rows_hi": 2}])
+def test_uneven_segmentations_are_rigorous(orc, built, tmp_path, kw):
+    """strips of uneven height (dnasynth_spec.ragged / rows_lo / rows_hi -- what dnasegment makes of a real network: no two blocks alike,
+    dnasegment.cpp:235-348): the segmentation invariants hold (every station inner in exactly one block, JSL(k) inside block k + 1,
+    every measurement in one block) and the phased result equals the simultaneous one"""
+    from dynadjust_amd import adjust
+    info = adjust.write_synthetic_network(str(tmp_path), "u", 14, 7, 0, kw.get("n_blocks", 1), seed=77, **{k: v for k, v in kw.items() if k != "n_blocks"})
+    net = orc.Network(str(tmp_path / "u"), True)
+    assert net.n_blocks == info["blocks"] and (info["blocks"] == 5 if "ragged" in kw else info["blocks"] >= 4)
+    sizes = [len(net.block_inner(b)) for b in range(net.n_blocks)] if hasattr(net, "block_inner") else None
+    if "ragged" in kw and sizes:
+        assert len(set(sizes)) > 1
+    _phased_vs_simultaneous(orc, str(tmp_path / "u"))
+
+
 def test_adjustment_recovers_the_truth(orc, built, tmp_path):
     """corner stations constrained at their true coordinates: the adjusted network must sit on the truth
     within the noise of the observations (3-6 mm per baseline component)"""
