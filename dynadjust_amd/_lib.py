@@ -263,6 +263,8 @@ def load():
     _sig(lib, "dnaadj_staged", i, [vp])
     _sig(lib, "dnagpu_profile_hbm_enable", i, [vp, i])
     _sig(lib, "dnagpu_profile_hbm_get", i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), i])
+    _sig(lib, "dnaadj_oscillation_history", sz, [vp, C.POINTER(C.c_double), sz])
+    _sig(lib, "dnaadj_summaries", sz, [vp, sz, C.c_char_p, sz])
     _sig(lib, "dnaadj_memory_plan", i, [vp, C.POINTER(C.c_double)])
     _sig(lib, "dnaadj_dist_set_timeout", None, [C.c_double])
     _sig(lib, "dnaadj_debug_stall_rank", None, [C.c_int, C.c_long, C.c_double])
@@ -303,7 +305,7 @@ def load():
 EXPORTED_DNAGPU = [
     "dnagpu_device_count", "dnagpu_create", "dnagpu_destroy", "dnagpu_last_error", "dnagpu_last_info", "dnagpu_sync",
     "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset", "dnagpu_debug_fail_allocation", "dnagpu_debug_fail_batch_workspaces", "dnagpu_debug_set_small_tiles", "dnagpu_debug_tile_order", "dnagpu_debug_set_pair_tiles", "dnagpu_fused_stats", "dnagpu_set_fused_launches", "dnagpu_debug_set_tile_dag", "dnagpu_debug_set_lookahead", "dnagpu_lookahead_stats", "dnagpu_set_tile_dag_workers", "dnagpu_tile_dag_stats", "dnagpu_debug_tile_dag_selftest",
-    "dnagpu_profile_get", "dnagpu_profile_hbm_enable", "dnagpu_profile_hbm_get", "dnagpu_matrix_pack_device", "dnagpu_matrix_unpack_device", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
+    "dnagpu_block_keep_corrections", "dnagpu_osc_reset", "dnagpu_osc_block", "dnagpu_osc_flagged", "dnagpu_osc_block_visits", "dnagpu_profile_get", "dnagpu_profile_hbm_enable", "dnagpu_profile_hbm_get", "dnagpu_matrix_pack_device", "dnagpu_matrix_unpack_device", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
     "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_download_packed_async", "dnagpu_copies_sync", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
@@ -328,7 +330,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_deserialise_adjusted_variance_matrices", "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",
     "dnaadj_block_flags", "dnaadj_junction_unknowns", "dnaadj_junction_payload_doubles", "dnaadj_phased_begin_iteration",
     "dnaadj_phased_forward_block", "dnaadj_phased_reverse_block", "dnaadj_phased_combine_block", "dnaadj_phased_finalise_block",
-    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_staged", "dnaadj_memory_plan", "dnaadj_dist_set_timeout", "dnaadj_debug_stall_rank", "dnaadj_condensed_schedule", "dnaadj_batched_block_steps", "dnaadj_batched_flops", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
+    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_staged", "dnaadj_oscillation_history", "dnaadj_summaries", "dnaadj_memory_plan", "dnaadj_dist_set_timeout", "dnaadj_debug_stall_rank", "dnaadj_condensed_schedule", "dnaadj_batched_block_steps", "dnaadj_batched_flops", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
     "dnaadj_phased_condensed_forward", "dnaadj_phased_condensed_reverse", "dnaadj_phased_rigorous_block", "dnaadj_phased_condense_blocks", "dnaadj_phased_condensed_chains",
     "dnaadj_phased_rigorous_blocks", "dnaadj_condensed_export",
     "dnaadj_condensed_import", "dnaadj_statistics_prepare", "dnaadj_statistics_blocks", "dnaadj_statistics_get_partial",

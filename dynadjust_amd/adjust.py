@@ -304,19 +304,35 @@ class DnaAdjust:
         """block steps that went through batched calls (settings.batch_blocks)"""
         return int(self.lib.dnaadj_batched_block_steps(self.h))
 
+    def oscillation_history(self):
+        """UpdateIterationDiagnostics' records: dicts keyed like the reference's OscillationRecord (dnaadjust.hpp:1277-1285)"""
+        n = self.lib.dnaadj_oscillation_history(self.h, None, 0)
+        out = (C.c_double * (9 * max(1, n)))()
+        self.lib.dnaadj_oscillation_history(self.h, out, n)
+        keys = ("station", "first_iteration", "last_iteration", "cycles", "first_mag", "last_mag", "last_e", "last_n", "last_up")
+        return [{k: (int(out[9 * i + j]) if j < 4 else float(out[9 * i + j])) for j, k in enumerate(keys)} for i in range(n)]
+
+    def summaries(self, limit=20):
+        """the text of PrintOscillationSummary() + PrintSuspectMeasurementSummary(limit)"""
+        n = self.lib.dnaadj_summaries(self.h, limit, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.dnaadj_summaries(self.h, limit, buf, n + 1)
+        return buf.value.decode("utf-8", errors="replace")
+
     def batched_flops(self):
         return float(self.lib.dnaadj_batched_flops(self.h))
 
     def memory_plan(self):
         """PrepareAdjustment's memory plan (dnaadj_memory_plan): where the staged variance matrices go, which blocks keep their factor"""
-        out = (C.c_double * 8)()
+        out = (C.c_double * 10)()
         if self.lib.dnaadj_memory_plan(self.h, out) != 0:
             return {}
         return {"staged_variances_host_bytes": int(out[0]), "staged_variances_packed_in_hbm_bytes": int(out[1]),
                 "staged_variances_host_gb": round(out[0] / 1e9, 2), "staged_variances_packed_in_hbm_gb": round(out[1] / 1e9, 2),
                 "blocks_keeping_their_factor": int(out[2]), "blocks_condensed": int(out[3]), "batch_members_beyond_first": int(out[4]),
                 "host_memory_available_gb": round(out[5] / 1e9, 1),
-                "copied_to_host_gb": round(out[6] / 1e9, 2), "waited_for_copies_ms": round(out[7], 1)}
+                "copied_to_host_gb": round(out[6] / 1e9, 2), "waited_for_copies_ms": round(out[7], 1),
+                "factors_made_again": int(out[8]), "blocks_without_kept_factor_refactor": bool(out[9])}
 
     def elimination_count(self):
         return self.lib.dnaadj_elimination_count(self.h)

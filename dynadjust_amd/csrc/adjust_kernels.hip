@@ -532,6 +532,51 @@ void launch_msr_stats(const double* wblk, const uint32_t* vec_wrow, const uint32
     hipLaunchKernelGGL(cluster_wb_kernel, dim3((n_vec * 3 + 255) / 256), dim3(256), 0, s, wblk, vec_wrow, vec_c0, vec_k, b, wb, n_vec);
     hipLaunchKernelGGL(msr_stats_kernel, dim3((n_vec + 255) / 256), dim3(256), 0, s, s1, s2, b, wb, S, nps, prec6, chi, n_vec);
 }
+// dna_adjust::UpdateIterationDiagnostics (ADJ:7450-7554), one block's visit: every station's correction of this iteration against the
+// correction the station was last seen with (the previous iteration -- or, for a station shared with an earlier block, that block's
+// visit in THIS iteration: the reference walks the blocks in order with one record per station).  Anti-parallel (cos < -0.5), similar in
+// size (ratio 0.3 ... 3), not both below a millimetre: the station's cycle count goes up, otherwise back to zero.  visit[s] = the count
+// where it has reached 2 (the host then keeps the history record), 0 elsewhere; *flagged counts those.  One thread per station; the
+// stations of a block are distinct, the blocks follow each other on one stream.
+__global__ void osc_update_kernel(const double* __restrict__ corr, const uint32_t* __restrict__ gidx, uint32_t n_stn, double* __restrict__ prev,
+                                  uint32_t* __restrict__ seen, uint32_t* __restrict__ cnt, uint32_t* __restrict__ visit, uint32_t* __restrict__ flagged) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_stn) return;
+    const uint32_t g = gidx[s];
+    const double cx = corr[3 * s], cy = corr[3 * s + 1], cz = corr[3 * s + 2];
+    visit[s] = 0;
+    if (!seen[g]) {
+        seen[g] = 1;
+        prev[3 * (size_t)g] = cx;
+        prev[3 * (size_t)g + 1] = cy;
+        prev[3 * (size_t)g + 2] = cz;
+        return;
+    }
+    const double px = prev[3 * (size_t)g], py = prev[3 * (size_t)g + 1], pz = prev[3 * (size_t)g + 2];
+    prev[3 * (size_t)g] = cx;
+    prev[3 * (size_t)g + 1] = cy;
+    prev[3 * (size_t)g + 2] = cz;
+    const double magCurr = sqrt(cx * cx + cy * cy + cz * cz), magPrev = sqrt(px * px + py * py + pz * pz);
+    if (magCurr < 0.001 && magPrev < 0.001) {
+        cnt[g] = 0;
+        return;
+    }
+    const double dot = cx * px + cy * py + cz * pz, denom = magCurr * magPrev;
+    const double cosAngle = denom > 1e-30 ? dot / denom : 0.0;
+    const double ratio = magPrev > 1e-30 ? magCurr / magPrev : 0.0;
+    uint32_t c = cnt[g];
+    c = (cosAngle < -0.5 && ratio > 0.3 && ratio < 3.0) ? c + 1 : 0;
+    cnt[g] = c;
+    if (c >= 2) {
+        visit[s] = c;
+        atomicAdd(flagged, 1u);
+    }
+}
+void launch_osc_update(const double* corr, const uint32_t* gidx, uint32_t n_stn, double* prev, uint32_t* seen, uint32_t* cnt, uint32_t* visit,
+                       uint32_t* flagged, hipStream_t s) {
+    if (n_stn) hipLaunchKernelGGL(osc_update_kernel, dim3((n_stn + 255) / 256), dim3(256), 0, s, corr, gidx, n_stn, prev, seen, cnt, visit, flagged);
+}
+
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s) {
     hipLaunchKernelGGL(update_estimates_kernel, dim3(1), dim3(1024), 0, s, xe, corr, n, out_val, out_idx);
 }

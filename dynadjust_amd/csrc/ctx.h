@@ -82,6 +82,8 @@ struct Block {
     struct DsEnt { uint64_t key; uint32_t pos, blk; };
     std::vector<DsEnt> h_ds_ents;
     // dnagpu_schur_carry: unknown order with the carried junction stations last, per junction list seen (forward / reverse)
+    double* corr_keep = nullptr;       // dnagpu_block_keep_corrections: a solution's corrections set aside (UpdateEstimatesFinal ADJ:3755)
+    uint32_t *osc_gidx = nullptr, *osc_visit = nullptr;   // dnagpu_osc_block: the stations' indices in the network, this iteration's visit record
     std::vector<uint32_t> h_schur_idx[2];
     uint32_t h_schur_nip[2] = {0, 0}, h_schur_npp[2] = {0, 0};      // (the padded orders the cached map was laid out for)
     uint32_t* schur_idx[2] = {};
@@ -140,6 +142,10 @@ struct dnagpu_ctx {
         double bytes;
         hipEvent_t e0, e1;
     };
+    // dnagpu_osc_*: per station of the network (UpdateIterationDiagnostics' corrPrev_ / stnOscCount_, ADJ:7472-7507)
+    double* osc_prev = nullptr;
+    uint32_t *osc_seen = nullptr, *osc_cnt = nullptr, *osc_flagged = nullptr;
+    size_t osc_stations = 0;
     bool hbm_profile = false;
     std::vector<HbmRec> hbm_recs[DNAGPU_NUM_CHAINS];
     std::vector<hipEvent_t> hbm_free[DNAGPU_NUM_CHAINS];

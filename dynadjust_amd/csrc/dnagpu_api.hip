@@ -233,7 +233,7 @@ void free_block(Block& b) {
     void* ptrs[] = {b.x_orig, b.x_rig, b.s1, b.s2, b.obs, b.Wblk,
                     b.vec_wrow, b.vec_c0, b.vec_k, b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc,
                     b.t_type, b.t_stn, b.t_blk0, b.t_vec0, b.t_val, b.t_pre, b.t_var, b.t_ih, b.t_th, b.s_llh, b.s_geoid, b.s_defl,
-                    b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1], b.schur_spos[0], b.schur_spos[1]};
+                    b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.osc_gidx, b.osc_visit, b.corr_keep, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1], b.schur_spos[0], b.schur_spos[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (void* p : b.retired) hipFree(p);
@@ -345,6 +345,15 @@ void dnagpu_destroy(dnagpu_ctx* ctx) {
         if (ctx->copy_stream[c]) hipStreamDestroy(ctx->copy_stream[c]);
     }
     if (ctx->bad_dev) hipFree(ctx->bad_dev);
+    for (void* p : {(void*)ctx->osc_prev, (void*)ctx->osc_seen, (void*)ctx->osc_cnt, (void*)ctx->osc_flagged})
+        if (p) hipFree(p);
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+        for (auto& r : ctx->hbm_recs[c]) {
+            hipEventDestroy(r.e0);
+            hipEventDestroy(r.e1);
+        }
+        for (hipEvent_t e : ctx->hbm_free[c]) hipEventDestroy(e);
+    }
     delete ctx;
 }
 
@@ -1513,10 +1522,92 @@ int dnagpu_block_msr_statistics(dnagpu_ctx* ctx, int chain, uint32_t blk, const 
 
 int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, double* corr) {
     CHK_CTX();
-    CHK_CHAIN();
     Block* b = find_block(ctx, blk);
+    if (chain < 0) {         // the corrections set aside by dnagpu_block_keep_corrections
+        if (!b || !b->corr_keep || (!corr && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_corrections: nothing kept");
+        return d2h(ctx, 0, corr, b->corr_keep, (size_t)b->n_stn * 3 * sizeof(double));
+    }
+    CHK_CHAIN();
     if (!b || (!corr && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_get_corrections: bad arguments");
     return d2h(ctx, chain, corr, b->corr[chain], (size_t)b->n_stn * 3 * sizeof(double));
+}
+
+/* ---- oscillation diagnostics (dna_adjust::UpdateIterationDiagnostics, ADJ:7450-7554) ---------------------------------------- */
+int dnagpu_osc_reset(dnagpu_ctx* ctx, size_t n_stations) {
+    CHK_CTX();
+    if (ctx->osc_stations != n_stations) {
+        HIPCHK(hipDeviceSynchronize());
+        for (void* p : {(void*)ctx->osc_prev, (void*)ctx->osc_seen, (void*)ctx->osc_cnt})
+            if (p) hipFree(p);
+        ctx->osc_prev = nullptr;
+        ctx->osc_seen = ctx->osc_cnt = nullptr;
+        ctx->osc_stations = 0;
+        if (n_stations) {
+            hipError_t e = dnagpu::poison_malloc(&ctx->osc_prev, 3 * n_stations * sizeof(double));
+            if (e == hipSuccess) e = dnagpu::poison_malloc(&ctx->osc_seen, n_stations * sizeof(uint32_t));
+            if (e == hipSuccess) e = dnagpu::poison_malloc(&ctx->osc_cnt, n_stations * sizeof(uint32_t));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, DNAGPU_ENOMEM, "oscillation diagnostics", e);
+            }
+            ctx->osc_stations = n_stations;
+        }
+    }
+    if (!ctx->osc_flagged) HIPCHK(dnagpu::poison_malloc(&ctx->osc_flagged, sizeof(uint32_t)));
+    hipStream_t st = ctx->stream[0];
+    if (n_stations) {
+        HIPCHK(hipMemsetAsync(ctx->osc_seen, 0, n_stations * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(ctx->osc_cnt, 0, n_stations * sizeof(uint32_t), st));
+    }
+    HIPCHK(hipMemsetAsync(ctx->osc_flagged, 0, sizeof(uint32_t), st));
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_keep_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !b->corr[chain]) return fail(ctx, DNAGPU_EINVAL, "block_keep_corrections: bad arguments");
+    if (!b->n_stn) return DNAGPU_OK;
+    if (!b->corr_keep) HIPCHK(dnagpu::poison_malloc(&b->corr_keep, (size_t)b->n_stn * 3 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(b->corr_keep, b->corr[chain], (size_t)b->n_stn * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
+    return DNAGPU_OK;
+}
+
+int dnagpu_osc_block(dnagpu_ctx* ctx, uint32_t blk, int corr_chain, const uint32_t* stations) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    const double* corr = !b ? nullptr : corr_chain < 0 ? b->corr_keep : corr_chain < DNAGPU_NUM_CHAINS ? b->corr[corr_chain] : nullptr;
+    if (!b || !corr || (!stations && b->n_stn) || !ctx->osc_flagged) return fail(ctx, DNAGPU_EINVAL, "osc_block: bad arguments");
+    hipStream_t st = ctx->stream[0];
+    if (!b->osc_gidx && b->n_stn) {
+        for (uint32_t s = 0; s < b->n_stn; ++s)
+            if (stations[s] >= ctx->osc_stations) return fail(ctx, DNAGPU_EINVAL, "osc_block: station out of range");
+        HIPCHK(dnagpu::poison_malloc(&b->osc_gidx, (size_t)b->n_stn * sizeof(uint32_t)));
+        HIPCHK(dnagpu::poison_malloc(&b->osc_visit, (size_t)b->n_stn * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(b->osc_gidx, stations, (size_t)b->n_stn * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    launch_osc_update(corr, b->osc_gidx, b->n_stn, ctx->osc_prev, ctx->osc_seen, ctx->osc_cnt, b->osc_visit, ctx->osc_flagged, st);
+    return DNAGPU_OK;
+}
+
+int dnagpu_osc_flagged(dnagpu_ctx* ctx, uint32_t* n_flagged) {
+    CHK_CTX();
+    if (!n_flagged || !ctx->osc_flagged) return fail(ctx, DNAGPU_EINVAL, "osc_flagged: bad arguments");
+    hipStream_t st = ctx->stream[0];
+    HIPCHK(hipMemcpyAsync(n_flagged, ctx->osc_flagged, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(ctx->osc_flagged, 0, sizeof(uint32_t), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DNAGPU_OK;
+}
+
+int dnagpu_osc_block_visits(dnagpu_ctx* ctx, uint32_t blk, uint32_t* visit) {
+    CHK_CTX();
+    Block* b = find_block(ctx, blk);
+    if (!b || !b->osc_visit || !visit) return fail(ctx, DNAGPU_EINVAL, "osc_block_visits: bad arguments");
+    HIPCHK(hipMemcpyAsync(visit, b->osc_visit, (size_t)b->n_stn * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream[0]));
+    HIPCHK(hipStreamSynchronize(ctx->stream[0]));
+    return DNAGPU_OK;
 }
 
 int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs) {

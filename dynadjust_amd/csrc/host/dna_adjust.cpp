@@ -49,19 +49,25 @@ void dna_adjust::FreeDevice() {
         if (b.red) dnagpu_matrix_destroy(ctx_, b.red);
         if (b.rig_host) (b.rig_on_device ? dnagpu_device_free : dnagpu_host_free)(ctx_, b.rig_host);
         b.rig_host = nullptr;
-        if (b.part) dnagpu_partial_destroy(ctx_, b.part);
+        if (b.part && !b.part_transient) dnagpu_partial_destroy(ctx_, b.part);
         b.part = nullptr;
+        for (dnagpu_partial*& tp : b.tpart) {
+            if (tp) dnagpu_partial_destroy(ctx_, tp);
+            tp = nullptr;
+        }
         b.jfwd = b.jrev = b.rigvar = b.finv = b.rinv = b.red = nullptr;
     }
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
         if (work_[c]) dnagpu_matrix_destroy(ctx_, work_[c]);
         if (kwork_[c]) dnagpu_matrix_destroy(ctx_, kwork_[c]);
-        work_[c] = kwork_[c] = nullptr;
+        if (tmpfac_[c]) dnagpu_matrix_destroy(ctx_, tmpfac_[c]);
+        work_[c] = kwork_[c] = tmpfac_[c] = nullptr;
         for (dnagpu_matrix* m : kbatch_[c]) dnagpu_matrix_destroy(ctx_, m);
         kbatch_[c].clear();
     }
     dnagpu_destroy(ctx_);
     ctx_ = nullptr;
+    osc_ready_ = false;
 }
 
 // ADJ:10049-10069
@@ -837,8 +843,11 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     batched_members_ = 0;
     batched_flops_ = 0.0;
     stageCopiedBytes_ = stageWaitNs_ = 0;
+    transient_count_ = 0;
     algorithmic_flops_ = 0.0;
     for (block_t& b : blocks_) b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
+    osc_ready_ = false;              // corrPrev_ / stnOscCount_ / oscHistory_ start empty (ADJ:2419-2421, 2584-2586)
+    oscHistory_.clear();
     const double t0 = now_ms();
     switch (projectSettings_.a.adjust_mode) {
         case SimultaneousMode: AdjustSimultaneous(); break;
@@ -879,6 +888,8 @@ void dna_adjust::AdjustSimultaneous() {
         UINT32 row = 0;
         Check(dnagpu_update_estimates(ctx_, c, 0, &mv, &row), 0, "AdjustSimultaneous()");
         maxCorr_ = mv;
+        B.corr_chain = c;
+        UpdateIterationDiagnostics();                   // (ADJ:2468)
         iterationCorrections_.push_back(maxCorr_);
         NoteIterationDone(it_t0);                       // the progress thread's message of this iteration (ADJ:2471-2472)
         bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
@@ -989,6 +1000,7 @@ void dna_adjust::AdjustPhased() {
             AdjustPhasedReverseCombine();
         }
         if (IsCancelled()) break;
+        UpdateIterationDiagnostics();                   // (ADJ:2631)
         iterationCorrections_.push_back(maxCorr_);
         NoteIterationDone(it_t0);
         bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
@@ -1074,6 +1086,7 @@ void dna_adjust::ResetAdjustment() {
         blocks_[b].has_rigvar = false;
         blocks_[b].has_finv = blocks_[b].has_rinv = blocks_[b].has_cinv = false;
         blocks_[b].inverse_kept = blocks_[b].inverse_pending = blocks_[b].part_valid = blocks_[b].rig_direct = blocks_[b].var_deferred = false;
+        blocks_[b].part_transient = false;
     }
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
     currentIteration_ = 0;
@@ -1539,37 +1552,195 @@ void dna_adjust::CloseOutputFiles() {
     if (printer_) printer_->Close();
 }
 
-// ADJ:7556: the reference keeps a history of stations whose corrections change sign from iteration to iteration (oscHistory_, filled by
-// UpdateIterationDiagnostics) and lists the worst twenty after an adjustment that did not converge.  The device path keeps no such
-// history (the corrections stay in HBM; only the largest one per iteration comes back): nothing is listed, which is also what
-// the reference prints for an adjustment that converged.
-void dna_adjust::PrintOscillationSummary() {}
+// dna_adjust::UpdateIterationDiagnostics (ADJ:7450-7554): after every iteration, block by block in order, every station's correction
+// against the one it was last seen with; a station whose corrections have turned round twice in a row with similar size is recorded
+// (first / last iteration, cycle count, first / last magnitude and the last correction in the local frame).  The comparison runs on the
+// device, where the corrections are (dnagpu_osc_block: osc_update_kernel, state per station of the network); the host keeps
+// oscHistory_ and only fetches a block's corrections when one of its visits was flagged -- none in an adjustment that converges.
+// Which corrections: those of the block's LAST solution, as in the reference's v_corrections_ -- under the reference's schedule
+// (a.schur_carry = 0, one chain) the same vectors, the last block's reverse solve "in isolation" included; under the condensed schedule
+// every block has one solution per iteration, the rigorous one.  Across GPUs every rank watches its own blocks.
+void dna_adjust::UpdateIterationDiagnostics() {
+    if (!ctx_ || blockCount_ == 0) return;
+    if (!osc_ready_) {
+        oscHistory_.clear();
+        Check(dnagpu_osc_reset(ctx_, bstBinaryRecords_.size()), 0, "UpdateIterationDiagnostics()");
+        osc_ready_ = true;
+    }
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        if (!OwnsBlock(b) || v_parameterStationList_[b].empty()) continue;
+        Check(dnagpu_osc_block(ctx_, b, blocks_[b].corr_chain, v_parameterStationList_[b].data()), b, "UpdateIterationDiagnostics()");
+    }
+    UINT32 flagged = 0;
+    Check(dnagpu_osc_flagged(ctx_, &flagged), 0, "UpdateIterationDiagnostics()");
+    if (!flagged) return;
+    std::vector<UINT32> visit;
+    std::vector<double> corr;
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        if (!OwnsBlock(b) || v_parameterStationList_[b].empty()) continue;
+        const std::vector<UINT32>& plist = v_parameterStationList_[b];
+        visit.resize(plist.size());
+        Check(dnagpu_osc_block_visits(ctx_, b, visit.data()), b, "UpdateIterationDiagnostics()");
+        bool any = false;
+        for (UINT32 v : visit) any = any || v != 0;
+        if (!any) continue;
+        corr.resize(3 * plist.size());
+        Check(dnagpu_block_get_corrections(ctx_, blocks_[b].corr_chain, b, corr.data()), b, "UpdateIterationDiagnostics()");
+        for (size_t s = 0; s < plist.size(); ++s) {
+            if (!visit[s]) continue;
+            const UINT32 stnIdx = plist[s];
+            // Rotate_CartLocal at the station's current position (ADJ:7511-7518)
+            double R[3][3];
+            geodesy::LocalToCartRotation(bstBinaryRecords_[stnIdx].currentLatitude, bstBinaryRecords_[stnIdx].currentLongitude, R);
+            double l[3];
+            for (int i = 0; i < 3; ++i) l[i] = R[0][i] * corr[3 * s] + R[1][i] * corr[3 * s + 1] + R[2][i] * corr[3 * s + 2];
+            const double localMag = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+            auto hit = oscHistory_.find(stnIdx);
+            if (hit == oscHistory_.end()) {
+                OscillationRecord rec;
+                rec.stnBstIdx = stnIdx;
+                rec.firstIteration = rec.lastIteration = currentIteration_;
+                rec.maxCycles = visit[s];
+                rec.firstMag = rec.lastMag = localMag;
+                rec.lastE = l[0];
+                rec.lastN = l[1];
+                rec.lastUp = l[2];
+                oscHistory_[stnIdx] = rec;
+            } else {
+                hit->second.lastIteration = currentIteration_;
+                hit->second.maxCycles = visit[s];
+                hit->second.lastMag = localMag;
+                hit->second.lastE = l[0];
+                hit->second.lastN = l[1];
+                hit->second.lastUp = l[2];
+            }
+        }
+    }
+}
 
-// ADJ:7652: the measurements whose N-statistic exceeds the critical value of the chosen confidence interval, largest first
+// ADJ:7556-7608: the twenty stations with the largest oscillation (0.1 m and more), in the reference's words
+void dna_adjust::PrintOscillationSummary(std::ostream& os) {
+    if (oscHistory_.empty()) return;
+    std::vector<const OscillationRecord*> sorted;
+    for (auto& kv : oscHistory_)
+        if (std::max(kv.second.firstMag, kv.second.lastMag) >= 0.1) sorted.push_back(&kv.second);
+    if (sorted.empty()) return;
+    std::stable_sort(sorted.begin(), sorted.end(), [](const OscillationRecord* a, const OscillationRecord* b) {
+        return std::max(a->firstMag, a->lastMag) > std::max(b->firstMag, b->lastMag);
+    });
+    const size_t limit = std::min(sorted.size(), (size_t)20);
+    os << std::endl;
+    os << "+ Oscillating stations detected (" << sorted.size() << " total, showing top " << limit << "):" << std::endl;
+    for (size_t i = 0; i < limit; ++i) {
+        const OscillationRecord* rec = sorted[i];
+        const double horizMag = std::sqrt(rec->lastE * rec->lastE + rec->lastN * rec->lastN), vertMag = std::fabs(rec->lastUp);
+        const char* direction = vertMag < 0.01 * horizMag ? "horizontal" : horizMag < 0.01 * vertMag ? "vertical" : "3D";
+        const station_t& st = bstBinaryRecords_.at(rec->stnBstIdx);
+        os << "  - " << std::string(st.stationName, strnlen(st.stationName, sizeof(st.stationName))) << std::fixed << std::setprecision(1) << " \xe2\x80\x94 "
+           << rec->firstMag << "m to " << rec->lastMag << "m" << ", " << direction << ", " << rec->maxCycles << " cycles" << " (iterations "
+           << rec->firstIteration << "-" << rec->lastIteration << ")" << std::endl;
+    }
+}
+
+// GetMsrStations (include/functions/dnatemplatestnmsrfuncs.hpp:70-131): the stations of the measurement a .bms record belongs to --
+// from its first-component records only (a G baseline's Y / Z rows name none), a cluster's from its beginning
+void dna_adjust::GetMsrStations(UINT32 msrIndex, std::vector<UINT32>& out) const {
+    out.clear();
+    const UINT32 id = bmsBinaryRecords_[msrIndex].clusterID;
+    size_t i = msrIndex;
+    bool cluster = false;
+    switch (bmsBinaryRecords_[msrIndex].measType) {
+        case 'D': case 'X': case 'Y':
+            while (i > 0 && bmsBinaryRecords_[i - 1].clusterID == id) --i;
+            cluster = true;
+            break;
+        default: break;
+    }
+    while (i < bmsBinaryRecords_.size() && bmsBinaryRecords_[i].clusterID == id) {
+        const measurement_t& m = bmsBinaryRecords_[i];
+        if (m.measType != 'D' && m.measStart != 0) {
+            ++i;
+            continue;
+        }
+        out.push_back(m.station1);
+        const char t = m.measType;
+        const bool one = t == 'H' || t == 'I' || t == 'J' || t == 'P' || t == 'Q' || t == 'R' || t == 'Y';
+        if (!one) out.push_back(m.station2);
+        if (t == 'A') out.push_back(m.station3);
+        if (!cluster) break;
+        ++i;
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+bool dna_adjust::MeasurementTouchesOscillatingStation(UINT32 msrIndex) const {
+    if (oscHistory_.empty() || msrIndex >= bmsBinaryRecords_.size()) return false;
+    std::vector<UINT32> stns;
+    GetMsrStations(msrIndex, stns);
+    for (UINT32 s : stns)
+        if (oscHistory_.count(s)) return true;
+    return false;
+}
+
+std::string dna_adjust::MeasurementStationNames(UINT32 msrIndex) const {
+    if (msrIndex >= bmsBinaryRecords_.size()) return "(measurement index unavailable)";
+    std::vector<UINT32> stns;
+    GetMsrStations(msrIndex, stns);
+    std::string names;
+    for (UINT32 s : stns) {
+        if (s >= bstBinaryRecords_.size()) continue;
+        if (!names.empty()) names += " -> ";
+        names += std::string(bstBinaryRecords_[s].stationName, strnlen(bstBinaryRecords_[s].stationName, sizeof(bstBinaryRecords_[s].stationName)));
+    }
+    return names.empty() ? "(stations unavailable)" : names;
+}
+
+// ADJ:7652-7780: the measurements tied to an oscillating station, then those whose N-statistic exceeds the critical value of the chosen
+// confidence interval, each list by |N-stat| (ties by record), `limit` lines each, in the reference's words
 void dna_adjust::PrintSuspectMeasurementSummary(std::ostream& os, size_t limit) const {
     if (bmsBinaryRecords_.empty() || limit == 0) return;
-    std::vector<UINT32> idx;
+    struct rec_t {
+        UINT32 idx;
+        double absN;
+        bool critical, osc;
+    };
+    std::vector<rec_t> osc, out;
     for (UINT32 i = 0; i < bmsBinaryRecords_.size(); ++i) {
         const measurement_t& m = bmsBinaryRecords_[i];
-        if (m.ignore || m.measStart > 2 || !std::isfinite(m.NStat) || !std::isfinite(m.residualPrec) || m.residualPrec <= 0.0) continue;
-        if (std::fabs(m.NStat) > criticalValue_) idx.push_back(i);
+        if (m.ignore || !std::isfinite(m.NStat) || !std::isfinite(m.residualPrec) || m.residualPrec <= 0.0) continue;
+        const double absN = std::fabs(m.NStat);
+        const bool critical = absN > criticalValue_, touches = MeasurementTouchesOscillatingStation(i);
+        if (!critical && !touches) continue;
+        if (touches) osc.push_back({i, absN, critical, true});
+        if (critical && !touches) out.push_back({i, absN, true, false});
     }
-    if (idx.empty()) return;
-    std::sort(idx.begin(), idx.end(), [&](UINT32 x, UINT32 y) { return std::fabs(bmsBinaryRecords_[x].NStat) > std::fabs(bmsBinaryRecords_[y].NStat); });
-    const size_t shown = std::min(limit, idx.size());
-    auto name = [&](UINT32 s) {
-        return s < bstBinaryRecords_.size() ? std::string(bstBinaryRecords_[s].stationName, strnlen(bstBinaryRecords_[s].stationName, sizeof(bstBinaryRecords_[s].stationName)))
-                                            : std::string("-");
+    if (osc.empty() && out.empty()) return;
+    auto by_nstat = [](const rec_t& a, const rec_t& b) { return a.absN == b.absN ? a.idx < b.idx : a.absN > b.absN; };
+    std::sort(osc.begin(), osc.end(), by_nstat);
+    std::sort(out.begin(), out.end(), by_nstat);
+    const std::ios::fmtflags flags = os.flags();
+    const std::streamsize prec = os.precision();
+    auto print_list = [&](const std::string& title, const std::vector<rec_t>& list) {
+        if (list.empty()) return;
+        const size_t shown = std::min(list.size(), limit);
+        os << std::endl << "+ " << title << " (" << list.size() << " total, showing top " << shown << "):" << std::endl;
+        for (size_t k = 0; k < shown; ++k) {
+            const measurement_t& m = bmsBinaryRecords_[list[k].idx];
+            os << "  - " << m.measType << " msr " << list[k].idx << " cluster " << m.clusterID << " file-order " << m.fileOrder << " "
+               << MeasurementStationNames(list[k].idx) << ": N=" << std::fixed << std::setprecision(2) << m.NStat;
+            if (std::isfinite(m.TStat) && std::fabs(m.TStat) > 0.0) os << ", T=" << std::fixed << std::setprecision(2) << m.TStat;
+            os << ", corr=" << std::scientific << std::setprecision(3) << m.measCorr << ", residual precision=" << std::scientific << std::setprecision(3)
+               << m.residualPrec << ", Pelzer=" << std::fixed << std::setprecision(2) << m.PelzerRel;
+            if (list[k].critical) os << ", exceeds critical";
+            if (list[k].osc) os << ", touches oscillating station";
+            os << std::endl;
+        }
     };
-    os << std::endl << "+ Suspect measurements (" << idx.size() << " exceed the critical value " << std::fixed << std::setprecision(2) << criticalValue_ << ", showing top " << shown
-       << "):" << std::endl;
-    for (size_t k = 0; k < shown; ++k) {
-        const measurement_t& m = bmsBinaryRecords_[idx[k]];
-        os << "  - " << m.measType << " " << name(m.station1);
-        if (m.measType != 'Y' && m.measType != 'H' && m.measType != 'R' && m.measType != 'I' && m.measType != 'J' && m.measType != 'P' && m.measType != 'Q') os << " -> " << name(m.station2);
-        os << std::fixed << std::setprecision(2) << ", N-stat " << m.NStat << std::setprecision(4) << ", correction " << m.measCorr << ", Pelzer " << std::setprecision(2) << m.PelzerRel
-           << std::endl;
-    }
+    print_list("Suspect measurements connected to oscillating stations", osc);
+    print_list(osc.empty() ? "Largest measurement N-statistics" : "Largest remaining measurement N-statistics", out);
+    os.flags(flags);
+    os.precision(prec);
 }
 
 std::string dna_adjust::GetIterationTime(const UINT32& iteration) const {

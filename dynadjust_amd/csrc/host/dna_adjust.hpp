@@ -9,6 +9,7 @@
 #include <cmath>
 #include <deque>
 #include <iostream>
+#include <map>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -108,7 +109,13 @@ public:
     std::string GetMaxCorrection(const UINT32& iteration) const;
     // dnaadjust.hpp:277 / :294-296 -- see dna_printer.hpp for what stands behind the printer
     DynAdjustPrinter* GetPrinter();
-    void PrintOscillationSummary();
+    void PrintOscillationSummary(std::ostream& os = std::cout);
+    // the stations UpdateIterationDiagnostics has recorded so far (dnaadjust.hpp:1277-1288 OscillationRecord), keyed by .bst index
+    struct OscillationRecord {
+        UINT32 stnBstIdx, firstIteration, lastIteration, maxCycles;
+        double firstMag, lastMag, lastE, lastN, lastUp;
+    };
+    const std::map<UINT32, OscillationRecord>& OscillationHistory() const { return oscHistory_; }
     void PrintSuspectMeasurementSummary(std::ostream& os = std::cout, size_t limit = 20) const;
     bool NewMessagesAvailable();
     bool GetMessageIteration(UINT32& iteration);
@@ -215,9 +222,13 @@ private:
         std::vector<UINT32> c_prev, c_next;   // jslprev_here / jsl_here as positions in keep (same order as those lists)
         constraint_list con_inner;            // constraints of the eliminated stations (first appearance in both directions)
         constraint_list ccon_fwd, ccon_rev, ccon_cmb;   // con_fwd / con_rev / con_cmb of the kept stations, positions in keep
+        int corr_chain = 0;                   // the chain whose corrections vector holds the block's last solution (UpdateIterationDiagnostics)
         dnagpu_partial* part = nullptr;       // a.keep_factors: the condensing step's factor, completed by the rigorous solve
         UINT32 shape_ni = 0, shape_nk = 0;    // the padded orders it is eliminated in: its own, or its bucket's (AssignBatchShapes)
         bool part_allowed = false, part_valid = false;
+        // a block the HBM budget denies a kept factor: its factor is made again where it is needed, in the chain's own storage (tmpfac_)
+        bool part_transient = false;
+        dnagpu_partial* tpart[DNAGPU_NUM_CHAINS] = {};
         bool var_deferred = false;            // a.defer_variances: this iteration's inverse exists as the completed factor in `part` only
         bool part_spine = false;              // a.defer_variances = 2: the kept factor in its light form (dnagpu_partial_create_spine)
         bool part_in_rigvar = false;          // the factor's inverse waits in rigvar's storage (dnagpu_partial_create_in): rigvar has n + 256
@@ -420,13 +431,19 @@ private:
     bool condensed_ok_ = false;
     // a.stage (the reference's --staged-adjustment keeps its block matrices in memory-mapped files): the rigorous variance
     // matrices live in page-locked host memory instead of HBM; switched on by itself when they would not fit
+    std::map<UINT32, OscillationRecord> oscHistory_;
+    bool osc_ready_ = false;
+    void UpdateIterationDiagnostics();
+    bool MeasurementTouchesOscillatingStation(UINT32 msrIndex) const;
+    void GetMsrStations(UINT32 msrIndex, std::vector<UINT32>& out) const;
+    std::string MeasurementStationNames(UINT32 msrIndex) const;
     bool staged_ = false;
     double host_available_ = 0.0;                               // what the host could still give when the plan was made (HostMemoryAvailable)
     size_t stage_host_bytes_ = 0, stage_device_bytes_ = 0;    // the staged store's plan: packed variance matrices in host / device memory
     bool Staged() const { return staged_; }
 public:
     bool IsStaged() const { return staged_; }
-    void MemoryPlan(double out[8]) const;
+    void MemoryPlan(double out[10]) const;
 private:
     std::vector<unsigned char> record_touched_;   // records whose statistics this process computed (UpdateMsrRecord)
     std::atomic<bool> chain_failed_{false};
@@ -515,6 +532,12 @@ private:
     dnagpu_ctx* ctx_ = nullptr;
     dnagpu_matrix* work_[DNAGPU_NUM_CHAINS] = {};
     dnagpu_matrix* kwork_[DNAGPU_NUM_CHAINS] = {};   // the kept block of a fused rigorous solve
+    dnagpu_matrix* tmpfac_[DNAGPU_NUM_CHAINS] = {};  // storage of the factor a block without a kept one makes again (TransientPartial), per chain
+    bool transient_ok_ = false;                      // PrepareCondensedBlocks: such blocks exist and the conditions hold (GNSS only, light factors)
+    std::atomic<uint64_t> transient_count_{0};
+    dnagpu_partial* TransientPartial(int c, UINT32 k);
+    bool BorrowTransientFactor(int c, UINT32 k);
+    void FinishVariancesTransient(int c, UINT32 k);
     UINT32 max_unknowns_ = 0, max_junction_ = 0;
 };
 

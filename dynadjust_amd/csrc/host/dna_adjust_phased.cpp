@@ -127,6 +127,9 @@ double dna_adjust::PhasedForwardBlock(int c, UINT32 k) {
     if (meta._blockLast || meta._blockIsolated) {
         // the forward result of the last block is rigorous (ADJ:3033-3057)
         PhasedNoteCorrection(mv);
+        // (these corrections are the block's result; a reverse solve of the same block may follow on this chain: set aside, ADJ:3755)
+        Check(dnagpu_block_keep_corrections(ctx_, c, k), k, "UpdateEstimatesForward()");
+        B.corr_chain = -1;
         Check(dnagpu_block_copy_stations(ctx_, c, k, 2, 1), k, "UpdateEstimatesForward()");
         StoreRigorousVariances(c, k, W);
         Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesForward()");      // (like PhasedFinaliseBlock: other chains read the rigorous results next)
@@ -179,6 +182,7 @@ double dna_adjust::PhasedReverseBlock(int c, UINT32 k) {
     B.has_rinv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
+    if (meta._blockFirst) B.corr_chain = c;       // (a first block's reverse solution is its result; the others' is only carried on)
     Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesReverse()");
     if (!meta._blockFirst && fwd_in) {
         Check(dnagpu_junction_gather(ctx_, c, k, reuse ? nullptr : W, B.jslprev_here.data(), B.jslprev_here.size(), blocks_[k - 1].jrev), k,
@@ -224,6 +228,7 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     B.has_cinv = ReuseInverses();
     double mv = 0.0;
     UINT32 row = 0;
+    B.corr_chain = c;
     Check(dnagpu_update_estimates(ctx_, c, k, &mv, &row), k, "UpdateEstimatesCombine()");
     return mv;
 }
@@ -497,7 +502,7 @@ void dna_adjust::DecideStaging() {
     }
 }
 
-void dna_adjust::MemoryPlan(double out[8]) const {
+void dna_adjust::MemoryPlan(double out[10]) const {
     out[0] = (double)stage_host_bytes_;
     out[1] = (double)stage_device_bytes_;
     out[2] = out[3] = 0.0;
@@ -510,6 +515,8 @@ void dna_adjust::MemoryPlan(double out[8]) const {
     out[5] = host_available_;
     out[6] = (double)stageCopiedBytes_.load();
     out[7] = (double)stageWaitNs_.load() / 1.0e6;
+    out[8] = (double)transient_count_.load();
+    out[9] = transient_ok_ ? 1.0 : 0.0;
 }
 
 // lists for the condensed schedule; condensed_ok_ = false falls back to the block-level chains
@@ -609,6 +616,24 @@ void dna_adjust::PrepareCondensedBlocks() {
         if (OwnsBlock(k)) rig += sq(3.0 * (double)v_parameterStationList_[k].size());
     later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? (double)stage_device_bytes_ : rig);
     double budget = (double)free_b - later;
+    if (const char* e = getenv("DNAGPU_FACTOR_BUDGET_GB")) budget = atof(e) * 1.0e9;      // (test hook: the memory-tight plans at any size)
+    // Blocks the budget denies a kept factor do not fall back to an inverse per iteration any more (n^3, and its copy to the staged store):
+    // in a GNSS-only network the normals of an iteration can be formed and eliminated AGAIN where the factor is needed -- in the rigorous
+    // solve, and once more for the variance matrix after the last iteration -- into one matrix per chain (0.36 n^3 each time instead of n^3;
+    // cfg4 on one GPU: 121 of 128 blocks).  Terrestrial networks keep the old fallback (their normals move with the estimates).
+    transient_ok_ = false;
+    {
+        double all = 0.0;
+        const bool spine_default = DeferVariances() && projectSettings_.a.defer_variances >= 2;
+        for (UINT32 k = 0; k < blockCount_; ++k)
+            if (OwnsBlock(k) && !blocks_[k].keep.empty())
+                all += (lend && !blocks_[k].rigvar) ? 2.0 * 256.0 * (3.0 * (double)v_parameterStationList_[k].size() + 512.0) * 8.0 : sq(3.0 * (double)v_parameterStationList_[k].size());
+        static const bool off = getenv("DNAGPU_TRANSIENT_FACTORS") && atoi(getenv("DNAGPU_TRANSIENT_FACTORS")) == 0;
+        if (all > budget && spine_default && !containsNonGPS_ && !ReuseRequested() && !off) {
+            transient_ok_ = true;
+            budget -= (double)NumChains() * sq((double)max_unknowns_);
+        }
+    }
     for (UINT32 k = 0; k < blockCount_; ++k) {
         block_t& B = blocks_[k];
         if (B.keep.empty() || !OwnsBlock(k)) continue;      // (a block is condensed and completed on its owner's GPU only)
@@ -625,6 +650,9 @@ void dna_adjust::PrepareCondensedBlocks() {
         B.part_spine = spine;
         max_keep = std::max(max_keep, B.keep.size());
     }
+    if (transient_ok_)
+        for (UINT32 k = 0; k < blockCount_; ++k)
+            if (OwnsBlock(k)) max_keep = std::max(max_keep, blocks_[k].keep.size());
     const int chains = NumChains();
     if (max_keep)
         for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &kwork_[c]), 0, "PrepareAdjustment(): kept-block work matrix");
@@ -642,6 +670,7 @@ void dna_adjust::PrepareCondensedBlocks() {
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
     B.rig_direct = false;
+    B.part_transient = false;
     B.var_deferred = false;         // (a factor left from the previous iteration is overwritten by this one's)
     B.prefactored = false;
     if (B.keep.empty()) return;
@@ -982,11 +1011,18 @@ void dna_adjust::RigorousBatch(int c, const std::vector<UINT32>& ks) {
 
 // a.defer_variances: X^T X for every block whose last rigorous solve left its inverse as a completed factor
 void dna_adjust::FinishDeferredVariances() {
-    std::vector<UINT32> todo;
-    for (UINT32 k = 0; k < blockCount_; ++k)
-        if (OwnsBlock(k) && blocks_[k].var_deferred && blocks_[k].part) todo.push_back(k);
-    if (todo.empty()) return;
+    std::vector<UINT32> todo, again;
+    for (UINT32 k = 0; k < blockCount_; ++k) {
+        if (!OwnsBlock(k) || !blocks_[k].var_deferred) continue;
+        if (blocks_[k].part)
+            todo.push_back(k);
+        else if (blocks_[k].part_transient)
+            again.push_back(k);
+    }
+    if (todo.empty() && again.empty()) return;
     FinishStagedCopies();
+    if (!again.empty()) ForBlocks(again, [&](int c, UINT32 k) { FinishVariancesTransient(c, k); });
+    if (todo.empty()) return;
     ForGroups(BatchGroups(todo, 2), [&](int c, const std::vector<UINT32>& ks) {
         // (staged adjustments keep this phase per block: a block's copy to host memory then overlaps the next block's products --
         //  measured with the members' inverses produced together and copied afterwards: 2.77 s per cfg3 step against 2.58 s)
@@ -1082,13 +1118,89 @@ void dna_adjust::CondensedReverseBlock(int c, UINT32 k) {
     CarryByElimination(c, cb, k, W, B.c_prev, blocks_[k - 1].jrev);
 }
 
+// the factor of a block that keeps none, in chain c's storage (a descriptor per block and chain: the capacity is the block's own shape)
+dnagpu_partial* dna_adjust::TransientPartial(int c, UINT32 k) {
+    block_t& B = blocks_[k];
+    std::lock_guard<std::mutex> lk(alloc_mutex_);
+    if (!tmpfac_[c] && dnagpu_matrix_create(ctx_, max_unknowns_ + 256, &tmpfac_[c]) != DNAGPU_OK) {
+        tmpfac_[c] = nullptr;
+        return nullptr;
+    }
+    if (!B.tpart[c]) {
+        const UINT32 n = (UINT32)v_parameterStationList_[k].size() * 3, nk = (UINT32)B.keep.size() * 3;
+        if (dnagpu_partial_create_spine(ctx_, n, nk, tmpfac_[c], &B.tpart[c]) != DNAGPU_OK) B.tpart[c] = nullptr;
+    }
+    return B.tpart[c];
+}
+
+// block k keeps no factor: form and eliminate its normals again, on this chain, and lend the result to the rigorous solve
+bool dna_adjust::BorrowTransientFactor(int c, UINT32 k) {
+    block_t& B = blocks_[k];
+    if (!transient_ok_ || B.part || B.keep.empty() || B.keep.size() >= v_parameterStationList_[k].size() || !CondensedSchedule()) return false;
+    dnagpu_partial* tp = TransientPartial(c, k);
+    if (!tp) return false;
+    Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+    Check(dnagpu_block_form_reduce(ctx_, c, k, B.con_inner.stn.data(), B.con_inner.w9.data(), B.con_inner.stn.size(), B.keep.data(), B.keep.size(), B.red, tp), k,
+          "Solve()");
+    B.part = tp;
+    B.part_spine = true;
+    B.part_valid = true;
+    B.part_transient = true;
+    const double nk = 3.0 * (double)B.keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;      // (work this schedule needs: the factor made a second time)
+    transient_count_++;
+    return true;
+}
+
 double dna_adjust::RigorousBlock(int c, UINT32 k) {
     const blockMeta_t& meta = v_blockMeta_[k];
+    block_t& B = blocks_[k];
+    const bool borrowed = BorrowTransientFactor(c, k);
+    struct give_back {
+        block_t& B;
+        bool on;
+        ~give_back() {
+            if (!on) return;
+            B.part = nullptr;          // (the chain's storage goes to the next block; B.var_deferred says the variance matrix is still owed)
+            B.part_valid = false;
+            B.part_spine = false;
+        }
+    } guard{B, borrowed};
     if (meta._blockLast || meta._blockIsolated) return PhasedForwardBlock(c, k);   // notes its correction and stores the variances itself
     double mv = meta._blockFirst ? PhasedReverseBlock(c, k) : PhasedCombineBlock(c, k);
     PhasedNoteCorrection(mv);
     PhasedFinaliseBlock(c, k);
     return mv;
+}
+
+// the variance matrix of a block whose last rigorous solve borrowed its factor: the factor once more, completed and inverted
+void dna_adjust::FinishVariancesTransient(int c, UINT32 k) {
+    block_t& B = blocks_[k];
+    const blockMeta_t& meta = v_blockMeta_[k];
+    if (!BorrowTransientFactor(c, k)) SignalExceptionAdjustment("UpdateEstimatesFinal(): no memory for the block's factor.", k);
+    const int kind = (meta._blockLast || meta._blockIsolated) ? 0 : meta._blockFirst ? 1 : 2;
+    dnagpu_matrix* K = kwork_[c];
+    PrepareKeptBlock(c, k, kind, K);
+    Check(dnagpu_partial_complete_factor(ctx_, c, B.part, K), k, "Solve()");
+    dnagpu_matrix* W = work_[c];
+    if (!Staged()) {
+        if (!B.rigvar) {
+            std::lock_guard<std::mutex> lk(alloc_mutex_);
+            Check(dnagpu_matrix_create(ctx_, RigvarCapacity(k), &B.rigvar), k, "rigorous variance matrix");
+        }
+        W = B.rigvar;
+    }
+    Check(dnagpu_partial_finish(ctx_, c, B.part, W), k, "Solve()");
+    B.part = nullptr;
+    B.part_valid = false;
+    B.part_spine = false;
+    B.var_deferred = false;
+    StoreRigorousVariances(c, k, W);
+    Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
+    const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    algorithmic_flops_ += nk * nk * nk * 2.0 / 3.0 + n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
 }
 
 // body(chain) on every chain in use (a.multi_thread: two host threads, one per chain); the first exception is rethrown
@@ -1222,6 +1334,7 @@ void dna_adjust::PhasedBeginIteration() {
 }
 
 bool dna_adjust::PhasedEndIteration() {
+    UpdateIterationDiagnostics();
     iterationCorrections_.push_back(maxCorr_);
     // (across GPUs only a cancellation every rank has agreed on ends the loop: the next collective needs all of them)
     const bool cancelled = Distributed() ? cancel_agreed_ : IsCancelled();

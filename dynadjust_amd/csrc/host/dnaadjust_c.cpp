@@ -494,7 +494,37 @@ int dnaadj_phased_finish(dnaadj_handle* h, int* status) {
 int dnaadj_staged(const dnaadj_handle* h) { return (h && h->adj && h->adj->IsStaged()) ? 1 : 0; }
 void dnaadj_dist_set_timeout(double seconds) { dynadjust::networkadjust::dist_set_collective_timeout(seconds); }
 void dnaadj_debug_stall_rank(int rank, long nth_agreement, double seconds) { dynadjust::networkadjust::debug_stall_rank(rank, nth_agreement, seconds); }
-int dnaadj_memory_plan(const dnaadj_handle* h, double out[8]) {
+size_t dnaadj_oscillation_history(const dnaadj_handle* h, double* out9, size_t cap_records) {
+    if (!h || !h->adj) return 0;
+    size_t i = 0;
+    for (const auto& kv : h->adj->OscillationHistory()) {
+        if (out9 && i < cap_records) {
+            const auto& r = kv.second;
+            const double v[9] = {(double)r.stnBstIdx, (double)r.firstIteration, (double)r.lastIteration, (double)r.maxCycles, r.firstMag, r.lastMag, r.lastE, r.lastN, r.lastUp};
+            std::copy(v, v + 9, out9 + 9 * i);
+        }
+        ++i;
+    }
+    return i;
+}
+size_t dnaadj_summaries(dnaadj_handle* h, size_t limit, char* buf, size_t cap) {
+    if (!h || !h->adj) return 0;
+    std::ostringstream os;
+    try {
+        h->adj->PrintOscillationSummary(os);
+        h->adj->PrintSuspectMeasurementSummary(os, limit);
+    } catch (...) {
+        return 0;
+    }
+    const std::string s = os.str();
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
+}
+int dnaadj_memory_plan(const dnaadj_handle* h, double out[10]) {
     if (!h || !h->adj || !out) return -1;
     h->adj->MemoryPlan(out);
     return 0;

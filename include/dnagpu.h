@@ -286,6 +286,20 @@ int dnagpu_solve_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, const dna
 /* estimated += corrections; returns the correction of largest magnitude (signed) and its row */
 int dnagpu_update_estimates(dnagpu_ctx* ctx, int chain, uint32_t blk, double* max_corr, uint32_t* max_row);
 int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, double* corr);
+/* Oscillation diagnostics (dna_adjust::UpdateIterationDiagnostics, ADJ:7450-7554): per station of the network the correction it was last
+ * seen with and its count of consecutive anti-parallel corrections of similar size stay on the device (corrPrev_ / stnOscCount_).
+ * dnagpu_osc_reset: n_stations records, all unseen (start of an adjustment).  dnagpu_osc_block: one block's visit of this iteration --
+ * its corrections of chain `corr_chain` against the records of its stations (`stations`: their indices in the network, kept after the
+ * first call), on chain 0's stream; call the blocks in order.  dnagpu_osc_flagged: how many visits since the last call found a count of
+ * 2 or more (and resets that counter; synchronises).  dnagpu_osc_block_visits: per station of the block the count where it is >= 2, else 0.
+ * A block's corrections can be set aside (dnagpu_block_keep_corrections: a copy on the chain's stream) where a later solve of the same
+ * block on the same chain would overwrite them -- the reference restores the last block's forward corrections after its reverse solve
+ * (UpdateEstimatesFinal, ADJ:3755); corr_chain / chain = -1 names the copy in dnagpu_osc_block / dnagpu_block_get_corrections. */
+int dnagpu_block_keep_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk);
+int dnagpu_osc_reset(dnagpu_ctx* ctx, size_t n_stations);
+int dnagpu_osc_block(dnagpu_ctx* ctx, uint32_t blk, int corr_chain, const uint32_t* stations);
+int dnagpu_osc_flagged(dnagpu_ctx* ctx, uint32_t* n_flagged);
+int dnagpu_osc_block_visits(dnagpu_ctx* ctx, uint32_t blk, uint32_t* visit);
 int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs);
 
 /* ---- junction carry -------------------------------------------------------- */

@@ -476,6 +476,13 @@ struct orc_adjustment {
     double* t_corr;              /* preAdjCorr */
     double* geo;                 /* lat, lon, h per station: the bst "current" geodetic coordinates */
     double* tm_field[8];
+    /* UpdateIterationDiagnostics (ADJ:7450): corrPrev_ / stnOscCount_ / oscHistory_ (dnaadjust.hpp:1274-1288), per station of the network */
+    double* osc_prev;
+    uint8_t* osc_seen;
+    uint32_t* osc_cnt;
+    int32_t* osc_slot;           /* station -> record in osc_hist, -1 = none */
+    orc_osc_record* osc_hist;
+    uint32_t n_osc;
     char err[512];
 };
 
@@ -1361,6 +1368,7 @@ void orc_adjust_destroy(orc_adjustment* a) {
         free(B->trow);
     }
     free(a->t_val); free(a->t_pre); free(a->t_corr); free(a->geo);
+    free(a->osc_prev); free(a->osc_seen); free(a->osc_cnt); free(a->osc_slot); free(a->osc_hist);
     for (int f = 0; f < 8; ++f) free(a->tm_field[f]);
     for (int f = 0; f < 7; ++f) free(a->msr_field[f]);
     free(a->blk);
@@ -1539,6 +1547,73 @@ int orc_adjust_prepare(orc_adjustment* a) {
 }
 
 /* AdjustSimultaneous (ADJ:2413-2511) for a GNSS-only network */
+/* dna_adjust::UpdateIterationDiagnostics (ADJ:7450-7554): block by block, station by station, the correction of this iteration against the
+ * one the station was last seen with; two anti-parallel turns of similar size in a row make a record.  The reference keeps the last
+ * correction of a record in the station's local frame (Rotate_CartLocal at the .bst position); the magnitudes are those of the same
+ * vector, so the record here holds the cartesian correction and the tests rotate. */
+static int update_iteration_diagnostics(orc_adjustment* a) {
+    const uint32_t ns = a->net.n_stations;
+    if (!a->osc_prev) {
+        a->osc_prev = (double*)calloc(3 * (size_t)ns + 1, sizeof(double));
+        a->osc_seen = (uint8_t*)calloc((size_t)ns + 1, 1);
+        a->osc_cnt = (uint32_t*)calloc((size_t)ns + 1, sizeof(uint32_t));
+        a->osc_slot = (int32_t*)malloc(((size_t)ns + 1) * sizeof(int32_t));
+        a->osc_hist = (orc_osc_record*)calloc((size_t)ns + 1, sizeof(orc_osc_record));
+        if (!a->osc_prev || !a->osc_seen || !a->osc_cnt || !a->osc_slot || !a->osc_hist) return -1;
+        for (uint32_t s = 0; s < ns; ++s) a->osc_slot[s] = -1;
+    }
+    for (uint32_t b = 0; b < a->n_blocks; ++b) {
+        const blk_t* B = &a->blk[b];
+        for (uint32_t s = 0; s < B->n_stn; ++s) {
+            const uint32_t g = B->stations[s];
+            const double cx = B->corr[3 * s], cy = B->corr[3 * s + 1], cz = B->corr[3 * s + 2];
+            const double magCurr = sqrt(cx * cx + cy * cy + cz * cz);
+            double* p = &a->osc_prev[3 * (size_t)g];
+            if (!a->osc_seen[g]) {                                   /* first time seeing this station: store and move on */
+                a->osc_seen[g] = 1;
+                p[0] = cx; p[1] = cy; p[2] = cz;
+                continue;
+            }
+            const double px = p[0], py = p[1], pz = p[2];
+            const double magPrev = sqrt(px * px + py * py + pz * pz);
+            p[0] = cx; p[1] = cy; p[2] = cz;
+            if (magCurr < 0.001 && magPrev < 0.001) {                /* sub-millimetre */
+                a->osc_cnt[g] = 0;
+                continue;
+            }
+            const double dot = cx * px + cy * py + cz * pz, denom = magCurr * magPrev;
+            const double cosAngle = denom > 1e-30 ? dot / denom : 0.0;
+            const double ratio = magPrev > 1e-30 ? magCurr / magPrev : 0.0;
+            if (cosAngle < -0.5 && ratio > 0.3 && ratio < 3.0)
+                a->osc_cnt[g]++;
+            else
+                a->osc_cnt[g] = 0;
+            if (a->osc_cnt[g] >= 2) {
+                orc_osc_record* r;
+                if (a->osc_slot[g] < 0) {
+                    a->osc_slot[g] = (int32_t)a->n_osc;
+                    r = &a->osc_hist[a->n_osc++];
+                    r->station = g;
+                    r->first_iteration = a->iterations;
+                    r->first_mag = magCurr;
+                } else {
+                    r = &a->osc_hist[a->osc_slot[g]];
+                }
+                r->last_iteration = a->iterations;
+                r->cycles = a->osc_cnt[g];
+                r->last_mag = magCurr;
+                r->cx = cx; r->cy = cy; r->cz = cz;
+            }
+        }
+    }
+    return 0;
+}
+
+uint32_t orc_adjust_oscillation_history(const orc_adjustment* a, orc_osc_record* out, uint32_t cap) {
+    for (uint32_t i = 0; out && i < a->n_osc && i < cap; ++i) out[i] = a->osc_hist[i];
+    return a->n_osc;
+}
+
 static int adjust_simultaneous(orc_adjustment* a) {
     blk_t* B = &a->blk[0];
     a->iterations = 0;
@@ -1547,6 +1622,7 @@ static int adjust_simultaneous(orc_adjustment* a) {
         if (solve(a, B, a->iterations < 2 || a->n_tm, 0)) return ORC_ADJUST_EXCEPTION_RAISED;   /* ADJ:2457 */
         for (uint32_t k = 0; k < B->n; ++k) B->est[k] += B->corr[k];                      /* ADJ:2463 */
         a->maxCorr = max_value(B->corr, B->n);                                            /* ADJ:2466 */
+        if (update_iteration_diagnostics(a)) return ORC_ADJUST_EXCEPTION_RAISED;          /* ADJ:2468 */
         if (a->iterations <= 64) a->max_corr_hist[a->iterations - 1] = a->maxCorr;
         if (!(fabs(a->maxCorr) > a->set.iteration_threshold)) break;                      /* ADJ:2477 */
         int last = (i + 1 >= a->set.max_iterations);
@@ -1699,6 +1775,7 @@ static int adjust_phased(orc_adjustment* a) {
         a->iterations++;
         if (phased_forward(a)) return ORC_ADJUST_EXCEPTION_RAISED;
         if (phased_reverse_combine(a)) return ORC_ADJUST_EXCEPTION_RAISED;
+        if (update_iteration_diagnostics(a)) return ORC_ADJUST_EXCEPTION_RAISED;          /* ADJ:2631 */
         if (a->iterations <= 64) a->max_corr_hist[a->iterations - 1] = a->maxCorr;
         if (!(fabs(a->maxCorr) > a->set.iteration_threshold)) break;                      /* ADJ:2639 */
         if (phased_update_adjustment(a)) return ORC_ADJUST_EXCEPTION_RAISED;

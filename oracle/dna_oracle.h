@@ -170,6 +170,14 @@ void orc_adjust_solve_stats(const orc_adjustment* a, uint64_t* solves, double* s
  * UpdateAdjustment(false) (meas-minus-computed from the rigorous estimates, ADJ:549), ComputePrecisionAdjMsrs_GX/_Y
  * (ADJ:8009/8037), UpdateMsrRecord (ADJ:8187), ComputeChiSquare_G/_XY (ADJ:8530/8551), ComputeGlobalNetStat (ADJ:6854),
  * ComputeGlobalPelzer (ADJ:8302).  `critical_value` = normal quantile of the confidence interval (ADJ:203-206). */
+/* a station recorded by UpdateIterationDiagnostics (ADJ:7450-7554; OscillationRecord dnaadjust.hpp:1277-1285): its last correction here in
+ * cartesian components (the reference stores it rotated into the local frame: same magnitude) */
+typedef struct {
+    uint32_t station, first_iteration, last_iteration, cycles;
+    double first_mag, last_mag, cx, cy, cz;
+} orc_osc_record;
+uint32_t orc_adjust_oscillation_history(const orc_adjustment* a, orc_osc_record* out, uint32_t cap);
+
 typedef struct {
     double chi_squared, sigma_zero, global_pelzer;
     uint32_t measurement_params, unknown_params, potential_outliers;

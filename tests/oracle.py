@@ -27,6 +27,11 @@ class OrcSettings(C.Structure):
                 ("max_iterations", C.c_uint32), ("scale_normals_to_unity", C.c_int), ("threads", C.c_int)]
 
 
+class OrcOscRecord(C.Structure):
+    _fields_ = [("station", C.c_uint32), ("first_iteration", C.c_uint32), ("last_iteration", C.c_uint32), ("cycles", C.c_uint32),
+                ("first_mag", C.c_double), ("last_mag", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("cz", C.c_double)]
+
+
 class OrcStatistics(C.Structure):
     _fields_ = [("chi_squared", C.c_double), ("sigma_zero", C.c_double), ("global_pelzer", C.c_double),
                 ("measurement_params", C.c_uint32), ("unknown_params", C.c_uint32), ("potential_outliers", C.c_uint32),
@@ -66,6 +71,8 @@ def load():
         lib.orc_weight_3x3.argtypes = [f64p, f64p]
         lib.orc_propagate_geo_cart.argtypes = [f64p, C.c_uint32, f64p, C.c_int]
         lib.orc_scale_gps_vcv.argtypes = [f64p, C.c_uint32, f64p, C.c_double, C.c_double, C.c_double, C.c_int]
+        lib.orc_adjust_oscillation_history.restype = C.c_uint32
+        lib.orc_adjust_oscillation_history.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         lib.orc_adjust_create.restype = C.c_void_p
         lib.orc_adjust_create.argtypes = [C.POINTER(OrcNetwork), C.POINTER(OrcSettings), C.c_int]
         lib.orc_adjust_destroy.argtypes = [C.c_void_p]
@@ -519,6 +526,15 @@ class Adjustment:
         rows = C.c_uint32()
         p = self.lib.orc_adjust_block_prec_adj_msrs(self.h, b, C.byref(rows))
         return np.ctypeslib.as_array(p, shape=(rows.value,)).copy()
+
+    def oscillation_history(self):
+        """UpdateIterationDiagnostics' records (ADJ:7450-7554), by station: dicts with the last correction in cartesian components"""
+        n = self.lib.orc_adjust_oscillation_history(self.h, None, 0)
+        recs = (OrcOscRecord * max(1, n))()
+        self.lib.orc_adjust_oscillation_history(self.h, recs, n)
+        out = [{"station": r.station, "first_iteration": r.first_iteration, "last_iteration": r.last_iteration, "cycles": r.cycles,
+                "first_mag": r.first_mag, "last_mag": r.last_mag, "last_xyz": (r.cx, r.cy, r.cz)} for r in recs[:n]]
+        return sorted(out, key=lambda d: d["station"])
 
     def iteration(self):
         if self.lib.orc_adjust_iteration(self.h):

@@ -326,6 +326,36 @@ class Builder:
         return bst, bms
 
 
+def build_oscillating_network(base, blocks=2, short=0.05, perturb=0.8, seed=4):
+    """A network whose iteration cannot settle: two stations (the middle of the first and of the third row) are each held by nothing but
+    two slope distances to their row neighbours -- nearly in line with them -- that are both `short` metres too short to meet, and an
+    ellipsoidal height.  Across the line the Gauss-Newton step then overshoots the line from either side (y -> y/2 - d short / y for a
+    line of half-length d): corrections of metres that turn round from iteration to iteration.  Every other station carries a GNSS
+    point.  4 x 3 stations, `blocks` strips; slope distances down the outer columns tie the strips together."""
+    b = Builder(4, 3, blocks, seed, defl=False, geoid=False, perturb=0.02)
+    rng = b.rng
+    loose = (1, 7)
+    for s in (0, 1, 2, 6, 7, 8):            # the two rows level: the loose stations in line with their neighbours (but for the parallel's sagitta)
+        b.llh[s][2] = 150.0
+        b.truth[s] = geo_to_cart(*b.llh[s])
+        b.init[s] = b.truth[s] + 0.02 * rng.standard_normal(3)
+    for s in range(b.n):
+        if s not in loose:
+            b.add_point(s)
+    for s in loose:
+        e, n, u = enu_axes(b.llh[s][0], b.llh[s][1])
+        b.init[s] = b.truth[s] + perturb * n + 0.01 * rng.standard_normal(3)       # off the line, across it
+        for t in (s - 1, s + 1):
+            b.add("S", min(s, t), max(s, t), ih=0.0, th=0.0)
+            b.recs[-1]["term1"] -= short
+            b.recs[-1]["preAdjMeas"] = b.recs[-1]["term1"]
+        b.add("R", s)
+    for c in (0, 2):                        # (not the middle column: a distance along it would hold the loose stations across their lines)
+        for r in range(3):
+            b.add("S", r * 3 + c, (r + 1) * 3 + c)
+    return b, b.write(base)
+
+
 def build_mixed_network(base, rows=6, cols=5, blocks=1, seed=1, types="SVZLHRBKACEM", defl=True, geoid=True):
     """a grid network observed with every terrestrial type in `types`, plus GNSS baselines along the first column and one
     GNSS point per corner for the datum"""

@@ -87,6 +87,39 @@ def test_small_blocks_of_unequal_size_share_a_bucket(built, orc, tmp_path):
     o.close()
 
 
+@pytest.mark.parametrize("stage", [False, True])
+def test_blocks_without_a_kept_factor_make_it_again(built, orc, tmp_path, monkeypatch, stage):
+    """the HBM budget denies every block a kept factor (DNAGPU_FACTOR_BUDGET_GB=0: what cfg4 on one GPU does to 121 of its 128 blocks): in a
+    GNSS-only network the factor is then formed and eliminated again in the rigorous solve and once more for the variance matrix (chain-owned
+    storage) instead of an inverse per iteration.  Same bits as the run in which every block keeps its factor; against the oracle as well."""
+    adjust.write_synthetic_network(str(tmp_path), "t", 48, 40, 0, 6, seed=33)
+    net = orc.Network(str(tmp_path / "t"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    monkeypatch.delenv("DNAGPU_FACTOR_BUDGET_GB", raising=False)
+    a0, st0 = _run(str(tmp_path), "t", multi_thread=True, batch_blocks=0, stage=stage)
+    assert st0 == ost and a0.memory_plan()["factors_made_again"] == 0 and a0.memory_plan()["blocks_keeping_their_factor"] == 6
+    x0, v0, c0 = _results(a0)
+    a0.close()
+    monkeypatch.setenv("DNAGPU_FACTOR_BUDGET_GB", "0")
+    a1, st1 = _run(str(tmp_path), "t", multi_thread=True, stage=stage)
+    plan = a1.memory_plan()
+    assert st1 == ost and plan["blocks_keeping_their_factor"] == 0 and plan["blocks_without_kept_factor_refactor"]
+    assert plan["factors_made_again"] == 6 * (a1.CurrentIteration() + 1)          # every rigorous solve + every variance matrix
+    assert a1.solve_count() == 6 * a1.CurrentIteration()
+    x1, v1, c1 = _results(a1)
+    assert c0 == c1
+    for b in range(6):
+        assert np.array_equal(x0[b], x1[b]) and np.array_equal(v0[b], v1[b])
+        vo = o.block_variances(b)
+        assert np.abs(x1[b] - o.block_estimates(b)).max() < 1e-8 and np.abs(v1[b] - vo).max() / np.abs(vo).max() < 1e-8
+    a1.GenerateStatistics()
+    assert abs(a1.GetSigmaZero() - o.statistics()[0].sigma_zero) < 1e-9
+    a1.close()
+    o.close()
+
+
 def test_batch_size_is_capped(built, tmp_path):
     """batch_blocks = 2: groups of at most two members, same bits"""
     adjust.write_synthetic_network(str(tmp_path), "c", 48, 40, 0, 6, seed=5)

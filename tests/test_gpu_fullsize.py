@@ -48,11 +48,12 @@ def _record(path, rec):
         pass
 
 
-@pytest.mark.parametrize("workload", ["cfg3q", "cfg3"])
+@pytest.mark.parametrize("workload", ["cfg3q", "cfg4q", "cfg3"])
 def test_against_the_oracle_record(built, golden_dir, tmp_path, workload):
     """the device path (condensed schedule, kept factors, four chains) against the committed record of the CPU oracle's run of the
     same network: cfg3q = four of cfg3's sixteen strips at cfg3's block size (n ~ 20 000: the oracle's run fits a 64 GB host),
-    cfg3 = the whole of it (when its record has been made: ~80 GB and 7.4e14 flops on the CPU)"""
+    cfg3 = the whole of it (when its record has been made: ~80 GB and 7.4e14 flops on the CPU); cfg4q = four of cfg4's 128 strips at cfg4's
+    block geometry (n ~ 27 000 with junction rows of 1 000 stations: J = 3 000, condensed blocks of 6 000 unknowns; 20 Solve() calls)"""
     path = os.path.join(golden_dir, f"{workload}_oracle.npz")
     if not os.path.exists(path):
         assert workload != "cfg3q", "tests/golden/cfg3q_oracle.npz is missing: python tools/make_fullsize_golden.py cfg3q"
@@ -191,3 +192,57 @@ def test_cfg4_sized_blocks(built, tmp_path):
     _record("parity_cfg4_blocks.json", {"blocks": B, "unknowns_per_block": int(est[1].size), "max_abs_dx_m": dx, "max_rel_dvar": dv})
     assert dx < TOL_X and dv < TOL_V, (dx, dv)
     r.close()
+
+
+def test_cfg4_full_size_properties(built, tmp_path):
+    """BASELINE.json configs[3] and [4] at FULL size on one GPU: 1 000 000 stations, 2 666 666 baselines (7 999 998 measurement rows), 128
+    blocks of n ~ 27 000 -- one AdjustNetwork() to convergence in staged mode (373 GB of packed variance matrices: page-locked host memory up
+    to the container's memory limit, the rest packed in HBM; blocks the HBM budget denies a kept factor make it again), then GenerateStatistics
+    = configs[4]'s propagation of the variances to every adjusted measurement.  No oracle can run this in the test's time (764 Solve() calls
+    of n^3 = 2e13: ~3 h of host LAPACK); cfg4's block geometry is pinned against the oracle by `cfg4q` above, and here the size-independent
+    properties are checked: convergence, sigma-zero inside its 95 % limits at 5 000 010 degrees of freedom, every station within 0.25 m of the
+    truth the measurements were drawn from, neighbouring blocks agreeing on their shared stations to 1e-8 m (the rigorous property of the
+    phased adjustment, ADJ:2794-2796), variance matrices symmetric positive on their diagonals and equal on shared stations' diagonal blocks
+    to 1e-8 relative, and the memory plan adding up."""
+    rows, cols, nbl, blocks = 1000, 1000, 2666666, 128
+    info = adjust.write_synthetic_network(str(tmp_path), "net", rows, cols, nbl, blocks)
+    assert info["stations"] == 1000000 and info["measurement_rows"] == 7999998 and info["blocks"] == 128
+    p = adjust.ProjectSettings("net", str(tmp_path), adjust_mode=adjust.PhasedMode, multi_thread=True, stage=True)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    plan = a.memory_plan()
+    total_packed = sum((3 * a.lib.dnaadj_block_station_count(a.h, k)) * (3 * a.lib.dnaadj_block_station_count(a.h, k) + 1) // 2 * 8 for k in range(128))
+    assert plan["staged_variances_host_bytes"] + plan["staged_variances_packed_in_hbm_bytes"] == total_packed
+    if plan["staged_variances_host_bytes"] > 0.85 * plan["host_memory_available_gb"] * 1e9:
+        a.close()
+        pytest.skip("the host's memory limit leaves no margin for the staged store")
+    import time
+    t0 = time.perf_counter()
+    st = a.AdjustNetwork()
+    dt = time.perf_counter() - t0
+    assert st == adjust.ADJUST_SUCCESS and a.CurrentIteration() <= 4
+    after = a.memory_plan()
+    a.GenerateStatistics()
+    assert a.GetDegreesOfFreedom() == 7999998 - (3 * 1000000 - 12)
+    assert a.GetChiSquaredLowerLimit() < a.GetSigmaZero() < a.GetChiSquaredUpperLimit()
+    truth = np.fromfile(str(tmp_path / "net.truth"), dtype=np.float64).reshape(-1, 3)
+    err = float(np.abs(a.adjusted_coordinates(1000000) - truth).max())
+    assert err < 0.25
+    # neighbouring blocks on their shared stations (estimates, and the 3 x 3 diagonal blocks of the variance matrices)
+    dx = dv = 0.0
+    for k in (0, 63, 126):
+        s0, s1 = a.block_stations(k), a.block_stations(k + 1)
+        x0, x1 = a.block_estimates(k).reshape(-1, 3), a.block_estimates(k + 1).reshape(-1, 3)
+        common, i0, i1 = np.intersect1d(s0, s1, return_indices=True)
+        assert common.size == 1000
+        dx = max(dx, float(np.abs(x0[i0] - x1[i1]).max()))
+        d0 = fullsize.sample_packed(a.block_variances_packed(k), 3 * s0.size)[0].reshape(-1, 3)
+        d1 = fullsize.sample_packed(a.block_variances_packed(k + 1), 3 * s1.size)[0].reshape(-1, 3)
+        assert d0.min() > 0 and d1.min() > 0
+        dv = max(dv, float(np.abs(d0[i0] - d1[i1]).max() / d0.max()))
+    _record("cfg4_full_size.json", {"stations": 1000000, "blocks": 128, "iterations": a.CurrentIteration(), "adjust_seconds": dt,
+                                    "sigma_zero": a.GetSigmaZero(), "chi_squared_limits": [a.GetChiSquaredLowerLimit(), a.GetChiSquaredUpperLimit()],
+                                    "degrees_of_freedom": a.GetDegreesOfFreedom(), "max_abs_error_vs_truth_m": err,
+                                    "shared_stations_max_abs_dx_m": dx, "shared_stations_max_rel_dvar": dv, "memory_plan": after})
+    assert dx < TOL_X and dv < TOL_V, (dx, dv)
+    a.close()

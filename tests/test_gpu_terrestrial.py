@@ -176,3 +176,48 @@ def test_reference_urban_sample_on_the_device(built, golden_dir, tmp_path, phase
     gf = {nm: rec[nm][rows3] for nm in names}
     _check_urban_tables(rep, stations, msrs, first_of, t_record, bs, be, sd, tf, gf, vec_of_record, loose=6.0 if sample == "gda2020" else 1.0)
     a.close()
+
+
+@pytest.mark.parametrize("phased,kw", [(False, {}), (True, {"schur_carry": False}), (True, {"schur_carry": True, "multi_thread": True})])
+def test_oscillation_diagnostics_on_the_device(built, orc, tmp_path, phased, kw):
+    """dna_adjust::UpdateIterationDiagnostics / PrintOscillationSummary / PrintSuspectMeasurementSummary (ADJ:7450-7780) behind the reference's
+    members: the corrections of every iteration are compared on the device (osc_update_kernel, one record per station of the network), the host
+    keeps the history.  On a network that cannot settle (two stations held across their lines by two distances too short to meet) the device
+    records the same stations, iterations and cycle counts as the oracle's restatement, the same magnitudes (the iteration is chaotic: rounding
+    differences double every iteration -- 1e-6 relative after ten), the last correction rotated into the station's local frame, and prints the
+    reference's summary lines -- under simultaneous adjustment, the reference's phased schedule and the condensed schedule."""
+    base = str(tmp_path / "o")
+    T.build_oscillating_network(base, blocks=2 if phased else 1)
+    net = orc.Network(base, phased)
+    o = orc.Adjustment(net, phased, max_iterations=10)
+    o.prepare()
+    ost = o.run()
+    want = o.oscillation_history()
+    assert ost == adjust.ADJUST_MAX_ITERATIONS_EXCEEDED and [r["station"] for r in want] == [1, 7]
+    a, st = _device_run(str(tmp_path), "o", phased, max_iterations=10, **kw)
+    assert st == ost and a.CurrentIteration() == 10
+    got = a.oscillation_history()
+    assert [r["station"] for r in got] == [1, 7]
+    bst = F.read_bst(base + ".bst")
+    for g, w in zip(got, want):
+        for k in ("first_iteration", "last_iteration", "cycles"):
+            assert g[k] == w[k], (k, g, w)
+        assert abs(g["first_mag"] - w["first_mag"]) < 1e-6 * w["first_mag"] and abs(g["last_mag"] - w["last_mag"]) < 1e-6 * w["last_mag"]
+        e, n, u = T.enu_axes(float(bst["currentLatitude"][g["station"]]), float(bst["currentLongitude"][g["station"]]))
+        back = g["last_e"] * e + g["last_n"] * n + g["last_up"] * u
+        assert np.abs(back - np.array(w["last_xyz"])).max() < 1e-6 * w["last_mag"]
+    a.GenerateStatistics()
+    text = a.summaries(limit=5)
+    assert "+ Oscillating stations detected (2 total, showing top 2):" in text
+    big = max(want, key=lambda r: max(r["first_mag"], r["last_mag"]))
+    line = [l for l in text.splitlines() if l.startswith("  - T%05d" % big["station"])]
+    assert line and "%.1fm to %.1fm" % (big["first_mag"], big["last_mag"]) in line[0] and "%d cycles" % big["cycles"] in line[0]
+    assert "(iterations %d-%d)" % (big["first_iteration"], big["last_iteration"]) in line[0] and " — " in line[0]
+    assert "+ Suspect measurements connected to oscillating stations (" in text and "touches oscillating station" in text
+    # an adjustment that converges records nothing and prints no oscillation summary
+    a.close()
+    T.build_mixed_network(str(tmp_path / "m"), rows=4, cols=3, blocks=2 if phased else 1, types="SVL")
+    a, st = _device_run(str(tmp_path), "m", phased, **kw)
+    assert st == 0 and a.oscillation_history() == [] and "Oscillating" not in a.summaries()
+    a.close()
+    o.close()

@@ -345,3 +345,30 @@ def test_phased_is_rigorous_with_direction_sets(orc, tmp_path, blocks):
     assert abs(ss.chi_squared - sp.chi_squared) < 1e-3 * ss.chi_squared and ss.dof == sp.dof
     s.close()
     p.close()
+
+
+@pytest.mark.parametrize("blocks", [1, 2])
+def test_oscillation_diagnostics_record_a_network_that_cannot_settle(orc, tmp_path, blocks):
+    """dna_adjust::UpdateIterationDiagnostics (ADJ:7450-7554), restated in the oracle: a network with two stations held across their lines by
+    nothing but two distances that are too short to meet (tests/terrestrial_net.py build_oscillating_network) runs out of iterations with
+    corrections of metres that turn round from one iteration to the next; both stations are recorded -- two anti-parallel turns of similar size
+    in a row -- and nobody else; phased and simultaneous adjustment record the same."""
+    base = str(tmp_path / "o")
+    T.build_oscillating_network(base, blocks=blocks)
+    net = orc.Network(base, blocks > 1)
+    o = orc.Adjustment(net, blocks > 1, max_iterations=10)
+    o.prepare()
+    assert o.run() == 1 and o.iterations() == 10            # ADJUST_MAX_ITERATIONS_EXCEEDED
+    hist = o.oscillation_history()
+    assert [r["station"] for r in hist] == [1, 7]
+    for r in hist:
+        assert r["cycles"] >= 2 and 3 <= r["first_iteration"] <= r["last_iteration"] <= 10
+        assert r["first_mag"] > 0.1 and r["last_mag"] > 0.1 and abs(np.linalg.norm(r["last_xyz"]) - r["last_mag"]) < 1e-12
+    o.close()
+    # a network that converges records nothing
+    T.build_mixed_network(str(tmp_path / "m"), rows=4, cols=3, blocks=blocks, types="SVL")
+    net = orc.Network(str(tmp_path / "m"), blocks > 1)
+    o = orc.Adjustment(net, blocks > 1)
+    o.prepare()
+    assert o.run() == 0 and o.oscillation_history() == []
+    o.close()
