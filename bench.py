@@ -771,6 +771,10 @@ def main():
                     help="BASELINE.json configs[4]: the timed step also propagates the rigorous variances to every adjusted measurement "
                          "(GenerateStatistics: precisions of the adjusted measurements A S A^T from the resident variance matrices, chi-square, "
                          "sigma-zero, N-statistics) -- with `--workload cfg4` on 8 GPUs that is configs[4]")
+    ap.add_argument("--plan", action="store_true",
+                    help="dry run, no GPU needed: print PrepareAdjustment's plan for --gpus N GPUs of --plan-hbm-gb each (block owners, HBM budget per rank, "
+                         "two-level runs, bytes of every exchange of an iteration: dnaadj_plan_distributed) and exit")
+    ap.add_argument("--plan-hbm-gb", type=float, default=309.2, help="memory of one GPU for --plan (MI355X: 309.2 GB visible)")
     ap.add_argument("--no-one-chain", action="store_true", help="skip the extra one-chain step behind roofline.frac_one_chain")
     ap.add_argument("--no-gemm-events", action="store_true", help="diagnostic: no HIP events around the GEMM launches (roofline.achieved = 0)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -785,6 +789,21 @@ def main():
         return
     if args.cpu_baseline_only:
         print(json.dumps(_cpu_baseline_sample(args.workload, *json.loads(args.cpu_args))), flush=True)
+        return
+
+    if args.plan:
+        from dynadjust_amd import adjust
+        rows, cols, nbl, blocks, phased, desc = WORKLOADS[args.workload]
+        d = tempfile.mkdtemp(prefix="dnagpu_plan_")
+        info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, max(1, blocks), **WORKLOAD_KW.get(args.workload, {}))
+        a = adjust.DnaAdjust()
+        p = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode if phased else adjust.SimultaneousMode, multi_thread=phased,
+                                   stage=phased and args.stage, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors)
+        plan = a.plan_distributed(p, args.gpus, args.plan_hbm_gb * 1e9)
+        a.close()
+        plan["workload"] = desc
+        plan["network"] = info
+        print(json.dumps(plan), flush=True)
         return
 
     import torch

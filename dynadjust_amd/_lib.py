@@ -265,6 +265,7 @@ def load():
     _sig(lib, "dnagpu_profile_hbm_get", i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), i])
     _sig(lib, "dnaadj_oscillation_history", sz, [vp, C.POINTER(C.c_double), sz])
     _sig(lib, "dnaadj_summaries", sz, [vp, sz, C.c_char_p, sz])
+    _sig(lib, "dnaadj_plan_distributed", i, [vp, C.POINTER(DnaAdjSettings), i, C.c_double, C.c_char_p, sz, C.POINTER(sz)])
     _sig(lib, "dnaadj_memory_plan", i, [vp, C.POINTER(C.c_double)])
     _sig(lib, "dnaadj_dist_set_timeout", None, [C.c_double])
     _sig(lib, "dnaadj_debug_stall_rank", None, [C.c_int, C.c_long, C.c_double])
@@ -330,7 +331,7 @@ EXPORTED_DNAADJ = [
     "dnaadj_deserialise_adjusted_variance_matrices", "dnaadj_update_binary_files", "dnastat_normal_quantile", "dnastat_chi_squared_quantile",
     "dnaadj_block_flags", "dnaadj_junction_unknowns", "dnaadj_junction_payload_doubles", "dnaadj_phased_begin_iteration",
     "dnaadj_phased_forward_block", "dnaadj_phased_reverse_block", "dnaadj_phased_combine_block", "dnaadj_phased_finalise_block",
-    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_staged", "dnaadj_oscillation_history", "dnaadj_summaries", "dnaadj_memory_plan", "dnaadj_dist_set_timeout", "dnaadj_debug_stall_rank", "dnaadj_condensed_schedule", "dnaadj_batched_block_steps", "dnaadj_batched_flops", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
+    "dnaadj_phased_note_correction", "dnaadj_phased_end_iteration", "dnaadj_phased_finish", "dnaadj_staged", "dnaadj_plan_distributed", "dnaadj_oscillation_history", "dnaadj_summaries", "dnaadj_memory_plan", "dnaadj_dist_set_timeout", "dnaadj_debug_stall_rank", "dnaadj_condensed_schedule", "dnaadj_batched_block_steps", "dnaadj_batched_flops", "dnaadj_condensed_payload_doubles", "dnaadj_phased_condense_block",
     "dnaadj_phased_condensed_forward", "dnaadj_phased_condensed_reverse", "dnaadj_phased_rigorous_block", "dnaadj_phased_condense_blocks", "dnaadj_phased_condensed_chains",
     "dnaadj_phased_rigorous_blocks", "dnaadj_condensed_export",
     "dnaadj_condensed_import", "dnaadj_statistics_prepare", "dnaadj_statistics_blocks", "dnaadj_statistics_get_partial",

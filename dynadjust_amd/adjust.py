@@ -99,6 +99,19 @@ class DnaAdjust:
 
     # ---- reference interface -------------------------------------------------
     def PrepareAdjustment(self, p):
+        self._chk(self.lib.dnaadj_prepare(self.h, C.byref(self._settings(p))))
+
+    def plan_distributed(self, p, world, hbm_bytes=309.0e9):
+        """dnaadj_plan_distributed: PrepareAdjustment's plan for `world` GPUs of `hbm_bytes` each, WITHOUT a device (dict from its JSON)"""
+        import json
+        s = self._settings(p)
+        need = C.c_size_t(0)
+        self._chk(self.lib.dnaadj_plan_distributed(self.h, C.byref(s), int(world), float(hbm_bytes), None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value + 16)
+        self._chk(self.lib.dnaadj_plan_distributed(self.h, C.byref(s), int(world), float(hbm_bytes), buf, need.value + 16, None))
+        return json.loads(buf.value.decode())
+
+    def _settings(self, p):
         s = DnaAdjSettings()
         self.lib.dnaadj_default_settings(C.byref(s))
         self._keep = [_b(p.bst_file), _b(p.bms_file), _b(p.asl_file), _b(p.seg_file), _b(getattr(p, "network_name", None)),
@@ -129,7 +142,7 @@ class DnaAdjust:
         s.dist_two_level = int(bool(getattr(p, "dist_two_level", True)))
         s.defer_variances = int(getattr(p, "defer_variances", 2))
         s.batch_blocks = int(getattr(p, "batch_blocks", 16))
-        self._chk(self.lib.dnaadj_prepare(self.h, C.byref(s)))
+        return s
 
     # ---- multi-GPU (include/dnaadjust_c.h "multi-GPU") ----
     def attach_rccl(self, rank, world, unique_id, device):

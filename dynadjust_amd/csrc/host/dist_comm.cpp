@@ -364,6 +364,31 @@ private:
 
 }  // namespace
 
+namespace {
+class PlanComm : public DistComm {
+public:
+    PlanComm(int rank, int world) : rank_(rank), world_(world) {}
+    int rank() const override { return rank_; }
+    int world() const override { return world_; }
+    const char* transport() const override { return "plan"; }
+    void group_begin() override { no(); }
+    void group_end() override { no(); }
+    void broadcast(double*, size_t, int) override { no(); }
+    void all_reduce_sum(double*, size_t) override { no(); }
+    void send(const double*, size_t, int) override { no(); }
+    void recv(double*, size_t, int) override { no(); }
+    void wait() override { no(); }
+    void broadcast_parts_on(hipStream_t, int, double* const*, const size_t*) override { no(); }
+    uint64_t bytes_moved() const override { return 0; }
+
+private:
+    static void no() { throw std::runtime_error("inter-GPU exchange: a plan has no transport"); }
+    int rank_, world_;
+};
+}  // namespace
+
+std::shared_ptr<DistComm> plan_comm_create(int rank, int world) { return std::make_shared<PlanComm>(rank, world); }
+
 bool rccl_available(std::string* why) {
     RcclApi& api = rccl();
     if (!api.handle && why) *why = api.error;

@@ -69,6 +69,10 @@ std::shared_ptr<DistComm> rccl_comm_create(int rank, int world, const unsigned c
 void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BYTES], const char* addr = nullptr, int port = 0,
                          double timeout_s = 120.0);
 
+// ---- plan (no transport) ---------------------------------------------------------------------------------------------------
+// a communicator that only knows its rank and the world size: what dna_adjust::PlanDistributed prepares against; every exchange throws
+std::shared_ptr<DistComm> plan_comm_create(int rank, int world);
+
 // ---- local (threads of one process) ---------------------------------------------------------------------------------------
 // creates the communicators of all `world` ranks at once; rank r's calls must come from one thread
 std::vector<std::shared_ptr<DistComm>> local_comm_create(int world, const std::vector<int>& devices);

@@ -597,35 +597,35 @@ void dna_adjust::PrepareBlocks() {
         max_unknowns_ = std::max<UINT32>(max_unknowns_, (UINT32)v_parameterStationList_[b].size() * 3);
         max_junction_ = std::max<UINT32>(max_junction_, (UINT32)v_JSL_[b].size() * 3);
     }
-    int rc = dnagpu_create(projectSettings_.a.device, &ctx_);
+    int rc = plan_only_ ? DNAGPU_OK : dnagpu_create(projectSettings_.a.device, &ctx_);
     if (rc != DNAGPU_OK) {
         ctx_ = nullptr;
         SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
     }
-    if (shares_device_) dnagpu_set_fused_launches(ctx_, 0);
+    if (shares_device_ && !plan_only_) dnagpu_set_fused_launches(ctx_, 0);
     // Chains that run side by side share the GPU's workgroup slots by agreement: a DAG launch (csrc/tile_dag.h) of one chain keeps
     // at most its share of persistent workers, so that a chain whose factorisation is waiting on its critical path cannot sit on the
     // slots the others have work for.  DNAGPU_DAG_WORKERS overrides (0 = every launch may take the whole GPU).
     {
         int share = 512 / std::max(1, NumChains() * (shares_device_ ? std::max(1, DistWorld()) : 1));
         if (const char* e = getenv("DNAGPU_DAG_WORKERS")) share = atoi(e);
-        dnagpu_set_tile_dag_workers(ctx_, std::max(0, share));
+        if (!plan_only_) dnagpu_set_tile_dag_workers(ctx_, std::max(0, share));
     }
     // several GPUs, one block (simultaneous adjustment): every GPU holds the block, the inverse itself is distributed -- large
     // launches split by tile columns, the parts exchanged over the communicator (dnagpu_set_inverse_exchange)
-    if (comm_ && comm_->world() > 1 && projectSettings_.a.adjust_mode == SimultaneousMode)
+    if (!plan_only_ && comm_ && comm_->world() > 1 && projectSettings_.a.adjust_mode == SimultaneousMode)
         Check(dnagpu_set_inverse_exchange(ctx_, comm_->rank(), comm_->world(), &dna_adjust::ExchangeTrampoline, this), 0, "PrepareAdjustment()");
     {
         // a chain costs three matrices of the largest block's order (work matrix, X, W): no more chains than blocks, and
         // no more than half of the free HBM for all of them together
         size_t free_b = 0, total_b = 0;
-        Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
+        MemInfo(&free_b, &total_b);
         const double per_chain = 3.0 * ((double)max_unknowns_ + 256.0) * ((double)max_unknowns_ + 256.0) * 8.0;
         while (mt_chains_ > 1 && ((UINT32)mt_chains_ > blockCount_ || per_chain * mt_chains_ > 0.5 * (double)free_b)) --mt_chains_;
         if (mt_chains_ < 2 && blockCount_ > 1 && 2.0 * per_chain <= 0.5 * (double)free_b) mt_chains_ = 2;   // the two junction chains
     }
     const int chains = NumChains();
-    for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, max_unknowns_, &work_[c]), 0, "PrepareAdjustment(): work matrix");
+    for (int c = 0; c < chains; ++c) NewMatrix(max_unknowns_, &work_[c], 0, "PrepareAdjustment(): work matrix");
 
     for (UINT32 b = 0; b < blockCount_; ++b) {
         currentBlock_ = b;
@@ -685,6 +685,12 @@ void dna_adjust::PrepareBlocks() {
                 for (UINT32 s : v_JSL_[b - 1]) B.jslprev_here.push_back(LocalIndex(b, s));
         }
         // device
+        if (plan_only_) {
+            // (stations: original, rigorous, estimates / rhs / corrections per chain; measurements: stations, observation, weights, b and W b
+            //  per chain, pair lists -- ~ what dnagpu_block_create + dnagpu_block_set_clusters allocate)
+            plan_bytes_ += (double)ns * 24.0 * (2.0 + 3.0 * chains) + (double)B.stn1.size() * (8.0 + 24.0 + 72.0 + 48.0 * chains + 60.0);
+            continue;
+        }
         Check(dnagpu_block_create(ctx_, b, ns, (UINT32)B.stn1.size()), b, "PrepareAdjustment(): block allocation");
         Check(dnagpu_block_set_stations(ctx_, b, xyz.data()), b, "PrepareAdjustment(): stations");
         {
@@ -717,7 +723,36 @@ void dna_adjust::PrepareBlocks() {
     ComputeBlockOwners(CondensedWanted() && !ReuseInverses());
     DecideStaging();
     PrepareCondensedBlocks();     // (+ ownership under the reference's schedule, the two-level plan, junction matrices / condensed blocks)
-    Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
+    if (!plan_only_) Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
+}
+
+// the reference's files and the lists derived from them (LoadNetworkFiles ... CreateStnAppearanceList): host only
+void dna_adjust::LoadAndListNetwork() {
+    LoadNetworkFiles();
+    switch (projectSettings_.a.adjust_mode) {
+        case SimultaneousMode: BuildSimultaneousLists(); break;
+        case PhasedMode:
+        case Phased_Block_1Mode: {
+            iostreams::seg_data_t seg;
+            iostreams::read_seg(projectSettings_.a.seg_file, seg, &bmsBinaryRecords_);
+            blockCount_ = seg.blockCount;
+            v_ISL_ = seg.ISL;
+            v_JSL_ = seg.JSL;
+            v_CML_ = seg.CML;
+            v_ContiguousNetList_ = seg.ContiguousNetList;
+            v_measurementCount_ = seg.measurementCount;
+            v_unknownsCount_ = seg.unknownsCount;
+            v_parameterStationCount_ = seg.parameterStationCount;
+            if (v_ISL_.size() != v_JSL_.size() || v_JSL_.size() != v_CML_.size())
+                throw std::runtime_error(
+                    "LoadPhasedBlocks(): An unrecoverable error was encountered when loading the phased adjustment blocks.");
+            break;
+        }
+        default: throw std::runtime_error("AdjustNetwork(): Unknown adjustment type");
+    }
+    if (blockCount_ == 0) throw std::runtime_error("PrepareAdjustment(): the network has no blocks.");
+    LoadSegmentationMetrics();
+    CreateStnAppearanceList();
 }
 
 // ADJ:258-442
@@ -767,31 +802,7 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
     currentBlock_ = 0;
     currentIteration_ = 0;
     try {
-        LoadNetworkFiles();
-        switch (projectSettings_.a.adjust_mode) {
-            case SimultaneousMode: BuildSimultaneousLists(); break;
-            case PhasedMode:
-            case Phased_Block_1Mode: {
-                iostreams::seg_data_t seg;
-                iostreams::read_seg(projectSettings_.a.seg_file, seg, &bmsBinaryRecords_);
-                blockCount_ = seg.blockCount;
-                v_ISL_ = seg.ISL;
-                v_JSL_ = seg.JSL;
-                v_CML_ = seg.CML;
-                v_ContiguousNetList_ = seg.ContiguousNetList;
-                v_measurementCount_ = seg.measurementCount;
-                v_unknownsCount_ = seg.unknownsCount;
-                v_parameterStationCount_ = seg.parameterStationCount;
-                if (v_ISL_.size() != v_JSL_.size() || v_JSL_.size() != v_CML_.size())
-                    throw std::runtime_error(
-                        "LoadPhasedBlocks(): An unrecoverable error was encountered when loading the phased adjustment blocks.");
-                break;
-            }
-            default: throw std::runtime_error("AdjustNetwork(): Unknown adjustment type");
-        }
-        if (blockCount_ == 0) throw std::runtime_error("PrepareAdjustment(): the network has no blocks.");
-        LoadSegmentationMetrics();
-        CreateStnAppearanceList();
+        LoadAndListNetwork();
         PrepareBlocks();
     } catch (const NetAdjustException&) {
         throw;

@@ -109,6 +109,11 @@ public:
     std::string GetMaxCorrection(const UINT32& iteration) const;
     // dnaadjust.hpp:277 / :294-296 -- see dna_printer.hpp for what stands behind the printer
     DynAdjustPrinter* GetPrinter();
+    // The plan PrepareAdjustment would make on each of `world` GPUs with `hbm_bytes` of memory, as JSON, WITHOUT a device: block owners, run
+    // boundaries and merge order of the two-level chains, per rank the HBM budget (blocks, chains' workspaces, variance matrices or staged store,
+    // kept factors, batch members) and the bytes of every exchange of an iteration.  (A dry run for a node one does not have yet, and the
+    // device-free pin of the schedule in host/dna_adjust_dist.cpp.)
+    std::string PlanDistributed(const project_settings& projectSettings, int world, double hbm_bytes);
     void PrintOscillationSummary(std::ostream& os = std::cout);
     // the stations UpdateIterationDiagnostics has recorded so far (dnaadjust.hpp:1277-1288 OscillationRecord), keyed by .bst index
     struct OscillationRecord {
@@ -437,6 +442,14 @@ private:
     bool MeasurementTouchesOscillatingStation(UINT32 msrIndex) const;
     void GetMsrStations(UINT32 msrIndex, std::vector<UINT32>& out) const;
     std::string MeasurementStationNames(UINT32 msrIndex) const;
+    // ---- plan mode (PlanDistributed): PrepareAdjustment's host side and memory plan without a device -- every device object the
+    // prepare path would create is only counted (plan_bytes_), the free HBM is what the caller says a GPU has
+    bool plan_only_ = false;
+    double plan_hbm_ = 0.0, plan_bytes_ = 0.0;
+    void NewMatrix(UINT32 n, dnagpu_matrix** m, UINT32 blk, const char* what);
+    void NewBlock(UINT32 id, UINT32 n_stn, UINT32 n_msr, UINT32 blk, const char* what);
+    void MemInfo(size_t* free_b, size_t* total_b);
+    void LoadAndListNetwork();
     bool staged_ = false;
     double host_available_ = 0.0;                               // what the host could still give when the plan was made (HostMemoryAvailable)
     size_t stage_host_bytes_ = 0, stage_device_bytes_ = 0;    // the staged store's plan: packed variance matrices in host / device memory

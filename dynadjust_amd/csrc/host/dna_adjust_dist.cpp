@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <numeric>
+#include <sstream>
 #include <set>
 #include <thread>
 
@@ -103,6 +104,101 @@ void dna_adjust::ComputeBlockOwners(bool condensed) {
         owner_[k] = r;
         load += cost[k];
     }
+}
+
+// PrepareAdjustment's plan for every rank of `world` GPUs with `hbm_bytes` each, without a device (plan_only_: device objects are counted,
+// not made).  The schedule functions are the ones the adjustment runs -- ComputeBlockOwners, DecideStaging, PrepareCondensedBlocks,
+// PrepareTwoLevel -- so what this prints is what PrepareAdjustment would decide, and tests/test_dist_plan.py pins it on the CPU.
+std::string dna_adjust::PlanDistributed(const project_settings& projectSettings, int world, double hbm_bytes) {
+    FreeDevice();
+    peers_.clear();
+    if (world < 1) world = 1;
+    plan_only_ = true;
+    plan_hbm_ = hbm_bytes;
+    std::ostringstream js;
+    js.precision(12);
+    try {
+        projectSettings_ = projectSettings;
+        projectSettings_.a.dist_world = world;
+        projectSettings_.a.devices.clear();
+        var_C_ = projectSettings_.a.fixed_std_dev * projectSettings_.a.fixed_std_dev;
+        var_F_ = projectSettings_.a.free_std_dev * projectSettings_.a.free_std_dev;
+        LoadAndListNetwork();
+        auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
+        auto padsq = [](double n) { const double p = std::ceil(n / 128.0) * 128.0; return (p * p + p) * 8.0; };
+        double total_n3 = 0.0;
+        for (UINT32 k = 0; k < blockCount_; ++k) total_n3 += std::pow(3.0 * (double)v_parameterStationList_[k].size(), 3.0);
+        js << "{\"world\": " << world << ", \"blocks\": " << blockCount_ << ", \"stations\": " << bstBinaryRecords_.size() << ", \"hbm_bytes_per_gpu\": " << hbm_bytes
+           << ", \"ranks\": [";
+        for (int r = 0; r < world; ++r) {
+            comm_ = plan_comm_create(r, world);
+            projectSettings_.a.dist_rank = r;
+            mt_chains_ = DNAGPU_DEFAULT_CHAINS;
+            if (const char* e = getenv("DNAGPU_CHAINS")) mt_chains_ = std::max(2, std::min(DNAGPU_NUM_CHAINS, atoi(e)));
+            staged_ = projectSettings_.a.stage != 0;
+            plan_bytes_ = 0.0;
+            PrepareBlocks();
+            const double prepared = plan_bytes_;
+            int first = -1, last = -1, own = 0, kept = 0;
+            double n3 = 0.0, rig = 0.0, kept_bytes = 0.0;
+            for (UINT32 k = 0; k < blockCount_; ++k) {
+                if (!OwnsBlock(k)) continue;
+                if (first < 0) first = (int)k;
+                last = (int)k;
+                ++own;
+                const double n = 3.0 * (double)v_parameterStationList_[k].size();
+                n3 += n * n * n;
+                rig += sq(n);
+                if (blocks_[k].part_allowed) {
+                    ++kept;
+                    if (!blocks_[k].part_in_rigvar) kept_bytes += sq(n);
+                }
+            }
+            const double chains_ws = 3.0 * (double)NumChains() * sq((double)max_unknowns_);
+            const double variances_hbm = staged_ ? (double)stage_device_bytes_ : rig;
+            const double batch_ws = (double)std::min(batch_limit_, (DNAGPU_BATCH_MAX - 1) * NumChains()) * batch_unit_;
+            const double committed = prepared + chains_ws + variances_hbm + kept_bytes + (transient_ok_ ? (double)NumChains() * sq((double)max_unknowns_) : 0.0);
+            // the exchanges of one iteration, bytes this rank takes part in
+            double exch_blocks = 0.0, exch_runs = 0.0;
+            for (UINT32 k = 0; k < blockCount_; ++k) exch_blocks += (double)CondensedPayloadDoubles(k) * 8.0;
+            if (two_level_ok_)
+                for (const segment_t& g : segs_) exch_runs += padsq(3.0 * (double)g.stations.size());
+            double coords = (double)world * 8.0;
+            for (UINT32 k = 0; k < blockCount_; ++k) coords += 24.0 * (double)v_parameterStationList_[k].size();
+            js << (r ? ", " : "") << "{\"rank\": " << r << ", \"first_block\": " << first << ", \"last_block\": " << last << ", \"own_blocks\": " << own
+               << ", \"share_of_sum_n3\": " << (total_n3 > 0 ? n3 / total_n3 : 0.0) << ", \"chains\": " << NumChains() << ", \"condensed_schedule\": "
+               << (condensed_ok_ ? "true" : "false") << ", \"two_level_chains\": " << (two_level_ok_ ? "true" : "false") << ", \"staged\": " << (staged_ ? "true" : "false")
+               << ", \"hbm\": {\"blocks_and_chain_data\": " << prepared << ", \"chain_workspaces\": " << chains_ws << ", \"variance_matrices\": " << variances_hbm
+               << ", \"staged_in_host_memory\": " << (double)stage_host_bytes_ << ", \"kept_factors_own_storage\": " << kept_bytes << ", \"batch_workspaces_up_to\": " << batch_ws
+               << ", \"committed\": " << committed << ", \"fits\": " << (committed <= hbm_bytes - 1.5e9 ? "true" : "false") << "}"
+               << ", \"blocks_keeping_their_factor\": " << kept << ", \"factors_made_again\": " << (transient_ok_ ? "true" : "false") << ", \"batch_members_beyond_first\": "
+               << batch_limit_ << ", \"exchange_bytes_per_iteration\": {\"condensed_blocks_one_level\": " << exch_blocks << ", \"run_systems_two_level\": " << exch_runs
+               << ", \"coordinates_all_reduce\": " << coords << "}";
+            if (two_level_ok_) {
+                const segment_t& g = segs_[r];
+                js << ", \"run\": {\"a\": " << g.a << ", \"b\": " << g.b << ", \"end_stations\": " << g.stations.size() << ", \"towards_previous\": " << g.posL.size()
+                   << ", \"towards_next\": " << g.posR.size() << ", \"merges\": [";
+                for (size_t i = 0; i < g.steps.size(); ++i)
+                    js << (i ? ", " : "") << "{\"block\": " << (g.a + 1 + i) << ", \"stations\": " << g.steps[i].n_stn << ", \"stay\": " << g.steps[i].keep.size() << "}";
+                js << "], \"level2_steps_each_way\": " << (world - 1) << ", \"level3_steps_each_way\": " << (g.b - g.a) << "}";
+            }
+            js << ", \"owners\": [";
+            for (UINT32 k = 0; k < blockCount_; ++k) js << (k ? "," : "") << BlockOwner(k);
+            js << "]}";
+            FreeTwoLevel();
+        }
+        js << "]}";
+    } catch (...) {
+        comm_.reset();
+        plan_only_ = false;
+        blocks_.clear();
+        throw;
+    }
+    comm_.reset();
+    plan_only_ = false;
+    blocks_.clear();
+    blockCount_ = 0;
+    return js.str();
 }
 
 // the exchange of the intra-block distributed inverse (dnagpu_set_inverse_exchange): no exception may cross the C boundary
@@ -334,8 +430,8 @@ void dna_adjust::PrepareTwoLevel() {
             pick(blocks_[k].ccon_rev, g.con_rev);
         }
         g.dev_block = 3 * blockCount_ + (UINT32)r;
-        Check(dnagpu_block_create(ctx_, g.dev_block, (UINT32)g.stations.size(), 0), g.a, "PrepareAdjustment(): run system");
-        Check(dnagpu_matrix_create(ctx_, (UINT32)g.stations.size() * 3, &g.S), g.a, "PrepareAdjustment(): run system");
+        NewBlock(g.dev_block, (UINT32)g.stations.size(), 0, g.a, "PrepareAdjustment(): run system");
+        NewMatrix((UINT32)g.stations.size() * 3, &g.S, g.a, "PrepareAdjustment(): run system");
     }
     // the merges of the own run
     segment_t& g = segs_[me];
@@ -372,7 +468,7 @@ void dna_adjust::PrepareTwoLevel() {
         }
         st.n_stn = (UINT32)U.size();
         st.dev_block = 2 * blockCount_ + k;
-        Check(dnagpu_block_create(ctx_, st.dev_block, st.n_stn, 0), k, "PrepareAdjustment(): run merge");
+        NewBlock(st.dev_block, st.n_stn, 0, k, "PrepareAdjustment(): run merge");
         max_keep = std::max(max_keep, stay.size());
         prev = stay;
         g.steps.push_back(std::move(st));
@@ -382,7 +478,7 @@ void dna_adjust::PrepareTwoLevel() {
         return;
     }
     if (g.steps.size() > 1)
-        for (dnagpu_matrix*& m : g.M) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &m), g.a, "PrepareAdjustment(): run merge");
+        for (dnagpu_matrix*& m : g.M) NewMatrix((UINT32)max_keep * 3, &m, g.a, "PrepareAdjustment(): run merge");
     two_level_ok_ = true;
 }
 

@@ -470,7 +470,7 @@ static double HostMemoryAvailable() {
 void dna_adjust::DecideStaging() {
     if (projectSettings_.a.adjust_mode == SimultaneousMode) return;
     size_t free_b = 0, total_b = 0;
-    Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
+    MemInfo(&free_b, &total_b);
     auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
     if (!staged_) {
         double need = 8.0e9 + 3.0 * (double)NumChains() * sq((double)max_unknowns_);
@@ -500,6 +500,31 @@ void dna_adjust::DecideStaging() {
             stage_device_bytes_ += bytes;
         }
     }
+}
+
+// plan mode: a device object is only counted (full square of the padded order + its vector, as dnagpu_matrix_create allocates)
+void dna_adjust::NewMatrix(UINT32 n, dnagpu_matrix** m, UINT32 blk, const char* what) {
+    if (plan_only_) {
+        const double np = std::ceil(((double)n + 0.0) / 128.0) * 128.0;
+        plan_bytes_ += (np * np + np) * 8.0;
+        return;
+    }
+    Check(dnagpu_matrix_create(ctx_, n, m), blk, what);
+}
+void dna_adjust::NewBlock(UINT32 id, UINT32 n_stn, UINT32 n_msr, UINT32 blk, const char* what) {
+    if (plan_only_) {
+        plan_bytes_ += (double)n_stn * 24.0 * (2.0 + 3.0 * NumChains()) + (double)n_msr * 200.0;
+        return;
+    }
+    Check(dnagpu_block_create(ctx_, id, n_stn, n_msr), blk, what);
+}
+void dna_adjust::MemInfo(size_t* free_b, size_t* total_b) {
+    if (plan_only_) {
+        *total_b = (size_t)plan_hbm_;
+        *free_b = (size_t)std::max(0.0, plan_hbm_ - 1.5e9 - plan_bytes_);       // (the runtime's own share: ~1.5 GB on the pool's boxes)
+        return;
+    }
+    Check(dnagpu_mem_info(ctx_, free_b, total_b), 0, "PrepareAdjustment()");
 }
 
 void dna_adjust::MemoryPlan(double out[10]) const {
@@ -534,12 +559,12 @@ void dna_adjust::AllocateChainData() {
         const bool mine = !two_level_ok_ || OwnsBlock(k);
         const UINT32 nj = (UINT32)v_JSL_[k].size() * 3;
         if (nj && (mine || ends[k])) {
-            if (!B.jfwd) Check(dnagpu_matrix_create(ctx_, nj, &B.jfwd), k, "PrepareAdjustment(): junction matrix");
-            if (!B.jrev) Check(dnagpu_matrix_create(ctx_, nj, &B.jrev), k, "PrepareAdjustment(): junction matrix");
+            if (!B.jfwd) NewMatrix(nj, &B.jfwd, k, "PrepareAdjustment(): junction matrix");
+            if (!B.jrev) NewMatrix(nj, &B.jrev, k, "PrepareAdjustment(): junction matrix");
         }
         if (condensed_ok_ && mine && !B.keep.empty() && !B.red) {
-            Check(dnagpu_block_create(ctx_, blockCount_ + k, (UINT32)B.keep.size(), 0), k, "PrepareAdjustment(): condensed block");
-            Check(dnagpu_matrix_create(ctx_, (UINT32)B.keep.size() * 3, &B.red), k, "PrepareAdjustment(): condensed block");
+            NewBlock(blockCount_ + k, (UINT32)B.keep.size(), 0, k, "PrepareAdjustment(): condensed block");
+            NewMatrix((UINT32)B.keep.size() * 3, &B.red, k, "PrepareAdjustment(): condensed block");
         }
     }
 }
@@ -609,7 +634,7 @@ void dna_adjust::PrepareCondensedBlocks() {
     // needs storage of its own, n^2 + 3 k n doubles.
     const bool lend = !Staged() && !ReuseRequested();
     size_t free_b = 0, total_b = 0, max_keep = 0;
-    Check(dnagpu_mem_info(ctx_, &free_b, &total_b), 0, "PrepareAdjustment()");
+    MemInfo(&free_b, &total_b);
     auto sq = [](double n) { return (n + 256.0) * (n + 256.0) * 8.0; };
     double later = 8.0e9, rig = 0.0;
     for (UINT32 k = 0; k < blockCount_; ++k)
@@ -655,7 +680,7 @@ void dna_adjust::PrepareCondensedBlocks() {
             if (OwnsBlock(k)) max_keep = std::max(max_keep, blocks_[k].keep.size());
     const int chains = NumChains();
     if (max_keep)
-        for (int c = 0; c < chains; ++c) Check(dnagpu_matrix_create(ctx_, (UINT32)max_keep * 3, &kwork_[c]), 0, "PrepareAdjustment(): kept-block work matrix");
+        for (int c = 0; c < chains; ++c) NewMatrix((UINT32)max_keep * 3, &kwork_[c], 0, "PrepareAdjustment(): kept-block work matrix");
     // a.batch_blocks: every member of a batch beyond the first works in a matrix of its own (+ the panels of a diagonal block, a
     // fifth of it): as many as what is left of the budget admits
     // (the workspaces belong to a chain and the groups of a phase run on all chains at once: what the chains have been granted together

@@ -74,38 +74,57 @@ void dnaadj_destroy(dnaadj_handle* h) {
 
 const char* dnaadj_last_error(const dnaadj_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
+static void to_project_settings(const dnaadj_settings* s, dynadjust::project_settings& p) {
+    p.a.bst_file = s->bst_file ? s->bst_file : "";
+    p.a.bms_file = s->bms_file ? s->bms_file : "";
+    p.a.seg_file = s->seg_file ? s->seg_file : "";
+    p.s.asl_file = s->asl_file ? s->asl_file : "";
+    p.a.adjust_mode = (uint16_t)s->adjust_mode;
+    p.a.multi_thread = (uint16_t)(s->multi_thread ? 1 : 0);
+    p.a.max_iterations = (uint16_t)s->max_iterations;
+    p.a.iteration_threshold = s->iteration_threshold;
+    p.a.free_std_dev = s->free_std_dev;
+    p.a.fixed_std_dev = s->fixed_std_dev;
+    p.a.scale_normals_to_unity = (uint16_t)(s->scale_normals_to_unity ? 1 : 0);
+    p.a.device = s->device;
+    if (s->confidence_interval > 0.0f) p.a.confidence_interval = s->confidence_interval;
+    p.o._adj_msr_tstat = (uint16_t)(s->output_tstat ? 1 : 0);
+    p.a.reuse_inverses = (uint16_t)(s->reuse_inverses ? 1 : 0);
+    p.a.schur_carry = (uint16_t)(s->schur_carry ? 1 : 0);
+    p.a.keep_factors = (uint16_t)(s->keep_factors ? 1 : 0);
+    p.a.stage = (uint16_t)(s->stage ? 1 : 0);
+    p.a.dist_rank = s->dist_rank;
+    p.a.dist_world = s->dist_world > 0 ? s->dist_world : 1;
+    if (s->n_devices > 1 && s->devices) p.a.devices.assign(s->devices, s->devices + s->n_devices);
+    if (s->dist_transport) p.a.dist_transport = s->dist_transport;
+    p.a.dist_two_level = (uint16_t)(s->dist_two_level ? 1 : 0);
+    p.a.defer_variances = (uint16_t)(s->defer_variances < 0 ? 0 : s->defer_variances > 2 ? 2 : s->defer_variances);
+    p.a.batch_blocks = (uint16_t)(s->batch_blocks < 0 ? 0 : s->batch_blocks > 16 ? 16 : s->batch_blocks);
+    if (s->network_name) p.g.network_name = s->network_name;
+    if (s->output_folder) p.g.output_folder = s->output_folder;
+}
+
 int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s) {
     if (!s) return DNAADJ_EINVAL;
     return guarded(h, [&] {
         dynadjust::project_settings p;
-        p.a.bst_file = s->bst_file ? s->bst_file : "";
-        p.a.bms_file = s->bms_file ? s->bms_file : "";
-        p.a.seg_file = s->seg_file ? s->seg_file : "";
-        p.s.asl_file = s->asl_file ? s->asl_file : "";
-        p.a.adjust_mode = (uint16_t)s->adjust_mode;
-        p.a.multi_thread = (uint16_t)(s->multi_thread ? 1 : 0);
-        p.a.max_iterations = (uint16_t)s->max_iterations;
-        p.a.iteration_threshold = s->iteration_threshold;
-        p.a.free_std_dev = s->free_std_dev;
-        p.a.fixed_std_dev = s->fixed_std_dev;
-        p.a.scale_normals_to_unity = (uint16_t)(s->scale_normals_to_unity ? 1 : 0);
-        p.a.device = s->device;
-        if (s->confidence_interval > 0.0f) p.a.confidence_interval = s->confidence_interval;
-        p.o._adj_msr_tstat = (uint16_t)(s->output_tstat ? 1 : 0);
-        p.a.reuse_inverses = (uint16_t)(s->reuse_inverses ? 1 : 0);
-        p.a.schur_carry = (uint16_t)(s->schur_carry ? 1 : 0);
-        p.a.keep_factors = (uint16_t)(s->keep_factors ? 1 : 0);
-        p.a.stage = (uint16_t)(s->stage ? 1 : 0);
-        p.a.dist_rank = s->dist_rank;
-        p.a.dist_world = s->dist_world > 0 ? s->dist_world : 1;
-        if (s->n_devices > 1 && s->devices) p.a.devices.assign(s->devices, s->devices + s->n_devices);
-        if (s->dist_transport) p.a.dist_transport = s->dist_transport;
-        p.a.dist_two_level = (uint16_t)(s->dist_two_level ? 1 : 0);
-        p.a.defer_variances = (uint16_t)(s->defer_variances < 0 ? 0 : s->defer_variances > 2 ? 2 : s->defer_variances);
-        p.a.batch_blocks = (uint16_t)(s->batch_blocks < 0 ? 0 : s->batch_blocks > 16 ? 16 : s->batch_blocks);
-        if (s->network_name) p.g.network_name = s->network_name;
-        if (s->output_folder) p.g.output_folder = s->output_folder;
+        to_project_settings(s, p);
         h->adj->PrepareAdjustment(p);
+    });
+}
+
+int dnaadj_plan_distributed(dnaadj_handle* h, const dnaadj_settings* s, int world, double hbm_bytes, char* json, size_t cap, size_t* needed) {
+    if (!s) return DNAADJ_EINVAL;
+    return guarded(h, [&] {
+        dynadjust::project_settings p;
+        to_project_settings(s, p);
+        const std::string text = h->adj->PlanDistributed(p, world, hbm_bytes);
+        if (needed) *needed = text.size() + 1;
+        if (json && cap) {
+            const size_t n = std::min(cap - 1, text.size());
+            memcpy(json, text.data(), n);
+            json[n] = 0;
+        }
     });
 }
 

@@ -79,6 +79,13 @@ void dnaadj_destroy(dnaadj_handle* h);
 const char* dnaadj_last_error(const dnaadj_handle* h);
 
 int dnaadj_prepare(dnaadj_handle* h, const dnaadj_settings* s);        /* dna_adjust::PrepareAdjustment */
+/* PrepareAdjustment's plan for `world` GPUs of `hbm_bytes` each as JSON, WITHOUT a device (a dry run for a node one does not have, and the
+ * device-free view of the N > 1 schedule): per rank the owned run of blocks and its share of sum n^3, the HBM budget (blocks and chain
+ * data, chains' workspaces, variance matrices or the staged store's host / device split, kept factors, batch workspaces) and whether it
+ * fits, the two-level chains' run (end stations, merges in order, steps per level) and the bytes of every exchange of an iteration
+ * (condensed blocks one-level, run systems two-level, the coordinates' all-reduce).  The handle is left unprepared.
+ * (the reference sizes its threads' work the same way before it starts them: dnaadjust-multi.cpp:92-140) */
+int dnaadj_plan_distributed(dnaadj_handle* h, const dnaadj_settings* s, int world, double hbm_bytes, char* json, size_t cap, size_t* needed);
 int dnaadj_adjust(dnaadj_handle* h, int* status);                      /* dna_adjust::AdjustNetwork -> _ADJUST_STATUS_ */
 int dnaadj_cancel(dnaadj_handle* h);                                   /* dna_adjust::CancelAdjustment */
 /* measurement helper (not in the reference): back to the state right after dnaadj_prepare, data stays in HBM */
