@@ -361,9 +361,24 @@ void dna_adjust::FreeTwoLevel() {
 
 void dna_adjust::PrepareTwoLevel() {
     FreeTwoLevel();
-    const int W = DistWorld(), me = DistRank();
+    seg_local_ = false;
+    int W = DistWorld(), me = DistRank();
     // (every condition below is the same on every rank: nothing that depends on a rank's free memory)
-    if (W < 2 || !projectSettings_.a.dist_two_level || !CondensedSchedule() || projectSettings_.a.reuse_inverses != 0) return;
+    if (!CondensedSchedule() || projectSettings_.a.reuse_inverses != 0) return;
+    // One GPU, many small blocks (round 4): the same three levels with the runs as VIRTUAL ranks of this GPU -- every run reduced on a
+    // chain of its own, the scan over the runs, every run's two chains on chains of their own; nothing is exchanged.  2 (B - 1) dependent
+    // steps on two chains become ~ B / V + V + 2 B / C on C chains (V runs): a third of the depth at B = 120, V = C = 8.  Only where the
+    // chain phase matters: at least 4 blocks per run and chains to run them side by side (DNAGPU_LOCAL_RUNS: 0 off, n runs).
+    const bool local = W < 2;
+    if (local) {
+        int V = NumChains() >= 4 ? NumChains() : 0;
+        if (const char* e = getenv("DNAGPU_LOCAL_RUNS")) V = atoi(e);
+        if (!projectSettings_.a.multi_thread || NumChains() < 2 || V < 2 || blockCount_ < (UINT32)(4 * V) || Distributed()) return;
+        W = V;
+        me = 0;
+    } else if (!projectSettings_.a.dist_two_level) {
+        return;
+    }
     // one contiguous network, every rank a run of at least one block
     if (!v_blockMeta_[0]._blockFirst || !v_blockMeta_[blockCount_ - 1]._blockLast) return;
     for (UINT32 k = 0; k < blockCount_; ++k) {
@@ -371,9 +386,16 @@ void dna_adjust::PrepareTwoLevel() {
         if (m._blockIsolated || (m._blockFirst && k != 0) || (m._blockLast && k != blockCount_ - 1)) return;
         if (blocks_[k].keep.empty()) return;
     }
+    std::vector<int> run_of(blockCount_, 0);
+    if (local) {
+        // runs of (nearly) equal block count: a chain step costs the same whatever the block's own size (the condensed blocks are alike)
+        for (UINT32 k = 0; k < blockCount_; ++k) run_of[k] = (int)(((uint64_t)k * (uint64_t)W) / blockCount_);
+    } else {
+        for (UINT32 k = 0; k < blockCount_; ++k) run_of[k] = BlockOwner(k);
+    }
     std::vector<int> first(W, -1), last(W, -1);
     for (UINT32 k = 0; k < blockCount_; ++k) {
-        const int r = BlockOwner(k);
+        const int r = run_of[k];
         if (first[r] < 0) first[r] = (int)k;
         if (last[r] >= 0 && last[r] != (int)k - 1) return;       // runs must be contiguous
         last[r] = (int)k;
@@ -433,59 +455,64 @@ void dna_adjust::PrepareTwoLevel() {
         NewBlock(g.dev_block, (UINT32)g.stations.size(), 0, g.a, "PrepareAdjustment(): run system");
         NewMatrix((UINT32)g.stations.size() * 3, &g.S, g.a, "PrepareAdjustment(): run system");
     }
-    // the merges of the own run
-    segment_t& g = segs_[me];
-    std::vector<UINT32> prev;
-    for (UINT32 p = 0; p < blocks_[g.a].keep.size(); ++p) prev.push_back(gid(g.a, p));
-    size_t max_keep = 0;
-    for (UINT32 k = g.a + 1; k <= g.b; ++k) {
-        seg_step_t st;
-        std::vector<UINT32> blk;
-        for (UINT32 p = 0; p < blocks_[k].keep.size(); ++p) blk.push_back(gid(k, p));
-        std::vector<UINT32> U = prev;
-        U.insert(U.end(), blk.begin(), blk.end());
-        std::sort(U.begin(), U.end());
-        U.erase(std::unique(U.begin(), U.end()), U.end());
-        for (UINT32 s : prev) st.pos_prev.push_back((UINT32)position(U, s));
-        for (UINT32 s : blk) st.pos_blk.push_back((UINT32)position(U, s));
-        // stations that stay: the run's first junction row and block k's junction row towards k + 1
-        std::vector<UINT32> stay;
-        for (UINT32 p : blocks_[g.a].c_prev) stay.push_back(gid(g.a, p));
-        if (k + 1 < blockCount_)
-            for (UINT32 p : blocks_[k].c_next) stay.push_back(gid(k, p));
-        std::sort(stay.begin(), stay.end());
-        stay.erase(std::unique(stay.begin(), stay.end()), stay.end());
-        for (UINT32 s : stay) st.keep.push_back((UINT32)position(U, s));
-        // constraints of the stations that leave inside the run: where the forward chain adds them (first appearance)
-        for (UINT32 kk : (k == g.a + 1 ? std::vector<UINT32>{g.a, k} : std::vector<UINT32>{k})) {
-            const constraint_list& src = blocks_[kk].ccon_fwd;
-            for (size_t i = 0; i < src.stn.size(); ++i) {
-                const UINT32 s = gid(kk, src.stn[i]);
-                if (position(g.stations, s) >= 0) continue;
-                st.con.stn.push_back((UINT32)position(U, s));
-                st.con.w9.insert(st.con.w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
+    // the merges of the own run (of every run, when they all live on this GPU)
+    for (int rr = 0; rr < W; ++rr) {
+        if (!local && rr != me) continue;
+        segment_t& g = segs_[rr];
+        std::vector<UINT32> prev;
+        for (UINT32 p = 0; p < blocks_[g.a].keep.size(); ++p) prev.push_back(gid(g.a, p));
+        size_t max_keep = 0;
+        for (UINT32 k = g.a + 1; k <= g.b; ++k) {
+            seg_step_t st;
+            std::vector<UINT32> blk;
+            for (UINT32 p = 0; p < blocks_[k].keep.size(); ++p) blk.push_back(gid(k, p));
+            std::vector<UINT32> U = prev;
+            U.insert(U.end(), blk.begin(), blk.end());
+            std::sort(U.begin(), U.end());
+            U.erase(std::unique(U.begin(), U.end()), U.end());
+            for (UINT32 s : prev) st.pos_prev.push_back((UINT32)position(U, s));
+            for (UINT32 s : blk) st.pos_blk.push_back((UINT32)position(U, s));
+            // stations that stay: the run's first junction row and block k's junction row towards k + 1
+            std::vector<UINT32> stay;
+            for (UINT32 p : blocks_[g.a].c_prev) stay.push_back(gid(g.a, p));
+            if (k + 1 < blockCount_)
+                for (UINT32 p : blocks_[k].c_next) stay.push_back(gid(k, p));
+            std::sort(stay.begin(), stay.end());
+            stay.erase(std::unique(stay.begin(), stay.end()), stay.end());
+            for (UINT32 s : stay) st.keep.push_back((UINT32)position(U, s));
+            // constraints of the stations that leave inside the run: where the forward chain adds them (first appearance)
+            for (UINT32 kk : (k == g.a + 1 ? std::vector<UINT32>{g.a, k} : std::vector<UINT32>{k})) {
+                const constraint_list& src = blocks_[kk].ccon_fwd;
+                for (size_t i = 0; i < src.stn.size(); ++i) {
+                    const UINT32 s = gid(kk, src.stn[i]);
+                    if (position(g.stations, s) >= 0) continue;
+                    st.con.stn.push_back((UINT32)position(U, s));
+                    st.con.w9.insert(st.con.w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
+                }
             }
+            st.n_stn = (UINT32)U.size();
+            st.dev_block = 2 * blockCount_ + k;
+            NewBlock(st.dev_block, st.n_stn, 0, k, "PrepareAdjustment(): run merge");
+            max_keep = std::max(max_keep, stay.size());
+            prev = stay;
+            g.steps.push_back(std::move(st));
         }
-        st.n_stn = (UINT32)U.size();
-        st.dev_block = 2 * blockCount_ + k;
-        NewBlock(st.dev_block, st.n_stn, 0, k, "PrepareAdjustment(): run merge");
-        max_keep = std::max(max_keep, stay.size());
-        prev = stay;
-        g.steps.push_back(std::move(st));
+        if (g.a != g.b && prev != g.stations) {       // (the last merge must leave exactly the run's end stations)
+            FreeTwoLevel();
+            return;
+        }
+        if (g.steps.size() > 1)
+            for (dnagpu_matrix*& m : g.M) NewMatrix((UINT32)max_keep * 3, &m, g.a, "PrepareAdjustment(): run merge");
     }
-    if (g.a != g.b && prev != g.stations) {       // (the last merge must leave exactly the run's end stations)
-        FreeTwoLevel();
-        return;
-    }
-    if (g.steps.size() > 1)
-        for (dnagpu_matrix*& m : g.M) NewMatrix((UINT32)max_keep * 3, &m, g.a, "PrepareAdjustment(): run merge");
     two_level_ok_ = true;
+    seg_local_ = local;
 }
 
 // level 1: the own run condensed to its end stations
-void dna_adjust::ReduceOwnRun() {
-    segment_t& g = segs_[DistRank()];
-    const int c = 0;
+void dna_adjust::ReduceOwnRun() { ReduceRun(0, DistRank()); }
+
+void dna_adjust::ReduceRun(int c, int run) {
+    segment_t& g = segs_[run];
     if (g.a == g.b) {
         Check(dnagpu_matrix_copy(ctx_, c, g.S, blocks_[g.a].red), g.a, "Solve()");
         Check(dnagpu_chain_sync(ctx_, c), g.a, "Solve()");
@@ -536,7 +563,7 @@ void dna_adjust::ExchangeRuns() {
 // level 2: the two chains over the runs (every rank, identical arithmetic): jfwd at the last block of every run but the last,
 // jrev at the block before every run but the first
 void dna_adjust::ScanRuns() {
-    const int W = DistWorld();
+    const int W = (int)segs_.size();
     const bool two = NumChains() > 1;
     auto load = [&](int c, segment_t& g) {
         dnagpu_matrix* Wm = work_[c];
@@ -587,6 +614,27 @@ void dna_adjust::OwnRunChains() {
             for (UINT32 k = g.a; k < g.b && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
         if (c == 1 || !two)
             for (UINT32 k = g.b; k > g.a && !IsCancelled() && !chain_failed_; --k) CondensedReverseBlock(c, k);
+    });
+}
+
+// the three levels on ONE GPU (seg_local_): the runs are dealt to the chains, nothing is exchanged
+void dna_adjust::LocalSegmentedChains() {
+    const int W = (int)segs_.size(), C = NumChains();
+    OnEveryChain([&](int c) {
+        for (int r = c; r < W && !IsCancelled() && !chain_failed_; r += C) ReduceRun(c, r);
+    });
+    if (IsCancelled()) return;
+    ScanRuns();
+    if (IsCancelled()) return;
+    // 2 W sequences: the forward chain of run q (q < W), the reverse chain of run q - W; the longest first is not needed, they are alike
+    OnEveryChain([&](int c) {
+        for (int q = c; q < 2 * W && !IsCancelled() && !chain_failed_; q += C) {
+            const segment_t& g = segs_[q % W];
+            if (q < W)
+                for (UINT32 k = g.a; k < g.b && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
+            else
+                for (UINT32 k = g.b; k > g.a && !IsCancelled() && !chain_failed_; --k) CondensedReverseBlock(c, k);
+        }
     });
 }
 

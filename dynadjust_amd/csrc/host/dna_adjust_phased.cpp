@@ -1290,6 +1290,10 @@ void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks) {
 
 // the forward chain on chain 0 beside the reverse chain on chain 1 (one after the other without a.multi_thread)
 void dna_adjust::CondensedChains() {
+    if (two_level_ok_ && seg_local_) {
+        LocalSegmentedChains();
+        return;
+    }
     const bool two = NumChains() > 1;
     OnEveryChain([&](int c) {
         if (c == 0)
