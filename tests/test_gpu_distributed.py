@@ -171,7 +171,7 @@ def test_segmented_chains_on_one_gpu(built, orc, tmp_path, monkeypatch, runs):
         a.close()
     assert res["runs"][2] > res["plain"][2]                 # (the merges of the runs are work the plain chains do not have)
     for k in range(blocks):
-        assert np.abs(res["runs"][0][k] - res["plain"][0][k]).max() < 1e-9
+        assert np.abs(res["runs"][0][k] - res["plain"][0][k]).max() < 5e-9      # (a few units in the last place of a 4e6 m coordinate)
     o.close()
 
 

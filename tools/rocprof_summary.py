@@ -25,7 +25,7 @@ def stats(d, out, header):
     per = defaultdict(lambda: [0, 0.0])
     t0, t1 = None, None
     n = 0
-    gemm_iv = []
+    gemm_iv, all_iv = [], []
     for path in _find(d, "kernel_trace.csv"):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -36,6 +36,7 @@ def stats(d, out, header):
                 t0 = s if t0 is None else min(t0, s)
                 t1 = e if t1 is None else max(t1, e)
                 n += 1
+                all_iv.append((s, e))
                 if "gemm_f64" in row["Kernel_Name"]:
                     gemm_iv.append((s, e))
     tot = sum(v[1] for v in per.values())
@@ -55,6 +56,17 @@ def stats(d, out, header):
         f.write("# kernel dispatches: %d, first start -> last end: %.3f s   (durations in microseconds)\n" % (n, (t1 - t0) / 1e9))
         f.write("# gemm_f64* kernels: %d dispatches, summed duration %.3f s, union of their intervals %.3f s\n"
                 % (len(gemm_iv), sum(e - s for s, e in gemm_iv) / 1e9, union / 1e9))
+        all_iv.sort()
+        busy, end = 0, None
+        for s, e in all_iv:
+            if end is None or s >= end:
+                busy += e - s
+                end = e
+            elif e > end:
+                busy += e - end
+                end = e
+        f.write("# all kernels: summed duration %.3f s, time with at least one kernel executing %.3f s (average overlap %.2f), device idle %.3f s\n"
+                % (tot / 1e6, busy / 1e9, (tot / 1e6) / max(busy / 1e9, 1e-12), (t1 - t0 - busy) / 1e9))
         f.write("%-112s %7s %14s %12s %7s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, (c, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             f.write("%-112s %7d %14.1f %12.3f %7.2f\n" % (name[:112], c, us, us / c, 100.0 * us / tot))
