@@ -623,8 +623,9 @@ void dna_adjust::PrepareBlocks() {
         const double per_chain = 3.0 * ((double)max_unknowns_ + 256.0) * ((double)max_unknowns_ + 256.0) * 8.0;
         while (mt_chains_ > 1 && ((UINT32)mt_chains_ > blockCount_ || per_chain * mt_chains_ > 0.5 * (double)free_b)) --mt_chains_;
         if (mt_chains_ < 2 && blockCount_ > 1 && 2.0 * per_chain <= 0.5 * (double)free_b) mt_chains_ = 2;   // the two junction chains
-        // many small blocks: the chain phase is what is left of an iteration, and its runs want chains of their own (PrepareTwoLevel, local)
-        if (!getenv("DNAGPU_CHAINS") && projectSettings_.a.multi_thread && blockCount_ >= 32 && DNAGPU_NUM_CHAINS * per_chain <= 0.05 * (double)free_b)
+        // DNAGPU_LOCAL_RUNS=n (opt-in, PrepareTwoLevel): many small blocks, the chains over n runs of them want chains of their own
+        if (!getenv("DNAGPU_CHAINS") && getenv("DNAGPU_LOCAL_RUNS") && atoi(getenv("DNAGPU_LOCAL_RUNS")) > 1 && projectSettings_.a.multi_thread &&
+            blockCount_ >= 32 && DNAGPU_NUM_CHAINS * per_chain <= 0.05 * (double)free_b)
             mt_chains_ = DNAGPU_NUM_CHAINS;
     }
     const int chains = NumChains();

@@ -365,13 +365,15 @@ void dna_adjust::PrepareTwoLevel() {
     int W = DistWorld(), me = DistRank();
     // (every condition below is the same on every rank: nothing that depends on a rank's free memory)
     if (!CondensedSchedule() || projectSettings_.a.reuse_inverses != 0) return;
-    // One GPU, many small blocks (round 4): the same three levels with the runs as VIRTUAL ranks of this GPU -- every run reduced on a
-    // chain of its own, the scan over the runs, every run's two chains on chains of their own; nothing is exchanged.  2 (B - 1) dependent
-    // steps on two chains become ~ B / V + V + 2 B / C on C chains (V runs): a third of the depth at B = 120, V = C = 8.  Only where the
-    // chain phase matters: at least 4 blocks per run and chains to run them side by side (DNAGPU_LOCAL_RUNS: 0 off, n runs).
+    // One GPU, many small blocks (round 4, opt-in: DNAGPU_LOCAL_RUNS=n): the same three levels with the runs as VIRTUAL ranks of this GPU --
+    // every run reduced on a chain of its own, the scan over the runs, every run's two chains on chains of their own; nothing is exchanged.
+    // 2 (B - 1) dependent steps on two chains become ~ B / V + V + 2 B / C on C chains (V runs): a third of the depth at B = 120, V = C = 8.
+    // MEASURED (profiles/r04_smallblocks_chains.txt): the depth is not what binds -- eight streams of dependent 30 - 60 us kernels slow each
+    // other down (leaf 55 -> 65 us, small products 31 -> 44 us) and the phase gains 7 % (99.5 -> 92.2 ms per iteration) while the batched
+    // phases lose what eight chains cost them: 598 against 567 - 576 ms per adjustment.  Hence off unless asked for.
     const bool local = W < 2;
     if (local) {
-        int V = NumChains() >= 4 ? NumChains() : 0;
+        int V = 0;
         if (const char* e = getenv("DNAGPU_LOCAL_RUNS")) V = atoi(e);
         if (!projectSettings_.a.multi_thread || NumChains() < 2 || V < 2 || blockCount_ < (UINT32)(4 * V) || Distributed()) return;
         W = V;

@@ -137,11 +137,11 @@ def test_two_level_chains(built, orc, tmp_path, ranks, blocks, mt):
     o.close()
 
 
-@pytest.mark.parametrize("runs", ["", "2", "5"])
+@pytest.mark.parametrize("runs", ["8", "2", "5"])
 def test_segmented_chains_on_one_gpu(built, orc, tmp_path, monkeypatch, runs):
     """many small blocks on ONE GPU (round 4): the two-level chains with the runs as virtual ranks of the GPU -- every run reduced on a chain of its
-    own, the scan over the runs, every run's forward and reverse chain on chains of their own (LocalSegmentedChains; nothing exchanged).  Default
-    (8 chains, 8 runs once there are 32 blocks), 2 and 5 runs (DNAGPU_LOCAL_RUNS): same results as the plain chains (DNAGPU_LOCAL_RUNS=0) to
+    own, the scan over the runs, every run's forward and reverse chain on chains of their own (LocalSegmentedChains; nothing exchanged; opt-in,
+    DNAGPU_LOCAL_RUNS = 8 / 2 / 5 runs -- measured: not faster, profiles/r04_smallblocks_chains.txt): same results as the plain chains (DNAGPU_LOCAL_RUNS=0) to
     rounding and as the oracle to 1e-8, statistics included."""
     blocks = 34
     adjust.write_synthetic_network(str(tmp_path), "n", 2 * blocks, 9, 0, blocks, seed=41)
