@@ -704,7 +704,8 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     ex = a.exchange_stats()
     mine = {"alg": a.algorithmic_flops(), "gemm_ms": prof_ms.value, "issued": prof_f.value, "solves": a.solve_count(), "completions": a.completion_count(),
             "eliminations": a.elimination_count(), "exchange_ms": ex["exchange_ms"], "chain_ms": ex["chain_ms"], "bytes": (ex["bytes"] - bytes0) / max(1, args.steps),
-            "rccl_ranks": a.device_instance_stats(0)["rccl_ranks"], "hbm0": hbm0, "hbm1": _hbm(lib, ctx), "staged": bool(lib.dnaadj_staged(a.h))}
+            "rccl_ranks": a.device_instance_stats(0)["rccl_ranks"], "hbm0": hbm0, "hbm1": _hbm(lib, ctx), "staged": bool(lib.dnaadj_staged(a.h)),
+            "batched_block_steps": a.batched_block_steps(), "batched_flops": a.batched_flops(), "plan": a.memory_plan()}
     allv = [None] * world
     dist.all_gather_object(allv, mine)
     stations = lib.dnaadj_station_count(a.h)
@@ -721,6 +722,11 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
                               p.multi_thread)
         out["hbm_per_rank"] = {"total_gb": [round(v["hbm1"][1] / 1e9, 1) for v in allv], "free_after_prepare_gb": [round(v["hbm0"][0] / 1e9, 1) for v in allv],
                                "free_at_end_gb": [round(v["hbm1"][0] / 1e9, 1) for v in allv], "variances_staged_in_host_memory": any(v["staged"] for v in allv)}
+        # what every rank batched of its own blocks (block steps and share of its flops in the LAST step) and the plan PrepareAdjustment made on it
+        out["batches_per_rank"] = {"batched_block_steps": [v["batched_block_steps"] for v in allv],
+                                   "batched_fraction_of_flops": [round(v["batched_flops"] / v["alg"], 3) if v["alg"] else 0.0 for v in allv],
+                                   "batch_members_beyond_first": [v["plan"].get("batch_members_beyond_first") for v in allv],
+                                   "blocks_keeping_their_factor": [v["plan"].get("blocks_keeping_their_factor") for v in allv]}
     a.close()
     return out
 
