@@ -464,6 +464,7 @@ int dnagpu_debug_fail_batch_workspaces(long n) {
 }
 
 long dnagpu_debug_set_small_tiles(long tiles) { return dnagpu::small_tiles_set(tiles); }
+long dnagpu_debug_set_tiny_tiles(long tiles) { return dnagpu::tiny_tiles_set(tiles); }
 
 long dnagpu_debug_set_pair_tiles(long tiles) { return dnagpu::pair_tiles_set(tiles); }
 

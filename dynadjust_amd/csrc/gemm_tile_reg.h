@@ -72,7 +72,7 @@ __device__ __forceinline__ void reg_tile_product(const double* A, int lda, const
     // the memory latency.  Measured gain: small (36 workgroups, K = 512: 25 -> 23 us; 136 workgroups, K = 1024: 49 -> 44 us) --
     // these launches are bound by the MFMA rate of the few CUs they occupy (13.7 us of the 23), not by the loads.
     // Slab s lives in ring slot s % RS from its load (issued at the start of slab s - RS) to its LDS store (during slab s - 1).
-    constexpr int RS = (TILE == 64) ? 3 : 1;
+    constexpr int RS = (TILE <= 64) ? 3 : 1;
     d2 ga[RS][G::NQ], gb[RS][G::NQ];
     uint32_t offa[G::NQ], offb[G::NQ];
     stage_offsets<A_KC, TILE, WAVES>(lda, tid, offa);
@@ -125,6 +125,7 @@ __device__ __forceinline__ void reg_tile_product(const double* A, int lda, const
     constexpr int NM = G::MI * G::NI;                 // MFMAs per k-step
     constexpr int NL = 2 * G::NQ;                     // global loads / LDS stores per slab
     constexpr int NR = G::MI + G::NI;                 // fragment reads per k-step (before ds_read2 merging)
+    constexpr bool HINTS = NM >= NL && NM >= NR / 2;   // (TILE = 32 has ONE MFMA per k-step: nothing to interleave, the compiler's order stands)
     auto slab = [&](int t, auto slot_tag) {
         constexpr bool more = true;
         constexpr int slot = decltype(slot_tag)::value;      // t % RS: free since slab t went to LDS; slab t + RS moves in
@@ -136,21 +137,25 @@ __device__ __forceinline__ void reg_tile_product(const double* A, int lda, const
         load_slab(t + RS, slot_tag);
         read_frags(As, Bs, 1, 1);
         mfmas(0);
+        if constexpr (HINTS) {
 #pragma unroll
-        for (int g = 0; g < NL; ++g) {
-            if (more) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);      // NM/NL MFMA
+            for (int g = 0; g < NL; ++g) {
+                if (more) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);      // NM/NL MFMA
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         read_frags(As, Bs, 2, 0);
         mfmas(1);
+        if constexpr (HINTS) {
 #pragma unroll
-        for (int g = 0; g < NR / 2; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NM / (NR / 2), 0);
+            for (int g = 0; g < NR / 2; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / (NR / 2), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         read_frags(As, Bs, 3, 1);
         mfmas(0);
         stage_store<A_KC, TILE, WAVES>(An, tid, ga[nxt]);
@@ -189,15 +194,16 @@ __device__ __forceinline__ void reg_tile_product(const double* A, int lda, const
         // C tile read in batches of 8 independent loads before it is combined (not one load-wait per element)
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi) {
+            constexpr int NB = G::NI >= 2 ? 2 : 1;       // (TILE = 32: one MFMA tile per wave along j)
 #pragma unroll
-            for (int n2 = 0; n2 < G::NI; n2 += 2) {
-                double cold[2][4];
+            for (int n2 = 0; n2 < G::NI; n2 += NB) {
+                double cold[NB][4];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) cold[ni][r] = cbase[(size_t)((n2 + ni) * 16 + 4 * r) * ldc + mi * 16];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[mi][n2 + ni][r] = alpha * acc[mi][n2 + ni][r] + beta * cold[ni][r];
             }

@@ -80,6 +80,10 @@ void launch_gemm_fused(const FusedArgs& f, int grid, hipStream_t s);
 // launches with fewer 128-tiles than this run on 64x64 block tiles
 // (cfg3, r02: 160 / 384 / 768 -> 3.83 / 3.79 / 3.77 s per step with four chains, 4.38 / 4.33 / 4.35 s with one)
 constexpr int SMALL_LAUNCH_TILES = 512;
+// ... and with fewer 128-tiles than this on 32 x 32 block tiles (DNAGPU_TINY_TILES; round 4).  A 64-tile of K = 512 is 13.7 us of MFMA time on
+// the ONE CU it occupies, and a product of a dozen 128-tiles occupies a fifth of the chip: sixteen times the workgroups of the 128-tile shape
+// spread the same flops over every CU there is.  Same bits (an element's k order does not depend on the tile it is computed in).
+constexpr int TINY_LAUNCH_TILES = 16;
 
 // Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).

@@ -250,6 +250,10 @@ void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
         launch_gemm_t<64, 4>(a, a_kc, b_kc, s);
         return;
     }
+    if (a.tile == 32) {
+        launch_gemm_t<32, 4>(a, a_kc, b_kc, s);
+        return;
+    }
     static const int k_asc = getenv("DNAGPU_K_ASCENDING") ? 1 : 0;   // diagnostic A/B switch
     GemmArgs b = a;
     b.k_ascending = k_asc;

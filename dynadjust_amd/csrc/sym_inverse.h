@@ -171,5 +171,6 @@ double schur_split();
 void fault_inject_reset(long nth);
 // threshold (in 128-tiles per launch) below which a launch uses the 64-tile kernel; negative restores the default; returns the old value
 long small_tiles_set(long v);
+long tiny_tiles_set(long v);      // 128-tiles per launch below which the product runs on 32 x 32 tiles (< 0: the default, TINY_LAUNCH_TILES)
 
 }  // namespace dnagpu

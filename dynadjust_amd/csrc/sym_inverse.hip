@@ -107,6 +107,15 @@ static std::atomic<long> g_small_tiles{[] {
     const char* e = getenv("DNAGPU_SMALL_TILES");
     return e ? atol(e) : (long)SMALL_LAUNCH_TILES;
 }()};
+static std::atomic<long> g_tiny_tiles{[] {
+    const char* e = getenv("DNAGPU_TINY_TILES");
+    return e ? atol(e) : (long)TINY_LAUNCH_TILES;
+}()};
+long tiny_tiles_set(long v) {
+    long old = g_tiny_tiles.load();
+    g_tiny_tiles.store(v < 0 ? (long)TINY_LAUNCH_TILES : v);
+    return old;
+}
 long small_tiles_set(long v) {
     long old = g_small_tiles.load();
     g_small_tiles.store(v < 0 ? (long)SMALL_LAUNCH_TILES : v);
@@ -117,11 +126,12 @@ hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo, int jt_hi
     long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
     // (a batched launch decides by one member's tiles, like the unbatched launch whose bits it must reproduce; counting all
     //  members' tiles -- the 128-tile shape from fewer tiles per member on -- measured no different: 2 479 against 2 483 ms per cfg3 step)
-    a.tile = total < g_small_tiles.load() ? 64 : 128;
+    a.tile = total < g_small_tiles.load() ? (total < g_tiny_tiles.load() ? 32 : 64) : 128;
     // (the pair threshold is part of the key: a table built before dnagpu_debug_set_pair_tiles changed it is not the one wanted after)
     const long pair_from = pair_tiles_get();
     const uint64_t shape = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
-                           ((uint64_t)(a.tile == 64 ? 1 : 0) << 37) | ((uint64_t)(pair_from > 0 && total >= pair_from ? 1 : 0) << 38) | ((uint64_t)(a.K / 16) << 40);
+                           ((uint64_t)(a.tile == 64 ? 1 : 0) << 37) | ((uint64_t)(pair_from > 0 && total >= pair_from ? 1 : 0) << 38) | ((uint64_t)(a.tile == 32 ? 1 : 0) << 39) |
+                           ((uint64_t)(a.K / 16) << 40);
     const auto key = std::make_pair(shape, jt_lo < 0 ? 0xffffffffu : ((uint32_t)jt_lo << 16) | (uint32_t)jt_hi);
     auto it = ws.order_cache.find(key);
     if (it == ws.order_cache.end()) {
