@@ -126,7 +126,8 @@ hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo, int jt_hi
     long total = a.lower ? (long)a.mt * (a.mt + 1) / 2 : (long)a.mt * a.nt;
     // (a batched launch decides by one member's tiles, like the unbatched launch whose bits it must reproduce; counting all
     //  members' tiles -- the 128-tile shape from fewer tiles per member on -- measured no different: 2 479 against 2 483 ms per cfg3 step)
-    a.tile = total < g_small_tiles.load() ? (total < g_tiny_tiles.load() ? 32 : 64) : 128;
+    // (the opt-in fused launches walk 64-tiles: with them on, the 32-tile shape stays out)
+    a.tile = total < g_small_tiles.load() ? ((total < g_tiny_tiles.load() && !ws.fuse) ? 32 : 64) : 128;
     // (the pair threshold is part of the key: a table built before dnagpu_debug_set_pair_tiles changed it is not the one wanted after)
     const long pair_from = pair_tiles_get();
     const uint64_t shape = (uint64_t)a.mt | ((uint64_t)a.nt << 16) | ((uint64_t)a.kmode << 32) | ((uint64_t)(a.lower ? 1 : 0) << 36) |
