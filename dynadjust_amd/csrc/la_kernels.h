@@ -83,7 +83,10 @@ constexpr int SMALL_LAUNCH_TILES = 512;
 // ... and with fewer 128-tiles than this on 32 x 32 block tiles (DNAGPU_TINY_TILES; round 4).  A 64-tile of K = 512 is 13.7 us of MFMA time on
 // the ONE CU it occupies, and a product of a dozen 128-tiles occupies a fifth of the chip: sixteen times the workgroups of the 128-tile shape
 // spread the same flops over every CU there is.  Same bits (an element's k order does not depend on the tile it is computed in).
-constexpr int TINY_LAUNCH_TILES = 16;
+// Measured (profiles/r04_tiny_tiles.txt; thresholds 0 / 8 / 16 / 32 / 64 / 128 / 256 / 512): inverse n = 6 144 27.7 -> 31.5 TFLOP/s, elimination
+// n = 19 968 49.7 -> 52.7, cfg2 404 -> 397 ms, cfg3 one chain 2 626 -> 2 575 ms, the small-block workload 569 -> 516 ms; 64 is where the
+// batched workloads stop gaining (single matrices gain another 1 - 2 % up to 256).
+constexpr int TINY_LAUNCH_TILES = 64;
 
 // Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).

@@ -116,7 +116,7 @@ int dnagpu_debug_fail_batch_workspaces(long n);
 /* Launches with fewer than `tiles` 128 x 128 tiles use the 64-tile latency kernel (default 160); 0 sends every launch through the
  * 128-tile throughput kernel (gemm_f64_dma_kernel), a negative value restores the default.  Returns the previous value. */
 long dnagpu_debug_set_small_tiles(long tiles);
-/* ... and below `tiles` on 32 x 32 tiles (default 16; 0: never; < 0: the default again): the products of the recursion's bottom and of the chains on
+/* ... and below `tiles` on 32 x 32 tiles (default 64; 0: never; < 0: the default again): the products of the recursion's bottom and of the chains on
  * condensed blocks, where a launch has too few 64-tiles to occupy the chip.  Same bits.  Returns the previous value. */
 long dnagpu_debug_set_tiny_tiles(long tiles);
 /* Opt-in experiment (off: measured no gain, tile_order.hip): launches of at least `tiles` 128-tiles with a triangular k range give every

@@ -106,9 +106,9 @@ def test_throughput_kernel_against_oracle_at_small_orders(gpu_ctx, orc, big_tile
     assert np.abs(inv_s - ref).max() / np.abs(ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("n", [100, 257, 640, 1000, 1500, 2304])
+@pytest.mark.parametrize("n", [100, 257, 640, 1000, 1500, 2304, 4096])
 def test_tiny_launches_on_32_tiles_have_the_bits_of_64_tiles(gpu_ctx, built, orc, n):
-    """DNAGPU_TINY_TILES (round 4): products of fewer than 16 128-tiles run on 32 x 32 block tiles -- sixteen times the workgroups of the 128-tile
+    """DNAGPU_TINY_TILES (round 4): products of fewer than 64 128-tiles run on 32 x 32 block tiles -- sixteen times the workgroups of the 128-tile
     shape, so that the bottom of the recursion and the chains on condensed blocks occupy more than a handful of CUs.  An element's k order does
     not depend on the tile it is computed in: the inverse is bit for bit the one with the 32-tile shape off, and within 1e-11 of the oracle."""
     M = _dense_spd(n, n + 7)
@@ -121,7 +121,7 @@ def test_tiny_launches_on_32_tiles_have_the_bits_of_64_tiles(gpu_ctx, built, orc
         inv64 = gpu_ctx.cholesky_inverse_packed(ap, n)
     finally:
         built.dnagpu_debug_set_tiny_tiles(old)
-    assert old == 16
+    assert old == 64
     assert np.array_equal(inv32, inv64)
     assert np.abs(inv32 - ref).max() / np.abs(ref).max() < 1e-11
 
