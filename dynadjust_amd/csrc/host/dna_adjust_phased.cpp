@@ -571,6 +571,7 @@ void dna_adjust::AllocateChainData() {
 
 void dna_adjust::PrepareCondensedBlocks() {
     condensed_ok_ = false;
+    transient_ok_ = false;
     batch_limit_ = 0;
     if (projectSettings_.a.adjust_mode == SimultaneousMode || !projectSettings_.a.schur_carry) {
         AllocateChainData();
