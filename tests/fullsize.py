@@ -14,7 +14,16 @@ WORKLOADS = {
     # four of cfg4's 128 strips at cfg4's block geometry: n ~ 27 000 unknowns per block, junction rows of 1 000 stations (J = 3 000),
     # condensed blocks of 6 000 unknowns -- 20 Solve() calls, ~4e14 flops and ~45 GB on the CPU
     "cfg4q": (32, 1000, 85000, 4, True),
+    # bench.py's `smallblocks`: the same 100 000 stations cut the way dnasegment's defaults would -- strips of 1 ... 10 rows of 150 stations,
+    # 120 blocks of n = 900 ... 4 950 -- whole: 1 074 Solve() calls, 4.4e13 flops, a minute on the CPU
+    "smallblocks": (668, 150, 266666, 1, True, {"rows_lo": 1, "rows_hi": 10}),
 }
+
+
+def synth_args(workload):
+    """(rows, cols, baselines, blocks, phased, extra generator arguments) of a workload"""
+    w = WORKLOADS[workload]
+    return w[0], w[1], w[2], w[3], w[4], (w[5] if len(w) > 5 else {})
 SEED = 20260928
 ROW_STRIDE = 8          # rows kept of every sampled column
 

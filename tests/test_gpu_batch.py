@@ -55,14 +55,19 @@ def test_small_blocks_of_unequal_size_share_a_bucket(built, orc, tmp_path):
     (own shapes: the padded ones differ in blocking, so equal to rounding, not bit for bit)."""
     info = adjust.write_synthetic_network(str(tmp_path), "s", 120, 100, 0, 1, seed=9, rows_lo=7, rows_hi=12)
     assert info["blocks"] >= 10
-    orc.use_mkl(True)
+    # (the faster of the host's LAPACKs: on the pool's non-Intel hosts the MKL runtime is five times slower than the OpenBLAS of the scipy wheel,
+    #  and this test was three minutes of the suite with it; the whole small-block workload against the oracle: tests/golden/smallblocks_oracle.npz)
+    fast = orc.scipy_openblas_path()
+    if not (fast and orc.use_lapack(fast)):
+        orc.use_mkl(True)
     try:
+        orc.load().orc_set_threads(min(os.cpu_count() or 1, 16))
         net = orc.Network(str(tmp_path / "s"), True)
         o = orc.Adjustment(net, True)
         o.prepare()
         ost = o.run()
     finally:
-        orc.use_mkl(False)
+        orc.use_lapack(None)
     a0, st0 = _run(str(tmp_path), "s", multi_thread=True, batch_blocks=0)
     assert st0 == ost and a0.batched_block_steps() == 0
     x0, v0, c0 = _results(a0)

@@ -25,8 +25,8 @@ TOL_V = 1e-8
 
 
 def _write(tmp_path, workload):
-    rows, cols, nbl, blocks, phased = fullsize.WORKLOADS[workload]
-    info = adjust.write_synthetic_network(str(tmp_path), "net", rows, cols, nbl, blocks, seed=fullsize.SEED)
+    rows, cols, nbl, blocks, phased, kw = fullsize.synth_args(workload)
+    info = adjust.write_synthetic_network(str(tmp_path), "net", rows, cols, nbl, blocks, seed=fullsize.SEED, **kw)
     return info, phased
 
 
@@ -48,12 +48,13 @@ def _record(path, rec):
         pass
 
 
-@pytest.mark.parametrize("workload", ["cfg3q", "cfg4q", "cfg3"])
+@pytest.mark.parametrize("workload", ["cfg3q", "cfg4q", "smallblocks", "cfg3"])
 def test_against_the_oracle_record(built, golden_dir, tmp_path, workload):
     """the device path (condensed schedule, kept factors, four chains) against the committed record of the CPU oracle's run of the
     same network: cfg3q = four of cfg3's sixteen strips at cfg3's block size (n ~ 20 000: the oracle's run fits a 64 GB host),
     cfg3 = the whole of it (when its record has been made: ~80 GB and 7.4e14 flops on the CPU); cfg4q = four of cfg4's 128 strips at cfg4's
-    block geometry (n ~ 27 000 with junction rows of 1 000 stations: J = 3 000, condensed blocks of 6 000 unknowns; 20 Solve() calls)"""
+    block geometry (n ~ 27 000 with junction rows of 1 000 stations: J = 3 000, condensed blocks of 6 000 unknowns; 30 Solve() calls);
+    smallblocks = bench.py's dnasegment-like cut of 100 200 stations into 120 blocks of n = 900 ... 4 950, whole (bucketed batches)"""
     path = os.path.join(golden_dir, f"{workload}_oracle.npz")
     if not os.path.exists(path):
         assert workload != "cfg3q", "tests/golden/cfg3q_oracle.npz is missing: python tools/make_fullsize_golden.py cfg3q"

@@ -30,9 +30,9 @@ def main():
     threads = int(os.environ.get("ORACLE_THREADS", "0")) or min(os.cpu_count() or 1, 64)
     from dynadjust_amd import adjust
     from tests import fullsize, oracle
-    rows, cols, nbl, blocks, phased = fullsize.WORKLOADS[workload]
+    rows, cols, nbl, blocks, phased, kw = fullsize.synth_args(workload)
     d = tempfile.mkdtemp(prefix="dnagpu_golden_")
-    info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, blocks, seed=fullsize.SEED)
+    info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, blocks, seed=fullsize.SEED, **kw)
     # the faster of the host's LAPACKs (dpotrf + dpotri at n = 4 096): the MKL runtime the reference links, or the OpenBLAS inside the scipy
     # wheel -- on a non-Intel host MKL can be several times slower
     lib = oracle.load()
