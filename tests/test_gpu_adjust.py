@@ -105,6 +105,34 @@ def test_gnss_cluster_parity_with_oracle(built, orc, tmp_path, rows, cols, nbl, 
     o.close()
 
 
+@pytest.mark.parametrize("rows,cols,blocks,xcl,ycl", [(10, 8, 3, 0, False), (9, 12, 4, 1000, True)])
+def test_device_against_the_extended_precision_solution(built, orc, tmp_path, rows, cols, blocks, xcl, ycl):
+    """the device path against the EXACT least-squares solution (tests/exact.py: numpy longdouble, dense, its own Cholesky): simultaneous and
+    phased results within three units in the last place of a 4e6 m coordinate (2.8e-9 m), variances within 1e-11 relative -- the 1e-8 m
+    claim argued through the exact answer instead of through another fp64 solver"""
+    from tests import exact
+    adjust.write_synthetic_network(str(tmp_path), "e", rows, cols, 0, blocks, seed=31 + rows, x_clusters=xcl, y_cluster=ycl)
+    net = orc.Network(str(tmp_path / "e"), False)
+    x, V, its = exact.solve(net)
+    a, st = _device_run(str(tmp_path), "e", False)
+    assert st == 0 and a.CurrentIteration() == its
+    assert float(np.abs(np.asarray(a.block_estimates(0), dtype=np.longdouble) - x).max()) < 2.8e-9
+    Vd = unpack_lower(a.block_variances_packed(0), 3 * net.n_stations)
+    assert float(np.abs(np.asarray(Vd, dtype=np.longdouble) - V).max() / np.abs(V).max()) < 1e-11
+    a.close()
+    for mt in (False, True):
+        p, st = _device_run(str(tmp_path), "e", True, multi_thread=mt)
+        assert st == 0
+        for b in range(p.blockCount()):
+            stn = p.block_stations(b)
+            xb = np.asarray(p.block_estimates(b), dtype=np.longdouble).reshape(-1, 3)
+            assert float(np.abs(xb - x.reshape(-1, 3)[stn]).max()) < 2.8e-9
+            idx = (3 * stn[:, None] + np.arange(3)).ravel()
+            Vb = np.asarray(unpack_lower(p.block_variances_packed(b), 3 * len(stn)), dtype=np.longdouble)
+            assert float(np.abs(Vb - V[np.ix_(idx, idx)]).max() / np.abs(V).max()) < 1e-11
+        p.close()
+
+
 def test_multiple_networks_and_isolated_blocks(built, orc, tmp_path):
     specs = [("a", 8, 5, 3), ("b", 5, 5, 1), ("c", 6, 6, 2)]
     for nm, r, c, blk in specs:
