@@ -115,6 +115,7 @@ std::string dna_adjust::PlanDistributed(const project_settings& projectSettings,
     if (world < 1) world = 1;
     plan_only_ = true;
     plan_hbm_ = hbm_bytes;
+    const std::shared_ptr<DistComm> attached = comm_;      // (a communicator the host attached survives the plan)
     std::ostringstream js;
     js.precision(12);
     try {
@@ -189,12 +190,12 @@ std::string dna_adjust::PlanDistributed(const project_settings& projectSettings,
         }
         js << "]}";
     } catch (...) {
-        comm_.reset();
+        comm_ = attached;
         plan_only_ = false;
         blocks_.clear();
         throw;
     }
-    comm_.reset();
+    comm_ = attached;
     plan_only_ = false;
     blocks_.clear();
     blockCount_ = 0;
