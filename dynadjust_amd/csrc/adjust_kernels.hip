@@ -450,30 +450,36 @@ __global__ void junction_scatter_kernel(double* __restrict__ D, uint32_t npd, co
 }
 
 // rhs[3 idx[a]+ei] += sum_j J(i, j) * (jest[j] - xe[3 idx[j/3] + j%3])
-// 64 rows per workgroup, the columns dealt round-robin to its four waves (j is wave-uniform: the difference is a scalar), four
-// accumulators per thread, the partial sums combined in a fixed order: deterministic, 30 workgroups and 120-term chains for a
-// 317-station junction instead of 8 workgroups and 1 900-term chains (310 us -> 40 us on the path of every chain step)
+// 16 rows per workgroup, the columns dealt round-robin to 16 lanes of threads, four accumulators per thread, the partial sums combined
+// through LDS in a fixed order: deterministic (the first version ran one thread per row: 310 us for a 317-station junction)
 __global__ __launch_bounds__(256) void junction_rhs_kernel(double* __restrict__ rhs, const double* __restrict__ xe, const uint32_t* __restrict__ idx,
                                                            uint32_t k, const double* __restrict__ J, uint32_t npj, const double* __restrict__ jest) {
-    __shared__ double part[4][64];
+    // round 4: 16 rows x 16 column lanes per workgroup (it was 64 rows x 4): four times the workgroups and a quarter of the terms per thread --
+    // on the path of every chain step this kernel is pure latency (35 us for a 150-station junction; ~10 us now)
+    __shared__ double part[16][17];
     const uint32_t nj = 3 * k;
-    const uint32_t r = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t i = blockIdx.x * 64 + r;
+    const uint32_t r = threadIdx.x & 15, c = threadIdx.x >> 4;
+    const uint32_t i = blockIdx.x * 16 + r;
     const uint32_t ic = i < nj ? i : nj - 1;
     double a[4] = {0.0, 0.0, 0.0, 0.0};
-    uint32_t j = w;
-    for (; j + 12 < nj; j += 16) {
+    uint32_t j = c;
+    for (; j + 48 < nj; j += 64) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t jj = j + 4 * u;
+            const uint32_t jj = j + 16 * u;
             const double bj = jest[jj] - xe[3 * idx[jj / 3] + jj % 3];
             a[u] += J[(size_t)jj * npj + ic] * bj;
         }
     }
-    for (; j < nj; j += 4) a[0] += J[(size_t)j * npj + ic] * (jest[j] - xe[3 * idx[j / 3] + j % 3]);
-    part[w][r] = (a[0] + a[1]) + (a[2] + a[3]);
+    for (; j < nj; j += 16) a[0] += J[(size_t)j * npj + ic] * (jest[j] - xe[3 * idx[j / 3] + j % 3]);
+    part[c][r] = (a[0] + a[1]) + (a[2] + a[3]);
     __syncthreads();
-    if (w == 0 && i < nj) rhs[3 * idx[i / 3] + i % 3] += (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+    if (c == 0 && i < nj) {
+        double s4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s4[q] = (part[4 * q][r] + part[4 * q + 1][r]) + (part[4 * q + 2][r] + part[4 * q + 3][r]);
+        rhs[3 * idx[i / 3] + i % 3] += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
 }
 
 // ---- launchers ---------------------------------------------------------------
@@ -592,7 +598,10 @@ __global__ __launch_bounds__(256) void schur_permute_kernel(const double* __rest
     const uint32_t il = threadIdx.x & 127;
     const uint32_t i = tr * 128 + il;
     const int32_t mi = map[i];
-    for (uint32_t jl = threadIdx.x >> 7; jl < 128; jl += 2) {
+    // (round 4: a tile's 128 columns over four workgroups -- blockIdx.z -- and the gathers of a thread unrolled: 43 -> ~12 us for the 7 x 7
+    //  tiles of a condensed block, on the path of every chain step)
+#pragma unroll 8
+    for (uint32_t jl = blockIdx.z * 32 + (threadIdx.x >> 7); jl < blockIdx.z * 32 + 32; jl += 2) {
         const uint32_t j = tc * 128 + jl;
         const int32_t mj = map[j];
         double v = 0.0;
@@ -775,7 +784,7 @@ void launch_unpermute(const double* F, uint32_t ldf, uint32_t npp, const int32_t
 
 void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, const double* rhs, double* dst, uint32_t ldd, uint32_t npp,
                           hipStream_t s) {
-    hipLaunchKernelGGL(schur_permute_kernel, dim3(npp / 128, npp / 128), dim3(256), 0, s, src, lds, map, rhs, dst, ldd);
+    hipLaunchKernelGGL(schur_permute_kernel, dim3(npp / 128, npp / 128, 4), dim3(256), 0, s, src, lds, map, rhs, dst, ldd);
 }
 void launch_schur_extract(const double* T, uint32_t ldt, uint32_t nj, uint32_t npj, double* S, double* S2, double* r, hipStream_t s) {
     hipLaunchKernelGGL(schur_extract_kernel, dim3((npj + 255) / 256, npj), dim3(256), 0, s, T, ldt, nj, npj, S, S2, r);
@@ -808,7 +817,7 @@ void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint3
 void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, const double* jest,
                          hipStream_t s) {
     if (!k) return;
-    hipLaunchKernelGGL(junction_rhs_kernel, dim3((3 * k + 63) / 64), dim3(256), 0, s, rhs, xe, idx, k, J, npj, jest);
+    hipLaunchKernelGGL(junction_rhs_kernel, dim3((3 * k + 15) / 16), dim3(256), 0, s, rhs, xe, idx, k, J, npj, jest);
 }
 
 }  // namespace dnagpu
