@@ -34,19 +34,18 @@ int main() {
     hipMemcpyFromSymbol(p, HIP_SYMBOL(dnagpu::leaf_probe), sizeof(p));
     auto d = [&](int a, int b) { return (double)(p[b] - p[a]); };
     printf("shader clocks (100 MHz constant clock on gfx9: x10 ns)\n");
-    printf("load            %8.0f\n", d(0, 1));
-    double diag = 0, panel = 0, trail = 0;
+    // (the overlapped schedule of round 4: leaf_body.h, potrf_trtri_tile_overlapped)
+    printf("block column 0 in      %8.0f\n", d(0, 1));
+    printf("diag 0 | rest in       %8.0f\n", d(1, 2));
+    // probe 3 + 2 kb is taken by wave 1 (after the seven other waves have met), the others by wave 0
+    double total = 0;
     for (int kb = 0; kb < 8; ++kb) {
-        int prev = kb == 0 ? 1 : 4 + 3 * (kb - 1);
-        printf("A kb=%d  diag %6.0f  panel %6.0f  trailing %6.0f\n", kb, d(prev, 2 + 3 * kb), d(2 + 3 * kb, 3 + 3 * kb), d(3 + 3 * kb, 4 + 3 * kb));
-        diag += d(prev, 2 + 3 * kb);
-        panel += d(2 + 3 * kb, 3 + 3 * kb);
-        trail += d(3 + 3 * kb, 4 + 3 * kb);
+        printf("kb=%d  panel + M(:, %d), waves 1..7 met %6.0f   whole step (diag %d | trailing + phase B step %d + row block %d out) %6.0f\n", kb, kb - 1,
+               d(2 + 2 * kb, 3 + 2 * kb), kb + 1, kb, kb - 1, d(2 + 2 * kb, 4 + 2 * kb));
+        total += d(2 + 2 * kb, 4 + 2 * kb);
     }
-    printf("phase A: diag %6.0f  panel %6.0f  trailing %6.0f\n", diag, panel, trail);
-    for (int kb = 0; kb < 8; ++kb) printf("B kb=%d  %6.0f\n", kb, d(kb == 0 ? 25 : 25 + kb, 26 + kb));
-    printf("phase B total   %8.0f\n", d(25, 33));
-    printf("store           %8.0f\n", d(33, 34));
-    printf("whole kernel    %8.0f\n", d(0, 34));
+    printf("steps %8.0f\n", total);
+    printf("row block 7 out        %8.0f\n", d(18, 20));
+    printf("whole kernel           %8.0f\n", d(0, 20));
     return 0;
 }
