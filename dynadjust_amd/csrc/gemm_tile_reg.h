@@ -78,6 +78,18 @@ __device__ __forceinline__ void reg_tile_product(const double* A, int lda, const
     stage_offsets<A_KC, TILE, WAVES>(lda, tid, offa);
     stage_offsets<B_KC, TILE, WAVES>(ldb, tid, offb);
     const int nk = (kend - kbeg) / 16;
+    // beta != 0 on the small tiles: the C tile is on its way from the start (its 2 us of latency were the tail of a 6 us launch)
+    constexpr bool CPRE = TILE <= 64;
+    const double* cpre = C + (size_t)(j0 + wn * G::WTN + (lane >> 4)) * ldc + i0 + wm * G::WTM + (lane & 15);
+    double cold0[CPRE ? G::MI : 1][CPRE ? G::NI : 1][4];
+    if (CPRE && beta != 0.0) {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cold0[mi][ni][r] = cpre[(size_t)(ni * 16 + 4 * r) * ldc + mi * 16];
+    }
     // (slabs beyond the last one are clamped to it: loaded again, stored to the idle buffer, never used -- the slab body stays
     // branch free)
     auto load_slab = [&](int sl, auto slot_tag) {
@@ -190,7 +202,14 @@ __device__ __forceinline__ void reg_tile_product(const double* A, int lda, const
 
     // epilogue: acc[mi][ni][r] = C(i = i0+wm*WTM+mi*16+(lane&15), j = j0+wn*WTN+ni*16+(lane>>4)+4r)
     double* cbase = C + (size_t)(j0 + wn * G::WTN + (lane >> 4)) * ldc + i0 + wm * G::WTM + (lane & 15);
-    if (beta != 0.0) {
+    if (CPRE && beta != 0.0) {
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = alpha * acc[mi][ni][r] + beta * cold0[mi][ni][r];
+    } else if (beta != 0.0) {
         // C tile read in batches of 8 independent loads before it is combined (not one load-wait per element)
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi) {
