@@ -34,7 +34,7 @@ void launch_scatter_add_vec3(double* y, const uint32_t* idx, uint32_t k, const d
 void launch_copy_vec3_indexed(double* y, const uint32_t* dst, const double* x, const uint32_t* src, uint32_t k, hipStream_t s);
 void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, hipStream_t s);
 void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, const double* jest,
-                         hipStream_t s);
+                         const double* jr, hipStream_t s);
 void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, const double* rhs, double* dst, uint32_t ldd, uint32_t npp,
                           hipStream_t s);
 void launch_form_ordered(double* F, uint32_t ld, uint32_t npp, const int32_t* map, const uint32_t* spos, const uint32_t* prow, const uint32_t* pcol,

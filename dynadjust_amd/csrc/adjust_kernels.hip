@@ -449,11 +449,12 @@ __global__ void junction_scatter_kernel(double* __restrict__ D, uint32_t npd, co
     D[(size_t)dj * npd + di] += J[(size_t)j * npj + i];
 }
 
-// rhs[3 idx[a]+ei] += sum_j J(i, j) * (jest[j] - xe[3 idx[j/3] + j%3])
+// rhs[3 idx[a]+ei] += (jr ? jr[i] : 0) + sum_j J(i, j) * (jest[j] - xe[3 idx[j/3] + j%3])
 // 16 rows per workgroup, the columns dealt round-robin to 16 lanes of threads, four accumulators per thread, the partial sums combined
 // through LDS in a fixed order: deterministic (the first version ran one thread per row: 310 us for a 317-station junction)
 __global__ __launch_bounds__(256) void junction_rhs_kernel(double* __restrict__ rhs, const double* __restrict__ xe, const uint32_t* __restrict__ idx,
-                                                           uint32_t k, const double* __restrict__ J, uint32_t npj, const double* __restrict__ jest) {
+                                                           uint32_t k, const double* __restrict__ J, uint32_t npj, const double* __restrict__ jest,
+                                                           const double* __restrict__ jr) {
     // round 4: 16 rows x 16 column lanes per workgroup (it was 64 rows x 4): four times the workgroups and a quarter of the terms per thread --
     // on the path of every chain step this kernel is pure latency (35 us for a 150-station junction; ~10 us now)
     __shared__ double part[16][17];
@@ -478,7 +479,10 @@ __global__ __launch_bounds__(256) void junction_rhs_kernel(double* __restrict__ 
         double s4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) s4[q] = (part[4 * q][r] + part[4 * q + 1][r]) + (part[4 * q + 2][r] + part[4 * q + 3][r]);
-        rhs[3 * idx[i / 3] + i % 3] += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        // jr (information form): the junction's own reduced right-hand side; the sum is then J * (the estimates it was formed at - xe),
+        // zero when both blocks hold the same estimates of their common stations
+        const double sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        rhs[3 * idx[i / 3] + i % 3] += jr ? jr[i] + sum : sum;
     }
 }
 
@@ -815,9 +819,8 @@ void launch_junction_scatter(double* D, uint32_t npd, const uint32_t* idx, uint3
     hipLaunchKernelGGL(junction_scatter_kernel, dim3((3 * k + 255) / 256, 3 * k), dim3(256), 0, s, D, npd, idx, k, J, npj);
 }
 void launch_junction_rhs(double* rhs, const double* xe, const uint32_t* idx, uint32_t k, const double* J, uint32_t npj, const double* jest,
-                         hipStream_t s) {
-    if (!k) return;
-    hipLaunchKernelGGL(junction_rhs_kernel, dim3((3 * k + 15) / 16), dim3(256), 0, s, rhs, xe, idx, k, J, npj, jest);
+                         const double* jr, hipStream_t s) {
+    hipLaunchKernelGGL(junction_rhs_kernel, dim3((3 * k + 15) / 16), dim3(256), 0, s, rhs, xe, idx, k, J, npj, jest, jr);
 }
 
 }  // namespace dnagpu

@@ -14,6 +14,8 @@
 struct dnagpu_matrix {
     double* F = nullptr;     // np_max x np_max storage, used with ld = np
     double* jest = nullptr;  // junction estimates attached to the matrix (n_max doubles)
+    double* jrhs = nullptr;  // information form (dnagpu_schur_carry): the reduced right-hand side that goes with F; allocated on first use
+    int form = 0;            // 0: jest = the junction stations' ADJUSTED estimates (weights F); 1: jest = the estimates F and jrhs were formed at
     uint32_t n_max = 0, np_max = 0;
     uint32_t n = 0, np = 0;  // current logical order / padded order
 };

@@ -15,6 +15,13 @@
 
 using namespace dnagpu;
 
+// dnagpu_schur_carry leaves its junction matrix in information form (no inverse of the complement): default; DNAGPU_INFO_CARRY=0 /
+// dnagpu_debug_set_info_carry(0) give the estimates form (complement inverted, estimates + corrections), e.g. to compare the two
+static std::atomic<int> g_info_carry{[] {
+    const char* e = getenv("DNAGPU_INFO_CARRY");
+    return (e && atoi(e) == 0) ? 0 : 1;
+}()};
+
 namespace {
 
 constexpr uint32_t SYMV_CHUNKS = 32;
@@ -465,6 +472,8 @@ int dnagpu_debug_fail_batch_workspaces(long n) {
 
 long dnagpu_debug_set_small_tiles(long tiles) { return dnagpu::small_tiles_set(tiles); }
 long dnagpu_debug_set_tiny_tiles(long tiles) { return dnagpu::tiny_tiles_set(tiles); }
+int dnagpu_debug_set_info_carry(int on) { return g_info_carry.exchange(on ? 1 : 0); }
+int dnagpu_info_carry(void) { return g_info_carry.load(); }
 
 long dnagpu_debug_set_pair_tiles(long tiles) { return dnagpu::pair_tiles_set(tiles); }
 
@@ -667,6 +676,7 @@ void dnagpu_matrix_destroy(dnagpu_ctx* ctx, dnagpu_matrix* m) {
     }
     if (m->F) hipFree(m->F);
     if (m->jest) hipFree(m->jest);
+    if (m->jrhs) hipFree(m->jrhs);
     delete m;
 }
 
@@ -797,6 +807,12 @@ int dnagpu_matrix_copy(dnagpu_ctx* ctx, int chain, dnagpu_matrix* dst, const dna
     dst->np = src->np;
     HIPCHK(hipMemcpyAsync(dst->F, src->F, (size_t)src->np * src->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
     HIPCHK(hipMemcpyAsync(dst->jest, src->jest, (size_t)src->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
+    dst->form = src->form;
+    if (src->form == 1) {
+        if (!dst->jrhs && dnagpu::poison_malloc(&dst->jrhs, (size_t)dst->np_max * sizeof(double)) != hipSuccess)
+            return fail(ctx, DNAGPU_ENOMEM, "matrix_copy: right-hand side of the information form");
+        HIPCHK(hipMemcpyAsync(dst->jrhs, src->jrhs, (size_t)src->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[chain]));
+    }
     return DNAGPU_OK;
 }
 
@@ -809,7 +825,7 @@ int dnagpu_matrix_resize(dnagpu_ctx* ctx, dnagpu_matrix* m, uint32_t n) {
 }
 
 int dnagpu_matrix_device_pointers(const dnagpu_matrix* m, double** matrix, double** vector, uint32_t* np) {
-    if (!m) return DNAGPU_EINVAL;
+    if (!m || m->form == 1) return DNAGPU_EINVAL;     // (the information form has a third part: see dnagpu_matrix_export)
     if (matrix) *matrix = m->F;
     if (vector) *vector = m->jest;
     if (np) *np = m->np;
@@ -820,6 +836,9 @@ int dnagpu_matrix_export(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, dou
     CHK_CTX();
     CHK_CHAIN();
     if (!m || !dst) return fail(ctx, DNAGPU_EINVAL, "matrix_export: null argument");
+    if (m->form == 1)
+        return fail(ctx, DNAGPU_EINVAL, "matrix_export: a junction matrix in information form (dnagpu_schur_carry) has no payload form; "
+                                        "run with DNAGPU_INFO_CARRY=0 to exchange it");
     size_t need = (size_t)m->np * m->np + m->np;
     if (cap_doubles < need) return fail(ctx, DNAGPU_EINVAL, "matrix_export: destination too small");
     HIPCHK(hipMemcpyAsync(dst, m->F, (size_t)m->np * m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
@@ -834,6 +853,7 @@ int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const dou
     if (!m || !src || n > m->n_max) return fail(ctx, DNAGPU_EINVAL, "matrix_import: bad arguments");
     m->n = n;
     m->np = pad128(n);
+    m->form = 0;
     HIPCHK(hipMemcpyAsync(m->F, src, (size_t)m->np * m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
     HIPCHK(hipMemcpyAsync(m->jest, src + (size_t)m->np * m->np, (size_t)m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
     HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
@@ -1709,6 +1729,7 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
     if (rc) return rc;
     if (src) launch_junction_gather(src->F, src->np, didx, (uint32_t)k, jm->F, jm->np, ctx->stream[chain]);
     launch_gather_vec3(b->x_est[chain], didx, (uint32_t)k, jm->jest, ctx->stream[chain]);
+    jm->form = 0;
     return DNAGPU_OK;
 }
 
@@ -1881,13 +1902,31 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
     hipStream_t st = ctx->stream[chain];
-    // the complement IS the weight matrix of the junction stations; its inverse (their variances) gives their corrections
     jm->n = nj;
     jm->np = npj;
-    launch_schur_extract(T, ldt, nj, npj, jm->F, m->F, ws.svec, st);
-    sym_inverse_async(ws, m->F, nj, npj, false, /*reset_info=*/false);
-    launch_symv(m->F, ws.svec, b->corr[chain], ctx->symv_part[chain], nj, npj, SYMV_CHUNKS, st);
-    launch_schur_estimates(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, b->corr[chain], jm->jest, st);
+    if (g_info_carry.load()) {
+        // information form: the complement S (the junction stations' weight matrix) and the reduced right-hand side r travel as they are,
+        // with the estimates they were formed at; the next block adds S to its normals and r + S (those estimates - its own) to its
+        // right-hand side (dnagpu_junction_rhs) -- what the estimates x + S^-1 r weighted by S contribute, without S^-1: no inverse of
+        // the complement (nj^3 flops and, for a 450-unknown junction, half of the step's launches)
+        if (!jm->jrhs && dnagpu::poison_malloc(&jm->jrhs, (size_t)jm->np_max * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            jm->jrhs = nullptr;
+            return fail(ctx, DNAGPU_ENOMEM, "schur_carry: right-hand side of the information form");
+        }
+        launch_schur_extract(T, ldt, nj, npj, jm->F, nullptr, jm->jrhs, st);
+        launch_gather_vec3(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, jm->jest, st);
+        jm->form = 1;
+        // (the elimination's verdict; a complement that is not positive definite shows in the block that receives it)
+        HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    } else {
+        // the complement IS the weight matrix of the junction stations; its inverse (their variances) gives their corrections
+        launch_schur_extract(T, ldt, nj, npj, jm->F, m->F, ws.svec, st);
+        sym_inverse_async(ws, m->F, nj, npj, false, /*reset_info=*/false);
+        launch_symv(m->F, ws.svec, b->corr[chain], ctx->symv_part[chain], nj, npj, SYMV_CHUNKS, st);
+        launch_schur_estimates(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, b->corr[chain], jm->jest, st);
+        jm->form = 0;
+    }
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
 }
@@ -2495,7 +2534,8 @@ int dnagpu_junction_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk_to, const uint3
     uint32_t* didx = nullptr;
     int rc = stage_u32(ctx, chain, idx_to, k, &didx);
     if (rc) return rc;
-    launch_junction_rhs(b->rhs[chain], b->x_est[chain], didx, (uint32_t)k, jm->F, jm->np, jm->jest, ctx->stream[chain]);
+    launch_junction_rhs(b->rhs[chain], b->x_est[chain], didx, (uint32_t)k, jm->F, jm->np, jm->jest, jm->form == 1 ? jm->jrhs : nullptr,
+                        ctx->stream[chain]);
     return DNAGPU_OK;
 }
 

@@ -582,7 +582,7 @@ void dna_adjust::ScanRuns() {
         Check(dnagpu_schur_carry(ctx_, c, g.dev_block, Wm, out.data(), out.size(), jm), k, "Solve()");
         const double n = 3.0 * (double)g.stations.size(), nj = 3.0 * (double)out.size(), ni = n - nj;
         std::lock_guard<std::mutex> lk(corr_mutex_);
-        algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + nj * nj * nj;
+        algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj);
     };
     OnEveryChain([&](int c) {
         if (c == 0)

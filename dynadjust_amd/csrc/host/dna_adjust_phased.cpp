@@ -83,8 +83,9 @@ void dna_adjust::CarryByElimination(int c, UINT32 dev_block, UINT32 k, dnagpu_ma
     const double n = dev_block == k ? nref : 3.0 * (double)blocks_[k].keep.size(), nj = 3.0 * (double)out.size(), ni = n - nj;
     std::lock_guard<std::mutex> lk(corr_mutex_);
     solve_flops_ += nref * nref * nref;
-    // Cholesky of the inner part, its panel under the junction rows, the complement's update, the complement's inverse
-    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + nj * nj * nj;
+    // Cholesky of the inner part, its panel under the junction rows, the complement's update, and -- estimates form only
+    // (DNAGPU_INFO_CARRY=0) -- the complement's inverse
+    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj);
     solve_count_++;
     elimination_count_++;
 }

@@ -219,8 +219,9 @@ class DeviceContext:
         jm.n = 3 * ix.size
 
     def schur_carry(self, blk, m, idx_out, jm, chain=0):
-        """jm <- Schur complement of the other unknowns of m onto the listed stations, junction estimates <- estimates +
-        corrections (dnagpu_schur_carry); m is destroyed"""
+        """jm <- Schur complement of the other unknowns of m onto the listed stations (dnagpu_schur_carry); m is destroyed.
+        Information form (default): junction estimates <- the block's estimates, the reduced right-hand side beside them;
+        estimates form (dnagpu_debug_set_info_carry(0)): junction estimates <- estimates + corrections"""
         ix, p = _u32(idx_out)
         self._chk(self.lib.dnagpu_schur_carry(self.h, chain, blk, m.h, p, ix.size, jm.h))
         jm.n = 3 * ix.size

@@ -119,6 +119,9 @@ long dnagpu_debug_set_small_tiles(long tiles);
 /* ... and below `tiles` on 32 x 32 tiles (default 64; 0: never; < 0: the default again): the products of the recursion's bottom and of the chains on
  * condensed blocks, where a launch has too few 64-tiles to occupy the chip.  Same bits.  Returns the previous value. */
 long dnagpu_debug_set_tiny_tiles(long tiles);
+/* dnagpu_schur_carry's result: 1 (default) information form, 0 estimates form (see there); returns the previous value.  Process-wide. */
+int dnagpu_debug_set_info_carry(int on);
+int dnagpu_info_carry(void);
 /* Opt-in experiment (off: measured no gain, tile_order.hip): launches of at least `tiles` 128-tiles with a triangular k range give every
  * workgroup two tiles of complementary length (0 = never, the default).  Takes effect for tables built afterwards.  Returns the previous value. */
 long dnagpu_debug_set_pair_tiles(long tiles);
@@ -321,9 +324,16 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
  * of its network.  ((N^-1)_JJ)^-1 is the Schur complement  N_JJ - N_JI N_II^-1 N_IJ  and the junction corrections solve
  * S dx_J = rhs_J - N_JI N_II^-1 rhs_I : both come out of eliminating the inner unknowns only (~0.35 n^3 flops).
  * m: the block's normals (lower triangle; contents are destroyed), rhs as left by dnagpu_form_rhs / dnagpu_junction_rhs.
- * jm (order 3k) <- S, jest <- estimated coordinates + corrections of the k listed stations: exactly what
- * dnagpu_junction_gather + dnagpu_invert leave there after a full solve, up to rounding.  The block's estimates and
- * corrections are NOT updated.  DNAGPU_ENOTPOSDEF like dnagpu_invert. */
+ * jm (order 3k) <- S, and
+ *   estimates form (DNAGPU_INFO_CARRY=0 / dnagpu_debug_set_info_carry(0)): jest <- estimated coordinates + corrections of the k
+ *     listed stations: exactly what dnagpu_junction_gather + dnagpu_invert leave there after a full solve, up to rounding;
+ *   information form (default, round 4): jest <- the estimated coordinates the block was linearised at, and the reduced right-hand
+ *     side r = rhs_J - N_JI N_II^-1 rhs_I beside it.  dnagpu_junction_rhs adds  r + S (jest - the receiving block's estimates)  --
+ *     what the weighted pseudo-observation "estimates + S^-1 r" of the estimates form contributes, with S^-1 cancelled
+ *     analytically: the complement is never factored or inverted (nj^3 flops less per step; for the 450-unknown junctions of
+ *     a dnasegment-like cut, half of a chain step).  Such a matrix cannot be exported (dnagpu_matrix_export /
+ *     dnagpu_matrix_device_pointers fail): the condensed schedule exchanges condensed blocks, never junction matrices.
+ * The block's estimates and corrections are NOT updated.  DNAGPU_ENOTPOSDEF like dnagpu_invert. */
 int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm);
 /* The same elimination as a stand-alone step: red (order 3k) <- Schur complement of all other unknowns of m onto the k
  * listed stations (list order), red's attached vector <- the reduced right-hand side.  With the stations a block shares

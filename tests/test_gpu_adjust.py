@@ -357,8 +357,10 @@ def _compare_statistics(a, o, confidence=95.0):
     so, fo = o.statistics(confidence)
     fd, rec = _device_fields(a, None)
     assert a.GetDegreesOfFreedom() == so.dof and a.GetMeasurementCount() == so.measurement_params
-    assert abs(a.GetChiSquared() - so.chi_squared) < 1e-9 * max(1.0, so.chi_squared)
-    assert abs(a.GetSigmaZero() - so.sigma_zero) < 1e-9 * max(1.0, so.sigma_zero)
+    # (1e-8 relative: the sum of squared residuals moves by 2.5e-9 of itself when the junction carry takes its information form --
+    #  residuals of millimetres agreeing to 1e-12 m, three orders below an ulp of the coordinates they are differences of)
+    assert abs(a.GetChiSquared() - so.chi_squared) < 1e-8 * max(1.0, so.chi_squared)
+    assert abs(a.GetSigmaZero() - so.sigma_zero) < 1e-8 * max(1.0, so.sigma_zero)
     assert abs(a.GetGlobalPelzerRel() - so.global_pelzer) < 1e-7
     assert a.GetPotentialOutlierCount() == so.potential_outliers
     for k in ("measAdj", "measCorr"):
@@ -574,6 +576,44 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
         for b in range(B):
             assert np.abs(x0[b] - x1[b]).max() < 1e-8
             assert np.abs(v0[b] - v1[b]).max() < 1e-8 * np.abs(v0[b]).max()
+
+
+@pytest.mark.parametrize("mt,blocks,terr,condensed", [(True, 6, False, True), (False, 4, False, True), (True, 4, True, True), (False, 5, False, False)])
+def test_information_form_of_the_junction_carry(built, orc, tmp_path, mt, blocks, terr, condensed):
+    """dnagpu_schur_carry in information form (default: the junction's weight matrix S and reduced right-hand side r travel, the
+    receiving block adds r + S (the sender's estimates - its own); S is never inverted) against its estimates form
+    (DNAGPU_INFO_CARRY=0: S inverted, estimates + S^-1 r carried, CarryStnEstimatesandVariancesForward dnaadjust.cpp:998-1128):
+    same adjustment, every iteration's correction, every estimate and variance; fewer flops counted.  A terrestrial network has its
+    estimates move between the iterations (the linearisation point of both blocks of a junction is the same one)."""
+    if terr:
+        from tests import terrestrial_net as T
+        T.build_mixed_network(str(tmp_path / "c"), 6, 4, blocks, seed=5)
+    else:
+        adjust.write_synthetic_network(str(tmp_path), "c", 18, 12, 0, blocks, seed=8, x_clusters=10, y_cluster=True, initial_sigma=0.3)
+    runs = []
+    for form in (0, 1):
+        old = built.dnagpu_debug_set_info_carry(form)
+        try:
+            a, st = _device_run(str(tmp_path), "c", True, multi_thread=mt, keep_factors=condensed, defer_variances=2 if condensed else 0)
+        finally:
+            built.dnagpu_debug_set_info_carry(old)
+        assert st == 0 and a.elimination_count() > 0
+        a.GenerateStatistics()
+        runs.append((a.CurrentIteration(), [a.block_estimates(b) for b in range(a.blockCount())], [a.block_variances_packed(b) for b in range(a.blockCount())],
+                     a.GetChiSquared(), [a.GetIterationCorrection(i + 1) for i in range(a.CurrentIteration())], a.algorithmic_flops()))
+        if form == 1:
+            net = orc.Network(str(tmp_path / "c"), True)
+            o = orc.Adjustment(net, True)
+            o.prepare()
+            _compare(a, st, o, o.run())
+            o.close()
+        a.close()
+    (it0, x0, v0, c0, corr0, f0), (it1, x1, v1, c1, corr1, f1) = runs
+    assert it0 == it1 and f1 < f0
+    assert abs(c0 - c1) < 1e-8 * c0 and np.abs(np.array(corr0) - np.array(corr1)).max() < 1e-9
+    for b in range(len(x0)):
+        assert np.abs(x0[b] - x1[b]).max() < 1e-9
+        assert np.abs(v0[b] - v1[b]).max() < 1e-9 * np.abs(v0[b]).max()
 
 
 @pytest.mark.parametrize("mt", [False, True])

@@ -157,12 +157,23 @@ def test_bad_arguments_are_rejected(gpu_ctx):
         gpu_ctx.block_compute_b(77)
 
 
+@pytest.fixture
+def carry_form(request, built):
+    """dnagpu_schur_carry in its estimates form (0) or its information form (1, the default)"""
+    old = built.dnagpu_debug_set_info_carry(request.param)
+    yield request.param
+    built.dnagpu_debug_set_info_carry(old)
+
+
+@pytest.mark.parametrize("carry_form", [0, 1], indirect=True)
 @pytest.mark.parametrize("rows,cols,strips,pick", [(9, 8, 3, "jsl"), (40, 30, 2, "jsl"), (40, 30, 2, "scattered"), (12, 11, 2, "all_but_one"),
                                                    (43, 43, 2, "one")])
-def test_schur_carry_equals_solve_gather_invert(gpu_ctx, built, orc, tmp_path, rows, cols, strips, pick):
+def test_schur_carry_equals_solve_gather_invert(gpu_ctx, built, orc, tmp_path, rows, cols, strips, pick, carry_form):
     """dnagpu_schur_carry (partial elimination of the inner unknowns) against the reference's sequence Solve ->
     gather the junction block of N^-1 -> invert it (CarryStnEstimatesandVariancesForward, dnaadjust.cpp:998-1128), on the
-    device and in numpy.  Sizes straddle the 128-tile boundaries (n = 3 * stations of the first strip + junction row)."""
+    device and in numpy.  Sizes straddle the 128-tile boundaries (n = 3 * stations of the first strip + junction row).
+    Both forms of the result: the estimates form carries estimates + corrections, the information form the estimates the block
+    was formed at and the reduced right-hand side -- what dnagpu_junction_rhs then adds is the same."""
     from dynadjust_amd import adjust
     adjust.write_synthetic_network(str(tmp_path), "s", rows, cols, 0, strips, seed=rows + cols)
     net = orc.Network(str(tmp_path / "s"), True)
@@ -204,21 +215,36 @@ def test_schur_carry_equals_solve_gather_invert(gpu_ctx, built, orc, tmp_path, r
     est = gpu_ctx.junction_get_estimates(js)
     scale = np.abs(W_ref).max()
     assert np.abs(W - W_ref).max() < 1e-9 * scale, np.abs(W - W_ref).max() / scale
-    assert np.abs(est - (x0[rws] + corr[rws])).max() < 1e-9
+    if carry_form == 0:
+        assert np.abs(est - (x0[rws] + corr[rws])).max() < 1e-9
+    else:
+        assert np.array_equal(est, x0[rws])
     assert np.array_equal(gpu_ctx.block_get_stations(0, 1, len(st0)), x0)          # the block's estimates are untouched
     # numpy: Schur complement and the reduced system
     inner = np.setdiff1d(np.arange(n0), rws)
     S = N0[np.ix_(rws, rws)] - N0[np.ix_(rws, inner)] @ np.linalg.solve(N0[np.ix_(inner, inner)], N0[np.ix_(inner, rws)]) if len(inner) else N0[np.ix_(rws, rws)]
     assert np.abs(W - S).max() < 1e-9 * scale
     d = np.linalg.solve(N0, rhs)
-    assert np.abs(est - (x0[rws] + d[rws])).max() < 1e-9
+    if carry_form == 0:
+        assert np.abs(est - (x0[rws] + d[rws])).max() < 1e-9
+    # what the receiving block adds to its right-hand side (here: the block itself, same estimates): W * corrections in either form
+    before = gpu_ctx.block_get_rhs(0, len(st0))
+    gpu_ctx.junction_rhs(0, idx, js)
+    added = (gpu_ctx.block_get_rhs(0, len(st0)) - before)[rws]
+    want = S @ d[rws]
+    # (estimates form: the corrections come back as (x + dx) - x, an ulp of a 6 000 km coordinate each, times the weights)
+    tol = 1e-9 * max(1.0, np.abs(want).max()) if carry_form else 2e-9 * np.abs(S).sum(axis=1).max()
+    assert np.abs(added - want).max() <= tol, (np.abs(added - want).max(), np.abs(want).max(), tol)
+    others = np.setdiff1d(np.arange(n0), rws)
+    assert not np.any((gpu_ctx.block_get_rhs(0, len(st0)) - before)[others])
+    gpu_ctx.form_rhs(0)
     # a second call with another station list (the reverse direction's) and back again: both orders stay cached
     idx2 = np.array(sorted(set(range(len(st0))) - set(stn))[:max(1, len(st0) // 5)], dtype=np.uint32)
     j2 = gpu_ctx.matrix(3 * len(idx2))
     m.upload_packed(a.block_normals(0), n0)
     gpu_ctx.schur_carry(0, m, idx2, j2)
     r2 = (3 * idx2[:, None] + np.arange(3)).ravel()
-    assert np.abs(gpu_ctx.junction_get_estimates(j2) - (x0[r2] + d[r2])).max() < 1e-9
+    assert np.abs(gpu_ctx.junction_get_estimates(j2) - (x0[r2] + (0 if carry_form else 1) * d[r2])).max() < 1e-9
     m.upload_packed(a.block_normals(0), n0)
     gpu_ctx.schur_carry(0, m, idx, js)
     assert np.array_equal(unpack_lower(js.download_packed(), 3 * len(idx)), W)      # deterministic
