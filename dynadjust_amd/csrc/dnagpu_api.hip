@@ -2585,6 +2585,7 @@ int dnagpu_junction_put_estimates(dnagpu_ctx* ctx, int chain, dnagpu_matrix* jm,
     CHK_CTX();
     CHK_CHAIN();
     if (!jm || 3 * k > jm->n_max || (k && !est)) return fail(ctx, DNAGPU_EINVAL, "junction_put_estimates: bad arguments");
+    jm->form = 0;        // (estimates from outside are adjusted estimates: the estimates form, whatever the matrix held before)
     if (!k) return DNAGPU_OK;
     HIPCHK(hipMemcpyAsync(jm->jest, est, 3 * k * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
     HIPCHK(hipStreamSynchronize(ctx->stream[chain]));

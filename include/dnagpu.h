@@ -423,7 +423,9 @@ int dnagpu_junction_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk_to, const uint3
 int dnagpu_block_add_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* idx, size_t k, const dnagpu_matrix* jm, int zero_first);
 int dnagpu_block_gather_stations(dnagpu_ctx* ctx, int chain, uint32_t dst_blk, const uint32_t* dst_pos, uint32_t src_blk, const uint32_t* src_idx,
                                  size_t k);
-/* read / write the junction estimates attached to a junction matrix (3k doubles) */
+/* read / write the junction estimates attached to a junction matrix (3k doubles).  After dnagpu_schur_carry in its information form
+ * (the default) "the estimates" are those the block was linearised at, not adjusted ones; writing estimates makes the matrix one in the
+ * estimates form (its reduced right-hand side is dropped). */
 int dnagpu_junction_get_estimates(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* jm, double* est);
 int dnagpu_junction_put_estimates(dnagpu_ctx* ctx, int chain, dnagpu_matrix* jm, const double* est, size_t k);
 
