@@ -2309,6 +2309,12 @@ int check_info_batch(dnagpu_ctx* ctx, int chain, int nb, int* failed_member) {
 
 extern "C" {
 
+int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max) {
+    CHK_CTX();
+    CHK_CHAIN();
+    return ensure_ws(ctx, chain, pad128(n_max) + 256);
+}
+
 int dnagpu_batch_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max, uint32_t k_max, int nb_wanted, int* nb_granted) {
     CHK_CTX();
     CHK_CHAIN();

@@ -727,6 +727,7 @@ void dna_adjust::PrepareBlocks() {
     ComputeBlockOwners(CondensedWanted() && !ReuseInverses());
     DecideStaging();
     PrepareCondensedBlocks();     // (+ ownership under the reference's schedule, the two-level plan, junction matrices / condensed blocks)
+    ReserveBuffers();
     if (!plan_only_) Check(dnagpu_sync(ctx_), 0, "PrepareAdjustment()");
 }
 

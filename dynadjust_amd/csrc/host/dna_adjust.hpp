@@ -332,6 +332,10 @@ private:
     size_t xbuf_cap_ = 0;
     double exchange_ms_ = 0.0, chain_ms_ = 0.0;
     void PrepareCondensedBlocks();
+    // what the plan of PrepareCondensedBlocks / DecideStaging has set aside is allocated here, not inside the first iteration: the chains'
+    // workspaces, the per-chain factor storage of blocks without a kept factor, the staged store (page-locked host memory / packed in HBM)
+    void ReserveBuffers();
+    void AllocateStagedSlot(UINT32 block);
     void AllocateChainData();
     void DecideStaging();
 public:

@@ -236,6 +236,42 @@ double dna_adjust::PhasedCombineBlock(int c, UINT32 k) {
     return mv;
 }
 
+// the block's place in the staged store: a packed triangle in page-locked host memory or, past the host's limit (DecideStaging), in HBM
+void dna_adjust::AllocateStagedSlot(UINT32 k) {
+    block_t& B = blocks_[k];
+    if (B.rig_host) return;
+    const size_t n = v_parameterStationList_[k].size() * 3;
+    if (B.rig_on_device) {
+        Check(dnagpu_device_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (packed, device)");
+        return;
+    }
+    // (the plan left a fifth of the host's limit free; if something else has taken it since, a clean failure here is better than the
+    //  container's memory limit ending the process -- and, on the pool's boxes, the box)
+    const double bytes = (double)(n * (n + 1) / 2 * sizeof(double));
+    if (HostMemoryAvailable() < bytes + 8.0e9)
+        SignalExceptionAdjustment("UpdateEstimatesFinal(): the host's memory limit leaves no room for the staged variance matrices.", k);
+    Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
+}
+
+// PrepareAdjustment's last step: first-use allocations that would otherwise sit inside the first iteration (cfg4 on one GPU: 95 GB of chain
+// workspaces and factor storage, 2.3 s of hipMalloc) and inside the variance phase (251 GB of page-locking).  DNAGPU_RESERVE=0: on first use.
+void dna_adjust::ReserveBuffers() {
+    static const bool off = getenv("DNAGPU_RESERVE") && atoi(getenv("DNAGPU_RESERVE")) == 0;
+    if (plan_only_ || off) return;
+    const int chains = NumChains();
+    for (int c = 0; c < chains; ++c) Check(dnagpu_chain_reserve(ctx_, c, max_unknowns_), 0, "PrepareAdjustment(): chain workspace");
+    if (transient_ok_) {
+        std::lock_guard<std::mutex> lk(alloc_mutex_);
+        for (int c = 0; c < chains; ++c)
+            if (!tmpfac_[c]) Check(dnagpu_matrix_create(ctx_, max_unknowns_ + 256, &tmpfac_[c]), 0, "PrepareAdjustment(): factor storage of a chain");
+    }
+    if (Staged() && projectSettings_.a.adjust_mode != SimultaneousMode) {
+        std::lock_guard<std::mutex> lk(alloc_mutex_);
+        for (UINT32 k = 0; k < blockCount_; ++k)
+            if (OwnsBlock(k)) AllocateStagedSlot(k);
+    }
+}
+
 // v_rigorousVariances_[k] = the inverse currently held by W (a copy, unless W already is the block's resident matrix)
 void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
     block_t& B = blocks_[k];
@@ -248,16 +284,7 @@ void dna_adjust::StoreRigorousVariances(int c, UINT32 k, dnagpu_matrix* W) {
         const size_t n = v_parameterStationList_[k].size() * 3;
         if (!B.rig_host) {
             std::lock_guard<std::mutex> lk(alloc_mutex_);
-            if (B.rig_on_device)
-                Check(dnagpu_device_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (packed, device)");
-            else {
-                // (the plan left a fifth of the host's limit free; if something else has taken it since, a clean failure here is better than the
-                //  container's memory limit ending the process -- and, on the pool's boxes, the box)
-                const double bytes = (double)(n * (n + 1) / 2 * sizeof(double));
-                if (HostMemoryAvailable() < bytes + 8.0e9)
-                    SignalExceptionAdjustment("UpdateEstimatesFinal(): the host's memory limit leaves no room for the staged variance matrices.", k);
-                Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
-            }
+            AllocateStagedSlot(k);
         }
         const auto t0 = std::chrono::steady_clock::now();
         // (on a copy stream: the chain goes on with its next block; AdjustPhased waits for the copies at the end of the iteration)

@@ -348,6 +348,10 @@ int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
  * the matrix less than form + add + reduce.  Same bits as that sequence. */
 int dnagpu_block_form_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* con_stn, const double* con_w9, size_t n_con,
                              const uint32_t* idx_keep, size_t k, dnagpu_matrix* red, dnagpu_partial* keep);
+/* A chain's inverse workspace (X and W: two (n_max + 256)^2 matrices, padded) is allocated on the chain's first call that needs it;
+ * dnagpu_chain_reserve makes that allocation now -- in PrepareAdjustment rather than inside the first iteration (hipMalloc of
+ * 2 x 5.9 GB per chain at n = 27 000 is seconds). */
+int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max);
 /* Batched forms of the three large steps of a block with a kept factor in its light form (dnagpu_partial_create_spine), for nb <=
  * DNAGPU_BATCH_MAX blocks of ONE shape (equal padded orders of the eliminated and of the kept part): the members' launches are merged --
  * every tile product and every leaf of the recursion is one launch that works on all members, in lock step.  The dependent chain of
