@@ -337,7 +337,7 @@ class DnaAdjust:
 
     def memory_plan(self):
         """PrepareAdjustment's memory plan (dnaadj_memory_plan): where the staged variance matrices go, which blocks keep their factor"""
-        out = (C.c_double * 10)()
+        out = (C.c_double * 12)()
         if self.lib.dnaadj_memory_plan(self.h, out) != 0:
             return {}
         return {"staged_variances_host_bytes": int(out[0]), "staged_variances_packed_in_hbm_bytes": int(out[1]),
@@ -345,7 +345,8 @@ class DnaAdjust:
                 "blocks_keeping_their_factor": int(out[2]), "blocks_condensed": int(out[3]), "batch_members_beyond_first": int(out[4]),
                 "host_memory_available_gb": round(out[5] / 1e9, 1),
                 "copied_to_host_gb": round(out[6] / 1e9, 2), "waited_for_copies_ms": round(out[7], 1),
-                "factors_made_again": int(out[8]), "blocks_without_kept_factor_refactor": bool(out[9])}
+                "factors_made_again": int(out[8]), "blocks_without_kept_factor_refactor": bool(out[9]),
+                "factors_taken_from_their_packed_copy": int(out[10]), "blocks_packing_their_factor": int(out[11])}
 
     def elimination_count(self):
         return self.lib.dnaadj_elimination_count(self.h)

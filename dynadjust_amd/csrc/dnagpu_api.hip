@@ -788,6 +788,35 @@ int dnagpu_matrix_unpack_device(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, co
     return DNAGPU_OK;
 }
 
+// A light (spine-form) factor as its packed lower triangle and back: where HBM cannot hold every block's factor as a square, a block whose
+// packed variance matrix will live in HBM anyway lends that slot to its factor during the iterations (half the bytes of the square).
+int dnagpu_partial_pack_device(dnagpu_ctx* ctx, int chain, const dnagpu_partial* p, double* dev_ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!p || !dev_ap || !p->spine || !p->valid || !p->npp) return fail(ctx, DNAGPU_EINVAL, "partial_pack_device: no light factor to pack");
+    launch_pack_lower(p->X, dev_ap, p->npp, p->npp, ctx->stream[chain]);
+    return DNAGPU_OK;
+}
+
+int dnagpu_partial_unpack_device(dnagpu_ctx* ctx, int chain, dnagpu_partial* dst, const dnagpu_partial* src, const double* dev_ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!dst || !src || !dev_ap || !dst->spine || !src->spine || !src->npp)
+        return fail(ctx, DNAGPU_EINVAL, "partial_unpack_device: bad arguments");
+    if (src->npp > dst->n_cap || src->njp > dst->k_cap) return fail(ctx, DNAGPU_EINVAL, "partial_unpack_device: retained factor capacity");
+    hipStream_t st = ctx->stream[chain];
+    if (dst != src) {
+        dst->n = src->n; dst->nj = src->nj; dst->nip = src->nip; dst->njp = src->njp; dst->npp = src->npp;
+        HIPCHK(hipMemcpyAsync(dst->map, src->map, (size_t)src->npp * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
+    if (dst->store) dst->store->n = 0;       // (its storage now holds a factor, not a matrix)
+    launch_unpack_lower(dev_ap, dst->X, dst->npp, dst->npp, st);
+    dst->completed = false;
+    dst->factored = false;
+    dst->valid = true;
+    return DNAGPU_OK;
+}
+
 int dnagpu_copies_sync(dnagpu_ctx* ctx) {
     CHK_CTX();
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {

@@ -1103,6 +1103,7 @@ void dna_adjust::ResetAdjustment() {
         blocks_[b].has_finv = blocks_[b].has_rinv = blocks_[b].has_cinv = false;
         blocks_[b].inverse_kept = blocks_[b].inverse_pending = blocks_[b].part_valid = blocks_[b].rig_direct = blocks_[b].var_deferred = false;
         blocks_[b].part_transient = false;
+        blocks_[b].fac_packed = false;
     }
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
     currentIteration_ = 0;

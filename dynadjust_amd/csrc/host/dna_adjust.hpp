@@ -234,6 +234,10 @@ private:
         // a block the HBM budget denies a kept factor: its factor is made again where it is needed, in the chain's own storage (tmpfac_)
         bool part_transient = false;
         dnagpu_partial* tpart[DNAGPU_NUM_CHAINS] = {};
+        // ... unless its packed variance matrix will live in HBM (rig_on_device): that slot holds the factor's packed lower triangle from the
+        // condensing step to the variance matrix that replaces it (fac_src: the chain's descriptor the factor was made with)
+        bool fac_packed = false;
+        dnagpu_partial* fac_src = nullptr;
         bool var_deferred = false;            // a.defer_variances: this iteration's inverse exists as the completed factor in `part` only
         bool part_spine = false;              // a.defer_variances = 2: the kept factor in its light form (dnagpu_partial_create_spine)
         bool part_in_rigvar = false;          // the factor's inverse waits in rigvar's storage (dnagpu_partial_create_in): rigvar has n + 256
@@ -463,7 +467,8 @@ private:
     bool Staged() const { return staged_; }
 public:
     bool IsStaged() const { return staged_; }
-    void MemoryPlan(double out[10]) const;
+    void MemoryPlan(double out[12]) const;
+    bool PacksItsFactor(UINT32 block) const;
 private:
     std::vector<unsigned char> record_touched_;   // records whose statistics this process computed (UpdateMsrRecord)
     std::atomic<bool> chain_failed_{false};
@@ -555,6 +560,7 @@ private:
     dnagpu_matrix* tmpfac_[DNAGPU_NUM_CHAINS] = {};  // storage of the factor a block without a kept one makes again (TransientPartial), per chain
     bool transient_ok_ = false;                      // PrepareCondensedBlocks: such blocks exist and the conditions hold (GNSS only, light factors)
     std::atomic<uint64_t> transient_count_{0};
+    std::atomic<uint64_t> unpacked_count_{0};      // rigorous solves / variance matrices that took their factor from its packed copy in HBM
     dnagpu_partial* TransientPartial(int c, UINT32 k);
     bool BorrowTransientFactor(int c, UINT32 k);
     void FinishVariancesTransient(int c, UINT32 k);

@@ -242,7 +242,8 @@ void dna_adjust::AllocateStagedSlot(UINT32 k) {
     if (B.rig_host) return;
     const size_t n = v_parameterStationList_[k].size() * 3;
     if (B.rig_on_device) {
-        Check(dnagpu_device_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (packed, device)");
+        // (n + 256: the slot also holds the block's light factor, packed, between its condensing step and its variance matrix)
+        Check(dnagpu_device_alloc(ctx_, (n + 256) * (n + 257) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (packed, device)");
         return;
     }
     // (the plan left a fifth of the host's limit free; if something else has taken it since, a clean failure here is better than the
@@ -526,14 +527,14 @@ void dna_adjust::DecideStaging() {
         block_t& B = blocks_[k];
         const size_t n = v_parameterStationList_[k].size() * 3, bytes = n * (n + 1) / 2 * sizeof(double);
         if (B.rig_host) {                        // (it exists already: counted where it is)
-            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += bytes;
+            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += B.rig_on_device ? (n + 256) * (n + 257) / 2 * sizeof(double) : bytes;
             continue;
         }
         if ((double)(stage_host_bytes_ + bytes) <= host) {
             stage_host_bytes_ += bytes;
         } else {
             B.rig_on_device = true;
-            stage_device_bytes_ += bytes;
+            stage_device_bytes_ += (n + 256) * (n + 257) / 2 * sizeof(double);       // (AllocateStagedSlot: room for the packed factor)
         }
     }
 }
@@ -563,7 +564,15 @@ void dna_adjust::MemInfo(size_t* free_b, size_t* total_b) {
     Check(dnagpu_mem_info(ctx_, free_b, total_b), 0, "PrepareAdjustment()");
 }
 
-void dna_adjust::MemoryPlan(double out[10]) const {
+// no kept factor of its own (the HBM budget), but a device slot for its packed variance matrix that can hold the packed factor meanwhile
+bool dna_adjust::PacksItsFactor(UINT32 k) const {
+    static const bool off = getenv("DNAGPU_PACKED_FACTORS") && atoi(getenv("DNAGPU_PACKED_FACTORS")) == 0;
+    const block_t& B = blocks_[k];
+    return !off && transient_ok_ && !B.part && !B.part_allowed && Staged() && B.rig_on_device && B.rig_host && !B.keep.empty() &&
+           B.keep.size() < v_parameterStationList_[k].size() && CondensedSchedule();
+}
+
+void dna_adjust::MemoryPlan(double out[12]) const {
     out[0] = (double)stage_host_bytes_;
     out[1] = (double)stage_device_bytes_;
     out[2] = out[3] = 0.0;
@@ -578,6 +587,10 @@ void dna_adjust::MemoryPlan(double out[10]) const {
     out[7] = (double)stageWaitNs_.load() / 1.0e6;
     out[8] = (double)transient_count_.load();
     out[9] = transient_ok_ ? 1.0 : 0.0;
+    out[10] = (double)unpacked_count_.load();
+    out[11] = 0.0;
+    for (UINT32 k = 0; k < blockCount_; ++k)
+        if (OwnsBlock(k) && PacksItsFactor(k)) out[11] += 1.0;
 }
 
 // lists for the condensed schedule; condensed_ok_ = false falls back to the block-level chains
@@ -733,6 +746,7 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
     B.rig_direct = false;
     B.part_transient = false;
+    B.fac_packed = false;
     B.var_deferred = false;         // (a factor left from the previous iteration is overwritten by this one's)
     B.prefactored = false;
     if (B.keep.empty()) return;
@@ -755,6 +769,18 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
                                        B.red, B.part), k, "Solve()");
         if (profileTimings_)
             profileUpdateNormalsNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    } else if (PacksItsFactor(k)) {
+        // no kept factor of its own, but a slot in HBM that waits for its packed variance matrix: the factor of this step -- made in the
+        // chain's storage like the one a rigorous solve would make again -- goes there as its packed lower triangle (BorrowTransientFactor
+        // unpacks it instead of eliminating the block a second and, after the last iteration, a third time)
+        dnagpu_partial* tp = TransientPartial(c, k);
+        if (!tp) SignalExceptionAdjustment("Solve(): no memory for the block's factor.", k);
+        Check(dnagpu_block_form_reduce(ctx_, c, k, B.con_inner.stn.data(), B.con_inner.w9.data(), B.con_inner.stn.size(), B.keep.data(), B.keep.size(),
+                                       B.red, tp), k, "Solve()");
+        Check(dnagpu_partial_pack_device(ctx_, c, tp, B.rig_host), k, "Solve()");
+        B.fac_packed = true;
+        B.fac_src = tp;
+        B.has_rigvar = false;       // (the slot holds the factor until the variance matrix of the last iteration replaces it)
     } else {
         FormNormals(c, k, W);
         AddConstraints(c, W, B.con_inner, +1, k);
@@ -1201,6 +1227,16 @@ bool dna_adjust::BorrowTransientFactor(int c, UINT32 k) {
     if (!transient_ok_ || B.part || B.keep.empty() || B.keep.size() >= v_parameterStationList_[k].size() || !CondensedSchedule()) return false;
     dnagpu_partial* tp = TransientPartial(c, k);
     if (!tp) return false;
+    if (B.fac_packed) {
+        // the condensing step's factor, from its packed copy (CondenseBlock)
+        Check(dnagpu_partial_unpack_device(ctx_, c, tp, B.fac_src, B.rig_host), k, "Solve()");
+        B.part = tp;
+        B.part_spine = true;
+        B.part_valid = true;
+        B.part_transient = true;
+        unpacked_count_++;
+        return true;
+    }
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     Check(dnagpu_block_form_reduce(ctx_, c, k, B.con_inner.stn.data(), B.con_inner.w9.data(), B.con_inner.stn.size(), B.keep.data(), B.keep.size(), B.red, tp), k,
           "Solve()");
@@ -1258,11 +1294,13 @@ void dna_adjust::FinishVariancesTransient(int c, UINT32 k) {
     B.part_valid = false;
     B.part_spine = false;
     B.var_deferred = false;
+    const bool unpacked = B.fac_packed;
+    B.fac_packed = false;           // (the slot takes the variance matrix now; the unpack above is ahead of that pack on the chain's stream)
     StoreRigorousVariances(c, k, W);
     Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
-    algorithmic_flops_ += nk * nk * nk * 2.0 / 3.0 + n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    algorithmic_flops_ += nk * nk * nk * 2.0 / 3.0 + n * n * n / 3.0 + (unpacked ? 0.0 : ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk);
 }
 
 // body(chain) on every chain in use (a.multi_thread: two host threads, one per chain); the first exception is rethrown

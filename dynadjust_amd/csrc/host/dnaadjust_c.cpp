@@ -543,7 +543,7 @@ size_t dnaadj_summaries(dnaadj_handle* h, size_t limit, char* buf, size_t cap) {
     }
     return s.size();
 }
-int dnaadj_memory_plan(const dnaadj_handle* h, double out[10]) {
+int dnaadj_memory_plan(const dnaadj_handle* h, double out[12]) {
     if (!h || !h->adj || !out) return -1;
     h->adj->MemoryPlan(out);
     return 0;

@@ -172,7 +172,9 @@ int dnaadj_staged(const dnaadj_handle* h);     /* 1 when the prepared adjustment
  * a batch of blocks may have, out[5] bytes of host memory the process could still take when the plan was made, out[6] bytes the last adjustment copied to host memory
  * (staged variance matrices), out[7] milliseconds it waited for those copies (FinishStagedCopies: what did not hide behind the products), out[8] how many times
  * the last adjustment made a block's factor AGAIN because the block may not keep one (rigorous solves + variance matrices), out[9] 1 when
- * that is the plan for the blocks without a kept factor (GNSS-only network, light factors) instead of an inverse per iteration */
+ * that is the plan for the blocks without a kept factor (GNSS-only network, light factors) instead of an inverse per iteration,
+ * out[10] how many times it took such a factor from its packed copy in HBM instead (the slot that waits for the block's packed
+ * variance matrix lends itself to the factor during the iterations), out[11] how many blocks do that */
 /* Oscillation diagnostics (dna_adjust::UpdateIterationDiagnostics / PrintOscillationSummary / PrintSuspectMeasurementSummary,
  * ADJ:7450-7780).  dnaadj_oscillation_history: the recorded stations, 9 doubles each (bst index, first iteration, last iteration, cycles,
  * first magnitude, last magnitude, last e / n / up), ascending by station; returns their number (cap_records limits what is written).
@@ -180,7 +182,7 @@ int dnaadj_staged(const dnaadj_handle* h);     /* 1 when the prepared adjustment
  * list), as text; returns the length needed. */
 size_t dnaadj_oscillation_history(const dnaadj_handle* h, double* out9, size_t cap_records);
 size_t dnaadj_summaries(dnaadj_handle* h, size_t limit, char* buf, size_t cap);
-int dnaadj_memory_plan(const dnaadj_handle* h, double out[10]);
+int dnaadj_memory_plan(const dnaadj_handle* h, double out[12]);
 int dnaadj_condensed_schedule(const dnaadj_handle* h);
 /* Across GPUs every wait for the other ranks has a deadline (default 600 s, DNAGPU_COLLECTIVE_TIMEOUT_S): past it the communicator is
  * aborted (ncclCommAbort) and AdjustNetwork() ends with ADJUST_EXCEPTION_RAISED on the ranks that are still alive -- the reference's

@@ -348,6 +348,11 @@ int dnagpu_block_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
  * the matrix less than form + add + reduce.  Same bits as that sequence. */
 int dnagpu_block_form_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* con_stn, const double* con_w9, size_t n_con,
                              const uint32_t* idx_keep, size_t k, dnagpu_matrix* red, dnagpu_partial* keep);
+/* A light factor (dnagpu_partial_create_spine, after its reduce) as the packed lower triangle of its npp x npp storage,
+ * npp (npp + 1) / 2 doubles of device memory (npp <= the capacity: n_max + 256 covers it), and back: dst takes src's orders and
+ * unknown order with the factor (dst == src allowed) and is then what src was after its reduce.  Exact copies. */
+int dnagpu_partial_pack_device(dnagpu_ctx* ctx, int chain, const dnagpu_partial* p, double* dev_ap);
+int dnagpu_partial_unpack_device(dnagpu_ctx* ctx, int chain, dnagpu_partial* dst, const dnagpu_partial* src, const double* dev_ap);
 /* A chain's inverse workspace (X and W: two (n_max + 256)^2 matrices, padded) is allocated on the chain's first call that needs it;
  * dnagpu_chain_reserve makes that allocation now -- in PrepareAdjustment rather than inside the first iteration (hipMalloc of
  * 2 x 5.9 GB per chain at n = 27 000 is seconds). */

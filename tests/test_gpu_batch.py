@@ -92,7 +92,7 @@ def test_small_blocks_of_unequal_size_share_a_bucket(built, orc, tmp_path):
     o.close()
 
 
-@pytest.mark.parametrize("stage", [False, True])
+@pytest.mark.parametrize("stage", [False, True, "hbm"])
 def test_blocks_without_a_kept_factor_make_it_again(built, orc, tmp_path, monkeypatch, stage):
     """the HBM budget denies every block a kept factor (DNAGPU_FACTOR_BUDGET_GB=0: what cfg4 on one GPU does to 121 of its 128 blocks): in a
     GNSS-only network the factor is then formed and eliminated again in the rigorous solve and once more for the variance matrix (chain-owned
@@ -103,15 +103,25 @@ def test_blocks_without_a_kept_factor_make_it_again(built, orc, tmp_path, monkey
     o.prepare()
     ost = o.run()
     monkeypatch.delenv("DNAGPU_FACTOR_BUDGET_GB", raising=False)
-    a0, st0 = _run(str(tmp_path), "t", multi_thread=True, batch_blocks=0, stage=stage)
+    a0, st0 = _run(str(tmp_path), "t", multi_thread=True, batch_blocks=0, stage=bool(stage))
     assert st0 == ost and a0.memory_plan()["factors_made_again"] == 0 and a0.memory_plan()["blocks_keeping_their_factor"] == 6
     x0, v0, c0 = _results(a0)
     a0.close()
     monkeypatch.setenv("DNAGPU_FACTOR_BUDGET_GB", "0")
-    a1, st1 = _run(str(tmp_path), "t", multi_thread=True, stage=stage)
+    # "hbm": the staged store's host part is full (DNAGPU_HOST_STORE_GB=0), every packed variance matrix stays in HBM -- and its slot holds
+    # the block's packed factor during the iterations: unpacked where the others eliminate again
+    packed = stage == "hbm"
+    if packed:
+        monkeypatch.setenv("DNAGPU_HOST_STORE_GB", "0")
+    a1, st1 = _run(str(tmp_path), "t", multi_thread=True, stage=bool(stage))
     plan = a1.memory_plan()
     assert st1 == ost and plan["blocks_keeping_their_factor"] == 0 and plan["blocks_without_kept_factor_refactor"]
-    assert plan["factors_made_again"] == 6 * (a1.CurrentIteration() + 1)          # every rigorous solve + every variance matrix
+    if packed:
+        assert plan["blocks_packing_their_factor"] == 6 and plan["factors_made_again"] == 0
+        assert plan["factors_taken_from_their_packed_copy"] == 6 * (a1.CurrentIteration() + 1)
+        assert plan["staged_variances_host_bytes"] == 0 and plan["staged_variances_packed_in_hbm_bytes"] > 0
+    else:
+        assert plan["factors_made_again"] == 6 * (a1.CurrentIteration() + 1)          # every rigorous solve + every variance matrix
     x1, v1, c1 = _results(a1)
     assert c0 == c1
     for b in range(6):
