@@ -527,14 +527,14 @@ void dna_adjust::DecideStaging() {
         block_t& B = blocks_[k];
         const size_t n = v_parameterStationList_[k].size() * 3, bytes = n * (n + 1) / 2 * sizeof(double);
         if (B.rig_host) {                        // (it exists already: counted where it is)
-            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += B.rig_on_device ? (n + 256) * (n + 257) / 2 * sizeof(double) : bytes;
+            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += bytes;
             continue;
         }
         if ((double)(stage_host_bytes_ + bytes) <= host) {
             stage_host_bytes_ += bytes;
         } else {
             B.rig_on_device = true;
-            stage_device_bytes_ += (n + 256) * (n + 257) / 2 * sizeof(double);       // (AllocateStagedSlot: room for the packed factor)
+            stage_device_bytes_ += bytes;
         }
     }
 }
@@ -689,7 +689,8 @@ void dna_adjust::PrepareCondensedBlocks() {
     double later = 8.0e9, rig = 0.0;
     for (UINT32 k = 0; k < blockCount_; ++k)
         if (OwnsBlock(k)) rig += sq(3.0 * (double)v_parameterStationList_[k].size());
-    later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? (double)stage_device_bytes_ : rig);
+    // (a device slot of the staged store is allocated with room for the block's packed factor: n + 256 rows, AllocateStagedSlot)
+    later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? 1.03 * (double)stage_device_bytes_ : rig);
     double budget = (double)free_b - later;
     if (const char* e = getenv("DNAGPU_FACTOR_BUDGET_GB")) budget = atof(e) * 1.0e9;      // (test hook: the memory-tight plans at any size)
     // Blocks the budget denies a kept factor do not fall back to an inverse per iteration any more (n^3, and its copy to the staged store):
