@@ -46,9 +46,13 @@ WORKLOADS = {
     # the same station count cut the way dnasegment's defaults would (150 stations per block and up, dnaoptions.hpp:381-382): strips of 1 ... 10
     # rows of 150 stations -> ~120 blocks of 150 ... 1 500 inner + 150 junction stations (n = 900 ... 4 950)
     "smallblocks": (668, 150, 266666, 0, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, ~120 blocks of 150 ... 1 500 inner stations (dnasegment-like cut)"),
+    # the reference's DEFAULT operating point: dnasegment cuts blocks of 150 stations unless told otherwise (min_inner_stations(150),
+    # max_total_stations(150): include/config/dnaoptions.hpp:382, dnasegment.cpp:594-596).  100 000 stations on a grid 50 wide, strips of
+    # 3 rows: 667 blocks of 150 inner + 50 junction stations, n = 600 unknowns each -- hundreds of small dense systems, not a few large ones
+    "dnasegment150": (2000, 50, 266666, 0, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, 667 blocks of 150 inner + 50 junction stations (dnasegment's default block size)"),
 }
 # extra arguments of the generator per workload (dnasynth_spec: ragged, rows_lo, rows_hi)
-WORKLOAD_KW = {"cfg3_ragged": {"ragged": 0.3}, "smallblocks": {"rows_lo": 1, "rows_hi": 10}}
+WORKLOAD_KW = {"cfg3_ragged": {"ragged": 0.3}, "smallblocks": {"rows_lo": 1, "rows_hi": 10}, "dnasegment150": {"rows_lo": 3, "rows_hi": 3}}
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk)
 
 
@@ -589,7 +593,7 @@ def bench_one_process(folder, name, phased, args, devices, transport):
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, devices=devices, dist_transport=transport, multi_thread=multi_thread,
                                schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage,
                                defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
-                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))))
+                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))), reuse_factors=not args.no_reuse_factors)
     a.PrepareAdjustment(p)
     lib = a.lib
     ctxs = [a.device_instance_context(r) for r in range(world)]
@@ -666,7 +670,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank, dist_rank=rank, dist_world=world,
                                multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
                                schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage, defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
-                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))))
+                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))), reuse_factors=not args.no_reuse_factors)
     a.PrepareAdjustment(p)
     lib, ctx = a.lib, a.device_context()
     hbm0 = _hbm(lib, ctx)
@@ -782,6 +786,10 @@ def main():
                          "two-level runs, bytes of every exchange of an iteration: dnaadj_plan_distributed) and exit")
     ap.add_argument("--plan-hbm-gb", type=float, default=309.2, help="memory of one GPU for --plan (MI355X: 309.2 GB visible)")
     ap.add_argument("--no-one-chain", action="store_true", help="skip the extra one-chain step behind roofline.frac_one_chain")
+    ap.add_argument("--no-reuse-factors", action="store_true",
+                    help="every iteration factors again (a.reuse_factors = 0): the schedule of rounds 1-4; by default iterations >= 2 of a GNSS-only "
+                         "network keep the factors of iteration 1 and renew right-hand sides only")
+    ap.add_argument("--no-refactor-leg", action="store_true", help="skip the extra step with a.reuse_factors = 0 behind `without_factor_reuse`")
     ap.add_argument("--no-gemm-events", action="store_true", help="diagnostic: no HIP events around the GEMM launches (roofline.achieved = 0)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-args", default="[]", help=argparse.SUPPRESS)
@@ -895,7 +903,7 @@ def main():
                                multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank,
                                reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors,
                                defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
-                               stage=phased and args.stage)
+                               stage=phased and args.stage, reuse_factors=not args.no_reuse_factors)
     t_p = time.perf_counter()
     a.PrepareAdjustment(p)
     prepare_s = time.perf_counter() - t_p
@@ -937,7 +945,8 @@ def main():
     iters = a.CurrentIteration()
     solves = a.solve_count()
     sum_n3 = a.solve_flops()           # reference-equivalent: n^3 per Solve() of the reference's schedule
-    alg = a.algorithmic_flops()        # what the step needs: n^3 per inverse, the elimination's own count per carry-only step
+    alg = a.algorithmic_flops()        # what the step executes: n^3 per inverse, the elimination's own count per carry-only step
+    alg_min = a.minimal_work_flops()   # of that, the minimal schedule's share: every factorisation once, the variance matrices once (nothing re-done)
     elims = a.elimination_count()
     ms_per_step = dt * 1e3 / args.steps
     value = stations * args.steps / dt
@@ -968,6 +977,10 @@ def main():
             "stations": stations, "baselines": info["baselines"], "measurement_rows": info["measurement_rows"], "blocks": blocks,
             "max_block_unknowns": info["max_block_unknowns"], "iterations_to_converge": iters, "solves_per_step": solves,
             "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses),
+            # a.reuse_factors: iterations >= 2 of a GNSS-only network keep the factors of iteration 1 (the reference's own rule in simultaneous mode,
+            # dnaadjust.cpp:2452-2457); block steps / chain steps of a step that were served from a kept factor (right-hand sides only)
+            "reuse_factors": bool(a.factor_reuses() or a.chain_step_reuses()), "factor_reuses_per_step": a.factor_reuses(),
+            "chain_step_reuses_per_step": a.chain_step_reuses(),
             "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
             "variance_matrices": "after the last iteration" if (a.completion_count() and not args.variances_every_iteration and not args.reuse_inverses) else "every iteration",
             "libdnagpu_sha16": _so_hash(),
@@ -1004,6 +1017,11 @@ def main():
             "achieved_gemm_busy": gemm_busy,
             "frac_gemm_busy": gemm_busy / FP64_MFMA_PEAK_TFLOPS,
             "frac_end_to_end": achieved / FP64_MFMA_PEAK_TFLOPS,      # (= frac; the name earlier rounds used)
+            # `frac` prices the flops the step EXECUTED; this one prices only those of the minimal schedule -- every factorisation once and the
+            # variance matrices once -- over the same wall time, so that work done again (a factor made a second time where HBM denies a kept
+            # one, an iteration that factors again) can never read as useful work
+            "frac_min_work": (alg_min / 1e12) / (ms_per_step / 1e3) / FP64_MFMA_PEAK_TFLOPS,
+            "algorithmic_flops_per_step": alg, "minimal_work_flops_per_step": alg_min,
             "frac_one_chain": None,           # filled below: the same step on ONE chain, timed in this run
             "traffic": traffic_from_profile(args.workload)[0],
             "traffic_source": traffic_from_profile(args.workload)[1],
@@ -1036,7 +1054,8 @@ def main():
         try:
             a1 = adjust.DnaAdjust()
             p1 = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode, multi_thread=False, device=local_rank, reuse_inverses=p.reuse_inverses,
-                                        schur_carry=p.schur_carry, keep_factors=p.keep_factors, defer_variances=p.defer_variances, stage=p.stage)
+                                        schur_carry=p.schur_carry, keep_factors=p.keep_factors, defer_variances=p.defer_variances, stage=p.stage,
+                                        reuse_factors=p.reuse_factors)
             a1.PrepareAdjustment(p1)
             ctx1 = a1.device_context()
             for timed in (False, True):
@@ -1057,6 +1076,31 @@ def main():
             a1.close()
         except Exception as e:                   # diagnostic only
             out["roofline"]["frac_one_chain_error"] = str(e)
+    # the schedule of rounds 1-4 beside it: every iteration factors again (a.reuse_factors = 0) -- one warm-up and one timed step, measured here
+    if phased and out["config"]["reuse_factors"] and not args.no_refactor_leg:
+        try:
+            a2 = adjust.DnaAdjust()
+            p2 = adjust.ProjectSettings("net", d, adjust_mode=adjust.PhasedMode, multi_thread=p.multi_thread, device=local_rank, reuse_inverses=p.reuse_inverses,
+                                        schur_carry=p.schur_carry, keep_factors=p.keep_factors, defer_variances=p.defer_variances, stage=p.stage, reuse_factors=False)
+            a2.PrepareAdjustment(p2)
+            for timed in (False, True):
+                a2.ResetAdjustment()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                if a2.AdjustNetwork() != adjust.ADJUST_SUCCESS:
+                    raise RuntimeError("the step without factor reuse did not converge")
+                if args.variance_propagation:
+                    a2.GenerateStatistics()
+                lib.dnagpu_sync(a2.device_context())
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t2
+            out["without_factor_reuse"] = {"ms_per_step": dt2 * 1e3, "value": stations / dt2, "unit": "stations/s",
+                                           "frac": (a2.algorithmic_flops() / 1e12) / dt2 / FP64_MFMA_PEAK_TFLOPS,
+                                           "frac_min_work": (a2.minimal_work_flops() / 1e12) / dt2 / FP64_MFMA_PEAK_TFLOPS,
+                                           "iterations": a2.CurrentIteration()}
+            a2.close()
+        except Exception as e:                   # diagnostic only
+            out["without_factor_reuse"] = {"error": str(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, iters, solves, sum_n3, stations)
     emit(out)

@@ -35,7 +35,7 @@ class ProjectSettings:
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
                  scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None,
                  reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False, dist_rank=0, dist_world=1, devices=None,
-                 dist_transport=None, dist_two_level=True, defer_variances=2, batch_blocks=16):
+                 dist_transport=None, dist_two_level=True, defer_variances=2, batch_blocks=16, reuse_factors=True):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
         self.network_name = network_name          # g.network_name
         self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
@@ -49,6 +49,7 @@ class ProjectSettings:
         self.dist_rank, self.dist_world, self.devices = dist_rank, dist_world, devices
         self.dist_transport, self.dist_two_level = dist_transport, dist_two_level
         self.defer_variances = defer_variances
+        self.reuse_factors = reuse_factors        # GNSS-only networks: iterations >= 2 keep the factors of iteration 1 (right-hand sides only)
         self.batch_blocks = batch_blocks          # condensed schedule: blocks of one shape as one batch of merged launches (0 / 1 = off)
         if network_name is not None:
             self.set_filenames(os.path.join(folder, network_name))
@@ -142,6 +143,7 @@ class DnaAdjust:
         s.dist_two_level = int(bool(getattr(p, "dist_two_level", True)))
         s.defer_variances = int(getattr(p, "defer_variances", 2))
         s.batch_blocks = int(getattr(p, "batch_blocks", 16))
+        s.reuse_factors = int(bool(getattr(p, "reuse_factors", True)))
         return s
 
     # ---- multi-GPU (include/dnaadjust_c.h "multi-GPU") ----
@@ -313,6 +315,17 @@ class DnaAdjust:
     def completion_count(self):
         return self.lib.dnaadj_completion_count(self.h)
 
+    def factor_reuses(self):
+        """reuse_factors: block steps of the last AdjustNetwork served from a factor kept since an earlier iteration"""
+        return int(self.lib.dnaadj_factor_reuses(self.h))
+
+    def minimal_work_flops(self):
+        """of algorithmic_flops(): every factorisation once + the variance matrices once -- nothing that was done again"""
+        return float(self.lib.dnaadj_minimal_work_flops(self.h))
+
+    def chain_step_reuses(self):
+        return int(self.lib.dnaadj_chain_step_reuses(self.h))
+
     def batched_block_steps(self):
         """block steps that went through batched calls (settings.batch_blocks)"""
         return int(self.lib.dnaadj_batched_block_steps(self.h))
@@ -347,6 +360,10 @@ class DnaAdjust:
                 "copied_to_host_gb": round(out[6] / 1e9, 2), "waited_for_copies_ms": round(out[7], 1),
                 "factors_made_again": int(out[8]), "blocks_without_kept_factor_refactor": bool(out[9]),
                 "factors_taken_from_their_packed_copy": int(out[10]), "blocks_packing_their_factor": int(out[11])}
+
+    def condensed_schedule(self):
+        """True when the prepared adjustment runs the condensed schedule (phased, schur_carry, a segmentation that fits it)"""
+        return bool(self.lib.dnaadj_condensed_schedule(self.h))
 
     def elimination_count(self):
         return self.lib.dnaadj_elimination_count(self.h)

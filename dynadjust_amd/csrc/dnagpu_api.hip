@@ -889,6 +889,74 @@ int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const dou
     return DNAGPU_OK;
 }
 
+// a junction matrix in either form: matrix, attached estimates, reduced right-hand side (zeros in the estimates form), form
+int dnagpu_junction_export(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* dst, size_t cap_doubles) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || !dst) return fail(ctx, DNAGPU_EINVAL, "junction_export: null argument");
+    const size_t np = m->np, need = np * np + 2 * np + 1;
+    if (cap_doubles < need) return fail(ctx, DNAGPU_EINVAL, "junction_export: destination too small");
+    if (m->form == 1 && !m->jrhs) return fail(ctx, DNAGPU_EINVAL, "junction_export: information form without its right-hand side");
+    hipStream_t st = ctx->stream[chain];
+    const double form = (double)m->form;
+    HIPCHK(hipMemcpyAsync(dst, m->F, np * np * sizeof(double), hipMemcpyDefault, st));
+    HIPCHK(hipMemcpyAsync(dst + np * np, m->jest, np * sizeof(double), hipMemcpyDefault, st));
+    if (m->form == 1)
+        HIPCHK(hipMemcpyAsync(dst + np * np + np, m->jrhs, np * sizeof(double), hipMemcpyDefault, st));
+    else {
+        const std::vector<double> zeros(np, 0.0);       // (dst may be host memory: no memset)
+        HIPCHK(hipMemcpyAsync(dst + np * np + np, zeros.data(), np * sizeof(double), hipMemcpyDefault, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    HIPCHK(hipMemcpyAsync(dst + np * np + 2 * np, &form, sizeof(double), hipMemcpyDefault, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DNAGPU_OK;
+}
+
+int dnagpu_junction_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* src, uint32_t n) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || !src || n > m->n_max) return fail(ctx, DNAGPU_EINVAL, "junction_import: bad arguments");
+    m->n = n;
+    m->np = pad128(n);
+    const size_t np = m->np;
+    hipStream_t st = ctx->stream[chain];
+    double form = 0.0;
+    HIPCHK(hipMemcpyAsync(&form, src + np * np + 2 * np, sizeof(double), hipMemcpyDefault, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (form != 0.0 && form != 1.0) return fail(ctx, DNAGPU_EINVAL, "junction_import: not a junction payload");
+    if (form == 1.0 && !m->jrhs && dnagpu::poison_malloc(&m->jrhs, (size_t)m->np_max * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        m->jrhs = nullptr;
+        return fail(ctx, DNAGPU_ENOMEM, "junction_import: right-hand side of the information form");
+    }
+    HIPCHK(hipMemcpyAsync(m->F, src, np * np * sizeof(double), hipMemcpyDefault, st));
+    HIPCHK(hipMemcpyAsync(m->jest, src + np * np, np * sizeof(double), hipMemcpyDefault, st));
+    if (form == 1.0) HIPCHK(hipMemcpyAsync(m->jrhs, src + np * np + np, np * sizeof(double), hipMemcpyDefault, st));
+    HIPCHK(hipStreamSynchronize(st));
+    m->form = (int)form;
+    return DNAGPU_OK;
+}
+
+int dnagpu_junction_device_pointers(dnagpu_ctx* ctx, dnagpu_matrix* m, int as_form, double** matrix, double** estimates, double** rhs, uint32_t* np,
+                                    int* form) {
+    CHK_CTX();
+    if (!m || as_form > 1) return fail(ctx, DNAGPU_EINVAL, "junction_device_pointers: bad arguments");
+    const int f = as_form >= 0 ? as_form : m->form;
+    if (f == 1 && !m->jrhs && dnagpu::poison_malloc(&m->jrhs, (size_t)m->np_max * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        m->jrhs = nullptr;
+        return fail(ctx, DNAGPU_ENOMEM, "junction_device_pointers: right-hand side of the information form");
+    }
+    if (as_form >= 0) m->form = as_form;       // (about to receive a junction of that form)
+    if (matrix) *matrix = m->F;
+    if (estimates) *estimates = m->jest;
+    if (rhs) *rhs = f == 1 ? m->jrhs : nullptr;
+    if (np) *np = m->np;
+    if (form) *form = f;
+    return DNAGPU_OK;
+}
+
 int dnagpu_set_inverse_exchange(dnagpu_ctx* ctx, int rank, int world, dnagpu_exchange_fn fn, void* user) {
     if (!ctx) return DNAGPU_EINVAL;
     if (world > 1 && fn && (rank < 0 || rank >= world)) return fail(ctx, DNAGPU_EINVAL, "set_inverse_exchange: bad rank");
@@ -1913,6 +1981,21 @@ int schur_eliminate(dnagpu_ctx* ctx, int chain, Block* b, dnagpu_matrix* m, cons
 }
 }  // namespace
 
+namespace {
+// forward half of the blocked substitution with a light factor (sym_inverse.h: sym_spine_async): for every diagonal block b of the
+// eliminated part  v_b <- X_bb v_b,  v_below <- v_below - L_(below, b) v_b  (below: everything under the block, kept rows included)
+void spine_forward(dnagpu_ctx* ctx, int chain, const dnagpu_partial* pf, double* rp) {
+    hipStream_t st = ctx->stream[chain];
+    const uint32_t ld = pf->npp;
+    double* part = ctx->symv_part[chain];
+    for (const auto& bl : sym_spine_blocks((int)(pf->nip / 128))) {
+        const uint32_t o = (uint32_t)bl.first * 128, h = (uint32_t)bl.second * 128, below = ld - (o + h);
+        launch_gemv(pf->X + (size_t)o * ld + o, ld, h, h, rp + o, part, SYMV_CHUNKS - 1, 1, nullptr, 1.0, rp + o, h, st);
+        launch_gemv(pf->X + (size_t)o * ld + o + h, ld, below, h, rp + o, part, SYMV_CHUNKS - 1, 0, rp + o + h, -1.0, rp + o + h, below, st);
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm) {
@@ -1958,6 +2041,66 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
     }
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
+}
+
+int dnagpu_schur_carry_keep(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm,
+                            dnagpu_partial* keep) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !m || !jm || !k || !idx_out || k >= b->n_stn || 3 * k > jm->n_max || m->n != 3 * b->n_stn || !keep || !keep->spine || keep->store)
+        return fail(ctx, DNAGPU_EINVAL, "schur_carry_keep: bad arguments");
+    if (!g_info_carry.load()) return fail(ctx, DNAGPU_EINVAL, "schur_carry_keep: the information form of the carry is switched off");
+    const uint32_t nj = (uint32_t)(3 * k), npj = pad128(nj);
+    const double* T = nullptr;
+    uint32_t ldt = 0;
+    int slot = 0;
+    int rc = schur_eliminate(ctx, chain, b, m, idx_out, k, &T, &ldt, &slot, keep);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    jm->n = nj;
+    jm->np = npj;
+    if (!jm->jrhs && dnagpu::poison_malloc(&jm->jrhs, (size_t)jm->np_max * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        jm->jrhs = nullptr;
+        return fail(ctx, DNAGPU_ENOMEM, "schur_carry: right-hand side of the information form");
+    }
+    launch_schur_extract(T, ldt, nj, npj, jm->F, nullptr, jm->jrhs, st);
+    launch_gather_vec3(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, jm->jest, st);
+    jm->form = 1;
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    rc = check_info(ctx, chain);
+    if (rc) keep->valid = false;
+    return rc;
+}
+
+int dnagpu_schur_carry_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm, const dnagpu_partial* keep) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || !jm || !k || !idx_out || !keep || !keep->spine || !keep->valid || keep->n != 3 * b->n_stn || keep->nj != 3 * k || jm->n != 3 * k ||
+        jm->form != 1 || !jm->jrhs)
+        return fail(ctx, DNAGPU_EINVAL, "schur_carry_rhs: bad arguments");
+    for (size_t i = 0; i < k; ++i)
+        if (idx_out[i] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "schur_carry_rhs: station out of range");
+    int rc = ensure_ws(ctx, chain, keep->npp);
+    if (!rc) rc = ensure_symv(ctx, chain, keep->npp);
+    if (rc) return rc;
+    uint32_t* didx = nullptr;
+    rc = stage_u32(ctx, chain, idx_out, k, &didx);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    double* rp = ws.svec;
+    launch_gather_map(b->rhs[chain], keep->map, keep->npp, rp, st);
+    spine_forward(ctx, chain, keep, rp);
+    HIPCHK(hipMemcpyAsync(jm->jrhs, rp + keep->nip, (size_t)keep->nj * sizeof(double), hipMemcpyDeviceToDevice, st));
+    launch_gather_vec3(b->x_est[chain], didx, (uint32_t)k, jm->jest, st);
+    HIPCHK(hipStreamSynchronize(st));
+    return DNAGPU_OK;
 }
 
 int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_partial** out) {
@@ -2123,11 +2266,7 @@ int dnagpu_partial_solve(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_
         const uint32_t ld = pf->npp;
         const std::vector<std::pair<int, int>> blocks = sym_spine_blocks((int)(pf->nip / 128));
         double* part = ctx->symv_part[chain];
-        for (const auto& bl : blocks) {
-            const uint32_t o = (uint32_t)bl.first * 128, h = (uint32_t)bl.second * 128, below = ld - (o + h);
-            launch_gemv(pf->X + (size_t)o * ld + o, ld, h, h, rp + o, part, SYMV_CHUNKS - 1, 1, nullptr, 1.0, rp + o, h, st);
-            launch_gemv(pf->X + (size_t)o * ld + o + h, ld, below, h, rp + o, part, SYMV_CHUNKS - 1, 0, rp + o + h, -1.0, rp + o + h, below, st);
-        }
+        spine_forward(ctx, chain, pf, rp);
         {
             const uint32_t o = pf->nip, h = pf->njp;
             launch_gemv(pf->X + (size_t)o * ld + o, ld, h, h, rp + o, part, SYMV_CHUNKS - 1, 1, nullptr, 1.0, rp + o, h, st);
@@ -2184,7 +2323,7 @@ int dnagpu_partial_reduce_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const dn
     CHK_CTX();
     CHK_CHAIN();
     Block* b = find_block(ctx, blk);
-    if (!b || !pf || !pf->completed || !red || red->n != pf->nj || 3 * b->n_stn != pf->n)
+    if (!b || !pf || !red || red->n != pf->nj || 3 * b->n_stn != pf->n || !(pf->spine ? (pf->valid || pf->factored) : pf->completed))
         return fail(ctx, DNAGPU_EINVAL, "partial_reduce_rhs: bad arguments");
     int rc = ensure_ws(ctx, chain, pf->npp);
     if (!rc) rc = ensure_symv(ctx, chain, pf->npp);
@@ -2193,6 +2332,16 @@ int dnagpu_partial_reduce_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const dn
     hipStream_t st = ctx->stream[chain];
     gemm_profile_close(ws);
     double* rp = ws.svec;                 // rhs in the elimination's order
+    if (pf->spine) {
+        // light form: the forward half of dnagpu_partial_solve's blocked substitution -- y_b = X_bb v_b, v_below -= L_(below, b) y_b over
+        // the eliminated part's diagonal blocks; the kept rows ride along in every panel and end as the reduced right-hand side
+        HbmTimed timed(ctx, chain, DNAGPU_HBM_SUBSTITUTION, 4.0 * (double)pf->npp * pf->npp);
+        launch_gather_map(b->rhs[chain], pf->map, pf->npp, rp, st);
+        spine_forward(ctx, chain, pf, rp);
+        HIPCHK(hipMemcpyAsync(red->jest, rp + pf->nip, (size_t)pf->nj * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return DNAGPU_OK;
+    }
     double* y = b->corr[chain];           // L_II^-1 rhs_I (n_i <= 3 n_stn values)
     launch_gather_map(b->rhs[chain], pf->map, pf->npp, rp, st);
     const uint32_t ni = pf->n - pf->nj;
@@ -2528,7 +2677,7 @@ int dnagpu_block_load_reduced(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_
     CHK_CHAIN();
     Block* rb = find_block(ctx, rblk);
     Block* sb = find_block(ctx, src_blk);
-    if (!rb || !sb || !red || !m || !idx_keep || rb->n_stn != k || red->n != 3 * k || red->n > m->n_max)
+    if (!rb || !sb || !red || !idx_keep || rb->n_stn != k || red->n != 3 * k || (m && red->n > m->n_max))
         return fail(ctx, DNAGPU_EINVAL, "block_load_reduced: bad arguments");
     for (size_t i = 0; i < k; ++i)
         if (idx_keep[i] >= sb->n_stn) return fail(ctx, DNAGPU_EINVAL, "block_load_reduced: station out of range");
@@ -2536,9 +2685,11 @@ int dnagpu_block_load_reduced(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_
     uint32_t* didx = nullptr;
     int rc = stage_u32(ctx, chain, idx_keep, k, &didx);
     if (rc) return rc;
-    m->n = red->n;
-    m->np = red->np;
-    HIPCHK(hipMemcpyAsync(m->F, red->F, (size_t)red->np * red->np * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (m) {      // (m = NULL: right-hand side and linearisation point only -- a step whose factor is kept, dnagpu_schur_carry_rhs)
+        m->n = red->n;
+        m->np = red->np;
+        HIPCHK(hipMemcpyAsync(m->F, red->F, (size_t)red->np * red->np * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     HIPCHK(hipMemcpyAsync(rb->rhs[chain], red->jest, (size_t)red->n * sizeof(double), hipMemcpyDeviceToDevice, st));
     launch_gather_vec3(sb->x_orig, didx, (uint32_t)k, rb->x_est[chain], st);
     return DNAGPU_OK;

@@ -55,6 +55,12 @@ void dna_adjust::FreeDevice() {
             if (tp) dnagpu_partial_destroy(ctx_, tp);
             tp = nullptr;
         }
+        for (int d = 0; d < 2; ++d) {
+            if (b.cfac[d]) dnagpu_partial_destroy(ctx_, b.cfac[d]);
+            b.cfac[d] = nullptr;
+            b.cfac_live[d] = b.cfac_denied[d] = false;
+        }
+        b.factor_live = b.factor_reused = false;
         b.jfwd = b.jrev = b.rigvar = b.finv = b.rinv = b.red = nullptr;
     }
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
@@ -835,7 +841,7 @@ void dna_adjust::SolveTry(int chain, UINT32 block, dnagpu_matrix* m) {
     {
         std::lock_guard<std::mutex> lk(corr_mutex_);
         solve_flops_ += n * n * n;
-        algorithmic_flops_ += n * n * n;
+        CountFlops(n * n * n, 0);
         solve_count_++;
     }
     Check(dnagpu_solve_corrections(ctx_, chain, block, m), block, "Solve()");
@@ -860,8 +866,12 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     batched_flops_ = 0.0;
     stageCopiedBytes_ = stageWaitNs_ = 0;
     transient_count_ = 0;
-    algorithmic_flops_ = 0.0;
-    for (block_t& b : blocks_) b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
+    algorithmic_flops_ = min_work_flops_ = 0.0;
+    for (block_t& b : blocks_) {
+        b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
+        b.factor_live = b.factor_reused = b.cfac_live[0] = b.cfac_live[1] = false;      // (a.reuse_factors: within one adjustment only)
+    }
+    factor_reuses_ = chain_reuses_ = 0;
     osc_ready_ = false;              // corrPrev_ / stnOscCount_ / oscHistory_ start empty (ADJ:2419-2421, 2584-2586)
     oscHistory_.clear();
     const double t0 = now_ms();
@@ -1104,6 +1114,7 @@ void dna_adjust::ResetAdjustment() {
         blocks_[b].inverse_kept = blocks_[b].inverse_pending = blocks_[b].part_valid = blocks_[b].rig_direct = blocks_[b].var_deferred = false;
         blocks_[b].part_transient = false;
         blocks_[b].fac_packed = false;
+        blocks_[b].factor_live = blocks_[b].factor_reused = blocks_[b].cfac_live[0] = blocks_[b].cfac_live[1] = false;
     }
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
     currentIteration_ = 0;
@@ -1116,7 +1127,7 @@ void dna_adjust::ResetAdjustment() {
     completion_count_ = 0;
     batched_members_ = 0;
     batched_flops_ = 0.0;
-    algorithmic_flops_ = 0.0;
+    algorithmic_flops_ = min_work_flops_ = 0.0;
     cancel_.store(false);
     cancel_agreed_ = false;
     adjustStatus_ = ADJUST_SUCCESS;

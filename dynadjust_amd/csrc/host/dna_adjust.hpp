@@ -189,6 +189,7 @@ public:
     double algorithmicFlops() const { return SumOverPeers([](const dna_adjust& a) { return a.algorithmic_flops_; }); }
     // this instance's own share of the above (one rank of a multi-GPU adjustment)
     double ownAlgorithmicFlops() const { return algorithmic_flops_; }
+    double minimalWorkFlops() const { return SumOverPeers([](const dna_adjust& a) { return a.min_work_flops_; }); }
     double ownSolveFlops() const { return solve_flops_; }
     UINT32 ownSolveCount() const { return solve_count_; }
     UINT32 ownEliminationCount() const { return elimination_count_; }
@@ -245,6 +246,15 @@ private:
         bool prefactored = false;             // a batched rigorous solve has completed the factor already (RigorousBatch)
         bool inverse_pending = false;
         bool inverse_kept = false;            // CondensedReuse(): rigvar holds this adjustment's inverse, part its factor
+        // a.reuse_factors (GNSS-only networks): the block's light factor, completed in an earlier iteration of this adjustment, is intact in
+        // `part` -- later iterations reduce and solve right-hand sides with it (CondenseBlock / CompleteFromPartial) and factor nothing
+        bool factor_live = false;
+        bool factor_reused = false;           // this iteration's condensing step took the kept factor (no flops to count in the rigorous solve)
+        // ... and the factors of the two chain steps on the block's condensed system (0: forward, 1: reverse), kept while the budget
+        // lasts (chain_fac_budget_); live: made in an earlier iteration of this adjustment
+        dnagpu_partial* cfac[2] = {nullptr, nullptr};
+        bool cfac_live[2] = {false, false};
+        bool cfac_denied[2] = {false, false};
         dnagpu_matrix* red = nullptr;         // Schur complement onto keep + reduced right-hand side (dnagpu_block_reduce)
         std::vector<double> prec_adj_msrs;    // v_precAdjMsrsFull_ (6 per GNSS vector, then 1 per terrestrial measurement)
         // terrestrial measurements of the block (CML order among themselves)
@@ -442,6 +452,20 @@ private:
     bool CompleteFromPartial(int chain, UINT32 block, int kind, dnagpu_matrix* W);
     // a.defer_variances: the inverses that the iterations left as completed factors (block_t::var_deferred), once the iterations have ended
     bool DeferVariances() const { return projectSettings_.a.defer_variances != 0 && !ReuseRequested(); }
+    // a.reuse_factors: iterations >= 2 of a GNSS-only network keep the factors of iteration 1 (the reference's own licence in
+    // simultaneous mode, ADJ:2452-2457); needs the condensed schedule with light kept factors
+    bool FactorReuse() const {
+        return projectSettings_.a.reuse_factors != 0 && !containsNonGPS_ && CondensedSchedule() && projectSettings_.a.keep_factors != 0 && DeferVariances() &&
+               projectSettings_.a.defer_variances >= 2;
+    }
+    double chain_fac_budget_ = 0.0;         // HBM set aside for the chain steps' kept factors (PrepareCondensedBlocks)
+    std::atomic<uint64_t> factor_reuses_{0}, chain_reuses_{0};    // block steps / chain steps served from a kept factor since AdjustNetwork() began
+    // a chain step on the condensed block of k: elimination with the factor kept (first time) or its right-hand side through the kept factor
+    void CarryCondensed(int chain, UINT32 dev_block, UINT32 block, int dir, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm);
+public:
+    uint64_t FactorReuses() const { return factor_reuses_.load(); }
+    uint64_t ChainStepReuses() const { return chain_reuses_.load(); }
+private:
     void FinishDeferredVariances();
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);
     bool condensed_ok_ = false;
@@ -549,6 +573,16 @@ private:
     double solve_flops_ = 0.0;
     UINT32 solve_count_ = 0;
     double algorithmic_flops_ = 0.0;  // n^3 per inverse, the elimination's own count per dnagpu_schur_carry step
+    // Of those, the flops of the MINIMAL schedule: what a GNSS-only network needs at all -- every factorisation once (iteration 1) and the
+    // variance matrices once -- however many iterations run and however often a block without a kept factor makes it again.  Work
+    // that is re-done counts in algorithmic_flops_ (it was executed) and not here: bench.py's roofline.frac_min_work.
+    // kind: 0 = work of an iteration (minimal in iteration 1, or whenever the design moves with the estimates), 1 = done once per
+    // adjustment (the variance matrices), 2 = re-done by construction (a factor made a second time)
+    double min_work_flops_ = 0.0;
+    void CountFlops(double f, int kind) {      // (callers hold corr_mutex_)
+        algorithmic_flops_ += f;
+        if (kind == 1 || (kind == 0 && (containsNonGPS_ || currentIteration_ <= 1))) min_work_flops_ += f;
+    }
     UINT32 completion_count_ = 0;    // rigorous solves that completed a kept factor (a.keep_factors)
     UINT32 condense_count_ = 0;      // dnagpu_block_reduce steps (condensed schedule)
     UINT32 elimination_count_ = 0;   // of those, steps done by dnagpu_schur_carry (a.schur_carry)

@@ -538,7 +538,7 @@ void dna_adjust::ReduceRun(int c, int run) {
         prev = out;
         const double nk = 3.0 * (double)st.keep.size(), ni = 3.0 * (double)st.n_stn - nk;
         std::lock_guard<std::mutex> lk(corr_mutex_);
-        algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+        CountFlops(ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk, 0);
     }
 }
 
@@ -582,7 +582,7 @@ void dna_adjust::ScanRuns() {
         Check(dnagpu_schur_carry(ctx_, c, g.dev_block, Wm, out.data(), out.size(), jm), k, "Solve()");
         const double n = 3.0 * (double)g.stations.size(), nj = 3.0 * (double)out.size(), ni = n - nj;
         std::lock_guard<std::mutex> lk(corr_mutex_);
-        algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj);
+        CountFlops(ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj), 0);
     };
     OnEveryChain([&](int c) {
         if (c == 0)
@@ -724,7 +724,11 @@ void dna_adjust::DistributedReferenceIteration() {
         if (fwd_rank != o) msgs.push_back({0, k - 1, fwd_rank, o});
         if (rev_rank != o) msgs.push_back({1, k, rev_rank, o});
     }
-    struct xfer_t { double *F, *v; UINT32 np; int peer; bool send; };
+    // Every junction that travels here left a step that carries (PhasedForwardBlock / PhasedReverseBlock): with a.schur_carry it was made by
+    // elimination and is in dnagpu_schur_carry's form -- by default the information form: matrix, linearisation point AND reduced right-hand
+    // side --, otherwise gathered from the block inverse and inverted (estimates form).  Both sides know which: one rule, same settings.
+    const int form = (SchurCarry() && dnagpu_info_carry()) ? 1 : 0;
+    struct xfer_t { double *F, *v, *r; UINT32 np; int peer; bool send; };
     std::vector<xfer_t> xfers;
     AgreeOnPhase("exchange of the junction matrices (preparation)", [&] {       // (see ExchangeCondensed)
         for (const junction_msg& g : msgs) {
@@ -732,8 +736,10 @@ void dna_adjust::DistributedReferenceIteration() {
             dnagpu_matrix* jm = g.kind == 0 ? blocks_[g.block].jfwd : blocks_[g.block].jrev;
             if (!jm) continue;
             if (g.dst == me) Check(dnagpu_matrix_resize(ctx_, jm, JunctionUnknowns(g.block)), g.block, "exchange");
-            xfer_t x{nullptr, nullptr, 0, g.src == me ? g.dst : g.src, g.src == me};
-            dnagpu_matrix_device_pointers(jm, &x.F, &x.v, &x.np);
+            xfer_t x{nullptr, nullptr, nullptr, 0, g.src == me ? g.dst : g.src, g.src == me};
+            int has = 0;
+            Check(dnagpu_junction_device_pointers(ctx_, jm, g.dst == me ? form : -1, &x.F, &x.v, &x.r, &x.np, &has), g.block, "exchange");
+            if (has != form) SignalExceptionAdjustment("AdjustPhased(): a junction matrix is not in the form the exchange expects.", g.block);
             xfers.push_back(x);
         }
     });
@@ -742,9 +748,11 @@ void dna_adjust::DistributedReferenceIteration() {
         if (x.send) {
             comm_->send(x.F, (size_t)x.np * x.np, x.peer);
             comm_->send(x.v, x.np, x.peer);
+            if (x.r) comm_->send(x.r, x.np, x.peer);
         } else {
             comm_->recv(x.F, (size_t)x.np * x.np, x.peer);
             comm_->recv(x.v, x.np, x.peer);
+            if (x.r) comm_->recv(x.r, x.np, x.peer);
         }
     }
     comm_->group_end();

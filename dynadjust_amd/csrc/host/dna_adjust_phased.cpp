@@ -85,7 +85,7 @@ void dna_adjust::CarryByElimination(int c, UINT32 dev_block, UINT32 k, dnagpu_ma
     solve_flops_ += nref * nref * nref;
     // Cholesky of the inner part, its panel under the junction rows, the complement's update, and -- estimates form only
     // (DNAGPU_INFO_CARRY=0) -- the complement's inverse
-    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj);
+    CountFlops(ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj), 0);
     solve_count_++;
     elimination_count_++;
 }
@@ -622,6 +622,7 @@ void dna_adjust::PrepareCondensedBlocks() {
     condensed_ok_ = false;
     transient_ok_ = false;
     batch_limit_ = 0;
+    chain_fac_budget_ = 0.0;
     if (projectSettings_.a.adjust_mode == SimultaneousMode || !projectSettings_.a.schur_carry) {
         AllocateChainData();
         return;
@@ -671,6 +672,14 @@ void dna_adjust::PrepareCondensedBlocks() {
         }
     }
     condensed_ok_ = true;
+    // DNAGPU_FORCE_BLOCK_CHAINS=1 (tests): as if a block did not fit the condensed schedule -- the chains run on the blocks themselves
+    // (a.schur_carry steps by elimination, junction matrices exchanged across ranks: DistributedReferenceIteration)
+    if (const char* e = getenv("DNAGPU_FORCE_BLOCK_CHAINS"))
+        if (atoi(e) != 0) {
+            condensed_ok_ = false;
+            AllocateChainData();
+            return;
+        }
     // what the chains need on the device -- junction matrices, condensed blocks -- for the blocks this rank works on
     PrepareTwoLevel();
     AllocateChainData();
@@ -737,6 +746,14 @@ void dna_adjust::PrepareCondensedBlocks() {
     // (the workspaces belong to a chain and the groups of a phase run on all chains at once: what the chains have been granted together
     //  stays inside this budget -- FitGroupsToBudget; a member also has a kept-block work matrix of its own, kbatch_)
     if (max_keep) budget -= (double)chains * sq(3.0 * (double)max_keep);           // (the kept-block work matrices just made)
+    // a.reuse_factors: the chain steps' factors on the condensed blocks (two per block, (ceil128(n_i) + ceil128(n_j + 1))^2 doubles each: 34 MB
+    // for cfg3's 1 900-unknown condensed blocks, 315 MB for cfg4's 6 000) are kept as far as a tenth of what is left goes, 16 GB at most
+    chain_fac_budget_ = 0.0;
+    if (projectSettings_.a.reuse_factors != 0 && !containsNonGPS_ && DeferVariances() && projectSettings_.a.defer_variances >= 2) {
+        chain_fac_budget_ = std::max(0.0, std::min(0.1 * budget, 16.0e9));
+        if (const char* e = getenv("DNAGPU_CHAIN_FACTOR_GB")) chain_fac_budget_ = atof(e) * 1.0e9;
+        budget -= chain_fac_budget_;
+    }
     batch_unit_ = 1.25 * sq((double)max_unknowns_) + sq(3.0 * (double)max_keep);
     batch_budget_ = std::max(0.0, budget);
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) batch_granted_[c] = 0;
@@ -757,6 +774,19 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
         Check(dnagpu_partial_reduce_rhs(ctx_, c, k, B.part, B.red), k, "Solve()");
         return;
     }
+    if (B.factor_live && B.part && FactorReuse()) {
+        // a.reuse_factors: the normals are those of the iteration that made the factor (GNSS only): the right-hand side alone is reduced,
+        // by substitution with the kept factor; the kept block's factor is still there as well (CompleteFromPartial: prefactored)
+        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+        Check(dnagpu_partial_reduce_rhs(ctx_, c, k, B.part, B.red), k, "Solve()");
+        B.part_valid = true;
+        B.prefactored = true;
+        B.factor_reused = true;
+        factor_reuses_++;
+        return;
+    }
+    B.factor_live = false;
+    B.factor_reused = false;
     dnagpu_matrix* W = work_[c];
     Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
     EnsurePartial(k);
@@ -863,7 +893,7 @@ void dna_adjust::NoteCondensed(UINT32 k) {
     std::lock_guard<std::mutex> lk(corr_mutex_);
     // a Cholesky factorisation of the eliminated part (plus its triangular inverse when the factor is kept), the panel under
     // the kept rows, the complement's update
-    algorithmic_flops_ += ((B.part && !B.part_spine) ? 2.0 : 1.0) * ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    CountFlops(((B.part && !B.part_spine) ? 2.0 : 1.0) * ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk, 0);
     condense_count_++;
 }
 
@@ -958,6 +988,12 @@ void dna_adjust::CondenseBatch(int c, const std::vector<UINT32>& ks) {
     std::vector<UINT32> members;
     for (UINT32 k : ks) {
         block_t& B = blocks_[k];
+        if (B.factor_live && B.part && FactorReuse()) {      // (its factor of an earlier iteration serves: right-hand side only)
+            CondenseBlock(c, k);
+            continue;
+        }
+        B.factor_live = false;
+        B.factor_reused = false;
         B.rig_direct = false;
         B.var_deferred = false;
         B.prefactored = false;
@@ -1032,12 +1068,20 @@ bool dna_adjust::CompleteFromPartial(int c, UINT32 k, int kind, dnagpu_matrix* W
     B.part_valid = false;
     B.inverse_pending = CondensedReuse();  // kept once StoreRigorousVariances has copied W into the block's own matrix
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
+    // a.reuse_factors: the block's own light factor, completed, stays where it is until the variance matrices are formed
+    const bool reused = B.factor_reused;
+    B.factor_reused = false;
+    B.factor_live = defer && B.part_spine && !B.part_transient && FactorReuse();
     std::lock_guard<std::mutex> lk(corr_mutex_);
     solve_flops_ += n * n * n;
     solve_count_++;
+    if (reused) {          // (nothing was factored: two substitutions)
+        completion_count_++;
+        return defer;
+    }
     // factor + invert the kept block, the two panel products of the kept rows, X^T X (now, or in FinishDeferredVariances)
     // (light form: only the kept block is factored and inverted here; the panel products wait with the inverse of the factor)
-    algorithmic_flops_ += B.part_spine ? nk * nk * nk * 2.0 / 3.0 : nk * nk * nk + nk * ni * ni + nk * nk * ni + (defer ? 0.0 : n * n * n / 3.0);
+    CountFlops(B.part_spine ? nk * nk * nk * 2.0 / 3.0 : nk * nk * nk + nk * ni * ni + nk * nk * ni + (defer ? 0.0 : n * n * n / 3.0), 0);
     completion_count_++;
     return defer;
 }
@@ -1068,7 +1112,10 @@ void dna_adjust::PrepareKeptBlock(int c, UINT32 k, int kind, dnagpu_matrix* K) {
 // The first half of RigorousBlock for the members of a batch: every member's kept block as its rigorous solve builds it, their factors
 // completed merged (the kept blocks are small: launches bound by latency, now with nb times the tiles).  The members' own solves
 // (substitution, estimates, junction carries: RigorousBlock, which finds the factor done) follow on whichever chain is free.
-void dna_adjust::RigorousBatch(int c, const std::vector<UINT32>& ks) {
+void dna_adjust::RigorousBatch(int c, const std::vector<UINT32>& ks_all) {
+    std::vector<UINT32> ks;
+    for (UINT32 k : ks_all)
+        if (!blocks_[k].prefactored) ks.push_back(k);      // (a.reuse_factors: the kept block's factor of an earlier iteration is still there)
     const int nb = (int)ks.size();
     if (nb >= 2 && BatchWorkspaces(c, ks)) {
         {
@@ -1134,13 +1181,14 @@ void dna_adjust::FinishVariancesBlock(int c, UINT32 k) {
     }
     Check(dnagpu_partial_finish(ctx_, c, B.part, W), k, "Solve()");
     B.var_deferred = false;
+    B.factor_live = false;          // (the factor has become the inverse)
     StoreRigorousVariances(c, k, W);
     Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
     // X^T X, and in the light form the inverse of the factor first (its diagonal blocks exist: ~ the eliminated part's trtri
     // with the kept rows riding along)
-    algorithmic_flops_ += n * n * n / 3.0 + (B.part_spine ? ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk : 0.0);
+    CountFlops(n * n * n / 3.0 + (B.part_spine ? ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk : 0.0), 1);
 }
 
 void dna_adjust::FinishVariancesBatch(int c, const std::vector<UINT32>& ks) {
@@ -1166,10 +1214,11 @@ void dna_adjust::FinishVariancesBatch(int c, const std::vector<UINT32>& ks) {
         const UINT32 k = ks[b];
         block_t& B = blocks_[k];
         B.var_deferred = false;
+        B.factor_live = false;
         StoreRigorousVariances(c, k, B.rigvar);
         const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
         std::lock_guard<std::mutex> lk(corr_mutex_);
-        algorithmic_flops_ += n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+        CountFlops(n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk, 1);
         batched_flops_ += n * n * n / 3.0 + ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
     }
     Check(dnagpu_chain_sync(ctx_, c), ks[0], "UpdateEstimatesFinal()");
@@ -1183,13 +1232,16 @@ void dna_adjust::CondensedForwardBlock(int c, UINT32 k) {
     const bool carried_in = !meta._blockFirst && !B.c_prev.empty();
     dnagpu_matrix* W = work_[c];
     const UINT32 cb = blockCount_ + k;
-    Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, W), k, "UpdateNormals()");
-    AddConstraints(c, W, B.ccon_fwd, +1, k);
+    // a.reuse_factors: the step's system is the one an earlier iteration factored -- only its right-hand side is put together
+    const bool rhs_only = B.cfac[0] && B.cfac_live[0] && FactorReuse();
+    Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, rhs_only ? nullptr : W), k, "UpdateNormals()");
+    if (!rhs_only) AddConstraints(c, W, B.ccon_fwd, +1, k);
     if (carried_in) {
-        Check(dnagpu_junction_scatter(ctx_, c, W, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesForward()");
+        if (!rhs_only)
+            Check(dnagpu_junction_scatter(ctx_, c, W, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "CarryStnEstimatesandVariancesForward()");
         Check(dnagpu_junction_rhs(ctx_, c, cb, B.c_prev.data(), B.c_prev.size(), blocks_[k - 1].jfwd), k, "Solve()");
     }
-    CarryByElimination(c, cb, k, W, B.c_next, B.jfwd);
+    CarryCondensed(c, cb, k, 0, W, B.c_next, B.jfwd);
 }
 
 // PhasedReverseBlock on the condensed block
@@ -1200,11 +1252,59 @@ void dna_adjust::CondensedReverseBlock(int c, UINT32 k) {
     const bool rev_in = !meta._blockLast && !B.c_next.empty();
     dnagpu_matrix* W = work_[c];
     const UINT32 cb = blockCount_ + k;
-    Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, W), k, "UpdateNormals()");
-    if (rev_in) Check(dnagpu_junction_scatter(ctx_, c, W, B.c_next.data(), B.c_next.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
-    AddConstraints(c, W, B.ccon_rev, +1, k);
+    const bool rhs_only = B.cfac[1] && B.cfac_live[1] && FactorReuse();
+    Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, rhs_only ? nullptr : W), k, "UpdateNormals()");
+    if (rev_in && !rhs_only)
+        Check(dnagpu_junction_scatter(ctx_, c, W, B.c_next.data(), B.c_next.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
+    if (!rhs_only) AddConstraints(c, W, B.ccon_rev, +1, k);
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, cb, B.c_next.data(), B.c_next.size(), B.jrev), k, "Solve()");
-    CarryByElimination(c, cb, k, W, B.c_prev, blocks_[k - 1].jrev);
+    CarryCondensed(c, cb, k, 1, W, B.c_prev, blocks_[k - 1].jrev);
+}
+
+// The carry of a chain step on block k's condensed system (dev_block), direction dir (0 forward, 1 reverse).  With a.reuse_factors the
+// step's factor is kept the first time (while the budget for such factors lasts) and every later iteration takes the step's right-hand
+// side through it (dnagpu_schur_carry_rhs): the complement S in jm is the same in every iteration, its right-hand side is renewed.
+void dna_adjust::CarryCondensed(int c, UINT32 dev_block, UINT32 k, int dir, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm) {
+    block_t& B = blocks_[k];
+    if (!FactorReuse() || out.size() >= B.keep.size() || !dnagpu_info_carry()) {
+        CarryByElimination(c, dev_block, k, W, out, jm);
+        return;
+    }
+    if (B.cfac[dir] && B.cfac_live[dir]) {
+        Check(dnagpu_schur_carry_rhs(ctx_, c, dev_block, out.data(), out.size(), jm, B.cfac[dir]), k, "Solve()");
+        const double nref = 3.0 * (double)v_parameterStationList_[k].size();
+        std::lock_guard<std::mutex> lk(corr_mutex_);
+        solve_flops_ += nref * nref * nref;       // (a Solve() of the reference all the same)
+        solve_count_++;
+        elimination_count_++;
+        chain_reuses_++;
+        return;
+    }
+    if (!B.cfac[dir] && !B.cfac_denied[dir]) {
+        const UINT32 n = 3 * (UINT32)B.keep.size(), nk = 3 * (UINT32)out.size();
+        const double np = std::ceil((double)(n - nk) / 128.0) * 128.0 + std::ceil((double)(nk + 1) / 128.0) * 128.0;
+        const double need = np * np * 8.0 + np * 4.0;
+        std::lock_guard<std::mutex> lk(alloc_mutex_);
+        if (need <= chain_fac_budget_ && dnagpu_partial_create_spine(ctx_, n, nk, nullptr, &B.cfac[dir]) == DNAGPU_OK) {
+            chain_fac_budget_ -= need;
+        } else {
+            B.cfac[dir] = nullptr;
+            B.cfac_denied[dir] = true;      // (no room: this step eliminates in every iteration, as before)
+        }
+    }
+    if (!B.cfac[dir]) {
+        CarryByElimination(c, dev_block, k, W, out, jm);
+        return;
+    }
+    Check(dnagpu_schur_carry_keep(ctx_, c, dev_block, W, out.data(), out.size(), jm, B.cfac[dir]), k, "Solve()");
+    B.cfac_live[dir] = true;
+    const double nref = 3.0 * (double)v_parameterStationList_[k].size();
+    const double n = 3.0 * (double)B.keep.size(), nj = 3.0 * (double)out.size(), ni = n - nj;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    solve_flops_ += nref * nref * nref;
+    CountFlops(ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj, 0);
+    solve_count_++;
+    elimination_count_++;
 }
 
 // the factor of a block that keeps none, in chain c's storage (a descriptor per block and chain: the capacity is the block's own shape)
@@ -1247,7 +1347,7 @@ bool dna_adjust::BorrowTransientFactor(int c, UINT32 k) {
     B.part_transient = true;
     const double nk = 3.0 * (double)B.keep.size(), ni = 3.0 * (double)v_parameterStationList_[k].size() - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
-    algorithmic_flops_ += ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;      // (work this schedule needs: the factor made a second time)
+    CountFlops(ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk, 2);      // (work this schedule needs: the factor made a second time)
     transient_count_++;
     return true;
 }
@@ -1301,7 +1401,8 @@ void dna_adjust::FinishVariancesTransient(int c, UINT32 k) {
     Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
-    algorithmic_flops_ += nk * nk * nk * 2.0 / 3.0 + n * n * n / 3.0 + (unpacked ? 0.0 : ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk);
+    CountFlops(nk * nk * nk * 2.0 / 3.0 + n * n * n / 3.0, 1);
+    if (!unpacked) CountFlops(ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk, 2);
 }
 
 // body(chain) on every chain in use (a.multi_thread: two host threads, one per chain); the first exception is rethrown
@@ -1461,21 +1562,21 @@ void dna_adjust::PhasedFinish() {
 size_t dna_adjust::JunctionPayloadDoubles(UINT32 k) const {
     size_t n = (size_t)v_JSL_.at(k).size() * 3;
     size_t np = n == 0 ? 128 : ((n + 127) / 128) * 128;
-    return np * np + np;
+    return np * np + 2 * np + 1;        // (matrix, estimates, reduced right-hand side, form: dnagpu_junction_export)
 }
 
 void dna_adjust::ExportJunction(int kind, UINT32 k, double* dst) {
     block_t& B = blocks_.at(k);
     dnagpu_matrix* jm = kind == 0 ? B.jfwd : B.jrev;
     if (!jm) return;
-    Check(dnagpu_matrix_export(ctx_, 0, jm, dst, JunctionPayloadDoubles(k)), k, "ExportJunction()");
+    Check(dnagpu_junction_export(ctx_, 0, jm, dst, JunctionPayloadDoubles(k)), k, "ExportJunction()");
 }
 
 void dna_adjust::ImportJunction(int kind, UINT32 k, const double* src) {
     block_t& B = blocks_.at(k);
     dnagpu_matrix* jm = kind == 0 ? B.jfwd : B.jrev;
     if (!jm) return;
-    Check(dnagpu_matrix_import(ctx_, 0, jm, src, JunctionUnknowns(k)), k, "ImportJunction()");
+    Check(dnagpu_junction_import(ctx_, 0, jm, src, JunctionUnknowns(k)), k, "ImportJunction()");
 }
 
 void dna_adjust::GetBlockStations(UINT32 k, int which, std::vector<double>& xyz) {

@@ -51,6 +51,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->dist_two_level = 1;
     s->defer_variances = 2;
     s->batch_blocks = 16;
+    s->reuse_factors = 1;
 }
 
 int dnaadj_create(dnaadj_handle** out) {
@@ -100,6 +101,7 @@ static void to_project_settings(const dnaadj_settings* s, dynadjust::project_set
     p.a.dist_two_level = (uint16_t)(s->dist_two_level ? 1 : 0);
     p.a.defer_variances = (uint16_t)(s->defer_variances < 0 ? 0 : s->defer_variances > 2 ? 2 : s->defer_variances);
     p.a.batch_blocks = (uint16_t)(s->batch_blocks < 0 ? 0 : s->batch_blocks > 16 ? 16 : s->batch_blocks);
+    p.a.reuse_factors = (uint16_t)(s->reuse_factors ? 1 : 0);
     if (s->network_name) p.g.network_name = s->network_name;
     if (s->output_folder) p.g.output_folder = s->output_folder;
 }
@@ -326,6 +328,9 @@ uint32_t dnaadj_solve_count(const dnaadj_handle* h) { return h && h->adj ? h->ad
 double dnaadj_algorithmic_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->algorithmicFlops() : 0.0; }
 uint32_t dnaadj_completion_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->completionCount() : 0; }
 uint32_t dnaadj_elimination_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->eliminationCount() : 0; }
+double dnaadj_minimal_work_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->minimalWorkFlops() : 0.0; }
+uint64_t dnaadj_factor_reuses(const dnaadj_handle* h) { return h && h->adj ? h->adj->FactorReuses() : 0; }
+uint64_t dnaadj_chain_step_reuses(const dnaadj_handle* h) { return h && h->adj ? h->adj->ChainStepReuses() : 0; }
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block) {
     if (!h || !h->adj || block >= h->adj->blockCount()) return 0;

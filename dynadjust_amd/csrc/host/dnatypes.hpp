@@ -236,6 +236,15 @@ struct adjust_settings {
     // reference's blocks have no such coupling -- its Solve() calls follow each other (ADJ:2812, ADJ:3512, ADJ:3556) -- and every
     // member's results are the bits of the unbatched calls.  0 / 1: off.  DNAGPU_BATCH overrides.
     UINT16 batch_blocks = 16;
+    // Not in the reference's phased mode (it has the same licence in simultaneous mode: SolveTry(CurrentIteration() < 2 ||
+    // ContainsNonGPS()), dnaadjust.cpp:2452-2457): in a GNSS-only network neither the design nor the weights move with the estimates,
+    // so the normals of every block -- and with them every factor of the condensed schedule: the blocks' light factors, the kept
+    // blocks' factors, the factors of the chain steps on the condensed blocks -- are the same in every iteration.  1 (default):
+    // iterations >= 2 keep the factors of iteration 1 and renew right-hand sides only (substitutions at HBM speed); the variance
+    // matrices are still formed once, after the last iteration.  0: every iteration factors again.  Needs the condensed schedule
+    // with light kept factors (schur_carry, keep_factors, defer_variances = 2); blocks that may not keep a factor (HBM budget)
+    // go on as before.
+    UINT16 reuse_factors = 1;
 };
 struct output_settings {
     UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement

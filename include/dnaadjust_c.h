@@ -67,6 +67,11 @@ typedef struct {
     int batch_blocks;          /* condensed schedule with kept factors (default 16 = DNAGPU_BATCH_MAX): blocks of one shape go through its large
                                   steps as one batch of up to this many members -- merged launches, in lock step (include/dnagpu.h,
                                   dnagpu_*_batched); every member's results are the bits of the unbatched calls.  0 / 1 = off */
+    int reuse_factors;         /* device path only (default 1): GNSS-only networks (the reference's own test, dnaadjust.cpp:2457, which it
+                                  applies in simultaneous mode) keep the factors of iteration 1 -- the blocks' light factors, the kept
+                                  blocks' factors, the chain steps' factors on the condensed blocks -- and renew right-hand sides only
+                                  from iteration 2 on; the variance matrices are formed once, after the last iteration, as before.
+                                  0 = every iteration factors again.  Needs schur_carry, keep_factors and defer_variances = 2 */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
@@ -104,6 +109,13 @@ double dnaadj_algorithmic_flops(const dnaadj_handle* h);               /* n^3 pe
 uint32_t dnaadj_solve_count(const dnaadj_handle* h);
 uint32_t dnaadj_completion_count(const dnaadj_handle* h);              /* of those, rigorous solves that completed a kept factor (keep_factors) */
 uint32_t dnaadj_elimination_count(const dnaadj_handle* h);             /* of those, carry-only steps done by elimination (schur_carry) */
+/* reuse_factors: block steps (condensing + rigorous solve counted once) / chain steps of the last dnaadj_adjust that were served from a
+ * factor kept since an earlier iteration -- right-hand sides only (this GPU's share) */
+uint64_t dnaadj_factor_reuses(const dnaadj_handle* h);
+/* of dnaadj_algorithmic_flops, the flops of the minimal schedule: every factorisation once and the variance matrices once (GNSS-only
+ * networks; with terrestrial measurements every iteration's factorisations count) -- nothing that was done again */
+double dnaadj_minimal_work_flops(const dnaadj_handle* h);
+uint64_t dnaadj_chain_step_reuses(const dnaadj_handle* h);
 uint32_t dnaadj_station_count(const dnaadj_handle* h);
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block);

@@ -195,6 +195,16 @@ int dnagpu_matrix_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const dou
  * A receiver sets the logical order first (dnagpu_matrix_resize: n <= n_max; contents untouched). */
 int dnagpu_matrix_resize(dnagpu_ctx* ctx, dnagpu_matrix* m, uint32_t n);
 int dnagpu_matrix_device_pointers(const dnagpu_matrix* m, double** matrix, double** vector, uint32_t* np);
+/* The same for a JUNCTION matrix in either form of dnagpu_schur_carry: np * np + 2 np + 1 doubles -- matrix, attached estimates, the reduced
+ * right-hand side of the information form (zeros in the estimates form), the form (0.0 / 1.0); import sets the form it finds.
+ * (dna_adjust exchanges v_junctionVariances* / v_junctionEstimates* between its threads by reference, dnaadjust-multi.cpp:365-641;
+ * across address spaces they travel as this payload.)  dnagpu_junction_device_pointers: the buffers themselves for an in-place exchange --
+ * as_form < 0: a sender, *form tells what it holds (rhs = NULL in the estimates form); as_form 0 / 1: a receiver about to take a
+ * junction of that form (the right-hand side's buffer is allocated if need be, the matrix's form is set). */
+int dnagpu_junction_export(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* dst, size_t cap_doubles);
+int dnagpu_junction_import(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const double* src, uint32_t n);
+int dnagpu_junction_device_pointers(dnagpu_ctx* ctx, dnagpu_matrix* m, int as_form, double** matrix, double** estimates, double** rhs, uint32_t* np,
+                                    int* form);
 /* Intra-block distributed inverse (networks with fewer blocks than GPUs, e.g. the simultaneous adjustment's one block): `world` contexts,
  * one per GPU, are given the same matrices and call dnagpu_invert together.  Every large launch of the recursion is split by tile
  * columns; a rank computes its columns and `exchange` hands every rank's part to all the others: part q (bufs[q], counts[q] doubles,
@@ -331,10 +341,20 @@ int dnagpu_junction_gather(dnagpu_ctx* ctx, int chain, uint32_t blk_from, const 
  *     side r = rhs_J - N_JI N_II^-1 rhs_I beside it.  dnagpu_junction_rhs adds  r + S (jest - the receiving block's estimates)  --
  *     what the weighted pseudo-observation "estimates + S^-1 r" of the estimates form contributes, with S^-1 cancelled
  *     analytically: the complement is never factored or inverted (nj^3 flops less per step; for the 450-unknown junctions of
- *     a dnasegment-like cut, half of a chain step).  Such a matrix cannot be exported (dnagpu_matrix_export /
- *     dnagpu_matrix_device_pointers fail): the condensed schedule exchanges condensed blocks, never junction matrices.
+ *     a dnasegment-like cut, half of a chain step).  Such a matrix travels by dnagpu_junction_export / _import /
+ *     _device_pointers (dnagpu_matrix_export and dnagpu_matrix_device_pointers, which know nothing of its right-hand side, refuse it).
  * The block's estimates and corrections are NOT updated.  DNAGPU_ENOTPOSDEF like dnagpu_invert. */
 int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm);
+/* The carry of a chain step whose system does not change between iterations (GNSS-only network, a.reuse_factors): the same elimination,
+ * information form only, with its factor KEPT in `keep` (a light factor with storage of its own: dnagpu_partial_create_spine(...,
+ * store = NULL, ...) for the step's n and k).  In every later iteration dnagpu_schur_carry_rhs takes the step's right-hand side
+ * (rhs(blk) as left by dnagpu_block_load_reduced / dnagpu_junction_rhs) through the kept factor by blocked substitution: jm's reduced
+ * right-hand side and linearisation point are renewed, its matrix (the complement S) stays -- no factorisation, HBM-bound.
+ * Replaces the repeated Solve() + CarryStnEstimatesandVariances* of dnaadjust.cpp:2812 / 998-1281 for iterations >= 2, the way the
+ * reference itself skips the inverse after iteration 1 in simultaneous mode (dnaadjust.cpp:2452-2457). */
+int dnagpu_schur_carry_keep(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm,
+                            dnagpu_partial* keep);
+int dnagpu_schur_carry_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm, const dnagpu_partial* keep);
 /* The same elimination as a stand-alone step: red (order 3k) <- Schur complement of all other unknowns of m onto the k
  * listed stations (list order), red's attached vector <- the reduced right-hand side.  With the stations a block shares
  * with its neighbours as the list, this condenses the block to its junction stations ONCE per iteration, independently of
@@ -409,10 +429,11 @@ int dnagpu_partial_finish(dnagpu_ctx* ctx, int chain, dnagpu_partial* pf, dnagpu
 /* After a completion the factor of the eliminated part is still there.  When the block's normals do not change between
  * iterations (GNSS-only network), the reduced right-hand side of the next iteration is  rhs_K - L_KI (L_II^-1 rhs_I) : two
  * matrix-vector products with the kept X = L_II^-1 and the kept panel instead of a new elimination.  red's vector <- that; red's
- * matrix (the Schur complement) is left as it is. */
+ * matrix (the Schur complement) is left as it is.  A light factor (dnagpu_partial_create_spine) serves from its reduce on, completed
+ * (dnagpu_partial_complete_factor) or not, until dnagpu_partial_finish: the forward half of dnagpu_partial_solve's substitution. */
 int dnagpu_partial_reduce_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_partial* pf, dnagpu_matrix* red);
-/* Start a chain step on a condensed block: m <- red, rhs(rblk) <- red's vector, estimated(rblk) <- original(src_blk)[idx_keep].
- * rblk: a block created with k stations and no measurements. */
+/* Start a chain step on a condensed block: m <- red (m = NULL: not needed, the step's factor is kept), rhs(rblk) <- red's vector,
+ * estimated(rblk) <- original(src_blk)[idx_keep].  rblk: a block created with k stations and no measurements. */
 int dnagpu_block_load_reduced(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k,
                               const dnagpu_matrix* red, dnagpu_matrix* m);
 /* dst[idx,idx] += jm (3x3 blocks), and rhs_extra of blk_to gets the pseudo

@@ -17,6 +17,9 @@ WORKLOADS = {
     # bench.py's `smallblocks`: the same 100 000 stations cut the way dnasegment's defaults would -- strips of 1 ... 10 rows of 150 stations,
     # 120 blocks of n = 900 ... 4 950 -- whole: 1 074 Solve() calls, 4.4e13 flops, a minute on the CPU
     "smallblocks": (668, 150, 266666, 1, True, {"rows_lo": 1, "rows_hi": 10}),
+    # bench.py's `dnasegment150`: dnasegment's DEFAULT block size (150 stations per block, include/config/dnaoptions.hpp:382): 667 blocks of
+    # 150 inner + 50 junction stations, n = 600 -- whole on the CPU in under a minute
+    "dnasegment150": (2000, 50, 266666, 1, True, {"rows_lo": 3, "rows_hi": 3}),
 }
 
 

@@ -149,6 +149,28 @@ def test_multiple_networks_and_isolated_blocks(built, orc, tmp_path):
     o.close()
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_random_segmentations_against_the_oracle(built, orc, tmp_path, seed):
+    """20 seeded block graphs that the strip generator cannot make (tests/segfuzz.py, tests/test_oracle_adjust.py::_fuzzed_project): junction
+    stations that stay junction over 2 ... 5 and more blocks (dnasegment.cpp:529-531), uneven junction sets, blocks without measurements of
+    their own, two network ids plus an isolated block (seg_file.cpp:305-392, dnaadjust.cpp:10449-10474) -- oracle live, device on both
+    schedules (condensed, and the reference's own with a.schur_carry = 0), one and four chains"""
+    from tests.test_oracle_adjust import _fuzzed_project
+    info = _fuzzed_project(tmp_path, seed)
+    net = orc.Network(str(tmp_path / "all"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    assert ost == 0
+    for schur in (True, False):
+        a, st = _device_run(str(tmp_path), "all", True, schur_carry=schur, multi_thread=bool((seed + schur) % 2))
+        _compare(a, st, o, ost)
+        if schur and a.CurrentIteration() >= 2 and a.condensed_schedule():
+            assert a.factor_reuses() > 0              # (GNSS only: iterations >= 2 on the kept factors, persistent junctions included)
+        a.close()
+    o.close()
+
+
 def test_iteration_limit_and_threshold(built, orc, golden_dir, tmp_path):
     a, st = _device_run(golden_dir, "tiny_net", True, max_iterations=1)
     assert st == adjust.ADJUST_MAX_ITERATIONS_EXCEEDED and a.CurrentIteration() == 1
@@ -639,6 +661,43 @@ def test_condensed_reuse_across_iterations(built, orc, tmp_path, mt):
     for b in range(B):
         assert np.abs(x0[b] - x1[b]).max() < 1e-9
         assert np.array_equal(v0[b], v1[b])                     # the very inverse of iteration 1
+
+
+@pytest.mark.parametrize("mt,blocks", [(False, 5), (True, 6)])
+def test_factor_reuse_across_iterations(built, orc, tmp_path, mt, blocks):
+    """a.reuse_factors (default): in a GNSS-only network the normals of an iteration do not depend on the estimates -- the reference's own
+    test in simultaneous mode, SolveTry(CurrentIteration() < 2 || ContainsNonGPS()), dnaadjust.cpp:2452-2457 -- so from the second iteration
+    on every block reduces and solves its right-hand side with the light factor of iteration 1, the chain steps on the condensed blocks take
+    theirs through their kept factors, and nothing is factored again.  Same iterations, corrections and estimates to rounding; the variance
+    matrices come from the same factor bits either way."""
+    adjust.write_synthetic_network(str(tmp_path), "r", 14, 12, 0, blocks, seed=9, x_clusters=20, y_cluster=True, initial_sigma=0.4)
+    runs = []
+    for reuse in (False, True):
+        a, st = _device_run(str(tmp_path), "r", True, multi_thread=mt, reuse_factors=reuse)
+        assert st == 0 and a.CurrentIteration() >= 2
+        a.GenerateStatistics()
+        runs.append((a.CurrentIteration(), a.factor_reuses(), a.chain_step_reuses(), a.algorithmic_flops(),
+                     [a.block_estimates(b) for b in range(a.blockCount())], [a.block_variances_packed(b) for b in range(a.blockCount())],
+                     a.GetChiSquared(), [a.GetIterationCorrection(i + 1) for i in range(a.CurrentIteration())]))
+        if reuse:
+            # a second adjustment on the same object starts over: the kept factors are those of ONE adjustment
+            a.ResetAdjustment()
+            assert a.AdjustNetwork() == 0 and a.CurrentIteration() == runs[-1][0]
+            assert a.factor_reuses() == runs[-1][1] and a.chain_step_reuses() == runs[-1][2]
+            for b in range(a.blockCount()):
+                assert np.array_equal(a.block_estimates(b), runs[-1][4][b])
+        a.close()
+    (it0, f0, c0, fl0, x0, v0, chi0, corr0), (it1, f1, c1, fl1, x1, v1, chi1, corr1) = runs
+    B = len(x0)
+    assert it0 == it1 and f0 == 0 and c0 == 0
+    assert f1 == (it1 - 1) * B                       # every block keeps its factor on this small network
+    assert c1 == (it1 - 1) * (2 * B - 4)             # ... and every chain step that eliminates anything (the two end steps do not)
+    assert fl1 < fl0                                 # one round of factorisations + the variance matrices, not it1 rounds
+    _against_oracle(orc, str(tmp_path / "r"), it1, x1, v1, corr1)
+    assert abs(chi0 - chi1) < 1e-9 * chi0 and np.abs(np.array(corr0) - np.array(corr1)).max() < 1e-10
+    for b in range(B):
+        assert np.abs(x0[b] - x1[b]).max() < 1e-9
+        assert np.abs(v0[b] - v1[b]).max() <= 1e-13 * np.abs(v0[b]).max()
 
 
 def test_phased_block_1_mode(built, orc, tmp_path):

@@ -38,8 +38,13 @@ def test_batched_blocks_have_the_bits_of_unbatched_ones(built, tmp_path, mt, row
     a0.close()
     a1, st1 = _run(str(tmp_path), "b", multi_thread=mt, batch_blocks=16)
     assert st1 == 0 and a1.CurrentIteration() == it0
-    # at least the interior blocks were batched in every phase of every iteration
-    assert a1.batched_block_steps() >= 2 * (2 * it0 + 1)
+    # at least the interior blocks were batched in every phase: condensing and kept-block factorisation once (a.reuse_factors: the later
+    # iterations of this GNSS-only network keep the factors of the first), the variance matrices once
+    assert a1.batched_block_steps() >= 2 * 3 and a1.factor_reuses() == (it0 - 1) * blocks
+    a2, st2 = _run(str(tmp_path), "b", multi_thread=mt, batch_blocks=16, reuse_factors=False)
+    # ... of every iteration when every iteration factors again
+    assert st2 == 0 and a2.batched_block_steps() >= 2 * (2 * it0 + 1) and a2.factor_reuses() == 0
+    a2.close()
     x1, v1, c1 = _results(a1)
     assert c0 == c1
     for b in range(blocks):

@@ -108,6 +108,30 @@ def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt
     o.close()
 
 
+@pytest.mark.parametrize("ranks,mt", [(2, False), (3, True)])
+def test_block_level_chains_by_elimination_across_ranks(built, orc, tmp_path, monkeypatch, ranks, mt):
+    """a.schur_carry on a segmentation that does not fit the condensed schedule (forced: DNAGPU_FORCE_BLOCK_CHAINS): the chains run on the
+    blocks themselves, every carry-only step by elimination -- junction matrices in dnagpu_schur_carry's information form (matrix,
+    linearisation point AND reduced right-hand side) -- and DistributedReferenceIteration sends them to the ranks that combine.  Round 4's
+    exchange knew the estimates form only: nothing was sent and the owner combined with stale junctions."""
+    adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 6, seed=10)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    monkeypatch.setenv("DNAGPU_FORCE_BLOCK_CHAINS", "1")
+    a = _run(str(tmp_path), "n", devices=[0] * ranks, dist_transport="local", schur_carry=True, multi_thread=mt)
+    st = a.AdjustNetworkDistributed()
+    assert not a.condensed_schedule() and a.elimination_count() > 0
+    assert st == ost and a.CurrentIteration() == o.iterations()
+    for i in range(o.iterations()):
+        assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < TOL_X
+    for k in range(6):
+        assert np.abs(a.block_estimates(k) - o.block_estimates(k)).max() < TOL_X
+        vo = o.block_variances(k)
+        assert np.abs(a.block_variances_packed(k) - vo).max() / np.abs(vo).max() < TOL_V
+    assert a.exchange_stats()["bytes"] > 0
+    a.close()
+    o.close()
+
+
 @pytest.mark.parametrize("ranks,blocks,mt", [(2, 6, False), (3, 8, True), (4, 8, True), (4, 4, False), (5, 9, True)])
 def test_two_level_chains(built, orc, tmp_path, ranks, blocks, mt):
     """a.dist_two_level: every rank condenses its own run of blocks to the run's end stations, the run systems are exchanged

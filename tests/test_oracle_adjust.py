@@ -71,6 +71,48 @@ def test_uneven_segmentations_are_rigorous(orc, built, tmp_path, kw):
     _phased_vs_simultaneous(orc, str(tmp_path / "u"))
 
 
+def _fuzzed_project(tmp_path, seed):
+    """one randomly cut network (persistent junctions, a last block without measurements of its own), a second one with another cut, and
+    an isolated single-block network, merged into one project with three network ids (tests/segfuzz.py)"""
+    from dynadjust_amd import adjust
+    from tests import segfuzz
+    rng = np.random.default_rng(1000 + seed)
+    info = []
+    for nm, rows, cols, mean in (("a", int(rng.integers(7, 12)), int(rng.integers(6, 11)), int(rng.integers(4, 14))),
+                                 ("b", int(rng.integers(5, 8)), int(rng.integers(5, 8)), int(rng.integers(3, 9)))):
+        adjust.write_synthetic_network(str(tmp_path), nm, rows, cols, 0, 1, seed=seed * 7 + ord(nm), initial_sigma=0.2)
+        info.append(segfuzz.write_cut(str(tmp_path / nm), rng, mean_block=mean, noise=float(rng.uniform(0.1, 0.6)), lone_last=bool(seed % 2)))
+    adjust.write_synthetic_network(str(tmp_path), "c", 4, 4, 0, 1, seed=seed + 3)
+    F.merge_networks([str(tmp_path / nm) for nm in "abc"], str(tmp_path / "all"))
+    return info
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_segmentations_are_rigorous(orc, built, tmp_path, seed):
+    """dnasegment-like cuts that the strip generator cannot make (tests/segfuzz.py): junction stations that STAY junction over several
+    blocks (dnasegment.cpp:529-531), junction sets of uneven size, blocks without a measurement of their own, two contiguous networks and
+    an isolated block in one project (dnaadjust.cpp:10449-10474) -- every network of the phased result equals its own simultaneous solution"""
+    info = _fuzzed_project(tmp_path, seed)
+    assert info[0]["max_junction_life"] >= 2 and info[0]["blocks"] >= 4
+    net, p, st = _run(orc, str(tmp_path / "all"), True)
+    assert st == 0 and p.n_blocks == info[0]["blocks"] + info[1]["blocks"] + 1
+    off = b0 = 0
+    for nm, blk in (("a", info[0]["blocks"]), ("b", info[1]["blocks"]), ("c", 1)):
+        ns, s, st_s = _run(orc, str(tmp_path / nm), False)
+        xs = s.block_estimates(0).reshape(-1, 3)
+        Vs = unpack_lower(s.block_variances(0), 3 * ns.n_stations)
+        for b in range(b0, b0 + blk):
+            stn = p.block_stations(b) - off
+            assert np.abs(p.block_estimates(b).reshape(-1, 3) - xs[stn]).max() < 5e-9
+            idx = (3 * stn[:, None] + np.arange(3)).ravel()
+            Vb = unpack_lower(p.block_variances(b), 3 * len(stn))
+            assert np.abs(Vb - Vs[np.ix_(idx, idx)]).max() / np.abs(Vs).max() < 1e-9
+        off += ns.n_stations
+        b0 += blk
+        s.close()
+    p.close()
+
+
 def test_adjustment_recovers_the_truth(orc, built, tmp_path):
     """corner stations constrained at their true coordinates: the adjusted network must sit on the truth
     within the noise of the observations (3-6 mm per baseline component)"""
