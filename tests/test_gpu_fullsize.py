@@ -48,13 +48,15 @@ def _record(path, rec):
         pass
 
 
-@pytest.mark.parametrize("workload", ["cfg3q", "cfg4q", "smallblocks", "cfg3"])
+@pytest.mark.parametrize("workload", ["cfg3q", "cfg4q", "smallblocks", "dnasegment150", "cfg3"])
 def test_against_the_oracle_record(built, golden_dir, tmp_path, workload):
     """the device path (condensed schedule, kept factors, four chains) against the committed record of the CPU oracle's run of the
     same network: cfg3q = four of cfg3's sixteen strips at cfg3's block size (n ~ 20 000: the oracle's run fits a 64 GB host),
     cfg3 = the whole of it (when its record has been made: ~80 GB and 7.4e14 flops on the CPU); cfg4q = four of cfg4's 128 strips at cfg4's
     block geometry (n ~ 27 000 with junction rows of 1 000 stations: J = 3 000, condensed blocks of 6 000 unknowns; 30 Solve() calls);
-    smallblocks = bench.py's dnasegment-like cut of 100 200 stations into 120 blocks of n = 900 ... 4 950, whole (bucketed batches)"""
+    smallblocks = bench.py's dnasegment-like cut of 100 200 stations into 120 blocks of n = 900 ... 4 950, whole (bucketed batches);
+    dnasegment150 = the reference's DEFAULT block size (150 stations per block, dnaoptions.hpp:382; dnasegment.cpp:594-596): 100 000 stations
+    in 666 blocks of n = 600, whole, four iterations"""
     path = os.path.join(golden_dir, f"{workload}_oracle.npz")
     if not os.path.exists(path):
         assert workload != "cfg3q", "tests/golden/cfg3q_oracle.npz is missing: python tools/make_fullsize_golden.py cfg3q"
