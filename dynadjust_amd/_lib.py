@@ -165,6 +165,7 @@ def load():
     _sig(lib, "dnagpu_junction_export", i, [vp, i, vp, vp, sz])
     _sig(lib, "dnagpu_junction_import", i, [vp, i, vp, vp, u32])
     _sig(lib, "dnagpu_junction_device_pointers", i, [vp, vp, i, vp, vp, vp, vp, vp])
+    _sig(lib, "dnagpu_chain_step_rhs", i, [vp, i, u32, u32, c_u32p, sz, vp, vp, c_u32p, sz, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_schur_carry_keep", i, [vp, i, u32, vp, c_u32p, sz, vp, vp])
     _sig(lib, "dnagpu_schur_carry_rhs", i, [vp, i, u32, c_u32p, sz, vp, vp])
     _sig(lib, "dnagpu_block_reduce", i, [vp, i, u32, vp, c_u32p, sz, vp, vp])
@@ -324,7 +325,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_get_b", "dnagpu_block_get_weights", "dnagpu_block_msr_statistics", "dnagpu_block_set_station_geo", "dnagpu_block_set_terrestrial",
     "dnagpu_block_set_direction_sets", "dnagpu_block_update_geodetic", "dnagpu_block_get_station_llh", "dnagpu_block_get_terrestrial", "dnagpu_block_terrestrial_precisions", "dnagpu_form_normals", "dnagpu_add_diag3x3", "dnagpu_form_rhs",
     "dnagpu_solve_corrections", "dnagpu_update_estimates", "dnagpu_block_get_corrections", "dnagpu_block_get_rhs",
-    "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_schur_carry_keep", "dnagpu_schur_carry_rhs", "dnagpu_junction_export", "dnagpu_junction_import", "dnagpu_junction_device_pointers", "dnagpu_block_reduce", "dnagpu_block_form_reduce", "dnagpu_batch_reserve", "dnagpu_block_form_reduce_batched", "dnagpu_partial_complete_factor_batched", "dnagpu_partial_finish_batched", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_create_spine", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
+    "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_schur_carry_keep", "dnagpu_schur_carry_rhs", "dnagpu_chain_step_rhs", "dnagpu_junction_export", "dnagpu_junction_import", "dnagpu_junction_device_pointers", "dnagpu_block_reduce", "dnagpu_block_form_reduce", "dnagpu_batch_reserve", "dnagpu_block_form_reduce_batched", "dnagpu_partial_complete_factor_batched", "dnagpu_partial_finish_batched", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_create_spine", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
 ]

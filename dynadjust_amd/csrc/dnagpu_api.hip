@@ -8,6 +8,7 @@
 #include <new>
 #include <vector>
 #include "adjust_kernels.h"
+#include "small_steps.h"
 #include "ctx.h"
 #include "la_kernels.h"
 #include "terrestrial.h"
@@ -179,7 +180,9 @@ void free_index_cache(dnagpu_ctx* ctx, int chain) {
 // stream synchronisation -- 4 - 5 per chain step of ~1.8 ms -- was a tenth of the chain phase
 int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, uint32_t** dev) {
     static const bool cache_on = !(getenv("DNAGPU_INDEX_CACHE") && atoi(getenv("DNAGPU_INDEX_CACHE")) == 0);     // (diagnostic switch)
-    if (cache_on && count >= 64) {
+    // (round 5: lists from 4 entries on -- a dnasegment-default cut has junction lists of a few dozen stations, and every list that misses
+    //  the cache costs a stream synchronisation in every chain step of every iteration)
+    if (cache_on && count >= 4) {
         uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
         for (size_t i = 0; i < count; ++i) h = (h ^ host[i]) * 1099511628211ull;
         auto& cache = ctx->idx_cache[chain];
@@ -192,7 +195,7 @@ int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, ui
         // a handful of lists per block and chain step: the cap follows the block count (cfg4: 128 blocks + 128 condensed blocks walked by
         // one chain), and a full cache is NOT flushed -- a flush in every iteration would cost more than the staging buffer it replaced --
         // the list at hand simply takes the staging buffer below
-        const size_t cap = std::max<size_t>(512, 16 * ctx->blocks.size());
+        const size_t cap = std::max<size_t>(512, 24 * ctx->blocks.size());
         uint32_t* d = nullptr;
         hipError_t e = cache.size() >= cap ? hipErrorOutOfMemory : dnagpu::poison_malloc(&d, count * sizeof(uint32_t));
         if (e == hipSuccess) {
@@ -2099,7 +2102,54 @@ int dnagpu_schur_carry_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint3
     spine_forward(ctx, chain, keep, rp);
     HIPCHK(hipMemcpyAsync(jm->jrhs, rp + keep->nip, (size_t)keep->nj * sizeof(double), hipMemcpyDeviceToDevice, st));
     launch_gather_vec3(b->x_est[chain], didx, (uint32_t)k, jm->jest, st);
-    HIPCHK(hipStreamSynchronize(st));
+    // (stream ordered, no wait: the next step of this chain follows on the same stream, other chains read jm after the chains' phase has
+    //  been synchronised)
+    return DNAGPU_OK;
+}
+
+int dnagpu_chain_step_rhs(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k_keep, const dnagpu_matrix* red,
+                          const dnagpu_matrix* jm_in, const uint32_t* idx_in, size_t k_in, dnagpu_matrix* jm_out, const uint32_t* idx_out, size_t k_out,
+                          const dnagpu_partial* keep) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* rb = find_block(ctx, rblk);
+    Block* sb = find_block(ctx, src_blk);
+    if (!rb || !sb || !red || !idx_keep || rb->n_stn != k_keep || red->n != 3 * k_keep || !jm_out || !idx_out || !k_out || !keep || !keep->spine ||
+        !keep->valid || keep->n != 3 * rb->n_stn || keep->nj != 3 * k_out || jm_out->n != 3 * k_out || jm_out->form != 1 || !jm_out->jrhs ||
+        (jm_in && (!idx_in || jm_in->n != 3 * k_in || jm_in->form != 1 || !jm_in->jrhs)))
+        return fail(ctx, DNAGPU_EINVAL, "chain_step_rhs: bad arguments");
+    const std::vector<std::pair<int, int>> blocks = sym_spine_blocks((int)(keep->nip / 128));
+    if (keep->npp > SMALL_STEP_MAX || 3 * k_keep > SMALL_STEP_MAX || (jm_in && 3 * k_in > SMALL_STEP_MAX) || blocks.size() > (size_t)SMALL_STEP_BLOCKS)
+        return DNAGPU_ETOOLARGE;        // (not an error: the caller takes the step through the separate calls)
+    for (size_t i = 0; i < k_keep; ++i)
+        if (idx_keep[i] >= sb->n_stn) return fail(ctx, DNAGPU_EINVAL, "chain_step_rhs: station out of range");
+    for (size_t i = 0; i < k_out; ++i)
+        if (idx_out[i] >= rb->n_stn) return fail(ctx, DNAGPU_EINVAL, "chain_step_rhs: station out of range");
+    for (size_t i = 0; jm_in && i < k_in; ++i)
+        if (idx_in[i] >= rb->n_stn) return fail(ctx, DNAGPU_EINVAL, "chain_step_rhs: station out of range");
+    ChainRhsStep a{};
+    uint32_t *dkeep = nullptr, *din = nullptr, *dout = nullptr;
+    int rc = stage_u32(ctx, chain, idx_keep, k_keep, &dkeep);
+    if (!rc) rc = stage_u32(ctx, chain, idx_out, k_out, &dout);
+    if (!rc && jm_in) rc = stage_u32(ctx, chain, idx_in, k_in, &din);
+    if (rc) return rc;
+    // (three lists through ONE staging buffer would overwrite each other: all of them must have come from the cache)
+    if (dkeep == ctx->scr_u32[chain] || dout == ctx->scr_u32[chain] || (jm_in && din == ctx->scr_u32[chain])) return DNAGPU_ETOOLARGE;
+    gemm_profile_close(ctx->ws[chain]);
+    a.red_rhs = red->jest; a.x_orig_src = sb->x_orig; a.keep_idx = dkeep; a.n_stn = rb->n_stn;
+    a.rhs = rb->rhs[chain]; a.x_est = rb->x_est[chain];
+    if (jm_in) {
+        a.J = jm_in->F; a.npj = jm_in->np; a.jest_in = jm_in->jest; a.jrhs_in = jm_in->jrhs; a.idx_in = din; a.k_in = (uint32_t)k_in;
+    }
+    a.X = keep->X; a.map = keep->map; a.npp = keep->npp; a.nip = keep->nip; a.nj = keep->nj;
+    a.nblocks = (int)blocks.size();
+    for (size_t q = 0; q < blocks.size(); ++q) {
+        a.blk_o[q] = (uint32_t)blocks[q].first * 128;
+        a.blk_h[q] = (uint32_t)blocks[q].second * 128;
+    }
+    a.jrhs_out = jm_out->jrhs; a.jest_out = jm_out->jest; a.idx_out = dout; a.k_out = (uint32_t)k_out;
+    launch_chain_rhs_step(a, ctx->stream[chain]);
+    HIPCHK(hipGetLastError());
     return DNAGPU_OK;
 }
 
@@ -2339,7 +2389,8 @@ int dnagpu_partial_reduce_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const dn
         launch_gather_map(b->rhs[chain], pf->map, pf->npp, rp, st);
         spine_forward(ctx, chain, pf, rp);
         HIPCHK(hipMemcpyAsync(red->jest, rp + pf->nip, (size_t)pf->nj * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
+        // (stream ordered, no wait: nothing here can fail on the device, and whoever reads red on another chain does so after the
+        //  phase's chains have been synchronised -- dna_adjust::OnEveryChain)
         return DNAGPU_OK;
     }
     double* y = b->corr[chain];           // L_II^-1 rhs_I (n_i <= 3 n_stn values)

@@ -947,24 +947,27 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
     // across GPUs with the condensed schedule a rank forms and solves its own blocks only (the chains run on condensed blocks,
     // whose right-hand sides arrive with them)
     const bool own_only = Distributed() && CondensedSchedule() && DistWorld() > 1;
-    for (UINT32 b = 0; b < blockCount_; ++b) {
-        if (IsCancelled()) break;
-        if (own_only && !OwnsBlock(b)) continue;
-        if (phased && v_blockMeta_[b]._blockLast) {
-            // estimated = original = rigorous (ADJ:516-517)
-            for (int c = 0; c < chains; ++c) Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
-            Check(dnagpu_block_copy_stations(ctx_, 0, b, 0, 2), b, "UpdateAdjustment()");
-        }
-        // every chain restarts from the rigorous estimates of the iteration just finished (multi-thread mode:
-        // v_estimatedStationsR_ = v_rigorousStations_ ADJ:569; v_estimatedStations_ = v_estimatedStationsR_ ADJ:3799)
-        for (int c = 0; c < chains; ++c) {
+    // every chain has its own estimates and meas-minus-computed of every block (any chain may take any block step): each chain's host thread
+    // renews its own (a dnasegment-default cut has hundreds of blocks: eight launches per block from ONE thread were 19 ms per iteration)
+    auto per_chain = [&](int c) {
+        for (UINT32 b = 0; b < blockCount_; ++b) {
+            if (IsCancelled()) break;
+            if (own_only && !OwnsBlock(b)) continue;
+            // a last block: estimated = original = rigorous (ADJ:516-517)
+            if (phased && v_blockMeta_[b]._blockLast && c == 0) Check(dnagpu_block_copy_stations(ctx_, 0, b, 0, 2), b, "UpdateAdjustment()");
+            // every chain restarts from the rigorous estimates of the iteration just finished (multi-thread mode:
+            // v_estimatedStationsR_ = v_rigorousStations_ ADJ:569; v_estimatedStations_ = v_estimatedStationsR_ ADJ:3799)
             if (phased) Check(dnagpu_block_copy_stations(ctx_, c, b, 1, 2), b, "UpdateAdjustment()");
             // non-GPS networks: the station records follow the estimates, the design of the next iteration is formed
             // in their local frames (UpdateGeographicCoords[Phased], ADJ:496-531, ADJ:541-545)
             if (containsNonGPS_) Check(dnagpu_block_update_geodetic(ctx_, c, b), b, "UpdateGeographicCoords()");
             Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
         }
-    }
+    };
+    if (chains > 1 && blockCount_ >= 32)
+        OnEveryChain(per_chain);
+    else
+        for (int c = 0; c < chains; ++c) per_chain(c);
     // Everything above was enqueued chain by chain; what follows reads across chains -- the reverse thread's chain takes the last block's
     // originals that chain 0 has just set, any chain the estimates another one restored.  The chains meet here, once per iteration
     // (found in round 3: under host load the reverse pass of the reference's multi-thread schedule started from the last block's

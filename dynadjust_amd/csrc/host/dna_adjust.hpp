@@ -462,6 +462,8 @@ private:
     std::atomic<uint64_t> factor_reuses_{0}, chain_reuses_{0};    // block steps / chain steps served from a kept factor since AdjustNetwork() began
     // a chain step on the condensed block of k: elimination with the factor kept (first time) or its right-hand side through the kept factor
     void CarryCondensed(int chain, UINT32 dev_block, UINT32 block, int dir, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm);
+    bool StepRhsInOneLaunch(int chain, UINT32 dev_block, UINT32 block, int dir, const dnagpu_matrix* jm_in, const std::vector<UINT32>& idx_in,
+                            dnagpu_matrix* jm_out, const std::vector<UINT32>& idx_out);
 public:
     uint64_t FactorReuses() const { return factor_reuses_.load(); }
     uint64_t ChainStepReuses() const { return chain_reuses_.load(); }

@@ -1234,6 +1234,7 @@ void dna_adjust::CondensedForwardBlock(int c, UINT32 k) {
     const UINT32 cb = blockCount_ + k;
     // a.reuse_factors: the step's system is the one an earlier iteration factored -- only its right-hand side is put together
     const bool rhs_only = B.cfac[0] && B.cfac_live[0] && FactorReuse();
+    if (rhs_only && StepRhsInOneLaunch(c, cb, k, 0, carried_in ? blocks_[k - 1].jfwd : nullptr, B.c_prev, B.jfwd, B.c_next)) return;
     Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, rhs_only ? nullptr : W), k, "UpdateNormals()");
     if (!rhs_only) AddConstraints(c, W, B.ccon_fwd, +1, k);
     if (carried_in) {
@@ -1253,12 +1254,34 @@ void dna_adjust::CondensedReverseBlock(int c, UINT32 k) {
     dnagpu_matrix* W = work_[c];
     const UINT32 cb = blockCount_ + k;
     const bool rhs_only = B.cfac[1] && B.cfac_live[1] && FactorReuse();
+    if (rhs_only && StepRhsInOneLaunch(c, cb, k, 1, rev_in ? B.jrev : nullptr, B.c_next, blocks_[k - 1].jrev, B.c_prev)) return;
     Check(dnagpu_block_load_reduced(ctx_, c, cb, k, B.keep.data(), B.keep.size(), B.red, rhs_only ? nullptr : W), k, "UpdateNormals()");
     if (rev_in && !rhs_only)
         Check(dnagpu_junction_scatter(ctx_, c, W, B.c_next.data(), B.c_next.size(), B.jrev), k, "CarryStnEstimatesandVariancesReverse()");
     if (!rhs_only) AddConstraints(c, W, B.ccon_rev, +1, k);
     if (rev_in) Check(dnagpu_junction_rhs(ctx_, c, cb, B.c_next.data(), B.c_next.size(), B.jrev), k, "Solve()");
     CarryCondensed(c, cb, k, 1, W, B.c_prev, blocks_[k - 1].jrev);
+}
+
+// A right-hand-side-only chain step (a.reuse_factors, iterations >= 2) on a small condensed system as ONE launch (dnagpu_chain_step_rhs):
+// true when it went out that way; false (nothing done) when the system is beyond that entry point's limits -- the caller takes the
+// separate calls.  The counters are those of CarryCondensed's reuse branch.
+bool dna_adjust::StepRhsInOneLaunch(int c, UINT32 dev_block, UINT32 k, int dir, const dnagpu_matrix* jm_in, const std::vector<UINT32>& idx_in,
+                                    dnagpu_matrix* jm_out, const std::vector<UINT32>& idx_out) {
+    static const bool off = getenv("DNAGPU_SMALL_STEPS") && atoi(getenv("DNAGPU_SMALL_STEPS")) == 0;
+    block_t& B = blocks_[k];
+    if (off || !dnagpu_info_carry() || idx_out.size() >= B.keep.size()) return false;
+    const int rc = dnagpu_chain_step_rhs(ctx_, c, dev_block, k, B.keep.data(), B.keep.size(), B.red, jm_in, idx_in.data(), jm_in ? idx_in.size() : 0, jm_out,
+                                         idx_out.data(), idx_out.size(), B.cfac[dir]);
+    if (rc == DNAGPU_ETOOLARGE) return false;
+    Check(rc, k, "Solve()");
+    const double nref = 3.0 * (double)v_parameterStationList_[k].size();
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    solve_flops_ += nref * nref * nref;
+    solve_count_++;
+    elimination_count_++;
+    chain_reuses_++;
+    return true;
 }
 
 // The carry of a chain step on block k's condensed system (dev_block), direction dir (0 forward, 1 reverse).  With a.reuse_factors the
@@ -1408,8 +1431,11 @@ void dna_adjust::FinishVariancesTransient(int c, UINT32 k) {
 // body(chain) on every chain in use (a.multi_thread: two host threads, one per chain); the first exception is rethrown
 void dna_adjust::OnEveryChain(const std::function<void(int)>& body) {
     const int chains = NumChains();
+    // every chain's stream is drained when its part of the phase ends: steps that do not have to wait for the device themselves (a.reuse_factors:
+    // right-hand sides through kept factors) leave their work queued, and the next phase reads across chains
     if (chains == 1) {
         body(0);
+        Check(dnagpu_chain_sync(ctx_, 0), 0, "AdjustNetwork()");
         return;
     }
     std::mutex m;
@@ -1417,6 +1443,7 @@ void dna_adjust::OnEveryChain(const std::function<void(int)>& body) {
     auto guarded = [&](int c) {
         try {
             body(c);
+            Check(dnagpu_chain_sync(ctx_, c), 0, "AdjustNetwork()");
         } catch (...) {
             std::lock_guard<std::mutex> lk(m);
             if (!error) error = std::current_exception();

@@ -54,6 +54,7 @@ typedef struct dnagpu_ctx dnagpu_ctx;
 #define DNAGPU_EHIP (-3)
 #define DNAGPU_ENOTPOSDEF (-4) /* dpotrf-style failure; column in dnagpu_last_info() */
 #define DNAGPU_ENODEVICE (-5)
+#define DNAGPU_ETOOLARGE (-6) /* a small-system entry point given a system beyond its limits: take the general calls (no error text) */
 
 #define DNAGPU_NUM_CHAINS 8        /* chains a context provides */
 #define DNAGPU_DEFAULT_CHAINS 4    /* chains the facade uses by itself (DNAGPU_CHAINS = 2 .. DNAGPU_NUM_CHAINS overrides) */
@@ -355,6 +356,15 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
 int dnagpu_schur_carry_keep(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* m, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm,
                             dnagpu_partial* keep);
 int dnagpu_schur_carry_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint32_t* idx_out, size_t k, dnagpu_matrix* jm, const dnagpu_partial* keep);
+/* A whole chain step of that kind on a SMALL condensed system as ONE launch (small_steps.hip): dnagpu_block_load_reduced(rblk, src_blk,
+ * idx_keep, red, m = NULL) + dnagpu_junction_rhs(rblk, idx_in, jm_in) (jm_in = NULL: no junction carried in) + dnagpu_schur_carry_rhs(rblk,
+ * idx_out, jm_out, keep) -- vectors in LDS, the kept factor streamed once, nothing waits for the host.  Both junctions in information
+ * form.  DNAGPU_ETOOLARGE (and nothing done) when the padded system or the junction carried in exceeds 2 048 unknowns or an index list
+ * could not be cached: the caller then issues the three calls.  dnasegment's default cut (150 stations per block, dnaoptions.hpp:382:
+ * condensed systems of a few hundred unknowns, hundreds of steps in a row) is what this is for. */
+int dnagpu_chain_step_rhs(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k_keep, const dnagpu_matrix* red,
+                          const dnagpu_matrix* jm_in, const uint32_t* idx_in, size_t k_in, dnagpu_matrix* jm_out, const uint32_t* idx_out, size_t k_out,
+                          const dnagpu_partial* keep);
 /* The same elimination as a stand-alone step: red (order 3k) <- Schur complement of all other unknowns of m onto the k
  * listed stations (list order), red's attached vector <- the reduced right-hand side.  With the stations a block shares
  * with its neighbours as the list, this condenses the block to its junction stations ONCE per iteration, independently of

@@ -76,3 +76,90 @@ def solve(net, fixed_std_dev=1e-6, free_std_dev=10.0, threshold=float(np.float32
         if float(np.abs(dx).max()) <= threshold:
             break
     return x, (_inverse(N) if variances else None), its
+
+
+# ---- at size: sparse assembly, blocked factorisation (tools/make_exact_golden.py -> tests/golden/exact_3k.npz) ---------------------------
+def _chol_blocked(N, nb=96):
+    """lower Cholesky factor of N (longdouble), right-looking by panels of nb columns: the panel by the column algorithm above, the
+    trailing update as one matrix product per panel"""
+    n = N.shape[0]
+    L = np.array(N, dtype=LD)
+    for o in range(0, n, nb):
+        e = min(n, o + nb)
+        for j in range(o, e):
+            d = np.sqrt(L[j, j])
+            L[j:, j] /= d
+            if j + 1 < e:
+                L[j + 1:, j + 1:e] -= np.outer(L[j + 1:, j], L[j + 1:e, j])
+        if e < n:
+            P = L[e:, o:e]
+            L[e:, e:] -= P @ P.T
+    return np.tril(L)
+
+
+def _tri_inverse_blocked(L, nb=96):
+    """X = L^-1 for lower triangular L (longdouble), block column by block column"""
+    n = L.shape[0]
+    X = np.zeros((n, n), dtype=LD)
+    for o in range(0, n, nb):
+        e = min(n, o + nb)
+        D = L[o:e, o:e]
+        Xd = np.zeros((e - o, e - o), dtype=LD)
+        for j in range(e - o):                  # D Xd = I by forward substitution, column by column
+            y = np.zeros(e - o, dtype=LD)
+            y[j] = LD(1)
+            for i in range(j, e - o):
+                y[i] = (y[i] - np.dot(D[i, j:i], y[j:i])) / D[i, i]
+            Xd[:, j] = y
+        X[o:e, o:e] = Xd
+    # below the diagonal blocks: X[i, j] = -X[i, i] * sum_{j <= k < i} L[i, k] X[k, j], block row by block row
+    for o in range(0, n, nb):
+        e = min(n, o + nb)
+        if o:
+            X[o:e, :o] = -(X[o:e, o:e] @ (L[o:e, :o] @ X[:o, :o]))
+    return X
+
+
+def solve_sparse(net, fixed_std_dev=1e-6, free_std_dev=10.0, threshold=float(np.float32(0.0005)), max_iterations=10):
+    """the same solution as solve() for networks of thousands of unknowns: the normals are assembled block by block from the baselines (no
+    dense design matrix), factored by panels.  Single 'G' baselines and CCC / FFF constraints.  Iterated like AdjustSimultaneous (the station
+    constraints weight the normals only, so the iteration count is part of the answer).  Returns (x, N^-1, iterations) in longdouble."""
+    assert net.n_clusters == 0
+    n = 3 * net.n_stations
+    N = np.zeros((n, n), dtype=LD)
+    Wb = []
+    for i in range(net.n_baselines):
+        v = np.array(net.vcv6[6 * i:6 * i + 6], dtype=LD)
+        V = np.array([[v[0], v[1], v[3]], [v[1], v[2], v[4]], [v[3], v[4], v[5]]], dtype=LD)
+        W = _inverse(V)
+        Wb.append(W)
+        a, b = 3 * int(net.stn1[i]), 3 * int(net.stn2[i])
+        N[a:a + 3, a:a + 3] += W
+        N[b:b + 3, b:b + 3] += W
+        N[a:a + 3, b:b + 3] -= W
+        N[b:b + 3, a:a + 3] -= W
+    for s in range(net.n_stations):
+        cst = net.constraints[3 * s:3 * s + 3]
+        assert cst in (b"CCC", b"FFF")
+        sd = LD(fixed_std_dev) if cst == b"CCC" else LD(free_std_dev)
+        N[3 * s:3 * s + 3, 3 * s:3 * s + 3] += np.eye(3, dtype=LD) / (sd * sd)
+    L = _chol_blocked(N)
+    X = _tri_inverse_blocked(L)
+    Ninv = X.T @ X
+    x = np.array(net.xyz0, dtype=LD)
+    obs = np.array(net.obs, dtype=LD).reshape(-1, 3)
+    its = 0
+    for _ in range(max_iterations):
+        its += 1
+        r = np.zeros(n, dtype=LD)
+        xs = x.reshape(-1, 3)
+        for i in range(net.n_baselines):
+            a, b = int(net.stn1[i]), int(net.stn2[i])
+            wb = Wb[i] @ (obs[i] - (xs[b] - xs[a]))
+            r[3 * b:3 * b + 3] += wb
+            r[3 * a:3 * a + 3] -= wb
+        dx = Ninv @ r
+        x = x + dx
+        if float(np.abs(dx).max()) <= threshold:
+            break
+    return x, Ninv, its

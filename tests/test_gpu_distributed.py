@@ -289,7 +289,9 @@ def test_a_cancellation_is_agreed_across_the_ranks(built, orc, tmp_path, schur, 
     import threading
     import time
     adjust.write_synthetic_network(str(tmp_path), "n", 60, 30, 0, 6, seed=4)
-    a = _run(str(tmp_path), "n", devices=[0, 0, 0], dist_transport="local", schur_carry=schur, max_iterations=10, iteration_threshold=1e-12)
+    # (a.reuse_factors off: with it the iterations after the first take a few milliseconds each and all ten are over before the cancellation arrives)
+    a = _run(str(tmp_path), "n", devices=[0, 0, 0], dist_transport="local", schur_carry=schur, max_iterations=10, iteration_threshold=1e-12,
+             reuse_factors=False)
     res = {}
 
     def run():

@@ -319,6 +319,31 @@ def check_against_reference_report(adj, names, stn, xyz, V, fields, stats):
     assert stats["outliers"] == 10                           # "(10 potential outliers)"
 
 
+def test_oracle_against_the_exact_solution_at_size(orc, built, golden_dir, tmp_path):
+    """the oracle, phased (3 blocks of n = 1 500, junctions of 300 unknowns, 1e12 constraint weights), against the committed extended-precision
+    solution of the same network of n = 3 600 unknowns (tests/golden/exact_3k.npz, tools/make_exact_golden.py; tests/test_gpu_exact.py holds
+    the device to the same record): 1e-8 m, 1e-8 relative -- measured: a few units in the last place of a 4e6 m coordinate"""
+    import json
+    from dynadjust_amd import adjust
+    from tests.test_gpu_exact import compare_with_exact
+    g = np.load(os.path.join(golden_dir, "exact_3k.npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    info = adjust.write_synthetic_network(str(tmp_path), "e", meta["rows"], meta["cols"], 0, meta["blocks"], seed=meta["seed"])
+    assert info["stations"] == meta["stations"]
+    fast = orc.scipy_openblas_path()
+    if fast:
+        orc.use_lapack(fast)
+    try:
+        net, p, st = _run(orc, str(tmp_path / "e"), True, threads=8)
+    finally:
+        orc.use_mkl(False)
+    assert st == 0 and p.iterations() == meta["iterations"]
+    rec = compare_with_exact(g, meta, p.n_blocks, p.block_stations, p.block_estimates, p.block_variances)
+    assert rec["max_abs_dx_m"] < 5e-9 and rec["max_rel_dvar_diagonal"] < 1e-9 and rec["max_rel_dvar_sampled_columns"] < 1e-9, rec
+    assert rec["max_rel_dfrobenius"] < 1e-9 and rec["max_rel_dquadratic_forms"] < 1e-8, rec
+    p.close()
+
+
 @pytest.mark.parametrize("importer", ["product", "test"])
 def test_reference_sample_gnss_network(orc, built, golden_dir, tmp_path, importer):
     """the oracle against the reference's published result for sampleData/gnss-network (129 G, 1 X cluster of 4,
