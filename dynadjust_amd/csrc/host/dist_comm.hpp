@@ -12,6 +12,7 @@
 //          never leaves one GPU needs no RCCL); buffers are device memory and are used in place
 //   local  ranks are threads of this process: device-to-device copies between the ranks' buffers, rendezvous through a
 //          barrier in host memory.  For ranks that share a device (RCCL refuses those) and for tests on a one-GPU box.
+//   shared ranks are PROCESSES without RCCL between them (several on one GPU, or no fabric): host-staged payloads over TCP
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -68,6 +69,13 @@ std::shared_ptr<DistComm> rccl_comm_create(int rank, int world, const unsigned c
 // MASTER_PORT + 17 of the environment (the variables torchrun, Slurm wrappers and MPI launch scripts export).
 void tcp_share_unique_id(int rank, int world, unsigned char id[DIST_UNIQUE_ID_BYTES], const char* addr = nullptr, int port = 0,
                          double timeout_s = 120.0);
+
+// ---- shared (processes without RCCL between them) ------------------------------------------------------------------------------
+// Ranks that are processes sharing ONE GPU (RCCL refuses two ranks on a device) or GPUs without a fabric: payloads staged through host
+// memory, one TCP connection per pair of ranks (the higher rank connects to addr : port + lower rank; addr / port default to MASTER_ADDR /
+// MASTER_PORT + 18 ...), all transfers of a group driven together.  Same deadline and "a rank has gone" behaviour as the other transports.
+// Collective over all ranks (dist_comm_shared.cpp).
+std::shared_ptr<DistComm> shared_comm_create(int rank, int world, int device, const char* addr = nullptr, int port = 0, double timeout_s = 120.0);
 
 // ---- plan (no transport) ---------------------------------------------------------------------------------------------------
 // a communicator that only knows its rank and the world size: what dna_adjust::PlanDistributed prepares against; every exchange throws

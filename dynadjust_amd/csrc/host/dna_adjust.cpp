@@ -798,10 +798,17 @@ void dna_adjust::PrepareAdjustment(const project_settings& projectSettings) {
         // one process per GPU and nobody attached a communicator: RCCL, the unique id from rank 0 over TCP (MASTER_ADDR / MASTER_PORT)
         try {
             const int world = std::max(1, projectSettings_.a.dist_world);
-            unsigned char id[DIST_UNIQUE_ID_BYTES] = {0};
-            if (projectSettings_.a.dist_rank == 0) rccl_unique_id(id);
-            tcp_share_unique_id(projectSettings_.a.dist_rank, world, id);
-            comm_ = rccl_comm_create(projectSettings_.a.dist_rank, world, id, projectSettings_.a.device);
+            std::string transport = projectSettings_.a.dist_transport;
+            if (transport.empty() && getenv("DNAGPU_DIST_TRANSPORT")) transport = getenv("DNAGPU_DIST_TRANSPORT");
+            if (transport == "shared") {
+                // processes that share a GPU (or have no fabric between theirs): host-staged over TCP (dist_comm_shared.cpp)
+                comm_ = shared_comm_create(projectSettings_.a.dist_rank, world, projectSettings_.a.device);
+            } else {
+                unsigned char id[DIST_UNIQUE_ID_BYTES] = {0};
+                if (projectSettings_.a.dist_rank == 0) rccl_unique_id(id);
+                tcp_share_unique_id(projectSettings_.a.dist_rank, world, id);
+                comm_ = rccl_comm_create(projectSettings_.a.dist_rank, world, id, projectSettings_.a.device);
+            }
         } catch (const std::exception& e) {
             SignalExceptionAdjustment(std::string("PrepareAdjustment(): cannot join the other GPUs' processes. Details: ") + e.what(), 0);
         }

@@ -57,7 +57,8 @@ typedef struct {
     int dist_world;            /* ... of dist_world (0 or 1 = single process) */
     int n_devices;             /* one process for several GPUs: how many entries `devices` has (0 or 1 = `device` only) */
     const int* devices;        /* their HIP ordinals */
-    const char* dist_transport;/* NULL = choose; "rccl"; "local" (ranks of one process sharing a GPU) */
+    const char* dist_transport;/* NULL = choose; "rccl"; "local" (ranks of one process sharing a GPU); "shared" (one PROCESS per rank without
+                                  RCCL between them -- several on one GPU, or no fabric: host-staged over TCP, dist_comm_shared.cpp) */
     int dist_two_level;        /* condensed chains across ranks (default 1): 1 = two-level where the blocks are one contiguous network and every
                                   rank owns a run (see dnatypes.hpp; cfg4-sized junction rows: 0.29 s instead of 1.75 s per iteration), 0 = on every rank */
     int defer_variances;       /* condensed schedule with kept factors (default 2): the corrections of an iteration come from every block's

@@ -289,8 +289,9 @@ def test_a_cancellation_is_agreed_across_the_ranks(built, orc, tmp_path, schur, 
     import threading
     import time
     adjust.write_synthetic_network(str(tmp_path), "n", 60, 30, 0, 6, seed=4)
-    # (a.reuse_factors off: with it the iterations after the first take a few milliseconds each and all ten are over before the cancellation arrives)
-    a = _run(str(tmp_path), "n", devices=[0, 0, 0], dist_transport="local", schur_carry=schur, max_iterations=10, iteration_threshold=1e-12,
+    # (thousands of iterations allowed, a.reuse_factors off: an iteration of this small network takes milliseconds -- ten of them were over before
+    #  the cancellation arrived once the per-step waits had gone)
+    a = _run(str(tmp_path), "n", devices=[0, 0, 0], dist_transport="local", schur_carry=schur, max_iterations=5000, iteration_threshold=1e-12,
              reuse_factors=False)
     res = {}
 
@@ -319,6 +320,75 @@ def test_a_cancellation_is_agreed_across_the_ranks(built, orc, tmp_path, schur, 
     assert np.abs(b.block_estimates(2) - o.block_estimates(2)).max() < TOL_X
     b.close()
     o.close()
+
+
+def _spawn_ranks(tmp_path, name, world, env_extra, timeout=300):
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multi_gpu_worker.py")
+    port = 29000 + (os.getpid() % 1000) + 3 * world
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", WORKER_DEVICE="0", WORKER_EXPECT="shared", DNAGPU_DIST_TRANSPORT="shared", **env_extra)
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), name], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail(f"the {world} ranks did not finish within {timeout} s")
+        outs.append(out.decode(errors="replace"))
+    return procs, outs
+
+
+@pytest.mark.parametrize("world,settings", [(2, {}), (3, {"multi_thread": True}), (3, {"schur_carry": False}), (2, {"dist_two_level": False})])
+def test_processes_sharing_the_gpu(built, orc, tmp_path, world, settings):
+    """The C++ driver with one PROCESS per rank on the one GPU there is (a.dist_transport "shared": host-staged over TCP, dist_comm_shared.cpp;
+    RCCL refuses two ranks on a device): the rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT alone, AgreeOnPhase across processes,
+    the two-level chains (and the one-level ones, and the reference's schedule with its junction messages), the statistics' all-reduce, the
+    variance matrices of the other ranks' blocks on their way to rank 0, which writes the result files -- what dnaadjust-multi.cpp:92-244 does
+    between threads, between address spaces.  Against the oracle."""
+    import json
+    adjust.write_synthetic_network(str(tmp_path), "n", 30, 12, 0, 6, seed=10)
+    os.makedirs(tmp_path / "out", exist_ok=True)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    procs, outs = _spawn_ranks(tmp_path, "n", world, {"WORKER_SETTINGS": json.dumps(settings)})
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = np.load(tmp_path / "result.npz")
+    assert int(res["status"]) == ost and int(res["iterations"]) == o.iterations() and int(res["rccl_ranks"]) == 0
+    assert int(res["exchanged_bytes"]) > 0
+    if settings.get("schur_carry", True):
+        assert sorted(set(res["owners"].tolist())) == list(range(world))
+    for k in range(6):
+        assert np.abs(res[f"est_{k}"] - o.block_estimates(k)).max() < TOL_X
+    for (t, r, c, d), k in zip(F.read_mtx(tmp_path / "out" / "n-rva.mtx", 6), range(6)):
+        vo = o.block_variances(k)
+        assert np.abs(d - vo).max() / np.abs(vo).max() < TOL_V          # the other ranks' blocks included: they travelled to rank 0
+    o.close()
+
+
+def test_a_killed_process_cannot_hang_the_others(built, tmp_path):
+    """three processes on the one GPU, ten slow iterations; rank 1 is killed (os._exit) in the middle of the adjustment: the other two must come
+    back with the exception of the transport -- "a rank has gone" -- within seconds, not wait for a collective that never completes
+    (the reference's threads cannot lose each other: dnaadjust-multi.cpp:36-58, 457-463)"""
+    import json
+    import time
+    adjust.write_synthetic_network(str(tmp_path), "n", 120, 40, 0, 6, seed=4)
+    os.makedirs(tmp_path / "out", exist_ok=True)
+    settings = {"max_iterations": 10, "iteration_threshold": 1e-12, "reuse_factors": False}
+    t0 = time.perf_counter()
+    procs, outs = _spawn_ranks(tmp_path, "n", 3, {"WORKER_SETTINGS": json.dumps(settings), "WORKER_DIE_AFTER_S": "0.15", "WORKER_DIE_RANK": "1",
+                                                   "DNAGPU_COLLECTIVE_TIMEOUT_S": "20"}, timeout=120)
+    dt = time.perf_counter() - t0
+    assert procs[1].returncode == 9, outs[1]
+    for r in (0, 2):
+        assert procs[r].returncode == 3, outs[r]
+        assert "a rank has gone" in outs[r] or "another" in outs[r] or "no answer from the other GPUs" in outs[r], outs[r]
+    assert dt < 90.0, dt
+    assert not os.path.exists(tmp_path / "result.npz")
 
 
 @pytest.mark.parametrize("ranks,rows,cols,small_tiles", [(2, 40, 40, None), (3, 18, 17, 4), (4, 24, 22, 16)])
