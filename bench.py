@@ -927,8 +927,6 @@ def main():
         print(f"[bench] warm-up step {time.perf_counter() - t_s:.2f} s", file=sys.stderr, flush=True)
     lib.dnagpu_profile_enable(ctx, 0 if args.no_gemm_events else 1)
     lib.dnagpu_profile_reset(ctx)
-    fl0, fp0 = C.c_uint64(), C.c_uint64()
-    lib.dnagpu_fused_stats(ctx, C.byref(fl0), C.byref(fp0))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -936,8 +934,6 @@ def main():
     lib.dnagpu_sync(ctx)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    fl1, fp1 = C.c_uint64(), C.c_uint64()
-    lib.dnagpu_fused_stats(ctx, C.byref(fl1), C.byref(fp1))
     prof_f, prof_ms, prof_n = C.c_double(), C.c_double(), C.c_uint64()
     lib.dnagpu_profile_get(ctx, C.byref(prof_f), C.byref(prof_ms), C.byref(prof_n))
     lib.dnagpu_profile_enable(ctx, 0)
@@ -1026,11 +1022,7 @@ def main():
             "traffic": traffic_from_profile(args.workload)[0],
             "traffic_source": traffic_from_profile(args.workload)[1],
             "traffic_unit": "bytes per launch (memory-side, FETCH_SIZE x 2 + WRITE_SIZE from the committed rocprofv3 --pmc passes of this workload)",
-            # tile-GEMM products per step; of them `fused_products_per_step` went out in `fused_launches_per_step` launches of the
-            # persistent kernel (runs of dependent small products, device-wide barriers in between) instead of one launch each
-            "launches_per_step": prof_n.value / args.steps,
-            "fused_products_per_step": (fp1.value - fp0.value) / args.steps,
-            "fused_launches_per_step": (fl1.value - fl0.value) / args.steps,
+            "launches_per_step": prof_n.value / args.steps,       # tile-GEMM products per step
             "gemm_ms_per_step": gemm_ms_per_step,
             "issued_tflops": (prof_f.value / 1e12) / (prof_ms.value / 1e3) if prof_ms.value > 0 else 0.0,
         },

@@ -137,7 +137,6 @@ struct dnagpu_ctx {
     int dist_rank = 0, dist_world = 1;            // intra-block distributed inverse (dnagpu_set_inverse_exchange)
     dnagpu_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
-    bool fuse = false;             // fused small launches (dnagpu_set_fused_launches; DNAGPU_FUSE=1 at creation)
     // dnagpu_profile_hbm_*: HIP events around every launch of the large HBM-bound kernels (kinds: dnagpu.h DNAGPU_HBM_*), per chain
     struct HbmRec {
         int kind;

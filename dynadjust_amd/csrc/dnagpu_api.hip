@@ -16,12 +16,9 @@
 
 using namespace dnagpu;
 
-// dnagpu_schur_carry leaves its junction matrix in information form (no inverse of the complement): default; DNAGPU_INFO_CARRY=0 /
-// dnagpu_debug_set_info_carry(0) give the estimates form (complement inverted, estimates + corrections), e.g. to compare the two
-static std::atomic<int> g_info_carry{[] {
-    const char* e = getenv("DNAGPU_INFO_CARRY");
-    return (e && atoi(e) == 0) ? 0 : 1;
-}()};
+// dnagpu_schur_carry leaves its junction matrix in information form (no inverse of the complement): default;
+// dnagpu_debug_set_info_carry(0) gives the estimates form (complement inverted, estimates + corrections), e.g. to compare the two
+static std::atomic<int> g_info_carry{1};
 
 namespace {
 
@@ -90,7 +87,6 @@ int ensure_ws(dnagpu_ctx* ctx, int chain, uint32_t np) {
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "inverse workspace allocation", e);
     }
     ws.prof.enabled = prof;
-    ws.fuse = ctx->fuse;
     ws.dist_rank = ctx->dist_rank;
     ws.dist_world = ctx->dist_world;
     ws.exchange = ctx->exchange;
@@ -266,11 +262,6 @@ int check_info(dnagpu_ctx* ctx, int chain) {
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, where ? where : "inverse", e);
     if ((e = hipGetLastError()) != hipSuccess) return fail(ctx, DNAGPU_EHIP, "kernel launch", e);   // (launches of this thread)
     int info = *ctx->ws[chain].info_host;
-    if (info == INFO_BARRIER_TIMEOUT) {
-        // a workgroup of a fused launch waited ~2 s for the others (la_kernels.h): the result is void; counter and expectation restart
-        gemm_fused_reset(ctx->ws[chain]);
-        return fail(ctx, DNAGPU_EHIP, "device-wide barrier of a fused GEMM launch timed out");
-    }
     if (info != INFO_SENTINEL) {
         char buf[128];
         snprintf(buf, sizeof(buf), "Matrix inversion failed, the matrix is singular. (leading minor %d)", info);
@@ -327,8 +318,6 @@ int dnagpu_create(int device, dnagpu_ctx** out) {
         dnagpu_destroy(ctx);
         return DNAGPU_ENOMEM;
     }
-    if (const char* e = getenv("DNAGPU_FUSE")) ctx->fuse = atoi(e) != 0;
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) ctx->ws[c].fuse = ctx->fuse;
     *out = ctx;
     return DNAGPU_OK;
 }
@@ -478,71 +467,11 @@ long dnagpu_debug_set_tiny_tiles(long tiles) { return dnagpu::tiny_tiles_set(til
 int dnagpu_debug_set_info_carry(int on) { return g_info_carry.exchange(on ? 1 : 0); }
 int dnagpu_info_carry(void) { return g_info_carry.load(); }
 
-long dnagpu_debug_set_pair_tiles(long tiles) { return dnagpu::pair_tiles_set(tiles); }
-
 long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo, int jt_hi, uint32_t* out, long cap, int* per_workgroup) {
-    int pairs = 0;
-    std::vector<uint32_t> t = dnagpu::build_tile_order(mt, nt, K, kmode, lower, tile, jt_lo, jt_hi, &pairs);
-    if (per_workgroup) *per_workgroup = pairs ? 2 : 1;
+    std::vector<uint32_t> t = dnagpu::build_tile_order(mt, nt, K, kmode, lower, tile, jt_lo, jt_hi);
+    if (per_workgroup) *per_workgroup = 1;
     for (long i = 0; out && i < cap && i < (long)t.size(); ++i) out[i] = t[i];
     return (long)t.size();
-}
-
-int dnagpu_debug_set_tile_dag(int on) { return dnagpu::dag_mode_set(on ? 1 : 0); }
-
-int dnagpu_debug_set_lookahead(int on, long min_tiles) { return dnagpu::lookahead_set(on ? 1 : 0, min_tiles); }
-
-int dnagpu_lookahead_stats(dnagpu_ctx* ctx, uint64_t* side_launches) {
-    CHK_CTX();
-    uint64_t n = 0;
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) n += ctx->ws[c].la_launches;
-    if (side_launches) *side_launches = n;
-    return DNAGPU_OK;
-}
-
-int dnagpu_set_tile_dag_workers(dnagpu_ctx* ctx, int workers) {
-    if (!ctx || workers < 0) return DNAGPU_EINVAL;
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) ctx->ws[c].dag_workers = workers;
-    return DNAGPU_OK;
-}
-
-int dnagpu_tile_dag_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* tasks) {
-    if (!ctx) return DNAGPU_EINVAL;
-    uint64_t l = 0, t = 0;
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        l += ctx->ws[c].dag_launches;
-        t += ctx->ws[c].dag_tasks;
-    }
-    if (launches) *launches = l;
-    if (tasks) *tasks = t;
-    return DNAGPU_OK;
-}
-
-int dnagpu_debug_tile_dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats6) {
-    if (kind < 1 || kind > 7 || ti < 0 || tj < 0 || ti + tj < 1 || ti + tj > 64) return DNAGPU_EINVAL;
-    return dnagpu::dag_selftest(kind, ti, tj, what, seed, stats6);
-}
-
-int dnagpu_set_fused_launches(dnagpu_ctx* ctx, int on) {
-    if (!ctx) return DNAGPU_EINVAL;
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        gemm_flush(ctx->ws[c]);
-        ctx->ws[c].fuse = on != 0;
-        ctx->fuse = on != 0;
-    }
-    return DNAGPU_OK;
-}
-
-int dnagpu_fused_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* products) {
-    if (!ctx) return DNAGPU_EINVAL;
-    uint64_t l = 0, o = 0;
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        l += ctx->ws[c].fused_launches;
-        o += ctx->ws[c].fused_ops;
-    }
-    if (launches) *launches = l;
-    if (products) *products = o;
-    return DNAGPU_OK;
 }
 
 int dnagpu_profile_enable(dnagpu_ctx* ctx, int on) {
@@ -618,14 +547,6 @@ int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uin
             iv.emplace_back(t0, t0 + dt);
         }
         p.used = 0;
-        // (launches on the look-ahead streams, one pair each; every driver call joins them to the chain's stream before it returns)
-        for (size_t i = 0; base && i + 1 < p.side_used; i += 2) {
-            float t0 = 0.f, dt = 0.f;
-            hipEventElapsedTime(&t0, base, p.side_pool[i]);
-            hipEventElapsedTime(&dt, p.side_pool[i], p.side_pool[i + 1]);
-            iv.emplace_back(t0, t0 + dt);
-        }
-        p.side_used = 0;
         f += p.flops;
         l += p.launches;
     }
@@ -870,7 +791,7 @@ int dnagpu_matrix_export(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, dou
     if (!m || !dst) return fail(ctx, DNAGPU_EINVAL, "matrix_export: null argument");
     if (m->form == 1)
         return fail(ctx, DNAGPU_EINVAL, "matrix_export: a junction matrix in information form (dnagpu_schur_carry) has no payload form; "
-                                        "run with DNAGPU_INFO_CARRY=0 to exchange it");
+                                        "use dnagpu_junction_export");
     size_t need = (size_t)m->np * m->np + m->np;
     if (cap_doubles < need) return fail(ctx, DNAGPU_EINVAL, "matrix_export: destination too small");
     HIPCHK(hipMemcpyAsync(dst, m->F, (size_t)m->np * m->np * sizeof(double), hipMemcpyDefault, ctx->stream[chain]));
@@ -2841,7 +2762,6 @@ extern "C" int dnagpu_bench_gemm(dnagpu_ctx* ctx, int variant, int mt, int nt, i
     size_t M = (size_t)mt * 128, N = (size_t)nt * 128;
     size_t ld = std::max(std::max(M, N), (size_t)K);
     size_t cols = ld;
-    if (const char* pad = getenv("DNAGPU_BENCH_LDPAD")) ld += (size_t)atoi(pad);      // leading dimension != a multiple of 128: the set-conflict probe
     double *A = nullptr, *B = nullptr, *Cc = nullptr;
     HIPCHK(dnagpu::poison_malloc(&A, ld * cols * sizeof(double)));
     HIPCHK(dnagpu::poison_malloc(&B, ld * cols * sizeof(double)));

@@ -1,8 +1,7 @@
 // The 128 x 128 fp64 tile product of the throughput kernel as a device function: one workgroup of 64 * WAVES threads computes
 //   C(i0.., j0..) = alpha * sum_{k in [kbeg, kend)} opA(i, k) opB(k, j) + beta * C
 // with v_mfma_f64_16x16x4_f64, operands global -> LDS by LDS-DMA (global_load_lds_dwordx4).  Used by gemm_f64_dma_kernel (one launch
-// per product, la_kernels.hip) and by the tile-DAG executor (one launch per factorisation, tile_dag.hip): the same instructions in
-// the same order, hence the same bits.  Replaces the dgemm / dsyrk / dtrsm calls inside dpotrf / dpotri of
+// per product, la_kernels.hip).  Replaces the dgemm / dsyrk / dtrsm calls inside dpotrf / dpotri of
 // matrix_2d::cholesky_inverse (dynadjust/include/math/dnamatrix_contiguous.cpp:952-1020).
 #pragma once
 #include <hip/hip_runtime.h>

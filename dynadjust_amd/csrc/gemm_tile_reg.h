@@ -1,6 +1,5 @@
-// The register-staged fp64 tile product (TILE = 64 / 4 waves x 32x32: the latency shape of the small products of the recursion;
-// TILE = 128 kept for A/B comparisons) as a device function, shared by gemm_f64_kernel (la_kernels.hip) and the tile-DAG executor
-// (tile_dag.hip): the same instructions in the same order, hence the same bits.
+// The register-staged fp64 tile product (TILE = 64 / 4 waves x 32 x 32 and TILE = 32 / 4 waves x 16 x 16: the latency shapes of the small
+// and tiny products of the recursion) as a device function of gemm_f64_kernel (la_kernels.hip).
 #pragma once
 #include "gemm_tile_dma.h"
 

@@ -608,15 +608,6 @@ void dna_adjust::PrepareBlocks() {
         ctx_ = nullptr;
         SignalExceptionAdjustment("PrepareAdjustment(): no MI355X device available (the adjustment has no CPU path).", 0);
     }
-    if (shares_device_ && !plan_only_) dnagpu_set_fused_launches(ctx_, 0);
-    // Chains that run side by side share the GPU's workgroup slots by agreement: a DAG launch (csrc/tile_dag.h) of one chain keeps
-    // at most its share of persistent workers, so that a chain whose factorisation is waiting on its critical path cannot sit on the
-    // slots the others have work for.  DNAGPU_DAG_WORKERS overrides (0 = every launch may take the whole GPU).
-    {
-        int share = 512 / std::max(1, NumChains() * (shares_device_ ? std::max(1, DistWorld()) : 1));
-        if (const char* e = getenv("DNAGPU_DAG_WORKERS")) share = atoi(e);
-        if (!plan_only_) dnagpu_set_tile_dag_workers(ctx_, std::max(0, share));
-    }
     // several GPUs, one block (simultaneous adjustment): every GPU holds the block, the inverse itself is distributed -- large
     // launches split by tile columns, the parts exchanged over the communicator (dnagpu_set_inverse_exchange)
     if (!plan_only_ && comm_ && comm_->world() > 1 && projectSettings_.a.adjust_mode == SimultaneousMode)
@@ -629,10 +620,6 @@ void dna_adjust::PrepareBlocks() {
         const double per_chain = 3.0 * ((double)max_unknowns_ + 256.0) * ((double)max_unknowns_ + 256.0) * 8.0;
         while (mt_chains_ > 1 && ((UINT32)mt_chains_ > blockCount_ || per_chain * mt_chains_ > 0.5 * (double)free_b)) --mt_chains_;
         if (mt_chains_ < 2 && blockCount_ > 1 && 2.0 * per_chain <= 0.5 * (double)free_b) mt_chains_ = 2;   // the two junction chains
-        // DNAGPU_LOCAL_RUNS=n (opt-in, PrepareTwoLevel): many small blocks, the chains over n runs of them want chains of their own
-        if (!getenv("DNAGPU_CHAINS") && getenv("DNAGPU_LOCAL_RUNS") && atoi(getenv("DNAGPU_LOCAL_RUNS")) > 1 && projectSettings_.a.multi_thread &&
-            blockCount_ >= 32 && DNAGPU_NUM_CHAINS * per_chain <= 0.05 * (double)free_b)
-            mt_chains_ = DNAGPU_NUM_CHAINS;
     }
     const int chains = NumChains();
     for (int c = 0; c < chains; ++c) NewMatrix(max_unknowns_, &work_[c], 0, "PrepareAdjustment(): work matrix");

@@ -325,9 +325,7 @@ private:
     };
     std::vector<segment_t> segs_;
     bool two_level_ok_ = false;
-    bool seg_local_ = false;                   // the runs are virtual ranks of this one GPU (LocalSegmentedChains)
     void ReduceRun(int c, int run);
-    void LocalSegmentedChains();
     void PrepareTwoLevel();
     void FreeTwoLevel();
     void ReduceOwnRun();                       // level 1

@@ -249,7 +249,6 @@ void dna_adjust::AgreeOnPhase(const char* phase, const std::function<void()>& bo
         body();
     } catch (const std::exception& e) {
         mine = std::current_exception();
-        if (getenv("DNAGPU_DEBUG_PHASES")) fprintf(stderr, "rank %d, %s: %s\n", DistRank(), phase, e.what());
     } catch (...) {
         mine = std::current_exception();
     }
@@ -362,26 +361,12 @@ void dna_adjust::FreeTwoLevel() {
 
 void dna_adjust::PrepareTwoLevel() {
     FreeTwoLevel();
-    seg_local_ = false;
-    int W = DistWorld(), me = DistRank();
+    const int W = DistWorld(), me = DistRank();
     // (every condition below is the same on every rank: nothing that depends on a rank's free memory)
     if (!CondensedSchedule() || projectSettings_.a.reuse_inverses != 0) return;
-    // One GPU, many small blocks (round 4, opt-in: DNAGPU_LOCAL_RUNS=n): the same three levels with the runs as VIRTUAL ranks of this GPU --
-    // every run reduced on a chain of its own, the scan over the runs, every run's two chains on chains of their own; nothing is exchanged.
-    // 2 (B - 1) dependent steps on two chains become ~ B / V + V + 2 B / C on C chains (V runs): a third of the depth at B = 120, V = C = 8.
-    // MEASURED (profiles/r04_smallblocks_chains.txt): the depth is not what binds -- eight streams of dependent 30 - 60 us kernels slow each
-    // other down (leaf 55 -> 65 us, small products 31 -> 44 us) and the phase gains 7 % (99.5 -> 92.2 ms per iteration) while the batched
-    // phases lose what eight chains cost them: 598 against 567 - 576 ms per adjustment.  Hence off unless asked for.
-    const bool local = W < 2;
-    if (local) {
-        int V = 0;
-        if (const char* e = getenv("DNAGPU_LOCAL_RUNS")) V = atoi(e);
-        if (!projectSettings_.a.multi_thread || NumChains() < 2 || V < 2 || blockCount_ < (UINT32)(4 * V) || Distributed()) return;
-        W = V;
-        me = 0;
-    } else if (!projectSettings_.a.dist_two_level) {
-        return;
-    }
+    // (the same three levels with the runs as virtual ranks of ONE GPU -- every run on a chain of its own -- were measured in round 4 and
+    //  again in round 5's pruning note: eight streams of dependent small kernels slow each other down; removed, profiles/HISTORY.md)
+    if (W < 2 || !projectSettings_.a.dist_two_level) return;
     // one contiguous network, every rank a run of at least one block
     if (!v_blockMeta_[0]._blockFirst || !v_blockMeta_[blockCount_ - 1]._blockLast) return;
     for (UINT32 k = 0; k < blockCount_; ++k) {
@@ -390,12 +375,7 @@ void dna_adjust::PrepareTwoLevel() {
         if (blocks_[k].keep.empty()) return;
     }
     std::vector<int> run_of(blockCount_, 0);
-    if (local) {
-        // runs of (nearly) equal block count: a chain step costs the same whatever the block's own size (the condensed blocks are alike)
-        for (UINT32 k = 0; k < blockCount_; ++k) run_of[k] = (int)(((uint64_t)k * (uint64_t)W) / blockCount_);
-    } else {
-        for (UINT32 k = 0; k < blockCount_; ++k) run_of[k] = BlockOwner(k);
-    }
+    for (UINT32 k = 0; k < blockCount_; ++k) run_of[k] = BlockOwner(k);
     std::vector<int> first(W, -1), last(W, -1);
     for (UINT32 k = 0; k < blockCount_; ++k) {
         const int r = run_of[k];
@@ -458,9 +438,9 @@ void dna_adjust::PrepareTwoLevel() {
         NewBlock(g.dev_block, (UINT32)g.stations.size(), 0, g.a, "PrepareAdjustment(): run system");
         NewMatrix((UINT32)g.stations.size() * 3, &g.S, g.a, "PrepareAdjustment(): run system");
     }
-    // the merges of the own run (of every run, when they all live on this GPU)
+    // the merges of the own run
     for (int rr = 0; rr < W; ++rr) {
-        if (!local && rr != me) continue;
+        if (rr != me) continue;
         segment_t& g = segs_[rr];
         std::vector<UINT32> prev;
         for (UINT32 p = 0; p < blocks_[g.a].keep.size(); ++p) prev.push_back(gid(g.a, p));
@@ -508,7 +488,6 @@ void dna_adjust::PrepareTwoLevel() {
             for (dnagpu_matrix*& m : g.M) NewMatrix((UINT32)max_keep * 3, &m, g.a, "PrepareAdjustment(): run merge");
     }
     two_level_ok_ = true;
-    seg_local_ = local;
 }
 
 // level 1: the own run condensed to its end stations
@@ -620,27 +599,6 @@ void dna_adjust::OwnRunChains() {
     });
 }
 
-// the three levels on ONE GPU (seg_local_): the runs are dealt to the chains, nothing is exchanged
-void dna_adjust::LocalSegmentedChains() {
-    const int W = (int)segs_.size(), C = NumChains();
-    OnEveryChain([&](int c) {
-        for (int r = c; r < W && !IsCancelled() && !chain_failed_; r += C) ReduceRun(c, r);
-    });
-    if (IsCancelled()) return;
-    ScanRuns();
-    if (IsCancelled()) return;
-    // 2 W sequences: the forward chain of run q (q < W), the reverse chain of run q - W; the longest first is not needed, they are alike
-    OnEveryChain([&](int c) {
-        for (int q = c; q < 2 * W && !IsCancelled() && !chain_failed_; q += C) {
-            const segment_t& g = segs_[q % W];
-            if (q < W)
-                for (UINT32 k = g.a; k < g.b && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
-            else
-                for (UINT32 k = g.b; k > g.a && !IsCancelled() && !chain_failed_; --k) CondensedReverseBlock(c, k);
-        }
-    });
-}
-
 void dna_adjust::DistributedCondensedIteration() {
     std::vector<UINT32> mine;
     for (UINT32 k = 0; k < blockCount_; ++k)
@@ -648,13 +606,7 @@ void dna_adjust::DistributedCondensedIteration() {
     AgreeOnPhase("condensing the blocks", [&] { CondenseBlocks(mine); });
     if (cancel_agreed_) return;
     if (two_level_ok_) {
-        // DNAGPU_LOCAL_EXCLUSIVE=1 (measurement aid for ranks that share one GPU, tools/gpu_chain_phase.py): the chain work of the
-        // ranks of this process runs one rank at a time and is timed inside the lock -- what a rank with a GPU of its own would spend
-        static std::mutex exclusive;
-        static const bool one_at_a_time = getenv("DNAGPU_LOCAL_EXCLUSIVE") && atoi(getenv("DNAGPU_LOCAL_EXCLUSIVE")) != 0;
         auto timed = [&](const std::function<void()>& body) {
-            std::unique_lock<std::mutex> lk(exclusive, std::defer_lock);
-            if (one_at_a_time) lk.lock();
             const double t0 = wall_ms();
             body();
             Check(dnagpu_sync(ctx_), 0, "AdjustNetwork()");

@@ -255,10 +255,9 @@ void dna_adjust::AllocateStagedSlot(UINT32 k) {
 }
 
 // PrepareAdjustment's last step: first-use allocations that would otherwise sit inside the first iteration (cfg4 on one GPU: 95 GB of chain
-// workspaces and factor storage, 2.3 s of hipMalloc) and inside the variance phase (251 GB of page-locking).  DNAGPU_RESERVE=0: on first use.
+// workspaces and factor storage, 2.3 s of hipMalloc) and inside the variance phase (251 GB of page-locking).
 void dna_adjust::ReserveBuffers() {
-    static const bool off = getenv("DNAGPU_RESERVE") && atoi(getenv("DNAGPU_RESERVE")) == 0;
-    if (plan_only_ || off) return;
+    if (plan_only_) return;
     const int chains = NumChains();
     for (int c = 0; c < chains; ++c) Check(dnagpu_chain_reserve(ctx_, c, max_unknowns_), 0, "PrepareAdjustment(): chain workspace");
     if (transient_ok_) {
@@ -376,9 +375,6 @@ void dna_adjust::AdjustPhasedMultiThreadIteration() {
 
     // combination solves until the queue is empty and the reverse pass is over
     auto drain = [&](int c) {
-        // DNAGPU_COMBINE_CHAIN=<c> (diagnostic): only that chain takes combination solves
-        static const int only = getenv("DNAGPU_COMBINE_CHAIN") ? atoi(getenv("DNAGPU_COMBINE_CHAIN")) : -1;
-        if (only >= 0 && c != only) return;
         for (;;) {
             UINT32 k;
             {
@@ -566,9 +562,8 @@ void dna_adjust::MemInfo(size_t* free_b, size_t* total_b) {
 
 // no kept factor of its own (the HBM budget), but a device slot for its packed variance matrix that can hold the packed factor meanwhile
 bool dna_adjust::PacksItsFactor(UINT32 k) const {
-    static const bool off = getenv("DNAGPU_PACKED_FACTORS") && atoi(getenv("DNAGPU_PACKED_FACTORS")) == 0;
     const block_t& B = blocks_[k];
-    return !off && transient_ok_ && !B.part && !B.part_allowed && Staged() && B.rig_on_device && B.rig_host && !B.keep.empty() &&
+    return transient_ok_ && !B.part && !B.part_allowed && Staged() && B.rig_on_device && B.rig_host && !B.keep.empty() &&
            B.keep.size() < v_parameterStationList_[k].size() && CondensedSchedule();
 }
 
@@ -713,8 +708,7 @@ void dna_adjust::PrepareCondensedBlocks() {
         for (UINT32 k = 0; k < blockCount_; ++k)
             if (OwnsBlock(k) && !blocks_[k].keep.empty())
                 all += (lend && !blocks_[k].rigvar) ? 2.0 * 256.0 * (3.0 * (double)v_parameterStationList_[k].size() + 512.0) * 8.0 : sq(3.0 * (double)v_parameterStationList_[k].size());
-        static const bool off = getenv("DNAGPU_TRANSIENT_FACTORS") && atoi(getenv("DNAGPU_TRANSIENT_FACTORS")) == 0;
-        if (all > budget && spine_default && !containsNonGPS_ && !ReuseRequested() && !off) {
+        if (all > budget && spine_default && !containsNonGPS_ && !ReuseRequested()) {
             transient_ok_ = true;
             budget -= (double)NumChains() * sq((double)max_unknowns_);
         }
@@ -751,7 +745,6 @@ void dna_adjust::PrepareCondensedBlocks() {
     chain_fac_budget_ = 0.0;
     if (projectSettings_.a.reuse_factors != 0 && !containsNonGPS_ && DeferVariances() && projectSettings_.a.defer_variances >= 2) {
         chain_fac_budget_ = std::max(0.0, std::min(0.1 * budget, 16.0e9));
-        if (const char* e = getenv("DNAGPU_CHAIN_FACTOR_GB")) chain_fac_budget_ = atof(e) * 1.0e9;
         budget -= chain_fac_budget_;
     }
     batch_unit_ = 1.25 * sq((double)max_unknowns_) + sq(3.0 * (double)max_keep);
@@ -837,7 +830,7 @@ void dna_adjust::AssignBatchShapes() {
         while (step * 16u <= t) step *= 2u;        // t in [16, 32): 2 tiles, [32, 64): 4
         return ((t + step - 1u) / step) * step;
     };
-    static const bool off = getenv("DNAGPU_BATCH_BUCKETS") && atoi(getenv("DNAGPU_BATCH_BUCKETS")) == 0;
+    const bool off = false;
     std::map<std::pair<UINT32, UINT32>, std::vector<UINT32>> members;
     for (UINT32 k = 0; k < blockCount_; ++k) {
         block_t& B = blocks_[k];
@@ -1268,9 +1261,8 @@ void dna_adjust::CondensedReverseBlock(int c, UINT32 k) {
 // separate calls.  The counters are those of CarryCondensed's reuse branch.
 bool dna_adjust::StepRhsInOneLaunch(int c, UINT32 dev_block, UINT32 k, int dir, const dnagpu_matrix* jm_in, const std::vector<UINT32>& idx_in,
                                     dnagpu_matrix* jm_out, const std::vector<UINT32>& idx_out) {
-    static const bool off = getenv("DNAGPU_SMALL_STEPS") && atoi(getenv("DNAGPU_SMALL_STEPS")) == 0;
     block_t& B = blocks_[k];
-    if (off || !dnagpu_info_carry() || idx_out.size() >= B.keep.size()) return false;
+    if (!dnagpu_info_carry() || idx_out.size() >= B.keep.size()) return false;
     const int rc = dnagpu_chain_step_rhs(ctx_, c, dev_block, k, B.keep.data(), B.keep.size(), B.red, jm_in, idx_in.data(), jm_in ? idx_in.size() : 0, jm_out,
                                          idx_out.data(), idx_out.size(), B.cfac[dir]);
     if (rc == DNAGPU_ETOOLARGE) return false;
@@ -1494,10 +1486,6 @@ void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks) {
 
 // the forward chain on chain 0 beside the reverse chain on chain 1 (one after the other without a.multi_thread)
 void dna_adjust::CondensedChains() {
-    if (two_level_ok_ && seg_local_) {
-        LocalSegmentedChains();
-        return;
-    }
     const bool two = NumChains() > 1;
     OnEveryChain([&](int c) {
         if (c == 0)

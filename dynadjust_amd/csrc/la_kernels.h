@@ -26,12 +26,9 @@ struct GemmArgs {
     int kmode;   // KMode: restricts the k range per tile (triangular operands)
     int lower;   // 1: only tiles it >= jt (square problems)
     int mirror;  // 1: also store C(j,i) for off-diagonal tiles
-    const uint32_t* order;  // device table: (it << 16 | jt) per workgroup, 0xffffffff = idle; bit 15 (128-tile launches only): walk k
-                            // from the tile's own end of the range towards the end all tiles share
-    int pairs = 0;          // 1: two table entries per workgroup (the second may be idle), computed one after the other
+    const uint32_t* order;  // device table: (it << 16 | jt) per workgroup, 0xffffffff = idle
     int grid;               // number of workgroups (= table length)
-    int tile;               // block tile of the launch: 128 (throughput) or 64 (small launches)
-    int k_ascending = 0;    // diagnostic: 1 = walk k upwards also for the k >= i / k >= j ranges (see gemm_f64_dma_kernel)
+    int tile;               // block tile of the launch: 128 (throughput), 64 (small launches) or 32 (tiny ones)
     int nb = 1;             // members of a batched launch (grid.y); member b works on A + dA[b], B + dB[b], C + dC[b]
     long long dA[BATCH_MAX], dB[BATCH_MAX], dC[BATCH_MAX];
 };
@@ -41,46 +38,10 @@ struct LeafBatch {
     long long dA[BATCH_MAX], dX[BATCH_MAX];     // member b: A + dA[b], X + dX[b], info[b]
 };
 
-// ---- fused small launches ---------------------------------------------------------------------------------------------------
-// The bottom of the recursion issues long runs of dependent GEMM launches of a handful of tiles each: between two leaves of a
-// node of 8 tiles there are up to 6 of them, each bound by launch latency (9-15 us for 3 us of MFMA work).  A run of such
-// launches becomes ONE launch of a persistent kernel: its workgroups walk the list of products, 64 x 64 tiles dealt round-robin,
-// and meet at a device-wide barrier (an atomic counter in HBM, release / acquire at agent scope) where the kernel boundary was.
-// MEASURED (round 2, profiles/r02_fused_launches.txt): bit-identical results, but no gain -- n = 6 144 inverse 8.68 ms fused against
-// 8.45 ms, cfg3 one chain 4.38 s against 4.35 s, four chains 3.90 s against 3.79 s.  A barrier (L2 write-back + invalidate on
-// every XCD, the atomic round trip) costs what a kernel boundary costs, and workgroups that wait for each other must all be
-// resident before the first barrier is passed -- with other chains' 1 ms tiles filling the chip that wait is longer than the launch
-// latencies saved.  Off by default (dnagpu_set_fused_launches / DNAGPU_FUSE=1 switch it on).
-struct FusedOp {
-    const double* A;
-    const double* B;
-    double* C;
-    int lda, ldb, ldc;
-    int mt, nt;      // 128-wide tiles (the kernel works on 64-wide ones)
-    int K;
-    double alpha, beta;
-    int kmode, lower, mirror;
-    int akc, bkc;    // operand layouts (A_KC / B_KC of the tile kernel)
-};
-constexpr int FUSED_MAX_OPS = 20;
-// Workgroups of a fused launch = the largest tile count of its products, at most this; products with more 64-tiles keep a launch of
-// their own.  All workgroups of a fused launch must be resident together (they wait for each other): 64 x 8 chains = 512 = what the
-// chip holds of this kernel (2 workgroups per CU), so even eight chains in their fused launches at once cannot starve each other.
-constexpr int FUSED_MAX_GRID = 64;
-struct FusedArgs {
-    int nops;
-    unsigned long long* counter;   // device word, only ever incremented; `base` = its value when this launch starts
-    unsigned long long base;
-    int* info;                     // a barrier that is not reached within ~2 s leaves DNAGPU_INFO_BARRIER_TIMEOUT here and the kernel exits
-    FusedOp op[FUSED_MAX_OPS];
-};
-constexpr int INFO_BARRIER_TIMEOUT = -9;
-void launch_gemm_fused(const FusedArgs& f, int grid, hipStream_t s);
-
 // launches with fewer 128-tiles than this run on 64x64 block tiles
 // (cfg3, r02: 160 / 384 / 768 -> 3.83 / 3.79 / 3.77 s per step with four chains, 4.38 / 4.33 / 4.35 s with one)
 constexpr int SMALL_LAUNCH_TILES = 512;
-// ... and with fewer 128-tiles than this on 32 x 32 block tiles (DNAGPU_TINY_TILES; round 4).  A 64-tile of K = 512 is 13.7 us of MFMA time on
+// ... and with fewer 128-tiles than this on 32 x 32 block tiles (round 4).  A 64-tile of K = 512 is 13.7 us of MFMA time on
 // the ONE CU it occupies, and a product of a dozen 128-tiles occupies a fifth of the chip: sixteen times the workgroups of the 128-tile shape
 // spread the same flops over every CU there is.  Same bits (an element's k order does not depend on the tile it is computed in).
 // Measured (profiles/r04_tiny_tiles.txt; thresholds 0 / 8 / 16 / 32 / 64 / 128 / 256 / 512): inverse n = 6 144 27.7 -> 31.5 TFLOP/s, elimination
@@ -91,10 +52,7 @@ constexpr int TINY_LAUNCH_TILES = 64;
 // Build the workgroup -> tile table for a launch shape (host side, see tile_order.cpp).
 // Returns the table (length = grid, multiple of 8 when more than 8 tiles).
 // jt_lo / jt_hi (128-tiles, -1 = all): only the tiles of these columns (one rank's share of a split launch)
-std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo = -1, int jt_hi = -1, int* pairs = nullptr);
-long pair_tiles_get();
-long pair_tiles_set(long tiles);   // launches of at least this many 128-tiles walk their tiles in pairs (tile_order.hip); 0 = never (default); returns the old value
-bool gemm_128_takes_pairs();   // the LDS-DMA kernel does; the register-staged diagnostic variants do not
+std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo = -1, int jt_hi = -1);
 std::vector<int> split_tile_columns(int mt, int nt, int K, int kmode, int lower, int world);
 
 void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);

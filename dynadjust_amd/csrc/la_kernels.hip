@@ -91,73 +91,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
     gemm_tile_body<A_KC, B_KC, TILE, WAVES>(a, (int)(packed >> 16), (int)(packed & 0xffffu), lds, dA, dB, dC);
 }
 
-// ---- fused small launches (la_kernels.h) -------------------------------------------------------------------------------------
-// Device-wide barrier between two products of a fused launch.  Every workgroup arrives once per barrier; the counter never
-// goes back, so barrier b of a launch that started at `base` is passed when the counter reaches base + (b + 1) * workgroups.
-// Release / acquire at agent scope: the tiles a workgroup wrote are visible to every XCD's L2 before it arrives, and nothing
-// it reads afterwards comes from a stale line.
-__device__ __forceinline__ bool fused_grid_barrier(unsigned long long* counter, unsigned long long target, int* info) {
-    __shared__ int timed_out;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        timed_out = 0;
-        __atomic_thread_fence(__ATOMIC_RELEASE);                    // (agent scope is the default of the HIP fence builtins below)
-        __threadfence();
-        atomicAdd(counter, 1ULL);
-        long spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1L << 24)) {                              // ~2 s: another workgroup never arrived
-                atomicMin(info, INFO_BARRIER_TIMEOUT);
-                timed_out = 1;
-                break;
-            }
-        }
-        __threadfence();
-    }
-    __syncthreads();
-    __threadfence();                                                // every wave: its later loads must miss the old lines
-    return timed_out == 0;
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_f64_fused_kernel(FusedArgs f) {
-    using G = Geo<64, 4>;
-    __shared__ __attribute__((aligned(16))) double lds[4 * G::OPBUF];
-    const int nwg = (int)gridDim.x;
-    for (int o = 0; o < f.nops; ++o) {
-        const FusedOp& a = f.op[o];
-        const int mt = 2 * a.mt, nt = 2 * a.nt;
-        const int total = a.lower ? mt * (mt + 1) / 2 : mt * nt;
-        for (int t = (int)blockIdx.x; t < total; t += nwg) {
-            int it, jt;
-            if (a.lower) {
-                it = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while ((it + 1) * (it + 2) / 2 <= t) ++it;
-                while (it * (it + 1) / 2 > t) --it;
-                jt = t - it * (it + 1) / 2;
-            } else {
-                it = t % mt;
-                jt = t / mt;
-            }
-            __syncthreads();        // the previous tile's last fragment reads
-            if (!a.akc && !a.bkc)
-                gemm_tile_body<false, false, 64, 4>(a, it, jt, lds);
-            else if (!a.akc && a.bkc)
-                gemm_tile_body<false, true, 64, 4>(a, it, jt, lds);
-            else if (a.akc && a.bkc)
-                gemm_tile_body<true, true, 64, 4>(a, it, jt, lds);
-            else
-                gemm_tile_body<true, false, 64, 4>(a, it, jt, lds);
-        }
-        if (o + 1 < f.nops && !fused_grid_barrier(f.counter, f.base + (unsigned long long)(o + 1) * (unsigned long long)nwg, f.info)) return;
-    }
-}
-
-void launch_gemm_fused(const FusedArgs& f, int grid, hipStream_t s) {
-    if (f.nops <= 0 || grid <= 0) return;
-    hipLaunchKernelGGL(gemm_f64_fused_kernel, dim3(grid), dim3(256), 0, s, f);
-}
-
 // The throughput kernel: TILE = 128, operands staged with LDS-DMA (no staging registers, no ds_write), two separate
 // LDS buffers (distinct __shared__ objects, so that the compiler knows a DMA into one never aliases the fragment
 // reads of the other and does not serialise them behind vmcnt).  The tile itself: dma_tile_product (gemm_tile_dma.h).
@@ -167,9 +100,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
     using G = Geo<TILE, WAVES>;
     __shared__ __attribute__((aligned(16))) double lds0[2 * G::OPBUF];
     __shared__ __attribute__((aligned(16))) double lds1[2 * G::OPBUF];
-    // One table entry per workgroup, or two (a.pairs): a workgroup then computes two tiles one after the other, the second one
-    // walked TOWARDS the k all tiles have in common (bit 15 of the entry), see tile_order.hip.
-    const int nparts = a.pairs ? 2 : 1;
     long long dA = 0, dB = 0, dC = 0;
     if (a.nb > 1) {     // a batched launch: this workgroup's member (uniform: scalar loads from the kernel arguments)
         const int b = (int)blockIdx.y;
@@ -177,29 +107,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
         dB = a.dB[b];
         dC = a.dC[b];
     }
-#pragma nounroll
-    for (int part = 0; part < nparts; ++part) {
-        const uint32_t packed = a.order[(size_t)blockIdx.x * nparts + part];
-        if (packed == 0xffffffffu) break;
-        const int it = (int)(packed >> 16), jt = (int)(packed & 0x7fffu);
-        const bool flip = (packed & 0x8000u) != 0;
-        int kbeg = 0, kend = a.K;
-        switch (a.kmode) {
-            case KM_LE_J: kend = (jt + 1) * 128; break;
-            case KM_GE_J: kbeg = jt * 128; break;
-            case KM_LE_I: kend = (it + 1) * 128; break;
-            case KM_GE_I: kbeg = it * 128; break;
-            default: break;
-        }
-        if (kend > a.K) kend = a.K;
-        if (part) __syncthreads();       // the first tile's last fragment reads are done before the next DMA lands
-        // Triangular ranges that END at a common k (k >= i, k >= j) are walked downwards: the workgroups of a super-tile,
-        // which share operand panels in their XCD's L2, then start together at the common end and stay in step, instead of
-        // each starting at its own first k and drifting apart by (tile distance) x 128 for the whole run.
-        const bool down = ((a.kmode == KM_GE_J || a.kmode == KM_GE_I) && !a.k_ascending) != flip;
-        dma_tile_product<A_KC, B_KC, WAVES>(a.A + dA, a.lda, a.B + dB, a.ldb, a.C + dC, a.ldc, it * TILE, jt * TILE, kbeg, kend, down, a.alpha, a.beta,
-                                            a.mirror && (it != jt), lds0, lds1);
+    const uint32_t packed = a.order[blockIdx.x];
+    if (packed == 0xffffffffu) return;
+    const int it = (int)(packed >> 16), jt = (int)(packed & 0x7fffu);
+    int kbeg = 0, kend = a.K;
+    switch (a.kmode) {
+        case KM_LE_J: kend = (jt + 1) * 128; break;
+        case KM_GE_J: kbeg = jt * 128; break;
+        case KM_LE_I: kend = (it + 1) * 128; break;
+        case KM_GE_I: kbeg = it * 128; break;
+        default: break;
     }
+    if (kend > a.K) kend = a.K;
+    // Triangular ranges that END at a common k (k >= i, k >= j) are walked downwards: the workgroups of a super-tile,
+    // which share operand panels in their XCD's L2, then start together at the common end and stay in step, instead of
+    // each starting at its own first k and drifting apart by (tile distance) x 128 for the whole run.
+    const bool down = a.kmode == KM_GE_J || a.kmode == KM_GE_I;
+    dma_tile_product<A_KC, B_KC, WAVES>(a.A + dA, a.lda, a.B + dB, a.ldb, a.C + dC, a.ldc, it * TILE, jt * TILE, kbeg, kend, down, a.alpha, a.beta,
+                                        a.mirror && (it != jt), lds0, lds1);
 }
 
 
@@ -229,40 +154,14 @@ static void launch_gemm_t(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) 
         hipLaunchKernelGGL((gemm_f64_kernel<true, false, TILE, WAVES>), grid, block, 0, s, a);
 }
 
-// DNAGPU_GEMM_VARIANT selects the 128-tile kernel for A/B comparisons: "dma4" (default), "dma8", "reg8", "reg4"
-static int gemm_variant_128() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("DNAGPU_GEMM_VARIANT");
-        v = 1;
-        if (e && !strcmp(e, "dma8")) v = 0;
-        if (e && !strcmp(e, "reg8")) v = 2;
-        if (e && !strcmp(e, "reg4")) v = 3;
-    }
-    return v;
-}
-
-bool gemm_128_takes_pairs() { return gemm_variant_128() <= 1; }
-
 void launch_gemm(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
     if (a.grid <= 0) return;
-    if (a.tile == 64) {
+    if (a.tile == 64)
         launch_gemm_t<64, 4>(a, a_kc, b_kc, s);
-        return;
-    }
-    if (a.tile == 32) {
+    else if (a.tile == 32)
         launch_gemm_t<32, 4>(a, a_kc, b_kc, s);
-        return;
-    }
-    static const int k_asc = getenv("DNAGPU_K_ASCENDING") ? 1 : 0;   // diagnostic A/B switch
-    GemmArgs b = a;
-    b.k_ascending = k_asc;
-    switch (gemm_variant_128()) {
-        case 1: launch_gemm_dma<4>(b, a_kc, b_kc, s); break;
-        case 2: launch_gemm_t<128, 8>(b, a_kc, b_kc, s); break;
-        case 3: launch_gemm_t<128, 4>(b, a_kc, b_kc, s); break;
-        default: launch_gemm_dma<8>(b, a_kc, b_kc, s); break;
-    }
+    else
+        launch_gemm_dma<4>(a, a_kc, b_kc, s);
 }
 
 // ----------------------------------------------------------------------------

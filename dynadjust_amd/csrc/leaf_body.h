@@ -1,6 +1,5 @@
-// The leaf of the recursive inverse as a device function: potrf + trtri of one 128 x 128 diagonal tile by ONE workgroup of NW waves
-// (8: the stand-alone leaf kernel, leaf_kernel.hip; 4: a task of the tile-DAG executor, tile_dag.hip).  The work is dealt to the
-// waves by 16 x 16 block, every block receives the same operations in the same order whatever NW is: same bits.
+// The leaf of the recursive inverse as a device function: potrf + trtri of one 128 x 128 diagonal tile by ONE workgroup of 8 waves
+// (leaf_kernel.hip).  The work is dealt to the waves by 16 x 16 block.
 // Replaces dpotrf / dtrtri on the diagonal blocks of matrix_2d::cholesky_inverse (dnamatrix_contiguous.cpp:982-1006).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -44,8 +43,7 @@ __device__ __forceinline__ d4 mma16(const double* a, int ars, int acs, const dou
 
 // The tile lives in LDS as its 36 lower 16x16 blocks (block (bi, bj), bi >= bj, number bi (bi + 1) / 2 + bj, rows BR apart):
 // 76.5 KiB instead of 149 KiB for the square tile + separate diagonal inverses, so that a leaf can share a CU with one workgroup
-// of the tile GEMM (72 KiB).  `blk(bi, bj)` of the caller says where a block lives (one array in the leaf kernel, the tile GEMM's
-// operand buffers in the DAG executor).
+// of the tile GEMM (72 KiB).  `blk(bi, bj)` of the caller says where a block lives (one array in the leaf kernel).
 constexpr int BR = 17;        // row stride inside a block (odd: conflict-free column reads)
 constexpr int BS = 16 * BR;   // doubles per block
 
@@ -125,184 +123,10 @@ __device__ __forceinline__ void diag_block(double* xd, double* const LT, int lan
     }
 }
 
-// A (lda): the tile, lower triangle read; X (ldx): receives L^-1 of the tile (lower, zeros above the diagonal); o: the tile's first
-// column in its matrix (a non-positive pivot in column c reports info = o + c + 1, like dpotrf).
-// LT: 256 doubles of LDS (the factor of the current diagonal block, transposed; wave 0 only).
-template <int NW, class Blk>
-__device__ __forceinline__ void potrf_trtri_tile(const double* __restrict__ A, int lda, double* __restrict__ X, int ldx, int o, int* info,
-                                                 double* const LT, Blk blk) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches instead of exec masks)
-    const int row = tid & 127;
-    constexpr int QN = NW / 2;                                    // threads per tile row
-    const int q = tid >> 7;  // 0..QN-1
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-
-    LEAF_PROBE(0);
-    // all 32 loads of a thread are in flight together (a rolled loop would pay the memory latency 32 times: 20 us of a 68 us leaf)
-    {
-        double v[128 / QN];
-#pragma unroll
-        for (int t = 0; t < 128 / QN; ++t) {
-            const int c = q + QN * t;
-            v[t] = (row >= c) ? A[(size_t)c * lda + row] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < 128 / QN; ++t) {
-            const int c = q + QN * t;
-            if ((row >> 4) >= (c >> 4)) blk(row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] = v[t];
-        }
-    }
-    __syncthreads();
-    LEAF_PROBE(1);
-
-    // ------------------------------- phase A: Cholesky -------------------------------
-    // diagonal block kb: factored by wave 0 in registers; what stays in LDS is its INVERSE D^-1 (the factor itself is not
-    // needed again: the panel below it is solved with D^-T, the trailing update uses the panel, X's diagonal block is D^-1)
-#pragma unroll 1
-    for (int kb = 0; kb < 8; ++kb) {
-        const int p0 = 16 * kb;
-        double* xd = blk(kb, kb);
-        if (wave == 0) diag_block(xd, LT, lane, info, o + p0);
-        LEAF_PROBE(2 + 3 * kb);
-        __syncthreads();
-        // panel slabs below the diagonal block: P = A_panel * D^-T, one slab per wave
-        for (int w = wave; w < 7 - kb; w += NW) {
-            double* P = blk(kb + 1 + w, kb);
-            d4 acc = mma16(P, BR, 1, xd, 1, BR, zero, 1.0, lane);
-            tile_store(P, lane, acc);
-        }
-        __syncthreads();
-        LEAF_PROBE(3 + 3 * kb);
-        // trailing update: tiles (ti, tj), kb < tj <= ti, dealt round-robin to the waves; a wave has the operands of its next
-        // tile on their way from LDS while the MFMAs of the current one run
-        {
-            const int nt = 7 - kb;  // tile rows below the panel
-            const int T = nt * (nt + 1) / 2;
-            const int lo = lane & 15, hi = lane >> 4;
-            auto fetch = [&](int t, d4& c, double (&a)[4], double (&b)[4], double*& C) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
-                C = blk(kb + 1 + ti, kb + 1 + tj);
-                c = tile_load(C, lane);
-                const double* A = blk(kb + 1 + ti, kb);
-                const double* B = blk(kb + 1 + tj, kb);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    a[kk] = A[lo * BR + 4 * kk + hi];
-                    b[kk] = B[lo * BR + 4 * kk + hi];
-                }
-            };
-            int t = wave;
-            d4 c = zero;
-            double av[4], bv[4];
-            double* C = nullptr;
-            if (t < T) fetch(t, c, av, bv, C);
-            while (t < T) {
-                const int tn = t + NW;
-                d4 cn = zero;
-                double an[4] = {0.0, 0.0, 0.0, 0.0}, bn[4] = {0.0, 0.0, 0.0, 0.0};
-                double* Cn = nullptr;
-                if (tn < T) fetch(tn, cn, an, bn, Cn);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk], c, 0, 0, 0);
-                tile_store(C, lane, c);
-                c = cn;
-                C = Cn;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    av[kk] = an[kk];
-                    bv[kk] = bn[kk];
-                }
-                t = tn;
-            }
-        }
-        __syncthreads();
-        LEAF_PROBE(4 + 3 * kb);
-    }
-
-    // ------------------------------- phase B: X = L^-1 -------------------------------
-#pragma unroll 1
-    for (int kb = 0; kb < 8; ++kb) {
-        const double* xd = blk(kb, kb);
-        // row block kb, columns left of the panel: M_k <- D^-1 * M_k (the diagonal block already is D^-1)
-        for (int tj = wave; tj < kb; tj += NW) {
-            double* M = blk(kb, tj);
-            d4 acc = mma16(xd, BR, 1, M, BR, 1, zero, 1.0, lane);
-            tile_store(M, lane, acc);
-        }
-        __syncthreads();
-        // tiles below and left of the panel: M(i, tj) -= L(i,kb) M_k(tj), (7 - kb) kb of them, dealt round-robin to the waves
-        // (a slab per wave left one wave with 7 tiles in a row at kb = 6), the next tile's operands in flight during the MFMAs
-        {
-            const int lo = lane & 15, hi = lane >> 4;
-            const int T = (7 - kb) * kb;
-            auto fetch = [&](int t, d4& c, double (&a)[4], double (&b)[4], double*& C) {
-                const int bi = kb + 1 + t / kb, tj = t % kb;
-                C = blk(bi, tj);
-                c = tile_load(C, lane);
-                const double* Lk = blk(bi, kb);
-                const double* Mk = blk(kb, tj);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    a[kk] = Lk[lo * BR + 4 * kk + hi];
-                    b[kk] = Mk[(4 * kk + hi) * BR + lo];
-                }
-            };
-            int t = wave;
-            d4 c = zero;
-            double av[4], bv[4];
-            double* C = nullptr;
-            if (t < T) fetch(t, c, av, bv, C);
-            while (t < T) {
-                const int tn = t + NW;
-                d4 cn = zero;
-                double an[4] = {0.0, 0.0, 0.0, 0.0}, bn[4] = {0.0, 0.0, 0.0, 0.0};
-                double* Cn = nullptr;
-                if (tn < T) fetch(tn, cn, an, bn, Cn);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk], c, 0, 0, 0);
-                tile_store(C, lane, c);
-                c = cn;
-                C = Cn;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    av[kk] = an[kk];
-                    bv[kk] = bn[kk];
-                }
-                t = tn;
-            }
-        }
-        __syncthreads();
-        // the panel's own column: M(i,kb) = -L(i,kb) D^-1 over L(i,kb), one tile per wave, after every reader of L(i,kb)
-        for (int w = wave; w < 7 - kb; w += NW) {
-            const int lo = lane & 15, hi = lane >> 4;
-            double* Lk = blk(kb + 1 + w, kb);
-            double lf[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lf[kk] = Lk[lo * BR + 4 * kk + hi];
-            d4 acc = zero;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lf[kk], xd[(4 * kk + hi) * BR + lo], acc, 0, 0, 0);
-            tile_store(Lk, lane, acc);
-        }
-        __syncthreads();
-        LEAF_PROBE(26 + kb);
-    }
-
-#pragma unroll 8
-    for (int c = q; c < 128; c += QN) {
-        double v = (row >= c) ? blk(row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] : 0.0;
-        X[(size_t)c * ldx + row] = v;
-    }
-    LEAF_PROBE(34);
-}
-
-// ---- the overlapped schedule (round 4; the stand-alone leaf kernel) ----
-// The same operations on every 16 x 16 block in the same order as potrf_trtri_tile above -- same bits -- but the serial part, the
-// diagonal blocks of wave 0 (8 x 4 600 of the old leaf's 91 600 clocks), no longer has the other waves wait for it:
+// ---- the overlapped schedule (round 4) ----
+// The same operations on every 16 x 16 block in the same order as the first, lock-step version (eight phases per 16-column panel, removed in
+// round 5) -- same bits -- but the serial part, the diagonal blocks of wave 0 (8 x 4 600 of the old leaf's 91 600 clocks), no longer has
+// the other waves wait for it:
 //   * phase B's step kb (X = L^-1, column block by column block) only touches block columns <= kb, phase A's steps > kb only block
 //     columns > kb: step kb of phase B runs beside the diagonal block kb + 1, and so does the trailing update of step kb but for the
 //     one block wave 0 needs (which it updates itself);

@@ -22,15 +22,13 @@ struct GemmProfile {
     std::vector<hipEvent_t> pool;  // start/stop pairs, one pair per run of consecutive gemm launches
     size_t used = 0;
     bool open = false;       // a run is in progress (start event recorded, stop event pending)
-    std::vector<hipEvent_t> side_pool;   // start/stop pairs of the launches on the look-ahead streams (one pair per launch)
-    size_t side_used = 0;
 };
 
 // A batched driver call: the drivers below run on member 0's buffers as always, and every launch they enqueue carries nb members --
 // the same product or leaf on nb matrices of one shape, in lock step (la_kernels.h: GemmArgs::nb).  The buffers a call touches are
 // registered here (member 0's address range, the other members' offsets in doubles); gemm() finds an operand's buffer by its
-// address.  While a batch is set the tile-DAG, fused-launch and split-launch paths are off, and P is addressed relative to the
-// diagonal block being factored (Rec::p_o) so that the members' panel buffers only need that block's columns.
+// address.  While a batch is set the split-launch path is off, and P is addressed relative to the diagonal block being factored
+// (Rec::p_o) so that the members' panel buffers only need that block's columns.
 struct InvBatch {
     int nb = 1;
     int nbuf = 0;
@@ -53,15 +51,6 @@ struct InvWorkspace {
     int* info = nullptr;     // device ints (dpotrf-style info, 0 = ok), one per member of a batched call (BATCH_MAX)
     int* info_host = nullptr;  // pinned host copy
     InvBatch batch;          // nb > 1: the call being enqueued is batched
-    // Look-ahead (sym_inverse.hip, Rec::trailing): the columns of a trailing update that the next diagonal block does not touch go to a
-    // low-priority side stream, and the chain's own stream goes on with that block -- its leaves and few-tile products, bound by launch
-    // latency, run beside a launch that fills the GPU instead of after it.  Hazards are tracked per launch (address boxes), so the
-    // result is the sequential one, bit for bit.
-    static constexpr int LA_SIDES = 2;
-    hipStream_t side[LA_SIDES] = {nullptr, nullptr};
-    std::vector<hipEvent_t> la_events;   // untimed; reused by every driver call (all of a call's side work is joined before it returns)
-    size_t la_used = 0;
-    uint64_t la_launches = 0;
     double* bX[BATCH_MAX] = {};   // members 1 .. of a batched call: their matrix being factored (bnp_cap^2) ...
     double* bW[BATCH_MAX] = {};   // ... and the panels inside a diagonal block (bw_cols x bnp_cap)
     uint32_t bnp_cap = 0, bw_cols = 0;
@@ -87,27 +76,7 @@ struct InvWorkspace {
     size_t dist_stage_cap = 0;
     uint64_t split_launches = 0;
     double exchanged_bytes = 0.0;
-    // fused small launches (la_kernels.h): products waiting to go out as one launch, the barrier counter and its expected value
-    bool fuse = false;             // opt-in (dnagpu_set_fused_launches, DNAGPU_FUSE=1): measured no gain, see la_kernels.h
-    std::vector<FusedOp> pending;
-    unsigned long long* sync_ctr = nullptr;
-    unsigned long long sync_base = 0;
-    uint64_t fused_launches = 0, fused_ops = 0;
-    // tile-DAG path (tile_dag.h): a whole driver call below as one launch
-    bool dag = true;               // dnagpu_set_tile_dag / DNAGPU_DAG=0 switch back to one launch per product
-    int dag_workers = 0;           // workgroups per launch (0: the default, 512 = what the GPU holds of this kernel); chains that run side by side share
-    uint32_t* dag_flags = nullptr; // completion flags of the tasks (a flag is raised by writing the launch's epoch: never cleared)
-    size_t dag_flags_cap = 0;
-    uint32_t dag_epoch = 0;
-    unsigned long long* dag_ticket = nullptr;   // the ticket counter and its value at the next launch's start
-    unsigned long long dag_ticket_base = 0;
-    uint64_t dag_launches = 0, dag_tasks = 0;
 };
-
-// sends the waiting small products out as one launch (called before anything else is enqueued on ws.stream)
-void gemm_flush(InvWorkspace& ws);
-// after a device-side barrier time-out: counter and expectation back to zero (stream must be idle)
-void gemm_fused_reset(InvWorkspace& ws);
 
 // returns the latched error (and where it happened) and clears it
 hipError_t inv_take_error(InvWorkspace& ws, const char** where);
@@ -117,8 +86,6 @@ void inv_note_error(InvWorkspace& ws, hipError_t e, const char* where);
 struct GemmArgs;
 // fills a.order / a.grid from the cache (building + uploading the table on first use)
 hipError_t gemm_attach_order(InvWorkspace& ws, GemmArgs& a, int jt_lo = -1, int jt_hi = -1);
-// process-wide switch of the look-ahead (DNAGPU_LOOKAHEAD) and the smallest side part in 128-tiles (< 0: unchanged); returns the old switch
-int lookahead_set(int on, long min_tiles = -1);
 
 // returns hipSuccess or an error; allocates for matrices up to np_cap (multiple of 128)
 hipError_t inv_workspace_alloc(InvWorkspace& ws, uint32_t np_cap, hipStream_t stream);
@@ -160,13 +127,9 @@ void gemm_profile_collect(InvWorkspace& ws);
 void gemm_profile_close(InvWorkspace& ws);   // ends the current run of gemm launches (call before enqueuing any other kernel)
 void gemm_profile_reset(InvWorkspace& ws);
 
-// process-wide switch of the tile-DAG path (DNAGPU_DAG, default 1); returns the old value
-int dag_mode_set(int on);
-// CPU self-test of the tile DAG's dependency analysis (sym_inverse.hip): 0 = every admissible order reproduces the recorded order's bits
-int dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats6);
 double schur_split();
 
-// DNAGPU_FAULT_INJECT=<n>: the n-th tile-table allocation of the process fails with hipErrorOutOfMemory (tests/test_gpu_matrix.py:
+// fault_inject_reset(n): the n-th tile-table allocation from now on fails with hipErrorOutOfMemory (tests/test_gpu_matrix.py:
 // a failed allocation in the middle of an inverse must surface as DNAGPU_ENOMEM, never as a silently skipped launch)
 void fault_inject_reset(long nth);
 // threshold (in 128-tiles per launch) below which a launch uses the 64-tile kernel; negative restores the default; returns the old value

@@ -114,7 +114,7 @@ int dnagpu_debug_fail_allocation(long nth);
 /* tests: the next n allocations of a batch's member workspaces (dnagpu_batch_reserve, dnagpu_*_batched) fail with DNAGPU_ENOMEM as if HBM
  * were full -- the caller must then run the blocks one at a time, with the same results */
 int dnagpu_debug_fail_batch_workspaces(long n);
-/* Launches with fewer than `tiles` 128 x 128 tiles use the 64-tile latency kernel (default 160); 0 sends every launch through the
+/* Launches with fewer than `tiles` 128 x 128 tiles use the 64-tile latency kernel (default 512); 0 sends every launch through the
  * 128-tile throughput kernel (gemm_f64_dma_kernel), a negative value restores the default.  Returns the previous value. */
 long dnagpu_debug_set_small_tiles(long tiles);
 /* ... and below `tiles` on 32 x 32 tiles (default 64; 0: never; < 0: the default again): the products of the recursion's bottom and of the chains on
@@ -123,43 +123,10 @@ long dnagpu_debug_set_tiny_tiles(long tiles);
 /* dnagpu_schur_carry's result: 1 (default) information form, 0 estimates form (see there); returns the previous value.  Process-wide. */
 int dnagpu_debug_set_info_carry(int on);
 int dnagpu_info_carry(void);
-/* Opt-in experiment (off: measured no gain, tile_order.hip): launches of at least `tiles` 128-tiles with a triangular k range give every
- * workgroup two tiles of complementary length (0 = never, the default).  Takes effect for tables built afterwards.  Returns the previous value. */
-long dnagpu_debug_set_pair_tiles(long tiles);
 /* The workgroup -> tile table a launch of this shape would use (host computation, no device needed): `out` receives up to `cap`
- * entries (it << 16 | jt, bit 15 = k walked towards the common end, 0xffffffff = idle), *per_workgroup = 1 or 2 entries per workgroup;
+ * entries (it << 16 | jt, 0xffffffff = idle), *per_workgroup = entries per workgroup (1);
  * jt_lo / jt_hi = -1 or the column range of one rank of a split launch.  Returns the number of entries the table has. */
 long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo, int jt_hi, uint32_t* out, long cap, int* per_workgroup);
-/* Opt-in experiment (off by default: measured no gain, la_kernels.h): runs of dependent small products of the recursion as ONE launch of a
- * persistent kernel, device-wide barriers between the products (DNAGPU_FUSE=1 or dnagpu_set_fused_launches).  Totals since the context was created. */
-int dnagpu_fused_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* products);
-/* The workgroups of a fused launch wait for each other, so all of them must be resident: fine for the chains of one context (up to
- * 8 x 64 workgroups = what the GPU holds), not for many contexts driving one GPU at once -- those switch it off (on = 0). */
-int dnagpu_set_fused_launches(dnagpu_ctx* ctx, int on);
-
-/* The tile-DAG path (csrc/tile_dag.h, default on; DNAGPU_DAG=0): every inverse / elimination / completion goes out as ONE launch whose
- * persistent workgroups execute the recorded tile tasks of the whole recursion, ordered by a list-scheduling simulation and
- * synchronised by completion flags, instead of one launch per product and leaf (dpotrf / dpotri of dnamatrix_contiguous.cpp:982-1006).
- * dnagpu_debug_set_tile_dag: process-wide switch, returns the previous value.  dnagpu_tile_dag_stats: launches / tasks since the context
- * was created.  dnagpu_debug_tile_dag_selftest: CPU-only check of the dependency analysis for the sequence `kind` (1 inverse, 2 schur,
- * 3 schur-keep, 4 complete(what), 5 spine, 6 spine-kept, 7 spine-finish) on ti + tj tiles: the tasks are executed on host buffers in the
- * recorded order and in the launch order, a random admissible order and the most out-of-order one the flags admit; returns how many of
- * those differ from the recorded order in any bit (0 = pass), -1 on a stall.  stats6: tasks, dependency runs, flops, simulated makespan,
- * critical path, summed task time (microseconds). */
-int dnagpu_debug_set_tile_dag(int on);
-/* Look-ahead inside a factorisation (opt-in, DNAGPU_LOOKAHEAD=1; measured no gain, profiles/r03_lookahead.txt): the tile columns of a trailing update that the next
- * diagonal block does not touch run on a low-priority side stream of the chain while the chain's own stream factors that block -- the
- * latency-bound leaves and few-tile products beside a launch that fills the GPU instead of after it.  Per-launch hazard tracking keeps
- * the sequential order wherever two launches touch the same tiles: same bits.  min_tiles: the smallest side part worth a stream of its
- * own, in 128-tiles (< 0: unchanged; default 1024).  Returns the old switch.  dnagpu_lookahead_stats: launches that went to side streams. */
-int dnagpu_debug_set_lookahead(int on, long min_tiles);
-int dnagpu_lookahead_stats(dnagpu_ctx* ctx, uint64_t* side_launches);
-/* workgroups a DAG launch of this context uses (0 = default 512: what the GPU holds of the kernel).  A host that runs c chains side by
- * side gives each 512 / c, so that one chain's waiting workers cannot take the others' slots */
-int dnagpu_set_tile_dag_workers(dnagpu_ctx* ctx, int workers);
-int dnagpu_tile_dag_stats(dnagpu_ctx* ctx, uint64_t* launches, uint64_t* tasks);
-int dnagpu_debug_tile_dag_selftest(int kind, int ti, int tj, int what, uint64_t seed, double* stats6);
-
 /* ---- device-resident work matrices ----------------------------------------
  * A work matrix is an np x np (np = ceil(n/128)*128) column-major buffer that
  * holds N, then N^-1.  Each chain owns one; junction matrices get their own. */

@@ -161,44 +161,6 @@ def test_two_level_chains(built, orc, tmp_path, ranks, blocks, mt):
     o.close()
 
 
-@pytest.mark.parametrize("runs", ["8", "2", "5"])
-def test_segmented_chains_on_one_gpu(built, orc, tmp_path, monkeypatch, runs):
-    """many small blocks on ONE GPU (round 4): the two-level chains with the runs as virtual ranks of the GPU -- every run reduced on a chain of its
-    own, the scan over the runs, every run's forward and reverse chain on chains of their own (LocalSegmentedChains; nothing exchanged; opt-in,
-    DNAGPU_LOCAL_RUNS = 8 / 2 / 5 runs -- measured: not faster, profiles/r04_smallblocks_chains.txt): same results as the plain chains (DNAGPU_LOCAL_RUNS=0) to
-    rounding and as the oracle to 1e-8, statistics included."""
-    blocks = 34
-    adjust.write_synthetic_network(str(tmp_path), "n", 2 * blocks, 9, 0, blocks, seed=41)
-    o, ost = _oracle(orc, str(tmp_path), "n")
-    ostat, _ = o.statistics()
-    res = {}
-    for tag, env in (("plain", "0"), ("runs", runs)):
-        if env:
-            monkeypatch.setenv("DNAGPU_LOCAL_RUNS", env)
-        else:
-            monkeypatch.delenv("DNAGPU_LOCAL_RUNS", raising=False)
-        a = _run(str(tmp_path), "n", multi_thread=True)
-        st = a.AdjustNetwork()
-        assert st == ost and a.CurrentIteration() == o.iterations()
-        for i in range(o.iterations()):
-            assert abs(a.GetIterationCorrection(i + 1) - o.max_correction(i + 1)) < TOL_X
-        x, v = [], []
-        for k in range(blocks):
-            x.append(a.block_estimates(k))
-            v.append(a.block_variances_packed(k))
-            vo = o.block_variances(k)
-            assert np.abs(x[k] - o.block_estimates(k)).max() < TOL_X, (tag, k)
-            assert np.abs(v[k] - vo).max() / np.abs(vo).max() < TOL_V, (tag, k)
-        a.GenerateStatistics()
-        assert abs(a.GetChiSquared() - ostat.chi_squared) / ostat.chi_squared < 1e-7
-        res[tag] = (x, v, a.algorithmic_flops())
-        a.close()
-    assert res["runs"][2] > res["plain"][2]                 # (the merges of the runs are work the plain chains do not have)
-    for k in range(blocks):
-        assert np.abs(res["runs"][0][k] - res["plain"][0][k]).max() < 5e-9      # (a few units in the last place of a 4e6 m coordinate)
-    o.close()
-
-
 @pytest.mark.parametrize("schur", [True, False])
 def test_one_rank_over_rccl(built, orc, tmp_path, schur, monkeypatch):
     """the RCCL transport itself on the one GPU this box has: communicator, in-place broadcasts, all-reduces"""

@@ -150,56 +150,6 @@ def test_dense_inverse_against_oracle_beyond_the_small_launch_threshold(gpu_ctx,
     assert np.abs(y - x).max() < 1e-10
 
 
-def test_paired_tile_walk_gives_the_same_inverse(built, gpu_ctx):
-    """opt-in tables in which a workgroup computes two tiles of complementary k length, the second walked towards the common end
-    (tile_order.hip): other summation order inside those tiles, same inverse to rounding.  n = 8 200: T = 65, the LAUUM (8 x 8 patches)
-    and the top-level triangular products (4 x 4 patches) are paired"""
-    from dynadjust_amd.device import DeviceContext
-    n = 8200
-    M = _dense_spd(n, 5)
-    ap = pack_lower(M)
-    ref = gpu_ctx.cholesky_inverse_packed(ap, n)
-    old = built.dnagpu_debug_set_pair_tiles(64)
-    try:
-        with DeviceContext(0) as ctx:                       # (tables are cached per context and shape: a fresh one builds paired tables)
-            inv = ctx.cholesky_inverse_packed(ap, n)
-    finally:
-        built.dnagpu_debug_set_pair_tiles(old)
-    d = np.abs(inv - ref).max() / np.abs(ref).max()
-    assert 0.0 < d < 1e-12, d                               # not the same bits (or the pairs did not happen), the same numbers
-    rng = np.random.default_rng(1)
-    x = rng.standard_normal(n)
-    assert np.abs(unpack_lower(inv, n) @ (M @ x) - x).max() < 1e-10
-
-
-@pytest.mark.parametrize("n", [200, 257, 640, 1000, 1500, 2304])
-def test_fused_small_launches_are_bit_identical(built, n):
-    """runs of small products go out as one launch of a persistent kernel with device-wide barriers in between
-    (la_kernels.h, gemm_f64_fused_kernel): the same tile code on the same tiles -- the inverse must not change by a bit -- in fewer
-    launches than products"""
-    import ctypes as C
-    from dynadjust_amd.device import DeviceContext
-    M = _dense_spd(n, 7 * n)
-    ap = pack_lower(M)
-    out = {}
-    for fused in (1, 0):
-        ctx = DeviceContext(0)
-        try:
-            assert built.dnagpu_set_fused_launches(ctx.h, fused) == 0
-            out[fused] = ctx.cholesky_inverse_packed(ap, n)
-            l, p = C.c_uint64(), C.c_uint64()
-            built.dnagpu_fused_stats(ctx.h, C.byref(l), C.byref(p))
-            if fused and n > 256:
-                assert 0 < l.value < p.value, (l.value, p.value)
-            if not fused:
-                assert l.value == 0
-        finally:
-            ctx.close()
-    assert np.array_equal(out[0], out[1])
-    inv = unpack_lower(out[1], n)
-    assert np.abs(inv @ M - np.eye(n)).max() < 1e-10
-
-
 def test_failed_allocation_inside_an_inverse_is_reported(built):
     """a tile-table allocation failing in the middle of the recursion must come back as DNAGPU_ENOMEM (never DNAGPU_OK with a
     skipped launch), and the context must work again afterwards"""
