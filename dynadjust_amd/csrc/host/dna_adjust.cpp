@@ -864,6 +864,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     for (block_t& b : blocks_) {
         b.inverse_kept = b.inverse_pending = b.part_valid = b.rig_direct = b.var_deferred = false;
         b.factor_live = b.factor_reused = b.cfac_live[0] = b.cfac_live[1] = false;      // (a.reuse_factors: within one adjustment only)
+        b.red_iter = 0;
     }
     factor_reuses_ = chain_reuses_ = 0;
     osc_ready_ = false;              // corrPrev_ / stnOscCount_ / oscHistory_ start empty (ADJ:2419-2421, 2584-2586)
@@ -1112,8 +1113,11 @@ void dna_adjust::ResetAdjustment() {
         blocks_[b].part_transient = false;
         blocks_[b].fac_packed = false;
         blocks_[b].factor_live = blocks_[b].factor_reused = blocks_[b].cfac_live[0] = blocks_[b].cfac_live[1] = false;
+        blocks_[b].red_iter = 0;
     }
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
+    osc_ready_ = false;              // (a second adjustment on the handle must not compare with the first one's corrections)
+    oscHistory_.clear();
     currentIteration_ = 0;
     maxCorr_ = 0.0;
     iterationCorrections_.clear();
@@ -1499,10 +1503,9 @@ void dna_adjust::DeSerialiseAdjustedVarianceMatrices() {
         rva.read(reinterpret_cast<char*>(packed.data()), (std::streamsize)(packed.size() * sizeof(double)));
         rva.read(reinterpret_cast<char*>(tail), sizeof(tail));
         if (phased && Staged()) {
-            if (!blocks_[b].rig_host)
-                Check(blocks_[b].rig_on_device ? dnagpu_device_alloc(ctx_, packed.size() * sizeof(double), (void**)&blocks_[b].rig_host)
-                                               : dnagpu_host_alloc(ctx_, packed.size() * sizeof(double), (void**)&blocks_[b].rig_host),
-                      b, "rigorous variance matrix (staged)");
+            // (through the staged store's own allocation: a device slot is sized for the block's packed factor as well, which a later
+            //  adjustment on this handle may park there -- ADVICE r4)
+            if (!blocks_[b].rig_host) AllocateStagedSlot(b);
             Check(dnagpu_copy(ctx_, blocks_[b].rig_host, packed.data(), packed.size() * sizeof(double)), b, "DeSerialiseAdjustedVarianceMatrices()");
         } else {
             dnagpu_matrix** slot = phased ? &blocks_[b].rigvar : &work_[0];

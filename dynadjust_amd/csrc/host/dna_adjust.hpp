@@ -250,6 +250,10 @@ private:
         // `part` -- later iterations reduce and solve right-hand sides with it (CondenseBlock / CompleteFromPartial) and factor nothing
         bool factor_live = false;
         bool factor_reused = false;           // this iteration's condensing step took the kept factor (no flops to count in the rigorous solve)
+        // a block WITHOUT a kept factor (HBM budget): the rigorous solve of iteration i, which has just made (or unpacked) the factor, also
+        // reduces the right-hand side of iteration i + 1 with it -- the block's next meas-minus-computed depends on its own rigorous
+        // estimates only --, so that iteration i + 1 needs no condensing step of its own: red_iter = the iteration red's vector is for
+        UINT32 red_iter = 0;
         // ... and the factors of the two chain steps on the block's condensed system (0: forward, 1: reverse), kept while the budget
         // lasts (chain_fac_budget_); live: made in an earlier iteration of this adjustment
         dnagpu_partial* cfac[2] = {nullptr, nullptr};

@@ -248,8 +248,9 @@ void dna_adjust::AllocateStagedSlot(UINT32 k) {
     }
     // (the plan left a fifth of the host's limit free; if something else has taken it since, a clean failure here is better than the
     //  container's memory limit ending the process -- and, on the pool's boxes, the box)
-    const double bytes = (double)(n * (n + 1) / 2 * sizeof(double));
-    if (HostMemoryAvailable() < bytes + 8.0e9)
+    // (margin: 8 GB on a large host, a fifth of what is left on a small one -- a tiny network must not fail for want of 8 GB: ADVICE r4)
+    const double bytes = (double)(n * (n + 1) / 2 * sizeof(double)), avail = HostMemoryAvailable();
+    if (avail < bytes + std::min(8.0e9, 0.2 * avail))
         SignalExceptionAdjustment("UpdateEstimatesFinal(): the host's memory limit leaves no room for the staged variance matrices.", k);
     Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
 }
@@ -694,7 +695,14 @@ void dna_adjust::PrepareCondensedBlocks() {
     for (UINT32 k = 0; k < blockCount_; ++k)
         if (OwnsBlock(k)) rig += sq(3.0 * (double)v_parameterStationList_[k].size());
     // (a device slot of the staged store is allocated with room for the block's packed factor: n + 256 rows, AllocateStagedSlot)
-    later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? 1.03 * (double)stage_device_bytes_ : rig);
+    // (a device slot is allocated with n + 256 rows: + 2 x 256 / n of its matrix, 9 % at n = 6 000 and 2 % at n = 27 000 -- budgeted as allocated)
+    double dev_slots = 0.0;
+    for (UINT32 k = 0; k < blockCount_; ++k)
+        if (OwnsBlock(k) && blocks_[k].rig_on_device) {
+            const double n = 3.0 * (double)v_parameterStationList_[k].size();
+            dev_slots += (n + 256.0) * (n + 257.0) / 2.0 * 8.0;
+        }
+    later += 3.0 * (double)NumChains() * sq((double)max_unknowns_) + (staged_ ? dev_slots : rig);
     double budget = (double)free_b - later;
     if (const char* e = getenv("DNAGPU_FACTOR_BUDGET_GB")) budget = atof(e) * 1.0e9;      // (test hook: the memory-tight plans at any size)
     // Blocks the budget denies a kept factor do not fall back to an inverse per iteration any more (n^3, and its copy to the staged store):
@@ -755,6 +763,17 @@ void dna_adjust::PrepareCondensedBlocks() {
 
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
     block_t& B = blocks_[k];
+    if (!B.keep.empty() && !B.part && B.red_iter == currentIteration_ && currentIteration_ >= 2 && FactorReuse()) {
+        // a.reuse_factors, a block that keeps no factor: the previous iteration's rigorous solve reduced this iteration's right-hand side
+        // already, with the factor it had in hand (RigorousBlock); the complement in red is that of every iteration.  A factor packed in
+        // the block's HBM slot (fac_packed) stays there for the rigorous solve.
+        B.rig_direct = false;
+        B.part_transient = false;
+        B.var_deferred = false;
+        B.prefactored = false;
+        factor_reuses_++;
+        return;
+    }
     B.rig_direct = false;
     B.part_transient = false;
     B.fac_packed = false;
@@ -1381,10 +1400,25 @@ double dna_adjust::RigorousBlock(int c, UINT32 k) {
             B.part_spine = false;
         }
     } guard{B, borrowed};
-    if (meta._blockLast || meta._blockIsolated) return PhasedForwardBlock(c, k);   // notes its correction and stores the variances itself
-    double mv = meta._blockFirst ? PhasedReverseBlock(c, k) : PhasedCombineBlock(c, k);
-    PhasedNoteCorrection(mv);
-    PhasedFinaliseBlock(c, k);
+    double mv;
+    if (meta._blockLast || meta._blockIsolated) {
+        mv = PhasedForwardBlock(c, k);   // notes its correction and stores the variances itself
+    } else {
+        mv = meta._blockFirst ? PhasedReverseBlock(c, k) : PhasedCombineBlock(c, k);
+        PhasedNoteCorrection(mv);
+        PhasedFinaliseBlock(c, k);
+    }
+    if (borrowed && B.part && B.part_spine && FactorReuse()) {
+        // The factor is about to go back to the chain.  The NEXT iteration's right-hand side of this block depends on nothing but the block's
+        // own rigorous estimates, which exist now: meas-minus-computed, right-hand side and its reduction by substitution with the factor
+        // in hand -- the next iteration then needs no condensing step (and no second elimination) for this block.  Wasted only when this
+        // iteration turns out to be the last (three matrix-vector passes over the factor).
+        Check(dnagpu_block_compute_b(ctx_, c, k), k, "UpdateAdjustment()");
+        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
+        Check(dnagpu_partial_reduce_rhs(ctx_, c, k, B.part, B.red), k, "Solve()");
+        Check(dnagpu_chain_sync(ctx_, c), k, "Solve()");        // (the chain's factor storage goes to its next block)
+        B.red_iter = currentIteration_ + 1;
+    }
     return mv;
 }
 
@@ -1550,6 +1584,17 @@ void dna_adjust::ImportCondensed(UINT32 k, const double* src) {
 
 void dna_adjust::PhasedBeginIteration() {
     if (!CondensedSchedule()) FinishStagedCopies();
+    if (currentIteration_ == 0) {
+        // the first iteration of an adjustment driven step by step (include/dnaadjust_c.h dnaadj_phased_*, which never passes through
+        // AdjustNetwork): factors kept by an earlier adjustment are not this one's, and the oscillation diagnostics start empty
+        for (block_t& b : blocks_) {
+            b.factor_live = b.factor_reused = b.cfac_live[0] = b.cfac_live[1] = false;
+            b.red_iter = 0;
+        }
+        factor_reuses_ = chain_reuses_ = 0;
+        osc_ready_ = false;
+        oscHistory_.clear();
+    }
     maxCorr_ = 0.0;
     ++currentIteration_;
 }

@@ -290,6 +290,10 @@ class DeviceContext:
         ix, p = _u32(idx_to)
         self._chk(self.lib.dnagpu_junction_rhs(self.h, chain, blk_to, p, ix.size, jm.h))
 
+    def junction_put_estimates(self, jm, est, chain=0):
+        e = np.ascontiguousarray(est, dtype=np.float64)
+        self._chk(self.lib.dnagpu_junction_put_estimates(self.h, chain, jm.h, e.ctypes.data_as(c_f64p), e.size // 3))
+
     def junction_get_estimates(self, jm, chain=0):
         out = np.empty(jm.n, dtype=np.float64)
         self._chk(self.lib.dnagpu_junction_get_estimates(self.h, chain, jm.h, out.ctypes.data_as(c_f64p)))

@@ -135,11 +135,13 @@ def test_cfg3_condensed_schedule_equals_reference_schedule(built, tmp_path):
 
 
 def test_cfg2_against_the_oracle(built, orc, tmp_path):
-    """BASELINE.json configs[1]: 10 000 stations, simultaneous, one n = 30 000 inverse -- against the oracle with the MKL
-    runtime (the LAPACK the reference links), every coordinate and every variance element"""
+    """BASELINE.json configs[1]: 10 000 stations, simultaneous, one n = 30 000 inverse -- against the oracle with a threaded LAPACK behind its
+    dpotrf / dpotri (the reference links whichever the host has: MKL, OpenBLAS ... -- here the OpenBLAS of the scipy wheel where present: on
+    the pool's non-Intel hosts the MKL runtime is several times slower, 97 s of the suite), every coordinate and every variance element"""
     info, phased = _write(tmp_path, "cfg2")
-    if not orc.use_mkl(True):
-        pytest.skip("needs the MKL runtime: the built-in Cholesky takes hours at n = 30 000")
+    fast = orc.scipy_openblas_path()
+    if not ((fast and orc.use_lapack(fast)) or orc.use_mkl(True)):
+        pytest.skip("needs a threaded LAPACK: the built-in Cholesky takes hours at n = 30 000")
     try:
         orc.load().orc_set_threads(min(os.cpu_count() or 1, 64))
         net = orc.Network(str(tmp_path / "net"), phased)

@@ -378,13 +378,21 @@ def test_light_kept_factor(gpu_ctx, built, orc, tmp_path, rows, cols, pick):
         x_ref = (ref @ rhs).reshape(x_factor.shape)
         scale = max(1e-30, np.abs(x_ref).max())
         assert np.abs(x_factor - x_ref).max() < 1e-9 * scale, np.abs(x_factor - x_ref).max() / scale
-    with pytest.raises(Exception):
-        gpu_ctx.partial_reduce_rhs(0, pf, red)                              # (needs the inverse of the eliminated part: the full form only)
+    # round 5 (a.reuse_factors): the light form reduces a right-hand side as well -- the forward half of the blocked substitution with the
+    # kept factor gives what the elimination's passenger row gave: the reduced right-hand side of the complement
+    r_elim = gpu_ctx.junction_get_estimates(red0).copy()
+    gpu_ctx.junction_put_estimates(red, np.zeros(nk))
+    gpu_ctx.partial_reduce_rhs(0, pf, red)
+    gpu_ctx.sync()
+    r_subst = gpu_ctx.junction_get_estimates(red)
+    assert np.abs(r_subst - r_elim).max() < 1e-9 * max(1.0, np.abs(r_elim).max())
     gpu_ctx.partial_finish(pf, store, n0)                                   # the lender receives the inverse
     got = unpack_lower(store.download_packed(), n0)
     assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
     with pytest.raises(Exception):
         gpu_ctx.partial_finish(pf, store, n0)
+    with pytest.raises(Exception):
+        gpu_ctx.partial_reduce_rhs(0, pf, red)                              # (the factor has become the inverse)
     gpu_ctx.partial_destroy(pf)
     for q in (m, red0, red, kk, store):
         q.close()
