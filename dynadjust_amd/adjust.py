@@ -323,6 +323,10 @@ class DnaAdjust:
         """of algorithmic_flops(): every factorisation once + the variance matrices once -- nothing that was done again"""
         return float(self.lib.dnaadj_minimal_work_flops(self.h))
 
+    def small_batch_steps(self):
+        """of factor_reuses(): block steps that went out as one launch over many small blocks (dnagpu_small_batch_*)"""
+        return int(self.lib.dnaadj_small_batch_steps(self.h))
+
     def chain_step_reuses(self):
         return int(self.lib.dnaadj_chain_step_reuses(self.h))
 

@@ -35,6 +35,15 @@ struct dnagpu_partial {
     bool factored = false;   // dnagpu_partial_complete_factor done: X = L^-1 of the WHOLE block (elimination order); the inverse itself is pending
 };
 
+// dnagpu_small_batch_*: the device-side table of many small blocks' per-iteration steps (small_steps.h) and what it owns
+struct dnagpu_small_batch {
+    uint32_t n = 0;
+    void* table = nullptr;                // SmallBlockDesc[n], device
+    double* result = nullptr;             // 2 n doubles, device
+    double* result_host = nullptr;        // ... and their page-locked landing zone
+    std::vector<uint32_t*> idx_dev;       // the junction station lists, device copies owned by the batch
+};
+
 namespace dnagpu {
 
 struct Block {

@@ -2074,6 +2074,119 @@ int dnagpu_chain_step_rhs(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t sr
     return DNAGPU_OK;
 }
 
+void dnagpu_small_batch_destroy(dnagpu_ctx* ctx, dnagpu_small_batch* sb) {
+    if (!sb) return;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+    }
+    if (sb->table) hipFree(sb->table);
+    if (sb->result) hipFree(sb->result);
+    if (sb->result_host) hipHostFree(sb->result_host);
+    for (uint32_t* p : sb->idx_dev) hipFree(p);
+    delete sb;
+}
+
+int dnagpu_small_batch_create(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, dnagpu_partial* const* pf, dnagpu_matrix* const* red,
+                              const dnagpu_matrix* const* j0, const uint32_t* const* idx0, const size_t* k0, const dnagpu_matrix* const* j1,
+                              const uint32_t* const* idx1, const size_t* k1, const int* last, dnagpu_small_batch** out) {
+    CHK_CTX();
+    if (!out || !n || !blks || !pf || !red || !j0 || !idx0 || !k0 || !j1 || !idx1 || !k1 || !last)
+        return fail(ctx, DNAGPU_EINVAL, "small_batch_create: bad arguments");
+    *out = nullptr;
+    std::vector<SmallBlockDesc> host(n);
+    dnagpu_small_batch* sb = new (std::nothrow) dnagpu_small_batch();
+    if (!sb) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    auto bail = [&](int rc) {
+        dnagpu_small_batch_destroy(ctx, sb);
+        return rc;
+    };
+    if (dnagpu::poison_malloc(&sb->result, (size_t)2 * n * sizeof(double)) != hipSuccess || hipHostMalloc(&sb->result_host, (size_t)2 * n * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        return bail(fail(ctx, DNAGPU_ENOMEM, "small_batch_create: result buffers"));
+    }
+    for (uint32_t q = 0; q < n; ++q) {
+        Block* b = find_block(ctx, blks[q]);
+        const dnagpu_partial* p = pf[q];
+        if (!b || !p || !red[q]) return bail(fail(ctx, DNAGPU_EINVAL, "small_batch_create: bad arguments"));
+        // (limits of the one-workgroup kernels; terrestrial rows and direction sets have no place in a reuse iteration)
+        const std::vector<std::pair<int, int>> blocks = sym_spine_blocks((int)(p->nip / 128));
+        if (!p->spine || !p->factored || p->n != 3 * b->n_stn || red[q]->n != p->nj || p->npp > SMALL_STEP_MAX || 3 * b->n_stn > SMALL_STEP_MAX ||
+            blocks.size() > (size_t)SMALL_STEP_BLOCKS || b->n_t || b->n_dsblk)
+            return bail(DNAGPU_ETOOLARGE);
+        if (last[q] && !b->corr_keep && dnagpu::poison_malloc(&b->corr_keep, (size_t)b->n_stn * 3 * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            b->corr_keep = nullptr;
+            return bail(fail(ctx, DNAGPU_ENOMEM, "small_batch_create: corrections set aside"));
+        }
+        SmallBlockDesc& d = host[q];
+        memset(&d, 0, sizeof(d));
+        d.wblk = b->Wblk; d.vec_wrow = b->vec_wrow; d.vec_c0 = b->vec_c0; d.vec_k = b->vec_k; d.n_vec = b->n_bl;
+        d.inc_off = b->inc_off; d.inc = b->inc; d.b = b->b[0];
+        d.wb = b->wb[0]; d.rhs = b->rhs[0]; d.corr = b->corr[0]; d.corr_keep = last[q] ? b->corr_keep : nullptr;
+        d.x_orig = b->x_orig; d.x_est = b->x_est[0]; d.x_rig = b->x_rig; d.n_stn = b->n_stn;
+        d.X = p->X; d.map = p->map; d.npp = p->npp; d.nip = p->nip; d.nj = p->nj;
+        d.nblocks = (int)blocks.size();
+        for (size_t e = 0; e < blocks.size(); ++e) {
+            d.blk_o[e] = (uint32_t)blocks[e].first * 128;
+            d.blk_h[e] = (uint32_t)blocks[e].second * 128;
+        }
+        d.red_rhs = red[q]->jest;
+        const dnagpu_matrix* jm[2] = {j0[q], j1[q]};
+        const uint32_t* ix[2] = {idx0[q], idx1[q]};
+        const size_t kk[2] = {k0[q], k1[q]};
+        for (int e = 0; e < 2; ++e) {
+            if (!jm[e]) continue;
+            if (!ix[e] || jm[e]->n != 3 * kk[e] || jm[e]->form != 1 || !jm[e]->jrhs || 3 * kk[e] > SMALL_STEP_MAX) return bail(DNAGPU_ETOOLARGE);
+            for (size_t i = 0; i < kk[e]; ++i)
+                if (ix[e][i] >= b->n_stn) return bail(fail(ctx, DNAGPU_EINVAL, "small_batch_create: station out of range"));
+            uint32_t* dev = nullptr;
+            if (dnagpu::poison_malloc(&dev, kk[e] * sizeof(uint32_t)) != hipSuccess ||
+                hipMemcpy(dev, ix[e], kk[e] * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipGetLastError();
+                if (dev) hipFree(dev);
+                return bail(fail(ctx, DNAGPU_ENOMEM, "small_batch_create: station lists"));
+            }
+            sb->idx_dev.push_back(dev);
+            d.J[e] = jm[e]->F; d.jest[e] = jm[e]->jest; d.jrhs[e] = jm[e]->jrhs; d.jidx[e] = dev; d.jk[e] = (uint32_t)kk[e]; d.jnp[e] = jm[e]->np;
+        }
+        d.last = last[q] ? 1u : 0u;
+        d.result = sb->result + 2 * (size_t)q;
+    }
+    if (dnagpu::poison_malloc(&sb->table, (size_t)n * sizeof(SmallBlockDesc)) != hipSuccess ||
+        hipMemcpy(sb->table, host.data(), (size_t)n * sizeof(SmallBlockDesc), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return bail(fail(ctx, DNAGPU_ENOMEM, "small_batch_create: block table"));
+    }
+    sb->n = n;
+    *out = sb;
+    return DNAGPU_OK;
+}
+
+int dnagpu_small_batch_condense(dnagpu_ctx* ctx, int chain, dnagpu_small_batch* sb) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!sb || !sb->n) return fail(ctx, DNAGPU_EINVAL, "small_batch_condense: bad arguments");
+    gemm_profile_close(ctx->ws[chain]);
+    launch_small_condense((const SmallBlockDesc*)sb->table, sb->n, ctx->stream[chain]);
+    HIPCHK(hipGetLastError());
+    return DNAGPU_OK;
+}
+
+int dnagpu_small_batch_solve(dnagpu_ctx* ctx, int chain, dnagpu_small_batch* sb, double* max_corr) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!sb || !sb->n || !max_corr) return fail(ctx, DNAGPU_EINVAL, "small_batch_solve: bad arguments");
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ctx->ws[chain]);
+    launch_small_solve((const SmallBlockDesc*)sb->table, sb->n, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sb->result_host, sb->result, (size_t)2 * sb->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint32_t q = 0; q < sb->n; ++q) max_corr[q] = sb->result_host[2 * (size_t)q];
+    return DNAGPU_OK;
+}
+
 int dnagpu_partial_create(dnagpu_ctx* ctx, uint32_t n_max, uint32_t k_max, dnagpu_partial** out) {
     CHK_CTX();
     if (!out || !k_max || k_max > n_max) return fail(ctx, DNAGPU_EINVAL, "partial_create: bad arguments");

@@ -34,6 +34,10 @@ dna_adjust::~dna_adjust() {
 
 void dna_adjust::FreeDevice() {
     if (!ctx_) return;
+    if (small_batch_) dnagpu_small_batch_destroy(ctx_, small_batch_);       // (before what it refers to: factors, junction matrices, blocks)
+    small_batch_ = nullptr;
+    small_batch_blocks_.clear();
+    small_batch_denied_ = small_batch_armed_ = false;
     FreeTwoLevel();
     if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);
     xbuf_dev_ = nullptr;
@@ -867,6 +871,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
         b.red_iter = 0;
     }
     factor_reuses_ = chain_reuses_ = 0;
+    small_batch_steps_ = 0;
     osc_ready_ = false;              // corrPrev_ / stnOscCount_ / oscHistory_ start empty (ADJ:2419-2421, 2584-2586)
     oscHistory_.clear();
     const double t0 = now_ms();

@@ -461,6 +461,15 @@ private:
                projectSettings_.a.defer_variances >= 2;
     }
     double chain_fac_budget_ = 0.0;         // HBM set aside for the chain steps' kept factors (PrepareCondensedBlocks)
+    // a.reuse_factors, many small blocks (a dnasegment-default cut): the per-block steps of iterations >= 2 as ONE launch over all of them
+    // (dnagpu_small_batch_*: a device-side table of the blocks' vectors, kept factors and carried junctions).  Made on first use for the set
+    // of blocks at hand; SmallBatchCondense marks the blocks it served, SmallBatchSolve takes exactly those.
+    dnagpu_small_batch* small_batch_ = nullptr;
+    std::vector<UINT32> small_batch_blocks_;
+    bool small_batch_denied_ = false, small_batch_armed_ = false;
+    std::atomic<uint64_t> small_batch_steps_{0};               // block steps served that way since AdjustNetwork() began
+    bool SmallBatchCondense(std::vector<UINT32>& blocks);     // serves what it can; `blocks` keeps the rest
+    void SmallBatchSolve(std::vector<UINT32>& blocks);
     std::atomic<uint64_t> factor_reuses_{0}, chain_reuses_{0};    // block steps / chain steps served from a kept factor since AdjustNetwork() began
     // a chain step on the condensed block of k: elimination with the factor kept (first time) or its right-hand side through the kept factor
     void CarryCondensed(int chain, UINT32 dev_block, UINT32 block, int dir, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm);
@@ -469,6 +478,7 @@ private:
 public:
     uint64_t FactorReuses() const { return factor_reuses_.load(); }
     uint64_t ChainStepReuses() const { return chain_reuses_.load(); }
+    uint64_t SmallBatchSteps() const { return small_batch_steps_.load(); }
 private:
     void FinishDeferredVariances();
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);

@@ -1450,8 +1450,9 @@ void dna_adjust::FinishVariancesTransient(int c, UINT32 k) {
     Check(dnagpu_chain_sync(ctx_, c), k, "UpdateEstimatesFinal()");
     const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size(), ni = n - nk;
     std::lock_guard<std::mutex> lk(corr_mutex_);
-    CountFlops(nk * nk * nk * 2.0 / 3.0 + n * n * n / 3.0, 1);
-    if (!unpacked) CountFlops(ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk, 2);
+    const double elim = ni * ni * ni / 3.0 + ni * ni * nk + ni * nk * nk;
+    CountFlops(nk * nk * nk * 2.0 / 3.0 + elim + n * n * n / 3.0, 1);     // kept block, L^-1 out of the light factor (the same count as the elimination), X^T X
+    if (!unpacked) CountFlops(elim, 2);
 }
 
 // body(chain) on every chain in use (a.multi_thread: two host threads, one per chain); the first exception is rethrown
@@ -1504,8 +1505,123 @@ void dna_adjust::ForBlocks(const std::vector<UINT32>& blocks, const std::functio
     });
 }
 
-void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks) {
+// The small-block fast path of iterations >= 2 (a.reuse_factors): every block of the list that still holds its completed light factor of
+// iteration 1, all of them small enough for the one-workgroup kernels, in one launch.  false: nothing done (too few blocks, a block beyond
+// the kernels' limits, no memory): the per-block path takes them.
+bool dna_adjust::SmallBatchCondense(std::vector<UINT32>& blocks) {
+    small_batch_armed_ = false;
+    if (!FactorReuse() || currentIteration_ < 2 || small_batch_denied_ || !dnagpu_info_carry()) return false;
+    std::vector<UINT32> E, rest;
+    for (UINT32 k : blocks) {
+        const block_t& B = blocks_[k];
+        // (the one-workgroup kernels hold a block's vectors in LDS: padded order of the factor and the block's unknowns up to 2 048)
+        const bool small = B.shape_ni + B.shape_nk <= 2048u && 3 * v_parameterStationList_[k].size() <= 2048u && 3 * B.jsl_here.size() <= 2048u &&
+                           3 * B.jslprev_here.size() <= 2048u;
+        (small && B.factor_live && B.part && B.part_spine && !B.part_transient && !B.keep.empty() ? E : rest).push_back(k);
+    }
+    if (E.size() < 32) return false;          // (a handful of blocks: the chains serve them as fast)
+    if (small_batch_ && E != small_batch_blocks_) {
+        dnagpu_small_batch_destroy(ctx_, small_batch_);
+        small_batch_ = nullptr;
+    }
+    if (!small_batch_) {
+        const size_t n = E.size();
+        std::vector<dnagpu_partial*> pf(n);
+        std::vector<dnagpu_matrix*> red(n);
+        std::vector<const dnagpu_matrix*> j0(n, nullptr), j1(n, nullptr);
+        std::vector<const UINT32*> i0(n, nullptr), i1(n, nullptr);
+        std::vector<size_t> k0(n, 0), k1(n, 0);
+        std::vector<int> last(n, 0);
+        for (size_t q = 0; q < n; ++q) {
+            const UINT32 k = E[q];
+            block_t& B = blocks_[k];
+            const blockMeta_t& meta = v_blockMeta_[k];
+            pf[q] = B.part;
+            red[q] = B.red;
+            const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
+            const bool fwd_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
+            // the order of PhasedForwardBlock (a last block: the forward junction only), PhasedReverseBlock (a first block: the reverse
+            // one only) and PhasedCombineBlock (reverse, then forward)
+            if (meta._blockLast || meta._blockIsolated) {
+                last[q] = 1;
+                if (fwd_in) { j0[q] = blocks_[k - 1].jfwd; i0[q] = B.jslprev_here.data(); k0[q] = B.jslprev_here.size(); }
+            } else {
+                if (rev_in) { j0[q] = B.jrev; i0[q] = B.jsl_here.data(); k0[q] = B.jsl_here.size(); }
+                if (!meta._blockFirst && fwd_in) { j1[q] = blocks_[k - 1].jfwd; i1[q] = B.jslprev_here.data(); k1[q] = B.jslprev_here.size(); }
+            }
+        }
+        const int rc = dnagpu_small_batch_create(ctx_, (uint32_t)n, E.data(), pf.data(), red.data(), j0.data(), i0.data(), k0.data(), j1.data(), i1.data(),
+                                                 k1.data(), last.data(), &small_batch_);
+        if (rc != DNAGPU_OK) {
+            small_batch_ = nullptr;
+            small_batch_denied_ = true;         // (a block beyond the kernels' limits, or no memory: the per-block path, for good)
+            return false;
+        }
+        small_batch_blocks_ = E;
+    }
+    Check(dnagpu_small_batch_condense(ctx_, 0, small_batch_), E.front(), "Solve()");
+    Check(dnagpu_chain_sync(ctx_, 0), E.front(), "Solve()");       // (the chains read the reduced right-hand sides on other streams)
+    for (UINT32 k : E) {
+        block_t& B = blocks_[k];
+        B.rig_direct = false;
+        B.var_deferred = false;
+        B.part_valid = true;
+        B.prefactored = true;
+        B.factor_reused = true;
+    }
+    factor_reuses_ += E.size();
+    small_batch_steps_ += E.size();
+    small_batch_armed_ = true;
+    blocks.swap(rest);
+    return true;
+}
+
+void dna_adjust::SmallBatchSolve(std::vector<UINT32>& blocks) {
+    if (!small_batch_armed_ || !small_batch_) return;
+    small_batch_armed_ = false;
+    // exactly the blocks the condensing step served must come back (they do: both lists are "all blocks" or "the own blocks")
+    std::vector<UINT32> rest;
+    size_t hit = 0;
+    for (UINT32 k : blocks) {
+        if (hit < small_batch_blocks_.size() && small_batch_blocks_[hit] == k)
+            ++hit;
+        else
+            rest.push_back(k);
+    }
+    if (hit != small_batch_blocks_.size()) {
+        // (not the same list: the blocks keep their flags -- part_valid, prefactored -- and the per-block path solves them from the kept factors)
+        return;
+    }
+    std::vector<double> mv(small_batch_blocks_.size());
+    Check(dnagpu_small_batch_solve(ctx_, 0, small_batch_, mv.data()), small_batch_blocks_.front(), "Solve()");
+    for (size_t q = 0; q < small_batch_blocks_.size(); ++q) {
+        const UINT32 k = small_batch_blocks_[q];
+        block_t& B = blocks_[k];
+        const blockMeta_t& meta = v_blockMeta_[k];
+        B.part_valid = false;
+        B.prefactored = false;
+        B.factor_reused = false;
+        B.var_deferred = true;          // (the variance matrix is still owed: FinishDeferredVariances)
+        B.has_rigvar = false;
+        B.factor_live = true;
+        B.corr_chain = (meta._blockLast || meta._blockIsolated) ? -1 : 0;
+        const double n = 3.0 * (double)v_parameterStationList_[k].size();
+        {
+            std::lock_guard<std::mutex> lk(corr_mutex_);
+            solve_flops_ += n * n * n;
+            solve_count_++;
+            completion_count_++;
+        }
+        PhasedNoteCorrection(mv[q]);
+    }
+    currentBlock_ = small_batch_blocks_.back();
+    blocks.swap(rest);
+}
+
+void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks_in) {
     forward_ = true;
+    std::vector<UINT32> blocks = blocks_in;
+    SmallBatchCondense(blocks);
     if (BatchCap() < 2) {
         ForBlocks(blocks, [&](int c, UINT32 k) { CondenseBlock(c, k); });
         return;
@@ -1529,10 +1645,12 @@ void dna_adjust::CondensedChains() {
     });
 }
 
-void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks) {
+void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks_in) {
     FinishStagedCopies();          // (the previous iteration's: their host buffers are about to be written again)
     forward_ = false;
     isCombining_ = true;
+    std::vector<UINT32> blocks = blocks_in;
+    SmallBatchSolve(blocks);
     if (BatchCap() >= 2) ForGroups(BatchGroups(blocks, 1), [&](int c, const std::vector<UINT32>& ks) { RigorousBatch(c, ks); });
     if (!IsCancelled()) ForBlocks(blocks, [&](int c, UINT32 k) { RigorousBlock(c, k); });
     isCombining_ = false;

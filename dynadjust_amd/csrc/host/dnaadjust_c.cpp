@@ -330,6 +330,7 @@ uint32_t dnaadj_completion_count(const dnaadj_handle* h) { return h && h->adj ? 
 uint32_t dnaadj_elimination_count(const dnaadj_handle* h) { return h && h->adj ? h->adj->eliminationCount() : 0; }
 double dnaadj_minimal_work_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->minimalWorkFlops() : 0.0; }
 uint64_t dnaadj_factor_reuses(const dnaadj_handle* h) { return h && h->adj ? h->adj->FactorReuses() : 0; }
+uint64_t dnaadj_small_batch_steps(const dnaadj_handle* h) { return h && h->adj ? h->adj->SmallBatchSteps() : 0; }
 uint64_t dnaadj_chain_step_reuses(const dnaadj_handle* h) { return h && h->adj ? h->adj->ChainStepReuses() : 0; }
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block) {

@@ -81,7 +81,210 @@ __device__ void wg_matvec(const double* __restrict__ A, uint32_t lda, uint32_t r
     __syncthreads();
 }
 
+// y[j] = base[j] + sign * sum_{i < rows, (LOWER: i >= j)} A[i + j * lda] * x[i],  j < cols: the transposed product.  A wave per column
+// (64 lanes x 8 B contiguous), four accumulators per lane, butterfly reduction: deterministic.  x, base, y: LDS (y may be base, not x).
+template <bool LOWER>
+__device__ void wg_matvec_t(const double* __restrict__ A, uint32_t lda, uint32_t rows, uint32_t cols, const double* x, const double* base, double sign,
+                            double* y) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t j = w; j < cols; j += NW) {
+        const double* col = A + (size_t)j * lda;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        uint32_t i = (LOWER ? (j & ~63u) : 0u) + lane;
+        for (; i + 192 < rows; i += 256) {
+            const double m0 = col[i], m1 = col[i + 64], m2 = col[i + 128], m3 = col[i + 192];
+            a0 += ((LOWER && i < j) ? 0.0 : m0) * x[i];
+            a1 += m1 * x[i + 64];
+            a2 += m2 * x[i + 128];
+            a3 += m3 * x[i + 192];
+        }
+        for (; i < rows; i += 64) a0 += ((LOWER && i < j) ? 0.0 : col[i]) * x[i];
+        double v = (a0 + a1) + (a2 + a3);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) y[j] = (base ? base[j] : 0.0) + sign * v;
+    }
+    __syncthreads();
+}
+
+// rhs (LDS, 3 n_stn) <- A^T W b of the block: wb(v) = sum_j' W(v, j') b(j') per vector (cluster_wb_kernel), then per station the signed sum
+// over its incident vectors in CML order (form_rhs_kernel) -- the same operations in the same order as the separate kernels
+__device__ void wg_form_rhs(const SmallBlockDesc& d, double* rhs) {
+    const int tid = threadIdx.x;
+    for (uint32_t t = tid; t < 3 * d.n_vec; t += NT) {
+        const uint32_t v = t / 3;
+        const int c = (int)(t - v * 3);
+        const uint32_t k = d.vec_k[v], c0 = d.vec_c0[v];
+        const double* row = d.wblk + (size_t)d.vec_wrow[v] * 9;
+        double acc = 0.0;
+        for (uint32_t jp = 0; jp < k; ++jp) {
+            const double* w = row + (size_t)jp * 9;
+            const double* bb = d.b + (size_t)(c0 + jp) * 3;
+            const double term = (w[c] * bb[0] + w[c + 3] * bb[1]) + w[c + 6] * bb[2];
+            acc = (jp == 0) ? term : acc + term;
+        }
+        d.wb[t] = acc;
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < 3 * d.n_stn; t += NT) {
+        const uint32_t s = t / 3;
+        const int c = (int)(t - s * 3);
+        double acc = 0.0;
+        for (uint32_t k = d.inc_off[s]; k < d.inc_off[s + 1]; ++k) {
+            const uint32_t e = d.inc[k];
+            const double v = d.wb[(size_t)(e >> 1) * 3 + c];
+            acc += (e & 1u) ? v : -v;
+        }
+        rhs[t] = acc;
+    }
+    __syncthreads();
+}
+
+// v (LDS, npp) <- rhs in the elimination's order, then the forward half of the blocked substitution (only what is not padding streams in)
+__device__ void wg_forward(const SmallBlockDesc& d, const double* rhs, double* v, double* t, double* part) {
+    const int tid = threadIdx.x;
+    for (uint32_t p = tid; p < d.npp; p += NT) {
+        const int32_t m = d.map[p];
+        v[p] = m >= 0 ? rhs[m] : 0.0;
+    }
+    __syncthreads();
+    const uint32_t ni = 3 * d.n_stn - d.nj, last = d.nip + d.nj;
+    for (int q = 0; q < d.nblocks; ++q) {
+        const uint32_t o = d.blk_o[q], h = d.blk_h[q];
+        if (o >= ni) break;
+        const uint32_t hr = min(h, ni - o), below = last - (o + h);
+        wg_matvec<true>(d.X + (size_t)o * d.npp + o, d.npp, hr, hr, v + o, nullptr, 1.0, t, part);
+        for (uint32_t i = tid; i < hr; i += NT) v[o + i] = t[i];
+        __syncthreads();
+        if (below) wg_matvec<false>(d.X + (size_t)o * d.npp + o + h, d.npp, below, hr, v + o, v + o + h, -1.0, v + o + h, part);
+    }
+}
+
 }  // namespace
+
+__global__ __launch_bounds__(NT) void small_condense_kernel(const SmallBlockDesc* __restrict__ table) {
+    __shared__ double rhs[SMALL_STEP_MAX], v[SMALL_STEP_MAX], t[SMALL_STEP_MAX], part[NW * 64];
+    const SmallBlockDesc& d = table[blockIdx.x];
+    const int tid = threadIdx.x;
+    wg_form_rhs(d, rhs);
+    for (uint32_t i = tid; i < 3 * d.n_stn; i += NT) d.rhs[i] = rhs[i];
+    wg_forward(d, rhs, v, t, part);
+    for (uint32_t i = tid; i < d.nj; i += NT) d.red_rhs[i] = v[d.nip + i];
+}
+
+__global__ __launch_bounds__(NT) void small_solve_kernel(const SmallBlockDesc* __restrict__ table) {
+    __shared__ double rhs[SMALL_STEP_MAX], v[SMALL_STEP_MAX], t[SMALL_STEP_MAX], u[SMALL_STEP_MAX], part[NW * 64];
+    __shared__ int any_dx;
+    __shared__ double best_v[NW];
+    __shared__ uint32_t best_i[NW];
+    const SmallBlockDesc& d = table[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n = 3 * d.n_stn;
+    // estimates back to the originals (PrepareAdjustmentReverse / ...Combine, ADJ:3157, 3863); a last block's forward solve starts from its estimates
+    if (!d.last)
+        for (uint32_t i = tid; i < n; i += NT) d.x_est[i] = d.x_orig[i];
+    if (tid == 0) any_dx = 0;
+    wg_form_rhs(d, rhs);            // (ends with a barrier: the estimates above are visible to the workgroup)
+    // the carried junctions, information form: rhs[their stations] += r + S (the estimates S and r were formed at - ours)
+    for (int q = 0; q < 2; ++q) {
+        if (!d.J[q]) continue;
+        const uint32_t nj = 3 * d.jk[q];
+        int mine = 0;
+        for (uint32_t j = tid; j < nj; j += NT) {
+            const double dx = d.jest[q][j] - d.x_est[3 * d.jidx[q][j / 3] + j % 3];
+            t[j] = dx;
+            mine |= dx != 0.0;
+        }
+        if (mine) any_dx = 1;
+        __syncthreads();
+        const bool nonzero = any_dx != 0;
+        __syncthreads();
+        if (tid == 0) any_dx = 0;
+        if (nonzero) {
+            wg_matvec<false>(d.J[q], d.jnp[q], nj, nj, t, nullptr, 1.0, u, part);
+        } else {
+            for (uint32_t j = tid; j < nj; j += NT) u[j] = 0.0;
+            __syncthreads();
+        }
+        for (uint32_t j = tid; j < nj; j += NT) rhs[3 * d.jidx[q][j / 3] + j % 3] += d.jrhs[q][j] + u[j];
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += NT) d.rhs[i] = rhs[i];
+    wg_forward(d, rhs, v, t, part);
+    // the kept block: v_K <- X_KK^T (X_KK v_K)
+    const uint32_t ni = n - d.nj, last = d.nip + d.nj;
+    {
+        const double* XK = d.X + (size_t)d.nip * d.npp + d.nip;
+        wg_matvec<true>(XK, d.npp, d.nj, d.nj, v + d.nip, nullptr, 1.0, t, part);
+        wg_matvec_t<true>(XK, d.npp, d.nj, d.nj, t, nullptr, 1.0, v + d.nip);
+    }
+    // backward: v_b <- X_bb^T (v_b - L_(below, b)^T v_below), from the last diagonal block of the eliminated part to the first
+    for (int q = d.nblocks - 1; q >= 0; --q) {
+        const uint32_t o = d.blk_o[q], h = d.blk_h[q];
+        if (o >= ni) continue;
+        const uint32_t hr = min(h, ni - o), below = last - (o + h);
+        if (below) {
+            wg_matvec_t<false>(d.X + (size_t)o * d.npp + o + h, d.npp, below, hr, v + o + h, v + o, -1.0, u);
+        } else {
+            for (uint32_t i = tid; i < hr; i += NT) u[i] = v[o + i];
+            __syncthreads();
+        }
+        wg_matvec_t<true>(d.X + (size_t)o * d.npp + o, d.npp, hr, hr, u, nullptr, 1.0, v + o);
+    }
+    // corrections in the block's own order; estimates += corrections; the correction of largest magnitude, first occurrence
+    // (matrix_2d::compute_maximum_value, MAT:1532); rigorous = estimated; original = rigorous (UpdateEstimatesFinal, ADJ:3744) but for a last block
+    for (uint32_t p = tid; p < d.npp; p += NT) {
+        const int32_t m = d.map[p];
+        if (m >= 0) rhs[m] = v[p];
+    }
+    __syncthreads();
+    double best = -1.0;
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t i = tid; i < n; i += NT) {
+        const double c = rhs[i];
+        d.corr[i] = c;
+        if (d.last) d.corr_keep[i] = c;
+        const double x = d.x_est[i] + c;
+        d.x_est[i] = x;
+        d.x_rig[i] = x;
+        if (!d.last) d.x_orig[i] = x;
+        const double a = fabs(c);
+        if (a > best) {
+            best = a;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const uint32_t oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        best_v[w] = best;
+        best_i[w] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < NW; ++q)
+            if (best_v[q] > best || (best_v[q] == best && best_i[q] < bi)) {
+                best = best_v[q];
+                bi = best_i[q];
+            }
+        d.result[0] = bi < n ? rhs[bi] : 0.0;
+        d.result[1] = (double)bi;
+    }
+}
+
+void launch_small_condense(const SmallBlockDesc* table, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(small_condense_kernel, dim3(n), dim3(NT), 0, s, table);
+}
+void launch_small_solve(const SmallBlockDesc* table, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(small_solve_kernel, dim3(n), dim3(NT), 0, s, table);
+}
 
 __global__ __launch_bounds__(NT) void chain_rhs_step_kernel(const ChainRhsStep a) {
     __shared__ double rhs[SMALL_STEP_MAX], xe[SMALL_STEP_MAX], v[SMALL_STEP_MAX], t[SMALL_STEP_MAX], part[NW * 64];

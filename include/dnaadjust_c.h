@@ -117,6 +117,9 @@ uint64_t dnaadj_factor_reuses(const dnaadj_handle* h);
  * networks; with terrestrial measurements every iteration's factorisations count) -- nothing that was done again */
 double dnaadj_minimal_work_flops(const dnaadj_handle* h);
 uint64_t dnaadj_chain_step_reuses(const dnaadj_handle* h);
+/* ... of the block steps, those that went out as one launch over many small blocks (dnagpu_small_batch_*: networks of 32 and more blocks
+ * of up to ~680 stations each -- a dnasegment-default cut) */
+uint64_t dnaadj_small_batch_steps(const dnaadj_handle* h);
 uint32_t dnaadj_station_count(const dnaadj_handle* h);
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block);

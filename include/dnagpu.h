@@ -332,6 +332,24 @@ int dnagpu_schur_carry_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, const uint3
 int dnagpu_chain_step_rhs(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t src_blk, const uint32_t* idx_keep, size_t k_keep, const dnagpu_matrix* red,
                           const dnagpu_matrix* jm_in, const uint32_t* idx_in, size_t k_in, dnagpu_matrix* jm_out, const uint32_t* idx_out, size_t k_out,
                           const dnagpu_partial* keep);
+/* The per-block steps of an iteration >= 2 (a.reuse_factors) for MANY small blocks as one launch each, a workgroup per block (small_steps.hip):
+ *   dnagpu_small_batch_condense   dnagpu_form_rhs + dnagpu_partial_reduce_rhs of every block of the batch (chain 0's vectors of the blocks)
+ *   dnagpu_small_batch_solve      every block's rigorous solve: estimates <- originals (not for a `last` block), right-hand side, + r + S dx of
+ *                                 the junctions j0 then j1 (information form; NULL: none; idx: their stations in the block), substitution with
+ *                                 the completed light factor pf, estimates += corrections, rigorous <- estimates, originals <- rigorous (not
+ *                                 for a last block, whose corrections are set aside like dnagpu_block_keep_corrections); max_corr[q] <- the
+ *                                 block's correction of largest magnitude.  What PhasedForwardBlock / ...ReverseBlock / ...CombineBlock +
+ *                                 UpdateEstimates* + UpdateEstimatesFinal do per block (dnaadjust.cpp:2812-3057, 3512-3800) for iterations >= 2.
+ * create: DNAGPU_ETOOLARGE (nothing made) when a block is beyond the one-workgroup kernels (padded order or junction > 2 048 unknowns,
+ * terrestrial rows, a factor that is not a completed light one): the caller keeps the per-block calls.  The batch refers to the blocks',
+ * factors' and junction matrices' storage: destroy it before any of them. */
+typedef struct dnagpu_small_batch dnagpu_small_batch;
+int dnagpu_small_batch_create(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, dnagpu_partial* const* pf, dnagpu_matrix* const* red,
+                              const dnagpu_matrix* const* j0, const uint32_t* const* idx0, const size_t* k0, const dnagpu_matrix* const* j1,
+                              const uint32_t* const* idx1, const size_t* k1, const int* last, dnagpu_small_batch** out);
+int dnagpu_small_batch_condense(dnagpu_ctx* ctx, int chain, dnagpu_small_batch* sb);
+int dnagpu_small_batch_solve(dnagpu_ctx* ctx, int chain, dnagpu_small_batch* sb, double* max_corr);
+void dnagpu_small_batch_destroy(dnagpu_ctx* ctx, dnagpu_small_batch* sb);
 /* The same elimination as a stand-alone step: red (order 3k) <- Schur complement of all other unknowns of m onto the k
  * listed stations (list order), red's attached vector <- the reduced right-hand side.  With the stations a block shares
  * with its neighbours as the list, this condenses the block to its junction stations ONCE per iteration, independently of

@@ -700,6 +700,41 @@ def test_factor_reuse_across_iterations(built, orc, tmp_path, mt, blocks):
         assert np.abs(v0[b] - v1[b]).max() <= 1e-13 * np.abs(v0[b]).max()
 
 
+@pytest.mark.parametrize("mt", [False, True])
+def test_many_small_blocks_in_one_launch(built, orc, tmp_path, mt):
+    """a dnasegment-like cut into 40 small blocks (strips of 2 rows of 24 stations; include/config/dnaoptions.hpp:382 makes 150-station blocks
+    by default): from iteration 2 on (a.reuse_factors) the condensing step and the rigorous solve of ALL blocks are one launch each
+    (dnagpu_small_batch_*: a workgroup per block), the chain steps one launch per step (dnagpu_chain_step_rhs).  Against the oracle, and
+    against the run in which every iteration factors again."""
+    info = adjust.write_synthetic_network(str(tmp_path), "m", 80, 24, 0, 1, seed=12, rows_lo=2, rows_hi=2, initial_sigma=0.3)
+    assert info["blocks"] == 40
+    net = orc.Network(str(tmp_path / "m"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "m", True, multi_thread=mt)
+    _compare(a, st, o, ost)
+    it = a.CurrentIteration()
+    assert it >= 2 and a.small_batch_steps() == (it - 1) * 40 and a.factor_reuses() == (it - 1) * 40
+    assert a.chain_step_reuses() == (it - 1) * (2 * 40 - 4)
+    fd, rec = _compare_statistics(a, o)
+    x1 = [a.block_estimates(b) for b in range(40)]
+    v1 = [a.block_variances_packed(b) for b in range(40)]
+    # the same handle again (the table of the blocks is kept), and the run without reuse
+    a.ResetAdjustment()
+    assert a.AdjustNetwork() == st and a.small_batch_steps() == (it - 1) * 40
+    for b in range(40):
+        assert np.array_equal(a.block_estimates(b), x1[b])
+    a.close()
+    r, st2 = _device_run(str(tmp_path), "m", True, multi_thread=mt, reuse_factors=False)
+    assert st2 == st and r.CurrentIteration() == it and r.small_batch_steps() == 0
+    for b in range(40):
+        assert np.abs(r.block_estimates(b) - x1[b]).max() < 1e-9
+        assert np.abs(r.block_variances_packed(b) - v1[b]).max() <= 1e-12 * np.abs(v1[b]).max()
+    r.close()
+    o.close()
+
+
 def test_phased_block_1_mode(built, orc, tmp_path):
     """Phased_Block_1Mode (AdjustPhasedBlock1, dnaadjust.cpp:2675): one reverse pass; block 1 is rigorous -- exactly what the first
     iteration of the full phased adjustment gives it -- the blocks between keep their reverse solution, the last block is not

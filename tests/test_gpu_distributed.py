@@ -53,7 +53,7 @@ def test_ranks_as_threads_sharing_the_gpu(built, orc, tmp_path, ranks, schur, mt
     owners = [a.block_owner(k) for k in range(6)]
     assert sorted(set(owners)) == list(range(min(ranks, 6))) if schur else max(owners) <= ranks - 1
     if schur:
-        from tests.numpy_backend import contiguous_owners      # the CPU (gloo) tests' restatement of the same partition
+        from tests.partition import contiguous_owners      # the CPU (gloo) tests' restatement of the same partition
         assert owners == sorted(owners)                       # contiguous runs of blocks per rank
         assert owners == contiguous_owners([float(3 * len(o.block_stations(k))) ** 3 for k in range(6)], ranks)
     assert st == ost and a.CurrentIteration() == o.iterations()

@@ -26,8 +26,8 @@ TOL_V = 1e-8
 
 
 def _need(n):
-    import torch
-    have = torch.cuda.device_count()
+    from dynadjust_amd import _lib
+    have = _lib.load().dnagpu_device_count()      # the library's own count: importing torch here costs minutes on a cold box
     if have < n:
         pytest.skip(f"needs {n} GPUs, this node shows {have}")
 

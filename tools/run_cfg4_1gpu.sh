@@ -11,7 +11,7 @@ export DNAGPU_PHASE_TIMES=1
 { free -g; nproc; echo "cpu.max $(cat /sys/fs/cgroup/cpu.max 2>&1)"; echo "memory.max $(cat /sys/fs/cgroup/memory.max 2>&1)"; } > $out/host_before.txt
 limit=$(cat /sys/fs/cgroup/memory.max 2>/dev/null)
 case "$limit" in ''|max) limit=0;; esac
-timeout ${LIMIT:-2400} python bench.py --workload cfg4 --gpus 1 --stage --steps 1 --warmup 0 --no-one-chain "$@" > $out/$tag.json 2> $out/$tag.err &
+timeout ${LIMIT:-2400} python bench.py --workload cfg4 --gpus 1 --stage --steps 1 --warmup 0 --no-one-chain --no-refactor-leg "$@" > $out/$tag.json 2> $out/$tag.err &
 pid=$!
 peak=0
 while kill -0 $pid 2>/dev/null; do
