@@ -110,6 +110,7 @@ struct Block {
 
 struct dnagpu_ctx {
     int device = 0;
+    int info_carry = 1;          // dnagpu_schur_carry leaves the information form (taken from the process default at dnagpu_create)
     std::mutex err_mutex;          // err / last_info: written by whichever chain's host thread fails (dnagpu_api.hip note_error)
     std::string err;
     int last_info = 0;

@@ -300,6 +300,7 @@ int dnagpu_create(int device, dnagpu_ctx** out) {
     dnagpu_ctx* ctx = new (std::nothrow) dnagpu_ctx();
     if (!ctx) return DNAGPU_ENOMEM;
     ctx->device = device;
+    ctx->info_carry = g_info_carry.load();
     if (hipSetDevice(device) != hipSuccess) {
         delete ctx;
         return DNAGPU_EHIP;
@@ -465,7 +466,13 @@ int dnagpu_debug_fail_batch_workspaces(long n) {
 long dnagpu_debug_set_small_tiles(long tiles) { return dnagpu::small_tiles_set(tiles); }
 long dnagpu_debug_set_tiny_tiles(long tiles) { return dnagpu::tiny_tiles_set(tiles); }
 int dnagpu_debug_set_info_carry(int on) { return g_info_carry.exchange(on ? 1 : 0); }
-int dnagpu_info_carry(void) { return g_info_carry.load(); }
+int dnagpu_ctx_set_info_carry(dnagpu_ctx* ctx, int on) {
+    if (!ctx) return DNAGPU_EINVAL;
+    const int old = ctx->info_carry;
+    ctx->info_carry = on ? 1 : 0;
+    return old;
+}
+int dnagpu_info_carry(const dnagpu_ctx* ctx) { return ctx ? ctx->info_carry : g_info_carry.load(); }
 
 long dnagpu_debug_tile_order(int mt, int nt, int K, int kmode, int lower, int tile, int jt_lo, int jt_hi, uint32_t* out, long cap, int* per_workgroup) {
     std::vector<uint32_t> t = dnagpu::build_tile_order(mt, nt, K, kmode, lower, tile, jt_lo, jt_hi);
@@ -1940,7 +1947,7 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
     hipStream_t st = ctx->stream[chain];
     jm->n = nj;
     jm->np = npj;
-    if (g_info_carry.load()) {
+    if (ctx->info_carry) {
         // information form: the complement S (the junction stations' weight matrix) and the reduced right-hand side r travel as they are,
         // with the estimates they were formed at; the next block adds S to its normals and r + S (those estimates - its own) to its
         // right-hand side (dnagpu_junction_rhs) -- what the estimates x + S^-1 r weighted by S contribute, without S^-1: no inverse of
@@ -1974,7 +1981,7 @@ int dnagpu_schur_carry_keep(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_mat
     Block* b = find_block(ctx, blk);
     if (!b || !m || !jm || !k || !idx_out || k >= b->n_stn || 3 * k > jm->n_max || m->n != 3 * b->n_stn || !keep || !keep->spine || keep->store)
         return fail(ctx, DNAGPU_EINVAL, "schur_carry_keep: bad arguments");
-    if (!g_info_carry.load()) return fail(ctx, DNAGPU_EINVAL, "schur_carry_keep: the information form of the carry is switched off");
+    if (!ctx->info_carry) return fail(ctx, DNAGPU_EINVAL, "schur_carry_keep: the information form of the carry is switched off");
     const uint32_t nj = (uint32_t)(3 * k), npj = pad128(nj);
     const double* T = nullptr;
     uint32_t ldt = 0;

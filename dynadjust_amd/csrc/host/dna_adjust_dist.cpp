@@ -561,7 +561,7 @@ void dna_adjust::ScanRuns() {
         Check(dnagpu_schur_carry(ctx_, c, g.dev_block, Wm, out.data(), out.size(), jm), k, "Solve()");
         const double n = 3.0 * (double)g.stations.size(), nj = 3.0 * (double)out.size(), ni = n - nj;
         std::lock_guard<std::mutex> lk(corr_mutex_);
-        CountFlops(ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj), 0);
+        CountFlops(ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry(ctx_) ? 0.0 : nj * nj * nj), 0);
     };
     OnEveryChain([&](int c) {
         if (c == 0)
@@ -679,7 +679,7 @@ void dna_adjust::DistributedReferenceIteration() {
     // Every junction that travels here left a step that carries (PhasedForwardBlock / PhasedReverseBlock): with a.schur_carry it was made by
     // elimination and is in dnagpu_schur_carry's form -- by default the information form: matrix, linearisation point AND reduced right-hand
     // side --, otherwise gathered from the block inverse and inverted (estimates form).  Both sides know which: one rule, same settings.
-    const int form = (SchurCarry() && dnagpu_info_carry()) ? 1 : 0;
+    const int form = (SchurCarry() && dnagpu_info_carry(ctx_)) ? 1 : 0;
     struct xfer_t { double *F, *v, *r; UINT32 np; int peer; bool send; };
     std::vector<xfer_t> xfers;
     AgreeOnPhase("exchange of the junction matrices (preparation)", [&] {       // (see ExchangeCondensed)

@@ -85,7 +85,7 @@ void dna_adjust::CarryByElimination(int c, UINT32 dev_block, UINT32 k, dnagpu_ma
     solve_flops_ += nref * nref * nref;
     // Cholesky of the inner part, its panel under the junction rows, the complement's update, and -- estimates form only
     // (DNAGPU_INFO_CARRY=0) -- the complement's inverse
-    CountFlops(ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry() ? 0.0 : nj * nj * nj), 0);
+    CountFlops(ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj + (dnagpu_info_carry(ctx_) ? 0.0 : nj * nj * nj), 0);
     solve_count_++;
     elimination_count_++;
 }
@@ -1281,7 +1281,7 @@ void dna_adjust::CondensedReverseBlock(int c, UINT32 k) {
 bool dna_adjust::StepRhsInOneLaunch(int c, UINT32 dev_block, UINT32 k, int dir, const dnagpu_matrix* jm_in, const std::vector<UINT32>& idx_in,
                                     dnagpu_matrix* jm_out, const std::vector<UINT32>& idx_out) {
     block_t& B = blocks_[k];
-    if (!dnagpu_info_carry() || idx_out.size() >= B.keep.size()) return false;
+    if (!dnagpu_info_carry(ctx_) || idx_out.size() >= B.keep.size()) return false;
     const int rc = dnagpu_chain_step_rhs(ctx_, c, dev_block, k, B.keep.data(), B.keep.size(), B.red, jm_in, idx_in.data(), jm_in ? idx_in.size() : 0, jm_out,
                                          idx_out.data(), idx_out.size(), B.cfac[dir]);
     if (rc == DNAGPU_ETOOLARGE) return false;
@@ -1300,7 +1300,7 @@ bool dna_adjust::StepRhsInOneLaunch(int c, UINT32 dev_block, UINT32 k, int dir, 
 // side through it (dnagpu_schur_carry_rhs): the complement S in jm is the same in every iteration, its right-hand side is renewed.
 void dna_adjust::CarryCondensed(int c, UINT32 dev_block, UINT32 k, int dir, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm) {
     block_t& B = blocks_[k];
-    if (!FactorReuse() || out.size() >= B.keep.size() || !dnagpu_info_carry()) {
+    if (!FactorReuse() || out.size() >= B.keep.size() || !dnagpu_info_carry(ctx_)) {
         CarryByElimination(c, dev_block, k, W, out, jm);
         return;
     }
@@ -1510,7 +1510,7 @@ void dna_adjust::ForBlocks(const std::vector<UINT32>& blocks, const std::functio
 // the kernels' limits, no memory): the per-block path takes them.
 bool dna_adjust::SmallBatchCondense(std::vector<UINT32>& blocks) {
     small_batch_armed_ = false;
-    if (!FactorReuse() || currentIteration_ < 2 || small_batch_denied_ || !dnagpu_info_carry()) return false;
+    if (!FactorReuse() || currentIteration_ < 2 || small_batch_denied_ || !dnagpu_info_carry(ctx_)) return false;
     std::vector<UINT32> E, rest;
     for (UINT32 k : blocks) {
         const block_t& B = blocks_[k];

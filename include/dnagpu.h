@@ -120,9 +120,13 @@ long dnagpu_debug_set_small_tiles(long tiles);
 /* ... and below `tiles` on 32 x 32 tiles (default 64; 0: never; < 0: the default again): the products of the recursion's bottom and of the chains on
  * condensed blocks, where a launch has too few 64-tiles to occupy the chip.  Same bits.  Returns the previous value. */
 long dnagpu_debug_set_tiny_tiles(long tiles);
-/* dnagpu_schur_carry's result: 1 (default) information form, 0 estimates form (see there); returns the previous value.  Process-wide. */
+/* dnagpu_schur_carry's result: 1 (default) information form, 0 estimates form (see there); returns the previous value.  The setting is taken
+ * over by the contexts created AFTER the call and stays with a context for its lifetime (dnagpu_info_carry(ctx); NULL: the value a new
+ * context would get): contexts running side by side never see each other's form. */
 int dnagpu_debug_set_info_carry(int on);
-int dnagpu_info_carry(void);
+int dnagpu_info_carry(const dnagpu_ctx* ctx);
+/* the same switch on one context (between adjustments: junction matrices made in one form are not read in the other); returns the previous value */
+int dnagpu_ctx_set_info_carry(dnagpu_ctx* ctx, int on);
 /* The workgroup -> tile table a launch of this shape would use (host computation, no device needed): `out` receives up to `cap`
  * entries (it << 16 | jt, 0xffffffff = idle), *per_workgroup = entries per workgroup (1);
  * jt_lo / jt_hi = -1 or the column range of one rank of a split launch.  Returns the number of entries the table has. */

@@ -158,11 +158,12 @@ def test_bad_arguments_are_rejected(gpu_ctx):
 
 
 @pytest.fixture
-def carry_form(request, built):
-    """dnagpu_schur_carry in its estimates form (0) or its information form (1, the default)"""
-    old = built.dnagpu_debug_set_info_carry(request.param)
+def carry_form(request, built, gpu_ctx):
+    """dnagpu_schur_carry in its estimates form (0) or its information form (1, the default) -- a setting of the context"""
+    old = built.dnagpu_ctx_set_info_carry(gpu_ctx.h, request.param)
+    assert built.dnagpu_info_carry(gpu_ctx.h) == request.param
     yield request.param
-    built.dnagpu_debug_set_info_carry(old)
+    built.dnagpu_ctx_set_info_carry(gpu_ctx.h, old)
 
 
 @pytest.mark.parametrize("carry_form", [0, 1], indirect=True)
