@@ -7,6 +7,8 @@ namespace dnagpu {
 void launch_weights(const double* vcv6, const uint32_t* dst, double* wblk, uint32_t n, int* bad, hipStream_t s);
 void launch_cluster_blocks(const double* F, uint32_t np, uint32_t k, double* wblk, hipStream_t s);
 void launch_diag_weights(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, double* w6, uint32_t n_vec, hipStream_t s);
+void launch_reset_block(const double* src, double* x_orig, double* x_rig, double* const* x_est, double* const* b, int chains, bool with_b,
+                        const uint32_t* s1, const uint32_t* s2, const double* obs, uint32_t n_stn, uint32_t n_bl, hipStream_t s);
 void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s);
 void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pent, const double* wblk, double* F,
                          uint32_t np, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift, hipStream_t s);

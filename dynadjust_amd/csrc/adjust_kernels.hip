@@ -89,6 +89,31 @@ __global__ void compute_b_kernel(const uint32_t* __restrict__ s1, const uint32_t
     b[t] = obs[t] - comp;
 }
 
+// ResetAdjustment for one block in one launch: the coordinates `src` (device) go to the original, estimated (every chain) and rigorous
+// coordinates, and measured-minus-computed of every chain is formed from them (the arithmetic of compute_b_kernel)
+#define RESET_MAX_CHAINS 8
+struct ResetBlockArgs {
+    const double* src;
+    double* x[2 + RESET_MAX_CHAINS];           // original, rigorous, estimated of chains 0 ..
+    double* b[RESET_MAX_CHAINS];
+    int nx, nb;                 // destinations in x / b
+};
+__global__ void reset_block_kernel(ResetBlockArgs a, const uint32_t* __restrict__ s1, const uint32_t* __restrict__ s2, const double* __restrict__ obs,
+                                   uint32_t n3, uint32_t n_bl) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n3) {
+        const double v = a.src[t];
+        for (int q = 0; q < a.nx; ++q) a.x[q][t] = v;
+    }
+    if (t < n_bl * 3 && a.nb) {
+        uint32_t i = t / 3, c = t - i * 3;
+        double comp = a.src[3 * s2[i] + c];
+        if (s1[i] != 0xffffffffu) comp = comp - a.src[3 * s1[i] + c];
+        const double r = obs[t] - comp;
+        for (int q = 0; q < a.nb; ++q) a.b[q][t] = r;
+    }
+}
+
 // one thread per (station-pair block, element): N(3r+ei, 3c+ej) = sum over the pair's contributions
 // (CML order) of +-W_block(ei, ej); a contribution = (index of a 3x3 weight block) << 1 | negative
 __global__ void form_normals_kernel(const uint32_t* __restrict__ prow, const uint32_t* __restrict__ pcol,
@@ -502,6 +527,21 @@ void launch_diag_weights(const double* wblk, const uint32_t* vec_wrow, const uin
 void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s) {
     if (!n_bl) return;
     hipLaunchKernelGGL(compute_b_kernel, dim3((n_bl * 3 + 255) / 256), dim3(256), 0, s, s1, s2, obs, xe, b, n_bl);
+}
+void launch_reset_block(const double* src, double* x_orig, double* x_rig, double* const* x_est, double* const* b, int chains, bool with_b,
+                        const uint32_t* s1, const uint32_t* s2, const double* obs, uint32_t n_stn, uint32_t n_bl, hipStream_t s) {
+    ResetBlockArgs a{};
+    if (chains > RESET_MAX_CHAINS) chains = RESET_MAX_CHAINS;      // (static_assert in dnagpu_api.hip: DNAGPU_NUM_CHAINS fits)
+    a.src = src;
+    a.x[0] = x_orig;
+    a.x[1] = x_rig;
+    for (int c = 0; c < chains; ++c) a.x[2 + c] = x_est[c];
+    a.nx = 2 + chains;
+    a.nb = (with_b && n_bl) ? chains : 0;
+    for (int c = 0; c < a.nb; ++c) a.b[c] = b[c];
+    const uint32_t n = std::max(3 * n_stn, a.nb ? 3 * n_bl : 0u);
+    if (!n) return;
+    hipLaunchKernelGGL(reset_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, s1, s2, obs, 3 * n_stn, n_bl);
 }
 void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pent, const double* wblk, double* F,
                          uint32_t np, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift, hipStream_t s) {

@@ -1039,6 +1039,19 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz) 
     return DNAGPU_OK;
 }
 
+static_assert(DNAGPU_NUM_CHAINS <= 8, "launch_reset_block passes one pointer per chain in its kernel arguments (RESET_MAX_CHAINS)");
+int dnagpu_block_reset_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, const double* dev_xyz, int with_b) {
+    CHK_CTX();
+    CHK_CHAIN();
+    Block* b = find_block(ctx, blk);
+    if (!b || (!dev_xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_reset_stations: bad arguments");
+    if (with_b && b->n_t) return fail(ctx, DNAGPU_EINVAL, "block_reset_stations: a block with terrestrial measurements takes dnagpu_block_compute_b");
+    launch_reset_block(dev_xyz, b->x_orig, b->x_rig, b->x_est, b->b, DNAGPU_NUM_CHAINS, with_b != 0, b->s1, b->s2, b->obs, b->n_stn, b->n_bl,
+                       ctx->stream[chain]);
+    HIPCHK(hipGetLastError());
+    return DNAGPU_OK;
+}
+
 int dnagpu_block_set_station_geo(dnagpu_ctx* ctx, uint32_t blk, const double* llh, const double* geoid, const double* defl) {
     CHK_CTX();
     Block* b = find_block(ctx, blk);

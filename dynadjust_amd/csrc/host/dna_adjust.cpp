@@ -41,6 +41,8 @@ void dna_adjust::FreeDevice() {
     FreeTwoLevel();
     if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);
     xbuf_dev_ = nullptr;
+    if (initial_dev_) dnagpu_device_free(ctx_, initial_dev_);
+    initial_dev_ = nullptr;
     if (agree_dev_) dnagpu_device_free(ctx_, agree_dev_);
     agree_dev_ = nullptr;
     xbuf_cap_ = 0;
@@ -883,6 +885,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
     }
     Check(dnagpu_sync(ctx_), 0, "AdjustNetwork()");
     adjust_ms_ = now_ms() - t0;
+    if (getenv("DNAGPU_PHASE_TIMES")) fprintf(stderr, "[phase] AdjustNetwork             %6.1f ms\n", adjust_ms_);
     PrintPerformanceProfile();
     return adjustStatus_;
 }
@@ -1011,6 +1014,7 @@ void dna_adjust::AdjustPhased() {
         return;
     }
     currentIteration_ = 0;
+    const bool times = getenv("DNAGPU_PHASE_TIMES") != nullptr;
     for (UINT32 i = 0; i < projectSettings_.a.max_iterations; ++i) {
         if (IsCancelled()) break;
         maxCorr_ = 0.0;
@@ -1029,14 +1033,20 @@ void dna_adjust::AdjustPhased() {
             AdjustPhasedReverseCombine();
         }
         if (IsCancelled()) break;
+        const double td = now_ms();
         UpdateIterationDiagnostics();                   // (ADJ:2631)
         iterationCorrections_.push_back(maxCorr_);
         NoteIterationDone(it_t0);
         bool iterate = !IsCancelled() && std::fabs(maxCorr_) > projectSettings_.a.iteration_threshold;
+        if (times) fprintf(stderr, "[phase] iteration %u diagnostics %6.1f ms\n", (unsigned)currentIteration_, now_ms() - td);
         if (!iterate) break;
+        const double tu = now_ms();
         UpdateAdjustment(iterate);
+        if (times) {
+            Check(dnagpu_sync(ctx_), 0, "AdjustPhased()");
+            fprintf(stderr, "[phase] iteration %u update      %6.1f ms\n", (unsigned)currentIteration_, now_ms() - tu);
+        }
     }
-    const bool times = getenv("DNAGPU_PHASE_TIMES") != nullptr;
     if (times) Check(dnagpu_sync(ctx_), 0, "AdjustPhased()");
     const double tv = now_ms();
     if (!IsCancelled()) FinishDeferredVariances();
@@ -1045,7 +1055,9 @@ void dna_adjust::AdjustPhased() {
         fprintf(stderr, "[phase] variance matrices    %8.1f ms\n", now_ms() - tv);
     }
     FinishStagedCopies();
+    const double tf = now_ms();
     ValidateandFinaliseAdjustment();
+    if (times) fprintf(stderr, "[phase] validate and finalise %6.1f ms\n", now_ms() - tf);
 }
 
 // staged mode: the rigorous variance matrices of the iteration are on their way to host memory on the chains' copy streams
@@ -1107,11 +1119,27 @@ void dna_adjust::ResetAdjustment() {
         return;
     }
     if (!ctx_) SignalExceptionAdjustment("ResetAdjustment(): PrepareAdjustment() has not been called.", 0);
+    const double t_reset = now_ms();
     exchange_ms_ = chain_ms_ = 0.0;
     const int chains = NumChains();
+    if (!initial_dev_) {
+        // the a-priori coordinates of every block, once more in HBM: a reset is then one launch per block instead of six copies from the
+        // host and a launch per chain (113 ms -> a few ms for the 666 blocks of a default dnasegment cut)
+        initial_off_.assign(blockCount_ + 1, 0);
+        for (UINT32 b = 0; b < blockCount_; ++b) initial_off_[b + 1] = initial_off_[b] + initial_xyz_[b].size();
+        std::vector<double> all(initial_off_[blockCount_]);
+        for (UINT32 b = 0; b < blockCount_; ++b) std::copy(initial_xyz_[b].begin(), initial_xyz_[b].end(), all.begin() + initial_off_[b]);
+        void* p = nullptr;
+        Check(dnagpu_device_alloc(ctx_, std::max<size_t>(all.size(), 1) * sizeof(double), &p), 0, "ResetAdjustment()");
+        initial_dev_ = (double*)p;
+        Check(dnagpu_copy(ctx_, initial_dev_, all.data(), all.size() * sizeof(double)), 0, "ResetAdjustment()");
+    }
+    for (UINT32 b = 0; b < blockCount_; ++b)
+        Check(dnagpu_block_reset_stations(ctx_, 0, b, initial_dev_ + initial_off_[b], blocks_[b].t_pos.empty() ? 1 : 0), b, "ResetAdjustment()");
+    if (containsNonGPS_) Check(dnagpu_chain_sync(ctx_, 0), 0, "ResetAdjustment()");
     for (UINT32 b = 0; b < blockCount_; ++b) {
-        Check(dnagpu_block_set_stations(ctx_, b, initial_xyz_[b].data()), b, "ResetAdjustment()");
-        for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "ResetAdjustment()");
+        if (!blocks_[b].t_pos.empty())
+            for (int c = 0; c < chains; ++c) Check(dnagpu_block_compute_b(ctx_, c, b), b, "ResetAdjustment()");
         blocks_[b].has_rigvar = false;
         blocks_[b].has_finv = blocks_[b].has_rinv = blocks_[b].has_cinv = false;
         blocks_[b].inverse_kept = blocks_[b].inverse_pending = blocks_[b].part_valid = blocks_[b].rig_direct = blocks_[b].var_deferred = false;
@@ -1121,6 +1149,7 @@ void dna_adjust::ResetAdjustment() {
         blocks_[b].red_iter = 0;
     }
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
+    if (getenv("DNAGPU_PHASE_TIMES")) fprintf(stderr, "[phase] ResetAdjustment           %6.1f ms\n", now_ms() - t_reset);
     osc_ready_ = false;              // (a second adjustment on the handle must not compare with the first one's corrections)
     oscHistory_.clear();
     currentIteration_ = 0;

@@ -554,6 +554,8 @@ private:
     std::vector<std::vector<stn_appear>> v_paramStnAppearance_;
     std::vector<block_t> blocks_;
     std::vector<std::vector<double>> initial_xyz_;   // per block, for ResetAdjustment
+    double* initial_dev_ = nullptr;                  // ... and once more on the device (block b at initial_off_[b])
+    std::vector<size_t> initial_off_;
 
     UINT32 blockCount_ = 1;
     std::atomic<UINT32> currentBlock_{0};   // written by every chain's thread, read by the progress thread (CurrentBlock())

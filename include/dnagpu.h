@@ -197,6 +197,9 @@ int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint
 int dnagpu_block_destroy(dnagpu_ctx* ctx, uint32_t blk);
 /* xyz: 3*n_stations; sets original == estimated == rigorous */
 int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz);
+/* the same from DEVICE memory, one launch on the chain's stream, not waited for; with_b: measured-minus-computed of every chain as well
+ * (dnagpu_block_compute_b's arithmetic; GNSS-only blocks) -- ResetAdjustment of a network of many small blocks */
+int dnagpu_block_reset_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, const double* dev_xyz, int with_b);
 /* stn1/stn2: block-local station of each baseline (CML order); obs: 3 per
  * baseline (dX,dY,dZ); vcv6: upper triangle per baseline in bms order
  * (XX, XY, YY, XZ, YZ, ZZ), already v-scaled.  Computes W = V^-1 on device. */
