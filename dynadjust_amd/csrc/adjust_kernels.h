@@ -9,6 +9,21 @@ void launch_cluster_blocks(const double* F, uint32_t np, uint32_t k, double* wbl
 void launch_diag_weights(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, double* w6, uint32_t n_vec, hipStream_t s);
 void launch_reset_block(const double* src, double* x_orig, double* x_rig, double* const* x_est, double* const* b, int chains, bool with_b,
                         const uint32_t* s1, const uint32_t* s2, const double* obs, uint32_t n_stn, uint32_t n_bl, hipStream_t s);
+// dnagpu_block_table_*: one row per block, one launch for all of them (GNSS-only blocks)
+struct BlockTableRow {
+    const double* init;                 // the a-priori coordinates (device), mode 0
+    double* x_orig;
+    double* x_rig;
+    double* x_est[8];
+    double* b[8];
+    const uint32_t* s1;
+    const uint32_t* s2;
+    const double* obs;
+    uint32_t n3, nb3, last, pad;
+};
+// mode 0 (ResetAdjustment): original = rigorous = estimated (every chain) = init.  mode 1 (UpdateAdjustment): estimated (chains 0 .. chains-1) =
+// rigorous, a last block's original = rigorous.  Both: measured-minus-computed of those chains from the new estimates.
+void launch_block_table(const BlockTableRow* rows, uint32_t n, uint32_t max_len, int mode, int chains, hipStream_t s);
 void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs, const double* xe, double* b, uint32_t n_bl, hipStream_t s);
 void launch_form_normals(const uint32_t* prow, const uint32_t* pcol, const uint32_t* poff, const uint32_t* pent, const double* wblk, double* F,
                          uint32_t np, uint32_t n_pairs, uint32_t n_gnss_blk, uint32_t terr_shift, hipStream_t s);

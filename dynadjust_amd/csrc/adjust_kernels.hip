@@ -528,6 +528,32 @@ void launch_compute_b(const uint32_t* s1, const uint32_t* s2, const double* obs,
     if (!n_bl) return;
     hipLaunchKernelGGL(compute_b_kernel, dim3((n_bl * 3 + 255) / 256), dim3(256), 0, s, s1, s2, obs, xe, b, n_bl);
 }
+__global__ void block_table_kernel(const BlockTableRow* __restrict__ rows, int mode, int chains) {
+    const BlockTableRow& r = rows[blockIdx.y];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* src = mode == 0 ? r.init : r.x_rig;
+    if (t < r.n3) {
+        const double v = src[t];
+        if (mode == 0) {
+            r.x_orig[t] = v;
+            r.x_rig[t] = v;
+        } else if (r.last) {
+            r.x_orig[t] = v;
+        }
+        for (int c = 0; c < chains; ++c) r.x_est[c][t] = v;
+    }
+    if (t < r.nb3) {
+        const uint32_t i = t / 3, c3 = t - i * 3;
+        double comp = src[3 * r.s2[i] + c3];                        // (compute_b_kernel's arithmetic)
+        if (r.s1[i] != 0xffffffffu) comp = comp - src[3 * r.s1[i] + c3];
+        const double v = r.obs[t] - comp;
+        for (int c = 0; c < chains; ++c) r.b[c][t] = v;
+    }
+}
+void launch_block_table(const BlockTableRow* rows, uint32_t n, uint32_t max_len, int mode, int chains, hipStream_t s) {
+    if (!n || !max_len) return;
+    hipLaunchKernelGGL(block_table_kernel, dim3((max_len + 255) / 256, n), dim3(256), 0, s, rows, mode, chains);
+}
 void launch_reset_block(const double* src, double* x_orig, double* x_rig, double* const* x_est, double* const* b, int chains, bool with_b,
                         const uint32_t* s1, const uint32_t* s2, const double* obs, uint32_t n_stn, uint32_t n_bl, hipStream_t s) {
     ResetBlockArgs a{};

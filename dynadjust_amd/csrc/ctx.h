@@ -44,6 +44,12 @@ struct dnagpu_small_batch {
     std::vector<uint32_t*> idx_dev;       // the junction station lists, device copies owned by the batch
 };
 
+// dnagpu_block_table_*: device rows (adjust_kernels.h BlockTableRow) of a set of GNSS-only blocks
+struct dnagpu_block_table {
+    uint32_t n = 0, max_len = 0;
+    void* rows = nullptr;
+};
+
 namespace dnagpu {
 
 struct Block {

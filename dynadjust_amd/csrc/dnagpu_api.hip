@@ -1052,6 +1052,93 @@ int dnagpu_block_reset_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, const 
     return DNAGPU_OK;
 }
 
+void dnagpu_block_table_destroy(dnagpu_ctx* ctx, dnagpu_block_table* t) {
+    if (!t) return;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+    }
+    if (t->rows) hipFree(t->rows);
+    delete t;
+}
+
+int dnagpu_block_table_create(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const int* last, const double* dev_init, const size_t* init_off,
+                              dnagpu_block_table** out) {
+    CHK_CTX();
+    static_assert(DNAGPU_NUM_CHAINS <= 8, "BlockTableRow holds one pointer per chain");
+    if (!out || !n || !blks || !last || !dev_init || !init_off) return fail(ctx, DNAGPU_EINVAL, "block_table_create: bad arguments");
+    *out = nullptr;
+    std::vector<BlockTableRow> host(n);
+    uint32_t max_len = 0;
+    for (uint32_t q = 0; q < n; ++q) {
+        Block* b = find_block(ctx, blks[q]);
+        if (!b) return fail(ctx, DNAGPU_EINVAL, "block_table_create: unknown block");
+        if (b->n_t || b->n_dsblk) return fail(ctx, DNAGPU_EINVAL, "block_table_create: a block with terrestrial measurements");
+        BlockTableRow& r = host[q];
+        memset(&r, 0, sizeof(r));
+        r.init = dev_init + init_off[q];
+        r.x_orig = b->x_orig;
+        r.x_rig = b->x_rig;
+        for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
+            r.x_est[c] = b->x_est[c];
+            r.b[c] = b->b[c];
+        }
+        r.s1 = b->s1;
+        r.s2 = b->s2;
+        r.obs = b->obs;
+        r.n3 = 3 * b->n_stn;
+        r.nb3 = 3 * b->n_bl;
+        r.last = last[q] ? 1u : 0u;
+        max_len = std::max(max_len, std::max(r.n3, r.nb3));
+    }
+    dnagpu_block_table* t = new (std::nothrow) dnagpu_block_table();
+    if (!t) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    if (dnagpu::poison_malloc(&t->rows, (size_t)n * sizeof(BlockTableRow)) != hipSuccess ||
+        hipMemcpy(t->rows, host.data(), (size_t)n * sizeof(BlockTableRow), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        dnagpu_block_table_destroy(ctx, t);
+        return fail(ctx, DNAGPU_ENOMEM, "block_table_create: rows");
+    }
+    t->n = n;
+    t->max_len = max_len;
+    *out = t;
+    return DNAGPU_OK;
+}
+
+int dnagpu_block_table_apply(dnagpu_ctx* ctx, int chain, const dnagpu_block_table* t, int mode, int chains) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!t || (mode != 0 && mode != 1) || chains < 1 || chains > DNAGPU_NUM_CHAINS) return fail(ctx, DNAGPU_EINVAL, "block_table_apply: bad arguments");
+    gemm_profile_close(ctx->ws[chain]);
+    launch_block_table((const BlockTableRow*)t->rows, t->n, t->max_len, mode, mode == 0 ? DNAGPU_NUM_CHAINS : chains, ctx->stream[chain]);
+    HIPCHK(hipGetLastError());
+    return DNAGPU_OK;
+}
+
+int dnagpu_chain_hold_info(dnagpu_ctx* ctx, int chain, int on) {
+    CHK_CTX();
+    CHK_CHAIN();
+    int rc = ensure_ws(ctx, chain, 128);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    if (on && !ws.hold_info) HIPCHK(hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ctx->stream[chain]));
+    ws.hold_info = on != 0;
+    return DNAGPU_OK;
+}
+
+int dnagpu_chain_take_info(dnagpu_ctx* ctx, int chain) {
+    CHK_CTX();
+    CHK_CHAIN();
+    int rc = ensure_ws(ctx, chain, 128);
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return check_info(ctx, chain);
+}
+
 int dnagpu_block_set_station_geo(dnagpu_ctx* ctx, uint32_t blk, const double* llh, const double* geoid, const double* defl) {
     CHK_CTX();
     Block* b = find_block(ctx, blk);
@@ -1983,6 +2070,7 @@ int dnagpu_schur_carry(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix* 
         launch_schur_estimates(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, b->corr[chain], jm->jest, st);
         jm->form = 0;
     }
+    if (ws.hold_info) return DNAGPU_OK;          // (dnagpu_chain_hold_info: the verdict is taken once, after the run of steps)
     HIPCHK(hipStreamSynchronize(st));
     return check_info(ctx, chain);
 }
@@ -2013,6 +2101,7 @@ int dnagpu_schur_carry_keep(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_mat
     launch_schur_extract(T, ldt, nj, npj, jm->F, nullptr, jm->jrhs, st);
     launch_gather_vec3(b->x_est[chain], b->schur_idx[slot], (uint32_t)k, jm->jest, st);
     jm->form = 1;
+    if (ws.hold_info) return DNAGPU_OK;          // (dnagpu_chain_hold_info; a failed run's factors are dropped by the caller)
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     rc = check_info(ctx, chain);
@@ -2125,6 +2214,28 @@ int dnagpu_small_batch_create(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks,
         (void)hipGetLastError();
         return bail(fail(ctx, DNAGPU_ENOMEM, "small_batch_create: result buffers"));
     }
+    // the junction station lists of all blocks in one device buffer (one allocation, one copy: 1 300 of each were 35 ms for 666 blocks)
+    std::vector<uint32_t> idx_all;
+    std::vector<size_t> idx_at(2 * (size_t)n, 0);
+    for (uint32_t q = 0; q < n; ++q) {
+        const dnagpu_matrix* jm[2] = {j0[q], j1[q]};
+        const uint32_t* ix[2] = {idx0[q], idx1[q]};
+        const size_t kk[2] = {k0[q], k1[q]};
+        for (int e = 0; e < 2; ++e) {
+            idx_at[2 * (size_t)q + e] = idx_all.size();
+            if (jm[e] && ix[e]) idx_all.insert(idx_all.end(), ix[e], ix[e] + kk[e]);
+        }
+    }
+    uint32_t* idx_dev_all = nullptr;
+    if (!idx_all.empty()) {
+        if (dnagpu::poison_malloc(&idx_dev_all, idx_all.size() * sizeof(uint32_t)) != hipSuccess ||
+            hipMemcpy(idx_dev_all, idx_all.data(), idx_all.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            if (idx_dev_all) hipFree(idx_dev_all);
+            return bail(fail(ctx, DNAGPU_ENOMEM, "small_batch_create: station lists"));
+        }
+        sb->idx_dev.push_back(idx_dev_all);
+    }
     for (uint32_t q = 0; q < n; ++q) {
         Block* b = find_block(ctx, blks[q]);
         const dnagpu_partial* p = pf[q];
@@ -2160,14 +2271,7 @@ int dnagpu_small_batch_create(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks,
             if (!ix[e] || jm[e]->n != 3 * kk[e] || jm[e]->form != 1 || !jm[e]->jrhs || 3 * kk[e] > SMALL_STEP_MAX) return bail(DNAGPU_ETOOLARGE);
             for (size_t i = 0; i < kk[e]; ++i)
                 if (ix[e][i] >= b->n_stn) return bail(fail(ctx, DNAGPU_EINVAL, "small_batch_create: station out of range"));
-            uint32_t* dev = nullptr;
-            if (dnagpu::poison_malloc(&dev, kk[e] * sizeof(uint32_t)) != hipSuccess ||
-                hipMemcpy(dev, ix[e], kk[e] * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
-                (void)hipGetLastError();
-                if (dev) hipFree(dev);
-                return bail(fail(ctx, DNAGPU_ENOMEM, "small_batch_create: station lists"));
-            }
-            sb->idx_dev.push_back(dev);
+            uint32_t* dev = idx_dev_all + idx_at[2 * (size_t)q + e];
             d.J[e] = jm[e]->F; d.jest[e] = jm[e]->jest; d.jrhs[e] = jm[e]->jrhs; d.jidx[e] = dev; d.jk[e] = (uint32_t)kk[e]; d.jnp[e] = jm[e]->np;
         }
         d.last = last[q] ? 1u : 0u;

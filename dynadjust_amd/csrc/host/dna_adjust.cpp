@@ -41,6 +41,9 @@ void dna_adjust::FreeDevice() {
     FreeTwoLevel();
     if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);
     xbuf_dev_ = nullptr;
+    if (block_table_) dnagpu_block_table_destroy(ctx_, block_table_);
+    block_table_ = nullptr;
+    block_table_denied_ = false;
     if (initial_dev_) dnagpu_device_free(ctx_, initial_dev_);
     initial_dev_ = nullptr;
     if (agree_dev_) dnagpu_device_free(ctx_, agree_dev_);
@@ -967,10 +970,15 @@ void dna_adjust::UpdateAdjustment(bool iterate) {
             Check(dnagpu_block_compute_b(ctx_, c, b), b, "UpdateAdjustment()");
         }
     };
-    if (chains > 1 && blockCount_ >= 32)
+    if (phased && !own_only && !IsCancelled() && EnsureBlockTable()) {
+        // GNSS-only: the same for every block and chain in one launch (666 blocks x 4 chains x 2 enqueues were 7 ms per iteration)
+        Check(dnagpu_sync(ctx_), 0, "UpdateAdjustment()");         // (the rigorous estimates of every chain's blocks are final)
+        Check(dnagpu_block_table_apply(ctx_, 0, block_table_, 1, chains), 0, "UpdateAdjustment()");
+    } else if (chains > 1 && blockCount_ >= 32) {
         OnEveryChain(per_chain);
-    else
+    } else {
         for (int c = 0; c < chains; ++c) per_chain(c);
+    }
     // Everything above was enqueued chain by chain; what follows reads across chains -- the reverse thread's chain takes the last block's
     // originals that chain 0 has just set, any chain the estimates another one restored.  The chains meet here, once per iteration
     // (found in round 3: under host load the reverse pass of the reference's multi-thread schedule started from the last block's
@@ -1113,6 +1121,39 @@ void dna_adjust::GetAdjustedCoordinates(std::vector<double>& xyz) {
     }
 }
 
+// the a-priori coordinates of every block, once more in HBM: a reset is then one launch instead of six copies from the host and a launch
+// per chain for every block (113 ms -> 3 ms for the 666 blocks of a default dnasegment cut)
+void dna_adjust::EnsureInitialOnDevice() {
+    if (initial_dev_) return;
+    initial_off_.assign(blockCount_ + 1, 0);
+    for (UINT32 b = 0; b < blockCount_; ++b) initial_off_[b + 1] = initial_off_[b] + initial_xyz_[b].size();
+    std::vector<double> all(initial_off_[blockCount_]);
+    for (UINT32 b = 0; b < blockCount_; ++b) std::copy(initial_xyz_[b].begin(), initial_xyz_[b].end(), all.begin() + initial_off_[b]);
+    void* p = nullptr;
+    Check(dnagpu_device_alloc(ctx_, std::max<size_t>(all.size(), 1) * sizeof(double), &p), 0, "ResetAdjustment()");
+    initial_dev_ = (double*)p;
+    Check(dnagpu_copy(ctx_, initial_dev_, all.data(), all.size() * sizeof(double)), 0, "ResetAdjustment()");
+}
+
+// GNSS-only phased networks: the blocks' coordinate bookkeeping between iterations (dnagpu_block_table_*) for all blocks in one launch
+bool dna_adjust::EnsureBlockTable() {
+    if (block_table_) return true;
+    if (block_table_denied_ || containsNonGPS_ || projectSettings_.a.adjust_mode == SimultaneousMode || blockCount_ < 8) return false;
+    EnsureInitialOnDevice();
+    std::vector<UINT32> ids(blockCount_);
+    std::vector<int> last(blockCount_);
+    for (UINT32 b = 0; b < blockCount_; ++b) {
+        ids[b] = b;
+        last[b] = v_blockMeta_[b]._blockLast ? 1 : 0;
+    }
+    if (dnagpu_block_table_create(ctx_, blockCount_, ids.data(), last.data(), initial_dev_, initial_off_.data(), &block_table_) != DNAGPU_OK) {
+        block_table_ = nullptr;
+        block_table_denied_ = true;
+        return false;
+    }
+    return true;
+}
+
 void dna_adjust::ResetAdjustment() {
     if (!peers_.empty() && !in_collective_) {
         OnEveryDevice([](dna_adjust& a) { a.ResetAdjustment(); });
@@ -1122,20 +1163,13 @@ void dna_adjust::ResetAdjustment() {
     const double t_reset = now_ms();
     exchange_ms_ = chain_ms_ = 0.0;
     const int chains = NumChains();
-    if (!initial_dev_) {
-        // the a-priori coordinates of every block, once more in HBM: a reset is then one launch per block instead of six copies from the
-        // host and a launch per chain (113 ms -> a few ms for the 666 blocks of a default dnasegment cut)
-        initial_off_.assign(blockCount_ + 1, 0);
-        for (UINT32 b = 0; b < blockCount_; ++b) initial_off_[b + 1] = initial_off_[b] + initial_xyz_[b].size();
-        std::vector<double> all(initial_off_[blockCount_]);
-        for (UINT32 b = 0; b < blockCount_; ++b) std::copy(initial_xyz_[b].begin(), initial_xyz_[b].end(), all.begin() + initial_off_[b]);
-        void* p = nullptr;
-        Check(dnagpu_device_alloc(ctx_, std::max<size_t>(all.size(), 1) * sizeof(double), &p), 0, "ResetAdjustment()");
-        initial_dev_ = (double*)p;
-        Check(dnagpu_copy(ctx_, initial_dev_, all.data(), all.size() * sizeof(double)), 0, "ResetAdjustment()");
+    EnsureInitialOnDevice();
+    if (EnsureBlockTable()) {
+        Check(dnagpu_block_table_apply(ctx_, 0, block_table_, 0, chains), 0, "ResetAdjustment()");
+    } else {
+        for (UINT32 b = 0; b < blockCount_; ++b)
+            Check(dnagpu_block_reset_stations(ctx_, 0, b, initial_dev_ + initial_off_[b], blocks_[b].t_pos.empty() ? 1 : 0), b, "ResetAdjustment()");
     }
-    for (UINT32 b = 0; b < blockCount_; ++b)
-        Check(dnagpu_block_reset_stations(ctx_, 0, b, initial_dev_ + initial_off_[b], blocks_[b].t_pos.empty() ? 1 : 0), b, "ResetAdjustment()");
     if (containsNonGPS_) Check(dnagpu_chain_sync(ctx_, 0), 0, "ResetAdjustment()");
     for (UINT32 b = 0; b < blockCount_; ++b) {
         if (!blocks_[b].t_pos.empty())

@@ -470,6 +470,8 @@ private:
     std::atomic<uint64_t> small_batch_steps_{0};               // block steps served that way since AdjustNetwork() began
     bool SmallBatchCondense(std::vector<UINT32>& blocks);     // serves what it can; `blocks` keeps the rest
     void SmallBatchSolve(std::vector<UINT32>& blocks);
+    void SmallBatchFirstSolve(std::vector<UINT32>& blocks);
+    bool EnsureSmallBatch(const std::vector<UINT32>& E);
     std::atomic<uint64_t> factor_reuses_{0}, chain_reuses_{0};    // block steps / chain steps served from a kept factor since AdjustNetwork() began
     // a chain step on the condensed block of k: elimination with the factor kept (first time) or its right-hand side through the kept factor
     void CarryCondensed(int chain, UINT32 dev_block, UINT32 block, int dir, dnagpu_matrix* W, const std::vector<UINT32>& out, dnagpu_matrix* jm);
@@ -556,6 +558,10 @@ private:
     std::vector<std::vector<double>> initial_xyz_;   // per block, for ResetAdjustment
     double* initial_dev_ = nullptr;                  // ... and once more on the device (block b at initial_off_[b])
     std::vector<size_t> initial_off_;
+    dnagpu_block_table* block_table_ = nullptr;      // GNSS-only networks of many blocks: ResetAdjustment / UpdateAdjustment as one launch
+    bool block_table_denied_ = false;
+    void EnsureInitialOnDevice();
+    bool EnsureBlockTable();
 
     UINT32 blockCount_ = 1;
     std::atomic<UINT32> currentBlock_{0};   // written by every chain's thread, read by the progress thread (CurrentBlock())

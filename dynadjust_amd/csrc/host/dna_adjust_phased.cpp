@@ -1505,6 +1505,49 @@ void dna_adjust::ForBlocks(const std::vector<UINT32>& blocks, const std::functio
     });
 }
 
+// the device table of the one-launch kernels for the blocks E (kept across iterations and adjustments while E stays the same)
+bool dna_adjust::EnsureSmallBatch(const std::vector<UINT32>& E) {
+    if (small_batch_ && E != small_batch_blocks_) {
+        dnagpu_small_batch_destroy(ctx_, small_batch_);
+        small_batch_ = nullptr;
+    }
+    if (small_batch_) return true;
+    const size_t n = E.size();
+    std::vector<dnagpu_partial*> pf(n);
+    std::vector<dnagpu_matrix*> red(n);
+    std::vector<const dnagpu_matrix*> j0(n, nullptr), j1(n, nullptr);
+    std::vector<const UINT32*> i0(n, nullptr), i1(n, nullptr);
+    std::vector<size_t> k0(n, 0), k1(n, 0);
+    std::vector<int> last(n, 0);
+    for (size_t q = 0; q < n; ++q) {
+        const UINT32 k = E[q];
+        block_t& B = blocks_[k];
+        const blockMeta_t& meta = v_blockMeta_[k];
+        pf[q] = B.part;
+        red[q] = B.red;
+        const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
+        const bool fwd_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
+        // the order of PhasedForwardBlock (a last block: the forward junction only), PhasedReverseBlock (a first block: the reverse
+        // one only) and PhasedCombineBlock (reverse, then forward)
+        if (meta._blockLast || meta._blockIsolated) {
+            last[q] = 1;
+            if (fwd_in) { j0[q] = blocks_[k - 1].jfwd; i0[q] = B.jslprev_here.data(); k0[q] = B.jslprev_here.size(); }
+        } else {
+            if (rev_in) { j0[q] = B.jrev; i0[q] = B.jsl_here.data(); k0[q] = B.jsl_here.size(); }
+            if (!meta._blockFirst && fwd_in) { j1[q] = blocks_[k - 1].jfwd; i1[q] = B.jslprev_here.data(); k1[q] = B.jslprev_here.size(); }
+        }
+    }
+    const int rc = dnagpu_small_batch_create(ctx_, (uint32_t)n, E.data(), pf.data(), red.data(), j0.data(), i0.data(), k0.data(), j1.data(), i1.data(),
+                                             k1.data(), last.data(), &small_batch_);
+    if (rc != DNAGPU_OK) {
+        small_batch_ = nullptr;
+        small_batch_denied_ = true;         // (a block beyond the kernels' limits, or no memory: the per-block path, for good)
+        return false;
+    }
+    small_batch_blocks_ = E;
+    return true;
+}
+
 // The small-block fast path of iterations >= 2 (a.reuse_factors): every block of the list that still holds its completed light factor of
 // iteration 1, all of them small enough for the one-workgroup kernels, in one launch.  false: nothing done (too few blocks, a block beyond
 // the kernels' limits, no memory): the per-block path takes them.
@@ -1520,45 +1563,7 @@ bool dna_adjust::SmallBatchCondense(std::vector<UINT32>& blocks) {
         (small && B.factor_live && B.part && B.part_spine && !B.part_transient && !B.keep.empty() ? E : rest).push_back(k);
     }
     if (E.size() < 32) return false;          // (a handful of blocks: the chains serve them as fast)
-    if (small_batch_ && E != small_batch_blocks_) {
-        dnagpu_small_batch_destroy(ctx_, small_batch_);
-        small_batch_ = nullptr;
-    }
-    if (!small_batch_) {
-        const size_t n = E.size();
-        std::vector<dnagpu_partial*> pf(n);
-        std::vector<dnagpu_matrix*> red(n);
-        std::vector<const dnagpu_matrix*> j0(n, nullptr), j1(n, nullptr);
-        std::vector<const UINT32*> i0(n, nullptr), i1(n, nullptr);
-        std::vector<size_t> k0(n, 0), k1(n, 0);
-        std::vector<int> last(n, 0);
-        for (size_t q = 0; q < n; ++q) {
-            const UINT32 k = E[q];
-            block_t& B = blocks_[k];
-            const blockMeta_t& meta = v_blockMeta_[k];
-            pf[q] = B.part;
-            red[q] = B.red;
-            const bool rev_in = !meta._blockLast && !B.jsl_here.empty();
-            const bool fwd_in = !meta._blockFirst && !meta._blockIsolated && !B.jslprev_here.empty();
-            // the order of PhasedForwardBlock (a last block: the forward junction only), PhasedReverseBlock (a first block: the reverse
-            // one only) and PhasedCombineBlock (reverse, then forward)
-            if (meta._blockLast || meta._blockIsolated) {
-                last[q] = 1;
-                if (fwd_in) { j0[q] = blocks_[k - 1].jfwd; i0[q] = B.jslprev_here.data(); k0[q] = B.jslprev_here.size(); }
-            } else {
-                if (rev_in) { j0[q] = B.jrev; i0[q] = B.jsl_here.data(); k0[q] = B.jsl_here.size(); }
-                if (!meta._blockFirst && fwd_in) { j1[q] = blocks_[k - 1].jfwd; i1[q] = B.jslprev_here.data(); k1[q] = B.jslprev_here.size(); }
-            }
-        }
-        const int rc = dnagpu_small_batch_create(ctx_, (uint32_t)n, E.data(), pf.data(), red.data(), j0.data(), i0.data(), k0.data(), j1.data(), i1.data(),
-                                                 k1.data(), last.data(), &small_batch_);
-        if (rc != DNAGPU_OK) {
-            small_batch_ = nullptr;
-            small_batch_denied_ = true;         // (a block beyond the kernels' limits, or no memory: the per-block path, for good)
-            return false;
-        }
-        small_batch_blocks_ = E;
-    }
+    if (!EnsureSmallBatch(E)) return false;
     Check(dnagpu_small_batch_condense(ctx_, 0, small_batch_), E.front(), "Solve()");
     Check(dnagpu_chain_sync(ctx_, 0), E.front(), "Solve()");       // (the chains read the reduced right-hand sides on other streams)
     for (UINT32 k : E) {
@@ -1618,6 +1623,60 @@ void dna_adjust::SmallBatchSolve(std::vector<UINT32>& blocks) {
     blocks.swap(rest);
 }
 
+// Iteration 1 of the same blocks: their kept blocks' factors have just been completed (RigorousBatch), their junction matrices are in place --
+// what is left of the rigorous solve is what the one-launch kernel does in every later iteration (right-hand side with the junctions'
+// contributions, its reduction by substitution, the kept block's solve, back-substitution, estimates).  58 us of launches per block otherwise (666 blocks of a default dnasegment cut: 39 ms -> 2 ms).
+void dna_adjust::SmallBatchFirstSolve(std::vector<UINT32>& blocks) {
+    if (!FactorReuse() || currentIteration_ != 1 || small_batch_denied_ || !dnagpu_info_carry(ctx_) || !DeferVariances()) return;
+    std::vector<UINT32> E, rest;
+    for (UINT32 k : blocks) {
+        const block_t& B = blocks_[k];
+        const bool small = B.shape_ni + B.shape_nk <= 2048u && 3 * v_parameterStationList_[k].size() <= 2048u && 3 * B.jsl_here.size() <= 2048u &&
+                           3 * B.jslprev_here.size() <= 2048u;
+        (small && B.part_valid && B.part && B.part_spine && !B.part_transient && !B.keep.empty() ? E : rest).push_back(k);
+    }
+    if (E.size() < 32) return;
+    // (the same blocks as SmallBatchCondense takes from iteration 2 on: one table serves both; those whose kept block no batch has
+    //  completed -- the odd one of a bucket -- get that here)
+    for (UINT32 k : E) {
+        block_t& B = blocks_[k];
+        if (B.prefactored) continue;
+        const blockMeta_t& meta = v_blockMeta_[k];
+        PrepareKeptBlock(0, k, (meta._blockLast || meta._blockIsolated) ? 0 : meta._blockFirst ? 1 : 2, kwork_[0]);
+        Check(dnagpu_partial_complete_factor(ctx_, 0, B.part, kwork_[0]), k, "Solve()");
+        B.prefactored = true;
+    }
+    if (!EnsureSmallBatch(E)) return;
+    std::vector<double> mv(E.size());
+    Check(dnagpu_small_batch_solve(ctx_, 0, small_batch_, mv.data()), E.front(), "Solve()");
+    for (size_t q = 0; q < E.size(); ++q) {
+        const UINT32 k = E[q];
+        block_t& B = blocks_[k];
+        const blockMeta_t& meta = v_blockMeta_[k];
+        B.part_valid = false;
+        B.prefactored = false;
+        B.factor_reused = false;
+        B.rig_direct = false;
+        B.var_deferred = true;
+        B.has_rigvar = false;
+        B.inverse_pending = CondensedReuse();
+        B.factor_live = true;
+        B.corr_chain = (meta._blockLast || meta._blockIsolated) ? -1 : 0;
+        const double n = 3.0 * (double)v_parameterStationList_[k].size(), nk = 3.0 * (double)B.keep.size();
+        {
+            std::lock_guard<std::mutex> lk(corr_mutex_);
+            solve_flops_ += n * n * n;
+            solve_count_++;
+            completion_count_++;
+            CountFlops(nk * nk * nk * 2.0 / 3.0, 0);         // (the kept block's factor and inverse: CompleteFromPartial's count)
+        }
+        PhasedNoteCorrection(mv[q]);
+    }
+    small_batch_steps_ += E.size();
+    currentBlock_ = E.back();
+    blocks.swap(rest);
+}
+
 void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks_in) {
     forward_ = true;
     std::vector<UINT32> blocks = blocks_in;
@@ -1637,12 +1696,42 @@ void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks_in) {
 // the forward chain on chain 0 beside the reverse chain on chain 1 (one after the other without a.multi_thread)
 void dna_adjust::CondensedChains() {
     const bool two = NumChains() > 1;
-    OnEveryChain([&](int c) {
-        if (c == 0)
-            for (UINT32 k = 0; k < blockCount_ && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
-        if (c == 1 || !two)
-            for (UINT32 kk = blockCount_; kk-- > 0 && !IsCancelled() && !chain_failed_;) CondensedReverseBlock(c, kk);
-    });
+    // Long chains of small steps (a dnasegment-default cut: 666 blocks): the elimination's verdict -- a pivot that is not positive -- is
+    // not waited for step by step (a wait per step kept the device idle while the host enqueued the next step's thirty launches) but
+    // taken once per chain; if any step failed, the phase is repeated the slow way, which names the block.
+    const bool held = blockCount_ >= 32 && dnagpu_info_carry(ctx_) != 0;
+    std::atomic<bool> failed{false};
+    auto run = [&](bool hold) {
+        OnEveryChain([&](int c) {
+            const bool mine = c == 0 || c == 1 || !two;
+            if (hold && mine) Check(dnagpu_chain_hold_info(ctx_, c, 1), 0, "Solve()");
+            try {
+                if (c == 0)
+                    for (UINT32 k = 0; k < blockCount_ && !IsCancelled() && !chain_failed_; ++k) CondensedForwardBlock(c, k);
+                if (c == 1 || !two)
+                    for (UINT32 kk = blockCount_; kk-- > 0 && !IsCancelled() && !chain_failed_;) CondensedReverseBlock(c, kk);
+            } catch (...) {
+                if (hold && mine) {
+                    dnagpu_chain_take_info(ctx_, c);
+                    dnagpu_chain_hold_info(ctx_, c, 0);
+                }
+                throw;
+            }
+            if (hold && mine) {
+                const int rc = dnagpu_chain_take_info(ctx_, c);
+                Check(dnagpu_chain_hold_info(ctx_, c, 0), 0, "Solve()");
+                if (rc == DNAGPU_ENOTPOSDEF)
+                    failed = true;
+                else
+                    Check(rc, 0, "Solve()");
+            }
+        });
+    };
+    run(held);
+    if (failed) {
+        for (block_t& B : blocks_) B.cfac_live[0] = B.cfac_live[1] = false;      // (factors of a failed run: every step eliminates again)
+        run(false);
+    }
 }
 
 void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks_in) {
@@ -1652,6 +1741,7 @@ void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks_in) {
     std::vector<UINT32> blocks = blocks_in;
     SmallBatchSolve(blocks);
     if (BatchCap() >= 2) ForGroups(BatchGroups(blocks, 1), [&](int c, const std::vector<UINT32>& ks) { RigorousBatch(c, ks); });
+    if (!IsCancelled()) SmallBatchFirstSolve(blocks);
     if (!IsCancelled()) ForBlocks(blocks, [&](int c, UINT32 k) { RigorousBlock(c, k); });
     isCombining_ = false;
 }

@@ -50,6 +50,7 @@ struct InvWorkspace {
     double* svec = nullptr;  // np_cap   : diagonal scaling
     int* info = nullptr;     // device ints (dpotrf-style info, 0 = ok), one per member of a batched call (BATCH_MAX)
     int* info_host = nullptr;  // pinned host copy
+    bool hold_info = false;    // dnagpu_chain_hold_info: the drivers leave `info` alone (the first failure of a run of calls stays in it)
     InvBatch batch;          // nb > 1: the call being enqueued is batched
     double* bX[BATCH_MAX] = {};   // members 1 .. of a batched call: their matrix being factored (bnp_cap^2) ...
     double* bW[BATCH_MAX] = {};   // ... and the panels inside a diagonal block (bw_cols x bnp_cap)

@@ -50,6 +50,12 @@ void inv_note_error(InvWorkspace& ws, hipError_t e, const char* where) {
     }
 }
 
+// 0x7f7f7f7f = "no failure", the sentinel atomicMin works against; skipped while a caller holds the verdict over a run of calls
+static void info_reset(InvWorkspace& ws) {
+    if (ws.hold_info) return;
+    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
+}
+
 hipError_t inv_take_error(InvWorkspace& ws, const char** where) {
     hipError_t e = ws.err;
     if (where) *where = ws.err_where;
@@ -487,7 +493,7 @@ void run_products(InvWorkspace& ws, uint64_t key, double* F, int ld, double* X, 
 }  // namespace
 
 void sym_inverse_async(InvWorkspace& ws, double* F, uint32_t n, uint32_t np, bool scale_to_unity, bool reset_info) {
-    if (reset_info) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
+    if (reset_info) info_reset(ws);  // 0x7f7f7f7f = "no failure" sentinel for atomicMin
     if (scale_to_unity) {
         launch_diag_rsqrt(F, ws.svec, n, np, ws.stream);
         launch_scale_sym(F, ws.svec, n, np, 1, ws.stream);
@@ -523,7 +529,7 @@ double schur_split() {
 }
 
 void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
+    info_reset(ws);
     auto ops = [&](Rec& rec, const double*) {
         if (ti > 0) rec.node(0, ti);
         if (ti > 0 && tj > 0) rec.eliminate(0, ti, tj);
@@ -533,7 +539,7 @@ void sym_schur_keep_async(InvWorkspace& ws, double* F, double* X, int ld, int ti
 }
 
 void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const double* WK, int ldwk, int ti, int tj, int what) {
-    if (what & 1) inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
+    if (what & 1) info_reset(ws);
     const int T = ti + tj;
     auto ops = [&](Rec& rec, const double* wk) {
         GemmArgs a;
@@ -570,7 +576,7 @@ void sym_complete_async(InvWorkspace& ws, double* F, double* X, int ld, const do
 }
 
 void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
+    info_reset(ws);
     const double split = schur_split();
     auto ops = [&](Rec& rec, const double*) { rec.spine(ti, tj, split); };
     run_products(ws, plan_key(DK_SPINE, 0, ti, tj), F, ld, S, ld, ws.W, ld, nullptr, ops);
@@ -578,7 +584,7 @@ void sym_spine_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int
 }
 
 void sym_spine_kept_async(InvWorkspace& ws, double* F, double* S, int ld, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
+    info_reset(ws);
     auto ops = [&](Rec& rec, const double*) {
         Rec::PLocal pl(rec, ti);
         rec.node(ti, tj);
@@ -617,7 +623,7 @@ std::vector<std::pair<int, int>> sym_spine_blocks(int ti) {
 }
 
 void sym_schur_async(InvWorkspace& ws, double* F, int ld, double* P, int ldp, int ti, int tj) {
-    inv_note_error(ws, hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), ws.stream), "info reset");
+    info_reset(ws);
     const int ldx = ti * 128;
     const double split = schur_split();
     auto ops = [&](Rec& rec, const double*) { rec.schur(ti, tj, split); };

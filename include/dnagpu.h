@@ -200,6 +200,22 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz);
 /* the same from DEVICE memory, one launch on the chain's stream, not waited for; with_b: measured-minus-computed of every chain as well
  * (dnagpu_block_compute_b's arithmetic; GNSS-only blocks) -- ResetAdjustment of a network of many small blocks */
 int dnagpu_block_reset_stations(dnagpu_ctx* ctx, int chain, uint32_t blk, const double* dev_xyz, int with_b);
+/* A set of GNSS-only blocks whose coordinate bookkeeping between iterations is ONE launch for all of them: block blks[q]'s a-priori
+ * coordinates at dev_init + init_off[q] (device memory that outlives the table), last[q] != 0 for the last block of a network.
+ * apply, mode 0 (ResetAdjustment): original = rigorous = estimated (every chain) = a-priori; mode 1 (UpdateAdjustment, dnaadjust.cpp:496-590):
+ * estimated (chains 0 .. chains-1) = rigorous, a last block's original = rigorous; both: measured-minus-computed of those chains
+ * (dnagpu_block_compute_b's arithmetic).  Enqueued on the chain's stream, not waited for.  EINVAL for a block with terrestrial measurements. */
+/* A run of elimination steps on one chain without a wait per step: while the verdict is held (on != 0) dnagpu_schur_carry and
+ * dnagpu_schur_carry_keep return as soon as their launches are enqueued and a pivot that is not positive stays recorded;
+ * dnagpu_chain_take_info waits for the chain, returns DNAGPU_ENOTPOSDEF (dnagpu_last_info: the leading minor) if any step of the run failed
+ * -- which one is not known: the caller repeats the run with the verdict not held to name it -- and clears the record. */
+int dnagpu_chain_hold_info(dnagpu_ctx* ctx, int chain, int on);
+int dnagpu_chain_take_info(dnagpu_ctx* ctx, int chain);
+typedef struct dnagpu_block_table dnagpu_block_table;
+int dnagpu_block_table_create(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const int* last, const double* dev_init, const size_t* init_off,
+                              dnagpu_block_table** out);
+int dnagpu_block_table_apply(dnagpu_ctx* ctx, int chain, const dnagpu_block_table* t, int mode, int chains);
+void dnagpu_block_table_destroy(dnagpu_ctx* ctx, dnagpu_block_table* t);
 /* stn1/stn2: block-local station of each baseline (CML order); obs: 3 per
  * baseline (dX,dY,dZ); vcv6: upper triangle per baseline in bms order
  * (XX, XY, YY, XZ, YZ, ZZ), already v-scaled.  Computes W = V^-1 on device. */

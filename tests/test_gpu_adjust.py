@@ -700,10 +700,30 @@ def test_factor_reuse_across_iterations(built, orc, tmp_path, mt, blocks):
         assert np.abs(v0[b] - v1[b]).max() <= 1e-13 * np.abs(v0[b]).max()
 
 
+def test_a_singular_chain_step_among_many_is_named(built, tmp_path):
+    """40 small blocks: the chains take the elimination's verdict once per chain, not per step (dnagpu_chain_hold_info); a step that
+    meets a pivot that is not positive makes the phase run again step by step, and the reference's message names the block
+    (dnamatrix_contiguous.cpp:983 through SolveTry, dnaadjust.cpp:6575-6582)"""
+    adjust.write_synthetic_network(str(tmp_path), "s", 80, 24, 0, 1, seed=12, rows_lo=2, rows_hi=2)
+    base = os.path.join(str(tmp_path), "s")
+    ISL, JSL, CML, nets = F.read_seg(base + ".seg")
+    assert len(ISL) == 40
+    msr = F.read_bms(base + ".bms")
+    target = int(JSL[20][len(JSL[20]) // 2])       # a junction station loses every measurement; free stations weigh nothing: a zero pivot
+    for k in range(len(CML)):
+        CML[k] = np.array([int(i) for i in CML[k] if int(msr[int(i)]["station1"]) != target and int(msr[int(i)]["station2"]) != target], dtype=np.uint32)
+    F.write_seg(base + ".seg", ISL, JSL, CML, nets, msr)
+    for mt in (False, True):
+        with pytest.raises(adjust.NetAdjustException) as e:
+            _device_run(str(tmp_path), "s", True, multi_thread=mt, free_std_dev=1e200)
+        import re
+        assert "singular" in str(e.value) and re.search(r"block (19|20|21|22)\b", str(e.value)), str(e.value)
+
+
 @pytest.mark.parametrize("mt", [False, True])
 def test_many_small_blocks_in_one_launch(built, orc, tmp_path, mt):
     """a dnasegment-like cut into 40 small blocks (strips of 2 rows of 24 stations; include/config/dnaoptions.hpp:382 makes 150-station blocks
-    by default): from iteration 2 on (a.reuse_factors) the condensing step and the rigorous solve of ALL blocks are one launch each
+    by default): the rigorous solve of ALL blocks is one launch in every iteration, from iteration 2 on (a.reuse_factors) the condensing step as well
     (dnagpu_small_batch_*: a workgroup per block), the chain steps one launch per step (dnagpu_chain_step_rhs).  Against the oracle, and
     against the run in which every iteration factors again."""
     info = adjust.write_synthetic_network(str(tmp_path), "m", 80, 24, 0, 1, seed=12, rows_lo=2, rows_hi=2, initial_sigma=0.3)
@@ -715,14 +735,14 @@ def test_many_small_blocks_in_one_launch(built, orc, tmp_path, mt):
     a, st = _device_run(str(tmp_path), "m", True, multi_thread=mt)
     _compare(a, st, o, ost)
     it = a.CurrentIteration()
-    assert it >= 2 and a.small_batch_steps() == (it - 1) * 40 and a.factor_reuses() == (it - 1) * 40
+    assert it >= 2 and a.small_batch_steps() == it * 40 and a.factor_reuses() == (it - 1) * 40      # (iteration 1: the rigorous solves only)
     assert a.chain_step_reuses() == (it - 1) * (2 * 40 - 4)
     fd, rec = _compare_statistics(a, o)
     x1 = [a.block_estimates(b) for b in range(40)]
     v1 = [a.block_variances_packed(b) for b in range(40)]
     # the same handle again (the table of the blocks is kept), and the run without reuse
     a.ResetAdjustment()
-    assert a.AdjustNetwork() == st and a.small_batch_steps() == (it - 1) * 40
+    assert a.AdjustNetwork() == st and a.small_batch_steps() == it * 40
     for b in range(40):
         assert np.array_equal(a.block_estimates(b), x1[b])
     a.close()
