@@ -137,6 +137,12 @@ struct dnagpu_ctx {
         uint32_t* dev = nullptr;
     };
     std::unordered_multimap<uint64_t, IndexList> idx_cache[DNAGPU_NUM_CHAINS];
+    // ... and the constraint weights that come with such lists (stage_f64: 9 doubles per station, the same in every iteration)
+    struct ValueList {
+        std::vector<double> host;
+        double* dev = nullptr;
+    };
+    std::unordered_multimap<uint64_t, ValueList> val_cache[DNAGPU_NUM_CHAINS];
     // pinned host landing zone for (max correction, row)
     double* red_val_host[DNAGPU_NUM_CHAINS] = {};
     uint32_t* red_idx_host[DNAGPU_NUM_CHAINS] = {};

@@ -169,16 +169,18 @@ void free_index_cache(dnagpu_ctx* ctx, int chain) {
     for (auto& kv : ctx->idx_cache[chain])
         if (kv.second.dev) hipFree(kv.second.dev);
     ctx->idx_cache[chain].clear();
+    for (auto& kv : ctx->val_cache[chain])
+        if (kv.second.dev) hipFree(kv.second.dev);
+    ctx->val_cache[chain].clear();
 }
 
 // upload a small host array to the chain's staging buffer (stream ordered).  Lists of 64 entries or more are kept (ctx.h IndexList):
 // the chain steps and rigorous solves of the condensed schedule send the same station lists in every iteration, and the upload's
 // stream synchronisation -- 4 - 5 per chain step of ~1.8 ms -- was a tenth of the chain phase
 int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, uint32_t** dev) {
-    static const bool cache_on = !(getenv("DNAGPU_INDEX_CACHE") && atoi(getenv("DNAGPU_INDEX_CACHE")) == 0);     // (diagnostic switch)
     // (round 5: lists from 4 entries on -- a dnasegment-default cut has junction lists of a few dozen stations, and every list that misses
     //  the cache costs a stream synchronisation in every chain step of every iteration)
-    if (cache_on && count >= 4) {
+    if (count >= 4) {
         uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
         for (size_t i = 0; i < count; ++i) h = (h ^ host[i]) * 1099511628211ull;
         auto& cache = ctx->idx_cache[chain];
@@ -219,6 +221,39 @@ int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, ui
 }
 
 int stage_f64(dnagpu_ctx* ctx, int chain, const double* host, size_t count, double** dev) {
+    // (round 5: kept by content like the index lists -- the constraint weights of a chain step are the same in every iteration, and the
+    //  upload's stream synchronisation stood in every step of a chain that otherwise waits for nothing)
+    if (count >= 9 && count <= 9 * 4096) {
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
+        for (size_t i = 0; i < count; ++i) {
+            uint64_t bits;
+            memcpy(&bits, host + i, sizeof(bits));
+            h = (h ^ bits) * 1099511628211ull;
+        }
+        auto& cache = ctx->val_cache[chain];
+        auto range = cache.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (it->second.host.size() == count && !memcmp(it->second.host.data(), host, count * sizeof(double))) {
+                *dev = it->second.dev;
+                return DNAGPU_OK;
+            }
+        const size_t cap = std::max<size_t>(512, 24 * ctx->blocks.size());
+        double* d = nullptr;
+        hipError_t e = cache.size() >= cap ? hipErrorOutOfMemory : dnagpu::poison_malloc(&d, count * sizeof(double));
+        if (e == hipSuccess) {
+            e = hipMemcpy(d, host, count * sizeof(double), hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                dnagpu_ctx::ValueList l;
+                l.host.assign(host, host + count);
+                l.dev = d;
+                cache.emplace(h, std::move(l));
+                *dev = d;
+                return DNAGPU_OK;
+            }
+            hipFree(d);
+        }
+        (void)hipGetLastError();
+    }
     int rc = ensure_scr_f64(ctx, chain, count);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->scr_f64[chain], host, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
