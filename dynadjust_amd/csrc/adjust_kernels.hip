@@ -872,18 +872,27 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const double* __restrict
                                                         double* __restrict__ inv, uint32_t np) {
     const uint32_t i = blockIdx.x * 128 + (threadIdx.x & 127);
     const int32_t mi = map[i];
-    for (uint32_t jl = threadIdx.x >> 7; jl < 128; jl += 2) {
-        const uint32_t j = blockIdx.y * 128 + jl;
-        const int32_t mj = map[j];
-        if (mi >= 0 && mj >= 0) inv[(size_t)mj * np + mi] = F[(size_t)j * ldf + i];
+    if (mi < 0) return;
+    // (round 5: a tile's 128 columns over four workgroups -- blockIdx.z -- and a thread's 16 loads in flight together: a 768 x 768 matrix of a
+    //  small block took 62 us on 36 workgroups of 64 dependent load / store pairs each)
+    const uint32_t j0 = blockIdx.y * 128 + blockIdx.z * 32 + (threadIdx.x >> 7);
+    double v[16];
+    int32_t mj[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        mj[t] = map[j0 + 2 * t];
+        v[t] = F[(size_t)(j0 + 2 * t) * ldf + i];
     }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        if (mj[t] >= 0) inv[(size_t)mj[t] * np + mi] = v[t];
 }
 
 void launch_partial_set_trailing(double* T, uint32_t ldt, uint32_t njp, const double* kk, uint32_t npk, uint32_t nj, hipStream_t s) {
     hipLaunchKernelGGL(partial_set_trailing_kernel, dim3((njp + 255) / 256, njp), dim3(256), 0, s, T, ldt, njp, kk, npk, nj);
 }
 void launch_unpermute(const double* F, uint32_t ldf, uint32_t npp, const int32_t* map, double* inv, uint32_t np, hipStream_t s) {
-    hipLaunchKernelGGL(unpermute_kernel, dim3(npp / 128, npp / 128), dim3(256), 0, s, F, ldf, map, inv, np);
+    hipLaunchKernelGGL(unpermute_kernel, dim3(npp / 128, npp / 128, 4), dim3(256), 0, s, F, ldf, map, inv, np);
 }
 
 void launch_schur_permute(const double* src, uint32_t lds, const int32_t* map, const double* rhs, double* dst, uint32_t ldd, uint32_t npp,

@@ -185,7 +185,10 @@ __device__ __forceinline__ void run_ops(int n, int lane, Gen gen) {
     }
 }
 
-// meet: one int of LDS (the counter the waves other than wave 0 meet at)
+// meet: two ints of LDS -- [0] the counter the waves other than wave 0 meet at, [1] the last 16-column block of the tile that holds
+// anything but identity padding (round 5): a tile whose trailing blocks are padding -- the ragged end of every matrix, the whole second
+// tile of a 150-unknown junction -- stops after its real blocks; every step it leaves out would have multiplied zeros and ones
+// (the padding's factor and inverse are the identity, its panels zero), so the results are the same bits.
 template <int NW, class Blk>
 __device__ __forceinline__ void potrf_trtri_tile_overlapped(const double* __restrict__ A, int lda, double* __restrict__ X, int ldx, int o, int* info,
                                                             double* const LT, int* const meet, Blk blk) {
@@ -197,7 +200,11 @@ __device__ __forceinline__ void potrf_trtri_tile_overlapped(const double* __rest
     const int oid = tid - 64;             // ... numbered
 
     LEAF_PROBE(0);
-    if (tid == 0) *meet = 0;
+    if (tid == 0) {
+        meet[0] = 0;
+        meet[1] = 0;
+    }
+    int real_blk = 0;       // the last row block this thread saw something other than padding in (an entry off the diagonal, a diagonal entry != 1)
     // block column 0 (16 columns x 128 rows: 4 elements per thread)
     {
         const int row = tid & 127, q = tid >> 7;
@@ -211,11 +218,13 @@ __device__ __forceinline__ void potrf_trtri_tile_overlapped(const double* __rest
         for (int t = 0; t < 4; ++t) {
             const int c = q + 4 * t;
             blk(row >> 4, 0)[(row & 15) * BR + c] = v[t];
+            if (row >= c && !(v[t] == (row == c ? 1.0 : 0.0))) real_blk = max(real_blk, row >> 4);
         }
     }
     __syncthreads();
     LEAF_PROBE(1);
     if (wave == 0) {
+        if (real_blk) atomicMax(&meet[1], real_blk);
         __builtin_amdgcn_s_setprio(2);
         diag_block(blk(0, 0), LT, lane, info, o);
         __builtin_amdgcn_s_setprio(0);
@@ -231,13 +240,16 @@ __device__ __forceinline__ void potrf_trtri_tile_overlapped(const double* __rest
         for (int t = 0; t < 32; ++t) {
             const int e = oid + NO * t, row = e & 127, c = 16 + (e >> 7);
             if ((row >> 4) >= (c >> 4)) blk(row >> 4, c >> 4)[(row & 15) * BR + (c & 15)] = v[t];
+            if (row >= c && !(v[t] == (row == c ? 1.0 : 0.0))) real_blk = max(real_blk, row >> 4);
         }
+        if (real_blk) atomicMax(&meet[1], real_blk);
     }
     __syncthreads();
     LEAF_PROBE(2);
+    const int nreal = __builtin_amdgcn_readfirstlane(meet[1]) + 1;      // blocks 0 .. nreal - 1 hold the matrix, the rest is identity padding
 
 #pragma unroll 1
-    for (int kb = 0; kb < 8; ++kb) {
+    for (int kb = 0; kb < nreal; ++kb) {
         const double* xd = blk(kb, kb);
         // round P: the panel below diagonal block kb, P = A_panel * D^-T (7 - kb blocks), and -- phase B, last operation of step
         // kb - 1, after every reader of L(i, kb-1) -- M(i, kb-1) = -L(i, kb-1) D_(kb-1)^-1, i >= kb (8 - kb blocks): all independent.
@@ -333,12 +345,16 @@ __device__ __forceinline__ void potrf_trtri_tile_overlapped(const double* __rest
         __syncthreads();
         LEAF_PROBE(4 + 2 * kb);
     }
-    // row block 7
+    // the row blocks the loop has not written: the last one always; after a shortened loop also the last real one and the padding's
+    // (identity rows, as they were loaded)
+#pragma unroll 1
+    for (int rb = nreal - 1; rb < 8; ++rb) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int e = tid + 512 * t, r = e & 15, c = e >> 4, row = 112 + r;
-        const double v = (row >= c) ? blk(7, c >> 4)[r * BR + (c & 15)] : 0.0;
-        X[(size_t)c * ldx + row] = v;
+        for (int t = 0; t < 4; ++t) {
+            const int e = tid + 512 * t, r = e & 15, c = e >> 4, row = 16 * rb + r;
+            const double v = (row >= c) ? blk(rb, c >> 4)[r * BR + (c & 15)] : 0.0;
+            X[(size_t)c * ldx + row] = v;
+        }
     }
     LEAF_PROBE(20);
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
     // LT: the factor of the current diagonal block, transposed (wave 0 only) -- first, so that its constant addresses fit the
     // 16-bit offset field of the ds instructions (behind S they took a register each)
     __shared__ double SH[256 + 36 * leaf::BS];
-    __shared__ int meet;
+    __shared__ int meet[2];
     double* const S = SH + 256;
     if (batch.nb > 1) {     // one workgroup per member of the batch
         const int b = (int)blockIdx.x;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512) void leaf_potrf_trtri_kernel(const double* __r
         X += batch.dX[b];
         info += b;
     }
-    leaf::potrf_trtri_tile_overlapped<8>(A + (size_t)o * lda + o, lda, X + (size_t)o * ldx + o, ldx, o, info, SH, &meet, [S](int bi, int bj) { return S + (bi * (bi + 1) / 2 + bj) * leaf::BS; });
+    leaf::potrf_trtri_tile_overlapped<8>(A + (size_t)o * lda + o, lda, X + (size_t)o * ldx + o, ldx, o, info, SH, meet, [S](int bi, int bj) { return S + (bi * (bi + 1) / 2 + bj) * leaf::BS; });
 }
 
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s, const LeafBatch* batch) {

@@ -604,7 +604,7 @@ def test_schur_carry_matches_full_solves(built, orc, tmp_path, mt, blocks, terr)
 def test_information_form_of_the_junction_carry(built, orc, tmp_path, mt, blocks, terr, condensed):
     """dnagpu_schur_carry in information form (default: the junction's weight matrix S and reduced right-hand side r travel, the
     receiving block adds r + S (the sender's estimates - its own); S is never inverted) against its estimates form
-    (DNAGPU_INFO_CARRY=0: S inverted, estimates + S^-1 r carried, CarryStnEstimatesandVariancesForward dnaadjust.cpp:998-1128):
+    (dnagpu_debug_set_info_carry(0): S inverted, estimates + S^-1 r carried, CarryStnEstimatesandVariancesForward dnaadjust.cpp:998-1128):
     same adjustment, every iteration's correction, every estimate and variance; fewer flops counted.  A terrestrial network has its
     estimates move between the iterations (the linearisation point of both blocks of a junction is the same one)."""
     if terr:

@@ -94,7 +94,7 @@ def big_tiles_only(built):
 
 @pytest.mark.parametrize("n", [129, 255, 257, 640, 1000, 1500])
 def test_throughput_kernel_against_oracle_at_small_orders(gpu_ctx, orc, big_tiles_only, n):
-    """DNAGPU_SMALL_TILES = 0: the LDS-DMA kernel -- swizzled S layout, descending k walk, tile tables -- runs the launches the
+    """dnagpu_debug_set_small_tiles(0): the LDS-DMA kernel -- swizzled S layout, descending k walk, tile tables -- runs the launches the
     64-tile kernel normally takes, at orders where the scalar oracle answers at once; element-wise comparison"""
     M = _dense_spd(n, n)
     ap = pack_lower(M)
@@ -108,7 +108,7 @@ def test_throughput_kernel_against_oracle_at_small_orders(gpu_ctx, orc, big_tile
 
 @pytest.mark.parametrize("n", [100, 257, 640, 1000, 1500, 2304, 4096])
 def test_tiny_launches_on_32_tiles_have_the_bits_of_64_tiles(gpu_ctx, built, orc, n):
-    """DNAGPU_TINY_TILES (round 4): products of fewer than 64 128-tiles run on 32 x 32 block tiles -- sixteen times the workgroups of the 128-tile
+    """dnagpu_debug_set_tiny_tiles (round 4): products of fewer than 64 128-tiles run on 32 x 32 block tiles -- sixteen times the workgroups of the 128-tile
     shape, so that the bottom of the recursion and the chains on condensed blocks occupy more than a handful of CUs.  An element's k order does
     not depend on the tile it is computed in: the inverse is bit for bit the one with the 32-tile shape off, and within 1e-11 of the oracle."""
     M = _dense_spd(n, n + 7)
