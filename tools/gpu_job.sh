@@ -1,10 +1,11 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-export GPU_MAX_HW_QUEUES=16
-mkdir -p gpurun_out/j13
-timeout 1200 python -m pytest tests/test_gpu_matrix.py tests/test_gpu_kernels.py tests/test_gpu_adjust.py tests/test_gpu_batch.py tests/test_gpu_terrestrial.py tests/test_gpu_exact.py -q -m gpu -x 2>&1 | tail -5
-for w in dnasegment150 smallblocks cfg3; do
-  DNAGPU_PHASE_TIMES=1 timeout 600 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain > gpurun_out/j13/$w.json 2> gpurun_out/j13/$w.err
-  cut -c1-250 gpurun_out/j13/$w.json; grep "phase" gpurun_out/j13/$w.err | tail -24 | grep "iteration 1\|variance\|AdjustNetwork"
-done
-timeout 300 python tools/gpu_inverse_bench.py 2>/dev/null | tail -12
+mkdir -p gpurun_out
+T0=$SECONDS
+timeout 1500 python -m pytest tests -q -m gpu -x --durations=15 2>&1 | tail -30 > gpurun_out/gpu_suite.txt
+echo "suite: $((SECONDS - T0)) s" >> gpurun_out/gpu_suite.txt
+tail -8 gpurun_out/gpu_suite.txt
+SKIP_PMC=1 TAG=r05 bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
+echo "total: $((SECONDS - T0)) s"
+for f in gpurun_out/profiles_new/r05_bench_*.json; do echo $f; cut -c1-300 $f; echo; done
+cat gpurun_out/profiles_new/r05_inverse_rates.txt

@@ -36,6 +36,7 @@ for w in smallblocks dnasegment150; do
   python $R/tools/rocprof_summary.py stats /tmp/kt_$w $O/${TAG}_${w}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --workload $w ${F}   (${TAG}; the trace covers PrepareAdjustment, ONE adjustment and the closing statistics)"
 done
 # ---- PMC passes (one chain; each counter set its own run) ----
+if [ -z "$SKIP_PMC" ]; then
 DNAGPU_MULTI_THREAD=0 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_mfma -o p --output-format csv -- timeout 600 $B $F > $O/pmc_mfma.log 2>&1
 python $R/tools/rocprof_summary.py pmc /tmp/pmc_mfma $O/${TAG}_cfg3_pmc_mfma_util.txt "DNAGPU_MULTI_THREAD=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- $CMD   (${TAG}, cfg3, one chain: MFMA pipe utilisation per kernel)"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -46,6 +47,7 @@ done
 (cd $O && python $R/tools/pmc_traffic_json.py ${TAG}_cfg3_pmc_fetch_size.txt ${TAG}_cfg3_pmc_write_size.txt ${TAG}_hbm_traffic.json cfg3 > /dev/null)
 DNAGPU_MULTI_THREAD=0 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d /tmp/pmc_l2 -o p --output-format csv -- timeout 600 $B $F > $O/pmc_l2.log 2>&1
 python $R/tools/rocprof_summary.py pmc /tmp/pmc_l2 $O/${TAG}_cfg3_pmc_l2_hits.txt "DNAGPU_MULTI_THREAD=0 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -- $CMD   (${TAG}, cfg3, one chain: L2 hits / misses per kernel; hit rate = HIT / (HIT + MISS))"
+fi
 # ---- rates and the N-GPU model ----
 { echo "# python tools/gpu_inverse_bench.py on 1 x MI355X (${TAG}), through the C-ABI, best of 3 timed repetitions, one chain"; timeout 300 python $R/tools/gpu_inverse_bench.py 2>/dev/null; } > $O/${TAG}_inverse_rates.txt
 timeout 600 python $R/tools/gpu_rank_share.py > $O/${TAG}_rank_share.txt 2>/dev/null
