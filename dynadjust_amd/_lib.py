@@ -35,7 +35,7 @@ class DnaAdjSettings(C.Structure):
                 ("scale_normals_to_unity", C.c_int), ("device", C.c_int), ("confidence_interval", C.c_float),
                 ("output_tstat", C.c_int), ("network_name", C.c_char_p), ("output_folder", C.c_char_p), ("reuse_inverses", C.c_int), ("schur_carry", C.c_int), ("stage", C.c_int), ("keep_factors", C.c_int),
                 ("dist_rank", C.c_int), ("dist_world", C.c_int), ("n_devices", C.c_int), ("devices", C.POINTER(C.c_int)),
-                ("dist_transport", C.c_char_p), ("dist_two_level", C.c_int), ("defer_variances", C.c_int), ("batch_blocks", C.c_int), ("reuse_factors", C.c_int)]
+                ("dist_transport", C.c_char_p), ("dist_two_level", C.c_int), ("defer_variances", C.c_int), ("batch_blocks", C.c_int), ("reuse_factors", C.c_int), ("chain_runs", C.c_int)]
 
 
 class DnaAdjStatistics(C.Structure):
@@ -167,6 +167,10 @@ def load():
     _sig(lib, "dnagpu_small_batch_condense", i, [vp, i, vp])
     _sig(lib, "dnagpu_small_batch_solve", i, [vp, i, vp, c_f64p])
     _sig(lib, "dnagpu_small_batch_destroy", None, [vp, vp])
+    _sig(lib, "dnagpu_chain_plan_create", i, [vp, sz, vp, sz, c_u32p, C.c_double, vp])
+    _sig(lib, "dnagpu_chain_plan_run", i, [vp, i, vp, sz])
+    _sig(lib, "dnagpu_chain_plan_run_rhs", i, [vp, i, vp, sz, sz])
+    _sig(lib, "dnagpu_chain_plan_destroy", None, [vp, vp])
     _sig(lib, "dnagpu_chain_step_rhs", i, [vp, i, u32, u32, c_u32p, sz, vp, vp, c_u32p, sz, vp, c_u32p, sz, vp])
     _sig(lib, "dnagpu_schur_carry_keep", i, [vp, i, u32, vp, c_u32p, sz, vp, vp])
     _sig(lib, "dnagpu_schur_carry_rhs", i, [vp, i, u32, c_u32p, sz, vp, vp])
@@ -230,6 +234,7 @@ def load():
     _sig(lib, "dnaadj_minimal_work_flops", C.c_double, [vp])
     _sig(lib, "dnaadj_chain_step_reuses", C.c_uint64, [vp])
     _sig(lib, "dnaadj_small_batch_steps", C.c_uint64, [vp])
+    _sig(lib, "dnaadj_chain_runs", C.c_int, [vp])
     _sig(lib, "dnaadj_algorithmic_flops", C.c_double, [vp])
     _sig(lib, "dnaadj_station_count", u32, [vp])
     _sig(lib, "dnaadj_block_station_count", u32, [vp, u32])
@@ -331,13 +336,14 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_schur_carry_keep", "dnagpu_schur_carry_rhs", "dnagpu_chain_step_rhs", "dnagpu_small_batch_create", "dnagpu_small_batch_condense", "dnagpu_small_batch_solve", "dnagpu_small_batch_destroy", "dnagpu_junction_export", "dnagpu_junction_import", "dnagpu_junction_device_pointers", "dnagpu_block_reduce", "dnagpu_block_form_reduce", "dnagpu_batch_reserve", "dnagpu_block_form_reduce_batched", "dnagpu_partial_complete_factor_batched", "dnagpu_partial_finish_batched", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_create_spine", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
+    "dnagpu_chain_plan_create", "dnagpu_chain_plan_run", "dnagpu_chain_plan_run_rhs", "dnagpu_chain_plan_destroy",
 ]
 
 EXPORTED_DNAADJ = [
     "dnaadj_default_settings", "dnaadj_create", "dnaadj_destroy", "dnaadj_last_error", "dnaadj_prepare", "dnaadj_adjust",
     "dnaadj_cancel", "dnaadj_reset", "dnaadj_block_count", "dnaadj_iterations", "dnaadj_max_correction", "dnaadj_iteration_correction",
     "dnaadj_measurement_count", "dnaadj_unknowns_count", "dnaadj_degrees_of_freedom", "dnaadj_adjust_time_ms",
-    "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_completion_count", "dnaadj_factor_reuses", "dnaadj_chain_step_reuses", "dnaadj_small_batch_steps", "dnaadj_minimal_work_flops", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
+    "dnaadj_solve_flops", "dnaadj_solve_count", "dnaadj_elimination_count", "dnaadj_completion_count", "dnaadj_factor_reuses", "dnaadj_chain_step_reuses", "dnaadj_small_batch_steps", "dnaadj_chain_runs", "dnaadj_minimal_work_flops", "dnaadj_algorithmic_flops", "dnaadj_station_count", "dnaadj_block_station_count", "dnaadj_block_stations",
     "dnaadj_block_estimates", "dnaadj_block_variances_packed", "dnaadj_adjusted_coordinates", "dnaadj_device_context",
     "dnaimport_text", "dnaimport_text_geo", "dnaadj_dist_rccl_available", "dnaadj_dist_unique_id", "dnaadj_dist_attach_rccl", "dnaadj_adjust_distributed", "dnaadj_dist_info",
     "dnaadj_block_owner", "dnaadj_exchange_stats", "dnaadj_device_instance_context", "dnaadj_device_instance_stats", "dnaadj_debug_cancel_instance", "dnaadj_debug_tcp_share_unique_id",

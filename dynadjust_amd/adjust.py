@@ -35,7 +35,7 @@ class ProjectSettings:
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
                  scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None,
                  reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False, dist_rank=0, dist_world=1, devices=None,
-                 dist_transport=None, dist_two_level=True, defer_variances=2, batch_blocks=16, reuse_factors=True):
+                 dist_transport=None, dist_two_level=True, defer_variances=2, batch_blocks=16, reuse_factors=True, chain_runs=-1):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
         self.network_name = network_name          # g.network_name
         self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
@@ -50,6 +50,7 @@ class ProjectSettings:
         self.dist_transport, self.dist_two_level = dist_transport, dist_two_level
         self.defer_variances = defer_variances
         self.reuse_factors = reuse_factors        # GNSS-only networks: iterations >= 2 keep the factors of iteration 1 (right-hand sides only)
+        self.chain_runs = chain_runs              # many small blocks on one GPU: the junction chains in this many runs advancing together (-1: choose)
         self.batch_blocks = batch_blocks          # condensed schedule: blocks of one shape as one batch of merged launches (0 / 1 = off)
         if network_name is not None:
             self.set_filenames(os.path.join(folder, network_name))
@@ -144,6 +145,7 @@ class DnaAdjust:
         s.defer_variances = int(getattr(p, "defer_variances", 2))
         s.batch_blocks = int(getattr(p, "batch_blocks", 16))
         s.reuse_factors = int(bool(getattr(p, "reuse_factors", True)))
+        s.chain_runs = int(getattr(p, "chain_runs", -1))
         return s
 
     # ---- multi-GPU (include/dnaadjust_c.h "multi-GPU") ----
@@ -326,6 +328,10 @@ class DnaAdjust:
     def small_batch_steps(self):
         """of factor_reuses(): block steps that went out as one launch over many small blocks (dnagpu_small_batch_*)"""
         return int(self.lib.dnaadj_small_batch_steps(self.h))
+
+    def chain_runs(self):
+        """a.chain_runs: the runs the junction chains are cut into (their steps advance together in merged launches); 0 = step by step"""
+        return int(self.lib.dnaadj_chain_runs(self.h))
 
     def chain_step_reuses(self):
         return int(self.lib.dnaadj_chain_step_reuses(self.h))

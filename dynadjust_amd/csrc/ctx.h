@@ -44,6 +44,22 @@ struct dnagpu_small_batch {
     std::vector<uint32_t*> idx_dev;       // the junction station lists, device copies owned by the batch
 };
 
+// dnagpu_chain_plan_*: chain steps as data (small_steps.h CbStep), grouped into lock-step batches
+struct dnagpu_chain_plan {
+    size_t n_steps = 0;
+    std::vector<uint32_t> batch_first;                // n_batches + 1
+    struct Shape { uint32_t nip, njp, npp, outnp_max; };
+    std::vector<Shape> shape;                         // per batch: the padded orders its members are eliminated in
+    void* table = nullptr;                            // CbStep[n_steps], device
+    void* blob = nullptr;                             // index lists, maps, constraint blocks, scratch vectors (one allocation)
+    double* factors = nullptr;                        // the steps' kept factors (one allocation)
+    std::vector<double*> X;                           // per step: its factor
+    struct Out { dnagpu_matrix* m; uint32_t nj; int junction; };
+    std::vector<Out> out;                             // per step: where its result goes (host-side fields are set when the step runs)
+    std::vector<uint8_t> factored;                    // per batch: dnagpu_chain_plan_run has been through it
+    double flops = 0.0;
+};
+
 // dnagpu_block_table_*: device rows (adjust_kernels.h BlockTableRow) of a set of GNSS-only blocks
 struct dnagpu_block_table {
     uint32_t n = 0, max_len = 0;

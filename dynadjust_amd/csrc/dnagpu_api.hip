@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 #include "adjust_kernels.h"
@@ -289,6 +290,8 @@ double* station_vec(Block& b, int which, int chain) {
         default: return nullptr;
     }
 }
+
+int check_info_batch(dnagpu_ctx* ctx, int chain, int nb, int* failed_member);
 
 int check_info(dnagpu_ctx* ctx, int chain) {
     // an enqueue that failed (table allocation, launch, copy) leaves `info` at its sentinel: it is reported first
@@ -1168,10 +1171,11 @@ int dnagpu_chain_take_info(dnagpu_ctx* ctx, int chain) {
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
     hipStream_t st = ctx->stream[chain];
-    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    // (every member's word: the run may have held batched steps -- dnagpu_chain_plan_run --, whose member b reports in info[b])
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, BATCH_MAX * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
-    return check_info(ctx, chain);
+    return check_info_batch(ctx, chain, BATCH_MAX, nullptr);
 }
 
 int dnagpu_block_set_station_geo(dnagpu_ctx* ctx, uint32_t blk, const double* llh, const double* geoid, const double* defl) {
@@ -2186,6 +2190,10 @@ int dnagpu_chain_step_rhs(dnagpu_ctx* ctx, int chain, uint32_t rblk, uint32_t sr
     const std::vector<std::pair<int, int>> blocks = sym_spine_blocks((int)(keep->nip / 128));
     if (keep->npp > SMALL_STEP_MAX || 3 * k_keep > SMALL_STEP_MAX || (jm_in && 3 * k_in > SMALL_STEP_MAX) || blocks.size() > (size_t)SMALL_STEP_BLOCKS)
         return DNAGPU_ETOOLARGE;        // (not an error: the caller takes the step through the separate calls)
+    // One workgroup streams the factor at one CU's share of the fabric (48 us per padded megabyte, profiles/HISTORY.md); the separate
+    // calls are a dozen launches (~ 100 us) whose products run at the chip's HBM rate: beyond ~ 2 MB of factor they are the faster way
+    // (cfg3's 2 048-unknown steps: 581 us in one launch).
+    if (((size_t)keep->nip * keep->nip / 2 + (size_t)(keep->npp - keep->nip) * keep->nip) * sizeof(double) > SMALL_STEP_BYTES) return DNAGPU_ETOOLARGE;
     for (size_t i = 0; i < k_keep; ++i)
         if (idx_keep[i] >= sb->n_stn) return fail(ctx, DNAGPU_EINVAL, "chain_step_rhs: station out of range");
     for (size_t i = 0; i < k_out; ++i)
@@ -2730,6 +2738,241 @@ int check_info_batch(dnagpu_ctx* ctx, int chain, int nb, int* failed_member) {
 }  // namespace
 
 extern "C" {
+
+// ---- chain plans (include/dnagpu.h; kernels: small_steps.hip) ---------------------------------------------------------------------------
+void dnagpu_chain_plan_destroy(dnagpu_ctx* ctx, dnagpu_chain_plan* plan) {
+    if (!plan) return;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+    }
+    if (plan->table) hipFree(plan->table);
+    if (plan->blob) hipFree(plan->blob);
+    if (plan->factors) hipFree(plan->factors);
+    delete plan;
+}
+
+int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain_step* steps, size_t n_batches, const uint32_t* batch_first,
+                             double max_bytes, dnagpu_chain_plan** out) {
+    CHK_CTX();
+    if (!out) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: null out");
+    *out = nullptr;
+    if (!n_steps || !steps || !n_batches || !batch_first || batch_first[0] != 0 || batch_first[n_batches] != n_steps)
+        return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad arguments");
+    std::unique_ptr<dnagpu_chain_plan> plan(new (std::nothrow) dnagpu_chain_plan());
+    if (!plan) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    plan->n_steps = n_steps;
+    plan->batch_first.assign(batch_first, batch_first + n_batches + 1);
+    plan->shape.resize(n_batches);
+    plan->factored.assign(n_batches, 0);
+    plan->X.resize(n_steps);
+    plan->out.resize(n_steps);
+    std::vector<CbStep> table(n_steps);
+    // everything the steps refer to that is not a matrix goes into one blob: offsets first, device addresses once it is allocated
+    std::vector<uint8_t> blob;
+    auto put = [&](const void* src, size_t bytes) {
+        const size_t off = (blob.size() + 15) & ~(size_t)15;
+        blob.resize(off + bytes);
+        if (src) memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    struct Offs { size_t est, con, map, keep, xe, rhs, pos[CB_SRC_MAX], inv[CB_SRC_MAX]; bool has_est, has_con; };
+    std::vector<Offs> offs(n_steps);
+    double factor_bytes = 0.0;
+    std::vector<size_t> x_off(n_steps);
+    for (size_t q = 0; q < n_batches; ++q) {
+        const uint32_t f = batch_first[q], l = batch_first[q + 1];
+        if (l <= f || l - f > (uint32_t)BATCH_MAX) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a batch is empty or too large");
+        uint32_t nip = 0, njp = 0, outnp_max = 0;
+        for (uint32_t s = f; s < l; ++s) {
+            const dnagpu_chain_step& st = steps[s];
+            const uint32_t n = 3 * st.n_stn, nj = (uint32_t)(3 * st.n_keep);
+            if (!st.n_stn || !st.n_keep || !st.keep || !st.out || st.n_src < 1 || st.n_src > CB_SRC_MAX || (st.n_con && (!st.con_stn || !st.con_w9)) ||
+                (st.est_blk == nullptr) != (st.est_idx == nullptr) || nj > st.out->n_max)
+                return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad step");
+            if (nj > n) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: more stations kept than there are");
+            if (n > SMALL_STEP_MAX) return DNAGPU_ETOOLARGE;      // (nj = n: nothing to eliminate -- the system itself is carried on)
+            nip = std::max(nip, pad128(n - nj));
+            njp = std::max(njp, pad128(nj + 1));
+            outnp_max = std::max(outnp_max, pad128(nj));
+        }
+        const uint32_t npp = nip + njp;
+        if (npp > SMALL_STEP_MAX || sym_spine_blocks((int)(nip / 128)).size() > (size_t)SMALL_STEP_BLOCKS) return DNAGPU_ETOOLARGE;
+        plan->shape[q] = {nip, njp, npp, outnp_max};
+        for (uint32_t s = f; s < l; ++s) {
+            x_off[s] = (size_t)(factor_bytes / 8.0);
+            factor_bytes += 8.0 * (double)npp * npp;
+        }
+    }
+    if (factor_bytes > max_bytes) return DNAGPU_ETOOLARGE;
+    for (size_t q = 0; q < n_batches; ++q) {
+        const dnagpu_chain_plan::Shape sh = plan->shape[q];
+        const auto blocks = sym_spine_blocks((int)(sh.nip / 128));
+        for (uint32_t s = batch_first[q]; s < batch_first[q + 1]; ++s) {
+            const dnagpu_chain_step& st = steps[s];
+            CbStep& d = table[s];
+            Offs& o = offs[s];
+            memset(&d, 0, sizeof(d));
+            const uint32_t n = 3 * st.n_stn, nj = (uint32_t)(3 * st.n_keep);
+            d.n_stn = st.n_stn; d.nj = nj; d.k_out = (uint32_t)st.n_keep; d.nip = sh.nip; d.njp = sh.njp; d.npp = sh.npp; d.n_src = (uint32_t)st.n_src;
+            d.nblocks = (int)blocks.size();
+            for (size_t b = 0; b < blocks.size(); ++b) {
+                d.blk_o[b] = (uint32_t)blocks[b].first * 128;
+                d.blk_h[b] = (uint32_t)blocks[b].second * 128;
+            }
+            // the elimination's order: the stations that leave (system order), padding, the kept stations (list order), the right-hand side's row
+            std::vector<uint8_t> kept(st.n_stn, 0);
+            for (size_t i = 0; i < st.n_keep; ++i) {
+                if (st.keep[i] >= st.n_stn || kept[st.keep[i]]) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad list of kept stations");
+                kept[st.keep[i]] = 1;
+            }
+            std::vector<int32_t> map(sh.npp, -1);
+            uint32_t pos = 0;
+            for (uint32_t t = 0; t < st.n_stn; ++t)
+                if (!kept[t])
+                    for (int c = 0; c < 3; ++c) map[pos++] = (int32_t)(3 * t + c);
+            for (size_t i = 0; i < st.n_keep; ++i)
+                for (int c = 0; c < 3; ++c) map[sh.nip + 3 * i + c] = (int32_t)(3 * st.keep[i] + c);
+            map[sh.nip + nj] = -2;
+            o.map = put(map.data(), map.size() * sizeof(int32_t));
+            o.keep = put(st.keep, st.n_keep * sizeof(uint32_t));
+            o.xe = put(nullptr, (size_t)n * sizeof(double));
+            o.rhs = put(nullptr, (size_t)n * sizeof(double));
+            o.has_est = st.est_blk != nullptr;
+            if (o.has_est) {
+                std::vector<const double*> ptr(st.n_stn);
+                for (uint32_t t = 0; t < st.n_stn; ++t) {
+                    Block* b = find_block(ctx, st.est_blk[t]);
+                    if (!b || st.est_idx[t] >= b->n_stn) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad linearisation point");
+                    ptr[t] = b->x_orig + (size_t)3 * st.est_idx[t];
+                }
+                o.est = put(ptr.data(), ptr.size() * sizeof(const double*));
+            }
+            o.has_con = st.n_con != 0;
+            if (o.has_con) {
+                std::vector<double> con((size_t)9 * st.n_stn, 0.0);
+                for (size_t i = 0; i < st.n_con; ++i) {
+                    if (st.con_stn[i] >= st.n_stn) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: constraint station out of range");
+                    for (int e = 0; e < 9; ++e) con[(size_t)9 * st.con_stn[i] + e] += st.con_w9[9 * i + e];
+                }
+                o.con = put(con.data(), con.size() * sizeof(double));
+            }
+            bool junction_in = false;
+            for (int r = 0; r < st.n_src; ++r) {
+                const dnagpu_chain_source& sc = st.src[r];
+                if (!sc.m || !sc.k || !sc.pos || 3 * sc.k > sc.m->n_max) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad source");
+                std::vector<int32_t> inv(st.n_stn, -1);
+                for (size_t a = 0; a < sc.k; ++a) {
+                    if (sc.pos[a] >= st.n_stn || inv[sc.pos[a]] >= 0) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad source station list");
+                    inv[sc.pos[a]] = (int32_t)a;
+                }
+                o.pos[r] = put(sc.pos, sc.k * sizeof(uint32_t));
+                o.inv[r] = put(inv.data(), inv.size() * sizeof(int32_t));
+                dnagpu_matrix* m = const_cast<dnagpu_matrix*>(sc.m);
+                if (sc.junction && !m->jrhs) HIPCHK(dnagpu::poison_malloc(&m->jrhs, (size_t)m->np_max * sizeof(double)));
+                d.src[r].F = m->F; d.src[r].np = pad128((uint32_t)(3 * sc.k)); d.src[r].k = (uint32_t)sc.k;
+                d.src[r].rhs = sc.junction ? m->jrhs : m->jest;
+                d.src[r].jest = sc.junction ? m->jest : nullptr;
+                junction_in = junction_in || sc.junction;
+            }
+            if ((junction_in || st.out_junction) && !o.has_est) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a junction needs the linearisation point");
+            if (st.out_junction && !st.out->jrhs) HIPCHK(dnagpu::poison_malloc(&st.out->jrhs, (size_t)st.out->np_max * sizeof(double)));
+            d.outS = st.out->F; d.outnp = pad128(nj);
+            d.out_rhs = st.out_junction ? st.out->jrhs : st.out->jest;
+            d.out_jest = st.out_junction ? st.out->jest : nullptr;
+            plan->out[s] = {st.out, nj, st.out_junction};
+        }
+    }
+    HIPCHK(dnagpu::poison_malloc(&plan->blob, blob.size() + 16));
+    HIPCHK(dnagpu::poison_malloc(&plan->factors, (size_t)factor_bytes + 16));
+    HIPCHK(dnagpu::poison_malloc(&plan->table, n_steps * sizeof(CbStep)));
+    uint8_t* base = (uint8_t*)plan->blob;
+    for (size_t s = 0; s < n_steps; ++s) {
+        CbStep& d = table[s];
+        const Offs& o = offs[s];
+        d.map = (const int32_t*)(base + o.map);
+        d.keep = (const uint32_t*)(base + o.keep);
+        d.xe = (double*)(base + o.xe);
+        d.rhs = (double*)(base + o.rhs);
+        d.est = o.has_est ? (const double* const*)(base + o.est) : nullptr;
+        d.con = o.has_con ? (const double*)(base + o.con) : nullptr;
+        for (uint32_t r = 0; r < d.n_src; ++r) {
+            d.src[r].pos = (const uint32_t*)(base + o.pos[r]);
+            d.src[r].inv = (const int32_t*)(base + o.inv[r]);
+        }
+        d.X = plan->factors + x_off[s];
+        plan->X[s] = d.X;
+    }
+    HIPCHK(hipMemcpy(plan->blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(plan->table, table.data(), n_steps * sizeof(CbStep), hipMemcpyHostToDevice));
+    *out = plan.release();
+    return DNAGPU_OK;
+}
+
+int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!plan || batch + 1 >= plan->batch_first.size()) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run: bad arguments");
+    const uint32_t first = plan->batch_first[batch], nb = plan->batch_first[batch + 1] - first;
+    const dnagpu_chain_plan::Shape sh = plan->shape[batch];
+    int rc = ensure_batch_ws(ctx, chain, (int)nb, sh.npp, batch_panel_cols(sh.nip, sh.njp));
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    const CbStep* table = (const CbStep*)plan->table + first;
+    CbMembers mem{};
+    double* F[BATCH_MAX];
+    double* X[BATCH_MAX];
+    double* P[BATCH_MAX];
+    for (uint32_t b = 0; b < nb; ++b) {
+        F[b] = b ? ws.bX[b] : ws.X;
+        X[b] = plan->X[first + b];
+        P[b] = b ? ws.bW[b] : ws.W;
+        mem.F[b] = F[b];
+    }
+    launch_cb_rhs(table, nb, st);
+    launch_cb_assemble(table, nb, mem, sh.npp, st);
+    HIPCHK(hipGetLastError());
+    if (nb > 1) {
+        InvBatch& bt = ws.batch;
+        bt = InvBatch();
+        bt.nb = (int)nb;
+        bt.add(F[0], (size_t)sh.npp * sh.npp, F);
+        bt.add(X[0], (size_t)sh.npp * sh.npp, X);
+        bt.add(P[0], ((size_t)ws.bw_cols + 128) * sh.npp, P);
+    }
+    sym_spine_async(ws, ws.X, X[0], (int)sh.npp, (int)(sh.nip / 128), (int)(sh.njp / 128));
+    ws.batch = InvBatch();
+    launch_cb_post(table, nb, mem, sh.nip, sh.npp, sh.outnp_max, st);
+    HIPCHK(hipGetLastError());
+    for (uint32_t b = 0; b < nb; ++b) {
+        const dnagpu_chain_plan::Out& o = plan->out[first + b];
+        o.m->n = o.nj;
+        o.m->np = pad128(o.nj);
+        o.m->form = o.junction ? 1 : 0;
+    }
+    plan->factored[batch] = 1;
+    if (ws.hold_info) return DNAGPU_OK;
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    rc = check_info_batch(ctx, chain, (int)nb, nullptr);
+    if (rc) plan->factored[batch] = 0;
+    return rc;
+}
+
+int dnagpu_chain_plan_run_rhs(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch_lo, size_t batch_hi) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!plan || batch_lo >= batch_hi || batch_hi >= plan->batch_first.size()) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run_rhs: bad arguments");
+    for (size_t q = batch_lo; q < batch_hi; ++q)
+        if (!plan->factored[q]) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run_rhs: a step has no factor yet");
+    const uint32_t first = plan->batch_first[batch_lo], n = plan->batch_first[batch_hi] - first;
+    gemm_profile_close(ctx->ws[chain]);
+    launch_cb_rhs_steps((const CbStep*)plan->table + first, n, ctx->stream[chain]);
+    HIPCHK(hipGetLastError());
+    return DNAGPU_OK;
+}
 
 int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max) {
     CHK_CTX();

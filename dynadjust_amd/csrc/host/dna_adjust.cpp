@@ -38,6 +38,7 @@ void dna_adjust::FreeDevice() {
     small_batch_ = nullptr;
     small_batch_blocks_.clear();
     small_batch_denied_ = small_batch_armed_ = false;
+    FreeLockstepChains();      // (before the matrices and blocks its plan refers to)
     FreeTwoLevel();
     if (xbuf_dev_) dnagpu_device_free(ctx_, xbuf_dev_);
     xbuf_dev_ = nullptr;
@@ -875,6 +876,7 @@ _ADJUST_STATUS_ dna_adjust::AdjustNetwork() {
         b.factor_live = b.factor_reused = b.cfac_live[0] = b.cfac_live[1] = false;      // (a.reuse_factors: within one adjustment only)
         b.red_iter = 0;
     }
+    lock_factored_ = false;
     factor_reuses_ = chain_reuses_ = 0;
     small_batch_steps_ = 0;
     osc_ready_ = false;              // corrPrev_ / stnOscCount_ / oscHistory_ start empty (ADJ:2419-2421, 2584-2586)
@@ -1182,6 +1184,7 @@ void dna_adjust::ResetAdjustment() {
         blocks_[b].factor_live = blocks_[b].factor_reused = blocks_[b].cfac_live[0] = blocks_[b].cfac_live[1] = false;
         blocks_[b].red_iter = 0;
     }
+    lock_factored_ = false;
     Check(dnagpu_sync(ctx_), 0, "ResetAdjustment()");
     if (getenv("DNAGPU_PHASE_TIMES")) fprintf(stderr, "[phase] ResetAdjustment           %6.1f ms\n", now_ms() - t_reset);
     osc_ready_ = false;              // (a second adjustment on the handle must not compare with the first one's corrections)

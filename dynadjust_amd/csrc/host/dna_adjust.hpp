@@ -336,6 +336,26 @@ private:
     void ExchangeRuns();
     void ScanRuns();                           // level 2
     void OwnRunChains();                       // level 3
+    // ---- the same three levels on ONE GPU, the runs advancing together (a.chain_runs; dna_adjust_phased.cpp LockstepChains) ----
+    // Every chain step is data on the device (dnagpu_chain_plan); a level's steps of all runs go out as batches of merged launches.
+    struct lock_group_t { UINT32 lo = 0, hi = 0; };          // batches lo .. hi - 1 of the plan: one step of every run of a level
+    struct lock_lane_t {                                     // a sequence of such groups, each depending on the one before
+        std::vector<lock_group_t> groups;
+        std::vector<double> flops;                           // per group: what its eliminations cost
+        std::vector<double> ref_flops;                       // ... and the reference's Solve()s its block steps stand for (n^3 each)
+        std::vector<UINT32> block_steps;                     // per group: how many of its steps are chain steps on a condensed block
+    };
+    struct lock_stage_t { std::vector<lock_lane_t> lanes; }; // lanes of a stage are independent of each other; stages follow each other
+    std::vector<lock_stage_t> lock_stages_;
+    std::vector<UINT32> lock_batch_slot_;                    // per batch of the plan: run / DNAGPU_BATCH_MAX of its members
+    dnagpu_chain_plan* lock_plan_ = nullptr;
+    std::vector<dnagpu_matrix*> lock_mats_;                  // the merged systems of the runs (owned)
+    bool lockstep_ok_ = false;
+    bool lock_factored_ = false;                             // the plan's factors are those of this adjustment's normals
+    int lock_runs_ = 0;
+    void PrepareLockstepChains();
+    void FreeLockstepChains();
+    bool LockstepChains();                                   // false: not run (the chains go step by step)
     std::shared_ptr<DistComm> comm_;
     bool force_distributed_ = false;           // DNAGPU_FORCE_DISTRIBUTED=1: the exchange steps also run with a single rank
     bool in_collective_ = false;               // this instance is being driven as one rank by OnEveryDevice
@@ -481,6 +501,7 @@ public:
     uint64_t FactorReuses() const { return factor_reuses_.load(); }
     uint64_t ChainStepReuses() const { return chain_reuses_.load(); }
     uint64_t SmallBatchSteps() const { return small_batch_steps_.load(); }
+    int ChainRuns() const { return lockstep_ok_ ? lock_runs_ : 0; }
 private:
     void FinishDeferredVariances();
     void CarryByElimination(int chain, UINT32 dev_block, UINT32 block, dnagpu_matrix* m, const std::vector<UINT32>& out, dnagpu_matrix* jm);

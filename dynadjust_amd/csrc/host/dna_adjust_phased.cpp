@@ -11,6 +11,9 @@
 #include <cmath>
 #include <condition_variable>
 #include <deque>
+#include <numeric>
+#include <set>
+#include <algorithm>
 #include <exception>
 #include <functional>
 #include <map>
@@ -759,6 +762,7 @@ void dna_adjust::PrepareCondensedBlocks() {
     batch_budget_ = std::max(0.0, budget);
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) batch_granted_[c] = 0;
     batch_limit_ = (int)std::max(0.0, std::min(1.0e6, batch_budget_ / batch_unit_));
+    PrepareLockstepChains();
 }
 
 void dna_adjust::CondenseBlock(int c, UINT32 k) {
@@ -1693,8 +1697,432 @@ void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks_in) {
     });
 }
 
+// ---- lock-step chains (a.chain_runs) ------------------------------------------------------------------------------------------------
+// A dnasegment-default cut has hundreds of blocks whose condensed systems are a few hundred unknowns: the two junction chains are
+// 2 (B - 1) steps of ~150 us in a row -- more than half of such an adjustment -- while a step is 0.1 us of the chip's arithmetic.  The
+// three levels of the multi-GPU chains (dna_adjust_dist.cpp: every run merged to its end stations, the chains over the runs, the chains
+// inside every run from the boundary values) on ONE GPU, with the runs' steps of a level advancing TOGETHER: every step is data on the
+// device (dnagpu_chain_plan), step j of all runs is one batch of merged launches.  2 B / W + W steps deep instead of B; the same
+// additions in the same order inside every run, so the results agree with the step-by-step chains to rounding.
+void dna_adjust::FreeLockstepChains() {
+    if (lock_plan_ && ctx_) dnagpu_chain_plan_destroy(ctx_, lock_plan_);
+    lock_plan_ = nullptr;
+    for (dnagpu_matrix* m : lock_mats_)
+        if (m && ctx_) dnagpu_matrix_destroy(ctx_, m);
+    lock_mats_.clear();
+    lock_stages_.clear();
+    lock_batch_slot_.clear();
+    lockstep_ok_ = lock_factored_ = false;
+    lock_runs_ = 0;
+}
+
+void dna_adjust::PrepareLockstepChains() {
+    FreeLockstepChains();
+    const UINT32 B = blockCount_;
+    const int want = projectSettings_.a.chain_runs;
+    if (want == 0 || want == 1 || !condensed_ok_ || !CondensedSchedule() || DistWorld() > 1 || ReuseRequested() || !dnagpu_info_carry(ctx_)) return;
+    int W = want > 1 ? want : (B >= 512 ? 32 : B >= 64 ? 16 : 1);
+    W = std::min<int>(W, (int)(B / 3));
+    if (W < 2) return;
+    // one contiguous network of small condensed systems, every block between two others carrying something both ways
+    if (!v_blockMeta_[0]._blockFirst || !v_blockMeta_[B - 1]._blockLast) return;
+    for (UINT32 k = 0; k < B; ++k) {
+        const blockMeta_t& m = v_blockMeta_[k];
+        const block_t& Bk = blocks_[k];
+        if (m._blockIsolated || (m._blockFirst && k != 0) || (m._blockLast && k != B - 1)) return;
+        if (Bk.keep.empty() || !Bk.red || 3 * Bk.keep.size() > 1024) return;
+        if ((k > 0 && Bk.c_prev.empty()) || (k + 1 < B && Bk.c_next.empty())) return;
+        if ((k + 1 < B && !Bk.jfwd) || (k > 0 && !blocks_[k - 1].jrev)) return;
+    }
+    auto gid = [&](UINT32 k, UINT32 keep_pos) { return v_parameterStationList_[k][blocks_[k].keep[keep_pos]]; };
+    auto position = [](const std::vector<UINT32>& sorted, UINT32 g) {
+        auto it = std::lower_bound(sorted.begin(), sorted.end(), g);
+        return (it != sorted.end() && *it == g) ? (long)(it - sorted.begin()) : -1L;
+    };
+    // the steps, in the order of the plan's batches; what their lists point at lives in `data` until the plan is made
+    struct step_data_t {
+        std::vector<UINT32> est_blk, est_idx, keep, con_stn, pos[3];
+        std::vector<double> con_w9;
+    };
+    std::deque<step_data_t> data;
+    std::vector<dnagpu_chain_step> steps;
+    std::vector<UINT32> batch_first{0};
+    std::vector<lock_stage_t> stages;
+    auto add_step = [&](step_data_t&& d, int n_src, const dnagpu_matrix* const* src, const int* src_junction, dnagpu_matrix* out, int out_junction, UINT32 n_stn) {
+        data.push_back(std::move(d));
+        step_data_t& D = data.back();
+        dnagpu_chain_step st{};
+        st.n_stn = n_stn;
+        st.est_blk = D.est_blk.empty() ? nullptr : D.est_blk.data();
+        st.est_idx = D.est_idx.empty() ? nullptr : D.est_idx.data();
+        st.n_src = n_src;
+        for (int q = 0; q < n_src; ++q) {
+            st.src[q].m = src[q];
+            st.src[q].junction = src_junction[q];
+            st.src[q].pos = D.pos[q].data();
+            st.src[q].k = D.pos[q].size();
+        }
+        st.con_stn = D.con_stn.data();
+        st.con_w9 = D.con_w9.data();
+        st.n_con = D.con_stn.size();
+        st.keep = D.keep.data();
+        st.n_keep = D.keep.size();
+        st.out = out;
+        st.out_junction = out_junction;
+        steps.push_back(st);
+        const double n = 3.0 * n_stn, nj = 3.0 * (double)D.keep.size(), ni = n - nj;
+        return ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj;
+    };
+    // a group = one step of every run that has it, in batches of DNAGPU_BATCH_MAX
+    // (a run stays in the same batch slot -- run / DNAGPU_BATCH_MAX -- through all groups: a slot's batches follow each other on one chain)
+    struct pending_t { std::function<double()> make; bool block_step; int run; double ref_flops; };
+    std::vector<UINT32> batch_slot;
+    auto close_group = [&](lock_lane_t& lane, std::vector<pending_t>& members) {
+        if (members.empty()) return;
+        lock_group_t g;
+        g.lo = (UINT32)batch_first.size() - 1;
+        double fl = 0.0, ref = 0.0;
+        UINT32 nblk = 0;
+        for (size_t i = 0; i < members.size(); ++i) {
+            fl += members[i].make();
+            ref += members[i].ref_flops;
+            nblk += members[i].block_step ? 1u : 0u;
+            const int slot = members[i].run / DNAGPU_BATCH_MAX;
+            if (i + 1 == members.size() || members[i + 1].run / DNAGPU_BATCH_MAX != slot) {
+                batch_first.push_back((UINT32)steps.size());
+                batch_slot.push_back((UINT32)slot);
+            }
+        }
+        g.hi = (UINT32)batch_first.size() - 1;
+        lane.groups.push_back(g);
+        lane.flops.push_back(fl);
+        lane.ref_flops.push_back(ref);
+        lane.block_steps.push_back(nblk);
+        members.clear();
+    };
+    struct run_t {
+        UINT32 a, b;
+        std::vector<UINT32> stations, posL, posR, est_blk, est_idx, sys_pos;
+        constraint_list con_fwd, con_rev;
+        std::vector<UINT32> prev;            // stations of the running merged system
+        const dnagpu_matrix* prev_m = nullptr;
+        const dnagpu_matrix* S = nullptr;    // the run's system: the last merge's output (or the one block's condensed system)
+    };
+    std::vector<run_t> runs((size_t)W);
+    try {
+        for (int r = 0; r < W; ++r) {
+            run_t& g = runs[r];
+            g.a = (UINT32)((uint64_t)r * B / (uint64_t)W);
+            g.b = (UINT32)((uint64_t)(r + 1) * B / (uint64_t)W) - 1;
+            const block_t& A = blocks_[g.a];
+            const block_t& Z = blocks_[g.b];
+            std::vector<UINT32> L, R;
+            for (UINT32 p : A.c_prev) L.push_back(gid(g.a, p));
+            if (g.b + 1 < B)
+                for (UINT32 p : Z.c_next) R.push_back(gid(g.b, p));
+            g.stations = L;
+            g.stations.insert(g.stations.end(), R.begin(), R.end());
+            std::sort(g.stations.begin(), g.stations.end());
+            g.stations.erase(std::unique(g.stations.begin(), g.stations.end()), g.stations.end());
+            for (UINT32 s : L) g.posL.push_back((UINT32)position(g.stations, s));
+            for (UINT32 s : R) g.posR.push_back((UINT32)position(g.stations, s));
+            std::set<UINT32> inL(L.begin(), L.end());
+            for (UINT32 s : g.stations) {
+                const UINT32 k = inL.count(s) ? g.a : g.b;
+                g.est_blk.push_back(k);
+                g.est_idx.push_back(LocalIndex(k, s));
+            }
+            for (UINT32 k = g.a; k <= g.b; ++k) {
+                auto pick = [&](const constraint_list& src, constraint_list& dst) {
+                    for (size_t i = 0; i < src.stn.size(); ++i) {
+                        const long q = position(g.stations, gid(k, src.stn[i]));
+                        if (q < 0) continue;
+                        dst.stn.push_back((UINT32)q);
+                        dst.w9.insert(dst.w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
+                    }
+                };
+                pick(blocks_[k].ccon_fwd, g.con_fwd);
+                pick(blocks_[k].ccon_rev, g.con_rev);
+            }
+            g.prev.clear();
+            for (UINT32 p = 0; p < A.keep.size(); ++p) g.prev.push_back(gid(g.a, p));
+            g.prev_m = A.red;
+            if (g.a == g.b) {
+                g.S = A.red;
+                for (UINT32 s : g.prev) {
+                    const long q = position(g.stations, s);
+                    if (q < 0) return;
+                    g.sys_pos.push_back((UINT32)q);
+                }
+            }
+        }
+        // level 1: the runs merged to their end stations, merge j of every run together
+        stages.emplace_back();
+        stages.back().lanes.emplace_back();
+        UINT32 longest = 0;
+        for (const run_t& g : runs) longest = std::max(longest, g.b - g.a);
+        bool bad = false;
+        for (UINT32 j = 1; j <= longest; ++j) {
+            std::vector<pending_t> members;
+            for (int r = 0; r < W; ++r) {
+                run_t& g = runs[r];
+                if (g.b - g.a < j) continue;
+                const UINT32 k = g.a + j;
+                members.push_back({[&, r, k]() -> double {
+                    run_t& g = runs[r];
+                    step_data_t d;
+                    std::vector<UINT32> blk;
+                    for (UINT32 p = 0; p < blocks_[k].keep.size(); ++p) blk.push_back(gid(k, p));
+                    std::vector<UINT32> U = g.prev;
+                    U.insert(U.end(), blk.begin(), blk.end());
+                    std::sort(U.begin(), U.end());
+                    U.erase(std::unique(U.begin(), U.end()), U.end());
+                    for (UINT32 s : g.prev) d.pos[0].push_back((UINT32)position(U, s));
+                    for (UINT32 s : blk) d.pos[1].push_back((UINT32)position(U, s));
+                    // stations that stay: the run's first junction row and block k's junction row towards k + 1
+                    std::vector<UINT32> stay;
+                    for (UINT32 p : blocks_[g.a].c_prev) stay.push_back(gid(g.a, p));
+                    if (k + 1 < B)
+                        for (UINT32 p : blocks_[k].c_next) stay.push_back(gid(k, p));
+                    std::sort(stay.begin(), stay.end());
+                    stay.erase(std::unique(stay.begin(), stay.end()), stay.end());
+                    for (UINT32 s : stay) {
+                        const long q = position(U, s);
+                        if (q < 0) bad = true;
+                        d.keep.push_back((UINT32)std::max(0L, q));
+                    }
+                    // constraints of the stations that leave inside the run: where the forward chain adds them (first appearance)
+                    for (UINT32 kk : (k == g.a + 1 ? std::vector<UINT32>{g.a, k} : std::vector<UINT32>{k})) {
+                        const constraint_list& src = blocks_[kk].ccon_fwd;
+                        for (size_t i = 0; i < src.stn.size(); ++i) {
+                            const UINT32 s = gid(kk, src.stn[i]);
+                            if (position(g.stations, s) >= 0) continue;
+                            d.con_stn.push_back((UINT32)position(U, s));
+                            d.con_w9.insert(d.con_w9.end(), src.w9.begin() + 9 * i, src.w9.begin() + 9 * i + 9);
+                        }
+                    }
+                    dnagpu_matrix* out = nullptr;
+                    NewMatrix((UINT32)stay.size() * 3, &out, k, "PrepareAdjustment(): run merge");
+                    lock_mats_.push_back(out);
+                    const dnagpu_matrix* src[2] = {g.prev_m, blocks_[k].red};
+                    const int junction[2] = {0, 0};
+                    const double fl = add_step(std::move(d), 2, src, junction, out, 0, (UINT32)U.size());
+                    g.prev = stay;
+                    g.prev_m = out;
+                    if (k == g.b) {
+                        if (stay != g.stations) bad = true;      // (the last merge must leave exactly the run's end stations)
+                        g.S = out;
+                        g.sys_pos.resize(g.stations.size());
+                        std::iota(g.sys_pos.begin(), g.sys_pos.end(), 0u);
+                    }
+                    return fl;
+                }, false, r, 0.0});
+            }
+            close_group(stages.back().lanes[0], members);
+            if (bad) {
+                FreeLockstepChains();
+                return;
+            }
+        }
+        auto nref3 = [&](UINT32 k) {
+            const double n = 3.0 * (double)v_parameterStationList_[k].size();
+            return n * n * n;
+        };
+        // level 2: the two chains over the runs
+        stages.emplace_back();
+        stages.back().lanes.resize(2);
+        for (int r = 0; r + 1 < W; ++r) {
+            std::vector<pending_t> members;
+            members.push_back({[&, r]() -> double {
+                run_t& g = runs[r];
+                step_data_t d;
+                d.est_blk = g.est_blk;
+                d.est_idx = g.est_idx;
+                d.pos[0] = g.sys_pos;
+                d.con_stn = g.con_fwd.stn;
+                d.con_w9 = g.con_fwd.w9;
+                d.keep = g.posR;
+                const dnagpu_matrix* src[2] = {g.S, nullptr};
+                const int junction[2] = {0, 1};
+                int n_src = 1;
+                if (r > 0) {
+                    d.pos[1] = g.posL;
+                    src[1] = blocks_[g.a - 1].jfwd;
+                    n_src = 2;
+                }
+                return add_step(std::move(d), n_src, src, junction, blocks_[g.b].jfwd, 1, (UINT32)g.stations.size());
+            }, true, 0, nref3(runs[r].b)});       // (it leaves what the forward step on the run's last block leaves: counted as that step)
+            close_group(stages.back().lanes[0], members);
+        }
+        for (int r = W - 1; r >= 1; --r) {
+            std::vector<pending_t> members;
+            members.push_back({[&, r]() -> double {
+                run_t& g = runs[r];
+                step_data_t d;
+                d.est_blk = g.est_blk;
+                d.est_idx = g.est_idx;
+                d.pos[0] = g.sys_pos;
+                d.con_stn = g.con_rev.stn;
+                d.con_w9 = g.con_rev.w9;
+                d.keep = g.posL;
+                const dnagpu_matrix* src[2] = {g.S, nullptr};
+                const int junction[2] = {0, 1};
+                int n_src = 1;
+                if (r + 1 < W) {
+                    d.pos[1] = g.posR;
+                    src[1] = blocks_[g.b].jrev;
+                    n_src = 2;
+                }
+                return add_step(std::move(d), n_src, src, junction, blocks_[g.a - 1].jrev, 1, (UINT32)g.stations.size());
+            }, true, 0, nref3(runs[r].a)});
+            close_group(stages.back().lanes[1], members);
+        }
+        // level 3: both chains inside every run, from the boundary values of level 2 (CondensedForwardBlock / CondensedReverseBlock as data)
+        stages.emplace_back();
+        stages.back().lanes.resize(2);
+        auto block_step = [&](UINT32 k, int dir) -> double {
+            const block_t& Bk = blocks_[k];
+            step_data_t d;
+            d.est_blk.assign(Bk.keep.size(), k);
+            d.est_idx = Bk.keep;
+            d.pos[0].resize(Bk.keep.size());
+            std::iota(d.pos[0].begin(), d.pos[0].end(), 0u);
+            const constraint_list& con = dir == 0 ? Bk.ccon_fwd : Bk.ccon_rev;
+            d.con_stn = con.stn;
+            d.con_w9 = con.w9;
+            const dnagpu_matrix* src[2] = {Bk.red, nullptr};
+            const int junction[2] = {0, 1};
+            int n_src = 1;
+            dnagpu_matrix* out;
+            if (dir == 0) {
+                d.keep = Bk.c_next;
+                if (k > 0) {
+                    d.pos[1] = Bk.c_prev;
+                    src[1] = blocks_[k - 1].jfwd;
+                    n_src = 2;
+                }
+                out = Bk.jfwd;
+            } else {
+                d.keep = Bk.c_prev;
+                if (k + 1 < B) {
+                    d.pos[1] = Bk.c_next;
+                    src[1] = Bk.jrev;
+                    n_src = 2;
+                }
+                out = blocks_[k - 1].jrev;
+            }
+            return add_step(std::move(d), n_src, src, junction, out, 1, (UINT32)Bk.keep.size());
+        };
+        for (UINT32 j = 0; j <= longest; ++j) {
+            std::vector<pending_t> members;
+            for (int r = 0; r < W; ++r) {
+                const run_t& g = runs[r];
+                if (g.a + j + 1 > g.b) continue;
+                const UINT32 k = g.a + j;
+                members.push_back({[&, k]() -> double { return block_step(k, 0); }, true, r, nref3(k)});
+            }
+            close_group(stages.back().lanes[0], members);
+        }
+        for (UINT32 j = 0; j <= longest; ++j) {
+            std::vector<pending_t> members;
+            for (int r = 0; r < W; ++r) {
+                const run_t& g = runs[r];
+                if (g.b < g.a + 1 + j) continue;
+                const UINT32 k = g.b - j;
+                members.push_back({[&, k]() -> double { return block_step(k, 1); }, true, r, nref3(k)});
+            }
+            close_group(stages.back().lanes[1], members);
+        }
+    } catch (...) {
+        FreeLockstepChains();      // (no room for the merged systems: the chains go step by step)
+        return;
+    }
+    const double budget = chain_fac_budget_ > 0.0 ? chain_fac_budget_ : 4.0e9;
+    const int rc = dnagpu_chain_plan_create(ctx_, steps.size(), steps.data(), batch_first.size() - 1, batch_first.data(), budget, &lock_plan_);
+    if (getenv("DNAGPU_PHASE_TIMES"))
+        fprintf(stderr, "[phase] chain plan: %d runs, %zu steps in %zu batches: %s\n", W, steps.size(), batch_first.size() - 1, rc == DNAGPU_OK ? "made" : "not made");
+    if (rc != DNAGPU_OK) {
+        lock_plan_ = nullptr;
+        FreeLockstepChains();
+        if (rc != DNAGPU_ETOOLARGE && rc != DNAGPU_ENOMEM) Check(rc, 0, "PrepareAdjustment(): chain plan");
+        return;
+    }
+    lock_stages_ = std::move(stages);
+    lock_batch_slot_ = std::move(batch_slot);
+    lock_runs_ = W;
+    lockstep_ok_ = true;
+}
+
+bool dna_adjust::LockstepChains() {
+    if (!lockstep_ok_ || !lock_plan_) return false;
+    const bool rhs_only = lock_factored_ && FactorReuse();
+    const int nch = std::min(NumChains(), 2);
+    bool failed = false;
+    std::mutex fm;
+    for (const lock_stage_t& stage : lock_stages_) {
+        OnEveryChain([&](int c) {
+            if (c >= nch) return;
+            if (!rhs_only) Check(dnagpu_chain_hold_info(ctx_, c, 1), 0, "Solve()");
+            try {
+                for (size_t l = 0; l < stage.lanes.size(); ++l) {
+                    const lock_lane_t& lane = stage.lanes[l];
+                    const bool dealt = !rhs_only && stage.lanes.size() == 1 && nch > 1;     // one lane: its batches dealt to the chains
+                    if (!dealt && (int)(l % (size_t)nch) != c) continue;
+                    for (const lock_group_t& g : lane.groups) {
+                        if (IsCancelled() || chain_failed_) break;
+                        if (rhs_only) {
+                            Check(dnagpu_chain_plan_run_rhs(ctx_, c, lock_plan_, g.lo, g.hi), 0, "Solve()");
+                        } else {
+                            for (UINT32 q = g.lo; q < g.hi; ++q)
+                                if (!dealt || (int)(lock_batch_slot_[q] % (UINT32)nch) == c) Check(dnagpu_chain_plan_run(ctx_, c, lock_plan_, q), 0, "Solve()");
+                        }
+                    }
+                }
+            } catch (...) {
+                if (!rhs_only) {
+                    dnagpu_chain_take_info(ctx_, c);
+                    dnagpu_chain_hold_info(ctx_, c, 0);
+                }
+                throw;
+            }
+            if (!rhs_only) {
+                const int rc = dnagpu_chain_take_info(ctx_, c);
+                Check(dnagpu_chain_hold_info(ctx_, c, 0), 0, "Solve()");
+                if (rc == DNAGPU_ENOTPOSDEF) {
+                    std::lock_guard<std::mutex> lk(fm);
+                    failed = true;
+                } else {
+                    Check(rc, 0, "Solve()");
+                }
+            }
+        });
+        if (failed || IsCancelled()) break;
+    }
+    if (failed) {
+        // a pivot that is not positive somewhere: the step-by-step chains repeat the phase and name the block
+        lock_factored_ = false;
+        return false;
+    }
+    if (IsCancelled()) return true;
+    std::lock_guard<std::mutex> lk(corr_mutex_);
+    for (const lock_stage_t& stage : lock_stages_)
+        for (const lock_lane_t& lane : stage.lanes)
+            for (size_t i = 0; i < lane.groups.size(); ++i) {
+                if (!rhs_only) CountFlops(lane.flops[i], 0);
+                // (a chain step on a condensed block stands for a Solve() of the reference: CarryCondensed's counters)
+                const UINT32 nb = lane.block_steps[i];
+                solve_flops_ += lane.ref_flops[i];
+                solve_count_ += nb;
+                elimination_count_ += nb;
+                if (rhs_only) chain_reuses_ += nb;
+            }
+    lock_factored_ = true;
+    return true;
+}
+
 // the forward chain on chain 0 beside the reverse chain on chain 1 (one after the other without a.multi_thread)
 void dna_adjust::CondensedChains() {
+    if (LockstepChains()) return;
     const bool two = NumChains() > 1;
     // Long chains of small steps (a dnasegment-default cut: 666 blocks): the elimination's verdict -- a pivot that is not positive -- is
     // not waited for step by step (a wait per step kept the device idle while the host enqueued the next step's thirty launches) but
@@ -1799,6 +2227,7 @@ void dna_adjust::PhasedBeginIteration() {
             b.factor_live = b.factor_reused = b.cfac_live[0] = b.cfac_live[1] = false;
             b.red_iter = 0;
         }
+        lock_factored_ = false;
         factor_reuses_ = chain_reuses_ = 0;
         osc_ready_ = false;
         oscHistory_.clear();

@@ -52,6 +52,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->defer_variances = 2;
     s->batch_blocks = 16;
     s->reuse_factors = 1;
+    s->chain_runs = -1;
 }
 
 int dnaadj_create(dnaadj_handle** out) {
@@ -102,6 +103,7 @@ static void to_project_settings(const dnaadj_settings* s, dynadjust::project_set
     p.a.defer_variances = (uint16_t)(s->defer_variances < 0 ? 0 : s->defer_variances > 2 ? 2 : s->defer_variances);
     p.a.batch_blocks = (uint16_t)(s->batch_blocks < 0 ? 0 : s->batch_blocks > 16 ? 16 : s->batch_blocks);
     p.a.reuse_factors = (uint16_t)(s->reuse_factors ? 1 : 0);
+    p.a.chain_runs = s->chain_runs < 0 ? -1 : s->chain_runs > 4096 ? 4096 : s->chain_runs;
     if (s->network_name) p.g.network_name = s->network_name;
     if (s->output_folder) p.g.output_folder = s->output_folder;
 }
@@ -331,6 +333,7 @@ uint32_t dnaadj_elimination_count(const dnaadj_handle* h) { return h && h->adj ?
 double dnaadj_minimal_work_flops(const dnaadj_handle* h) { return h && h->adj ? h->adj->minimalWorkFlops() : 0.0; }
 uint64_t dnaadj_factor_reuses(const dnaadj_handle* h) { return h && h->adj ? h->adj->FactorReuses() : 0; }
 uint64_t dnaadj_small_batch_steps(const dnaadj_handle* h) { return h && h->adj ? h->adj->SmallBatchSteps() : 0; }
+int dnaadj_chain_runs(const dnaadj_handle* h) { return h && h->adj ? h->adj->ChainRuns() : 0; }
 uint64_t dnaadj_chain_step_reuses(const dnaadj_handle* h) { return h && h->adj ? h->adj->ChainStepReuses() : 0; }
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block) {

@@ -245,6 +245,9 @@ struct adjust_settings {
     // with light kept factors (schur_carry, keep_factors, defer_variances = 2); blocks that may not keep a factor (HBM budget)
     // go on as before.
     UINT16 reuse_factors = 1;
+    // condensed schedule on one GPU, many small blocks: the two junction chains cut into this many runs whose steps advance together in
+    // merged launches (dna_adjust::LockstepChains).  -1 = choose (32 runs from 512 blocks, 16 from 64, else one), 0 / 1 = one run.
+    int chain_runs = -1;
 };
 struct output_settings {
     UINT16 _adj_msr_tstat = 0;   // --output-tstat-adj-msr: Student's t statistic of every adjusted measurement

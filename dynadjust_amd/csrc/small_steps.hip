@@ -347,4 +347,166 @@ void launch_chain_rhs_step(const ChainRhsStep& a, hipStream_t s) {
     hipLaunchKernelGGL(chain_rhs_step_kernel, dim3(1), dim3(NT), 0, s, a);
 }
 
+
+// ---- chain plans (small_steps.h) ------------------------------------------------------------------------------------------------------
+namespace {
+
+// rhs, xe (LDS, 3 n_stn) <- the step's right-hand side and linearisation point: every source's right-hand side at its stations; an
+// information-form junction adds r + S (the estimates S and r were formed at - ours), as dnagpu_junction_rhs / chain_rhs_step_kernel do
+__device__ void wg_step_rhs(const CbStep& d, double* rhs, double* xe, double* t, double* v, double* part, int* any_dx) {
+    const int tid = threadIdx.x;
+    const uint32_t n = 3 * d.n_stn;
+    if (tid == 0) *any_dx = 0;
+    for (uint32_t i = tid; i < n; i += NT) {
+        rhs[i] = 0.0;
+        xe[i] = d.est ? d.est[i / 3][i % 3] : 0.0;
+    }
+    __syncthreads();
+    for (uint32_t q = 0; q < d.n_src; ++q) {
+        const CbSrc& sc = d.src[q];
+        const uint32_t nq = 3 * sc.k;
+        if (sc.jest) {
+            int mine = 0;
+            for (uint32_t j = tid; j < nq; j += NT) {
+                const double dx = sc.jest[j] - xe[3 * sc.pos[j / 3] + j % 3];
+                t[j] = dx;
+                mine |= dx != 0.0;
+            }
+            if (mine) *any_dx = 1;
+            __syncthreads();
+            const bool nonzero = *any_dx != 0;
+            __syncthreads();
+            if (tid == 0) *any_dx = 0;
+            if (nonzero) {
+                wg_matvec<false>(sc.F, sc.np, nq, nq, t, nullptr, 1.0, v, part);
+            } else {
+                for (uint32_t j = tid; j < nq; j += NT) v[j] = 0.0;
+                __syncthreads();
+            }
+            for (uint32_t j = tid; j < nq; j += NT) rhs[3 * sc.pos[j / 3] + j % 3] += sc.rhs[j] + v[j];
+        } else {
+            for (uint32_t j = tid; j < nq; j += NT) rhs[3 * sc.pos[j / 3] + j % 3] += sc.rhs[j];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(NT) void cb_rhs_kernel(const CbStep* __restrict__ table) {
+    __shared__ double rhs[SMALL_STEP_MAX], xe[SMALL_STEP_MAX], v[SMALL_STEP_MAX], t[SMALL_STEP_MAX], part[NW * 64];
+    __shared__ int any_dx;
+    const CbStep& d = table[blockIdx.x];
+    wg_step_rhs(d, rhs, xe, t, v, part, &any_dx);
+    for (uint32_t i = threadIdx.x; i < 3 * d.n_stn; i += NT) {
+        d.rhs[i] = rhs[i];
+        d.xe[i] = xe[i];
+    }
+}
+
+// The step's system in the elimination's order (what dnagpu_block_load_reduced + add_diag3x3 + junction_scatter + schur_permute leave):
+// element (i, j), i >= j, is the sum over the sources that hold both unknowns, plus the constraint block of the station; the row map = -2
+// carries the right-hand side; identity on the padding's diagonal.  One workgroup per quarter of a 128 x 128 tile of the lower tile triangle.
+__global__ __launch_bounds__(256) void cb_assemble_kernel(const CbStep* __restrict__ table, const CbMembers mem, uint32_t npp) {
+    const uint32_t b = blockIdx.z >> 2, qz = blockIdx.z & 3;
+    const CbStep& d = table[b];
+    double* __restrict__ dst = mem.F[b];
+    const uint32_t tr = blockIdx.x, tc = blockIdx.y;
+    if (tc > tr) return;
+    const uint32_t il = threadIdx.x & 127;
+    const uint32_t i = tr * 128 + il;
+    const int32_t mi = d.map[i];
+    const uint32_t su = mi >= 0 ? (uint32_t)mi / 3 : 0, eu = mi >= 0 ? (uint32_t)mi % 3 : 0;
+    int32_t ai[CB_SRC_MAX];
+#pragma unroll
+    for (int q = 0; q < CB_SRC_MAX; ++q) ai[q] = (mi >= 0 && (uint32_t)q < d.n_src) ? d.src[q].inv[su] : -1;
+#pragma unroll 4
+    for (uint32_t jl = qz * 32 + (threadIdx.x >> 7); jl < qz * 32 + 32; jl += 2) {
+        const uint32_t j = tc * 128 + jl;
+        const int32_t mj = d.map[j];
+        double v = 0.0;
+        if (i >= j) {
+            if (mi >= 0 && mj >= 0) {
+                const uint32_t sv = (uint32_t)mj / 3, ev = (uint32_t)mj % 3;
+#pragma unroll
+                for (int q = 0; q < CB_SRC_MAX; ++q) {
+                    if (ai[q] < 0) continue;
+                    const int32_t bj = d.src[q].inv[sv];
+                    if (bj < 0) continue;
+                    const uint32_t r0 = 3 * (uint32_t)ai[q] + eu, c0 = 3 * (uint32_t)bj + ev;
+                    const uint32_t r = r0 > c0 ? r0 : c0, c = r0 > c0 ? c0 : r0;
+                    v += d.src[q].F[(size_t)c * d.src[q].np + r];
+                }
+                if (d.con && su == sv) v += d.con[(size_t)su * 9 + ev * 3 + eu];
+            } else if (mi == -2) {
+                v = mj >= 0 ? d.rhs[mj] : 0.0;
+            } else if (mi == -1 && i == j) {
+                v = 1.0;
+            }
+        }
+        dst[(size_t)j * npp + i] = v;
+    }
+}
+
+// after the elimination: the trailing block of a member's matrix holds the complement (lower) and, in row nj, the reduced right-hand side
+__global__ __launch_bounds__(256) void cb_post_kernel(const CbStep* __restrict__ table, const CbMembers mem, uint32_t nip, uint32_t npp,
+                                                      uint32_t outnp_max) {
+    const CbStep& d = table[blockIdx.z];
+    const double* __restrict__ T = mem.F[blockIdx.z] + (size_t)nip * npp + nip;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (j < outnp_max) {
+        if (j >= d.outnp || i >= d.outnp) return;
+        double v = i == j ? 1.0 : 0.0;
+        if (i < d.nj && j < d.nj) v = i >= j ? T[(size_t)j * npp + i] : T[(size_t)i * npp + j];
+        d.outS[(size_t)j * d.outnp + i] = v;
+        if (i == 0 && j < d.nj) d.out_rhs[j] = T[(size_t)j * npp + d.nj];
+        return;
+    }
+    // (the row that carried the right-hand side is no unknown: its entries in the kept factor's panels go)
+    if (i < nip) d.X[(size_t)i * npp + nip + d.nj] = 0.0;
+    if (d.out_jest && i < 3 * d.k_out) d.out_jest[i] = d.xe[3 * d.keep[i / 3] + i % 3];
+}
+
+// a right-hand-side-only step with its factor kept: chain_rhs_step_kernel from a table, for any number of independent steps
+__global__ __launch_bounds__(NT) void cb_rhs_steps_kernel(const CbStep* __restrict__ table) {
+    __shared__ double rhs[SMALL_STEP_MAX], xe[SMALL_STEP_MAX], v[SMALL_STEP_MAX], t[SMALL_STEP_MAX], part[NW * 64];
+    __shared__ int any_dx;
+    const CbStep& d = table[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t n = 3 * d.n_stn;
+    wg_step_rhs(d, rhs, xe, t, v, part, &any_dx);
+    for (uint32_t p = tid; p < d.npp; p += NT) {
+        const int32_t m = d.map[p];
+        v[p] = m >= 0 ? rhs[m] : 0.0;
+    }
+    __syncthreads();
+    const uint32_t ni = n - d.nj, last = d.nip + d.nj;
+    for (int q = 0; q < d.nblocks; ++q) {
+        const uint32_t o = d.blk_o[q], h = d.blk_h[q];
+        if (o >= ni) break;
+        const uint32_t hr = min(h, ni - o), below = last - (o + h);
+        wg_matvec<true>(d.X + (size_t)o * d.npp + o, d.npp, hr, hr, v + o, nullptr, 1.0, t, part);
+        for (uint32_t i = tid; i < hr; i += NT) v[o + i] = t[i];
+        __syncthreads();
+        if (below) wg_matvec<false>(d.X + (size_t)o * d.npp + o + h, d.npp, below, hr, v + o, v + o + h, -1.0, v + o + h, part);
+    }
+    for (uint32_t i = tid; i < d.nj; i += NT) d.out_rhs[i] = v[d.nip + i];
+    if (d.out_jest)
+        for (uint32_t i = tid; i < 3 * d.k_out; i += NT) d.out_jest[i] = xe[3 * d.keep[i / 3] + i % 3];
+}
+
+void launch_cb_rhs(const CbStep* table, uint32_t nb, hipStream_t s) {
+    if (nb) hipLaunchKernelGGL(cb_rhs_kernel, dim3(nb), dim3(NT), 0, s, table);
+}
+void launch_cb_assemble(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t npp, hipStream_t s) {
+    if (nb) hipLaunchKernelGGL(cb_assemble_kernel, dim3(npp / 128, npp / 128, 4 * nb), dim3(256), 0, s, table, m, npp);
+}
+void launch_cb_post(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t nip, uint32_t npp, uint32_t outnp_max, hipStream_t s) {
+    const uint32_t rows = outnp_max > nip ? outnp_max : nip;
+    if (nb) hipLaunchKernelGGL(cb_post_kernel, dim3((rows + 255) / 256, outnp_max + 1, nb), dim3(256), 0, s, table, m, nip, npp, outnp_max);
+}
+void launch_cb_rhs_steps(const CbStep* table, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(cb_rhs_steps_kernel, dim3(n), dim3(NT), 0, s, table);
+}
+
 }  // namespace dnagpu

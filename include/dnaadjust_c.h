@@ -73,6 +73,10 @@ typedef struct {
                                   blocks' factors, the chain steps' factors on the condensed blocks -- and renew right-hand sides only
                                   from iteration 2 on; the variance matrices are formed once, after the last iteration, as before.
                                   0 = every iteration factors again.  Needs schur_carry, keep_factors and defer_variances = 2 */
+    int chain_runs;            /* condensed schedule on ONE GPU, many small blocks (a dnasegment-default cut; default -1 = choose): the two
+                                  junction chains are cut into this many runs whose steps advance together in merged launches
+                                  (dna_adjust::LockstepChains, dnagpu_chain_plan_*): 2 B / W + W steps deep instead of B.  0 / 1 = one
+                                  run (the chains step by step, block after block) */
 } dnaadj_settings;
 
 #define DNAADJ_OK 0
@@ -120,6 +124,8 @@ uint64_t dnaadj_chain_step_reuses(const dnaadj_handle* h);
 /* ... of the block steps, those that went out as one launch over many small blocks (dnagpu_small_batch_*: networks of 32 and more blocks
  * of up to ~680 stations each -- a dnasegment-default cut) */
 uint64_t dnaadj_small_batch_steps(const dnaadj_handle* h);
+/* a.chain_runs: the runs the junction chains of this network are cut into (steps advancing together, dna_adjust::LockstepChains); 0 = step by step */
+int dnaadj_chain_runs(const dnaadj_handle* h);
 uint32_t dnaadj_station_count(const dnaadj_handle* h);
 
 uint32_t dnaadj_block_station_count(const dnaadj_handle* h, uint32_t block);

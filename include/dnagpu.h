@@ -373,6 +373,43 @@ int dnagpu_small_batch_create(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks,
 int dnagpu_small_batch_condense(dnagpu_ctx* ctx, int chain, dnagpu_small_batch* sb);
 int dnagpu_small_batch_solve(dnagpu_ctx* ctx, int chain, dnagpu_small_batch* sb, double* max_corr);
 void dnagpu_small_batch_destroy(dnagpu_ctx* ctx, dnagpu_small_batch* sb);
+/* ---- chain plans: the chain steps of the condensed schedule as data, taken through the elimination in lock-step batches ----
+ * A chain step -- PhasedForwardBlock / PhasedReverseBlock on a condensed block (dnaadjust.cpp:2812, 3109, with
+ * CarryStnEstimatesandVariancesForward / ...Reverse :998-1281), a merge of two condensed systems, a step over a run's system -- adds a
+ * few systems into one (reduced systems: matrix + right-hand side in the attached vector; junction matrices in information form),
+ * adds constraint blocks, eliminates all stations but `keep` and leaves their complement in `out` (an information-form junction with
+ * the kept stations' estimates, or a reduced system).  dnagpu_chain_plan_create puts n_steps such steps on the device, grouped into
+ * batches (batch q = steps batch_first[q] .. batch_first[q + 1] - 1, at most DNAGPU_BATCH_MAX, independent of each other; its members are
+ * eliminated in one padded shape, the largest of theirs) and owns their factors; dnagpu_chain_plan_run takes one batch through assembly,
+ * elimination (factor kept, light form) and output as ONE sequence of merged launches, without waiting (the verdict of the eliminations
+ * stays in the chain: dnagpu_chain_hold_info / _take_info); dnagpu_chain_plan_run_rhs takes the steps of batches q_lo .. q_hi - 1
+ * (independent of each other, factored before) through their kept factors, right-hand sides only, in ONE launch.  A long chain of
+ * small steps -- a dnasegment-default cut -- is bound by its length: cut into runs that advance together it is 2 B / W + W steps deep
+ * instead of B (dna_adjust::LockstepChains).  DNAGPU_ETOOLARGE (nothing made) when a step is beyond the small-system kernels
+ * (more than 2 048 unknowns), has nothing to eliminate, or the factors exceed `max_bytes`.  The plan refers to the matrices' and
+ * blocks' storage: destroy it before any of them. */
+typedef struct dnagpu_chain_plan dnagpu_chain_plan;
+typedef struct dnagpu_chain_source {
+    const dnagpu_matrix* m;
+    int junction;               /* 0: a reduced system (right-hand side in the attached vector); 1: a junction matrix, information form */
+    const uint32_t* pos;        /* station a of m is station pos[a] of the step's system */
+    size_t k;
+} dnagpu_chain_source;
+typedef struct dnagpu_chain_step {
+    uint32_t n_stn;                                   /* stations of the step's system */
+    const uint32_t* est_blk; const uint32_t* est_idx; /* the linearisation point: station s = station est_idx[s] of block est_blk[s] (its originals); NULL: none */
+    int n_src;
+    dnagpu_chain_source src[3];
+    const uint32_t* con_stn; const double* con_w9; size_t n_con;      /* constraint blocks (dnagpu_add_diag3x3) */
+    const uint32_t* keep; size_t n_keep;              /* the stations carried on, in the order of out's unknowns */
+    dnagpu_matrix* out;
+    int out_junction;                                 /* 1: information-form junction (estimates of the kept stations attached); 0: reduced system */
+} dnagpu_chain_step;
+int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain_step* steps, size_t n_batches, const uint32_t* batch_first,
+                             double max_bytes, dnagpu_chain_plan** out);
+int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch);
+int dnagpu_chain_plan_run_rhs(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch_lo, size_t batch_hi);
+void dnagpu_chain_plan_destroy(dnagpu_ctx* ctx, dnagpu_chain_plan* plan);
 /* The same elimination as a stand-alone step: red (order 3k) <- Schur complement of all other unknowns of m onto the k
  * listed stations (list order), red's attached vector <- the reduced right-hand side.  With the stations a block shares
  * with its neighbours as the list, this condenses the block to its junction stations ONCE per iteration, independently of

@@ -755,6 +755,59 @@ def test_many_small_blocks_in_one_launch(built, orc, tmp_path, mt):
     o.close()
 
 
+@pytest.mark.parametrize("mt,runs,reuse", [(True, 4, True), (False, 7, True), (True, 13, False), (True, -1, True)])
+def test_chains_in_lock_step(built, orc, tmp_path, mt, runs, reuse):
+    """a.chain_runs: the two junction chains of a many-block network cut into runs whose steps advance together (dna_adjust::LockstepChains:
+    every run merged to its end stations, the chains over the runs, the chains inside every run from the boundary values -- each level's
+    steps of all runs as batches of merged launches, dnagpu_chain_plan_*).  Against the oracle and against the chains step by step
+    (same additions in the same order inside a run: agreement to rounding); runs of equal and of unequal length, more runs than a batch
+    holds would need (13 runs of 3 - 4 blocks), one chain and two, with and without factor reuse, twice on one handle."""
+    nb = 70 if runs < 0 else 40
+    info = adjust.write_synthetic_network(str(tmp_path), "m", 2 * nb, 24, 0, 1, seed=12, rows_lo=2, rows_hi=2, initial_sigma=0.3)
+    assert info["blocks"] == nb
+    net = orc.Network(str(tmp_path / "m"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    a, st = _device_run(str(tmp_path), "m", True, multi_thread=mt, chain_runs=runs, reuse_factors=reuse)
+    assert a.chain_runs() == (16 if runs < 0 else runs)
+    _compare(a, st, o, ost)
+    it = a.CurrentIteration()
+    assert it >= 2 and a.chain_step_reuses() == ((it - 1) * (2 * nb - 2) if reuse else 0)
+    _compare_statistics(a, o)
+    x1 = [a.block_estimates(b) for b in range(nb)]
+    v1 = [a.block_variances_packed(b) for b in range(nb)]
+    a.ResetAdjustment()
+    assert a.AdjustNetwork() == st and a.CurrentIteration() == it
+    for b in range(nb):
+        assert np.array_equal(a.block_estimates(b), x1[b])
+    a.close()
+    r, st2 = _device_run(str(tmp_path), "m", True, multi_thread=mt, chain_runs=0, reuse_factors=reuse)
+    assert r.chain_runs() == 0 and st2 == st and r.CurrentIteration() == it
+    for b in range(nb):
+        assert np.abs(r.block_estimates(b) - x1[b]).max() < 1e-9
+        assert np.abs(r.block_variances_packed(b) - v1[b]).max() <= 1e-11 * np.abs(v1[b]).max()
+    r.close()
+    o.close()
+
+
+def test_a_singular_step_of_lock_step_chains_is_named(built, tmp_path):
+    """the lock-step chains take the eliminations' verdict once per level; a pivot that is not positive sends the phase to the chains step
+    by step, which name the block (test_a_singular_chain_step_among_many_is_named)"""
+    adjust.write_synthetic_network(str(tmp_path), "s", 80, 24, 0, 1, seed=12, rows_lo=2, rows_hi=2)
+    base = os.path.join(str(tmp_path), "s")
+    ISL, JSL, CML, nets = F.read_seg(base + ".seg")
+    msr = F.read_bms(base + ".bms")
+    target = int(JSL[20][len(JSL[20]) // 2])
+    for k in range(len(CML)):
+        CML[k] = np.array([int(i) for i in CML[k] if int(msr[int(i)]["station1"]) != target and int(msr[int(i)]["station2"]) != target], dtype=np.uint32)
+    F.write_seg(base + ".seg", ISL, JSL, CML, nets, msr)
+    with pytest.raises(adjust.NetAdjustException) as e:
+        _device_run(str(tmp_path), "s", True, multi_thread=True, free_std_dev=1e200, chain_runs=5)
+    import re
+    assert "singular" in str(e.value) and re.search(r"block (19|20|21|22)\b", str(e.value)), str(e.value)
+
+
 def test_phased_block_1_mode(built, orc, tmp_path):
     """Phased_Block_1Mode (AdjustPhasedBlock1, dnaadjust.cpp:2675): one reverse pass; block 1 is rigorous -- exactly what the first
     iteration of the full phased adjustment gives it -- the blocks between keep their reverse solution, the last block is not

@@ -1,11 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
-T0=$SECONDS
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=15 2>&1 | tail -30 > gpurun_out/gpu_suite.txt
-echo "suite: $((SECONDS - T0)) s" >> gpurun_out/gpu_suite.txt
-tail -8 gpurun_out/gpu_suite.txt
-SKIP_PMC=1 TAG=r05 bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-echo "total: $((SECONDS - T0)) s"
-for f in gpurun_out/profiles_new/r05_bench_*.json; do echo $f; cut -c1-300 $f; echo; done
-cat gpurun_out/profiles_new/r05_inverse_rates.txt
+mkdir -p gpurun_out/j3
+timeout 900 python -m pytest tests/test_gpu_adjust.py -q -m gpu -x -k "lock_step or singular or many_small" 2>&1 | tail -30
+timeout 900 python -m pytest tests/test_gpu_adjust.py tests/test_gpu_batch.py tests/test_gpu_fullsize.py tests/test_gpu_distributed.py -q -m gpu -x --deselect tests/test_gpu_fullsize.py::test_cfg4_full_size_properties 2>&1 | tail -8
