@@ -593,7 +593,8 @@ def bench_one_process(folder, name, phased, args, devices, transport):
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, devices=devices, dist_transport=transport, multi_thread=multi_thread,
                                schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage,
                                defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
-                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))), reuse_factors=not args.no_reuse_factors)
+                               dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))), reuse_factors=not args.no_reuse_factors,
+                               chain_runs=args.chain_runs)
     a.PrepareAdjustment(p)
     lib = a.lib
     ctxs = [a.device_instance_context(r) for r in range(world)]
@@ -786,6 +787,9 @@ def main():
                          "two-level runs, bytes of every exchange of an iteration: dnaadj_plan_distributed) and exit")
     ap.add_argument("--plan-hbm-gb", type=float, default=309.2, help="memory of one GPU for --plan (MI355X: 309.2 GB visible)")
     ap.add_argument("--no-one-chain", action="store_true", help="skip the extra one-chain step behind roofline.frac_one_chain")
+    ap.add_argument("--chain-runs", type=int, default=-1,
+                    help="a.chain_runs: the junction chains of a many-block network on one GPU cut into this many runs whose steps advance "
+                         "together (lock-step chains); -1 = choose (32 runs from 512 blocks, 16 from 64), 0 = the chains step by step")
     ap.add_argument("--no-reuse-factors", action="store_true",
                     help="every iteration factors again (a.reuse_factors = 0): the schedule of rounds 1-4; by default iterations >= 2 of a GNSS-only "
                          "network keep the factors of iteration 1 and renew right-hand sides only")
@@ -975,7 +979,7 @@ def main():
             "mode": "phased" if phased else "simultaneous", "reuse_inverses": bool(p.reuse_inverses),
             # a.reuse_factors: iterations >= 2 of a GNSS-only network keep the factors of iteration 1 (the reference's own rule in simultaneous mode,
             # dnaadjust.cpp:2452-2457); block steps / chain steps of a step that were served from a kept factor (right-hand sides only)
-            "reuse_factors": bool(a.factor_reuses() or a.chain_step_reuses()), "factor_reuses_per_step": a.factor_reuses(),
+            "reuse_factors": bool(a.factor_reuses() or a.chain_step_reuses()), "chain_runs": a.chain_runs(), "factor_reuses_per_step": a.factor_reuses(),
             "chain_step_reuses_per_step": a.chain_step_reuses(),
             "schur_carry": bool(elims), "eliminations_per_step": elims, "keep_factors": bool(a.completion_count()),
             "variance_matrices": "after the last iteration" if (a.completion_count() and not args.variances_every_iteration and not args.reuse_inverses) else "every iteration",

@@ -42,6 +42,14 @@ void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_
 void launch_msr_stats(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const uint32_t* s1,
                       const uint32_t* s2, const double* b, double* wb, const double* S, uint32_t nps, double* prec6, double* chi, uint32_t n_vec,
                       hipStream_t s);
+struct OscRow {
+    const double* corr;
+    const uint32_t* gidx;
+    uint32_t* visit;
+    uint32_t n_stn;
+};
+void launch_osc_update_stations(const OscRow* rows, const uint32_t* off, const void* visits, uint32_t n_global, double* prev, uint32_t* seen, uint32_t* cnt,
+                                uint32_t* flagged, hipStream_t s);
 void launch_osc_update(const double* corr, const uint32_t* gidx, uint32_t n_stn, double* prev, uint32_t* seen, uint32_t* cnt, uint32_t* visit,
                        uint32_t* flagged, hipStream_t s);
 void launch_update_estimates(double* xe, const double* corr, uint32_t n, double* out_val, uint32_t* out_idx, hipStream_t s);

@@ -648,6 +648,59 @@ __global__ void osc_update_kernel(const double* __restrict__ corr, const uint32_
         atomicAdd(flagged, 1u);
     }
 }
+// The same for MANY blocks in one launch (a dnasegment-default cut: 666 launches of ~3 us per iteration otherwise).  A station shared by
+// several blocks is visited by each of them IN ORDER -- the state it is compared with is the previous visit's, possibly a block earlier in
+// this very iteration -- so the launch goes by STATION: a thread takes one station of the network through its visits (block, position in
+// the block) in block order, its state in registers.  off / visits: the stations' visit lists (CSR), built once per set of blocks.
+__global__ __launch_bounds__(256) void osc_update_stations_kernel(const OscRow* __restrict__ rows, const uint32_t* __restrict__ off,
+                                                                  const uint2* __restrict__ visits, uint32_t n_global, double* __restrict__ prev,
+                                                                  uint32_t* __restrict__ seen, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flagged) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_global) return;
+    const uint32_t v0 = off[g], v1 = off[g + 1];
+    if (v0 == v1) return;
+    bool was_seen = seen[g] != 0;
+    double px = prev[3 * (size_t)g], py = prev[3 * (size_t)g + 1], pz = prev[3 * (size_t)g + 2];
+    uint32_t c = cnt[g], hits = 0;
+    for (uint32_t v = v0; v < v1; ++v) {
+        const uint2 w = visits[v];
+        const OscRow r = rows[w.x];
+        const uint32_t s = w.y;
+        const double cx = r.corr[3 * s], cy = r.corr[3 * s + 1], cz = r.corr[3 * s + 2];
+        uint32_t mark = 0;
+        if (was_seen) {
+            const double magCurr = sqrt(cx * cx + cy * cy + cz * cz), magPrev = sqrt(px * px + py * py + pz * pz);
+            if (magCurr < 0.001 && magPrev < 0.001) {
+                c = 0;
+            } else {
+                const double dot = cx * px + cy * py + cz * pz, denom = magCurr * magPrev;
+                const double cosAngle = denom > 1e-30 ? dot / denom : 0.0;
+                const double ratio = magPrev > 1e-30 ? magCurr / magPrev : 0.0;
+                c = (cosAngle < -0.5 && ratio > 0.3 && ratio < 3.0) ? c + 1 : 0;
+                if (c >= 2) {
+                    mark = c;
+                    ++hits;
+                }
+            }
+        }
+        r.visit[s] = mark;
+        was_seen = true;
+        px = cx;
+        py = cy;
+        pz = cz;
+    }
+    seen[g] = 1;
+    prev[3 * (size_t)g] = px;
+    prev[3 * (size_t)g + 1] = py;
+    prev[3 * (size_t)g + 2] = pz;
+    cnt[g] = c;
+    if (hits) atomicAdd(flagged, hits);
+}
+void launch_osc_update_stations(const OscRow* rows, const uint32_t* off, const void* visits, uint32_t n_global, double* prev, uint32_t* seen, uint32_t* cnt,
+                                uint32_t* flagged, hipStream_t s) {
+    if (n_global)
+        hipLaunchKernelGGL(osc_update_stations_kernel, dim3((n_global + 255) / 256), dim3(256), 0, s, rows, off, (const uint2*)visits, n_global, prev, seen, cnt, flagged);
+}
 void launch_osc_update(const double* corr, const uint32_t* gidx, uint32_t n_stn, double* prev, uint32_t* seen, uint32_t* cnt, uint32_t* visit,
                        uint32_t* flagged, hipStream_t s) {
     if (n_stn) hipLaunchKernelGGL(osc_update_kernel, dim3((n_stn + 255) / 256), dim3(256), 0, s, corr, gidx, n_stn, prev, seen, cnt, visit, flagged);

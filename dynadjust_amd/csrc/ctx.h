@@ -185,6 +185,11 @@ struct dnagpu_ctx {
     double* osc_prev = nullptr;
     uint32_t *osc_seen = nullptr, *osc_cnt = nullptr, *osc_flagged = nullptr;
     size_t osc_stations = 0;
+    // dnagpu_osc_blocks: the blocks' rows (adjust_kernels.h OscRow) and the stations' visit lists of its one launch, kept while the blocks stay the same
+    void* osc_rows = nullptr;
+    uint32_t* osc_off = nullptr;
+    void* osc_visits = nullptr;
+    uint64_t osc_key = 0;
     bool hbm_profile = false;
     std::vector<HbmRec> hbm_recs[DNAGPU_NUM_CHAINS];
     std::vector<hipEvent_t> hbm_free[DNAGPU_NUM_CHAINS];

@@ -383,7 +383,7 @@ void dnagpu_destroy(dnagpu_ctx* ctx) {
         if (ctx->copy_stream[c]) hipStreamDestroy(ctx->copy_stream[c]);
     }
     if (ctx->bad_dev) hipFree(ctx->bad_dev);
-    for (void* p : {(void*)ctx->osc_prev, (void*)ctx->osc_seen, (void*)ctx->osc_cnt, (void*)ctx->osc_flagged})
+    for (void* p : {(void*)ctx->osc_prev, (void*)ctx->osc_seen, (void*)ctx->osc_cnt, (void*)ctx->osc_flagged, ctx->osc_rows, (void*)ctx->osc_off, ctx->osc_visits})
         if (p) hipFree(p);
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
         for (auto& r : ctx->hbm_recs[c]) {
@@ -1730,6 +1730,7 @@ int dnagpu_osc_reset(dnagpu_ctx* ctx, size_t n_stations) {
         ctx->osc_prev = nullptr;
         ctx->osc_seen = ctx->osc_cnt = nullptr;
         ctx->osc_stations = 0;
+        ctx->osc_key = 0;       // (the visit lists of dnagpu_osc_blocks are per station of the network)
         if (n_stations) {
             hipError_t e = dnagpu::poison_malloc(&ctx->osc_prev, 3 * n_stations * sizeof(double));
             if (e == hipSuccess) e = dnagpu::poison_malloc(&ctx->osc_seen, n_stations * sizeof(uint32_t));
@@ -1776,6 +1777,60 @@ int dnagpu_osc_block(dnagpu_ctx* ctx, uint32_t blk, int corr_chain, const uint32
         HIPCHK(hipMemcpy(b->osc_gidx, stations, (size_t)b->n_stn * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     launch_osc_update(corr, b->osc_gidx, b->n_stn, ctx->osc_prev, ctx->osc_seen, ctx->osc_cnt, b->osc_visit, ctx->osc_flagged, st);
+    return DNAGPU_OK;
+}
+
+int dnagpu_osc_blocks(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const int* corr_chain, const uint32_t* const* stations) {
+    CHK_CTX();
+    if (!n) return DNAGPU_OK;
+    if (!blks || !corr_chain || !stations || !ctx->osc_flagged) return fail(ctx, DNAGPU_EINVAL, "osc_blocks: bad arguments");
+    std::vector<OscRow> rows(n);
+    for (uint32_t q = 0; q < n; ++q) {
+        Block* b = find_block(ctx, blks[q]);
+        const double* corr = !b ? nullptr : corr_chain[q] < 0 ? b->corr_keep : corr_chain[q] < DNAGPU_NUM_CHAINS ? b->corr[corr_chain[q]] : nullptr;
+        if (!b || !corr || (!stations[q] && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "osc_blocks: bad arguments");
+        if (!b->osc_gidx && b->n_stn) {
+            for (uint32_t s = 0; s < b->n_stn; ++s)
+                if (stations[q][s] >= ctx->osc_stations) return fail(ctx, DNAGPU_EINVAL, "osc_blocks: station out of range");
+            HIPCHK(dnagpu::poison_malloc(&b->osc_gidx, (size_t)b->n_stn * sizeof(uint32_t)));
+            HIPCHK(dnagpu::poison_malloc(&b->osc_visit, (size_t)b->n_stn * sizeof(uint32_t)));
+            HIPCHK(hipMemcpy(b->osc_gidx, stations[q], (size_t)b->n_stn * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        rows[q] = {corr, b->osc_gidx, b->osc_visit, b->n_stn};
+    }
+    hipStream_t st = ctx->stream[0];
+    // the stations' visit lists (block order) and the rows' table: built and uploaded when the set of blocks or their vectors change
+    uint64_t key = 1469598103934665603ull;
+    for (uint32_t q = 0; q < n; ++q) {
+        key = (key ^ blks[q]) * 1099511628211ull;
+        key = (key ^ (uint64_t)(uintptr_t)rows[q].corr) * 1099511628211ull;
+    }
+    if (key != ctx->osc_key || !ctx->osc_rows) {
+        HIPCHK(hipStreamSynchronize(st));
+        for (void* p : {ctx->osc_rows, (void*)ctx->osc_off, ctx->osc_visits})
+            if (p) hipFree(p);
+        ctx->osc_rows = ctx->osc_visits = nullptr;
+        ctx->osc_off = nullptr;
+        ctx->osc_key = 0;
+        std::vector<uint32_t> off(ctx->osc_stations + 1, 0);
+        for (uint32_t q = 0; q < n; ++q)
+            for (uint32_t s = 0; s < rows[q].n_stn; ++s) off[stations[q][s] + 1]++;
+        for (size_t g = 0; g < ctx->osc_stations; ++g) off[g + 1] += off[g];
+        std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+        std::vector<uint2> visits(off.back() ? off.back() : 1);
+        for (uint32_t q = 0; q < n; ++q)          // (blocks in the order given: a station's visits end up in block order)
+            for (uint32_t s = 0; s < rows[q].n_stn; ++s) visits[fill[stations[q][s]]++] = make_uint2(q, s);
+        HIPCHK(dnagpu::poison_malloc(&ctx->osc_rows, (size_t)n * sizeof(OscRow)));
+        HIPCHK(dnagpu::poison_malloc(&ctx->osc_off, off.size() * sizeof(uint32_t)));
+        HIPCHK(dnagpu::poison_malloc(&ctx->osc_visits, visits.size() * sizeof(uint2)));
+        HIPCHK(hipMemcpy(ctx->osc_rows, rows.data(), (size_t)n * sizeof(OscRow), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->osc_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->osc_visits, visits.data(), visits.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        ctx->osc_key = key;
+    }
+    launch_osc_update_stations((const OscRow*)ctx->osc_rows, ctx->osc_off, ctx->osc_visits, (uint32_t)ctx->osc_stations, ctx->osc_prev, ctx->osc_seen,
+                               ctx->osc_cnt, ctx->osc_flagged, st);
+    HIPCHK(hipGetLastError());
     return DNAGPU_OK;
 }
 

@@ -1666,9 +1666,18 @@ void dna_adjust::UpdateIterationDiagnostics() {
         Check(dnagpu_osc_reset(ctx_, bstBinaryRecords_.size()), 0, "UpdateIterationDiagnostics()");
         osc_ready_ = true;
     }
-    for (UINT32 b = 0; b < blockCount_; ++b) {
-        if (!OwnsBlock(b) || v_parameterStationList_[b].empty()) continue;
-        Check(dnagpu_osc_block(ctx_, b, blocks_[b].corr_chain, v_parameterStationList_[b].data()), b, "UpdateIterationDiagnostics()");
+    {
+        // (all blocks of this rank in one launch, in block order)
+        std::vector<UINT32> ids;
+        std::vector<int> chains;
+        std::vector<const UINT32*> lists;
+        for (UINT32 b = 0; b < blockCount_; ++b) {
+            if (!OwnsBlock(b) || v_parameterStationList_[b].empty()) continue;
+            ids.push_back(b);
+            chains.push_back(blocks_[b].corr_chain);
+            lists.push_back(v_parameterStationList_[b].data());
+        }
+        Check(dnagpu_osc_blocks(ctx_, (uint32_t)ids.size(), ids.data(), chains.data(), lists.data()), 0, "UpdateIterationDiagnostics()");
     }
     UINT32 flagged = 0;
     Check(dnagpu_osc_flagged(ctx_, &flagged), 0, "UpdateIterationDiagnostics()");

@@ -1978,8 +1978,10 @@ void dna_adjust::PrepareLockstepChains() {
             close_group(stages.back().lanes[1], members);
         }
         // level 3: both chains inside every run, from the boundary values of level 2 (CondensedForwardBlock / CondensedReverseBlock as data)
+        // (a lane per direction and batch slot: the slots of a direction are independent of each other and go to chains of their own)
+        const int slots = (W + DNAGPU_BATCH_MAX - 1) / DNAGPU_BATCH_MAX;
         stages.emplace_back();
-        stages.back().lanes.resize(2);
+        stages.back().lanes.resize((size_t)(2 * slots));
         auto block_step = [&](UINT32 k, int dir) -> double {
             const block_t& Bk = blocks_[k];
             step_data_t d;
@@ -2013,25 +2015,28 @@ void dna_adjust::PrepareLockstepChains() {
             }
             return add_step(std::move(d), n_src, src, junction, out, 1, (UINT32)Bk.keep.size());
         };
-        for (UINT32 j = 0; j <= longest; ++j) {
-            std::vector<pending_t> members;
-            for (int r = 0; r < W; ++r) {
-                const run_t& g = runs[r];
-                if (g.a + j + 1 > g.b) continue;
-                const UINT32 k = g.a + j;
-                members.push_back({[&, k]() -> double { return block_step(k, 0); }, true, r, nref3(k)});
+        for (int slot = 0; slot < slots; ++slot) {
+            const int r_lo = slot * DNAGPU_BATCH_MAX, r_hi = std::min(W, r_lo + DNAGPU_BATCH_MAX);
+            for (UINT32 j = 0; j <= longest; ++j) {
+                std::vector<pending_t> members;
+                for (int r = r_lo; r < r_hi; ++r) {
+                    const run_t& g = runs[r];
+                    if (g.a + j + 1 > g.b) continue;
+                    const UINT32 k = g.a + j;
+                    members.push_back({[&, k]() -> double { return block_step(k, 0); }, true, r, nref3(k)});
+                }
+                close_group(stages.back().lanes[(size_t)(2 * slot)], members);
             }
-            close_group(stages.back().lanes[0], members);
-        }
-        for (UINT32 j = 0; j <= longest; ++j) {
-            std::vector<pending_t> members;
-            for (int r = 0; r < W; ++r) {
-                const run_t& g = runs[r];
-                if (g.b < g.a + 1 + j) continue;
-                const UINT32 k = g.b - j;
-                members.push_back({[&, k]() -> double { return block_step(k, 1); }, true, r, nref3(k)});
+            for (UINT32 j = 0; j <= longest; ++j) {
+                std::vector<pending_t> members;
+                for (int r = r_lo; r < r_hi; ++r) {
+                    const run_t& g = runs[r];
+                    if (g.b < g.a + 1 + j) continue;
+                    const UINT32 k = g.b - j;
+                    members.push_back({[&, k]() -> double { return block_step(k, 1); }, true, r, nref3(k)});
+                }
+                close_group(stages.back().lanes[(size_t)(2 * slot + 1)], members);
             }
-            close_group(stages.back().lanes[1], members);
         }
     } catch (...) {
         FreeLockstepChains();      // (no room for the merged systems: the chains go step by step)
@@ -2056,7 +2061,7 @@ void dna_adjust::PrepareLockstepChains() {
 bool dna_adjust::LockstepChains() {
     if (!lockstep_ok_ || !lock_plan_) return false;
     const bool rhs_only = lock_factored_ && FactorReuse();
-    const int nch = std::min(NumChains(), 2);
+    const int nch = std::min(NumChains(), 4);
     bool failed = false;
     std::mutex fm;
     for (const lock_stage_t& stage : lock_stages_) {

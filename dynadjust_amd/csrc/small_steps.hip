@@ -407,6 +407,7 @@ __global__ __launch_bounds__(NT) void cb_rhs_kernel(const CbStep* __restrict__ t
 // The step's system in the elimination's order (what dnagpu_block_load_reduced + add_diag3x3 + junction_scatter + schur_permute leave):
 // element (i, j), i >= j, is the sum over the sources that hold both unknowns, plus the constraint block of the station; the row map = -2
 // carries the right-hand side; identity on the padding's diagonal.  One workgroup per quarter of a 128 x 128 tile of the lower tile triangle.
+// The sources hold BOTH triangles (schur_extract_kernel / cb_post_kernel write them so).
 __global__ __launch_bounds__(256) void cb_assemble_kernel(const CbStep* __restrict__ table, const CbMembers mem, uint32_t npp) {
     const uint32_t b = blockIdx.z >> 2, qz = blockIdx.z & 3;
     const CbStep& d = table[b];
@@ -417,34 +418,51 @@ __global__ __launch_bounds__(256) void cb_assemble_kernel(const CbStep* __restri
     const uint32_t i = tr * 128 + il;
     const int32_t mi = d.map[i];
     const uint32_t su = mi >= 0 ? (uint32_t)mi / 3 : 0, eu = mi >= 0 ? (uint32_t)mi % 3 : 0;
+    const uint32_t nsrc = d.n_src;
     int32_t ai[CB_SRC_MAX];
 #pragma unroll
-    for (int q = 0; q < CB_SRC_MAX; ++q) ai[q] = (mi >= 0 && (uint32_t)q < d.n_src) ? d.src[q].inv[su] : -1;
-#pragma unroll 4
-    for (uint32_t jl = qz * 32 + (threadIdx.x >> 7); jl < qz * 32 + 32; jl += 2) {
-        const uint32_t j = tc * 128 + jl;
-        const int32_t mj = d.map[j];
-        double v = 0.0;
-        if (i >= j) {
-            if (mi >= 0 && mj >= 0) {
-                const uint32_t sv = (uint32_t)mj / 3, ev = (uint32_t)mj % 3;
+    for (int q = 0; q < CB_SRC_MAX; ++q) ai[q] = (mi >= 0 && (uint32_t)q < nsrc) ? d.src[q].inv[su] : -1;
+    // a thread's 16 columns: their map entries, then their source stations, then the matrix entries -- each round of loads in flight together
+    // (one column at a time the kernel was three dependent loads deep per element: 42 us for a batch of sixteen 640-unknown systems)
+    const uint32_t j0 = tc * 128 + qz * 32 + (threadIdx.x >> 7);
+    int32_t mj[16];
 #pragma unroll
-                for (int q = 0; q < CB_SRC_MAX; ++q) {
-                    if (ai[q] < 0) continue;
-                    const int32_t bj = d.src[q].inv[sv];
-                    if (bj < 0) continue;
-                    const uint32_t r0 = 3 * (uint32_t)ai[q] + eu, c0 = 3 * (uint32_t)bj + ev;
-                    const uint32_t r = r0 > c0 ? r0 : c0, c = r0 > c0 ? c0 : r0;
-                    v += d.src[q].F[(size_t)c * d.src[q].np + r];
-                }
-                if (d.con && su == sv) v += d.con[(size_t)su * 9 + ev * 3 + eu];
-            } else if (mi == -2) {
-                v = mj >= 0 ? d.rhs[mj] : 0.0;
-            } else if (mi == -1 && i == j) {
-                v = 1.0;
-            }
+    for (int t = 0; t < 16; ++t) mj[t] = d.map[j0 + 2 * t];
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = 0.0;
+    if (mi >= 0) {
+#pragma unroll
+        for (int q = 0; q < CB_SRC_MAX; ++q) {
+            if (ai[q] < 0) continue;         // (uniform over most of a wave: a source covers whole station ranges)
+            const CbSrc& sc = d.src[q];
+            int32_t bj[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) bj[t] = (mj[t] >= 0 && i >= j0 + 2 * t) ? sc.inv[(uint32_t)mj[t] / 3] : -1;
+            const size_t r0 = 3 * (size_t)ai[q] + eu;
+            double f[16];
+            // (every source holds both triangles: no swap to the lower one, the rows of a column stay coalesced)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) f[t] = bj[t] >= 0 ? sc.F[(size_t)(3 * (uint32_t)bj[t] + (uint32_t)mj[t] % 3) * sc.np + r0] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] += f[t];
         }
-        dst[(size_t)j * npp + i] = v;
+        if (d.con) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (mj[t] >= 0 && i >= j0 + 2 * t && (uint32_t)mj[t] / 3 == su) v[t] += d.con[(size_t)su * 9 + ((uint32_t)mj[t] % 3) * 3 + eu];
+        }
+    } else if (mi == -2) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = mj[t] >= 0 ? d.rhs[mj[t]] : 0.0;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = (i == j0 + 2 * t) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t j = j0 + 2 * t;
+        dst[(size_t)j * npp + i] = i >= j ? v[t] : 0.0;
     }
 }
 

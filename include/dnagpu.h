@@ -305,6 +305,9 @@ int dnagpu_block_get_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, doubl
 int dnagpu_block_keep_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk);
 int dnagpu_osc_reset(dnagpu_ctx* ctx, size_t n_stations);
 int dnagpu_osc_block(dnagpu_ctx* ctx, uint32_t blk, int corr_chain, const uint32_t* stations);
+/* ... and the visits of n blocks, in the order given, as ONE launch (the blocks follow each other inside it: a station shared by several blocks is
+ * compared with its previous visit, which may be an earlier block's of this iteration) */
+int dnagpu_osc_blocks(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const int* corr_chain, const uint32_t* const* stations);
 int dnagpu_osc_flagged(dnagpu_ctx* ctx, uint32_t* n_flagged);
 int dnagpu_osc_block_visits(dnagpu_ctx* ctx, uint32_t blk, uint32_t* visit);
 int dnagpu_block_get_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk, double* rhs);

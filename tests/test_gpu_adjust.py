@@ -791,6 +791,29 @@ def test_chains_in_lock_step(built, orc, tmp_path, mt, runs, reuse):
     o.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_lock_step_chains_on_random_segmentations(built, orc, tmp_path, seed):
+    """the lock-step chains on cuts the strip generator cannot make (tests/segfuzz.py): junction stations that stay junction over several
+    blocks -- they persist through the merges of a run and across run boundaries --, junction sets of uneven size (the members of a batch
+    are eliminated in the largest member's padded shape), runs of unequal length.  Oracle live."""
+    from tests import segfuzz
+    rng = np.random.default_rng(4000 + seed)
+    adjust.write_synthetic_network(str(tmp_path), "a", int(rng.integers(16, 26)), int(rng.integers(5, 9)), 0, 1, seed=seed * 5 + 1, initial_sigma=0.2)
+    info = segfuzz.write_cut(str(tmp_path / "a"), rng, mean_block=int(rng.integers(4, 9)), noise=float(rng.uniform(0.1, 0.5)), lone_last=False)
+    assert info["blocks"] >= 9 and info["nets"] == 1
+    net = orc.Network(str(tmp_path / "a"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    assert ost == 0
+    runs = 2 + seed % 3
+    a, st = _device_run(str(tmp_path), "a", True, multi_thread=bool(seed % 2), chain_runs=runs)
+    assert a.chain_runs() == runs, info
+    _compare(a, st, o, ost)
+    a.close()
+    o.close()
+
+
 def test_a_singular_step_of_lock_step_chains_is_named(built, tmp_path):
     """the lock-step chains take the eliminations' verdict once per level; a pivot that is not positive sends the phase to the chains step
     by step, which name the block (test_a_singular_chain_step_among_many_is_named)"""
