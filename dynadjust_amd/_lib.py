@@ -326,7 +326,7 @@ def load():
 EXPORTED_DNAGPU = [
     "dnagpu_device_count", "dnagpu_create", "dnagpu_destroy", "dnagpu_last_error", "dnagpu_last_info", "dnagpu_sync",
     "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset", "dnagpu_debug_fail_allocation", "dnagpu_debug_fail_batch_workspaces", "dnagpu_debug_set_small_tiles", "dnagpu_debug_set_tiny_tiles", "dnagpu_debug_set_info_carry", "dnagpu_info_carry", "dnagpu_ctx_set_info_carry", "dnagpu_chain_reserve", "dnagpu_partial_pack_device", "dnagpu_partial_unpack_device", "dnagpu_debug_tile_order",
-    "dnagpu_block_keep_corrections", "dnagpu_osc_reset", "dnagpu_osc_block", "dnagpu_osc_blocks", "dnagpu_osc_flagged", "dnagpu_osc_block_visits", "dnagpu_profile_get", "dnagpu_profile_hbm_enable", "dnagpu_profile_hbm_get", "dnagpu_matrix_pack_device", "dnagpu_matrix_unpack_device", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
+    "dnagpu_block_keep_corrections", "dnagpu_osc_reset", "dnagpu_osc_block", "dnagpu_osc_blocks", "dnagpu_form_rhs_batched", "dnagpu_osc_flagged", "dnagpu_osc_block_visits", "dnagpu_profile_get", "dnagpu_profile_hbm_enable", "dnagpu_profile_hbm_get", "dnagpu_matrix_pack_device", "dnagpu_matrix_unpack_device", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
     "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_download_packed_async", "dnagpu_copies_sync", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_reset_stations", "dnagpu_chain_hold_info", "dnagpu_chain_take_info", "dnagpu_block_table_create", "dnagpu_block_table_apply", "dnagpu_block_table_destroy", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",
     "dnagpu_block_get_stations", "dnagpu_block_put_stations", "dnagpu_block_copy_stations", "dnagpu_block_compute_b",
@@ -336,7 +336,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_schur_carry_keep", "dnagpu_schur_carry_rhs", "dnagpu_chain_step_rhs", "dnagpu_small_batch_create", "dnagpu_small_batch_condense", "dnagpu_small_batch_solve", "dnagpu_small_batch_destroy", "dnagpu_junction_export", "dnagpu_junction_import", "dnagpu_junction_device_pointers", "dnagpu_block_reduce", "dnagpu_block_form_reduce", "dnagpu_batch_reserve", "dnagpu_block_form_reduce_batched", "dnagpu_partial_complete_factor_batched", "dnagpu_partial_finish_batched", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_create_spine", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
-    "dnagpu_chain_plan_create", "dnagpu_chain_plan_run", "dnagpu_chain_plan_run_rhs", "dnagpu_chain_plan_destroy",
+    "dnagpu_chain_plan_create", "dnagpu_chain_plan_run", "dnagpu_chain_plan_run_rhs", "dnagpu_chain_plan_destroy", "dnagpu_partial_complete_factor_planned",
 ]
 
 EXPORTED_DNAADJ = [

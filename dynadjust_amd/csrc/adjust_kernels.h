@@ -42,6 +42,38 @@ void launch_form_rhs(const double* wblk, const uint32_t* vec_wrow, const uint32_
 void launch_msr_stats(const double* wblk, const uint32_t* vec_wrow, const uint32_t* vec_c0, const uint32_t* vec_k, const uint32_t* s1,
                       const uint32_t* s2, const double* b, double* wb, const double* S, uint32_t nps, double* prec6, double* chi, uint32_t n_vec,
                       hipStream_t s);
+// members of a batched launch (blockIdx.z), passed by value
+struct FormMember {
+    double* F;
+    const int32_t* map;
+    int32_t* map_out;
+    const uint32_t *spos, *prow, *pcol, *poff, *pent;
+    const double* wblk;
+    const uint32_t* con_stn;
+    const double* con_w9;
+    const double* rhs;
+    uint32_t n_pairs, n_gnss_blk, terr_shift, n_con, rhs_row;
+};
+struct FormBatch { FormMember m[16]; };
+void launch_form_ordered_batch(const FormBatch& fb, int nb, uint32_t ld, uint32_t npp, hipStream_t s);
+struct ExtractMember {
+    const double* T;
+    double *X, *S, *r;
+    uint32_t nj, npj;
+};
+struct ExtractBatch { ExtractMember m[16]; };
+void launch_extract_batch(const ExtractBatch& eb, int nb, uint32_t nip, uint32_t npp, uint32_t npj_max, hipStream_t s);
+struct RhsMember {
+    const double* wblk;
+    const uint32_t *vec_wrow, *vec_c0, *vec_k;
+    const double* b;
+    double* wb;
+    const uint32_t *ioff, *inc;
+    double* rhs;
+    uint32_t n_vec, n_stn;
+};
+struct RhsBatch { RhsMember m[16]; };
+void launch_form_rhs_batch(const RhsBatch& rb, int nb, hipStream_t s);
 struct OscRow {
     const double* corr;
     const uint32_t* gidx;

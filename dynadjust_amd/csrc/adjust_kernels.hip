@@ -218,6 +218,134 @@ void launch_form_ordered(double* F, uint32_t ld, uint32_t npp, const int32_t* ma
     hipLaunchKernelGGL(rhs_row_kernel, dim3((npp + 255) / 256), dim3(256), 0, s, F, ld, rhs_row, map, rhs, npp);
 }
 
+// ---- the same for the members of a batch (dnagpu_block_form_reduce_batched): one launch per kernel for all of them, blockIdx.z = member.
+// A dnasegment-default cut condenses 666 blocks in 42 batches: per member the kernels above (and the two of the right-hand side, the map's
+// copy, the passenger row's memset, the extraction) were eleven launches of 3 - 8 us, 7 000 per iteration.  Same operations per element.
+__global__ __launch_bounds__(256) void init_ordered_batch_kernel(const FormBatch fb, uint32_t ld) {
+    const FormMember& m = fb.m[blockIdx.z];
+    const uint32_t tr = blockIdx.x, tc = blockIdx.y;
+    if (tc > tr) return;
+    const uint32_t i = tr * 128 + (threadIdx.x & 127);
+    const int32_t mi = m.map[i];
+    if (tc == 0 && threadIdx.x < 128) m.map_out[i] = mi;         // (the kept factor's own copy of the order)
+    const bool pad = mi == -1;
+    for (uint32_t jl = threadIdx.x >> 7; jl < 128; jl += 2) {
+        const uint32_t j = tc * 128 + jl;
+        m.F[(size_t)j * ld + i] = (i == j && pad) ? 1.0 : 0.0;
+    }
+}
+__global__ void form_normals_ordered_batch_kernel(const FormBatch fb, uint32_t ld) {
+    const FormMember& m = fb.m[blockIdx.z];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m.n_pairs * 9) return;
+    uint32_t p = t / 9, e = t - p * 9;
+    int ei = e % 3, ej = e / 3;
+    uint32_t r = m.prow[p], c = m.pcol[p];
+    if (r == c && ei < ej) return;
+    double s = 0.0;
+    uint32_t k0 = m.poff[p], k1 = m.poff[p + 1];
+    for (uint32_t k = k0; k < k1; ++k) {
+        uint32_t ent = m.pent[k];
+        uint32_t blk = ent >> 1;
+        if (blk >= m.n_gnss_blk) blk += m.terr_shift;
+        double w = m.wblk[(size_t)blk * 9 + e];
+        s += (ent & 1u) ? -w : w;
+    }
+    const uint32_t pr = m.spos[r] + ei, pc = m.spos[c] + ej;
+    if (pr >= pc)
+        m.F[(size_t)pc * ld + pr] = s;
+    else
+        m.F[(size_t)pr * ld + pc] = s;
+}
+__global__ void add_diag3x3_ordered_batch_kernel(const FormBatch fb, uint32_t ld) {
+    const FormMember& m = fb.m[blockIdx.z];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m.n_con * 9) return;
+    uint32_t q = t / 9, e = t - q * 9;
+    int ei = e % 3, ej = e / 3;
+    if (ei < ej) return;
+    const uint32_t s0 = m.spos[m.con_stn[q]];
+    m.F[(size_t)(s0 + ej) * ld + s0 + ei] += m.con_w9[(size_t)q * 9 + ej * 3 + ei];
+}
+__global__ void rhs_row_batch_kernel(const FormBatch fb, uint32_t ld, uint32_t npp) {
+    const FormMember& m = fb.m[blockIdx.z];
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npp) return;
+    const int32_t mp = m.map[p];
+    if (mp >= 0) m.F[(size_t)p * ld + m.rhs_row] = m.rhs[mp];
+}
+void launch_form_ordered_batch(const FormBatch& fb, int nb, uint32_t ld, uint32_t npp, hipStream_t s) {
+    uint32_t max_pairs = 0, max_con = 0;
+    for (int b = 0; b < nb; ++b) {
+        max_pairs = max_pairs > fb.m[b].n_pairs ? max_pairs : fb.m[b].n_pairs;
+        max_con = max_con > fb.m[b].n_con ? max_con : fb.m[b].n_con;
+    }
+    hipLaunchKernelGGL(init_ordered_batch_kernel, dim3(npp / 128, npp / 128, nb), dim3(256), 0, s, fb, ld);
+    if (max_pairs) hipLaunchKernelGGL(form_normals_ordered_batch_kernel, dim3((max_pairs * 9 + 255) / 256, 1, nb), dim3(256), 0, s, fb, ld);
+    if (max_con) hipLaunchKernelGGL(add_diag3x3_ordered_batch_kernel, dim3((max_con * 9 + 255) / 256, 1, nb), dim3(256), 0, s, fb, ld);
+    hipLaunchKernelGGL(rhs_row_batch_kernel, dim3((npp + 255) / 256, 1, nb), dim3(256), 0, s, fb, ld, npp);
+}
+// after the members' elimination: complement (both triangles, identity padded) and reduced right-hand side out of the trailing block of
+// each member's matrix (schur_extract_kernel), the passenger row's entries in the kept factor's panels cleared
+__global__ __launch_bounds__(256) void extract_batch_kernel(const ExtractBatch eb, uint32_t nip, uint32_t npp, uint32_t npj_max) {
+    const ExtractMember& m = eb.m[blockIdx.z];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (j < npj_max) {
+        if (j >= m.npj || i >= m.npj) return;
+        double v = i == j ? 1.0 : 0.0;
+        if (i < m.nj && j < m.nj) v = i >= j ? m.T[(size_t)j * npp + i] : m.T[(size_t)i * npp + j];
+        m.S[(size_t)j * m.npj + i] = v;
+        if (i == 0) m.r[j] = j < m.nj ? m.T[(size_t)j * npp + m.nj] : 0.0;
+        return;
+    }
+    if (i < nip) m.X[(size_t)i * npp + nip + m.nj] = 0.0;
+}
+void launch_extract_batch(const ExtractBatch& eb, int nb, uint32_t nip, uint32_t npp, uint32_t npj_max, hipStream_t s) {
+    const uint32_t rows = npj_max > nip ? npj_max : nip;
+    hipLaunchKernelGGL(extract_batch_kernel, dim3((rows + 255) / 256, npj_max + 1, nb), dim3(256), 0, s, eb, nip, npp, npj_max);
+}
+// A^T W b of the members (cluster_wb_kernel + form_rhs_kernel)
+__global__ void cluster_wb_batch_kernel(const RhsBatch rb) {
+    const RhsMember& m = rb.m[blockIdx.z];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m.n_vec * 3) return;
+    uint32_t v = t / 3;
+    int c = t - v * 3;
+    const uint32_t k = m.vec_k[v], c0 = m.vec_c0[v];
+    const double* row = m.wblk + (size_t)m.vec_wrow[v] * 9;
+    double acc = 0.0;
+    for (uint32_t jp = 0; jp < k; ++jp) {
+        const double* w = row + (size_t)jp * 9;
+        const double* bb = m.b + (size_t)(c0 + jp) * 3;
+        double term = (w[c] * bb[0] + w[c + 3] * bb[1]) + w[c + 6] * bb[2];
+        acc = (jp == 0) ? term : acc + term;
+    }
+    m.wb[t] = acc;
+}
+__global__ void form_rhs_batch_kernel(const RhsBatch rb) {
+    const RhsMember& m = rb.m[blockIdx.z];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m.n_stn * 3) return;
+    uint32_t s = t / 3;
+    int c = t - s * 3;
+    double acc = 0.0;
+    for (uint32_t k = m.ioff[s]; k < m.ioff[s + 1]; ++k) {
+        uint32_t e = m.inc[k];
+        double v = m.wb[(size_t)(e >> 1) * 3 + c];
+        acc += (e & 1u) ? v : -v;
+    }
+    m.rhs[t] = acc;
+}
+void launch_form_rhs_batch(const RhsBatch& rb, int nb, hipStream_t s) {
+    uint32_t max_vec = 0, max_stn = 0;
+    for (int b = 0; b < nb; ++b) {
+        max_vec = max_vec > rb.m[b].n_vec ? max_vec : rb.m[b].n_vec;
+        max_stn = max_stn > rb.m[b].n_stn ? max_stn : rb.m[b].n_stn;
+    }
+    if (max_vec) hipLaunchKernelGGL(cluster_wb_batch_kernel, dim3((max_vec * 3 + 255) / 256, 1, nb), dim3(256), 0, s, rb);
+    if (max_stn) hipLaunchKernelGGL(form_rhs_batch_kernel, dim3((max_stn * 3 + 255) / 256, 1, nb), dim3(256), 0, s, rb);
+}
+
 // wb(v) = sum_j' W(v, j') b(j') over the vectors j' of v's cluster (the AtVinv columns of the cluster times b)
 __global__ void cluster_wb_kernel(const double* __restrict__ wblk, const uint32_t* __restrict__ vec_wrow, const uint32_t* __restrict__ vec_c0,
                                   const uint32_t* __restrict__ vec_k, const double* __restrict__ b, double* __restrict__ wb, uint32_t n_vec) {

@@ -1900,6 +1900,22 @@ int dnagpu_form_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk) {
     return DNAGPU_OK;
 }
 
+int dnagpu_form_rhs_batched(dnagpu_ctx* ctx, int chain, int nb, const uint32_t* blks) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (nb < 1 || nb > BATCH_MAX || !blks) return fail(ctx, DNAGPU_EINVAL, "form_rhs_batched: bad arguments");
+    RhsBatch rb{};
+    for (int q = 0; q < nb; ++q) {
+        Block* b = find_block(ctx, blks[q]);
+        if (!b) return fail(ctx, DNAGPU_EINVAL, "form_rhs_batched: unknown block");
+        rb.m[q] = {b->Wblk, b->vec_wrow, b->vec_c0, b->vec_k, b->b[chain], b->wb[chain], b->inc_off, b->inc, b->rhs[chain], b->n_bl, b->n_stn};
+    }
+    gemm_profile_close(ctx->ws[chain]);
+    launch_form_rhs_batch(rb, nb, ctx->stream[chain]);
+    HIPCHK(hipGetLastError());
+    return DNAGPU_OK;
+}
+
 int dnagpu_solve_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* m) {
     CHK_CTX();
     CHK_CHAIN();
@@ -2831,7 +2847,7 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
         if (src) memcpy(blob.data() + off, src, bytes);
         return off;
     };
-    struct Offs { size_t est, con, map, keep, xe, rhs, pos[CB_SRC_MAX], inv[CB_SRC_MAX]; bool has_est, has_con; };
+    struct Offs { size_t est, con, map, keep, xe, rhs, pos[CB_SRC_MAX], inv[CB_SRC_MAX]; bool has_est, has_con, has_map; };
     std::vector<Offs> offs(n_steps);
     double factor_bytes = 0.0;
     std::vector<size_t> x_off(n_steps);
@@ -2839,8 +2855,16 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
         const uint32_t f = batch_first[q], l = batch_first[q + 1];
         if (l <= f || l - f > (uint32_t)BATCH_MAX) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a batch is empty or too large");
         uint32_t nip = 0, njp = 0, outnp_max = 0;
+        bool matrix_only = false;
         for (uint32_t s = f; s < l; ++s) {
             const dnagpu_chain_step& st = steps[s];
+            if (s == f) matrix_only = st.matrix_only != 0;
+            if ((st.matrix_only != 0) != matrix_only) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a batch mixes steps of two kinds");
+            if (matrix_only) {
+                if (!st.n_stn || st.n_src < 1 || st.n_src > CB_SRC_MAX || (st.n_con && (!st.con_stn || !st.con_w9))) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad step");
+                if (3 * st.n_stn > SMALL_STEP_MAX) return DNAGPU_ETOOLARGE;
+                continue;
+            }
             const uint32_t n = 3 * st.n_stn, nj = (uint32_t)(3 * st.n_keep);
             if (!st.n_stn || !st.n_keep || !st.keep || !st.out || st.n_src < 1 || st.n_src > CB_SRC_MAX || (st.n_con && (!st.con_stn || !st.con_w9)) ||
                 (st.est_blk == nullptr) != (st.est_idx == nullptr) || nj > st.out->n_max)
@@ -2852,6 +2876,11 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
             outnp_max = std::max(outnp_max, pad128(nj));
         }
         const uint32_t npp = nip + njp;
+        if (matrix_only) {
+            plan->shape[q] = {0, 0, 0, 0};
+            for (uint32_t s = f; s < l; ++s) x_off[s] = 0;
+            continue;
+        }
         if (npp > SMALL_STEP_MAX || sym_spine_blocks((int)(nip / 128)).size() > (size_t)SMALL_STEP_BLOCKS) return DNAGPU_ETOOLARGE;
         plan->shape[q] = {nip, njp, npp, outnp_max};
         for (uint32_t s = f; s < l; ++s) {
@@ -2868,8 +2897,10 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
             CbStep& d = table[s];
             Offs& o = offs[s];
             memset(&d, 0, sizeof(d));
-            const uint32_t n = 3 * st.n_stn, nj = (uint32_t)(3 * st.n_keep);
-            d.n_stn = st.n_stn; d.nj = nj; d.k_out = (uint32_t)st.n_keep; d.nip = sh.nip; d.njp = sh.njp; d.npp = sh.npp; d.n_src = (uint32_t)st.n_src;
+            const bool mo = st.matrix_only != 0;
+            const uint32_t n = 3 * st.n_stn, nj = mo ? n : (uint32_t)(3 * st.n_keep);
+            d.n_stn = st.n_stn; d.nj = nj; d.k_out = mo ? 0u : (uint32_t)st.n_keep; d.nip = sh.nip; d.njp = sh.njp; d.npp = sh.npp; d.n_src = (uint32_t)st.n_src;
+            o.has_map = !mo;
             d.nblocks = (int)blocks.size();
             for (size_t b = 0; b < blocks.size(); ++b) {
                 d.blk_o[b] = (uint32_t)blocks[b].first * 128;
@@ -2877,23 +2908,26 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
             }
             // the elimination's order: the stations that leave (system order), padding, the kept stations (list order), the right-hand side's row
             std::vector<uint8_t> kept(st.n_stn, 0);
-            for (size_t i = 0; i < st.n_keep; ++i) {
+            for (size_t i = 0; i < st.n_keep && !mo; ++i) {
                 if (st.keep[i] >= st.n_stn || kept[st.keep[i]]) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad list of kept stations");
                 kept[st.keep[i]] = 1;
             }
-            std::vector<int32_t> map(sh.npp, -1);
-            uint32_t pos = 0;
-            for (uint32_t t = 0; t < st.n_stn; ++t)
-                if (!kept[t])
-                    for (int c = 0; c < 3; ++c) map[pos++] = (int32_t)(3 * t + c);
-            for (size_t i = 0; i < st.n_keep; ++i)
-                for (int c = 0; c < 3; ++c) map[sh.nip + 3 * i + c] = (int32_t)(3 * st.keep[i] + c);
-            map[sh.nip + nj] = -2;
-            o.map = put(map.data(), map.size() * sizeof(int32_t));
-            o.keep = put(st.keep, st.n_keep * sizeof(uint32_t));
-            o.xe = put(nullptr, (size_t)n * sizeof(double));
-            o.rhs = put(nullptr, (size_t)n * sizeof(double));
-            o.has_est = st.est_blk != nullptr;
+            o.map = o.keep = o.xe = o.rhs = 0;
+            if (!mo) {
+                std::vector<int32_t> map(sh.npp, -1);
+                uint32_t pos = 0;
+                for (uint32_t t = 0; t < st.n_stn; ++t)
+                    if (!kept[t])
+                        for (int c = 0; c < 3; ++c) map[pos++] = (int32_t)(3 * t + c);
+                for (size_t i = 0; i < st.n_keep; ++i)
+                    for (int c = 0; c < 3; ++c) map[sh.nip + 3 * i + c] = (int32_t)(3 * st.keep[i] + c);
+                map[sh.nip + nj] = -2;
+                o.map = put(map.data(), map.size() * sizeof(int32_t));
+                o.keep = put(st.keep, st.n_keep * sizeof(uint32_t));
+                o.xe = put(nullptr, (size_t)n * sizeof(double));
+                o.rhs = put(nullptr, (size_t)n * sizeof(double));
+            }
+            o.has_est = !mo && st.est_blk != nullptr;
             if (o.has_est) {
                 std::vector<const double*> ptr(st.n_stn);
                 for (uint32_t t = 0; t < st.n_stn; ++t) {
@@ -2930,6 +2964,10 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
                 d.src[r].jest = sc.junction ? m->jest : nullptr;
                 junction_in = junction_in || sc.junction;
             }
+            if (mo) {
+                plan->out[s] = {nullptr, nj, 0};
+                continue;
+            }
             if ((junction_in || st.out_junction) && !o.has_est) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a junction needs the linearisation point");
             if (st.out_junction && !st.out->jrhs) HIPCHK(dnagpu::poison_malloc(&st.out->jrhs, (size_t)st.out->np_max * sizeof(double)));
             d.outS = st.out->F; d.outnp = pad128(nj);
@@ -2945,17 +2983,17 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
     for (size_t s = 0; s < n_steps; ++s) {
         CbStep& d = table[s];
         const Offs& o = offs[s];
-        d.map = (const int32_t*)(base + o.map);
-        d.keep = (const uint32_t*)(base + o.keep);
-        d.xe = (double*)(base + o.xe);
-        d.rhs = (double*)(base + o.rhs);
+        d.map = o.has_map ? (const int32_t*)(base + o.map) : nullptr;
+        d.keep = o.has_map ? (const uint32_t*)(base + o.keep) : nullptr;
+        d.xe = o.has_map ? (double*)(base + o.xe) : nullptr;
+        d.rhs = o.has_map ? (double*)(base + o.rhs) : nullptr;
         d.est = o.has_est ? (const double* const*)(base + o.est) : nullptr;
         d.con = o.has_con ? (const double*)(base + o.con) : nullptr;
         for (uint32_t r = 0; r < d.n_src; ++r) {
             d.src[r].pos = (const uint32_t*)(base + o.pos[r]);
             d.src[r].inv = (const int32_t*)(base + o.inv[r]);
         }
-        d.X = plan->factors + x_off[s];
+        d.X = o.has_map ? plan->factors + x_off[s] : nullptr;
         plan->X[s] = d.X;
     }
     HIPCHK(hipMemcpy(plan->blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -2970,6 +3008,7 @@ int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, s
     if (!plan || batch + 1 >= plan->batch_first.size()) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run: bad arguments");
     const uint32_t first = plan->batch_first[batch], nb = plan->batch_first[batch + 1] - first;
     const dnagpu_chain_plan::Shape sh = plan->shape[batch];
+    if (!sh.npp) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run: a batch of kept blocks (dnagpu_partial_complete_factor_planned takes those)");
     int rc = ensure_batch_ws(ctx, chain, (int)nb, sh.npp, batch_panel_cols(sh.nip, sh.njp));
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
@@ -2987,7 +3026,7 @@ int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, s
         mem.F[b] = F[b];
     }
     launch_cb_rhs(table, nb, st);
-    launch_cb_assemble(table, nb, mem, sh.npp, st);
+    launch_cb_assemble(table, nb, mem, sh.npp, 0, sh.npp, st);
     HIPCHK(hipGetLastError());
     if (nb > 1) {
         InvBatch& bt = ws.batch;
@@ -3021,12 +3060,49 @@ int dnagpu_chain_plan_run_rhs(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* pla
     CHK_CHAIN();
     if (!plan || batch_lo >= batch_hi || batch_hi >= plan->batch_first.size()) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run_rhs: bad arguments");
     for (size_t q = batch_lo; q < batch_hi; ++q)
-        if (!plan->factored[q]) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run_rhs: a step has no factor yet");
+        if (!plan->factored[q] || !plan->shape[q].npp) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run_rhs: a step has no factor yet");
     const uint32_t first = plan->batch_first[batch_lo], n = plan->batch_first[batch_hi] - first;
     gemm_profile_close(ctx->ws[chain]);
     launch_cb_rhs_steps((const CbStep*)plan->table + first, n, ctx->stream[chain]);
     HIPCHK(hipGetLastError());
     return DNAGPU_OK;
+}
+
+int dnagpu_partial_complete_factor_planned(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch, dnagpu_partial* const* pf, int* failed_member) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (failed_member) *failed_member = -1;
+    if (!plan || batch + 1 >= plan->batch_first.size() || plan->shape[batch].npp || !pf) return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_planned: bad arguments");
+    const uint32_t first = plan->batch_first[batch];
+    const int nb = (int)(plan->batch_first[batch + 1] - first);
+    for (int b = 0; b < nb; ++b) {
+        if (!pf[b] || !pf[b]->valid || !pf[b]->spine || pf[b]->nj != plan->out[first + b].nj || pf[b]->nip != pf[0]->nip || pf[b]->njp != pf[0]->njp)
+            return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_planned: bad arguments");
+        for (int q = 0; q < b; ++q)
+            if (pf[q] == pf[b]) return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_planned: a member listed twice");
+    }
+    const uint32_t nip = pf[0]->nip, njp = pf[0]->njp, npp = pf[0]->npp;
+    int rc = ensure_batch_ws(ctx, chain, nb, npp, batch_panel_cols(nip, njp));
+    if (rc) return rc;
+    InvWorkspace& ws = ctx->ws[chain];
+    hipStream_t st = ctx->stream[chain];
+    gemm_profile_close(ws);
+    CbMembers mem{};
+    for (int b = 0; b < nb; ++b) {
+        pf[b]->valid = false;
+        pf[b]->completed = false;
+        mem.F[b] = b ? ws.bX[b] : ws.X;      // scratch: the kept block's factorisation passes through it
+    }
+    launch_cb_assemble((const CbStep*)plan->table + first, (uint32_t)nb, mem, npp, nip, njp, st);
+    HIPCHK(hipGetLastError());
+    set_batch(ws, nb, npp, pf);
+    sym_spine_kept_async(ws, ws.X, pf[0]->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
+    ws.batch = InvBatch();
+    HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    rc = check_info_batch(ctx, chain, nb, failed_member);
+    for (int b = 0; b < nb; ++b) pf[b]->factored = rc == DNAGPU_OK;
+    return rc;
 }
 
 int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max) {
@@ -3091,8 +3167,46 @@ int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const u
     InvWorkspace& ws = ctx->ws[chain];
     hipStream_t st = ctx->stream[chain];
     gemm_profile_close(ws);
-    // every member's normals formed in its elimination order, in its own matrix (schur_eliminate, one member at a time)
+    // every member's normals formed in its elimination order, in its own matrix: one launch per kernel for all members (their lists of
+    // constraints must have device copies of their own -- the cache of stage_u32 / stage_f64 --, else one member at a time as before)
+    FormBatch fb{};
+    bool merged = true;
     for (int b = 0; b < nb; ++b) {
+        const uint32_t n = 3 * blk[b]->n_stn, nj = (uint32_t)(3 * k[b]);
+        int slot = -1;
+        const int32_t* map_dev = nullptr;
+        const uint32_t* spos_dev = nullptr;
+        rc = schur_order(ctx, blk[b], idx_keep[b], k[b], nip, nj, npp, &slot, &map_dev, &spos_dev);
+        if (rc) return rc;
+        dnagpu_partial* kp = keep[b];
+        kp->valid = false;
+        kp->completed = false;
+        kp->factored = false;
+        kp->n = n; kp->nj = nj; kp->nip = nip; kp->njp = njp; kp->npp = npp;
+        if (kp->store) kp->store->n = 0;
+        uint32_t* dstn = nullptr;
+        double* dw = nullptr;
+        if (n_con[b] && merged) {
+            rc = stage_u32(ctx, chain, con_stn[b], n_con[b], &dstn);
+            if (!rc) rc = stage_f64(ctx, chain, con_w9[b], n_con[b] * 9, &dw);
+            if (rc) return rc;
+            if (dstn == ctx->scr_u32[chain] || dw == ctx->scr_f64[chain]) merged = false;
+        }
+        Block* B = blk[b];
+        FormMember& m = fb.m[b];
+        m.F = b ? ws.bX[b] : ws.X;
+        m.map = map_dev; m.map_out = kp->map; m.spos = spos_dev;
+        m.prow = B->pair_row; m.pcol = B->pair_col; m.poff = B->pair_off; m.pent = B->pair_ent; m.wblk = B->Wblk;
+        m.con_stn = dstn; m.con_w9 = dw; m.rhs = B->rhs[chain];
+        m.n_pairs = B->n_pairs; m.n_gnss_blk = B->n_wblk; m.terr_shift = (uint32_t)chain * (B->n_tblk + B->n_dsblk); m.n_con = (uint32_t)n_con[b];
+        m.rhs_row = nip + nj;
+    }
+    if (merged) {
+        HbmTimed timed(ctx, chain, DNAGPU_HBM_FORM_ORDERED, 4.0 * (double)npp * npp * nb);
+        launch_form_ordered_batch(fb, nb, npp, npp, st);
+        HIPCHK(hipGetLastError());
+    }
+    for (int b = 0; b < nb && !merged; ++b) {
         const uint32_t n = 3 * blk[b]->n_stn, nj = (uint32_t)(3 * k[b]);
         int slot = -1;
         const int32_t* map_dev = nullptr;
@@ -3126,15 +3240,20 @@ int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const u
     set_batch(ws, nb, npp, keep);
     sym_spine_async(ws, ws.X, keep[0]->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
     ws.batch = InvBatch();
-    for (int b = 0; b < nb; ++b) {
-        dnagpu_partial* kp = keep[b];
-        const uint32_t nj = kp->nj;
-        const double* F = b ? ws.bX[b] : ws.X;
-        HIPCHK(hipMemset2DAsync(kp->X + nip + nj, (size_t)npp * sizeof(double), 0, sizeof(double), nip, st));     // the passenger row's panel entries
-        kp->valid = true;
-        red[b]->n = nj;
-        red[b]->np = pad128(nj);
-        launch_schur_extract(F + (size_t)nip * npp + nip, npp, red[b]->n, red[b]->np, red[b]->F, nullptr, red[b]->jest, st);
+    {
+        ExtractBatch eb{};
+        uint32_t npj_max = 0;
+        for (int b = 0; b < nb; ++b) {
+            dnagpu_partial* kp = keep[b];
+            const double* F = b ? ws.bX[b] : ws.X;
+            kp->valid = true;
+            red[b]->n = kp->nj;
+            red[b]->np = pad128(kp->nj);
+            eb.m[b] = {F + (size_t)nip * npp + nip, kp->X, red[b]->F, red[b]->jest, kp->nj, red[b]->np};
+            npj_max = std::max(npj_max, red[b]->np);
+        }
+        launch_extract_batch(eb, nb, nip, npp, npj_max, st);      // (+ the passenger row's panel entries cleared)
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

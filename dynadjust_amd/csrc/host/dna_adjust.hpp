@@ -353,6 +353,11 @@ private:
     bool lockstep_ok_ = false;
     bool lock_factored_ = false;                             // the plan's factors are those of this adjustment's normals
     int lock_runs_ = 0;
+    // ... and the kept blocks of the rigorous solves of a many-block network as data too (matrix_only steps: RigorousBatch)
+    dnagpu_chain_plan* rig_plan_ = nullptr;
+    std::map<std::vector<UINT32>, size_t> rig_batches_;      // a batch's members -> its batch of rig_plan_
+    bool rig_plan_denied_ = false;
+    void EnsureRigorousPlan(const std::vector<std::vector<UINT32>>& groups);
     void PrepareLockstepChains();
     void FreeLockstepChains();
     bool LockstepChains();                                   // false: not run (the chains go step by step)

@@ -1013,15 +1013,17 @@ void dna_adjust::CondenseBatch(int c, const std::vector<UINT32>& ks) {
         B.rig_direct = false;
         B.var_deferred = false;
         B.prefactored = false;
-        Check(dnagpu_form_rhs(ctx_, c, k), k, "Solve()");
         EnsurePartial(k);
         B.part_valid = false;
         if (B.part && B.part_in_rigvar) B.has_rigvar = false;
-        if (B.part)
+        if (B.part) {
             members.push_back(k);
-        else
-            CondenseBlock(c, k);       // (no room for its factor after all)
+        } else {
+            CondenseBlock(c, k);       // (no room for its factor after all; forms its right-hand side itself)
+        }
     }
+    // the members' right-hand sides: two merged launches
+    if (!members.empty()) Check(dnagpu_form_rhs_batched(ctx_, c, (int)members.size(), members.data()), members[0], "Solve()");
     if (members.size() < 2) {
         for (UINT32 k : members) CondenseBlock(c, k);
         return;
@@ -1146,19 +1148,102 @@ void dna_adjust::RigorousBatch(int c, const std::vector<UINT32>& ks_all) {
         }
         std::vector<dnagpu_partial*> part(nb);
         std::vector<const dnagpu_matrix*> kk(nb);
-        for (int b = 0; b < nb; ++b) {
-            const UINT32 k = ks[b];
-            const blockMeta_t& meta = v_blockMeta_[k];
-            const int kind = meta._blockLast ? 0 : meta._blockFirst ? 1 : 2;
-            PrepareKeptBlock(c, k, kind, kbatch_[c][b]);
-            part[b] = blocks_[k].part;
-            kk[b] = kbatch_[c][b];
-        }
         int failed = -1;
-        Check(dnagpu_partial_complete_factor_batched(ctx_, c, nb, part.data(), kk.data(), &failed), ks[failed >= 0 ? failed : 0], "Solve()");
+        const auto planned = rig_plan_ ? rig_batches_.find(ks) : rig_batches_.end();
+        if (planned != rig_batches_.end()) {
+            // (the members' kept blocks assembled by one launch from the plan's description of them: EnsureRigorousPlan)
+            for (int b = 0; b < nb; ++b) part[b] = blocks_[ks[b]].part;
+            Check(dnagpu_partial_complete_factor_planned(ctx_, c, rig_plan_, planned->second, part.data(), &failed), ks[failed >= 0 ? failed : 0], "Solve()");
+        } else {
+            for (int b = 0; b < nb; ++b) {
+                const UINT32 k = ks[b];
+                const blockMeta_t& meta = v_blockMeta_[k];
+                const int kind = meta._blockLast ? 0 : meta._blockFirst ? 1 : 2;
+                PrepareKeptBlock(c, k, kind, kbatch_[c][b]);
+                part[b] = blocks_[k].part;
+                kk[b] = kbatch_[c][b];
+            }
+            Check(dnagpu_partial_complete_factor_batched(ctx_, c, nb, part.data(), kk.data(), &failed), ks[failed >= 0 ? failed : 0], "Solve()");
+        }
         batched_members_ += (uint64_t)nb;
         for (UINT32 k : ks) blocks_[k].prefactored = true;
     }
+}
+
+// The kept blocks of the batched rigorous solves of a many-block network as data on the device (dnagpu_chain_plan, matrix_only steps): what
+// PrepareKeptBlock puts together call by call -- the reduced block, the junction weights carried in from both sides, the constraints -- is
+// then ONE launch per batch (a dnasegment-default cut: 666 blocks x 8 launches per iteration otherwise).  Made on first use for the groups at hand.
+void dna_adjust::EnsureRigorousPlan(const std::vector<std::vector<UINT32>>& groups) {
+    if (rig_plan_ || rig_plan_denied_ || blockCount_ < 32 || !condensed_ok_) return;
+    struct step_data_t {
+        std::vector<UINT32> pos0, con_stn;
+        std::vector<double> con_w9;
+    };
+    std::deque<step_data_t> data;
+    std::vector<dnagpu_chain_step> steps;
+    std::vector<UINT32> batch_first{0};
+    std::map<std::vector<UINT32>, size_t> batches;
+    for (const std::vector<UINT32>& g : groups) {
+        if (g.size() < 2) continue;
+        bool ok = true;
+        for (UINT32 k : g) {
+            const block_t& B = blocks_[k];
+            const blockMeta_t& meta = v_blockMeta_[k];
+            ok = ok && !B.keep.empty() && B.red && 3 * B.keep.size() <= 2048 && !meta._blockIsolated;
+            if (ok && !meta._blockFirst && !B.c_prev.empty()) ok = k > 0 && blocks_[k - 1].jfwd;
+            if (ok && !meta._blockLast && !B.c_next.empty()) ok = B.jrev != nullptr;
+        }
+        if (!ok) continue;
+        for (UINT32 k : g) {
+            const block_t& B = blocks_[k];
+            const blockMeta_t& meta = v_blockMeta_[k];
+            const int kind = meta._blockLast ? 0 : meta._blockFirst ? 1 : 2;
+            const bool rev_in = !meta._blockLast && !B.c_next.empty(), fwd_in = !meta._blockFirst && !B.c_prev.empty();
+            data.emplace_back();
+            step_data_t& D = data.back();
+            D.pos0.resize(B.keep.size());
+            std::iota(D.pos0.begin(), D.pos0.end(), 0u);
+            auto add_con = [&](const constraint_list& cl, double sign) {
+                D.con_stn.insert(D.con_stn.end(), cl.stn.begin(), cl.stn.end());
+                for (double w : cl.w9) D.con_w9.push_back(sign * w);
+            };
+            dnagpu_chain_step st{};
+            st.n_stn = (UINT32)B.keep.size();
+            st.matrix_only = 1;
+            st.src[0] = {B.red, 0, D.pos0.data(), D.pos0.size()};
+            st.n_src = 1;
+            // (the order of PrepareKeptBlock's additions)
+            if (kind == 0) {
+                add_con(B.ccon_fwd, +1.0);
+                if (fwd_in) st.src[st.n_src++] = {blocks_[k - 1].jfwd, 1, B.c_prev.data(), B.c_prev.size()};
+            } else {
+                if (rev_in) st.src[st.n_src++] = {B.jrev, 1, B.c_next.data(), B.c_next.size()};
+                add_con(B.ccon_rev, +1.0);
+                if (kind == 2) {
+                    if (fwd_in) st.src[st.n_src++] = {blocks_[k - 1].jfwd, 1, B.c_prev.data(), B.c_prev.size()};
+                    add_con(B.ccon_cmb, -1.0);
+                }
+            }
+            st.con_stn = D.con_stn.data();
+            st.con_w9 = D.con_w9.data();
+            st.n_con = D.con_stn.size();
+            steps.push_back(st);
+        }
+        batches[g] = batch_first.size() - 1;
+        batch_first.push_back((UINT32)steps.size());
+    }
+    if (steps.empty()) {
+        rig_plan_denied_ = true;
+        return;
+    }
+    const int rc = dnagpu_chain_plan_create(ctx_, steps.size(), steps.data(), batch_first.size() - 1, batch_first.data(), 1.0e18, &rig_plan_);
+    if (rc != DNAGPU_OK) {
+        rig_plan_ = nullptr;
+        rig_plan_denied_ = true;
+        if (rc != DNAGPU_ETOOLARGE && rc != DNAGPU_ENOMEM) Check(rc, 0, "Solve()");
+        return;
+    }
+    rig_batches_ = std::move(batches);
 }
 
 // a.defer_variances: X^T X for every block whose last rigorous solve left its inverse as a completed factor
@@ -1707,6 +1792,10 @@ void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks_in) {
 void dna_adjust::FreeLockstepChains() {
     if (lock_plan_ && ctx_) dnagpu_chain_plan_destroy(ctx_, lock_plan_);
     lock_plan_ = nullptr;
+    if (rig_plan_ && ctx_) dnagpu_chain_plan_destroy(ctx_, rig_plan_);
+    rig_plan_ = nullptr;
+    rig_batches_.clear();
+    rig_plan_denied_ = false;
     for (dnagpu_matrix* m : lock_mats_)
         if (m && ctx_) dnagpu_matrix_destroy(ctx_, m);
     lock_mats_.clear();
@@ -2173,7 +2262,11 @@ void dna_adjust::RigorousBlocks(const std::vector<UINT32>& blocks_in) {
     isCombining_ = true;
     std::vector<UINT32> blocks = blocks_in;
     SmallBatchSolve(blocks);
-    if (BatchCap() >= 2) ForGroups(BatchGroups(blocks, 1), [&](int c, const std::vector<UINT32>& ks) { RigorousBatch(c, ks); });
+    if (BatchCap() >= 2) {
+        std::vector<std::vector<UINT32>> groups = BatchGroups(blocks, 1);
+        EnsureRigorousPlan(groups);
+        ForGroups(std::move(groups), [&](int c, const std::vector<UINT32>& ks) { RigorousBatch(c, ks); });
+    }
     if (!IsCancelled()) SmallBatchFirstSolve(blocks);
     if (!IsCancelled()) ForBlocks(blocks, [&](int c, UINT32 k) { RigorousBlock(c, k); });
     isCombining_ = false;

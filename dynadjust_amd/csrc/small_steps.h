@@ -115,7 +115,8 @@ struct CbMembers {
 // members = table[0 .. nb): the right-hand sides and linearisation points (one workgroup per member) ...
 void launch_cb_rhs(const CbStep* table, uint32_t nb, hipStream_t s);
 // ... the systems, in elimination order, into the members' matrices (all members share the padded orders npp = nip + njp) ...
-void launch_cb_assemble(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t npp, hipStream_t s);
+// (off / ext: the diagonal block of the members' matrices the systems go to -- 0 / npp for a chain step)
+void launch_cb_assemble(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t npp, uint32_t off, uint32_t ext, hipStream_t s);
 // ... and, after the elimination, complement / right-hand side / estimates out, the passenger row of the kept factor cleared
 void launch_cb_post(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t nip, uint32_t npp, uint32_t outnp_max, hipStream_t s);
 // the same steps with their factors kept (a.reuse_factors, iterations >= 2): right-hand sides only, any number of independent steps, one launch

@@ -408,15 +408,18 @@ __global__ __launch_bounds__(NT) void cb_rhs_kernel(const CbStep* __restrict__ t
 // element (i, j), i >= j, is the sum over the sources that hold both unknowns, plus the constraint block of the station; the row map = -2
 // carries the right-hand side; identity on the padding's diagonal.  One workgroup per quarter of a 128 x 128 tile of the lower tile triangle.
 // The sources hold BOTH triangles (schur_extract_kernel / cb_post_kernel write them so).
-__global__ __launch_bounds__(256) void cb_assemble_kernel(const CbStep* __restrict__ table, const CbMembers mem, uint32_t npp) {
+// (off: the block of the member's matrix -- rows and columns off .. off + ext - 1 -- the system goes to: 0 for a chain step; the trailing block of
+//  a kept factor's matrix for a step that eliminates nothing, d.map = nullptr: the system in its own order, identity beyond it)
+__global__ __launch_bounds__(256) void cb_assemble_kernel(const CbStep* __restrict__ table, const CbMembers mem, uint32_t npp, uint32_t off) {
     const uint32_t b = blockIdx.z >> 2, qz = blockIdx.z & 3;
     const CbStep& d = table[b];
-    double* __restrict__ dst = mem.F[b];
+    double* __restrict__ dst = mem.F[b] + (size_t)off * npp + off;
+    const uint32_t n3 = 3 * d.n_stn;
     const uint32_t tr = blockIdx.x, tc = blockIdx.y;
     if (tc > tr) return;
     const uint32_t il = threadIdx.x & 127;
     const uint32_t i = tr * 128 + il;
-    const int32_t mi = d.map[i];
+    const int32_t mi = d.map ? d.map[i] : (i < n3 ? (int32_t)i : -1);
     const uint32_t su = mi >= 0 ? (uint32_t)mi / 3 : 0, eu = mi >= 0 ? (uint32_t)mi % 3 : 0;
     const uint32_t nsrc = d.n_src;
     int32_t ai[CB_SRC_MAX];
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void cb_assemble_kernel(const CbStep* __restri
     const uint32_t j0 = tc * 128 + qz * 32 + (threadIdx.x >> 7);
     int32_t mj[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) mj[t] = d.map[j0 + 2 * t];
+    for (int t = 0; t < 16; ++t) mj[t] = d.map ? d.map[j0 + 2 * t] : (j0 + 2 * t < n3 ? (int32_t)(j0 + 2 * t) : -1);
     double v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = 0.0;
@@ -516,8 +519,8 @@ __global__ __launch_bounds__(NT) void cb_rhs_steps_kernel(const CbStep* __restri
 void launch_cb_rhs(const CbStep* table, uint32_t nb, hipStream_t s) {
     if (nb) hipLaunchKernelGGL(cb_rhs_kernel, dim3(nb), dim3(NT), 0, s, table);
 }
-void launch_cb_assemble(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t npp, hipStream_t s) {
-    if (nb) hipLaunchKernelGGL(cb_assemble_kernel, dim3(npp / 128, npp / 128, 4 * nb), dim3(256), 0, s, table, m, npp);
+void launch_cb_assemble(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t npp, uint32_t off, uint32_t ext, hipStream_t s) {
+    if (nb) hipLaunchKernelGGL(cb_assemble_kernel, dim3(ext / 128, ext / 128, 4 * nb), dim3(256), 0, s, table, m, npp, off);
 }
 void launch_cb_post(const CbStep* table, uint32_t nb, const CbMembers& m, uint32_t nip, uint32_t npp, uint32_t outnp_max, hipStream_t s) {
     const uint32_t rows = outnp_max > nip ? outnp_max : nip;

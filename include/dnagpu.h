@@ -288,6 +288,8 @@ int dnagpu_form_normals(dnagpu_ctx* ctx, int chain, uint32_t blk, dnagpu_matrix*
 int dnagpu_add_diag3x3(dnagpu_ctx* ctx, int chain, dnagpu_matrix* m, const uint32_t* stn, const double* w9, size_t k, int sign);
 /* rhs = sum_i A_i^T W_i b_i (real measurements) */
 int dnagpu_form_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk);
+/* ... of up to DNAGPU_BATCH_MAX blocks as two merged launches (the members of a batched condensing step) */
+int dnagpu_form_rhs_batched(dnagpu_ctx* ctx, int chain, int nb, const uint32_t* blks);
 /* corrections = m * rhs  (m holds N^-1) */
 int dnagpu_solve_corrections(dnagpu_ctx* ctx, int chain, uint32_t blk, const dnagpu_matrix* m);
 /* estimated += corrections; returns the correction of largest magnitude (signed) and its row */
@@ -407,12 +409,19 @@ typedef struct dnagpu_chain_step {
     const uint32_t* keep; size_t n_keep;              /* the stations carried on, in the order of out's unknowns */
     dnagpu_matrix* out;
     int out_junction;                                 /* 1: information-form junction (estimates of the kept stations attached); 0: reduced system */
+    int matrix_only;                                  /* 1: nothing is eliminated and nothing carried on (keep, out, est_*: unused): the assembled MATRIX is the kept
+                                                         block of a block's rigorous solve, taken by dnagpu_partial_complete_factor_planned (a batch holds
+                                                         steps of one kind only) */
 } dnagpu_chain_step;
 int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain_step* steps, size_t n_batches, const uint32_t* batch_first,
                              double max_bytes, dnagpu_chain_plan** out);
 int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch);
 int dnagpu_chain_plan_run_rhs(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch_lo, size_t batch_hi);
 void dnagpu_chain_plan_destroy(dnagpu_ctx* ctx, dnagpu_chain_plan* plan);
+/* dnagpu_partial_complete_factor_batched with the members' kept blocks described by the matrix_only steps of batch `batch` (step b <-> pf[b]):
+ * the kept blocks -- reduced block + carried junction weights + constraints, what dna_adjust::PrepareKeptBlock puts together call by call --
+ * are assembled by ONE launch straight into the members' matrices, then factored and inverted in lock step. */
+int dnagpu_partial_complete_factor_planned(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch, dnagpu_partial* const* pf, int* failed_member);
 /* The same elimination as a stand-alone step: red (order 3k) <- Schur complement of all other unknowns of m onto the k
  * listed stations (list order), red's attached vector <- the reduced right-hand side.  With the stations a block shares
  * with its neighbours as the list, this condenses the block to its junction stations ONCE per iteration, independently of
