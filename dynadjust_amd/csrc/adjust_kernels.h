@@ -74,6 +74,14 @@ struct RhsMember {
 };
 struct RhsBatch { RhsMember m[16]; };
 void launch_form_rhs_batch(const RhsBatch& rb, int nb, hipStream_t s);
+struct UnpermuteMember {
+    const double* F;
+    const int32_t* map;
+    double* inv;
+    uint32_t n, np;
+};
+struct UnpermuteBatch { UnpermuteMember m[16]; };
+void launch_unpermute_batch(const UnpermuteBatch& ub, int nb, uint32_t npp, hipStream_t s);
 struct OscRow {
     const double* corr;
     const uint32_t* gidx;

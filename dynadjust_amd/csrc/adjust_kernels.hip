@@ -1069,6 +1069,42 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const double* __restrict
         if (mj[t] >= 0) inv[(size_t)mj[t] * np + mi] = v[t];
 }
 
+// the members of a batch (dnagpu_partial_finish_batched): identity padding of every member's inverse (init_padding_kernel) and its un-permutation,
+// two launches for all members
+__global__ void init_padding_batch_kernel(const UnpermuteBatch ub) {
+    const UnpermuteMember& m = ub.m[blockIdx.y];
+    const uint32_t j = blockIdx.x;
+    if (j >= m.np) return;
+    for (uint32_t i = (j >= m.n ? 0 : m.n) + threadIdx.x; i < m.np; i += blockDim.x) m.inv[(size_t)j * m.np + i] = (i == j) ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(256) void unpermute_batch_kernel(const UnpermuteBatch ub, uint32_t ldf) {
+    const UnpermuteMember& m = ub.m[blockIdx.z >> 2];
+    const uint32_t i = blockIdx.x * 128 + (threadIdx.x & 127);
+    const int32_t mi = m.map[i];
+    if (mi < 0) return;
+    const uint32_t j0 = blockIdx.y * 128 + (blockIdx.z & 3) * 32 + (threadIdx.x >> 7);
+    double v[16];
+    int32_t mj[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        mj[t] = m.map[j0 + 2 * t];
+        v[t] = m.F[(size_t)(j0 + 2 * t) * ldf + i];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        if (mj[t] >= 0) m.inv[(size_t)mj[t] * m.np + mi] = v[t];
+}
+void launch_unpermute_batch(const UnpermuteBatch& ub, int nb, uint32_t npp, hipStream_t s) {
+    uint32_t np_max = 0;
+    bool pad = false;
+    for (int b = 0; b < nb; ++b) {
+        np_max = np_max > ub.m[b].np ? np_max : ub.m[b].np;
+        pad = pad || ub.m[b].np > ub.m[b].n;
+    }
+    if (pad) hipLaunchKernelGGL(init_padding_batch_kernel, dim3(np_max, nb), dim3(128), 0, s, ub);
+    hipLaunchKernelGGL(unpermute_batch_kernel, dim3(npp / 128, npp / 128, 4 * nb), dim3(256), 0, s, ub, npp);
+}
+
 void launch_partial_set_trailing(double* T, uint32_t ldt, uint32_t njp, const double* kk, uint32_t npk, uint32_t nj, hipStream_t s) {
     hipLaunchKernelGGL(partial_set_trailing_kernel, dim3((njp + 255) / 256, njp), dim3(256), 0, s, T, ldt, njp, kk, npk, nj);
 }

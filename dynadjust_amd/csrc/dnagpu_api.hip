@@ -3316,15 +3316,19 @@ int dnagpu_partial_finish_batched(dnagpu_ctx* ctx, int chain, int nb, dnagpu_par
     set_batch(ws, nb, npp, pf);
     sym_spine_finish_async(ws, ws.X, pf[0]->X, (int)npp, (int)(nip / 128), (int)(njp / 128));
     ws.batch = InvBatch();
-    for (int b = 0; b < nb; ++b) {
-        const double* F = b ? ws.bX[b] : ws.X;
-        inv[b]->n = pf[b]->n;
-        inv[b]->np = pad128(pf[b]->n);
-        launch_init_padding(inv[b]->F, inv[b]->n, inv[b]->np, st);
-        {
-            HbmTimed t(ctx, chain, DNAGPU_HBM_UNPERMUTE, 16.0 * (double)inv[b]->np * inv[b]->np);
-            launch_unpermute(F, npp, npp, pf[b]->map, inv[b]->F, inv[b]->np, st);
+    {
+        // (padding and un-permutation of all members: two launches)
+        UnpermuteBatch ub{};
+        double bytes = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            inv[b]->n = pf[b]->n;
+            inv[b]->np = pad128(pf[b]->n);
+            ub.m[b] = {b ? ws.bX[b] : ws.X, pf[b]->map, inv[b]->F, inv[b]->n, inv[b]->np};
+            bytes += 16.0 * (double)inv[b]->np * inv[b]->np;
         }
+        HbmTimed t(ctx, chain, DNAGPU_HBM_UNPERMUTE, bytes);
+        launch_unpermute_batch(ub, nb, npp, st);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemsetAsync(ws.info, 0x7f, BATCH_MAX * sizeof(int), st));
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
