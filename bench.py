@@ -907,7 +907,7 @@ def main():
                                multi_thread=phased and bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))), device=local_rank,
                                reuse_inverses=phased and args.reuse_inverses, schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors,
                                defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
-                               stage=phased and args.stage, reuse_factors=not args.no_reuse_factors)
+                               stage=phased and args.stage, reuse_factors=not args.no_reuse_factors, chain_runs=args.chain_runs)
     t_p = time.perf_counter()
     a.PrepareAdjustment(p)
     prepare_s = time.perf_counter() - t_p

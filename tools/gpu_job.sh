@@ -1,10 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out/j8
-timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_exact.py -q -m gpu -x 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_gpu_adjust.py -q -m gpu -x -k "lock_step or many_small or deserialise or statistics or reuse" 2>&1 | tail -3
-for w in dnasegment150 smallblocks; do
-  DNAGPU_PHASE_TIMES=1 timeout 600 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain > gpurun_out/j8/$w.json 2> gpurun_out/j8/$w.err
-  cut -c1-250 gpurun_out/j8/$w.json; grep "phase" gpurun_out/j8/$w.err | tail -24 | grep "variance\|AdjustNetwork" | tail -2
-done
-timeout 600 python -m pytest tests/test_gpu_fullsize.py -q -m gpu -x -k "record" 2>&1 | tail -3
+mkdir -p gpurun_out/j9
+B="timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain"
+for s in 0.12 0.16 0.25; do echo "split $s: $(DNAGPU_XSPLIT=$s $B 2>/dev/null | cut -c100-240)"; done
+for t in 256 1024; do echo "small_tiles $t: $(DNAGPU_BENCH_SMALL_TILES=$t $B 2>/dev/null | cut -c100-240)"; done
+for r in 8 16 24 48 64; do echo "chain_runs $r: $(timeout 600 python bench.py --workload dnasegment150 --chain-runs $r --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c100-240)"; done
+for r in 4 8 24; do echo "smallblocks chain_runs $r: $(timeout 600 python bench.py --workload smallblocks --chain-runs $r --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c100-240)"; done
