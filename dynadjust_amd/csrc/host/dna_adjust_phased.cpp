@@ -1174,7 +1174,7 @@ void dna_adjust::RigorousBatch(int c, const std::vector<UINT32>& ks_all) {
 // PrepareKeptBlock puts together call by call -- the reduced block, the junction weights carried in from both sides, the constraints -- is
 // then ONE launch per batch (a dnasegment-default cut: 666 blocks x 8 launches per iteration otherwise).  Made on first use for the groups at hand.
 void dna_adjust::EnsureRigorousPlan(const std::vector<std::vector<UINT32>>& groups) {
-    if (rig_plan_ || rig_plan_denied_ || blockCount_ < 32 || !condensed_ok_) return;
+    if (!ctx_ || rig_plan_ || rig_plan_denied_ || blockCount_ < 32 || !condensed_ok_) return;
     struct step_data_t {
         std::vector<UINT32> pos0, con_stn;
         std::vector<double> con_w9;
@@ -1809,7 +1809,7 @@ void dna_adjust::PrepareLockstepChains() {
     FreeLockstepChains();
     const UINT32 B = blockCount_;
     const int want = projectSettings_.a.chain_runs;
-    if (want == 0 || want == 1 || !condensed_ok_ || !CondensedSchedule() || DistWorld() > 1 || ReuseRequested() || !dnagpu_info_carry(ctx_)) return;
+    if (!ctx_ || want == 0 || want == 1 || !condensed_ok_ || !CondensedSchedule() || DistWorld() > 1 || ReuseRequested() || !dnagpu_info_carry(ctx_)) return;
     int W = want > 1 ? want : (B >= 512 ? 32 : B >= 64 ? 16 : 1);
     W = std::min<int>(W, (int)(B / 3));
     if (W < 2) return;

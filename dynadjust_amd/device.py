@@ -44,6 +44,17 @@ def unpack_lower(ap, n, symmetric=True):
     return full
 
 
+class ChainSource(C.Structure):
+    _fields_ = [("m", C.c_void_p), ("junction", C.c_int), ("pos", C.POINTER(C.c_uint32)), ("k", C.c_size_t)]
+
+
+class ChainStep(C.Structure):
+    """dnagpu_chain_step (include/dnagpu.h)"""
+    _fields_ = [("n_stn", C.c_uint32), ("est_blk", C.POINTER(C.c_uint32)), ("est_idx", C.POINTER(C.c_uint32)), ("n_src", C.c_int),
+                ("src", ChainSource * 3), ("con_stn", C.POINTER(C.c_uint32)), ("con_w9", C.POINTER(C.c_double)), ("n_con", C.c_size_t),
+                ("keep", C.POINTER(C.c_uint32)), ("n_keep", C.c_size_t), ("out", C.c_void_p), ("out_junction", C.c_int), ("matrix_only", C.c_int)]
+
+
 class Matrix:
     def __init__(self, ctx, n_max):
         self.ctx = ctx
@@ -212,6 +223,74 @@ class DeviceContext:
         out = np.empty(3 * n_stations, dtype=np.float64)
         self._chk(self.lib.dnagpu_block_get_rhs(self.h, chain, blk, out.ctypes.data_as(c_f64p)))
         return out
+
+    # ---- chain plans (dnagpu_chain_plan_*): steps = dicts with n_stn, est (block, idx) or None, sources [(Matrix, junction, pos)],
+    #      con (stn, w9) or None, keep, out (Matrix), out_junction ----
+    def chain_plan_create(self, steps, batch_first, max_bytes=1e12):
+        arr = (ChainStep * len(steps))()
+        self._plan_keep = keep_alive = []
+        for q, st in enumerate(steps):
+            d = arr[q]
+            d.n_stn = int(st["n_stn"])
+            if st.get("est") is not None:
+                eb, pb = _u32(st["est"][0])
+                ei, pi = _u32(st["est"][1])
+                keep_alive += [eb, ei]
+                d.est_blk, d.est_idx = pb, pi
+            d.n_src = len(st["sources"])
+            for r, (m, junction, pos) in enumerate(st["sources"]):
+                ps, pp = _u32(pos)
+                keep_alive.append(ps)
+                d.src[r].m, d.src[r].junction, d.src[r].pos, d.src[r].k = m.h, int(junction), pp, ps.size
+            if st.get("con") is not None:
+                cs, pcs = _u32(st["con"][0])
+                cw, pcw = _f64(st["con"][1])
+                keep_alive += [cs, cw]
+                d.con_stn, d.con_w9, d.n_con = pcs, pcw, cs.size
+            kp, pk = _u32(st["keep"])
+            keep_alive.append(kp)
+            d.keep, d.n_keep = pk, kp.size
+            d.out, d.out_junction = st["out"].h, int(st["out_junction"])
+        bf, pbf = _u32(batch_first)
+        h = C.c_void_p()
+        self._chk(self.lib.dnagpu_chain_plan_create(self.h, len(steps), C.cast(arr, C.c_void_p), bf.size - 1, pbf, float(max_bytes), C.byref(h)))
+        return h
+
+    def chain_plan_run(self, plan, batch, chain=0):
+        self._chk(self.lib.dnagpu_chain_plan_run(self.h, chain, plan, int(batch)))
+
+    def chain_plan_run_rhs(self, plan, lo, hi, chain=0):
+        self._chk(self.lib.dnagpu_chain_plan_run_rhs(self.h, chain, plan, int(lo), int(hi)))
+
+    def chain_plan_destroy(self, plan):
+        self.lib.dnagpu_chain_plan_destroy(self.h, plan)
+
+    def junction_payload_put(self, m, F, est, rhs=None, chain=0):
+        """m <- full matrix F (both triangles), attached vector est, information form when rhs is given (dnagpu_junction_import)"""
+        n = F.shape[0]
+        npad = ((n + 127) // 128) * 128 if n else 128
+        buf = np.zeros(npad * npad + 2 * npad + 1)
+        Fp = np.eye(npad)
+        Fp[:n, :n] = F
+        buf[:npad * npad] = Fp.T.ravel()
+        buf[npad * npad:npad * npad + n] = est
+        if rhs is not None:
+            buf[npad * npad + npad:npad * npad + npad + n] = rhs
+            buf[-1] = 1.0
+        b, pb = _f64(buf)
+        self._chk(self.lib.dnagpu_junction_import(self.h, chain, m.h, C.cast(pb, C.c_void_p), n))
+        m.n = n
+
+    def junction_payload_get(self, m, n, chain=0):
+        """(F, attached vector, rhs or None) of a matrix (dnagpu_junction_export)"""
+        npad = ((n + 127) // 128) * 128 if n else 128
+        buf = np.zeros(npad * npad + 2 * npad + 1)
+        b, pb = _f64(buf)
+        self._chk(self.lib.dnagpu_junction_export(self.h, chain, m.h, C.cast(pb, C.c_void_p), b.size))
+        F = b[:npad * npad].reshape(npad, npad).T[:n, :n].copy()
+        est = b[npad * npad:npad * npad + n].copy()
+        rhs = b[npad * npad + npad:npad * npad + npad + n].copy() if b[-1] == 1.0 else None
+        return F, est, rhs
 
     def junction_gather(self, blk_from, src, idx_from, jm, chain=0):
         ix, p = _u32(idx_from)

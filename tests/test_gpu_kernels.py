@@ -580,3 +580,81 @@ def test_reduce_keep_and_complete(gpu_ctx, built, orc, tmp_path, rows, cols, pic
     for q in (m, red0, red1, kk, inv):
         q.close()
     gpu_ctx.block_destroy(0)
+
+
+def test_chain_plan_steps_against_numpy(gpu_ctx):
+    """dnagpu_chain_plan_*: chain steps as data.  A step adds a reduced system (all stations) and an information-form junction (some
+    stations, linearised at other estimates) into one system, adds constraint blocks and eliminates all stations but the kept ones: complement,
+    reduced right-hand side and the kept stations' estimates against dense numpy -- one step alone, three steps of unequal size as ONE
+    batch (the largest member's padded shape), a step that eliminates nothing, then right-hand sides only through the kept factors."""
+    rng = np.random.default_rng(7)
+
+    def spd(n):
+        a = rng.standard_normal((n, n))
+        return a @ a.T + n * np.eye(n)
+
+    n_blk = 40
+    xyz = rng.standard_normal(3 * n_blk) * 1e3
+    gpu_ctx.block_create(0, n_blk, 0)
+    gpu_ctx.block_set_stations(0, xyz)
+    cases, steps, keep_mats = [], [], []
+    for n_stn, k_j, n_keep, n_con in ((30, 8, 10, 2), (30, 8, 10, 2), (22, 5, 7, 0), (30, 30, 12, 3), (9, 4, 9, 1)):
+        est_idx = rng.permutation(n_blk)[:n_stn].astype(np.uint32)
+        A, a_rhs = spd(3 * n_stn), rng.standard_normal(3 * n_stn)
+        pos = rng.permutation(n_stn)[:k_j].astype(np.uint32)
+        S, s_rhs = spd(3 * k_j), rng.standard_normal(3 * k_j)
+        x = xyz.reshape(-1, 3)[est_idx].ravel()
+        jest = x.reshape(-1, 3)[pos].ravel() + rng.standard_normal(3 * k_j) * 1e-3
+        con_stn = rng.permutation(n_stn)[:n_con].astype(np.uint32)
+        con_w9 = np.concatenate([spd(3).T.ravel() for _ in range(n_con)]) if n_con else np.zeros(0)
+        keep = rng.permutation(n_stn)[:n_keep].astype(np.uint32)
+        mA, mJ, out = gpu_ctx.matrix(3 * n_stn), gpu_ctx.matrix(3 * k_j), gpu_ctx.matrix(3 * n_keep)
+        gpu_ctx.junction_payload_put(mA, A, a_rhs)
+        gpu_ctx.junction_payload_put(mJ, S, jest, s_rhs)
+        keep_mats += [mA, mJ, out]
+        steps.append({"n_stn": n_stn, "est": (np.zeros(n_stn, dtype=np.uint32), est_idx), "sources": [(mA, 0, np.arange(n_stn, dtype=np.uint32)), (mJ, 1, pos)],
+                      "con": (con_stn, con_w9) if n_con else None, "keep": keep, "out": out, "out_junction": 1})
+        cases.append((n_stn, A, a_rhs, pos, S, s_rhs, x, jest, con_stn, con_w9, keep, mA, out))
+
+    def expected(c, a_rhs=None):
+        n_stn, A, a0, pos, S, s_rhs, x, jest, con_stn, con_w9, keep, mA, out = c
+        a_rhs = a0 if a_rhs is None else a_rhs
+        K, r = A.copy(), a_rhs.copy()
+        rows = (3 * pos[:, None] + np.arange(3)).ravel()
+        K[np.ix_(rows, rows)] += S
+        r[rows] += s_rhs + S @ (jest - x[rows])
+        for q, s in enumerate(con_stn):
+            K[3 * s:3 * s + 3, 3 * s:3 * s + 3] += con_w9[9 * q:9 * q + 9].reshape(3, 3).T
+        kr = (3 * keep[:, None] + np.arange(3)).ravel()
+        ir = np.setdiff1d(np.arange(3 * n_stn), kr)
+        if ir.size == 0:
+            return K[np.ix_(kr, kr)], r[kr], x[kr]
+        Kii = np.linalg.inv(K[np.ix_(ir, ir)])
+        return K[np.ix_(kr, kr)] - K[np.ix_(kr, ir)] @ Kii @ K[np.ix_(ir, kr)], r[kr] - K[np.ix_(kr, ir)] @ Kii @ r[ir], x[kr]
+
+    plan = gpu_ctx.chain_plan_create(steps, [0, 1, 4, 5])
+    for batch in range(3):
+        gpu_ctx.chain_plan_run(plan, batch)
+    for c in cases:
+        S_e, r_e, x_e = expected(c)
+        F, est, rhs = gpu_ctx.junction_payload_get(c[-1], 3 * len(c[10]))
+        assert rhs is not None and np.array_equal(est, x_e)
+        assert np.abs(F - S_e).max() <= 1e-11 * np.abs(S_e).max() and np.abs(F - F.T).max() == 0.0
+        assert np.abs(rhs - r_e).max() <= 1e-10 * max(1.0, np.abs(r_e).max())
+    # new right-hand sides of the reduced systems: through the kept factors, all five steps in one launch
+    new = []
+    for c in cases:
+        a2 = rng.standard_normal(3 * c[0])
+        gpu_ctx.junction_payload_put(c[11], c[1], a2)
+        new.append(a2)
+    gpu_ctx.chain_plan_run_rhs(plan, 0, 3)
+    gpu_ctx.sync()
+    for c, a2 in zip(cases, new):
+        S_e, r_e, x_e = expected(c, a2)
+        F, est, rhs = gpu_ctx.junction_payload_get(c[-1], 3 * len(c[10]))
+        assert np.abs(F - S_e).max() <= 1e-11 * np.abs(S_e).max()
+        assert np.abs(rhs - r_e).max() <= 1e-10 * max(1.0, np.abs(r_e).max())
+    gpu_ctx.chain_plan_destroy(plan)
+    for m in keep_mats:
+        m.close()
+    gpu_ctx.block_destroy(0)
