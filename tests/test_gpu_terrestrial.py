@@ -84,6 +84,26 @@ def test_terrestrial_parity_with_oracle(built, orc, tmp_path, rows, cols, blocks
     o.close()
 
 
+@pytest.mark.parametrize("mt,runs,types", [(True, 3, "SVZL"), (False, 4, "SLVD")])
+def test_terrestrial_chains_in_lock_step(built, orc, tmp_path, mt, runs, types):
+    """a.chain_runs on a network with terrestrial measurements: the normals move with the estimates, so every iteration factors again --
+    the lock-step chains (dna_adjust::LockstepChains) run in their eliminating form in EVERY iteration (no kept factors, a.reuse_factors
+    does not apply).  Twelve strips; against the oracle."""
+    b, (bst, bms) = T.build_mixed_network(str(tmp_path / "t"), 26, 4, 12, seed=31, types=types)
+    net, o, ost = _oracle_run(orc, str(tmp_path / "t"), True)
+    a, st = _device_run(str(tmp_path), "t", True, multi_thread=mt, chain_runs=runs)
+    assert st == 0 and a.CurrentIteration() >= 2 and a.blockCount() == 12
+    assert a.chain_runs() == runs and a.chain_step_reuses() == 0
+    _compare(a, st, o, ost, tol_x=1e-8, tol_v=1e-8)
+    r, st2 = _device_run(str(tmp_path), "t", True, multi_thread=mt, chain_runs=0)
+    assert r.chain_runs() == 0 and st2 == st and r.CurrentIteration() == a.CurrentIteration()
+    for k in range(12):
+        assert np.abs(r.block_estimates(k) - a.block_estimates(k)).max() < 1e-8
+    a.close()
+    r.close()
+    o.close()
+
+
 @pytest.mark.parametrize("phased,blocks", [(False, 1), (True, 3)])
 def test_direction_sets_and_coordinates_from_text_files(built, orc, tmp_path, phased, blocks):
     """the measurement types no reference sample contains -- direction sets with ignored directions, I / J / P / Q -- from DNA text through
