@@ -1810,18 +1810,54 @@ void dna_adjust::PrepareLockstepChains() {
     const UINT32 B = blockCount_;
     const int want = projectSettings_.a.chain_runs;
     if (!ctx_ || want == 0 || want == 1 || !condensed_ok_ || !CondensedSchedule() || DistWorld() > 1 || ReuseRequested() || !dnagpu_info_carry(ctx_)) return;
-    int W = want > 1 ? want : (B >= 512 ? 32 : B >= 64 ? 16 : 1);
-    W = std::min<int>(W, (int)(B / 3));
-    if (W < 2) return;
-    // one contiguous network of small condensed systems, every block between two others carrying something both ways
-    if (!v_blockMeta_[0]._blockFirst || !v_blockMeta_[B - 1]._blockLast) return;
-    for (UINT32 k = 0; k < B; ++k) {
+    // the contiguous networks of the project (dnaadjust.cpp:10449-10474: a block whose junction list is empty ends one; an isolated block
+    // is a network of its own without a chain step): their chains are independent of each other and advance together like the runs of one
+    struct net_t { UINT32 s, e; int runs; };
+    std::vector<net_t> nets;
+    std::vector<UINT32> net_s(B, 0), net_e(B, 0);
+    UINT32 chained = 0;
+    for (UINT32 k = 0; k < B;) {
         const blockMeta_t& m = v_blockMeta_[k];
-        const block_t& Bk = blocks_[k];
-        if (m._blockIsolated || (m._blockFirst && k != 0) || (m._blockLast && k != B - 1)) return;
-        if (Bk.keep.empty() || !Bk.red || 3 * Bk.keep.size() > 1024) return;
-        if ((k > 0 && Bk.c_prev.empty()) || (k + 1 < B && Bk.c_next.empty())) return;
-        if ((k + 1 < B && !Bk.jfwd) || (k > 0 && !blocks_[k - 1].jrev)) return;
+        if (m._blockIsolated) {
+            ++k;
+            continue;
+        }
+        if (!m._blockFirst) return;
+        UINT32 e = k;
+        while (!v_blockMeta_[e]._blockLast) {
+            ++e;
+            if (e >= B || v_blockMeta_[e]._blockIsolated || v_blockMeta_[e]._blockFirst) return;
+        }
+        if (e > k) {
+            nets.push_back({k, e, 1});
+            chained += e - k + 1;
+            for (UINT32 q = k; q <= e; ++q) {
+                net_s[q] = k;
+                net_e[q] = e;
+            }
+        }
+        k = e + 1;
+    }
+    int W = want > 1 ? want : (chained >= 512 ? 32 : chained >= 64 ? 16 : 1);
+    W = std::min<int>(W, (int)(chained / 3));
+    if (W < 2) return;
+    // small condensed systems, every block between two others carrying something both ways
+    for (const net_t& n : nets)
+        for (UINT32 k = n.s; k <= n.e; ++k) {
+            const block_t& Bk = blocks_[k];
+            if (Bk.keep.empty() || !Bk.red || 3 * Bk.keep.size() > 1024) return;
+            if ((k > n.s && Bk.c_prev.empty()) || (k < n.e && Bk.c_next.empty())) return;
+            if ((k < n.e && !Bk.jfwd) || (k > n.s && !blocks_[k - 1].jrev)) return;
+        }
+    // the runs: W of them dealt to the networks by their length, at least three blocks to a run
+    {
+        int total = 0;
+        for (net_t& n : nets) {
+            const UINT32 len = n.e - n.s + 1;
+            n.runs = std::max(1, std::min<int>((int)(len / 3), (int)std::lround((double)W * len / (double)chained)));
+            total += n.runs;
+        }
+        W = total;
     }
     auto gid = [&](UINT32 k, UINT32 keep_pos) { return v_parameterStationList_[k][blocks_[k].keep[keep_pos]]; };
     auto position = [](const std::vector<UINT32>& sorted, UINT32 g) {
@@ -1890,7 +1926,8 @@ void dna_adjust::PrepareLockstepChains() {
         members.clear();
     };
     struct run_t {
-        UINT32 a, b;
+        UINT32 a, b, s, e;                   // its blocks; its network's blocks
+        int net, index, of;                  // its network; its place among that network's runs
         std::vector<UINT32> stations, posL, posR, est_blk, est_idx, sys_pos;
         constraint_list con_fwd, con_rev;
         std::vector<UINT32> prev;            // stations of the running merged system
@@ -1899,15 +1936,30 @@ void dna_adjust::PrepareLockstepChains() {
     };
     std::vector<run_t> runs((size_t)W);
     try {
+        {
+            int r = 0;
+            for (size_t q = 0; q < nets.size(); ++q) {
+                const UINT32 len = nets[q].e - nets[q].s + 1;
+                for (int i = 0; i < nets[q].runs; ++i, ++r) {
+                    run_t& g = runs[r];
+                    g.s = nets[q].s;
+                    g.e = nets[q].e;
+                    g.net = (int)q;
+                    g.index = i;
+                    g.of = nets[q].runs;
+                    g.a = g.s + (UINT32)((uint64_t)i * len / (uint64_t)nets[q].runs);
+                    g.b = g.s + (UINT32)((uint64_t)(i + 1) * len / (uint64_t)nets[q].runs) - 1;
+                }
+            }
+        }
         for (int r = 0; r < W; ++r) {
             run_t& g = runs[r];
-            g.a = (UINT32)((uint64_t)r * B / (uint64_t)W);
-            g.b = (UINT32)((uint64_t)(r + 1) * B / (uint64_t)W) - 1;
             const block_t& A = blocks_[g.a];
             const block_t& Z = blocks_[g.b];
             std::vector<UINT32> L, R;
-            for (UINT32 p : A.c_prev) L.push_back(gid(g.a, p));
-            if (g.b + 1 < B)
+            if (g.a > g.s)
+                for (UINT32 p : A.c_prev) L.push_back(gid(g.a, p));
+            if (g.b < g.e)
                 for (UINT32 p : Z.c_next) R.push_back(gid(g.b, p));
             g.stations = L;
             g.stations.insert(g.stations.end(), R.begin(), R.end());
@@ -1955,7 +2007,7 @@ void dna_adjust::PrepareLockstepChains() {
             std::vector<pending_t> members;
             for (int r = 0; r < W; ++r) {
                 run_t& g = runs[r];
-                if (g.b - g.a < j) continue;
+                if (g.b - g.a < j || g.of < 2) continue;       // (a network that is one run needs no run system)
                 const UINT32 k = g.a + j;
                 members.push_back({[&, r, k]() -> double {
                     run_t& g = runs[r];
@@ -1970,8 +2022,9 @@ void dna_adjust::PrepareLockstepChains() {
                     for (UINT32 s : blk) d.pos[1].push_back((UINT32)position(U, s));
                     // stations that stay: the run's first junction row and block k's junction row towards k + 1
                     std::vector<UINT32> stay;
-                    for (UINT32 p : blocks_[g.a].c_prev) stay.push_back(gid(g.a, p));
-                    if (k + 1 < B)
+                    if (g.a > g.s)
+                        for (UINT32 p : blocks_[g.a].c_prev) stay.push_back(gid(g.a, p));
+                    if (k < g.e)
                         for (UINT32 p : blocks_[k].c_next) stay.push_back(gid(k, p));
                     std::sort(stay.begin(), stay.end());
                     stay.erase(std::unique(stay.begin(), stay.end()), stay.end());
@@ -2020,8 +2073,12 @@ void dna_adjust::PrepareLockstepChains() {
         // level 2: the two chains over the runs
         stages.emplace_back();
         stages.back().lanes.resize(2);
-        for (int r = 0; r + 1 < W; ++r) {
+        int most_runs = 1;
+        for (const net_t& n : nets) most_runs = std::max(most_runs, n.runs);
+        for (int i = 0; i + 1 < most_runs; ++i) {       // (forward step i of every network that has it)
             std::vector<pending_t> members;
+            for (int r = 0; r < W; ++r) {
+                if (runs[r].index != i || i + 1 >= runs[r].of) continue;
             members.push_back({[&, r]() -> double {
                 run_t& g = runs[r];
                 step_data_t d;
@@ -2034,17 +2091,20 @@ void dna_adjust::PrepareLockstepChains() {
                 const dnagpu_matrix* src[2] = {g.S, nullptr};
                 const int junction[2] = {0, 1};
                 int n_src = 1;
-                if (r > 0) {
+                if (g.index > 0) {
                     d.pos[1] = g.posL;
                     src[1] = blocks_[g.a - 1].jfwd;
                     n_src = 2;
                 }
                 return add_step(std::move(d), n_src, src, junction, blocks_[g.b].jfwd, 1, (UINT32)g.stations.size());
-            }, true, 0, nref3(runs[r].b)});       // (it leaves what the forward step on the run's last block leaves: counted as that step)
+            }, true, runs[r].net, nref3(runs[r].b)});       // (it leaves what the forward step on the run's last block leaves: counted as that step)
+            }
             close_group(stages.back().lanes[0], members);
         }
-        for (int r = W - 1; r >= 1; --r) {
+        for (int i = 0; i + 1 < most_runs; ++i) {       // (reverse step i of every network that has it: its run of.. - 1 - i)
             std::vector<pending_t> members;
+            for (int r = 0; r < W; ++r) {
+                if (runs[r].of < 2 || runs[r].index != runs[r].of - 1 - i || runs[r].index < 1) continue;
             members.push_back({[&, r]() -> double {
                 run_t& g = runs[r];
                 step_data_t d;
@@ -2057,13 +2117,14 @@ void dna_adjust::PrepareLockstepChains() {
                 const dnagpu_matrix* src[2] = {g.S, nullptr};
                 const int junction[2] = {0, 1};
                 int n_src = 1;
-                if (r + 1 < W) {
+                if (g.index + 1 < g.of) {
                     d.pos[1] = g.posR;
                     src[1] = blocks_[g.b].jrev;
                     n_src = 2;
                 }
                 return add_step(std::move(d), n_src, src, junction, blocks_[g.a - 1].jrev, 1, (UINT32)g.stations.size());
-            }, true, 0, nref3(runs[r].a)});
+            }, true, runs[r].net, nref3(runs[r].a)});
+            }
             close_group(stages.back().lanes[1], members);
         }
         // level 3: both chains inside every run, from the boundary values of level 2 (CondensedForwardBlock / CondensedReverseBlock as data)
@@ -2087,7 +2148,7 @@ void dna_adjust::PrepareLockstepChains() {
             dnagpu_matrix* out;
             if (dir == 0) {
                 d.keep = Bk.c_next;
-                if (k > 0) {
+                if (k > net_s[k]) {
                     d.pos[1] = Bk.c_prev;
                     src[1] = blocks_[k - 1].jfwd;
                     n_src = 2;
@@ -2095,7 +2156,7 @@ void dna_adjust::PrepareLockstepChains() {
                 out = Bk.jfwd;
             } else {
                 d.keep = Bk.c_prev;
-                if (k + 1 < B) {
+                if (k < net_e[k]) {
                     d.pos[1] = Bk.c_next;
                     src[1] = Bk.jrev;
                     n_src = 2;

@@ -814,6 +814,25 @@ def test_lock_step_chains_on_random_segmentations(built, orc, tmp_path, seed):
     o.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_lock_step_chains_over_several_networks(built, orc, tmp_path, seed):
+    """a project with three network ids -- two randomly cut contiguous networks and an isolated block (tests/test_oracle_adjust.py::_fuzzed_project):
+    the chains of the networks are independent of each other and advance together like the runs of one (the runs are dealt to the networks by
+    their length; a short network is one run); the isolated block has no chain step.  Oracle live."""
+    from tests.test_oracle_adjust import _fuzzed_project
+    info = _fuzzed_project(tmp_path, 50 + seed)
+    net = orc.Network(str(tmp_path / "all"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    assert ost == 0
+    a, st = _device_run(str(tmp_path), "all", True, multi_thread=bool(seed % 2), chain_runs=3 + seed % 2)
+    assert a.chain_runs() >= 2, info
+    _compare(a, st, o, ost)
+    a.close()
+    o.close()
+
+
 def test_a_singular_step_of_lock_step_chains_is_named(built, tmp_path):
     """the lock-step chains take the eliminations' verdict once per level; a pivot that is not positive sends the phase to the chains step
     by step, which name the block (test_a_singular_chain_step_among_many_is_named)"""
