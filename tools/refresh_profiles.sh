@@ -14,6 +14,8 @@ timeout 600 $B --steps 3 --warmup 1 --no-cpu-baseline 2> $O/bench_cfg3.err | tai
 timeout 600 $B --workload cfg2 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg2.json
 timeout 600 $B --workload smallblocks --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/${TAG}_bench_smallblocks.json
 timeout 900 $B --workload dnasegment150 --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/${TAG}_bench_dnasegment150.json
+timeout 600 $B --workload dnasegment150 --chain-runs 0 --steps 3 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg 2>/dev/null | tail -1 > $O/${TAG}_bench_dnasegment150_chains_step_by_step.json
+timeout 600 $B --workload smallblocks --chain-runs 0 --steps 3 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg 2>/dev/null | tail -1 > $O/${TAG}_bench_smallblocks_chains_step_by_step.json
 timeout 600 $B --workload cfg3_ragged --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_ragged.json
 timeout 600 $B --workload cfg4_slice --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg4_slice.json
 timeout 600 $B --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg --variance-propagation 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_variance_propagation.json
@@ -21,7 +23,7 @@ timeout 600 $B --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain --no-refact
 timeout 600 $B --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg --reference-schedule 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_reference_schedule.json
 DNAGPU_FORCE_DISTRIBUTED=1 timeout 600 $B --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_rccl_one_rank.json
 for w in cfg3 smallblocks dnasegment150; do
-  DNAGPU_PHASE_TIMES=1 timeout 600 $B --workload $w --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg 2>&1 | grep "^\[phase\]" | tail -16 > $O/${TAG}_${w}_phase_times.txt
+  DNAGPU_PHASE_TIMES=1 timeout 600 $B --workload $w --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg 2>&1 | grep "^\[phase\]" | tail -40 > $O/${TAG}_${w}_phase_times.txt
 done
 # ---- kernel traces ----
 CMD="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-one-chain --no-refactor-leg"
