@@ -181,7 +181,7 @@ void free_index_cache(dnagpu_ctx* ctx, int chain) {
 int stage_u32(dnagpu_ctx* ctx, int chain, const uint32_t* host, size_t count, uint32_t** dev) {
     // (round 5: lists from 4 entries on -- a dnasegment-default cut has junction lists of a few dozen stations, and every list that misses
     //  the cache costs a stream synchronisation in every chain step of every iteration)
-    if (count >= 4) {
+    if (count >= 1) {      // (every list: a one-station list of constraints through the staging buffer kept its whole batch off the merged launches)
         uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
         for (size_t i = 0; i < count; ++i) h = (h ^ host[i]) * 1099511628211ull;
         auto& cache = ctx->idx_cache[chain];
@@ -2976,9 +2976,17 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
             plan->out[s] = {st.out, nj, st.out_junction};
         }
     }
-    HIPCHK(dnagpu::poison_malloc(&plan->blob, blob.size() + 16));
-    HIPCHK(dnagpu::poison_malloc(&plan->factors, (size_t)factor_bytes + 16));
-    HIPCHK(dnagpu::poison_malloc(&plan->table, n_steps * sizeof(CbStep)));
+    {
+        hipError_t e = dnagpu::poison_malloc(&plan->blob, blob.size() + 16);
+        if (e == hipSuccess) e = dnagpu::poison_malloc(&plan->factors, (size_t)factor_bytes + 16);
+        if (e == hipSuccess) e = dnagpu::poison_malloc(&plan->table, n_steps * sizeof(CbStep));
+        if (e != hipSuccess) {      // (nothing half allocated stays behind: the caller runs the chains step by step and needs the memory for that)
+            (void)hipGetLastError();
+            for (void* q : {plan->blob, (void*)plan->factors, plan->table})
+                if (q) hipFree(q);
+            return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "chain_plan_create: device allocation", e);
+        }
+    }
     uint8_t* base = (uint8_t*)plan->blob;
     for (size_t s = 0; s < n_steps; ++s) {
         CbStep& d = table[s];

@@ -1,12 +1,27 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
-T0=$SECONDS
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=8 2>&1 | tail -20 > gpurun_out/gpu_suite.txt
-echo "suite: $((SECONDS - T0)) s" >> gpurun_out/gpu_suite.txt
-tail -14 gpurun_out/gpu_suite.txt
-TAG=r05 bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-echo "total: $((SECONDS - T0)) s"
-for f in gpurun_out/profiles_new/r05_bench_*.json; do echo $f; cut -c100-260 $f; echo; done
-cat gpurun_out/profiles_new/r05_inverse_rates.txt
-cat gpurun_out/profiles_new/r05_hbm_traffic.json | head -30
+R=$PWD
+O=$R/gpurun_out/profiles_new
+mkdir -p $O
+DNAGPU_POISON_ALLOC=1 timeout 900 python -m pytest tests/test_gpu_adjust.py tests/test_gpu_terrestrial.py tests/test_gpu_kernels.py tests/test_gpu_batch.py -q -m gpu -x -k "lock_step or many_small or chain_plan or bucket or singular" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_adjust.py tests/test_gpu_batch.py tests/test_gpu_kernels.py -q -m gpu -x 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+TAG=r05
+B="python $R/bench.py"
+F="--steps 1 --warmup 0 --no-cpu-baseline --no-one-chain --no-refactor-leg"
+CMD="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-one-chain --no-refactor-leg"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- timeout 600 $B $F > $O/pmc_$c.log 2>&1
+  lc=$(echo $c | tr A-Z a-z)
+  python $R/tools/rocprof_summary.py pmc /tmp/pmc_$c $O/${TAG}_cfg3_pmc_$lc.txt "rocprofv3 --pmc $c --kernel-trace -- $CMD   (${TAG}, cfg3)"
+done
+(cd $O && python $R/tools/pmc_traffic_json.py ${TAG}_cfg3_pmc_fetch_size.txt ${TAG}_cfg3_pmc_write_size.txt ${TAG}_hbm_traffic.json cfg3 > /dev/null)
+cat $O/${TAG}_hbm_traffic.json | tail -4
+cd $R
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3.json; cut -c100-240 $O/${TAG}_bench_cfg3.json
+python - <<'PY'
+import json
+r=json.load(open('gpurun_out/profiles_new/r05_bench_cfg3.json'))
+print(r['roofline'].get('traffic'), r['roofline'].get('traffic_source'))
+print([ (k['kernel'][:30],k['launches'],k['frac']) for k in r['roofline_hbm']['kernels']])
+PY
