@@ -51,8 +51,14 @@ WORKLOADS = {
     # 3 rows: 667 blocks of 150 inner + 50 junction stations, n = 600 unknowns each -- hundreds of small dense systems, not a few large ones
     "dnasegment150": (2000, 50, 266666, 0, True, "synthetic 100k-station / 800k-measurement network, phased adjustment, 667 blocks of 150 inner + 50 junction stations (dnasegment's default block size)"),
 }
+# a PROJECT of the national size at the reference's default cut: ten contiguous networks (network ids) of the dnasegment150 kind in one set of files,
+# 1M stations in 6 660 blocks.  (One strip of 20 000 x 50 stations would be a different problem: its normal equations are so ill-conditioned along
+# the strip that the iterations act as iterative refinement and do not reach the 0.5 mm threshold in ten.)
+WORKLOADS["dnasegment150_10x"] = (2000, 50, 266666, 0, True, "synthetic 1M-station / 8M-measurement project, phased adjustment, ten networks of 666 blocks of 150 inner + 50 junction stations each (dnasegment's default block size)")
 # extra arguments of the generator per workload (dnasynth_spec: ragged, rows_lo, rows_hi)
-WORKLOAD_KW = {"cfg3_ragged": {"ragged": 0.3}, "smallblocks": {"rows_lo": 1, "rows_hi": 10}, "dnasegment150": {"rows_lo": 3, "rows_hi": 3}}
+WORKLOAD_KW = {"cfg3_ragged": {"ragged": 0.3}, "smallblocks": {"rows_lo": 1, "rows_hi": 10}, "dnasegment150": {"rows_lo": 3, "rows_hi": 3},
+               "dnasegment150_10x": {"rows_lo": 3, "rows_hi": 3}}
+WORKLOAD_COPIES = {"dnasegment150_10x": 10}
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk)
 
 
@@ -856,7 +862,22 @@ def main():
     rows, cols, nbl, blocks, phased, desc = WORKLOADS[args.workload]
     d = tempfile.mkdtemp(prefix=f"dnagpu_bench_r{rank}_")
     t_w = time.perf_counter()
-    info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, max(1, blocks), **WORKLOAD_KW.get(args.workload, {}))
+    copies = WORKLOAD_COPIES.get(args.workload, 1)
+    if copies > 1:
+        # several independently generated networks merged into one project (station / measurement indices offset, a network id per source)
+        from tests import dnaformats
+        parts = []
+        for q in range(copies):
+            info = adjust.write_synthetic_network(d, f"part{q}", rows, cols, nbl, max(1, blocks), seed=20260930 + q, **WORKLOAD_KW.get(args.workload, {}))
+            parts.append(os.path.join(d, f"part{q}"))
+        dnaformats.merge_networks(parts, os.path.join(d, "net"))
+        with open(os.path.join(d, "net.truth"), "wb") as f:        # (the generator's true coordinates, in the merged station order)
+            for part in parts:
+                f.write(open(part + ".truth", "rb").read())
+        info = dict(info, stations=info["stations"] * copies, baselines=info["baselines"] * copies, measurement_rows=info["measurement_rows"] * copies,
+                    blocks=info["blocks"] * copies, networks=copies)
+    else:
+        info = adjust.write_synthetic_network(d, "net", rows, cols, nbl, max(1, blocks), **WORKLOAD_KW.get(args.workload, {}))
     blocks = info["blocks"]
     synth_s = time.perf_counter() - t_w
     stations = info["stations"]

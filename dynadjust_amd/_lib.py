@@ -336,7 +336,7 @@ EXPORTED_DNAGPU = [
     "dnagpu_block_add_rhs", "dnagpu_block_gather_stations", "dnagpu_junction_gather", "dnagpu_schur_carry", "dnagpu_schur_carry_keep", "dnagpu_schur_carry_rhs", "dnagpu_chain_step_rhs", "dnagpu_small_batch_create", "dnagpu_small_batch_condense", "dnagpu_small_batch_solve", "dnagpu_small_batch_destroy", "dnagpu_junction_export", "dnagpu_junction_import", "dnagpu_junction_device_pointers", "dnagpu_block_reduce", "dnagpu_block_form_reduce", "dnagpu_batch_reserve", "dnagpu_block_form_reduce_batched", "dnagpu_partial_complete_factor_batched", "dnagpu_partial_finish_batched", "dnagpu_mem_info", "dnagpu_device_alloc", "dnagpu_device_free", "dnagpu_copy", "dnagpu_matrix_resize", "dnagpu_matrix_device_pointers", "dnagpu_set_inverse_exchange", "dnagpu_inverse_exchange_stats", "dnagpu_host_alloc", "dnagpu_host_free", "dnagpu_partial_create", "dnagpu_partial_create_in", "dnagpu_partial_create_spine", "dnagpu_partial_destroy", "dnagpu_partial_complete", "dnagpu_partial_complete_factor", "dnagpu_partial_solve", "dnagpu_partial_finish", "dnagpu_partial_reduce_rhs",
     "dnagpu_block_load_reduced", "dnagpu_junction_scatter", "dnagpu_junction_rhs", "dnagpu_junction_get_estimates",
     "dnagpu_junction_put_estimates", "dnagpu_chain_wait", "dnagpu_chain_sync",
-    "dnagpu_chain_plan_create", "dnagpu_chain_plan_run", "dnagpu_chain_plan_run_rhs", "dnagpu_chain_plan_destroy", "dnagpu_partial_complete_factor_planned",
+    "dnagpu_chain_plan_create", "dnagpu_chain_plan_info", "dnagpu_chain_plan_run", "dnagpu_chain_plan_run_rhs", "dnagpu_chain_plan_destroy", "dnagpu_partial_complete_factor_planned",
 ]
 
 EXPORTED_DNAADJ = [

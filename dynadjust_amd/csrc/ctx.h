@@ -57,6 +57,8 @@ struct dnagpu_chain_plan {
     struct Out { dnagpu_matrix* m; uint32_t nj; int junction; };
     std::vector<Out> out;                             // per step: where its result goes (host-side fields are set when the step runs)
     std::vector<uint8_t> factored;                    // per batch: dnagpu_chain_plan_run has been through it
+    bool keeps = true;                                // the steps' factors stay (false: beyond the budget -- every run eliminates again)
+    double factor_bytes = 0.0;
     double flops = 0.0;
 };
 
@@ -139,6 +141,8 @@ struct dnagpu_ctx {
     hipStream_t stream[DNAGPU_NUM_CHAINS] = {};
     hipEvent_t ev[DNAGPU_NUM_CHAINS] = {};
     dnagpu::InvWorkspace ws[DNAGPU_NUM_CHAINS];
+    double* plan_scratch[DNAGPU_NUM_CHAINS] = {};      // dnagpu_chain_plan_run of a plan that keeps no factors: the members' factors of one batch
+    size_t plan_scratch_cap[DNAGPU_NUM_CHAINS] = {};
     double* symv_part[DNAGPU_NUM_CHAINS] = {};
     uint32_t symv_cap[DNAGPU_NUM_CHAINS] = {};
     // small per-chain staging buffers for index lists / 3x3 weights / vectors

@@ -383,6 +383,8 @@ void dnagpu_destroy(dnagpu_ctx* ctx) {
         if (ctx->copy_stream[c]) hipStreamDestroy(ctx->copy_stream[c]);
     }
     if (ctx->bad_dev) hipFree(ctx->bad_dev);
+    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c)
+        if (ctx->plan_scratch[c]) hipFree(ctx->plan_scratch[c]);
     for (void* p : {(void*)ctx->osc_prev, (void*)ctx->osc_seen, (void*)ctx->osc_cnt, (void*)ctx->osc_flagged, ctx->osc_rows, (void*)ctx->osc_off, ctx->osc_visits})
         if (p) hipFree(p);
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
@@ -2888,7 +2890,9 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
             factor_bytes += 8.0 * (double)npp * npp;
         }
     }
-    if (factor_bytes > max_bytes) return DNAGPU_ETOOLARGE;
+    // beyond the budget the plan keeps no factors: every run of a batch eliminates again, into scratch of the chain it runs on
+    plan->keeps = factor_bytes <= max_bytes;
+    plan->factor_bytes = plan->keeps ? factor_bytes : 0.0;
     for (size_t q = 0; q < n_batches; ++q) {
         const dnagpu_chain_plan::Shape sh = plan->shape[q];
         const auto blocks = sym_spine_blocks((int)(sh.nip / 128));
@@ -2978,7 +2982,7 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
     }
     {
         hipError_t e = dnagpu::poison_malloc(&plan->blob, blob.size() + 16);
-        if (e == hipSuccess) e = dnagpu::poison_malloc(&plan->factors, (size_t)factor_bytes + 16);
+        if (e == hipSuccess && plan->keeps) e = dnagpu::poison_malloc(&plan->factors, (size_t)factor_bytes + 16);
         if (e == hipSuccess) e = dnagpu::poison_malloc(&plan->table, n_steps * sizeof(CbStep));
         if (e != hipSuccess) {      // (nothing half allocated stays behind: the caller runs the chains step by step and needs the memory for that)
             (void)hipGetLastError();
@@ -3001,7 +3005,7 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
             d.src[r].pos = (const uint32_t*)(base + o.pos[r]);
             d.src[r].inv = (const int32_t*)(base + o.inv[r]);
         }
-        d.X = o.has_map ? plan->factors + x_off[s] : nullptr;
+        d.X = (o.has_map && plan->keeps) ? plan->factors + x_off[s] : nullptr;
         plan->X[s] = d.X;
     }
     HIPCHK(hipMemcpy(plan->blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -3027,11 +3031,23 @@ int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, s
     double* F[BATCH_MAX];
     double* X[BATCH_MAX];
     double* P[BATCH_MAX];
+    if (!plan->keeps) {
+        const size_t need = (size_t)nb * sh.npp * sh.npp;
+        if (ctx->plan_scratch_cap[chain] < need) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (ctx->plan_scratch[chain]) hipFree(ctx->plan_scratch[chain]);
+            ctx->plan_scratch[chain] = nullptr;
+            ctx->plan_scratch_cap[chain] = 0;
+            HIPCHK(dnagpu::poison_malloc(&ctx->plan_scratch[chain], need * sizeof(double)));
+            ctx->plan_scratch_cap[chain] = need;
+        }
+    }
     for (uint32_t b = 0; b < nb; ++b) {
         F[b] = b ? ws.bX[b] : ws.X;
-        X[b] = plan->X[first + b];
+        X[b] = plan->keeps ? plan->X[first + b] : ctx->plan_scratch[chain] + (size_t)b * sh.npp * sh.npp;
         P[b] = b ? ws.bW[b] : ws.W;
         mem.F[b] = F[b];
+        mem.X[b] = X[b];
     }
     launch_cb_rhs(table, nb, st);
     launch_cb_assemble(table, nb, mem, sh.npp, 0, sh.npp, st);
@@ -3054,13 +3070,20 @@ int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, s
         o.m->np = pad128(o.nj);
         o.m->form = o.junction ? 1 : 0;
     }
-    plan->factored[batch] = 1;
+    plan->factored[batch] = plan->keeps ? 1 : 0;
     if (ws.hold_info) return DNAGPU_OK;
     HIPCHK(hipMemcpyAsync(ws.info_host, ws.info, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     rc = check_info_batch(ctx, chain, (int)nb, nullptr);
     if (rc) plan->factored[batch] = 0;
     return rc;
+}
+
+int dnagpu_chain_plan_info(const dnagpu_chain_plan* plan, int* keeps_factors, double* factor_bytes) {
+    if (!plan) return DNAGPU_EINVAL;
+    if (keeps_factors) *keeps_factors = plan->keeps ? 1 : 0;
+    if (factor_bytes) *factor_bytes = plan->factor_bytes;
+    return DNAGPU_OK;
 }
 
 int dnagpu_chain_plan_run_rhs(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch_lo, size_t batch_hi) {

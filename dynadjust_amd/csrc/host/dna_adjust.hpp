@@ -352,6 +352,7 @@ private:
     std::vector<dnagpu_matrix*> lock_mats_;                  // the merged systems of the runs (owned)
     bool lockstep_ok_ = false;
     bool lock_factored_ = false;                             // the plan's factors are those of this adjustment's normals
+    bool lock_keeps_ = false;                                // the plan keeps its steps' factors (they fit chain_fac_budget_)
     int lock_runs_ = 0;
     // ... and the kept blocks of the rigorous solves of a many-block network as data too (matrix_only steps: RigorousBatch)
     dnagpu_chain_plan* rig_plan_ = nullptr;

@@ -1838,7 +1838,7 @@ void dna_adjust::PrepareLockstepChains() {
         }
         k = e + 1;
     }
-    int W = want > 1 ? want : (chained >= 512 ? 32 : chained >= 64 ? 16 : 1);
+    int W = want > 1 ? want : (chained >= 2048 ? 64 : chained >= 512 ? 32 : chained >= 64 ? 16 : 1);
     W = std::min<int>(W, (int)(chained / 3));
     if (W < 2) return;
     // small condensed systems, every block between two others carrying something both ways
@@ -2192,15 +2192,29 @@ void dna_adjust::PrepareLockstepChains() {
         FreeLockstepChains();      // (no room for the merged systems: the chains go step by step)
         return;
     }
-    const double budget = chain_fac_budget_ > 0.0 ? chain_fac_budget_ : 4.0e9;
+    // the steps' factors are kept (a.reuse_factors: right-hand sides only from iteration 2 on) while they fit what PrepareCondensedBlocks set
+    // aside for chain steps' factors; beyond that the plan keeps none and every iteration eliminates again -- in lock step all the same
+    // (a network of many small blocks leaves most of the memory unused: its plan may take up to half of what the batch workspaces were left)
+    const double budget = FactorReuse() ? std::max(chain_fac_budget_, std::min(0.5 * batch_budget_, 96.0e9)) : 0.0;
     const int rc = dnagpu_chain_plan_create(ctx_, steps.size(), steps.data(), batch_first.size() - 1, batch_first.data(), budget, &lock_plan_);
     if (getenv("DNAGPU_PHASE_TIMES"))
-        fprintf(stderr, "[phase] chain plan: %d runs, %zu steps in %zu batches: %s\n", W, steps.size(), batch_first.size() - 1, rc == DNAGPU_OK ? "made" : "not made");
+        fprintf(stderr, "[phase] chain plan: %d runs, %zu steps in %zu batches: %s (budget for kept factors %.2f GB)\n", W, steps.size(), batch_first.size() - 1,
+                rc == DNAGPU_OK ? "made" : "not made", budget / 1.0e9);
     if (rc != DNAGPU_OK) {
         lock_plan_ = nullptr;
         FreeLockstepChains();
         if (rc != DNAGPU_ETOOLARGE && rc != DNAGPU_ENOMEM) Check(rc, 0, "PrepareAdjustment(): chain plan");
         return;
+    }
+    {
+        int keeps = 0;
+        double bytes = 0.0;
+        dnagpu_chain_plan_info(lock_plan_, &keeps, &bytes);
+        lock_keeps_ = keeps != 0;
+        const double own = std::min(bytes, chain_fac_budget_);
+        chain_fac_budget_ -= own;
+        batch_budget_ = std::max(0.0, batch_budget_ - (bytes - own));
+        batch_limit_ = (int)std::max(0.0, std::min(1.0e6, batch_unit_ > 0.0 ? batch_budget_ / batch_unit_ : 0.0));
     }
     lock_stages_ = std::move(stages);
     lock_batch_slot_ = std::move(batch_slot);
@@ -2210,7 +2224,7 @@ void dna_adjust::PrepareLockstepChains() {
 
 bool dna_adjust::LockstepChains() {
     if (!lockstep_ok_ || !lock_plan_) return false;
-    const bool rhs_only = lock_factored_ && FactorReuse();
+    const bool rhs_only = lock_factored_ && lock_keeps_ && FactorReuse();
     const int nch = std::min(NumChains(), 4);
     bool failed = false;
     std::mutex fm;

@@ -111,6 +111,7 @@ struct CbStep {
 };
 struct CbMembers {
     double* F[16];          // the matrices the members of a batch are factored in (the chain's workspaces)
+    double* X[16];          // ... and where their factors go: the plan's kept factors, or scratch of the chain when the plan keeps none
 };
 // members = table[0 .. nb): the right-hand sides and linearisation points (one workgroup per member) ...
 void launch_cb_rhs(const CbStep* table, uint32_t nb, hipStream_t s);

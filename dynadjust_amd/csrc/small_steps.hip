@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void cb_post_kernel(const CbStep* __restrict__
         return;
     }
     // (the row that carried the right-hand side is no unknown: its entries in the kept factor's panels go)
-    if (i < nip) d.X[(size_t)i * npp + nip + d.nj] = 0.0;
+    if (i < nip) mem.X[blockIdx.z][(size_t)i * npp + nip + d.nj] = 0.0;
     if (d.out_jest && i < 3 * d.k_out) d.out_jest[i] = d.xe[3 * d.keep[i / 3] + i % 3];
 }
 

@@ -391,7 +391,7 @@ void dnagpu_small_batch_destroy(dnagpu_ctx* ctx, dnagpu_small_batch* sb);
  * (independent of each other, factored before) through their kept factors, right-hand sides only, in ONE launch.  A long chain of
  * small steps -- a dnasegment-default cut -- is bound by its length: cut into runs that advance together it is 2 B / W + W steps deep
  * instead of B (dna_adjust::LockstepChains).  DNAGPU_ETOOLARGE (nothing made) when a step is beyond the small-system kernels
- * (more than 2 048 unknowns), has nothing to eliminate, or the factors exceed `max_bytes`.  The plan refers to the matrices' and
+ * (more than 2 048 unknowns).  Factors beyond `max_bytes`: the plan keeps none (dnagpu_chain_plan_info).  The plan refers to the matrices' and
  * blocks' storage: destroy it before any of them. */
 typedef struct dnagpu_chain_plan dnagpu_chain_plan;
 typedef struct dnagpu_chain_source {
@@ -415,6 +415,9 @@ typedef struct dnagpu_chain_step {
 } dnagpu_chain_step;
 int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain_step* steps, size_t n_batches, const uint32_t* batch_first,
                              double max_bytes, dnagpu_chain_plan** out);
+/* keeps_factors: 0 when the steps' factors exceeded max_bytes -- the plan then keeps none (dnagpu_chain_plan_run eliminates into scratch of its chain
+ * every time, dnagpu_chain_plan_run_rhs is refused); factor_bytes: what the kept factors take */
+int dnagpu_chain_plan_info(const dnagpu_chain_plan* plan, int* keeps_factors, double* factor_bytes);
 int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch);
 int dnagpu_chain_plan_run_rhs(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, size_t batch_lo, size_t batch_hi);
 void dnagpu_chain_plan_destroy(dnagpu_ctx* ctx, dnagpu_chain_plan* plan);

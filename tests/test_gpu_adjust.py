@@ -814,6 +814,22 @@ def test_lock_step_chains_on_random_segmentations(built, orc, tmp_path, seed):
     o.close()
 
 
+def test_lock_step_chains_without_room_for_their_factors(built, orc, tmp_path, monkeypatch):
+    """the steps' factors of a chain plan are kept while they fit what PrepareAdjustment sets aside for chain steps' factors; beyond that the plan
+    keeps none and every iteration eliminates again -- in lock step all the same (DNAGPU_FACTOR_BUDGET_GB: the memory-tight plan at any size)"""
+    info = adjust.write_synthetic_network(str(tmp_path), "m", 80, 24, 0, 1, seed=12, rows_lo=2, rows_hi=2, initial_sigma=0.3)
+    net = orc.Network(str(tmp_path / "m"), True)
+    o = orc.Adjustment(net, True)
+    o.prepare()
+    ost = o.run()
+    monkeypatch.setenv("DNAGPU_FACTOR_BUDGET_GB", "0.0002")
+    a, st = _device_run(str(tmp_path), "m", True, multi_thread=True, chain_runs=4)
+    assert a.chain_runs() == 4 and a.CurrentIteration() >= 2 and a.chain_step_reuses() == 0
+    _compare(a, st, o, ost)
+    a.close()
+    o.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_lock_step_chains_over_several_networks(built, orc, tmp_path, seed):
     """a project with three network ids -- two randomly cut contiguous networks and an isolated block (tests/test_oracle_adjust.py::_fuzzed_project):

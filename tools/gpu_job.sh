@@ -3,8 +3,8 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 R=$PWD
 O=$R/gpurun_out/profiles_new
 mkdir -p $O
-DNAGPU_POISON_ALLOC=1 timeout 900 python -m pytest tests/test_gpu_adjust.py tests/test_gpu_terrestrial.py tests/test_gpu_kernels.py tests/test_gpu_batch.py -q -m gpu -x -k "lock_step or many_small or chain_plan or bucket or singular" 2>&1 | tail -4
-timeout 900 python -m pytest tests/test_gpu_adjust.py tests/test_gpu_batch.py tests/test_gpu_kernels.py -q -m gpu -x 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_adjust.py tests/test_gpu_batch.py tests/test_gpu_kernels.py tests/test_gpu_terrestrial.py -q -m gpu -x 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -q -m gpu -x -k "record" 2>&1 | tail -3
 cd /tmp && export TMPDIR=/tmp
 TAG=r05
 B="python $R/bench.py"
@@ -16,12 +16,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python $R/tools/rocprof_summary.py pmc /tmp/pmc_$c $O/${TAG}_cfg3_pmc_$lc.txt "rocprofv3 --pmc $c --kernel-trace -- $CMD   (${TAG}, cfg3)"
 done
 (cd $O && python $R/tools/pmc_traffic_json.py ${TAG}_cfg3_pmc_fetch_size.txt ${TAG}_cfg3_pmc_write_size.txt ${TAG}_hbm_traffic.json cfg3 > /dev/null)
-cat $O/${TAG}_hbm_traffic.json | tail -4
+tail -3 $O/${TAG}_hbm_traffic.json
 cd $R
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3.json; cut -c100-240 $O/${TAG}_bench_cfg3.json
-python - <<'PY'
-import json
-r=json.load(open('gpurun_out/profiles_new/r05_bench_cfg3.json'))
-print(r['roofline'].get('traffic'), r['roofline'].get('traffic_source'))
-print([ (k['kernel'][:30],k['launches'],k['frac']) for k in r['roofline_hbm']['kernels']])
-PY
+for w in dnasegment150 smallblocks; do timeout 600 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c100-240; done
