@@ -27,7 +27,8 @@ constexpr uint32_t SYMV_CHUNKS = 32;
 constexpr int INFO_SENTINEL = 0x7f7f7f7f;
 // dnagpu_debug_fail_batch_workspaces(n): the next n allocations of a batch's member workspaces fail as if HBM were full (tests)
 std::atomic<long> g_fail_batch_ws{0};
-static_assert(DNAGPU_BATCH_MAX == BATCH_MAX, "include/dnagpu.h and la_kernels.h disagree on the batch size");
+static_assert(DNAGPU_CHAIN_BATCH_MAX == BATCH_MAX && DNAGPU_BATCH_MAX <= BATCH_MAX, "include/dnagpu.h and la_kernels.h disagree on the batch sizes");
+constexpr int BLOCK_BATCH_MAX = DNAGPU_BATCH_MAX;      // (the by-value member tables of the block batches: adjust_kernels.h FormBatch ...)
 
 // Error text and dpotrf-style info are kept twice: per host thread (every chain of a context is driven by its own host thread,
 // and two chains may fail together) and in the context, under a mutex, for any other thread that asks afterwards.
@@ -1802,12 +1803,17 @@ int dnagpu_osc_blocks(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const i
     }
     hipStream_t st = ctx->stream[0];
     // the stations' visit lists (block order) and the rows' table: built and uploaded when the set of blocks or their vectors change
-    uint64_t key = 1469598103934665603ull;
-    for (uint32_t q = 0; q < n; ++q) {
-        key = (key ^ blks[q]) * 1099511628211ull;
-        key = (key ^ (uint64_t)(uintptr_t)rows[q].corr) * 1099511628211ull;
-    }
-    if (key != ctx->osc_key || !ctx->osc_rows) {
+    // (the visit lists depend on the blocks only; which chain's corrections a block is read from changes from iteration to iteration -- the
+    //  rows' table is uploaded again when it does, 32 bytes per block)
+    uint64_t key = 1469598103934665603ull ^ (uint64_t)n;
+    for (uint32_t q = 0; q < n; ++q) key = (key ^ blks[q]) * 1099511628211ull;
+    if (key == ctx->osc_key && ctx->osc_rows) {
+        if (ctx->osc_rows_host.size() != (size_t)n * sizeof(OscRow) || memcmp(ctx->osc_rows_host.data(), rows.data(), (size_t)n * sizeof(OscRow))) {
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpy(ctx->osc_rows, rows.data(), (size_t)n * sizeof(OscRow), hipMemcpyHostToDevice));
+            ctx->osc_rows_host.assign((const uint8_t*)rows.data(), (const uint8_t*)rows.data() + (size_t)n * sizeof(OscRow));
+        }
+    } else {
         HIPCHK(hipStreamSynchronize(st));
         for (void* p : {ctx->osc_rows, (void*)ctx->osc_off, ctx->osc_visits})
             if (p) hipFree(p);
@@ -1828,6 +1834,7 @@ int dnagpu_osc_blocks(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const i
         HIPCHK(hipMemcpy(ctx->osc_rows, rows.data(), (size_t)n * sizeof(OscRow), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ctx->osc_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ctx->osc_visits, visits.data(), visits.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        ctx->osc_rows_host.assign((const uint8_t*)rows.data(), (const uint8_t*)rows.data() + (size_t)n * sizeof(OscRow));
         ctx->osc_key = key;
     }
     launch_osc_update_stations((const OscRow*)ctx->osc_rows, ctx->osc_off, ctx->osc_visits, (uint32_t)ctx->osc_stations, ctx->osc_prev, ctx->osc_seen,
@@ -1905,7 +1912,7 @@ int dnagpu_form_rhs(dnagpu_ctx* ctx, int chain, uint32_t blk) {
 int dnagpu_form_rhs_batched(dnagpu_ctx* ctx, int chain, int nb, const uint32_t* blks) {
     CHK_CTX();
     CHK_CHAIN();
-    if (nb < 1 || nb > BATCH_MAX || !blks) return fail(ctx, DNAGPU_EINVAL, "form_rhs_batched: bad arguments");
+    if (nb < 1 || nb > BLOCK_BATCH_MAX || !blks) return fail(ctx, DNAGPU_EINVAL, "form_rhs_batched: bad arguments");
     RhsBatch rb{};
     for (int q = 0; q < nb; ++q) {
         Block* b = find_block(ctx, blks[q]);
@@ -2862,6 +2869,7 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
             const dnagpu_chain_step& st = steps[s];
             if (s == f) matrix_only = st.matrix_only != 0;
             if ((st.matrix_only != 0) != matrix_only) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a batch mixes steps of two kinds");
+            if (matrix_only && l - f > (uint32_t)BLOCK_BATCH_MAX) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a batch of kept blocks is too large");
             if (matrix_only) {
                 if (!st.n_stn || st.n_src < 1 || st.n_src > CB_SRC_MAX || (st.n_con && (!st.con_stn || !st.con_w9))) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad step");
                 if (3 * st.n_stn > SMALL_STEP_MAX) return DNAGPU_ETOOLARGE;
@@ -3021,31 +3029,34 @@ int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, s
     const uint32_t first = plan->batch_first[batch], nb = plan->batch_first[batch + 1] - first;
     const dnagpu_chain_plan::Shape sh = plan->shape[batch];
     if (!sh.npp) return fail(ctx, DNAGPU_EINVAL, "chain_plan_run: a batch of kept blocks (dnagpu_partial_complete_factor_planned takes those)");
-    int rc = ensure_batch_ws(ctx, chain, (int)nb, sh.npp, batch_panel_cols(sh.nip, sh.njp));
+    // The members' matrices and panels live in scratch of the plan's own size on this chain -- NOT in the chain's batch workspaces, which are
+    // as large as the largest BLOCK the chain has batched (a network of large blocks with small junctions: 3 GB per member) --; member 0's
+    // panels are the chain's W, as in every batched call.
+    int rc = ensure_ws(ctx, chain, sh.npp);
     if (rc) return rc;
     InvWorkspace& ws = ctx->ws[chain];
     hipStream_t st = ctx->stream[chain];
     gemm_profile_close(ws);
     const CbStep* table = (const CbStep*)plan->table + first;
+    const size_t wspan = ((size_t)batch_panel_cols(sh.nip, sh.njp) + 128) * sh.npp, msq = (size_t)sh.npp * sh.npp;
+    const size_t per = msq + wspan + (plan->keeps ? 0 : msq);
+    if (ctx->plan_scratch_cap[chain] < (size_t)nb * per) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (ctx->plan_scratch[chain]) hipFree(ctx->plan_scratch[chain]);
+        ctx->plan_scratch[chain] = nullptr;
+        ctx->plan_scratch_cap[chain] = 0;
+        HIPCHK(dnagpu::poison_malloc(&ctx->plan_scratch[chain], (size_t)nb * per * sizeof(double)));
+        ctx->plan_scratch_cap[chain] = (size_t)nb * per;
+    }
     CbMembers mem{};
     double* F[BATCH_MAX];
     double* X[BATCH_MAX];
     double* P[BATCH_MAX];
-    if (!plan->keeps) {
-        const size_t need = (size_t)nb * sh.npp * sh.npp;
-        if (ctx->plan_scratch_cap[chain] < need) {
-            HIPCHK(hipStreamSynchronize(st));
-            if (ctx->plan_scratch[chain]) hipFree(ctx->plan_scratch[chain]);
-            ctx->plan_scratch[chain] = nullptr;
-            ctx->plan_scratch_cap[chain] = 0;
-            HIPCHK(dnagpu::poison_malloc(&ctx->plan_scratch[chain], need * sizeof(double)));
-            ctx->plan_scratch_cap[chain] = need;
-        }
-    }
     for (uint32_t b = 0; b < nb; ++b) {
-        F[b] = b ? ws.bX[b] : ws.X;
-        X[b] = plan->keeps ? plan->X[first + b] : ctx->plan_scratch[chain] + (size_t)b * sh.npp * sh.npp;
-        P[b] = b ? ws.bW[b] : ws.W;
+        double* base = ctx->plan_scratch[chain] + (size_t)b * per;
+        F[b] = base;
+        P[b] = b ? base + msq : ws.W;
+        X[b] = plan->keeps ? plan->X[first + b] : base + msq + wspan;
         mem.F[b] = F[b];
         mem.X[b] = X[b];
     }
@@ -3056,11 +3067,11 @@ int dnagpu_chain_plan_run(dnagpu_ctx* ctx, int chain, dnagpu_chain_plan* plan, s
         InvBatch& bt = ws.batch;
         bt = InvBatch();
         bt.nb = (int)nb;
-        bt.add(F[0], (size_t)sh.npp * sh.npp, F);
-        bt.add(X[0], (size_t)sh.npp * sh.npp, X);
-        bt.add(P[0], ((size_t)ws.bw_cols + 128) * sh.npp, P);
+        bt.add(F[0], msq, F);
+        bt.add(X[0], msq, X);
+        bt.add(P[0], wspan, P);
     }
-    sym_spine_async(ws, ws.X, X[0], (int)sh.npp, (int)(sh.nip / 128), (int)(sh.njp / 128));
+    sym_spine_async(ws, F[0], X[0], (int)sh.npp, (int)(sh.nip / 128), (int)(sh.njp / 128));
     ws.batch = InvBatch();
     launch_cb_post(table, nb, mem, sh.nip, sh.npp, sh.outnp_max, st);
     HIPCHK(hipGetLastError());
@@ -3146,7 +3157,7 @@ int dnagpu_batch_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max, uint32_t k_
     CHK_CTX();
     CHK_CHAIN();
     if (!nb_granted || nb_wanted < 1 || !k_max || k_max > n_max) return fail(ctx, DNAGPU_EINVAL, "batch_reserve: bad arguments");
-    nb_wanted = std::min(nb_wanted, (int)BATCH_MAX);
+    nb_wanted = std::min(nb_wanted, (int)BLOCK_BATCH_MAX);
     const uint32_t njp = pad128(k_max + 1), nip = pad128(n_max - k_max ? n_max - k_max : 1), npp = nip + njp;
     *nb_granted = 1;
     if (nb_wanted > 1) {
@@ -3166,7 +3177,7 @@ int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const u
     CHK_CTX();
     CHK_CHAIN();
     if (failed_member) *failed_member = -1;
-    if (nb < 1 || nb > BATCH_MAX || !blks || !con_stn || !con_w9 || !n_con || !idx_keep || !k || !red || !keep)
+    if (nb < 1 || nb > BLOCK_BATCH_MAX || !blks || !con_stn || !con_w9 || !n_con || !idx_keep || !k || !red || !keep)
         return fail(ctx, DNAGPU_EINVAL, "block_form_reduce_batched: bad arguments");
     Block* blk[BATCH_MAX];
     uint32_t nip = 0, njp = 0, npp = 0;
@@ -3295,7 +3306,7 @@ int dnagpu_partial_complete_factor_batched(dnagpu_ctx* ctx, int chain, int nb, d
     CHK_CTX();
     CHK_CHAIN();
     if (failed_member) *failed_member = -1;
-    if (nb < 1 || nb > BATCH_MAX || !pf || !kk) return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_batched: bad arguments");
+    if (nb < 1 || nb > BLOCK_BATCH_MAX || !pf || !kk) return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_batched: bad arguments");
     for (int b = 0; b < nb; ++b) {
         if (!pf[b] || !pf[b]->valid || !pf[b]->spine || !kk[b] || kk[b]->n != pf[b]->nj || pf[b]->nip != pf[0]->nip || pf[b]->njp != pf[0]->njp)
             return fail(ctx, DNAGPU_EINVAL, "partial_complete_factor_batched: bad arguments");
@@ -3327,7 +3338,7 @@ int dnagpu_partial_complete_factor_batched(dnagpu_ctx* ctx, int chain, int nb, d
 int dnagpu_partial_finish_batched(dnagpu_ctx* ctx, int chain, int nb, dnagpu_partial* const* pf, dnagpu_matrix* const* inv) {
     CHK_CTX();
     CHK_CHAIN();
-    if (nb < 1 || nb > BATCH_MAX || !pf || !inv) return fail(ctx, DNAGPU_EINVAL, "partial_finish_batched: bad arguments");
+    if (nb < 1 || nb > BLOCK_BATCH_MAX || !pf || !inv) return fail(ctx, DNAGPU_EINVAL, "partial_finish_batched: bad arguments");
     for (int b = 0; b < nb; ++b) {
         if (!pf[b] || !pf[b]->factored || !pf[b]->spine || !inv[b] || pf[b]->n > inv[b]->n_max || pf[b]->nip != pf[0]->nip || pf[b]->njp != pf[0]->njp)
             return fail(ctx, DNAGPU_EINVAL, "partial_finish_batched: bad arguments");

@@ -347,7 +347,7 @@ private:
     };
     struct lock_stage_t { std::vector<lock_lane_t> lanes; }; // lanes of a stage are independent of each other; stages follow each other
     std::vector<lock_stage_t> lock_stages_;
-    std::vector<UINT32> lock_batch_slot_;                    // per batch of the plan: run / DNAGPU_BATCH_MAX of its members
+    std::vector<UINT32> lock_batch_slot_;                    // per batch of the plan: run / DNAGPU_CHAIN_BATCH_MAX of its members
     dnagpu_chain_plan* lock_plan_ = nullptr;
     std::vector<dnagpu_matrix*> lock_mats_;                  // the merged systems of the runs (owned)
     bool lockstep_ok_ = false;

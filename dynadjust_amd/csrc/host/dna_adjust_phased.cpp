@@ -1898,8 +1898,8 @@ void dna_adjust::PrepareLockstepChains() {
         const double n = 3.0 * n_stn, nj = 3.0 * (double)D.keep.size(), ni = n - nj;
         return ni * ni * ni / 3.0 + ni * ni * nj + ni * nj * nj;
     };
-    // a group = one step of every run that has it, in batches of DNAGPU_BATCH_MAX
-    // (a run stays in the same batch slot -- run / DNAGPU_BATCH_MAX -- through all groups: a slot's batches follow each other on one chain)
+    // a group = one step of every run that has it, in batches of DNAGPU_CHAIN_BATCH_MAX
+    // (a run stays in the same batch slot -- run / DNAGPU_CHAIN_BATCH_MAX -- through all groups: a slot's batches follow each other on one chain)
     struct pending_t { std::function<double()> make; bool block_step; int run; double ref_flops; };
     std::vector<UINT32> batch_slot;
     auto close_group = [&](lock_lane_t& lane, std::vector<pending_t>& members) {
@@ -1912,8 +1912,8 @@ void dna_adjust::PrepareLockstepChains() {
             fl += members[i].make();
             ref += members[i].ref_flops;
             nblk += members[i].block_step ? 1u : 0u;
-            const int slot = members[i].run / DNAGPU_BATCH_MAX;
-            if (i + 1 == members.size() || members[i + 1].run / DNAGPU_BATCH_MAX != slot) {
+            const int slot = members[i].run / DNAGPU_CHAIN_BATCH_MAX;
+            if (i + 1 == members.size() || members[i + 1].run / DNAGPU_CHAIN_BATCH_MAX != slot) {
                 batch_first.push_back((UINT32)steps.size());
                 batch_slot.push_back((UINT32)slot);
             }
@@ -2129,7 +2129,7 @@ void dna_adjust::PrepareLockstepChains() {
         }
         // level 3: both chains inside every run, from the boundary values of level 2 (CondensedForwardBlock / CondensedReverseBlock as data)
         // (a lane per direction and batch slot: the slots of a direction are independent of each other and go to chains of their own)
-        const int slots = (W + DNAGPU_BATCH_MAX - 1) / DNAGPU_BATCH_MAX;
+        const int slots = (W + DNAGPU_CHAIN_BATCH_MAX - 1) / DNAGPU_CHAIN_BATCH_MAX;
         stages.emplace_back();
         stages.back().lanes.resize((size_t)(2 * slots));
         auto block_step = [&](UINT32 k, int dir) -> double {
@@ -2166,7 +2166,7 @@ void dna_adjust::PrepareLockstepChains() {
             return add_step(std::move(d), n_src, src, junction, out, 1, (UINT32)Bk.keep.size());
         };
         for (int slot = 0; slot < slots; ++slot) {
-            const int r_lo = slot * DNAGPU_BATCH_MAX, r_hi = std::min(W, r_lo + DNAGPU_BATCH_MAX);
+            const int r_lo = slot * DNAGPU_CHAIN_BATCH_MAX, r_hi = std::min(W, r_lo + DNAGPU_CHAIN_BATCH_MAX);
             for (UINT32 j = 0; j <= longest; ++j) {
                 std::vector<pending_t> members;
                 for (int r = r_lo; r < r_hi; ++r) {

@@ -13,7 +13,7 @@ enum KMode { KM_FULL = 0, KM_LE_J = 1, KM_GE_J = 2, KM_LE_I = 3, KM_GE_I = 4 };
 // an element offset of their own (their buffers are separate allocations).  The workgroups of member 1 follow those of member 0
 // in the same launch: no launch boundary, no partly filled last wave between them, and the short launches at the bottom of the
 // recursion have nb times the tiles (sym_inverse.h: InvBatch).
-constexpr int BATCH_MAX = 16;
+constexpr int BATCH_MAX = 32;      // (members of a merged launch: 32 for the steps of a chain plan, include/dnagpu.h DNAGPU_CHAIN_BATCH_MAX; block batches stay at 16)
 
 struct GemmArgs {
     const double* A;

@@ -110,8 +110,8 @@ struct CbStep {
     uint32_t blk_o[SMALL_STEP_BLOCKS], blk_h[SMALL_STEP_BLOCKS];
 };
 struct CbMembers {
-    double* F[16];          // the matrices the members of a batch are factored in (the chain's workspaces)
-    double* X[16];          // ... and where their factors go: the plan's kept factors, or scratch of the chain when the plan keeps none
+    double* F[32];          // the matrices the members of a batch are factored in (the chain's workspaces)
+    double* X[32];          // ... and where their factors go: the plan's kept factors, or scratch of the chain when the plan keeps none
 };
 // members = table[0 .. nb): the right-hand sides and linearisation points (one workgroup per member) ...
 void launch_cb_rhs(const CbStep* table, uint32_t nb, hipStream_t s);

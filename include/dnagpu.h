@@ -384,7 +384,7 @@ void dnagpu_small_batch_destroy(dnagpu_ctx* ctx, dnagpu_small_batch* sb);
  * few systems into one (reduced systems: matrix + right-hand side in the attached vector; junction matrices in information form),
  * adds constraint blocks, eliminates all stations but `keep` and leaves their complement in `out` (an information-form junction with
  * the kept stations' estimates, or a reduced system).  dnagpu_chain_plan_create puts n_steps such steps on the device, grouped into
- * batches (batch q = steps batch_first[q] .. batch_first[q + 1] - 1, at most DNAGPU_BATCH_MAX, independent of each other; its members are
+ * batches (batch q = steps batch_first[q] .. batch_first[q + 1] - 1, at most DNAGPU_CHAIN_BATCH_MAX -- DNAGPU_BATCH_MAX for matrix_only steps --, independent of each other; its members are
  * eliminated in one padded shape, the largest of theirs) and owns their factors; dnagpu_chain_plan_run takes one batch through assembly,
  * elimination (factor kept, light form) and output as ONE sequence of merged launches, without waiting (the verdict of the eliminations
  * stays in the chain: dnagpu_chain_hold_info / _take_info); dnagpu_chain_plan_run_rhs takes the steps of batches q_lo .. q_hi - 1
@@ -458,6 +458,7 @@ int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max);
  * n_max unknowns with k_max kept ones: *nb_granted = nb_wanted, or 1 when they do not fit (nothing stays allocated then beside the chain's
  * own workspace; the caller runs the blocks one at a time).  The batched calls allocate the same on demand and fail with DNAGPU_ENOMEM. */
 #define DNAGPU_BATCH_MAX 16
+#define DNAGPU_CHAIN_BATCH_MAX 32   /* steps per batch of a chain plan (dnagpu_chain_plan_create) */
 int dnagpu_batch_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max, uint32_t k_max, int nb_wanted, int* nb_granted);
 int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const uint32_t* blks, const uint32_t* const* con_stn,
                                      const double* const* con_w9, const size_t* n_con, const uint32_t* const* idx_keep, const size_t* k,

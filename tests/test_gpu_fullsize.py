@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 from dynadjust_amd import adjust
+from tests import dnaformats as F
 from tests import fullsize
 
 pytestmark = pytest.mark.gpu
@@ -251,3 +252,61 @@ def test_cfg4_full_size_properties(built, tmp_path):
                                     "shared_stations_max_abs_dx_m": dx, "shared_stations_max_rel_dvar": dv, "memory_plan": after})
     assert dx < TOL_X and dv < TOL_V, (dx, dv)
     a.close()
+
+
+def test_default_cut_project_of_a_million_stations(built, tmp_path):
+    """a project of the national size at the reference's DEFAULT cut (dnasegment: 150 stations per block, dnaoptions.hpp:382): ten contiguous
+    networks of 666 blocks (n = 600) each in one set of files -- 1 000 000 stations, 6 660 blocks, ten network ids (the networks generated
+    independently and merged, tests/dnaformats.py::merge_networks).  The junction chains of all ten networks advance together in lock step
+    (60 runs, dna_adjust::LockstepChains; one network's geometry is pinned against the oracle by `dnasegment150` above).  No oracle runs this in
+    the test's time; the size-independent properties: convergence, sigma-zero inside its 95 % limits at 5 000 100 degrees of freedom, every
+    station within 0.25 m of the truth, neighbouring blocks equal on their shared stations to 1e-8 m / 1e-8 relative, networks independent of
+    each other (the first network's estimates are those of the same network adjusted alone, to rounding)."""
+    parts = []
+    for q in range(10):
+        info = adjust.write_synthetic_network(str(tmp_path), f"part{q}", 2000, 50, 266666, 1, seed=20260930 + q, rows_lo=3, rows_hi=3)
+        parts.append(str(tmp_path / f"part{q}"))
+    F.merge_networks(parts, str(tmp_path / "net"))
+    truth = np.concatenate([np.fromfile(p + ".truth", dtype=np.float64) for p in parts]).reshape(-1, 3)
+    nb1, ns1 = info["blocks"], info["stations"]
+    p = adjust.ProjectSettings("net", str(tmp_path), adjust_mode=adjust.PhasedMode, multi_thread=True)
+    a = adjust.DnaAdjust()
+    a.PrepareAdjustment(p)
+    assert a.blockCount() == 10 * nb1 and a.chain_runs() >= 40
+    import time
+    t0 = time.perf_counter()
+    st = a.AdjustNetwork()
+    dt = time.perf_counter() - t0
+    assert st == adjust.ADJUST_SUCCESS and a.CurrentIteration() <= 5
+    a.GenerateStatistics()
+    assert a.GetDegreesOfFreedom() == 10 * (3 * 266666 - (3 * ns1 - 12))
+    assert a.GetChiSquaredLowerLimit() < a.GetSigmaZero() < a.GetChiSquaredUpperLimit()
+    err = float(np.abs(a.adjusted_coordinates(10 * ns1) - truth).max())
+    assert err < 0.25
+    dx = dv = 0.0
+    for k in (0, nb1 // 2, nb1 - 2, nb1, 5 * nb1 + 7, 10 * nb1 - 2):
+        s0, s1 = a.block_stations(k), a.block_stations(k + 1)
+        x0, x1 = a.block_estimates(k).reshape(-1, 3), a.block_estimates(k + 1).reshape(-1, 3)
+        common, i0, i1 = np.intersect1d(s0, s1, return_indices=True)
+        assert common.size == 50
+        dx = max(dx, float(np.abs(x0[i0] - x1[i1]).max()))
+        d0 = fullsize.sample_packed(a.block_variances_packed(k), 3 * s0.size)[0].reshape(-1, 3)
+        d1 = fullsize.sample_packed(a.block_variances_packed(k + 1), 3 * s1.size)[0].reshape(-1, 3)
+        assert d0.min() > 0 and d1.min() > 0
+        dv = max(dv, float(np.abs(d0[i0] - d1[i1]).max() / d0.max()))
+    # the last block of one network and the first of the next share nothing
+    assert np.intersect1d(a.block_stations(nb1 - 1), a.block_stations(nb1)).size == 0
+    x_first = [a.block_estimates(k).copy() for k in (0, nb1 // 3, nb1 - 1)]
+    iters = a.CurrentIteration()
+    sigma = a.GetSigmaZero()
+    a.close()
+    # the first network alone
+    b = adjust.DnaAdjust()
+    b.PrepareAdjustment(adjust.ProjectSettings("part0", str(tmp_path), adjust_mode=adjust.PhasedMode, multi_thread=True))
+    assert b.AdjustNetwork() == adjust.ADJUST_SUCCESS
+    alone = max(float(np.abs(b.block_estimates(k) - x).max()) for k, x in zip((0, nb1 // 3, nb1 - 1), x_first))
+    b.close()
+    _record("default_cut_project_full_size.json", {"stations": 10 * ns1, "blocks": 10 * nb1, "networks": 10, "iterations": iters, "adjust_seconds": dt,
+                                                   "sigma_zero": sigma, "max_abs_error_vs_truth_m": err, "shared_stations_max_abs_dx_m": dx,
+                                                   "shared_stations_max_rel_dvar": dv, "first_network_alone_max_abs_dx_m": alone})
+    assert dx < TOL_X and dv < TOL_V and alone < 5e-9, (dx, dv, alone)
