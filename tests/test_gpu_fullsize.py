@@ -288,7 +288,7 @@ def test_default_cut_project_of_a_million_stations(built, tmp_path):
         s0, s1 = a.block_stations(k), a.block_stations(k + 1)
         x0, x1 = a.block_estimates(k).reshape(-1, 3), a.block_estimates(k + 1).reshape(-1, 3)
         common, i0, i1 = np.intersect1d(s0, s1, return_indices=True)
-        assert common.size == 50
+        assert 40 <= common.size <= 50            # (the junction row of the next strip: the stations a measurement of this block ends at)
         dx = max(dx, float(np.abs(x0[i0] - x1[i1]).max()))
         d0 = fullsize.sample_packed(a.block_variances_packed(k), 3 * s0.size)[0].reshape(-1, 3)
         d1 = fullsize.sample_packed(a.block_variances_packed(k + 1), 3 * s1.size)[0].reshape(-1, 3)
