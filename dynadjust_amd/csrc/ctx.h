@@ -72,6 +72,8 @@ namespace dnagpu {
 
 struct Block {
     uint32_t n_stn = 0, n_bl = 0;
+    bool wb_own = false;        // dnagpu_block_set_terrestrial has given wb[] allocations of their own (GNSS + terrestrial vectors)
+    void* arena = nullptr;      // dnagpu_block_create: everything of a fixed size in one allocation (stations, the vectors of every chain, baselines)
     // stations (3*n_stn)
     // "estimated" state exists once per chain (the reference's v_*_ / v_*R_ twins,
     // dnaadjust.hpp:1340-1348) so that the forward and the reverse/combine chain can

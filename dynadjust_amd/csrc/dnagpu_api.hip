@@ -270,11 +270,12 @@ Block* find_block(dnagpu_ctx* ctx, uint32_t blk) {
 }
 
 void free_block(Block& b) {
+    // (dnagpu_block_create's arrays -- stations, vectors per chain, baselines -- are one arena)
+    if (b.arena) hipFree(b.arena);
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c)
-        for (void* p : {(void*)b.x_est[c], (void*)b.rhs[c], (void*)b.corr[c], (void*)b.wb[c], (void*)b.b[c], (void*)b.red[c], (void*)b.tb[c], (void*)b.trow[c]})
+        for (void* p : {(void*)b.tb[c], (void*)b.trow[c], b.wb_own ? (void*)b.wb[c] : nullptr})
             if (p) hipFree(p);
-    void* ptrs[] = {b.x_orig, b.x_rig, b.s1, b.s2, b.obs, b.Wblk,
-                    b.vec_wrow, b.vec_c0, b.vec_k, b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc,
+    void* ptrs[] = {b.Wblk, b.pair_row, b.pair_col, b.pair_off, b.pair_ent, b.inc_off, b.inc,
                     b.t_type, b.t_stn, b.t_blk0, b.t_vec0, b.t_val, b.t_pre, b.t_var, b.t_ih, b.t_th, b.s_llh, b.s_geoid, b.s_defl,
                     b.ds_a, b.ds_b, b.ds_pq, b.ds_w, b.ds_row0, b.ds_k, b.ds_woff, b.ds_wts, b.osc_gidx, b.osc_visit, b.corr_keep, b.schur_idx[0], b.schur_idx[1], b.schur_map[0], b.schur_map[1], b.schur_spos[0], b.schur_spos[1]};
     for (void* p : ptrs)
@@ -1026,10 +1027,12 @@ int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint
     b.n_bl = n_baselines;
     size_t nv = std::max<size_t>(3 * (size_t)n_stations, 1) * sizeof(double);
     size_t nb = std::max<size_t>(n_baselines, 1);
-    hipError_t e = hipSuccess;
-    auto A = [&](void** p, size_t bytes) {
-        if (e == hipSuccess) e = dnagpu::poison_malloc(p, bytes);
-    };
+    // One allocation per block for everything of a fixed size (a dnasegment-default cut of a million stations is 20 000 device blocks:
+    // condensed blocks and run systems included -- 56 allocations and 16 memsets each were most of PrepareAdjustment's nine seconds):
+    // sizes first, then the pointers into the arena.
+    struct Slot { void** p; size_t bytes; };
+    std::vector<Slot> slots;
+    auto A = [&](void** p, size_t bytes) { slots.push_back({p, bytes}); };
     A((void**)&b.x_orig, nv);
     A((void**)&b.x_rig, nv);
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
@@ -1046,13 +1049,24 @@ int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint
     A((void**)&b.vec_wrow, nb * sizeof(uint32_t));
     A((void**)&b.vec_c0, nb * sizeof(uint32_t));
     A((void**)&b.vec_k, nb * sizeof(uint32_t));
+    size_t total = 0;
+    for (const Slot& sl : slots) total += (sl.bytes + 255) & ~(size_t)255;
+    hipError_t e = dnagpu::poison_malloc(&b.arena, total);
     if (e != hipSuccess) {
-        free_block(b);
+        (void)hipGetLastError();
         return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "block allocation", e);
     }
+    {
+        uint8_t* at = (uint8_t*)b.arena;
+        for (const Slot& sl : slots) {
+            *sl.p = at;
+            at += (sl.bytes + 255) & ~(size_t)255;
+        }
+    }
+    // (right-hand sides and corrections start at zero; with DNAGPU_POISON_ALLOC the rest keeps its NaN)
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        hipMemset(b.rhs[c], 0, nv);
-        hipMemset(b.corr[c], 0, nv);
+        hipMemsetAsync(b.rhs[c], 0, nv, ctx->stream[0]);
+        hipMemsetAsync(b.corr[c], 0, nv, ctx->stream[0]);
     }
     ctx->blocks[blk] = b;
     return DNAGPU_OK;
@@ -1074,9 +1088,11 @@ int dnagpu_block_set_stations(dnagpu_ctx* ctx, uint32_t blk, const double* xyz) 
     if (!b || (!xyz && b->n_stn)) return fail(ctx, DNAGPU_EINVAL, "block_set_stations: bad arguments");
     size_t bytes = 3 * (size_t)b->n_stn * sizeof(double);
     if (!bytes) return DNAGPU_OK;
-    HIPCHK(hipMemcpy(b->x_orig, xyz, bytes, hipMemcpyHostToDevice));
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) HIPCHK(hipMemcpy(b->x_est[c], xyz, bytes, hipMemcpyHostToDevice));
+    // one upload, then one launch that copies it to the originals and to every chain's estimates (ten blocking copies before)
     HIPCHK(hipMemcpy(b->x_rig, xyz, bytes, hipMemcpyHostToDevice));
+    launch_reset_block(b->x_rig, b->x_orig, b->x_rig, b->x_est, b->b, DNAGPU_NUM_CHAINS, false, b->s1, b->s2, b->obs, b->n_stn, b->n_bl, ctx->stream[0]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream[0]));
     return DNAGPU_OK;
 }
 
@@ -1248,10 +1264,11 @@ int dnagpu_block_set_terrestrial(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_t, co
     if (cluster_cml_pos) b->h_cpos.assign(cluster_cml_pos, cluster_cml_pos + n_clusters);
     // the W b vectors of the GNSS measurements are followed by the terrestrial ones
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        if (b->wb[c]) hipFree(b->wb[c]);
+        if (b->wb[c] && b->wb_own) hipFree(b->wb[c]);      // (the arena's vectors are not freed one by one)
         b->wb[c] = nullptr;
         HIPCHK(dnagpu::poison_malloc(&b->wb[c], std::max<size_t>((size_t)b->n_bl + nv, 1) * 3 * sizeof(double)));
     }
+    b->wb_own = true;
     if (!n_t) return DNAGPU_OK;
     auto upv = [&](void** dev, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = dnagpu::poison_malloc(dev, bytes);
