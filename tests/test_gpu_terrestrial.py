@@ -201,7 +201,7 @@ def test_reference_urban_sample_on_the_device(built, golden_dir, tmp_path, phase
 @pytest.mark.parametrize("phased,kw", [(False, {}), (True, {"schur_carry": False}), (True, {"schur_carry": True, "multi_thread": True})])
 def test_oscillation_diagnostics_on_the_device(built, orc, tmp_path, phased, kw):
     """dna_adjust::UpdateIterationDiagnostics / PrintOscillationSummary / PrintSuspectMeasurementSummary (ADJ:7450-7780) behind the reference's
-    members: the corrections of every iteration are compared on the device (osc_update_kernel, one record per station of the network), the host
+    members: the corrections of every iteration are compared on the device (osc_update_stations_kernel: one launch for all blocks, a thread takes a station through its visits in block order; one record per station of the network), the host
     keeps the history.  On a network that cannot settle (two stations held across their lines by two distances too short to meet) the device
     records the same stations, iterations and cycle counts as the oracle's restatement, the same magnitudes (the iteration is chaotic: rounding
     differences double every iteration -- 1e-6 relative after ten), the last correction rotated into the station's local frame, and prints the

@@ -1,6 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-for w in dnasegment150 smallblocks dnasegment150_10x cfg3; do
-  echo "$w: $(DNAGPU_PHASE_TIMES=1 timeout 600 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c100-230)"
-done
-timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_matrix.py -q -m gpu -x 2>&1 | tail -3
+DNAGPU_POISON_ALLOC=1 timeout 1500 python -m pytest tests/test_gpu_batch.py tests/test_gpu_distributed.py tests/test_gpu_exact.py tests/test_gpu_matrix.py tests/test_boundary_cpp.py tests/test_gpu_fullsize.py -q -m gpu -x --deselect tests/test_gpu_fullsize.py::test_cfg4_full_size_properties 2>&1 | tail -4
