@@ -1,3 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-DNAGPU_POISON_ALLOC=1 timeout 1500 python -m pytest tests/test_gpu_batch.py tests/test_gpu_distributed.py tests/test_gpu_exact.py tests/test_gpu_matrix.py tests/test_boundary_cpp.py tests/test_gpu_fullsize.py -q -m gpu -x --deselect tests/test_gpu_fullsize.py::test_cfg4_full_size_properties 2>&1 | tail -4
+mkdir -p gpurun_out
+T0=$SECONDS
+timeout 1500 python -m pytest tests -q -m gpu -x --durations=10 > gpurun_out/gpu_suite_full.txt 2>&1
+grep -n "passed\|failed\|error" gpurun_out/gpu_suite_full.txt | tail -3
+grep "s call" gpurun_out/gpu_suite_full.txt | head -10 > gpurun_out/gpu_suite.txt
+grep "passed\|failed" gpurun_out/gpu_suite_full.txt | tail -1 >> gpurun_out/gpu_suite.txt
+echo "suite: $((SECONDS - T0)) s" >> gpurun_out/gpu_suite.txt
+cat gpurun_out/gpu_suite.txt
