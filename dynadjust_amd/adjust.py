@@ -35,7 +35,7 @@ class ProjectSettings:
                  max_iterations=10, iteration_threshold=0.0005, free_std_dev=10.0, fixed_std_dev=1e-6,
                  scale_normals_to_unity=False, device=0, confidence_interval=95.0, output_tstat=False, output_folder=None,
                  reuse_inverses=False, schur_carry=True, keep_factors=True, stage=False, dist_rank=0, dist_world=1, devices=None,
-                 dist_transport=None, dist_two_level=True, defer_variances=2, batch_blocks=16, reuse_factors=True, chain_runs=-1):
+                 dist_transport=None, dist_two_level=True, defer_variances=2, batch_blocks=32, reuse_factors=True, chain_runs=-1):
         self.bst_file = self.bms_file = self.asl_file = self.seg_file = None
         self.network_name = network_name          # g.network_name
         self.output_folder = output_folder if output_folder is not None else folder   # g.output_folder
@@ -143,7 +143,7 @@ class DnaAdjust:
         s.dist_transport = self._transport
         s.dist_two_level = int(bool(getattr(p, "dist_two_level", True)))
         s.defer_variances = int(getattr(p, "defer_variances", 2))
-        s.batch_blocks = int(getattr(p, "batch_blocks", 16))
+        s.batch_blocks = int(getattr(p, "batch_blocks", 32))
         s.reuse_factors = int(bool(getattr(p, "reuse_factors", True)))
         s.chain_runs = int(getattr(p, "chain_runs", -1))
         return s

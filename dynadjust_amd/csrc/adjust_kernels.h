@@ -54,14 +54,15 @@ struct FormMember {
     const double* rhs;
     uint32_t n_pairs, n_gnss_blk, terr_shift, n_con, rhs_row;
 };
-struct FormBatch { FormMember m[16]; };
+struct FormBatch { FormMember m[32]; };
+static_assert(sizeof(FormBatch) <= 3968, "the members of a batch travel as kernel arguments (4 KB)");
 void launch_form_ordered_batch(const FormBatch& fb, int nb, uint32_t ld, uint32_t npp, hipStream_t s);
 struct ExtractMember {
     const double* T;
     double *X, *S, *r;
     uint32_t nj, npj;
 };
-struct ExtractBatch { ExtractMember m[16]; };
+struct ExtractBatch { ExtractMember m[32]; };
 void launch_extract_batch(const ExtractBatch& eb, int nb, uint32_t nip, uint32_t npp, uint32_t npj_max, hipStream_t s);
 struct RhsMember {
     const double* wblk;
@@ -72,7 +73,7 @@ struct RhsMember {
     double* rhs;
     uint32_t n_vec, n_stn;
 };
-struct RhsBatch { RhsMember m[16]; };
+struct RhsBatch { RhsMember m[32]; };
 void launch_form_rhs_batch(const RhsBatch& rb, int nb, hipStream_t s);
 struct UnpermuteMember {
     const double* F;
@@ -80,7 +81,7 @@ struct UnpermuteMember {
     double* inv;
     uint32_t n, np;
 };
-struct UnpermuteBatch { UnpermuteMember m[16]; };
+struct UnpermuteBatch { UnpermuteMember m[32]; };
 void launch_unpermute_batch(const UnpermuteBatch& ub, int nb, uint32_t npp, hipStream_t s);
 struct OscRow {
     const double* corr;

@@ -50,7 +50,7 @@ void dnaadj_default_settings(dnaadj_settings* s) {
     s->keep_factors = 1;
     s->dist_two_level = 1;
     s->defer_variances = 2;
-    s->batch_blocks = 16;
+    s->batch_blocks = 32;
     s->reuse_factors = 1;
     s->chain_runs = -1;
 }
@@ -101,7 +101,7 @@ static void to_project_settings(const dnaadj_settings* s, dynadjust::project_set
     if (s->dist_transport) p.a.dist_transport = s->dist_transport;
     p.a.dist_two_level = (uint16_t)(s->dist_two_level ? 1 : 0);
     p.a.defer_variances = (uint16_t)(s->defer_variances < 0 ? 0 : s->defer_variances > 2 ? 2 : s->defer_variances);
-    p.a.batch_blocks = (uint16_t)(s->batch_blocks < 0 ? 0 : s->batch_blocks > 16 ? 16 : s->batch_blocks);
+    p.a.batch_blocks = (uint16_t)(s->batch_blocks < 0 ? 0 : s->batch_blocks > DNAGPU_BATCH_MAX ? DNAGPU_BATCH_MAX : s->batch_blocks);
     p.a.reuse_factors = (uint16_t)(s->reuse_factors ? 1 : 0);
     p.a.chain_runs = s->chain_runs < 0 ? -1 : s->chain_runs > 4096 ? 4096 : s->chain_runs;
     if (s->network_name) p.g.network_name = s->network_name;

@@ -235,7 +235,7 @@ struct adjust_settings {
     // schedule as ONE batch of up to this many members: merged launches, in lock step (include/dnagpu.h, dnagpu_*_batched).  The
     // reference's blocks have no such coupling -- its Solve() calls follow each other (ADJ:2812, ADJ:3512, ADJ:3556) -- and every
     // member's results are the bits of the unbatched calls.  0 / 1: off.  DNAGPU_BATCH overrides.
-    UINT16 batch_blocks = 16;
+    UINT16 batch_blocks = 32;
     // Not in the reference's phased mode (it has the same licence in simultaneous mode: SolveTry(CurrentIteration() < 2 ||
     // ContainsNonGPS()), dnaadjust.cpp:2452-2457): in a GNSS-only network neither the design nor the weights move with the estimates,
     // so the normals of every block -- and with them every factor of the condensed schedule: the blocks' light factors, the kept

@@ -65,7 +65,7 @@ typedef struct {
                                   completed factor and the inverses (rigorous variance matrices) are formed once, after the last iteration;
                                   2 = the condensing step also stops at the factor (no inverse of the eliminated part until the end),
                                   0 = an inverse per block and iteration like dna_adjust::Solve */
-    int batch_blocks;          /* condensed schedule with kept factors (default 16 = DNAGPU_BATCH_MAX): blocks of one shape go through its large
+    int batch_blocks;          /* condensed schedule with kept factors (default 32 = DNAGPU_BATCH_MAX): blocks of one shape go through its large
                                   steps as one batch of up to this many members -- merged launches, in lock step (include/dnagpu.h,
                                   dnagpu_*_batched); every member's results are the bits of the unbatched calls.  0 / 1 = off */
     int reuse_factors;         /* device path only (default 1): GNSS-only networks (the reference's own test, dnaadjust.cpp:2457, which it

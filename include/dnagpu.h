@@ -457,7 +457,7 @@ int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max);
  * dnagpu_batch_reserve allocates the members' workspaces on `chain` (a matrix + the panels of a diagonal block each) for nb_wanted blocks of
  * n_max unknowns with k_max kept ones: *nb_granted = nb_wanted, or 1 when they do not fit (nothing stays allocated then beside the chain's
  * own workspace; the caller runs the blocks one at a time).  The batched calls allocate the same on demand and fail with DNAGPU_ENOMEM. */
-#define DNAGPU_BATCH_MAX 16
+#define DNAGPU_BATCH_MAX 32
 #define DNAGPU_CHAIN_BATCH_MAX 32   /* steps per batch of a chain plan (dnagpu_chain_plan_create) */
 int dnagpu_batch_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max, uint32_t k_max, int nb_wanted, int* nb_granted);
 int dnagpu_block_form_reduce_batched(dnagpu_ctx* ctx, int chain, int nb, const uint32_t* blks, const uint32_t* const* con_stn,
