@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- stations adjusted / s of the phased least-squares adjustment hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|small]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg4|cfg4_slice|cfg3_ragged|smallblocks|dnasegment150|dnasegment150_10x|small]
 
 A "step" is one complete dna_adjust::AdjustNetwork() (phased: forward + reverse + combine sweeps,
 iterated to the reference's convergence threshold) on one synthetic network whose matrices and
@@ -11,6 +11,9 @@ coordinates back between steps; file loading and PrepareAdjustment are outside t
 Default workload (N = 1): BASELINE.json configs[2] "synthetic 100k-station / 800k-measurement
 network, phased adjustment, 16 blocks, 1 x MI355X" -- the largest named phased configuration that
 fits one GPU (the metric is quoted on the phased adjustment).
+
+Other workloads: the reference's default cut (dnasegment150: 666 blocks of 150 stations; dnasegment150_10x: a project of ten such networks,
+1M stations), mixed small blocks (smallblocks), cfg2 / cfg4 / cfg4_slice of BASELINE.json, uneven strips (cfg3_ragged).
 
 One JSON line is printed by rank 0 (see DESIGN.md "Measurement" for every field).
 """
