@@ -1,10 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
-T0=$SECONDS
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=10 > gpurun_out/gpu_suite_full.txt 2>&1
-grep "s call" gpurun_out/gpu_suite_full.txt | head -10 > gpurun_out/gpu_suite.txt
-grep "passed\|failed" gpurun_out/gpu_suite_full.txt | tail -1 >> gpurun_out/gpu_suite.txt
-echo "suite: $((SECONDS - T0)) s" >> gpurun_out/gpu_suite.txt
-tail -3 gpurun_out/gpu_suite.txt
-grep -B2 -A12 "Error\|FAILED" gpurun_out/gpu_suite_full.txt | head -40
+B="timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain"
+for i in 1 2 3; do
+  echo "b32: $($B 2>/dev/null | cut -c100-215)"
+  echo "b16: $(DNAGPU_LIB_OVERRIDE=$PWD/variants/libdnagpu_b16.so $B 2>/dev/null | cut -c100-215)"
+done
