@@ -1,7 +1,11 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-B="timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain"
-for i in 1 2 3; do
-  echo "b32: $($B 2>/dev/null | cut -c100-215)"
-  echo "b16: $(DNAGPU_LIB_OVERRIDE=$PWD/variants/libdnagpu_b16.so $B 2>/dev/null | cut -c100-215)"
-done
+mkdir -p gpurun_out/j34
+TAG=cfg5 bash tools/run_cfg4_1gpu.sh --variance-propagation > gpurun_out/j34/cfg5_run.log 2>&1
+cp gpurun_out/cfg4/cfg5.* gpurun_out/j34/ 2>/dev/null
+python - <<'PY'
+import json
+r=json.load(open('gpurun_out/j34/cfg5.json'))
+print(r['ms_per_step'], r['value'], r['roofline']['frac'], r['roofline'].get('frac_min_work'), r['config'].get('variance_propagation_in_step'), r['check'])
+PY
+grep "phase" gpurun_out/j34/cfg5.err | tail -6
