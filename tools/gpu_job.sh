@@ -1,11 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out/j34
-TAG=cfg5 bash tools/run_cfg4_1gpu.sh --variance-propagation > gpurun_out/j34/cfg5_run.log 2>&1
-cp gpurun_out/cfg4/cfg5.* gpurun_out/j34/ 2>/dev/null
-python - <<'PY'
-import json
-r=json.load(open('gpurun_out/j34/cfg5.json'))
-print(r['ms_per_step'], r['value'], r['roofline']['frac'], r['roofline'].get('frac_min_work'), r['config'].get('variance_propagation_in_step'), r['check'])
-PY
-grep "phase" gpurun_out/j34/cfg5.err | tail -6
+for r in 16 24 32 40 48 64; do echo "dnasegment150 chain_runs $r: $(timeout 600 python bench.py --workload dnasegment150 --chain-runs $r --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c179-215)"; done
+for r in 8 16 24 32; do echo "smallblocks chain_runs $r: $(timeout 600 python bench.py --workload smallblocks --chain-runs $r --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c178-215)"; done
+for r in 40 60 96 128; do echo "10x chain_runs $r: $(timeout 900 python bench.py --workload dnasegment150_10x --chain-runs $r --steps 2 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c179-215)"; done
