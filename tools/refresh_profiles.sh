@@ -17,12 +17,13 @@ timeout 900 $B --workload dnasegment150 --steps 3 --warmup 1 2>/dev/null | tail 
 timeout 600 $B --workload dnasegment150 --chain-runs 0 --steps 3 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg 2>/dev/null | tail -1 > $O/${TAG}_bench_dnasegment150_chains_step_by_step.json
 timeout 600 $B --workload smallblocks --chain-runs 0 --steps 3 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg 2>/dev/null | tail -1 > $O/${TAG}_bench_smallblocks_chains_step_by_step.json
 timeout 600 $B --workload cfg3_ragged --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_ragged.json
+timeout 1500 $B --workload dnasegment150_10x --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/${TAG}_bench_dnasegment150_10x.json
 timeout 600 $B --workload cfg4_slice --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg4_slice.json
 timeout 600 $B --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg --variance-propagation 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_variance_propagation.json
 timeout 600 $B --steps 2 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg --stage 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_staged.json
 timeout 600 $B --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg --reference-schedule 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_reference_schedule.json
 DNAGPU_FORCE_DISTRIBUTED=1 timeout 600 $B --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg3_rccl_one_rank.json
-for w in cfg3 smallblocks dnasegment150; do
+for w in cfg3 smallblocks dnasegment150 dnasegment150_10x; do
   DNAGPU_PHASE_TIMES=1 timeout 600 $B --workload $w --steps 1 --warmup 1 --no-cpu-baseline --no-one-chain --no-refactor-leg 2>&1 | grep "^\[phase\]" | tail -40 > $O/${TAG}_${w}_phase_times.txt
 done
 # ---- kernel traces ----
@@ -53,4 +54,5 @@ fi
 # ---- rates and the N-GPU model ----
 { echo "# python tools/gpu_inverse_bench.py on 1 x MI355X (${TAG}), through the C-ABI, best of 3 timed repetitions, one chain"; timeout 300 python $R/tools/gpu_inverse_bench.py 2>/dev/null; } > $O/${TAG}_inverse_rates.txt
 timeout 600 python $R/tools/gpu_rank_share.py > $O/${TAG}_rank_share.txt 2>/dev/null
+# cfg4 / cfg5 at full size on one GPU (7 min each): TAG=cfg4 bash tools/run_cfg4_1gpu.sh ; TAG=cfg5 bash tools/run_cfg4_1gpu.sh --variance-propagation
 ls -la $O
