@@ -1,5 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-for r in 16 24 32 40 48 64; do echo "dnasegment150 chain_runs $r: $(timeout 600 python bench.py --workload dnasegment150 --chain-runs $r --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c179-215)"; done
-for r in 8 16 24 32; do echo "smallblocks chain_runs $r: $(timeout 600 python bench.py --workload smallblocks --chain-runs $r --steps 3 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c178-215)"; done
-for r in 40 60 96 128; do echo "10x chain_runs $r: $(timeout 900 python bench.py --workload dnasegment150_10x --chain-runs $r --steps 2 --warmup 1 --no-cpu-baseline --no-refactor-leg --no-one-chain 2>/dev/null | cut -c179-215)"; done
+T0=$SECONDS
+SKIP_PMC=1 TAG=r05 bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
+echo "total: $((SECONDS - T0)) s"
+for f in gpurun_out/profiles_new/r05_bench_*.json; do echo "$(basename $f): $(cut -c100-215 $f)"; done
+cat gpurun_out/profiles_new/r05_inverse_rates.txt | tail -4
