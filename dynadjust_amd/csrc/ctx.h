@@ -196,6 +196,7 @@ struct dnagpu_ctx {
     uint32_t* osc_off = nullptr;
     void* osc_visits = nullptr;
     uint64_t osc_key = 0;
+    std::vector<uint32_t> osc_blks;          // the block ids the visit lists were built for (osc_key is their hash)
     std::vector<uint8_t> osc_rows_host;      // the rows as uploaded last
     bool hbm_profile = false;
     std::vector<HbmRec> hbm_recs[DNAGPU_NUM_CHAINS];

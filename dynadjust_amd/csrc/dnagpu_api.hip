@@ -1064,10 +1064,19 @@ int dnagpu_block_create(dnagpu_ctx* ctx, uint32_t blk, uint32_t n_stations, uint
         }
     }
     // (right-hand sides and corrections start at zero; with DNAGPU_POISON_ALLOC the rest keeps its NaN)
+    // Each chain's pair -- rhs[c] and corr[c] are neighbours in the arena -- is zeroed by ONE memset on that chain's OWN stream: the chain
+    // streams do not wait for each other (hipStreamNonBlocking), and whatever a chain enqueues on the block next is ordered behind it.
     for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) {
-        hipMemsetAsync(b.rhs[c], 0, nv, ctx->stream[0]);
-        hipMemsetAsync(b.corr[c], 0, nv, ctx->stream[0]);
+        const size_t span = (size_t)((uint8_t*)b.corr[c] - (uint8_t*)b.rhs[c]) + nv;
+        hipError_t em = hipMemsetAsync(b.rhs[c], 0, span, ctx->stream[c]);
+        if (em != hipSuccess) {
+            (void)hipGetLastError();
+            hipDeviceSynchronize();
+            hipFree(b.arena);
+            return fail(ctx, DNAGPU_EHIP, "block allocation: zeroing", em);
+        }
     }
+    ctx->osc_key = 0;       // (the visit lists of dnagpu_osc_blocks describe the blocks that existed when they were built)
     ctx->blocks[blk] = b;
     return DNAGPU_OK;
 }
@@ -1079,6 +1088,7 @@ int dnagpu_block_destroy(dnagpu_ctx* ctx, uint32_t blk) {
     HIPCHK(hipDeviceSynchronize());
     free_block(*b);
     ctx->blocks.erase(blk);
+    ctx->osc_key = 0;       // (dnagpu_osc_blocks: a block of the same id created later may have other stations)
     return DNAGPU_OK;
 }
 
@@ -1824,7 +1834,9 @@ int dnagpu_osc_blocks(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const i
     //  rows' table is uploaded again when it does, 32 bytes per block)
     uint64_t key = 1469598103934665603ull ^ (uint64_t)n;
     for (uint32_t q = 0; q < n; ++q) key = (key ^ blks[q]) * 1099511628211ull;
-    if (key == ctx->osc_key && ctx->osc_rows) {
+    // (the key is a hash: the list of block ids itself decides; dnagpu_block_create / _destroy clear the key, a block's station list is
+    //  set once, by its first visit here)
+    if (key == ctx->osc_key && ctx->osc_rows && ctx->osc_blks.size() == n && !memcmp(ctx->osc_blks.data(), blks, (size_t)n * sizeof(uint32_t))) {
         if (ctx->osc_rows_host.size() != (size_t)n * sizeof(OscRow) || memcmp(ctx->osc_rows_host.data(), rows.data(), (size_t)n * sizeof(OscRow))) {
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipMemcpy(ctx->osc_rows, rows.data(), (size_t)n * sizeof(OscRow), hipMemcpyHostToDevice));
@@ -1852,6 +1864,7 @@ int dnagpu_osc_blocks(dnagpu_ctx* ctx, uint32_t n, const uint32_t* blks, const i
         HIPCHK(hipMemcpy(ctx->osc_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ctx->osc_visits, visits.data(), visits.size() * sizeof(uint2), hipMemcpyHostToDevice));
         ctx->osc_rows_host.assign((const uint8_t*)rows.data(), (const uint8_t*)rows.data() + (size_t)n * sizeof(OscRow));
+        ctx->osc_blks.assign(blks, blks + n);
         ctx->osc_key = key;
     }
     launch_osc_update_stations((const OscRow*)ctx->osc_rows, ctx->osc_off, ctx->osc_visits, (uint32_t)ctx->osc_stations, ctx->osc_prev, ctx->osc_seen,
@@ -2856,8 +2869,25 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
     *out = nullptr;
     if (!n_steps || !steps || !n_batches || !batch_first || batch_first[0] != 0 || batch_first[n_batches] != n_steps)
         return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: bad arguments");
-    std::unique_ptr<dnagpu_chain_plan> plan(new (std::nothrow) dnagpu_chain_plan());
+    // (whatever the plan has allocated on the device goes with it on every error path below: its factors alone can be 96 GB)
+    struct PlanDeleter {
+        void operator()(dnagpu_chain_plan* p) const {
+            if (!p) return;
+            for (void* q : {p->table, p->blob, (void*)p->factors})
+                if (q) hipFree(q);
+            delete p;
+        }
+    };
+    std::unique_ptr<dnagpu_chain_plan, PlanDeleter> plan(new (std::nothrow) dnagpu_chain_plan());
     if (!plan) return fail(ctx, DNAGPU_ENOMEM, "host allocation");
+    // a junction's right-hand side, allocated on first use: no memory for it is DNAGPU_ENOMEM (the caller then runs the chains step by step)
+    auto ensure_jrhs = [&](dnagpu_matrix* m) -> int {
+        if (m->jrhs) return DNAGPU_OK;
+        hipError_t e = dnagpu::poison_malloc(&m->jrhs, (size_t)m->np_max * sizeof(double));
+        if (e == hipSuccess) return DNAGPU_OK;
+        (void)hipGetLastError();
+        return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "chain_plan_create: junction right-hand side", e);
+    };
     plan->n_steps = n_steps;
     plan->batch_first.assign(batch_first, batch_first + n_batches + 1);
     plan->shape.resize(n_batches);
@@ -2987,7 +3017,8 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
                 o.pos[r] = put(sc.pos, sc.k * sizeof(uint32_t));
                 o.inv[r] = put(inv.data(), inv.size() * sizeof(int32_t));
                 dnagpu_matrix* m = const_cast<dnagpu_matrix*>(sc.m);
-                if (sc.junction && !m->jrhs) HIPCHK(dnagpu::poison_malloc(&m->jrhs, (size_t)m->np_max * sizeof(double)));
+                if (sc.junction)
+                    if (int rcj = ensure_jrhs(m)) return rcj;
                 d.src[r].F = m->F; d.src[r].np = pad128((uint32_t)(3 * sc.k)); d.src[r].k = (uint32_t)sc.k;
                 d.src[r].rhs = sc.junction ? m->jrhs : m->jest;
                 d.src[r].jest = sc.junction ? m->jest : nullptr;
@@ -2998,7 +3029,8 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
                 continue;
             }
             if ((junction_in || st.out_junction) && !o.has_est) return fail(ctx, DNAGPU_EINVAL, "chain_plan_create: a junction needs the linearisation point");
-            if (st.out_junction && !st.out->jrhs) HIPCHK(dnagpu::poison_malloc(&st.out->jrhs, (size_t)st.out->np_max * sizeof(double)));
+            if (st.out_junction)
+                if (int rcj = ensure_jrhs(st.out)) return rcj;
             d.outS = st.out->F; d.outnp = pad128(nj);
             d.out_rhs = st.out_junction ? st.out->jrhs : st.out->jest;
             d.out_jest = st.out_junction ? st.out->jest : nullptr;
@@ -3011,8 +3043,6 @@ int dnagpu_chain_plan_create(dnagpu_ctx* ctx, size_t n_steps, const dnagpu_chain
         if (e == hipSuccess) e = dnagpu::poison_malloc(&plan->table, n_steps * sizeof(CbStep));
         if (e != hipSuccess) {      // (nothing half allocated stays behind: the caller runs the chains step by step and needs the memory for that)
             (void)hipGetLastError();
-            for (void* q : {plan->blob, (void*)plan->factors, plan->table})
-                if (q) hipFree(q);
             return fail(ctx, e == hipErrorOutOfMemory ? DNAGPU_ENOMEM : DNAGPU_EHIP, "chain_plan_create: device allocation", e);
         }
     }

@@ -29,7 +29,24 @@ namespace networkadjust {
 
 namespace {
 
-constexpr int32_t SHARED_HELLO = 0x444e4132;     // "DNA2": what a connecting rank says first, followed by its rank
+constexpr int32_t SHARED_HELLO = 0x444e4133;     // "DNA3": first word of the greeting both sides of a new connection exchange
+
+// The greeting: {SHARED_HELLO, rank, world size, job}.  The connecting rank sends its own, the accepting rank checks it and answers with
+// its own, which the connecting rank checks in turn -- a listener of another job (another world size, another rendezvous) on the same
+// port is recognised on BOTH sides instead of being talked to.  `job` is what every rank of one job can derive alone: the base port, the
+// world size and the launcher's rendezvous (MASTER_ADDR / MASTER_PORT).  Ports base .. base + world - 2 must be free per communicator:
+// two communicators created at the same time on one host need different bases (DNAGPU_MASTER_PORT, or the launcher's MASTER_PORT).
+int32_t job_id(int world, int base_port) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+        for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char*)p)[i]) * 1099511628211ull;
+    };
+    mix(&world, sizeof(world));
+    mix(&base_port, sizeof(base_port));
+    for (const char* name : {"MASTER_ADDR", "MASTER_PORT"})
+        if (const char* e = getenv(name)) mix(e, strlen(e) + 1);
+    return (int32_t)(h ^ (h >> 32));
+}
 
 void hip_ok(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string("inter-GPU exchange (shared): ") + what + ": " + hipGetErrorString(e));
@@ -115,6 +132,17 @@ private:
         }
         try {
             // connect to every lower rank (all ranks of a shared-GPU run live on the rendezvous host)
+            const int32_t job = job_id(world_, base_port);
+            auto read_all = [](int fd, void* buf, size_t n) {
+                size_t have = 0;
+                while (have < n) {
+                    ssize_t r = ::recv(fd, (char*)buf + have, n - have, 0);
+                    if (r <= 0) return false;
+                    have += (size_t)r;
+                }
+                return true;
+            };
+            const timeval io = {1, 0};               // (a silent peer holds a greeting up for a second, not the whole rendezvous)
             for (int q = 0; q < rank_; ++q) {
                 addrinfo hints, *res = nullptr;
                 memset(&hints, 0, sizeof(hints));
@@ -122,19 +150,32 @@ private:
                 hints.ai_socktype = SOCK_STREAM;
                 if (getaddrinfo(host.c_str(), std::to_string(base_port + q).c_str(), &hints, &res) != 0 || !res)
                     throw std::runtime_error("inter-GPU exchange (shared): cannot resolve " + host);
-                for (;;) {
-                    int s = ::socket(AF_INET, SOCK_STREAM, 0);
-                    if (s >= 0 && ::connect(s, res->ai_addr, res->ai_addrlen) == 0) {
-                        const int32_t hello[2] = {SHARED_HELLO, rank_};
-                        if (::send(s, hello, sizeof(hello), MSG_NOSIGNAL) == (ssize_t)sizeof(hello)) {
-                            fd_[(size_t)q] = s;
-                            break;
+                bool connected = false;
+                std::string refused;
+                while (!connected) {
+                    for (addrinfo* ai = res; ai && !connected; ai = ai->ai_next) {       // (every address the name resolves to)
+                        int s = ::socket(AF_INET, SOCK_STREAM, 0);
+                        if (s < 0) continue;
+                        if (::connect(s, ai->ai_addr, ai->ai_addrlen) == 0) {
+                            setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &io, sizeof(io));
+                            const int32_t hello[4] = {SHARED_HELLO, rank_, world_, job};
+                            int32_t back[4] = {0, -1, 0, 0};
+                            if (::send(s, hello, sizeof(hello), MSG_NOSIGNAL) == (ssize_t)sizeof(hello) && read_all(s, back, sizeof(back))) {
+                                if (back[0] == SHARED_HELLO && back[1] == q && back[2] == world_ && back[3] == job) {
+                                    fd_[(size_t)q] = s;
+                                    connected = true;
+                                    break;
+                                }
+                                refused = " (a listener of another job answered there)";
+                            }
                         }
+                        ::close(s);
                     }
-                    if (s >= 0) ::close(s);
+                    if (connected) break;
                     if (std::chrono::steady_clock::now() > deadline) {
                         freeaddrinfo(res);
-                        throw std::runtime_error("inter-GPU exchange (shared): rank " + std::to_string(q) + " not reachable at " + host + ":" + std::to_string(base_port + q));
+                        throw std::runtime_error("inter-GPU exchange (shared): rank " + std::to_string(q) + " not reachable at " + host + ":" +
+                                                 std::to_string(base_port + q) + refused);
                     }
                     std::this_thread::sleep_for(std::chrono::milliseconds(50));
                 }
@@ -148,16 +189,11 @@ private:
                 if (::poll(&pf, 1, (int)std::min(1000.0, left * 1e3)) <= 0) continue;
                 int c = ::accept(ls, nullptr, nullptr);
                 if (c < 0) continue;
-                timeval io = {5, 0};
                 setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &io, sizeof(io));
-                int32_t hello[2] = {0, -1};
-                size_t have = 0;
-                while (have < sizeof(hello)) {
-                    ssize_t r = ::recv(c, (char*)hello + have, sizeof(hello) - have, 0);
-                    if (r <= 0) break;
-                    have += (size_t)r;
-                }
-                if (have == sizeof(hello) && hello[0] == SHARED_HELLO && hello[1] > rank_ && hello[1] < world_ && fd_[(size_t)hello[1]] < 0) {
+                int32_t hello[4] = {0, -1, 0, 0};
+                const int32_t mine[4] = {SHARED_HELLO, rank_, world_, job};
+                if (read_all(c, hello, sizeof(hello)) && hello[0] == SHARED_HELLO && hello[1] > rank_ && hello[1] < world_ && hello[2] == world_ &&
+                    hello[3] == job && fd_[(size_t)hello[1]] < 0 && ::send(c, mine, sizeof(mine), MSG_NOSIGNAL) == (ssize_t)sizeof(mine)) {
                     fd_[(size_t)hello[1]] = c;
                     ++got;
                 } else {

@@ -16,6 +16,10 @@ namespace {
 
 constexpr int NT = 1024;            // threads of the workgroup (16 waves)
 constexpr int NW = NT / 64;
+// The one-workgroup kernels below keep up to five vectors of SMALL_STEP_MAX doubles and the column slices' partial sums in static LDS
+// (5 x 16 KiB + 8 KiB): more than the 64 KiB a workgroup has on gfx90a / gfx942.  They are written for the 160 KiB of gfx950 (the only
+// target of this library's build, __graft_entry__.py) and take a CU to themselves.
+static_assert((5 * SMALL_STEP_MAX + NW * 64) * sizeof(double) + 256 <= 160 * 1024, "the vectors of a small step must fit the LDS of one gfx950 workgroup");
 
 // y[i] = base[i] + sign * sum_{j < cols, (LOWER: j <= i)} A[i + j * lda] * x[j],  i < rows.   x, base, y: LDS (y may be base, not x);
 // part: NW * 64 doubles of LDS.  Rows in groups of 64 (a lane per row: coalesced columns), the waves left over split the columns
@@ -24,6 +28,7 @@ template <bool LOWER>
 __device__ void wg_matvec(const double* __restrict__ A, uint32_t lda, uint32_t rows, uint32_t cols, const double* x, const double* base, double sign,
                           double* y, double* part) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (rows == 0) return;                   // (uniform; nothing to write, and no row group to deal the waves to)
     const uint32_t RG = (rows + 63) / 64;
     if (RG >= (uint32_t)NW) {
         for (uint32_t rg = w; rg < RG; rg += NW) {
@@ -87,6 +92,7 @@ template <bool LOWER>
 __device__ void wg_matvec_t(const double* __restrict__ A, uint32_t lda, uint32_t rows, uint32_t cols, const double* x, const double* base, double sign,
                             double* y) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (cols == 0) return;                   // (uniform)
     for (uint32_t j = w; j < cols; j += NW) {
         const double* col = A + (size_t)j * lda;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
