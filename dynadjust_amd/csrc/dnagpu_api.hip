@@ -507,18 +507,6 @@ int dnagpu_debug_fail_batch_workspaces(long n) {
 
 long dnagpu_debug_set_small_tiles(long tiles) { return dnagpu::small_tiles_set(tiles); }
 long dnagpu_debug_set_tiny_tiles(long tiles) { return dnagpu::tiny_tiles_set(tiles); }
-int dnagpu_debug_set_side_share(int pct) { return dnagpu::side_share_set(pct); }
-int dnagpu_ctx_set_lookahead(dnagpu_ctx* ctx, int on) {
-    if (!ctx) return DNAGPU_EINVAL;
-    const int old = ctx->ws[0].lookahead ? 1 : 0;
-    for (int c = 0; c < DNAGPU_NUM_CHAINS; ++c) ctx->ws[c].lookahead = on != 0;
-    return old;
-}
-uint64_t dnagpu_lookahead_nodes(dnagpu_ctx* ctx) {
-    uint64_t n = 0;
-    for (int c = 0; ctx && c < DNAGPU_NUM_CHAINS; ++c) n += ctx->ws[c].la_nodes;
-    return n;
-}
 int dnagpu_debug_set_info_carry(int on) { return g_info_carry.exchange(on ? 1 : 0); }
 int dnagpu_ctx_set_info_carry(dnagpu_ctx* ctx, int on) {
     if (!ctx) return DNAGPU_EINVAL;
@@ -607,13 +595,6 @@ int dnagpu_profile_get(dnagpu_ctx* ctx, double* gemm_flops, double* gemm_ms, uin
             hipEventElapsedTime(&dt, p.pool[i], p.pool[i + 1]);
             iv.emplace_back(t0, t0 + dt);
         }
-        // (look-ahead launches on the chain's side streams: everything there has been waited for on the chain's stream)
-        for (size_t i = 0; base && i + 1 < p.sused; i += 2) {
-            float t0 = 0.f, dt = 0.f;
-            if (hipEventElapsedTime(&t0, base, p.spool[i]) != hipSuccess || hipEventElapsedTime(&dt, p.spool[i], p.spool[i + 1]) != hipSuccess) continue;
-            iv.emplace_back(t0, t0 + dt);
-        }
-        p.sused = 0;
         p.used = 0;
         f += p.flops;
         l += p.launches;

@@ -30,8 +30,6 @@ struct GemmArgs {
     int grid;               // number of workgroups (= table length)
     int tile;               // block tile of the launch: 128 (throughput), 64 (small launches) or 32 (tiny ones)
     int nb = 1;             // members of a batched launch (grid.y); member b works on A + dA[b], B + dB[b], C + dC[b]
-    int side = 0;           // 1: a look-ahead launch on a side stream (sym_inverse.hip): at most a share of the chip's workgroup slots, the
-                            // workgroups walking the table (entry b, b + gridDim.x, ...) -- the critical path's launches find a slot beside it
     long long dA[BATCH_MAX], dB[BATCH_MAX], dC[BATCH_MAX];
 };
 
@@ -58,7 +56,6 @@ std::vector<uint32_t> build_tile_order(int mt, int nt, int K, int kmode, int low
 std::vector<int> split_tile_columns(int mt, int nt, int K, int kmode, int lower, int world);
 
 void launch_gemm(const GemmArgs& a, int a_kcontig, int b_kcontig, hipStream_t s);
-int side_share_set(int pct);     // share (percent) of the chip's workgroup slots a side launch (GemmArgs::side) may hold; <= 0: the default; returns the old value
 void launch_leaf(const double* A, int lda, double* X, int ldx, int o, int* info, hipStream_t s, const LeafBatch* batch = nullptr);
 void launch_unpack_lower(const double* ap, double* F, uint32_t n, uint32_t np, hipStream_t s);
 void launch_pack_lower(const double* F, double* ap, uint32_t n, uint32_t np, hipStream_t s);

@@ -24,8 +24,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#include <algorithm>
-#include <atomic>
 #include <type_traits>
 #include "la_kernels.h"
 #include "gemm_tile_dma.h"
@@ -93,22 +91,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_kernel(GemmArg
     gemm_tile_body<A_KC, B_KC, TILE, WAVES>(a, (int)(packed >> 16), (int)(packed & 0xffffu), lds, dA, dB, dC);
 }
 
-// The same tiles by a launch that holds only a share of the chip's workgroup slots (GemmArgs::side, one matrix): gridDim.x workgroups, a
-// multiple of 8, walk the table -- entry b, b + gridDim.x, ... : the entries of one XCD's list stay on that XCD -- so that the launches of
-// the factorisation's critical path on the chain's own stream (a leaf, a product of a few tiles) find a free slot while it runs.
-// Every element is computed as in the one-tile-per-workgroup launch: same bits.
-template <bool A_KC, bool B_KC, int TILE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_walk_kernel(GemmArgs a) {
-    using G = Geo<TILE, WAVES>;
-    __shared__ __attribute__((aligned(16))) double lds[4 * G::OPBUF];
-    for (int b = (int)blockIdx.x; b < a.grid; b += (int)gridDim.x) {
-        const uint32_t packed = a.order[b];
-        if (packed == 0xffffffffu) continue;
-        gemm_tile_body<A_KC, B_KC, TILE, WAVES>(a, (int)(packed >> 16), (int)(packed & 0xffffu), lds);
-        __syncthreads();
-    }
-}
-
 // The throughput kernel: TILE = 128, operands staged with LDS-DMA (no staging registers, no ds_write), two separate
 // LDS buffers (distinct __shared__ objects, so that the compiler knows a DMA into one never aliases the fragment
 // reads of the other and does not serialise them behind vmcnt).  The tile itself: dma_tile_product (gemm_tile_dma.h).
@@ -146,80 +128,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_kernel(Gem
 }
 
 
-template <bool A_KC, bool B_KC, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void gemm_f64_dma_walk_kernel(GemmArgs a) {      // (see gemm_f64_walk_kernel)
-    constexpr int TILE = 128;
-    using G = Geo<TILE, WAVES>;
-    __shared__ __attribute__((aligned(16))) double lds0[2 * G::OPBUF];
-    __shared__ __attribute__((aligned(16))) double lds1[2 * G::OPBUF];
-    const bool down = a.kmode == KM_GE_J || a.kmode == KM_GE_I;
-    for (int b = (int)blockIdx.x; b < a.grid; b += (int)gridDim.x) {
-        const uint32_t packed = a.order[b];
-        if (packed == 0xffffffffu) continue;
-        const int it = (int)(packed >> 16), jt = (int)(packed & 0x7fffu);
-        int kbeg = 0, kend = a.K;
-        switch (a.kmode) {
-            case KM_LE_J: kend = (jt + 1) * 128; break;
-            case KM_GE_J: kbeg = jt * 128; break;
-            case KM_LE_I: kend = (it + 1) * 128; break;
-            case KM_GE_I: kbeg = it * 128; break;
-            default: break;
-        }
-        if (kend > a.K) kend = a.K;
-        dma_tile_product<A_KC, B_KC, WAVES>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, it * TILE, jt * TILE, kbeg, kend, down, a.alpha, a.beta,
-                                            a.mirror && (it != jt), lds0, lds1);
-        __syncthreads();
-    }
-}
-
-// Workgroups of a side launch (GemmArgs::side): the share `side_share()` of the slots the kernel can hold on the whole chip, a multiple of 8
-static std::atomic<int> g_side_share_pct{75};
-int side_share_set(int pct) {
-    const int old = g_side_share_pct.load();
-    g_side_share_pct.store(pct <= 0 ? 75 : std::min(100, pct));
-    return old;
-}
-template <class K>
-static int side_grid(K kernel, int threads, int& cache) {
-    if (cache <= 0) {
-        int per_cu = 0, dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        cache = per_cu * cus;
-    }
-    const int g = (int)((long)cache * g_side_share_pct.load() / 100) & ~7;
-    return g < 8 ? 8 : g;
-}
-
 template <int WAVES>
 static void launch_gemm_dma(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
-    if (a.side && a.nb == 1) {
-        static int slots[4] = {0, 0, 0, 0};
-        dim3 block(64 * WAVES);
-        int cap;
-        if (!a_kc && !b_kc) {
-            if ((cap = side_grid(gemm_f64_dma_walk_kernel<false, false, WAVES>, 64 * WAVES, slots[0])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_dma_walk_kernel<false, false, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        } else if (!a_kc && b_kc) {
-            if ((cap = side_grid(gemm_f64_dma_walk_kernel<false, true, WAVES>, 64 * WAVES, slots[1])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_dma_walk_kernel<false, true, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        } else if (a_kc && b_kc) {
-            if ((cap = side_grid(gemm_f64_dma_walk_kernel<true, true, WAVES>, 64 * WAVES, slots[2])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_dma_walk_kernel<true, true, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        } else {
-            if ((cap = side_grid(gemm_f64_dma_walk_kernel<true, false, WAVES>, 64 * WAVES, slots[3])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_dma_walk_kernel<true, false, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        }
-    }
     dim3 grid(a.grid, a.nb), block(64 * WAVES);
     if (!a_kc && !b_kc)
         hipLaunchKernelGGL((gemm_f64_dma_kernel<false, false, WAVES>), grid, block, 0, s, a);
@@ -233,32 +143,6 @@ static void launch_gemm_dma(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s
 
 template <int TILE, int WAVES>
 static void launch_gemm_t(const GemmArgs& a, int a_kc, int b_kc, hipStream_t s) {
-    if (a.side && a.nb == 1) {
-        static int slots[4] = {0, 0, 0, 0};
-        dim3 block(64 * WAVES);
-        int cap;
-        if (!a_kc && !b_kc) {
-            if ((cap = side_grid(gemm_f64_walk_kernel<false, false, TILE, WAVES>, 64 * WAVES, slots[0])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_walk_kernel<false, false, TILE, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        } else if (!a_kc && b_kc) {
-            if ((cap = side_grid(gemm_f64_walk_kernel<false, true, TILE, WAVES>, 64 * WAVES, slots[1])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_walk_kernel<false, true, TILE, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        } else if (a_kc && b_kc) {
-            if ((cap = side_grid(gemm_f64_walk_kernel<true, true, TILE, WAVES>, 64 * WAVES, slots[2])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_walk_kernel<true, true, TILE, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        } else {
-            if ((cap = side_grid(gemm_f64_walk_kernel<true, false, TILE, WAVES>, 64 * WAVES, slots[3])) < a.grid) {
-                hipLaunchKernelGGL((gemm_f64_walk_kernel<true, false, TILE, WAVES>), dim3(cap), block, 0, s, a);
-                return;
-            }
-        }
-    }
     dim3 grid(a.grid, a.nb), block(64 * WAVES);
     if (!a_kc && !b_kc)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false, TILE, WAVES>), grid, block, 0, s, a);

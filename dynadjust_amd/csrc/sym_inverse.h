@@ -22,14 +22,7 @@ struct GemmProfile {
     std::vector<hipEvent_t> pool;  // start/stop pairs, one pair per run of consecutive gemm launches
     size_t used = 0;
     bool open = false;       // a run is in progress (start event recorded, stop event pending)
-    std::vector<hipEvent_t> spool; // ... and the pairs around the look-ahead launches on the side streams (they overlap the runs above in time)
-    size_t sused = 0;
 };
-
-constexpr int LA_STREAMS = 4;        // side streams of a chain: one per level (log2 of the node's tiles) of the nodes that look ahead
-constexpr int LA_MIN_TILES = 8;      // nodes of fewer 128-tiles defer nothing (their trailing update is a handful of tiles)
-constexpr int LA_MAX_TILES = 64;     // nodes of more tiles defer nothing: their products fill the chip, and hide the critical path of their children, anyway
-constexpr size_t LA_EVENTS = 4096;   // ring of ordering events per chain
 
 // A batched driver call: the drivers below run on member 0's buffers as always, and every launch they enqueue carries nb members --
 // the same product or leaf on nb matrices of one shape, in lock step (la_kernels.h: GemmArgs::nb).  The buffers a call touches are
@@ -66,14 +59,6 @@ struct InvWorkspace {
     uint32_t np_cap = 0;
     hipStream_t stream = nullptr;
     GemmProfile prof;
-    // Look-ahead inside the factorisation of ONE matrix (sym_inverse.hip Rec::node; dnagpu_ctx_set_lookahead): the part of a node's
-    // trailing update that its right child's first half does not touch, and the product T21 = W21 X11, go to a side stream of the node's
-    // level; the chain's own stream carries the critical path (leaf -> the few tiles the next leaf needs -> leaf ...).
-    bool lookahead = false;
-    hipStream_t side[LA_STREAMS] = {};
-    std::vector<hipEvent_t> la_ev;
-    size_t la_next = 0;
-    uint64_t la_nodes = 0;       // nodes that deferred work since the workspace was made (diagnostic)
     // workgroup->tile tables per launch shape (see tile_order.hip) and tile-column range (0xffffffff: all columns), device resident
     std::map<std::pair<uint64_t, uint32_t>, std::pair<uint32_t*, int>> order_cache;
     std::set<uint64_t> planned;  // driver call shapes (sym_inverse.hip plan_key) whose tile-order tables are all built

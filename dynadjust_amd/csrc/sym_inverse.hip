@@ -38,10 +38,6 @@ void inv_workspace_free(InvWorkspace& ws) {
     if (ws.dist_stage) hipFree(ws.dist_stage);
     if (ws.info_host) hipHostFree(ws.info_host);
     for (hipEvent_t ev : ws.prof.pool) hipEventDestroy(ev);
-    for (hipEvent_t ev : ws.prof.spool) hipEventDestroy(ev);
-    for (hipEvent_t ev : ws.la_ev) hipEventDestroy(ev);
-    for (int q = 0; q < LA_STREAMS; ++q)
-        if (ws.side[q]) hipStreamDestroy(ws.side[q]);
     for (auto& kv : ws.order_cache)
         if (kv.second.first) hipFree(kv.second.first);
     ws = InvWorkspace();
@@ -244,20 +240,7 @@ static bool batch_offsets(const InvBatch& bt, const double* p, long long* d) {
     return false;
 }
 
-// side: a look-ahead launch (Rec::node) -- on that stream, holding a share of the chip's slots only (GemmArgs::side); its flops are counted
-// here, its time by the event pairs the caller puts around a group of such launches (GemmProfile::spool)
-void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc, hipStream_t side = nullptr) {
-    if (side) {
-        if (ws.err != hipSuccess || gemm_attach_order(ws, a) != hipSuccess) return;
-        if (ws.prof.enabled) {
-            ws.prof.flops += gemm_flops(a);
-            ws.prof.launches++;
-        }
-        a.side = 1;
-        launch_gemm(a, akc, bkc, side);
-        inv_note_error(ws, hipGetLastError(), "tile GEMM launch (look-ahead)");
-        return;
-    }
+void gemm(InvWorkspace& ws, GemmArgs a, int akc, int bkc) {
     if (ws.batch.nb > 1) {
         if (ws.err != hipSuccess || gemm_attach_order(ws, a) != hipSuccess) return;
         a.nb = ws.batch.nb;
@@ -305,7 +288,6 @@ void gemm_profile_collect(InvWorkspace& ws) {
         p.gemm_ms += ms;
     }
     p.used = 0;
-    p.sused = 0;        // (the side launches' pairs overlap the runs: only dnagpu_profile_get, which forms the union, reads them)
 }
 
 void gemm_profile_reset(InvWorkspace& ws) {
@@ -313,7 +295,6 @@ void gemm_profile_reset(InvWorkspace& ws) {
     ws.prof.gemm_ms = 0.0;
     ws.prof.launches = 0;
     ws.prof.used = 0;
-    ws.prof.sused = 0;
     ws.prof.open = false;
 }
 
@@ -338,72 +319,11 @@ struct Rec {
         ~PLocal() { r.p_o = old; }
     };
 
-    void gemm(InvWorkspace& w_, GemmArgs a, int akc, int bkc, hipStream_t side = nullptr) {
+    void gemm(InvWorkspace& w_, GemmArgs a, int akc, int bkc) {
         if (dry)
             gemm_attach_order(w_, a);
         else
-            dnagpu::gemm(w_, a, akc, bkc, side);
-    }
-
-    // ---- look-ahead inside the factorisation of one matrix (InvWorkspace::lookahead; never in a batched or split call) ----
-    // A node of 8 ... 64 tiles splits its panel and its trailing update by the halves of its RIGHT child: what that child's first half
-    // works on (r1 tile rows) stays on the chain's stream; the rest -- rows r1 .. r of the panel, of the update, and T21 = W21 X11, which
-    // nothing needs before the node's last product -- goes to the side stream of the node's depth, in launches that leave workgroup slots
-    // free (GemmArgs::side).  The chain's stream then carries leaf -> the few tiles the next leaf needs -> leaf ...; the bulk of a node
-    // runs beside the critical path of its right child's first half instead of in front of it.  The right child waits for the deferred
-    // update (`pend`) before ITS panel, which is the first thing to read those tiles.  The same products on the same elements in the
-    // same k order: same bits as without look-ahead.
-    bool la = false;
-    hipStream_t side_stream(int depth) {
-        hipStream_t& st = ws.side[depth % LA_STREAMS];
-        if (!st) inv_note_error(ws, hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "look-ahead stream");
-        return st;
-    }
-    hipEvent_t mark(hipStream_t st) {
-        if (ws.la_ev.size() < LA_EVENTS && ws.la_next >= ws.la_ev.size()) {
-            hipEvent_t ev = nullptr;
-            inv_note_error(ws, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "look-ahead event");
-            if (!ev) return nullptr;
-            ws.la_ev.push_back(ev);
-        }
-        hipEvent_t ev = ws.la_ev[ws.la_next % ws.la_ev.size()];
-        ws.la_next++;
-        inv_note_error(ws, hipEventRecord(ev, st), "look-ahead event");
-        return ev;
-    }
-    void after(hipStream_t st, hipEvent_t ev) {
-        if (ev && st) inv_note_error(ws, hipStreamWaitEvent(st, ev, 0), "look-ahead wait");
-    }
-    void side_time(hipStream_t st) {            // one of a pair of timing events around a group of side launches
-        GemmProfile& p = ws.prof;
-        if (!p.enabled || !st) return;
-        if (p.sused + 1 > p.spool.size()) {
-            hipEvent_t ev;
-            hipEventCreate(&ev);
-            p.spool.push_back(ev);
-        }
-        hipEventRecord(p.spool[p.sused++], st);
-    }
-    // rows [row0, row0 + rows) of the panel W21 = A21 X11^T below the h x h block at o
-    void panel(int o, int h, int row0, int rows, hipStream_t side) {
-        GemmArgs a;
-        a.A = f(o + h + row0, o); a.lda = ld;
-        a.B = x(o, o); a.ldb = ldx;
-        a.C = w(o + h + row0, o); a.ldc = ldp;
-        a.mt = rows; a.nt = h; a.K = h * 128;
-        a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_LE_J; a.lower = 0; a.mirror = 0;
-        gemm(ws, a, 0, 0, side);
-    }
-    // A22(rows, cols) -= W21(rows) W21(cols)^T: the lower tiles of a diagonal part (cols < 0) or a rectangle of it
-    void update(int o, int h, int row0, int rows, int col0, int cols, hipStream_t side) {
-        GemmArgs a;
-        const bool tri = cols < 0;
-        a.A = w(o + h + row0, o); a.lda = ldp;
-        a.B = w(o + h + (tri ? row0 : col0), o); a.ldb = ldp;
-        a.C = f(o + h + row0, o + h + (tri ? row0 : col0)); a.ldc = ld;
-        a.mt = rows; a.nt = tri ? rows : cols; a.K = h * 128;
-        a.alpha = -1.0; a.beta = 1.0; a.kmode = KM_FULL; a.lower = tri ? 1 : 0; a.mirror = 0;
-        gemm(ws, a, 0, 0, side);
+            dnagpu::gemm(w_, a, akc, bkc);
     }
 
     // W21 = A21 * X11^T (L21 = A21 L11^-T) for the r tile rows below the h x h block at o, then A22 -= W21 * W21^T (lower tiles)
@@ -424,9 +344,7 @@ struct Rec {
     }
 
     // Cholesky factor and its inverse of the s x s tile block at o: F keeps T21 = L21 L11^-1 below the diagonal, X = L^-1
-    // pend: the deferred part of the parent's trailing update (look-ahead), to be waited for before this node's panel; depth: of the
-    // look-ahead nodes above this one
-    void node(int o, int s, hipEvent_t pend = nullptr, int depth = 0) {
+    void node(int o, int s) {
         if (s == 1) {
             if (!dry && ws.err == hipSuccess) {
                 gemm_profile_close(ws);
@@ -447,9 +365,9 @@ struct Rec {
         }
         int h = s / 2;
         int r = s - h;
-        const bool defer = la && s >= LA_MIN_TILES && s <= LA_MAX_TILES;
-        node(o, h, nullptr, depth);
-        if (pend && !dry) after(ws.stream, pend);
+        node(o, h);
+        eliminate(o, h, r);
+        node(o + h, r);
         GemmArgs a;
         // T21 = W21 * X11  -> stored where A21 was
         a.A = w(o + h, o); a.lda = ldp;
@@ -457,38 +375,7 @@ struct Rec {
         a.C = f(o + h, o); a.ldc = ld;
         a.mt = r; a.nt = h; a.K = h * 128;
         a.alpha = 1.0; a.beta = 0.0; a.kmode = KM_GE_J; a.lower = 0; a.mirror = 0;
-        if (!defer) {
-            eliminate(o, h, r);
-            node(o + h, r, nullptr, depth);
-            gemm(ws, a, 0, 1);
-        } else {
-            const int r1 = r / 2, r2 = r - r1;       // the halves of the right child
-            hipStream_t sd = dry ? nullptr : side_stream(depth);
-            hipEvent_t e_a = nullptr, e_b = nullptr, e_d = nullptr, e_t = nullptr;
-            if (!dry) {
-                ws.la_nodes++;
-                e_a = mark(ws.stream);               // X11 is final, A21 as the panel reads it
-            }
-            panel(o, h, 0, r1, nullptr);
-            if (!dry) e_b = mark(ws.stream);         // the first r1 tile rows of W21
-            update(o, h, 0, r1, 0, -1, nullptr);
-            if (!dry) {
-                after(sd, e_a);
-                side_time(sd);
-            }
-            panel(o, h, r1, r2, sd);
-            if (!dry) after(sd, e_b);
-            update(o, h, r1, r2, 0, r1, sd);
-            update(o, h, r1, r2, 0, -1, sd);
-            if (!dry) e_d = mark(sd);
-            gemm(ws, a, 0, 1, sd);                   // T21: overwrites A21, which both halves of the panel have read
-            if (!dry) {
-                side_time(sd);
-                e_t = mark(sd);
-            }
-            node(o + h, r, e_d, depth + 1);
-            if (!dry) after(ws.stream, e_t);
-        }
+        gemm(ws, a, 0, 1);
         // X21 = -X22 * T21
         a.A = x(o + h, o + h); a.lda = ldx;
         a.B = f(o + h, o); a.ldb = ld;
@@ -595,11 +482,8 @@ inline uint64_t plan_key(int family, int what, int ti, int tj) {
 // the per-product path: planning pass (tile-order tables) on first use of the shape, then the launches
 template <class Ops>
 void run_products(InvWorkspace& ws, uint64_t key, double* F, int ld, double* X, int ldx, double* P, int ldp, const double* WK, Ops&& ops) {
-    const bool la = ws.lookahead && ws.batch.nb == 1 && ws.dist_world == 1;
-    if (la) key |= 1ull << 62;          // (its launches have other shapes)
     for (int pass = ws.planned.count(key) ? 1 : 0; pass < 2; ++pass) {
         Rec rec{ws, F, ld, X, ldx, P, ldp, pass == 0};
-        rec.la = la;
         ops(rec, WK);
         if (ws.err != hipSuccess) return;
     }

@@ -120,15 +120,6 @@ long dnagpu_debug_set_small_tiles(long tiles);
 /* ... and below `tiles` on 32 x 32 tiles (default 64; 0: never; < 0: the default again): the products of the recursion's bottom and of the chains on
  * condensed blocks, where a launch has too few 64-tiles to occupy the chip.  Same bits.  Returns the previous value. */
 long dnagpu_debug_set_tiny_tiles(long tiles);
-/* Look-ahead inside the factorisation of ONE matrix (the dpotrf / dpotri pair of matrix_2d::cholesky_inverse, dnamatrix_contiguous.cpp:982-1006, run
- * alone): a node of 8 ... 64 tiles of the recursion sends the part of its trailing update that the next diagonal blocks do not touch, and the
- * product that only its own last step needs, to a side stream of the chain, in launches that hold a share of the chip's workgroup slots
- * (dnagpu_debug_set_side_share, percent; <= 0: the default) -- the chain's own stream carries the critical path beside them.  Same bits as
- * without.  Batched and split (multi-GPU) calls never look ahead.  Per context; returns the previous value.  dnagpu_lookahead_nodes: nodes that
- * deferred work so far, over the context's chains (diagnostic). */
-int dnagpu_ctx_set_lookahead(dnagpu_ctx* ctx, int on);
-int dnagpu_debug_set_side_share(int pct);
-uint64_t dnagpu_lookahead_nodes(dnagpu_ctx* ctx);
 /* dnagpu_schur_carry's result: 1 (default) information form, 0 estimates form (see there); returns the previous value.  The setting is taken
  * over by the contexts created AFTER the call and stays with a context for its lifetime (dnagpu_info_carry(ctx); NULL: the value a new
  * context would get): contexts running side by side never see each other's form. */

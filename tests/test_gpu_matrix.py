@@ -127,59 +127,6 @@ def test_tiny_launches_on_32_tiles_have_the_bits_of_64_tiles(gpu_ctx, built, orc
         assert np.abs(inv32 - ref).max() / np.abs(ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("n", [900, 1024, 1500, 2304, 3000, 4096, 6016, 9000])
-def test_look_ahead_has_the_bits_of_the_sequential_recursion(gpu_ctx, built, n):
-    """dnagpu_ctx_set_lookahead (round 6): nodes of 8 ... 64 tiles send the part of their trailing update that the next diagonal blocks do
-    not touch, and T21 = W21 X11, to a side stream in launches that walk their tile table with a share of the chip's workgroup slots.
-    The same products on the same elements in the same k order: the inverse, the elimination's Schur complement and the completed
-    inverse of a kept factor are bit for bit those without look-ahead -- with the side launches at a share small enough that every
-    one of them walks its table (5 %), and at the default."""
-    M = _dense_spd(n, n + 11)
-    ap = pack_lower(M)
-    ns = n // 3
-    keep = np.arange(ns - max(1, ns // 10), ns, dtype=np.uint32)
-
-    def run():
-        m = gpu_ctx.matrix(n)
-        red = gpu_ctx.matrix(3 * len(keep))
-        inv = gpu_ctx.matrix(n)
-        pf = gpu_ctx.partial_create(n, 3 * len(keep))
-        gpu_ctx.block_create(7, ns, 0)
-        gpu_ctx.block_set_stations(7, np.zeros(3 * ns))
-        try:
-            m.upload_packed(ap, n)
-            m.invert()
-            out = [m.download_packed()]
-            m.upload_packed(pack_lower(M[: 3 * ns, : 3 * ns]), 3 * ns)
-            gpu_ctx.block_reduce(7, m, keep, red)
-            out.append(red.download_packed())
-            m.upload_packed(pack_lower(M[: 3 * ns, : 3 * ns]), 3 * ns)
-            gpu_ctx.block_reduce(7, m, keep, red, keep=pf)
-            gpu_ctx.partial_complete(pf, red, inv, 3 * ns)
-            out.append(inv.download_packed())
-            return out
-        finally:
-            gpu_ctx.partial_destroy(pf)
-            gpu_ctx.block_destroy(7)
-            for q in (m, red, inv):
-                q.close()
-
-    assert built.dnagpu_ctx_set_lookahead(gpu_ctx.h, 0) in (0, 1)
-    ref = run()
-    nodes0 = built.dnagpu_lookahead_nodes(gpu_ctx.h)
-    try:
-        for share in (5, 0):
-            built.dnagpu_debug_set_side_share(share)
-            built.dnagpu_ctx_set_lookahead(gpu_ctx.h, 1)
-            got = run()
-            for a, b in zip(ref, got):
-                assert np.array_equal(a, b)
-    finally:
-        built.dnagpu_ctx_set_lookahead(gpu_ctx.h, 0)
-        built.dnagpu_debug_set_side_share(0)
-    assert built.dnagpu_lookahead_nodes(gpu_ctx.h) > nodes0
-
-
 @pytest.mark.parametrize("n", [2304, 4096, 6016])
 def test_dense_inverse_against_oracle_beyond_the_small_launch_threshold(gpu_ctx, orc, n):
     """n >= 2 304 (T = 18: 171 lower tiles > SMALL_LAUNCH_TILES = 160): the top-level launches of the recursion run on the
