@@ -325,7 +325,7 @@ def load():
 
 EXPORTED_DNAGPU = [
     "dnagpu_device_count", "dnagpu_create", "dnagpu_destroy", "dnagpu_last_error", "dnagpu_last_info", "dnagpu_sync",
-    "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset", "dnagpu_debug_fail_allocation", "dnagpu_debug_fail_batch_workspaces", "dnagpu_debug_set_small_tiles", "dnagpu_debug_set_tiny_tiles", "dnagpu_debug_set_info_carry", "dnagpu_info_carry", "dnagpu_ctx_set_info_carry", "dnagpu_chain_reserve", "dnagpu_partial_pack_device", "dnagpu_partial_unpack_device", "dnagpu_debug_tile_order",
+    "dnagpu_cholesky_inverse_packed", "dnagpu_multiply_sym_packed", "dnagpu_profile_enable", "dnagpu_profile_reset", "dnagpu_debug_fail_allocation", "dnagpu_debug_fail_batch_workspaces", "dnagpu_debug_set_small_tiles", "dnagpu_debug_set_tiny_tiles", "dnagpu_debug_set_info_carry", "dnagpu_info_carry", "dnagpu_ctx_set_info_carry", "dnagpu_chain_reserve", "dnagpu_copy_stage_reserve", "dnagpu_partial_pack_device", "dnagpu_partial_unpack_device", "dnagpu_partial_pack_host_async", "dnagpu_partial_unpack_host", "dnagpu_debug_tile_order",
     "dnagpu_block_keep_corrections", "dnagpu_osc_reset", "dnagpu_osc_block", "dnagpu_osc_blocks", "dnagpu_form_rhs_batched", "dnagpu_osc_flagged", "dnagpu_osc_block_visits", "dnagpu_profile_get", "dnagpu_profile_hbm_enable", "dnagpu_profile_hbm_get", "dnagpu_matrix_pack_device", "dnagpu_matrix_unpack_device", "dnagpu_matrix_create", "dnagpu_matrix_destroy", "dnagpu_matrix_reset",
     "dnagpu_matrix_upload_packed", "dnagpu_matrix_download_packed", "dnagpu_matrix_download_packed_async", "dnagpu_copies_sync", "dnagpu_matrix_copy", "dnagpu_matrix_export", "dnagpu_matrix_import", "dnagpu_invert",
     "dnagpu_block_create", "dnagpu_block_destroy", "dnagpu_block_set_stations", "dnagpu_block_reset_stations", "dnagpu_chain_hold_info", "dnagpu_chain_take_info", "dnagpu_block_table_create", "dnagpu_block_table_apply", "dnagpu_block_table_destroy", "dnagpu_block_set_baselines", "dnagpu_block_set_clusters",

@@ -692,14 +692,10 @@ int dnagpu_matrix_download_packed(dnagpu_ctx* ctx, int chain, const dnagpu_matri
     return DNAGPU_OK;
 }
 
-int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap) {
-    CHK_CTX();
-    CHK_CHAIN();
-    if (!m || (!ap && m->n)) return fail(ctx, DNAGPU_EINVAL, "matrix_download_packed_async: bad arguments");
-    const size_t cnt = (size_t)m->n * (m->n + 1) / 2;
-    if (!cnt) return DNAGPU_OK;
+// the chain's copy stream, its two events and a staging buffer of at least cnt doubles; 1: made, 0: not (the caller takes the blocking path)
+static int ensure_copy_stage(dnagpu_ctx* ctx, int chain, size_t cnt, int* rc_out) {
+    *rc_out = DNAGPU_OK;
     if (!ctx->copy_stream[chain]) {
-        // created into locals and committed together: a half-made set must not look usable to the next call
         hipStream_t cs = nullptr;
         hipEvent_t pd = nullptr, cd = nullptr;
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess ||
@@ -709,14 +705,19 @@ int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu
             if (cd) hipEventDestroy(cd);
             if (pd) hipEventDestroy(pd);
             if (cs) hipStreamDestroy(cs);
-            return dnagpu_matrix_download_packed(ctx, chain, m, ap);
+            return 0;
         }
         ctx->copy_stream[chain] = cs;
         ctx->pack_done[chain] = pd;
         ctx->copy_done[chain] = cd;
     }
     if (ctx->stage_cap[chain] < cnt) {
-        HIPCHK(hipStreamSynchronize(ctx->copy_stream[chain]));
+        hipError_t e = hipStreamSynchronize(ctx->copy_stream[chain]);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream[chain]);      // (an upload through the buffer that the chain has not consumed yet)
+        if (e != hipSuccess) {
+            *rc_out = fail(ctx, DNAGPU_EHIP, "copy staging buffer", e);
+            return 0;
+        }
         ctx->copy_pending[chain] = false;
         if (ctx->stage_buf[chain]) hipFree(ctx->stage_buf[chain]);
         ctx->stage_buf[chain] = nullptr;
@@ -724,10 +725,74 @@ int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu
         if (dnagpu::poison_malloc(&ctx->stage_buf[chain], cnt * sizeof(double)) != hipSuccess) {
             (void)hipGetLastError();
             ctx->stage_buf[chain] = nullptr;
-            return dnagpu_matrix_download_packed(ctx, chain, m, ap);   // no room for the staging buffer: the chain waits for its copy
+            return 0;
         }
         ctx->stage_cap[chain] = cnt;
     }
+    return 1;
+}
+
+// A light factor to page-locked HOST memory as its packed lower triangle, and back (round 6): a block the HBM budget denies a kept factor,
+// and whose packed variance matrix will live in a host slot of the staged store, parks its factor THERE between its condensing step and its
+// variance matrix -- 2.9 GB at n = 27 000 take 51 ms over the host link, beside the other chains' work, where eliminating the block again
+// takes 100 ms of the whole chip.  Out: packed on the chain's stream into the chain's staging buffer, copied on its copy stream
+// (dnagpu_copies_sync before the slot is read).  Back: copied into the staging buffer and unpacked on the chain's stream.
+int dnagpu_partial_pack_host_async(dnagpu_ctx* ctx, int chain, const dnagpu_partial* p, double* host_ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!p || !host_ap || !p->spine || !p->valid || !p->npp) return fail(ctx, DNAGPU_EINVAL, "partial_pack_host_async: no light factor to pack");
+    const size_t cnt = (size_t)p->npp * (p->npp + 1) / 2;
+    int rc = DNAGPU_OK;
+    if (!ensure_copy_stage(ctx, chain, cnt, &rc)) {
+        if (rc) return rc;
+        // no copy stream or no room for a staging buffer: through the chain's L^-1 workspace, the chain waits for its copy
+        rc = ensure_ws(ctx, chain, p->npp);
+        if (rc) return rc;
+        launch_pack_lower(p->X, ctx->ws[chain].W, p->npp, p->npp, ctx->stream[chain]);
+        HIPCHK(hipMemcpyAsync(host_ap, ctx->ws[chain].W, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[chain]));
+        HIPCHK(hipStreamSynchronize(ctx->stream[chain]));
+        return DNAGPU_OK;
+    }
+    if (ctx->copy_pending[chain]) HIPCHK(hipStreamWaitEvent(ctx->stream[chain], ctx->copy_done[chain], 0));
+    launch_pack_lower(p->X, ctx->stage_buf[chain], p->npp, p->npp, ctx->stream[chain]);
+    HIPCHK(hipEventRecord(ctx->pack_done[chain], ctx->stream[chain]));
+    HIPCHK(hipStreamWaitEvent(ctx->copy_stream[chain], ctx->pack_done[chain], 0));
+    HIPCHK(hipMemcpyAsync(host_ap, ctx->stage_buf[chain], cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream[chain]));
+    HIPCHK(hipEventRecord(ctx->copy_done[chain], ctx->copy_stream[chain]));
+    ctx->copy_pending[chain] = true;
+    return DNAGPU_OK;
+}
+
+int dnagpu_partial_unpack_host(dnagpu_ctx* ctx, int chain, dnagpu_partial* dst, const dnagpu_partial* src, const double* host_ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!dst || !src || !host_ap || !dst->spine || !src->spine || !src->npp) return fail(ctx, DNAGPU_EINVAL, "partial_unpack_host: bad arguments");
+    const size_t cnt = (size_t)src->npp * (src->npp + 1) / 2;
+    int rc = DNAGPU_OK;
+    double* stage = nullptr;
+    if (ensure_copy_stage(ctx, chain, cnt, &rc)) {
+        // (a copy OUT of the staging buffer that is still on its way leaves first)
+        if (ctx->copy_pending[chain]) HIPCHK(hipStreamWaitEvent(ctx->stream[chain], ctx->copy_done[chain], 0));
+        stage = ctx->stage_buf[chain];
+    } else {
+        if (rc) return rc;
+        rc = ensure_ws(ctx, chain, src->npp);          // (the panels' workspace: dead between driver calls, and not where dst lives)
+        if (rc) return rc;
+        stage = ctx->ws[chain].W;
+    }
+    HIPCHK(hipMemcpyAsync(stage, host_ap, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream[chain]));
+    return dnagpu_partial_unpack_device(ctx, chain, dst, src, stage);
+}
+
+int dnagpu_matrix_download_packed_async(dnagpu_ctx* ctx, int chain, const dnagpu_matrix* m, double* ap) {
+    CHK_CTX();
+    CHK_CHAIN();
+    if (!m || (!ap && m->n)) return fail(ctx, DNAGPU_EINVAL, "matrix_download_packed_async: bad arguments");
+    const size_t cnt = (size_t)m->n * (m->n + 1) / 2;
+    if (!cnt) return DNAGPU_OK;
+    int rc = DNAGPU_OK;
+    if (!ensure_copy_stage(ctx, chain, cnt, &rc))       // (no copy stream, or no room for the staging buffer: the chain waits for its copy)
+        return rc ? rc : dnagpu_matrix_download_packed(ctx, chain, m, ap);
     // the previous copy out of this buffer must have left before it is packed again
     if (ctx->copy_pending[chain]) HIPCHK(hipStreamWaitEvent(ctx->stream[chain], ctx->copy_done[chain], 0));
     {
@@ -3198,6 +3263,14 @@ int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max) {
     CHK_CTX();
     CHK_CHAIN();
     return ensure_ws(ctx, chain, pad128(n_max) + 256);
+}
+
+int dnagpu_copy_stage_reserve(dnagpu_ctx* ctx, int chain, size_t doubles) {
+    CHK_CTX();
+    CHK_CHAIN();
+    int rc = DNAGPU_OK;
+    if (doubles) ensure_copy_stage(ctx, chain, doubles, &rc);     // (no room now: the copies take their blocking path when they come)
+    return rc;
 }
 
 int dnagpu_batch_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max, uint32_t k_max, int nb_wanted, int* nb_granted) {

@@ -218,6 +218,7 @@ private:
         dnagpu_matrix* rigvar = nullptr;      // v_rigorousVariances_
         double* rig_host = nullptr;           // staged: v_rigorousVariances_ packed (lower, column-major) in page-locked host memory ...
         bool rig_on_device = false;           // ... or, where the host's memory limit ends (DecideStaging), the same packed image in HBM
+        bool rig_slot_factor = false;         // the slot has room for the block's packed light factor as well (n + 256 rows): PacksItsFactor
         bool has_rigvar = false;
         // a.reuse_inverses: the inverse of the forward / reverse normals of this block (the combined one is rigvar)
         dnagpu_matrix* finv = nullptr;
@@ -235,8 +236,9 @@ private:
         // a block the HBM budget denies a kept factor: its factor is made again where it is needed, in the chain's own storage (tmpfac_)
         bool part_transient = false;
         dnagpu_partial* tpart[DNAGPU_NUM_CHAINS] = {};
-        // ... unless its packed variance matrix will live in HBM (rig_on_device): that slot holds the factor's packed lower triangle from the
-        // condensing step to the variance matrix that replaces it (fac_src: the chain's descriptor the factor was made with)
+        // ... unless the slot of its packed variance matrix in the staged store -- in HBM (rig_on_device) or, round 6, in page-locked host
+        // memory -- has room for it (rig_slot_factor): that slot holds the factor's packed lower triangle from the condensing step to the
+        // variance matrix that replaces it (fac_src: the chain's descriptor the factor was made with)
         bool fac_packed = false;
         dnagpu_partial* fac_src = nullptr;
         bool var_deferred = false;            // a.defer_variances: this iteration's inverse exists as the completed factor in `part` only
@@ -378,6 +380,7 @@ private:
     // workspaces, the per-chain factor storage of blocks without a kept factor, the staged store (page-locked host memory / packed in HBM)
     void ReserveBuffers();
     void AllocateStagedSlot(UINT32 block);
+    size_t StagedSlotBytes(UINT32 block, bool* holds_factor) const;
     void AllocateChainData();
     void DecideStaging();
 public:
@@ -643,7 +646,8 @@ private:
     dnagpu_matrix* tmpfac_[DNAGPU_NUM_CHAINS] = {};  // storage of the factor a block without a kept one makes again (TransientPartial), per chain
     bool transient_ok_ = false;                      // PrepareCondensedBlocks: such blocks exist and the conditions hold (GNSS only, light factors)
     std::atomic<uint64_t> transient_count_{0};
-    std::atomic<uint64_t> unpacked_count_{0};      // rigorous solves / variance matrices that took their factor from its packed copy in HBM
+    std::atomic<uint64_t> unpacked_count_{0};      // rigorous solves / variance matrices that took their factor from its packed copy in HBM or host memory
+    std::atomic<bool> host_factor_copies_{false};  // a condensing step has sent a packed factor to a host slot: the phase ends with the copies waited for
     dnagpu_partial* TransientPartial(int c, UINT32 k);
     bool BorrowTransientFactor(int c, UINT32 k);
     void FinishVariancesTransient(int c, UINT32 k);

@@ -247,15 +247,29 @@ void dna_adjust::AllocateStagedSlot(UINT32 k) {
     if (B.rig_on_device) {
         // (n + 256: the slot also holds the block's light factor, packed, between its condensing step and its variance matrix)
         Check(dnagpu_device_alloc(ctx_, (n + 256) * (n + 257) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (packed, device)");
+        B.rig_slot_factor = true;
         return;
     }
     // (the plan left a fifth of the host's limit free; if something else has taken it since, a clean failure here is better than the
     //  container's memory limit ending the process -- and, on the pool's boxes, the box)
     // (margin: 8 GB on a large host, a fifth of what is left on a small one -- a tiny network must not fail for want of 8 GB: ADVICE r4)
-    const double bytes = (double)(n * (n + 1) / 2 * sizeof(double)), avail = HostMemoryAvailable();
+    const size_t slot = StagedSlotBytes(k, &B.rig_slot_factor);
+    const double bytes = (double)slot, avail = HostMemoryAvailable();
     if (avail < bytes + std::min(8.0e9, 0.2 * avail))
         SignalExceptionAdjustment("UpdateEstimatesFinal(): the host's memory limit leaves no room for the staged variance matrices.", k);
-    Check(dnagpu_host_alloc(ctx_, n * (n + 1) / 2 * sizeof(double), (void**)&B.rig_host), k, "rigorous variance matrix (host)");
+    Check(dnagpu_host_alloc(ctx_, slot, (void**)&B.rig_host), k, "rigorous variance matrix (host)");
+}
+
+// Bytes of block k's slot in the staged store: its packed variance matrix, n (n + 1) / 2 doubles -- or, where the block may park its packed
+// light factor in the slot while the iterations run (GNSS-only networks under the condensed schedule with the variance matrices made after
+// the last iteration: what PacksItsFactor asks for; a block of a few hundred unknowns never lacks the HBM for its factor, and 256 more rows
+// would double its slot), n + 256 rows.
+size_t dna_adjust::StagedSlotBytes(UINT32 k, bool* holds_factor) const {
+    const size_t n = v_parameterStationList_[k].size() * 3;
+    const bool f = !containsNonGPS_ && projectSettings_.a.adjust_mode != SimultaneousMode && projectSettings_.a.schur_carry && projectSettings_.a.keep_factors &&
+                   projectSettings_.a.defer_variances >= 2 && n >= 768;
+    if (holds_factor) *holds_factor = f;
+    return (f ? (n + 256) * (n + 257) / 2 : n * (n + 1) / 2) * sizeof(double);
 }
 
 // PrepareAdjustment's last step: first-use allocations that would otherwise sit inside the first iteration (cfg4 on one GPU: 95 GB of chain
@@ -271,8 +285,16 @@ void dna_adjust::ReserveBuffers() {
     }
     if (Staged() && projectSettings_.a.adjust_mode != SimultaneousMode) {
         std::lock_guard<std::mutex> lk(alloc_mutex_);
+        bool host_slots = false;
         for (UINT32 k = 0; k < blockCount_; ++k)
-            if (OwnsBlock(k)) AllocateStagedSlot(k);
+            if (OwnsBlock(k)) {
+                AllocateStagedSlot(k);
+                host_slots = host_slots || !blocks_[k].rig_on_device;
+            }
+        // (what travels to and from the host slots -- packed variance matrices, packed factors -- passes through a staging buffer per chain)
+        if (host_slots)
+            for (int c = 0; c < chains; ++c)
+                Check(dnagpu_copy_stage_reserve(ctx_, c, ((size_t)max_unknowns_ + 256) * ((size_t)max_unknowns_ + 257) / 2), 0, "PrepareAdjustment(): copy staging buffer");
     }
 }
 
@@ -527,11 +549,12 @@ void dna_adjust::DecideStaging() {
         block_t& B = blocks_[k];
         const size_t n = v_parameterStationList_[k].size() * 3, bytes = n * (n + 1) / 2 * sizeof(double);
         if (B.rig_host) {                        // (it exists already: counted where it is)
-            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += bytes;
+            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += B.rig_on_device ? bytes : StagedSlotBytes(k, nullptr);
             continue;
         }
-        if ((double)(stage_host_bytes_ + bytes) <= host) {
-            stage_host_bytes_ += bytes;
+        const size_t host_slot = StagedSlotBytes(k, nullptr);       // (with room for the block's packed factor where it may park it there)
+        if ((double)(stage_host_bytes_ + host_slot) <= host) {
+            stage_host_bytes_ += host_slot;
         } else {
             B.rig_on_device = true;
             stage_device_bytes_ += bytes;
@@ -564,10 +587,11 @@ void dna_adjust::MemInfo(size_t* free_b, size_t* total_b) {
     Check(dnagpu_mem_info(ctx_, free_b, total_b), 0, "PrepareAdjustment()");
 }
 
-// no kept factor of its own (the HBM budget), but a device slot for its packed variance matrix that can hold the packed factor meanwhile
+// no kept factor of its own (the HBM budget), but a slot for its packed variance matrix -- in HBM or in page-locked host memory -- that can hold
+// the packed factor meanwhile
 bool dna_adjust::PacksItsFactor(UINT32 k) const {
     const block_t& B = blocks_[k];
-    return transient_ok_ && !B.part && !B.part_allowed && Staged() && B.rig_on_device && B.rig_host && !B.keep.empty() &&
+    return transient_ok_ && !B.part && !B.part_allowed && Staged() && B.rig_host && B.rig_slot_factor && !B.keep.empty() &&
            B.keep.size() < v_parameterStationList_[k].size() && CondensedSchedule();
 }
 
@@ -824,7 +848,13 @@ void dna_adjust::CondenseBlock(int c, UINT32 k) {
         if (!tp) SignalExceptionAdjustment("Solve(): no memory for the block's factor.", k);
         Check(dnagpu_block_form_reduce(ctx_, c, k, B.con_inner.stn.data(), B.con_inner.w9.data(), B.con_inner.stn.size(), B.keep.data(), B.keep.size(),
                                        B.red, tp), k, "Solve()");
-        Check(dnagpu_partial_pack_device(ctx_, c, tp, B.rig_host), k, "Solve()");
+        if (B.rig_on_device) {
+            Check(dnagpu_partial_pack_device(ctx_, c, tp, B.rig_host), k, "Solve()");
+        } else {
+            // (to the block's host slot, on the chain's copy stream: CondenseBlocks waits for the copies of its phase)
+            Check(dnagpu_partial_pack_host_async(ctx_, c, tp, B.rig_host), k, "Solve()");
+            host_factor_copies_ = true;
+        }
         B.fac_packed = true;
         B.fac_src = tp;
         B.has_rigvar = false;       // (the slot holds the factor until the variance matrix of the last iteration replaces it)
@@ -1453,7 +1483,10 @@ bool dna_adjust::BorrowTransientFactor(int c, UINT32 k) {
     if (!tp) return false;
     if (B.fac_packed) {
         // the condensing step's factor, from its packed copy (CondenseBlock)
-        Check(dnagpu_partial_unpack_device(ctx_, c, tp, B.fac_src, B.rig_host), k, "Solve()");
+        if (B.rig_on_device)
+            Check(dnagpu_partial_unpack_device(ctx_, c, tp, B.fac_src, B.rig_host), k, "Solve()");
+        else
+            Check(dnagpu_partial_unpack_host(ctx_, c, tp, B.fac_src, B.rig_host), k, "Solve()");
         B.part = tp;
         B.part_spine = true;
         B.part_valid = true;
@@ -1772,14 +1805,16 @@ void dna_adjust::CondenseBlocks(const std::vector<UINT32>& blocks_in) {
     SmallBatchCondense(blocks);
     if (BatchCap() < 2) {
         ForBlocks(blocks, [&](int c, UINT32 k) { CondenseBlock(c, k); });
-        return;
+    } else {
+        ForGroups(BatchGroups(blocks, 0), [&](int c, const std::vector<UINT32>& ks) {
+            if (ks.size() >= 2)
+                CondenseBatch(c, ks);
+            else
+                CondenseBlock(c, ks[0]);
+        });
     }
-    ForGroups(BatchGroups(blocks, 0), [&](int c, const std::vector<UINT32>& ks) {
-        if (ks.size() >= 2)
-            CondenseBatch(c, ks);
-        else
-            CondenseBlock(c, ks[0]);
-    });
+    // factors on their way to the host slots of the staged store (CondenseBlock): the rigorous solves read them back, on whatever chain
+    if (host_factor_copies_.exchange(false)) FinishStagedCopies();
 }
 
 // ---- lock-step chains (a.chain_runs) ------------------------------------------------------------------------------------------------

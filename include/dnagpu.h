@@ -443,10 +443,19 @@ int dnagpu_block_form_reduce(dnagpu_ctx* ctx, int chain, uint32_t blk, const uin
  * unknown order with the factor (dst == src allowed) and is then what src was after its reduce.  Exact copies. */
 int dnagpu_partial_pack_device(dnagpu_ctx* ctx, int chain, const dnagpu_partial* p, double* dev_ap);
 int dnagpu_partial_unpack_device(dnagpu_ctx* ctx, int chain, dnagpu_partial* dst, const dnagpu_partial* src, const double* dev_ap);
+/* ... and through page-locked HOST memory (round 6): a block whose packed variance matrix will live in a host slot of the staged store parks its
+ * factor there -- packed on the chain's stream, copied on the chain's copy stream (dnagpu_copies_sync before the slot is read or written again);
+ * back: copied and unpacked on the chain's stream.  host_ap: (npp (npp + 1) / 2) doubles, npp <= n + 256.  Replaces the second and third
+ * dpotrf of a block per iteration that the reference's Solve() repeats anyway (dnaadjust.cpp:6586-6647). */
+int dnagpu_partial_pack_host_async(dnagpu_ctx* ctx, int chain, const dnagpu_partial* p, double* host_ap);
+int dnagpu_partial_unpack_host(dnagpu_ctx* ctx, int chain, dnagpu_partial* dst, const dnagpu_partial* src, const double* host_ap);
 /* A chain's inverse workspace (X and W: two (n_max + 256)^2 matrices, padded) is allocated on the chain's first call that needs it;
  * dnagpu_chain_reserve makes that allocation now -- in PrepareAdjustment rather than inside the first iteration (hipMalloc of
  * 2 x 5.9 GB per chain at n = 27 000 is seconds). */
 int dnagpu_chain_reserve(dnagpu_ctx* ctx, int chain, uint32_t n_max);
+/* ... and the chain's copy stream with its staging buffer of `doubles` (dnagpu_matrix_download_packed_async, dnagpu_partial_pack_host_async,
+ * dnagpu_partial_unpack_host), so that the staged store's first copy does not allocate either. */
+int dnagpu_copy_stage_reserve(dnagpu_ctx* ctx, int chain, size_t doubles);
 /* Batched forms of the three large steps of a block with a kept factor in its light form (dnagpu_partial_create_spine), for nb <=
  * DNAGPU_BATCH_MAX blocks of ONE shape (equal padded orders of the eliminated and of the kept part): the members' launches are merged --
  * every tile product and every leaf of the recursion is one launch that works on all members, in lock step.  The dependent chain of
