@@ -670,14 +670,19 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     from dynadjust_amd import adjust
     if not phased:
         raise SystemExit("the simultaneous adjustment does not shard: run it with --gpus 1")
-    # rank 0's ncclUniqueId to everybody through the control plane
-    idt = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        idt = torch.frombuffer(bytearray(adjust.rccl_unique_id()), dtype=torch.uint8).clone()
-    dist.broadcast(idt, src=0)
     a = adjust.DnaAdjust()
-    a.attach_rccl(rank, world, bytes(idt.numpy().tobytes()), local_rank)
+    shared = os.environ.get("DNAGPU_DIST_TRANSPORT") == "shared"
+    if not shared:
+        # rank 0's ncclUniqueId to everybody through the control plane
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(adjust.rccl_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(idt, src=0)
+        a.attach_rccl(rank, world, bytes(idt.numpy().tobytes()), local_rank)
+    # (DNAGPU_DIST_TRANSPORT=shared: launched ranks WITHOUT RCCL between them -- several processes on one GPU with DNAGPU_BENCH_SHARE_GPU=1: the
+    #  launcher's command line, rendezvous, agreement and reporting paths on a one-GPU box; the library makes its own connections, host-staged)
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank, dist_rank=rank, dist_world=world,
+                               dist_transport="shared" if shared else None,
                                multi_thread=bool(int(os.environ.get("DNAGPU_MULTI_THREAD", "1"))),
                                schur_carry=not args.reference_schedule, keep_factors=not args.no_keep_factors, stage=args.stage, defer_variances=0 if args.variances_every_iteration else int(os.environ.get("DNAGPU_DEFER_VARIANCES", "2")),
                                dist_two_level=bool(int(os.environ.get("DNAGPU_TWO_LEVEL", "1"))), reuse_factors=not args.no_reuse_factors)
@@ -719,7 +724,7 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
     mine = {"alg": a.algorithmic_flops(), "gemm_ms": prof_ms.value, "issued": prof_f.value, "solves": a.solve_count(), "completions": a.completion_count(),
             "eliminations": a.elimination_count(), "exchange_ms": ex["exchange_ms"], "chain_ms": ex["chain_ms"], "bytes": (ex["bytes"] - bytes0) / max(1, args.steps),
             "rccl_ranks": a.device_instance_stats(0)["rccl_ranks"], "hbm0": hbm0, "hbm1": _hbm(lib, ctx), "staged": bool(lib.dnaadj_staged(a.h)),
-            "batched_block_steps": a.batched_block_steps(), "batched_flops": a.batched_flops(), "plan": a.memory_plan()}
+            "batched_block_steps": a.batched_block_steps(), "batched_flops": a.batched_flops(), "plan": a.memory_plan(), "device": local_rank}
     allv = [None] * world
     dist.all_gather_object(allv, mine)
     stations = lib.dnaadj_station_count(a.h)
@@ -734,6 +739,10 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
         out = _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, allv, owners, check,
                               "C++ (libdnagpu.so): one process per GPU (torchrun ranks), RCCL called from the library", tr, min(v["rccl_ranks"] for v in allv),
                               p.multi_thread)
+        if len({v["device"] for v in allv}) < world:
+            out["config"]["ranks_share_gpus"] = True     # DNAGPU_BENCH_SHARE_GPU=1: a code-path check on a box with fewer GPUs, NOT a scaling measurement
+            out["n_gpus"] = len({v["device"] for v in allv})
+            out["config"]["ranks"] = world
         out["hbm_per_rank"] = {"total_gb": [round(v["hbm1"][1] / 1e9, 1) for v in allv], "free_after_prepare_gb": [round(v["hbm0"][0] / 1e9, 1) for v in allv],
                                "free_at_end_gb": [round(v["hbm1"][0] / 1e9, 1) for v in allv], "variances_staged_in_host_memory": any(v["staged"] for v in allv)}
         # what every rank batched of its own blocks (block steps and share of its flops in the LAST step) and the plan PrepareAdjustment made on it

@@ -332,6 +332,37 @@ def test_processes_sharing_the_gpu(built, orc, tmp_path, world, settings):
     o.close()
 
 
+def test_bench_as_the_driver_launches_it_for_two_gpus(built):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K
+    --warmup W`: the command line the driver uses for its N > 1 runs, on the ONE GPU there is -- the two ranks share it (DNAGPU_BENCH_SHARE_GPU=1)
+    and talk through the host-staged transport instead of RCCL (DNAGPU_DIST_TRANSPORT=shared; RCCL refuses two ranks on a device).  What runs is
+    everything around RCCL itself: the launcher's environment, the gloo control plane, the C++ driver's rendezvous and two-level chains across
+    PROCESSES, barrier + max-over-ranks timing, the gathered per-rank records, ONE JSON line from rank 0 with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29100 + (os.getpid() % 800)
+    env = dict(os.environ, DNAGPU_BENCH_SHARE_GPU="1", DNAGPU_DIST_TRANSPORT="shared", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["ranks_share_gpus"] and out["config"]["ranks"] == 2 and out["n_gpus"] == 1      # (said, not hidden: this is no scaling measurement)
+    assert out["config"]["transport"] == "shared" and out["config"]["rccl_ranks"] == 0
+    assert sorted(out["config"]["blocks_per_rank"]) == [2, 2]
+    # (the statistics come from an all-reduce across the two processes; the truth the generator kept bounds the estimates)
+    assert 0.9 < out["check"]["sigma_zero"] < 1.1 and out["check"]["max_abs_error_vs_truth_m"] < 0.5
+
+
 def test_a_killed_process_cannot_hang_the_others(built, tmp_path):
     """three processes on the one GPU, ten slow iterations; rank 1 is killed (os._exit) in the middle of the adjustment: the other two must come
     back with the exception of the transport -- "a rank has gone" -- within seconds, not wait for a collective that never completes
