@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 # reverse chain of the condensed schedule landed on one queue (chain phase 27 -> 48 ms per iteration).  Must be set before the
 # HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# RCCL between processes shares device memory by dmabuf handles; the pool's host driver supports no other kind (without this,
+# ncclCommInitRank fails with "hipIpcGetMemHandle: invalid argument").  Set on the GPU boxes already; kept here for a bare environment.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WORKLOADS = {
     # name: (rows, cols, baselines, blocks, phased, description)
@@ -672,13 +675,35 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
         raise SystemExit("the simultaneous adjustment does not shard: run it with --gpus 1")
     a = adjust.DnaAdjust()
     shared = os.environ.get("DNAGPU_DIST_TRANSPORT") == "shared"
+    fallback_note = None
     if not shared:
         # rank 0's ncclUniqueId to everybody through the control plane
         idt = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            idt = torch.frombuffer(bytearray(adjust.rccl_unique_id()), dtype=torch.uint8).clone()
+        err = ""
+        try:
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(adjust.rccl_unique_id()), dtype=torch.uint8).clone()
+        except Exception as e:      # (librccl missing on rank 0: the others must not wait for an id that never comes)
+            err = str(e)
         dist.broadcast(idt, src=0)
-        a.attach_rccl(rank, world, bytes(idt.numpy().tobytes()), local_rank)
+        try:
+            if not err:
+                a.attach_rccl(rank, world, bytes(idt.numpy().tobytes()), local_rank)
+        except Exception as e:
+            err = str(e)
+        # A communicator that cannot start on ANY rank (no fabric path, a driver without dmabuf IPC, ...) must not cost the run: every rank
+        # learns of it here, BEFORE the first collective, and all of them take the library's host-staged transport instead -- slower exchanges
+        # (the two-level chains move a few MB per iteration), the same C++ driver, and the JSON line says so (config.transport, config.rccl_failed).
+        bad = torch.tensor([1 if err else 0], dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            msgs = [None] * world
+            dist.all_gather_object(msgs, err)
+            fallback_note = next((m for m in msgs if m), "RCCL could not start")
+            print(f"[bench] rank {rank}: RCCL could not start ({fallback_note}): host-staged transport between the ranks", file=sys.stderr, flush=True)
+            a.close()
+            a = adjust.DnaAdjust()
+            shared = True
     # (DNAGPU_DIST_TRANSPORT=shared: launched ranks WITHOUT RCCL between them -- several processes on one GPU with DNAGPU_BENCH_SHARE_GPU=1: the
     #  launcher's command line, rendezvous, agreement and reporting paths on a one-GPU box; the library makes its own connections, host-staged)
     p = adjust.ProjectSettings(name, folder, adjust_mode=adjust.PhasedMode, device=local_rank, dist_rank=rank, dist_world=world,
@@ -739,6 +764,8 @@ def bench_distributed_native(folder, name, phased, args, dist, rank, world, loca
         out = _multi_gpu_line(args, world, dt, stations, B, its, solves, ref, allv, owners, check,
                               "C++ (libdnagpu.so): one process per GPU (torchrun ranks), RCCL called from the library", tr, min(v["rccl_ranks"] for v in allv),
                               p.multi_thread)
+        if fallback_note:
+            out["config"]["rccl_failed"] = fallback_note[:300]
         if len({v["device"] for v in allv}) < world:
             out["config"]["ranks_share_gpus"] = True     # DNAGPU_BENCH_SHARE_GPU=1: a code-path check on a box with fewer GPUs, NOT a scaling measurement
             out["n_gpus"] = len({v["device"] for v in allv})
@@ -916,8 +943,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         # N > 1: the driver is C++ (dna_adjust::AdjustPhasedDistributed), the exchange RCCL called from the library; torch.distributed
-        # is the launcher's control plane here (unique-id broadcast, barriers, the max over the ranks' clocks).  A library whose RCCL
-        # cannot start is FATAL: no silent change of driver.
+        # is the launcher's control plane here (unique-id broadcast, barriers, the max over the ranks' clocks).  If RCCL cannot start on
+        # any rank, all ranks take the library's host-staged transport instead -- the same C++ driver, and never silently: config.transport
+        # says "shared" and config.rccl_failed why (bench_distributed_native).
         if dist_backend == "gloo":
             from tests import parallel_harness
             result = parallel_harness.bench_distributed(d, "net", phased, args, dist, rank, world, local_rank, dist_backend)

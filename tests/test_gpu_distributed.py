@@ -332,20 +332,24 @@ def test_processes_sharing_the_gpu(built, orc, tmp_path, world, settings):
     o.close()
 
 
-def test_bench_as_the_driver_launches_it_for_two_gpus(built):
+@pytest.mark.parametrize("transport", ["shared", "rccl refused"])
+def test_bench_as_the_driver_launches_it_for_two_gpus(built, transport):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K
     --warmup W`: the command line the driver uses for its N > 1 runs, on the ONE GPU there is -- the two ranks share it (DNAGPU_BENCH_SHARE_GPU=1)
     and talk through the host-staged transport instead of RCCL (DNAGPU_DIST_TRANSPORT=shared; RCCL refuses two ranks on a device).  What runs is
     everything around RCCL itself: the launcher's environment, the gloo control plane, the C++ driver's rendezvous and two-level chains across
-    PROCESSES, barrier + max-over-ranks timing, the gathered per-rank records, ONE JSON line from rank 0 with the contract's keys."""
+    PROCESSES, barrier + max-over-ranks timing, the gathered per-rank records, ONE JSON line from rank 0 with the contract's keys.
+    "rccl refused": nothing asks for the host-staged transport -- ncclCommInitRank refuses the second rank on the device, every rank learns of
+    it before the first collective and all of them change to the host-staged transport together; the line says so (config.rccl_failed)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29100 + (os.getpid() % 800)
     env = dict(os.environ, DNAGPU_BENCH_SHARE_GPU="1", DNAGPU_DIST_TRANSPORT="shared", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + (("DNAGPU_DIST_TRANSPORT",) if transport != "shared" else ()):
         env.pop(k, None)
+    port += 40 * (transport != "shared")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
@@ -358,6 +362,7 @@ def test_bench_as_the_driver_launches_it_for_two_gpus(built):
     assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["ranks_share_gpus"] and out["config"]["ranks"] == 2 and out["n_gpus"] == 1      # (said, not hidden: this is no scaling measurement)
     assert out["config"]["transport"] == "shared" and out["config"]["rccl_ranks"] == 0
+    assert ("rccl_failed" in out["config"]) == (transport != "shared")
     assert sorted(out["config"]["blocks_per_rank"]) == [2, 2]
     # (the statistics come from an all-reduce across the two processes; the truth the generator kept bounds the estimates)
     assert 0.9 < out["check"]["sigma_zero"] < 1.1 and out["check"]["max_abs_error_vs_truth_m"] < 0.5
