@@ -3,7 +3,7 @@
 # Regenerates the round's measurement records under gpurun_out/profiles_new/ on the GPU box (run through gpurun from the repo root): bench
 # records, rocprofv3 kernel stats, PMC passes (MFMA utilisation, HBM traffic, L2 hit rates: separate passes), inverse rates, the rank-share model.
 R=$PWD
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 O=$R/gpurun_out/profiles_new
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
