@@ -544,17 +544,22 @@ void dna_adjust::DecideStaging() {
     host_available_ = HostMemoryAvailable();
     double host = 0.8 * host_available_;
     if (const char* e = getenv("DNAGPU_HOST_STORE_GB")) host = atof(e) * 1.0e9;
+    // (stage_host_bytes_ / stage_device_bytes_: the packed variance matrices, as the plan reports them; the host's limit is met by the slots,
+    //  which have room for the block's packed factor where it may park it there: StagedSlotBytes)
+    size_t host_slots = 0;
     for (UINT32 k = 0; k < blockCount_; ++k) {
         if (!OwnsBlock(k)) continue;
         block_t& B = blocks_[k];
         const size_t n = v_parameterStationList_[k].size() * 3, bytes = n * (n + 1) / 2 * sizeof(double);
+        const size_t host_slot = StagedSlotBytes(k, nullptr);
         if (B.rig_host) {                        // (it exists already: counted where it is)
-            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += B.rig_on_device ? bytes : StagedSlotBytes(k, nullptr);
+            (B.rig_on_device ? stage_device_bytes_ : stage_host_bytes_) += bytes;
+            if (!B.rig_on_device) host_slots += host_slot;
             continue;
         }
-        const size_t host_slot = StagedSlotBytes(k, nullptr);       // (with room for the block's packed factor where it may park it there)
-        if ((double)(stage_host_bytes_ + host_slot) <= host) {
-            stage_host_bytes_ += host_slot;
+        if ((double)(host_slots + host_slot) <= host) {
+            host_slots += host_slot;
+            stage_host_bytes_ += bytes;
         } else {
             B.rig_on_device = true;
             stage_device_bytes_ += bytes;
