@@ -43,8 +43,11 @@ def main():
     a.SerialiseAdjustedVarianceMatrices()          # collective: the other ranks' variance matrices travel to rank 0
     if rank == 0:
         B = a.blockCount()
+        plan = a.memory_plan()
         out = {"status": st, "iterations": a.CurrentIteration(), "chi": a.GetChiSquared(), "rccl_ranks": a.device_instance_stats(0)["rccl_ranks"],
-               "owners": np.array([a.block_owner(k) for k in range(B)]), "exchanged_bytes": a.exchange_stats()["bytes"]}
+               "owners": np.array([a.block_owner(k) for k in range(B)]), "exchanged_bytes": a.exchange_stats()["bytes"],
+               "factors_parked": plan["blocks_packing_their_factor"], "factors_taken": plan["factors_taken_from_their_packed_copy"],
+               "factors_made_again": plan["factors_made_again"], "staged_host_bytes": plan["staged_variances_host_bytes"]}
         for k in range(B):
             out[f"est_{k}"] = a.block_estimates(k)
         np.savez(os.path.join(folder, "result.npz"), **out)

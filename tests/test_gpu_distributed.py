@@ -332,6 +332,30 @@ def test_processes_sharing_the_gpu(built, orc, tmp_path, world, settings):
     o.close()
 
 
+def test_parked_factors_across_processes(built, orc, tmp_path):
+    """The memory-tight plan in a multi-process run: the HBM budget denies every block a kept factor (DNAGPU_FACTOR_BUDGET_GB=0, what cfg4 does to its
+    blocks on one GPU), the variance matrices are staged -- every rank parks the packed factors of ITS blocks in the page-locked host slots that wait
+    for their variance matrices and takes them back for the rigorous solves and the variance matrices (round 6; dna_adjust_phased.cpp
+    PacksItsFactor / BorrowTransientFactor), inside the phases the ranks agree on.  Two processes on the one GPU; against the oracle."""
+    import json
+    adjust.write_synthetic_network(str(tmp_path), "n", 48, 40, 0, 6, seed=33)
+    os.makedirs(tmp_path / "out", exist_ok=True)
+    o, ost = _oracle(orc, str(tmp_path), "n")
+    procs, outs = _spawn_ranks(tmp_path, "n", 2, {"WORKER_SETTINGS": json.dumps({"stage": True, "multi_thread": True}), "DNAGPU_FACTOR_BUDGET_GB": "0"})
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = np.load(tmp_path / "result.npz")
+    assert int(res["status"]) == ost and int(res["iterations"]) == o.iterations()
+    # (rank 0's own plan: its three blocks park their factors, nothing is eliminated twice)
+    assert int(res["factors_parked"]) == 3 and int(res["factors_made_again"]) == 0 and int(res["staged_host_bytes"]) > 0
+    assert int(res["factors_taken"]) == 3 * (int(res["iterations"]) + 1)
+    for k in range(6):
+        assert np.abs(res[f"est_{k}"] - o.block_estimates(k)).max() < TOL_X
+    for (t, r, c, d), k in zip(F.read_mtx(tmp_path / "out" / "n-rva.mtx", 6), range(6)):
+        vo = o.block_variances(k)
+        assert np.abs(d - vo).max() / np.abs(vo).max() < TOL_V
+    o.close()
+
+
 @pytest.mark.parametrize("transport", ["shared", "rccl refused"])
 def test_bench_as_the_driver_launches_it_for_two_gpus(built, transport):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K
