@@ -1878,7 +1878,9 @@ void dna_adjust::PrepareLockstepChains() {
         }
         k = e + 1;
     }
-    int W = want > 1 ? want : (chained >= 2048 ? 64 : chained >= 512 ? 32 : chained >= 64 ? 16 : 1);
+    // (the runs' boundaries come from a scan -- level 2 below, 2 log2 W levels deep --, the steps inside the runs are 2 x blocks-per-run deep:
+    //  about eight blocks to a run; dnasegment150's 666 blocks: 16 / 32 / 48 / 64 / 96 / 128 / 160 runs -> 47.0 / 38.0 / 35.7 / 34.3 / 34.0 / 34.4 / 36.0 ms)
+    int W = want > 1 ? want : (chained >= 64 ? std::max<int>(16, std::min<int>(512, (int)(chained / 8))) : 1);
     W = std::min<int>(W, (int)(chained / 3));
     if (W < 2) return;
     // small condensed systems, every block between two others carrying something both ways
@@ -2110,63 +2112,197 @@ void dna_adjust::PrepareLockstepChains() {
             const double n = 3.0 * (double)v_parameterStationList_[k].size();
             return n * n * n;
         };
-        // level 2: the two chains over the runs
+        // level 2: the junction matrices at the runs' boundaries -- forward (everything left of a boundary condensed onto it) and reverse -- as a
+        // SCAN over the runs of a network instead of two chains of W - 1 steps each (round 6).  The runs' systems are the leaves of a binary
+        // tree; going up, the two halves of a span are merged to the span's end stations (its first run's junction row towards the run
+        // before, its last run's towards the run after: the step of level 1, on two systems); going down, a node hands the junction matrix
+        // at its middle boundary to both sides -- forward from its left half and the forward matrix at its own left end, reverse from its
+        // right half and the reverse matrix at its right end.  2 log2 W levels instead of W - 1, every level's steps of all networks in
+        // merged launches; the same additions, associated differently: results agree with the step-by-step chains to rounding.
+        // A station's constraint weights go in where the station leaves (a merge) or where the chain in question meets it first (a
+        // boundary step: the stations that stay, unless the matrix carried in has them already) -- once per direction, as in
+        // AddConstraintStationstoNormalsForward / ...Reverse (ADJ:1884-1958).
+        struct span_t {
+            int i = 0, j = 0;                       // its runs (indices into `runs`)
+            int left = -1, right = -1, height = 0, depth = 0;
+            std::vector<UINT32> stations;           // L(i) u R(j), global ids, ascending
+            std::vector<UINT32> sys;                // global ids in the order of S's stations (set when S is)
+            const dnagpu_matrix* S = nullptr;
+        };
+        std::vector<span_t> spans;
+        std::vector<int> roots;
+        std::map<UINT32, std::array<double, 9>> end_con;       // constraint weights of the runs' end stations, by global id
+        auto run_L = [&](int r) {
+            std::vector<UINT32> v;
+            for (UINT32 q : runs[r].posL) v.push_back(runs[r].stations[q]);
+            return v;
+        };
+        auto run_R = [&](int r) {
+            std::vector<UINT32> v;
+            for (UINT32 q : runs[r].posR) v.push_back(runs[r].stations[q]);
+            return v;
+        };
+        for (const run_t& g : runs)
+            for (const constraint_list* cl : {&g.con_fwd, &g.con_rev})
+                for (size_t q = 0; q < cl->stn.size(); ++q) {
+                    std::array<double, 9> w;
+                    std::copy(cl->w9.begin() + 9 * q, cl->w9.begin() + 9 * q + 9, w.begin());
+                    end_con[g.stations[cl->stn[q]]] = w;
+                }
+        std::function<int(int, int, int)> build = [&](int i, int j, int depth) -> int {
+            span_t sp;
+            sp.i = i;
+            sp.j = j;
+            sp.depth = depth;
+            sp.stations = run_L(i);
+            const std::vector<UINT32> R = run_R(j);
+            sp.stations.insert(sp.stations.end(), R.begin(), R.end());
+            std::sort(sp.stations.begin(), sp.stations.end());
+            sp.stations.erase(std::unique(sp.stations.begin(), sp.stations.end()), sp.stations.end());
+            if (i < j) {
+                const int m = i + (j - i) / 2;
+                sp.left = build(i, m, depth + 1);
+                sp.right = build(m + 1, j, depth + 1);
+                sp.height = 1 + std::max(spans[sp.left].height, spans[sp.right].height);
+            }
+            spans.push_back(std::move(sp));
+            return (int)spans.size() - 1;
+        };
+        {
+            int r0 = 0;
+            for (const net_t& n : nets) {
+                if (n.runs >= 2) roots.push_back(build(r0, r0 + n.runs - 1, 0));
+                r0 += n.runs;
+            }
+        }
+        auto leaf_system = [&](span_t& sp) {       // (a leaf's system is its run's: known once level 1's steps have been made)
+            if (sp.left >= 0 || sp.S) return;
+            const run_t& g = runs[sp.i];
+            sp.S = g.S;
+            for (UINT32 q : g.sys_pos) sp.sys.push_back(g.stations[q]);
+        };
+        auto positions = [&](const std::vector<UINT32>& sorted, const std::vector<UINT32>& ids, std::vector<UINT32>& out) {
+            for (UINT32 s : ids) {
+                const long q = position(sorted, s);
+                if (q < 0) bad = true;
+                out.push_back((UINT32)std::max(0L, q));
+            }
+        };
+        auto add_con = [&](step_data_t& d, const std::vector<UINT32>& sorted, UINT32 s) {
+            const auto it = end_con.find(s);
+            const long q = position(sorted, s);
+            if (it == end_con.end() || q < 0) {
+                bad = true;
+                return;
+            }
+            d.con_stn.push_back((UINT32)q);
+            d.con_w9.insert(d.con_w9.end(), it->second.begin(), it->second.end());
+        };
+        int top = 0, deepest = 0;
+        for (const span_t& sp : spans) {
+            top = std::max(top, sp.height);
+            deepest = std::max(deepest, sp.depth);
+        }
+        // ... going up: the spans that somebody's boundary step needs (all but the roots), lowest first.  (One lane beside an empty one:
+        // a stage of ONE lane has its batches dealt to the chains, and a merge reads what any batch of the level below has written.)
         stages.emplace_back();
         stages.back().lanes.resize(2);
-        int most_runs = 1;
-        for (const net_t& n : nets) most_runs = std::max(most_runs, n.runs);
-        for (int i = 0; i + 1 < most_runs; ++i) {       // (forward step i of every network that has it)
+        for (int h = 1; h < top; ++h) {
             std::vector<pending_t> members;
-            for (int r = 0; r < W; ++r) {
-                if (runs[r].index != i || i + 1 >= runs[r].of) continue;
-            members.push_back({[&, r]() -> double {
-                run_t& g = runs[r];
-                step_data_t d;
-                d.est_blk = g.est_blk;
-                d.est_idx = g.est_idx;
-                d.pos[0] = g.sys_pos;
-                d.con_stn = g.con_fwd.stn;
-                d.con_w9 = g.con_fwd.w9;
-                d.keep = g.posR;
-                const dnagpu_matrix* src[2] = {g.S, nullptr};
-                const int junction[2] = {0, 1};
-                int n_src = 1;
-                if (g.index > 0) {
-                    d.pos[1] = g.posL;
-                    src[1] = blocks_[g.a - 1].jfwd;
-                    n_src = 2;
-                }
-                return add_step(std::move(d), n_src, src, junction, blocks_[g.b].jfwd, 1, (UINT32)g.stations.size());
-            }, true, runs[r].net, nref3(runs[r].b)});       // (it leaves what the forward step on the run's last block leaves: counted as that step)
+            int idx = 0;
+            for (size_t q = 0; q < spans.size(); ++q) {
+                if (spans[q].height != h || spans[q].depth == 0) continue;
+                members.push_back({[&, q]() -> double {
+                    span_t& N = spans[q];
+                    span_t& A = spans[N.left];
+                    span_t& Bs = spans[N.right];
+                    leaf_system(A);
+                    leaf_system(Bs);
+                    step_data_t d;
+                    std::vector<UINT32> U = A.stations;
+                    U.insert(U.end(), Bs.stations.begin(), Bs.stations.end());
+                    std::sort(U.begin(), U.end());
+                    U.erase(std::unique(U.begin(), U.end()), U.end());
+                    positions(U, A.sys, d.pos[0]);
+                    positions(U, Bs.sys, d.pos[1]);
+                    positions(U, N.stations, d.keep);
+                    for (UINT32 s : U)
+                        if (position(N.stations, s) < 0) add_con(d, U, s);
+                    if (!A.S || !Bs.S) {
+                        bad = true;
+                        return 0.0;
+                    }
+                    dnagpu_matrix* out = nullptr;
+                    NewMatrix((UINT32)N.stations.size() * 3, &out, runs[N.i].a, "PrepareAdjustment(): span merge");
+                    lock_mats_.push_back(out);
+                    const dnagpu_matrix* src[2] = {A.S, Bs.S};
+                    const int junction[2] = {0, 0};
+                    const double fl = add_step(std::move(d), 2, src, junction, out, 0, (UINT32)U.size());
+                    N.S = out;
+                    N.sys = N.stations;
+                    return fl;
+                }, false, idx++, 0.0});
             }
             close_group(stages.back().lanes[0], members);
-        }
-        for (int i = 0; i + 1 < most_runs; ++i) {       // (reverse step i of every network that has it: its run of.. - 1 - i)
-            std::vector<pending_t> members;
-            for (int r = 0; r < W; ++r) {
-                if (runs[r].of < 2 || runs[r].index != runs[r].of - 1 - i || runs[r].index < 1) continue;
-            members.push_back({[&, r]() -> double {
-                run_t& g = runs[r];
-                step_data_t d;
-                d.est_blk = g.est_blk;
-                d.est_idx = g.est_idx;
-                d.pos[0] = g.sys_pos;
-                d.con_stn = g.con_rev.stn;
-                d.con_w9 = g.con_rev.w9;
-                d.keep = g.posL;
-                const dnagpu_matrix* src[2] = {g.S, nullptr};
-                const int junction[2] = {0, 1};
-                int n_src = 1;
-                if (g.index + 1 < g.of) {
-                    d.pos[1] = g.posR;
-                    src[1] = blocks_[g.b].jrev;
-                    n_src = 2;
-                }
-                return add_step(std::move(d), n_src, src, junction, blocks_[g.a - 1].jrev, 1, (UINT32)g.stations.size());
-            }, true, runs[r].net, nref3(runs[r].a)});
+            if (bad) {
+                FreeLockstepChains();
+                return;
             }
-            close_group(stages.back().lanes[1], members);
         }
+        // ... going down: the node's middle boundary, forward (lane 0) and reverse (lane 1)
+        stages.emplace_back();
+        stages.back().lanes.resize(2);
+        for (int dir = 0; dir < 2; ++dir)
+            for (int dep = 0; dep <= deepest; ++dep) {
+                std::vector<pending_t> members;
+                int idx = 0;
+                for (size_t q = 0; q < spans.size(); ++q) {
+                    if (spans[q].depth != dep || spans[q].left < 0) continue;
+                    const int m = spans[spans[q].left].j;         // the boundary between runs m and m + 1
+                    members.push_back({[&, q, dir, m]() -> double {
+                        span_t& N = spans[q];
+                        span_t& H = spans[dir == 0 ? N.left : N.right];      // the half the boundary's matrix is condensed from
+                        leaf_system(H);
+                        if (!H.S) {
+                            bad = true;
+                            return 0.0;
+                        }
+                        const int first = N.i - runs[N.i].index, last = first + runs[N.i].of - 1;      // the network's runs
+                        step_data_t d;
+                        positions(H.stations, H.sys, d.pos[0]);
+                        const std::vector<UINT32> Lh = run_L(H.i), Rh = run_R(H.j);
+                        const std::vector<UINT32>& in = dir == 0 ? Lh : Rh;           // where the carried matrix comes in ...
+                        const std::vector<UINT32>& outl = dir == 0 ? Rh : Lh;         // ... and what this step leaves
+                        const bool carried = dir == 0 ? H.i > first : H.j < last;
+                        std::set<UINT32> in_set;
+                        if (carried) in_set.insert(in.begin(), in.end());
+                        positions(H.stations, outl, d.keep);
+                        for (UINT32 s : outl)
+                            if (!in_set.count(s)) add_con(d, H.stations, s);
+                        const std::set<UINT32> from_left(Lh.begin(), Lh.end());
+                        for (UINT32 s : H.stations) {
+                            const UINT32 k = from_left.count(s) ? runs[H.i].a : runs[H.j].b;
+                            d.est_blk.push_back(k);
+                            d.est_idx.push_back(LocalIndex(k, s));
+                        }
+                        const dnagpu_matrix* src[2] = {H.S, nullptr};
+                        const int junction[2] = {0, 1};
+                        int n_src = 1;
+                        if (carried) {
+                            positions(H.stations, in, d.pos[1]);
+                            src[1] = dir == 0 ? blocks_[runs[H.i].a - 1].jfwd : blocks_[runs[H.j].b].jrev;
+                            n_src = 2;
+                        }
+                        dnagpu_matrix* out = dir == 0 ? blocks_[runs[m].b].jfwd : blocks_[runs[m + 1].a - 1].jrev;
+                        return add_step(std::move(d), n_src, src, junction, out, 1, (UINT32)H.stations.size());
+                    }, true, idx++, nref3(dir == 0 ? runs[m].b : runs[m + 1].a)});   // (what the chain's step on that block leaves: counted as that step)
+                }
+                close_group(stages.back().lanes[(size_t)dir], members);
+                if (bad) {
+                    FreeLockstepChains();
+                    return;
+                }
+            }
         // level 3: both chains inside every run, from the boundary values of level 2 (CondensedForwardBlock / CondensedReverseBlock as data)
         // (a lane per direction and batch slot: the slots of a direction are independent of each other and go to chains of their own)
         const int slots = (W + DNAGPU_CHAIN_BATCH_MAX - 1) / DNAGPU_CHAIN_BATCH_MAX;
